@@ -1,0 +1,254 @@
+"""ctypes binding of the CPU ORACLE (test infrastructure -- see oracle/rsdsfm_oracle.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+PARITY UNPINNED: see the header of oracle/rsdsfm_oracle.c.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+TERMINATION = {0: "gradient", 1: "parameter", 2: "function", 3: "max_iter", 4: "failure", 5: "min_radius"}
+
+
+class LmSummary(C.Structure):
+    _fields_ = [
+        ("num_iterations", C.c_int32),
+        ("num_successful_steps", C.c_int32),
+        ("num_unsuccessful_steps", C.c_int32),
+        ("termination", C.c_int32),
+        ("initial_cost", C.c_double),
+        ("final_cost", C.c_double),
+        ("final_radius", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class RansacOut(C.Structure):
+    _fields_ = [
+        ("num_inliers", C.c_int64),
+        ("best_trial", C.c_int32),
+        ("_pad", C.c_int32),
+        ("w", C.c_double * 3),
+        ("v", C.c_double * 3),
+        ("k", C.c_double),
+        ("inlier_error", C.c_double),
+        ("inlier_idx", C.c_void_p),
+        ("inliers", C.c_void_p),
+        ("alpha", C.c_void_p),
+        ("alpha_k", C.c_void_p),
+        ("mask", C.c_void_p),
+        ("inv_depth", C.c_void_p),
+        ("trial_count", C.c_void_p),
+        ("trial_err", C.c_void_p),
+        ("trial_vel", C.c_void_p),
+        ("trial_steps", C.c_void_p),
+    ]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "librsdsfm_oracle.so")
+    src = os.path.join(_HERE, "rsdsfm_oracle.c")
+    hdr = os.path.join(_HERE, "rsdsfm_oracle.h")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(
+            ["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-std=c99", "-shared", "-o", so, src, "-lm"]
+        )
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.rso_score.restype = C.c_int64
+        _LIB.rso_flatten.restype = C.c_int64
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _v3(a):
+    return (C.c_double * 3)(*[float(x) for x in a])
+
+
+def get_alpha(flow_px, h, gamma):
+    flow_px = _f64(flow_px)
+    n = flow_px.shape[0]
+    out = np.empty(n)
+    lib().rso_get_alpha(_p(flow_px), C.c_int64(n), C.c_double(h), C.c_double(gamma), _p(out))
+    return out
+
+
+def get_alpha_k(q_px, flow_px, h, gamma):
+    q_px, flow_px = _f64(q_px), _f64(flow_px)
+    n = flow_px.shape[0]
+    out = np.empty(n)
+    lib().rso_get_alpha_k(_p(q_px), _p(flow_px), C.c_int64(n), C.c_double(h), C.c_double(gamma), _p(out))
+    return out
+
+
+def calculate_velocities(q9, u9, alpha9, alpha_k9, use_alpha_k=False, k_sign_mode=0):
+    q9, u9, alpha9, alpha_k9 = _f64(q9), _f64(u9), _f64(alpha9), _f64(alpha_k9)
+    w = (C.c_double * 3)()
+    v = (C.c_double * 3)()
+    k = C.c_double()
+    rc = lib().rso_calculate_velocities(_p(q9), _p(u9), _p(alpha9), _p(alpha_k9), int(use_alpha_k), int(k_sign_mode), w, v, C.byref(k))
+    return np.array(w[:]), np.array(v[:]), k.value, rc
+
+
+def residual(x, y, ux, uy, alpha, alpha_k, v, w, k, rho):
+    r = (C.c_double * 2)()
+    d = C.c_double
+    lib().rso_residual(d(x), d(y), d(ux), d(uy), d(alpha), d(alpha_k), _v3(v), _v3(w), d(k), d(rho), r)
+    return np.array(r[:])
+
+
+def estimate_inverse_depths(q, u, v, w, k, alpha, alpha_k, mode=1):
+    q, u, alpha, alpha_k = _f64(q), _f64(u), _f64(alpha), _f64(alpha_k)
+    n = q.shape[0]
+    rho = np.empty(n)
+    sm = LmSummary()
+    rc = lib().rso_estimate_inverse_depths(_p(q), _p(u), C.c_int64(n), _v3(v), _v3(w), C.c_double(k), _p(alpha), _p(alpha_k), int(mode), _p(rho), C.byref(sm))
+    assert rc == 0
+    return rho, sm.as_dict()
+
+
+def score(q, u, alpha, alpha_k, v, w, k, rho, tol):
+    q, u, alpha, alpha_k, rho = _f64(q), _f64(u), _f64(alpha), _f64(alpha_k), _f64(rho)
+    n = q.shape[0]
+    mask = np.empty(n, dtype=np.uint8)
+    err = C.c_double()
+    cnt = lib().rso_score(_p(q), _p(u), _p(alpha), _p(alpha_k), C.c_int64(n), _v3(v), _v3(w), C.c_double(k), _p(rho), C.c_double(tol), _p(mask), C.byref(err))
+    return int(cnt), err.value, mask
+
+
+def sample_indices(n, trials, seed):
+    out = np.empty(trials * 9, dtype=np.int32)
+    lib().rso_sample_indices(C.c_int64(n), C.c_int32(trials), C.c_uint64(seed), _p(out))
+    return out.reshape(trials, 9)
+
+
+def ransac(q, u, alpha, alpha_k, use_alpha_k, iterations, tol, samples, depth_mode=1, k_sign_mode=0):
+    q, u, alpha, alpha_k = _f64(q), _f64(u), _f64(alpha), _f64(alpha_k)
+    samples = np.ascontiguousarray(samples, dtype=np.int32).reshape(-1)
+    n = q.shape[0]
+    T = int(iterations)
+    bufs = dict(
+        inlier_idx=np.zeros(n, dtype=np.int64),
+        inliers=np.zeros((n, 3)),
+        alpha=np.zeros(n),
+        alpha_k=np.zeros(n),
+        mask=np.zeros(n, dtype=np.uint8),
+        inv_depth=np.zeros(n),
+        trial_count=np.zeros(max(T, 1), dtype=np.int64),
+        trial_err=np.zeros(max(T, 1)),
+        trial_vel=np.zeros((max(T, 1), 7)),
+        trial_steps=np.zeros(max(T, 1), dtype=np.int32),
+    )
+    out = RansacOut()
+    for name, arr in bufs.items():
+        setattr(out, name, arr.ctypes.data)
+    rc = lib().rso_ransac(_p(q), _p(u), _p(alpha), _p(alpha_k), C.c_int64(n), int(use_alpha_k), C.c_int32(T), C.c_double(tol), _p(samples), int(depth_mode), int(k_sign_mode), C.byref(out))
+    if rc != 0:
+        raise RuntimeError("rso_ransac failed rc=%d" % rc)
+    m = int(out.num_inliers)
+    return dict(
+        num_inliers=m,
+        best_trial=int(out.best_trial),
+        w=np.array(out.w[:]),
+        v=np.array(out.v[:]),
+        k=float(out.k),
+        inlier_error=float(out.inlier_error),
+        inlier_idx=bufs["inlier_idx"][:m].copy(),
+        inliers=bufs["inliers"][:m].copy(),
+        alpha=bufs["alpha"][:m].copy(),
+        alpha_k=bufs["alpha_k"][:m].copy(),
+        mask=bufs["mask"],
+        inv_depth=bufs["inv_depth"],
+        trial_count=bufs["trial_count"][:T],
+        trial_err=bufs["trial_err"][:T],
+        trial_vel=bufs["trial_vel"][:T],
+        trial_steps=bufs["trial_steps"][:T],
+    )
+
+
+def refine(flow, inliers, alpha, alpha_k, v, w, k, const_acceleration=False, flow_index_mode=0, inlier_idx=None):
+    flow, inliers, alpha, alpha_k = _f64(flow), _f64(inliers), _f64(alpha), _f64(alpha_k)
+    m = inliers.shape[0]
+    idx = None if inlier_idx is None else np.ascontiguousarray(inlier_idx, dtype=np.int64)
+    out = np.empty((m, 3))
+    vo, wo, ko = (C.c_double * 3)(), (C.c_double * 3)(), C.c_double()
+    sm = LmSummary()
+    rc = lib().rso_refine(_p(flow), C.c_int64(flow.shape[0]), C.c_int64(m), _p(inliers), _p(alpha), _p(alpha_k), None if idx is None else _p(idx), _v3(v), _v3(w), C.c_double(k), int(const_acceleration), int(flow_index_mode), _p(out), vo, wo, C.byref(ko), C.byref(sm))
+    if rc != 0:
+        raise RuntimeError("rso_refine failed rc=%d" % rc)
+    return dict(inliers=out, v=np.array(vo[:]), w=np.array(wo[:]), k=ko.value, summary=sm.as_dict())
+
+
+def flatten(flow_img, fx, fy, cx, cy, gamma, thr=1e-10):
+    flow_img = _f64(flow_img)
+    rows, cols = flow_img.shape[:2]
+    n = rows * cols
+    q, u, qpx, fpx = np.empty((n, 2)), np.empty((n, 2)), np.empty((n, 2)), np.empty((n, 2))
+    d = C.c_double
+    pos = lib().rso_flatten(_p(flow_img), C.c_int32(rows), C.c_int32(cols), d(fx), d(fy), d(cx), d(cy), d(gamma), d(thr), _p(q), _p(u), _p(qpx), _p(fpx))
+    return q[:pos].copy(), u[:pos].copy(), qpx[:pos].copy(), fpx[:pos].copy()
+
+
+def canonicalize_sign(inliers, v):
+    inliers = _f64(inliers).copy()
+    vv = _v3(v)
+    flipped = lib().rso_canonicalize_sign(_p(inliers), C.c_int64(inliers.shape[0]), vv)
+    return inliers, np.array(vv[:]), bool(flipped)
+
+
+def scatter_depth(inliers, fx, fy, cx, cy, rows, cols):
+    inliers = _f64(inliers)
+    m = inliers.shape[0]
+    dm = np.zeros((cols, rows))  # col-major rows x cols  == C-order (cols, rows)
+    xs, ys = np.empty(m, dtype=np.int32), np.empty(m, dtype=np.int32)
+    d = C.c_double
+    lib().rso_scatter_depth(_p(inliers), C.c_int64(m), d(fx), d(fy), d(cx), d(cy), C.c_int32(rows), C.c_int32(cols), _p(dm), _p(xs), _p(ys))
+    return dm.T.copy(), xs, ys
+
+
+def pose_table(v, w, k, gamma, rows):
+    R, t = np.empty((rows, 9)), np.empty((rows, 3))
+    lib().rso_pose_table(_v3(v), _v3(w), C.c_double(k), C.c_double(gamma), C.c_int32(rows), _p(R), _p(t))
+    return R.reshape(rows, 3, 3), t
+
+
+def jacobi_svd9(Z):
+    Z = _f64(Z)
+    sv, V = np.empty(9), np.empty((9, 9))
+    lib().rso_jacobi_svd9(_p(Z), _p(sv), _p(V))
+    return sv, V
+
+
+def eigvals_general(A):
+    A = _f64(A)
+    n = A.shape[0]
+    re, im = np.empty(n), np.empty(n)
+    rc = lib().rso_eigvals_general(_p(A), int(n), _p(re), _p(im))
+    assert rc == 0, rc
+    return re + 1j * im
+
+
+def eig_sym3(S):
+    S = _f64(S)
+    lam, V = np.empty(3), np.empty((3, 3))
+    lib().rso_eig_sym3(_p(S), _p(lam), _p(V))
+    return lam, V

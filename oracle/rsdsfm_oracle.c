@@ -1,0 +1,1345 @@
+/*
+ * rsdsfm_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).  See rsdsfm_oracle.h.
+ *
+ * PARITY UNPINNED (no reference golden vectors exist, the reference is unbuildable here).
+ * Every function cites the reference lines it restates; paths are relative to /root/reference/src.
+ * Third-party arithmetic restated from the published algorithms of the versions the reference pins in
+ * its README (Eigen 3.3.4: JacobiSVD.h, Jacobi.h, AngleAxis.h; Ceres 1.14.0: trust_region_minimizer.cc,
+ * levenberg_marquardt_strategy.cc, schur_eliminator_impl.h).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared  (no FMA contraction: the HIP kernels are compiled the
+ * same way so that integer outputs can be compared bit-exactly).
+ */
+#include "rsdsfm_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+/* ------------------------------------------------------------------------------------------------ */
+/* RS scale factors                                                                                  */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* minimal.cc:179-186 */
+void rso_get_alpha(const double* flow_px, int64_t n, double h, double gamma, double* alpha) {
+    for (int64_t i = 0; i < n; ++i) alpha[i] = 1 + gamma * flow_px[2 * i + 1] / h;
+}
+
+/* minimal.cc:188-197 */
+void rso_get_alpha_k(const double* q_px, const double* flow_px, int64_t n, double h, double gamma,
+                     double* alpha_k) {
+    for (int64_t i = 0; i < n; ++i) {
+        double part1 = gamma * q_px[2 * i + 1] / h;
+        double part2 = 1.0 + gamma * (q_px[2 * i + 1] + flow_px[2 * i + 1]) / h;
+        alpha_k[i] = 0.5 * (part2 * part2 - part1 * part1);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Eigen 3.3.4 JacobiSVD<Matrix<double,9,9>>(ComputeFullV) restated (two-sided Jacobi, square case:   */
+/* no QR preconditioner).  Used at minimal.cc:98-101.                                                */
+/* ------------------------------------------------------------------------------------------------ */
+
+typedef struct { double c, s; } jrot;
+
+/* Jacobi.h JacobiRotation::makeJacobi(x, y, z) for the real symmetric 2x2 [[x,y],[y,z]] */
+static jrot make_jacobi(double x, double y, double z) {
+    jrot j;
+    double deno = 2.0 * fabs(y);
+    if (deno < DBL_MIN) {
+        j.c = 1.0;
+        j.s = 0.0;
+    } else {
+        double tau = (x - z) / deno;
+        double w = sqrt(tau * tau + 1.0);
+        double t = (tau > 0.0) ? 1.0 / (tau + w) : 1.0 / (tau - w);
+        double sign_t = t > 0.0 ? 1.0 : -1.0;
+        double n = 1.0 / sqrt(t * t + 1.0);
+        j.s = -sign_t * (y / fabs(y)) * fabs(t) * n;
+        j.c = n;
+    }
+    return j;
+}
+
+/* apply_rotation_in_the_plane: x' = c x + s y ; y' = -s x + c y  (real case), strided vectors */
+static void rot_plane(double* x, int incx, double* y, int incy, int n, jrot j) {
+    if (j.c == 1.0 && j.s == 0.0) return;
+    for (int i = 0; i < n; ++i) {
+        double xi = x[i * incx], yi = y[i * incy];
+        x[i * incx] = j.c * xi + j.s * yi;
+        y[i * incy] = -j.s * xi + j.c * yi;
+    }
+}
+
+/* JacobiSVD.h real_2x2_jacobi_svd */
+static void real_2x2_jacobi_svd(const double* W, int n, int p, int q, jrot* j_left, jrot* j_right) {
+    double m[4] = {W[p * n + p], W[p * n + q], W[q * n + p], W[q * n + q]};
+    jrot rot1;
+    double t = m[0] + m[3];
+    double d = m[2] - m[1];
+    if (fabs(d) < DBL_MIN) {
+        rot1.s = 0.0;
+        rot1.c = 1.0;
+    } else {
+        double u = t / d;
+        double tmp = sqrt(1.0 + u * u);
+        rot1.s = 1.0 / tmp;
+        rot1.c = u / tmp;
+    }
+    /* m.applyOnTheLeft(0,1,rot1): rows 0 and 1 */
+    rot_plane(&m[0], 1, &m[2], 1, 2, rot1);
+    *j_right = make_jacobi(m[0], m[1], m[3]);
+    /* *j_left = rot1 * j_right->transpose() ; transpose = (c,-s); product (c1c2 - s1s2, c1s2 + s1c2) */
+    jrot jt = {j_right->c, -j_right->s};
+    j_left->c = rot1.c * jt.c - rot1.s * jt.s;
+    j_left->s = rot1.c * jt.s + rot1.s * jt.c;
+}
+
+/* row-major n x n in, singular values (descending) and V (row-major, columns = right singular vectors) */
+static void jacobi_svd_square(const double* A, int n, double* sv, double* V) {
+    double* W = (double*)malloc(sizeof(double) * n * n);
+    const double precision = 2.0 * DBL_EPSILON;
+    const double consider_as_zero = DBL_MIN;
+    double scale = 0.0;
+    for (int i = 0; i < n * n; ++i)
+        if (fabs(A[i]) > scale) scale = fabs(A[i]);
+    if (scale == 0.0) scale = 1.0;
+    for (int i = 0; i < n * n; ++i) W[i] = A[i] / scale;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
+    double max_diag = 0.0;
+    for (int i = 0; i < n; ++i)
+        if (fabs(W[i * n + i]) > max_diag) max_diag = fabs(W[i * n + i]);
+    int finished = 0;
+    int sweeps = 0;
+    while (!finished && sweeps < 1000) {
+        finished = 1;
+        ++sweeps;
+        for (int p = 1; p < n; ++p) {
+            for (int q = 0; q < p; ++q) {
+                double threshold = precision * max_diag;
+                if (threshold < consider_as_zero) threshold = consider_as_zero;
+                if (fabs(W[p * n + q]) > threshold || fabs(W[q * n + p]) > threshold) {
+                    finished = 0;
+                    jrot jl, jr;
+                    real_2x2_jacobi_svd(W, n, p, q, &jl, &jr);
+                    /* m_workMatrix.applyOnTheLeft(p,q,j_left): rows p,q */
+                    rot_plane(&W[p * n], 1, &W[q * n], 1, n, jl);
+                    /* m_workMatrix.applyOnTheRight(p,q,j_right): cols p,q with j.transpose() */
+                    jrot jrt = {jr.c, -jr.s};
+                    rot_plane(&W[p], n, &W[q], n, n, jrt);
+                    /* m_matrixV.applyOnTheRight(p,q,j_right) */
+                    rot_plane(&V[p], n, &V[q], n, n, jrt);
+                    double a = fabs(W[p * n + p]), b = fabs(W[q * n + q]);
+                    if (a > max_diag) max_diag = a;
+                    if (b > max_diag) max_diag = b;
+                }
+            }
+        }
+    }
+    /* step 3: singular values = |diag| (the sign goes into U, which is not computed) */
+    for (int i = 0; i < n; ++i) sv[i] = fabs(W[i * n + i]) * scale;
+    /* step 4: sort descending, swapping V columns */
+    for (int i = 0; i < n; ++i) {
+        int pos = i;
+        double best = sv[i];
+        for (int j = i + 1; j < n; ++j)
+            if (sv[j] > best) {
+                best = sv[j];
+                pos = j;
+            }
+        if (best == 0.0) break;
+        if (pos != i) {
+            double t = sv[i];
+            sv[i] = sv[pos];
+            sv[pos] = t;
+            for (int r = 0; r < n; ++r) {
+                double tv = V[r * n + i];
+                V[r * n + i] = V[r * n + pos];
+                V[r * n + pos] = tv;
+            }
+        }
+    }
+    free(W);
+}
+
+void rso_jacobi_svd9(const double Z[81], double sv[9], double V[81]) { jacobi_svd_square(Z, 9, sv, V); }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* SelfAdjointEigenSolver<Matrix3d> (minimal.cc:111-113): ascending eigenvalues, orthonormal         */
+/* eigenvectors (signs implementation-defined; the recovered w is invariant to them).  Restated as   */
+/* a cyclic Jacobi eigen-solver.                                                                     */
+/* ------------------------------------------------------------------------------------------------ */
+void rso_eig_sym3(const double S[9], double lam[3], double V[9]) {
+    double a[9];
+    memcpy(a, S, sizeof(a));
+    for (int i = 0; i < 9; ++i) V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        int rotated = 0;
+        for (int p = 0; p < 2; ++p) {
+            for (int q = p + 1; q < 3; ++q) {
+                double apq = a[p * 3 + q];
+                if (apq == 0.0) continue;
+                if (fabs(apq) <= 1e-20 * (fabs(a[p * 3 + p]) + fabs(a[q * 3 + q]))) {
+                    a[p * 3 + q] = a[q * 3 + p] = 0.0;
+                    continue;
+                }
+                rotated = 1;
+                double theta = (a[q * 3 + q] - a[p * 3 + p]) / (2.0 * apq);
+                double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                /* A <- J^T A J with J = [[c, s],[-s, c]] on (p,q) */
+                for (int k = 0; k < 3; ++k) {
+                    double akp = a[k * 3 + p], akq = a[k * 3 + q];
+                    a[k * 3 + p] = c * akp - s * akq;
+                    a[k * 3 + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    double apk = a[p * 3 + k], aqk = a[q * 3 + k];
+                    a[p * 3 + k] = c * apk - s * aqk;
+                    a[q * 3 + k] = s * apk + c * aqk;
+                }
+                a[p * 3 + q] = a[q * 3 + p] = 0.0;
+                for (int k = 0; k < 3; ++k) {
+                    double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+                    V[k * 3 + p] = c * vkp - s * vkq;
+                    V[k * 3 + q] = s * vkp + c * vkq;
+                }
+            }
+        }
+        if (!rotated) break;
+    }
+    lam[0] = a[0];
+    lam[1] = a[4];
+    lam[2] = a[8];
+    /* sort ascending, permuting eigenvector columns */
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2 - i; ++j)
+            if (lam[j] > lam[j + 1]) {
+                double t = lam[j];
+                lam[j] = lam[j + 1];
+                lam[j + 1] = t;
+                for (int r = 0; r < 3; ++r) {
+                    double tv = V[r * 3 + j];
+                    V[r * 3 + j] = V[r * 3 + j + 1];
+                    V[r * 3 + j + 1] = tv;
+                }
+            }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* EigenSolver<MatrixXd>::compute(M, false) eigenvalues (minimal.cc:71-73): Householder Hessenberg   */
+/* reduction + Francis double-shift QR (the EISPACK hqr scheme Eigen's RealSchur descends from).     */
+/* ------------------------------------------------------------------------------------------------ */
+#define RSO_EIG_MAXN 8
+int rso_eigvals_general(const double* A, int nn, double* re, double* im) {
+    if (nn < 1 || nn > RSO_EIG_MAXN) return -1;
+    double H[RSO_EIG_MAXN][RSO_EIG_MAXN];
+    for (int i = 0; i < nn; ++i)
+        for (int j = 0; j < nn; ++j) H[i][j] = A[i * nn + j];
+    /* Householder reduction to upper Hessenberg form */
+    for (int m = 1; m < nn - 1; ++m) {
+        double scale = 0.0;
+        for (int i = m; i < nn; ++i) scale += fabs(H[i][m - 1]);
+        if (scale == 0.0) continue;
+        double ort[RSO_EIG_MAXN];
+        double hh = 0.0;
+        for (int i = nn - 1; i >= m; --i) {
+            ort[i] = H[i][m - 1] / scale;
+            hh += ort[i] * ort[i];
+        }
+        double g = sqrt(hh);
+        if (ort[m] > 0) g = -g;
+        hh -= ort[m] * g;
+        ort[m] -= g;
+        for (int j = m; j < nn; ++j) {
+            double f = 0.0;
+            for (int i = nn - 1; i >= m; --i) f += ort[i] * H[i][j];
+            f /= hh;
+            for (int i = m; i < nn; ++i) H[i][j] -= f * ort[i];
+        }
+        for (int i = 0; i < nn; ++i) {
+            double f = 0.0;
+            for (int j = nn - 1; j >= m; --j) f += ort[j] * H[i][j];
+            f /= hh;
+            for (int j = m; j < nn; ++j) H[i][j] -= f * ort[j];
+        }
+        ort[m] *= scale;
+        H[m][m - 1] = scale * g;
+        for (int i = m + 1; i < nn; ++i) H[i][m - 1] = 0.0;
+    }
+    /* hqr: eigenvalues only */
+    int n = nn - 1;
+    const int low = 0;
+    const double eps = DBL_EPSILON;
+    double exshift = 0.0, p = 0, q = 0, r = 0, s = 0, z = 0, t, w, x, y;
+    double norm = 0.0;
+    for (int i = 0; i < nn; ++i)
+        for (int j = (i - 1 > 0 ? i - 1 : 0); j < nn; ++j) norm += fabs(H[i][j]);
+    int iter = 0, total = 0;
+    while (n >= low) {
+        if (++total > 10000) return -2;
+        int l = n;
+        while (l > low) {
+            s = fabs(H[l - 1][l - 1]) + fabs(H[l][l]);
+            if (s == 0.0) s = norm;
+            if (fabs(H[l][l - 1]) < eps * s) break;
+            l--;
+        }
+        if (l == n) {
+            H[n][n] += exshift;
+            re[n] = H[n][n];
+            im[n] = 0.0;
+            n--;
+            iter = 0;
+        } else if (l == n - 1) {
+            w = H[n][n - 1] * H[n - 1][n];
+            p = (H[n - 1][n - 1] - H[n][n]) / 2.0;
+            q = p * p + w;
+            z = sqrt(fabs(q));
+            H[n][n] += exshift;
+            H[n - 1][n - 1] += exshift;
+            x = H[n][n];
+            if (q >= 0) {
+                z = (p >= 0) ? p + z : p - z;
+                re[n - 1] = x + z;
+                re[n] = re[n - 1];
+                if (z != 0.0) re[n] = x - w / z;
+                im[n - 1] = 0.0;
+                im[n] = 0.0;
+            } else {
+                re[n - 1] = x + p;
+                re[n] = x + p;
+                im[n - 1] = z;
+                im[n] = -z;
+            }
+            n -= 2;
+            iter = 0;
+        } else {
+            x = H[n][n];
+            y = 0.0;
+            w = 0.0;
+            if (l < n) {
+                y = H[n - 1][n - 1];
+                w = H[n][n - 1] * H[n - 1][n];
+            }
+            if (iter == 10) {
+                exshift += x;
+                for (int i = low; i <= n; ++i) H[i][i] -= x;
+                s = fabs(H[n][n - 1]) + fabs(H[n - 1][n - 2]);
+                x = y = 0.75 * s;
+                w = -0.4375 * s * s;
+            }
+            if (iter == 30) {
+                s = (y - x) / 2.0;
+                s = s * s + w;
+                if (s > 0) {
+                    s = sqrt(s);
+                    if (y < x) s = -s;
+                    s = x - w / ((y - x) / 2.0 + s);
+                    for (int i = low; i <= n; ++i) H[i][i] -= s;
+                    exshift += s;
+                    x = y = w = 0.964;
+                }
+            }
+            iter++;
+            int m = n - 2;
+            while (m >= l) {
+                z = H[m][m];
+                r = x - z;
+                s = y - z;
+                p = (r * s - w) / H[m + 1][m] + H[m][m + 1];
+                q = H[m + 1][m + 1] - z - r - s;
+                r = H[m + 2][m + 1];
+                s = fabs(p) + fabs(q) + fabs(r);
+                p /= s;
+                q /= s;
+                r /= s;
+                if (m == l) break;
+                if (fabs(H[m][m - 1]) * (fabs(q) + fabs(r)) <
+                    eps * (fabs(p) * (fabs(H[m - 1][m - 1]) + fabs(z) + fabs(H[m + 1][m + 1]))))
+                    break;
+                m--;
+            }
+            for (int i = m + 2; i <= n; ++i) {
+                H[i][i - 2] = 0.0;
+                if (i > m + 2) H[i][i - 3] = 0.0;
+            }
+            for (int k = m; k <= n - 1; ++k) {
+                int notlast = (k != n - 1);
+                if (k != m) {
+                    p = H[k][k - 1];
+                    q = H[k + 1][k - 1];
+                    r = notlast ? H[k + 2][k - 1] : 0.0;
+                    x = fabs(p) + fabs(q) + fabs(r);
+                    if (x != 0.0) {
+                        p /= x;
+                        q /= x;
+                        r /= x;
+                    }
+                }
+                if (x == 0.0) break;
+                s = sqrt(p * p + q * q + r * r);
+                if (p < 0) s = -s;
+                if (s != 0) {
+                    if (k != m)
+                        H[k][k - 1] = -s * x;
+                    else if (l != m)
+                        H[k][k - 1] = -H[k][k - 1];
+                    p += s;
+                    x = p / s;
+                    y = q / s;
+                    z = r / s;
+                    q /= p;
+                    r /= p;
+                    for (int j = k; j < nn; ++j) {
+                        p = H[k][j] + q * H[k + 1][j];
+                        if (notlast) {
+                            p += r * H[k + 2][j];
+                            H[k + 2][j] -= p * z;
+                        }
+                        H[k][j] -= p * x;
+                        H[k + 1][j] -= p * y;
+                    }
+                    int imax = (n < k + 3) ? n : k + 3;
+                    for (int i = 0; i <= imax; ++i) {
+                        p = x * H[i][k] + y * H[i][k + 1];
+                        if (notlast) {
+                            p += z * H[i][k + 2];
+                            H[i][k + 2] -= p * r;
+                        }
+                        H[i][k] -= p;
+                        H[i][k + 1] -= p * q;
+                    }
+                }
+            }
+        }
+    }
+    (void)t;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* small dense helpers                                                                               */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* MatrixXd::inverse() for dynamic sizes = PartialPivLU; row-major n x n, n <= 8.  returns 0 / -1 singular */
+static int inverse_lu(const double* A, int n, double* Ainv) {
+    double lu[64];
+    int piv[8];
+    memcpy(lu, A, sizeof(double) * n * n);
+    for (int i = 0; i < n; ++i) piv[i] = i;
+    for (int k = 0; k < n; ++k) {
+        int pr = k;
+        double best = fabs(lu[k * n + k]);
+        for (int i = k + 1; i < n; ++i)
+            if (fabs(lu[i * n + k]) > best) {
+                best = fabs(lu[i * n + k]);
+                pr = i;
+            }
+        if (best == 0.0) return -1;
+        if (pr != k) {
+            for (int j = 0; j < n; ++j) {
+                double t = lu[k * n + j];
+                lu[k * n + j] = lu[pr * n + j];
+                lu[pr * n + j] = t;
+            }
+            int ti = piv[k];
+            piv[k] = piv[pr];
+            piv[pr] = ti;
+        }
+        for (int i = k + 1; i < n; ++i) {
+            lu[i * n + k] /= lu[k * n + k];
+            double f = lu[i * n + k];
+            for (int j = k + 1; j < n; ++j) lu[i * n + j] -= f * lu[k * n + j];
+        }
+    }
+    for (int c = 0; c < n; ++c) {
+        double y[8];
+        for (int i = 0; i < n; ++i) {
+            double s = (piv[i] == c) ? 1.0 : 0.0;
+            for (int j = 0; j < i; ++j) s -= lu[i * n + j] * y[j];
+            y[i] = s;
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            double s = y[i];
+            for (int j = i + 1; j < n; ++j) s -= lu[i * n + j] * Ainv[j * n + c];
+            Ainv[i * n + c] = s / lu[i * n + i];
+        }
+    }
+    return 0;
+}
+
+/* C(m x n) = A(m x k) * B(k x n), row-major, coefficient-wise sum in k order */
+static void matmul(const double* A, const double* B, double* C, int m, int k, int n) {
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int t = 0; t < k; ++t) s += A[i * k + t] * B[t * n + j];
+            C[i * n + j] = s;
+        }
+}
+
+static void transpose3(const double* A, double* At) {
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) At[j * 3 + i] = A[i * 3 + j];
+}
+
+/* Eigen AngleAxisd(angle, axis).toRotationMatrix() (AngleAxis.h), row-major 3x3 */
+static void angle_axis_R(double angle, const double ax[3], double R[9]) {
+    double sn = sin(angle), c = cos(angle);
+    double sin_axis[3] = {sn * ax[0], sn * ax[1], sn * ax[2]};
+    double cos1_axis[3] = {(1.0 - c) * ax[0], (1.0 - c) * ax[1], (1.0 - c) * ax[2]};
+    double tmp;
+    tmp = cos1_axis[0] * ax[1];
+    R[0 * 3 + 1] = tmp - sin_axis[2];
+    R[1 * 3 + 0] = tmp + sin_axis[2];
+    tmp = cos1_axis[0] * ax[2];
+    R[0 * 3 + 2] = tmp + sin_axis[1];
+    R[2 * 3 + 0] = tmp - sin_axis[1];
+    tmp = cos1_axis[1] * ax[2];
+    R[1 * 3 + 2] = tmp - sin_axis[0];
+    R[2 * 3 + 1] = tmp + sin_axis[0];
+    R[0] = cos1_axis[0] * ax[0] + c;
+    R[4] = cos1_axis[1] * ax[1] + c;
+    R[8] = cos1_axis[2] * ax[2] + c;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* minimal::calculateVelocities  (minimal.cc:36-177)                                                 */
+/* ------------------------------------------------------------------------------------------------ */
+int rso_calculate_velocities(const double q[18], const double u[18], const double alpha[9],
+                             const double alpha_k[9], int use_alpha_k, int k_sign_mode, double w_out[3],
+                             double v_out[3], double* k_out) {
+    const double THRESHOLD_LAMBDA = 0.000001;
+    const double TOL_IMAG = 0.00001;
+    int rc = 0;
+    double k = 0.0;
+    double beta[9];
+    double Z[81]; /* row i = point i */
+    for (int i = 0; i < 9; ++i) {
+        double x = q[2 * i], y = q[2 * i + 1], ux = u[2 * i], uy = u[2 * i + 1];
+        Z[i * 9 + 0] = -uy;
+        Z[i * 9 + 1] = ux;
+        Z[i * 9 + 2] = uy * x - ux * y;
+        Z[i * 9 + 3] = x * x;
+        Z[i * 9 + 4] = 2.0 * x * y;
+        Z[i * 9 + 5] = 2.0 * x;
+        Z[i * 9 + 6] = y * y;
+        Z[i * 9 + 7] = 2 * y;
+        Z[i * 9 + 8] = 1.0;
+    }
+    if (use_alpha_k) {
+        /* minimal.cc:58-80 */
+        double a[9], a_inv[9], efhj[36], dg[18], bc[18];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) a[i * 3 + j] = Z[i * 9 + j];
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 6; ++j) efhj[i * 6 + j] = Z[(3 + i) * 9 + 3 + j];
+        for (int i = 0; i < 6; ++i)
+            for (int j = 0; j < 3; ++j) dg[i * 3 + j] = Z[(3 + i) * 9 + j];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 6; ++j) bc[i * 6 + j] = Z[i * 9 + 3 + j];
+        double p[36], pk[36], pk_inv[36], m[36];
+        if (inverse_lu(a, 3, a_inv) != 0) {
+            k = INFINITY;
+            rc = -2;
+        } else {
+            double dga[18];
+            matmul(dg, a_inv, dga, 6, 3, 3); /* dg * a_inv */
+            for (int which = 0; which < 2; ++which) {
+                const double* al = which == 0 ? alpha : alpha_k;
+                double t1[18], t2[36];
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 3; ++j) t1[i * 3 + j] = dga[i * 3 + j] * al[j]; /* * diag(al_f3) */
+                matmul(t1, bc, t2, 6, 3, 6);
+                double* dst = which == 0 ? p : pk;
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j) dst[i * 6 + j] = al[3 + i] * efhj[i * 6 + j] - t2[i * 6 + j];
+            }
+            if (inverse_lu(pk, 6, pk_inv) != 0) {
+                k = INFINITY;
+                rc = -2;
+            } else {
+                matmul(p, pk_inv, m, 6, 6, 6);
+                double re[6], im[6];
+                if (rso_eigvals_general(m, 6, re, im) != 0) {
+                    k = INFINITY;
+                    rc = -2;
+                } else {
+                    k = INFINITY;
+                    for (int i = 0; i < 6; ++i)
+                        if (fabs(im[i]) < TOL_IMAG && fabs(re[i]) < fabs(k)) k = re[i];
+                    if (isinf(k)) rc = -1;
+                    if (k_sign_mode == 1 && !isinf(k)) k = -k;
+                }
+            }
+        }
+        for (int i = 0; i < 9; ++i) beta[i] = (alpha[i] + k * alpha_k[i]) * (2.0 / (2.0 + k));
+    } else {
+        for (int i = 0; i < 9; ++i) beta[i] = alpha[i];
+    }
+    for (int i = 0; i < 9; ++i)
+        for (int j = 3; j < 9; ++j) Z[i * 9 + j] *= beta[i];
+
+    double sv[9], V[81];
+    jacobi_svd_square(Z, 9, sv, V);
+    double e[9];
+    for (int i = 0; i < 9; ++i) e[i] = V[i * 9 + 8];
+    double norm_v0 = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    for (int i = 0; i < 9; ++i) e[i] = e[i] / norm_v0;
+    double v0[3] = {e[0], e[1], e[2]};
+    double S[9] = {e[3], e[4], e[5], e[4], e[6], e[7], e[5], e[7], e[8]};
+    double lamb[3], v1[9];
+    rso_eig_sym3(S, lamb, v1);
+    for (int r = 0; r < 3; ++r) { /* v1.col(0).swap(v1.col(2)) */
+        double t = v1[r * 3 + 0];
+        v1[r * 3 + 0] = v1[r * 3 + 2];
+        v1[r * 3 + 2] = t;
+    }
+    double sigma[3] = {(2 * lamb[2] + lamb[1] - lamb[0]) / 3, (lamb[2] + 2 * lamb[1] + lamb[0]) / 3,
+                       (-lamb[2] + lamb[1] + 2 * lamb[0]) / 3};
+    double lambda = sigma[0] - sigma[2];
+    double theta = 0;
+    if (!(lambda < THRESHOLD_LAMBDA)) theta = acos(-sigma[1] / lambda);
+    const double uy[3] = {0, 1, 0}, uz[3] = {0, 0, 1};
+    double r_v[9], r_u[9], r_vt[9], v_[9], u_[9], r_z1[9], r_z2[9];
+    angle_axis_R((theta - M_PI) / 2, uy, r_v);
+    angle_axis_R(theta, uy, r_u);
+    transpose3(r_v, r_vt);
+    matmul(v1, r_vt, v_, 3, 3, 3);
+    double negv[9];
+    for (int i = 0; i < 9; ++i) negv[i] = -v_[i];
+    matmul(negv, r_u, u_, 3, 3, 3);
+    angle_axis_R(M_PI / 2, uz, r_z1);
+    angle_axis_R(-M_PI / 2, uz, r_z2);
+    const double sig1[9] = {1, 0, 0, 0, 1, 0, 0, 0, 0};
+    double sig_lamb[9];
+    for (int i = 0; i < 9; ++i) sig_lamb[i] = lambda * sig1[i];
+    const double* bases[2] = {v_, u_};
+    const double* rz[2] = {r_z1, r_z2};
+    double v_vecs[4][3];
+    for (int b = 0; b < 2; ++b)
+        for (int z = 0; z < 2; ++z) {
+            double t1[9], t2[9], bt[9], mm[9];
+            matmul(bases[b], rz[z], t1, 3, 3, 3);
+            matmul(t1, sig1, t2, 3, 3, 3);
+            transpose3(bases[b], bt);
+            matmul(t2, bt, mm, 3, 3, 3);
+            v_vecs[b * 2 + z][0] = mm[2 * 3 + 1];
+            v_vecs[b * 2 + z][1] = mm[0 * 3 + 2];
+            v_vecs[b * 2 + z][2] = mm[1 * 3 + 0];
+        }
+    int index_max = 0;
+    double best = 0;
+    for (int c = 0; c < 4; ++c) {
+        double d = v_vecs[c][0] * v0[0] + v_vecs[c][1] * v0[1] + v_vecs[c][2] * v0[2];
+        if (c == 0 || d > best) {
+            best = d;
+            index_max = c;
+        }
+    }
+    /* minimal.cc:159-173: omega from the OTHER basis */
+    const double* wb = (index_max < 2) ? u_ : v_;
+    const double* wz = (index_max % 2 == 0) ? r_z1 : r_z2;
+    double t1[9], t2[9], bt[9], w_hat[9];
+    matmul(wb, wz, t1, 3, 3, 3);
+    matmul(t1, sig_lamb, t2, 3, 3, 3);
+    transpose3(wb, bt);
+    matmul(t2, bt, w_hat, 3, 3, 3);
+    w_out[0] = w_hat[2 * 3 + 1];
+    w_out[1] = w_hat[0 * 3 + 2];
+    w_out[2] = w_hat[1 * 3 + 0];
+    v_out[0] = v0[0];
+    v_out[1] = v0[1];
+    v_out[2] = v0[2];
+    *k_out = k;
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* residual + per-pixel model                                                                        */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* nonlinearRefinement.cc:32-52, T = double, same evaluation order */
+void rso_residual(double x, double y, double ux, double uy, double alpha, double alpha_k, const double v[3],
+                  const double w[3], double k, double rho, double r[2]) {
+    double beta = (2.0 / (2.0 + k)) * (alpha + k * alpha_k);
+    double p0 = beta * -1.0 * (rho * (x * v[2] - v[0]) + (x * y * w[0]) - (1.0 + x * x) * w[1] + y * w[2]);
+    double p1 = beta * -1.0 * (rho * (y * v[2] - v[1]) + (1.0 + y * y) * w[0] - x * y * w[1] - x * w[2]);
+    r[0] = ux - p0;
+    r[1] = uy - p1;
+}
+
+/* d r / d rho  ( = beta * a ), the only non-constant Jacobian column of the dense depth solve */
+static inline void jac_rho(double x, double y, double alpha, double alpha_k, const double v[3], double k,
+                           double J[2]) {
+    double beta = (2.0 / (2.0 + k)) * (alpha + k * alpha_k);
+    J[0] = beta * (x * v[2] - v[0]);
+    J[1] = beta * (y * v[2] - v[1]);
+}
+
+/* Ceres 1.14 defaults (Solver::Options) used by every solve in nonlinearRefinement.cc */
+#define CERES_MAX_ITER 50
+#define CERES_INITIAL_RADIUS 1e4
+#define CERES_MAX_RADIUS 1e16
+#define CERES_MIN_RADIUS 1e-32
+#define CERES_MIN_REL_DECREASE 1e-3
+#define CERES_MIN_LM_DIAG 1e-6
+#define CERES_MAX_LM_DIAG 1e32
+#define CERES_FUNCTION_TOL 1e-6
+#define CERES_GRADIENT_TOL 1e-10
+#define CERES_PARAMETER_TOL 1e-8
+#define CERES_MAX_INVALID 5
+
+static inline double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* LevenbergMarquardtStrategy::StepAccepted */
+static inline double radius_accept(double radius, double q) {
+    double t = 2.0 * q - 1.0;
+    double f = 1.0 - t * t * t;
+    if (f < 1.0 / 3.0) f = 1.0 / 3.0;
+    radius = radius / f;
+    if (radius > CERES_MAX_RADIUS) radius = CERES_MAX_RADIUS;
+    return radius;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* nonlinear_refinement::estimateInverseDepths  (nonlinearRefinement.cc:109-180)                      */
+/* ------------------------------------------------------------------------------------------------ */
+int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, const double v[3],
+                                const double w[3], double k, const double* alpha, const double* alpha_k,
+                                int mode, double* rho, rso_lm_summary* summary) {
+    rso_lm_summary sm;
+    memset(&sm, 0, sizeof(sm));
+    if (n < 0) return -1;
+    if (mode == 0) {
+        /* exact optimum of the linear 1-D problem: one undamped Gauss-Newton step from rho = 1 */
+        double c0 = 0.0, c1 = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            double J[2], r[2];
+            jac_rho(q[2 * i], q[2 * i + 1], alpha[i], alpha_k[i], v, k, J);
+            rso_residual(q[2 * i], q[2 * i + 1], u[2 * i], u[2 * i + 1], alpha[i], alpha_k[i], v, w, k, 1.0, r);
+            c0 += r[0] * r[0] + r[1] * r[1];
+            double h = J[0] * J[0] + J[1] * J[1];
+            double g = J[0] * r[0] + J[1] * r[1];
+            double rr = (h > 0.0) ? 1.0 - g / h : 1.0;
+            rho[i] = rr;
+            rso_residual(q[2 * i], q[2 * i + 1], u[2 * i], u[2 * i + 1], alpha[i], alpha_k[i], v, w, k, rr, r);
+            c1 += r[0] * r[0] + r[1] * r[1];
+        }
+        sm.num_iterations = 1;
+        sm.num_successful_steps = 1;
+        sm.termination = RSO_TERM_GRADIENT;
+        sm.initial_cost = 0.5 * c0;
+        sm.final_cost = 0.5 * c1;
+        sm.final_radius = 0.0;
+        if (summary) *summary = sm;
+        return 0;
+    }
+
+    /* mode 1: Ceres 1.14 TrustRegionMinimizer + LevenbergMarquardtStrategy, N independent 1x1 e-blocks */
+    double* J = (double*)malloc(sizeof(double) * 2 * (n > 0 ? n : 1));
+    double* s = (double*)malloc(sizeof(double) * (n > 0 ? n : 1));
+    double* res = (double*)malloc(sizeof(double) * 2 * (n > 0 ? n : 1));
+    double* cand = (double*)malloc(sizeof(double) * (n > 0 ? n : 1));
+    double cost = 0.0, gmax = 0.0, xsq = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        rho[i] = 1.0; /* nonlinearRefinement.cc:140 */
+        jac_rho(q[2 * i], q[2 * i + 1], alpha[i], alpha_k[i], v, k, &J[2 * i]);
+        s[i] = 1.0 / (1.0 + sqrt(J[2 * i] * J[2 * i] + J[2 * i + 1] * J[2 * i + 1])); /* jacobi scaling */
+        rso_residual(q[2 * i], q[2 * i + 1], u[2 * i], u[2 * i + 1], alpha[i], alpha_k[i], v, w, k, rho[i],
+                     &res[2 * i]);
+        cost += res[2 * i] * res[2 * i] + res[2 * i + 1] * res[2 * i + 1];
+        double g = fabs(J[2 * i] * res[2 * i] + J[2 * i + 1] * res[2 * i + 1]);
+        if (g > gmax) gmax = g;
+        xsq += rho[i] * rho[i];
+    }
+    cost *= 0.5;
+    double x_norm = sqrt(xsq);
+    double radius = CERES_INITIAL_RADIUS, decrease_factor = 2.0;
+    int iteration = 0, invalid = 0;
+    sm.initial_cost = cost;
+    sm.termination = -1;
+    if (n == 0 || gmax <= CERES_GRADIENT_TOL) sm.termination = RSO_TERM_GRADIENT;
+    while (sm.termination < 0) {
+        if (iteration >= CERES_MAX_ITER) {
+            sm.termination = RSO_TERM_MAX_ITER;
+            break;
+        }
+        if (radius < CERES_MIN_RADIUS) {
+            sm.termination = RSO_TERM_MIN_RADIUS;
+            break;
+        }
+        ++iteration;
+        double model_change = 0.0, stepsq = 0.0, ccost = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            double jt0 = J[2 * i] * s[i], jt1 = J[2 * i + 1] * s[i];
+            double ht = jt0 * jt0 + jt1 * jt1;
+            double D = sqrt(clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG) / radius);
+            double gt = jt0 * res[2 * i] + jt1 * res[2 * i + 1];
+            double step = -(gt / (ht + D * D));
+            double m0 = jt0 * step, m1 = jt1 * step;
+            model_change -= m0 * (res[2 * i] + m0 / 2.0) + m1 * (res[2 * i + 1] + m1 / 2.0);
+            cand[i] = rho[i] + step * s[i];
+            double dx = rho[i] - cand[i];
+            stepsq += dx * dx;
+            double rc[2];
+            rso_residual(q[2 * i], q[2 * i + 1], u[2 * i], u[2 * i + 1], alpha[i], alpha_k[i], v, w, k, cand[i], rc);
+            ccost += rc[0] * rc[0] + rc[1] * rc[1];
+        }
+        ccost *= 0.5;
+        if (!(model_change > 0.0)) { /* HandleInvalidStep */
+            ++sm.num_unsuccessful_steps;
+            if (++invalid >= CERES_MAX_INVALID) {
+                sm.termination = RSO_TERM_FAILURE;
+                break;
+            }
+            radius *= 0.5;
+            continue;
+        }
+        invalid = 0;
+        double step_norm = sqrt(stepsq);
+        if (step_norm <= CERES_PARAMETER_TOL * (x_norm + CERES_PARAMETER_TOL)) {
+            sm.termination = RSO_TERM_PARAMETER;
+            break;
+        }
+        double cost_change = cost - ccost;
+        if (fabs(cost_change) <= CERES_FUNCTION_TOL * cost) {
+            sm.termination = RSO_TERM_FUNCTION;
+            break;
+        }
+        double rel = cost_change / model_change;
+        if (rel > CERES_MIN_REL_DECREASE) { /* HandleSuccessfulStep */
+            xsq = 0.0;
+            cost = 0.0;
+            gmax = 0.0;
+            for (int64_t i = 0; i < n; ++i) {
+                rho[i] = cand[i];
+                xsq += rho[i] * rho[i];
+                rso_residual(q[2 * i], q[2 * i + 1], u[2 * i], u[2 * i + 1], alpha[i], alpha_k[i], v, w, k, rho[i],
+                             &res[2 * i]);
+                cost += res[2 * i] * res[2 * i] + res[2 * i + 1] * res[2 * i + 1];
+                double g = fabs(J[2 * i] * res[2 * i] + J[2 * i + 1] * res[2 * i + 1]);
+                if (g > gmax) gmax = g;
+            }
+            cost *= 0.5;
+            x_norm = sqrt(xsq);
+            radius = radius_accept(radius, rel);
+            decrease_factor = 2.0;
+            ++sm.num_successful_steps;
+            if (gmax <= CERES_GRADIENT_TOL) sm.termination = RSO_TERM_GRADIENT;
+        } else { /* HandleUnsuccessfulStep */
+            ++sm.num_unsuccessful_steps;
+            radius = radius / decrease_factor;
+            decrease_factor *= 2.0;
+        }
+    }
+    sm.num_iterations = iteration;
+    sm.final_cost = cost;
+    sm.final_radius = radius;
+    if (summary) *summary = sm;
+    free(J);
+    free(s);
+    free(res);
+    free(cand);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* scoring (minimal.cc:255-275)                                                                      */
+/* ------------------------------------------------------------------------------------------------ */
+static inline double point_error(double x, double y, double ux, double uy, double alpha, double alpha_k,
+                                 const double v[3], const double w[3], double k, double rho) {
+    double beta = (alpha + k * alpha_k) * (2.0 / (2.0 + k));
+    /* A*v, B*w as Eigen evaluates the 2x3 * 3x1 products (terms in column order) */
+    double av0 = v[0] + (-x) * v[2];
+    double av1 = v[1] + (-y) * v[2];
+    double bw0 = (-x * y) * w[0] + (1 + x * x) * w[1] + (-y) * w[2];
+    double bw1 = (-(1 + y * y)) * w[0] + (x * y) * w[1] + x * w[2];
+    double e0 = beta * (av0 * rho + bw0) - ux;
+    double e1 = beta * (av1 * rho + bw1) - uy;
+    return sqrt(e0 * e0 + e1 * e1);
+}
+
+int64_t rso_score(const double* q, const double* u, const double* alpha, const double* alpha_k, int64_t n,
+                  const double v[3], const double w[3], double k, const double* rho, double tol, uint8_t* mask,
+                  double* err_sum) {
+    int64_t count = 0;
+    double es = 0.0;
+    for (int64_t j = 0; j < n; ++j) {
+        double err = point_error(q[2 * j], q[2 * j + 1], u[2 * j], u[2 * j + 1], alpha[j], alpha_k[j], v, w, k, rho[j]);
+        int in = err < tol;
+        if (mask) mask[j] = (uint8_t)in;
+        if (in) {
+            ++count;
+            es += err;
+        }
+    }
+    if (err_sum) *err_sum = es;
+    return count;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* sampler (minimal.cc:226-244 with rand() -> splitmix64)                                            */
+/* ------------------------------------------------------------------------------------------------ */
+static inline uint64_t splitmix64(uint64_t* state) {
+    uint64_t z = (*state += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+void rso_sample_indices(int64_t n, int32_t trials, uint64_t seed, int32_t* samples) {
+    int32_t* indices = (int32_t*)malloc(sizeof(int32_t) * (n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; ++i) indices[i] = (int32_t)i;
+    uint64_t st = seed;
+    for (int32_t t = 0; t < trials; ++t) {
+        int64_t n_temp = n;
+        for (int j = 0; j < 9; ++j) {
+            int64_t r = (int64_t)(splitmix64(&st) % (uint64_t)n_temp);
+            int32_t tmp = indices[n_temp - 1];
+            indices[n_temp - 1] = indices[r];
+            indices[r] = tmp;
+            samples[t * 9 + j] = indices[n_temp - 1];
+            n_temp--;
+        }
+    }
+    free(indices);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* minimal::ransac (minimal.cc:209-306), samples injected                                            */
+/* ------------------------------------------------------------------------------------------------ */
+int rso_ransac(const double* q, const double* u, const double* alpha, const double* alpha_k, int64_t n,
+               int use_alpha_k, int32_t iterations, double tol, const int32_t* samples, int depth_mode,
+               int k_sign_mode, rso_ransac_out* out) {
+    if (n < 9 || !samples || !out) return -1;
+    double* inv_depth = (double*)malloc(sizeof(double) * n);
+    uint8_t* mask = (uint8_t*)malloc(n);
+    int64_t best_count = -1;
+    double best_err = 0.0;
+    out->best_trial = -1;
+    memset(out->w, 0, sizeof(out->w));
+    memset(out->v, 0, sizeof(out->v));
+    out->k = 0;
+    for (int32_t t = 0; t < iterations; ++t) {
+        double cq[18], cu[18], ca[9], cak[9];
+        for (int j = 0; j < 9; ++j) {
+            int64_t idx = samples[t * 9 + j];
+            if (idx < 0 || idx >= n) {
+                free(inv_depth);
+                free(mask);
+                return -2;
+            }
+            cq[2 * j] = q[2 * idx];
+            cq[2 * j + 1] = q[2 * idx + 1];
+            cu[2 * j] = u[2 * idx];
+            cu[2 * j + 1] = u[2 * idx + 1];
+            ca[j] = alpha[idx];
+            cak[j] = alpha_k[idx];
+        }
+        double w[3], v[3], k;
+        rso_calculate_velocities(cq, cu, ca, cak, use_alpha_k, k_sign_mode, w, v, &k);
+        rso_lm_summary sm;
+        rso_estimate_inverse_depths(q, u, n, v, w, k, alpha, alpha_k, depth_mode, inv_depth, &sm);
+        double err = 0.0;
+        int64_t count = rso_score(q, u, alpha, alpha_k, n, v, w, k, inv_depth, tol, mask, &err);
+        if (out->trial_count) out->trial_count[t] = count;
+        if (out->trial_err) out->trial_err[t] = err;
+        if (out->trial_vel) {
+            memcpy(&out->trial_vel[7 * t], w, 3 * sizeof(double));
+            memcpy(&out->trial_vel[7 * t + 3], v, 3 * sizeof(double));
+            out->trial_vel[7 * t + 6] = k;
+        }
+        if (out->trial_steps) out->trial_steps[t] = sm.num_successful_steps;
+        if (count > best_count || (count == best_count && err < best_err)) {
+            best_count = count;
+            best_err = err;
+            out->best_trial = t;
+            memcpy(out->w, w, sizeof(w));
+            memcpy(out->v, v, sizeof(v));
+            out->k = k;
+            memcpy(out->mask, mask, n);
+            memcpy(out->inv_depth, inv_depth, sizeof(double) * n);
+        }
+    }
+    if (best_count < 0) { /* iterations == 0: the reference would build arrays of size -1 */
+        best_count = 0;
+        memset(out->mask, 0, n);
+        memset(out->inv_depth, 0, sizeof(double) * n);
+    }
+    int64_t j = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (out->mask[i]) {
+            out->inliers[3 * j] = q[2 * i];
+            out->inliers[3 * j + 1] = q[2 * i + 1];
+            out->inliers[3 * j + 2] = 1.0 / out->inv_depth[i];
+            out->alpha[j] = alpha[i];
+            out->alpha_k[j] = alpha_k[i];
+            out->inlier_idx[j] = i;
+            ++j;
+        }
+    }
+    out->num_inliers = best_count;
+    out->inlier_error = best_err;
+    free(inv_depth);
+    free(mask);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* nonlinear_refinement::nonLinearRefinement (nonlinearRefinement.cc:183-252)                         */
+/* Ceres trust-region LM + DENSE_SCHUR: rho_i are the 1x1 e-blocks, (v, w[, k]) the f-blocks.         */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* residual and analytic Jacobian wrt p = (v0,v1,v2,w0,w1,w2,k) and rho, at (p, rho) */
+static inline void resid_jac(double x, double y, double ux, double uy, double alpha, double alpha_k,
+                             const double p[7], double rho, double r[2], double Jp[2][7], double Jr[2]) {
+    const double* v = p;
+    const double* w = p + 3;
+    double k = p[6];
+    double beta = (2.0 / (2.0 + k)) * (alpha + k * alpha_k);
+    double a0 = x * v[2] - v[0], a1 = y * v[2] - v[1];
+    double in0 = rho * a0 + (x * y * w[0]) - (1.0 + x * x) * w[1] + y * w[2];
+    double in1 = rho * a1 + (1.0 + y * y) * w[0] - x * y * w[1] - x * w[2];
+    r[0] = ux - beta * -1.0 * in0;
+    r[1] = uy - beta * -1.0 * in1;
+    double br = beta * rho;
+    Jp[0][0] = -br;
+    Jp[1][0] = 0.0;
+    Jp[0][1] = 0.0;
+    Jp[1][1] = -br;
+    Jp[0][2] = br * x;
+    Jp[1][2] = br * y;
+    Jp[0][3] = beta * (x * y);
+    Jp[1][3] = beta * (1.0 + y * y);
+    Jp[0][4] = -(beta * (1.0 + x * x));
+    Jp[1][4] = -(beta * (x * y));
+    Jp[0][5] = beta * y;
+    Jp[1][5] = -(beta * x);
+    double dbeta = 2.0 * (2.0 * alpha_k - alpha) / ((2.0 + k) * (2.0 + k));
+    Jp[0][6] = dbeta * in0;
+    Jp[1][6] = dbeta * in1;
+    Jr[0] = beta * a0;
+    Jr[1] = beta * a1;
+}
+
+/* dense Cholesky solve, n <= 7, A symmetric positive definite (row-major, overwritten).  0 ok / -1 */
+static int chol_solve(double* A, int n, const double* b, double* x) {
+    for (int j = 0; j < n; ++j) {
+        double d = A[j * n + j];
+        for (int t = 0; t < j; ++t) d -= A[j * n + t] * A[j * n + t];
+        if (!(d > 0.0)) return -1;
+        d = sqrt(d);
+        A[j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) {
+            double sacc = A[i * n + j];
+            for (int t = 0; t < j; ++t) sacc -= A[i * n + t] * A[j * n + t];
+            A[i * n + j] = sacc / d;
+        }
+    }
+    double yv[8];
+    for (int i = 0; i < n; ++i) {
+        double sacc = b[i];
+        for (int t = 0; t < i; ++t) sacc -= A[i * n + t] * yv[t];
+        yv[i] = sacc / A[i * n + i];
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double sacc = yv[i];
+        for (int t = i + 1; t < n; ++t) sacc -= A[t * n + i] * x[t];
+        x[i] = sacc / A[i * n + i];
+    }
+    return 0;
+}
+
+int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl, const double* alpha,
+               const double* alpha_k, const int64_t* inlier_idx, const double v_in[3], const double w_in[3],
+               double k_in, int const_acceleration, int flow_index_mode, double* inl_out, double v_out[3],
+               double w_out[3], double* k_out, rso_lm_summary* summary) {
+    rso_lm_summary sm;
+    memset(&sm, 0, sizeof(sm));
+    if (m < 0 || (flow_index_mode == 1 && !inlier_idx)) return -1;
+    const int np = const_acceleration ? 7 : 6;
+    double p[7] = {v_in[0], v_in[1], v_in[2], w_in[0], w_in[1], w_in[2], k_in};
+    double* rho = (double*)malloc(sizeof(double) * (m > 0 ? m : 1));
+    double* cand = (double*)malloc(sizeof(double) * (m > 0 ? m : 1));
+    double* srho = (double*)malloc(sizeof(double) * (m > 0 ? m : 1));
+    double* uu = (double*)malloc(sizeof(double) * 2 * (m > 0 ? m : 1));
+    for (int64_t i = 0; i < m; ++i) {
+        int64_t fi = (flow_index_mode == 1) ? inlier_idx[i] : i; /* nonlinearRefinement.cc:211-212 (Q2) */
+        if (fi < 0 || fi >= n_flow) {
+            free(rho), free(cand), free(srho), free(uu);
+            return -2;
+        }
+        uu[2 * i] = flow[2 * fi];
+        uu[2 * i + 1] = flow[2 * fi + 1];
+        rho[i] = 1.0 / inl[3 * i + 2]; /* nonlinearRefinement.cc:213 */
+    }
+    /* iteration zero: cost, gradient, jacobi scaling from the initial Jacobian */
+    double sp[7], colsq[7] = {0}, gp[7] = {0};
+    double cost = 0.0, gmax = 0.0, xsq = 0.0;
+    for (int64_t i = 0; i < m; ++i) {
+        double r[2], Jp[2][7], Jr[2];
+        resid_jac(inl[3 * i], inl[3 * i + 1], uu[2 * i], uu[2 * i + 1], alpha[i], alpha_k[i], p, rho[i], r, Jp, Jr);
+        cost += r[0] * r[0] + r[1] * r[1];
+        for (int c = 0; c < np; ++c) {
+            colsq[c] += Jp[0][c] * Jp[0][c] + Jp[1][c] * Jp[1][c];
+            gp[c] += Jp[0][c] * r[0] + Jp[1][c] * r[1];
+        }
+        srho[i] = 1.0 / (1.0 + sqrt(Jr[0] * Jr[0] + Jr[1] * Jr[1]));
+        double g = fabs(Jr[0] * r[0] + Jr[1] * r[1]);
+        if (g > gmax) gmax = g;
+        xsq += rho[i] * rho[i];
+    }
+    cost *= 0.5;
+    for (int c = 0; c < np; ++c) {
+        sp[c] = 1.0 / (1.0 + sqrt(colsq[c]));
+        if (fabs(gp[c]) > gmax) gmax = fabs(gp[c]);
+        xsq += p[c] * p[c];
+    }
+    double x_norm = sqrt(xsq);
+    double radius = CERES_INITIAL_RADIUS, decrease_factor = 2.0;
+    int iteration = 0, invalid = 0;
+    sm.initial_cost = cost;
+    sm.termination = -1;
+    if (m == 0 || gmax <= CERES_GRADIENT_TOL) sm.termination = RSO_TERM_GRADIENT;
+    while (sm.termination < 0) {
+        if (iteration >= CERES_MAX_ITER) {
+            sm.termination = RSO_TERM_MAX_ITER;
+            break;
+        }
+        if (radius < CERES_MIN_RADIUS) {
+            sm.termination = RSO_TERM_MIN_RADIUS;
+            break;
+        }
+        ++iteration;
+        /* pass 1: Schur complement of the scaled, LM-augmented normal equations */
+        double FtF[49] = {0}, C[49] = {0}, Ftb[7] = {0}, cvec[7] = {0};
+        for (int64_t i = 0; i < m; ++i) {
+            double r[2], Jp[2][7], Jr[2];
+            resid_jac(inl[3 * i], inl[3 * i + 1], uu[2 * i], uu[2 * i + 1], alpha[i], alpha_k[i], p, rho[i], r, Jp, Jr);
+            double E0 = Jr[0] * srho[i], E1 = Jr[1] * srho[i];
+            double ht = E0 * E0 + E1 * E1;
+            double D = sqrt(clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG) / radius);
+            double ete_inv = 1.0 / (ht + D * D);
+            double Etb = E0 * r[0] + E1 * r[1];
+            double F[2][7], EtF[7];
+            for (int c = 0; c < np; ++c) {
+                F[0][c] = Jp[0][c] * sp[c];
+                F[1][c] = Jp[1][c] * sp[c];
+                EtF[c] = E0 * F[0][c] + E1 * F[1][c];
+            }
+            for (int a = 0; a < np; ++a) {
+                Ftb[a] += F[0][a] * r[0] + F[1][a] * r[1];
+                cvec[a] += EtF[a] * (ete_inv * Etb);
+                for (int b = a; b < np; ++b) {
+                    FtF[a * 7 + b] += F[0][a] * F[0][b] + F[1][a] * F[1][b];
+                    C[a * 7 + b] += EtF[a] * (ete_inv * EtF[b]);
+                }
+            }
+        }
+        double S[49], rhs[7], yp[7], Dp[7];
+        for (int a = 0; a < np; ++a) {
+            Dp[a] = sqrt(clampd(FtF[a * 7 + a], CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG) / radius);
+            rhs[a] = Ftb[a] - cvec[a];
+            for (int b = a; b < np; ++b) {
+                double sab = FtF[a * 7 + b] - C[a * 7 + b];
+                if (a == b) sab += Dp[a] * Dp[a];
+                S[a * np + b] = sab;
+                S[b * np + a] = sab;
+            }
+        }
+        int solve_ok = chol_solve(S, np, rhs, yp) == 0;
+        double model_change = 0.0, stepsq = 0.0, ccost = 0.0;
+        double pc[7];
+        memcpy(pc, p, sizeof(pc));
+        if (solve_ok) {
+            double step_p[7];
+            for (int c = 0; c < np; ++c) {
+                step_p[c] = -yp[c];
+                pc[c] = p[c] + step_p[c] * sp[c];
+                double dx = p[c] - pc[c];
+                stepsq += dx * dx;
+            }
+            /* pass 2: back-substitution, model cost change, candidate cost */
+            for (int64_t i = 0; i < m; ++i) {
+                double r[2], Jp[2][7], Jr[2];
+                resid_jac(inl[3 * i], inl[3 * i + 1], uu[2 * i], uu[2 * i + 1], alpha[i], alpha_k[i], p, rho[i], r, Jp, Jr);
+                double E0 = Jr[0] * srho[i], E1 = Jr[1] * srho[i];
+                double ht = E0 * E0 + E1 * E1;
+                double D = sqrt(clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG) / radius);
+                double ete_inv = 1.0 / (ht + D * D);
+                double Etb = E0 * r[0] + E1 * r[1];
+                double Fy0 = 0.0, Fy1 = 0.0;
+                for (int c = 0; c < np; ++c) {
+                    Fy0 += Jp[0][c] * sp[c] * yp[c];
+                    Fy1 += Jp[1][c] * sp[c] * yp[c];
+                }
+                double ye = ete_inv * (Etb - (E0 * Fy0 + E1 * Fy1));
+                double step_e = -ye;
+                double m0 = -Fy0 + E0 * step_e, m1 = -Fy1 + E1 * step_e;
+                model_change -= m0 * (r[0] + m0 / 2.0) + m1 * (r[1] + m1 / 2.0);
+                cand[i] = rho[i] + step_e * srho[i];
+                double dx = rho[i] - cand[i];
+                stepsq += dx * dx;
+                double rc[2];
+                double Jp2[2][7], Jr2[2];
+                resid_jac(inl[3 * i], inl[3 * i + 1], uu[2 * i], uu[2 * i + 1], alpha[i], alpha_k[i], pc, cand[i], rc, Jp2, Jr2);
+                ccost += rc[0] * rc[0] + rc[1] * rc[1];
+            }
+            ccost *= 0.5;
+        }
+        if (!solve_ok || !(model_change > 0.0)) {
+            ++sm.num_unsuccessful_steps;
+            if (++invalid >= CERES_MAX_INVALID) {
+                sm.termination = RSO_TERM_FAILURE;
+                break;
+            }
+            radius *= 0.5;
+            continue;
+        }
+        invalid = 0;
+        double step_norm = sqrt(stepsq);
+        if (step_norm <= CERES_PARAMETER_TOL * (x_norm + CERES_PARAMETER_TOL)) {
+            sm.termination = RSO_TERM_PARAMETER;
+            break;
+        }
+        double cost_change = cost - ccost;
+        if (fabs(cost_change) <= CERES_FUNCTION_TOL * cost) {
+            sm.termination = RSO_TERM_FUNCTION;
+            break;
+        }
+        double rel = cost_change / model_change;
+        if (rel > CERES_MIN_REL_DECREASE) {
+            memcpy(p, pc, sizeof(pc));
+            xsq = 0.0;
+            cost = 0.0;
+            gmax = 0.0;
+            for (int c = 0; c < np; ++c) gp[c] = 0.0;
+            for (int64_t i = 0; i < m; ++i) {
+                rho[i] = cand[i];
+                xsq += rho[i] * rho[i];
+                double r[2], Jp[2][7], Jr[2];
+                resid_jac(inl[3 * i], inl[3 * i + 1], uu[2 * i], uu[2 * i + 1], alpha[i], alpha_k[i], p, rho[i], r, Jp, Jr);
+                cost += r[0] * r[0] + r[1] * r[1];
+                for (int c = 0; c < np; ++c) gp[c] += Jp[0][c] * r[0] + Jp[1][c] * r[1];
+                double g = fabs(Jr[0] * r[0] + Jr[1] * r[1]);
+                if (g > gmax) gmax = g;
+            }
+            cost *= 0.5;
+            for (int c = 0; c < np; ++c) {
+                xsq += p[c] * p[c];
+                if (fabs(gp[c]) > gmax) gmax = fabs(gp[c]);
+            }
+            x_norm = sqrt(xsq);
+            radius = radius_accept(radius, rel);
+            decrease_factor = 2.0;
+            ++sm.num_successful_steps;
+            if (gmax <= CERES_GRADIENT_TOL) sm.termination = RSO_TERM_GRADIENT;
+        } else {
+            ++sm.num_unsuccessful_steps;
+            radius = radius / decrease_factor;
+            decrease_factor *= 2.0;
+        }
+    }
+    sm.num_iterations = iteration;
+    sm.final_cost = cost;
+    sm.final_radius = radius;
+    for (int64_t i = 0; i < m; ++i) { /* nonlinearRefinement.cc:244-248 */
+        inl_out[3 * i] = inl[3 * i];
+        inl_out[3 * i + 1] = inl[3 * i + 1];
+        inl_out[3 * i + 2] = 1.0 / rho[i];
+    }
+    v_out[0] = p[0], v_out[1] = p[1], v_out[2] = p[2];
+    w_out[0] = p[3], w_out[1] = p[4], w_out[2] = p[5];
+    *k_out = p[6];
+    if (summary) *summary = sm;
+    free(rho), free(cand), free(srho), free(uu);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* caller-side glue                                                                                  */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* main.cc:398-432 / errorMeasure.cpp:66-97 : column-major scan, threshold, normalisation */
+int64_t rso_flatten(const double* flow_img, int32_t rows, int32_t cols, double fx, double fy, double cx,
+                    double cy, double gamma, double thr, double* q, double* u, double* q_px, double* flow_px) {
+    int64_t pos = 0;
+    for (int32_t i = 0; i < cols; ++i) {
+        for (int32_t j = 0; j < rows; ++j) {
+            double dx = flow_img[((int64_t)j * cols + i) * 2];
+            double dy = flow_img[((int64_t)j * cols + i) * 2 + 1];
+            double norm = dx * dx + dy * dy;
+            if (norm > thr) {
+                q_px[2 * pos] = (double)i;
+                q_px[2 * pos + 1] = (double)j;
+                flow_px[2 * pos] = dx;
+                flow_px[2 * pos + 1] = dy;
+                u[2 * pos] = dx * gamma / fx;
+                u[2 * pos + 1] = dy * gamma / fy;
+                q[2 * pos] = (i - cx) * 1.0 / fx;
+                q[2 * pos + 1] = (j - cy) * 1.0 / fy;
+                ++pos;
+            }
+        }
+    }
+    return pos;
+}
+
+/* main.cc:466-478 */
+int rso_canonicalize_sign(double* inl, int64_t m, double v[3]) {
+    double count_z = 0;
+    for (int64_t i = 0; i < m; ++i) count_z += inl[3 * i + 2];
+    double z_mean = count_z * 1.0 / (double)m;
+    if (z_mean < 0) {
+        for (int64_t i = 0; i < m; ++i) inl[3 * i + 2] *= -1.0;
+        v[0] *= -1.0;
+        v[1] *= -1.0;
+        v[2] *= -1.0;
+        return 1;
+    }
+    return 0;
+}
+
+/* main.cc:495-509 */
+void rso_scatter_depth(const double* inl, int64_t m, double fx, double fy, double cx, double cy, int32_t rows,
+                       int32_t cols, double* depth_map, int32_t* xs, int32_t* ys) {
+    for (int64_t i = 0; i < m; ++i) {
+        int x = (int)(fx * inl[3 * i] + cx + 0.5);
+        int y = (int)(fy * inl[3 * i + 1] + cy + 0.5);
+        if (xs) xs[i] = x;
+        if (ys) ys[i] = y;
+        if (x >= 0 && x < cols && y >= 0 && y < rows && depth_map) depth_map[(int64_t)x * rows + y] = inl[3 * i + 2];
+    }
+}
+
+/* rsframe.cc:771-800 */
+void rso_pose_table(const double v[3], const double w[3], double k, double gamma, int32_t rows, double* R,
+                    double* t) {
+    for (int32_t i = 0; i < rows; ++i) {
+        double beta_1 = 0.0;
+        if (i > 0)
+            beta_1 = (gamma * i / rows + 0.5 * k * (gamma * gamma * i * i) / ((double)rows * rows)) * (2.0 / (2.0 + k));
+        double* Ri = &R[(int64_t)i * 9];
+        /* I + beta_1 * skew(w) */
+        Ri[0] = 1.0 + beta_1 * 0.0;
+        Ri[1] = 0.0 + beta_1 * -w[2];
+        Ri[2] = 0.0 + beta_1 * w[1];
+        Ri[3] = 0.0 + beta_1 * w[2];
+        Ri[4] = 1.0 + beta_1 * 0.0;
+        Ri[5] = 0.0 + beta_1 * -w[0];
+        Ri[6] = 0.0 + beta_1 * -w[1];
+        Ri[7] = 0.0 + beta_1 * w[0];
+        Ri[8] = 1.0 + beta_1 * 0.0;
+        t[(int64_t)i * 3 + 0] = 0.0 + beta_1 * v[0];
+        t[(int64_t)i * 3 + 1] = 0.0 + beta_1 * v[1];
+        t[(int64_t)i * 3 + 2] = 0.0 + beta_1 * v[2];
+    }
+}

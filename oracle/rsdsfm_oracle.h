@@ -1,0 +1,138 @@
+/*
+ * rsdsfm_oracle.h -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ *
+ * Plain-C restatement of the rolling-shutter differential-SfM hot path of
+ * ThomasZiegler/RS-aware-differential-SfM (src/minimal.cc, src/nonlinearRefinement.cc and
+ * the caller-side glue).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library, and only as the checker / reported CPU baseline.
+ *
+ * PARITY UNPINNED: the reference ships no tests / golden vectors and cannot be built in this
+ * image (it needs Ceres 1.14.0, Eigen 3.3.4, OpenCV 3.4.0 and Boost 1.58, none of which are
+ * on disk).  The third-party arithmetic (Eigen JacobiSVD / eigen-solvers, Ceres
+ * trust-region LM + DENSE_SCHUR) is restated from the published algorithms of those pinned
+ * versions.  What pins this oracle instead: analytic known-answer data and an independent
+ * numpy/scipy cross-check (tests/golden/make_golden.py).
+ *
+ * Layout conventions (those of the reference boundary): all floating data fp64; a
+ * "2xN" array is N interleaved (x,y) pairs (Eigen column-major Array2Xd), a "3xN" array is
+ * N interleaved triples.
+ */
+#ifndef RSDSFM_ORACLE_H
+#define RSDSFM_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Ceres-style termination types of the emulated trust-region loop. */
+enum {
+    RSO_TERM_GRADIENT = 0,  /* CONVERGENCE: gradient max-norm <= 1e-10                    */
+    RSO_TERM_PARAMETER = 1, /* CONVERGENCE: step norm <= 1e-8 (|x| + 1e-8)                  */
+    RSO_TERM_FUNCTION = 2,  /* CONVERGENCE: |cost change| <= 1e-6 cost                      */
+    RSO_TERM_MAX_ITER = 3,  /* NO_CONVERGENCE: 50 iterations                                */
+    RSO_TERM_FAILURE = 4,   /* 5 consecutive invalid steps / linear-solver failure          */
+    RSO_TERM_MIN_RADIUS = 5 /* CONVERGENCE: trust-region radius < 1e-32                     */
+};
+
+typedef struct rso_lm_summary {
+    int32_t num_iterations;       /* index of the last iteration started (Ceres iterations.size()-1) */
+    int32_t num_successful_steps; /* accepted steps (iteration 0 not counted)               */
+    int32_t num_unsuccessful_steps;
+    int32_t termination;
+    double initial_cost;
+    double final_cost;
+    double final_radius;
+} rso_lm_summary;
+
+/* minimal.cc:179-186 */
+void rso_get_alpha(const double* flow_px2n, int64_t n, double h, double gamma, double* alpha_n);
+/* minimal.cc:188-197 */
+void rso_get_alpha_k(const double* q_px2n, const double* flow_px2n, int64_t n, double h, double gamma,
+                     double* alpha_k_n);
+
+/* minimal.cc:36-177.  k_sign_mode: 0 = compat (reference quirk Q4: eig(P*inv(Pk))), 1 = fixed (negated).
+ * returns 0, or <0 when no real eigenvalue k was found (k is left +inf in the reference). */
+int rso_calculate_velocities(const double q[18], const double u[18], const double alpha[9],
+                             const double alpha_k[9], int use_alpha_k, int k_sign_mode, double w[3],
+                             double v[3], double* k);
+
+/* nonlinearRefinement.cc:32-52 (double instantiation of RsResidual::operator()) */
+void rso_residual(double x, double y, double ux, double uy, double alpha, double alpha_k,
+                  const double v[3], const double w[3], double k, double rho, double r[2]);
+
+/* nonlinearRefinement.cc:109-180.  mode 0: exact per-pixel least-squares optimum (one undamped
+ * Gauss-Newton step from rho=1); mode 1: emulation of the Ceres 1.14 trust-region LM the reference runs. */
+int rso_estimate_inverse_depths(const double* q2n, const double* u2n, int64_t n, const double v[3],
+                                const double w[3], double k, const double* alpha_n,
+                                const double* alpha_k_n, int mode, double* inv_depth_n,
+                                rso_lm_summary* summary);
+
+/* minimal.cc:255-275: per-point residual norm, inlier flag; returns count, *err_sum = sum over inliers. */
+int64_t rso_score(const double* q2n, const double* u2n, const double* alpha_n, const double* alpha_k_n,
+                  int64_t n, const double v[3], const double w[3], double k, const double* inv_depth_n,
+                  double tol, uint8_t* mask_n, double* err_sum);
+
+/* The reference sampler (minimal.cc:226-244) with its rand() replaced by splitmix64(seed):
+ * persistent index permutation, 9 partial Fisher-Yates draws per trial. */
+void rso_sample_indices(int64_t n, int32_t trials, uint64_t seed, int32_t* samples_9xT);
+
+typedef struct rso_ransac_out {
+    int64_t num_inliers;
+    int32_t best_trial;
+    int32_t _pad;
+    double w[3], v[3], k;
+    double inlier_error;
+    int64_t* inlier_idx; /* [n] capacity, first num_inliers valid                          */
+    double* inliers;     /* [3n] (x, y, z = 1/rho)                                         */
+    double* alpha;       /* [n]                                                            */
+    double* alpha_k;     /* [n]                                                            */
+    uint8_t* mask;       /* [n]                                                            */
+    double* inv_depth;   /* [n] dense rho of the best trial                                */
+    int64_t* trial_count; /* [T] or NULL                                                   */
+    double* trial_err;    /* [T] or NULL                                                   */
+    double* trial_vel;    /* [7T] (w, v, k) or NULL                                        */
+    int32_t* trial_steps; /* [T] accepted LM steps of each trial's depth solve, or NULL     */
+} rso_ransac_out;
+
+/* minimal.cc:209-306 with injected samples (9 indices per trial). */
+int rso_ransac(const double* q2n, const double* u2n, const double* alpha_n, const double* alpha_k_n,
+               int64_t n, int use_alpha_k, int32_t iterations, double tol, const int32_t* samples_9xT,
+               int depth_mode, int k_sign_mode, rso_ransac_out* out);
+
+/* nonlinearRefinement.cc:183-252.  flow_index_mode 0 = compat (quirk Q2: flow(.,rank)), 1 = gathered
+ * (flow(., inlier_idx[rank])).  inliers_out is 3xM. */
+int rso_refine(const double* flow2n, int64_t n_flow, int64_t m, const double* inliers_3m,
+               const double* alpha_m, const double* alpha_k_m, const int64_t* inlier_idx_or_null,
+               const double v_in[3], const double w_in[3], double k_in, int const_acceleration,
+               int flow_index_mode, double* inliers_out_3m, double v_out[3], double w_out[3],
+               double* k_out, rso_lm_summary* summary);
+
+/* main.cc:398-444 / errorMeasure.cpp:66-111 (shrinking variant).  flow image row-major rows x cols x 2.
+ * returns the number of kept points. */
+int64_t rso_flatten(const double* flow_img, int32_t rows, int32_t cols, double fx, double fy, double cx,
+                    double cy, double gamma, double flow_threshold, double* q2n, double* u2n,
+                    double* q_px2n, double* flow_px2n);
+
+/* main.cc:466-478: flips z and v when mean z < 0; returns 1 if flipped. */
+int rso_canonicalize_sign(double* inliers_3m, int64_t m, double v[3]);
+
+/* main.cc:495-509: x=int(fx*qx+cx+.5), y=int(fy*qy+cy+.5), depth_map(y,x)=z (col-major rows x cols).
+ * out-of-image points are skipped (the reference would write out of bounds).  xs/ys may be NULL. */
+void rso_scatter_depth(const double* inliers_3m, int64_t m, double fx, double fy, double cx, double cy,
+                       int32_t rows, int32_t cols, double* depth_map_colmajor, int32_t* xs, int32_t* ys);
+
+/* rsframe.cc:771-800: per-scanline relative pose, R row-major [rows][9], t [rows][3]. */
+void rso_pose_table(const double v[3], const double w[3], double k, double gamma, int32_t rows,
+                    double* R_rows9, double* t_rows3);
+
+/* exposed for direct testing of the restated third-party pieces */
+void rso_jacobi_svd9(const double Z_rowmajor[81], double sv[9], double V_rowmajor[81]);
+int rso_eigvals_general(const double* A_rowmajor, int n, double* re, double* im);
+void rso_eig_sym3(const double S[9], double lam[3], double V_rowmajor[9]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

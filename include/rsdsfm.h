@@ -1,0 +1,171 @@
+/*
+ * rsdsfm.h -- C ABI of the MI355X-native rolling-shutter differential-SfM solver.
+ *
+ * Drop-in boundary for the hot path of ThomasZiegler/RS-aware-differential-SfM: every entry point
+ * replaces one free function of the reference's `minimal::` / `nonlinear_refinement::` namespaces (or
+ * one block of caller-side glue) and cites it (paths relative to the reference's src/).  The reference
+ * has no FFI layer of its own; a maintainer binds these through the header-only C++ mirror in
+ * rs-aware-differential-sfm_amd/host/ (see INTEGRATION.md).
+ *
+ * Conventions: all floating data IEEE fp64; a "2xN" array is N interleaved (x, y) pairs (Eigen
+ * column-major Array2Xd), "3xN" is N interleaved triples.  Functions return RSDSFM_OK (0) or a negative
+ * error code; rsdsfm_last_error() gives text.  A context binds one HIP device + one stream and is
+ * single-owner (one per GPU / thread).  There is NO CPU fallback: without a usable HIP device
+ * rsdsfm_create fails.
+ *
+ * Two families:
+ *   host-pointer API  (rsdsfm_xxx)      caller-owned HOST buffers, synchronous -- the reference's semantics.
+ *   device API        (rsdsfm_xxx_dev)  caller-owned DEVICE buffers (16-byte aligned), asynchronous on the
+ *                                       context's stream -- what bench.py and the multi-GPU driver use.
+ */
+#ifndef RSDSFM_H
+#define RSDSFM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSDSFM_OK 0
+#define RSDSFM_ERR_INVALID (-1)     /* bad argument (null pointer, n < 9, misaligned device pointer ...) */
+#define RSDSFM_ERR_HIP (-2)         /* HIP runtime error */
+#define RSDSFM_ERR_NO_DEVICE (-3)   /* no usable gfx950 device */
+#define RSDSFM_ERR_NUMERIC (-4)     /* solver failure (singular system, no real k, LM failure) */
+#define RSDSFM_ERR_PENDING (-5)     /* device LM state machine needs more launches (see rsdsfm_depth_finish_dev) */
+
+/* depth_mode */
+#define RSDSFM_DEPTH_CLOSED_FORM 0  /* exact per-pixel least-squares optimum (one undamped GN step from rho=1) */
+#define RSDSFM_DEPTH_CERES_LM 1     /* emulation of the Ceres 1.14 trust-region LM the reference runs (default) */
+
+/* k_sign_mode (reference quirk Q4, minimal.cc:72) */
+#define RSDSFM_K_COMPAT 0
+#define RSDSFM_K_FIXED 1
+
+/* flow_index_mode of rsdsfm_refine (reference quirk Q2, nonlinearRefinement.cc:211-212) */
+#define RSDSFM_FLOW_COMPAT_RANK 0
+#define RSDSFM_FLOW_GATHERED 1
+
+/* termination of the emulated Ceres trust-region loop */
+#define RSDSFM_TERM_GRADIENT 0
+#define RSDSFM_TERM_PARAMETER 1
+#define RSDSFM_TERM_FUNCTION 2
+#define RSDSFM_TERM_MAX_ITER 3
+#define RSDSFM_TERM_FAILURE 4
+#define RSDSFM_TERM_MIN_RADIUS 5
+
+typedef struct rsdsfm_ctx rsdsfm_ctx;
+
+typedef struct rsdsfm_lm_summary {
+    int32_t num_iterations;
+    int32_t num_successful_steps;
+    int32_t num_unsuccessful_steps;
+    int32_t termination;
+    double initial_cost;
+    double final_cost;
+    double final_radius;
+} rsdsfm_lm_summary;
+
+/* replaces RansacValues (minimal.h:57-76) + the extras SURVEY Q2 asks for.  Arrays are caller-owned with
+ * capacity n (HOST pointers for rsdsfm_ransac, DEVICE pointers for rsdsfm_ransac_dev); NULL = not wanted
+ * (inliers/alpha/alpha_k/inlier_idx/mask/inv_depth may each be NULL). */
+typedef struct rsdsfm_ransac_out {
+    int64_t num_inliers;
+    int32_t best_trial;
+    int32_t _pad;
+    double w[3], v[3], k;
+    double inlier_error;
+    int64_t* inlier_idx; /* [n]  index of each inlier in the input arrays                       */
+    double* inliers;     /* [3n] (x, y, z = 1/rho)                                               */
+    double* alpha;       /* [n]                                                                  */
+    double* alpha_k;     /* [n]                                                                  */
+    uint8_t* mask;       /* [n]                                                                  */
+    double* inv_depth;   /* [n]  dense rho of the best trial                                     */
+    int64_t* trial_count; /* [T] HOST, or NULL                                                   */
+    double* trial_err;    /* [T] HOST, or NULL                                                   */
+    double* trial_vel;    /* [7T] HOST (w, v, k), or NULL                                        */
+    int32_t* trial_steps; /* [T] HOST accepted LM steps of each trial's depth solve, or NULL      */
+} rsdsfm_ransac_out;
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* context                                                                                                */
+/* ---------------------------------------------------------------------------------------------------- */
+/* stream_or_null: a hipStream_t to adopt (e.g. torch.cuda.current_stream().cuda_stream) or NULL = own stream */
+int rsdsfm_create(rsdsfm_ctx** ctx, int device, void* stream_or_null);
+void rsdsfm_destroy(rsdsfm_ctx* ctx);
+const char* rsdsfm_last_error(const rsdsfm_ctx* ctx);
+const char* rsdsfm_version(void);
+int rsdsfm_synchronize(rsdsfm_ctx* ctx);
+/* name of the HIP kernel that dominates the given entry point (for profiling / roofline reports) */
+const char* rsdsfm_kernel_name(const char* entry_point);
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* host-pointer API -- one per reference function                                                         */
+/* ---------------------------------------------------------------------------------------------------- */
+/* minimal::getAlpha  minimal.cc:179-186 */
+int rsdsfm_get_alpha(rsdsfm_ctx* ctx, const double* flow_px2n, int64_t n, double h, double gamma, double* alpha_n);
+/* minimal::getAlphaK  minimal.cc:188-197 */
+int rsdsfm_get_alpha_k(rsdsfm_ctx* ctx, const double* q_px2n, const double* flow_px2n, int64_t n, double h,
+                       double gamma, double* alpha_k_n);
+/* minimal::calculateVelocities  minimal.cc:36-177  (batch of `count` 9-point hypotheses, one lane each) */
+int rsdsfm_calculate_velocities(rsdsfm_ctx* ctx, const double* q_18xT, const double* u_18xT,
+                                const double* alpha_9xT, const double* alpha_k_9xT, int32_t count,
+                                int use_alpha_k, int k_sign_mode, double* w_3xT, double* v_3xT, double* k_T);
+/* nonlinear_refinement::estimateInverseDepths  nonlinearRefinement.cc:109-180
+ * (and estimateInverseDepth :55-106 with n = 1) */
+int rsdsfm_estimate_inverse_depths(rsdsfm_ctx* ctx, const double* q2n, const double* u2n, int64_t n,
+                                   const double v[3], const double w[3], double k, const double* alpha_n,
+                                   const double* alpha_k_n, int depth_mode, double* inv_depth_n,
+                                   rsdsfm_lm_summary* summary_or_null);
+/* minimal::ransac  minimal.cc:209-306.  samples_9xT: injected 9-index samples (int32, T*9) or NULL = the
+ * reference's partial Fisher-Yates sampler driven by splitmix64(seed) instead of srand(time)/rand(). */
+int rsdsfm_ransac(rsdsfm_ctx* ctx, const double* q2n, const double* u2n, const double* alpha_n,
+                  const double* alpha_k_n, int64_t n, int use_alpha_k, int32_t iterations, double tolerance,
+                  const int32_t* samples_9xT_or_null, uint64_t seed, int depth_mode, int k_sign_mode,
+                  rsdsfm_ransac_out* out);
+/* nonlinear_refinement::nonLinearRefinement  nonlinearRefinement.cc:183-252.  inliers in/out are 3xM. */
+int rsdsfm_refine(rsdsfm_ctx* ctx, const double* flow2n, int64_t n_flow, int64_t m, const double* inliers_3m,
+                  const double* alpha_m, const double* alpha_k_m, const int64_t* inlier_idx_or_null,
+                  const double v_in[3], const double w_in[3], double k_in, int const_acceleration,
+                  int flow_index_mode, double* inliers_out_3m, double v_out[3], double w_out[3], double* k_out,
+                  rsdsfm_lm_summary* summary_or_null);
+/* caller glue main.cc:398-444 / errorMeasure.cpp:66-111: column-major scan of the row-major flow image,
+ * threshold, normalisation, alpha / alpha_k.  Outputs have capacity rows*cols; *n_out = kept points. */
+int rsdsfm_flatten(rsdsfm_ctx* ctx, const double* flow_img_rows_cols_2, int32_t rows, int32_t cols, double fx,
+                   double fy, double cx, double cy, double gamma, double flow_threshold, double* q2n,
+                   double* u2n, double* alpha_n, double* alpha_k_n, int64_t* n_out);
+/* caller glue main.cc:466-509: mean-z sign flip of (z, v), then depth_map(y, x) = z with
+ * x = int(fx*qx+cx+.5), y = int(fy*qy+cy+.5); depth_map is rows x cols column-major (Eigen MatrixXd) and
+ * is zero-filled first.  xs/ys (int32[m], the scanline index is ys) may be NULL.  *flipped may be NULL. */
+int rsdsfm_depth_map(rsdsfm_ctx* ctx, double* inliers_3m_inout, int64_t m, double v_inout[3], double fx,
+                     double fy, double cx, double cy, int32_t rows, int32_t cols,
+                     double* depth_map_colmajor, int32_t* xs_or_null, int32_t* ys_or_null, int* flipped);
+/* RsFrame::setRelativePose  rsframe.cc:771-800: per-scanline R (row-major 3x3) and t */
+int rsdsfm_pose_table(rsdsfm_ctx* ctx, const double v[3], const double w[3], double k, double gamma,
+                      int32_t rows, double* R_rows9, double* t_rows3);
+
+/* ---------------------------------------------------------------------------------------------------- */
+/* device API (asynchronous on the context's stream; pointers are DEVICE memory, 16-byte aligned)          */
+/* ---------------------------------------------------------------------------------------------------- */
+/* estimateInverseDepths on device-resident inputs.  Enqueues the fixed fast-path launch sequence (two
+ * launches of the fused LM kernel in RSDSFM_DEPTH_CERES_LM mode) and returns without synchronising. */
+int rsdsfm_estimate_inverse_depths_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n, int64_t n,
+                                       const double v[3], const double w[3], double k, const double* d_alpha_n,
+                                       const double* d_alpha_k_n, int depth_mode, double* d_inv_depth_n);
+/* One launch of the fused LM kernel (building block of the two calls around it; also what bench.py brackets
+ * with HIP events to time the dominant kernel).  first != 0: the launch of LM iteration zero (fresh state). */
+int rsdsfm_depth_lm_launch_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n, int64_t n,
+                               const double v[3], const double w[3], double k, const double* d_alpha_n,
+                               const double* d_alpha_k_n, double* d_inv_depth_n, int first);
+/* Synchronises, drives the device LM state machine to completion if the fast path did not finish it
+ * (rare: more than 4 LM iterations or a rejected step) and returns the summary.  Returns the number of
+ * EXTRA launches that were needed in *extra_launches (may be NULL). */
+int rsdsfm_depth_finish_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n, int64_t n,
+                            const double v[3], const double w[3], double k, const double* d_alpha_n,
+                            const double* d_alpha_k_n, double* d_inv_depth_n, rsdsfm_lm_summary* summary_or_null,
+                            int32_t* extra_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSDSFM_H */

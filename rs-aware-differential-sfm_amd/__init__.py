@@ -1,0 +1,270 @@
+"""rsdsfm -- MI355X-native rolling-shutter differential-SfM solver (Python binding of the C ABI).
+
+The package directory is `rs-aware-differential-sfm_amd/`; import it through the repo-root shim
+`import rsdsfm`.  Everything here goes through include/rsdsfm.h (ctypes, plain pointers and sizes): the HIP
+library `librsdsfm_hip.so` IS the product.  There is no CPU fallback: if the library is missing or no
+gfx950 device is usable, loading / Solver() raises.
+
+Mirrors the reference's function boundary (reference: src/minimal.h:79-161, src/nonlinearRefinement.h:37-113):
+    Solver.get_alpha / get_alpha_k / calculate_velocities / ransac
+    Solver.estimate_inverse_depths / non_linear_refinement
+    Solver.flatten / depth_map / pose_table            (caller glue, rsframe.cc:771-800)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import synth  # noqa: F401  (analytic data generator used by tests and bench)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librsdsfm_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rsdsfm.h")
+
+OK = 0
+ERR_PENDING = -5
+DEPTH_CLOSED_FORM, DEPTH_CERES_LM = 0, 1
+K_COMPAT, K_FIXED = 0, 1
+FLOW_COMPAT_RANK, FLOW_GATHERED = 0, 1
+TERMINATION = {0: "gradient", 1: "parameter", 2: "function", 3: "max_iter", 4: "failure", 5: "min_radius"}
+
+_lib = None
+
+
+class RsdsfmError(RuntimeError):
+    pass
+
+
+class LmSummary(C.Structure):
+    _fields_ = [
+        ("num_iterations", C.c_int32),
+        ("num_successful_steps", C.c_int32),
+        ("num_unsuccessful_steps", C.c_int32),
+        ("termination", C.c_int32),
+        ("initial_cost", C.c_double),
+        ("final_cost", C.c_double),
+        ("final_radius", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class RansacOut(C.Structure):
+    _fields_ = [
+        ("num_inliers", C.c_int64),
+        ("best_trial", C.c_int32),
+        ("_pad", C.c_int32),
+        ("w", C.c_double * 3),
+        ("v", C.c_double * 3),
+        ("k", C.c_double),
+        ("inlier_error", C.c_double),
+        ("inlier_idx", C.c_void_p),
+        ("inliers", C.c_void_p),
+        ("alpha", C.c_void_p),
+        ("alpha_k", C.c_void_p),
+        ("mask", C.c_void_p),
+        ("inv_depth", C.c_void_p),
+        ("trial_count", C.c_void_p),
+        ("trial_err", C.c_void_p),
+        ("trial_vel", C.c_void_p),
+        ("trial_steps", C.c_void_p),
+    ]
+
+
+def declared_symbols():
+    """Names of every function include/rsdsfm.h declares (used by the CPU symbol-export test)."""
+    import re
+
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(rsdsfm_[a-z0-9_]+)\s*\(", txt)))
+
+
+def load_library(build_if_missing=True):
+    """Loads librsdsfm_hip.so (building it with hipcc when it is absent and hipcc exists).  Raises otherwise."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if not build_if_missing:
+            raise RsdsfmError("HIP extension %s is missing (run: python rs-aware-differential-sfm_amd/build.py)" % LIB_PATH)
+        from . import build as _build
+
+        _build.build()
+    lib = C.CDLL(LIB_PATH)
+    lib.rsdsfm_version.restype = C.c_char_p
+    lib.rsdsfm_last_error.restype = C.c_char_p
+    lib.rsdsfm_last_error.argtypes = [C.c_void_p]
+    lib.rsdsfm_kernel_name.restype = C.c_char_p
+    lib.rsdsfm_kernel_name.argtypes = [C.c_char_p]
+    lib.rsdsfm_destroy.restype = None
+    lib.rsdsfm_destroy.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _v3(a):
+    return (C.c_double * 3)(*[float(x) for x in a])
+
+
+def _dp(ptr):
+    """device pointer (int / torch data_ptr) -> c_void_p"""
+    return C.c_void_p(int(ptr))
+
+
+class Solver:
+    """One context = one HIP device + one stream (single owner).  `stream`: a raw hipStream_t handle to adopt,
+    e.g. torch.cuda.current_stream().cuda_stream, or None for a private stream."""
+
+    def __init__(self, device=0, stream=None):
+        self.lib = load_library()
+        self._ctx = C.c_void_p()
+        rc = self.lib.rsdsfm_create(C.byref(self._ctx), int(device), C.c_void_p(stream) if stream else None)
+        if rc != OK:
+            self._ctx = None
+            raise RsdsfmError("rsdsfm_create(device=%d) failed with %d (no usable gfx950 device? there is no CPU fallback)" % (device, rc))
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self.lib.rsdsfm_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc, what):
+        if rc != OK:
+            msg = self.lib.rsdsfm_last_error(self._ctx)
+            raise RsdsfmError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+    def synchronize(self):
+        self._check(self.lib.rsdsfm_synchronize(self._ctx), "rsdsfm_synchronize")
+
+    # ---- minimal:: ----
+    def get_alpha(self, flow_px, h, gamma):
+        flow_px = _f64(flow_px)
+        n = flow_px.shape[0]
+        out = np.empty(n)
+        self._check(self.lib.rsdsfm_get_alpha(self._ctx, _p(flow_px), C.c_int64(n), C.c_double(h), C.c_double(gamma), _p(out)), "rsdsfm_get_alpha")
+        return out
+
+    def get_alpha_k(self, q_px, flow_px, h, gamma):
+        q_px, flow_px = _f64(q_px), _f64(flow_px)
+        n = flow_px.shape[0]
+        out = np.empty(n)
+        self._check(self.lib.rsdsfm_get_alpha_k(self._ctx, _p(q_px), _p(flow_px), C.c_int64(n), C.c_double(h), C.c_double(gamma), _p(out)), "rsdsfm_get_alpha_k")
+        return out
+
+    def calculate_velocities(self, q, u, alpha, alpha_k, use_alpha_k=False, k_sign_mode=K_COMPAT):
+        """q, u: (T, 9, 2) or (9, 2); alpha, alpha_k: (T, 9) or (9,).  Returns w (T,3), v (T,3), k (T,)."""
+        q, u, alpha, alpha_k = _f64(q), _f64(u), _f64(alpha), _f64(alpha_k)
+        single = q.ndim == 2
+        T = 1 if single else q.shape[0]
+        w, v, k = np.empty((T, 3)), np.empty((T, 3)), np.empty(T)
+        self._check(self.lib.rsdsfm_calculate_velocities(self._ctx, _p(q), _p(u), _p(alpha), _p(alpha_k), C.c_int32(T), int(use_alpha_k), int(k_sign_mode), _p(w), _p(v), _p(k)), "rsdsfm_calculate_velocities")
+        return (w[0], v[0], float(k[0])) if single else (w, v, k)
+
+    def ransac(self, q, u, alpha, alpha_k, use_alpha_k, iterations, tolerance, samples=None, seed=0, depth_mode=DEPTH_CERES_LM, k_sign_mode=K_COMPAT):
+        q, u, alpha, alpha_k = _f64(q), _f64(u), _f64(alpha), _f64(alpha_k)
+        n, T = q.shape[0], int(iterations)
+        smp = None if samples is None else np.ascontiguousarray(samples, dtype=np.int32).reshape(-1)
+        bufs = dict(
+            inlier_idx=np.zeros(n, dtype=np.int64), inliers=np.zeros((n, 3)), alpha=np.zeros(n), alpha_k=np.zeros(n),
+            mask=np.zeros(n, dtype=np.uint8), inv_depth=np.zeros(n), trial_count=np.zeros(max(T, 1), dtype=np.int64),
+            trial_err=np.zeros(max(T, 1)), trial_vel=np.zeros((max(T, 1), 7)), trial_steps=np.zeros(max(T, 1), dtype=np.int32),
+        )
+        out = RansacOut()
+        for name, arr in bufs.items():
+            setattr(out, name, arr.ctypes.data)
+        self._check(self.lib.rsdsfm_ransac(self._ctx, _p(q), _p(u), _p(alpha), _p(alpha_k), C.c_int64(n), int(use_alpha_k), C.c_int32(T), C.c_double(tolerance), _p(smp), C.c_uint64(seed), int(depth_mode), int(k_sign_mode), C.byref(out)), "rsdsfm_ransac")
+        m = int(out.num_inliers)
+        return dict(
+            num_inliers=m, best_trial=int(out.best_trial), w=np.array(out.w[:]), v=np.array(out.v[:]), k=float(out.k),
+            inlier_error=float(out.inlier_error), inlier_idx=bufs["inlier_idx"][:m].copy(), inliers=bufs["inliers"][:m].copy(),
+            alpha=bufs["alpha"][:m].copy(), alpha_k=bufs["alpha_k"][:m].copy(), mask=bufs["mask"], inv_depth=bufs["inv_depth"],
+            trial_count=bufs["trial_count"][:T], trial_err=bufs["trial_err"][:T], trial_vel=bufs["trial_vel"][:T],
+            trial_steps=bufs["trial_steps"][:T],
+        )
+
+    # ---- nonlinear_refinement:: ----
+    def estimate_inverse_depths(self, q, u, v, w, k, alpha, alpha_k, mode=DEPTH_CERES_LM):
+        q, u, alpha, alpha_k = _f64(q), _f64(u), _f64(alpha), _f64(alpha_k)
+        n = q.shape[0]
+        rho = np.empty(n)
+        sm = LmSummary()
+        self._check(self.lib.rsdsfm_estimate_inverse_depths(self._ctx, _p(q), _p(u), C.c_int64(n), _v3(v), _v3(w), C.c_double(k), _p(alpha), _p(alpha_k), int(mode), _p(rho), C.byref(sm)), "rsdsfm_estimate_inverse_depths")
+        return rho, sm.as_dict()
+
+    def estimate_inverse_depth(self, q, v, w, flow, k, alpha, alpha_k, mode=DEPTH_CERES_LM):
+        """single-pixel variant (nonlinearRefinement.cc:55-106)"""
+        rho, _ = self.estimate_inverse_depths(np.asarray(q).reshape(1, 2), np.asarray(flow).reshape(1, 2), v, w, k, [alpha], [alpha_k], mode)
+        return float(rho[0])
+
+    def non_linear_refinement(self, flow, inliers, alpha, alpha_k, v, w, k, const_acceleration=False, flow_index_mode=FLOW_COMPAT_RANK, inlier_idx=None):
+        flow, inliers, alpha, alpha_k = _f64(flow), _f64(inliers), _f64(alpha), _f64(alpha_k)
+        m = inliers.shape[0]
+        idx = None if inlier_idx is None else np.ascontiguousarray(inlier_idx, dtype=np.int64)
+        out = np.empty((m, 3))
+        vo, wo, ko = (C.c_double * 3)(), (C.c_double * 3)(), C.c_double()
+        sm = LmSummary()
+        self._check(self.lib.rsdsfm_refine(self._ctx, _p(flow), C.c_int64(flow.shape[0]), C.c_int64(m), _p(inliers), _p(alpha), _p(alpha_k), _p(idx), _v3(v), _v3(w), C.c_double(k), int(const_acceleration), int(flow_index_mode), _p(out), vo, wo, C.byref(ko), C.byref(sm)), "rsdsfm_refine")
+        return dict(inliers=out, v=np.array(vo[:]), w=np.array(wo[:]), k=ko.value, summary=sm.as_dict())
+
+    # ---- caller glue ----
+    def flatten(self, flow_img, K, gamma, thr=1e-10):
+        flow_img = _f64(flow_img)
+        rows, cols = flow_img.shape[:2]
+        n = rows * cols
+        q, u, a, ak = np.empty((n, 2)), np.empty((n, 2)), np.empty(n), np.empty(n)
+        cnt = C.c_int64()
+        d = C.c_double
+        self._check(self.lib.rsdsfm_flatten(self._ctx, _p(flow_img), C.c_int32(rows), C.c_int32(cols), d(K[0]), d(K[1]), d(K[2]), d(K[3]), d(gamma), d(thr), _p(q), _p(u), _p(a), _p(ak), C.byref(cnt)), "rsdsfm_flatten")
+        m = cnt.value
+        return q[:m].copy(), u[:m].copy(), a[:m].copy(), ak[:m].copy()
+
+    def depth_map(self, inliers, v, K, rows, cols):
+        inl = _f64(inliers).copy()
+        m = inl.shape[0]
+        vv = _v3(v)
+        dm = np.zeros((cols, rows))
+        xs, ys = np.empty(m, dtype=np.int32), np.empty(m, dtype=np.int32)
+        flipped = C.c_int()
+        d = C.c_double
+        self._check(self.lib.rsdsfm_depth_map(self._ctx, _p(inl), C.c_int64(m), vv, d(K[0]), d(K[1]), d(K[2]), d(K[3]), C.c_int32(rows), C.c_int32(cols), _p(dm), _p(xs), _p(ys), C.byref(flipped)), "rsdsfm_depth_map")
+        return dict(depth_map=dm.T.copy(), inliers=inl, v=np.array(vv[:]), xs=xs, ys=ys, flipped=bool(flipped.value))
+
+    def pose_table(self, v, w, k, gamma, rows):
+        R, t = np.empty((rows, 9)), np.empty((rows, 3))
+        self._check(self.lib.rsdsfm_pose_table(self._ctx, _v3(v), _v3(w), C.c_double(k), C.c_double(gamma), C.c_int32(rows), _p(R), _p(t)), "rsdsfm_pose_table")
+        return R.reshape(rows, 3, 3), t
+
+    # ---- device API (raw device pointers, asynchronous) ----
+    def estimate_inverse_depths_dev(self, d_q, d_u, n, v, w, k, d_alpha, d_alpha_k, d_rho, mode=DEPTH_CERES_LM):
+        self._check(self.lib.rsdsfm_estimate_inverse_depths_dev(self._ctx, _dp(d_q), _dp(d_u), C.c_int64(n), _v3(v), _v3(w), C.c_double(k), _dp(d_alpha), _dp(d_alpha_k), int(mode), _dp(d_rho)), "rsdsfm_estimate_inverse_depths_dev")
+
+    def depth_lm_launch_dev(self, d_q, d_u, n, v, w, k, d_alpha, d_alpha_k, d_rho, first=True):
+        self._check(self.lib.rsdsfm_depth_lm_launch_dev(self._ctx, _dp(d_q), _dp(d_u), C.c_int64(n), _v3(v), _v3(w), C.c_double(k), _dp(d_alpha), _dp(d_alpha_k), _dp(d_rho), int(bool(first))), "rsdsfm_depth_lm_launch_dev")
+
+    def depth_finish_dev(self, d_q, d_u, n, v, w, k, d_alpha, d_alpha_k, d_rho):
+        sm = LmSummary()
+        extra = C.c_int32()
+        self._check(self.lib.rsdsfm_depth_finish_dev(self._ctx, _dp(d_q), _dp(d_u), C.c_int64(n), _v3(v), _v3(w), C.c_double(k), _dp(d_alpha), _dp(d_alpha_k), _dp(d_rho), C.byref(sm), C.byref(extra)), "rsdsfm_depth_finish_dev")
+        return sm.as_dict(), extra.value

@@ -1,0 +1,304 @@
+// capi.hip -- extern "C" entry points of librsdsfm_hip.so (see include/rsdsfm.h).
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "rsdsfm_internal.hpp"
+
+namespace rsdsfm {
+
+int fail(Ctx* c, int code, const char* msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+int ensure_stage(Ctx* c, size_t bytes) {
+    if (bytes <= c->stage_bytes) return RSDSFM_OK;
+    if (c->d_stage) RSDSFM_HIP_CHECK(c, hipFree(c->d_stage));
+    c->d_stage = nullptr;
+    c->stage_bytes = 0;
+    size_t want = std::max(bytes, (size_t)1 << 20);
+    RSDSFM_HIP_CHECK(c, hipMalloc(&c->d_stage, want));
+    c->stage_bytes = want;
+    return RSDSFM_OK;
+}
+
+// bump allocator over the staging buffer (256-byte aligned slices)
+struct StageAlloc {
+    char* base;
+    size_t off = 0;
+    explicit StageAlloc(void* b) : base(static_cast<char*>(b)) {}
+    template <class T>
+    T* take(size_t count) {
+        T* p = reinterpret_cast<T*>(base + off);
+        off += (count * sizeof(T) + 255) & ~(size_t)255;
+        return p;
+    }
+    static size_t need(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+};
+
+static void fill_summary(const LmState& st, rsdsfm_lm_summary* s) {
+    if (!s) return;
+    s->num_iterations = st.iteration;
+    s->num_successful_steps = st.num_successful;
+    s->num_unsuccessful_steps = st.num_unsuccessful;
+    s->termination = st.termination;
+    s->initial_cost = st.initial_cost;
+    s->final_cost = st.cost;
+    s->final_radius = st.radius;
+}
+
+static int read_lm_state(Ctx* c) {
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(c->h_lm, c->d_lm, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return RSDSFM_OK;
+}
+
+}  // namespace rsdsfm
+
+using namespace rsdsfm;
+
+struct rsdsfm_ctx {
+    Ctx c;
+};
+
+#define CTX_OR_FAIL(ctx)                  \
+    if (!(ctx)) return RSDSFM_ERR_INVALID; \
+    Ctx* c = &(ctx)->c;                    \
+    (void)c
+
+extern "C" {
+
+const char* rsdsfm_version(void) { return "rsdsfm-mi355x 0.1.0 (gfx950, fp64, -ffp-contract=off)"; }
+
+int rsdsfm_create(rsdsfm_ctx** out, int device, void* stream_or_null) {
+    if (!out) return RSDSFM_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RSDSFM_ERR_NO_DEVICE;
+    if (device < 0 || device >= count) return RSDSFM_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return RSDSFM_ERR_HIP;
+    rsdsfm_ctx* ctx = new (std::nothrow) rsdsfm_ctx();
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
+    if (stream_or_null) {
+        c->stream = static_cast<hipStream_t>(stream_or_null);
+        c->own_stream = false;
+    } else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return RSDSFM_ERR_HIP;
+        }
+        c->own_stream = true;
+    }
+    bool ok = hipMalloc(&c->d_partials, sizeof(double) * 2048 * 64) == hipSuccess &&
+              hipMalloc(&c->d_tickets, sizeof(unsigned) * 16) == hipSuccess &&
+              hipMalloc(&c->d_lm, sizeof(LmState)) == hipSuccess &&
+              hipHostMalloc(reinterpret_cast<void**>(&c->h_lm), sizeof(LmState), hipHostMallocDefault) == hipSuccess &&
+              hipMemset(c->d_tickets, 0, sizeof(unsigned) * 16) == hipSuccess &&
+              hipMemset(c->d_lm, 0, sizeof(LmState)) == hipSuccess;
+    if (!ok) {
+        rsdsfm_destroy(ctx);
+        return RSDSFM_ERR_HIP;
+    }
+    *out = ctx;
+    return RSDSFM_OK;
+}
+
+void rsdsfm_destroy(rsdsfm_ctx* ctx) {
+    if (!ctx) return;
+    Ctx* c = &ctx->c;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_partials) (void)hipFree(c->d_partials);
+    if (c->d_tickets) (void)hipFree(c->d_tickets);
+    if (c->d_lm) (void)hipFree(c->d_lm);
+    if (c->h_lm) (void)hipHostFree(c->h_lm);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete ctx;
+}
+
+const char* rsdsfm_last_error(const rsdsfm_ctx* ctx) { return ctx ? ctx->c.err.c_str() : "null context"; }
+
+int rsdsfm_synchronize(rsdsfm_ctx* ctx) {
+    CTX_OR_FAIL(ctx);
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return RSDSFM_OK;
+}
+
+const char* rsdsfm_kernel_name(const char* entry_point) {
+    if (!entry_point) return "";
+    if (!strcmp(entry_point, "estimate_inverse_depths_lm")) return "depth_lm_kernel";
+    if (!strcmp(entry_point, "estimate_inverse_depths_closed_form")) return "depth_closed_form_kernel";
+    return "";
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dense depth solve
+// ---------------------------------------------------------------------------------------------------
+int rsdsfm_estimate_inverse_depths_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_u, int64_t n,
+                                       const double v[3], const double w[3], double k, const double* d_alpha,
+                                       const double* d_alpha_k, int depth_mode, double* d_rho) {
+    CTX_OR_FAIL(ctx);
+    if (n < 0 || !v || !w) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    if (n > 0 && (!d_q || !d_u || !d_alpha || !d_alpha_k || !d_rho)) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
+    Pose pose;
+    memcpy(pose.v, v, sizeof(pose.v));
+    memcpy(pose.w, w, sizeof(pose.w));
+    pose.k = k;
+    if (depth_mode == RSDSFM_DEPTH_CLOSED_FORM) return depth_closed_form_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho);
+    if (depth_mode != RSDSFM_DEPTH_CERES_LM) return fail(c, RSDSFM_ERR_INVALID, "unknown depth_mode");
+    int rc = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 1);
+    if (rc != RSDSFM_OK) return rc;
+    return depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 0);
+}
+
+int rsdsfm_depth_lm_launch_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_u, int64_t n, const double v[3],
+                               const double w[3], double k, const double* d_alpha, const double* d_alpha_k,
+                               double* d_rho, int first) {
+    CTX_OR_FAIL(ctx);
+    if (n < 0 || !v || !w) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    if (n > 0 && (!d_q || !d_u || !d_alpha || !d_alpha_k || !d_rho)) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
+    Pose pose;
+    memcpy(pose.v, v, sizeof(pose.v));
+    memcpy(pose.w, w, sizeof(pose.w));
+    pose.k = k;
+    return depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, first ? 1 : 0);
+}
+
+int rsdsfm_depth_finish_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_u, int64_t n, const double v[3],
+                            const double w[3], double k, const double* d_alpha, const double* d_alpha_k,
+                            double* d_rho, rsdsfm_lm_summary* summary, int32_t* extra_launches) {
+    CTX_OR_FAIL(ctx);
+    if (!v || !w) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    Pose pose;
+    memcpy(pose.v, v, sizeof(pose.v));
+    memcpy(pose.w, w, sizeof(pose.w));
+    pose.k = k;
+    int extra = 0;
+    int rc = read_lm_state(c);
+    if (rc != RSDSFM_OK) return rc;
+    while (c->h_lm->status != 1) {
+        if (extra > 2 * kMaxIter + 8) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machine did not terminate");
+        rc = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 0);
+        if (rc != RSDSFM_OK) return rc;
+        ++extra;
+        rc = read_lm_state(c);
+        if (rc != RSDSFM_OK) return rc;
+    }
+    fill_summary(*c->h_lm, summary);
+    if (extra_launches) *extra_launches = extra;
+    if (c->h_lm->termination == RSDSFM_TERM_FAILURE) return fail(c, RSDSFM_ERR_NUMERIC, "LM failure (5 consecutive invalid steps)");
+    return RSDSFM_OK;
+}
+
+int rsdsfm_estimate_inverse_depths(rsdsfm_ctx* ctx, const double* q, const double* u, int64_t n, const double v[3],
+                                   const double w[3], double k, const double* alpha, const double* alpha_k,
+                                   int depth_mode, double* inv_depth, rsdsfm_lm_summary* summary) {
+    CTX_OR_FAIL(ctx);
+    if (n < 0 || !v || !w) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    if (n > 0 && (!q || !u || !alpha || !alpha_k || !inv_depth)) return fail(c, RSDSFM_ERR_INVALID, "null pointer");
+    const size_t N = (size_t)n;
+    int rc = ensure_stage(c, 2 * StageAlloc::need(16 * N) + 3 * StageAlloc::need(8 * N) + 1024);
+    if (rc != RSDSFM_OK) return rc;
+    StageAlloc sa(c->d_stage);
+    double* d_q = sa.take<double>(2 * N);
+    double* d_u = sa.take<double>(2 * N);
+    double* d_a = sa.take<double>(N);
+    double* d_ak = sa.take<double>(N);
+    double* d_rho = sa.take<double>(N);
+    if (n > 0) {
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_q, q, 16 * N, hipMemcpyHostToDevice, c->stream));
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_u, u, 16 * N, hipMemcpyHostToDevice, c->stream));
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_a, alpha, 8 * N, hipMemcpyHostToDevice, c->stream));
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_ak, alpha_k, 8 * N, hipMemcpyHostToDevice, c->stream));
+    }
+    rc = rsdsfm_estimate_inverse_depths_dev(ctx, d_q, d_u, n, v, w, k, d_a, d_ak, depth_mode, d_rho);
+    if (rc != RSDSFM_OK) return rc;
+    if (depth_mode == RSDSFM_DEPTH_CERES_LM) {
+        rc = rsdsfm_depth_finish_dev(ctx, d_q, d_u, n, v, w, k, d_a, d_ak, d_rho, summary, nullptr);
+        if (rc != RSDSFM_OK) return rc;
+    } else if (summary) {
+        memset(summary, 0, sizeof(*summary));
+        summary->num_iterations = 1;
+        summary->num_successful_steps = 1;
+        summary->termination = RSDSFM_TERM_GRADIENT;
+    }
+    if (n > 0) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(inv_depth, d_rho, 8 * N, hipMemcpyDeviceToHost, c->stream));
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return RSDSFM_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// RS scale factors, pose table
+// ---------------------------------------------------------------------------------------------------
+int rsdsfm_get_alpha(rsdsfm_ctx* ctx, const double* flow_px, int64_t n, double h, double gamma, double* alpha) {
+    CTX_OR_FAIL(ctx);
+    if (n < 0 || (n > 0 && (!flow_px || !alpha))) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    const size_t N = (size_t)n;
+    int rc = ensure_stage(c, StageAlloc::need(16 * N) + StageAlloc::need(8 * N));
+    if (rc != RSDSFM_OK) return rc;
+    StageAlloc sa(c->d_stage);
+    double* d_f = sa.take<double>(2 * N);
+    double* d_a = sa.take<double>(N);
+    if (n == 0) return RSDSFM_OK;
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_f, flow_px, 16 * N, hipMemcpyHostToDevice, c->stream));
+    rc = alpha_launch(c, d_f, n, h, gamma, d_a);
+    if (rc != RSDSFM_OK) return rc;
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(alpha, d_a, 8 * N, hipMemcpyDeviceToHost, c->stream));
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return RSDSFM_OK;
+}
+
+int rsdsfm_get_alpha_k(rsdsfm_ctx* ctx, const double* q_px, const double* flow_px, int64_t n, double h, double gamma,
+                       double* alpha_k) {
+    CTX_OR_FAIL(ctx);
+    if (n < 0 || (n > 0 && (!q_px || !flow_px || !alpha_k))) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    const size_t N = (size_t)n;
+    int rc = ensure_stage(c, 2 * StageAlloc::need(16 * N) + StageAlloc::need(8 * N));
+    if (rc != RSDSFM_OK) return rc;
+    StageAlloc sa(c->d_stage);
+    double* d_q = sa.take<double>(2 * N);
+    double* d_f = sa.take<double>(2 * N);
+    double* d_a = sa.take<double>(N);
+    if (n == 0) return RSDSFM_OK;
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_q, q_px, 16 * N, hipMemcpyHostToDevice, c->stream));
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_f, flow_px, 16 * N, hipMemcpyHostToDevice, c->stream));
+    rc = alpha_k_launch(c, d_q, d_f, n, h, gamma, d_a);
+    if (rc != RSDSFM_OK) return rc;
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(alpha_k, d_a, 8 * N, hipMemcpyDeviceToHost, c->stream));
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return RSDSFM_OK;
+}
+
+int rsdsfm_pose_table(rsdsfm_ctx* ctx, const double v[3], const double w[3], double k, double gamma, int32_t rows,
+                      double* R, double* t) {
+    CTX_OR_FAIL(ctx);
+    if (rows < 0 || !v || !w || (rows > 0 && (!R || !t))) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    if (rows == 0) return RSDSFM_OK;
+    Pose pose;
+    memcpy(pose.v, v, sizeof(pose.v));
+    memcpy(pose.w, w, sizeof(pose.w));
+    pose.k = k;
+    const size_t Rr = (size_t)rows;
+    int rc = ensure_stage(c, StageAlloc::need(72 * Rr) + StageAlloc::need(24 * Rr));
+    if (rc != RSDSFM_OK) return rc;
+    StageAlloc sa(c->d_stage);
+    double* d_R = sa.take<double>(9 * Rr);
+    double* d_t = sa.take<double>(3 * Rr);
+    rc = pose_table_launch(c, pose, gamma, rows, d_R, d_t);
+    if (rc != RSDSFM_OK) return rc;
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(R, d_R, 72 * Rr, hipMemcpyDeviceToHost, c->stream));
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(t, d_t, 24 * Rr, hipMemcpyDeviceToHost, c->stream));
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return RSDSFM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,108 @@
+// rsdsfm_internal.hpp -- shared definitions of the MI355X (gfx950) solver library.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/rsdsfm.h"
+
+namespace rsdsfm {
+
+// ---------------------------------------------------------------------------------------------------
+// Ceres 1.14 Solver::Options defaults used by every solve in nonlinearRefinement.cc (the reference
+// only sets linear_solver_type = DENSE_SCHUR, nonlinearRefinement.cc:160-161, :225-226)
+// ---------------------------------------------------------------------------------------------------
+constexpr int kMaxIter = 50;
+constexpr double kInitialRadius = 1e4;
+constexpr double kMaxRadius = 1e16;
+constexpr double kMinRadius = 1e-32;
+constexpr double kMinRelDecrease = 1e-3;
+constexpr double kMinLmDiag = 1e-6;
+constexpr double kMaxLmDiag = 1e32;
+constexpr double kFunctionTol = 1e-6;
+constexpr double kGradientTol = 1e-10;
+constexpr double kParameterTol = 1e-8;
+constexpr int kMaxInvalid = 5;
+
+// speculative LM batching: one kernel launch evaluates up to KMAX consecutive LM iterations under the
+// assumption that every step is accepted with step quality ~1 (radius x3); the decision logic (run by
+// the last workgroup to finish) verifies the assumption and replans when it does not hold.
+constexpr int KMAX = 4;
+constexpr int NS = 3 + 5 * KMAX;  // sums per launch: [2cost, xsq, gmax] + KMAX x [2cost, model, stepsq, xsq, gmax]
+
+struct Pose {
+    double v[3];
+    double w[3];
+    double k;
+};
+
+// Device-resident state machine of one emulated Ceres trust-region solve (dense depth problem).
+struct LmState {
+    int32_t status;  // 0 = running (next launch speculates K more iterations), 1 = done, rho holds the result,
+                     // 2 = done, next launch must write the result (apply)
+    int32_t n_hist;  // accepted steps so far (their radii are hist[0..n_hist))
+    int32_t K;       // candidates to speculate in the next launch (0 = apply only)
+    int32_t write_which;  // which state index (0 = after hist, j = after candidate j) the next launch writes
+    int32_t iteration;    // Ceres iteration counter
+    int32_t num_successful;
+    int32_t num_unsuccessful;
+    int32_t invalid_run;
+    int32_t termination;  // RSDSFM_TERM_* or -1
+    int32_t rho_holds;    // the output buffer holds the state after this many accepted steps (-1 = nothing valid)
+    int32_t launches;     // kernel launches consumed
+    int32_t _pad;
+    double radius;
+    double decrease_factor;
+    double cost;  // cost of the current state
+    double initial_cost;
+    double hist[kMaxIter];
+    double cand[KMAX];
+};
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    // scratch (device)
+    double* d_partials = nullptr;  // [max_blocks][NS]
+    unsigned* d_tickets = nullptr; // [16] hierarchical arrival counters (zeroed at creation, reset by the last arriver)
+    LmState* d_lm = nullptr;       // state machine of the depth solve
+    LmState* h_lm = nullptr;       // pinned host copy
+    // staging buffers for the host-pointer API (grown on demand)
+    void* d_stage = nullptr;
+    size_t stage_bytes = 0;
+    int num_cus = 256;
+};
+
+constexpr int kDepthBlock = 256;
+constexpr int kDepthMaxBlocks = 512;
+
+#define RSDSFM_HIP_CHECK(ctx, expr)                                                            \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                    \
+            return RSDSFM_ERR_HIP;                                                             \
+        }                                                                                      \
+    } while (0)
+
+int fail(Ctx* c, int code, const char* msg);
+int ensure_stage(Ctx* c, size_t bytes);
+
+// depth_kernels.hip
+int depth_closed_form_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak,
+                             int64_t n, const Pose& pose, double* rho);
+int depth_lm_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
+                    const Pose& pose, double* rho, int first);
+
+}  // namespace rsdsfm
+
+namespace rsdsfm {
+// glue_kernels.hip
+int alpha_launch(Ctx* c, const double* flow_px, int64_t n, double h, double gamma, double* alpha);
+int alpha_k_launch(Ctx* c, const double* q_px, const double* flow_px, int64_t n, double h, double gamma, double* alpha_k);
+int pose_table_launch(Ctx* c, const Pose& pose, double gamma, int rows, double* R, double* t);
+}  // namespace rsdsfm

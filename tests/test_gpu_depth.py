@@ -1,0 +1,122 @@
+"""GPU parity: the HIP dense depth solve (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Bars: LM decisions / counters are integers -> exact; rho within 1e-9 relative of the oracle on the same
+inputs (north-star bar: 1e-5); in practice the kernels reproduce the oracle bit for bit because both are
+compiled without FMA contraction and use the reference's operation order."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def solver(rsdsfm):
+    s = rsdsfm.Solver(0)
+    yield s
+    s.close()
+
+
+def _check_summary(sm, ref):
+    for k in ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination"):
+        assert sm[k] == ref[k], (k, sm, ref)
+    assert np.isclose(sm["initial_cost"], ref["initial_cost"], rtol=1e-12)
+    assert np.isclose(sm["final_cost"], ref["final_cost"], rtol=1e-9, atol=1e-25)
+    assert np.isclose(sm["final_radius"], ref["final_radius"], rtol=1e-15)
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_depth_vs_golden_and_oracle(golden, oracle, solver, case):
+    g = lambda k: golden[case + "/" + k]
+    q, u, a, ak = g("q"), g("u"), g("alpha"), g("alpha_k")
+    W, V, K = g("hyp_w"), g("hyp_v"), g("hyp_k")
+    for t in range(len(W)):
+        for mode in (0, 1):
+            rho, sm = solver.estimate_inverse_depths(q, u, V[t], W[t], K[t], a, ak, mode=mode)
+            rho_o, sm_o = oracle.estimate_inverse_depths(q, u, V[t], W[t], K[t], a, ak, mode=mode)
+            assert np.allclose(rho, rho_o, rtol=1e-9, atol=1e-13)
+            if mode == 1:
+                _check_summary(sm, sm_o)
+                ref = g("lm_summary")[t]
+                assert sm["num_successful_steps"] == int(ref[1]) and sm["termination"] == int(ref[3])
+            if t < 3:
+                assert np.allclose(rho, g("rho_lm" if mode else "rho_cf")[t], rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 9, 255, 256, 257, 1000, 4097])
+def test_ragged_sizes(oracle, solver, rsdsfm, n):
+    d = rsdsfm.synth.make_config(1, rows=72, cols=96)
+    q, u, a, ak = d["q"][:n], d["u"][:n], d["alpha"][:n], d["alpha_k"][:n]
+    v, w, k = np.array([0.6, 0.7, 0.3]), np.array([0.01, -0.02, 0.008]), 0.1
+    for mode in (0, 1):
+        rho, sm = solver.estimate_inverse_depths(q, u, v, w, k, a, ak, mode=mode)
+        rho_o, sm_o = oracle.estimate_inverse_depths(q, u, v, w, k, a, ak, mode=mode)
+        assert rho.shape == (n,)
+        assert np.allclose(rho, rho_o, rtol=1e-9, atol=1e-13)
+        if mode == 1:
+            _check_summary(sm, sm_o)
+
+
+def test_single_pixel_variant(oracle, solver):
+    # estimateInverseDepth (nonlinearRefinement.cc:55-106) == the dense solve with n = 1
+    v, w = np.array([0.1, 0.9, 0.2]), np.array([0.01, 0.0, -0.01])
+    r = solver.estimate_inverse_depth([0.1, -0.2], v, w, [0.02, 0.03], 0.0, 1.05, 0.55)
+    ro, _ = oracle.estimate_inverse_depths([[0.1, -0.2]], [[0.02, 0.03]], v, w, 0.0, [1.05], [0.55], mode=1)
+    assert np.isclose(r, ro[0], rtol=1e-12)
+
+
+def test_many_lm_iterations_fallback_path(oracle, solver, rsdsfm):
+    """Data built so that the LM needs more iterations than one speculative launch covers: a pixel whose
+    Jacobian is tiny (clamped LM diagonal) converges slowly and keeps the step norm above the parameter
+    tolerance.  Exercises the replanning / continuation launches."""
+    d = rsdsfm.synth.make_config(1, rows=40, cols=48)
+    q, u, a, ak = d["q"].copy(), d["u"].copy(), d["alpha"], d["alpha_k"]
+    t = d["truth"]
+    v = np.array([0.05, 0.03, 1.0])
+    v /= np.linalg.norm(v)
+    w = t["w"]
+    # focus of expansion inside the image: pixels next to it have |J| ~ 0 -> clamped diagonal
+    q[7] = [v[0] / v[2] + 1e-7, v[1] / v[2] - 2e-7]
+    u[7] = [3e-4, -2e-4]
+    rho, sm = solver.estimate_inverse_depths(q, u, v, w, 0.0, a, ak, mode=1)
+    rho_o, sm_o = oracle.estimate_inverse_depths(q, u, v, w, 0.0, a, ak, mode=1)
+    _check_summary(sm, sm_o)
+    assert sm["num_iterations"] > 4
+    assert np.allclose(rho, rho_o, rtol=1e-9, atol=1e-13)
+
+
+def test_full_size_properties(solver, rsdsfm):
+    """1280x720 (BASELINE config 2): size-independent properties.  (a) noise-free model data: closed-form
+    depth recovers rho_true*|v| to 1e-10 relative; (b) LM iterate obeys rho_lm - rho* = (1 - rho*) * prod eps_t for
+    unclamped pixels; (c) linearity: scaling (v -> s v) scales rho by 1/s."""
+    d = rsdsfm.synth.make_config(2)
+    q, u, a, ak, t = d["q"], d["u"], d["alpha"], d["alpha_k"], d["truth"]
+    assert len(q) == 1280 * 720
+    nv = np.linalg.norm(t["v"])
+    v, w = t["v"] / nv, t["w"]
+    rho0, _ = solver.estimate_inverse_depths(q, u, v, w, 0.0, a, ak, mode=0)
+    rho_true = (1.0 / t["Z"]).T.reshape(-1) * nv
+    assert np.allclose(rho0, rho_true, rtol=1e-10)
+    rho1, sm = solver.estimate_inverse_depths(q, u, v, w, 0.0, a, ak, mode=1)
+    eps = 1.0
+    R = 1e4
+    for _ in range(sm["num_successful_steps"]):
+        eps *= (1.0 / R) / (1.0 + 1.0 / R)
+        R *= 3
+    assert np.allclose(rho1 - rho0, (1.0 - rho0) * eps, rtol=1e-6, atol=1e-15)
+    rho_s, _ = solver.estimate_inverse_depths(q, u, 2.0 * v, w, 0.0, a, ak, mode=0)
+    assert np.allclose(rho_s, rho0 / 2.0, rtol=1e-12)
+
+
+def test_alpha_and_pose_table(oracle, solver, rsdsfm):
+    d = rsdsfm.synth.make_config(1, rows=60, cols=80)
+    q, u, qpx, fpx = oracle.flatten(d["flow_img"], *d["K"], d["gamma"])
+    assert np.array_equal(solver.get_alpha(fpx, 60, d["gamma"]), oracle.get_alpha(fpx, 60, d["gamma"]))
+    assert np.array_equal(solver.get_alpha_k(qpx, fpx, 60, d["gamma"]), oracle.get_alpha_k(qpx, fpx, 60, d["gamma"]))
+    v, w = np.array([0.03, 0.02, 0.01]), np.array([0.002, -0.003, 0.0087])
+    for k in (0.0, 0.4):
+        R, t = solver.pose_table(v, w, k, 0.8, 720)
+        Ro, to = oracle.pose_table(v, w, k, 0.8, 720)
+        assert np.array_equal(R, Ro) and np.array_equal(t, to)
+        assert np.array_equal(R[0], np.eye(3)) and np.array_equal(t[0], np.zeros(3))

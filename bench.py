@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--nbuf", type=int, default=7, help="rotating HBM buffer sets (7 x 59 MB > 256 MiB L3)")
     args = ap.parse_args()
 
     import numpy as np
@@ -82,20 +83,25 @@ def main():
     k = 0.0
     mode = rsdsfm.DEPTH_CERES_LM if args.workload == "depth" else rsdsfm.DEPTH_CLOSED_FORM
 
-    nbuf = 7  # 7 x (48+8) B x 921600 = 361 MB > 256 MiB Infinity Cache
+    nbuf = args.nbuf  # default 7 x (48+8) B x 921600 = 361 MB > 256 MiB Infinity Cache
     sets = []
     for _ in range(nbuf):
         sets.append(dict(
             q=torch.from_numpy(data["q"]).to(dev), u=torch.from_numpy(data["u"]).to(dev),
             a=torch.from_numpy(data["alpha"]).to(dev), ak=torch.from_numpy(data["alpha_k"]).to(dev),
             rho=torch.empty(n, dtype=torch.float64, device=dev)))
-    stream = torch.cuda.current_stream()
+    # a NON-default torch stream: its handle is non-null, so the library adopts it (a null handle would make the
+    # context create a private stream) and torch.cuda.Event timings see the kernels
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     solver = rsdsfm.Solver(local_rank, stream=stream.cuda_stream)
 
+    calls = [solver.prepared_depth_step(s["q"].data_ptr(), s["u"].data_ptr(), n, v, w, k, s["a"].data_ptr(),
+                                        s["ak"].data_ptr(), s["rho"].data_ptr(), mode=mode) for s in sets]
+
     def step(i):
-        s = sets[i % nbuf]
-        solver.estimate_inverse_depths_dev(s["q"].data_ptr(), s["u"].data_ptr(), n, v, w, k, s["a"].data_ptr(),
-                                           s["ak"].data_ptr(), s["rho"].data_ptr(), mode=mode)
+        calls[i % nbuf]()
 
     def barrier():
         if world > 1:
@@ -149,7 +155,7 @@ def main():
             e0[i].record(stream)
             if mode == rsdsfm.DEPTH_CERES_LM:
                 solver.depth_lm_launch_dev(s["q"].data_ptr(), s["u"].data_ptr(), n, v, w, k, s["a"].data_ptr(),
-                                           s["ak"].data_ptr(), s["rho"].data_ptr(), first=True)
+                                           s["ak"].data_ptr(), s["rho"].data_ptr(), launch_id=0)
             else:
                 step(i)
             e1[i].record(stream)
@@ -179,7 +185,7 @@ def main():
                                    "(%s), pose fixed; one pair per GPU, %d rotating HBM buffer sets" %
                                    ("Ceres-1.14 LM emulation" if mode == 1 else "closed-form GN", nbuf),
                        "rows": rows, "cols": cols, "pixels": n, "depth_mode": int(mode),
-                       "launches_per_step": 2 if mode == 1 else 1, "extra_lm_launches": int(extra),
+                       "launches_per_step": 3 if mode == 1 else 1, "extra_lm_launches": int(extra),
                        "lm_summary": summary, "max_rel_err_vs_truth": max_rel},
             "roofline": {"bound": "hbm", "kernel": "depth_lm_kernel" if mode == 1 else "depth_closed_form_kernel",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -147,18 +147,20 @@ int rsdsfm_pose_table(rsdsfm_ctx* ctx, const double v[3], const double w[3], dou
 /* ---------------------------------------------------------------------------------------------------- */
 /* device API (asynchronous on the context's stream; pointers are DEVICE memory, 16-byte aligned)          */
 /* ---------------------------------------------------------------------------------------------------- */
-/* estimateInverseDepths on device-resident inputs.  Enqueues the fixed fast-path launch sequence (two
- * launches of the fused LM kernel in RSDSFM_DEPTH_CERES_LM mode) and returns without synchronising. */
+/* estimateInverseDepths on device-resident inputs.  Enqueues the fixed fast-path launch sequence (in
+ * RSDSFM_DEPTH_CERES_LM mode: speculative LM launch 0, the decide kernel, launch 1 = apply / continue / no-op)
+ * and returns without synchronising. */
 int rsdsfm_estimate_inverse_depths_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n, int64_t n,
                                        const double v[3], const double w[3], double k, const double* d_alpha_n,
                                        const double* d_alpha_k_n, int depth_mode, double* d_inv_depth_n);
-/* One launch of the fused LM kernel (building block of the two calls around it; also what bench.py brackets
- * with HIP events to time the dominant kernel).  first != 0: the launch of LM iteration zero (fresh state). */
+/* One launch of the fused LM kernel (building block of the calls around it; also what bench.py brackets with
+ * HIP events to time the dominant kernel).  launch_id 0 = the launch of LM iteration zero (fresh state);
+ * launch_id > 0 acts only if the device state machine designated that launch. */
 int rsdsfm_depth_lm_launch_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n, int64_t n,
                                const double v[3], const double w[3], double k, const double* d_alpha_n,
-                               const double* d_alpha_k_n, double* d_inv_depth_n, int first);
+                               const double* d_alpha_k_n, double* d_inv_depth_n, int launch_id);
 /* Synchronises, drives the device LM state machine to completion if the fast path did not finish it
- * (rare: more than 4 LM iterations or a rejected step) and returns the summary.  Returns the number of
+ * (rare: more than 3 LM iterations or a rejected step) and returns the summary.  Returns the number of
  * EXTRA launches that were needed in *extra_launches (may be NULL). */
 int rsdsfm_depth_finish_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n, int64_t n,
                             const double v[3], const double w[3], double k, const double* d_alpha_n,

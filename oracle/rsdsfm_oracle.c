@@ -778,12 +778,17 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
         }
         ++iteration;
         double model_change = 0.0, stepsq = 0.0, ccost = 0.0;
+        /* LevenbergMarquardtStrategy::ComputeStep forms D = sqrt(clamp(diag)/radius) and the linear solver adds
+         * D^2 to the diagonal; restated as D^2 = clamp(diag) * (1/radius) (differs from sqrt-then-square by at
+         * most 2 ulp of D^2, far below the emulation's own uncertainty) so that the per-pixel inner loop of the
+         * HIP kernels, which mirror this arithmetic operation for operation, needs one division per iteration. */
+        const double inv_radius = 1.0 / radius;
         for (int64_t i = 0; i < n; ++i) {
             double jt0 = J[2 * i] * s[i], jt1 = J[2 * i + 1] * s[i];
             double ht = jt0 * jt0 + jt1 * jt1;
-            double D = sqrt(clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG) / radius);
+            double lam = clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG) * inv_radius;
             double gt = jt0 * res[2 * i] + jt1 * res[2 * i + 1];
-            double step = -(gt / (ht + D * D));
+            double step = -(gt / (ht + lam));
             double m0 = jt0 * step, m1 = jt1 * step;
             model_change -= m0 * (res[2 * i] + m0 / 2.0) + m1 * (res[2 * i + 1] + m1 / 2.0);
             cand[i] = rho[i] + step * s[i];
@@ -1119,15 +1124,17 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
             break;
         }
         ++iteration;
-        /* pass 1: Schur complement of the scaled, LM-augmented normal equations */
+        /* pass 1: Schur complement of the scaled, LM-augmented normal equations (D^2 = clamp(diag)/radius
+         * restated as clamp(diag) * (1/radius), see rso_estimate_inverse_depths) */
+        const double inv_radius = 1.0 / radius;
         double FtF[49] = {0}, C[49] = {0}, Ftb[7] = {0}, cvec[7] = {0};
         for (int64_t i = 0; i < m; ++i) {
             double r[2], Jp[2][7], Jr[2];
             resid_jac(inl[3 * i], inl[3 * i + 1], uu[2 * i], uu[2 * i + 1], alpha[i], alpha_k[i], p, rho[i], r, Jp, Jr);
             double E0 = Jr[0] * srho[i], E1 = Jr[1] * srho[i];
             double ht = E0 * E0 + E1 * E1;
-            double D = sqrt(clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG) / radius);
-            double ete_inv = 1.0 / (ht + D * D);
+            double lam = clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG) * inv_radius;
+            double ete_inv = 1.0 / (ht + lam);
             double Etb = E0 * r[0] + E1 * r[1];
             double F[2][7], EtF[7];
             for (int c = 0; c < np; ++c) {
@@ -1146,11 +1153,11 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
         }
         double S[49], rhs[7], yp[7], Dp[7];
         for (int a = 0; a < np; ++a) {
-            Dp[a] = sqrt(clampd(FtF[a * 7 + a], CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG) / radius);
+            Dp[a] = clampd(FtF[a * 7 + a], CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG) * inv_radius; /* = D_f^2 */
             rhs[a] = Ftb[a] - cvec[a];
             for (int b = a; b < np; ++b) {
                 double sab = FtF[a * 7 + b] - C[a * 7 + b];
-                if (a == b) sab += Dp[a] * Dp[a];
+                if (a == b) sab += Dp[a];
                 S[a * np + b] = sab;
                 S[b * np + a] = sab;
             }
@@ -1173,8 +1180,8 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
                 resid_jac(inl[3 * i], inl[3 * i + 1], uu[2 * i], uu[2 * i + 1], alpha[i], alpha_k[i], p, rho[i], r, Jp, Jr);
                 double E0 = Jr[0] * srho[i], E1 = Jr[1] * srho[i];
                 double ht = E0 * E0 + E1 * E1;
-                double D = sqrt(clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG) / radius);
-                double ete_inv = 1.0 / (ht + D * D);
+                double lam = clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG) * inv_radius;
+                double ete_inv = 1.0 / (ht + lam);
                 double Etb = E0 * r[0] + E1 * r[1];
                 double Fy0 = 0.0, Fy1 = 0.0;
                 for (int c = 0; c < np; ++c) {

@@ -18,7 +18,7 @@ import numpy as np
 from . import synth  # noqa: F401  (analytic data generator used by tests and bench)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librsdsfm_hip.so")
+LIB_PATH = os.environ.get("RSDSFM_LIB") or os.path.join(_HERE, "librsdsfm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rsdsfm.h")
 
 OK = 0
@@ -260,8 +260,22 @@ class Solver:
     def estimate_inverse_depths_dev(self, d_q, d_u, n, v, w, k, d_alpha, d_alpha_k, d_rho, mode=DEPTH_CERES_LM):
         self._check(self.lib.rsdsfm_estimate_inverse_depths_dev(self._ctx, _dp(d_q), _dp(d_u), C.c_int64(n), _v3(v), _v3(w), C.c_double(k), _dp(d_alpha), _dp(d_alpha_k), int(mode), _dp(d_rho)), "rsdsfm_estimate_inverse_depths_dev")
 
-    def depth_lm_launch_dev(self, d_q, d_u, n, v, w, k, d_alpha, d_alpha_k, d_rho, first=True):
-        self._check(self.lib.rsdsfm_depth_lm_launch_dev(self._ctx, _dp(d_q), _dp(d_u), C.c_int64(n), _v3(v), _v3(w), C.c_double(k), _dp(d_alpha), _dp(d_alpha_k), _dp(d_rho), int(bool(first))), "rsdsfm_depth_lm_launch_dev")
+    def prepared_depth_step(self, d_q, d_u, n, v, w, k, d_alpha, d_alpha_k, d_rho, mode=DEPTH_CERES_LM):
+        """Returns a zero-argument callable that enqueues one dense depth solve with pre-marshalled arguments
+        (keeps the per-step host cost at one foreign call; used by bench.py)."""
+        fn = self.lib.rsdsfm_estimate_inverse_depths_dev
+        args = (self._ctx, _dp(d_q), _dp(d_u), C.c_int64(n), _v3(v), _v3(w), C.c_double(k), _dp(d_alpha), _dp(d_alpha_k), C.c_int(int(mode)), _dp(d_rho))
+        check = self._check
+
+        def call():
+            rc = fn(*args)
+            if rc != OK:
+                check(rc, "rsdsfm_estimate_inverse_depths_dev")
+
+        return call
+
+    def depth_lm_launch_dev(self, d_q, d_u, n, v, w, k, d_alpha, d_alpha_k, d_rho, launch_id=0):
+        self._check(self.lib.rsdsfm_depth_lm_launch_dev(self._ctx, _dp(d_q), _dp(d_u), C.c_int64(n), _v3(v), _v3(w), C.c_double(k), _dp(d_alpha), _dp(d_alpha_k), _dp(d_rho), int(launch_id)), "rsdsfm_depth_lm_launch_dev")
 
     def depth_finish_dev(self, d_q, d_u, n, v, w, k, d_alpha, d_alpha_k, d_rho):
         sm = LmSummary()

@@ -102,6 +102,12 @@ int rsdsfm_create(rsdsfm_ctx** out, int device, void* stream_or_null) {
               hipHostMalloc(reinterpret_cast<void**>(&c->h_lm), sizeof(LmState), hipHostMallocDefault) == hipSuccess &&
               hipMemset(c->d_tickets, 0, sizeof(unsigned) * 16) == hipSuccess &&
               hipMemset(c->d_lm, 0, sizeof(LmState)) == hipSuccess;
+    if (ok) {
+        memset(c->h_lm, 0, sizeof(LmState));
+        c->h_lm->predict = 1;  // noisy data (the common case inside RANSAC) stops after one accepted step
+        c->h_lm->status = 1;
+        ok = hipMemcpy(c->d_lm, c->h_lm, sizeof(LmState), hipMemcpyHostToDevice) == hipSuccess;
+    }
     if (!ok) {
         rsdsfm_destroy(ctx);
         return RSDSFM_ERR_HIP;
@@ -154,22 +160,28 @@ int rsdsfm_estimate_inverse_depths_dev(rsdsfm_ctx* ctx, const double* d_q, const
     pose.k = k;
     if (depth_mode == RSDSFM_DEPTH_CLOSED_FORM) return depth_closed_form_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho);
     if (depth_mode != RSDSFM_DEPTH_CERES_LM) return fail(c, RSDSFM_ERR_INVALID, "unknown depth_mode");
-    int rc = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 1);
+    // fixed fast-path sequence: speculate (launch 0) -> decide -> launch 1 (apply / continue / no-op)
+    int rc = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 0);
     if (rc != RSDSFM_OK) return rc;
-    return depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 0);
+    rc = depth_lm_decide_launch(c, n, 0);
+    if (rc != RSDSFM_OK) return rc;
+    rc = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 1);
+    c->lm_issued_k = 2;
+    c->lm_issued_d = 1;
+    return rc;
 }
 
 int rsdsfm_depth_lm_launch_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_u, int64_t n, const double v[3],
                                const double w[3], double k, const double* d_alpha, const double* d_alpha_k,
-                               double* d_rho, int first) {
+                               double* d_rho, int launch_id) {
     CTX_OR_FAIL(ctx);
-    if (n < 0 || !v || !w) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    if (n < 0 || !v || !w || launch_id < 0) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     if (n > 0 && (!d_q || !d_u || !d_alpha || !d_alpha_k || !d_rho)) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
     Pose pose;
     memcpy(pose.v, v, sizeof(pose.v));
     memcpy(pose.w, w, sizeof(pose.w));
     pose.k = k;
-    return depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, first ? 1 : 0);
+    return depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, launch_id);
 }
 
 int rsdsfm_depth_finish_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_u, int64_t n, const double v[3],
@@ -184,14 +196,34 @@ int rsdsfm_depth_finish_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_
     int extra = 0;
     int rc = read_lm_state(c);
     if (rc != RSDSFM_OK) return rc;
-    while (c->h_lm->status != 1) {
-        if (extra > 2 * kMaxIter + 8) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machine did not terminate");
-        rc = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 0);
+    for (;;) {
+        const LmState& st = *c->h_lm;
+        if (st.status == 1) break;
+        if (extra > 4 * kMaxIter + 8) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machine did not terminate");
+        if (st.status == 2) {  // result known, needs the designated launch to write it
+            if (st.next_launch < c->lm_issued_k) break;  // that launch already ran
+            rc = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, st.next_launch);
+            if (rc != RSDSFM_OK) return rc;
+            c->lm_issued_k = st.next_launch + 1;
+            ++extra;
+            break;
+        }
+        // status 0: launch `next_launch` must speculate (it may already have, in the fast path) and be decided
+        const int id = st.next_launch;
+        if (id >= c->lm_issued_k) {
+            rc = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, id);
+            if (rc != RSDSFM_OK) return rc;
+            c->lm_issued_k = id + 1;
+            ++extra;
+        }
+        rc = depth_lm_decide_launch(c, n, id);
         if (rc != RSDSFM_OK) return rc;
+        c->lm_issued_d = id + 1;
         ++extra;
         rc = read_lm_state(c);
         if (rc != RSDSFM_OK) return rc;
     }
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     fill_summary(*c->h_lm, summary);
     if (extra_launches) *extra_launches = extra;
     if (c->h_lm->termination == RSDSFM_TERM_FAILURE) return fail(c, RSDSFM_ERR_NUMERIC, "LM failure (5 consecutive invalid steps)");

@@ -7,10 +7,11 @@
 //  * depth_lm_kernel          : emulation of the Ceres 1.14 trust-region Levenberg-Marquardt the
 //    reference runs.  Ceres' accept / converge decisions are GLOBAL (summed cost, step norm, max
 //    gradient), so one launch speculatively evaluates up to KMAX consecutive LM iterations per pixel
-//    (radius x3 each, which is what an exact-model step produces), block-reduces the 5 per-iteration sums,
-//    and the LAST workgroup to finish reduces all partials in a fixed order and runs the trust-region
-//    state machine (lm_advance) on them.  The launch also writes the most likely final iterate, so the
-//    common case costs one streaming pass: 48 B read + 8 B written per pixel.
+//    (radius x3 each, which is what an exact-model step produces) and block-reduces the 5 per-iteration sums;
+//    depth_lm_decide_kernel (one workgroup) then reduces the per-workgroup partials in a fixed order and
+//    runs the trust-region state machine (lm_advance) on them.  The launch also writes the most likely final iterate, so the
+//    common case costs one streaming pass: 48 B read + 8 B written per pixel.  The LM diagonal is formed as
+//    clamp(diag) * (1/radius) (see the oracle for why), so the inner loop has one fp64 division per iteration.
 //
 // HBM-bound streaming, one lane per pixel PAIR so that every global access is a 16-byte vector
 // (q: 2 x dwordx4, u: 2 x dwordx4, alpha / alpha_k / rho: dwordx4).  No LDS tiling (no reuse), no MFMA.
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(kDepthBlock) void depth_closed_form_kernel(const do
 // j (0-based): base = 3 + 5 j : [sum |r(cand)|^2, model_cost_change, sum step^2, sum cand^2, max |J.r(cand)|]
 // `first`: this is the launch of iteration zero (current state = rho == 1, nothing accepted yet).
 // `used_K`, `used_write` : the plan the launch that produced `sums` ran with.
-__device__ void lm_advance(LmState& st, const double* sums, int64_t n, int first, int used_K, int used_write) {
+__device__ void lm_advance(LmState& st, const double* sums, int64_t n, int first, int used_K, int used_write,
+                           int launch_id) {
     if (first) {
         st.status = 0;
         st.n_hist = 0;
@@ -155,11 +157,13 @@ __device__ void lm_advance(LmState& st, const double* sums, int64_t n, int first
     else st.rho_holds = -1;
     if (st.termination < 0 && st.iteration >= kMaxIter) st.termination = RSDSFM_TERM_MAX_ITER;
     if (st.termination < 0 && st.radius < kMinRadius) st.termination = RSDSFM_TERM_MIN_RADIUS;
+    st.next_launch = launch_id + 1;
     if (st.termination >= 0) {
+        st.predict = st.n_hist < KMAX ? st.n_hist : KMAX;
         if (st.rho_holds == st.n_hist) {
             st.status = 1;
         } else {
-            st.status = 2;
+            st.status = 2;  // launch `next_launch` replays the accepted steps and writes the result
             st.K = 0;
             st.write_which = 0;
         }
@@ -180,11 +184,12 @@ __device__ void lm_advance(LmState& st, const double* sums, int64_t n, int first
 // ---------------------------------------------------------------------------------------------------
 struct LmPlanLds {
     int n_hist, K, write_which;
-    double hist[kMaxIter];
-    double cand[KMAX];
+    double inv_hist[kMaxIter];  // 1 / radius of each accepted step
+    double inv_cand[KMAX];      // 1 / radius of each speculated step
 };
 
-// one pixel through the planned LM trajectory; returns the state selected by write_which
+// one pixel through the planned LM trajectory; returns the state selected by write_which.
+// Arithmetic mirrors oracle/rsdsfm_oracle.c rso_estimate_inverse_depths (mode 1) operation for operation.
 __device__ __forceinline__ double lm_pixel(double x, double y, double ux, double uy, double al, double ak,
                                            const Pose& pose, double two_over, const LmPlanLds& plan,
                                            double (&acc)[NS]) {
@@ -198,9 +203,9 @@ __device__ __forceinline__ double lm_pixel(double x, double y, double ux, double
     double r0, r1;
     m.residual(rho, r0, r1);
     for (int h = 0; h < plan.n_hist; ++h) {  // replay the accepted steps
-        const double D = sqrt(diag / plan.hist[h]);
+        const double lam = diag * plan.inv_hist[h];
         const double gt = jt0 * r0 + jt1 * r1;
-        const double step = -(gt / (ht + D * D));
+        const double step = -(gt / (ht + lam));
         rho = rho + step * s;
         m.residual(rho, r0, r1);
     }
@@ -213,9 +218,9 @@ __device__ __forceinline__ double lm_pixel(double x, double y, double ux, double
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {
         if (j < plan.K) {
-            const double D = sqrt(diag / plan.cand[j]);
+            const double lam = diag * plan.inv_cand[j];
             const double gt = jt0 * r0 + jt1 * r1;
-            const double step = -(gt / (ht + D * D));
+            const double step = -(gt / (ht + lam));
             const double m0 = jt0 * step, m1 = jt1 * step;
             acc[3 + 5 * j + 1] -= m0 * (r0 + m0 / 2.0) + m1 * (r1 + m1 / 2.0);
             const double cand = rho + step * s;
@@ -234,37 +239,41 @@ __device__ __forceinline__ double lm_pixel(double x, double y, double ux, double
 
 __device__ __forceinline__ bool is_max_slot(int s) { return s == 2 || (s >= 3 && ((s - 3) % 5) == 4); }
 
+// launch_id 0 = the launch of LM iteration zero (fresh state, built-in plan); launch_id > 0 acts only if the
+// state machine designated exactly this launch (next_launch) to continue (status 0) or to apply (status 2).
 __global__ __launch_bounds__(kDepthBlock) void depth_lm_kernel(const double2* __restrict__ q,
                                                                const double2* __restrict__ u,
                                                                const double2* __restrict__ alpha2,
                                                                const double2* __restrict__ alpha_k2, int64_t n,
                                                                Pose pose, double2* __restrict__ rho2,
-                                                               LmState* state, double* partials,
-                                                               unsigned* tickets, int first) {
+                                                               const LmState* __restrict__ state,
+                                                               double* __restrict__ partials, int launch_id) {
     __shared__ LmPlanLds plan;
     __shared__ double s_red[kDepthBlock / 64][NS];
-    __shared__ double s_fin[kDepthBlock / 64][NS];
     const int tid = threadIdx.x;
-    if (!first && state->status == 1) return;  // already finished: nothing to do
-    if (first) {
+    if (launch_id == 0) {
         if (tid == 0) {
             plan.n_hist = 0;
             plan.K = KMAX;
-            plan.write_which = 1;  // speculate: the first iterate is the final one (noisy data stops there)
+            // speculate which iterate is final: what the previous solve on this context accepted (1 at start)
+            const int pr = state->predict;
+            plan.write_which = (pr >= 0 && pr <= KMAX) ? pr : 1;
             double r = kInitialRadius;
             for (int j = 0; j < KMAX; ++j) {
-                plan.cand[j] = r;
+                plan.inv_cand[j] = 1.0 / r;
                 r = radius_accept(r, 1.0);
             }
         }
     } else {
+        const int status = state->status;
+        if (status == 1 || state->next_launch != launch_id) return;  // finished, or not this launch's turn
         if (tid == 0) {
             plan.n_hist = state->n_hist;
-            plan.K = state->K;
-            plan.write_which = state->write_which;
+            plan.K = (status == 2) ? 0 : state->K;
+            plan.write_which = (status == 2) ? 0 : state->write_which;
         }
-        if (tid < kMaxIter) plan.hist[tid] = state->hist[tid];
-        if (tid < KMAX) plan.cand[tid] = state->cand[tid];
+        if (tid < kMaxIter) plan.inv_hist[tid] = 1.0 / state->hist[tid];
+        if (tid < KMAX) plan.inv_cand[tid] = 1.0 / state->cand[tid];
     }
     __syncthreads();
 
@@ -291,82 +300,87 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lm_kernel(const double2* __
         const double* alpha_k = reinterpret_cast<const double*>(alpha_k2);
         reinterpret_cast<double*>(rho2)[i] = lm_pixel(qa.x, qa.y, ua.x, ua.y, alpha[i], alpha_k[i], pose, two_over, plan, acc);
     }
+    if (plan.K == 0) return;  // apply-only launch: no sums
 
-    // ---- workgroup reduction of the NS sums (fixed order), partial published by wave 0 ----
+    // ---- workgroup partial (DPP wave reduction, then the 4 waves in order), one row of `partials` per workgroup ----
     const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        double v = is_max_slot(s) ? wave_max(acc[s]) : wave_sum(acc[s]);
-        if (lane == 0) s_red[wv][s] = v;
+        double r = is_max_slot(s) ? wave_max(acc[s]) : wave_sum(acc[s]);
+        if (lane == 0) s_red[wv][s] = r;
     }
     __syncthreads();
-    if (wv == 0 && lane < NS) {
-        double v = s_red[0][lane];
-        for (int w2 = 1; w2 < kDepthBlock / 64; ++w2) v = is_max_slot(lane) ? fmax(v, s_red[w2][lane]) : v + s_red[w2][lane];
-        store_agent(&partials[(int64_t)blockIdx.x * NS + lane], v);
+    if (tid < NS) {
+        double r = s_red[0][tid];
+        for (int w2 = 1; w2 < kDepthBlock / 64; ++w2) r = is_max_slot(tid) ? fmax(r, s_red[w2][tid]) : r + s_red[w2][tid];
+        partials[(int64_t)blockIdx.x * NS + tid] = r;
     }
-    if (!arrive_last(tickets, gridDim.x)) return;
+}
 
-    // ---- last workgroup: reduce all partials in block order, then run the trust-region state machine ----
-    const int nb = gridDim.x;
+// One workgroup: reduces the per-workgroup partials of launch `launch_id` in block order and advances the
+// trust-region state machine.  Acts only if that launch actually speculated (status 0 and its turn).
+__global__ __launch_bounds__(kDecideBlock) void depth_lm_decide_kernel(const double* __restrict__ partials, int nblocks,
+                                                                       LmState* state, int64_t n, int launch_id) {
+    __shared__ double s_red[kDecideBlock / 64][NS];
+    __shared__ double s_sums[NS];
+    __shared__ LmState s_state;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (launch_id > 0 && (state->status != 0 || state->next_launch != launch_id)) return;
     double fin[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) fin[s] = 0.0;
-    for (int b = tid; b < nb; b += kDepthBlock) {
+    for (int b = tid; b < nblocks; b += kDecideBlock) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            double v = load_agent(&partials[(int64_t)b * NS + s]);
+            double v = partials[(int64_t)b * NS + s];
             fin[s] = is_max_slot(s) ? fmax(fin[s], v) : fin[s] + v;
         }
     }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-        double v = is_max_slot(s) ? wave_max(fin[s]) : wave_sum(fin[s]);
-        if (lane == 0) s_fin[wv][s] = v;
+        double r = is_max_slot(s) ? wave_max(fin[s]) : wave_sum(fin[s]);
+        if (lane == 0) s_red[wv][s] = r;
     }
-    __syncthreads();
-    // the state machine runs on LDS copies (dynamically indexed: keep it out of registers / scratch)
-    __shared__ LmState s_state;
-    __shared__ double s_sums[NS];
-    if (tid < NS) {
-        double v = s_fin[0][tid];
-        for (int w2 = 1; w2 < kDepthBlock / 64; ++w2) v = is_max_slot(tid) ? fmax(v, s_fin[w2][tid]) : v + s_fin[w2][tid];
-        s_sums[tid] = v;
-    }
-    {
+    {   // LDS copy of the state: the state machine indexes it dynamically (keep it out of registers / scratch)
         const int nwords = (int)(sizeof(LmState) / sizeof(int32_t));
         const int32_t* src = reinterpret_cast<const int32_t*>(state);
         int32_t* dst = reinterpret_cast<int32_t*>(&s_state);
-        for (int i = tid; i < nwords; i += kDepthBlock) dst[i] = src[i];
+        for (int i = tid; i < nwords; i += kDecideBlock) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (tid < NS) {
+        double r = s_red[0][tid];
+        for (int w2 = 1; w2 < kDecideBlock / 64; ++w2) r = is_max_slot(tid) ? fmax(r, s_red[w2][tid]) : r + s_red[w2][tid];
+        s_sums[tid] = r;
     }
     __syncthreads();
     if (tid == 0) {
-        const int used_K = plan.K, used_write = plan.write_which;
-        if (used_K == 0) {  // apply-only launch: the buffer now holds the final state
-            s_state.launches += 1;
-            s_state.rho_holds = s_state.n_hist;
-            s_state.status = 1;
-        } else {
-            lm_advance(s_state, s_sums, n, first, used_K, used_write);
-        }
+        const int used_K = (launch_id == 0) ? KMAX : s_state.K;
+        const int pr = s_state.predict;
+        const int used_write = (launch_id == 0) ? ((pr >= 0 && pr <= KMAX) ? pr : 1) : s_state.write_which;
+        lm_advance(s_state, s_sums, n, launch_id == 0, used_K, used_write, launch_id);
     }
     __syncthreads();
     {
         const int nwords = (int)(sizeof(LmState) / sizeof(int32_t));
         int32_t* dst = reinterpret_cast<int32_t*>(state);
         const int32_t* src = reinterpret_cast<const int32_t*>(&s_state);
-        for (int i = tid; i < nwords; i += kDepthBlock) dst[i] = src[i];
+        for (int i = tid; i < nwords; i += kDecideBlock) dst[i] = src[i];
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
+// balanced grid: every thread runs the same number of grid-stride iterations (no half-idle second sweep)
 static inline int depth_grid(int64_t n, int max_blocks) {
     int64_t npairs = n >> 1;
     int64_t blocks = (npairs + kDepthBlock - 1) / kDepthBlock;
     if (blocks < 1) blocks = 1;
-    if (blocks > max_blocks) blocks = max_blocks;
+    if (blocks > max_blocks) {
+        int64_t iters = (blocks + max_blocks - 1) / max_blocks;
+        blocks = (blocks + iters - 1) / iters;
+    }
     return (int)blocks;
 }
 
@@ -387,14 +401,22 @@ int depth_closed_form_launch(Ctx* c, const double* q, const double* u, const dou
 }
 
 int depth_lm_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
-                    const Pose& pose, double* rho, int first) {
+                    const Pose& pose, double* rho, int launch_id) {
     if (!aligned16(q) || !aligned16(u) || !aligned16(a) || !aligned16(ak) || !aligned16(rho))
         return fail(c, RSDSFM_ERR_INVALID, "device pointers must be 16-byte aligned");
     const int grid = depth_grid(n, kDepthMaxBlocks);
     hipLaunchKernelGGL(depth_lm_kernel, dim3(grid), dim3(kDepthBlock), 0, c->stream,
                        reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u),
                        reinterpret_cast<const double2*>(a), reinterpret_cast<const double2*>(ak), n, pose,
-                       reinterpret_cast<double2*>(rho), c->d_lm, c->d_partials, c->d_tickets, first);
+                       reinterpret_cast<double2*>(rho), c->d_lm, c->d_partials, launch_id);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+int depth_lm_decide_launch(Ctx* c, int64_t n, int launch_id) {
+    const int grid = depth_grid(n, kDepthMaxBlocks);
+    hipLaunchKernelGGL(depth_lm_decide_kernel, dim3(1), dim3(kDecideBlock), 0, c->stream, c->d_partials, grid, c->d_lm, n,
+                       launch_id);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

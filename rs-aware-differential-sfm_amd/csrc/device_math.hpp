@@ -71,52 +71,38 @@ __device__ __forceinline__ double point_error(double x, double y, double ux, dou
     return sqrt(e0 * e0 + e1 * e1);
 }
 
-// ---- wave64 / workgroup reductions (deterministic: fixed butterfly order) ----
+// ---- wave64 reductions on the VALU (DPP row shifts / broadcasts; no LDS traffic).  Fixed combination
+// order -> deterministic.  The result is returned to every lane (read from lane 63).  wave_max assumes
+// non-negative inputs (lanes shifted in read 0), which holds for every max slot (they are absolute values).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lane63(double v) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_move<0xb1, 0xf>(v);   // quad_perm:[1,0,3,2]
+    v += dpp_move<0x4e, 0xf>(v);   // quad_perm:[2,3,0,1]
+    v += dpp_move<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_move<0x118, 0xf>(v);  // row_shr:8   -> lanes 12..15 of each row hold the row sum
+    v += dpp_move<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_move<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+    return lane63(v);
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
-    return v;
-}
-
-// Arrival counter: returns true in exactly one workgroup per launch -- the last one whose wave 0 called it.
-// Payload written by wave 0 with agent-scope relaxed atomic stores (write-through) BEFORE the call is
-// visible to the last arriver through agent-scope relaxed atomic loads (cdna guide G16, "8-B agent
-// atomics both sides").  Hierarchical (8 group counters + 1 top counter) so that no word sees more than
-// nblocks/8 returning atomics.  Counters are zero at entry and are reset by their last arriver.
-// Must be called by all threads of the workgroup (contains __syncthreads()).
-__device__ __forceinline__ bool arrive_last(unsigned* tickets, int nblocks) {
-    __shared__ int s_last;
-    if (threadIdx.x == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int group = blockIdx.x & 7;
-        const int ngroup = (nblocks - group + 7) >> 3;
-        const int ngroups = nblocks < 8 ? nblocks : 8;
-        int last = 0;
-        unsigned t = __hip_atomic_fetch_add(&tickets[group], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == (unsigned)(ngroup - 1)) {
-            __hip_atomic_store(&tickets[group], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned tt = __hip_atomic_fetch_add(&tickets[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (tt == (unsigned)(ngroups - 1)) {
-                __hip_atomic_store(&tickets[8], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                last = 1;
-            }
-        }
-        s_last = last;
-    }
-    __syncthreads();
-    return s_last != 0;
-}
-
-__device__ __forceinline__ void store_agent(double* p, double v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double load_agent(const double* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    v = fmax(v, dpp_move<0xb1, 0xf>(v));
+    v = fmax(v, dpp_move<0x4e, 0xf>(v));
+    v = fmax(v, dpp_move<0x114, 0xf>(v));
+    v = fmax(v, dpp_move<0x118, 0xf>(v));
+    v = fmax(v, dpp_move<0x142, 0xa>(v));
+    v = fmax(v, dpp_move<0x143, 0xc>(v));
+    return lane63(v);
 }
 
 }  // namespace rsdsfm

@@ -29,7 +29,7 @@ constexpr int kMaxInvalid = 5;
 // speculative LM batching: one kernel launch evaluates up to KMAX consecutive LM iterations under the
 // assumption that every step is accepted with step quality ~1 (radius x3); the decision logic (run by
 // the last workgroup to finish) verifies the assumption and replans when it does not hold.
-constexpr int KMAX = 4;
+constexpr int KMAX = 3;
 constexpr int NS = 3 + 5 * KMAX;  // sums per launch: [2cost, xsq, gmax] + KMAX x [2cost, model, stepsq, xsq, gmax]
 
 struct Pose {
@@ -51,7 +51,10 @@ struct LmState {
     int32_t invalid_run;
     int32_t termination;  // RSDSFM_TERM_* or -1
     int32_t rho_holds;    // the output buffer holds the state after this many accepted steps (-1 = nothing valid)
-    int32_t launches;     // kernel launches consumed
+    int32_t launches;     // speculative launches consumed by the state machine
+    int32_t next_launch;  // status 0: id of the launch that must speculate next; status 2: id of the launch that applies
+    int32_t predict;      // accepted-step count of the previous solve on this context: the iterate launch 0 of the
+                          // NEXT solve writes speculatively (a branch predictor; results never depend on it)
     int32_t _pad;
     double radius;
     double decrease_factor;
@@ -67,10 +70,12 @@ struct Ctx {
     bool own_stream = false;
     std::string err;
     // scratch (device)
-    double* d_partials = nullptr;  // [max_blocks][NS]
-    unsigned* d_tickets = nullptr; // [16] hierarchical arrival counters (zeroed at creation, reset by the last arriver)
+    double* d_partials = nullptr;  // [max_blocks][NS] per-workgroup partial sums, then [8][NS] group partials
+    unsigned* d_tickets = nullptr; // spare device words
     LmState* d_lm = nullptr;       // state machine of the depth solve
     LmState* h_lm = nullptr;       // pinned host copy
+    int lm_issued_k = 0;           // depth_lm_kernel launches issued for the current solve
+    int lm_issued_d = 0;           // depth_lm_decide_kernel launches issued for the current solve
     // staging buffers for the host-pointer API (grown on demand)
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -78,7 +83,8 @@ struct Ctx {
 };
 
 constexpr int kDepthBlock = 256;
-constexpr int kDepthMaxBlocks = 512;
+constexpr int kDepthMaxBlocks = 1024;
+constexpr int kDecideBlock = 256;
 
 #define RSDSFM_HIP_CHECK(ctx, expr)                                                            \
     do {                                                                                       \
@@ -96,7 +102,8 @@ int ensure_stage(Ctx* c, size_t bytes);
 int depth_closed_form_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak,
                              int64_t n, const Pose& pose, double* rho);
 int depth_lm_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
-                    const Pose& pose, double* rho, int first);
+                    const Pose& pose, double* rho, int launch_id);
+int depth_lm_decide_launch(Ctx* c, int64_t n, int launch_id);
 
 }  // namespace rsdsfm
 

@@ -78,7 +78,7 @@ def test_many_lm_iterations_fallback_path(oracle, solver, rsdsfm):
     w = t["w"]
     # focus of expansion inside the image: pixels next to it have |J| ~ 0 -> clamped diagonal
     q[7] = [v[0] / v[2] + 1e-7, v[1] / v[2] - 2e-7]
-    u[7] = [3e-4, -2e-4]
+    u[7] = [3e-2, -2e-2]
     rho, sm = solver.estimate_inverse_depths(q, u, v, w, 0.0, a, ak, mode=1)
     rho_o, sm_o = oracle.estimate_inverse_depths(q, u, v, w, 0.0, a, ak, mode=1)
     _check_summary(sm, sm_o)

@@ -153,6 +153,13 @@ int rsdsfm_pose_table(rsdsfm_ctx* ctx, const double v[3], const double w[3], dou
 int rsdsfm_estimate_inverse_depths_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n, int64_t n,
                                        const double v[3], const double w[3], double k, const double* d_alpha_n,
                                        const double* d_alpha_k_n, int depth_mode, double* d_inv_depth_n);
+/* minimal::ransac on device-resident inputs.  The arrays of `out` (inlier_idx, inliers, alpha, alpha_k, mask,
+ * inv_depth) are DEVICE pointers with capacity n (each may be NULL); its trial_* arrays are HOST pointers.
+ * samples_9xT_or_null is a HOST pointer.  Synchronises once at the end to return the scalars of `out`. */
+int rsdsfm_ransac_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n, const double* d_alpha_n,
+                      const double* d_alpha_k_n, int64_t n, int use_alpha_k, int32_t iterations, double tolerance,
+                      const int32_t* samples_9xT_or_null, uint64_t seed, int depth_mode, int k_sign_mode,
+                      rsdsfm_ransac_out* out);
 /* One launch of the fused LM kernel (building block of the calls around it; also what bench.py brackets with
  * HIP events to time the dominant kernel).  launch_id 0 = the launch of LM iteration zero (fresh state);
  * launch_id > 0 acts only if the device state machine designated that launch. */

@@ -16,6 +16,7 @@ int fail(Ctx* c, int code, const char* msg) {
 
 int ensure_stage(Ctx* c, size_t bytes) {
     if (bytes <= c->stage_bytes) return RSDSFM_OK;
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     if (c->d_stage) RSDSFM_HIP_CHECK(c, hipFree(c->d_stage));
     c->d_stage = nullptr;
     c->stage_bytes = 0;
@@ -25,19 +26,30 @@ int ensure_stage(Ctx* c, size_t bytes) {
     return RSDSFM_OK;
 }
 
-// bump allocator over the staging buffer (256-byte aligned slices)
-struct StageAlloc {
-    char* base;
-    size_t off = 0;
-    explicit StageAlloc(void* b) : base(static_cast<char*>(b)) {}
-    template <class T>
-    T* take(size_t count) {
-        T* p = reinterpret_cast<T*>(base + off);
-        off += (count * sizeof(T) + 255) & ~(size_t)255;
-        return p;
-    }
-    static size_t need(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
-};
+int ensure_ws(Ctx* c, size_t bytes) {
+    if (bytes <= c->ws_bytes) return RSDSFM_OK;
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (c->d_ws) RSDSFM_HIP_CHECK(c, hipFree(c->d_ws));
+    c->d_ws = nullptr;
+    c->ws_bytes = 0;
+    size_t want = std::max(bytes, (size_t)1 << 20);
+    RSDSFM_HIP_CHECK(c, hipMalloc(&c->d_ws, want));
+    c->ws_bytes = want;
+    return RSDSFM_OK;
+}
+
+int ensure_pinned(Ctx* c, size_t bytes) {
+    if (bytes <= c->pinned_bytes) return RSDSFM_OK;
+    if (c->h_pinned) RSDSFM_HIP_CHECK(c, hipHostFree(c->h_pinned));
+    c->h_pinned = nullptr;
+    c->pinned_bytes = 0;
+    size_t want = std::max(bytes, (size_t)1 << 16);
+    RSDSFM_HIP_CHECK(c, hipHostMalloc(&c->h_pinned, want, hipHostMallocDefault));
+    c->pinned_bytes = want;
+    return RSDSFM_OK;
+}
+
+using StageAlloc = Arena;
 
 static void fill_summary(const LmState& st, rsdsfm_lm_summary* s) {
     if (!s) return;
@@ -59,10 +71,6 @@ static int read_lm_state(Ctx* c) {
 }  // namespace rsdsfm
 
 using namespace rsdsfm;
-
-struct rsdsfm_ctx {
-    Ctx c;
-};
 
 #define CTX_OR_FAIL(ctx)                  \
     if (!(ctx)) return RSDSFM_ERR_INVALID; \
@@ -126,6 +134,8 @@ void rsdsfm_destroy(rsdsfm_ctx* ctx) {
     if (c->d_lm) (void)hipFree(c->d_lm);
     if (c->h_lm) (void)hipHostFree(c->h_lm);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete ctx;
 }

@@ -1,0 +1,202 @@
+// lm_common.hpp -- pieces shared by the dense depth kernels and the batched RANSAC kernels:
+// the closed-form per-pixel solve, the per-pixel speculative LM trajectory and the Ceres trust-region
+// state machine that consumes its sums.  (reference: nonlinearRefinement.cc:109-180 + Ceres 1.14 defaults)
+#pragma once
+
+#include "device_math.hpp"
+#include "rsdsfm_internal.hpp"
+
+namespace rsdsfm {
+
+__device__ __forceinline__ double closed_form_rho(double x, double y, double ux, double uy, double al, double ak,
+                                                  const Pose& pose, double two_over) {
+    PixelModel m;
+    m.init(x, y, ux, uy, al, ak, pose, two_over);
+    double r0, r1;
+    m.residual(1.0, r0, r1);
+    double h = m.J0 * m.J0 + m.J1 * m.J1;
+    double g = m.J0 * r0 + m.J1 * r1;
+    return (h > 0.0) ? 1.0 - g / h : 1.0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Ceres trust-region state machine on speculative sums
+// ---------------------------------------------------------------------------------------------------
+// sums layout: [0] = sum |r|^2 of the current state, [1] = sum rho^2, [2] = max |J.r| ; then for candidate
+// j (0-based): base = 3 + 5 j : [sum |r(cand)|^2, model_cost_change, sum step^2, sum cand^2, max |J.r(cand)|]
+// `first`: this is the launch of iteration zero (current state = rho == 1, nothing accepted yet).
+// `used_K`, `used_write` : the plan the launch that produced `sums` ran with.
+__device__ inline void lm_advance(LmState& st, const double* sums, int64_t n, int first, int used_K, int used_write,
+                           int launch_id) {
+    if (first) {
+        st.status = 0;
+        st.n_hist = 0;
+        st.iteration = 0;
+        st.num_successful = 0;
+        st.num_unsuccessful = 0;
+        st.invalid_run = 0;
+        st.termination = -1;
+        st.rho_holds = -1;
+        st.launches = 0;
+        st.radius = kInitialRadius;
+        st.decrease_factor = 2.0;
+        st.initial_cost = 0.5 * sums[0];
+        double r = kInitialRadius;
+        for (int j = 0; j < KMAX; ++j) {  // the plan the first launch ran with (mirrors depth_lm_kernel)
+            st.cand[j] = r;
+            r = radius_accept(r, 1.0);
+        }
+    }
+    st.launches += 1;
+    const int base_hist = st.n_hist;
+    double cost = 0.5 * sums[0];
+    double x_norm = sqrt(sums[1]);
+    int accepted_in_batch = 0;  // candidates 0..accepted_in_batch-1 were accepted in sequence
+    if (first && (n == 0 || sums[2] <= kGradientTol)) st.termination = RSDSFM_TERM_GRADIENT;
+    for (int j = 0; j < used_K && st.termination < 0; ++j) {
+        if (st.iteration >= kMaxIter) {
+            st.termination = RSDSFM_TERM_MAX_ITER;
+            break;
+        }
+        if (st.radius < kMinRadius) {
+            st.termination = RSDSFM_TERM_MIN_RADIUS;
+            break;
+        }
+        if (st.cand[j] != st.radius) break;  // speculation no longer matches the trust-region state: replan
+        const double* s = sums + 3 + 5 * j;
+        st.iteration += 1;
+        const double model_change = s[1];
+        const double ccost = 0.5 * s[0];
+        if (!(model_change > 0.0)) {  // HandleInvalidStep
+            st.num_unsuccessful += 1;
+            st.invalid_run += 1;
+            if (st.invalid_run >= kMaxInvalid) {
+                st.termination = RSDSFM_TERM_FAILURE;
+                break;
+            }
+            st.radius *= 0.5;
+            break;
+        }
+        st.invalid_run = 0;
+        const double step_norm = sqrt(s[2]);
+        if (step_norm <= kParameterTol * (x_norm + kParameterTol)) {
+            st.termination = RSDSFM_TERM_PARAMETER;
+            break;
+        }
+        const double cost_change = cost - ccost;
+        if (fabs(cost_change) <= kFunctionTol * cost) {
+            st.termination = RSDSFM_TERM_FUNCTION;
+            break;
+        }
+        const double rel = cost_change / model_change;
+        if (rel > kMinRelDecrease) {  // HandleSuccessfulStep
+            st.hist[st.n_hist] = st.radius;
+            st.n_hist += 1;
+            accepted_in_batch = j + 1;
+            cost = ccost;
+            x_norm = sqrt(s[3]);
+            st.radius = radius_accept(st.radius, rel);
+            st.decrease_factor = 2.0;
+            st.num_successful += 1;
+            if (s[4] <= kGradientTol) {
+                st.termination = RSDSFM_TERM_GRADIENT;
+                break;
+            }
+        } else {  // HandleUnsuccessfulStep
+            st.num_unsuccessful += 1;
+            st.radius = st.radius / st.decrease_factor;
+            st.decrease_factor *= 2.0;
+            break;
+        }
+    }
+    st.cost = cost;
+    // what does the output buffer hold after the launch that produced these sums?
+    if (used_write <= accepted_in_batch) st.rho_holds = base_hist + used_write;
+    else st.rho_holds = -1;
+    if (st.termination < 0 && st.iteration >= kMaxIter) st.termination = RSDSFM_TERM_MAX_ITER;
+    if (st.termination < 0 && st.radius < kMinRadius) st.termination = RSDSFM_TERM_MIN_RADIUS;
+    st.next_launch = launch_id + 1;
+    if (st.termination >= 0) {
+        st.predict = st.n_hist < KMAX ? st.n_hist : KMAX;
+        if (st.rho_holds == st.n_hist) {
+            st.status = 1;
+        } else {
+            st.status = 2;  // launch `next_launch` replays the accepted steps and writes the result
+            st.K = 0;
+            st.write_which = 0;
+        }
+    } else {  // continue: speculate the next KMAX iterations from the current trust-region state
+        st.status = 0;
+        st.K = KMAX;
+        st.write_which = 0;
+        double r = st.radius;
+        for (int j = 0; j < KMAX; ++j) {
+            st.cand[j] = r;
+            r = radius_accept(r, 1.0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// fused LM kernel
+// ---------------------------------------------------------------------------------------------------
+struct LmPlanLds {
+    int n_hist, K, write_which;
+    double inv_hist[kMaxIter];  // 1 / radius of each accepted step
+    double inv_cand[KMAX];      // 1 / radius of each speculated step
+};
+
+// one pixel through the planned LM trajectory; returns the state selected by write_which.
+// Arithmetic mirrors oracle/rsdsfm_oracle.c rso_estimate_inverse_depths (mode 1) operation for operation.
+__device__ __forceinline__ double lm_pixel(double x, double y, double ux, double uy, double al, double ak,
+                                           const Pose& pose, double two_over, const LmPlanLds& plan,
+                                           double (&acc)[NS]) {
+    PixelModel m;
+    m.init(x, y, ux, uy, al, ak, pose, two_over);
+    const double s = 1.0 / (1.0 + sqrt(m.J0 * m.J0 + m.J1 * m.J1));  // Jacobi scaling (iteration 0 Jacobian)
+    const double jt0 = m.J0 * s, jt1 = m.J1 * s;
+    const double ht = jt0 * jt0 + jt1 * jt1;
+    const double diag = clampd(ht, kMinLmDiag, kMaxLmDiag);
+    double rho = 1.0;  // nonlinearRefinement.cc:140
+    double r0, r1;
+    m.residual(rho, r0, r1);
+    for (int h = 0; h < plan.n_hist; ++h) {  // replay the accepted steps
+        const double lam = diag * plan.inv_hist[h];
+        const double gt = jt0 * r0 + jt1 * r1;
+        const double step = -(gt / (ht + lam));
+        rho = rho + step * s;
+        m.residual(rho, r0, r1);
+    }
+    double out = rho;
+    if (plan.K > 0) {
+        acc[0] += r0 * r0 + r1 * r1;
+        acc[1] += rho * rho;
+        acc[2] = fmax(acc[2], fabs(m.J0 * r0 + m.J1 * r1));
+    }
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        if (j < plan.K) {
+            const double lam = diag * plan.inv_cand[j];
+            const double gt = jt0 * r0 + jt1 * r1;
+            const double step = -(gt / (ht + lam));
+            const double m0 = jt0 * step, m1 = jt1 * step;
+            acc[3 + 5 * j + 1] -= m0 * (r0 + m0 / 2.0) + m1 * (r1 + m1 / 2.0);
+            const double cand = rho + step * s;
+            const double dx = rho - cand;
+            acc[3 + 5 * j + 2] += dx * dx;
+            m.residual(cand, r0, r1);
+            acc[3 + 5 * j + 0] += r0 * r0 + r1 * r1;
+            acc[3 + 5 * j + 3] += cand * cand;
+            acc[3 + 5 * j + 4] = fmax(acc[3 + 5 * j + 4], fabs(m.J0 * r0 + m.J1 * r1));
+            rho = cand;
+            if (plan.write_which == j + 1) out = cand;
+        }
+    }
+    return out;
+}
+
+__device__ __forceinline__ bool is_max_slot(int s) { return s == 2 || (s >= 3 && ((s - 3) % 5) == 4); }
+
+
+}  // namespace rsdsfm

@@ -1,0 +1,709 @@
+// minimal9_kernels.hip -- batched 9-point minimal solver on MI355X (gfx950).
+//
+// Replaces minimal::calculateVelocities (reference minimal.cc:36-177): one wavefront LANE per hypothesis.
+// Each lane owns a private 9x9 work matrix W, a 9x9 V (two-sided Jacobi SVD, Eigen 3.3.4 JacobiSVD restated)
+// and the temporaries of the optional k-estimation (6x6 LU inverse + Hessenberg/Francis-QR eigenvalues), all
+// held in LDS with a lane-interleaved layout  element e of lane l  at  lds[e * 64 + l]  -- every dynamic index
+// is the same across lanes of an instruction, so ds_read_b64/ds_write_b64 are conflict-free and nothing spills
+// to scratch.  One wave per workgroup (the per-lane state is 1.3 KB without / 2.3 KB with k-estimation, i.e.
+// 83 KB / 150 KB of the CU's 160 KB LDS).  T is at most a few thousand: this kernel is latency-bound and tiny;
+// correctness and agreement with the CPU oracle (same algorithms, same operation order) matter, not FLOPs.
+#include <float.h>
+
+#include "device_math.hpp"
+#include "rsdsfm_internal.hpp"
+
+namespace rsdsfm {
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+
+// lane-interleaved LDS vector: v[i] is element i of this lane
+struct LVec {
+    double* p;
+    __device__ __forceinline__ double& operator[](int i) const { return p[i * 64]; }
+    __device__ __forceinline__ LVec at(int off) const { return LVec{p + off * 64}; }
+};
+
+struct Rot {
+    double c, s;
+};
+
+// Jacobi.h JacobiRotation::makeJacobi(x, y, z)
+__device__ __forceinline__ Rot make_jacobi(double x, double y, double z) {
+    Rot j;
+    double deno = 2.0 * fabs(y);
+    if (deno < DBL_MIN) {
+        j.c = 1.0;
+        j.s = 0.0;
+    } else {
+        double tau = (x - z) / deno;
+        double w = sqrt(tau * tau + 1.0);
+        double t = (tau > 0.0) ? 1.0 / (tau + w) : 1.0 / (tau - w);
+        double sign_t = t > 0.0 ? 1.0 : -1.0;
+        double n = 1.0 / sqrt(t * t + 1.0);
+        j.s = -sign_t * (y / fabs(y)) * fabs(t) * n;
+        j.c = n;
+    }
+    return j;
+}
+
+// x' = c x + s y ; y' = -s x + c y over n strided elements of M
+__device__ __forceinline__ void rot_plane(LVec M, int x0, int incx, int y0, int incy, int n, Rot j) {
+    if (j.c == 1.0 && j.s == 0.0) return;
+    for (int i = 0; i < n; ++i) {
+        double xi = M[x0 + i * incx], yi = M[y0 + i * incy];
+        M[x0 + i * incx] = j.c * xi + j.s * yi;
+        M[y0 + i * incy] = -j.s * xi + j.c * yi;
+    }
+}
+
+// JacobiSVD.h real_2x2_jacobi_svd on W(p,q)
+__device__ __forceinline__ void real_2x2_jacobi_svd(LVec W, int p, int q, Rot& jl, Rot& jr) {
+    double m0 = W[p * 9 + p], m1 = W[p * 9 + q], m2 = W[q * 9 + p], m3 = W[q * 9 + q];
+    Rot rot1;
+    double t = m0 + m3;
+    double d = m2 - m1;
+    if (fabs(d) < DBL_MIN) {
+        rot1.s = 0.0;
+        rot1.c = 1.0;
+    } else {
+        double u = t / d;
+        double tmp = sqrt(1.0 + u * u);
+        rot1.s = 1.0 / tmp;
+        rot1.c = u / tmp;
+    }
+    if (!(rot1.c == 1.0 && rot1.s == 0.0)) {  // m.applyOnTheLeft(0,1,rot1)
+        double a0 = rot1.c * m0 + rot1.s * m2, a2 = -rot1.s * m0 + rot1.c * m2;
+        double a1 = rot1.c * m1 + rot1.s * m3, a3 = -rot1.s * m1 + rot1.c * m3;
+        m0 = a0, m1 = a1, m2 = a2, m3 = a3;
+    }
+    jr = make_jacobi(m0, m1, m3);
+    Rot jt = {jr.c, -jr.s};
+    jl.c = rot1.c * jt.c - rot1.s * jt.s;
+    jl.s = rot1.c * jt.s + rot1.s * jt.c;
+}
+
+// Two-sided Jacobi SVD of the 9x9 in W (destroyed); V accumulates the right rotations; sv/col: 9 slots each.
+// On return e[i] = V(i, column of the smallest singular value) is written to `e_out`.
+__device__ void jacobi_svd9_nullvec(LVec W, LVec V, LVec sv, LVec col, double e_out[9]) {
+    const double precision = 2.0 * DBL_EPSILON;
+    double scale = 0.0;
+    for (int i = 0; i < 81; ++i) scale = fmax(scale, fabs(W[i]));
+    if (scale == 0.0) scale = 1.0;
+    for (int i = 0; i < 81; ++i) W[i] = W[i] / scale;
+    for (int i = 0; i < 9; ++i)
+        for (int j = 0; j < 9; ++j) V[i * 9 + j] = (i == j) ? 1.0 : 0.0;
+    double max_diag = 0.0;
+    for (int i = 0; i < 9; ++i) max_diag = fmax(max_diag, fabs(W[i * 9 + i]));
+    bool finished = false;
+    int sweeps = 0;
+    while (!finished && sweeps < 1000) {
+        finished = true;
+        ++sweeps;
+        for (int p = 1; p < 9; ++p) {
+            for (int q = 0; q < p; ++q) {
+                double threshold = precision * max_diag;
+                if (threshold < DBL_MIN) threshold = DBL_MIN;
+                if (fabs(W[p * 9 + q]) > threshold || fabs(W[q * 9 + p]) > threshold) {
+                    finished = false;
+                    Rot jl, jr;
+                    real_2x2_jacobi_svd(W, p, q, jl, jr);
+                    rot_plane(W, p * 9, 1, q * 9, 1, 9, jl);  // applyOnTheLeft: rows p, q
+                    Rot jrt = {jr.c, -jr.s};
+                    rot_plane(W, p, 9, q, 9, 9, jrt);  // applyOnTheRight: cols p, q
+                    rot_plane(V, p, 9, q, 9, 9, jrt);
+                    max_diag = fmax(max_diag, fmax(fabs(W[p * 9 + p]), fabs(W[q * 9 + q])));
+                }
+            }
+        }
+    }
+    for (int i = 0; i < 9; ++i) {
+        sv[i] = fabs(W[i * 9 + i]) * scale;
+        col[i] = (double)i;
+    }
+    // selection sort, descending (JacobiSVD step 4); track the column permutation instead of moving V
+    for (int i = 0; i < 9; ++i) {
+        int pos = i;
+        double best = sv[i];
+        for (int j = i + 1; j < 9; ++j) {
+            double sj = sv[j];
+            if (sj > best) {
+                best = sj;
+                pos = j;
+            }
+        }
+        if (best == 0.0) break;
+        if (pos != i) {
+            double t = sv[i];
+            sv[i] = sv[pos];
+            sv[pos] = t;
+            double tc = col[i];
+            col[i] = col[pos];
+            col[pos] = tc;
+        }
+    }
+    const int c8 = (int)col[8];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) e_out[i] = V[i * 9 + c8];
+}
+
+// PartialPivLU inverse (MatrixXd::inverse()), row-major n x n (n = 3 or 6).  A, Ainv, lu: n*n slots; piv, y: n slots.
+__device__ int inverse_lu(LVec A, int n, LVec Ainv, LVec lu, LVec piv, LVec y) {
+    for (int i = 0; i < n * n; ++i) lu[i] = A[i];
+    for (int i = 0; i < n; ++i) piv[i] = (double)i;
+    for (int k = 0; k < n; ++k) {
+        int pr = k;
+        double best = fabs(lu[k * n + k]);
+        for (int i = k + 1; i < n; ++i) {
+            double c = fabs(lu[i * n + k]);
+            if (c > best) {
+                best = c;
+                pr = i;
+            }
+        }
+        if (best == 0.0) return -1;
+        if (pr != k) {
+            for (int j = 0; j < n; ++j) {
+                double t = lu[k * n + j];
+                lu[k * n + j] = lu[pr * n + j];
+                lu[pr * n + j] = t;
+            }
+            double ti = piv[k];
+            piv[k] = piv[pr];
+            piv[pr] = ti;
+        }
+        for (int i = k + 1; i < n; ++i) {
+            double f = lu[i * n + k] / lu[k * n + k];
+            lu[i * n + k] = f;
+            for (int j = k + 1; j < n; ++j) lu[i * n + j] -= f * lu[k * n + j];
+        }
+    }
+    for (int c = 0; c < n; ++c) {
+        for (int i = 0; i < n; ++i) {
+            double s = ((int)piv[i] == c) ? 1.0 : 0.0;
+            for (int j = 0; j < i; ++j) s -= lu[i * n + j] * y[j];
+            y[i] = s;
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            double s = y[i];
+            for (int j = i + 1; j < n; ++j) s -= lu[i * n + j] * Ainv[j * n + c];
+            Ainv[i * n + c] = s / lu[i * n + i];
+        }
+    }
+    return 0;
+}
+
+// eigenvalues of the general real 6x6 in H (destroyed): Householder Hessenberg + Francis double-shift QR (hqr).
+// Eigenvalues are stored by index (re = ev[0..6), im = ev[6..12)) so that the caller can scan them in index
+// order exactly like minimal.cc:75-80.
+__device__ int eig6_values(LVec H, LVec ort, LVec ev) {
+    const int nn = 6;
+    for (int m = 1; m < nn - 1; ++m) {
+        double scale = 0.0;
+        for (int i = m; i < nn; ++i) scale += fabs(H[i * nn + m - 1]);
+        if (scale == 0.0) continue;
+        double hh = 0.0;
+        for (int i = nn - 1; i >= m; --i) {
+            double o = H[i * nn + m - 1] / scale;
+            ort[i] = o;
+            hh += o * o;
+        }
+        double g = sqrt(hh);
+        if (ort[m] > 0) g = -g;
+        hh -= ort[m] * g;
+        ort[m] = ort[m] - g;
+        for (int j = m; j < nn; ++j) {
+            double f = 0.0;
+            for (int i = nn - 1; i >= m; --i) f += ort[i] * H[i * nn + j];
+            f /= hh;
+            for (int i = m; i < nn; ++i) H[i * nn + j] -= f * ort[i];
+        }
+        for (int i = 0; i < nn; ++i) {
+            double f = 0.0;
+            for (int j = nn - 1; j >= m; --j) f += ort[j] * H[i * nn + j];
+            f /= hh;
+            for (int j = m; j < nn; ++j) H[i * nn + j] -= f * ort[j];
+        }
+        ort[m] = ort[m] * scale;
+        H[m * nn + m - 1] = scale * g;
+        for (int i = m + 1; i < nn; ++i) H[i * nn + m - 1] = 0.0;
+    }
+    int n = nn - 1;
+    const int low = 0;
+    const double eps = DBL_EPSILON;
+    double exshift = 0.0, p = 0, q = 0, r = 0, s = 0, z = 0, w, x, y;
+    double norm = 0.0;
+    for (int i = 0; i < nn; ++i)
+        for (int j = (i - 1 > 0 ? i - 1 : 0); j < nn; ++j) norm += fabs(H[i * nn + j]);
+    int iter = 0, total = 0;
+    while (n >= low) {
+        if (++total > 10000) return -2;
+        int l = n;
+        while (l > low) {
+            s = fabs(H[(l - 1) * nn + l - 1]) + fabs(H[l * nn + l]);
+            if (s == 0.0) s = norm;
+            if (fabs(H[l * nn + l - 1]) < eps * s) break;
+            l--;
+        }
+        if (l == n) {
+            double hnn = H[n * nn + n] + exshift;
+            H[n * nn + n] = hnn;
+            ev[n] = hnn;
+            ev[6 + n] = 0.0;
+            n--;
+            iter = 0;
+        } else if (l == n - 1) {
+            w = H[n * nn + n - 1] * H[(n - 1) * nn + n];
+            p = (H[(n - 1) * nn + n - 1] - H[n * nn + n]) / 2.0;
+            q = p * p + w;
+            z = sqrt(fabs(q));
+            H[n * nn + n] = H[n * nn + n] + exshift;
+            H[(n - 1) * nn + n - 1] = H[(n - 1) * nn + n - 1] + exshift;
+            x = H[n * nn + n];
+            double re_lo, re_hi, im_lo, im_hi;  // index n-1 and n
+            if (q >= 0) {
+                z = (p >= 0) ? p + z : p - z;
+                re_lo = x + z;
+                re_hi = re_lo;
+                if (z != 0.0) re_hi = x - w / z;
+                im_lo = 0.0;
+                im_hi = 0.0;
+            } else {
+                re_lo = x + p;
+                re_hi = x + p;
+                im_lo = z;
+                im_hi = -z;
+            }
+            ev[n - 1] = re_lo;
+            ev[n] = re_hi;
+            ev[6 + n - 1] = im_lo;
+            ev[6 + n] = im_hi;
+            n -= 2;
+            iter = 0;
+        } else {
+            x = H[n * nn + n];
+            y = 0.0;
+            w = 0.0;
+            if (l < n) {
+                y = H[(n - 1) * nn + n - 1];
+                w = H[n * nn + n - 1] * H[(n - 1) * nn + n];
+            }
+            if (iter == 10) {
+                exshift += x;
+                for (int i = low; i <= n; ++i) H[i * nn + i] -= x;
+                s = fabs(H[n * nn + n - 1]) + fabs(H[(n - 1) * nn + n - 2]);
+                x = y = 0.75 * s;
+                w = -0.4375 * s * s;
+            }
+            if (iter == 30) {
+                s = (y - x) / 2.0;
+                s = s * s + w;
+                if (s > 0) {
+                    s = sqrt(s);
+                    if (y < x) s = -s;
+                    s = x - w / ((y - x) / 2.0 + s);
+                    for (int i = low; i <= n; ++i) H[i * nn + i] -= s;
+                    exshift += s;
+                    x = y = w = 0.964;
+                }
+            }
+            iter++;
+            int m = n - 2;
+            while (m >= l) {
+                z = H[m * nn + m];
+                r = x - z;
+                s = y - z;
+                p = (r * s - w) / H[(m + 1) * nn + m] + H[m * nn + m + 1];
+                q = H[(m + 1) * nn + m + 1] - z - r - s;
+                r = H[(m + 2) * nn + m + 1];
+                s = fabs(p) + fabs(q) + fabs(r);
+                p /= s;
+                q /= s;
+                r /= s;
+                if (m == l) break;
+                if (fabs(H[m * nn + m - 1]) * (fabs(q) + fabs(r)) <
+                    eps * (fabs(p) * (fabs(H[(m - 1) * nn + m - 1]) + fabs(z) + fabs(H[(m + 1) * nn + m + 1]))))
+                    break;
+                m--;
+            }
+            for (int i = m + 2; i <= n; ++i) {
+                H[i * nn + i - 2] = 0.0;
+                if (i > m + 2) H[i * nn + i - 3] = 0.0;
+            }
+            for (int k = m; k <= n - 1; ++k) {
+                const bool notlast = (k != n - 1);
+                if (k != m) {
+                    p = H[k * nn + k - 1];
+                    q = H[(k + 1) * nn + k - 1];
+                    r = notlast ? H[(k + 2) * nn + k - 1] : 0.0;
+                    x = fabs(p) + fabs(q) + fabs(r);
+                    if (x != 0.0) {
+                        p /= x;
+                        q /= x;
+                        r /= x;
+                    }
+                }
+                if (x == 0.0) break;
+                s = sqrt(p * p + q * q + r * r);
+                if (p < 0) s = -s;
+                if (s != 0) {
+                    if (k != m)
+                        H[k * nn + k - 1] = -s * x;
+                    else if (l != m)
+                        H[k * nn + k - 1] = -H[k * nn + k - 1];
+                    p += s;
+                    x = p / s;
+                    y = q / s;
+                    z = r / s;
+                    q /= p;
+                    r /= p;
+                    for (int j = k; j < nn; ++j) {
+                        p = H[k * nn + j] + q * H[(k + 1) * nn + j];
+                        if (notlast) {
+                            p += r * H[(k + 2) * nn + j];
+                            H[(k + 2) * nn + j] -= p * z;
+                        }
+                        H[k * nn + j] -= p * x;
+                        H[(k + 1) * nn + j] -= p * y;
+                    }
+                    const int imax = (n < k + 3) ? n : k + 3;
+                    for (int i = 0; i <= imax; ++i) {
+                        p = x * H[i * nn + k] + y * H[i * nn + k + 1];
+                        if (notlast) {
+                            p += z * H[i * nn + k + 2];
+                            H[i * nn + k + 2] -= p * r;
+                        }
+                        H[i * nn + k] -= p;
+                        H[i * nn + k + 1] -= p * q;
+                    }
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+// ---- 3x3 helpers in registers (fully unrolled, statically indexed) ----
+__device__ __forceinline__ void mm3(const double (&A)[9], const double (&B)[9], double (&C)[9]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) s += A[i * 3 + t] * B[t * 3 + j];
+            C[i * 3 + j] = s;
+        }
+}
+__device__ __forceinline__ void tr3(const double (&A)[9], double (&At)[9]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) At[j * 3 + i] = A[i * 3 + j];
+}
+// Eigen AngleAxisd(angle, axis).toRotationMatrix()
+__device__ __forceinline__ void angle_axis_R(double angle, double ax0, double ax1, double ax2, double (&R)[9]) {
+    double sn = sin(angle), c = cos(angle);
+    double sa0 = sn * ax0, sa1 = sn * ax1, sa2 = sn * ax2;
+    double c0 = (1.0 - c) * ax0, c1 = (1.0 - c) * ax1, c2 = (1.0 - c) * ax2;
+    double tmp;
+    tmp = c0 * ax1;
+    R[1] = tmp - sa2;
+    R[3] = tmp + sa2;
+    tmp = c0 * ax2;
+    R[2] = tmp + sa1;
+    R[6] = tmp - sa1;
+    tmp = c1 * ax2;
+    R[5] = tmp - sa0;
+    R[7] = tmp + sa0;
+    R[0] = c0 * ax0 + c;
+    R[4] = c1 * ax1 + c;
+    R[8] = c2 * ax2 + c;
+}
+
+// cyclic Jacobi eigen-solver of a symmetric 3x3 (ascending eigenvalues); mirrors rso_eig_sym3
+__device__ void eig_sym3(const double (&S)[9], double (&lam)[3], double (&V)[9]) {
+    double a[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        a[i] = S[i];
+        V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+    }
+    for (int sweep = 0; sweep < 64; ++sweep) {
+        bool rotated = false;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                double apq = a[p * 3 + q];
+                if (apq != 0.0) {
+                    if (fabs(apq) <= 1e-20 * (fabs(a[p * 3 + p]) + fabs(a[q * 3 + q]))) {
+                        a[p * 3 + q] = a[q * 3 + p] = 0.0;
+                    } else {
+                        rotated = true;
+                        double theta = (a[q * 3 + q] - a[p * 3 + p]) / (2.0 * apq);
+                        double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            double akp = a[k * 3 + p], akq = a[k * 3 + q];
+                            a[k * 3 + p] = c * akp - s * akq;
+                            a[k * 3 + q] = s * akp + c * akq;
+                        }
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            double apk = a[p * 3 + k], aqk = a[q * 3 + k];
+                            a[p * 3 + k] = c * apk - s * aqk;
+                            a[q * 3 + k] = s * apk + c * aqk;
+                        }
+                        a[p * 3 + q] = a[q * 3 + p] = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            double vkp = V[k * 3 + p], vkq = V[k * 3 + q];
+                            V[k * 3 + p] = c * vkp - s * vkq;
+                            V[k * 3 + q] = s * vkp + c * vkq;
+                        }
+                    }
+                }
+            }
+        }
+        if (!rotated) break;
+    }
+    lam[0] = a[0];
+    lam[1] = a[4];
+    lam[2] = a[8];
+    // bubble sort ascending with the oracle's comparison sequence (0,1),(1,2),(0,1)
+#define RSDSFM_CSWAP(j)                               \
+    if (lam[j] > lam[j + 1]) {                        \
+        double t_ = lam[j];                           \
+        lam[j] = lam[j + 1];                          \
+        lam[j + 1] = t_;                              \
+        _Pragma("unroll") for (int r_ = 0; r_ < 3; ++r_) { \
+            double tv_ = V[r_ * 3 + j];               \
+            V[r_ * 3 + j] = V[r_ * 3 + j + 1];        \
+            V[r_ * 3 + j + 1] = tv_;                  \
+        }                                             \
+    }
+    RSDSFM_CSWAP(0)
+    RSDSFM_CSWAP(1)
+    RSDSFM_CSWAP(0)
+#undef RSDSFM_CSWAP
+}
+
+constexpr int kSlotsNoK = 81 + 81 + 18;           // W, V, sv/col
+constexpr int kSlotsK = 294;                      // + k-estimation temporaries (partly overlaid on V / sv / col)
+
+}  // namespace
+
+// hyp_out: [T][8] = w(3), v(3), k, status (0 ok, -1 no real k, -2 singular system)
+__global__ __launch_bounds__(64) void minimal9_kernel(const double* __restrict__ q, const double* __restrict__ u,
+                                                     const double* __restrict__ alpha,
+                                                     const double* __restrict__ alpha_k,
+                                                     const int32_t* __restrict__ samples, int T, int use_alpha_k,
+                                                     int k_sign_mode, double* __restrict__ hyp_out) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int t = blockIdx.x * 64 + lane;
+    if (t >= T) return;  // per-lane independent work, no workgroup barriers below
+    LVec base{lds + lane};
+    LVec Z = base.at(0), V = base.at(81), sv = base.at(162), col = base.at(171);
+
+    // ---- gather the 9 points (minimal.cc:240-243) and build Z (minimal.cc:45-54) ----
+    double al[9], alk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int64_t idx = samples ? (int64_t)samples[t * 9 + i] : (int64_t)t * 9 + i;
+        const double x = q[2 * idx], y = q[2 * idx + 1], ux = u[2 * idx], uy = u[2 * idx + 1];
+        al[i] = alpha[idx];
+        alk[i] = alpha_k[idx];
+        Z[i * 9 + 0] = -uy;
+        Z[i * 9 + 1] = ux;
+        Z[i * 9 + 2] = uy * x - ux * y;
+        Z[i * 9 + 3] = x * x;
+        Z[i * 9 + 4] = 2.0 * x * y;
+        Z[i * 9 + 5] = 2.0 * x;
+        Z[i * 9 + 6] = y * y;
+        Z[i * 9 + 7] = 2 * y;
+        Z[i * 9 + 8] = 1.0;
+    }
+    int rc = 0;
+    double k = 0.0;
+    double beta[9];
+    if (use_alpha_k) {
+        // minimal.cc:58-80; temporaries live after the SVD slots
+        // region A = the (not yet used) V / sv / col slots [81, 180); region B = [180, 294)
+        LVec P = base.at(81), PK = base.at(117), a = base.at(153), a_inv = base.at(162), piv = base.at(171);
+        LVec lu = base.at(180), PKinv = base.at(216), dga = base.at(252), yv = base.at(270), ort = base.at(276),
+             ev = base.at(282);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) a[i * 3 + j] = Z[i * 9 + j];
+        if (inverse_lu(a, 3, a_inv, lu, piv, yv) != 0) {
+            k = INFINITY;
+            rc = -2;
+        } else {
+            // dga = dg * a_inv  (dg = Z[3:9, 0:3])
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 3; ++j) {
+                    double s = 0.0;
+                    for (int tt = 0; tt < 3; ++tt) s += Z[(3 + i) * 9 + tt] * a_inv[tt * 3 + j];
+                    dga[i * 3 + j] = s;
+                }
+            for (int which = 0; which < 2; ++which) {
+                LVec dst = which == 0 ? P : PK;
+                const double d0 = which == 0 ? al[0] : alk[0], d1 = which == 0 ? al[1] : alk[1],
+                             d2 = which == 0 ? al[2] : alk[2];
+                for (int i = 0; i < 6; ++i) {
+                    // al[3 + i] with a dynamic index: pick it from registers without spilling
+                    double ali = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r)
+                        if (r == i) ali = which == 0 ? al[3 + r] : alk[3 + r];
+                    for (int j = 0; j < 6; ++j) {
+                        // (dga * diag(alpha_f3)) * bc ,  bc = Z[0:3, 3:9]
+                        double s = 0.0;
+                        s += (dga[i * 3 + 0] * d0) * Z[0 * 9 + 3 + j];
+                        s += (dga[i * 3 + 1] * d1) * Z[1 * 9 + 3 + j];
+                        s += (dga[i * 3 + 2] * d2) * Z[2 * 9 + 3 + j];
+                        dst[i * 6 + j] = ali * Z[(3 + i) * 9 + 3 + j] - s;                        // efhj = Z[3:9, 3:9]
+                    }
+                }
+            }
+            if (inverse_lu(PK, 6, PKinv, lu, piv, yv) != 0) {
+                k = INFINITY;
+                rc = -2;
+            } else {
+                LVec M = lu;  // lu is free again
+                for (int i = 0; i < 6; ++i)
+                    for (int j = 0; j < 6; ++j) {
+                        double s = 0.0;
+                        for (int tt = 0; tt < 6; ++tt) s += P[i * 6 + tt] * PKinv[tt * 6 + j];
+                        M[i * 6 + j] = s;
+                    }
+                if (eig6_values(M, ort, ev) != 0) {
+                    k = INFINITY;
+                    rc = -2;
+                } else {
+                    k = INFINITY;  // real eigenvalue of smallest magnitude (minimal.cc:75-80)
+                    for (int i = 0; i < 6; ++i)
+                        if (fabs(ev[6 + i]) < 0.00001 && fabs(ev[i]) < fabs(k)) k = ev[i];
+                    if (isinf(k)) rc = -1;
+                    if (k_sign_mode == RSDSFM_K_FIXED && !isinf(k)) k = -k;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) beta[i] = (al[i] + k * alk[i]) * (2.0 / (2.0 + k));
+    } else {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) beta[i] = al[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+        for (int j = 3; j < 9; ++j) Z[i * 9 + j] = Z[i * 9 + j] * beta[i];
+
+    // ---- null vector (minimal.cc:98-103) ----
+    double e[9];
+    jacobi_svd9_nullvec(Z, V, sv, col, e);
+    const double norm_v0 = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) e[i] = e[i] / norm_v0;
+
+    // ---- Ma et al. recovery of omega (minimal.cc:105-174) ----
+    const double S[9] = {e[3], e[4], e[5], e[4], e[6], e[7], e[5], e[7], e[8]};
+    double lamb[3], v1[9];
+    eig_sym3(S, lamb, v1);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        double tt = v1[r * 3 + 0];
+        v1[r * 3 + 0] = v1[r * 3 + 2];
+        v1[r * 3 + 2] = tt;
+    }
+    const double sigma0 = (2 * lamb[2] + lamb[1] - lamb[0]) / 3;
+    const double sigma1 = (lamb[2] + 2 * lamb[1] + lamb[0]) / 3;
+    const double sigma2 = (-lamb[2] + lamb[1] + 2 * lamb[0]) / 3;
+    const double lambda = sigma0 - sigma2;
+    double theta = 0;
+    if (!(lambda < 0.000001)) theta = acos(-sigma1 / lambda);
+    double r_v[9], r_u[9], r_vt[9], v_[9], u_[9], r_z1[9], r_z2[9], negv[9];
+    angle_axis_R((theta - kPi) / 2, 0, 1, 0, r_v);
+    angle_axis_R(theta, 0, 1, 0, r_u);
+    tr3(r_v, r_vt);
+    mm3(v1, r_vt, v_);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) negv[i] = -v_[i];
+    mm3(negv, r_u, u_);
+    angle_axis_R(kPi / 2, 0, 0, 1, r_z1);
+    angle_axis_R(-kPi / 2, 0, 0, 1, r_z2);
+    const double sig1[9] = {1, 0, 0, 0, 1, 0, 0, 0, 0};
+    double sig_lamb[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sig_lamb[i] = lambda * sig1[i];
+    double dots[4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+#pragma unroll
+        for (int zz = 0; zz < 2; ++zz) {
+            double t1[9], t2[9], bt[9], mm[9];
+            if (b == 0) {
+                if (zz == 0) mm3(v_, r_z1, t1); else mm3(v_, r_z2, t1);
+                mm3(t1, sig1, t2);
+                tr3(v_, bt);
+            } else {
+                if (zz == 0) mm3(u_, r_z1, t1); else mm3(u_, r_z2, t1);
+                mm3(t1, sig1, t2);
+                tr3(u_, bt);
+            }
+            mm3(t2, bt, mm);
+            dots[b * 2 + zz] = mm[7] * e[0] + mm[2] * e[1] + mm[3] * e[2];  // (M(2,1), M(0,2), M(1,0)) . v0
+        }
+    }
+    int index_max = 0;
+    double best = dots[0];
+#pragma unroll
+    for (int c = 1; c < 4; ++c)
+        if (dots[c] > best) {
+            best = dots[c];
+            index_max = c;
+        }
+    double wb[9], wz[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        wb[i] = (index_max < 2) ? u_[i] : v_[i];  // omega from the OTHER basis (minimal.cc:159-173)
+        wz[i] = (index_max % 2 == 0) ? r_z1[i] : r_z2[i];
+    }
+    double t1[9], t2[9], bt[9], w_hat[9];
+    mm3(wb, wz, t1);
+    mm3(t1, sig_lamb, t2);
+    tr3(wb, bt);
+    mm3(t2, bt, w_hat);
+    double* o = hyp_out + (int64_t)t * 8;
+    o[0] = w_hat[7];
+    o[1] = w_hat[2];
+    o[2] = w_hat[3];
+    o[3] = e[0];
+    o[4] = e[1];
+    o[5] = e[2];
+    o[6] = k;
+    o[7] = (double)rc;
+}
+
+int minimal9_launch(Ctx* c, const double* q, const double* u, const double* alpha, const double* alpha_k,
+                    const int32_t* samples, int T, int use_alpha_k, int k_sign_mode, double* hyp_out) {
+    if (T <= 0) return RSDSFM_OK;
+    const size_t lds_bytes = (size_t)(use_alpha_k ? kSlotsK : kSlotsNoK) * 64 * sizeof(double);
+    static bool attr_set = false;
+    if (!attr_set) {
+        RSDSFM_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(minimal9_kernel),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)((size_t)kSlotsK * 64 * sizeof(double))));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(minimal9_kernel, dim3((T + 63) / 64), dim3(64), lds_bytes, c->stream, q, u, alpha, alpha_k, samples, T,
+                       use_alpha_k, k_sign_mode, hyp_out);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+}  // namespace rsdsfm

@@ -1,0 +1,248 @@
+// ransac_host.hip -- host orchestration of minimal::calculateVelocities / minimal::ransac over the HIP kernels
+// (reference minimal.cc:36-177, :209-306) and their C-ABI entry points.
+#include <string.h>
+
+#include <algorithm>
+#include <unordered_map>
+#include <vector>
+
+#include "rsdsfm_internal.hpp"
+
+namespace rsdsfm {
+
+namespace {
+
+inline uint64_t splitmix64(uint64_t& state) {
+    uint64_t z = (state += 0x9E3779B97F4A7C15ULL);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+// The reference sampler (minimal.cc:226-244): a persistent index permutation, 9 partial Fisher-Yates draws per
+// trial (swap the drawn slot with the last live slot).  rand() is replaced by splitmix64(seed) (quirk Q1: the
+// reference reseeds with time(NULL) inside the loop and is not reproducible).  The permutation is kept sparse:
+// only 9 T slots ever differ from the identity.
+void sample_indices(int64_t n, int T, uint64_t seed, std::vector<int32_t>& out) {
+    std::unordered_map<int64_t, int32_t> perm;
+    auto get = [&](int64_t i) -> int32_t {
+        auto it = perm.find(i);
+        return it == perm.end() ? (int32_t)i : it->second;
+    };
+    out.resize((size_t)T * 9);
+    uint64_t st = seed;
+    for (int t = 0; t < T; ++t) {
+        int64_t n_temp = n;
+        for (int j = 0; j < 9; ++j) {
+            const int64_t r = (int64_t)(splitmix64(st) % (uint64_t)n_temp);
+            const int32_t a = get(n_temp - 1), b = get(r);
+            perm[n_temp - 1] = b;
+            perm[r] = a;
+            out[(size_t)t * 9 + j] = b;
+            n_temp--;
+        }
+    }
+}
+
+}  // namespace
+
+// Device-resident RANSAC.  d_* inputs and the arrays of `out` are device pointers (any of the out arrays may be
+// NULL); scalars of `out` and its trial_* arrays (host) are filled after one final synchronisation.
+int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n,
+                  int use_alpha_k, int T, double tol, const int32_t* h_samples, uint64_t seed, int depth_mode,
+                  int k_sign_mode, rsdsfm_ransac_out* out) {
+    if (!out) return fail(c, RSDSFM_ERR_INVALID, "null out");
+    if (n < 9) return fail(c, RSDSFM_ERR_INVALID, "ransac needs at least 9 points (the reference would compute rand() % 0)");
+    if (T < 0) return fail(c, RSDSFM_ERR_INVALID, "negative iterations");
+    if (depth_mode != RSDSFM_DEPTH_CLOSED_FORM && depth_mode != RSDSFM_DEPTH_CERES_LM) return fail(c, RSDSFM_ERR_INVALID, "unknown depth_mode");
+    if (n > (int64_t)INT32_MAX) return fail(c, RSDSFM_ERR_INVALID, "n exceeds the int32 sample index range");
+    std::vector<int32_t> samples;
+    if (T > 0) {
+        if (h_samples) {
+            samples.assign(h_samples, h_samples + (size_t)T * 9);
+            for (int32_t s : samples)
+                if (s < 0 || s >= n) return fail(c, RSDSFM_ERR_INVALID, "sample index out of range");
+        } else {
+            sample_indices(n, T, seed, samples);
+        }
+    }
+    const int Tn = std::max(T, 1);
+    const int grid = ransac_pixel_grid(c, n);
+    const int batch = std::min(Tn, kRansacBatch);
+    size_t need = Arena::need(sizeof(int32_t) * Tn * 9) + Arena::need(sizeof(double) * Tn * 8) +
+                  Arena::need(sizeof(LmState) * Tn) + Arena::need(sizeof(double) * (size_t)grid * batch * NS) +
+                  Arena::need(sizeof(int)) + 2 * Arena::need(sizeof(double) * Tn) + Arena::need(sizeof(RansacBest)) +
+                  2 * Arena::need(sizeof(int64_t) * 2048) + Arena::need(sizeof(double) * (size_t)n) + Arena::need((size_t)n) + 4096;
+    int rc = ensure_ws(c, need);
+    if (rc != RSDSFM_OK) return rc;
+    Arena ws(c->d_ws);
+    int32_t* d_samples = ws.take<int32_t>((size_t)Tn * 9);
+    double* d_hyp = ws.take<double>((size_t)Tn * 8);
+    LmState* d_states = ws.take<LmState>(Tn);
+    double* d_partials = ws.take<double>((size_t)grid * batch * NS);
+    int* d_running = ws.take<int>(1);
+    double* d_tcount = ws.take<double>(Tn);
+    double* d_terr = ws.take<double>(Tn);
+    RansacBest* d_best = ws.take<RansacBest>(1);
+    int64_t* d_bcounts = ws.take<int64_t>(2048);
+    int64_t* d_boffs = ws.take<int64_t>(2048);
+    double* d_rho = out->inv_depth ? out->inv_depth : ws.take<double>((size_t)n);
+    uint8_t* d_mask = out->mask ? out->mask : ws.take<uint8_t>((size_t)n);
+
+    rc = ensure_pinned(c, sizeof(RansacBest) + sizeof(int) + sizeof(double) * 2 * Tn + sizeof(double) * 8 * Tn + sizeof(LmState) * Tn + 64);
+    if (rc != RSDSFM_OK) return rc;
+    char* hp = static_cast<char*>(c->h_pinned);
+    RansacBest* h_best = reinterpret_cast<RansacBest*>(hp);
+    int* h_running = reinterpret_cast<int*>(hp + sizeof(RansacBest));
+    double* h_tcount = reinterpret_cast<double*>(hp + sizeof(RansacBest) + 16);
+    double* h_terr = h_tcount + Tn;
+    double* h_hyp = h_terr + Tn;
+    LmState* h_states = reinterpret_cast<LmState*>(h_hyp + (size_t)8 * Tn);
+
+    RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_states, 0, sizeof(LmState) * Tn, c->stream));
+    if (T > 0) {
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_samples, samples.data(), sizeof(int32_t) * (size_t)T * 9, hipMemcpyHostToDevice, c->stream));
+        rc = minimal9_launch(c, d_q, d_u, d_a, d_ak, d_samples, T, use_alpha_k, k_sign_mode, d_hyp);
+        if (rc != RSDSFM_OK) return rc;
+        for (int b0 = 0; b0 < T; b0 += batch) {
+            const int B = std::min(batch, T - b0);
+            if (depth_mode == RSDSFM_DEPTH_CERES_LM) {
+                for (int round = 0;; ++round) {
+                    if (round > 4 * kMaxIter) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machines did not terminate");
+                    rc = ransac_lm_round_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, d_partials, d_running, round);
+                    if (rc != RSDSFM_OK) return rc;
+                    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_running, d_running, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+                    if (*h_running == 0) break;
+                }
+            }
+            rc = ransac_score_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, depth_mode, tol, d_partials,
+                                     d_tcount + b0, d_terr + b0);
+            if (rc != RSDSFM_OK) return rc;
+        }
+    }
+    rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best);
+    if (rc != RSDSFM_OK) return rc;
+    rc = ransac_final_launch(c, d_q, d_u, d_a, d_ak, n, d_best, d_states, depth_mode, tol, d_rho, d_mask, d_bcounts, d_boffs,
+                             out->inlier_idx, out->inliers, out->alpha, out->alpha_k);
+    if (rc != RSDSFM_OK) return rc;
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, c->stream));
+    if (T > 0) {
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_tcount, d_tcount, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_terr, d_terr, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_hyp, d_hyp, sizeof(double) * 8 * T, hipMemcpyDeviceToHost, c->stream));
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_states, d_states, sizeof(LmState) * T, hipMemcpyDeviceToHost, c->stream));
+    }
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (h_best->num_inliers != h_best->num_inliers_scan) return fail(c, RSDSFM_ERR_NUMERIC, "inlier count mismatch between scoring and compaction");
+    out->num_inliers = h_best->num_inliers;
+    out->best_trial = h_best->best_trial;
+    memcpy(out->w, &h_best->hyp[0], 3 * sizeof(double));
+    memcpy(out->v, &h_best->hyp[3], 3 * sizeof(double));
+    out->k = h_best->hyp[6];
+    out->inlier_error = h_best->inlier_error;
+    for (int t = 0; t < T; ++t) {
+        if (out->trial_count) out->trial_count[t] = (int64_t)h_tcount[t];
+        if (out->trial_err) out->trial_err[t] = h_terr[t];
+        if (out->trial_vel) memcpy(out->trial_vel + (size_t)7 * t, h_hyp + (size_t)8 * t, 7 * sizeof(double));
+        if (out->trial_steps) out->trial_steps[t] = depth_mode == RSDSFM_DEPTH_CERES_LM ? h_states[t].num_successful : 1;
+    }
+    return RSDSFM_OK;
+}
+
+}  // namespace rsdsfm
+
+using namespace rsdsfm;
+
+extern "C" {
+
+int rsdsfm_calculate_velocities(rsdsfm_ctx* ctx, const double* q, const double* u, const double* alpha, const double* alpha_k,
+                                int32_t count, int use_alpha_k, int k_sign_mode, double* w, double* v, double* k) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    if (count < 0 || (count > 0 && (!q || !u || !alpha || !alpha_k || !w || !v || !k))) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    if (count == 0) return RSDSFM_OK;
+    const size_t T = (size_t)count;
+    int rc = ensure_stage(c, 2 * Arena::need(144 * T) + 2 * Arena::need(72 * T) + Arena::need(64 * T));
+    if (rc != RSDSFM_OK) return rc;
+    Arena sa(c->d_stage);
+    double* d_q = sa.take<double>(18 * T);
+    double* d_u = sa.take<double>(18 * T);
+    double* d_a = sa.take<double>(9 * T);
+    double* d_ak = sa.take<double>(9 * T);
+    double* d_h = sa.take<double>(8 * T);
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_q, q, 144 * T, hipMemcpyHostToDevice, c->stream));
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_u, u, 144 * T, hipMemcpyHostToDevice, c->stream));
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_a, alpha, 72 * T, hipMemcpyHostToDevice, c->stream));
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_ak, alpha_k, 72 * T, hipMemcpyHostToDevice, c->stream));
+    rc = minimal9_launch(c, d_q, d_u, d_a, d_ak, nullptr, count, use_alpha_k, k_sign_mode, d_h);
+    if (rc != RSDSFM_OK) return rc;
+    std::vector<double> h(8 * T);
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h.data(), d_h, 64 * T, hipMemcpyDeviceToHost, c->stream));
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    int worst = 0;
+    for (size_t t = 0; t < T; ++t) {
+        memcpy(w + 3 * t, &h[8 * t], 3 * sizeof(double));
+        memcpy(v + 3 * t, &h[8 * t + 3], 3 * sizeof(double));
+        k[t] = h[8 * t + 6];
+        if (h[8 * t + 7] != 0.0) worst = (int)h[8 * t + 7];
+    }
+    if (worst != 0) return fail(c, RSDSFM_ERR_NUMERIC, worst == -1 ? "no real eigenvalue k for at least one hypothesis" : "singular system in the k estimation");
+    return RSDSFM_OK;
+}
+
+int rsdsfm_ransac_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_u, const double* d_alpha, const double* d_alpha_k,
+                      int64_t n, int use_alpha_k, int32_t iterations, double tolerance, const int32_t* samples, uint64_t seed,
+                      int depth_mode, int k_sign_mode, rsdsfm_ransac_out* out) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    if (!d_q || !d_u || !d_alpha || !d_alpha_k) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
+    return ransac_device(c, d_q, d_u, d_alpha, d_alpha_k, n, use_alpha_k, iterations, tolerance, samples, seed, depth_mode, k_sign_mode, out);
+}
+
+int rsdsfm_ransac(rsdsfm_ctx* ctx, const double* q, const double* u, const double* alpha, const double* alpha_k, int64_t n,
+                  int use_alpha_k, int32_t iterations, double tolerance, const int32_t* samples, uint64_t seed, int depth_mode,
+                  int k_sign_mode, rsdsfm_ransac_out* out) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    if (!out || !q || !u || !alpha || !alpha_k) return fail(c, RSDSFM_ERR_INVALID, "null pointer");
+    if (n < 9) return fail(c, RSDSFM_ERR_INVALID, "ransac needs at least 9 points (the reference would compute rand() % 0)");
+    const size_t N = (size_t)n;
+    int rc = ensure_stage(c, 2 * Arena::need(16 * N) + 6 * Arena::need(8 * N) + Arena::need(24 * N) + Arena::need(N) + 4096);
+    if (rc != RSDSFM_OK) return rc;
+    Arena sa(c->d_stage);
+    double* d_q = sa.take<double>(2 * N);
+    double* d_u = sa.take<double>(2 * N);
+    double* d_a = sa.take<double>(N);
+    double* d_ak = sa.take<double>(N);
+    rsdsfm_ransac_out dev = *out;
+    dev.inlier_idx = sa.take<int64_t>(N);
+    dev.inliers = sa.take<double>(3 * N);
+    dev.alpha = sa.take<double>(N);
+    dev.alpha_k = sa.take<double>(N);
+    dev.inv_depth = sa.take<double>(N);
+    dev.mask = sa.take<uint8_t>(N);
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_q, q, 16 * N, hipMemcpyHostToDevice, c->stream));
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_u, u, 16 * N, hipMemcpyHostToDevice, c->stream));
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_a, alpha, 8 * N, hipMemcpyHostToDevice, c->stream));
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_ak, alpha_k, 8 * N, hipMemcpyHostToDevice, c->stream));
+    rc = ransac_device(c, d_q, d_u, d_a, d_ak, n, use_alpha_k, iterations, tolerance, samples, seed, depth_mode, k_sign_mode, &dev);
+    if (rc != RSDSFM_OK) return rc;
+    const size_t M = (size_t)dev.num_inliers;
+    if (out->inlier_idx && M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(out->inlier_idx, dev.inlier_idx, 8 * M, hipMemcpyDeviceToHost, c->stream));
+    if (out->inliers && M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(out->inliers, dev.inliers, 24 * M, hipMemcpyDeviceToHost, c->stream));
+    if (out->alpha && M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(out->alpha, dev.alpha, 8 * M, hipMemcpyDeviceToHost, c->stream));
+    if (out->alpha_k && M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(out->alpha_k, dev.alpha_k, 8 * M, hipMemcpyDeviceToHost, c->stream));
+    if (out->inv_depth) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(out->inv_depth, dev.inv_depth, 8 * N, hipMemcpyDeviceToHost, c->stream));
+    if (out->mask) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(out->mask, dev.mask, N, hipMemcpyDeviceToHost, c->stream));
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    out->num_inliers = dev.num_inliers;
+    out->best_trial = dev.best_trial;
+    memcpy(out->w, dev.w, sizeof(dev.w));
+    memcpy(out->v, dev.v, sizeof(dev.v));
+    out->k = dev.k;
+    out->inlier_error = dev.inlier_error;
+    return RSDSFM_OK;
+}
+
+}  // extern "C"

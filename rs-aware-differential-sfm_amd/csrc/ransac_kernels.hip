@@ -1,0 +1,523 @@
+// ransac_kernels.hip -- hypothesis-batched RANSAC on MI355X (gfx950).
+//
+// Replaces the trial loop of minimal::ransac (reference minimal.cc:230-289) and its inlier compaction
+// (minimal.cc:291-305).  The reference runs, per trial, a Ceres depth solve of ALL points and then scores them;
+// here all T hypotheses are processed together:
+//
+//   ransac_lm_kernel      every workgroup keeps a tile of pixels in registers (48 B/pixel read ONCE per round for
+//                         all hypotheses), loops over the hypotheses and block-reduces the NS speculative-LM sums
+//                         of each (DPP wave reductions), accumulating them in LDS -> partials[block][T][NS]
+//   ransac_decide_kernel  one workgroup per hypothesis: fixed-order reduction of the partials + the Ceres
+//                         trust-region state machine (lm_advance); counts the hypotheses that need another round
+//   ransac_score_kernel   per hypothesis: replay the accepted LM steps per pixel (or closed form), residual norm,
+//                         inlier test (minimal.cc:255-275) -> partial {count, sum err}
+//   ransac_select_kernel  fixed-order reduction, then the reference's sequential best-trial rule (minimal.cc:278)
+//   ransac_final_kernel / ransac_scan_kernel / ransac_scatter_kernel
+//                         dense rho + mask of the best trial, and the order-preserving compaction of
+//                         (x, y, 1/rho), alpha, alpha_k, index (block counts -> exclusive scan -> scatter)
+//
+// Pixels are streamed (HBM-bound when T is small, VALU-bound for large T: ~250 fp64 ops per pixel-hypothesis).
+#include "device_math.hpp"
+#include "lm_common.hpp"
+#include "rsdsfm_internal.hpp"
+
+namespace rsdsfm {
+
+namespace {
+
+constexpr int kRB = 256;  // workgroup size of the pixel kernels
+constexpr int kRP = 4;    // pixels per thread per tile (register-resident across the hypothesis loop)
+
+struct Tile {
+    double x[kRP], y[kRP], ux[kRP], uy[kRP], al[kRP], ak[kRP];
+    bool ok[kRP];
+};
+
+__device__ __forceinline__ void load_tile(Tile& t, const double2* __restrict__ q, const double2* __restrict__ u,
+                                          const double* __restrict__ alpha, const double* __restrict__ alpha_k,
+                                          int64_t base, int64_t n) {
+#pragma unroll
+    for (int j = 0; j < kRP; ++j) {
+        const int64_t i = base + threadIdx.x + (int64_t)j * kRB;
+        t.ok[j] = i < n;
+        if (t.ok[j]) {
+            double2 qq = q[i], uu = u[i];
+            t.x[j] = qq.x;
+            t.y[j] = qq.y;
+            t.ux[j] = uu.x;
+            t.uy[j] = uu.y;
+            t.al[j] = alpha[i];
+            t.ak[j] = alpha_k[i];
+        } else {
+            t.x[j] = t.y[j] = t.ux[j] = t.uy[j] = 0.0;
+            t.al[j] = t.ak[j] = 1.0;
+        }
+    }
+}
+
+__device__ __forceinline__ Pose load_pose(const double* __restrict__ hyp, int t) {
+    Pose p;
+    const double* h = hyp + (int64_t)t * 8;
+    p.w[0] = h[0];
+    p.w[1] = h[1];
+    p.w[2] = h[2];
+    p.v[0] = h[3];
+    p.v[1] = h[4];
+    p.v[2] = h[5];
+    p.k = h[6];
+    return p;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// per-hypothesis speculative LM sums
+// ---------------------------------------------------------------------------------------------------
+// round 0: every hypothesis starts from the built-in plan; round r > 0: only hypotheses whose state machine is
+// still running (status 0) and expects launch r take part.  partials: [gridDim.x][T][NS].
+__global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
+                                                       const double* __restrict__ alpha,
+                                                       const double* __restrict__ alpha_k, int64_t n,
+                                                       const double* __restrict__ hyp, int T,
+                                                       const LmState* __restrict__ states,
+                                                       double* __restrict__ partials, int round) {
+    extern __shared__ double s_acc[];  // [T][NS]
+    __shared__ LmPlanLds plan;
+    __shared__ double s_red[2][kRB / 64][NS];
+    __shared__ int s_active;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < T * NS; i += kRB) s_acc[i] = 0.0;
+    if (round == 0 && tid == 0) {
+        plan.n_hist = 0;
+        plan.K = KMAX;
+        plan.write_which = 0;
+        double r = kInitialRadius;
+        for (int j = 0; j < KMAX; ++j) {
+            plan.inv_cand[j] = 1.0 / r;
+            r = radius_accept(r, 1.0);
+        }
+    }
+    __syncthreads();
+
+    const int64_t tile_pixels = (int64_t)kRB * kRP;
+    const int64_t ntiles = (n + tile_pixels - 1) / tile_pixels;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        Tile px;
+        load_tile(px, q, u, alpha, alpha_k, tile * tile_pixels, n);
+        for (int t = 0; t < T; ++t) {
+            if (round > 0) {
+                __syncthreads();  // previous hypothesis is done with `plan`
+                if (tid == 0) {
+                    const LmState& st = states[t];
+                    const int act = (st.status == 0 && st.next_launch == round) ? 1 : 0;
+                    s_active = act;
+                    if (act) {
+                        plan.n_hist = st.n_hist;
+                        plan.K = st.K;
+                        plan.write_which = 0;
+                    }
+                }
+                __syncthreads();
+                if (!s_active) continue;
+                if (tid < kMaxIter) plan.inv_hist[tid] = 1.0 / states[t].hist[tid];
+                if (tid < KMAX) plan.inv_cand[tid] = 1.0 / states[t].cand[tid];
+                __syncthreads();
+            }
+            const Pose pose = load_pose(hyp, t);
+            const double two_over = 2.0 / (2.0 + pose.k);
+            double acc[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] = 0.0;
+#pragma unroll
+            for (int j = 0; j < kRP; ++j)
+                if (px.ok[j]) (void)lm_pixel(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, plan, acc);
+            double(*red)[NS] = s_red[t & 1];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                double r = is_max_slot(s) ? wave_max(acc[s]) : wave_sum(acc[s]);
+                if (lane == 0) red[wv][s] = r;
+            }
+            __syncthreads();
+            if (tid < NS) {
+                double r = red[0][tid];
+                for (int w2 = 1; w2 < kRB / 64; ++w2) r = is_max_slot(tid) ? fmax(r, red[w2][tid]) : r + red[w2][tid];
+                double& a = s_acc[t * NS + tid];
+                a = is_max_slot(tid) ? fmax(a, r) : a + r;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    double* out = partials + (int64_t)blockIdx.x * T * NS;
+    for (int i = tid; i < T * NS; i += kRB) out[i] = s_acc[i];
+}
+
+// one workgroup per hypothesis
+__global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __restrict__ partials, int nblocks, int T,
+                                                           LmState* states, int64_t n, int round, int* running) {
+    __shared__ double s_red[4][NS];
+    __shared__ double s_sums[NS];
+    __shared__ LmState s_state;
+    const int t = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    LmState* state = states + t;
+    if (round > 0 && (state->status != 0 || state->next_launch != round)) return;
+    double fin[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) fin[s] = 0.0;
+    for (int b = tid; b < nblocks; b += 256) {
+        const double* row = partials + ((int64_t)b * T + t) * NS;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) fin[s] = is_max_slot(s) ? fmax(fin[s], row[s]) : fin[s] + row[s];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        double r = is_max_slot(s) ? wave_max(fin[s]) : wave_sum(fin[s]);
+        if (lane == 0) s_red[wv][s] = r;
+    }
+    {
+        const int nwords = (int)(sizeof(LmState) / sizeof(int32_t));
+        const int32_t* src = reinterpret_cast<const int32_t*>(state);
+        int32_t* dst = reinterpret_cast<int32_t*>(&s_state);
+        for (int i = tid; i < nwords; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (tid < NS) {
+        double r = s_red[0][tid];
+        for (int w2 = 1; w2 < 4; ++w2) r = is_max_slot(tid) ? fmax(r, s_red[w2][tid]) : r + s_red[w2][tid];
+        s_sums[tid] = r;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int used_K = (round == 0) ? KMAX : s_state.K;
+        lm_advance(s_state, s_sums, n, round == 0, used_K, 0, round);
+        if (s_state.status == 0) atomicAdd(running, 1);
+    }
+    __syncthreads();
+    {
+        const int nwords = (int)(sizeof(LmState) / sizeof(int32_t));
+        int32_t* dst = reinterpret_cast<int32_t*>(state);
+        const int32_t* src = reinterpret_cast<const int32_t*>(&s_state);
+        for (int i = tid; i < nwords; i += 256) dst[i] = src[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// scoring
+// ---------------------------------------------------------------------------------------------------
+// rho of one pixel under hypothesis state `st` (accepted LM steps replayed) or closed form
+__device__ __forceinline__ double hyp_rho(double x, double y, double ux, double uy, double al, double ak, const Pose& pose,
+                                          double two_over, int depth_mode, const LmPlanLds& plan) {
+    if (depth_mode == RSDSFM_DEPTH_CLOSED_FORM) return closed_form_rho(x, y, ux, uy, al, ak, pose, two_over);
+    double dummy[NS];
+    return lm_pixel(x, y, ux, uy, al, ak, pose, two_over, plan, dummy);  // plan.K == 0: replay only
+}
+
+// score partials: [gridDim.x][T][2] = {count, sum of inlier errors}
+__global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
+                                                          const double* __restrict__ alpha,
+                                                          const double* __restrict__ alpha_k, int64_t n,
+                                                          const double* __restrict__ hyp, int T,
+                                                          const LmState* __restrict__ states, int depth_mode, double tol,
+                                                          double* __restrict__ partials) {
+    extern __shared__ double s_acc[];  // [T][2]
+    __shared__ LmPlanLds plan;
+    __shared__ double s_red[2][kRB / 64][2];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < T * 2; i += kRB) s_acc[i] = 0.0;
+    __syncthreads();
+    const int64_t tile_pixels = (int64_t)kRB * kRP;
+    const int64_t ntiles = (n + tile_pixels - 1) / tile_pixels;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        Tile px;
+        load_tile(px, q, u, alpha, alpha_k, tile * tile_pixels, n);
+        for (int t = 0; t < T; ++t) {
+            if (depth_mode == RSDSFM_DEPTH_CERES_LM) {
+                __syncthreads();
+                if (tid == 0) {
+                    plan.n_hist = states[t].n_hist;
+                    plan.K = 0;
+                    plan.write_which = 0;
+                }
+                if (tid < kMaxIter) plan.inv_hist[tid] = 1.0 / states[t].hist[tid];
+                __syncthreads();
+            }
+            const Pose pose = load_pose(hyp, t);
+            const double two_over = 2.0 / (2.0 + pose.k);
+            double cnt = 0.0, es = 0.0;
+#pragma unroll
+            for (int j = 0; j < kRP; ++j) {
+                if (px.ok[j]) {
+                    const double rho = hyp_rho(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, depth_mode, plan);
+                    const double err = point_error(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, rho);
+                    if (err < tol) {
+                        cnt += 1.0;
+                        es += err;
+                    }
+                }
+            }
+            double(*red)[2] = s_red[t & 1];
+            double rc = wave_sum(cnt), re = wave_sum(es);
+            if (lane == 0) {
+                red[wv][0] = rc;
+                red[wv][1] = re;
+            }
+            __syncthreads();
+            if (tid < 2) {
+                double r = red[0][tid];
+                for (int w2 = 1; w2 < kRB / 64; ++w2) r += red[w2][tid];
+                s_acc[t * 2 + tid] += r;
+            }
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    double* out = partials + (int64_t)blockIdx.x * T * 2;
+    for (int i = tid; i < T * 2; i += kRB) out[i] = s_acc[i];
+}
+
+// fixed-order reduction of one hypothesis batch's score partials into trial_count / trial_err (already offset)
+__global__ __launch_bounds__(256) void ransac_reduce_scores_kernel(const double* __restrict__ partials, int nblocks, int T,
+                                                                  double* __restrict__ trial_count,
+                                                                  double* __restrict__ trial_err) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    double c = 0.0, e = 0.0;
+    for (int b = 0; b < nblocks; ++b) {
+        c += partials[((int64_t)b * T + t) * 2 + 0];
+        e += partials[((int64_t)b * T + t) * 2 + 1];
+    }
+    trial_count[t] = c;
+    trial_err[t] = e;
+}
+
+// the reference's best-trial rule (minimal.cc:278-285) over all trials in order: strictly more inliers, or
+// equally many with a strictly smaller error sum; the earlier trial wins ties.
+__global__ void ransac_pick_kernel(const double* __restrict__ trial_count, const double* __restrict__ trial_err, int T,
+                                   const double* __restrict__ hyp, RansacBest* best) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double best_count = -1.0, best_err = 0.0;
+    int bi = -1;
+    for (int t = 0; t < T; ++t) {
+        const double c = trial_count[t], e = trial_err[t];
+        if (c > best_count || (c == best_count && e < best_err)) {
+            best_count = c;
+            best_err = e;
+            bi = t;
+        }
+    }
+    best->best_trial = bi;
+    best->num_inliers = bi >= 0 ? (int64_t)best_count : 0;
+    best->inlier_error = best_err;
+    for (int i = 0; i < 8; ++i) best->hyp[i] = bi >= 0 ? hyp[(int64_t)bi * 8 + i] : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// best trial: dense rho + mask, then order-preserving compaction
+// ---------------------------------------------------------------------------------------------------
+// Block b owns the contiguous pixel range [b*chunk, (b+1)*chunk), chunk a multiple of kRB.
+__global__ __launch_bounds__(kRB) void ransac_final_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
+                                                          const double* __restrict__ alpha,
+                                                          const double* __restrict__ alpha_k, int64_t n, int64_t chunk,
+                                                          const RansacBest* __restrict__ best,
+                                                          const LmState* __restrict__ states, int depth_mode, double tol,
+                                                          double* __restrict__ rho_out, uint8_t* __restrict__ mask_out,
+                                                          int64_t* __restrict__ block_counts) {
+    __shared__ LmPlanLds plan;
+    __shared__ int s_cnt[kRB / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int bt = best->best_trial;
+    Pose pose;
+    pose.w[0] = best->hyp[0], pose.w[1] = best->hyp[1], pose.w[2] = best->hyp[2];
+    pose.v[0] = best->hyp[3], pose.v[1] = best->hyp[4], pose.v[2] = best->hyp[5];
+    pose.k = best->hyp[6];
+    if (depth_mode == RSDSFM_DEPTH_CERES_LM && bt >= 0) {
+        if (tid == 0) {
+            plan.n_hist = states[bt].n_hist;
+            plan.K = 0;
+            plan.write_which = 0;
+        }
+        if (tid < kMaxIter) plan.inv_hist[tid] = 1.0 / states[bt].hist[tid];
+    }
+    __syncthreads();
+    const double two_over = 2.0 / (2.0 + pose.k);
+    const int64_t i0 = (int64_t)blockIdx.x * chunk;
+    const int64_t i1 = (i0 + chunk < n) ? i0 + chunk : n;
+    int count = 0;
+    for (int64_t i = i0 + tid; i < i1; i += kRB) {
+        double2 qq = q[i], uu = u[i];
+        const double al = alpha[i], ak = alpha_k[i];
+        bool in = false;
+        double rho = 0.0;
+        if (bt >= 0) {
+            rho = hyp_rho(qq.x, qq.y, uu.x, uu.y, al, ak, pose, two_over, depth_mode, plan);
+            in = point_error(qq.x, qq.y, uu.x, uu.y, al, ak, pose, two_over, rho) < tol;
+        }
+        rho_out[i] = rho;
+        mask_out[i] = in ? 1 : 0;
+        count += in ? 1 : 0;
+    }
+    // block count (integers: order irrelevant)
+    for (int off = 32; off >= 1; off >>= 1) count += __shfl_xor(count, off, 64);
+    if (lane == 0) s_cnt[wv] = count;
+    __syncthreads();
+    if (tid == 0) {
+        int c = 0;
+        for (int w2 = 0; w2 < kRB / 64; ++w2) c += s_cnt[w2];
+        block_counts[blockIdx.x] = c;
+    }
+}
+
+// exclusive scan of the block counts (single workgroup; nblocks <= a few thousand)
+__global__ __launch_bounds__(256) void ransac_scan_kernel(const int64_t* __restrict__ block_counts, int nblocks,
+                                                         int64_t* __restrict__ block_offsets, RansacBest* best) {
+    __shared__ int64_t s_part[256];
+    const int tid = threadIdx.x;
+    const int per = (nblocks + 255) / 256;
+    int64_t sum = 0;
+    for (int j = 0; j < per; ++j) {
+        const int b = tid * per + j;
+        if (b < nblocks) sum += block_counts[b];
+    }
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t run = 0;
+        for (int i = 0; i < 256; ++i) {
+            int64_t v = s_part[i];
+            s_part[i] = run;
+            run += v;
+        }
+        best->num_inliers_scan = run;
+    }
+    __syncthreads();
+    int64_t run = s_part[tid];
+    for (int j = 0; j < per; ++j) {
+        const int b = tid * per + j;
+        if (b < nblocks) {
+            block_offsets[b] = run;
+            run += block_counts[b];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kRB) void ransac_scatter_kernel(const double2* __restrict__ q, const double* __restrict__ alpha,
+                                                            const double* __restrict__ alpha_k, int64_t n, int64_t chunk,
+                                                            const double* __restrict__ rho, const uint8_t* __restrict__ mask,
+                                                            const int64_t* __restrict__ block_offsets,
+                                                            int64_t* __restrict__ inlier_idx, double* __restrict__ inliers,
+                                                            double* __restrict__ out_alpha, double* __restrict__ out_alpha_k) {
+    __shared__ int s_wave[kRB / 64];
+    __shared__ int64_t s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t i0 = (int64_t)blockIdx.x * chunk;
+    const int64_t i1 = (i0 + chunk < n) ? i0 + chunk : n;
+    if (tid == 0) s_base = block_offsets[blockIdx.x];
+    __syncthreads();
+    for (int64_t start = i0; start < i1; start += kRB) {
+        const int64_t i = start + tid;
+        const bool in = (i < i1) && mask[i] != 0;
+        const unsigned long long bal = __ballot(in);
+        const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wv] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, total = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < kRB / 64; ++w2) {
+            const int c = s_wave[w2];
+            if (w2 < wv) woff += c;
+            total += c;
+        }
+        if (in) {
+            const int64_t o = s_base + woff + prefix;
+            double2 qq = q[i];
+            if (inlier_idx) inlier_idx[o] = i;
+            if (inliers) {
+                inliers[3 * o + 0] = qq.x;
+                inliers[3 * o + 1] = qq.y;
+                inliers[3 * o + 2] = 1.0 / rho[i];  // minimal.cc:299
+            }
+            if (out_alpha) out_alpha[o] = alpha[i];
+            if (out_alpha_k) out_alpha_k[o] = alpha_k[i];
+        }
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------
+int ransac_pixel_grid(const Ctx* c, int64_t n) {
+    const int64_t tiles = (n + (int64_t)kRB * kRP - 1) / ((int64_t)kRB * kRP);
+    int64_t g = tiles < 1 ? 1 : tiles;
+    const int64_t cap = (int64_t)c->num_cus * 4;
+    if (g > cap) {
+        const int64_t iters = (g + cap - 1) / cap;
+        g = (g + iters - 1) / iters;
+    }
+    return (int)g;
+}
+
+int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
+                           const double* hyp, int T, LmState* states, double* partials, int* running, int round) {
+    const int grid = ransac_pixel_grid(c, n);
+    hipLaunchKernelGGL(ransac_lm_kernel, dim3(grid), dim3(kRB), sizeof(double) * T * NS, c->stream,
+                       reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states,
+                       partials, round);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    RSDSFM_HIP_CHECK(c, hipMemsetAsync(running, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, states, n, round, running);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+// scores the hypothesis batch [0, T) of `hyp` / `states`; trial_count / trial_err point at the batch's slots
+int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
+                        const double* hyp, int T, const LmState* states, int depth_mode, double tol, double* partials,
+                        double* trial_count, double* trial_err) {
+    const int grid = ransac_pixel_grid(c, n);
+    hipLaunchKernelGGL(ransac_score_kernel, dim3(grid), dim3(kRB), sizeof(double) * T * 2, c->stream,
+                       reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states,
+                       depth_mode, tol, partials);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(ransac_reduce_scores_kernel, dim3((T + 255) / 256), dim3(256), 0, c->stream, partials, grid, T,
+                       trial_count, trial_err);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best) {
+    hipLaunchKernelGGL(ransac_pick_kernel, dim3(1), dim3(64), 0, c->stream, trial_count, trial_err, T, hyp, best);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
+                        RansacBest* best, const LmState* states, int depth_mode, double tol, double* rho, uint8_t* mask,
+                        int64_t* block_counts, int64_t* block_offsets, int64_t* inlier_idx, double* inliers,
+                        double* out_alpha, double* out_alpha_k) {
+    int64_t blocks = (n + kRB - 1) / kRB;
+    if (blocks < 1) blocks = 1;
+    const int64_t cap = 2048;
+    int64_t chunk = kRB;
+    if (blocks > cap) {
+        chunk = ((blocks + cap - 1) / cap) * kRB;
+        blocks = (n + chunk - 1) / chunk;
+    }
+    hipLaunchKernelGGL(ransac_final_kernel, dim3((int)blocks), dim3(kRB), 0, c->stream, reinterpret_cast<const double2*>(q),
+                       reinterpret_cast<const double2*>(u), a, ak, n, chunk, best, states, depth_mode, tol, rho, mask,
+                       block_counts);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(ransac_scan_kernel, dim3(1), dim3(256), 0, c->stream, block_counts, (int)blocks, block_offsets, best);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    if (inlier_idx || inliers || out_alpha || out_alpha_k) {
+        hipLaunchKernelGGL(ransac_scatter_kernel, dim3((int)blocks), dim3(kRB), 0, c->stream, reinterpret_cast<const double2*>(q),
+                           a, ak, n, chunk, rho, mask, block_offsets, inlier_idx, inliers, out_alpha, out_alpha_k);
+        RSDSFM_HIP_CHECK(c, hipGetLastError());
+    }
+    return RSDSFM_OK;
+}
+
+}  // namespace rsdsfm

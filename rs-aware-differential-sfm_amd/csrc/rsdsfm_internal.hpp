@@ -64,6 +64,18 @@ struct LmState {
     double cand[KMAX];
 };
 
+// device-resident result header of a RANSAC run
+struct RansacBest {
+    int32_t best_trial;
+    int32_t _pad;
+    int64_t num_inliers;       // from the score of the best trial
+    int64_t num_inliers_scan;  // total of the compaction scan (must agree)
+    double inlier_error;
+    double hyp[8];  // w(3), v(3), k, status of the best trial
+};
+
+constexpr int kRansacBatch = 128;  // hypotheses per pixel pass (LDS accumulators: 128 x NS x 8 B = 18 KB)
+
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -79,6 +91,11 @@ struct Ctx {
     // staging buffers for the host-pointer API (grown on demand)
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
+    // internal workspace of the multi-kernel pipelines (grown on demand)
+    void* d_ws = nullptr;
+    size_t ws_bytes = 0;
+    void* h_pinned = nullptr;  // small pinned host buffer for result headers
+    size_t pinned_bytes = 0;
     int num_cus = 256;
 };
 
@@ -97,6 +114,23 @@ constexpr int kDecideBlock = 256;
 
 int fail(Ctx* c, int code, const char* msg);
 int ensure_stage(Ctx* c, size_t bytes);
+int ensure_ws(Ctx* c, size_t bytes);
+int ensure_pinned(Ctx* c, size_t bytes);
+
+// bump allocator over a device arena (256-byte aligned slices)
+struct Arena {
+    char* base;
+    size_t off = 0;
+    explicit Arena(void* b) : base(static_cast<char*>(b)) {}
+    template <class T>
+    T* take(size_t count) {
+        T* p = reinterpret_cast<T*>(base + off);
+        off += need(count * sizeof(T));
+        return p;
+    }
+    static size_t need(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+};
+
 
 // depth_kernels.hip
 int depth_closed_form_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak,
@@ -113,3 +147,29 @@ int alpha_launch(Ctx* c, const double* flow_px, int64_t n, double h, double gamm
 int alpha_k_launch(Ctx* c, const double* q_px, const double* flow_px, int64_t n, double h, double gamma, double* alpha_k);
 int pose_table_launch(Ctx* c, const Pose& pose, double gamma, int rows, double* R, double* t);
 }  // namespace rsdsfm
+
+namespace rsdsfm {
+// minimal9_kernels.hip : hyp_out [T][8] = w(3), v(3), k, status
+int minimal9_launch(Ctx* c, const double* q, const double* u, const double* alpha, const double* alpha_k,
+                    const int32_t* samples, int T, int use_alpha_k, int k_sign_mode, double* hyp_out);
+}  // namespace rsdsfm
+
+namespace rsdsfm {
+// ransac_kernels.hip
+int ransac_pixel_grid(const Ctx* c, int64_t n);
+int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
+                           const double* hyp, int T, LmState* states, double* partials, int* running, int round);
+int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
+                        const double* hyp, int T, const LmState* states, int depth_mode, double tol, double* partials,
+                        double* trial_count, double* trial_err);
+int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best);
+int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
+                        RansacBest* best, const LmState* states, int depth_mode, double tol, double* rho, uint8_t* mask,
+                        int64_t* block_counts, int64_t* block_offsets, int64_t* inlier_idx, double* inliers,
+                        double* out_alpha, double* out_alpha_k);
+}  // namespace rsdsfm
+
+// the opaque handle of the C ABI
+struct rsdsfm_ctx {
+    rsdsfm::Ctx c;
+};

@@ -1,0 +1,144 @@
+"""GPU parity: batched 9-point minimal solver and hypothesis-batched RANSAC (through the C ABI) against the
+CPU oracle on identical inputs and identical injected samples.  Integer outputs (per-trial inlier counts, best
+trial, inlier mask, inlier index list, accepted LM steps) bit-exact; floats 1e-9 relative (north-star: 1e-5)."""
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def solver(rsdsfm):
+    s = rsdsfm.Solver(0)
+    yield s
+    s.close()
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_calculate_velocities_vs_oracle_and_golden(golden, oracle, solver, case):
+    g = lambda k: golden[case + "/" + k]
+    q, u, a, ak, samples = g("q"), g("u"), g("alpha"), g("alpha_k"), g("samples")
+    use_k = bool(g("use_k"))
+    W, V, K = solver.calculate_velocities(q[samples], u[samples], a[samples], ak[samples], use_k)
+    for t in range(len(samples)):
+        s = samples[t]
+        wo, vo, ko, rc = oracle.calculate_velocities(q[s], u[s], a[s], ak[s], use_k)
+        # same algorithm, same rotation order: the sign of the SVD null vector agrees as well
+        assert np.allclose(V[t], vo, atol=1e-10), (t, V[t], vo)
+        assert np.allclose(W[t], wo, atol=1e-10), (t, W[t], wo)
+        assert abs(K[t] - ko) <= 1e-9 * max(1.0, abs(ko))
+        # and the independent numpy fixture up to the null-vector sign
+        sgn = np.sign(V[t] @ g("hyp_v")[t])
+        assert np.allclose(sgn * V[t], g("hyp_v")[t], atol=1e-8)
+        assert np.allclose(W[t], g("hyp_w")[t], atol=1e-8)
+    # k_sign_mode fixed = negated k (quirk Q4)
+    if use_k:
+        W2, V2, K2 = solver.calculate_velocities(q[samples], u[samples], a[samples], ak[samples], True, k_sign_mode=1)
+        assert np.allclose(K2, -K, rtol=1e-12)
+
+
+def test_minimal_known_answer(solver, rsdsfm):
+    """noise-free model data: w_true, +-v_true/|v| recovered"""
+    d = rsdsfm.synth.make_config(1, rows=96, cols=128, v=np.array([0.03, 0.02, 0.01]), w=np.array([0.002, -0.003, 0.0087]))
+    rng = np.random.default_rng(5)
+    idx = np.stack([rng.choice(len(d["q"]), 9, replace=False) for _ in range(130)])  # > 2 workgroups of 64 lanes
+    W, V, K = solver.calculate_velocities(d["q"][idx], d["u"][idx], d["alpha"][idx], d["alpha_k"][idx], False)
+    t = d["truth"]
+    vt = t["v"] / np.linalg.norm(t["v"])
+    ok = 0
+    for i in range(len(idx)):
+        sgn = np.sign(V[i] @ vt)
+        if np.allclose(W[i], t["w"], atol=1e-7) and np.allclose(sgn * V[i], vt, atol=1e-6):
+            ok += 1
+    assert ok >= 120  # a few random 9-point samples are near-degenerate
+
+
+def _compare_ransac(r, ro, rho_rtol=1e-9):
+    assert np.array_equal(r["trial_count"], ro["trial_count"])
+    assert np.array_equal(r["trial_steps"], ro["trial_steps"])
+    assert np.allclose(r["trial_err"], ro["trial_err"], rtol=1e-9, atol=1e-12)
+    assert np.allclose(r["trial_vel"], ro["trial_vel"], rtol=1e-8, atol=1e-10)
+    assert r["best_trial"] == ro["best_trial"]
+    assert r["num_inliers"] == ro["num_inliers"]
+    assert np.array_equal(r["mask"], ro["mask"])
+    assert np.array_equal(r["inlier_idx"], ro["inlier_idx"])
+    assert np.allclose(r["inv_depth"], ro["inv_depth"], rtol=rho_rtol, atol=1e-13)
+    assert np.allclose(r["inliers"], ro["inliers"], rtol=rho_rtol, atol=1e-13)
+    assert np.array_equal(r["alpha"], ro["alpha"]) and np.array_equal(r["alpha_k"], ro["alpha_k"])
+    assert np.allclose(r["w"], ro["w"], atol=1e-10) and np.allclose(r["v"], ro["v"], atol=1e-10)
+    assert abs(r["k"] - ro["k"]) <= 1e-9 * max(1.0, abs(ro["k"]))
+
+
+@pytest.mark.parametrize("case", ["noisy_k0", "deepflow_k0", "noisy_k04"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_ransac_golden_cases(golden, oracle, solver, case, mode):
+    g = lambda k: golden[case + "/" + k]
+    q, u, a, ak, samples = g("q"), g("u"), g("alpha"), g("alpha_k"), g("samples")
+    use_k = bool(g("use_k"))
+    r = solver.ransac(q, u, a, ak, use_k, len(samples), 0.05, samples=samples, depth_mode=mode)
+    ro = oracle.ransac(q, u, a, ak, use_k, len(samples), 0.05, samples, depth_mode=mode)
+    _compare_ransac(r, ro)
+    assert np.array_equal(r["trial_count"], g("count_lm" if mode else "count_cf"))
+
+
+@pytest.mark.parametrize("T", [1, 5, 50, 130])
+def test_ransac_deepflow_like(oracle, solver, rsdsfm, T):
+    """DeepFlow-like data (0.3 px noise, 10 % outliers), tight tolerance so that the inlier sets are selective;
+    T = 130 exercises more than one hypothesis batch."""
+    d = rsdsfm.synth.make_config(3, rows=135, cols=240)
+    q, u, a, ak = d["q"], d["u"], d["alpha"], d["alpha_k"]
+    samples = oracle.sample_indices(len(q), T, 1234)
+    for mode in (0, 1):
+        r = solver.ransac(q, u, a, ak, False, T, 0.002, samples=samples, depth_mode=mode)
+        ro = oracle.ransac(q, u, a, ak, False, T, 0.002, samples, depth_mode=mode)
+        _compare_ransac(r, ro)
+        assert 0 < r["num_inliers"] < len(q)
+
+
+def test_ransac_builtin_sampler_matches_reference_sampler(oracle, solver, rsdsfm):
+    """samples=NULL: the library's sampler is the reference's partial Fisher-Yates (minimal.cc:226-244) driven by
+    splitmix64(seed) -- identical to the oracle's restatement, so the whole run matches."""
+    d = rsdsfm.synth.make_config(3, rows=90, cols=120)
+    q, u, a, ak = d["q"], d["u"], d["alpha"], d["alpha_k"]
+    T, seed = 12, 0xC0FFEE
+    r = solver.ransac(q, u, a, ak, False, T, 0.003, samples=None, seed=seed, depth_mode=1)
+    ro = oracle.ransac(q, u, a, ak, False, T, 0.003, oracle.sample_indices(len(q), T, seed), depth_mode=1)
+    _compare_ransac(r, ro)
+
+
+def test_ransac_edge_cases(oracle, solver, rsdsfm):
+    d = rsdsfm.synth.make_config(1, rows=24, cols=32)
+    q, u, a, ak = d["q"], d["u"], d["alpha"], d["alpha_k"]
+    # fewer than 9 points: error, not UB (reference Q8: rand() % 0)
+    with pytest.raises(rsdsfm.RsdsfmError):
+        solver.ransac(q[:8], u[:8], a[:8], ak[:8], False, 3, 0.05, seed=1)
+    # exactly 9 points
+    s9 = np.arange(9, dtype=np.int32).reshape(1, 9)
+    r = solver.ransac(q[:9], u[:9], a[:9], ak[:9], False, 1, 0.05, samples=s9, depth_mode=0)
+    ro = oracle.ransac(q[:9], u[:9], a[:9], ak[:9], False, 1, 0.05, s9, depth_mode=0)
+    _compare_ransac(r, ro)
+    # zero tolerance: no inliers
+    r = solver.ransac(q, u, a, ak, False, 2, 0.0, seed=3, depth_mode=1)
+    assert r["num_inliers"] == 0 and r["mask"].sum() == 0 and len(r["inlier_idx"]) == 0
+    # out-of-range injected sample index: rejected
+    bad = np.full((1, 9), len(q), dtype=np.int32)
+    with pytest.raises(rsdsfm.RsdsfmError):
+        solver.ransac(q, u, a, ak, False, 1, 0.05, samples=bad)
+
+
+def test_ransac_full_size_invariants(solver, rsdsfm):
+    """1280x720, noise-free model data, T = 8: every trial explains every point (N inliers at tol 0.05,
+    SURVEY 8c-1); permutation invariance of the scoring: reversing the point order gives the same counts."""
+    d = rsdsfm.synth.make_config(2)
+    q, u, a, ak = d["q"], d["u"], d["alpha"], d["alpha_k"]
+    n = len(q)
+    rng = np.random.default_rng(11)
+    samples = np.stack([rng.choice(n, 9, replace=False) for _ in range(8)]).astype(np.int32)
+    r = solver.ransac(q, u, a, ak, False, 8, 0.05, samples=samples, depth_mode=1)
+    assert np.all(r["trial_count"] == n) and r["num_inliers"] == n
+    assert np.array_equal(r["inlier_idx"], np.arange(n))
+    rr = solver.ransac(q[::-1], u[::-1], a[::-1], ak[::-1], False, 8, 0.05, samples=(n - 1 - samples), depth_mode=1)
+    assert np.array_equal(rr["trial_count"], r["trial_count"])
+    assert np.allclose(rr["inv_depth"][::-1], r["inv_depth"], rtol=1e-12)

@@ -153,6 +153,16 @@ int rsdsfm_pose_table(rsdsfm_ctx* ctx, const double v[3], const double w[3], dou
 int rsdsfm_estimate_inverse_depths_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n, int64_t n,
                                        const double v[3], const double w[3], double k, const double* d_alpha_n,
                                        const double* d_alpha_k_n, int depth_mode, double* d_inv_depth_n);
+/* flatten / depth map / pose table on device-resident buffers (same semantics as the host-pointer variants; the
+ * scalar results *n_out, v_inout, *flipped are returned after one synchronisation) */
+int rsdsfm_flatten_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t rows, int32_t cols, double fx, double fy,
+                       double cx, double cy, double gamma, double flow_threshold, double* d_q2n, double* d_u2n,
+                       double* d_alpha_n, double* d_alpha_k_n, int64_t* n_out);
+int rsdsfm_depth_map_dev(rsdsfm_ctx* ctx, double* d_inliers_3m_inout, int64_t m, double v_inout[3], double fx, double fy,
+                         double cx, double cy, int32_t rows, int32_t cols, double* d_depth_map_colmajor,
+                         int32_t* d_xs_or_null, int32_t* d_ys_or_null, int* flipped);
+int rsdsfm_pose_table_dev(rsdsfm_ctx* ctx, const double v[3], const double w[3], double k, double gamma, int32_t rows,
+                          double* d_R_rows9, double* d_t_rows3);
 /* minimal::ransac on device-resident inputs.  The arrays of `out` (inlier_idx, inliers, alpha, alpha_k, mask,
  * inv_depth) are DEVICE pointers with capacity n (each may be NULL); its trial_* arrays are HOST pointers.
  * samples_9xT_or_null is a HOST pointer.  Synchronises once at the end to return the scalars of `out`. */
@@ -160,6 +170,13 @@ int rsdsfm_ransac_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n,
                       const double* d_alpha_k_n, int64_t n, int use_alpha_k, int32_t iterations, double tolerance,
                       const int32_t* samples_9xT_or_null, uint64_t seed, int depth_mode, int k_sign_mode,
                       rsdsfm_ransac_out* out);
+/* nonLinearRefinement on device-resident inputs (d_inlier_idx may be NULL in compat mode).  v/w/k and the
+ * summary are HOST.  Polls the device-resident termination flag every few LM iterations. */
+int rsdsfm_refine_dev(rsdsfm_ctx* ctx, const double* d_flow2n, int64_t n_flow, int64_t m, const double* d_inliers_3m,
+                      const double* d_alpha_m, const double* d_alpha_k_m, const int64_t* d_inlier_idx_or_null,
+                      const double v_in[3], const double w_in[3], double k_in, int const_acceleration,
+                      int flow_index_mode, double* d_inliers_out_3m, double v_out[3], double w_out[3], double* k_out,
+                      rsdsfm_lm_summary* summary_or_null);
 /* One launch of the fused LM kernel (building block of the calls around it; also what bench.py brackets with
  * HIP events to time the dominant kernel).  launch_id 0 = the launch of LM iteration zero (fresh state);
  * launch_id > 0 acts only if the device state machine designated that launch. */

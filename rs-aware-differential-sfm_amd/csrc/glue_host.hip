@@ -1,0 +1,138 @@
+// glue_host.hip -- C ABI of the caller-side glue: flatten (main.cc:398-444 + getAlpha/getAlphaK), depth map
+// (main.cc:466-509), per-scanline pose table (rsframe.cc:771-800), host- and device-pointer variants.
+#include <string.h>
+
+#include "rsdsfm_internal.hpp"
+
+using namespace rsdsfm;
+
+extern "C" {
+
+int rsdsfm_flatten_dev(rsdsfm_ctx* ctx, const double* d_img, int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
+                       double gamma, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* n_out) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    if (rows < 0 || cols < 0 || !n_out) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    const int64_t n = (int64_t)rows * cols;
+    if (n == 0) {
+        *n_out = 0;
+        return RSDSFM_OK;
+    }
+    if (!d_img || !d_q || !d_u || !d_alpha || !d_alpha_k) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
+    int rc = ensure_ws(c, 2 * Arena::need(sizeof(int64_t) * 2048) + Arena::need(64) + 1024);
+    if (rc != RSDSFM_OK) return rc;
+    rc = ensure_pinned(c, 64);
+    if (rc != RSDSFM_OK) return rc;
+    Arena ws(c->d_ws);
+    int64_t* d_counts = ws.take<int64_t>(2048);
+    int64_t* d_offsets = ws.take<int64_t>(2048);
+    int64_t* d_total = ws.take<int64_t>(1);
+    rc = flatten_launch(c, d_img, rows, cols, fx, fy, cx, cy, gamma, thr, d_q, d_u, d_alpha, d_alpha_k, d_counts, d_offsets, d_total);
+    if (rc != RSDSFM_OK) return rc;
+    int64_t* h_total = static_cast<int64_t*>(c->h_pinned);
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    *n_out = *h_total;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_flatten(rsdsfm_ctx* ctx, const double* img, int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
+                   double gamma, double thr, double* q, double* u, double* alpha, double* alpha_k, int64_t* n_out) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    if (rows < 0 || cols < 0 || !n_out) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    const size_t N = (size_t)rows * (size_t)cols;
+    if (N == 0) {
+        *n_out = 0;
+        return RSDSFM_OK;
+    }
+    if (!img || !q || !u || !alpha || !alpha_k) return fail(c, RSDSFM_ERR_INVALID, "null pointer");
+    int rc = ensure_stage(c, 3 * Arena::need(16 * N) + 2 * Arena::need(8 * N) + 1024);
+    if (rc != RSDSFM_OK) return rc;
+    Arena sa(c->d_stage);
+    double* d_img = sa.take<double>(2 * N);
+    double* d_q = sa.take<double>(2 * N);
+    double* d_u = sa.take<double>(2 * N);
+    double* d_a = sa.take<double>(N);
+    double* d_ak = sa.take<double>(N);
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_img, img, 16 * N, hipMemcpyHostToDevice, c->stream));
+    int64_t cnt = 0;
+    rc = rsdsfm_flatten_dev(ctx, d_img, rows, cols, fx, fy, cx, cy, gamma, thr, d_q, d_u, d_a, d_ak, &cnt);
+    if (rc != RSDSFM_OK) return rc;
+    const size_t Mk = (size_t)cnt;
+    if (Mk) {
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(q, d_q, 16 * Mk, hipMemcpyDeviceToHost, c->stream));
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(u, d_u, 16 * Mk, hipMemcpyDeviceToHost, c->stream));
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(alpha, d_a, 8 * Mk, hipMemcpyDeviceToHost, c->stream));
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(alpha_k, d_ak, 8 * Mk, hipMemcpyDeviceToHost, c->stream));
+    }
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    *n_out = cnt;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_depth_map_dev(rsdsfm_ctx* ctx, double* d_inl, int64_t m, double v_inout[3], double fx, double fy, double cx, double cy,
+                         int32_t rows, int32_t cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, int* flipped) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    if (m < 0 || rows < 0 || cols < 0 || !v_inout) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    const size_t npix = (size_t)rows * (size_t)cols;
+    if ((m > 0 && !d_inl) || (npix > 0 && !d_depth_map)) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
+    int rc = ensure_ws(c, Arena::need(64) + Arena::need(8 * npix) + Arena::need(8 * 1024) + 1024);
+    if (rc != RSDSFM_OK) return rc;
+    rc = ensure_pinned(c, 64);
+    if (rc != RSDSFM_OK) return rc;
+    Arena ws(c->d_ws);
+    double* d_header = ws.take<double>(4);
+    long long* d_owner = ws.take<long long>(npix);
+    double* d_partials = ws.take<double>(1024);
+    rc = depth_map_launch(c, d_inl, m, v_inout, fx, fy, cx, cy, rows, cols, d_depth_map, d_xs, d_ys, d_header, d_owner, d_partials);
+    if (rc != RSDSFM_OK) return rc;
+    double* h_header = static_cast<double*>(c->h_pinned);
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_header, d_header, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (flipped) *flipped = h_header[0] != 0.0;
+    v_inout[0] = h_header[1];
+    v_inout[1] = h_header[2];
+    v_inout[2] = h_header[3];
+    return RSDSFM_OK;
+}
+
+int rsdsfm_depth_map(rsdsfm_ctx* ctx, double* inl, int64_t m, double v_inout[3], double fx, double fy, double cx, double cy,
+                     int32_t rows, int32_t cols, double* depth_map, int32_t* xs, int32_t* ys, int* flipped) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    if (m < 0 || rows < 0 || cols < 0 || !v_inout || (m > 0 && !inl)) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    const size_t M = (size_t)m, npix = (size_t)rows * (size_t)cols;
+    if (npix > 0 && !depth_map) return fail(c, RSDSFM_ERR_INVALID, "null depth_map");
+    int rc = ensure_stage(c, Arena::need(24 * M) + Arena::need(8 * npix) + 2 * Arena::need(4 * M) + 1024);
+    if (rc != RSDSFM_OK) return rc;
+    Arena sa(c->d_stage);
+    double* d_inl = sa.take<double>(3 * M);
+    double* d_map = sa.take<double>(npix);
+    int32_t* d_xs = sa.take<int32_t>(M);
+    int32_t* d_ys = sa.take<int32_t>(M);
+    if (M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_inl, inl, 24 * M, hipMemcpyHostToDevice, c->stream));
+    rc = rsdsfm_depth_map_dev(ctx, d_inl, m, v_inout, fx, fy, cx, cy, rows, cols, d_map, d_xs, d_ys, flipped);
+    if (rc != RSDSFM_OK) return rc;
+    if (M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(inl, d_inl, 24 * M, hipMemcpyDeviceToHost, c->stream));
+    if (npix) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(depth_map, d_map, 8 * npix, hipMemcpyDeviceToHost, c->stream));
+    if (xs && M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(xs, d_xs, 4 * M, hipMemcpyDeviceToHost, c->stream));
+    if (ys && M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(ys, d_ys, 4 * M, hipMemcpyDeviceToHost, c->stream));
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return RSDSFM_OK;
+}
+
+int rsdsfm_pose_table_dev(rsdsfm_ctx* ctx, const double v[3], const double w[3], double k, double gamma, int32_t rows, double* d_R,
+                          double* d_t) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    if (rows < 0 || !v || !w || (rows > 0 && (!d_R || !d_t))) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    Pose pose;
+    memcpy(pose.v, v, sizeof(pose.v));
+    memcpy(pose.w, w, sizeof(pose.w));
+    pose.k = k;
+    return pose_table_launch(c, pose, gamma, rows, d_R, d_t);
+}
+
+}  // extern "C"

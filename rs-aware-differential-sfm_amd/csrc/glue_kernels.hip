@@ -1,6 +1,10 @@
 // glue_kernels.hip -- RS scale factors, per-scanline pose table.
 //   minimal::getAlpha / getAlphaK   reference minimal.cc:179-197
 //   RsFrame::setRelativePose        reference rsframe.cc:771-800
+#include <string.h>
+
+#include <algorithm>
+
 #include "device_math.hpp"
 #include "rsdsfm_internal.hpp"
 
@@ -71,6 +75,251 @@ int alpha_k_launch(Ctx* c, const double* q_px, const double* flow_px, int64_t n,
 int pose_table_launch(Ctx* c, const Pose& pose, double gamma, int rows, double* R, double* t) {
     if (rows <= 0) return RSDSFM_OK;
     hipLaunchKernelGGL(pose_table_kernel, dim3((rows + 255) / 256), dim3(256), 0, c->stream, pose, gamma, rows, R, t);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+}  // namespace rsdsfm
+
+// =====================================================================================================
+// caller-side glue of the hot path
+//   flatten   : reference main.cc:398-444 / errorMeasure.cpp:66-111 (shrinking variant) fused with
+//               minimal::getAlpha / getAlphaK (minimal.cc:179-197)
+//   depth map : reference main.cc:466-509 (mean-z sign flip, scatter of inlier depths)
+// =====================================================================================================
+namespace rsdsfm {
+
+namespace {
+constexpr int kGB = 256;
+
+// scan position p (column-major: p = i * rows + j) -> flow of pixel (row j, col i) of the row-major image
+__device__ __forceinline__ double2 flow_at(const double2* __restrict__ img, int rows, int cols, int64_t p, int& i, int& j) {
+    i = (int)(p / rows);
+    j = (int)(p - (int64_t)i * rows);
+    return img[(int64_t)j * cols + i];
+}
+}  // namespace
+
+// pass 1: per-block count of kept pixels (|flow|^2 > thr), blocks own contiguous ranges of the scan order
+__global__ __launch_bounds__(kGB) void flatten_count_kernel(const double2* __restrict__ img, int rows, int cols, double thr,
+                                                           int64_t chunk, int64_t* __restrict__ block_counts) {
+    __shared__ int s_cnt[kGB / 64];
+    const int64_t n = (int64_t)rows * cols;
+    const int64_t p0 = (int64_t)blockIdx.x * chunk, p1 = (p0 + chunk < n) ? p0 + chunk : n;
+    int count = 0;
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += kGB) {
+        int i, j;
+        const double2 f = flow_at(img, rows, cols, p, i, j);
+        const double norm = f.x * f.x + f.y * f.y;
+        count += (norm > thr) ? 1 : 0;
+    }
+    for (int off = 32; off >= 1; off >>= 1) count += __shfl_xor(count, off, 64);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = count;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0;
+        for (int w2 = 0; w2 < kGB / 64; ++w2) c += s_cnt[w2];
+        block_counts[blockIdx.x] = c;
+    }
+}
+
+__global__ __launch_bounds__(256) void glue_scan_kernel(const int64_t* __restrict__ block_counts, int nblocks,
+                                                       int64_t* __restrict__ block_offsets, int64_t* __restrict__ total) {
+    __shared__ int64_t s_part[256];
+    const int tid = threadIdx.x;
+    const int per = (nblocks + 255) / 256;
+    int64_t sum = 0;
+    for (int j = 0; j < per; ++j) {
+        const int b = tid * per + j;
+        if (b < nblocks) sum += block_counts[b];
+    }
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t run = 0;
+        for (int i = 0; i < 256; ++i) {
+            int64_t v = s_part[i];
+            s_part[i] = run;
+            run += v;
+        }
+        *total = run;
+    }
+    __syncthreads();
+    int64_t run = s_part[tid];
+    for (int j = 0; j < per; ++j) {
+        const int b = tid * per + j;
+        if (b < nblocks) {
+            block_offsets[b] = run;
+            run += block_counts[b];
+        }
+    }
+}
+
+// pass 2: order-preserving scatter of (q, u, alpha, alpha_k)
+__global__ __launch_bounds__(kGB) void flatten_scatter_kernel(const double2* __restrict__ img, int rows, int cols, double fx,
+                                                             double fy, double cx, double cy, double gamma, double thr,
+                                                             int64_t chunk, const int64_t* __restrict__ block_offsets,
+                                                             double2* __restrict__ q, double2* __restrict__ u,
+                                                             double* __restrict__ alpha, double* __restrict__ alpha_k) {
+    __shared__ int s_wave[kGB / 64];
+    __shared__ int64_t s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t n = (int64_t)rows * cols;
+    const int64_t p0 = (int64_t)blockIdx.x * chunk, p1 = (p0 + chunk < n) ? p0 + chunk : n;
+    const double h = (double)rows;
+    if (tid == 0) s_base = block_offsets[blockIdx.x];
+    __syncthreads();
+    for (int64_t start = p0; start < p1; start += kGB) {
+        const int64_t p = start + tid;
+        int i = 0, j = 0;
+        double2 f = make_double2(0.0, 0.0);
+        bool keep = false;
+        if (p < p1) {
+            f = flow_at(img, rows, cols, p, i, j);
+            const double norm = f.x * f.x + f.y * f.y;
+            keep = norm > thr;
+        }
+        const unsigned long long bal = __ballot(keep);
+        const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wv] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, total = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < kGB / 64; ++w2) {
+            const int c = s_wave[w2];
+            if (w2 < wv) woff += c;
+            total += c;
+        }
+        if (keep) {
+            const int64_t o = s_base + woff + prefix;
+            q[o] = make_double2((i - cx) * 1.0 / fx, (j - cy) * 1.0 / fy);
+            u[o] = make_double2(f.x * gamma / fx, f.y * gamma / fy);
+            alpha[o] = 1 + gamma * f.y / h;  // minimal.cc:183 with pixel flow, h = rows (quirk Q6)
+            const double part1 = gamma * (double)j / h;
+            const double part2 = 1.0 + gamma * ((double)j + f.y) / h;
+            alpha_k[o] = 0.5 * (part2 * part2 - part1 * part1);
+        }
+        __syncthreads();
+        if (tid == 0) s_base += total;
+        __syncthreads();
+    }
+}
+
+// ---- depth map ----
+// fixed-order sum of z = inliers(2, i): per-block partials then one workgroup
+__global__ __launch_bounds__(kGB) void zsum_partial_kernel(const double* __restrict__ inl, int64_t m, double* __restrict__ partials) {
+    __shared__ double s_red[kGB / 64];
+    double acc = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kGB;
+    for (int64_t i = (int64_t)blockIdx.x * kGB + threadIdx.x; i < m; i += stride) acc += inl[3 * i + 2];
+    const double r = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = s_red[0];
+        for (int w2 = 1; w2 < kGB / 64; ++w2) t += s_red[w2];
+        partials[blockIdx.x] = t;
+    }
+}
+
+// header: [0] = flipped flag (as double), [1..3] = v after the flip
+__global__ __launch_bounds__(256) void zsum_decide_kernel(const double* __restrict__ partials, int nblocks, int64_t m, Pose pose_v,
+                                                         double* __restrict__ header) {
+    __shared__ double s_red[4];
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) acc += partials[b];
+    const double r = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double count_z = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+        const double z_mean = count_z * 1.0 / (double)m;  // main.cc:472 (NaN for m == 0: no flip)
+        const bool flip = z_mean < 0;
+        header[0] = flip ? 1.0 : 0.0;
+        header[1] = flip ? pose_v.v[0] * -1.0 : pose_v.v[0];
+        header[2] = flip ? pose_v.v[1] * -1.0 : pose_v.v[1];
+        header[3] = flip ? pose_v.v[2] * -1.0 : pose_v.v[2];
+    }
+}
+
+// flips z in place if requested, computes pixel indices, claims pixels for the HIGHEST inlier index (the
+// reference's sequential loop lets the last writer win, main.cc:499-508)
+__global__ __launch_bounds__(kGB) void depth_claim_kernel(double* __restrict__ inl, int64_t m, const double* __restrict__ header,
+                                                         double fx, double fy, double cx, double cy, int rows, int cols,
+                                                         long long* __restrict__ owner, int32_t* __restrict__ xs,
+                                                         int32_t* __restrict__ ys) {
+    const bool flip = header[0] != 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kGB;
+    for (int64_t i = (int64_t)blockIdx.x * kGB + threadIdx.x; i < m; i += stride) {
+        if (flip) inl[3 * i + 2] = inl[3 * i + 2] * -1.0;
+        const int x = (int)(fx * inl[3 * i] + cx + 0.5);
+        const int y = (int)(fy * inl[3 * i + 1] + cy + 0.5);
+        if (xs) xs[i] = x;
+        if (ys) ys[i] = y;
+        if (x >= 0 && x < cols && y >= 0 && y < rows) atomicMax(&owner[(int64_t)x * rows + y], (long long)i);
+    }
+}
+
+__global__ __launch_bounds__(kGB) void depth_write_kernel(const double* __restrict__ inl, const long long* __restrict__ owner,
+                                                         int64_t npix, double* __restrict__ depth_map) {
+    const int64_t stride = (int64_t)gridDim.x * kGB;
+    for (int64_t p = (int64_t)blockIdx.x * kGB + threadIdx.x; p < npix; p += stride) {
+        const long long o = owner[p];
+        depth_map[p] = (o >= 0) ? inl[3 * o + 2] : 0.0;
+    }
+}
+
+static inline void glue_chunking(int64_t n, int64_t& chunk, int& blocks) {
+    int64_t b = (n + kGB - 1) / kGB;
+    if (b < 1) b = 1;
+    chunk = kGB;
+    if (b > 2048) {
+        chunk = ((b + 2047) / 2048) * kGB;
+        b = (n + chunk - 1) / chunk;
+    }
+    blocks = (int)b;
+}
+
+// d_total: device int64 receiving the number of kept points; workspace: 2 x 2048 int64
+int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, double fx, double fy, double cx, double cy, double gamma,
+                   double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* d_counts,
+                   int64_t* d_offsets, int64_t* d_total) {
+    const int64_t n = (int64_t)rows * cols;
+    int64_t chunk;
+    int blocks;
+    glue_chunking(n, chunk, blocks);
+    hipLaunchKernelGGL(flatten_count_kernel, dim3(blocks), dim3(kGB), 0, c->stream, reinterpret_cast<const double2*>(d_img), rows,
+                       cols, thr, chunk, d_counts);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(glue_scan_kernel, dim3(1), dim3(256), 0, c->stream, d_counts, blocks, d_offsets, d_total);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(flatten_scatter_kernel, dim3(blocks), dim3(kGB), 0, c->stream, reinterpret_cast<const double2*>(d_img), rows,
+                       cols, fx, fy, cx, cy, gamma, thr, chunk, d_offsets, reinterpret_cast<double2*>(d_q),
+                       reinterpret_cast<double2*>(d_u), d_alpha, d_alpha_k);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+// d_header: 4 doubles (flipped, v'); d_owner: rows*cols int64; d_partials: >= 1024 doubles
+int depth_map_launch(Ctx* c, double* d_inl, int64_t m, const double v[3], double fx, double fy, double cx, double cy, int rows,
+                     int cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, double* d_header, long long* d_owner,
+                     double* d_partials) {
+    const int64_t npix = (int64_t)rows * cols;
+    Pose pv;
+    memset(&pv, 0, sizeof(pv));
+    pv.v[0] = v[0], pv.v[1] = v[1], pv.v[2] = v[2];
+    int zb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (m + kGB - 1) / kGB));
+    hipLaunchKernelGGL(zsum_partial_kernel, dim3(zb), dim3(kGB), 0, c->stream, d_inl, m, d_partials);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(zsum_decide_kernel, dim3(1), dim3(256), 0, c->stream, d_partials, zb, m, pv, d_header);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_owner, 0xFF, sizeof(long long) * (size_t)npix, c->stream));  // -1
+    if (m > 0) {
+        hipLaunchKernelGGL(depth_claim_kernel, dim3(stream_grid(m)), dim3(kGB), 0, c->stream, d_inl, m, d_header, fx, fy, cx, cy, rows,
+                           cols, d_owner, d_xs, d_ys);
+        RSDSFM_HIP_CHECK(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(depth_write_kernel, dim3(stream_grid(npix)), dim3(kGB), 0, c->stream, d_inl, d_owner, npix, d_depth_map);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -1,0 +1,142 @@
+// refine_host.hip -- host orchestration + C ABI of nonlinear_refinement::nonLinearRefinement
+// (reference nonlinearRefinement.cc:183-252) over the kernels of refine_kernels.hip.
+#include <string.h>
+
+#include <algorithm>
+
+#include "rsdsfm_internal.hpp"
+
+namespace rsdsfm {
+
+// all pointers DEVICE (d_inlier_idx may be null in compat mode); v/w/k and summary on the host
+int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
+                  const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
+                  int const_acceleration, int flow_index_mode, double* d_inl_out, double v_out[3], double w_out[3], double* k_out,
+                  rsdsfm_lm_summary* summary) {
+    if (m < 0 || n_flow < 0 || !v_in || !w_in || !v_out || !w_out || !k_out) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    if (flow_index_mode != RSDSFM_FLOW_COMPAT_RANK && flow_index_mode != RSDSFM_FLOW_GATHERED) return fail(c, RSDSFM_ERR_INVALID, "unknown flow_index_mode");
+    if (flow_index_mode == RSDSFM_FLOW_GATHERED && m > 0 && !d_inlier_idx) return fail(c, RSDSFM_ERR_INVALID, "gathered mode needs inlier_idx");
+    if (m > 0 && (!d_flow || !d_inl || !d_alpha || !d_alpha_k || !d_inl_out)) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
+    const int np = const_acceleration ? 7 : 6;
+    const size_t M = (size_t)std::max<int64_t>(m, 1);
+    const size_t npart = (size_t)refine_partials_doubles(c, m);
+    int rc = ensure_ws(c, Arena::need(sizeof(RefineState)) + Arena::need(16 * M) + 3 * Arena::need(8 * M) + Arena::need(8 * npart) + Arena::need(64) + 1024);
+    if (rc != RSDSFM_OK) return rc;
+    rc = ensure_pinned(c, sizeof(RefineState) + 64);
+    if (rc != RSDSFM_OK) return rc;
+    Arena ws(c->d_ws);
+    RefineBuffers B;
+    B.flow = d_flow;
+    B.n_flow = n_flow;
+    B.m = m;
+    B.inl = d_inl;
+    B.alpha = d_alpha;
+    B.alpha_k = d_alpha_k;
+    B.inlier_idx = d_inlier_idx;
+    B.flow_index_mode = flow_index_mode;
+    B.state = ws.take<RefineState>(1);
+    B.uu = ws.take<double>(2 * M);
+    B.rho_a = ws.take<double>(M);
+    B.rho_b = ws.take<double>(M);
+    B.srho = ws.take<double>(M);
+    B.partials = ws.take<double>(npart);
+    B.bad_index = ws.take<int>(1);
+    RefineState* hs = static_cast<RefineState*>(c->h_pinned);
+    int* h_bad = reinterpret_cast<int*>(static_cast<char*>(c->h_pinned) + sizeof(RefineState));
+    memset(hs, 0, sizeof(RefineState));
+    hs->np = np;
+    for (int i = 0; i < 3; ++i) {
+        hs->p[i] = v_in[i];
+        hs->p[3 + i] = w_in[i];
+    }
+    hs->p[6] = k_in;
+    hs->termination = -1;
+    hs->radius = kInitialRadius;
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(B.state, hs, sizeof(RefineState), hipMemcpyHostToDevice, c->stream));
+    RSDSFM_HIP_CHECK(c, hipMemsetAsync(B.bad_index, 0, sizeof(int), c->stream));
+    rc = refine_init_launch(c, B, np);
+    if (rc != RSDSFM_OK) return rc;
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_bad, B.bad_index, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    // LM iterations are enqueued in chunks; kernels of a finished solve return immediately
+    const int chunk = 5;
+    for (int launched = 0;;) {
+        for (int i = 0; i < chunk; ++i) {
+            rc = refine_iter_launch(c, B, np);
+            if (rc != RSDSFM_OK) return rc;
+        }
+        launched += chunk;
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(hs, B.state, sizeof(RefineState), hipMemcpyDeviceToHost, c->stream));
+        RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        if (*h_bad) return fail(c, RSDSFM_ERR_INVALID, "flow index out of range (flow has fewer columns than inliers / bad inlier_idx)");
+        if (hs->termination >= 0) break;
+        if (launched > 4 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
+    }
+    rc = refine_finish_launch(c, B, d_inl_out);
+    if (rc != RSDSFM_OK) return rc;
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 3; ++i) {
+        v_out[i] = hs->p[i];
+        w_out[i] = hs->p[3 + i];
+    }
+    *k_out = hs->p[6];
+    if (summary) {
+        summary->num_iterations = hs->iteration;
+        summary->num_successful_steps = hs->num_successful;
+        summary->num_unsuccessful_steps = hs->num_unsuccessful;
+        summary->termination = hs->termination;
+        summary->initial_cost = hs->initial_cost;
+        summary->final_cost = hs->cost;
+        summary->final_radius = hs->radius;
+    }
+    return RSDSFM_OK;
+}
+
+}  // namespace rsdsfm
+
+using namespace rsdsfm;
+
+extern "C" {
+
+int rsdsfm_refine_dev(rsdsfm_ctx* ctx, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
+                      const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
+                      int const_acceleration, int flow_index_mode, double* d_inl_out, double v_out[3], double w_out[3], double* k_out,
+                      rsdsfm_lm_summary* summary) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    return refine_device(&ctx->c, d_flow, n_flow, m, d_inl, d_alpha, d_alpha_k, d_inlier_idx, v_in, w_in, k_in, const_acceleration,
+                         flow_index_mode, d_inl_out, v_out, w_out, k_out, summary);
+}
+
+int rsdsfm_refine(rsdsfm_ctx* ctx, const double* flow, int64_t n_flow, int64_t m, const double* inl, const double* alpha,
+                  const double* alpha_k, const int64_t* inlier_idx, const double v_in[3], const double w_in[3], double k_in,
+                  int const_acceleration, int flow_index_mode, double* inl_out, double v_out[3], double w_out[3], double* k_out,
+                  rsdsfm_lm_summary* summary) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    if (m < 0 || n_flow < 0) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    if (m > 0 && (!flow || !inl || !alpha || !alpha_k || !inl_out)) return fail(c, RSDSFM_ERR_INVALID, "null pointer");
+    const size_t M = (size_t)m, NF = (size_t)n_flow;
+    int rc = ensure_stage(c, Arena::need(16 * NF) + 2 * Arena::need(24 * M) + 3 * Arena::need(8 * M) + 2048);
+    if (rc != RSDSFM_OK) return rc;
+    Arena sa(c->d_stage);
+    double* d_flow = sa.take<double>(2 * NF);
+    double* d_inl = sa.take<double>(3 * M);
+    double* d_out = sa.take<double>(3 * M);
+    double* d_a = sa.take<double>(M);
+    double* d_ak = sa.take<double>(M);
+    int64_t* d_idx = sa.take<int64_t>(M);
+    if (NF) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_flow, flow, 16 * NF, hipMemcpyHostToDevice, c->stream));
+    if (M) {
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_inl, inl, 24 * M, hipMemcpyHostToDevice, c->stream));
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_a, alpha, 8 * M, hipMemcpyHostToDevice, c->stream));
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_ak, alpha_k, 8 * M, hipMemcpyHostToDevice, c->stream));
+        if (inlier_idx) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_idx, inlier_idx, 8 * M, hipMemcpyHostToDevice, c->stream));
+    }
+    rc = refine_device(c, d_flow, n_flow, m, d_inl, d_a, d_ak, inlier_idx ? d_idx : nullptr, v_in, w_in, k_in, const_acceleration,
+                       flow_index_mode, d_out, v_out, w_out, k_out, summary);
+    if (rc != RSDSFM_OK) return rc;
+    if (M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(inl_out, d_out, 24 * M, hipMemcpyDeviceToHost, c->stream));
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return RSDSFM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,531 @@
+// refine_kernels.hip -- joint nonlinear refinement of (v, w[, k], rho_i) on MI355X (gfx950).
+//
+// Replaces nonlinear_refinement::nonLinearRefinement (reference nonlinearRefinement.cc:183-252): one Ceres problem
+// over the inliers, trust-region LM with DENSE_SCHUR.  The rho_i are the 1x1 e-blocks, (v, w[, k]) the f-blocks,
+// so every LM iteration is two streaming passes over the inliers plus two single-workgroup kernels:
+//
+//   refine_schur_kernel    per inlier: residual + analytic 2x(NP+1) Jacobian (Jacobi-scaled), LM-damped 1x1
+//                          e-block inverse, contribution to F^T F, F^T E (E^T E)^-1 E^T F, F^T b, ... (70 sums for
+//                          NP = 7), DPP/LDS block reduction -> partials[block][NSCHUR]
+//   refine_solve_kernel    fixed-order reduction, reduced NP x NP system + LM diagonal, Cholesky, candidate (v,w,k)
+//   refine_backsub_kernel  per inlier: back-substitution of rho_i, model cost change, candidate residual / cost and
+//                          (speculatively) the gradient / norms at the candidate -> partials[block][NBACK]
+//   refine_decide_kernel   fixed-order reduction + the Ceres trust-region decisions (accept / reject / converge)
+//
+// rho lives in two device buffers that swap on acceptance (no copy).  All state is device-resident
+// (RefineState); the host only polls the termination flag every few iterations.
+// Arithmetic mirrors oracle/rsdsfm_oracle.c rso_refine operation for operation (per-inlier terms bit-identical;
+// the global sums differ only in summation order).
+#include "device_math.hpp"
+#include "rsdsfm_internal.hpp"
+
+namespace rsdsfm {
+
+namespace {
+
+constexpr int kFB = 256;
+
+template <int NP>
+struct RJ {
+    double r[2];
+    double Jp[2][NP];
+    double Jr[2];
+};
+
+// residual and analytic Jacobian at (p, rho); p = (v0,v1,v2,w0,w1,w2,k)
+template <int NP>
+__device__ __forceinline__ void resid_jac(double x, double y, double ux, double uy, double alpha, double alpha_k,
+                                          const double (&p)[7], double rho, RJ<NP>& o) {
+    const double k = p[6];
+    const double beta = (2.0 / (2.0 + k)) * (alpha + k * alpha_k);
+    const double a0 = x * p[2] - p[0], a1 = y * p[2] - p[1];
+    const double in0 = rho * a0 + (x * y * p[3]) - (1.0 + x * x) * p[4] + y * p[5];
+    const double in1 = rho * a1 + (1.0 + y * y) * p[3] - x * y * p[4] - x * p[5];
+    o.r[0] = ux - beta * -1.0 * in0;
+    o.r[1] = uy - beta * -1.0 * in1;
+    const double br = beta * rho;
+    o.Jp[0][0] = -br;
+    o.Jp[1][0] = 0.0;
+    o.Jp[0][1] = 0.0;
+    o.Jp[1][1] = -br;
+    o.Jp[0][2] = br * x;
+    o.Jp[1][2] = br * y;
+    o.Jp[0][3] = beta * (x * y);
+    o.Jp[1][3] = beta * (1.0 + y * y);
+    o.Jp[0][4] = -(beta * (1.0 + x * x));
+    o.Jp[1][4] = -(beta * (x * y));
+    o.Jp[0][5] = beta * y;
+    o.Jp[1][5] = -(beta * x);
+    if (NP == 7) {
+        const double dbeta = 2.0 * (2.0 * alpha_k - alpha) / ((2.0 + k) * (2.0 + k));
+        o.Jp[0][NP - 1] = dbeta * in0;
+        o.Jp[1][NP - 1] = dbeta * in1;
+    }
+    o.Jr[0] = beta * a0;
+    o.Jr[1] = beta * a1;
+}
+
+// generic fixed-order workgroup reduction of NV per-thread values; kinds: slot s is a max slot iff s == max_slot
+template <int NV>
+__device__ __forceinline__ void block_reduce_store(const double (&v)[NV], int max_slot, double (*s_red)[NV],
+                                                   double* __restrict__ out_row) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int s = 0; s < NV; ++s) {
+        double r = (s == max_slot) ? wave_max(v[s]) : wave_sum(v[s]);
+        if (lane == 0) s_red[wv][s] = r;
+    }
+    __syncthreads();
+    if (tid < NV) {
+        double r = s_red[0][tid];
+        for (int w2 = 1; w2 < kFB / 64; ++w2) r = (tid == max_slot) ? fmax(r, s_red[w2][tid]) : r + s_red[w2][tid];
+        out_row[tid] = r;
+    }
+}
+
+// single-workgroup fixed-order reduction of partials[nblocks][NV] into s_out[NV]
+template <int NV>
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int nblocks, int max_slot,
+                                                double (*s_red)[NV], double* s_out) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double fin[NV];
+#pragma unroll
+    for (int s = 0; s < NV; ++s) fin[s] = 0.0;
+    for (int b = tid; b < nblocks; b += kFB) {
+        const double* row = partials + (int64_t)b * NV;
+#pragma unroll
+        for (int s = 0; s < NV; ++s) fin[s] = (s == max_slot) ? fmax(fin[s], row[s]) : fin[s] + row[s];
+    }
+#pragma unroll
+    for (int s = 0; s < NV; ++s) {
+        double r = (s == max_slot) ? wave_max(fin[s]) : wave_sum(fin[s]);
+        if (lane == 0) s_red[wv][s] = r;
+    }
+    __syncthreads();
+    if (tid < NV) {
+        double r = s_red[0][tid];
+        for (int w2 = 1; w2 < kFB / 64; ++w2) r = (tid == max_slot) ? fmax(r, s_red[w2][tid]) : r + s_red[w2][tid];
+        s_out[tid] = r;
+    }
+    __syncthreads();
+}
+
+template <int NP>
+struct Counts {
+    static constexpr int TRI = NP * (NP + 1) / 2;
+    static constexpr int NINIT = 1 + NP + NP + 1 + 1;       // cost2, colsq[NP], gp[NP], gmax_rho (max), xsq_rho
+    static constexpr int INIT_MAX = 1 + 2 * NP;
+    static constexpr int NSCHUR = 2 * TRI + 2 * NP;         // FtF tri, C tri, Ftb, cvec
+    static constexpr int NBACK = 3 + 1 + NP + 1 + 1;        // model, stepsq_rho, ccost2 | cost2@cand (= ccost2), gp[NP], gmax_rho, xsq_rho
+    static constexpr int BACK_MAX = 3 + 1 + NP;
+};
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// iteration zero
+// ---------------------------------------------------------------------------------------------------
+// gathers the flow of each inlier (nonlinearRefinement.cc:209-213; quirk Q2: flow(., rank) unless gathered), sets
+// rho = 1/z, Jacobi scale of the rho columns, and the iteration-zero sums.
+template <int NP>
+__global__ __launch_bounds__(kFB) void refine_init_kernel(const double2* __restrict__ flow, int64_t n_flow, int64_t m,
+                                                         const double* __restrict__ inl, const double* __restrict__ alpha,
+                                                         const double* __restrict__ alpha_k,
+                                                         const int64_t* __restrict__ inlier_idx, int flow_index_mode,
+                                                         const RefineState* __restrict__ st, double2* __restrict__ uu,
+                                                         double* __restrict__ rho0, double* __restrict__ srho,
+                                                         double* __restrict__ partials, int* __restrict__ bad_index) {
+    using CT = Counts<NP>;
+    __shared__ double s_red[kFB / 64][CT::NINIT];
+    double p[7];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) p[c] = st->p[c];
+    double acc[CT::NINIT];
+#pragma unroll
+    for (int s = 0; s < CT::NINIT; ++s) acc[s] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kFB;
+    for (int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x; i < m; i += stride) {
+        int64_t fi = (flow_index_mode == RSDSFM_FLOW_GATHERED) ? inlier_idx[i] : i;
+        if (fi < 0 || fi >= n_flow) {
+            *bad_index = 1;
+            fi = 0;
+        }
+        const double2 f = flow[fi];
+        uu[i] = f;
+        const double x = inl[3 * i], y = inl[3 * i + 1];
+        const double rho = 1.0 / inl[3 * i + 2];
+        rho0[i] = rho;
+        RJ<NP> o;
+        resid_jac<NP>(x, y, f.x, f.y, alpha[i], alpha_k[i], p, rho, o);
+        acc[0] += o.r[0] * o.r[0] + o.r[1] * o.r[1];
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            acc[1 + c] += o.Jp[0][c] * o.Jp[0][c] + o.Jp[1][c] * o.Jp[1][c];
+            acc[1 + NP + c] += o.Jp[0][c] * o.r[0] + o.Jp[1][c] * o.r[1];
+        }
+        srho[i] = 1.0 / (1.0 + sqrt(o.Jr[0] * o.Jr[0] + o.Jr[1] * o.Jr[1]));
+        acc[CT::INIT_MAX] = fmax(acc[CT::INIT_MAX], fabs(o.Jr[0] * o.r[0] + o.Jr[1] * o.r[1]));
+        acc[CT::INIT_MAX + 1] += rho * rho;
+    }
+    block_reduce_store<CT::NINIT>(acc, CT::INIT_MAX, s_red, partials + (int64_t)blockIdx.x * CT::NINIT);
+}
+
+template <int NP>
+__global__ __launch_bounds__(kFB) void refine_init_decide_kernel(const double* __restrict__ partials, int nblocks,
+                                                                RefineState* st, int64_t m) {
+    using CT = Counts<NP>;
+    __shared__ double s_red[kFB / 64][CT::NINIT];
+    __shared__ double s[CT::NINIT];
+    reduce_partials<CT::NINIT>(partials, nblocks, CT::INIT_MAX, s_red, s);
+    if (threadIdx.x == 0) {
+        double gmax = s[CT::INIT_MAX], xsq = s[CT::INIT_MAX + 1];
+        for (int c = 0; c < NP; ++c) {
+            st->sp[c] = 1.0 / (1.0 + sqrt(s[1 + c]));
+            if (fabs(s[1 + NP + c]) > gmax) gmax = fabs(s[1 + NP + c]);
+            xsq += st->p[c] * st->p[c];
+        }
+        st->cost = 0.5 * s[0];
+        st->initial_cost = st->cost;
+        st->gmax = gmax;
+        st->x_norm = sqrt(xsq);
+        st->radius = kInitialRadius;
+        st->decrease_factor = 2.0;
+        st->iteration = 0;
+        st->invalid_run = 0;
+        st->num_successful = 0;
+        st->num_unsuccessful = 0;
+        st->cur = 0;
+        st->solve_ok = 0;
+        st->termination = (m == 0 || gmax <= kGradientTol) ? RSDSFM_TERM_GRADIENT : -1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pass 1: Schur complement sums
+// ---------------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(kFB) void refine_schur_kernel(int64_t m, const double* __restrict__ inl,
+                                                          const double2* __restrict__ uu, const double* __restrict__ alpha,
+                                                          const double* __restrict__ alpha_k,
+                                                          const double* __restrict__ rho_a, const double* __restrict__ rho_b,
+                                                          const double* __restrict__ srho, const RefineState* __restrict__ st,
+                                                          double* __restrict__ partials) {
+    using CT = Counts<NP>;
+    __shared__ double s_red[kFB / 64][CT::NSCHUR];
+    if (st->termination >= 0 || st->iteration >= kMaxIter || st->radius < kMinRadius) return;
+    double p[7], sp[NP];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) p[c] = st->p[c];
+#pragma unroll
+    for (int c = 0; c < NP; ++c) sp[c] = st->sp[c];
+    const double inv_radius = 1.0 / st->radius;
+    const double* __restrict__ rho = st->cur ? rho_b : rho_a;
+    double acc[CT::NSCHUR];
+#pragma unroll
+    for (int s = 0; s < CT::NSCHUR; ++s) acc[s] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kFB;
+    for (int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x; i < m; i += stride) {
+        const double2 f = uu[i];
+        RJ<NP> o;
+        resid_jac<NP>(inl[3 * i], inl[3 * i + 1], f.x, f.y, alpha[i], alpha_k[i], p, rho[i], o);
+        const double sr = srho[i];
+        const double E0 = o.Jr[0] * sr, E1 = o.Jr[1] * sr;
+        const double ht = E0 * E0 + E1 * E1;
+        const double lam = clampd(ht, kMinLmDiag, kMaxLmDiag) * inv_radius;
+        const double ete_inv = 1.0 / (ht + lam);
+        const double Etb = E0 * o.r[0] + E1 * o.r[1];
+        double F0[NP], F1[NP], EtF[NP];
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            F0[c] = o.Jp[0][c] * sp[c];
+            F1[c] = o.Jp[1][c] * sp[c];
+            EtF[c] = E0 * F0[c] + E1 * F1[c];
+        }
+        int tri = 0;
+#pragma unroll
+        for (int a = 0; a < NP; ++a) {
+            acc[2 * CT::TRI + a] += F0[a] * o.r[0] + F1[a] * o.r[1];
+            acc[2 * CT::TRI + NP + a] += EtF[a] * (ete_inv * Etb);
+#pragma unroll
+            for (int b = a; b < NP; ++b) {
+                acc[tri] += F0[a] * F0[b] + F1[a] * F1[b];
+                acc[CT::TRI + tri] += EtF[a] * (ete_inv * EtF[b]);
+                ++tri;
+            }
+        }
+    }
+    block_reduce_store<CT::NSCHUR>(acc, -1, s_red, partials + (int64_t)blockIdx.x * CT::NSCHUR);
+}
+
+// reduced system + Cholesky (one workgroup; the solve itself runs on one lane: NP <= 7)
+template <int NP>
+__global__ __launch_bounds__(kFB) void refine_solve_kernel(const double* __restrict__ partials, int nblocks,
+                                                          RefineState* st) {
+    using CT = Counts<NP>;
+    __shared__ double s_red[kFB / 64][CT::NSCHUR];
+    __shared__ double s[CT::NSCHUR];
+    __shared__ double S[NP * NP];
+    __shared__ double rhs[NP], yv[NP], yp[NP];
+    if (st->termination >= 0) return;
+    if (st->iteration >= kMaxIter) {  // top-of-loop checks of TrustRegionMinimizer
+        if (threadIdx.x == 0) st->termination = RSDSFM_TERM_MAX_ITER;
+        return;
+    }
+    if (st->radius < kMinRadius) {
+        if (threadIdx.x == 0) st->termination = RSDSFM_TERM_MIN_RADIUS;
+        return;
+    }
+    reduce_partials<CT::NSCHUR>(partials, nblocks, -1, s_red, s);
+    if (threadIdx.x == 0) {
+        st->iteration += 1;
+        const double inv_radius = 1.0 / st->radius;
+        int tri = 0;
+        for (int a = 0; a < NP; ++a) {
+            rhs[a] = s[2 * CT::TRI + a] - s[2 * CT::TRI + NP + a];
+            for (int b = a; b < NP; ++b) {
+                double sab = s[tri] - s[CT::TRI + tri];
+                if (a == b) sab += clampd(s[tri], kMinLmDiag, kMaxLmDiag) * inv_radius;  // D_f^2
+                S[a * NP + b] = sab;
+                S[b * NP + a] = sab;
+                ++tri;
+            }
+        }
+        // dense Cholesky solve (mirrors the oracle's chol_solve)
+        int ok = 1;
+        for (int j = 0; j < NP && ok; ++j) {
+            double d = S[j * NP + j];
+            for (int t = 0; t < j; ++t) d -= S[j * NP + t] * S[j * NP + t];
+            if (!(d > 0.0)) {
+                ok = 0;
+                break;
+            }
+            d = sqrt(d);
+            S[j * NP + j] = d;
+            for (int i = j + 1; i < NP; ++i) {
+                double sacc = S[i * NP + j];
+                for (int t = 0; t < j; ++t) sacc -= S[i * NP + t] * S[j * NP + t];
+                S[i * NP + j] = sacc / d;
+            }
+        }
+        if (ok) {
+            for (int i = 0; i < NP; ++i) {
+                double sacc = rhs[i];
+                for (int t = 0; t < i; ++t) sacc -= S[i * NP + t] * yv[t];
+                yv[i] = sacc / S[i * NP + i];
+            }
+            for (int i = NP - 1; i >= 0; --i) {
+                double sacc = yv[i];
+                for (int t = i + 1; t < NP; ++t) sacc -= S[t * NP + i] * yp[t];
+                yp[i] = sacc / S[i * NP + i];
+            }
+            double stepsq = 0.0;
+            for (int c = 0; c < 7; ++c) st->pc[c] = st->p[c];
+            for (int c = 0; c < NP; ++c) {
+                st->yp[c] = yp[c];
+                const double step = -yp[c];
+                const double pc = st->p[c] + step * st->sp[c];
+                st->pc[c] = pc;
+                const double dx = st->p[c] - pc;
+                stepsq += dx * dx;
+            }
+            st->stepsq_p = stepsq;
+        }
+        st->solve_ok = ok;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pass 2: back-substitution + candidate evaluation
+// ---------------------------------------------------------------------------------------------------
+template <int NP>
+__global__ __launch_bounds__(kFB) void refine_backsub_kernel(int64_t m, const double* __restrict__ inl,
+                                                            const double2* __restrict__ uu, const double* __restrict__ alpha,
+                                                            const double* __restrict__ alpha_k, double* __restrict__ rho_a,
+                                                            double* __restrict__ rho_b, const double* __restrict__ srho,
+                                                            const RefineState* __restrict__ st, double* __restrict__ partials) {
+    using CT = Counts<NP>;
+    __shared__ double s_red[kFB / 64][CT::NBACK];
+    if (st->termination >= 0 || !st->solve_ok) return;
+    double p[7], pc[7], sp[NP], yp[NP];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+        p[c] = st->p[c];
+        pc[c] = st->pc[c];
+    }
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        sp[c] = st->sp[c];
+        yp[c] = st->yp[c];
+    }
+    const double inv_radius = 1.0 / st->radius;
+    const double* __restrict__ rho = st->cur ? rho_b : rho_a;
+    double* __restrict__ cand = st->cur ? rho_a : rho_b;
+    double acc[CT::NBACK];
+#pragma unroll
+    for (int s = 0; s < CT::NBACK; ++s) acc[s] = 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kFB;
+    for (int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x; i < m; i += stride) {
+        const double2 f = uu[i];
+        const double x = inl[3 * i], y = inl[3 * i + 1], al = alpha[i], ak = alpha_k[i];
+        const double rh = rho[i];
+        RJ<NP> o;
+        resid_jac<NP>(x, y, f.x, f.y, al, ak, p, rh, o);
+        const double sr = srho[i];
+        const double E0 = o.Jr[0] * sr, E1 = o.Jr[1] * sr;
+        const double ht = E0 * E0 + E1 * E1;
+        const double lam = clampd(ht, kMinLmDiag, kMaxLmDiag) * inv_radius;
+        const double ete_inv = 1.0 / (ht + lam);
+        const double Etb = E0 * o.r[0] + E1 * o.r[1];
+        double Fy0 = 0.0, Fy1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            Fy0 += o.Jp[0][c] * sp[c] * yp[c];
+            Fy1 += o.Jp[1][c] * sp[c] * yp[c];
+        }
+        const double ye = ete_inv * (Etb - (E0 * Fy0 + E1 * Fy1));
+        const double step_e = -ye;
+        const double m0 = -Fy0 + E0 * step_e, m1 = -Fy1 + E1 * step_e;
+        acc[0] -= m0 * (o.r[0] + m0 / 2.0) + m1 * (o.r[1] + m1 / 2.0);
+        const double cd = rh + step_e * sr;
+        cand[i] = cd;
+        const double dx = rh - cd;
+        acc[1] += dx * dx;
+        RJ<NP> oc;
+        resid_jac<NP>(x, y, f.x, f.y, al, ak, pc, cd, oc);
+        const double c2 = oc.r[0] * oc.r[0] + oc.r[1] * oc.r[1];
+        acc[2] += c2;
+        // quantities of HandleSuccessfulStep at the candidate (used only if the step is accepted)
+        acc[3] += c2;
+#pragma unroll
+        for (int c = 0; c < NP; ++c) acc[4 + c] += oc.Jp[0][c] * oc.r[0] + oc.Jp[1][c] * oc.r[1];
+        acc[CT::BACK_MAX] = fmax(acc[CT::BACK_MAX], fabs(oc.Jr[0] * oc.r[0] + oc.Jr[1] * oc.r[1]));
+        acc[CT::BACK_MAX + 1] += cd * cd;
+    }
+    block_reduce_store<CT::NBACK>(acc, CT::BACK_MAX, s_red, partials + (int64_t)blockIdx.x * CT::NBACK);
+}
+
+template <int NP>
+__global__ __launch_bounds__(kFB) void refine_decide_kernel(const double* __restrict__ partials, int nblocks,
+                                                           RefineState* st) {
+    using CT = Counts<NP>;
+    __shared__ double s_red[kFB / 64][CT::NBACK];
+    __shared__ double s[CT::NBACK];
+    if (st->termination >= 0) return;
+    const int solve_ok = st->solve_ok;
+    if (solve_ok) reduce_partials<CT::NBACK>(partials, nblocks, CT::BACK_MAX, s_red, s);
+    if (threadIdx.x != 0) return;
+    const double model_change = solve_ok ? s[0] : 0.0;
+    if (!solve_ok || !(model_change > 0.0)) {  // HandleInvalidStep
+        st->num_unsuccessful += 1;
+        st->invalid_run += 1;
+        if (st->invalid_run >= kMaxInvalid) {
+            st->termination = RSDSFM_TERM_FAILURE;
+            return;
+        }
+        st->radius *= 0.5;
+        return;
+    }
+    st->invalid_run = 0;
+    const double step_norm = sqrt(st->stepsq_p + s[1]);
+    const double ccost = 0.5 * s[2];
+    if (step_norm <= kParameterTol * (st->x_norm + kParameterTol)) {
+        st->termination = RSDSFM_TERM_PARAMETER;
+        return;
+    }
+    const double cost_change = st->cost - ccost;
+    if (fabs(cost_change) <= kFunctionTol * st->cost) {
+        st->termination = RSDSFM_TERM_FUNCTION;
+        return;
+    }
+    const double rel = cost_change / model_change;
+    if (rel > kMinRelDecrease) {  // HandleSuccessfulStep
+        double gmax = s[CT::BACK_MAX], xsq = s[CT::BACK_MAX + 1];
+        for (int c = 0; c < 7; ++c) st->p[c] = st->pc[c];
+        for (int c = 0; c < NP; ++c) {
+            xsq += st->p[c] * st->p[c];
+            if (fabs(s[4 + c]) > gmax) gmax = fabs(s[4 + c]);
+        }
+        st->cur ^= 1;
+        st->cost = 0.5 * s[3];
+        st->gmax = gmax;
+        st->x_norm = sqrt(xsq);
+        st->radius = radius_accept(st->radius, rel);
+        st->decrease_factor = 2.0;
+        st->num_successful += 1;
+        if (gmax <= kGradientTol) st->termination = RSDSFM_TERM_GRADIENT;
+    } else {  // HandleUnsuccessfulStep
+        st->num_unsuccessful += 1;
+        st->radius = st->radius / st->decrease_factor;
+        st->decrease_factor *= 2.0;
+    }
+}
+
+// nonlinearRefinement.cc:244-248
+__global__ __launch_bounds__(kFB) void refine_finish_kernel(int64_t m, const double* __restrict__ inl,
+                                                           const double* __restrict__ rho_a, const double* __restrict__ rho_b,
+                                                           const RefineState* __restrict__ st, double* __restrict__ inl_out) {
+    const double* __restrict__ rho = st->cur ? rho_b : rho_a;
+    const int64_t stride = (int64_t)gridDim.x * kFB;
+    for (int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x; i < m; i += stride) {
+        inl_out[3 * i] = inl[3 * i];
+        inl_out[3 * i + 1] = inl[3 * i + 1];
+        inl_out[3 * i + 2] = 1.0 / rho[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------
+static inline int refine_grid(const Ctx* c, int64_t m) {
+    int64_t b = (m + kFB - 1) / kFB;
+    const int64_t cap = (int64_t)c->num_cus * 2;
+    if (b < 1) b = 1;
+    if (b > cap) {
+        const int64_t iters = (b + cap - 1) / cap;
+        b = (b + iters - 1) / iters;
+    }
+    return (int)b;
+}
+
+int refine_partials_doubles(const Ctx* c, int64_t m) { return refine_grid(c, m) * Counts<7>::NSCHUR; }
+
+template <int NP>
+static int refine_init_t(Ctx* c, const RefineBuffers& B) {
+    const int grid = refine_grid(c, B.m);
+    hipLaunchKernelGGL(refine_init_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, reinterpret_cast<const double2*>(B.flow), B.n_flow,
+                       B.m, B.inl, B.alpha, B.alpha_k, B.inlier_idx, B.flow_index_mode, B.state, reinterpret_cast<double2*>(B.uu),
+                       B.rho_a, B.srho, B.partials, B.bad_index);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(refine_init_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, B.state, B.m);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+template <int NP>
+static int refine_iter_t(Ctx* c, const RefineBuffers& B) {
+    const int grid = refine_grid(c, B.m);
+    hipLaunchKernelGGL(refine_schur_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m, B.inl, reinterpret_cast<const double2*>(B.uu),
+                       B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(refine_solve_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, B.state);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(refine_backsub_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m, B.inl, reinterpret_cast<const double2*>(B.uu),
+                       B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(refine_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, B.state);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+int refine_init_launch(Ctx* c, const RefineBuffers& B, int np) { return np == 7 ? refine_init_t<7>(c, B) : refine_init_t<6>(c, B); }
+int refine_iter_launch(Ctx* c, const RefineBuffers& B, int np) { return np == 7 ? refine_iter_t<7>(c, B) : refine_iter_t<6>(c, B); }
+
+int refine_finish_launch(Ctx* c, const RefineBuffers& B, double* inl_out) {
+    if (B.m == 0) return RSDSFM_OK;
+    hipLaunchKernelGGL(refine_finish_kernel, dim3(refine_grid(c, B.m)), dim3(kFB), 0, c->stream, B.m, B.inl, B.rho_a, B.rho_b, B.state,
+                       inl_out);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+}  // namespace rsdsfm

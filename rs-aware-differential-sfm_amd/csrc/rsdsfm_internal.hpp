@@ -146,6 +146,12 @@ namespace rsdsfm {
 int alpha_launch(Ctx* c, const double* flow_px, int64_t n, double h, double gamma, double* alpha);
 int alpha_k_launch(Ctx* c, const double* q_px, const double* flow_px, int64_t n, double h, double gamma, double* alpha_k);
 int pose_table_launch(Ctx* c, const Pose& pose, double gamma, int rows, double* R, double* t);
+int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, double fx, double fy, double cx, double cy, double gamma,
+                   double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* d_counts,
+                   int64_t* d_offsets, int64_t* d_total);
+int depth_map_launch(Ctx* c, double* d_inl, int64_t m, const double v[3], double fx, double fy, double cx, double cy, int rows,
+                     int cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, double* d_header, long long* d_owner,
+                     double* d_partials);
 }  // namespace rsdsfm
 
 namespace rsdsfm {
@@ -167,6 +173,35 @@ int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* 
                         RansacBest* best, const LmState* states, int depth_mode, double tol, double* rho, uint8_t* mask,
                         int64_t* block_counts, int64_t* block_offsets, int64_t* inlier_idx, double* inliers,
                         double* out_alpha, double* out_alpha_k);
+}  // namespace rsdsfm
+
+namespace rsdsfm {
+// device-resident state of the joint refinement (refine_kernels.hip)
+struct RefineState {
+    int32_t np, cur, iteration, invalid_run, num_successful, num_unsuccessful, termination, solve_ok;
+    double p[7], pc[7], sp[7], yp[7];
+    double radius, decrease_factor, cost, initial_cost, x_norm, gmax, stepsq_p;
+};
+struct RefineBuffers {
+    const double* flow;  // 2 x n_flow
+    int64_t n_flow, m;
+    const double* inl;  // 3 x m
+    const double* alpha;
+    const double* alpha_k;
+    const int64_t* inlier_idx;
+    int flow_index_mode;
+    RefineState* state;
+    double* uu;     // 2 x m gathered flow
+    double* rho_a;  // the two rho buffers (swap on acceptance)
+    double* rho_b;
+    double* srho;
+    double* partials;
+    int* bad_index;
+};
+int refine_partials_doubles(const Ctx* c, int64_t m);
+int refine_init_launch(Ctx* c, const RefineBuffers& B, int np);
+int refine_iter_launch(Ctx* c, const RefineBuffers& B, int np);
+int refine_finish_launch(Ctx* c, const RefineBuffers& B, double* inl_out);
 }  // namespace rsdsfm
 
 // the opaque handle of the C ABI

@@ -183,6 +183,18 @@ int rsdsfm_refine_dev(rsdsfm_ctx* ctx, const double* d_flow2n, int64_t n_flow, i
 int rsdsfm_depth_lm_launch_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n, int64_t n,
                                const double v[3], const double w[3], double k, const double* d_alpha_n,
                                const double* d_alpha_k_n, double* d_inv_depth_n, int launch_id);
+/* ---- stage-level entry points of the ROW-TILED (multi-GPU) dense depth solve --------------------------------
+ * Every rank owns a contiguous index range (its shard) of the flattened arrays.  Per LM launch `id`:
+ *   rsdsfm_depth_lm_launch_dev(shard, id)  ->  rsdsfm_depth_lm_reduce_dev  (one row of NS sums)
+ *   all-gather of the rows over ranks (RCCL, rank order)  ->  rsdsfm_depth_lm_decide_rows_dev on EVERY rank
+ * so that all ranks run the trust-region state machine on identical sums and take identical decisions;
+ * rsdsfm_depth_lm_state (synchronises) tells the driver whether another launch is needed.  The depth shards
+ * are finally all-gathered into the full map.  See rs-aware-differential-sfm_amd/dist.py. */
+int rsdsfm_depth_lm_sums_row_size(void);
+int rsdsfm_depth_lm_reduce_dev(rsdsfm_ctx* ctx, int64_t n_shard, double* d_row_out);
+int rsdsfm_depth_lm_decide_rows_dev(rsdsfm_ctx* ctx, const double* d_rows, int32_t nrows, int64_t n_total, int launch_id);
+/* status: 0 = launch *next_launch must speculate, 1 = done (result written), 2 = done, launch *next_launch writes it */
+int rsdsfm_depth_lm_state(rsdsfm_ctx* ctx, int32_t* status, int32_t* next_launch, rsdsfm_lm_summary* summary_or_null);
 /* Synchronises, drives the device LM state machine to completion if the fast path did not finish it
  * (rare: more than 3 LM iterations or a rejected step) and returns the summary.  Returns the number of
  * EXTRA launches that were needed in *extra_launches (may be NULL). */

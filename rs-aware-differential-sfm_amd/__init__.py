@@ -15,7 +15,7 @@ import os
 
 import numpy as np
 
-from . import synth  # noqa: F401  (analytic data generator used by tests and bench)
+from . import dist, synth  # noqa: F401  (multi-GPU driver; analytic data generator used by tests and bench)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RSDSFM_LIB") or os.path.join(_HERE, "librsdsfm_hip.so")
@@ -276,6 +276,17 @@ class Solver:
 
     def depth_lm_launch_dev(self, d_q, d_u, n, v, w, k, d_alpha, d_alpha_k, d_rho, launch_id=0):
         self._check(self.lib.rsdsfm_depth_lm_launch_dev(self._ctx, _dp(d_q), _dp(d_u), C.c_int64(n), _v3(v), _v3(w), C.c_double(k), _dp(d_alpha), _dp(d_alpha_k), _dp(d_rho), int(launch_id)), "rsdsfm_depth_lm_launch_dev")
+
+    def depth_lm_reduce_dev(self, n_shard, d_row):
+        self._check(self.lib.rsdsfm_depth_lm_reduce_dev(self._ctx, C.c_int64(n_shard), _dp(d_row)), "rsdsfm_depth_lm_reduce_dev")
+
+    def depth_lm_decide_rows_dev(self, d_rows, nrows, n_total, launch_id):
+        self._check(self.lib.rsdsfm_depth_lm_decide_rows_dev(self._ctx, _dp(d_rows), C.c_int32(nrows), C.c_int64(n_total), int(launch_id)), "rsdsfm_depth_lm_decide_rows_dev")
+
+    def depth_lm_state(self):
+        status, nxt, sm = C.c_int32(), C.c_int32(), LmSummary()
+        self._check(self.lib.rsdsfm_depth_lm_state(self._ctx, C.byref(status), C.byref(nxt), C.byref(sm)), "rsdsfm_depth_lm_state")
+        return status.value, nxt.value, sm.as_dict()
 
     def depth_finish_dev(self, d_q, d_u, n, v, w, k, d_alpha, d_alpha_k, d_rho):
         sm = LmSummary()

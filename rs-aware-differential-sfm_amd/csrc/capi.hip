@@ -194,6 +194,31 @@ int rsdsfm_depth_lm_launch_dev(rsdsfm_ctx* ctx, const double* d_q, const double*
     return depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, launch_id);
 }
 
+// ---- stage-level entry points of the row-tiled (multi-GPU) dense depth solve ----
+int rsdsfm_depth_lm_sums_row_size(void) { return NS; }
+
+int rsdsfm_depth_lm_reduce_dev(rsdsfm_ctx* ctx, int64_t n_shard, double* d_row) {
+    CTX_OR_FAIL(ctx);
+    if (n_shard < 0 || !d_row) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    return depth_lm_reduce_launch(c, n_shard, d_row);
+}
+
+int rsdsfm_depth_lm_decide_rows_dev(rsdsfm_ctx* ctx, const double* d_rows, int32_t nrows, int64_t n_total, int launch_id) {
+    CTX_OR_FAIL(ctx);
+    if (!d_rows || nrows < 1 || n_total < 0 || launch_id < 0) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    return depth_lm_decide_rows_launch(c, d_rows, nrows, n_total, launch_id);
+}
+
+int rsdsfm_depth_lm_state(rsdsfm_ctx* ctx, int32_t* status, int32_t* next_launch, rsdsfm_lm_summary* summary) {
+    CTX_OR_FAIL(ctx);
+    int rc = read_lm_state(c);
+    if (rc != RSDSFM_OK) return rc;
+    if (status) *status = c->h_lm->status;
+    if (next_launch) *next_launch = c->h_lm->next_launch;
+    fill_summary(*c->h_lm, summary);
+    return RSDSFM_OK;
+}
+
 int rsdsfm_depth_finish_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_u, int64_t n, const double v[3],
                             const double w[3], double k, const double* d_alpha, const double* d_alpha_k,
                             double* d_rho, rsdsfm_lm_summary* summary, int32_t* extra_launches) {

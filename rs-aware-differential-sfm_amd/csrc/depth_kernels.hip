@@ -225,6 +225,49 @@ int depth_lm_launch(Ctx* c, const double* q, const double* u, const double* a, c
     return RSDSFM_OK;
 }
 
+// fixed-order reduction of this context's per-workgroup partials (the last depth_lm_kernel launch over n points)
+// into ONE row of NS sums -- the unit the row-tiled multi-GPU driver all-gathers
+__global__ __launch_bounds__(kDecideBlock) void depth_lm_reduce_kernel(const double* __restrict__ partials, int nblocks,
+                                                                       double* __restrict__ row) {
+    __shared__ double s_red[kDecideBlock / 64][NS];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double fin[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) fin[s] = 0.0;
+    for (int b = tid; b < nblocks; b += kDecideBlock) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            double v = partials[(int64_t)b * NS + s];
+            fin[s] = is_max_slot(s) ? fmax(fin[s], v) : fin[s] + v;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        double r = is_max_slot(s) ? wave_max(fin[s]) : wave_sum(fin[s]);
+        if (lane == 0) s_red[wv][s] = r;
+    }
+    __syncthreads();
+    if (tid < NS) {
+        double r = s_red[0][tid];
+        for (int w2 = 1; w2 < kDecideBlock / 64; ++w2) r = is_max_slot(tid) ? fmax(r, s_red[w2][tid]) : r + s_red[w2][tid];
+        row[tid] = r;
+    }
+}
+
+int depth_lm_reduce_launch(Ctx* c, int64_t n, double* d_row) {
+    const int grid = depth_grid(n, kDepthMaxBlocks);
+    hipLaunchKernelGGL(depth_lm_reduce_kernel, dim3(1), dim3(kDecideBlock), 0, c->stream, c->d_partials, grid, d_row);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+// decide on caller-provided rows (e.g. the all-gathered per-rank rows, in rank order)
+int depth_lm_decide_rows_launch(Ctx* c, const double* d_rows, int nrows, int64_t n_total, int launch_id) {
+    hipLaunchKernelGGL(depth_lm_decide_kernel, dim3(1), dim3(kDecideBlock), 0, c->stream, d_rows, nrows, c->d_lm, n_total, launch_id);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
 int depth_lm_decide_launch(Ctx* c, int64_t n, int launch_id) {
     const int grid = depth_grid(n, kDepthMaxBlocks);
     hipLaunchKernelGGL(depth_lm_decide_kernel, dim3(1), dim3(kDecideBlock), 0, c->stream, c->d_partials, grid, c->d_lm, n,

@@ -138,6 +138,8 @@ int depth_closed_form_launch(Ctx* c, const double* q, const double* u, const dou
 int depth_lm_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                     const Pose& pose, double* rho, int launch_id);
 int depth_lm_decide_launch(Ctx* c, int64_t n, int launch_id);
+int depth_lm_reduce_launch(Ctx* c, int64_t n, double* d_row);
+int depth_lm_decide_rows_launch(Ctx* c, const double* d_rows, int nrows, int64_t n_total, int launch_id);
 
 }  // namespace rsdsfm
 

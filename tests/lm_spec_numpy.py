@@ -1,0 +1,220 @@
+"""TEST INFRASTRUCTURE: a numpy restatement of the product's *speculative* LM protocol (depth_lm_kernel +
+lm_advance in rs-aware-differential-sfm_amd/csrc/lm_common.hpp / depth_kernels.hip), used
+
+  * to check on the CPU that the protocol (speculate KMAX iterations per launch, decide on the summed rows,
+    replan, apply) reproduces the oracle's straightforward Ceres-style LM, and
+  * as the stage backend of the world_size-2 gloo tests of the row-tiled driver (dist.py).
+
+It is a checker, never shipped: the product path is the HIP library only."""
+import numpy as np
+
+KMAX = 3
+NS = 3 + 5 * KMAX
+MAX_ITER, R0, RMAX, RMIN = 50, 1e4, 1e16, 1e-32
+MINREL, DMIN, DMAX, FTOL, GTOL, PTOL, MAXINV = 1e-3, 1e-6, 1e32, 1e-6, 1e-10, 1e-8, 5
+
+
+def radius_accept(radius, q):
+    t = 2.0 * q - 1.0
+    f = max(1.0 - t * t * t, 1.0 / 3.0)
+    return min(radius / f, RMAX)
+
+
+def is_max_slot(s):
+    return s == 2 or (s >= 3 and (s - 3) % 5 == 4)
+
+
+class State:
+    def __init__(self):
+        self.status, self.n_hist, self.K, self.write_which = 1, 0, KMAX, 0
+        self.iteration = self.num_successful = self.num_unsuccessful = self.invalid_run = 0
+        self.termination, self.rho_holds, self.launches, self.next_launch, self.predict = -1, -1, 0, 0, 1
+        self.radius, self.decrease_factor, self.cost, self.initial_cost = R0, 2.0, 0.0, 0.0
+        self.hist, self.cand = [], [0.0] * KMAX
+
+    def summary(self):
+        return dict(num_iterations=self.iteration, num_successful_steps=self.num_successful, num_unsuccessful_steps=self.num_unsuccessful,
+                    termination=self.termination, initial_cost=self.initial_cost, final_cost=self.cost, final_radius=self.radius)
+
+
+def plan_cands(r):
+    out = []
+    for _ in range(KMAX):
+        out.append(r)
+        r = radius_accept(r, 1.0)
+    return out
+
+
+def lm_advance(st, sums, n, first, used_K, used_write, launch_id):
+    if first:
+        pred = st.predict
+        st.__init__()
+        st.predict = pred
+        st.status, st.initial_cost = 0, 0.5 * sums[0]
+        st.cand = plan_cands(R0)
+    st.launches += 1
+    base_hist = st.n_hist
+    cost, x_norm, accepted = 0.5 * sums[0], np.sqrt(sums[1]), 0
+    if first and (n == 0 or sums[2] <= GTOL):
+        st.termination = 0
+    j = 0
+    while j < used_K and st.termination < 0:
+        if st.iteration >= MAX_ITER:
+            st.termination = 3
+            break
+        if st.radius < RMIN:
+            st.termination = 5
+            break
+        if st.cand[j] != st.radius:
+            break
+        s = sums[3 + 5 * j: 8 + 5 * j]
+        st.iteration += 1
+        model_change, ccost = s[1], 0.5 * s[0]
+        if not (model_change > 0.0):
+            st.num_unsuccessful += 1
+            st.invalid_run += 1
+            if st.invalid_run >= MAXINV:
+                st.termination = 4
+                break
+            st.radius *= 0.5
+            break
+        st.invalid_run = 0
+        if np.sqrt(s[2]) <= PTOL * (x_norm + PTOL):
+            st.termination = 1
+            break
+        cost_change = cost - ccost
+        if abs(cost_change) <= FTOL * cost:
+            st.termination = 2
+            break
+        rel = cost_change / model_change
+        if rel > MINREL:
+            st.hist.append(st.radius)
+            st.n_hist += 1
+            accepted = j + 1
+            cost, x_norm = ccost, np.sqrt(s[3])
+            st.radius = radius_accept(st.radius, rel)
+            st.decrease_factor = 2.0
+            st.num_successful += 1
+            if s[4] <= GTOL:
+                st.termination = 0
+                break
+        else:
+            st.num_unsuccessful += 1
+            st.radius = st.radius / st.decrease_factor
+            st.decrease_factor *= 2.0
+            break
+        j += 1
+    st.cost = cost
+    st.rho_holds = base_hist + used_write if used_write <= accepted else -1
+    if st.termination < 0 and st.iteration >= MAX_ITER:
+        st.termination = 3
+    if st.termination < 0 and st.radius < RMIN:
+        st.termination = 5
+    st.next_launch = launch_id + 1
+    if st.termination >= 0:
+        st.predict = min(st.n_hist, KMAX)
+        if st.rho_holds == st.n_hist:
+            st.status = 1
+        else:
+            st.status, st.K, st.write_which = 2, 0, 0
+    else:
+        st.status, st.K, st.write_which = 0, KMAX, 0
+        st.cand = plan_cands(st.radius)
+
+
+class NumpyDepthStage:
+    """Same interface as dist.HipDepthStage, on host arrays wrapped in CPU torch tensors."""
+
+    def __init__(self, q, u, alpha, alpha_k, v, w, k, torch):
+        self.torch = torch
+        self.q, self.u, self.a, self.ak = (np.asarray(x, dtype=np.float64) for x in (q, u, alpha, alpha_k))
+        self.v, self.w, self.k = np.asarray(v, float), np.asarray(w, float), float(k)
+        self.n = len(self.a)
+        self.rho = np.ones(self.n)
+        self.st = State()
+        x, y = self.q[:, 0], self.q[:, 1]
+        beta = (2.0 / (2.0 + self.k)) * (self.a + self.k * self.ak)
+        self.nbeta = beta * -1.0
+        self.a0, self.a1 = x * self.v[2] - self.v[0], y * self.v[2] - self.v[1]
+        self.c0 = (x * y * self.w[0], (1.0 + x * x) * self.w[1], y * self.w[2])
+        self.c1 = ((1.0 + y * y) * self.w[0], x * y * self.w[1], x * self.w[2])
+        self.J0, self.J1 = beta * self.a0, beta * self.a1
+        self.s = 1.0 / (1.0 + np.sqrt(self.J0 * self.J0 + self.J1 * self.J1))
+        self.jt0, self.jt1 = self.J0 * self.s, self.J1 * self.s
+        self.ht = self.jt0 * self.jt0 + self.jt1 * self.jt1
+        self.diag = np.clip(self.ht, DMIN, DMAX)
+
+    def _res(self, rho):
+        p0 = self.nbeta * (rho * self.a0 + self.c0[0] - self.c0[1] + self.c0[2])
+        p1 = self.nbeta * (rho * self.a1 + self.c1[0] - self.c1[1] - self.c1[2])
+        return self.u[:, 0] - p0, self.u[:, 1] - p1
+
+    def _step(self, rho, r0, r1, radius):
+        lam = self.diag * (1.0 / radius)
+        step = -((self.jt0 * r0 + self.jt1 * r1) / (self.ht + lam))
+        return step
+
+    def closed_form(self):
+        r0, r1 = self._res(np.ones(self.n))
+        h = self.J0 * self.J0 + self.J1 * self.J1
+        g = self.J0 * r0 + self.J1 * r1
+        self.rho = np.where(h > 0, 1.0 - g / np.where(h > 0, h, 1.0), 1.0)
+
+    def lm_launch(self, launch_id):
+        st = self.st
+        if launch_id == 0:
+            n_hist, hist, K, cand = 0, [], KMAX, plan_cands(R0)
+            write = st.predict if 0 <= st.predict <= KMAX else 1
+        else:
+            if st.status == 1 or st.next_launch != launch_id:
+                return
+            n_hist, hist = st.n_hist, st.hist
+            K, cand, write = (0, [], 0) if st.status == 2 else (st.K, st.cand, st.write_which)
+        self._used = (K, write)
+        rho = np.ones(self.n)
+        r0, r1 = self._res(rho)
+        for h in range(n_hist):
+            rho = rho + self._step(rho, r0, r1, hist[h]) * self.s
+            r0, r1 = self._res(rho)
+        out = rho
+        sums = np.zeros(NS)
+        if K > 0:
+            sums[0] = np.sum(r0 * r0 + r1 * r1)
+            sums[1] = np.sum(rho * rho)
+            sums[2] = np.max(np.abs(self.J0 * r0 + self.J1 * r1), initial=0.0)
+        for j in range(K):
+            step = self._step(rho, r0, r1, cand[j])
+            m0, m1 = self.jt0 * step, self.jt1 * step
+            sums[3 + 5 * j + 1] = -np.sum(m0 * (r0 + m0 / 2.0) + m1 * (r1 + m1 / 2.0))
+            cd = rho + step * self.s
+            sums[3 + 5 * j + 2] = np.sum((rho - cd) ** 2)
+            r0, r1 = self._res(cd)
+            sums[3 + 5 * j + 0] = np.sum(r0 * r0 + r1 * r1)
+            sums[3 + 5 * j + 3] = np.sum(cd * cd)
+            sums[3 + 5 * j + 4] = np.max(np.abs(self.J0 * r0 + self.J1 * r1), initial=0.0)
+            rho = cd
+            if write == j + 1:
+                out = cd
+        self.rho = out
+        self._sums = sums
+
+    def lm_reduce(self):
+        return self.torch.from_numpy(self._sums.copy())
+
+    def lm_decide_rows(self, rows, n_total, launch_id):
+        rows = rows.numpy()
+        sums = np.zeros(NS)
+        for s in range(NS):
+            sums[s] = rows[:, s].max() if is_max_slot(s) else sum(float(x) for x in rows[:, s])  # rank order
+        st = self.st
+        if launch_id > 0 and (st.status != 0 or st.next_launch != launch_id):
+            return
+        used_K = KMAX if launch_id == 0 else st.K
+        used_write = (st.predict if 0 <= st.predict <= KMAX else 1) if launch_id == 0 else st.write_which
+        lm_advance(st, sums, n_total, launch_id == 0, used_K, used_write, launch_id)
+
+    def lm_state(self):
+        return self.st.status, self.st.next_launch, self.st.summary()
+
+    def result(self):
+        return self.torch.from_numpy(self.rho)

@@ -1,0 +1,112 @@
+"""CPU: (1) the speculative LM protocol the HIP kernels implement (restated in numpy, tests/lm_spec_numpy.py)
+reproduces the oracle's straightforward Ceres-style LM; (2) the row-tiled multi-GPU driver (dist.py) run as TWO
+gloo processes on CPU gives exactly the unsharded result and every rank ends with the full depth map."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import GOLDEN_CASES, ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import lm_spec_numpy as L  # noqa: E402
+
+
+def _solve_single(rsdsfm, q, u, a, ak, v, w, k, nshards=1):
+    bounds, per = rsdsfm.dist.shard_bounds(len(a), nshards)
+    stages = [L.NumpyDepthStage(q[i0:i1], u[i0:i1], a[i0:i1], ak[i0:i1], v, w, k, torch) for i0, i1 in bounds]
+    drv = rsdsfm.dist.TiledDepthSolve(stages, len(a), per, torch, None)
+    rho, sm = drv.solve(1)
+    return rho.numpy(), sm
+
+
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_speculative_protocol_equals_oracle_lm(golden, oracle, rsdsfm, case):
+    g = lambda k: golden[case + "/" + k]
+    q, u, a, ak = g("q"), g("u"), g("alpha"), g("alpha_k")
+    for t in range(6):
+        v, w, k = g("hyp_v")[t], g("hyp_w")[t], float(g("hyp_k")[t])
+        rho, sm = _solve_single(rsdsfm, q, u, a, ak, v, w, k)
+        rho_o, sm_o = oracle.estimate_inverse_depths(q, u, v, w, k, a, ak, mode=1)
+        for key in ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination"):
+            assert sm[key] == sm_o[key], (key, sm, sm_o)
+        assert np.isclose(sm["final_radius"], sm_o["final_radius"], rtol=1e-15)
+        assert np.allclose(rho, rho_o, rtol=1e-12, atol=1e-15)
+        # row-tiling invariance: 3 logical shards, same decisions, same depths
+        rho3, sm3 = _solve_single(rsdsfm, q, u, a, ak, v, w, k, nshards=3)
+        assert sm3["num_successful_steps"] == sm["num_successful_steps"] and sm3["termination"] == sm["termination"]
+        assert np.array_equal(rho3, rho)
+
+
+def test_speculative_protocol_long_trajectory(oracle, rsdsfm):
+    """more LM iterations than one speculative launch covers (continuation launches + apply)"""
+    d = rsdsfm.synth.make_config(1, rows=40, cols=48)
+    q, u, a, ak = d["q"].copy(), d["u"].copy(), d["alpha"], d["alpha_k"]
+    v = np.array([0.05, 0.03, 1.0])
+    v /= np.linalg.norm(v)
+    w = d["truth"]["w"]
+    q[7] = [v[0] / v[2] + 1e-7, v[1] / v[2] - 2e-7]
+    u[7] = [3e-2, -2e-2]
+    rho, sm = _solve_single(rsdsfm, q, u, a, ak, v, w, 0.0, nshards=2)
+    rho_o, sm_o = oracle.estimate_inverse_depths(q, u, v, w, 0.0, a, ak, mode=1)
+    assert sm["num_iterations"] == sm_o["num_iterations"] > 4 and sm["termination"] == sm_o["termination"]
+    assert np.allclose(rho, rho_o, rtol=1e-12, atol=1e-15)
+
+
+def test_shard_bounds(rsdsfm):
+    for n in (0, 1, 9, 10, 1001, 921600):
+        for p in (1, 2, 3, 8):
+            b, per = rsdsfm.dist.shard_bounds(n, p)
+            assert len(b) == p and b[0][0] == 0 and b[-1][1] == n
+            assert all(b[i][1] == b[i + 1][0] for i in range(p - 1))
+            assert all(i0 % 2 == 0 for i0, i1 in b if i1 > i0) and all(i1 - i0 <= per for i0, i1 in b)
+
+
+def _worker(rank, world, port, case, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import rsdsfm
+    import lm_spec_numpy as LL
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+    q, u, a, ak = (g[case + "/" + k] for k in ("q", "u", "alpha", "alpha_k"))
+    v, w, k = g[case + "/hyp_v"][1], g[case + "/hyp_w"][1], float(g[case + "/hyp_k"][1])
+    bounds, per = rsdsfm.dist.shard_bounds(len(a), world)
+    i0, i1 = bounds[rank]
+    res = {}
+    for mode in (0, 1):
+        st = LL.NumpyDepthStage(q[i0:i1], u[i0:i1], a[i0:i1], ak[i0:i1], v, w, k, torch)
+        drv = rsdsfm.dist.TiledDepthSolve([st], len(a), per, torch, dist)
+        rho, sm = drv.solve(mode)
+        res["rho%d" % mode] = rho.numpy()
+        if sm:
+            res["steps"] = np.array(sm["num_successful_steps"])
+            res["term"] = np.array(sm["termination"])
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), **res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["noisy_k0", "clean_k0"])
+def test_row_tiled_driver_gloo_world2(tmp_path, oracle, golden, case):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
+    g = lambda k: golden[case + "/" + k]
+    q, u, a, ak = g("q"), g("u"), g("alpha"), g("alpha_k")
+    v, w, k = g("hyp_v")[1], g("hyp_w")[1], float(g("hyp_k")[1])
+    rho0, _ = oracle.estimate_inverse_depths(q, u, v, w, k, a, ak, mode=0)
+    rho1, sm1 = oracle.estimate_inverse_depths(q, u, v, w, k, a, ak, mode=1)
+    r = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % i)) for i in range(2)]
+    for i in range(2):  # every rank holds the full, identical depth map after the all-gather
+        assert r[i]["rho0"].shape == rho0.shape
+        assert np.allclose(r[i]["rho0"], rho0, rtol=1e-12, atol=1e-15)
+        assert np.allclose(r[i]["rho1"], rho1, rtol=1e-12, atol=1e-15)
+        assert int(r[i]["steps"]) == sm1["num_successful_steps"] and int(r[i]["term"]) == sm1["termination"]
+    assert np.array_equal(r[0]["rho1"], r[1]["rho1"]) and np.array_equal(r[0]["rho0"], r[1]["rho0"])

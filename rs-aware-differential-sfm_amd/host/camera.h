@@ -1,0 +1,59 @@
+// camera.h -- the facade of the reference's Camera (src/camera.h) over the frames: intrinsics (incl. the five
+// hard-coded phone calibrations, camera.cc:179-206), gamma, pose and depth map forwarding (camera.cc:335-371).
+// Image, flow, CSV and visualisation members are out of scope.
+#ifndef RSDSFM_HOST_CAMERA_H
+#define RSDSFM_HOST_CAMERA_H
+
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "rsframe.h"
+
+class Camera {
+public:
+    Camera() {}
+    rsdsfm::lite::Matrix3d getIntrinsics() { return K_; }
+    void setIntrinsics(const rsdsfm::lite::Matrix3d& K) {
+        K_ = K;
+        for (auto& f : frames_) f.setIntrinsics(K_);
+    }
+    /** reference camera.cc:179-206 */
+    void setIntrinsics(const std::string source_camera) {
+        double fx, fy, cx, cy;
+        if (source_camera == "iphone") fx = 1505.1283359786307, fy = 1513.7789208311444, cx = 657.81734686405991, cy = 349.91807538147589;
+        else if (source_camera == "galaxy_stabil") fx = 1803.29785922382, fy = 1799.35406531529, cx = 945.304708272490, cy = 544.684292978344;
+        else if (source_camera == "galaxy") fx = 1492.41306997746, fy = 1491.09286590722, cx = 949.571146410704, cy = 554.675409391795;
+        else if (source_camera == "galaxy_old") fx = 3154.53208221173, fy = 3152.28696217577, cx = 1969.87107268891, cy = 1521.27056048818;
+        else if (source_camera == "galaxy_vga") fx = 484.450845764569, fy = 485.345469134313, cx = 313.442094604855, cy = 241.383116350144;
+        else {
+            std::cerr << "No valid source camera specified";
+            return;
+        }
+        rsdsfm::lite::Matrix3d K = rsdsfm::lite::Matrix3d::Zero();
+        K(0, 0) = fx, K(1, 1) = fy, K(0, 2) = cx, K(1, 2) = cy, K(2, 2) = 1.0;
+        setIntrinsics(K);
+    }
+    /** frames are 1-based like the reference; only the frame geometry is kept (no pixel data) */
+    void addFrame(int rows, int cols) {
+        frames_.emplace_back(rows, cols);
+        frames_.back().setIntrinsics(K_);
+    }
+    RsFrame getFrame(const int frameNr) { return frames_[(size_t)frameNr - 1]; }
+    RsFrame& frame(const int frameNr) { return frames_[(size_t)frameNr - 1]; }
+    rsdsfm::lite::MatrixXd getDepthMap(const int frameNr) { return frames_[(size_t)frameNr - 1].getDepthMap(); }
+    void setDepthMap(const int frameNr, rsdsfm::lite::MatrixXd depth_map) { frames_[(size_t)frameNr - 1].setDepthMap(depth_map); }
+    /** reference camera.cc:340-342 */
+    void setPose(const int frameNr, const double k, const rsdsfm::lite::Vector3d& linear_velocity, const rsdsfm::lite::Vector3d& angular_velocity) {
+        frames_[(size_t)frameNr - 1].setRelativePose(linear_velocity, angular_velocity, k);
+    }
+    void setGamma(const double gamma) {
+        for (auto& f : frames_) f.setGamma(gamma);
+    }
+
+private:
+    rsdsfm::lite::Matrix3d K_;
+    std::vector<RsFrame> frames_;
+};
+
+#endif

@@ -1,0 +1,47 @@
+// rsframe.h -- the part of the reference's RsFrame (src/rsframe.h) that consumes the solver's output: frame size,
+// gamma, intrinsics, depth map and the per-scanline relative pose table (setRelativePose, rsframe.cc:771-800, computed
+// by the pose_table HIP kernel).  Image / OpenCV / CSV members of the reference class are out of scope.
+#ifndef RSDSFM_HOST_RSFRAME_H
+#define RSDSFM_HOST_RSFRAME_H
+
+#include <vector>
+
+#include "minimal.h"
+#include "scanline.h"
+
+class RsFrame {
+public:
+    RsFrame() : rows_(0), cols_(0), gamma_(1.0) {}
+    RsFrame(int rows, int cols) : rows_(rows), cols_(cols), gamma_(1.0), scanlines_((size_t)rows) {}
+    void setIntrinsics(const rsdsfm::lite::Matrix3d& intrinsics) { K_ = intrinsics; }
+    void setGamma(const double gamma) { gamma_ = gamma; }
+    int getRows() const { return rows_; }
+    int getCols() const { return cols_; }
+    void setDepthMap(const rsdsfm::lite::MatrixXd& depth_map) { depth_map_ = depth_map; }
+    rsdsfm::lite::MatrixXd getDepthMap() { return depth_map_; }
+    const Scanline& getScanline(int i) const { return scanlines_[(size_t)i]; }
+
+    /** reference rsframe.cc:771-800 */
+    void setRelativePose(const rsdsfm::lite::Vector3d& linear_velocity, const rsdsfm::lite::Vector3d& angular_velocity, const double k) {
+        std::vector<double> R((size_t)rows_ * 9), t((size_t)rows_ * 3);
+        rsdsfm::check(rsdsfm_pose_table(rsdsfm::default_context(), linear_velocity.data(), angular_velocity.data(), k, gamma_, rows_,
+                                        R.data(), t.data()),
+                      "rsdsfm_pose_table");
+        for (int i = 0; i < rows_; ++i) {
+            rsdsfm::lite::Matrix3d Ri;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) Ri(r, c) = R[(size_t)i * 9 + r * 3 + c];
+            scanlines_[(size_t)i].setRelativeRotation(Ri);
+            scanlines_[(size_t)i].setRelativeTranslation(rsdsfm::lite::Vector3d(t[(size_t)i * 3], t[(size_t)i * 3 + 1], t[(size_t)i * 3 + 2]));
+        }
+    }
+
+private:
+    int rows_, cols_;
+    double gamma_;
+    rsdsfm::lite::Matrix3d K_;
+    rsdsfm::lite::MatrixXd depth_map_;
+    std::vector<Scanline> scanlines_;
+};
+
+#endif

@@ -1,0 +1,89 @@
+// single_run.cpp -- the solver part of the reference's evaluateSingleRun() (main.cc:398-522) written against the
+// drop-in C++ mirror (host/minimal.h, host/nonlinearRefinement.h, host/camera.h): flatten -> getAlpha/getAlphaK ->
+// ransac -> nonLinearRefinement -> sign canonicalisation + depth map -> Camera::setPose.
+// Reads a raw flow image, prints the results as JSON on stdout; driven by tests/test_gpu_cpp_mirror.py.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../rs-aware-differential-sfm_amd/host/camera.h"
+#include "../../rs-aware-differential-sfm_amd/host/nonlinearRefinement.h"
+
+using namespace rsdsfm::lite;
+
+int main(int argc, char** argv) {
+    if (argc < 12) {
+        std::fprintf(stderr, "usage: single_run flow.bin rows cols fx fy cx cy gamma trials tol seed\n");
+        return 2;
+    }
+    const int rows = std::atoi(argv[2]), cols = std::atoi(argv[3]);
+    const double fx = std::atof(argv[4]), fy = std::atof(argv[5]), cx = std::atof(argv[6]), cy = std::atof(argv[7]);
+    const double gamma = std::atof(argv[8]);
+    const int ransac_trials = std::atoi(argv[9]);
+    const double ransac_tol = std::atof(argv[10]);
+    rsdsfm::set_ransac_seed((uint64_t)std::strtoull(argv[11], nullptr, 10));
+    const double flow_threshold = 1e-10;  // main.cc:311
+
+    std::vector<double> img((size_t)rows * cols * 2);
+    FILE* f = std::fopen(argv[1], "rb");
+    if (!f || std::fread(img.data(), sizeof(double), img.size(), f) != img.size()) return 3;
+    std::fclose(f);
+
+    try {
+        // flatten (main.cc:398-432, shrinking variant) + alpha (main.cc:437-438), one fused device pass
+        Matrix2Xd coord(2, (long)rows * cols), flow(2, (long)rows * cols);
+        ArrayXd alpha((long)rows * cols), alphaK((long)rows * cols);
+        int64_t n = 0;
+        rsdsfm::check(rsdsfm_flatten(rsdsfm::default_context(), img.data(), rows, cols, fx, fy, cx, cy, gamma, flow_threshold, coord.data(),
+                                     flow.data(), alpha.data(), alphaK.data(), &n),
+                      "rsdsfm_flatten");
+        coord.conservativeResize(2, (long)n);
+        flow.conservativeResize(2, (long)n);
+        alpha.conservativeResize((long)n);
+        alphaK.conservativeResize((long)n);
+
+        // run ransac (main.cc:447), then the nonlinear refinement (main.cc:457) on the gathered flow
+        RansacValues ransac_results = minimal::ransac(coord, flow, alpha, alphaK, false, ransac_trials, ransac_tol, true);
+        nonlinear_refinement::flow_index_mode() = RSDSFM_FLOW_GATHERED;
+        RansacValues results = nonlinear_refinement::nonLinearRefinement(flow, ransac_results, false, false);
+
+        // sign flip + depth map (main.cc:466-509)
+        MatrixXd depth_map(rows, cols);
+        std::vector<int32_t> ys((size_t)results.num_inliers);
+        int flipped = 0;
+        double v[3] = {results.v(0), results.v(1), results.v(2)};
+        rsdsfm::check(rsdsfm_depth_map(rsdsfm::default_context(), results.inliers.data(), results.num_inliers, v, fx, fy, cx, cy, rows, cols,
+                                       depth_map.data(), nullptr, ys.data(), &flipped),
+                      "rsdsfm_depth_map");
+        results.v = Vector3d(v[0], v[1], v[2]);
+
+        // relative pose per scanline (main.cc:516 -> camera.cc:340 -> rsframe.cc:771)
+        Camera camera;
+        Matrix3d K = Matrix3d::Zero();
+        K(0, 0) = fx, K(1, 1) = fy, K(0, 2) = cx, K(1, 2) = cy, K(2, 2) = 1.0;
+        camera.setIntrinsics(K);
+        camera.addFrame(rows, cols);
+        camera.setGamma(gamma);
+        camera.setPose(1, results.k, results.v, results.w);
+        camera.setDepthMap(1, depth_map);
+        const Scanline& last = camera.frame(1).getScanline(rows - 1);
+
+        double zsum = 0;
+        for (long i = 0; i < results.num_inliers; ++i) zsum += results.inliers(2, i);
+        long long ysum = 0;
+        for (int32_t y : ys) ysum += y;
+        std::printf("{\"n\": %lld, \"ransac_inliers\": %d, \"ransac_w\": [%.17g, %.17g, %.17g], \"ransac_v\": [%.17g, %.17g, %.17g], "
+                    "\"w\": [%.17g, %.17g, %.17g], \"v\": [%.17g, %.17g, %.17g], \"k\": %.17g, \"flipped\": %d, \"zsum\": %.17g, "
+                    "\"ysum\": %lld, \"last_t\": [%.17g, %.17g, %.17g], \"last_R01\": %.17g}\n",
+                    (long long)n, ransac_results.num_inliers, ransac_results.w(0), ransac_results.w(1), ransac_results.w(2), ransac_results.v(0),
+                    ransac_results.v(1), ransac_results.v(2), results.w(0), results.w(1), results.w(2), results.v(0), results.v(1),
+                    results.v(2), results.k, flipped, zsum, ysum, last.getRelativeTranslation()(0), last.getRelativeTranslation()(1),
+                    last.getRelativeTranslation()(2), last.getRelativeRotation()(0, 1));
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "error: %s\n", e.what());
+        return 1;
+    }
+    rsdsfm_destroy(rsdsfm::default_context());
+    return 0;
+}

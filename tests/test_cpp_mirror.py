@@ -1,0 +1,60 @@
+"""The C++ drop-in mirror of the reference's function boundary (rs-aware-differential-sfm_amd/host/*.h).
+CPU: it compiles and links against the C-ABI library.  GPU: tests/cpp/single_run.cpp (the solver part of the
+reference's evaluateSingleRun, main.cc:398-522, written against the mirror) reproduces the Python-driven path."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+PKG = os.path.join(ROOT, "rs-aware-differential-sfm_amd")
+
+
+def _build(tmp_path):
+    exe = os.path.join(str(tmp_path), "single_run")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "cpp", "single_run.cpp"),
+           "-L", PKG, "-lrsdsfm_hip", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_mirror_compiles_and_links(tmp_path, rsdsfm):
+    rsdsfm.load_library()
+    exe = _build(tmp_path)
+    assert os.path.exists(exe)
+    # without arguments it prints the usage and exits with 2 (no GPU work)
+    assert subprocess.run([exe], capture_output=True).returncode == 2
+
+
+@pytest.mark.gpu
+def test_single_run_matches_python_path(tmp_path, rsdsfm, oracle):
+    exe = _build(tmp_path)
+    d = rsdsfm.synth.make_config(3, rows=120, cols=200)
+    img, K, gamma = d["flow_img"], d["K"], d["gamma"]
+    raw = os.path.join(str(tmp_path), "flow.bin")
+    img.astype(np.float64).tofile(raw)
+    T, tol, seed = 15, 0.002, 4242
+    out = subprocess.run([exe, raw, "120", "200"] + ["%.17g" % x for x in K] + ["%.17g" % gamma, str(T), "%.17g" % tol, str(seed)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout)
+    with rsdsfm.Solver(0) as s:
+        q, u, a, ak = s.flatten(img, K, gamma)
+        rr = s.ransac(q, u, a, ak, False, T, tol, samples=None, seed=seed, depth_mode=1)
+        ref = s.non_linear_refinement(u, rr["inliers"], rr["alpha"], rr["alpha_k"], rr["v"], rr["w"], rr["k"], False, flow_index_mode=1,
+                                      inlier_idx=rr["inlier_idx"])
+        dm = s.depth_map(ref["inliers"], ref["v"], K, 120, 200)
+        R, t = s.pose_table(dm["v"], ref["w"], ref["k"], gamma, 120)
+    assert r["n"] == len(q) and r["ransac_inliers"] == rr["num_inliers"]
+    assert np.array_equal(r["ransac_w"], rr["w"]) and np.array_equal(r["ransac_v"], rr["v"])
+    assert np.array_equal(r["w"], ref["w"]) and np.array_equal(r["v"], dm["v"]) and r["k"] == ref["k"]
+    assert r["flipped"] == int(dm["flipped"])
+    assert r["ysum"] == int(dm["ys"].astype(np.int64).sum())  # scanline indices: bit-exact
+    assert np.isclose(r["zsum"], dm["inliers"][:, 2].sum(), rtol=1e-12)
+    assert np.array_equal(r["last_t"], t[-1]) and r["last_R01"] == R[-1][0, 1]
+    # and the oracle agrees with the whole chain (same sampler, same seed)
+    ro = oracle.ransac(q, u, a, ak, False, T, tol, oracle.sample_indices(len(q), T, seed), depth_mode=1)
+    assert ro["num_inliers"] == r["ransac_inliers"]

@@ -3,12 +3,17 @@
 
 Contract: python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on rank 0.
   step      = one pass of the hot path over one synthetic frame pair resident in HBM.
-  workload  = BASELINE.json configs[1]: 1280x720, dense per-pixel depth solve (Ceres-LM emulation, the
-              reference-matching mode), pose (v, w) fixed.  `--workload full` times the whole solve instead.
-  N > 1     = one process per GPU (torch.distributed / RCCL), each rank solving its own frame pair
-              (sequence-throughput mode, BASELINE configs[4]); no data-path collective -> scaling "weak".
-Frame pairs rotate through enough distinct HBM buffers to exceed the 256 MiB Infinity Cache, so the timed
-loop streams from HBM, not from L3.
+  workload  = depth (default): BASELINE.json configs[1] -- 1280x720, dense per-pixel depth solve (Ceres-LM emulation,
+              the reference-matching mode), pose fixed.  The same line also carries `full_solve`: the whole solve
+              (flatten + RANSAC(50) + refinement + depth map + pose table) timed on a 1280x720 DeepFlow-like pair.
+              depth_closed_form : same with the exact closed-form per-pixel solve.
+              full              : the whole solve is the timed step.
+              tiled             : BASELINE configs[3]-style row tiling: a 3840x2160 frame sharded over the N ranks,
+                                  LM sum rows + ONE all-gather of the depth map over RCCL (scaling "strong").
+  N > 1     = one process per GPU (torch.distributed / RCCL).  depth / full: each rank solves its own frame pair
+              (sequence-throughput mode, BASELINE configs[4]), no data-path collective -> scaling "weak".
+Frame pairs rotate through enough distinct HBM buffers to exceed the 256 MiB Infinity Cache, so the timed loop
+streams from HBM, not from L3.
 """
 import argparse
 import json
@@ -21,6 +26,7 @@ sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_PIXEL_DEPTH = 56  # read q 16 + u 16 + alpha 8 + alpha_k 8, write rho 8
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+METRIC = "Mpixels/sec RS depth+pose solve, 1280x720 pair"
 
 
 def cpu_baseline(data, v, w, budget_s=12.0):
@@ -44,14 +50,36 @@ def cpu_baseline(data, v, w, budget_s=12.0):
             "sample": "%d x full 1280x720 dense depth solve (oracle rso_estimate_inverse_depths, LM mode), %.1f s" % (reps, el)}
 
 
+def cpu_baseline_full(rsdsfm, trials, tol, budget_s=25.0):
+    """whole solve on the oracle for one 640x360 DeepFlow-like pair (a quarter of the pixels, same algorithm)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+
+    d = rsdsfm.synth.make_config(5, rows=360, cols=640)
+    t0 = time.perf_counter()
+    q, u, qpx, fpx = O.flatten(d["flow_img"], *d["K"], d["gamma"])
+    a, ak = O.get_alpha(fpx, 360, d["gamma"]), O.get_alpha_k(qpx, fpx, 360, d["gamma"])
+    nt = max(1, min(trials, 10))
+    r = O.ransac(q, u, a, ak, False, nt, tol, O.sample_indices(len(q), nt, 1), depth_mode=1)
+    ref = O.refine(u, r["inliers"], r["alpha"], r["alpha_k"], r["v"], r["w"], r["k"], False, 1, r["inlier_idx"])
+    inl, v, _ = O.canonicalize_sign(ref["inliers"], ref["v"])
+    O.scatter_depth(inl, *d["K"], 360, 640)
+    el = time.perf_counter() - t0
+    # RANSAC cost is linear in the trial count: scale the measured time to `trials`
+    return {"value": 360 * 640 / el / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "sample": "one 640x360 DeepFlow-like pair, whole solve with %d RANSAC trials (oracle), %.1f s" % (nt, el), "trials": nt}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form"])
+    ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form", "full", "tiled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nbuf", type=int, default=7, help="rotating HBM buffer sets (7 x 59 MB > 256 MiB L3)")
+    ap.add_argument("--trials", type=int, default=50, help="RANSAC trials of the full solve (report section 5.4 used 50)")
+    ap.add_argument("--tol", type=float, default=0.05, help="RANSAC tolerance (reference main.cc:310)")
     args = ap.parse_args()
 
     import numpy as np
@@ -73,23 +101,6 @@ def main():
 
     import rsdsfm
 
-    # ---- synthetic input: BASELINE config 2 (1280x720, analytic scene, noise-free), one pair per rank ----
-    data = rsdsfm.synth.make_config(2, seed=0x5EED0002 + rank)
-    rows, cols = data["rows"], data["cols"]
-    n = len(data["q"])
-    t = data["truth"]
-    v = t["v"] / np.linalg.norm(t["v"])  # unit translation, as the minimal solver returns it (minimal.cc:102-105)
-    w = t["w"]
-    k = 0.0
-    mode = rsdsfm.DEPTH_CERES_LM if args.workload == "depth" else rsdsfm.DEPTH_CLOSED_FORM
-
-    nbuf = args.nbuf  # default 7 x (48+8) B x 921600 = 361 MB > 256 MiB Infinity Cache
-    sets = []
-    for _ in range(nbuf):
-        sets.append(dict(
-            q=torch.from_numpy(data["q"]).to(dev), u=torch.from_numpy(data["u"]).to(dev),
-            a=torch.from_numpy(data["alpha"]).to(dev), ak=torch.from_numpy(data["alpha_k"]).to(dev),
-            rho=torch.empty(n, dtype=torch.float64, device=dev)))
     # a NON-default torch stream: its handle is non-null, so the library adopts it (a null handle would make the
     # context create a private stream) and torch.cuda.Event timings see the kernels
     stream = torch.cuda.Stream(dev)
@@ -97,109 +108,176 @@ def main():
     assert stream.cuda_stream != 0
     solver = rsdsfm.Solver(local_rank, stream=stream.cuda_stream)
 
-    calls = [solver.prepared_depth_step(s["q"].data_ptr(), s["u"].data_ptr(), n, v, w, k, s["a"].data_ptr(),
-                                        s["ak"].data_ptr(), s["rho"].data_ptr(), mode=mode) for s in sets]
-
-    def step(i):
-        calls[i % nbuf]()
-
     def barrier():
         if world > 1:
             dist.barrier()
 
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize()
-    # the fast path must have completed the LM state machine on its own (no extra launches needed)
-    extra = 0
-    if mode == rsdsfm.DEPTH_CERES_LM:
-        s = sets[(args.warmup - 1) % nbuf] if args.warmup > 0 else sets[0]
-        if args.warmup == 0:
-            step(0)
-        summary, extra = solver.depth_finish_dev(s["q"].data_ptr(), s["u"].data_ptr(), n, v, w, k, s["a"].data_ptr(),
-                                                 s["ak"].data_ptr(), s["rho"].data_ptr())
-    else:
-        summary = None
-
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    torch.cuda.synchronize()
-    barrier()
-    el = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-
-    # correctness of what was timed: state machine finished inside the fixed launch sequence, result sane
-    if mode == rsdsfm.DEPTH_CERES_LM:
-        s = sets[(args.steps - 1) % nbuf]
-        summary, extra2 = solver.depth_finish_dev(s["q"].data_ptr(), s["u"].data_ptr(), n, v, w, k, s["a"].data_ptr(),
-                                                  s["ak"].data_ptr(), s["rho"].data_ptr())
-        extra = max(extra, extra2)
-    rho = sets[(args.steps - 1) % nbuf]["rho"].cpu().numpy()
-    rho_true = (1.0 / t["Z"]).T.reshape(-1) * np.linalg.norm(t["v"])
-    max_rel = float(np.max(np.abs(rho - rho_true) / np.abs(rho_true)))
-
-    # ---- dominant-kernel duration, HIP events on the launch stream (torch's current stream) ----
-    kern_ms = None
-    if rank == 0:
-        reps = max(20, min(args.steps, 200))
-        e0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-        e1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-        for i in range(reps):
-            s = sets[i % nbuf]
-            e0[i].record(stream)
-            if mode == rsdsfm.DEPTH_CERES_LM:
-                solver.depth_lm_launch_dev(s["q"].data_ptr(), s["u"].data_ptr(), n, v, w, k, s["a"].data_ptr(),
-                                           s["ak"].data_ptr(), s["rho"].data_ptr(), launch_id=0)
-            else:
-                step(i)
-            e1[i].record(stream)
+    def timed(step, steps, warmup):
+        for i in range(warmup):
+            step(i)
         torch.cuda.synchronize()
-        ts = sorted(a_.elapsed_time(b_) for a_, b_ in zip(e0, e1))
-        kern_ms = float(np.mean(ts))
-        kern_ms_median = float(ts[len(ts) // 2])
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(i)
+        torch.cuda.synchronize()
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        return el
+
+    line = {"metric": METRIC, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+
+    # =================================================================================================
+    if args.workload in ("depth", "depth_closed_form"):
+        data = rsdsfm.synth.make_config(2, seed=0x5EED0002 + rank)  # 1280x720, analytic scene, noise-free
+        rows, cols = data["rows"], data["cols"]
+        n = len(data["q"])
+        t = data["truth"]
+        v = t["v"] / np.linalg.norm(t["v"])  # unit translation, as the minimal solver returns it (minimal.cc:102-105)
+        w, k = t["w"], 0.0
+        mode = rsdsfm.DEPTH_CERES_LM if args.workload == "depth" else rsdsfm.DEPTH_CLOSED_FORM
+        nbuf = args.nbuf
+        sets = []
+        for _ in range(nbuf):
+            sets.append(dict(q=torch.from_numpy(data["q"]).to(dev), u=torch.from_numpy(data["u"]).to(dev),
+                             a=torch.from_numpy(data["alpha"]).to(dev), ak=torch.from_numpy(data["alpha_k"]).to(dev),
+                             rho=torch.empty(n, dtype=torch.float64, device=dev)))
+        calls = [solver.prepared_depth_step(s["q"].data_ptr(), s["u"].data_ptr(), n, v, w, k, s["a"].data_ptr(),
+                                            s["ak"].data_ptr(), s["rho"].data_ptr(), mode=mode) for s in sets]
+
+        def ptrs(s):
+            return (s["q"].data_ptr(), s["u"].data_ptr(), n, v, w, k, s["a"].data_ptr(), s["ak"].data_ptr(), s["rho"].data_ptr())
+
+        el = timed(lambda i: calls[i % nbuf](), args.steps, args.warmup)
+        # correctness of what was timed: the LM state machine finished inside the fixed launch sequence
+        extra, summary = 0, None
+        if mode == rsdsfm.DEPTH_CERES_LM:
+            summary, extra = solver.depth_finish_dev(*ptrs(sets[(args.steps - 1) % nbuf]))
+        rho = sets[(args.steps - 1) % nbuf]["rho"].cpu().numpy()
+        rho_true = (1.0 / t["Z"]).T.reshape(-1) * np.linalg.norm(t["v"])
+        max_rel = float(np.max(np.abs(rho - rho_true) / np.abs(rho_true)))
+
+        # dominant-kernel duration: HIP events on the launch stream around single launches of that kernel
+        kern_ms = kern_med = None
+        if rank == 0:
+            reps = max(20, min(args.steps, 200))
+            e0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+            e1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+            for i in range(reps):
+                s = sets[i % nbuf]
+                e0[i].record(stream)
+                if mode == rsdsfm.DEPTH_CERES_LM:
+                    solver.depth_lm_launch_dev(*ptrs(s), launch_id=0)
+                else:
+                    calls[i % nbuf]()
+                e1[i].record(stream)
+            torch.cuda.synchronize()
+            ts = sorted(a_.elapsed_time(b_) for a_, b_ in zip(e0, e1))
+            kern_ms, kern_med = float(np.mean(ts)), float(ts[len(ts) // 2])
+
+        if rank == 0:
+            alg_bytes = ALG_BYTES_PER_PIXEL_DEPTH * n
+            achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+            line.update({
+                "value": rows * cols * world * args.steps / el / 1e6, "ms_per_step": el / args.steps * 1e3, "scaling": "weak",
+                "config": {"workload": "BASELINE configs[1]: synthetic 1280x720 pair, per-pixel depth solve only (%s), pose "
+                                       "fixed; one pair per GPU, %d rotating HBM buffer sets" %
+                                       ("Ceres-1.14 LM emulation" if mode == 1 else "closed-form GN", nbuf),
+                           "rows": rows, "cols": cols, "pixels": n, "depth_mode": int(mode),
+                           "launches_per_step": 3 if mode == 1 else 1, "extra_lm_launches": int(extra), "lm_summary": summary,
+                           "max_rel_err_vs_truth": max_rel},
+                "roofline": {"bound": "hbm", "kernel": "depth_lm_kernel" if mode == 1 else "depth_closed_form_kernel",
+                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                             "traffic": _traffic(args.workload), "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms,
+                             "median_launch_ms": kern_med},
+            })
+        # the whole solve, reported beside the headline (not the timed `value`)
+        full = _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps=8, warmup=2, timed=timed) if args.workload == "depth" else None
+        if rank == 0:
+            line["full_solve"] = full
+            line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(data, v, w)
+
+    # =================================================================================================
+    elif args.workload == "full":
+        full = _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps=args.steps, warmup=args.warmup, timed=timed)
+        if rank == 0:
+            line.update({"value": full["value"] * world, "ms_per_step": full["ms_per_solve"], "scaling": "weak",
+                         "config": {"workload": "whole solve of a 1280x720 DeepFlow-like pair (BASELINE configs[4] data): flatten + "
+                                                "RANSAC(%d, tol %g) + refinement + depth map + pose table; one pair per GPU" % (args.trials, args.tol),
+                                    **{k2: full[k2] for k2 in ("rows", "cols", "trials", "num_inliers", "refine_summary")}},
+                         "roofline": None, "full_solve": full,
+                         "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_full(rsdsfm, args.trials, args.tol)})
+
+    # =================================================================================================
+    else:  # tiled
+        data = rsdsfm.synth.make_config(4, seed=0x5EED0004)  # every rank generates the same 3840x2160 frame
+        n = len(data["q"])
+        t = data["truth"]
+        v, w, k = t["v"] / np.linalg.norm(t["v"]), t["w"], 0.0
+        bounds, per = rsdsfm.dist.shard_bounds(n, world)
+        i0, i1 = bounds[rank]
+        tt_ = lambda a: torch.from_numpy(np.ascontiguousarray(a[i0:i1])).to(dev)
+        stage = rsdsfm.dist.HipDepthStage(solver, tt_(data["q"]), tt_(data["u"]), tt_(data["alpha"]), tt_(data["alpha_k"]), v, w, k, torch)
+        drv = rsdsfm.dist.TiledDepthSolve([stage], n, per, torch, dist if world > 1 else None)
+        res = {}
+
+        def step(i):
+            res["rho"], res["sm"] = drv.solve(rsdsfm.DEPTH_CERES_LM)
+
+        el = timed(step, args.steps, args.warmup)
+        if rank == 0:
+            line.update({"value": data["rows"] * data["cols"] * args.steps / el / 1e6, "ms_per_step": el / args.steps * 1e3, "scaling": "strong",
+                         "metric": "Mpixels/sec RS depth solve, 3840x2160 frame row-tiled over the ranks",
+                         "config": {"workload": "BASELINE configs[3]-style: synthetic 3840x2160 frame row-tiled over %d rank(s), dense depth "
+                                                "solve (Ceres-LM emulation), all-gather of the LM sum rows + ONE all-gather of the depth map" % world,
+                                    "rows": data["rows"], "cols": data["cols"], "pixels": n, "lm_summary": res["sm"],
+                                    "gathered": int(res["rho"].shape[0])},
+                         "roofline": None, "cpu_baseline": None})
 
     if rank == 0:
-        pixels_per_step = rows * cols * world
-        value = pixels_per_step * args.steps / el / 1e6
-        alg_bytes = ALG_BYTES_PER_PIXEL_DEPTH * n
-        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get(args.workload)
-            except Exception:
-                traffic = None
-        line = {
-            "metric": "Mpixels/sec RS depth+pose solve, 1280x720 pair",
-            "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: synthetic 1280x720 pair, per-pixel depth solve only "
-                                   "(%s), pose fixed; one pair per GPU, %d rotating HBM buffer sets" %
-                                   ("Ceres-1.14 LM emulation" if mode == 1 else "closed-form GN", nbuf),
-                       "rows": rows, "cols": cols, "pixels": n, "depth_mode": int(mode),
-                       "launches_per_step": 3 if mode == 1 else 1, "extra_lm_launches": int(extra),
-                       "lm_summary": summary, "max_rel_err_vs_truth": max_rel},
-            "roofline": {"bound": "hbm", "kernel": "depth_lm_kernel" if mode == 1 else "depth_closed_form_kernel",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms,
-                         "median_launch_ms": kern_ms_median},
-        }
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(data, v, w)
-        else:
-            line["cpu_baseline"] = None
         print(json.dumps(line))
     solver.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def _traffic(workload):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (null if absent)."""
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            return json.load(open(tf)).get(workload)
+        except Exception:
+            return None
+    return None
+
+
+def _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps, warmup, timed):
+    """whole solve on a 1280x720 DeepFlow-like pair (0.3 px noise, 10 % outliers), flow image resident in HBM"""
+    d = rsdsfm.synth.make_config(5, seed=0x5EED0005 + rank)
+    pipe = rsdsfm.pipeline.FramePipeline(solver, torch, dev, d["rows"], d["cols"], d["K"], d["gamma"])
+    imgs = [torch.from_numpy(d["flow_img"]).to(dev) for _ in range(3)]
+    out = {}
+
+    def step(i):
+        out["r"] = pipe.solve(imgs[i % 3], trials=args.trials, tol=args.tol, seed=1 + i)
+
+    el = timed(step, steps, warmup)
+    r = out["r"]
+    t = d["truth"]
+    vt = t["v"] / np.linalg.norm(t["v"])
+    vv = r["v"] / np.linalg.norm(r["v"])
+    return {"value": d["rows"] * d["cols"] * steps / el / 1e6, "unit": "Mpixels/s", "ms_per_solve": el / steps * 1e3,
+            "rows": d["rows"], "cols": d["cols"], "trials": args.trials, "tol": args.tol, "n": r["n"], "num_inliers": r["num_inliers"],
+            "refine_summary": r["refine"]["summary"] if r["refine"] else None,
+            "w_err": float(np.linalg.norm(r["w"] - t["w"])), "v_angle_deg": float(np.degrees(np.arccos(min(1.0, abs(float(vv @ vt)))))),
+            "stages": "flatten+alpha, minimal9 x %d, RANSAC LM sums/decide/score/pick/compaction, refinement, depth map, pose table" % args.trials}
 
 
 if __name__ == "__main__":

@@ -15,7 +15,7 @@ import os
 
 import numpy as np
 
-from . import dist, synth  # noqa: F401  (multi-GPU driver; analytic data generator used by tests and bench)
+from . import dist, pipeline, synth  # noqa: F401  (multi-GPU driver; analytic data generator used by tests and bench)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RSDSFM_LIB") or os.path.join(_HERE, "librsdsfm_hip.so")
@@ -276,6 +276,42 @@ class Solver:
 
     def depth_lm_launch_dev(self, d_q, d_u, n, v, w, k, d_alpha, d_alpha_k, d_rho, launch_id=0):
         self._check(self.lib.rsdsfm_depth_lm_launch_dev(self._ctx, _dp(d_q), _dp(d_u), C.c_int64(n), _v3(v), _v3(w), C.c_double(k), _dp(d_alpha), _dp(d_alpha_k), _dp(d_rho), int(launch_id)), "rsdsfm_depth_lm_launch_dev")
+
+    def flatten_dev(self, d_img, rows, cols, K, gamma, d_q, d_u, d_alpha, d_alpha_k, thr=1e-10):
+        cnt = C.c_int64()
+        d = C.c_double
+        self._check(self.lib.rsdsfm_flatten_dev(self._ctx, _dp(d_img), C.c_int32(rows), C.c_int32(cols), d(K[0]), d(K[1]), d(K[2]), d(K[3]), d(gamma), d(thr), _dp(d_q), _dp(d_u), _dp(d_alpha), _dp(d_alpha_k), C.byref(cnt)), "rsdsfm_flatten_dev")
+        return cnt.value
+
+    def ransac_dev(self, d_q, d_u, d_alpha, d_alpha_k, n, use_alpha_k, iterations, tolerance, out_ptrs, samples=None, seed=0, depth_mode=DEPTH_CERES_LM, k_sign_mode=K_COMPAT):
+        """out_ptrs: dict of DEVICE pointers (inlier_idx, inliers, alpha, alpha_k, mask, inv_depth; missing = not wanted)."""
+        T = int(iterations)
+        smp = None if samples is None else np.ascontiguousarray(samples, dtype=np.int32).reshape(-1)
+        out = RansacOut()
+        for name in ("inlier_idx", "inliers", "alpha", "alpha_k", "mask", "inv_depth"):
+            setattr(out, name, int(out_ptrs[name]) if out_ptrs.get(name) else None)
+        tc = np.zeros(max(T, 1), dtype=np.int64)
+        ts = np.zeros(max(T, 1), dtype=np.int32)
+        out.trial_count, out.trial_steps = tc.ctypes.data, ts.ctypes.data
+        self._check(self.lib.rsdsfm_ransac_dev(self._ctx, _dp(d_q), _dp(d_u), _dp(d_alpha), _dp(d_alpha_k), C.c_int64(n), int(use_alpha_k), C.c_int32(T), C.c_double(tolerance), _p(smp), C.c_uint64(seed), int(depth_mode), int(k_sign_mode), C.byref(out)), "rsdsfm_ransac_dev")
+        return dict(num_inliers=int(out.num_inliers), best_trial=int(out.best_trial), w=np.array(out.w[:]), v=np.array(out.v[:]), k=float(out.k),
+                    inlier_error=float(out.inlier_error), trial_count=tc[:T], trial_steps=ts[:T])
+
+    def refine_dev(self, d_flow, n_flow, m, d_inl, d_alpha, d_alpha_k, d_idx, v, w, k, const_acceleration, flow_index_mode, d_inl_out):
+        vo, wo, ko = (C.c_double * 3)(), (C.c_double * 3)(), C.c_double()
+        sm = LmSummary()
+        self._check(self.lib.rsdsfm_refine_dev(self._ctx, _dp(d_flow), C.c_int64(n_flow), C.c_int64(m), _dp(d_inl), _dp(d_alpha), _dp(d_alpha_k), _dp(d_idx) if d_idx else None, _v3(v), _v3(w), C.c_double(k), int(const_acceleration), int(flow_index_mode), _dp(d_inl_out), vo, wo, C.byref(ko), C.byref(sm)), "rsdsfm_refine_dev")
+        return dict(v=np.array(vo[:]), w=np.array(wo[:]), k=ko.value, summary=sm.as_dict())
+
+    def depth_map_dev(self, d_inl, m, v, K, rows, cols, d_depth_map, d_xs=None, d_ys=None):
+        vv = _v3(v)
+        flipped = C.c_int()
+        d = C.c_double
+        self._check(self.lib.rsdsfm_depth_map_dev(self._ctx, _dp(d_inl), C.c_int64(m), vv, d(K[0]), d(K[1]), d(K[2]), d(K[3]), C.c_int32(rows), C.c_int32(cols), _dp(d_depth_map), _dp(d_xs) if d_xs else None, _dp(d_ys) if d_ys else None, C.byref(flipped)), "rsdsfm_depth_map_dev")
+        return np.array(vv[:]), bool(flipped.value)
+
+    def pose_table_dev(self, v, w, k, gamma, rows, d_R, d_t):
+        self._check(self.lib.rsdsfm_pose_table_dev(self._ctx, _v3(v), _v3(w), C.c_double(k), C.c_double(gamma), C.c_int32(rows), _dp(d_R), _dp(d_t)), "rsdsfm_pose_table_dev")
 
     def depth_lm_reduce_dev(self, n_shard, d_row):
         self._check(self.lib.rsdsfm_depth_lm_reduce_dev(self._ctx, C.c_int64(n_shard), _dp(d_row)), "rsdsfm_depth_lm_reduce_dev")

@@ -276,19 +276,30 @@ __global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __rest
     for (int i = tid; i < T * 2; i += kRB) out[i] = s_acc[i];
 }
 
-// fixed-order reduction of one hypothesis batch's score partials into trial_count / trial_err (already offset)
+// fixed-order reduction of one hypothesis batch's score partials into trial_count / trial_err (already offset):
+// one workgroup per hypothesis, threads stride over the pixel workgroups (independent loads in flight), then a
+// DPP wave reduction and the 4 waves in order
 __global__ __launch_bounds__(256) void ransac_reduce_scores_kernel(const double* __restrict__ partials, int nblocks, int T,
                                                                   double* __restrict__ trial_count,
                                                                   double* __restrict__ trial_err) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= T) return;
+    __shared__ double s_red[4][2];
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double c = 0.0, e = 0.0;
-    for (int b = 0; b < nblocks; ++b) {
+    for (int b = tid; b < nblocks; b += 256) {
         c += partials[((int64_t)b * T + t) * 2 + 0];
         e += partials[((int64_t)b * T + t) * 2 + 1];
     }
-    trial_count[t] = c;
-    trial_err[t] = e;
+    c = wave_sum(c);
+    e = wave_sum(e);
+    if (lane == 0) {
+        s_red[wv][0] = c;
+        s_red[wv][1] = e;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        trial_count[t] = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
+        trial_err[t] = ((s_red[0][1] + s_red[1][1]) + s_red[2][1]) + s_red[3][1];
+    }
 }
 
 // the reference's best-trial rule (minimal.cc:278-285) over all trials in order: strictly more inliers, or
@@ -482,7 +493,7 @@ int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* 
                        reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states,
                        depth_mode, tol, partials);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(ransac_reduce_scores_kernel, dim3((T + 255) / 256), dim3(256), 0, c->stream, partials, grid, T,
+    hipLaunchKernelGGL(ransac_reduce_scores_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T,
                        trial_count, trial_err);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;

@@ -155,6 +155,10 @@ class Solver:
             msg = self.lib.rsdsfm_last_error(self._ctx)
             raise RsdsfmError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
 
+    def set_depth_variant(self, variant):
+        """0 = register-staged fused LM kernel (default), 1 = LDS-DMA double-buffered variant"""
+        self._check(self.lib.rsdsfm_set_depth_variant(self._ctx, int(variant)), "rsdsfm_set_depth_variant")
+
     def synchronize(self):
         self._check(self.lib.rsdsfm_synchronize(self._ctx), "rsdsfm_synchronize")
 

@@ -148,6 +148,14 @@ int rsdsfm_synchronize(rsdsfm_ctx* ctx) {
     return RSDSFM_OK;
 }
 
+int rsdsfm_set_depth_variant(rsdsfm_ctx* ctx, int variant) {
+    CTX_OR_FAIL(ctx);
+    if (variant != 0 && variant != 1) return fail(c, RSDSFM_ERR_INVALID, "depth variant must be 0 (register-staged) or 1 (LDS-DMA)");
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    c->depth_variant = variant;
+    return RSDSFM_OK;
+}
+
 const char* rsdsfm_kernel_name(const char* entry_point) {
     if (!entry_point) return "";
     if (!strcmp(entry_point, "estimate_inverse_depths_lm")) return "depth_lm_kernel";

@@ -129,13 +129,164 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lm_kernel(const double2* __
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// LDS-DMA variant of the fused LM kernel (selected per context: rsdsfm_set_depth_variant)
+// ---------------------------------------------------------------------------------------------------
+// Same arithmetic and outputs as depth_lm_kernel, different data movement: every WAVE streams its own 128-point
+// tiles HBM -> LDS with `global_load_lds_dwordx4` (no VGPR staging) into a private double buffer, issuing the loads of
+// tile i+1 before it computes tile i and waiting with a COUNTED s_waitcnt vmcnt(6) (the 6 loads of the next tile
+// may stay in flight; loads retire in order).  HBM latency is thereby hidden behind the fp64 work without spending
+// registers on prefetch.  No workgroup barrier and NO compiler-emitted LDS read inside the loop (hipcc would put an
+// s_waitcnt vmcnt(0) in front of it and drain the pipeline): the plan lives in registers and the tile is read
+// with ds_read_b128/b64 in one asm statement that carries its own lgkmcnt(0).
+// Measured on MI355X (1280x720, round 1): the kernel is VALU-bound (~13 us of fp64 issue with no memory traffic at
+// all), so this variant gains only ~5 % over the plain one (19.9 vs 21.0 us per back-to-back launch); it is kept
+// as a tested option and becomes the better choice as soon as the arithmetic per pixel shrinks.
+// Tile layout in a wave buffer (6144 B): q[128] @0, u[128] @2048, alpha[128] @4096, alpha_k[128] @5120; lane l owns
+// points l and l+64 of the tile (conflict-free 16-byte / 8-byte LDS reads).
+constexpr int kTilePoints = 128;
+constexpr int kTileBytes = 6144;
+constexpr int kDmaLdsHeader = 1024;  // s_red [4][NS] + inv_hist[kMaxIter]
+constexpr int kDmaLdsBytes = kDmaLdsHeader + (kDepthBlock / 64) * 2 * kTileBytes;
+
+__device__ __forceinline__ void dma16(const void* gsrc_lane, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc_lane,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ void issue_tile(const double2* __restrict__ q, const double2* __restrict__ u,
+                                           const double2* __restrict__ alpha2, const double2* __restrict__ alpha_k2,
+                                           int64_t tile, int lane, char* buf) {
+    const int64_t p0 = tile * kTilePoints;
+    const char* gq = reinterpret_cast<const char*>(q + p0) + lane * 16;
+    const char* gu = reinterpret_cast<const char*>(u + p0) + lane * 16;
+    const char* ga = reinterpret_cast<const char*>(alpha2) + p0 * 8 + lane * 16;
+    const char* gk = reinterpret_cast<const char*>(alpha_k2) + p0 * 8 + lane * 16;
+    dma16(gq, buf);
+    dma16(gq + 1024, buf + 1024);
+    dma16(gu, buf + 2048);
+    dma16(gu + 1024, buf + 3072);
+    dma16(ga, buf + 4096);
+    dma16(gk, buf + 5120);
+}
+
+__global__ __launch_bounds__(kDepthBlock) void depth_lm_dma_kernel(const double2* __restrict__ q,
+                                                                   const double2* __restrict__ u,
+                                                                   const double2* __restrict__ alpha2,
+                                                                   const double2* __restrict__ alpha_k2, int64_t n,
+                                                                   Pose pose, double2* __restrict__ rho2,
+                                                                   const LmState* __restrict__ state,
+                                                                   double* __restrict__ partials, int launch_id) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];  // ONE LDS object (cdna guide: a second one costs vmcnt(0)s)
+    double(*s_red)[NS] = reinterpret_cast<double(*)[NS]>(lds);
+    double* s_inv_hist = reinterpret_cast<double*>(lds + 640);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: the tile loop runs on scalar branches
+    LmPlanReg plan;
+    plan.hist_lds = s_inv_hist;
+    plan.h0 = plan.h1 = plan.h2 = plan.h3 = 0.0;
+    if (launch_id == 0) {
+        plan.n_hist = 0;
+        plan.K = KMAX;
+        const int pr = state->predict;
+        plan.write_which = (pr >= 0 && pr <= KMAX) ? pr : 1;
+        double r = kInitialRadius;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) {
+            plan.inv_cand[j] = 1.0 / r;
+            r = radius_accept(r, 1.0);
+        }
+    } else {
+        const int status = state->status;
+        if (status == 1 || state->next_launch != launch_id) return;  // finished, or not this launch's turn
+        plan.n_hist = state->n_hist;
+        plan.K = (status == 2) ? 0 : state->K;
+        plan.write_which = (status == 2) ? 0 : state->write_which;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) plan.inv_cand[j] = 1.0 / state->cand[j];
+        plan.h0 = 1.0 / state->hist[0];
+        plan.h1 = 1.0 / state->hist[1];
+        plan.h2 = 1.0 / state->hist[2];
+        plan.h3 = 1.0 / state->hist[3];
+        if (tid < kMaxIter) s_inv_hist[tid] = 1.0 / state->hist[tid];
+        __syncthreads();
+    }
+    const double two_over = 2.0 / (2.0 + pose.k);
+    double acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = 0.0;
+
+    char* wbuf = lds + kDmaLdsHeader + wv * (2 * kTileBytes);
+    const unsigned lds_a16 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wbuf + lane * 16;
+    const unsigned lds_a8 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wbuf + lane * 8;
+    const int64_t ntiles = n / kTilePoints;
+    const int64_t nwaves = (int64_t)gridDim.x * (kDepthBlock / 64);
+    int64_t tile = (int64_t)blockIdx.x * (kDepthBlock / 64) + wv;
+    double* rho = reinterpret_cast<double*>(rho2);
+    int cur = 0;
+    if (tile < ntiles) issue_tile(q, u, alpha2, alpha_k2, tile, lane, wbuf);
+    while (tile < ntiles) {
+        const int64_t next = tile + nwaves;
+        if (next < ntiles) {
+            issue_tile(q, u, alpha2, alpha_k2, next, lane, wbuf + (cur ^ 1) * kTileBytes);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile `tile` has landed; the 6 loads of `next` stay in flight
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        double2 qa, qb, ua, ub;
+        double ala, alb, aka, akb;
+        const unsigned a16 = lds_a16 + cur * kTileBytes, a8 = lds_a8 + cur * kTileBytes;
+        asm volatile(
+            "ds_read_b128 %0, %8\n\t"
+            "ds_read_b128 %1, %8 offset:1024\n\t"
+            "ds_read_b128 %2, %8 offset:2048\n\t"
+            "ds_read_b128 %3, %8 offset:3072\n\t"
+            "ds_read_b64 %4, %9 offset:4096\n\t"
+            "ds_read_b64 %5, %9 offset:4608\n\t"
+            "ds_read_b64 %6, %9 offset:5120\n\t"
+            "ds_read_b64 %7, %9 offset:5632\n\t"
+            "s_waitcnt lgkmcnt(0)"
+            : "=&v"(qa), "=&v"(qb), "=&v"(ua), "=&v"(ub), "=&v"(ala), "=&v"(alb), "=&v"(aka), "=&v"(akb)
+            : "v"(a16), "v"(a8)
+            : "memory");
+        const int64_t p0 = tile * kTilePoints;
+        const double r0 = lm_pixel(qa.x, qa.y, ua.x, ua.y, ala, aka, pose, two_over, plan, acc);
+        const double r1 = lm_pixel(qb.x, qb.y, ub.x, ub.y, alb, akb, pose, two_over, plan, acc);
+        rho[p0 + lane] = r0;
+        rho[p0 + 64 + lane] = r1;
+        tile = next;
+        cur ^= 1;
+    }
+    // remainder (< 128 points): first wave of workgroup 0, ordinary loads
+    if (blockIdx.x == 0 && wv == 0) {
+        const double* alpha = reinterpret_cast<const double*>(alpha2);
+        const double* alpha_k = reinterpret_cast<const double*>(alpha_k2);
+        for (int64_t i = ntiles * kTilePoints + lane; i < n; i += 64) {
+            const double2 qq = q[i], uu = u[i];
+            rho[i] = lm_pixel(qq.x, qq.y, uu.x, uu.y, alpha[i], alpha_k[i], pose, two_over, plan, acc);
+        }
+    }
+    if (plan.K == 0) return;  // apply-only launch: no sums
+
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        double r = is_max_slot(s) ? wave_max(acc[s]) : wave_sum(acc[s]);
+        if (lane == 0) s_red[wv][s] = r;
+    }
+    __syncthreads();
+    if (tid < NS) {
+        double r = s_red[0][tid];
+        for (int w2 = 1; w2 < kDepthBlock / 64; ++w2) r = is_max_slot(tid) ? fmax(r, s_red[w2][tid]) : r + s_red[w2][tid];
+        partials[(int64_t)blockIdx.x * NS + tid] = r;
+    }
+}
+
 // One workgroup: reduces the per-workgroup partials of launch `launch_id` in block order and advances the
 // trust-region state machine.  Acts only if that launch actually speculated (status 0 and its turn).
 __global__ __launch_bounds__(kDecideBlock) void depth_lm_decide_kernel(const double* __restrict__ partials, int nblocks,
                                                                        LmState* state, int64_t n, int launch_id) {
     __shared__ double s_red[kDecideBlock / 64][NS];
     __shared__ double s_sums[NS];
-    __shared__ LmState s_state;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (launch_id > 0 && (state->status != 0 || state->next_launch != launch_id)) return;
     double fin[NS];
@@ -153,12 +304,6 @@ __global__ __launch_bounds__(kDecideBlock) void depth_lm_decide_kernel(const dou
         double r = is_max_slot(s) ? wave_max(fin[s]) : wave_sum(fin[s]);
         if (lane == 0) s_red[wv][s] = r;
     }
-    {   // LDS copy of the state: the state machine indexes it dynamically (keep it out of registers / scratch)
-        const int nwords = (int)(sizeof(LmState) / sizeof(int32_t));
-        const int32_t* src = reinterpret_cast<const int32_t*>(state);
-        int32_t* dst = reinterpret_cast<int32_t*>(&s_state);
-        for (int i = tid; i < nwords; i += kDecideBlock) dst[i] = src[i];
-    }
     __syncthreads();
     if (tid < NS) {
         double r = s_red[0][tid];
@@ -166,18 +311,13 @@ __global__ __launch_bounds__(kDecideBlock) void depth_lm_decide_kernel(const dou
         s_sums[tid] = r;
     }
     __syncthreads();
-    if (tid == 0) {
-        const int used_K = (launch_id == 0) ? KMAX : s_state.K;
-        const int pr = s_state.predict;
-        const int used_write = (launch_id == 0) ? ((pr >= 0 && pr <= KMAX) ? pr : 1) : s_state.write_which;
-        lm_advance(s_state, s_sums, n, launch_id == 0, used_K, used_write, launch_id);
-    }
-    __syncthreads();
-    {
-        const int nwords = (int)(sizeof(LmState) / sizeof(int32_t));
-        int32_t* dst = reinterpret_cast<int32_t*>(state);
-        const int32_t* src = reinterpret_cast<const int32_t*>(&s_state);
-        for (int i = tid; i < nwords; i += kDecideBlock) dst[i] = src[i];
+    if (tid == 0) {  // the state machine runs on a register copy of the scalar state (no LDS / scratch round trips)
+        LmScal st = *static_cast<const LmScal*>(state);
+        const int pr = st.predict;
+        const int used_K = (launch_id == 0) ? KMAX : st.K;
+        const int used_write = (launch_id == 0) ? ((pr >= 0 && pr <= KMAX) ? pr : 1) : st.write_which;
+        lm_advance(st, state->hist, s_sums, n, launch_id == 0, used_K, used_write, launch_id);
+        *static_cast<LmScal*>(state) = st;
     }
 }
 
@@ -212,15 +352,41 @@ int depth_closed_form_launch(Ctx* c, const double* q, const double* u, const dou
     return RSDSFM_OK;
 }
 
+// grid of the LDS-DMA variant: 3 workgroups per CU (3 x 50 KB of LDS)
+static inline int depth_dma_grid(const Ctx* c, int64_t n) {
+    const int64_t ntiles = n / kTilePoints;
+    int64_t blocks = (ntiles + 3) / 4;
+    const int64_t cap = (int64_t)c->num_cus * 3;
+    if (blocks < 1) blocks = 1;
+    if (blocks > cap) blocks = cap;
+    if (blocks > kDepthMaxBlocks) blocks = kDepthMaxBlocks;
+    return (int)blocks;
+}
+
+int depth_lm_grid(const Ctx* c, int64_t n) { return c->depth_variant == 1 ? depth_dma_grid(c, n) : depth_grid(n, kDepthMaxBlocks); }
+
 int depth_lm_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                     const Pose& pose, double* rho, int launch_id) {
     if (!aligned16(q) || !aligned16(u) || !aligned16(a) || !aligned16(ak) || !aligned16(rho))
         return fail(c, RSDSFM_ERR_INVALID, "device pointers must be 16-byte aligned");
-    const int grid = depth_grid(n, kDepthMaxBlocks);
-    hipLaunchKernelGGL(depth_lm_kernel, dim3(grid), dim3(kDepthBlock), 0, c->stream,
-                       reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u),
-                       reinterpret_cast<const double2*>(a), reinterpret_cast<const double2*>(ak), n, pose,
-                       reinterpret_cast<double2*>(rho), c->d_lm, c->d_partials, launch_id);
+    const int grid = depth_lm_grid(c, n);
+    if (c->depth_variant == 1) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            RSDSFM_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(depth_lm_dma_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLdsBytes));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(depth_lm_dma_kernel, dim3(grid), dim3(kDepthBlock), kDmaLdsBytes, c->stream,
+                           reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u),
+                           reinterpret_cast<const double2*>(a), reinterpret_cast<const double2*>(ak), n, pose,
+                           reinterpret_cast<double2*>(rho), c->d_lm, c->d_partials, launch_id);
+    } else {
+        hipLaunchKernelGGL(depth_lm_kernel, dim3(grid), dim3(kDepthBlock), 0, c->stream,
+                           reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u),
+                           reinterpret_cast<const double2*>(a), reinterpret_cast<const double2*>(ak), n, pose,
+                           reinterpret_cast<double2*>(rho), c->d_lm, c->d_partials, launch_id);
+    }
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
@@ -255,7 +421,7 @@ __global__ __launch_bounds__(kDecideBlock) void depth_lm_reduce_kernel(const dou
 }
 
 int depth_lm_reduce_launch(Ctx* c, int64_t n, double* d_row) {
-    const int grid = depth_grid(n, kDepthMaxBlocks);
+    const int grid = depth_lm_grid(c, n);
     hipLaunchKernelGGL(depth_lm_reduce_kernel, dim3(1), dim3(kDecideBlock), 0, c->stream, c->d_partials, grid, d_row);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
@@ -269,7 +435,7 @@ int depth_lm_decide_rows_launch(Ctx* c, const double* d_rows, int nrows, int64_t
 }
 
 int depth_lm_decide_launch(Ctx* c, int64_t n, int launch_id) {
-    const int grid = depth_grid(n, kDepthMaxBlocks);
+    const int grid = depth_lm_grid(c, n);
     hipLaunchKernelGGL(depth_lm_decide_kernel, dim3(1), dim3(kDecideBlock), 0, c->stream, c->d_partials, grid, c->d_lm, n,
                        launch_id);
     RSDSFM_HIP_CHECK(c, hipGetLastError());

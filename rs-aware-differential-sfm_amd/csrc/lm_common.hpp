@@ -27,8 +27,9 @@ __device__ __forceinline__ double closed_form_rho(double x, double y, double ux,
 // j (0-based): base = 3 + 5 j : [sum |r(cand)|^2, model_cost_change, sum step^2, sum cand^2, max |J.r(cand)|]
 // `first`: this is the launch of iteration zero (current state = rho == 1, nothing accepted yet).
 // `used_K`, `used_write` : the plan the launch that produced `sums` ran with.
-__device__ inline void lm_advance(LmState& st, const double* sums, int64_t n, int first, int used_K, int used_write,
-                           int launch_id) {
+// `st` is a register copy of the scalar state; accepted radii are appended to `hist` (device memory).
+__device__ __forceinline__ void lm_advance(LmScal& st, double* hist, const double* sums, int64_t n, int first, int used_K,
+                                           int used_write, int launch_id) {
     if (first) {
         st.status = 0;
         st.n_hist = 0;
@@ -43,6 +44,7 @@ __device__ inline void lm_advance(LmState& st, const double* sums, int64_t n, in
         st.decrease_factor = 2.0;
         st.initial_cost = 0.5 * sums[0];
         double r = kInitialRadius;
+#pragma unroll
         for (int j = 0; j < KMAX; ++j) {  // the plan the first launch ran with (mirrors depth_lm_kernel)
             st.cand[j] = r;
             r = radius_accept(r, 1.0);
@@ -54,7 +56,9 @@ __device__ inline void lm_advance(LmState& st, const double* sums, int64_t n, in
     double x_norm = sqrt(sums[1]);
     int accepted_in_batch = 0;  // candidates 0..accepted_in_batch-1 were accepted in sequence
     if (first && (n == 0 || sums[2] <= kGradientTol)) st.termination = RSDSFM_TERM_GRADIENT;
-    for (int j = 0; j < used_K && st.termination < 0; ++j) {
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) {
+        if (!(j < used_K && st.termination < 0)) break;
         if (st.iteration >= kMaxIter) {
             st.termination = RSDSFM_TERM_MAX_ITER;
             break;
@@ -91,7 +95,7 @@ __device__ inline void lm_advance(LmState& st, const double* sums, int64_t n, in
         }
         const double rel = cost_change / model_change;
         if (rel > kMinRelDecrease) {  // HandleSuccessfulStep
-            st.hist[st.n_hist] = st.radius;
+            hist[st.n_hist] = st.radius;
             st.n_hist += 1;
             accepted_in_batch = j + 1;
             cost = ccost;
@@ -131,6 +135,7 @@ __device__ inline void lm_advance(LmState& st, const double* sums, int64_t n, in
         st.K = KMAX;
         st.write_which = 0;
         double r = st.radius;
+#pragma unroll
         for (int j = 0; j < KMAX; ++j) {
             st.cand[j] = r;
             r = radius_accept(r, 1.0);
@@ -145,12 +150,26 @@ struct LmPlanLds {
     int n_hist, K, write_which;
     double inv_hist[kMaxIter];  // 1 / radius of each accepted step
     double inv_cand[KMAX];      // 1 / radius of each speculated step
+    __device__ __forceinline__ double inv_hist_at(int h) const { return inv_hist[h]; }
+};
+
+// register-resident copy of the plan (for kernels whose main loop must not touch LDS through compiler-emitted
+// ds_reads, see depth_lm_dma_kernel); accepted steps beyond the 4th (rare) are read from `hist_lds`
+struct LmPlanReg {
+    int n_hist, K, write_which;
+    double inv_cand[KMAX];
+    double h0, h1, h2, h3;
+    const double* hist_lds;
+    __device__ __forceinline__ double inv_hist_at(int h) const {
+        return h == 0 ? h0 : (h == 1 ? h1 : (h == 2 ? h2 : (h == 3 ? h3 : hist_lds[h])));
+    }
 };
 
 // one pixel through the planned LM trajectory; returns the state selected by write_which.
 // Arithmetic mirrors oracle/rsdsfm_oracle.c rso_estimate_inverse_depths (mode 1) operation for operation.
+template <class Plan>
 __device__ __forceinline__ double lm_pixel(double x, double y, double ux, double uy, double al, double ak,
-                                           const Pose& pose, double two_over, const LmPlanLds& plan,
+                                           const Pose& pose, double two_over, const Plan& plan,
                                            double (&acc)[NS]) {
     PixelModel m;
     m.init(x, y, ux, uy, al, ak, pose, two_over);
@@ -162,7 +181,7 @@ __device__ __forceinline__ double lm_pixel(double x, double y, double ux, double
     double r0, r1;
     m.residual(rho, r0, r1);
     for (int h = 0; h < plan.n_hist; ++h) {  // replay the accepted steps
-        const double lam = diag * plan.inv_hist[h];
+        const double lam = diag * plan.inv_hist_at(h);
         const double gt = jt0 * r0 + jt1 * r1;
         const double step = -(gt / (ht + lam));
         rho = rho + step * s;

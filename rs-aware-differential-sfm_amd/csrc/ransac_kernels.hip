@@ -27,6 +27,9 @@ namespace {
 
 constexpr int kRB = 256;  // workgroup size of the pixel kernels
 constexpr int kRP = 4;    // pixels per thread per tile (register-resident across the hypothesis loop)
+// LM iterations speculated in round 0: noisy data (the common case inside RANSAC) is decided at iteration 2
+// (function tolerance); hypotheses that need more simply take another round
+constexpr int kRansacK0 = KMAX;
 
 struct Tile {
     double x[kRP], y[kRP], ux[kRP], uy[kRP], al[kRP], ak[kRP];
@@ -40,33 +43,26 @@ __device__ __forceinline__ void load_tile(Tile& t, const double2* __restrict__ q
     for (int j = 0; j < kRP; ++j) {
         const int64_t i = base + threadIdx.x + (int64_t)j * kRB;
         t.ok[j] = i < n;
-        if (t.ok[j]) {
-            double2 qq = q[i], uu = u[i];
-            t.x[j] = qq.x;
-            t.y[j] = qq.y;
-            t.ux[j] = uu.x;
-            t.uy[j] = uu.y;
-            t.al[j] = alpha[i];
-            t.ak[j] = alpha_k[i];
-        } else {
-            t.x[j] = t.y[j] = t.ux[j] = t.uy[j] = 0.0;
-            t.al[j] = t.ak[j] = 1.0;
-        }
+        const int64_t ii = t.ok[j] ? i : n - 1;  // out-of-range lanes load a valid point and are masked by ok[]
+        const double2 qq = q[ii], uu = u[ii];
+        t.x[j] = qq.x;
+        t.y[j] = qq.y;
+        t.ux[j] = uu.x;
+        t.uy[j] = uu.y;
+        t.al[j] = alpha[ii];
+        t.ak[j] = alpha_k[ii];
     }
 }
 
-__device__ __forceinline__ Pose load_pose(const double* __restrict__ hyp, int t) {
-    Pose p;
-    const double* h = hyp + (int64_t)t * 8;
-    p.w[0] = h[0];
-    p.w[1] = h[1];
-    p.w[2] = h[2];
-    p.v[0] = h[3];
-    p.v[1] = h[4];
-    p.v[2] = h[5];
-    p.k = h[6];
-    return p;
-}
+// hypothesis pose from the (wave-uniform) hypothesis table; written field by field so that it stays in registers
+#define RSDSFM_LOAD_POSE(pose, hyp, t)                       \
+    Pose pose;                                               \
+    {                                                        \
+        const double* h_ = (hyp) + (int64_t)(t) * 8;          \
+        pose.w[0] = h_[0], pose.w[1] = h_[1], pose.w[2] = h_[2]; \
+        pose.v[0] = h_[3], pose.v[1] = h_[4], pose.v[2] = h_[5]; \
+        pose.k = h_[6];                                      \
+    }
 
 }  // namespace
 
@@ -89,7 +85,7 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
     for (int i = tid; i < T * NS; i += kRB) s_acc[i] = 0.0;
     if (round == 0 && tid == 0) {
         plan.n_hist = 0;
-        plan.K = KMAX;
+        plan.K = kRansacK0;
         plan.write_which = 0;
         double r = kInitialRadius;
         for (int j = 0; j < KMAX; ++j) {
@@ -123,7 +119,7 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
                 if (tid < KMAX) plan.inv_cand[tid] = 1.0 / states[t].cand[tid];
                 __syncthreads();
             }
-            const Pose pose = load_pose(hyp, t);
+            RSDSFM_LOAD_POSE(pose, hyp, t)
             const double two_over = 2.0 / (2.0 + pose.k);
             double acc[NS];
 #pragma unroll
@@ -157,7 +153,6 @@ __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __rest
                                                            LmState* states, int64_t n, int round, int* running) {
     __shared__ double s_red[4][NS];
     __shared__ double s_sums[NS];
-    __shared__ LmState s_state;
     const int t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     LmState* state = states + t;
@@ -175,12 +170,6 @@ __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __rest
         double r = is_max_slot(s) ? wave_max(fin[s]) : wave_sum(fin[s]);
         if (lane == 0) s_red[wv][s] = r;
     }
-    {
-        const int nwords = (int)(sizeof(LmState) / sizeof(int32_t));
-        const int32_t* src = reinterpret_cast<const int32_t*>(state);
-        int32_t* dst = reinterpret_cast<int32_t*>(&s_state);
-        for (int i = tid; i < nwords; i += 256) dst[i] = src[i];
-    }
     __syncthreads();
     if (tid < NS) {
         double r = s_red[0][tid];
@@ -189,16 +178,11 @@ __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __rest
     }
     __syncthreads();
     if (tid == 0) {
-        const int used_K = (round == 0) ? KMAX : s_state.K;
-        lm_advance(s_state, s_sums, n, round == 0, used_K, 0, round);
-        if (s_state.status == 0) atomicAdd(running, 1);
-    }
-    __syncthreads();
-    {
-        const int nwords = (int)(sizeof(LmState) / sizeof(int32_t));
-        int32_t* dst = reinterpret_cast<int32_t*>(state);
-        const int32_t* src = reinterpret_cast<const int32_t*>(&s_state);
-        for (int i = tid; i < nwords; i += 256) dst[i] = src[i];
+        LmScal st = *static_cast<const LmScal*>(state);
+        const int used_K = (round == 0) ? kRansacK0 : st.K;
+        lm_advance(st, state->hist, s_sums, n, round == 0, used_K, 0, round);
+        if (st.status == 0) atomicAdd(running, 1);
+        *static_cast<LmScal*>(state) = st;
     }
 }
 
@@ -242,7 +226,7 @@ __global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __rest
                 if (tid < kMaxIter) plan.inv_hist[tid] = 1.0 / states[t].hist[tid];
                 __syncthreads();
             }
-            const Pose pose = load_pose(hyp, t);
+            RSDSFM_LOAD_POSE(pose, hyp, t)
             const double two_over = 2.0 / (2.0 + pose.k);
             double cnt = 0.0, es = 0.0;
 #pragma unroll

@@ -39,7 +39,8 @@ struct Pose {
 };
 
 // Device-resident state machine of one emulated Ceres trust-region solve (dense depth problem).
-struct LmState {
+// LmScal: the scalar part (lives in registers while lm_advance runs); LmState adds the accepted-radius history.
+struct LmScal {
     int32_t status;  // 0 = running (next launch speculates K more iterations), 1 = done, rho holds the result,
                      // 2 = done, next launch must write the result (apply)
     int32_t n_hist;  // accepted steps so far (their radii are hist[0..n_hist))
@@ -60,8 +61,10 @@ struct LmState {
     double decrease_factor;
     double cost;  // cost of the current state
     double initial_cost;
-    double hist[kMaxIter];
     double cand[KMAX];
+};
+struct LmState : LmScal {
+    double hist[kMaxIter];
 };
 
 // device-resident result header of a RANSAC run
@@ -97,6 +100,7 @@ struct Ctx {
     void* h_pinned = nullptr;  // small pinned host buffer for result headers
     size_t pinned_bytes = 0;
     int num_cus = 256;
+    int depth_variant = 0;  // 0 = register-staged depth_lm_kernel, 1 = LDS-DMA depth_lm_dma_kernel
 };
 
 constexpr int kDepthBlock = 256;

@@ -11,9 +11,11 @@ from conftest import GOLDEN_CASES
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def solver(rsdsfm):
+@pytest.fixture(scope="module", params=[0, 1], ids=["regstage", "ldsdma"])
+def solver(rsdsfm, request):
+    """every test of this module runs on both data-movement variants of the fused LM kernel"""
     s = rsdsfm.Solver(0)
+    s.set_depth_variant(request.param)
     yield s
     s.close()
 

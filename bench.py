@@ -261,12 +261,15 @@ def _traffic(workload):
 def _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps, warmup, timed):
     """whole solve on a 1280x720 DeepFlow-like pair (0.3 px noise, 10 % outliers), flow image resident in HBM"""
     d = rsdsfm.synth.make_config(5, seed=0x5EED0005 + rank)
-    pipe = rsdsfm.pipeline.FramePipeline(solver, torch, dev, d["rows"], d["cols"], d["K"], d["gamma"])
+    rows, cols = d["rows"], d["cols"]
     imgs = [torch.from_numpy(d["flow_img"]).to(dev) for _ in range(3)]
+    depth_map = torch.empty((cols, rows), dtype=torch.float64, device=dev)  # column-major rows x cols
+    R, tt = torch.empty((rows, 9), dtype=torch.float64, device=dev), torch.empty((rows, 3), dtype=torch.float64, device=dev)
     out = {}
 
-    def step(i):
-        out["r"] = pipe.solve(imgs[i % 3], trials=args.trials, tol=args.tol, seed=1 + i)
+    def step(i):  # ONE C-ABI call per frame pair (rsdsfm_solve_frame_dev)
+        out["r"] = solver.solve_frame_dev(imgs[i % 3].data_ptr(), rows, cols, d["K"], d["gamma"], depth_map.data_ptr(), R.data_ptr(),
+                                          tt.data_ptr(), trials=args.trials, tol=args.tol, seed=1 + i)
 
     el = timed(step, steps, warmup)
     r = out["r"]
@@ -275,7 +278,7 @@ def _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps, warmup, timed
     vv = r["v"] / np.linalg.norm(r["v"])
     return {"value": d["rows"] * d["cols"] * steps / el / 1e6, "unit": "Mpixels/s", "ms_per_solve": el / steps * 1e3,
             "rows": d["rows"], "cols": d["cols"], "trials": args.trials, "tol": args.tol, "n": r["n"], "num_inliers": r["num_inliers"],
-            "refine_summary": r["refine"]["summary"] if r["refine"] else None,
+            "refine_summary": r["refine_summary"],
             "w_err": float(np.linalg.norm(r["w"] - t["w"])), "v_angle_deg": float(np.degrees(np.arccos(min(1.0, abs(float(vv @ vt)))))),
             "stages": "flatten+alpha, minimal9 x %d, RANSAC LM sums/decide/score/pick/compaction, refinement, depth map, pose table" % args.trials}
 

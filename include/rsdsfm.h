@@ -166,6 +166,37 @@ int rsdsfm_depth_map_dev(rsdsfm_ctx* ctx, double* d_inliers_3m_inout, int64_t m,
                          int32_t* d_xs_or_null, int32_t* d_ys_or_null, int* flipped);
 int rsdsfm_pose_table_dev(rsdsfm_ctx* ctx, const double v[3], const double w[3], double k, double gamma, int32_t rows,
                           double* d_R_rows9, double* d_t_rows3);
+/* ---- one frame pair end to end (the solver part of evaluateSingleRun, main.cc:398-522) --------------------------- */
+typedef struct rsdsfm_frame_params {
+    int32_t ransac_trials;        /* main.cc:304 (5); the report used 50                                */
+    int32_t use_acceleration_mode; /* main.cc:306                                                       */
+    int32_t use_refinement;       /* main.cc:307                                                        */
+    int32_t depth_mode;           /* RSDSFM_DEPTH_*                                                     */
+    int32_t k_sign_mode;          /* RSDSFM_K_*                                                         */
+    int32_t _pad;
+    double ransac_tol;            /* main.cc:310 (0.05)                                                 */
+    double flow_threshold;        /* main.cc:311 (1e-10)                                                */
+    uint64_t seed;                /* sampler seed (reference: srand(time))                              */
+} rsdsfm_frame_params;
+
+typedef struct rsdsfm_frame_result {
+    int64_t n_points, num_inliers;
+    int32_t best_trial, flipped;
+    double ransac_w[3], ransac_v[3], ransac_k;
+    double w[3], v[3], k;            /* after refinement and sign canonicalisation                       */
+    rsdsfm_lm_summary refine_summary;
+    const double* d_inliers;         /* DEVICE, 3 x num_inliers (x, y, z), valid until the next call on the context */
+    const int64_t* d_inlier_idx;     /* DEVICE                                                            */
+    const int32_t* d_scanline;       /* DEVICE, scanline (image row) index of each inlier                 */
+} rsdsfm_frame_result;
+
+/* flow image (rows x cols x 2, row-major) resident in HBM -> pose, depth map (rows x cols column-major, DEVICE) and
+ * per-scanline pose table (DEVICE, may be NULL).  Runs flatten, ransac, nonLinearRefinement (gathered flow), the sign
+ * flip / depth scatter and setRelativePose back to back on the context's stream. */
+int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t rows, int32_t cols, double fx, double fy,
+                           double cx, double cy, double gamma, const rsdsfm_frame_params* params,
+                           double* d_depth_map_colmajor, double* d_R_rows9_or_null, double* d_t_rows3_or_null,
+                           rsdsfm_frame_result* result);
 /* minimal::ransac on device-resident inputs.  The arrays of `out` (inlier_idx, inliers, alpha, alpha_k, mask,
  * inv_depth) are DEVICE pointers with capacity n (each may be NULL); its trial_* arrays are HOST pointers.
  * samples_9xT_or_null is a HOST pointer.  Synchronises once at the end to return the scalars of `out`. */

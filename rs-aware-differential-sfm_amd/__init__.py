@@ -50,6 +50,19 @@ class LmSummary(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class FrameParams(C.Structure):
+    _fields_ = [("ransac_trials", C.c_int32), ("use_acceleration_mode", C.c_int32), ("use_refinement", C.c_int32),
+                ("depth_mode", C.c_int32), ("k_sign_mode", C.c_int32), ("_pad", C.c_int32), ("ransac_tol", C.c_double),
+                ("flow_threshold", C.c_double), ("seed", C.c_uint64)]
+
+
+class FrameResult(C.Structure):
+    _fields_ = [("n_points", C.c_int64), ("num_inliers", C.c_int64), ("best_trial", C.c_int32), ("flipped", C.c_int32),
+                ("ransac_w", C.c_double * 3), ("ransac_v", C.c_double * 3), ("ransac_k", C.c_double),
+                ("w", C.c_double * 3), ("v", C.c_double * 3), ("k", C.c_double), ("refine_summary", LmSummary),
+                ("d_inliers", C.c_void_p), ("d_inlier_idx", C.c_void_p), ("d_scanline", C.c_void_p)]
+
+
 class RansacOut(C.Structure):
     _fields_ = [
         ("num_inliers", C.c_int64),
@@ -316,6 +329,21 @@ class Solver:
 
     def pose_table_dev(self, v, w, k, gamma, rows, d_R, d_t):
         self._check(self.lib.rsdsfm_pose_table_dev(self._ctx, _v3(v), _v3(w), C.c_double(k), C.c_double(gamma), C.c_int32(rows), _dp(d_R), _dp(d_t)), "rsdsfm_pose_table_dev")
+
+    def solve_frame_dev(self, d_flow_img, rows, cols, K, gamma, d_depth_map, d_R=None, d_t=None, trials=50, tol=0.05, seed=1,
+                        use_acceleration_mode=False, use_refinement=True, depth_mode=DEPTH_CERES_LM, k_sign_mode=K_COMPAT, flow_threshold=1e-10):
+        """the whole solve of one frame pair in ONE C-ABI call (rsdsfm_solve_frame_dev)"""
+        prm = FrameParams(int(trials), int(use_acceleration_mode), int(use_refinement), int(depth_mode), int(k_sign_mode), 0,
+                          float(tol), float(flow_threshold), int(seed))
+        res = FrameResult()
+        d = C.c_double
+        self._check(self.lib.rsdsfm_solve_frame_dev(self._ctx, _dp(d_flow_img), C.c_int32(rows), C.c_int32(cols), d(K[0]), d(K[1]), d(K[2]), d(K[3]),
+                                                    d(gamma), C.byref(prm), _dp(d_depth_map), _dp(d_R) if d_R else None, _dp(d_t) if d_t else None,
+                                                    C.byref(res)), "rsdsfm_solve_frame_dev")
+        return dict(n=int(res.n_points), num_inliers=int(res.num_inliers), best_trial=int(res.best_trial), flipped=bool(res.flipped),
+                    ransac_w=np.array(res.ransac_w[:]), ransac_v=np.array(res.ransac_v[:]), ransac_k=float(res.ransac_k),
+                    w=np.array(res.w[:]), v=np.array(res.v[:]), k=float(res.k), refine_summary=res.refine_summary.as_dict(),
+                    d_inliers=res.d_inliers, d_inlier_idx=res.d_inlier_idx, d_scanline=res.d_scanline)
 
     def depth_lm_reduce_dev(self, n_shard, d_row):
         self._check(self.lib.rsdsfm_depth_lm_reduce_dev(self._ctx, C.c_int64(n_shard), _dp(d_row)), "rsdsfm_depth_lm_reduce_dev")

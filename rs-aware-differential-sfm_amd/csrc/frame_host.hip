@@ -1,0 +1,97 @@
+// frame_host.hip -- rsdsfm_solve_frame_dev: the solver part of the reference's evaluateSingleRun() (main.cc:398-522) as
+// ONE call on device-resident buffers: flatten + alpha -> RANSAC -> nonlinear refinement -> sign flip + depth map ->
+// per-scanline pose table.  Pure orchestration of the stage entry points (no extra kernels).
+#include <string.h>
+
+#include "rsdsfm_internal.hpp"
+
+namespace rsdsfm {
+int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n, int use_alpha_k, int T,
+                  double tol, const int32_t* h_samples, uint64_t seed, int depth_mode, int k_sign_mode, rsdsfm_ransac_out* out);
+int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
+                  const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
+                  int const_acceleration, int flow_index_mode, double* d_inl_out, double v_out[3], double w_out[3], double* k_out,
+                  rsdsfm_lm_summary* summary);
+}  // namespace rsdsfm
+
+using namespace rsdsfm;
+
+extern "C" {
+
+int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t rows, int32_t cols, double fx, double fy, double cx,
+                           double cy, double gamma, const rsdsfm_frame_params* prm, double* d_depth_map, double* d_R_rows9,
+                           double* d_t_rows3, rsdsfm_frame_result* res) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    if (!prm || !res || rows <= 0 || cols <= 0 || !d_flow_img || !d_depth_map) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    const size_t N = (size_t)rows * (size_t)cols;
+    // frame buffers live in the context's frame arena (separate from the per-stage workspace)
+    const size_t need = 2 * Arena::need(16 * N) + 4 * Arena::need(8 * N) + 2 * Arena::need(24 * N) + Arena::need(8 * N) + Arena::need(N) +
+                        Arena::need(4 * N) + 4096;
+    if (need > c->frame_bytes) {
+        RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        if (c->d_frame) RSDSFM_HIP_CHECK(c, hipFree(c->d_frame));
+        c->d_frame = nullptr;
+        c->frame_bytes = 0;
+        RSDSFM_HIP_CHECK(c, hipMalloc(&c->d_frame, need));
+        c->frame_bytes = need;
+    }
+    Arena fa(c->d_frame);
+    double* d_q = fa.take<double>(2 * N);
+    double* d_u = fa.take<double>(2 * N);
+    double* d_a = fa.take<double>(N);
+    double* d_ak = fa.take<double>(N);
+    double* d_in_a = fa.take<double>(N);
+    double* d_in_ak = fa.take<double>(N);
+    double* d_inl = fa.take<double>(3 * N);
+    double* d_inl_ref = fa.take<double>(3 * N);
+    int64_t* d_idx = fa.take<int64_t>(N);
+    uint8_t* d_mask = fa.take<uint8_t>(N);
+    int32_t* d_ys = fa.take<int32_t>(N);
+
+    memset(res, 0, sizeof(*res));
+    int64_t n = 0;
+    int rc = rsdsfm_flatten_dev(ctx, d_flow_img, rows, cols, fx, fy, cx, cy, gamma, prm->flow_threshold, d_q, d_u, d_a, d_ak, &n);
+    if (rc != RSDSFM_OK) return rc;
+    res->n_points = n;
+    rsdsfm_ransac_out ro;
+    memset(&ro, 0, sizeof(ro));
+    ro.inlier_idx = d_idx;
+    ro.inliers = d_inl;
+    ro.alpha = d_in_a;
+    ro.alpha_k = d_in_ak;
+    ro.mask = d_mask;
+    rc = ransac_device(c, d_q, d_u, d_a, d_ak, n, prm->use_acceleration_mode, prm->ransac_trials, prm->ransac_tol, nullptr, prm->seed,
+                       prm->depth_mode, prm->k_sign_mode, &ro);
+    if (rc != RSDSFM_OK) return rc;
+    res->num_inliers = ro.num_inliers;
+    res->best_trial = ro.best_trial;
+    memcpy(res->ransac_w, ro.w, sizeof(ro.w));
+    memcpy(res->ransac_v, ro.v, sizeof(ro.v));
+    res->ransac_k = ro.k;
+    double v[3] = {ro.v[0], ro.v[1], ro.v[2]}, w[3] = {ro.w[0], ro.w[1], ro.w[2]}, k = ro.k;
+    double* d_final = d_inl;
+    if (prm->use_refinement) {
+        rc = refine_device(c, d_u, n, ro.num_inliers, d_inl, d_in_a, d_in_ak, d_idx, v, w, k, prm->use_acceleration_mode,
+                           RSDSFM_FLOW_GATHERED, d_inl_ref, v, w, &k, &res->refine_summary);
+        if (rc != RSDSFM_OK) return rc;
+        d_final = d_inl_ref;
+    }
+    int flipped = 0;
+    rc = rsdsfm_depth_map_dev(ctx, d_final, ro.num_inliers, v, fx, fy, cx, cy, rows, cols, d_depth_map, nullptr, d_ys, &flipped);
+    if (rc != RSDSFM_OK) return rc;
+    res->flipped = flipped;
+    memcpy(res->v, v, sizeof(v));
+    memcpy(res->w, w, sizeof(w));
+    res->k = k;
+    if (d_R_rows9 && d_t_rows3) {
+        rc = rsdsfm_pose_table_dev(ctx, v, w, k, gamma, rows, d_R_rows9, d_t_rows3);
+        if (rc != RSDSFM_OK) return rc;
+    }
+    res->d_inliers = d_final;
+    res->d_inlier_idx = d_idx;
+    res->d_scanline = d_ys;
+    return RSDSFM_OK;
+}
+
+}  // extern "C"

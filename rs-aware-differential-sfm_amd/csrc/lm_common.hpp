@@ -167,10 +167,15 @@ struct LmPlanReg {
 
 // one pixel through the planned LM trajectory; returns the state selected by write_which.
 // Arithmetic mirrors oracle/rsdsfm_oracle.c rso_estimate_inverse_depths (mode 1) operation for operation.
-template <class Plan>
+struct NoHook {
+    __device__ __forceinline__ void operator()(int, double) const {}
+};
+
+// `hook(j, rho_j)` is called with every speculated iterate (j = 0 .. K-1: the state after j+1 accepted steps)
+template <class Plan, class Hook = NoHook>
 __device__ __forceinline__ double lm_pixel(double x, double y, double ux, double uy, double al, double ak,
                                            const Pose& pose, double two_over, const Plan& plan,
-                                           double (&acc)[NS]) {
+                                           double (&acc)[NS], const Hook& hook = Hook()) {
     PixelModel m;
     m.init(x, y, ux, uy, al, ak, pose, two_over);
     const double s = 1.0 / (1.0 + sqrt(m.J0 * m.J0 + m.J1 * m.J1));  // Jacobi scaling (iteration 0 Jacobian)
@@ -209,6 +214,7 @@ __device__ __forceinline__ double lm_pixel(double x, double y, double ux, double
             acc[3 + 5 * j + 3] += cand * cand;
             acc[3 + 5 * j + 4] = fmax(acc[3 + 5 * j + 4], fabs(m.J0 * r0 + m.J1 * r1));
             rho = cand;
+            hook(j, cand);
             if (plan.write_which == j + 1) out = cand;
         }
     }

@@ -67,11 +67,10 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
         }
     }
     const int Tn = std::max(T, 1);
-    const int grid = ransac_pixel_grid(c, n);
     const int batch = std::min(Tn, kRansacBatch);
     size_t need = Arena::need(sizeof(int32_t) * Tn * 9) + Arena::need(sizeof(double) * Tn * 8) +
-                  Arena::need(sizeof(LmState) * Tn) + Arena::need(sizeof(double) * (size_t)grid * batch * NS) +
-                  Arena::need(sizeof(int)) + 2 * Arena::need(sizeof(double) * Tn) + Arena::need(sizeof(RansacBest)) +
+                  Arena::need(sizeof(LmState) * Tn) + Arena::need(sizeof(double) * (size_t)ransac_lm_partials_doubles(c, n, batch)) +
+                  Arena::need(sizeof(int) * 2) + Arena::need(sizeof(int) * Tn) + 2 * Arena::need(sizeof(double) * Tn) + Arena::need(sizeof(RansacBest)) +
                   2 * Arena::need(sizeof(int64_t) * 2048) + Arena::need(sizeof(double) * (size_t)n) + Arena::need((size_t)n) + 4096;
     int rc = ensure_ws(c, need);
     if (rc != RSDSFM_OK) return rc;
@@ -79,8 +78,9 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     int32_t* d_samples = ws.take<int32_t>((size_t)Tn * 9);
     double* d_hyp = ws.take<double>((size_t)Tn * 8);
     LmState* d_states = ws.take<LmState>(Tn);
-    double* d_partials = ws.take<double>((size_t)grid * batch * NS);
-    int* d_running = ws.take<int>(1);
+    double* d_partials = ws.take<double>((size_t)ransac_lm_partials_doubles(c, n, batch));
+    int* d_flags = ws.take<int>(2);  // {running, unscored}
+    int* d_scored = ws.take<int>(Tn);
     double* d_tcount = ws.take<double>(Tn);
     double* d_terr = ws.take<double>(Tn);
     RansacBest* d_best = ws.take<RansacBest>(1);
@@ -89,7 +89,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     double* d_rho = out->inv_depth ? out->inv_depth : ws.take<double>((size_t)n);
     uint8_t* d_mask = out->mask ? out->mask : ws.take<uint8_t>((size_t)n);
 
-    rc = ensure_pinned(c, sizeof(RansacBest) + sizeof(int) + sizeof(double) * 2 * Tn + sizeof(double) * 8 * Tn + sizeof(LmState) * Tn + 64);
+    rc = ensure_pinned(c, sizeof(RansacBest) + 2 * sizeof(int) + sizeof(double) * 2 * Tn + sizeof(double) * 8 * Tn + sizeof(LmState) * Tn + 64);
     if (rc != RSDSFM_OK) return rc;
     char* hp = static_cast<char*>(c->h_pinned);
     RansacBest* h_best = reinterpret_cast<RansacBest*>(hp);
@@ -100,25 +100,33 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     LmState* h_states = reinterpret_cast<LmState*>(h_hyp + (size_t)8 * Tn);
 
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_states, 0, sizeof(LmState) * Tn, c->stream));
+    RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_scored, 0, sizeof(int) * Tn, c->stream));
     if (T > 0) {
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_samples, samples.data(), sizeof(int32_t) * (size_t)T * 9, hipMemcpyHostToDevice, c->stream));
         rc = minimal9_launch(c, d_q, d_u, d_a, d_ak, d_samples, T, use_alpha_k, k_sign_mode, d_hyp);
         if (rc != RSDSFM_OK) return rc;
         for (int b0 = 0; b0 < T; b0 += batch) {
             const int B = std::min(batch, T - b0);
+            bool need_score = true;
             if (depth_mode == RSDSFM_DEPTH_CERES_LM) {
+                RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_flags, 0, sizeof(int) * 2, c->stream));
                 for (int round = 0;; ++round) {
                     if (round > 4 * kMaxIter) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machines did not terminate");
-                    rc = ransac_lm_round_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, d_partials, d_running, round);
+                    rc = ransac_lm_round_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, d_partials, d_flags,
+                                                d_scored + b0, d_tcount + b0, d_terr + b0, round, tol);
                     if (rc != RSDSFM_OK) return rc;
-                    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_running, d_running, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+                    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_running, d_flags, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
                     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-                    if (*h_running == 0) break;
+                    if (h_running[0] == 0) break;
                 }
+                need_score = h_running[1] > 0;  // hypotheses whose final iterate is not the fused one-step state
             }
-            rc = ransac_score_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, depth_mode, tol, d_partials,
-                                     d_tcount + b0, d_terr + b0);
-            if (rc != RSDSFM_OK) return rc;
+            if (need_score) {
+                rc = ransac_score_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, depth_mode, tol,
+                                         depth_mode == RSDSFM_DEPTH_CERES_LM ? d_scored + b0 : nullptr, d_partials, d_tcount + b0,
+                                         d_terr + b0);
+                if (rc != RSDSFM_OK) return rc;
+            }
         }
     }
     rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best);

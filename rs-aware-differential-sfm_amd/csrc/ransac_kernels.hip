@@ -31,6 +31,26 @@ constexpr int kRP = 4;    // pixels per thread per tile (register-resident acros
 // (function tolerance); hypotheses that need more simply take another round
 constexpr int kRansacK0 = KMAX;
 
+// LM sums + fused scores {count, sum err} of the iterates after ONE and after TWO accepted steps -- what noisy
+// data (the common case inside RANSAC) ends with, depending on how far rho = 1 is from the optimum
+constexpr int kFused = 2;
+constexpr int NSR = NS + 2 * kFused;
+
+struct ScoreHook {
+    double x, y, ux, uy, al, ak, two_over, tol;
+    const Pose* pose;
+    double* sc;  // [2 * kFused] = {count, err} per fused state
+    __device__ __forceinline__ void operator()(int j, double rho) const {
+        if (j < kFused) {
+            const double e = point_error(x, y, ux, uy, al, ak, *pose, two_over, rho);
+            if (e < tol) {
+                sc[2 * j] += 1.0;
+                sc[2 * j + 1] += e;
+            }
+        }
+    }
+};
+
 struct Tile {
     double x[kRP], y[kRP], ux[kRP], uy[kRP], al[kRP], ak[kRP];
     bool ok[kRP];
@@ -76,13 +96,13 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
                                                        const double* __restrict__ alpha_k, int64_t n,
                                                        const double* __restrict__ hyp, int T,
                                                        const LmState* __restrict__ states,
-                                                       double* __restrict__ partials, int round) {
-    extern __shared__ double s_acc[];  // [T][NS]
+                                                       double* __restrict__ partials, int round, double tol) {
+    extern __shared__ double s_acc[];  // [T][NSR]
     __shared__ LmPlanLds plan;
-    __shared__ double s_red[2][kRB / 64][NS];
+    __shared__ double s_red[2][kRB / 64][NSR];
     __shared__ int s_active;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int i = tid; i < T * NS; i += kRB) s_acc[i] = 0.0;
+    for (int i = tid; i < T * NSR; i += kRB) s_acc[i] = 0.0;
     if (round == 0 && tid == 0) {
         plan.n_hist = 0;
         plan.K = kRansacK0;
@@ -124,54 +144,69 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
             double acc[NS];
 #pragma unroll
             for (int s = 0; s < NS; ++s) acc[s] = 0.0;
+            double sc[2 * kFused];
+#pragma unroll
+            for (int s = 0; s < 2 * kFused; ++s) sc[s] = 0.0;
 #pragma unroll
             for (int j = 0; j < kRP; ++j)
-                if (px.ok[j]) (void)lm_pixel(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, plan, acc);
-            double(*red)[NS] = s_red[t & 1];
+                if (px.ok[j]) {
+                    const ScoreHook hook{px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], two_over, tol, &pose, sc};
+                    (void)lm_pixel(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, plan, acc, hook);
+                }
+            double(*red)[NSR] = s_red[t & 1];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 double r = is_max_slot(s) ? wave_max(acc[s]) : wave_sum(acc[s]);
                 if (lane == 0) red[wv][s] = r;
             }
+#pragma unroll
+            for (int s = 0; s < 2 * kFused; ++s) {
+                const double r = wave_sum(sc[s]);
+                if (lane == 0) red[wv][NS + s] = r;
+            }
             __syncthreads();
-            if (tid < NS) {
+            if (tid < NSR) {
                 double r = red[0][tid];
                 for (int w2 = 1; w2 < kRB / 64; ++w2) r = is_max_slot(tid) ? fmax(r, red[w2][tid]) : r + red[w2][tid];
-                double& a = s_acc[t * NS + tid];
+                double& a = s_acc[t * NSR + tid];
                 a = is_max_slot(tid) ? fmax(a, r) : a + r;
             }
         }
         __syncthreads();
     }
     __syncthreads();
-    double* out = partials + (int64_t)blockIdx.x * T * NS;
-    for (int i = tid; i < T * NS; i += kRB) out[i] = s_acc[i];
+    double* out = partials + (int64_t)blockIdx.x * T * NSR;
+    for (int i = tid; i < T * NSR; i += kRB) out[i] = s_acc[i];
 }
 
 // one workgroup per hypothesis
+// flags[0]: hypotheses still running after this round; flags[1]: hypotheses that finished WITHOUT a fused score
+// (accepted-step count != 1) and need the separate score pass.  scored[t] = 1 when trial_count/err were filled here.
 __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __restrict__ partials, int nblocks, int T,
-                                                           LmState* states, int64_t n, int round, int* running) {
-    __shared__ double s_red[4][NS];
-    __shared__ double s_sums[NS];
+                                                           LmState* states, int64_t n, int round, int* flags,
+                                                           int* __restrict__ scored, double* __restrict__ trial_count,
+                                                           double* __restrict__ trial_err) {
+    __shared__ double s_red[4][NSR];
+    __shared__ double s_sums[NSR];
     const int t = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     LmState* state = states + t;
     if (round > 0 && (state->status != 0 || state->next_launch != round)) return;
-    double fin[NS];
+    double fin[NSR];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) fin[s] = 0.0;
+    for (int s = 0; s < NSR; ++s) fin[s] = 0.0;
     for (int b = tid; b < nblocks; b += 256) {
-        const double* row = partials + ((int64_t)b * T + t) * NS;
+        const double* row = partials + ((int64_t)b * T + t) * NSR;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) fin[s] = is_max_slot(s) ? fmax(fin[s], row[s]) : fin[s] + row[s];
+        for (int s = 0; s < NSR; ++s) fin[s] = is_max_slot(s) ? fmax(fin[s], row[s]) : fin[s] + row[s];
     }
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
+    for (int s = 0; s < NSR; ++s) {
         double r = is_max_slot(s) ? wave_max(fin[s]) : wave_sum(fin[s]);
         if (lane == 0) s_red[wv][s] = r;
     }
     __syncthreads();
-    if (tid < NS) {
+    if (tid < NSR) {
         double r = s_red[0][tid];
         for (int w2 = 1; w2 < 4; ++w2) r = is_max_slot(tid) ? fmax(r, s_red[w2][tid]) : r + s_red[w2][tid];
         s_sums[tid] = r;
@@ -181,7 +216,15 @@ __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __rest
         LmScal st = *static_cast<const LmScal*>(state);
         const int used_K = (round == 0) ? kRansacK0 : st.K;
         lm_advance(st, state->hist, s_sums, n, round == 0, used_K, 0, round);
-        if (st.status == 0) atomicAdd(running, 1);
+        if (st.status == 0) {
+            atomicAdd(&flags[0], 1);
+        } else if (round == 0 && st.n_hist >= 1 && st.n_hist <= kFused) {  // a fused iterate is the final one
+            trial_count[t] = s_sums[NS + 2 * (st.n_hist - 1)];
+            trial_err[t] = s_sums[NS + 2 * (st.n_hist - 1) + 1];
+            scored[t] = 1;
+        } else {
+            atomicAdd(&flags[1], 1);
+        }
         *static_cast<LmScal*>(state) = st;
     }
 }
@@ -203,7 +246,7 @@ __global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __rest
                                                           const double* __restrict__ alpha_k, int64_t n,
                                                           const double* __restrict__ hyp, int T,
                                                           const LmState* __restrict__ states, int depth_mode, double tol,
-                                                          double* __restrict__ partials) {
+                                                          const int* __restrict__ scored, double* __restrict__ partials) {
     extern __shared__ double s_acc[];  // [T][2]
     __shared__ LmPlanLds plan;
     __shared__ double s_red[2][kRB / 64][2];
@@ -216,6 +259,7 @@ __global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __rest
         Tile px;
         load_tile(px, q, u, alpha, alpha_k, tile * tile_pixels, n);
         for (int t = 0; t < T; ++t) {
+            if (scored && scored[t]) continue;  // already scored by the fused LM pass (uniform branch)
             if (depth_mode == RSDSFM_DEPTH_CERES_LM) {
                 __syncthreads();
                 if (tid == 0) {
@@ -264,10 +308,12 @@ __global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __rest
 // one workgroup per hypothesis, threads stride over the pixel workgroups (independent loads in flight), then a
 // DPP wave reduction and the 4 waves in order
 __global__ __launch_bounds__(256) void ransac_reduce_scores_kernel(const double* __restrict__ partials, int nblocks, int T,
+                                                                  const int* __restrict__ scored,
                                                                   double* __restrict__ trial_count,
                                                                   double* __restrict__ trial_err) {
     __shared__ double s_red[4][2];
     const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (scored && scored[t]) return;
     double c = 0.0, e = 0.0;
     for (int b = tid; b < nblocks; b += 256) {
         c += partials[((int64_t)b * T + t) * 2 + 0];
@@ -455,30 +501,35 @@ int ransac_pixel_grid(const Ctx* c, int64_t n) {
     return (int)g;
 }
 
+int ransac_lm_partials_doubles(const Ctx* c, int64_t n, int batch) { return ransac_pixel_grid(c, n) * batch * NSR; }
+
+// flags: device int[2] = {running, unscored}; flags[0] is cleared here, flags[1] by the caller once per batch
 int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
-                           const double* hyp, int T, LmState* states, double* partials, int* running, int round) {
+                           const double* hyp, int T, LmState* states, double* partials, int* flags, int* scored,
+                           double* trial_count, double* trial_err, int round, double tol) {
     const int grid = ransac_pixel_grid(c, n);
-    hipLaunchKernelGGL(ransac_lm_kernel, dim3(grid), dim3(kRB), sizeof(double) * T * NS, c->stream,
+    hipLaunchKernelGGL(ransac_lm_kernel, dim3(grid), dim3(kRB), sizeof(double) * T * NSR, c->stream,
                        reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states,
-                       partials, round);
+                       partials, round, tol);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    RSDSFM_HIP_CHECK(c, hipMemsetAsync(running, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, states, n, round, running);
+    RSDSFM_HIP_CHECK(c, hipMemsetAsync(flags, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, states, n, round, flags, scored,
+                       trial_count, trial_err);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
 
-// scores the hypothesis batch [0, T) of `hyp` / `states`; trial_count / trial_err point at the batch's slots
+// scores the hypotheses of the batch [0, T) that are not yet scored; trial_count / trial_err point at the batch's slots
 int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
-                        const double* hyp, int T, const LmState* states, int depth_mode, double tol, double* partials,
-                        double* trial_count, double* trial_err) {
+                        const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
+                        double* partials, double* trial_count, double* trial_err) {
     const int grid = ransac_pixel_grid(c, n);
     hipLaunchKernelGGL(ransac_score_kernel, dim3(grid), dim3(kRB), sizeof(double) * T * 2, c->stream,
                        reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states,
-                       depth_mode, tol, partials);
+                       depth_mode, tol, scored, partials);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(ransac_reduce_scores_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T,
-                       trial_count, trial_err);
+    hipLaunchKernelGGL(ransac_reduce_scores_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, scored, trial_count,
+                       trial_err);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

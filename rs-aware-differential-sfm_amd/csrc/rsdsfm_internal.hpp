@@ -97,6 +97,8 @@ struct Ctx {
     // internal workspace of the multi-kernel pipelines (grown on demand)
     void* d_ws = nullptr;
     size_t ws_bytes = 0;
+    void* d_frame = nullptr;   // frame buffers of rsdsfm_solve_frame_dev
+    size_t frame_bytes = 0;
     void* h_pinned = nullptr;  // small pinned host buffer for result headers
     size_t pinned_bytes = 0;
     int num_cus = 256;
@@ -169,11 +171,13 @@ int minimal9_launch(Ctx* c, const double* q, const double* u, const double* alph
 namespace rsdsfm {
 // ransac_kernels.hip
 int ransac_pixel_grid(const Ctx* c, int64_t n);
+int ransac_lm_partials_doubles(const Ctx* c, int64_t n, int batch);
 int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
-                           const double* hyp, int T, LmState* states, double* partials, int* running, int round);
+                           const double* hyp, int T, LmState* states, double* partials, int* flags, int* scored,
+                           double* trial_count, double* trial_err, int round, double tol);
 int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
-                        const double* hyp, int T, const LmState* states, int depth_mode, double tol, double* partials,
-                        double* trial_count, double* trial_err);
+                        const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
+                        double* partials, double* trial_count, double* trial_err);
 int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best);
 int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         RansacBest* best, const LmState* states, int depth_mode, double tol, double* rho, uint8_t* mask,

@@ -1,0 +1,44 @@
+"""GPU: the one-call frame solve (rsdsfm_solve_frame_dev) equals the stage-by-stage path and the oracle chain."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_solve_frame_dev_matches_stages_and_oracle(oracle, rsdsfm):
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(3, rows=144, cols=256)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    img = torch.from_numpy(d["flow_img"]).to(dev)
+    dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+    R = torch.empty((rows, 9), dtype=torch.float64, device=dev)
+    t = torch.empty((rows, 3), dtype=torch.float64, device=dev)
+    T, tol, seed = 12, 0.002, 99
+    with rsdsfm.Solver(0) as s:
+        r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), trials=T, tol=tol, seed=seed)
+        s.synchronize()
+        # stage by stage (host-pointer API)
+        q, u, a, ak = s.flatten(d["flow_img"], K, gamma)
+        rr = s.ransac(q, u, a, ak, False, T, tol, samples=None, seed=seed, depth_mode=1)
+        ref = s.non_linear_refinement(u, rr["inliers"], rr["alpha"], rr["alpha_k"], rr["v"], rr["w"], rr["k"], False, flow_index_mode=1,
+                                      inlier_idx=rr["inlier_idx"])
+        dmap = s.depth_map(ref["inliers"], ref["v"], K, rows, cols)
+        Rr, tr = s.pose_table(dmap["v"], ref["w"], ref["k"], gamma, rows)
+    assert r["n"] == len(q) and r["num_inliers"] == rr["num_inliers"] and r["best_trial"] == rr["best_trial"]
+    assert np.array_equal(r["ransac_w"], rr["w"]) and np.array_equal(r["ransac_v"], rr["v"])
+    assert np.array_equal(r["w"], ref["w"]) and np.array_equal(r["v"], dmap["v"]) and r["k"] == ref["k"]
+    assert r["refine_summary"] == ref["summary"]
+    assert np.array_equal(dm.cpu().numpy().T, dmap["depth_map"])
+    assert np.array_equal(R.cpu().numpy().reshape(rows, 3, 3), Rr) and np.array_equal(t.cpu().numpy(), tr)
+    # oracle chain on the same sampler / seed
+    ro = oracle.ransac(q, u, a, ak, False, T, tol, oracle.sample_indices(len(q), T, seed), depth_mode=1)
+    assert ro["num_inliers"] == r["num_inliers"] and ro["best_trial"] == r["best_trial"]
+    refo = oracle.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], False, 1, ro["inlier_idx"])
+    inl_o, v_o, _ = oracle.canonicalize_sign(refo["inliers"], refo["v"])
+    assert np.allclose(r["v"], v_o, rtol=1e-6, atol=1e-10) and np.allclose(r["w"], refo["w"], rtol=1e-6, atol=1e-10)
+    dm_o, _, ys_o = oracle.scatter_depth(inl_o, *K, rows, cols)
+    got = dm.cpu().numpy().T
+    assert np.array_equal(got != 0, dm_o != 0)
+    assert np.allclose(got, dm_o, rtol=1e-6)

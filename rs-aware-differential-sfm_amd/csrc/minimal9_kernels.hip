@@ -43,19 +43,27 @@ __device__ __forceinline__ Rot make_jacobi(double x, double y, double z) {
         double t = (tau > 0.0) ? 1.0 / (tau + w) : 1.0 / (tau - w);
         double sign_t = t > 0.0 ? 1.0 : -1.0;
         double n = 1.0 / sqrt(t * t + 1.0);
-        j.s = -sign_t * (y / fabs(y)) * fabs(t) * n;
+        j.s = -sign_t * copysign(1.0, y) * fabs(t) * n;  // y / |y| (y != 0 here) without the division
         j.c = n;
     }
     return j;
 }
 
-// x' = c x + s y ; y' = -s x + c y over n strided elements of M
+// x' = c x + s y ; y' = -s x + c y over 9 strided elements of M.  All 18 LDS reads are issued before the first use
+// (a single wave has nobody to hide the ~64-cycle ds_read latency behind, so back-to-back dependent reads dominate).
 __device__ __forceinline__ void rot_plane(LVec M, int x0, int incx, int y0, int incy, int n, Rot j) {
+    (void)n;
     if (j.c == 1.0 && j.s == 0.0) return;
-    for (int i = 0; i < n; ++i) {
-        double xi = M[x0 + i * incx], yi = M[y0 + i * incy];
-        M[x0 + i * incx] = j.c * xi + j.s * yi;
-        M[y0 + i * incy] = -j.s * xi + j.c * yi;
+    double xv[9], yv[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        xv[i] = M[x0 + i * incx];
+        yv[i] = M[y0 + i * incy];
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        M[x0 + i * incx] = j.c * xv[i] + j.s * yv[i];
+        M[y0 + i * incy] = -j.s * xv[i] + j.c * yv[i];
     }
 }
 

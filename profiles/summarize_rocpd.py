@@ -6,7 +6,7 @@ for f in glob.glob(sys.argv[1]+'/**/*_results.db', recursive=True):
     agg=collections.defaultdict(list)
     meta={}
     for r in rows:
-        k=r[0].split('(')[0]; agg[k].append(r[2]-r[1]); meta[k]=r[3:]
+        k=r[0].split('(')[0].replace('void ',''); agg[k].append(r[2]-r[1]); meta[k]=r[3:]
     tot=sum(sum(v) for v in agg.values())
     print("%-60s %7s %10s %10s %10s %10s %6s  grid/wg/vgpr/agpr/sgpr/lds/scratch"%("kernel","calls","total_us","avg_us","med_us","min_us","pct"))
     for k,v in sorted(agg.items(), key=lambda kv:-sum(kv[1])):

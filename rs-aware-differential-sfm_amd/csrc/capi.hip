@@ -159,7 +159,7 @@ int rsdsfm_set_depth_variant(rsdsfm_ctx* ctx, int variant) {
 
 const char* rsdsfm_kernel_name(const char* entry_point) {
     if (!entry_point) return "";
-    if (!strcmp(entry_point, "estimate_inverse_depths_lm")) return "depth_lm_kernel";
+    if (!strcmp(entry_point, "estimate_inverse_depths_lm")) return "depth_lm_kernel<1>";
     if (!strcmp(entry_point, "estimate_inverse_depths_closed_form")) return "depth_closed_form_kernel";
     return "";
 }

@@ -53,6 +53,9 @@ __global__ __launch_bounds__(kDepthBlock) void depth_closed_form_kernel(const do
 
 // launch_id 0 = the launch of LM iteration zero (fresh state, built-in plan); launch_id > 0 acts only if the
 // state machine designated exactly this launch (next_launch) to continue (status 0) or to apply (status 2).
+// FIRST = 1: launch 0 of a solve (always a full speculative pass); FIRST = 0: follow-up launches (apply / continue /
+// no-op).  Same code; the template only gives the two roles distinct kernel names in profiles.
+template <int FIRST>
 __global__ __launch_bounds__(kDepthBlock) void depth_lm_kernel(const double2* __restrict__ q,
                                                                const double2* __restrict__ u,
                                                                const double2* __restrict__ alpha2,
@@ -170,6 +173,7 @@ __device__ __forceinline__ void issue_tile(const double2* __restrict__ q, const 
     dma16(gk, buf + 5120);
 }
 
+template <int FIRST>
 __global__ __launch_bounds__(kDepthBlock) void depth_lm_dma_kernel(const double2* __restrict__ q,
                                                                    const double2* __restrict__ u,
                                                                    const double2* __restrict__ alpha2,
@@ -370,22 +374,31 @@ int depth_lm_launch(Ctx* c, const double* q, const double* u, const double* a, c
     if (!aligned16(q) || !aligned16(u) || !aligned16(a) || !aligned16(ak) || !aligned16(rho))
         return fail(c, RSDSFM_ERR_INVALID, "device pointers must be 16-byte aligned");
     const int grid = depth_lm_grid(c, n);
+    const double2 *q2 = reinterpret_cast<const double2*>(q), *u2 = reinterpret_cast<const double2*>(u),
+                  *a2 = reinterpret_cast<const double2*>(a), *ak2 = reinterpret_cast<const double2*>(ak);
+    double2* rho2 = reinterpret_cast<double2*>(rho);
     if (c->depth_variant == 1) {
         static bool attr_set = false;
         if (!attr_set) {
-            RSDSFM_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(depth_lm_dma_kernel),
+            RSDSFM_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(depth_lm_dma_kernel<1>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLdsBytes));
+            RSDSFM_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(depth_lm_dma_kernel<0>),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLdsBytes));
             attr_set = true;
         }
-        hipLaunchKernelGGL(depth_lm_dma_kernel, dim3(grid), dim3(kDepthBlock), kDmaLdsBytes, c->stream,
-                           reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u),
-                           reinterpret_cast<const double2*>(a), reinterpret_cast<const double2*>(ak), n, pose,
-                           reinterpret_cast<double2*>(rho), c->d_lm, c->d_partials, launch_id);
+        if (launch_id == 0)
+            hipLaunchKernelGGL(depth_lm_dma_kernel<1>, dim3(grid), dim3(kDepthBlock), kDmaLdsBytes, c->stream, q2, u2, a2, ak2, n, pose,
+                               rho2, c->d_lm, c->d_partials, launch_id);
+        else
+            hipLaunchKernelGGL(depth_lm_dma_kernel<0>, dim3(grid), dim3(kDepthBlock), kDmaLdsBytes, c->stream, q2, u2, a2, ak2, n, pose,
+                               rho2, c->d_lm, c->d_partials, launch_id);
     } else {
-        hipLaunchKernelGGL(depth_lm_kernel, dim3(grid), dim3(kDepthBlock), 0, c->stream,
-                           reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u),
-                           reinterpret_cast<const double2*>(a), reinterpret_cast<const double2*>(ak), n, pose,
-                           reinterpret_cast<double2*>(rho), c->d_lm, c->d_partials, launch_id);
+        if (launch_id == 0)
+            hipLaunchKernelGGL(depth_lm_kernel<1>, dim3(grid), dim3(kDepthBlock), 0, c->stream, q2, u2, a2, ak2, n, pose, rho2, c->d_lm,
+                               c->d_partials, launch_id);
+        else
+            hipLaunchKernelGGL(depth_lm_kernel<0>, dim3(grid), dim3(kDepthBlock), 0, c->stream, q2, u2, a2, ak2, n, pose, rho2, c->d_lm,
+                               c->d_partials, launch_id);
     }
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;

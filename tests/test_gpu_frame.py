@@ -42,3 +42,29 @@ def test_solve_frame_dev_matches_stages_and_oracle(oracle, rsdsfm):
     got = dm.cpu().numpy().T
     assert np.array_equal(got != 0, dm_o != 0)
     assert np.allclose(got, dm_o, rtol=1e-6)
+
+
+def test_full_solve_4k_frame(rsdsfm):
+    """3840x2160 (BASELINE configs[3] size): the whole solve runs at the largest configured size -- workspace sizing,
+    64-bit indexing, compaction over > 2048 workgroups -- and recovers the motion of the DeepFlow-like pair."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(4)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    img = torch.from_numpy(d["flow_img"]).to(dev)
+    dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+    with rsdsfm.Solver(0) as s:
+        r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=8, tol=0.002, seed=5)
+        s.synchronize()
+    n = rows * cols
+    assert r["n"] == n and 0.5 * n < r["num_inliers"] < 0.95 * n  # 10 % outliers + noise tail rejected
+    t = d["truth"]
+    vt = t["v"] / np.linalg.norm(t["v"])
+    vv = r["v"] / np.linalg.norm(r["v"])
+    assert np.linalg.norm(r["w"] - t["w"]) < 2e-4 and abs(float(vv @ vt)) > 0.999
+    got = dm.cpu().numpy().T
+    assert int((got != 0).sum()) == r["num_inliers"]
+    Z = t["Z"] / np.linalg.norm(t["v"]) * np.linalg.norm(r["v"])
+    mask = got != 0
+    assert np.median(np.abs(got[mask] - Z[mask]) / Z[mask]) < 0.05

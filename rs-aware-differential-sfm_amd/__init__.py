@@ -12,6 +12,7 @@ Mirrors the reference's function boundary (reference: src/minimal.h:79-161, src/
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -105,6 +106,14 @@ def load_library(build_if_missing=True):
         from . import build as _build
 
         _build.build()
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 (same soname as /opt/rocm's).  If this
+    # library were loaded first it would pull in the system runtime and a later `import torch` would find "No HIP GPUs".
+    # Importing torch first (when it is installed) makes both share torch's runtime.
+    if "torch" not in sys.modules and os.environ.get("RSDSFM_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     lib.rsdsfm_version.restype = C.c_char_p
     lib.rsdsfm_last_error.restype = C.c_char_p

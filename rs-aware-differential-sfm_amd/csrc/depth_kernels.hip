@@ -293,6 +293,9 @@ __global__ __launch_bounds__(kDecideBlock) void depth_lm_decide_kernel(const dou
     __shared__ double s_sums[NS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (launch_id > 0 && (state->status != 0 || state->next_launch != launch_id)) return;
+    // the scalar state is fetched now so that its global round trip overlaps the loads of the partials
+    LmScal st;
+    if (tid == 0) st = *static_cast<const LmScal*>(state);
     double fin[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) fin[s] = 0.0;
@@ -316,7 +319,6 @@ __global__ __launch_bounds__(kDecideBlock) void depth_lm_decide_kernel(const dou
     }
     __syncthreads();
     if (tid == 0) {  // the state machine runs on a register copy of the scalar state (no LDS / scratch round trips)
-        LmScal st = *static_cast<const LmScal*>(state);
         const int pr = st.predict;
         const int used_K = (launch_id == 0) ? KMAX : st.K;
         const int used_write = (launch_id == 0) ? ((pr >= 0 && pr <= KMAX) ? pr : 1) : st.write_which;

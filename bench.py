@@ -10,6 +10,8 @@ Contract: python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on
               full              : the whole solve is the timed step.
               tiled             : BASELINE configs[3]-style row tiling: a 3840x2160 frame sharded over the N ranks,
                                   LM sum rows + ONE all-gather of the depth map over RCCL (scaling "strong").
+              tiled_full        : the WHOLE solve of a 3840x2160 frame split into column slabs over the N ranks
+                                  (rsdsfm_tile_* stages, dist.TiledFrameSolve; scaling "strong").
   N > 1     = one process per GPU (torch.distributed / RCCL).  depth / full: each rank solves its own frame pair
               (sequence-throughput mode, BASELINE configs[4]), no data-path collective -> scaling "weak".
 Frame pairs rotate through enough distinct HBM buffers to exceed the 256 MiB Infinity Cache, so the timed loop
@@ -75,7 +77,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form", "full", "tiled"])
+    ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nbuf", type=int, default=7, help="rotating HBM buffer sets (7 x 59 MB > 256 MiB L3)")
     ap.add_argument("--trials", type=int, default=50, help="RANSAC trials of the full solve (report section 5.4 used 50)")
@@ -222,6 +224,35 @@ def main():
                                     **{k2: full[k2] for k2 in ("rows", "cols", "trials", "num_inliers", "refine_summary")}},
                          "roofline": None, "full_solve": full,
                          "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_full(rsdsfm, args.trials, args.tol)})
+
+    # =================================================================================================
+    elif args.workload == "tiled_full":
+        # one 3840x2160 DeepFlow-like frame split into column slabs over the ranks: the WHOLE solve (flatten, RANSAC,
+        # refinement, sign fix + depth map) through the rsdsfm_tile_* stage entry points; every rank holds only its slab
+        data = rsdsfm.synth.make_config(4, seed=0x5EED0004)
+        rows, cols = data["rows"], data["cols"]
+        bounds, per = rsdsfm.dist.slab_bounds(cols, world)
+        c0, c1 = bounds[rank]
+        slab = torch.from_numpy(np.ascontiguousarray(data["flow_img"][:, c0:c1, :])).to(dev)
+        res = {}
+
+        def step(i):
+            shard = rsdsfm.dist.HipFrameShard(solver, slab, c0, data["K"], data["gamma"], torch)  # flatten is part of the solve
+            drv = rsdsfm.dist.TiledFrameSolve([shard], rows, cols, per, torch, dist if world > 1 else None)
+            res["r"] = drv.solve(trials=args.trials, tol=args.tol, seed=1 + i)
+
+        el = timed(step, args.steps, args.warmup)
+        if rank == 0:
+            r = res["r"]
+            t = data["truth"]
+            line.update({"value": rows * cols * args.steps / el / 1e6, "ms_per_step": el / args.steps * 1e3, "scaling": "strong",
+                         "metric": "Mpixels/sec RS whole solve, 3840x2160 frame column-tiled over the ranks",
+                         "config": {"workload": "BASELINE configs[3]-size DeepFlow-like frame, column slabs over %d rank(s): flatten + RANSAC(%d, tol %g) "
+                                                "+ refinement + depth map; all-gathers of the stage sum rows + ONE all-gather of the depth slabs"
+                                                % (world, args.trials, args.tol),
+                                    "rows": rows, "cols": cols, "n": r["n"], "num_inliers": r["num_inliers"], "ransac_rounds": r["ransac_rounds"],
+                                    "refine_summary": r["refine_summary"], "w_err": float(np.linalg.norm(r["w"] - t["w"]))},
+                         "roofline": None, "cpu_baseline": None})
 
     # =================================================================================================
     else:  # tiled

@@ -237,6 +237,82 @@ int rsdsfm_depth_finish_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* 
                             const double* d_alpha_k_n, double* d_inv_depth_n, rsdsfm_lm_summary* summary_or_null,
                             int32_t* extra_launches);
 
+/* ---- stage-level entry points of the ROW-TILED (multi-GPU) WHOLE-FRAME solve -----------------------------------
+ * RANSAC (minimal.cc:209-306), nonLinearRefinement (nonlinearRefinement.cc:183-252) and the
+ * caller glue (main.cc:398-522) with the image split into COLUMN SLABS, one per rank.  The reference flattens the
+ * image column-major (main.cc:398-444), so the slabs' point lists concatenated in rank order are the reference's
+ * point list.  Each "*_rows_dev" stage works on the caller's shard and leaves a small row of sums on the device;
+ * the driver all-gathers the rows in rank order (RCCL) and passes the gathered [nranks][...] array to the matching
+ * decide / apply stage, which EVERY rank runs identically (the kernels that reduce per-workgroup partials in the
+ * single-GPU solve reduce the per-rank rows) -- all ranks take identical decisions, nothing is broadcast.
+ * All calls are asynchronous on the context's stream unless noted.  Driver: rs-aware-differential-sfm_amd/dist.py
+ * (TiledFrameSolve). */
+/* flatten of one slab: d_img_slab is the row-major [rows][slab_cols][2] slab whose first column is image column
+ * col0; q.x is computed from the GLOBAL column.  Synchronises (returns the shard's point count). */
+int rsdsfm_flatten_slab_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int32_t rows, int32_t slab_cols, int32_t col0,
+                            double fx, double fy, double cx, double cy, double gamma, double thr, double* d_q2n,
+                            double* d_u2n, double* d_alpha_n, double* d_alpha_k_n, int64_t* n_out);
+/* host: the deterministic sampler of rsdsfm_ransac (9 partial Fisher-Yates draws per trial, minimal.cc:226-244,
+ * splitmix64(seed) in place of rand()); n = GLOBAL point count, samples = 9 * iterations global indices */
+int rsdsfm_sample_indices(int64_t n, int32_t iterations, uint64_t seed, int32_t* samples);
+/* minimal::calculateVelocities (minimal.cc:36-177) on `count` packed 9-point sets already on the device:
+ * d_q9 / d_u9 = count x 9 x 2, d_alpha9 / d_alpha_k9 = count x 9; d_hyp = count x 8: w(3), v(3), k, status */
+int rsdsfm_minimal9_dev(rsdsfm_ctx* ctx, const double* d_q9, const double* d_u9, const double* d_alpha9,
+                        const double* d_alpha_k9, int32_t count, int use_alpha_k, int k_sign_mode, double* d_hyp);
+size_t rsdsfm_tile_lm_state_bytes(void);   /* bytes of one per-hypothesis LM state (caller zero-fills count of them) */
+size_t rsdsfm_tile_best_bytes(void);       /* bytes of the device-resident winner record                             */
+int32_t rsdsfm_tile_ransac_row_size(void); /* doubles per hypothesis in an LM sums row                               */
+int32_t rsdsfm_tile_ransac_batch(void);    /* max hypotheses per *_rows_dev call (128)                               */
+/* round r of the speculative LM depth solves of hypotheses [0, count): shard sums -> d_rows[count][row_size] */
+int rsdsfm_tile_ransac_lm_rows_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n, const double* d_alpha_n,
+                                   const double* d_alpha_k_n, int64_t n_shard, const double* d_hyp, int32_t count,
+                                   const void* d_states, int32_t round, double tolerance, double* d_rows);
+/* gathered rows [nranks][count][row_size] -> trust-region decisions; d_flags[0] = hypotheses still running (cleared
+ * here), d_flags[1] += hypotheses that need the separate score pass (caller clears it once per batch) */
+int rsdsfm_tile_ransac_decide_dev(rsdsfm_ctx* ctx, const double* d_rows_all, int32_t nranks, int32_t count, void* d_states,
+                                  int64_t n_total, int32_t round, int32_t* d_flags, int32_t* d_scored, double* d_trial_count,
+                                  double* d_trial_err);
+/* inlier scores (minimal.cc:255-275) of the not yet scored hypotheses: shard sums -> d_rows[count][2] */
+int rsdsfm_tile_ransac_score_rows_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n, const double* d_alpha_n,
+                                      const double* d_alpha_k_n, int64_t n_shard, const double* d_hyp, int32_t count,
+                                      const void* d_states, int depth_mode, double tolerance, const int32_t* d_scored_or_null,
+                                      double* d_rows);
+int rsdsfm_tile_ransac_score_merge_dev(rsdsfm_ctx* ctx, const double* d_rows_all, int32_t nranks, int32_t count,
+                                       const int32_t* d_scored_or_null, double* d_trial_count, double* d_trial_err);
+/* the reference's best-trial rule (minimal.cc:278-285) over all trials -> d_best */
+int rsdsfm_tile_ransac_pick_dev(rsdsfm_ctx* ctx, const double* d_trial_count, const double* d_trial_err, int32_t iterations,
+                                const double* d_hyp, void* d_best);
+/* dense 1/depth + mask of the winner on the shard and its order-preserving compaction (minimal.cc:291-305).
+ * Synchronises.  out->num_inliers is the SHARD's count; best_trial, w, v, k, inlier_error are the global winner's.
+ * d_inlier_idx holds shard-local indices.  The out arrays of `out` are ignored (pass the device arrays explicitly). */
+int rsdsfm_tile_ransac_final_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n, const double* d_alpha_n,
+                                 const double* d_alpha_k_n, int64_t n_shard, void* d_best, const void* d_states, int depth_mode,
+                                 double tolerance, double* d_inv_depth_n, uint8_t* d_mask_n, int64_t* d_inlier_idx,
+                                 double* d_inliers3m, double* d_out_alpha, double* d_out_alpha_k, rsdsfm_ransac_out* out);
+int64_t rsdsfm_tile_ransac_global_inliers(rsdsfm_ctx* ctx, const void* d_best); /* synchronises; -1 on error */
+/* joint refinement on the shard's inliers.  begin opens a session on the context (flow = the shard's flattened u,
+ * inlier_idx shard-local: RSDSFM_FLOW_GATHERED only); stage 0 = iteration-zero sums, then per LM iteration stage 1
+ * (Schur sums -> reduced solve) and stage 2 (back-substitution sums -> accept / reject / converge):
+ *   rows_dev(stage) -> all-gather -> apply_dev(stage) on every rank;  poll (synchronises) reads the state machine
+ * (summary->termination == -1 while running); finish writes (x, y, 1/rho) and closes the session. */
+int rsdsfm_tile_refine_begin_dev(rsdsfm_ctx* ctx, const double* d_flow2n, int64_t n_flow, int64_t m_shard, const double* d_inl3m,
+                                 const double* d_alpha_m, const double* d_alpha_k_m, const int64_t* d_inlier_idx,
+                                 const double v_in[3], const double w_in[3], double k_in, int const_acceleration,
+                                 int flow_index_mode);
+int32_t rsdsfm_tile_refine_row_size(int const_acceleration, int32_t stage);
+int rsdsfm_tile_refine_rows_dev(rsdsfm_ctx* ctx, int32_t stage, double* d_row);
+int rsdsfm_tile_refine_apply_dev(rsdsfm_ctx* ctx, int32_t stage, const double* d_rows_all, int32_t nranks, int64_t m_total);
+int rsdsfm_tile_refine_poll(rsdsfm_ctx* ctx, double v_out[3], double w_out[3], double* k_out, rsdsfm_lm_summary* summary);
+int rsdsfm_tile_refine_finish_dev(rsdsfm_ctx* ctx, double* d_inl_out3m);
+/* sign fix (main.cc:466-481) + depth map (main.cc:499-508) of one slab: zsum_dev leaves the shard's sum of z on the
+ * device; depth_map_dev takes the gathered [nranks] sums, decides the flip from the global mean, flips the shard's z
+ * in place and writes the column-major [slab_cols][rows] slab of the map.  Synchronises (flip flag, v). */
+int rsdsfm_tile_zsum_dev(rsdsfm_ctx* ctx, const double* d_inl3m, int64_t m_shard, double* d_zsum1);
+int rsdsfm_tile_depth_map_dev(rsdsfm_ctx* ctx, double* d_inl3m, int64_t m_shard, const double* d_zsums_all, int32_t nranks,
+                              int64_t m_total, double v_inout[3], double fx, double fy, double cx, double cy, int32_t rows,
+                              int32_t col0, int32_t slab_cols, double* d_depth_slab, int32_t* d_xs_or_null,
+                              int32_t* d_ys_or_null, int* flipped);
+
 #ifdef __cplusplus
 }
 #endif

@@ -370,3 +370,103 @@ class Solver:
         extra = C.c_int32()
         self._check(self.lib.rsdsfm_depth_finish_dev(self._ctx, _dp(d_q), _dp(d_u), C.c_int64(n), _v3(v), _v3(w), C.c_double(k), _dp(d_alpha), _dp(d_alpha_k), _dp(d_rho), C.byref(sm), C.byref(extra)), "rsdsfm_depth_finish_dev")
         return sm.as_dict(), extra.value
+
+
+# ---------------------------------------------------------------------------------------------------
+# stage-level wrappers of the row-tiled whole-frame solve (include/rsdsfm.h "ROW-TILED WHOLE-FRAME"; driver: dist.py)
+# ---------------------------------------------------------------------------------------------------
+def _np0(ptr):
+    return _dp(ptr) if ptr else None
+
+
+def tile_sizes():
+    """(bytes per LM state, bytes of the winner record, doubles per LM row, hypotheses per rows call)"""
+    lib = load_library()
+    lib.rsdsfm_tile_lm_state_bytes.restype = C.c_size_t
+    lib.rsdsfm_tile_best_bytes.restype = C.c_size_t
+    return (int(lib.rsdsfm_tile_lm_state_bytes()), int(lib.rsdsfm_tile_best_bytes()), int(lib.rsdsfm_tile_ransac_row_size()),
+            int(lib.rsdsfm_tile_ransac_batch()))
+
+
+def sample_indices(n, iterations, seed):
+    """the deterministic sampler of rsdsfm_ransac (host side): [iterations, 9] int32 global indices"""
+    lib = load_library()
+    out = np.zeros((max(int(iterations), 0), 9), dtype=np.int32)
+    rc = lib.rsdsfm_sample_indices(C.c_int64(n), C.c_int32(iterations), C.c_uint64(seed), _p(out))
+    if rc != OK:
+        raise RsdsfmError("rsdsfm_sample_indices failed (%d): needs 9 <= n < 2^31" % rc)
+    return out
+
+
+class _TileMixin:
+    def flatten_slab_dev(self, d_img_slab, rows, slab_cols, col0, K, gamma, d_q, d_u, d_alpha, d_alpha_k, thr=1e-10):
+        cnt = C.c_int64()
+        d = C.c_double
+        self._check(self.lib.rsdsfm_flatten_slab_dev(self._ctx, _np0(d_img_slab), C.c_int32(rows), C.c_int32(slab_cols), C.c_int32(col0), d(K[0]), d(K[1]), d(K[2]), d(K[3]), d(gamma), d(thr), _np0(d_q), _np0(d_u), _np0(d_alpha), _np0(d_alpha_k), C.byref(cnt)), "rsdsfm_flatten_slab_dev")
+        return cnt.value
+
+    def minimal9_dev(self, d_q9, d_u9, d_a9, d_ak9, count, use_alpha_k, k_sign_mode, d_hyp):
+        self._check(self.lib.rsdsfm_minimal9_dev(self._ctx, _np0(d_q9), _np0(d_u9), _np0(d_a9), _np0(d_ak9), C.c_int32(count), int(use_alpha_k), int(k_sign_mode), _np0(d_hyp)), "rsdsfm_minimal9_dev")
+
+    def tile_ransac_lm_rows_dev(self, d_q, d_u, d_a, d_ak, n, d_hyp, count, d_states, rnd, tol, d_rows):
+        self._check(self.lib.rsdsfm_tile_ransac_lm_rows_dev(self._ctx, _np0(d_q), _np0(d_u), _np0(d_a), _np0(d_ak), C.c_int64(n), _dp(d_hyp), C.c_int32(count), _dp(d_states), C.c_int32(rnd), C.c_double(tol), _dp(d_rows)), "rsdsfm_tile_ransac_lm_rows_dev")
+
+    def tile_ransac_decide_dev(self, d_rows_all, nranks, count, d_states, n_total, rnd, d_flags, d_scored, d_tcount, d_terr):
+        self._check(self.lib.rsdsfm_tile_ransac_decide_dev(self._ctx, _dp(d_rows_all), C.c_int32(nranks), C.c_int32(count), _dp(d_states), C.c_int64(n_total), C.c_int32(rnd), _dp(d_flags), _dp(d_scored), _dp(d_tcount), _dp(d_terr)), "rsdsfm_tile_ransac_decide_dev")
+
+    def tile_ransac_score_rows_dev(self, d_q, d_u, d_a, d_ak, n, d_hyp, count, d_states, depth_mode, tol, d_scored, d_rows):
+        self._check(self.lib.rsdsfm_tile_ransac_score_rows_dev(self._ctx, _np0(d_q), _np0(d_u), _np0(d_a), _np0(d_ak), C.c_int64(n), _dp(d_hyp), C.c_int32(count), _dp(d_states), int(depth_mode), C.c_double(tol), _np0(d_scored), _dp(d_rows)), "rsdsfm_tile_ransac_score_rows_dev")
+
+    def tile_ransac_score_merge_dev(self, d_rows_all, nranks, count, d_scored, d_tcount, d_terr):
+        self._check(self.lib.rsdsfm_tile_ransac_score_merge_dev(self._ctx, _dp(d_rows_all), C.c_int32(nranks), C.c_int32(count), _np0(d_scored), _dp(d_tcount), _dp(d_terr)), "rsdsfm_tile_ransac_score_merge_dev")
+
+    def tile_ransac_pick_dev(self, d_tcount, d_terr, iterations, d_hyp, d_best):
+        self._check(self.lib.rsdsfm_tile_ransac_pick_dev(self._ctx, _np0(d_tcount), _np0(d_terr), C.c_int32(iterations), _np0(d_hyp), _dp(d_best)), "rsdsfm_tile_ransac_pick_dev")
+
+    def tile_ransac_final_dev(self, d_q, d_u, d_a, d_ak, n, d_best, d_states, depth_mode, tol, d_rho, d_mask, d_idx, d_inl, d_oa, d_oak):
+        out = RansacOut()
+        self._check(self.lib.rsdsfm_tile_ransac_final_dev(self._ctx, _np0(d_q), _np0(d_u), _np0(d_a), _np0(d_ak), C.c_int64(n), _dp(d_best), _dp(d_states), int(depth_mode), C.c_double(tol), _np0(d_rho), _np0(d_mask), _np0(d_idx), _np0(d_inl), _np0(d_oa), _np0(d_oak), C.byref(out)), "rsdsfm_tile_ransac_final_dev")
+        return dict(shard_inliers=int(out.num_inliers), best_trial=int(out.best_trial), w=np.array(out.w[:]), v=np.array(out.v[:]), k=float(out.k), inlier_error=float(out.inlier_error))
+
+    def tile_ransac_global_inliers(self, d_best):
+        self.lib.rsdsfm_tile_ransac_global_inliers.restype = C.c_int64
+        r = int(self.lib.rsdsfm_tile_ransac_global_inliers(self._ctx, _dp(d_best)))
+        if r < 0:
+            raise RsdsfmError("rsdsfm_tile_ransac_global_inliers failed")
+        return r
+
+    def tile_refine_begin_dev(self, d_flow, n_flow, m, d_inl, d_alpha, d_alpha_k, d_idx, v, w, k, const_acceleration, flow_index_mode=FLOW_GATHERED):
+        self._check(self.lib.rsdsfm_tile_refine_begin_dev(self._ctx, _np0(d_flow), C.c_int64(n_flow), C.c_int64(m), _np0(d_inl), _np0(d_alpha), _np0(d_alpha_k), _np0(d_idx), _v3(v), _v3(w), C.c_double(k), int(const_acceleration), int(flow_index_mode)), "rsdsfm_tile_refine_begin_dev")
+
+    def tile_refine_row_size(self, const_acceleration, stage):
+        return int(self.lib.rsdsfm_tile_refine_row_size(int(const_acceleration), C.c_int32(stage)))
+
+    def tile_refine_rows_dev(self, stage, d_row):
+        self._check(self.lib.rsdsfm_tile_refine_rows_dev(self._ctx, C.c_int32(stage), _dp(d_row)), "rsdsfm_tile_refine_rows_dev")
+
+    def tile_refine_apply_dev(self, stage, d_rows_all, nranks, m_total):
+        self._check(self.lib.rsdsfm_tile_refine_apply_dev(self._ctx, C.c_int32(stage), _dp(d_rows_all), C.c_int32(nranks), C.c_int64(m_total)), "rsdsfm_tile_refine_apply_dev")
+
+    def tile_refine_poll(self):
+        vo, wo, ko = (C.c_double * 3)(), (C.c_double * 3)(), C.c_double()
+        sm = LmSummary()
+        self._check(self.lib.rsdsfm_tile_refine_poll(self._ctx, vo, wo, C.byref(ko), C.byref(sm)), "rsdsfm_tile_refine_poll")
+        return dict(v=np.array(vo[:]), w=np.array(wo[:]), k=ko.value, summary=sm.as_dict(), running=sm.termination < 0)
+
+    def tile_refine_finish_dev(self, d_inl_out):
+        self._check(self.lib.rsdsfm_tile_refine_finish_dev(self._ctx, _np0(d_inl_out)), "rsdsfm_tile_refine_finish_dev")
+
+    def tile_zsum_dev(self, d_inl, m, d_zsum):
+        self._check(self.lib.rsdsfm_tile_zsum_dev(self._ctx, _np0(d_inl), C.c_int64(m), _dp(d_zsum)), "rsdsfm_tile_zsum_dev")
+
+    def tile_depth_map_dev(self, d_inl, m, d_zsums_all, nranks, m_total, v, K, rows, col0, slab_cols, d_depth_slab, d_xs=None, d_ys=None):
+        vv = _v3(v)
+        flipped = C.c_int()
+        d = C.c_double
+        self._check(self.lib.rsdsfm_tile_depth_map_dev(self._ctx, _np0(d_inl), C.c_int64(m), _dp(d_zsums_all), C.c_int32(nranks), C.c_int64(m_total), vv, d(K[0]), d(K[1]), d(K[2]), d(K[3]), C.c_int32(rows), C.c_int32(col0), C.c_int32(slab_cols), _np0(d_depth_slab), _np0(d_xs), _np0(d_ys), C.byref(flipped)), "rsdsfm_tile_depth_map_dev")
+        return np.array(vv[:]), bool(flipped.value)
+
+
+for _name, _fn in list(vars(_TileMixin).items()):
+    if not _name.startswith("__"):
+        setattr(Solver, _name, _fn)

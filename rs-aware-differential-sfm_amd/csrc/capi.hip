@@ -136,6 +136,8 @@ void rsdsfm_destroy(rsdsfm_ctx* ctx) {
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_frame) (void)hipFree(c->d_frame);
+    if (c->d_tile) (void)hipFree(c->d_tile);
+    delete static_cast<RefineBuffers*>(c->tile_session);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete ctx;

@@ -6,13 +6,11 @@
 
 using namespace rsdsfm;
 
-extern "C" {
-
-int rsdsfm_flatten_dev(rsdsfm_ctx* ctx, const double* d_img, int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
-                       double gamma, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* n_out) {
-    if (!ctx) return RSDSFM_ERR_INVALID;
-    Ctx* c = &ctx->c;
-    if (rows < 0 || cols < 0 || !n_out) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+// flatten of a column slab: d_img is the row-major [rows][cols] slab whose first column is image column col0
+static int flatten_device(Ctx* c, const double* d_img, int32_t rows, int32_t cols, int32_t col0, double fx, double fy, double cx,
+                          double cy, double gamma, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k,
+                          int64_t* n_out) {
+    if (rows < 0 || cols < 0 || col0 < 0 || !n_out) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     const int64_t n = (int64_t)rows * cols;
     if (n == 0) {
         *n_out = 0;
@@ -27,13 +25,28 @@ int rsdsfm_flatten_dev(rsdsfm_ctx* ctx, const double* d_img, int32_t rows, int32
     int64_t* d_counts = ws.take<int64_t>(2048);
     int64_t* d_offsets = ws.take<int64_t>(2048);
     int64_t* d_total = ws.take<int64_t>(1);
-    rc = flatten_launch(c, d_img, rows, cols, fx, fy, cx, cy, gamma, thr, d_q, d_u, d_alpha, d_alpha_k, d_counts, d_offsets, d_total);
+    rc = flatten_launch(c, d_img, rows, cols, col0, fx, fy, cx, cy, gamma, thr, d_q, d_u, d_alpha, d_alpha_k, d_counts, d_offsets, d_total);
     if (rc != RSDSFM_OK) return rc;
     int64_t* h_total = static_cast<int64_t*>(c->h_pinned);
     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     *n_out = *h_total;
     return RSDSFM_OK;
+}
+
+extern "C" {
+
+int rsdsfm_flatten_dev(rsdsfm_ctx* ctx, const double* d_img, int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
+                       double gamma, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* n_out) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    return flatten_device(&ctx->c, d_img, rows, cols, 0, fx, fy, cx, cy, gamma, thr, d_q, d_u, d_alpha, d_alpha_k, n_out);
+}
+
+int rsdsfm_flatten_slab_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int32_t rows, int32_t slab_cols, int32_t col0, double fx,
+                            double fy, double cx, double cy, double gamma, double thr, double* d_q, double* d_u, double* d_alpha,
+                            double* d_alpha_k, int64_t* n_out) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    return flatten_device(&ctx->c, d_img_slab, rows, slab_cols, col0, fx, fy, cx, cy, gamma, thr, d_q, d_u, d_alpha, d_alpha_k, n_out);
 }
 
 int rsdsfm_flatten(rsdsfm_ctx* ctx, const double* img, int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,

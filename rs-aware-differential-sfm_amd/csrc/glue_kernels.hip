@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256) void glue_scan_kernel(const int64_t* __restric
 // pass 2: order-preserving scatter of (q, u, alpha, alpha_k)
 __global__ __launch_bounds__(kGB) void flatten_scatter_kernel(const double2* __restrict__ img, int rows, int cols, double fx,
                                                              double fy, double cx, double cy, double gamma, double thr,
-                                                             int64_t chunk, const int64_t* __restrict__ block_offsets,
+                                                             int col0, int64_t chunk,
+                                                             const int64_t* __restrict__ block_offsets,
                                                              double2* __restrict__ q, double2* __restrict__ u,
                                                              double* __restrict__ alpha, double* __restrict__ alpha_k) {
     __shared__ int s_wave[kGB / 64];
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(kGB) void flatten_scatter_kernel(const double2* __r
         }
         if (keep) {
             const int64_t o = s_base + woff + prefix;
-            q[o] = make_double2((i - cx) * 1.0 / fx, (j - cy) * 1.0 / fy);
+            q[o] = make_double2(((i + col0) - cx) * 1.0 / fx, (j - cy) * 1.0 / fy);
             u[o] = make_double2(f.x * gamma / fx, f.y * gamma / fy);
             alpha[o] = 1 + gamma * f.y / h;  // minimal.cc:183 with pixel flow, h = rows (quirk Q6)
             const double part1 = gamma * (double)j / h;
@@ -245,9 +246,9 @@ __global__ __launch_bounds__(256) void zsum_decide_kernel(const double* __restri
 // flips z in place if requested, computes pixel indices, claims pixels for the HIGHEST inlier index (the
 // reference's sequential loop lets the last writer win, main.cc:499-508)
 __global__ __launch_bounds__(kGB) void depth_claim_kernel(double* __restrict__ inl, int64_t m, const double* __restrict__ header,
-                                                         double fx, double fy, double cx, double cy, int rows, int cols,
-                                                         long long* __restrict__ owner, int32_t* __restrict__ xs,
-                                                         int32_t* __restrict__ ys) {
+                                                         double fx, double fy, double cx, double cy, int rows, int col0,
+                                                         int ncols, long long* __restrict__ owner,
+                                                         int32_t* __restrict__ xs, int32_t* __restrict__ ys) {
     const bool flip = header[0] != 0.0;
     const int64_t stride = (int64_t)gridDim.x * kGB;
     for (int64_t i = (int64_t)blockIdx.x * kGB + threadIdx.x; i < m; i += stride) {
@@ -256,7 +257,7 @@ __global__ __launch_bounds__(kGB) void depth_claim_kernel(double* __restrict__ i
         const int y = (int)(fy * inl[3 * i + 1] + cy + 0.5);
         if (xs) xs[i] = x;
         if (ys) ys[i] = y;
-        if (x >= 0 && x < cols && y >= 0 && y < rows) atomicMax(&owner[(int64_t)x * rows + y], (long long)i);
+        if (x >= col0 && x < col0 + ncols && y >= 0 && y < rows) atomicMax(&owner[(int64_t)(x - col0) * rows + y], (long long)i);
     }
 }
 
@@ -281,8 +282,8 @@ static inline void glue_chunking(int64_t n, int64_t& chunk, int& blocks) {
 }
 
 // d_total: device int64 receiving the number of kept points; workspace: 2 x 2048 int64
-int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, double fx, double fy, double cx, double cy, double gamma,
-                   double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* d_counts,
+int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, int col0, double fx, double fy, double cx, double cy,
+                   double gamma, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* d_counts,
                    int64_t* d_offsets, int64_t* d_total) {
     const int64_t n = (int64_t)rows * cols;
     int64_t chunk;
@@ -294,8 +295,52 @@ int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, double fx, d
     hipLaunchKernelGGL(glue_scan_kernel, dim3(1), dim3(256), 0, c->stream, d_counts, blocks, d_offsets, d_total);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(flatten_scatter_kernel, dim3(blocks), dim3(kGB), 0, c->stream, reinterpret_cast<const double2*>(d_img), rows,
-                       cols, fx, fy, cx, cy, gamma, thr, chunk, d_offsets, reinterpret_cast<double2*>(d_q),
+                       cols, fx, fy, cx, cy, gamma, thr, col0, chunk, d_offsets, reinterpret_cast<double2*>(d_q),
                        reinterpret_cast<double2*>(d_u), d_alpha, d_alpha_k);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+// the shard's z sum as one double (the all-gather payload of the row-tiled solve); d_partials: >= 1024 doubles
+__global__ __launch_bounds__(256) void zsum_row_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ out) {
+    __shared__ double s_red[4];
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) acc += partials[b];
+    const double r = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = r;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+}
+
+static inline int zsum_blocks(int64_t m) { return (int)std::min<int64_t>(1024, std::max<int64_t>(1, (m + kGB - 1) / kGB)); }
+
+int zsum_row_launch(Ctx* c, const double* d_inl, int64_t m, double* d_partials, double* d_out) {
+    const int zb = zsum_blocks(m);
+    hipLaunchKernelGGL(zsum_partial_kernel, dim3(zb), dim3(kGB), 0, c->stream, d_inl, m, d_partials);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(zsum_row_kernel, dim3(1), dim3(256), 0, c->stream, d_partials, zb, d_out);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+// sign decision from nz partial z sums over m_total points, then claim + write of the column slab [col0, col0 + ncols)
+// d_header: 4 doubles (flipped, v'); d_owner: rows*ncols int64
+int depth_map_slab_launch(Ctx* c, double* d_inl, int64_t m, const double* d_zsums, int nz, int64_t m_total, const double v[3],
+                          double fx, double fy, double cx, double cy, int rows, int col0, int ncols, double* d_depth_map,
+                          int32_t* d_xs, int32_t* d_ys, double* d_header, long long* d_owner) {
+    const int64_t npix = (int64_t)rows * ncols;
+    Pose pv;
+    memset(&pv, 0, sizeof(pv));
+    pv.v[0] = v[0], pv.v[1] = v[1], pv.v[2] = v[2];
+    hipLaunchKernelGGL(zsum_decide_kernel, dim3(1), dim3(256), 0, c->stream, d_zsums, nz, m_total, pv, d_header);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_owner, 0xFF, sizeof(long long) * (size_t)npix, c->stream));  // -1
+    if (m > 0) {
+        hipLaunchKernelGGL(depth_claim_kernel, dim3(stream_grid(m)), dim3(kGB), 0, c->stream, d_inl, m, d_header, fx, fy, cx, cy, rows,
+                           col0, ncols, d_owner, d_xs, d_ys);
+        RSDSFM_HIP_CHECK(c, hipGetLastError());
+    }
+    hipLaunchKernelGGL(depth_write_kernel, dim3(stream_grid(npix)), dim3(kGB), 0, c->stream, d_inl, d_owner, npix, d_depth_map);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
@@ -304,24 +349,11 @@ int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, double fx, d
 int depth_map_launch(Ctx* c, double* d_inl, int64_t m, const double v[3], double fx, double fy, double cx, double cy, int rows,
                      int cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, double* d_header, long long* d_owner,
                      double* d_partials) {
-    const int64_t npix = (int64_t)rows * cols;
-    Pose pv;
-    memset(&pv, 0, sizeof(pv));
-    pv.v[0] = v[0], pv.v[1] = v[1], pv.v[2] = v[2];
-    int zb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (m + kGB - 1) / kGB));
+    const int zb = zsum_blocks(m);
     hipLaunchKernelGGL(zsum_partial_kernel, dim3(zb), dim3(kGB), 0, c->stream, d_inl, m, d_partials);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(zsum_decide_kernel, dim3(1), dim3(256), 0, c->stream, d_partials, zb, m, pv, d_header);
-    RSDSFM_HIP_CHECK(c, hipGetLastError());
-    RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_owner, 0xFF, sizeof(long long) * (size_t)npix, c->stream));  // -1
-    if (m > 0) {
-        hipLaunchKernelGGL(depth_claim_kernel, dim3(stream_grid(m)), dim3(kGB), 0, c->stream, d_inl, m, d_header, fx, fy, cx, cy, rows,
-                           cols, d_owner, d_xs, d_ys);
-        RSDSFM_HIP_CHECK(c, hipGetLastError());
-    }
-    hipLaunchKernelGGL(depth_write_kernel, dim3(stream_grid(npix)), dim3(kGB), 0, c->stream, d_inl, d_owner, npix, d_depth_map);
-    RSDSFM_HIP_CHECK(c, hipGetLastError());
-    return RSDSFM_OK;
+    return depth_map_slab_launch(c, d_inl, m, d_partials, zb, m, v, fx, fy, cx, cy, rows, 0, cols, d_depth_map, d_xs, d_ys, d_header,
+                                 d_owner);
 }
 
 }  // namespace rsdsfm

@@ -46,6 +46,12 @@ void sample_indices(int64_t n, int T, uint64_t seed, std::vector<int32_t>& out) 
 
 }  // namespace
 
+void sample_indices(int64_t n, int T, uint64_t seed, int32_t* out) {
+    std::vector<int32_t> v;
+    sample_indices(n, T, seed, v);
+    if (!v.empty()) memcpy(out, v.data(), sizeof(int32_t) * v.size());
+}
+
 // Device-resident RANSAC.  d_* inputs and the arrays of `out` are device pointers (any of the out arrays may be
 // NULL); scalars of `out` and its trial_* arrays (host) are filled after one final synchronisation.
 int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n,

@@ -179,19 +179,10 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
     for (int i = tid; i < T * NSR; i += kRB) out[i] = s_acc[i];
 }
 
-// one workgroup per hypothesis
-// flags[0]: hypotheses still running after this round; flags[1]: hypotheses that finished WITHOUT a fused score
-// (accepted-step count != 1) and need the separate score pass.  scored[t] = 1 when trial_count/err were filled here.
-__global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __restrict__ partials, int nblocks, int T,
-                                                           LmState* states, int64_t n, int round, int* flags,
-                                                           int* __restrict__ scored, double* __restrict__ trial_count,
-                                                           double* __restrict__ trial_err) {
-    __shared__ double s_red[4][NSR];
-    __shared__ double s_sums[NSR];
-    const int t = blockIdx.x;
+// fixed-order reduction of partials[nblocks][T][NSR] of hypothesis t into s_sums[NSR] (256 threads)
+__device__ __forceinline__ void reduce_hyp_sums(const double* __restrict__ partials, int nblocks, int T, int t,
+                                                double (*s_red)[NSR], double* s_sums) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    LmState* state = states + t;
-    if (round > 0 && (state->status != 0 || state->next_launch != round)) return;
     double fin[NSR];
 #pragma unroll
     for (int s = 0; s < NSR; ++s) fin[s] = 0.0;
@@ -212,6 +203,39 @@ __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __rest
         s_sums[tid] = r;
     }
     __syncthreads();
+}
+
+// row-tiled solve: the shard's partials of every hypothesis reduced to one row [T][NSR] (the all-gather payload;
+// the gathered [ranks][T][NSR] array is then what ransac_decide_kernel reduces, ranks in place of workgroups)
+__global__ __launch_bounds__(256) void ransac_lm_rows_kernel(const double* __restrict__ partials, int nblocks, int T,
+                                                            const LmState* __restrict__ states, int round,
+                                                            double* __restrict__ rows) {
+    __shared__ double s_red[4][NSR];
+    __shared__ double s_sums[NSR];
+    const int t = blockIdx.x;
+    const LmState* state = states + t;
+    if (round > 0 && (state->status != 0 || state->next_launch != round)) {
+        if (threadIdx.x < NSR) rows[(int64_t)t * NSR + threadIdx.x] = 0.0;
+        return;
+    }
+    reduce_hyp_sums(partials, nblocks, T, t, s_red, s_sums);
+    if (threadIdx.x < NSR) rows[(int64_t)t * NSR + threadIdx.x] = s_sums[threadIdx.x];
+}
+
+// one workgroup per hypothesis
+// flags[0]: hypotheses still running after this round; flags[1]: hypotheses that finished WITHOUT a fused score
+// (accepted-step count != 1) and need the separate score pass.  scored[t] = 1 when trial_count/err were filled here.
+__global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __restrict__ partials, int nblocks, int T,
+                                                           LmState* states, int64_t n, int round, int* flags,
+                                                           int* __restrict__ scored, double* __restrict__ trial_count,
+                                                           double* __restrict__ trial_err) {
+    __shared__ double s_red[4][NSR];
+    __shared__ double s_sums[NSR];
+    const int t = blockIdx.x;
+    const int tid = threadIdx.x;
+    LmState* state = states + t;
+    if (round > 0 && (state->status != 0 || state->next_launch != round)) return;
+    reduce_hyp_sums(partials, nblocks, T, t, s_red, s_sums);
     if (tid == 0) {
         LmScal st = *static_cast<const LmScal*>(state);
         const int used_K = (round == 0) ? kRansacK0 : st.K;
@@ -329,6 +353,33 @@ __global__ __launch_bounds__(256) void ransac_reduce_scores_kernel(const double*
     if (tid == 0) {
         trial_count[t] = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
         trial_err[t] = ((s_red[0][1] + s_red[1][1]) + s_red[2][1]) + s_red[3][1];
+    }
+}
+
+// row-tiled solve: the shard's score partials reduced to rows[T][2] (zeros for hypotheses already scored)
+__global__ __launch_bounds__(256) void ransac_score_rows_kernel(const double* __restrict__ partials, int nblocks, int T,
+                                                               const int* __restrict__ scored, double* __restrict__ rows) {
+    __shared__ double s_red[4][2];
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (scored && scored[t]) {
+        if (tid < 2) rows[(int64_t)t * 2 + tid] = 0.0;
+        return;
+    }
+    double c = 0.0, e = 0.0;
+    for (int b = tid; b < nblocks; b += 256) {
+        c += partials[((int64_t)b * T + t) * 2 + 0];
+        e += partials[((int64_t)b * T + t) * 2 + 1];
+    }
+    c = wave_sum(c);
+    e = wave_sum(e);
+    if (lane == 0) {
+        s_red[wv][0] = c;
+        s_red[wv][1] = e;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        rows[(int64_t)t * 2 + 0] = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
+        rows[(int64_t)t * 2 + 1] = ((s_red[0][1] + s_red[1][1]) + s_red[2][1]) + s_red[3][1];
     }
 }
 
@@ -533,6 +584,51 @@ int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* 
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
+
+// ---- row-tiled stages (one shard of the points per rank; see dist.py TiledFrameSolve) ----
+int ransac_lm_rows_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
+                          const double* hyp, int T, const LmState* states, double* partials, int round, double tol, double* rows) {
+    const int grid = ransac_pixel_grid(c, n);
+    hipLaunchKernelGGL(ransac_lm_kernel, dim3(grid), dim3(kRB), sizeof(double) * T * NSR, c->stream,
+                       reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states,
+                       partials, round, tol);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(ransac_lm_rows_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, states, round, rows);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+int ransac_decide_rows_launch(Ctx* c, const double* rows_all, int nranks, int T, LmState* states, int64_t n_total, int round,
+                              int* flags, int* scored, double* trial_count, double* trial_err) {
+    RSDSFM_HIP_CHECK(c, hipMemsetAsync(flags, 0, sizeof(int), c->stream));
+    hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, rows_all, nranks, T, states, n_total, round, flags,
+                       scored, trial_count, trial_err);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+int ransac_score_rows_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
+                             const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
+                             double* partials, double* rows) {
+    const int grid = ransac_pixel_grid(c, n);
+    hipLaunchKernelGGL(ransac_score_kernel, dim3(grid), dim3(kRB), sizeof(double) * T * 2, c->stream,
+                       reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states,
+                       depth_mode, tol, scored, partials);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(ransac_score_rows_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, scored, rows);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+int ransac_score_merge_launch(Ctx* c, const double* rows_all, int nranks, int T, const int* scored, double* trial_count,
+                              double* trial_err) {
+    hipLaunchKernelGGL(ransac_reduce_scores_kernel, dim3(T), dim3(256), 0, c->stream, rows_all, nranks, T, scored, trial_count,
+                       trial_err);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+int ransac_rows_doubles() { return NSR; }
 
 int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best) {
     hipLaunchKernelGGL(ransac_pick_kernel, dim3(1), dim3(64), 0, c->stream, trial_count, trial_err, T, hyp, best);

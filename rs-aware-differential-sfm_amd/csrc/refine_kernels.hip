@@ -517,6 +517,67 @@ static int refine_iter_t(Ctx* c, const RefineBuffers& B) {
     return RSDSFM_OK;
 }
 
+// ---- row-tiled stages (one shard of the inliers per rank; see dist.py TiledFrameSolve) ----
+// the shard's partials reduced to one row (the all-gather payload); the decide kernels then reduce the gathered
+// [ranks][NV] array exactly as they reduce per-workgroup partials
+template <int NV>
+__global__ __launch_bounds__(kFB) void refine_row_kernel(const double* __restrict__ partials, int nblocks, int max_slot,
+                                                        double* __restrict__ row) {
+    __shared__ double s_red[kFB / 64][NV];
+    __shared__ double s[NV];
+    reduce_partials<NV>(partials, nblocks, max_slot, s_red, s);
+    if (threadIdx.x < NV) row[threadIdx.x] = s[threadIdx.x];
+}
+
+template <int NP>
+static int refine_stage_rows_t(Ctx* c, const RefineBuffers& B, int stage, double* row) {
+    using CT = Counts<NP>;
+    const int grid = refine_grid(c, B.m);
+    if (stage == 0) {
+        hipLaunchKernelGGL(refine_init_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, reinterpret_cast<const double2*>(B.flow),
+                           B.n_flow, B.m, B.inl, B.alpha, B.alpha_k, B.inlier_idx, B.flow_index_mode, B.state,
+                           reinterpret_cast<double2*>(B.uu), B.rho_a, B.srho, B.partials, B.bad_index);
+        RSDSFM_HIP_CHECK(c, hipGetLastError());
+        hipLaunchKernelGGL(refine_row_kernel<CT::NINIT>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, CT::INIT_MAX, row);
+    } else if (stage == 1) {
+        hipLaunchKernelGGL(refine_schur_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m, B.inl,
+                           reinterpret_cast<const double2*>(B.uu), B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
+        RSDSFM_HIP_CHECK(c, hipGetLastError());
+        hipLaunchKernelGGL(refine_row_kernel<CT::NSCHUR>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, -1, row);
+    } else {
+        hipLaunchKernelGGL(refine_backsub_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m, B.inl,
+                           reinterpret_cast<const double2*>(B.uu), B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
+        RSDSFM_HIP_CHECK(c, hipGetLastError());
+        hipLaunchKernelGGL(refine_row_kernel<CT::NBACK>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, CT::BACK_MAX, row);
+    }
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+template <int NP>
+static int refine_stage_apply_t(Ctx* c, const RefineBuffers& B, int stage, const double* rows_all, int nranks, int64_t m_total) {
+    if (stage == 0)
+        hipLaunchKernelGGL(refine_init_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state, m_total);
+    else if (stage == 1)
+        hipLaunchKernelGGL(refine_solve_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state);
+    else
+        hipLaunchKernelGGL(refine_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+int refine_stage_row_doubles(int np, int stage) {
+    if (np == 7) return stage == 0 ? Counts<7>::NINIT : stage == 1 ? Counts<7>::NSCHUR : Counts<7>::NBACK;
+    return stage == 0 ? Counts<6>::NINIT : stage == 1 ? Counts<6>::NSCHUR : Counts<6>::NBACK;
+}
+int refine_stage_rows_launch(Ctx* c, const RefineBuffers& B, int np, int stage, double* row) {
+    return np == 7 ? refine_stage_rows_t<7>(c, B, stage, row) : refine_stage_rows_t<6>(c, B, stage, row);
+}
+int refine_stage_apply_launch(Ctx* c, const RefineBuffers& B, int np, int stage, const double* rows_all, int nranks, int64_t m_total) {
+    return np == 7 ? refine_stage_apply_t<7>(c, B, stage, rows_all, nranks, m_total)
+                   : refine_stage_apply_t<6>(c, B, stage, rows_all, nranks, m_total);
+}
+
 int refine_init_launch(Ctx* c, const RefineBuffers& B, int np) { return np == 7 ? refine_init_t<7>(c, B) : refine_init_t<6>(c, B); }
 int refine_iter_launch(Ctx* c, const RefineBuffers& B, int np) { return np == 7 ? refine_iter_t<7>(c, B) : refine_iter_t<6>(c, B); }
 

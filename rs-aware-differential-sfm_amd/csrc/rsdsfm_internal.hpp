@@ -103,6 +103,11 @@ struct Ctx {
     size_t pinned_bytes = 0;
     int num_cus = 256;
     int depth_variant = 0;  // 0 = register-staged depth_lm_kernel, 1 = LDS-DMA depth_lm_dma_kernel
+    // row-tiled refinement session (tiled_host.hip): buffers live in d_tile, not in the shared workspace
+    void* d_tile = nullptr;
+    size_t tile_bytes = 0;
+    void* tile_session = nullptr;  // heap RefineBuffers of the open session
+    int tile_np = 0;
 };
 
 constexpr int kDepthBlock = 256;
@@ -154,12 +159,16 @@ namespace rsdsfm {
 int alpha_launch(Ctx* c, const double* flow_px, int64_t n, double h, double gamma, double* alpha);
 int alpha_k_launch(Ctx* c, const double* q_px, const double* flow_px, int64_t n, double h, double gamma, double* alpha_k);
 int pose_table_launch(Ctx* c, const Pose& pose, double gamma, int rows, double* R, double* t);
-int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, double fx, double fy, double cx, double cy, double gamma,
-                   double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* d_counts,
+int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, int col0, double fx, double fy, double cx, double cy,
+                   double gamma, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* d_counts,
                    int64_t* d_offsets, int64_t* d_total);
 int depth_map_launch(Ctx* c, double* d_inl, int64_t m, const double v[3], double fx, double fy, double cx, double cy, int rows,
                      int cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, double* d_header, long long* d_owner,
                      double* d_partials);
+int zsum_row_launch(Ctx* c, const double* d_inl, int64_t m, double* d_partials, double* d_out);
+int depth_map_slab_launch(Ctx* c, double* d_inl, int64_t m, const double* d_zsums, int nz, int64_t m_total, const double v[3],
+                          double fx, double fy, double cx, double cy, int rows, int col0, int ncols, double* d_depth_map,
+                          int32_t* d_xs, int32_t* d_ys, double* d_header, long long* d_owner);
 }  // namespace rsdsfm
 
 namespace rsdsfm {
@@ -183,6 +192,18 @@ int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* 
                         RansacBest* best, const LmState* states, int depth_mode, double tol, double* rho, uint8_t* mask,
                         int64_t* block_counts, int64_t* block_offsets, int64_t* inlier_idx, double* inliers,
                         double* out_alpha, double* out_alpha_k);
+// row-tiled stages
+int ransac_rows_doubles();
+int ransac_lm_rows_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
+                          const double* hyp, int T, const LmState* states, double* partials, int round, double tol, double* rows);
+int ransac_decide_rows_launch(Ctx* c, const double* rows_all, int nranks, int T, LmState* states, int64_t n_total, int round,
+                              int* flags, int* scored, double* trial_count, double* trial_err);
+int ransac_score_rows_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
+                             const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
+                             double* partials, double* rows);
+int ransac_score_merge_launch(Ctx* c, const double* rows_all, int nranks, int T, const int* scored, double* trial_count,
+                              double* trial_err);
+void sample_indices(int64_t n, int T, uint64_t seed, int32_t* out);
 }  // namespace rsdsfm
 
 namespace rsdsfm {
@@ -212,6 +233,10 @@ int refine_partials_doubles(const Ctx* c, int64_t m);
 int refine_init_launch(Ctx* c, const RefineBuffers& B, int np);
 int refine_iter_launch(Ctx* c, const RefineBuffers& B, int np);
 int refine_finish_launch(Ctx* c, const RefineBuffers& B, double* inl_out);
+// row-tiled stages: stage 0 = iteration-zero sums, 1 = Schur sums, 2 = back-substitution sums
+int refine_stage_row_doubles(int np, int stage);
+int refine_stage_rows_launch(Ctx* c, const RefineBuffers& B, int np, int stage, double* row);
+int refine_stage_apply_launch(Ctx* c, const RefineBuffers& B, int np, int stage, const double* rows_all, int nranks, int64_t m_total);
 }  // namespace rsdsfm
 
 // the opaque handle of the C ABI

@@ -119,3 +119,230 @@ class TiledDepthSolve:
             assert len({s[1] for s in states}) == 1
             launch_id = states[0][1]
         raise RuntimeError("LM state machine did not terminate")
+
+
+# ---------------------------------------------------------------------------------------------------
+# row-tiled WHOLE-FRAME solve (flatten -> RANSAC -> refinement -> sign fix + depth map), SURVEY section 8(e)
+# ---------------------------------------------------------------------------------------------------
+def slab_bounds(cols, nslabs):
+    """contiguous column slabs [(c0, c1)] of the image; the reference flattens column-major (main.cc:398-444), so the
+    slabs' point lists in slab order concatenate to the reference's point list"""
+    per = -(-cols // nslabs)
+    return [(min(cols, s * per), min(cols, (s + 1) * per)) for s in range(nslabs)], per
+
+
+class HipFrameShard:
+    """One column slab of the flow image resident on this process' GPU; owns the slab's flattened arrays.
+    `solver` must run on torch's current stream (Solver(device, stream=torch.cuda.current_stream().cuda_stream))."""
+
+    def __init__(self, solver, img_slab, col0, K, gamma, torch, thr=1e-10):
+        self.s, self.torch, self.K, self.gamma, self.col0 = solver, torch, K, gamma, int(col0)
+        self.img = img_slab.contiguous()
+        self.rows, self.ncols = int(self.img.shape[0]), int(self.img.shape[1])
+        npix = max(self.rows * self.ncols, 1)
+        f64 = dict(dtype=torch.float64, device=self.img.device)
+        self.q, self.u = torch.empty(2 * npix, **f64), torch.empty(2 * npix, **f64)
+        self.a, self.ak = torch.empty(npix, **f64), torch.empty(npix, **f64)
+        self.n = solver.flatten_slab_dev(self.img.data_ptr(), self.rows, self.ncols, self.col0, K, gamma, self.q.data_ptr(),
+                                         self.u.data_ptr(), self.a.data_ptr(), self.ak.data_ptr(), thr)
+        self.m = 0
+
+    def point_ptrs(self):
+        return self.q.data_ptr(), self.u.data_ptr(), self.a.data_ptr(), self.ak.data_ptr(), self.n
+
+    def packed_points(self, loc):
+        """rows (qx, qy, ux, uy, alpha, alpha_k) of the shard-local indices `loc` (int64 tensor)"""
+        torch = self.torch
+        q, u = self.q.view(-1, 2), self.u.view(-1, 2)
+        return torch.cat([q[loc], u[loc], self.a[loc].unsqueeze(1), self.ak[loc].unsqueeze(1)], dim=1)
+
+
+class TiledFrameSolve:
+    """shards: the HipFrameShard objects this process owns, in global slab order (rank-major).  dist: an initialised
+    torch.distributed (backend "nccl" = RCCL) or None.  Every collective is an all-gather / all-reduce of a few
+    hundred bytes to a few KB (latency-bound) except the final all-gather of the depth-map slabs."""
+
+    def __init__(self, shards, rows, cols, per_cols, torch, dist=None):
+        from . import tile_sizes
+
+        self.shards, self.rows, self.cols, self.per_cols, self.torch, self.dist = shards, rows, cols, per_cols, torch, dist
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.state_bytes, self.best_bytes, self.nsr, self.batch = tile_sizes()
+        self.dev = shards[0].img.device
+        self.s0 = shards[0].s  # the context that runs the per-process (replicated) decisions
+
+    # -- collectives ------------------------------------------------------------------------------
+    def _all_gather(self, t):
+        """[local, ...] -> [world * local, ...] in rank order"""
+        if self.dist is None or self.world == 1:
+            return t.contiguous()
+        outs = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(outs, t.contiguous())
+        return self.torch.cat(outs, dim=0).contiguous()
+
+    def _all_reduce_sum(self, t):
+        if self.dist is not None and self.world > 1:
+            self.dist.all_reduce(t)
+        return t
+
+    # -- stages -----------------------------------------------------------------------------------
+    def _sampled_points(self, samples, offsets):
+        """the 9 T sampled points (global indices) packed [9 T, 6]: every shard contributes the rows it owns, zeros
+        elsewhere; the sum over shards / ranks is exact (one non-zero term per entry)"""
+        torch = self.torch
+        smp = torch.from_numpy(samples.reshape(-1).astype(np.int64)).to(self.dev)
+        acc = torch.zeros(smp.shape[0], 6, dtype=torch.float64, device=self.dev)
+        for sh, off in zip(self.shards, offsets):
+            if sh.n == 0:
+                continue
+            loc = smp - off
+            mine = (loc >= 0) & (loc < sh.n)
+            pts = sh.packed_points(loc.clamp(0, sh.n - 1))
+            acc += torch.where(mine.unsqueeze(1), pts, torch.zeros_like(pts))
+        return self._all_reduce_sum(acc)
+
+    def _ransac(self, T, tol, seed, use_alpha_k, depth_mode, k_sign_mode, samples):
+        from . import sample_indices
+
+        torch, s0 = self.torch, self.s0
+        L = len(self.shards)
+        counts = self._all_gather(torch.tensor([sh.n for sh in self.shards], dtype=torch.int64, device=self.dev)).cpu().numpy()
+        n_total = int(counts.sum())
+        first = (self.dist.get_rank() if self.dist is not None else 0) * L
+        offs_all = np.concatenate([[0], np.cumsum(counts)])
+        self.offsets = [int(offs_all[first + i]) for i in range(L)]
+        self.n_total = n_total
+        if n_total < 9:
+            raise ValueError("ransac needs at least 9 points (the reference would compute rand() % 0)")
+        if samples is None:
+            samples = sample_indices(n_total, T, seed)
+        samples = np.ascontiguousarray(samples, dtype=np.int32).reshape(T, 9)
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        i32 = dict(dtype=torch.int32, device=self.dev)
+        Tn = max(T, 1)
+        hyp = torch.zeros(Tn * 8, **f64)
+        states = torch.zeros(Tn * self.state_bytes, dtype=torch.uint8, device=self.dev)
+        scored = torch.zeros(Tn, **i32)
+        tcount, terr = torch.zeros(Tn, **f64), torch.zeros(Tn, **f64)
+        best = torch.zeros(self.best_bytes, dtype=torch.uint8, device=self.dev)
+        rounds = 0
+        if T > 0:
+            pts = self._sampled_points(samples, self.offsets)
+            q9, u9 = pts[:, 0:2].contiguous(), pts[:, 2:4].contiguous()
+            a9, ak9 = pts[:, 4].contiguous(), pts[:, 5].contiguous()
+            s0.minimal9_dev(q9.data_ptr(), u9.data_ptr(), a9.data_ptr(), ak9.data_ptr(), T, use_alpha_k, k_sign_mode, hyp.data_ptr())
+            for b0 in range(0, T, self.batch):
+                B = min(self.batch, T - b0)
+                hyp_b = hyp.data_ptr() + 8 * 8 * b0
+                st_b = states.data_ptr() + self.state_bytes * b0
+                sc_b, tc_b, te_b = scored.data_ptr() + 4 * b0, tcount.data_ptr() + 8 * b0, terr.data_ptr() + 8 * b0
+                need_score = True
+                if depth_mode == DEPTH_CERES_LM:
+                    flags = torch.zeros(2, **i32)
+                    for rnd in range(4 * 50 + 1):
+                        rows = torch.empty(L, B, self.nsr, **f64)
+                        for i, sh in enumerate(self.shards):
+                            sh.s.tile_ransac_lm_rows_dev(*sh.point_ptrs(), hyp_b, B, st_b, rnd, tol, rows[i].data_ptr())
+                        rows_all = self._all_gather(rows)  # [slabs, B, NSR] in global slab order
+                        s0.tile_ransac_decide_dev(rows_all.data_ptr(), int(rows_all.shape[0]), B, st_b, n_total, rnd, flags.data_ptr(), sc_b, tc_b, te_b)
+                        rounds += 1
+                        fl = flags.cpu().numpy()
+                        if fl[0] == 0:
+                            break
+                    else:
+                        raise RuntimeError("LM state machines did not terminate")
+                    need_score = fl[1] > 0
+                if need_score:
+                    rows = torch.empty(L, B, 2, **f64)
+                    for i, sh in enumerate(self.shards):
+                        sh.s.tile_ransac_score_rows_dev(*sh.point_ptrs(), hyp_b, B, st_b, depth_mode, tol, sc_b if depth_mode == DEPTH_CERES_LM else 0, rows[i].data_ptr())
+                    rows_all = self._all_gather(rows)
+                    s0.tile_ransac_score_merge_dev(rows_all.data_ptr(), int(rows_all.shape[0]), B, sc_b if depth_mode == DEPTH_CERES_LM else 0, tc_b, te_b)
+        s0.tile_ransac_pick_dev(tcount.data_ptr(), terr.data_ptr(), T, hyp.data_ptr(), best.data_ptr())
+        m_total = s0.tile_ransac_global_inliers(best.data_ptr())
+        win = None
+        for sh in self.shards:
+            n1 = max(sh.n, 1)
+            sh.rho = torch.empty(n1, **f64)
+            sh.mask = torch.empty(n1, dtype=torch.uint8, device=self.dev)
+            sh.idx = torch.empty(n1, dtype=torch.int64, device=self.dev)
+            sh.inl = torch.empty(3 * n1, **f64)
+            sh.in_a, sh.in_ak = torch.empty(n1, **f64), torch.empty(n1, **f64)
+            # the compaction scan rewrites the record's scan total, so every shard works on its own copy
+            best_s = best.clone()
+            win = sh.s.tile_ransac_final_dev(*sh.point_ptrs()[:4], sh.n, best_s.data_ptr(), states.data_ptr(), depth_mode, tol, sh.rho.data_ptr(),
+                                             sh.mask.data_ptr(), sh.idx.data_ptr(), sh.inl.data_ptr(), sh.in_a.data_ptr(), sh.in_ak.data_ptr())
+            sh.m = win["shard_inliers"]
+        ms = self._all_gather(torch.tensor([sh.m for sh in self.shards], dtype=torch.int64, device=self.dev)).cpu().numpy()
+        if int(ms.sum()) != m_total:
+            raise RuntimeError("inlier count mismatch between scoring (%d) and compaction (%d)" % (m_total, int(ms.sum())))
+        self.m_total, self.m_all = m_total, ms
+        return dict(n=n_total, num_inliers=m_total, best_trial=win["best_trial"], ransac_w=win["w"], ransac_v=win["v"], ransac_k=win["k"],
+                    inlier_error=win["inlier_error"], trial_count=tcount[:T].cpu().numpy().astype(np.int64), trial_err=terr[:T].cpu().numpy(),
+                    ransac_rounds=rounds)
+
+    def _staged(self, stage, size):
+        """one refinement stage: shard rows -> all-gather -> identical apply on every shard's state machine"""
+        torch = self.torch
+        rows = torch.empty(len(self.shards), size, dtype=torch.float64, device=self.dev)
+        for i, sh in enumerate(self.shards):
+            sh.s.tile_refine_rows_dev(stage, rows[i].data_ptr())
+        rows_all = self._all_gather(rows)
+        for sh in self.shards:
+            sh.s.tile_refine_apply_dev(stage, rows_all.data_ptr(), int(rows_all.shape[0]), self.m_total)
+        return rows_all
+
+    def _refine(self, v, w, k, const_acceleration):
+        torch = self.torch
+        sizes = [self.s0.tile_refine_row_size(const_acceleration, st) for st in range(3)]
+        for sh in self.shards:
+            sh.inl_ref = torch.empty(3 * max(sh.m, 1), dtype=torch.float64, device=self.dev)
+            sh.s.tile_refine_begin_dev(sh.u.data_ptr(), sh.n, sh.m, sh.inl.data_ptr(), sh.in_a.data_ptr(), sh.in_ak.data_ptr(), sh.idx.data_ptr(), v, w, k, const_acceleration)
+        keep = [self._staged(0, sizes[0])]
+        st = self.s0.tile_refine_poll()
+        it = 0
+        while st["running"]:
+            if it > 4 * 50 + 16:
+                raise RuntimeError("refinement did not terminate")
+            keep = [self._staged(1, sizes[1]), self._staged(2, sizes[2])]
+            st = self.s0.tile_refine_poll()  # synchronises: the gathered rows above are consumed
+            it += 1
+        for sh in self.shards:
+            sh.s.tile_refine_finish_dev(sh.inl_ref.data_ptr())
+        del keep
+        return st
+
+    def solve(self, trials=50, tol=0.05, seed=1, use_acceleration_mode=False, use_refinement=True, depth_mode=DEPTH_CERES_LM,
+              k_sign_mode=0, samples=None, pose_table=False):
+        """returns the dict of Solver.solve_frame_dev (same keys) plus depth_map (torch, column-major [cols * rows]);
+        the shards keep their refined inliers (sh.final, 3 x sh.m) and scanline indices (sh.ys)."""
+        torch = self.torch
+        res = self._ransac(int(trials), float(tol), int(seed), int(bool(use_acceleration_mode)), depth_mode, k_sign_mode, samples)
+        v, w, k = res["ransac_v"], res["ransac_w"], res["ransac_k"]
+        if use_refinement:
+            st = self._refine(v, w, k, bool(use_acceleration_mode))
+            v, w, k = st["v"], st["w"], st["k"]
+            res["refine_summary"] = st["summary"]
+            for sh in self.shards:
+                sh.final = sh.inl_ref
+        else:
+            for sh in self.shards:
+                sh.final = sh.inl
+        zs = torch.empty(len(self.shards), dtype=torch.float64, device=self.dev)
+        for i, sh in enumerate(self.shards):
+            sh.s.tile_zsum_dev(sh.final.data_ptr(), sh.m, zs[i].data_ptr())
+        zs_all = self._all_gather(zs)
+        slabs = torch.zeros(len(self.shards), self.per_cols * self.rows, dtype=torch.float64, device=self.dev)
+        flipped, v_out = False, v
+        for i, sh in enumerate(self.shards):
+            sh.ys = torch.empty(max(sh.m, 1), dtype=torch.int32, device=self.dev)
+            v_out, flipped = sh.s.tile_depth_map_dev(sh.final.data_ptr(), sh.m, zs_all.data_ptr(), int(zs_all.shape[0]), self.m_total, v, sh.K, self.rows,
+                                                     sh.col0, sh.ncols, slabs[i].data_ptr(), None, sh.ys.data_ptr())
+        depth = self._all_gather(slabs).reshape(-1)[: self.cols * self.rows]  # the one data-path all-gather
+        res.update(v=np.asarray(v_out), w=np.asarray(w), k=float(k), flipped=flipped, depth_map=depth)
+        if pose_table:
+            R = torch.empty(self.rows * 9, dtype=torch.float64, device=self.dev)
+            t = torch.empty(self.rows * 3, dtype=torch.float64, device=self.dev)
+            self.s0.pose_table_dev(v_out, w, k, self.shards[0].gamma, self.rows, R.data_ptr(), t.data_ptr())
+            res.update(R=R, t=t)
+        return res

@@ -110,3 +110,77 @@ def test_row_tiled_driver_gloo_world2(tmp_path, oracle, golden, case):
         assert np.allclose(r[i]["rho1"], rho1, rtol=1e-12, atol=1e-15)
         assert int(r[i]["steps"]) == sm1["num_successful_steps"] and int(r[i]["term"]) == sm1["termination"]
     assert np.array_equal(r[0]["rho1"], r[1]["rho1"]) and np.array_equal(r[0]["rho0"], r[1]["rho0"])
+
+
+# ---------------------------------------------------------------------------------------------------
+# row-tiled WHOLE-FRAME driver (dist.TiledFrameSolve): host logic + a world_size-2 gloo run on CPU tensors with the
+# oracle-backed stage stand-in (tests/tile_oracle_stub.py); the HIP stages themselves run in tests/test_gpu_tiled_frame.py
+# ---------------------------------------------------------------------------------------------------
+def test_slab_bounds(rsdsfm):
+    for cols in (1, 7, 250, 1280, 3840):
+        for p in (1, 2, 3, 8):
+            b, per = rsdsfm.dist.slab_bounds(cols, p)
+            assert len(b) == p and b[0][0] == 0 and b[-1][1] == cols
+            assert all(b[i][1] == b[i + 1][0] for i in range(p - 1))
+            # every slab but the last non-empty one is full, so the padded slabs concatenate to the full map
+            full = [c1 - c0 == per for c0, c1 in b]
+            nonempty = [c1 > c0 for c0, c1 in b]
+            last = max(i for i in range(p) if nonempty[i])
+            assert all(full[:last]) and not any(nonempty[last + 1:])
+
+
+def test_sampler_matches_oracle(rsdsfm, oracle):
+    for n, T, seed in ((9, 1, 0), (10, 3, 5), (5000, 50, 99), (921600, 7, 1)):
+        assert np.array_equal(rsdsfm.sample_indices(n, T, seed), oracle.sample_indices(n, T, seed))
+    with pytest.raises(rsdsfm.RsdsfmError):
+        rsdsfm.sample_indices(8, 1, 0)
+
+
+def _frame_worker(rank, world, port, out_dir, nlocal):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import rsdsfm
+    import oracle_py
+    from tile_oracle_stub import OracleTileSolver
+
+    d = rsdsfm.synth.make_config(3, rows=36, cols=50)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    bounds, per = rsdsfm.dist.slab_bounds(cols, world * nlocal)
+    shards = []
+    for c0, c1 in bounds[rank * nlocal:(rank + 1) * nlocal]:
+        slab = torch.from_numpy(np.ascontiguousarray(d["flow_img"][:, c0:c1, :]))
+        shards.append(rsdsfm.dist.HipFrameShard(OracleTileSolver(oracle_py), slab, c0, K, gamma, torch))
+    drv = rsdsfm.dist.TiledFrameSolve(shards, rows, cols, per, torch, dist)
+    r = drv.solve(trials=9, tol=0.004, seed=11, use_refinement=False, depth_mode=0)
+    np.savez(os.path.join(out_dir, "frame%d.npz" % rank), depth=r["depth_map"].numpy(), v=r["v"], w=r["w"], k=r["k"], n=r["n"],
+             m=r["num_inliers"], best=r["best_trial"], tc=r["trial_count"], te=r["trial_err"], flipped=r["flipped"],
+             inl=np.concatenate([sh.final[: 3 * sh.m].numpy() for sh in shards]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nlocal", [1, 2])
+def test_tiled_frame_driver_gloo_world2(tmp_path, oracle, rsdsfm, nlocal):
+    port = 31500 + (os.getpid() % 2000) + nlocal
+    mp.spawn(_frame_worker, args=(2, port, str(tmp_path), nlocal), nprocs=2, join=True)
+    d = rsdsfm.synth.make_config(3, rows=36, cols=50)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    # the unsharded oracle chain on the same sampler / seed
+    q, u, a, ak = d["q"], d["u"], d["alpha"], d["alpha_k"]
+    ro = oracle.ransac(q, u, a, ak, False, 9, 0.004, oracle.sample_indices(len(q), 9, 11), depth_mode=0)
+    inl_o, v_o, flipped_o = oracle.canonicalize_sign(ro["inliers"], ro["v"])
+    dm_o, _, _ = oracle.scatter_depth(inl_o, *K, rows, cols)
+    r = [np.load(os.path.join(str(tmp_path), "frame%d.npz" % i)) for i in range(2)]
+    for i in range(2):
+        assert int(r[i]["n"]) == len(q) and int(r[i]["m"]) == ro["num_inliers"] and int(r[i]["best"]) == ro["best_trial"]
+        assert np.array_equal(r[i]["tc"], ro["trial_count"]) and np.allclose(r[i]["te"], ro["trial_err"], rtol=1e-12)
+        assert bool(r[i]["flipped"]) == flipped_o
+        assert np.array_equal(r[i]["v"], v_o) and np.array_equal(r[i]["w"], ro["w"]) and float(r[i]["k"]) == ro["k"]
+        # every rank ends with the full, identical map (column-major [cols][rows])
+        assert np.array_equal(r[i]["depth"].reshape(cols, rows).T, dm_o)
+    # the ranks' inliers concatenate (rank order) to the oracle's inlier list
+    assert np.array_equal(np.concatenate([r[0]["inl"], r[1]["inl"]]).reshape(-1, 3), inl_o)

@@ -10,16 +10,19 @@ def _run(rsdsfm, torch, d, v, w, k, nshards, mode):
     dev = torch.device("cuda", 0)
     n = len(d["alpha"])
     bounds, per = rsdsfm.dist.shard_bounds(n, nshards)
-    solvers = [rsdsfm.Solver(0) for _ in range(nshards)]
-    stages = []
-    for s, (i0, i1) in zip(solvers, bounds):
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a[i0:i1])).to(dev)
-        stages.append(rsdsfm.dist.HipDepthStage(s, t(d["q"]), t(d["u"]), t(d["alpha"]), t(d["alpha_k"]), v, w, k, torch))
-    drv = rsdsfm.dist.TiledDepthSolve(stages, n, per, torch, None)
-    rho, sm = drv.solve(mode)
-    for s in solvers:
-        s.synchronize()
-    out = rho.cpu().numpy()
+    # the contexts share torch's (non-default) current stream, so the driver's torch ops and the stage kernels are ordered
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        solvers = [rsdsfm.Solver(0, stream=stream.cuda_stream) for _ in range(nshards)]
+        stages = []
+        for s, (i0, i1) in zip(solvers, bounds):
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a[i0:i1])).to(dev)
+            stages.append(rsdsfm.dist.HipDepthStage(s, t(d["q"]), t(d["u"]), t(d["alpha"]), t(d["alpha_k"]), v, w, k, torch))
+        drv = rsdsfm.dist.TiledDepthSolve(stages, n, per, torch, None)
+        rho, sm = drv.solve(mode)
+        for s in solvers:
+            s.synchronize()
+        out = rho.cpu().numpy()
     for s in solvers:
         s.close()
     return out, sm

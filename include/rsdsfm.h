@@ -46,6 +46,15 @@ extern "C" {
 #define RSDSFM_FLOW_COMPAT_RANK 0
 #define RSDSFM_FLOW_GATHERED 1
 
+/* mode of rsdsfm_back_project: per-scanline relative poses (RsFrame::backProject, rsframe.cc:803) or the pose of
+ * scanline 0 for every pixel (RsFrame::backProjectGs, rsframe.cc:842) */
+#define RSDSFM_BACKPROJECT_RS 0
+#define RSDSFM_BACKPROJECT_GS 1
+
+/* q5_mode of rsdsfm_back_project (reference quirk Q5: spaceToPlane scales the y coordinate by f_x, rsframe.cc:639) */
+#define RSDSFM_Q5_COMPAT 0
+#define RSDSFM_Q5_FIXED 1
+
 /* termination of the emulated Ceres trust-region loop */
 #define RSDSFM_TERM_GRADIENT 0
 #define RSDSFM_TERM_PARAMETER 1
@@ -312,6 +321,32 @@ int rsdsfm_tile_depth_map_dev(rsdsfm_ctx* ctx, double* d_inl3m, int64_t m_shard,
                               int64_t m_total, double v_inout[3], double fx, double fy, double cx, double cy, int32_t rows,
                               int32_t col0, int32_t slab_cols, double* d_depth_slab, int32_t* d_xs_or_null,
                               int32_t* d_ys_or_null, int* flipped);
+
+/* ---- consumers of the solve's output ----------------------------------------------------------
+ * Images are 8-bit BGR, row-major rows x cols x 3 (cv::Mat CV_8UC3 as the reference holds them); the depth map is the
+ * column-major rows x cols array of rsdsfm_depth_map; R / t the per-scanline table of rsdsfm_pose_table. */
+/* RsFrame::backProject / backProjectGs (rsframe.cc:803-878): forward splat of the rolling-shutter image into the
+ * global-shutter image; pixels of colour (1,1,1) are skipped; of several source pixels hitting one target the one
+ * latest in the reference's scan (y outer, x inner) wins.  coords3d (may be NULL): rows x cols x 3 floats, world
+ * point of every processed pixel (RsFrame::get3dCoordinates), 0 for skipped pixels. */
+int rsdsfm_back_project(rsdsfm_ctx* ctx, const uint8_t* image_bgr, const double* depth_map_colmajor, const double* R_rows9,
+                        const double* t_rows3, double fx, double fy, double cx, double cy, int32_t rows, int32_t cols,
+                        int mode, int q5_mode, uint8_t* gs_image_bgr, float* coords3d_or_null);
+int rsdsfm_back_project_dev(rsdsfm_ctx* ctx, const uint8_t* d_image_bgr, const double* d_depth_map_colmajor,
+                            const double* d_R_rows9, const double* d_t_rows3, double fx, double fy, double cx, double cy,
+                            int32_t rows, int32_t cols, int mode, int q5_mode, uint8_t* d_gs_image_bgr,
+                            float* d_coords3d_or_null);
+/* Camera::interpolateCrackyImage (camera.cc:753-774; main.cc:523 calls it with offset 1).  in and out must not alias. */
+int rsdsfm_interpolate_cracky(rsdsfm_ctx* ctx, const uint8_t* image_in_bgr, int32_t rows, int32_t cols, int32_t offset,
+                              uint8_t* image_out_bgr);
+int rsdsfm_interpolate_cracky_dev(rsdsfm_ctx* ctx, const uint8_t* d_image_in_bgr, int32_t rows, int32_t cols, int32_t offset,
+                                  uint8_t* d_image_out_bgr);
+/* the 8-bit depth image of evaluateSingleRun (main.cc:480-509): depth_est(y, x) = 10 + int((z - z_min) * 244 /
+ * (z_max - z_min)), row-major rows x cols, 0 where no inlier lands; inliers = 3 x m (x, y, z) AFTER the sign fix. */
+int rsdsfm_depth_preview(rsdsfm_ctx* ctx, const double* inliers3m, int64_t m, double fx, double fy, double cx, double cy,
+                         int32_t rows, int32_t cols, uint8_t* depth_est);
+int rsdsfm_depth_preview_dev(rsdsfm_ctx* ctx, const double* d_inliers3m, int64_t m, double fx, double fy, double cx, double cy,
+                             int32_t rows, int32_t cols, uint8_t* d_depth_est);
 
 #ifdef __cplusplus
 }

@@ -252,3 +252,32 @@ def eig_sym3(S):
     lam, V = np.empty(3), np.empty((3, 3))
     lib().rso_eig_sym3(_p(S), _p(lam), _p(V))
     return lam, V
+
+
+def depth_preview(inliers, fx, fy, cx, cy, rows, cols):
+    inliers = _f64(inliers)
+    out = np.zeros((rows, cols), dtype=np.uint8)
+    d = C.c_double
+    lib().rso_depth_preview(_p(inliers), C.c_int64(inliers.shape[0]), d(fx), d(fy), d(cx), d(cy), C.c_int32(rows), C.c_int32(cols), _p(out))
+    return out
+
+
+def back_project(image_bgr, depth_map, R, t, fx, fy, cx, cy, mode=0, q5_mode=0, want_coords=True):
+    """depth_map: (rows, cols) array (as scatter_depth returns it); R: (rows, 3, 3) / (rows, 9); t: (rows, 3)"""
+    img = np.ascontiguousarray(image_bgr, dtype=np.uint8)
+    rows, cols = img.shape[:2]
+    dm = np.ascontiguousarray(np.asarray(depth_map, dtype=np.float64).T)  # column-major rows x cols
+    R, t = _f64(np.asarray(R).reshape(rows, 9)), _f64(t)
+    gs = np.zeros_like(img)
+    c3 = np.zeros((rows, cols, 3), dtype=np.float32) if want_coords else None
+    d = C.c_double
+    lib().rso_back_project(_p(img), _p(dm), _p(R), _p(t), d(fx), d(fy), d(cx), d(cy), C.c_int32(rows), C.c_int32(cols), int(mode), int(q5_mode), _p(gs), None if c3 is None else _p(c3))
+    return gs, c3
+
+
+def interpolate_cracky(image_bgr, offset=1):
+    img = np.ascontiguousarray(image_bgr, dtype=np.uint8)
+    rows, cols = img.shape[:2]
+    out = np.zeros_like(img)
+    lib().rso_interpolate_cracky(_p(img), C.c_int32(rows), C.c_int32(cols), C.c_int32(offset), _p(out))
+    return out

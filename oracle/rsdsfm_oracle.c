@@ -1350,3 +1350,119 @@ void rso_pose_table(const double v[3], const double w[3], double k, double gamma
         t[(int64_t)i * 3 + 2] = 0.0 + beta_1 * v[2];
     }
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* depth preview, RS -> GS back projection, crack interpolation                      */
+/* ------------------------------------------------------------------------------------------------ */
+/* double -> int like the reference's int(x) on x86-64 (cvttsd2si): truncation; non-finite / out of range -> INT_MIN */
+static int rso_trunc_int(double x) {
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return INT32_MIN;
+    return (int)x;
+}
+
+void rso_depth_preview(const double* inl, int64_t m, double fx, double fy, double cx, double cy, int32_t rows,
+                       int32_t cols, uint8_t* out) {
+    memset(out, 0, (size_t)rows * (size_t)cols);
+    double z_min = INFINITY, z_max = 0; /* main.cc:481-482 */
+    for (int64_t i = 0; i < m; ++i) {
+        if (inl[3 * i + 2] < z_min) z_min = inl[3 * i + 2];
+        if (inl[3 * i + 2] > z_max) z_max = inl[3 * i + 2];
+    }
+    const int min_z_value = 10;
+    double multiplier = 244.0 / (z_max - z_min);
+    for (int64_t i = 0; i < m; ++i) {
+        int x = (int)(fx * inl[3 * i] + cx + 0.5);
+        int y = (int)(fy * inl[3 * i + 1] + cy + 0.5);
+        double sc = (inl[3 * i + 2] - z_min) * multiplier;
+        int zi = rso_trunc_int(sc);
+        if (zi == INT32_MIN) zi = 0;
+        int z = min_z_value + zi;
+        if (x >= 0 && x < cols && y >= 0 && y < rows) out[(int64_t)y * cols + x] = (uint8_t)z; /* int -> uchar: mod 256 */
+    }
+}
+
+void rso_back_project(const uint8_t* img, const double* depth, const double* R, const double* t, double fx, double fy,
+                      double cx, double cy, int32_t rows, int32_t cols, int mode, int q5_mode, uint8_t* gs, float* c3d) {
+    memset(gs, 0, (size_t)rows * (size_t)cols * 3); /* gs_image *= 0 */
+    if (c3d) memset(c3d, 0, sizeof(float) * (size_t)rows * (size_t)cols * 3);
+    const double fyp = q5_mode == 0 ? fx : fy; /* Q5: spaceToPlane uses f_x_ for y (rsframe.cc:639) */
+    const double* R0 = R;
+    const double* t0 = t;
+    for (int32_t y = 0; y < rows; ++y) {
+        const double* Rs = mode == 0 ? R + (int64_t)y * 9 : R0;
+        const double* ts = mode == 0 ? t + (int64_t)y * 3 : t0;
+        for (int32_t x = 0; x < cols; ++x) {
+            const uint8_t* px = img + ((int64_t)y * cols + x) * 3;
+            if (px[0] == 1 && px[1] == 1 && px[2] == 1) continue;
+            /* planeToSpace(Vector2d(x, y)) */
+            double nx = ((double)x - cx) * 1.0 / fx;
+            double ny = ((double)y - cy) * 1.0 / fy;
+            double z = depth[(int64_t)x * rows + y];
+            double pc[3] = {z * nx, z * ny, z * 1.0};
+            /* cameraToWorldFrame: P^-1 = [R^T, -R^T t; 0 1], product evaluated left to right */
+            double pw[3];
+            for (int i = 0; i < 3; ++i) {
+                double rt0 = Rs[0 * 3 + i], rt1 = Rs[1 * 3 + i], rt2 = Rs[2 * 3 + i]; /* row i of R^T */
+                double ti = ((-rt0) * ts[0] + (-rt1) * ts[1]) + (-rt2) * ts[2];
+                pw[i] = ((rt0 * pc[0] + rt1 * pc[1]) + rt2 * pc[2]) + ti * 1.0;
+            }
+            /* worldToCameraFrame(., 0): P = [R0 t0; 0 1] */
+            double pg[3];
+            for (int i = 0; i < 3; ++i)
+                pg[i] = ((R0[i * 3 + 0] * pw[0] + R0[i * 3 + 1] * pw[1]) + R0[i * 3 + 2] * pw[2]) + t0[i] * 1.0;
+            /* spaceToPlane */
+            double gx = pg[0] / pg[2] * fx + cx;
+            double gy = pg[1] / pg[2] * fyp + cy;
+            if (c3d) {
+                float* c = c3d + ((int64_t)y * cols + x) * 3;
+                c[0] = (float)pw[0];
+                c[1] = (float)pw[1];
+                c[2] = (float)pw[2];
+            }
+            int ix = rso_trunc_int(gx + 0.5), iy = rso_trunc_int(gy + 0.5);
+            if (ix >= 0 && ix < cols && iy >= 0 && iy < rows) {
+                uint8_t* o = gs + ((int64_t)iy * cols + ix) * 3;
+                o[0] = px[0];
+                o[1] = px[1];
+                o[2] = px[2];
+            }
+        }
+    }
+}
+
+static int rso_is_black(const uint8_t* p, unsigned threshold) { /* cv::norm(Vec3b) <= threshold (camera.cc:694) */
+    double n = sqrt((double)p[0] * p[0] + (double)p[1] * p[1] + (double)p[2] * p[2]);
+    return n <= (double)threshold;
+}
+static uint8_t rso_saturate_u8(double v) { /* cv::saturate_cast<uchar>(double): cvRound (nearest even), then clamp */
+    long r = lrint(v);
+    return (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+}
+
+void rso_interpolate_cracky(const uint8_t* in, int32_t rows, int32_t cols, int32_t offset, uint8_t* out) {
+    memcpy(out, in, (size_t)rows * (size_t)cols * 3);
+    const unsigned thr = 15;
+    for (int32_t row = offset; row < rows - offset; ++row) {
+        for (int32_t col = offset; col < cols - offset; ++col) {
+            const uint8_t* p = in + ((int64_t)row * cols + col) * 3;
+            if (!rso_is_black(p, thr)) continue;
+            const uint8_t* nb[4] = {in + ((int64_t)(row - offset) * cols + col) * 3, in + ((int64_t)(row + offset) * cols + col) * 3,
+                                    in + ((int64_t)row * cols + (col - offset)) * 3, in + ((int64_t)row * cols + (col + offset)) * 3};
+            double sum[3] = {0, 0, 0};
+            unsigned count = 0;
+            for (int j = 0; j < 4; ++j)
+                if (!rso_is_black(nb[j], thr)) {
+                    sum[0] += (double)nb[j][0];
+                    sum[1] += (double)nb[j][1];
+                    sum[2] += (double)nb[j][2];
+                    count++;
+                }
+            if (count == 0) continue; /* not a colourful area (camera.cc:764) */
+            uint8_t* o = out + ((int64_t)row * cols + col) * 3;
+            double inv = 1 / (double)count;
+            o[0] = rso_saturate_u8(inv * sum[0]);
+            o[1] = rso_saturate_u8(inv * sum[1]);
+            o[2] = rso_saturate_u8(inv * sum[2]);
+        }
+    }
+}

@@ -127,6 +127,35 @@ void rso_scatter_depth(const double* inliers_3m, int64_t m, double fx, double fy
 void rso_pose_table(const double v[3], const double w[3], double k, double gamma, int32_t rows,
                     double* R_rows9, double* t_rows3);
 
+/* ---- RS -> GS rectifier and the 8-bit depth preview ---------------------------------- */
+/* main.cc:480-509: 8-bit depth image.  z_min = +inf, z_max = 0 over the inliers; multiplier = 244/(z_max - z_min);
+ * depth_est(y, x) = (uchar)(10 + int((z - z_min) * multiplier)), sequential (last writer wins), row-major
+ * rows x cols, zero elsewhere.  Out-of-image points are skipped (the reference would write out of bounds); a
+ * non-finite product (z_max == z_min) is defined as 0 here (the reference's int(NaN) is undefined behaviour). */
+void rso_depth_preview(const double* inliers_3m, int64_t m, double fx, double fy, double cx, double cy, int32_t rows,
+                       int32_t cols, uint8_t* depth_est_rowmajor);
+
+/* RsFrame::backProject (rsframe.cc:803-839; mode 0) / backProjectGs (rsframe.cc:842-878; mode 1):
+ * every pixel (x, y) of the BGR rolling-shutter image that is not the marker colour (1,1,1) is lifted with the depth
+ * map (planeToSpace rsframe.cc:644-664), moved to the world frame with the relative pose of ITS scanline y (mode 0) or of
+ * scanline 0 (mode 1) (cameraToWorldFrame rsframe.cc:712-736), brought back with the pose of scanline 0
+ * (worldToCameraFrame rsframe.cc:687-709) and projected (spaceToPlane rsframe.cc:628-641); the pixel is copied to
+ * gs(int(py+.5), int(px+.5)) when that lies in the image.  Sequential scan (y outer, x inner): the LAST writer wins.
+ * q5_mode 0 = compat (spaceToPlane multiplies the y coordinate by f_x, quirk Q5), 1 = fixed (f_y).
+ * coords3d (may be NULL): rows x cols x 3 floats, the world point of every processed pixel, 0 for skipped pixels (the
+ * reference leaves those uninitialised).  depth_map is column-major rows x cols; R/t the per-scanline pose table.
+ * The 4x4 homogeneous products are evaluated left to right (Eigen's coefficient-based product order, unverifiable
+ * here); a non-finite or out-of-int-range projection counts as outside the image (x86 cvttsd2si semantics). */
+void rso_back_project(const uint8_t* image_bgr, const double* depth_map_colmajor, const double* R_rows9,
+                      const double* t_rows3, double fx, double fy, double cx, double cy, int32_t rows, int32_t cols,
+                      int mode, int q5_mode, uint8_t* gs_image_bgr, float* coords3d_or_null);
+
+/* Camera::interpolateCrackyImage (camera.cc:694-774): every black pixel (||bgr||_2 <= 15) in [offset, rows-offset) x
+ * [offset, cols-offset) that has a non-black neighbour at distance `offset` (above, below, left, right) becomes the
+ * average of its non-black neighbours, rounded to nearest-even and saturated (cv::saturate_cast<uchar>(double)). */
+void rso_interpolate_cracky(const uint8_t* image_in_bgr, int32_t rows, int32_t cols, int32_t offset,
+                            uint8_t* image_out_bgr);
+
 /* exposed for direct testing of the restated third-party pieces */
 void rso_jacobi_svd9(const double Z_rowmajor[81], double sv[9], double V_rowmajor[81]);
 int rso_eigvals_general(const double* A_rowmajor, int n, double* re, double* im);

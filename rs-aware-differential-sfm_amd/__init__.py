@@ -470,3 +470,54 @@ class _TileMixin:
 for _name, _fn in list(vars(_TileMixin).items()):
     if not _name.startswith("__"):
         setattr(Solver, _name, _fn)
+
+
+# ---------------------------------------------------------------------------------------------------
+# consumers of the solve's output: back projection, crack interpolation, 8-bit depth image
+# ---------------------------------------------------------------------------------------------------
+BACKPROJECT_RS, BACKPROJECT_GS = 0, 1
+Q5_COMPAT, Q5_FIXED = 0, 1
+
+
+class _RectifyMixin:
+    def back_project(self, image_bgr, depth_map, R, t, K, mode=BACKPROJECT_RS, q5_mode=Q5_COMPAT, want_coords=True):
+        """RsFrame::backProject / backProjectGs.  depth_map: (rows, cols) array; R: (rows, 3, 3) or (rows, 9); t: (rows, 3)."""
+        img = np.ascontiguousarray(image_bgr, dtype=np.uint8)
+        rows, cols = img.shape[:2]
+        dm = np.ascontiguousarray(np.asarray(depth_map, dtype=np.float64).T)  # column-major rows x cols
+        Rr, tt = _f64(np.asarray(R).reshape(rows, 9)), _f64(t)
+        gs = np.zeros_like(img)
+        c3 = np.zeros((rows, cols, 3), dtype=np.float32) if want_coords else None
+        d = C.c_double
+        self._check(self.lib.rsdsfm_back_project(self._ctx, _p(img), _p(dm), _p(Rr), _p(tt), d(K[0]), d(K[1]), d(K[2]), d(K[3]), C.c_int32(rows), C.c_int32(cols), int(mode), int(q5_mode), _p(gs), _p(c3)), "rsdsfm_back_project")
+        return gs, c3
+
+    def back_project_dev(self, d_img, d_depth_map, d_R, d_t, K, rows, cols, d_gs, d_coords=None, mode=BACKPROJECT_RS, q5_mode=Q5_COMPAT):
+        d = C.c_double
+        self._check(self.lib.rsdsfm_back_project_dev(self._ctx, _dp(d_img), _dp(d_depth_map), _dp(d_R), _dp(d_t), d(K[0]), d(K[1]), d(K[2]), d(K[3]), C.c_int32(rows), C.c_int32(cols), int(mode), int(q5_mode), _dp(d_gs), _dp(d_coords) if d_coords else None), "rsdsfm_back_project_dev")
+
+    def interpolate_cracky(self, image_bgr, offset=1):
+        img = np.ascontiguousarray(image_bgr, dtype=np.uint8)
+        rows, cols = img.shape[:2]
+        out = np.zeros_like(img)
+        self._check(self.lib.rsdsfm_interpolate_cracky(self._ctx, _p(img), C.c_int32(rows), C.c_int32(cols), C.c_int32(offset), _p(out)), "rsdsfm_interpolate_cracky")
+        return out
+
+    def interpolate_cracky_dev(self, d_in, rows, cols, d_out, offset=1):
+        self._check(self.lib.rsdsfm_interpolate_cracky_dev(self._ctx, _dp(d_in), C.c_int32(rows), C.c_int32(cols), C.c_int32(offset), _dp(d_out)), "rsdsfm_interpolate_cracky_dev")
+
+    def depth_preview(self, inliers, K, rows, cols):
+        inl = _f64(inliers).reshape(-1, 3)
+        out = np.zeros((rows, cols), dtype=np.uint8)
+        d = C.c_double
+        self._check(self.lib.rsdsfm_depth_preview(self._ctx, _p(inl), C.c_int64(inl.shape[0]), d(K[0]), d(K[1]), d(K[2]), d(K[3]), C.c_int32(rows), C.c_int32(cols), _p(out)), "rsdsfm_depth_preview")
+        return out
+
+    def depth_preview_dev(self, d_inl, m, K, rows, cols, d_out):
+        d = C.c_double
+        self._check(self.lib.rsdsfm_depth_preview_dev(self._ctx, _np0(d_inl), C.c_int64(m), d(K[0]), d(K[1]), d(K[2]), d(K[3]), C.c_int32(rows), C.c_int32(cols), _dp(d_out)), "rsdsfm_depth_preview_dev")
+
+
+for _name, _fn in list(vars(_RectifyMixin).items()):
+    if not _name.startswith("__"):
+        setattr(Solver, _name, _fn)

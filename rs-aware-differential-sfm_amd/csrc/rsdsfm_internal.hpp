@@ -239,6 +239,16 @@ int refine_stage_rows_launch(Ctx* c, const RefineBuffers& B, int np, int stage, 
 int refine_stage_apply_launch(Ctx* c, const RefineBuffers& B, int np, int stage, const double* rows_all, int nranks, int64_t m_total);
 }  // namespace rsdsfm
 
+namespace rsdsfm {
+// rectify_kernels.hip
+int back_project_launch(Ctx* c, const unsigned char* d_img, const double* d_depth_cm, const double* d_R, const double* d_t, double fx,
+                        double fy, double cx, double cy, int rows, int cols, int mode, int q5_mode, unsigned char* d_gs, float* d_c3d,
+                        int* d_owner);
+int interpolate_cracky_launch(Ctx* c, const unsigned char* d_in, int rows, int cols, int offset, unsigned char* d_out);
+int depth_preview_launch(Ctx* c, const double* d_inl, int64_t m, double fx, double fy, double cx, double cy, int rows, int cols,
+                         unsigned char* d_out, double* d_partials, double* d_header, int* d_owner);
+}  // namespace rsdsfm
+
 // the opaque handle of the C ABI
 struct rsdsfm_ctx {
     rsdsfm::Ctx c;

@@ -20,6 +20,11 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_rectify():
+    return np.load(os.path.join(ROOT, "tests", "golden", "golden_rectify_v1.npz"))
+
+
+@pytest.fixture(scope="session")
 def oracle():
     import oracle_py
 
@@ -35,3 +40,4 @@ def rsdsfm():
 
 
 GOLDEN_CASES = ["clean_k0", "noisy_k0", "deepflow_k0", "clean_k04", "noisy_k04"]
+RECTIFY_CASES = ["k0", "k04"]

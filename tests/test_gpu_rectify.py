@@ -1,0 +1,141 @@
+"""GPU: RS -> GS back projection, crack interpolation and 8-bit depth image through the C ABI against
+the oracle and the committed fixtures.  Everything here is byte / index work: bit-exact, including the float32 world
+points (same per-pixel operation chain, no contraction)."""
+import numpy as np
+import pytest
+
+from conftest import RECTIFY_CASES
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(rsdsfm, oracle, rows, cols, seed, k=0.0, cfg=1):
+    d = rsdsfm.synth.make_config(cfg, rows=rows, cols=cols, k=k)
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, size=(rows, cols, 3), dtype=np.uint8)
+    img[rng.random((rows, cols)) < 0.05] = (2, 3, 1)
+    img[rng.random((rows, cols)) < 0.01] = (1, 1, 1)
+    depth = np.array(d["truth"]["Z"])
+    depth[rng.random((rows, cols)) < 0.07] = 0.0
+    v, w = np.array([0.12, 0.10, 0.05]), np.array([0.03, -0.02, 0.06])
+    R, t = oracle.pose_table(v, w, k, d["gamma"], rows)
+    return d, img, depth, R, t
+
+
+@pytest.mark.parametrize("case", RECTIFY_CASES)
+def test_rectify_matches_golden(golden_rectify, rsdsfm, case):
+    g = lambda k: golden_rectify[case + "/" + k]
+    K = tuple(g("K"))
+    rows, cols = g("depth").shape
+    with rsdsfm.Solver(0) as s:
+        for mode in (0, 1):
+            for q5 in (0, 1):
+                gs, c3 = s.back_project(g("image"), g("depth"), g("R"), g("t"), K, mode=mode, q5_mode=q5)
+                assert np.array_equal(gs, g("gs_m%d_q%d" % (mode, q5)))
+                assert np.allclose(c3, g("c3_m%d" % mode), rtol=2e-6, atol=1e-7)
+        for off in (1, 2):
+            assert np.array_equal(s.interpolate_cracky(g("gs_m0_q0"), off), g("interp_off%d" % off))
+        assert np.array_equal(s.depth_preview(g("inliers"), K, rows, cols), g("preview"))
+
+
+@pytest.mark.parametrize("rows,cols,k", [(1, 1, 0.0), (7, 5, 0.0), (64, 32, 0.0), (65, 33, 0.4), (131, 257, 0.0), (720, 1280, 0.4)])
+def test_back_project_equals_oracle(oracle, rsdsfm, rows, cols, k):
+    """ragged tile edges (tiles are 32 x 64), a single pixel, and BASELINE's 1280x720"""
+    d, img, depth, R, t = _scene(rsdsfm, oracle, rows, cols, seed=rows * 1000 + cols, k=k)
+    K = d["K"]
+    with rsdsfm.Solver(0) as s:
+        for mode, q5 in ((0, 0), (0, 1), (1, 0)):
+            gs, c3 = s.back_project(img, depth, R, t, K, mode=mode, q5_mode=q5)
+            gs_o, c3_o = oracle.back_project(img, depth, R, t, *K, mode=mode, q5_mode=q5)
+            assert np.array_equal(gs, gs_o), (mode, q5)
+            assert np.array_equal(c3.view(np.uint32), c3_o.view(np.uint32)), (mode, q5)
+        gs2, none = s.back_project(img, depth, R, t, K, want_coords=False)
+        assert none is None and np.array_equal(gs2, oracle.back_project(img, depth, R, t, *K)[0])
+
+
+def test_back_project_collisions_last_writer_wins(oracle, rsdsfm):
+    """a strong forward motion squeezes many source pixels onto few targets: the winner must be the pixel latest in the
+    reference's scan for every target, independent of the GPU's execution order (integer atomicMax)"""
+    rows, cols = 300, 400
+    d, img, depth, _, _ = _scene(rsdsfm, oracle, rows, cols, seed=5)
+    K = d["K"]
+    R, t = oracle.pose_table(np.array([0.0, 0.0, -3.0]), np.array([0.2, 0.1, 0.3]), 0.0, d["gamma"], rows)
+    with rsdsfm.Solver(0) as s:
+        outs = [s.back_project(img, np.abs(depth) + 1.0, R, t, K, want_coords=False)[0] for _ in range(3)]
+    exp = oracle.back_project(img, np.abs(depth) + 1.0, R, t, *K, want_coords=False)[0]
+    covered = (exp.reshape(-1, 3).sum(axis=1) != 0).mean()
+    assert covered < 0.9  # many collisions / cracks
+    for o in outs:
+        assert np.array_equal(o, exp)
+
+
+@pytest.mark.parametrize("rows,cols,off", [(3, 3, 1), (40, 61, 1), (40, 61, 3), (5, 4, 2), (720, 1280, 1)])
+def test_interpolate_equals_oracle(oracle, rsdsfm, rows, cols, off):
+    rng = np.random.default_rng(rows + cols + off)
+    img = rng.integers(0, 256, size=(rows, cols, 3), dtype=np.uint8)
+    img[rng.random((rows, cols)) < 0.4] = rng.integers(0, 10, size=3, dtype=np.uint8)  # many black pixels, runs of them
+    with rsdsfm.Solver(0) as s:
+        assert np.array_equal(s.interpolate_cracky(img, off), oracle.interpolate_cracky(img, off))
+
+
+def test_preview_equals_oracle_and_device_chain(oracle, rsdsfm):
+    """host API on random inliers (collisions, out-of-image points, negative depths), then the device chain
+    solve_frame_dev -> depth_preview_dev / back_project_dev / interpolate_cracky_dev on buffers that never leave HBM"""
+    import torch
+
+    rng = np.random.default_rng(1)
+    K = (300.0, 310.0, 100.0, 75.0)
+    rows, cols = 150, 200
+    inl = np.column_stack([rng.uniform(-0.4, 0.4, 30000), rng.uniform(-0.3, 0.3, 30000), rng.normal(2.0, 1.5, 30000)])
+    with rsdsfm.Solver(0) as s:
+        assert np.array_equal(s.depth_preview(inl, K, rows, cols), oracle.depth_preview(inl, *K, rows, cols))
+        assert np.array_equal(s.depth_preview(inl[:1], K, rows, cols), oracle.depth_preview(inl[:1], *K, rows, cols))
+        assert np.array_equal(s.depth_preview(np.zeros((0, 3)), K, rows, cols), np.zeros((rows, cols), dtype=np.uint8))
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        d = rsdsfm.synth.make_config(3, rows=144, cols=256)
+        rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+        img = rng.integers(16, 256, size=(rows, cols, 3), dtype=np.uint8)
+        t_img = torch.from_numpy(img).to(dev)
+        flow = torch.from_numpy(d["flow_img"]).to(dev)
+        dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+        R = torch.empty((rows, 9), dtype=torch.float64, device=dev)
+        t = torch.empty((rows, 3), dtype=torch.float64, device=dev)
+        gs = torch.empty((rows, cols, 3), dtype=torch.uint8, device=dev)
+        fixed = torch.empty_like(gs)
+        c3 = torch.empty((rows, cols, 3), dtype=torch.float32, device=dev)
+        prev = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
+        with rsdsfm.Solver(0, stream=stream.cuda_stream) as s:
+            r = s.solve_frame_dev(flow.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), trials=10, tol=0.002, seed=4)
+            s.depth_preview_dev(r["d_inliers"], r["num_inliers"], K, rows, cols, prev.data_ptr())
+            s.back_project_dev(t_img.data_ptr(), dm.data_ptr(), R.data_ptr(), t.data_ptr(), K, rows, cols, gs.data_ptr(), c3.data_ptr())
+            s.interpolate_cracky_dev(gs.data_ptr(), rows, cols, fixed.data_ptr(), offset=1)
+            s.synchronize()
+            m = r["num_inliers"]
+            inl_t = torch.empty(3 * m, dtype=torch.float64, device=dev)
+            import ctypes
+
+            hip = ctypes.CDLL("libamdhip64.so")
+            assert hip.hipMemcpy(ctypes.c_void_p(inl_t.data_ptr()), ctypes.c_void_p(r["d_inliers"]), ctypes.c_size_t(24 * m), 3) == 0
+            inl_h = inl_t.cpu().numpy().reshape(m, 3)
+        dm_h = dm.cpu().numpy().T
+        gs_o, c3_o = oracle.back_project(img, dm_h, R.cpu().numpy(), t.cpu().numpy(), *K)
+        assert np.array_equal(gs.cpu().numpy(), gs_o) and np.array_equal(c3.cpu().numpy().view(np.uint32), c3_o.view(np.uint32))
+        assert np.array_equal(fixed.cpu().numpy(), oracle.interpolate_cracky(gs_o, 1))
+        assert np.array_equal(prev.cpu().numpy(), oracle.depth_preview(inl_h, *K, rows, cols))
+        assert (prev.cpu().numpy() != 0).sum() == (dm_h != 0).sum()
+
+
+def test_rectify_argument_errors(rsdsfm):
+    img = np.zeros((4, 4, 3), dtype=np.uint8)
+    R, t = np.tile(np.eye(3).reshape(1, 9), (4, 1)), np.zeros((4, 3))
+    with rsdsfm.Solver(0) as s:
+        with pytest.raises(rsdsfm.RsdsfmError):
+            s.back_project(img, np.ones((4, 4)), R, t, (1.0, 1.0, 2.0, 2.0), mode=2)
+        with pytest.raises(rsdsfm.RsdsfmError):
+            s.back_project(img, np.ones((4, 4)), R, t, (1.0, 1.0, 2.0, 2.0), q5_mode=7)
+        with pytest.raises(rsdsfm.RsdsfmError):
+            s.interpolate_cracky(img, -1)
+        e = np.zeros((0, 5, 3), dtype=np.uint8)
+        assert s.interpolate_cracky(e, 1).shape == (0, 5, 3)

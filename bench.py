@@ -10,6 +10,8 @@ Contract: python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on
               full              : the whole solve is the timed step.
               tiled             : BASELINE configs[3]-style row tiling: a 3840x2160 frame sharded over the N ranks,
                                   LM sum rows + ONE all-gather of the depth map over RCCL (scaling "strong").
+              rectify           : SURVEY 8(f-1) consumers of the solve on a 1280x720 frame resident in HBM: RS -> GS back
+                                  projection (+ float3 world points), crack interpolation, 8-bit depth image.
               tiled_full        : the WHOLE solve of a 3840x2160 frame split into column slabs over the N ranks
                                   (rsdsfm_tile_* stages, dist.TiledFrameSolve; scaling "strong").
   N > 1     = one process per GPU (torch.distributed / RCCL).  depth / full: each rank solves its own frame pair
@@ -77,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full"])
+    ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nbuf", type=int, default=7, help="rotating HBM buffer sets (7 x 59 MB > 256 MiB L3)")
     ap.add_argument("--trials", type=int, default=50, help="RANSAC trials of the full solve (report section 5.4 used 50)")
@@ -226,6 +228,64 @@ def main():
                          "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_full(rsdsfm, args.trials, args.tol)})
 
     # =================================================================================================
+    elif args.workload == "rectify":
+        # main.cc:480-523 after the solve: 8-bit depth image, backProject, interpolateCrackyImage; one 1280x720 frame per GPU
+        data = rsdsfm.synth.make_config(2, seed=0x5EED0002 + rank)
+        rows, cols, K, gamma = data["rows"], data["cols"], data["K"], data["gamma"]
+        npix = rows * cols
+        t = data["truth"]
+        rng = np.random.default_rng(7 + rank)
+        img_h = rng.integers(16, 256, size=(rows, cols, 3), dtype=np.uint8)
+        depth_h = np.ascontiguousarray(np.array(t["Z"]).T)  # column-major rows x cols, every pixel an inlier
+        nbuf = args.nbuf
+        R = torch.empty((rows, 9), dtype=torch.float64, device=dev)
+        tt = torch.empty((rows, 3), dtype=torch.float64, device=dev)
+        solver.pose_table_dev(t["v"] * 3.0, t["w"] * 4.0, 0.0, gamma, rows, R.data_ptr(), tt.data_ptr())
+        inl_h = np.column_stack([data["q"], (np.array(t["Z"]).T.reshape(-1))])  # (x, y, z) in the flattened order
+        sets = [dict(img=torch.from_numpy(img_h).to(dev), depth=torch.from_numpy(depth_h).to(dev), inl=torch.from_numpy(inl_h).to(dev),
+                     gs=torch.empty((rows, cols, 3), dtype=torch.uint8, device=dev), fixed=torch.empty((rows, cols, 3), dtype=torch.uint8, device=dev),
+                     c3=torch.empty((rows, cols, 3), dtype=torch.float32, device=dev), prev=torch.empty((rows, cols), dtype=torch.uint8, device=dev))
+                for _ in range(nbuf)]
+
+        def bp(s):
+            solver.back_project_dev(s["img"].data_ptr(), s["depth"].data_ptr(), R.data_ptr(), tt.data_ptr(), K, rows, cols, s["gs"].data_ptr(), s["c3"].data_ptr())
+
+        def step(i):
+            s = sets[i % nbuf]
+            solver.depth_preview_dev(s["inl"].data_ptr(), npix, K, rows, cols, s["prev"].data_ptr())
+            bp(s)
+            solver.interpolate_cracky_dev(s["gs"].data_ptr(), rows, cols, s["fixed"].data_ptr(), offset=1)
+
+        el = timed(step, args.steps, args.warmup)
+        kern_ms = None
+        if rank == 0:
+            BURST, reps = 10, 20
+            ts = []
+            for i in range(reps):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                for b in range(BURST):
+                    bp(sets[(i * BURST + b) % nbuf])
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1) / BURST)
+            kern_ms = float(np.mean(ts))
+            alg = 26 * npix  # read 3 B image + 8 B depth, write 3 B image + 12 B world point
+            achieved = alg / (kern_ms * 1e-3) / 1e9
+            s = sets[(args.steps - 1) % nbuf]
+            covered = float((s["gs"].view(-1, 3).sum(dim=1) != 0).double().mean().item())
+            line.update({"value": npix * world * args.steps / el / 1e6, "ms_per_step": el / args.steps * 1e3, "scaling": "weak",
+                         "metric": "Mpixels/sec RS->GS rectification (depth image + back projection + crack interpolation), 1280x720 frame",
+                         "dtype": "u8/f64",
+                         "config": {"workload": "SURVEY 8(f-1): 8-bit depth image + backProject (with float3 world points) + interpolateCrackyImage of "
+                                                "a synthetic 1280x720 BGR frame, depth map and pose table resident in HBM; one frame per GPU",
+                                    "rows": rows, "cols": cols, "gs_coverage": covered},
+                         "roofline": {"bound": "hbm", "kernel": "back projection = 2 memsets + back_project_claim_kernel + back_project_write_kernel",
+                                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                      "traffic": _traffic("rectify"), "alg_bytes_per_launch": alg, "avg_launch_ms": kern_ms},
+                         "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_rectify(img_h, np.array(t["Z"]), R.cpu().numpy(), tt.cpu().numpy(), K, inl_h)})
+
+    # =================================================================================================
     elif args.workload == "tiled_full":
         # one 3840x2160 DeepFlow-like frame split into column slabs over the ranks: the WHOLE solve (flatten, RANSAC,
         # refinement, sign fix + depth map) through the rsdsfm_tile_* stage entry points; every rank holds only its slab
@@ -285,6 +345,27 @@ def main():
     solver.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def cpu_baseline_rectify(img, depth, R, t, K, inl, budget_s=8.0):
+    """the oracle's depth image + back projection + crack interpolation (scalar C, 1 thread) on the same frame"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+
+    O.lib()
+    rows, cols = img.shape[:2]
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        O.depth_preview(inl, *K, rows, cols)
+        gs, _ = O.back_project(img, depth, R, t, *K)
+        O.interpolate_cracky(gs, 1)
+        reps += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    el = time.perf_counter() - t0
+    return {"value": rows * cols * reps / el / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "port",
+            "sample": "%d whole 1280x720 frames (depth image + back projection + interpolation) in %.1f s" % (reps, el)}
 
 
 def _traffic(workload):

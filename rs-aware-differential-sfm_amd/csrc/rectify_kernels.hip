@@ -9,7 +9,7 @@
 //       gathers the winners.  Byte / index work, HBM-bound: 3 B image + 8 B depth read, 3 B + 12 B (world point as
 //       float3) written per pixel = 26 B/pixel algorithmic.
 //       The depth map arrives column-major (Eigen MatrixXd, what depth_write_kernel produces) while the image is
-//       row-major: each workgroup stages a 32 x 64 (x, y) tile of the depth map through LDS (coalesced along y),
+//       row-major: each workgroup stages a 64 x 16 (x, y) tile of the depth map through LDS (coalesced along y),
 //       then walks the tile along x (coalesced image reads / float3 writes).
 //   interpolate_cracky_kernel
 //       Camera::interpolateCrackyImage (camera.cc:694-774): 4-neighbour fill of black pixels.
@@ -30,8 +30,9 @@ namespace rsdsfm {
 
 namespace {
 
-constexpr int kTX = 32;  // tile width  (image columns)
-constexpr int kTY = 64;  // tile height (image rows = scanlines)
+constexpr int kTX = 64;  // tile width  (image columns) = one wave
+constexpr int kTY = 16;  // tile height (image rows = scanlines): 16 x 8 B = one 128-byte line of the column-major depth map per column
+constexpr int kCB = 512; // threads of the claim kernel: 8 waves x 2 scanlines
 constexpr int kBP = 256;
 
 // double -> int like the reference's int(x) on x86-64 (cvttsd2si): non-finite / out of range -> INT_MIN
@@ -40,10 +41,10 @@ __device__ __forceinline__ int trunc_int(double x) {
     return (int)x;
 }
 
-__device__ __forceinline__ bool is_black(unsigned b, unsigned g, unsigned r) {  // cv::norm(Vec3b) <= 15
-    const double n = sqrt((double)b * (double)b + (double)g * (double)g + (double)r * (double)r);
-    return n <= 15.0;
-}
+// cv::norm(Vec3b) <= 15 (camera.cc:694): sqrt(b^2 + g^2 + r^2) <= 15 in double.  The sum of squares is an integer
+// below 2^18 and sqrt is correctly rounded and monotone (sqrt(225) = 15 exactly, sqrt(226) > 15), so the comparison is
+// decided exactly by the integers.
+__device__ __forceinline__ bool is_black(unsigned b, unsigned g, unsigned r) { return b * b + g * g + r * r <= 225u; }
 
 __device__ __forceinline__ unsigned char saturate_u8(double v) {  // cvRound (nearest even) + clamp
     const long long r = __double2ll_rn(v);
@@ -52,50 +53,85 @@ __device__ __forceinline__ unsigned char saturate_u8(double v) {  // cvRound (ne
 
 }  // namespace
 
-// grid: (ceil(cols / kTX), ceil(rows / kTY)); owner: rows*cols int32 (pre-set to -1), row-major
-__global__ __launch_bounds__(kBP) void back_project_claim_kernel(const unsigned char* __restrict__ img,
+// grid: (ceil(cols / kTX), ceil(rows / kTY)); owner: rows*cols int32 (pre-set to -1), row-major.
+// A wave walks one scanline segment of 64 pixels at a time, so the scanline index is wave-uniform and its pose (12
+// doubles) comes through the scalar data path; every pixel of the image is visited exactly once, so the world point of
+// skipped (marker) pixels is zeroed here instead of by a separate memset.
+__global__ __launch_bounds__(kCB) void back_project_claim_kernel(const unsigned char* __restrict__ img,
                                                                 const double* __restrict__ depth_cm,
                                                                 const double* __restrict__ R, const double* __restrict__ t,
                                                                 double fx, double fy, double cx, double cy, double fyp, int rows,
                                                                 int cols, int mode, int* __restrict__ owner,
                                                                 float* __restrict__ c3d) {
+    constexpr int RPW = kTY / (kCB / kTX);  // scanlines per wave
     __shared__ double s_z[kTX][kTY + 1];
     const int x0 = blockIdx.x * kTX, y0 = blockIdx.y * kTY;
     const int tid = threadIdx.x;
-    // stage the depth tile: lanes run along y (contiguous in the column-major map)
-    {
-        const int ly = tid & (kTY - 1);
-        for (int lx = tid / kTY; lx < kTX; lx += kBP / kTY) {
-            const int x = x0 + lx, y = y0 + ly;
-            s_z[lx][ly] = (x < cols && y < rows) ? depth_cm[(int64_t)x * rows + y] : 0.0;
-        }
-    }
-    __syncthreads();
     const int lx = tid & (kTX - 1);
     const int x = x0 + lx;
+    const int wv = __builtin_amdgcn_readfirstlane(tid / kTX);
+    // everything this thread needs from global memory is requested up front, so the latencies overlap:
+    // (1) its share of the depth tile (lanes along y: contiguous in the column-major map)
+    double zst[kTX * kTY / kCB];
+    {
+        const int ly = tid & (kTY - 1);
+#pragma unroll
+        for (int j = 0; j < kTX * kTY / kCB; ++j) {
+            const int xx = x0 + tid / kTY + j * (kCB / kTY), yy = y0 + ly;
+            zst[j] = (xx < cols && yy < rows) ? depth_cm[(int64_t)xx * rows + yy] : 0.0;
+        }
+    }
+    // (2) the pixels of its scanlines, (3) their poses (wave-uniform -> scalar loads) and the pose of scanline 0
+    unsigned pb[RPW], pg_[RPW], pr[RPW];
+    double Rr[RPW][9], tr[RPW][3];
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int y = y0 + wv + j * (kCB / kTX);
+        const bool live = y < rows && x < cols;
+        const int64_t s = live ? (int64_t)y * cols + x : 0;
+        pb[j] = img[3 * s], pg_[j] = img[3 * s + 1], pr[j] = img[3 * s + 2];
+        const int ys = (mode == 0 && y < rows) ? y : 0;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rr[j][i] = R[(int64_t)ys * 9 + i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) tr[j][i] = t[(int64_t)ys * 3 + i];
+    }
+    double R0[9], t0[3];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R0[i] = R[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) t0[i] = t[i];
+    {
+        const int ly = tid & (kTY - 1);
+#pragma unroll
+        for (int j = 0; j < kTX * kTY / kCB; ++j) s_z[tid / kTY + j * (kCB / kTY)][ly] = zst[j];
+    }
+    __syncthreads();
     if (x >= cols) return;
     const double nx = ((double)x - cx) * 1.0 / fx;
-    for (int ly = tid / kTX; ly < kTY; ly += kBP / kTX) {
-        const int y = y0 + ly;
+#pragma unroll
+    for (int j = 0; j < RPW; ++j) {
+        const int ly = wv + j * (kCB / kTX);
+        const int y = y0 + ly;  // wave-uniform
         if (y >= rows) break;
         const int64_t s = (int64_t)y * cols + x;
-        const unsigned b = img[3 * s], g = img[3 * s + 1], r = img[3 * s + 2];
-        if (b == 1 && g == 1 && r == 1) continue;  // marker colour: pixel not processed (rsframe.cc:816)
-        const double* Rs = mode == 0 ? R + (int64_t)y * 9 : R;
-        const double* ts = mode == 0 ? t + (int64_t)y * 3 : t;
+        if (pb[j] == 1 && pg_[j] == 1 && pr[j] == 1) {  // marker colour: pixel not processed (rsframe.cc:816)
+            if (c3d) c3d[3 * s] = 0.0f, c3d[3 * s + 1] = 0.0f, c3d[3 * s + 2] = 0.0f;
+            continue;
+        }
         const double ny = ((double)y - cy) * 1.0 / fy;
         const double z = s_z[lx][ly];
         const double pc0 = z * nx, pc1 = z * ny, pc2 = z * 1.0;
         double pw[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const double rt0 = Rs[i], rt1 = Rs[3 + i], rt2 = Rs[6 + i];  // row i of R^T
-            const double ti = ((-rt0) * ts[0] + (-rt1) * ts[1]) + (-rt2) * ts[2];
+            const double rt0 = Rr[j][i], rt1 = Rr[j][3 + i], rt2 = Rr[j][6 + i];  // row i of R^T
+            const double ti = ((-rt0) * tr[j][0] + (-rt1) * tr[j][1]) + (-rt2) * tr[j][2];
             pw[i] = ((rt0 * pc0 + rt1 * pc1) + rt2 * pc2) + ti * 1.0;
         }
         double pg[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) pg[i] = ((R[i * 3] * pw[0] + R[i * 3 + 1] * pw[1]) + R[i * 3 + 2] * pw[2]) + t[i] * 1.0;
+        for (int i = 0; i < 3; ++i) pg[i] = ((R0[i * 3] * pw[0] + R0[i * 3 + 1] * pw[1]) + R0[i * 3 + 2] * pw[2]) + t0[i] * 1.0;
         const double gx = pg[0] / pg[2] * fx + cx;
         const double gy = pg[1] / pg[2] * fyp + cy;
         if (c3d) {
@@ -114,58 +150,86 @@ __global__ __launch_bounds__(kBP) void back_project_write_kernel(const unsigned 
                                                                 unsigned char* __restrict__ gs) {
     const int64_t stride = (int64_t)gridDim.x * kBP * 4;
     for (int64_t p0 = ((int64_t)blockIdx.x * kBP + threadIdx.x) * 4; p0 < npix; p0 += stride) {
-        unsigned char v[12];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int64_t p = p0 + j;
-            const int o = p < npix ? owner[p] : -1;
-            v[3 * j] = o >= 0 ? img[3 * (int64_t)o] : 0;
-            v[3 * j + 1] = o >= 0 ? img[3 * (int64_t)o + 1] : 0;
-            v[3 * j + 2] = o >= 0 ? img[3 * (int64_t)o + 2] : 0;
-        }
         if (p0 + 4 <= npix) {
+            const int4 o = *reinterpret_cast<const int4*>(owner + p0);  // p0 multiple of 4: 16-byte aligned
+            const int oo[4] = {o.x, o.y, o.z, o.w};
+            unsigned v[12];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t src = 3 * (int64_t)(oo[j] >= 0 ? oo[j] : 0);
+                const unsigned b = img[src], g = img[src + 1], r = img[src + 2];
+                v[3 * j] = oo[j] >= 0 ? b : 0u;
+                v[3 * j + 1] = oo[j] >= 0 ? g : 0u;
+                v[3 * j + 2] = oo[j] >= 0 ? r : 0u;
+            }
             unsigned* dst = reinterpret_cast<unsigned*>(gs + 3 * p0);  // 12 p0 bytes: 4-byte aligned
-            dst[0] = v[0] | (v[1] << 8) | (v[2] << 16) | ((unsigned)v[3] << 24);
-            dst[1] = v[4] | (v[5] << 8) | (v[6] << 16) | ((unsigned)v[7] << 24);
-            dst[2] = v[8] | (v[9] << 8) | (v[10] << 16) | ((unsigned)v[11] << 24);
+            dst[0] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+            dst[1] = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
+            dst[2] = v[8] | (v[9] << 8) | (v[10] << 16) | (v[11] << 24);
         } else {
-            for (int64_t p = p0; p < npix; ++p)
-                for (int c = 0; c < 3; ++c) gs[3 * p + c] = v[3 * (p - p0) + c];
+            for (int64_t p = p0; p < npix; ++p) {
+                const int o = owner[p];
+                gs[3 * p] = o >= 0 ? img[3 * (int64_t)o] : 0;
+                gs[3 * p + 1] = o >= 0 ? img[3 * (int64_t)o + 1] : 0;
+                gs[3 * p + 2] = o >= 0 ? img[3 * (int64_t)o + 2] : 0;
+            }
         }
     }
 }
 
+// one pixel of the stencil; (b, g, r) hold the pixel's own colour on entry and the result on exit
+__device__ __forceinline__ void interpolate_pixel(const unsigned char* __restrict__ in, int rows, int cols, int offset, int64_t p,
+                                                  unsigned& b, unsigned& g, unsigned& r) {
+    const int row = (int)(p / cols), col = (int)(p - (int64_t)row * cols);
+    if (!(row >= offset && row < rows - offset && col >= offset && col < cols - offset && is_black(b, g, r))) return;
+    const int64_t nb[4] = {p - (int64_t)offset * cols, p + (int64_t)offset * cols, p - offset, p + offset};
+    double s0 = 0, s1 = 0, s2 = 0;
+    unsigned count = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned nb0 = in[3 * nb[j]], nb1 = in[3 * nb[j] + 1], nb2 = in[3 * nb[j] + 2];
+        if (!is_black(nb0, nb1, nb2)) {
+            s0 += (double)nb0;
+            s1 += (double)nb1;
+            s2 += (double)nb2;
+            count++;
+        }
+    }
+    if (count > 0) {
+        const double inv = 1 / (double)count;
+        b = saturate_u8(inv * s0);
+        g = saturate_u8(inv * s1);
+        r = saturate_u8(inv * s2);
+    }
+}
+
+// 4 pixels (12 bytes = 3 dwords) per thread: most pixels are not black and are simply copied
 __global__ __launch_bounds__(kBP) void interpolate_cracky_kernel(const unsigned char* __restrict__ in, int rows, int cols,
                                                                 int offset, unsigned char* __restrict__ out) {
     const int64_t npix = (int64_t)rows * cols;
-    const int64_t stride = (int64_t)gridDim.x * kBP;
-    for (int64_t p = (int64_t)blockIdx.x * kBP + threadIdx.x; p < npix; p += stride) {
-        const int row = (int)(p / cols), col = (int)(p - (int64_t)row * cols);
-        unsigned b = in[3 * p], g = in[3 * p + 1], r = in[3 * p + 2];
-        if (row >= offset && row < rows - offset && col >= offset && col < cols - offset && is_black(b, g, r)) {
-            const int64_t nb[4] = {p - (int64_t)offset * cols, p + (int64_t)offset * cols, p - offset, p + offset};
-            double s0 = 0, s1 = 0, s2 = 0;
-            unsigned count = 0;
+    const int64_t stride = (int64_t)gridDim.x * kBP * 4;
+    for (int64_t p0 = ((int64_t)blockIdx.x * kBP + threadIdx.x) * 4; p0 < npix; p0 += stride) {
+        if (p0 + 4 <= npix) {
+            const unsigned* src = reinterpret_cast<const unsigned*>(in + 3 * p0);  // 12 p0 bytes: 4-byte aligned
+            unsigned w[3] = {src[0], src[1], src[2]};
+            unsigned v[12];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned nb0 = in[3 * nb[j]], nb1 = in[3 * nb[j] + 1], nb2 = in[3 * nb[j] + 2];
-                if (!is_black(nb0, nb1, nb2)) {
-                    s0 += (double)nb0;
-                    s1 += (double)nb1;
-                    s2 += (double)nb2;
-                    count++;
-                }
-            }
-            if (count > 0) {
-                const double inv = 1 / (double)count;
-                b = saturate_u8(inv * s0);
-                g = saturate_u8(inv * s1);
-                r = saturate_u8(inv * s2);
+            for (int j = 0; j < 12; ++j) v[j] = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) interpolate_pixel(in, rows, cols, offset, p0 + j, v[3 * j], v[3 * j + 1], v[3 * j + 2]);
+            unsigned* dst = reinterpret_cast<unsigned*>(out + 3 * p0);
+            dst[0] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+            dst[1] = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
+            dst[2] = v[8] | (v[9] << 8) | (v[10] << 16) | (v[11] << 24);
+        } else {
+            for (int64_t p = p0; p < npix; ++p) {
+                unsigned b = in[3 * p], g = in[3 * p + 1], r = in[3 * p + 2];
+                interpolate_pixel(in, rows, cols, offset, p, b, g, r);
+                out[3 * p] = (unsigned char)b;
+                out[3 * p + 1] = (unsigned char)g;
+                out[3 * p + 2] = (unsigned char)r;
             }
         }
-        out[3 * p] = (unsigned char)b;
-        out[3 * p + 1] = (unsigned char)g;
-        out[3 * p + 2] = (unsigned char)r;
     }
 }
 
@@ -200,52 +264,89 @@ __global__ __launch_bounds__(kBP) void preview_minmax_kernel(const double* __res
     }
 }
 
-// single workgroup: header[0] = z_min, header[1] = multiplier = 244 / (z_max - z_min)
+// single workgroup: header[0] = z_min, header[1] = multiplier = 244 / (z_max - z_min)   (min / max are exact in any order)
 __global__ __launch_bounds__(kBP) void preview_header_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ header) {
-    __shared__ double s_min[kBP], s_max[kBP];
+    __shared__ double s_min[kBP / 64], s_max[kBP / 64];
     double lo = INFINITY, hi = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += kBP) {
         if (partials[2 * b] < lo) lo = partials[2 * b];
         if (partials[2 * b + 1] > hi) hi = partials[2 * b + 1];
     }
-    s_min[threadIdx.x] = lo;
-    s_max[threadIdx.x] = hi;
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double ol = __shfl_xor(lo, off, 64), oh = __shfl_xor(hi, off, 64);
+        if (ol < lo) lo = ol;
+        if (oh > hi) hi = oh;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_min[threadIdx.x >> 6] = lo;
+        s_max[threadIdx.x >> 6] = hi;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int i = 1; i < kBP; ++i) {
-            if (s_min[i] < lo) lo = s_min[i];
-            if (s_max[i] > hi) hi = s_max[i];
+        for (int w2 = 1; w2 < kBP / 64; ++w2) {
+            if (s_min[w2] < lo) lo = s_min[w2];
+            if (s_max[w2] > hi) hi = s_max[w2];
         }
         header[0] = lo;
         header[1] = 244.0 / (hi - lo);
     }
 }
 
-// owner: rows*cols int32 row-major, pre-set to -1; the highest inlier index wins (the reference's last writer)
+// owner: cols*rows int32 COLUMN-major (x * rows + y, the order the inliers arrive in: coalesced atomics), pre-set to
+// -1; the highest inlier index wins (the reference's last writer)
 __global__ __launch_bounds__(kBP) void preview_claim_kernel(const double* __restrict__ inl, int64_t m, double fx, double fy, double cx,
                                                            double cy, int rows, int cols, int* __restrict__ owner) {
     const int64_t stride = (int64_t)gridDim.x * kBP;
     for (int64_t i = (int64_t)blockIdx.x * kBP + threadIdx.x; i < m; i += stride) {
         const int x = (int)(fx * inl[3 * i] + cx + 0.5);
         const int y = (int)(fy * inl[3 * i + 1] + cy + 0.5);
-        if (x >= 0 && x < cols && y >= 0 && y < rows) atomicMax(&owner[(int64_t)y * cols + x], (int)i);
+        if (x >= 0 && x < cols && y >= 0 && y < rows) atomicMax(&owner[(int64_t)x * rows + y], (int)i);
     }
 }
 
+// grid: (ceil(cols / 32), ceil(rows / 32)).  Reads the column-major owner tile along y (coalesced; the winners of
+// neighbouring pixels are neighbouring inliers, so the z gather is local too), transposes the bytes through LDS and
+// writes the row-major 8-bit image along x.
 __global__ __launch_bounds__(kBP) void preview_write_kernel(const double* __restrict__ inl, const int* __restrict__ owner,
-                                                           const double* __restrict__ header, int64_t npix,
+                                                           const double* __restrict__ header, int rows, int cols,
                                                            unsigned char* __restrict__ out) {
+    constexpr int T = 32;
+    __shared__ unsigned char s_v[T][T + 4];  // [y][x]
     const double z_min = header[0], mult = header[1];
-    const int64_t stride = (int64_t)gridDim.x * kBP;
-    for (int64_t p = (int64_t)blockIdx.x * kBP + threadIdx.x; p < npix; p += stride) {
-        const int o = owner[p];
-        unsigned char v = 0;
-        if (o >= 0) {
-            int zi = trunc_int((inl[3 * (int64_t)o + 2] - z_min) * mult);
-            if (zi == INT32_MIN) zi = 0;
-            v = (unsigned char)(10 + zi);  // int -> uchar: modulo 256, like the reference's assignment
+    const int x0 = blockIdx.x * T, y0 = blockIdx.y * T;
+    const int tid = threadIdx.x;
+    {
+        const int ly = tid & (T - 1);
+        const int y = y0 + ly;
+        int o[T * T / kBP];
+#pragma unroll
+        for (int j = 0; j < T * T / kBP; ++j) {
+            const int x = x0 + (tid / T) + j * (kBP / T);
+            o[j] = (x < cols && y < rows) ? owner[(int64_t)x * rows + y] : -1;
         }
-        out[p] = v;
+        double z[T * T / kBP];
+#pragma unroll
+        for (int j = 0; j < T * T / kBP; ++j) z[j] = o[j] >= 0 ? inl[3 * (int64_t)o[j] + 2] : 0.0;
+#pragma unroll
+        for (int j = 0; j < T * T / kBP; ++j) {
+            unsigned char v = 0;
+            if (o[j] >= 0) {
+                int zi = trunc_int((z[j] - z_min) * mult);
+                if (zi == INT32_MIN) zi = 0;
+                v = (unsigned char)(10 + zi);  // int -> uchar: modulo 256, like the reference's assignment
+            }
+            s_v[ly][(tid / T) + j * (kBP / T)] = v;
+        }
+    }
+    __syncthreads();
+    const int lx = tid & (T - 1);
+    const int x = x0 + lx;
+    if (x >= cols) return;
+#pragma unroll
+    for (int j = 0; j < T * T / kBP; ++j) {
+        const int ly = (tid / T) + j * (kBP / T);
+        const int y = y0 + ly;
+        if (y < rows) out[(int64_t)y * cols + x] = s_v[ly][lx];
     }
 }
 
@@ -262,9 +363,8 @@ int back_project_launch(Ctx* c, const unsigned char* d_img, const double* d_dept
                         int* d_owner) {
     const int64_t npix = (int64_t)rows * cols;
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_owner, 0xFF, sizeof(int) * (size_t)npix, c->stream));
-    if (d_c3d) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_c3d, 0, sizeof(float) * 3 * (size_t)npix, c->stream));
     dim3 grid((cols + kTX - 1) / kTX, (rows + kTY - 1) / kTY);
-    hipLaunchKernelGGL(back_project_claim_kernel, grid, dim3(kBP), 0, c->stream, d_img, d_depth_cm, d_R, d_t, fx, fy, cx, cy,
+    hipLaunchKernelGGL(back_project_claim_kernel, grid, dim3(kCB), 0, c->stream, d_img, d_depth_cm, d_R, d_t, fx, fy, cx, cy,
                        q5_mode == 0 ? fx : fy, rows, cols, mode, d_owner, d_c3d);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(back_project_write_kernel, dim3(stream_grid(npix, 4)), dim3(kBP), 0, c->stream, d_img, d_owner, npix, d_gs);
@@ -273,7 +373,7 @@ int back_project_launch(Ctx* c, const unsigned char* d_img, const double* d_dept
 }
 
 int interpolate_cracky_launch(Ctx* c, const unsigned char* d_in, int rows, int cols, int offset, unsigned char* d_out) {
-    hipLaunchKernelGGL(interpolate_cracky_kernel, dim3(stream_grid((int64_t)rows * cols)), dim3(kBP), 0, c->stream, d_in, rows, cols,
+    hipLaunchKernelGGL(interpolate_cracky_kernel, dim3(stream_grid((int64_t)rows * cols, 4)), dim3(kBP), 0, c->stream, d_in, rows, cols,
                        offset, d_out);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
@@ -294,7 +394,8 @@ int depth_preview_launch(Ctx* c, const double* d_inl, int64_t m, double fx, doub
                            d_owner);
         RSDSFM_HIP_CHECK(c, hipGetLastError());
     }
-    hipLaunchKernelGGL(preview_write_kernel, dim3(stream_grid(npix)), dim3(kBP), 0, c->stream, d_inl, d_owner, d_header, npix, d_out);
+    hipLaunchKernelGGL(preview_write_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(kBP), 0, c->stream, d_inl, d_owner, d_header,
+                       rows, cols, d_out);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

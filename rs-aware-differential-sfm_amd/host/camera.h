@@ -1,6 +1,7 @@
 // camera.h -- the facade of the reference's Camera (src/camera.h) over the frames: intrinsics (incl. the five
 // hard-coded phone calibrations, camera.cc:179-206), gamma, pose and depth map forwarding (camera.cc:335-371).
-// Image, flow, CSV and visualisation members are out of scope.
+// plus the rectifier entry points backProject / backProjectGs (camera.cc:353-361) and interpolateCrackyImage
+// (camera.cc:753-774).  Flow, CSV and visualisation members are out of scope.
 #ifndef RSDSFM_HOST_CAMERA_H
 #define RSDSFM_HOST_CAMERA_H
 
@@ -46,6 +47,18 @@ public:
     /** reference camera.cc:340-342 */
     void setPose(const int frameNr, const double k, const rsdsfm::lite::Vector3d& linear_velocity, const rsdsfm::lite::Vector3d& angular_velocity) {
         frames_[(size_t)frameNr - 1].setRelativePose(linear_velocity, angular_velocity, k);
+    }
+    void setImage(const int frameNr, const rsdsfm::ImageBGR& image) { frames_[(size_t)frameNr - 1].setImage(image); }
+    /** reference camera.cc:353-361 */
+    void backProject(const int frameNr) { frames_[(size_t)frameNr - 1].backProject(); }
+    void backProjectGs(const int frameNr) { frames_[(size_t)frameNr - 1].backProjectGs(); }
+    /** reference camera.cc:753-774 */
+    rsdsfm::ImageBGR interpolateCrackyImage(const rsdsfm::ImageBGR& image_in, const unsigned offset) {
+        rsdsfm::ImageBGR image_out(image_in.rows(), image_in.cols());
+        rsdsfm::check(rsdsfm_interpolate_cracky(rsdsfm::default_context(), image_in.data(), image_in.rows(), image_in.cols(), (int32_t)offset,
+                                                image_out.data()),
+                      "rsdsfm_interpolate_cracky");
+        return image_out;
     }
     void setGamma(const double gamma) {
         for (auto& f : frames_) f.setGamma(gamma);

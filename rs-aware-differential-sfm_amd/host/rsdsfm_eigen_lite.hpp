@@ -123,3 +123,44 @@ private:
 }  // namespace lite
 }  // namespace rsdsfm
 #endif
+
+#include <vector>
+
+namespace rsdsfm {
+
+// stand-in for the reference's cv::Mat of type CV_8UC3: row-major rows x cols x (b, g, r)
+class ImageBGR {
+public:
+    ImageBGR() : r_(0), c_(0) {}
+    ImageBGR(int rows, int cols) : r_(rows), c_(cols), d_((size_t)rows * (size_t)cols * 3, 0) {}
+    int rows() const { return r_; }
+    int cols() const { return c_; }
+    unsigned char* data() { return d_.data(); }
+    const unsigned char* data() const { return d_.data(); }
+    unsigned char& at(int row, int col, int ch) { return d_[((size_t)row * (size_t)c_ + (size_t)col) * 3 + (size_t)ch]; }
+    unsigned char at(int row, int col, int ch) const { return d_[((size_t)row * (size_t)c_ + (size_t)col) * 3 + (size_t)ch]; }
+    ImageBGR clone() const { return *this; }
+
+private:
+    int r_, c_;
+    std::vector<unsigned char> d_;
+};
+
+// stand-in for cv::Mat_<cv::Vec3f>: row-major rows x cols x 3 floats
+class ImageXYZf {
+public:
+    ImageXYZf() : r_(0), c_(0) {}
+    ImageXYZf(int rows, int cols) : r_(rows), c_(cols), d_((size_t)rows * (size_t)cols * 3, 0.0f) {}
+    int rows() const { return r_; }
+    int cols() const { return c_; }
+    float* data() { return d_.data(); }
+    const float* data() const { return d_.data(); }
+    float at(int row, int col, int ch) const { return d_[((size_t)row * (size_t)c_ + (size_t)col) * 3 + (size_t)ch]; }
+
+private:
+    int r_, c_;
+    std::vector<float> d_;
+};
+
+}  // namespace rsdsfm
+

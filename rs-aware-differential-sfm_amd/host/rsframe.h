@@ -1,6 +1,8 @@
 // rsframe.h -- the part of the reference's RsFrame (src/rsframe.h) that consumes the solver's output: frame size,
 // gamma, intrinsics, depth map and the per-scanline relative pose table (setRelativePose, rsframe.cc:771-800, computed
-// by the pose_table HIP kernel).  Image / OpenCV / CSV members of the reference class are out of scope.
+// by the pose_table HIP kernel), plus the rectifier that consumes them: backProject / backProjectGs
+// (rsframe.cc:803-878) on a plain BGR byte image (rsdsfm::ImageBGR in place of cv::Mat).  File / OpenCV / CSV
+// members of the reference class are out of scope.
 #ifndef RSDSFM_HOST_RSFRAME_H
 #define RSDSFM_HOST_RSFRAME_H
 
@@ -20,6 +22,20 @@ public:
     void setDepthMap(const rsdsfm::lite::MatrixXd& depth_map) { depth_map_ = depth_map; }
     rsdsfm::lite::MatrixXd getDepthMap() { return depth_map_; }
     const Scanline& getScanline(int i) const { return scanlines_[(size_t)i]; }
+    void setImage(const rsdsfm::ImageBGR& image) { image_ = image; }
+    rsdsfm::ImageBGR getRsImage() { return image_; }
+    rsdsfm::ImageBGR getGsImage() { return gs_image_; }
+    rsdsfm::ImageXYZf get3dCoordinates() { return coordinates_3d_; }
+
+    /** reference rsframe.cc:803-839: RS image -> 3-D -> GS image with the per-scanline relative poses */
+    void backProject() { backProjectImpl(RSDSFM_BACKPROJECT_RS); }
+    /** reference rsframe.cc:842-878: the same with the pose of the first scanline for every pixel */
+    void backProjectGs() { backProjectImpl(RSDSFM_BACKPROJECT_GS); }
+    /** reference quirk Q5 (spaceToPlane scales y by f_x, rsframe.cc:639): RSDSFM_Q5_COMPAT (default) or RSDSFM_Q5_FIXED */
+    static int& q5_mode() {
+        static int mode = RSDSFM_Q5_COMPAT;
+        return mode;
+    }
 
     /** reference rsframe.cc:771-800 */
     void setRelativePose(const rsdsfm::lite::Vector3d& linear_velocity, const rsdsfm::lite::Vector3d& angular_velocity, const double k) {
@@ -37,11 +53,29 @@ public:
     }
 
 private:
+    void backProjectImpl(int mode) {
+        std::vector<double> R((size_t)rows_ * 9), t((size_t)rows_ * 3);
+        for (int i = 0; i < rows_; ++i) {
+            const Scanline& sl = scanlines_[(size_t)i];
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) R[(size_t)i * 9 + (size_t)(r * 3 + c)] = sl.getRelativeRotation()(r, c);
+                t[(size_t)i * 3 + (size_t)r] = sl.getRelativeTranslation()(r);
+            }
+        }
+        gs_image_ = rsdsfm::ImageBGR(rows_, cols_);
+        coordinates_3d_ = rsdsfm::ImageXYZf(rows_, cols_);
+        rsdsfm::check(rsdsfm_back_project(rsdsfm::default_context(), image_.data(), depth_map_.data(), R.data(), t.data(), K_(0, 0), K_(1, 1),
+                                          K_(0, 2), K_(1, 2), rows_, cols_, mode, q5_mode(), gs_image_.data(), coordinates_3d_.data()),
+                      "rsdsfm_back_project");
+    }
+
     int rows_, cols_;
     double gamma_;
     rsdsfm::lite::Matrix3d K_;
     rsdsfm::lite::MatrixXd depth_map_;
     std::vector<Scanline> scanlines_;
+    rsdsfm::ImageBGR image_, gs_image_;
+    rsdsfm::ImageXYZf coordinates_3d_;
 };
 
 #endif

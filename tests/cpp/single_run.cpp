@@ -69,17 +69,42 @@ int main(int argc, char** argv) {
         camera.setDepthMap(1, depth_map);
         const Scanline& last = camera.frame(1).getScanline(rows - 1);
 
+        // 8-bit depth image (main.cc:480-509), then RS -> GS back projection and crack interpolation (main.cc:515-523) of
+        // a deterministic test image
+        std::vector<uint8_t> depth_est((size_t)rows * (size_t)cols);
+        rsdsfm::check(rsdsfm_depth_preview(rsdsfm::default_context(), results.inliers.data(), results.num_inliers, fx, fy, cx, cy, rows, cols,
+                                           depth_est.data()),
+                      "rsdsfm_depth_preview");
+        rsdsfm::ImageBGR rs_image(rows, cols);
+        for (int y = 0; y < rows; ++y)
+            for (int x = 0; x < cols; ++x) {
+                rs_image.at(y, x, 0) = (unsigned char)((40 + 5 * x + 3 * y) % 256);
+                rs_image.at(y, x, 1) = (unsigned char)((200 + 7 * y + 254 * x) % 256);
+                rs_image.at(y, x, 2) = (unsigned char)((90 + x + 99 * (((x / 4) + (y / 4)) % 2)) % 256);
+            }
+        camera.setImage(1, rs_image);
+        camera.frame(1).backProject();
+        rsdsfm::ImageBGR backprojection = camera.interpolateCrackyImage(camera.frame(1).getGsImage(), 1);
+        unsigned long long preview_sum = 0, gs_sum = 0, bp_sum = 0;
+        for (uint8_t b : depth_est) preview_sum += b;
+        {
+            rsdsfm::ImageBGR gs = camera.frame(1).getGsImage();
+            for (size_t i = 0; i < (size_t)rows * (size_t)cols * 3; ++i) gs_sum += (unsigned long long)gs.data()[i] * (i % 251 + 1);
+            for (size_t i = 0; i < (size_t)rows * (size_t)cols * 3; ++i) bp_sum += (unsigned long long)backprojection.data()[i] * (i % 251 + 1);
+        }
+
         double zsum = 0;
         for (long i = 0; i < results.num_inliers; ++i) zsum += results.inliers(2, i);
         long long ysum = 0;
         for (int32_t y : ys) ysum += y;
         std::printf("{\"n\": %lld, \"ransac_inliers\": %d, \"ransac_w\": [%.17g, %.17g, %.17g], \"ransac_v\": [%.17g, %.17g, %.17g], "
                     "\"w\": [%.17g, %.17g, %.17g], \"v\": [%.17g, %.17g, %.17g], \"k\": %.17g, \"flipped\": %d, \"zsum\": %.17g, "
-                    "\"ysum\": %lld, \"last_t\": [%.17g, %.17g, %.17g], \"last_R01\": %.17g}\n",
+                    "\"ysum\": %lld, \"last_t\": [%.17g, %.17g, %.17g], \"last_R01\": %.17g, \"preview_sum\": %llu, \"gs_sum\": %llu, "
+                    "\"bp_sum\": %llu}\n",
                     (long long)n, ransac_results.num_inliers, ransac_results.w(0), ransac_results.w(1), ransac_results.w(2), ransac_results.v(0),
                     ransac_results.v(1), ransac_results.v(2), results.w(0), results.w(1), results.w(2), results.v(0), results.v(1),
                     results.v(2), results.k, flipped, zsum, ysum, last.getRelativeTranslation()(0), last.getRelativeTranslation()(1),
-                    last.getRelativeTranslation()(2), last.getRelativeRotation()(0, 1));
+                    last.getRelativeTranslation()(2), last.getRelativeRotation()(0, 1), preview_sum, gs_sum, bp_sum);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

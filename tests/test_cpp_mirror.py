@@ -55,6 +55,13 @@ def test_single_run_matches_python_path(tmp_path, rsdsfm, oracle):
     assert r["ysum"] == int(dm["ys"].astype(np.int64).sum())  # scanline indices: bit-exact
     assert np.isclose(r["zsum"], dm["inliers"][:, 2].sum(), rtol=1e-12)
     assert np.array_equal(r["last_t"], t[-1]) and r["last_R01"] == R[-1][0, 1]
+    # 8-bit depth image, back projection and crack interpolation of the mirror's deterministic test image
+    yy, xx = np.mgrid[0:120, 0:200]
+    rs = np.stack([(40 + 5 * xx + 3 * yy) % 256, (200 + 7 * yy + 254 * xx) % 256, (90 + xx + 99 * ((xx // 4 + yy // 4) % 2)) % 256], axis=2).astype(np.uint8)
+    wsum = lambda a: int((a.reshape(-1).astype(np.uint64) * (np.arange(a.size, dtype=np.uint64) % np.uint64(251) + np.uint64(1))).sum())
+    gs_o, _ = oracle.back_project(rs, dm["depth_map"], R, t, *K)
+    assert r["preview_sum"] == int(oracle.depth_preview(dm["inliers"], *K, 120, 200).astype(np.uint64).sum())
+    assert r["gs_sum"] == wsum(gs_o) and r["bp_sum"] == wsum(oracle.interpolate_cracky(gs_o, 1))
     # and the oracle agrees with the whole chain (same sampler, same seed)
     ro = oracle.ransac(q, u, a, ak, False, T, tol, oracle.sample_indices(len(q), T, seed), depth_mode=1)
     assert ro["num_inliers"] == r["ransac_inliers"]

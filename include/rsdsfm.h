@@ -348,6 +348,20 @@ int rsdsfm_depth_preview(rsdsfm_ctx* ctx, const double* inliers3m, int64_t m, do
 int rsdsfm_depth_preview_dev(rsdsfm_ctx* ctx, const double* d_inliers3m, int64_t m, double fx, double fy, double cx, double cy,
                              int32_t rows, int32_t cols, uint8_t* d_depth_est);
 
+/* ---- ground-truth flow between two rolling-shutter frames ---------------------------------------
+ * Camera::calculateTrueFlow (camera.cc:209-249) + RsFrame::calculateImageCoordinatesRsFrame (rsframe.cc:740-768).
+ * world_{x,y,z}: the unprojection maps of frame 1 (Eigen MatrixXd, column-major rows x cols; all-zero = void pixel);
+ * R2 / t2: pose table of the rows2 scanlines of frame 2 (as rsdsfm_pose_table lays it out); flow: rows x cols x 2
+ * doubles row-major (cv::Mat_<cv::Point_<double>>); best_row (may be NULL): winning scanline per pixel, -1 = void.
+ * rows2 must be >= 1 (the reference would read scanline 0 of an empty frame). */
+int rsdsfm_true_flow(rsdsfm_ctx* ctx, const double* world_x, const double* world_y, const double* world_z, int32_t rows,
+                     int32_t cols, const double* R2_rows9, const double* t2_rows3, int32_t rows2, double fx, double fy,
+                     double cx, double cy, int q5_mode, double* flow, int32_t* best_row_or_null);
+int rsdsfm_true_flow_dev(rsdsfm_ctx* ctx, const double* d_world_x, const double* d_world_y, const double* d_world_z,
+                         int32_t rows, int32_t cols, const double* d_R2_rows9, const double* d_t2_rows3, int32_t rows2,
+                         double fx, double fy, double cx, double cy, int q5_mode, double* d_flow,
+                         int32_t* d_best_row_or_null);
+
 #ifdef __cplusplus
 }
 #endif

@@ -281,3 +281,19 @@ def interpolate_cracky(image_bgr, offset=1):
     out = np.zeros_like(img)
     lib().rso_interpolate_cracky(_p(img), C.c_int32(rows), C.c_int32(cols), C.c_int32(offset), _p(out))
     return out
+
+
+def true_flow(world_xyz, R2, t2, fx, fy, cx, cy, q5_mode=0):
+    """world_xyz: (rows, cols, 3) world point per pixel of frame 1 (zeros = void); R2: (rows2, 3, 3) / (rows2, 9); t2: (rows2, 3).
+    Returns flow (rows, cols, 2) and the winning scanline (rows, cols) int32 (-1 = void)."""
+    w = np.asarray(world_xyz, dtype=np.float64)
+    rows, cols = w.shape[:2]
+    maps = [np.ascontiguousarray(w[:, :, c].T) for c in range(3)]  # column-major rows x cols
+    t2 = _f64(t2)
+    rows2 = t2.shape[0]
+    R2 = _f64(np.asarray(R2).reshape(rows2, 9))
+    flow = np.zeros((rows, cols, 2))
+    best = np.zeros((rows, cols), dtype=np.int32)
+    d = C.c_double
+    lib().rso_true_flow(_p(maps[0]), _p(maps[1]), _p(maps[2]), C.c_int32(rows), C.c_int32(cols), _p(R2), _p(t2), C.c_int32(rows2), d(fx), d(fy), d(cx), d(cy), int(q5_mode), _p(flow), _p(best))
+    return flow, best

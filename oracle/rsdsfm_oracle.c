@@ -1466,3 +1466,51 @@ void rso_interpolate_cracky(const uint8_t* in, int32_t rows, int32_t cols, int32
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* ground-truth flow (camera.cc:209-249, rsframe.cc:740-768)                         */
+/* ------------------------------------------------------------------------------------------------ */
+static void rso_project_scanline(const double* Ri, const double* ti, const double W[3], double fx, double fyp, double cx,
+                                 double cy, double* px, double* py) {
+    /* worldToCameraFrame: [R t; 0 1] * (W, 1), evaluated left to right; then spaceToPlane */
+    double pc[3];
+    for (int j = 0; j < 3; ++j) pc[j] = ((Ri[j * 3 + 0] * W[0] + Ri[j * 3 + 1] * W[1]) + Ri[j * 3 + 2] * W[2]) + ti[j] * 1.0;
+    *px = pc[0] / pc[2] * fx + cx;
+    *py = pc[1] / pc[2] * fyp + cy;
+}
+
+void rso_true_flow(const double* wx, const double* wy, const double* wz, int32_t rows, int32_t cols, const double* R2,
+                   const double* t2, int32_t rows2, double fx, double fy, double cx, double cy, int q5_mode, double* flow,
+                   int32_t* best_row_out) {
+    const double fyp = q5_mode == 0 ? fx : fy;
+    for (int32_t v = 0; v < rows; ++v) {
+        for (int32_t u = 0; u < cols; ++u) {
+            const int64_t cm = (int64_t)u * rows + v;
+            const double W[3] = {wx[cm], wy[cm], wz[cm]};
+            double f2x = (double)u, f2y = (double)v;
+            int32_t best_row = -1;
+            if (sqrt(W[0] * W[0] + W[1] * W[1] + W[2] * W[2]) != 0) {
+                double min_diff = INFINITY;
+                best_row = 0;
+                for (int32_t i = 0; i < rows2; ++i) {
+                    double px, py;
+                    rso_project_scanline(R2 + (int64_t)i * 9, t2 + (int64_t)i * 3, W, fx, fyp, cx, cy, &px, &py);
+                    double diff = fabs(py - (double)i);
+                    if (diff < min_diff) {
+                        min_diff = diff;
+                        best_row = i;
+                    }
+                }
+                double px, py;
+                rso_project_scanline(R2 + (int64_t)best_row * 9, t2 + (int64_t)best_row * 3, W, fx, fyp, cx, cy, &px, &py);
+                if (sqrt(px * px + py * py) != 0) {
+                    f2x = px;
+                    f2y = py;
+                }
+            }
+            flow[((int64_t)v * cols + u) * 2 + 0] = f2x - (double)u;
+            flow[((int64_t)v * cols + u) * 2 + 1] = f2y - (double)v;
+            if (best_row_out) best_row_out[(int64_t)v * cols + u] = best_row;
+        }
+    }
+}

@@ -156,6 +156,19 @@ void rso_back_project(const uint8_t* image_bgr, const double* depth_map_colmajor
 void rso_interpolate_cracky(const uint8_t* image_in_bgr, int32_t rows, int32_t cols, int32_t offset,
                             uint8_t* image_out_bgr);
 
+/* ---- ground-truth flow between two rolling-shutter frames ------------------------------- */
+/* Camera::calculateTrueFlow (camera.cc:209-249) with RsFrame::calculateImageCoordinatesRsFrame (rsframe.cc:740-768):
+ * every pixel (u, v) of frame 1 has a world point W (unprojection maps, column-major rows x cols each); W is projected
+ * into frame 2 with the pose of EVERY scanline i of frame 2 (worldToCameraFrame rsframe.cc:687-709, spaceToPlane
+ * :628-641, quirk Q5 as in rso_back_project) and the scanline with the smallest |y_projected - i| wins (first minimum);
+ * flow(v, u) = projection with that pose - (u, v).  Void pixels (||W|| == 0, computed as sqrt of the sum of squares
+ * like Eigen's norm()) and projections of norm 0 give zero flow.  rows2 = scanlines of frame 2.
+ * flow: rows x cols x 2 row-major (cv::Mat_<Point_<double>>); best_row (may be NULL): winning scanline, -1 for void
+ * pixels.  If no scanline yields a finite displacement the reference's best_row is uninitialised; here it is 0. */
+void rso_true_flow(const double* world_x, const double* world_y, const double* world_z, int32_t rows, int32_t cols,
+                   const double* R2_rows9, const double* t2_rows3, int32_t rows2, double fx, double fy, double cx,
+                   double cy, int q5_mode, double* flow_rowmajor, int32_t* best_row_or_null);
+
 /* exposed for direct testing of the restated third-party pieces */
 void rso_jacobi_svd9(const double Z_rowmajor[81], double sv[9], double V_rowmajor[81]);
 int rso_eigvals_general(const double* A_rowmajor, int n, double* re, double* im);

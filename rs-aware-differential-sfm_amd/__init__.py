@@ -521,3 +521,32 @@ class _RectifyMixin:
 for _name, _fn in list(vars(_RectifyMixin).items()):
     if not _name.startswith("__"):
         setattr(Solver, _name, _fn)
+
+
+# ---------------------------------------------------------------------------------------------------
+# ground-truth flow between two rolling-shutter frames
+# ---------------------------------------------------------------------------------------------------
+class _TrueFlowMixin:
+    def true_flow(self, world_xyz, R2, t2, K, q5_mode=Q5_COMPAT, want_best_row=True):
+        """Camera::calculateTrueFlow.  world_xyz: (rows, cols, 3) world point per pixel of frame 1 (zeros = void);
+        R2: (rows2, 3, 3) or (rows2, 9); t2: (rows2, 3).  Returns flow (rows, cols, 2) and the winning scanlines."""
+        w = np.asarray(world_xyz, dtype=np.float64)
+        rows, cols = w.shape[:2]
+        maps = [np.ascontiguousarray(w[:, :, c].T) for c in range(3)]  # column-major rows x cols (Eigen MatrixXd)
+        tt = _f64(t2)
+        rows2 = tt.shape[0]
+        Rr = _f64(np.asarray(R2).reshape(rows2, 9))
+        flow = np.zeros((rows, cols, 2))
+        best = np.zeros((rows, cols), dtype=np.int32) if want_best_row else None
+        d = C.c_double
+        self._check(self.lib.rsdsfm_true_flow(self._ctx, _p(maps[0]), _p(maps[1]), _p(maps[2]), C.c_int32(rows), C.c_int32(cols), _p(Rr), _p(tt), C.c_int32(rows2), d(K[0]), d(K[1]), d(K[2]), d(K[3]), int(q5_mode), _p(flow), _p(best)), "rsdsfm_true_flow")
+        return flow, best
+
+    def true_flow_dev(self, d_wx, d_wy, d_wz, rows, cols, d_R2, d_t2, rows2, K, d_flow, d_best_row=None, q5_mode=Q5_COMPAT):
+        d = C.c_double
+        self._check(self.lib.rsdsfm_true_flow_dev(self._ctx, _dp(d_wx), _dp(d_wy), _dp(d_wz), C.c_int32(rows), C.c_int32(cols), _dp(d_R2), _dp(d_t2), C.c_int32(rows2), d(K[0]), d(K[1]), d(K[2]), d(K[3]), int(q5_mode), _dp(d_flow), _dp(d_best_row) if d_best_row else None), "rsdsfm_true_flow_dev")
+
+
+for _name, _fn in list(vars(_TrueFlowMixin).items()):
+    if not _name.startswith("__"):
+        setattr(Solver, _name, _fn)

@@ -1,0 +1,85 @@
+// gtflow_kernels.hip -- SURVEY section 8(f-2): ground-truth optical flow between two rolling-shutter frames (gfx950).
+//
+// Replaces Camera::calculateTrueFlow (reference camera.cc:209-249) and RsFrame::calculateImageCoordinatesRsFrame
+// (rsframe.cc:740-768): for every pixel of frame 1 with a world point W, W is projected with the pose of EVERY scanline
+// i of frame 2 and the scanline minimising |y_projected - i| wins (first minimum, strict <).  rows * cols * rows2
+// projections (6.6e8 at 1280x720): the only compute-heavy loop outside the solver.  It is VALU-bound fp64 work, not
+// GEMM-shaped (one IEEE division per projection, an argmin with an index-dependent target):
+//   * one pixel per lane; the scanline loop is uniform across the machine, so the pose rows come through the scalar
+//     data path (s_load) and are broadcast operands of the VALU instructions -- no LDS, no vector loads in the loop;
+//   * only what decides the argmin is computed in the loop (camera-frame y and z: 6 mul + 6 add, 1 division, the
+//     intrinsics and the compare); the x coordinate is computed once for the winner.  Each value that is computed is
+//     computed with the reference's operation order, so flows and winners are bit-identical to the oracle's;
+//   * the world maps are column-major (Eigen) and the flow row-major (cv::Mat): 24 B read + 16 B written per pixel,
+//     negligible against rows2 x ~30 fp64 instructions per pixel.
+#include <math.h>
+
+#include "rsdsfm_internal.hpp"
+
+namespace rsdsfm {
+
+namespace {
+constexpr int kGF = 256;
+}
+
+// one wave = 64 consecutive pixels of one image row (u fastest); grid-stride over rows * ceil(cols / 64) segments
+__global__ __launch_bounds__(kGF) void true_flow_kernel(const double* __restrict__ wx, const double* __restrict__ wy,
+                                                       const double* __restrict__ wz, int rows, int cols,
+                                                       const double* __restrict__ R2, const double* __restrict__ t2, int rows2,
+                                                       double fx, double fyp, double cx, double cy, double2* __restrict__ flow,
+                                                       int* __restrict__ best_row_out) {
+    const int64_t npix = (int64_t)rows * cols;
+    const int64_t stride = (int64_t)gridDim.x * kGF;
+    for (int64_t p = (int64_t)blockIdx.x * kGF + threadIdx.x; p < npix; p += stride) {
+        const int v = (int)(p / cols), u = (int)(p - (int64_t)v * cols);
+        const int64_t cm = (int64_t)u * rows + v;
+        const double X = wx[cm], Y = wy[cm], Z = wz[cm];
+        double f2x = (double)u, f2y = (double)v;
+        int best_row = -1;
+        if (sqrt(X * X + Y * Y + Z * Z) != 0) {
+            double min_diff = INFINITY;
+            best_row = 0;
+#pragma unroll 4
+            for (int i = 0; i < rows2; ++i) {
+                const double* Ri = R2 + (int64_t)i * 9;  // uniform address: scalar loads
+                const double* ti = t2 + (int64_t)i * 3;
+                const double yc = ((Ri[3] * X + Ri[4] * Y) + Ri[5] * Z) + ti[1] * 1.0;
+                const double zc = ((Ri[6] * X + Ri[7] * Y) + Ri[8] * Z) + ti[2] * 1.0;
+                const double py = yc / zc * fyp + cy;
+                const double diff = fabs(py - (double)i);
+                if (diff < min_diff) {
+                    min_diff = diff;
+                    best_row = i;
+                }
+            }
+            const double* Ri = R2 + (int64_t)best_row * 9;
+            const double* ti = t2 + (int64_t)best_row * 3;
+            const double xc = ((Ri[0] * X + Ri[1] * Y) + Ri[2] * Z) + ti[0] * 1.0;
+            const double yc = ((Ri[3] * X + Ri[4] * Y) + Ri[5] * Z) + ti[1] * 1.0;
+            const double zc = ((Ri[6] * X + Ri[7] * Y) + Ri[8] * Z) + ti[2] * 1.0;
+            const double px = xc / zc * fx + cx;
+            const double py = yc / zc * fyp + cy;
+            if (sqrt(px * px + py * py) != 0) {
+                f2x = px;
+                f2y = py;
+            }
+        }
+        flow[p] = make_double2(f2x - (double)u, f2y - (double)v);
+        if (best_row_out) best_row_out[p] = best_row;
+    }
+}
+
+int true_flow_launch(Ctx* c, const double* d_wx, const double* d_wy, const double* d_wz, int rows, int cols, const double* d_R2,
+                     const double* d_t2, int rows2, double fx, double fy, double cx, double cy, int q5_mode, double* d_flow,
+                     int* d_best_row) {
+    const int64_t npix = (int64_t)rows * cols;
+    int64_t blocks = (npix + kGF - 1) / kGF;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(true_flow_kernel, dim3((int)blocks), dim3(kGF), 0, c->stream, d_wx, d_wy, d_wz, rows, cols, d_R2, d_t2, rows2, fx,
+                       q5_mode == 0 ? fx : fy, cx, cy, reinterpret_cast<double2*>(d_flow), d_best_row);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+}  // namespace rsdsfm

@@ -113,6 +113,39 @@ def preview_np(inl, K, rows, cols):
     return out
 
 
+def true_flow_np(world, R2, t2, K, q5_fixed):
+    """Camera::calculateTrueFlow (camera.cc:209-249) + calculateImageCoordinatesRsFrame (rsframe.cc:740-768)"""
+    fx, fy, cx, cy = K
+    rows, cols = world.shape[:2]
+    rows2 = R2.shape[0]
+    P = np.zeros((rows2, 4, 4))
+    P[:, :3, :3], P[:, :3, 3], P[:, 3, 3] = R2, t2, 1.0
+    flow = np.zeros((rows, cols, 2))
+    best = np.full((rows, cols), -1, dtype=np.int32)
+
+    def project(i, W):
+        pc = (P[i] @ np.append(W, 1.0))[:3]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.array([pc[0] / pc[2] * fx + cx, pc[1] / pc[2] * (fy if q5_fixed else fx) + cy])
+
+    for v in range(rows):
+        for u in range(cols):
+            W = world[v, u]
+            f2 = np.array([float(u), float(v)])
+            if np.linalg.norm(W) != 0:
+                min_diff, b = np.inf, 0
+                for i in range(rows2):
+                    diff = abs(project(i, W)[1] - float(i))
+                    if diff < min_diff:
+                        min_diff, b = diff, i
+                best[v, u] = b
+                pt = project(b, W)
+                if np.linalg.norm(pt) != 0:
+                    f2 = pt
+            flow[v, u] = f2 - np.array([float(u), float(v)])
+    return flow, best
+
+
 def texture(rows, cols, seed):
     """deterministic BGR test image: smooth colour ramps + a checker, dark (black) patches, a few marker pixels"""
     r = synth.splitmix64(seed, rows * cols).reshape(rows, cols)
@@ -152,6 +185,17 @@ def main():
         inl = np.array(pts)
         out[g("inliers")] = inl
         out[g("preview")] = preview_np(inl, K, rows, cols)
+        # ground-truth flow: world points of frame 1 (scanline-0 camera frame = world), frame 2 = the same rolling
+        # shutter motion continued by one frame time
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        world = np.stack([(xx - cx) / fx, (yy - cy) / fy, np.ones((rows, cols))], axis=2) * np.array(t_["Z"])[:, :, None]
+        world[holes] = 0.0
+        R2 = R.copy()
+        t2 = t + np.array([0.04, 0.02, 0.01])
+        out[g("world")], out[g("R2")], out[g("t2")] = world, R2, t2
+        for q5 in (0, 1):
+            fl, bst = true_flow_np(world, R2, t2, K, bool(q5))
+            out[g("tf_flow_q%d" % q5)], out[g("tf_best_q%d" % q5)] = fl, bst
     np.savez_compressed(os.path.join(HERE, "golden_rectify_v1.npz"), **out)
     print("wrote golden_rectify_v1.npz:", {k2: v2.shape for k2, v2 in out.items() if hasattr(v2, "shape")})
 

@@ -139,3 +139,71 @@ def test_rectify_argument_errors(rsdsfm):
             s.interpolate_cracky(img, -1)
         e = np.zeros((0, 5, 3), dtype=np.uint8)
         assert s.interpolate_cracky(e, 1).shape == (0, 5, 3)
+
+
+# ---------------------------------------------------------------------------------------------------
+# ground-truth flow search
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", RECTIFY_CASES)
+def test_true_flow_matches_golden(golden_rectify, rsdsfm, case):
+    g = lambda k: golden_rectify[case + "/" + k]
+    K = tuple(g("K"))
+    with rsdsfm.Solver(0) as s:
+        for q5 in (0, 1):
+            flow, best = s.true_flow(g("world"), g("R2"), g("t2"), K, q5_mode=q5)
+            assert np.array_equal(best, g("tf_best_q%d" % q5))
+            assert np.allclose(flow, g("tf_flow_q%d" % q5), rtol=1e-12, atol=1e-11)
+
+
+def _flow_scene(rsdsfm, oracle, rows, cols, seed, rows2=None):
+    d = rsdsfm.synth.make_config(1, rows=rows, cols=cols)
+    fx, fy, cx, cy = d["K"]
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    Z = np.array(d["truth"]["Z"])
+    world = np.stack([(xx - cx) / fx, (yy - cy) / fy, np.ones((rows, cols))], axis=2) * Z[:, :, None]
+    world[rng.random((rows, cols)) < 0.1] = 0.0
+    rows2 = rows if rows2 is None else rows2
+    R2, t2 = oracle.pose_table(np.array([0.12, 0.10, 0.05]), np.array([0.03, -0.02, 0.06]), 0.3, d["gamma"], rows2)
+    t2 = t2 + np.array([0.04, 0.02, 0.01])
+    return d["K"], world, R2, t2
+
+
+@pytest.mark.parametrize("rows,cols,rows2", [(1, 1, 1), (5, 7, 5), (33, 65, 33), (64, 50, 40), (120, 200, 120), (240, 320, 240)])
+def test_true_flow_equals_oracle(oracle, rsdsfm, rows, cols, rows2):
+    """winning scanlines and flows BIT-exact (same per-projection operation chain, no contraction), incl. a frame 2 with
+    a different number of scanlines and pixels whose best scanline is the first / last one"""
+    K, world, R2, t2 = _flow_scene(rsdsfm, oracle, rows, cols, seed=rows + cols, rows2=rows2)
+    with rsdsfm.Solver(0) as s:
+        for q5 in (0, 1):
+            flow, best = s.true_flow(world, R2, t2, K, q5_mode=q5)
+            flow_o, best_o = oracle.true_flow(world, R2, t2, *K, q5_mode=q5)
+            assert np.array_equal(best, best_o)
+            assert np.array_equal(flow.view(np.uint64), flow_o.view(np.uint64))
+        f2, none = s.true_flow(world, R2, t2, K, want_best_row=False)
+        assert none is None and np.array_equal(f2, oracle.true_flow(world, R2, t2, *K)[0])
+
+
+def test_true_flow_degenerate_points_and_errors(oracle, rsdsfm):
+    K = (50.0, 50.0, 13.0, 10.0)
+    rows = 12
+    R = np.tile(np.eye(3), (rows, 1, 1))
+    t = np.zeros((rows, 3))
+    w = np.zeros((2, 3, 3))
+    w[0, 0] = [0.1, 0.2, 0.0]       # on the principal plane: every displacement is inf
+    w[0, 1] = [0.1, 0.2, -3.0]      # behind the camera
+    w[0, 2] = [0.0, 0.0, 0.0]       # void
+    w[1, 0] = [1e-200, 0.0, 0.0]    # ||W||^2 underflows to 0: treated as void (Eigen's norm())
+    w[1, 1] = [0.0, (4.5 - K[3]) / K[1] * 4.0, 4.0]  # tie between scanlines 4 and 5: 4 wins
+    w[1, 2] = [np.nan, 1.0, 2.0]
+    with rsdsfm.Solver(0) as s:
+        flow, best = s.true_flow(w, R, t, K, q5_mode=1)
+        flow_o, best_o = oracle.true_flow(w, R, t, *K, q5_mode=1)
+        assert np.array_equal(best, best_o) and best[1, 1] == 4 and best[0, 2] == -1 and best[1, 0] == -1
+        assert np.array_equal(np.isnan(flow), np.isnan(flow_o))
+        fin = np.isfinite(flow_o)
+        assert np.array_equal(flow[fin], flow_o[fin])
+        with pytest.raises(rsdsfm.RsdsfmError):
+            s.true_flow(w, R[:0], t[:0], K)
+        with pytest.raises(rsdsfm.RsdsfmError):
+            s.true_flow(w, R, t, K, q5_mode=3)

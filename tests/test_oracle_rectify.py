@@ -124,3 +124,54 @@ def test_preview_properties(oracle):
     neg = oracle.depth_preview(np.array([[0.0, 0.0, -2.0], [0.01, 0.0, -1.0]]), *K, rows, cols)
     assert neg[12, 16] == 10 and neg[12, 17] == 10 + int(1.0 * 122.0)
     assert np.array_equal(oracle.depth_preview(np.zeros((0, 3)), *K, rows, cols), np.zeros((rows, cols), dtype=np.uint8))
+
+
+@pytest.mark.parametrize("case", RECTIFY_CASES)
+def test_true_flow_matches_golden(golden_rectify, oracle, case):
+    g = lambda k: golden_rectify[case + "/" + k]
+    K = tuple(g("K"))
+    for q5 in (0, 1):
+        flow, best = oracle.true_flow(g("world"), g("R2"), g("t2"), *K, q5_mode=q5)
+        assert np.array_equal(best, g("tf_best_q%d" % q5))  # winning scanlines: bit-exact
+        assert np.allclose(flow, g("tf_flow_q%d" % q5), rtol=1e-12, atol=1e-11)  # 4x4 matmul summation order only
+
+
+def test_true_flow_properties(oracle, rsdsfm):
+    """(1) a static camera (identity poses) returns zero flow with winner = the pixel's own row; (2) void pixels give
+    zero flow and winner -1; (3) a pure image-plane shift is recovered; (4) ties keep the FIRST scanline; (5) a point
+    behind / on the camera plane never crashes (non-finite displacements lose every comparison)"""
+    rows, cols = 20, 26
+    K = (50.0, 50.0, 13.0, 10.0)
+    fx, fy, cx, cy = K
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    Z = 2.0 + 0.1 * xx + 0.05 * yy
+    world = np.stack([(xx - cx) / fx, (yy - cy) / fy, np.ones((rows, cols))], axis=2) * Z[:, :, None]
+    world[3, 4] = 0.0
+    R = np.tile(np.eye(3), (rows, 1, 1))
+    t = np.zeros((rows, 3))
+    flow, best = oracle.true_flow(world, R, t, *K, q5_mode=1)
+    assert np.abs(flow).max() < 1e-12 and best[3, 4] == -1 and np.all(flow[3, 4] == 0)
+    exp = np.tile(np.arange(rows)[:, None], (1, cols))
+    exp[3, 4] = -1
+    assert np.array_equal(best, exp)
+    # every scanline has the same pose -> |py - i| is minimised at the row nearest to py; shift by t_y so that py moves
+    t2 = t.copy()
+    t2[:, 1] = 0.1
+    flow2, best2 = oracle.true_flow(world, R, t2, *K, q5_mode=1)
+    m = best2 >= 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        py = (world[:, :, 1] + 0.1) / world[:, :, 2] * fy + cy
+    assert np.array_equal(best2[m], np.argmin(np.abs(py[:, :, None] - np.arange(rows)), axis=2)[m])  # argmin = first minimum
+    assert np.allclose(flow2[:, :, 1][m], (py - yy)[m], atol=1e-12) and np.allclose(flow2[:, :, 0][m], 0, atol=1e-12)
+    # tie: a point exactly half-way between two scanlines (py = 4.5) -> rows 4 and 5 are equally close, 4 wins
+    w1 = np.zeros((1, 1, 3))
+    w1[0, 0] = [0.0, (4.5 - cy) / fy * 4.0, 4.0]
+    _, b = oracle.true_flow(w1, R, t, *K, q5_mode=1)
+    assert b[0, 0] == 4
+    # behind the camera / on the principal plane
+    w2 = np.zeros((1, 2, 3))
+    w2[0, 0] = [0.1, 0.2, 0.0]
+    w2[0, 1] = [0.1, 0.2, -3.0]
+    f, b = oracle.true_flow(w2, R, t, *K, q5_mode=1)
+    assert b[0, 0] == 0 and not np.isfinite(f[0, 0]).all()  # z = 0: inf displacement everywhere, scanline 0 kept
+    assert b[0, 1] >= 0 and np.isfinite(f[0, 1]).all()

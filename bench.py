@@ -12,6 +12,8 @@ Contract: python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on
                                   LM sum rows + ONE all-gather of the depth map over RCCL (scaling "strong").
               rectify           : SURVEY 8(f-1) consumers of the solve on a 1280x720 frame resident in HBM: RS -> GS back
                                   projection (+ float3 world points), crack interpolation, 8-bit depth image.
+              true_flow         : SURVEY 8(f-2) ground-truth flow search (rows x cols x rows scanline projections) of a
+                                  1280x720 frame pair.
               tiled_full        : the WHOLE solve of a 3840x2160 frame split into column slabs over the N ranks
                                   (rsdsfm_tile_* stages, dist.TiledFrameSolve; scaling "strong").
   N > 1     = one process per GPU (torch.distributed / RCCL).  depth / full: each rank solves its own frame pair
@@ -79,7 +81,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify"])
+    ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify", "true_flow"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nbuf", type=int, default=7, help="rotating HBM buffer sets (7 x 59 MB > 256 MiB L3)")
     ap.add_argument("--trials", type=int, default=50, help="RANSAC trials of the full solve (report section 5.4 used 50)")
@@ -284,6 +286,58 @@ def main():
                                       "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                                       "traffic": _traffic("rectify"), "alg_bytes_per_launch": alg, "avg_launch_ms": kern_ms},
                          "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_rectify(img_h, np.array(t["Z"]), R.cpu().numpy(), tt.cpu().numpy(), K, inl_h)})
+
+    # =================================================================================================
+    elif args.workload == "true_flow":
+        # Camera::calculateTrueFlow: every pixel of frame 1 against every scanline pose of frame 2; one pair per GPU
+        data = rsdsfm.synth.make_config(2, seed=0x5EED0002 + rank)
+        rows, cols, K, gamma = data["rows"], data["cols"], data["K"], data["gamma"]
+        npix = rows * cols
+        t = data["truth"]
+        fx, fy, cx, cy = K
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        Z = np.array(t["Z"])
+        wpts = np.stack([(xx - cx) / fx, (yy - cy) / fy, np.ones((rows, cols))], axis=2) * Z[:, :, None]
+        maps = [torch.from_numpy(np.ascontiguousarray(wpts[:, :, c2].T)).to(dev) for c2 in range(3)]
+        R2 = torch.empty((rows, 9), dtype=torch.float64, device=dev)
+        t2 = torch.empty((rows, 3), dtype=torch.float64, device=dev)
+        solver.pose_table_dev(t["v"] * 3.0, t["w"] * 4.0, 0.0, gamma, rows, R2.data_ptr(), t2.data_ptr())
+        t2 += torch.tensor([0.04, 0.02, 0.01], dtype=torch.float64, device=dev)
+        flow = torch.empty((rows, cols, 2), dtype=torch.float64, device=dev)
+        best = torch.empty((rows, cols), dtype=torch.int32, device=dev)
+
+        def step(i):
+            solver.true_flow_dev(maps[0].data_ptr(), maps[1].data_ptr(), maps[2].data_ptr(), rows, cols, R2.data_ptr(), t2.data_ptr(), rows, K,
+                                 flow.data_ptr(), best.data_ptr())
+
+        el = timed(step, args.steps, args.warmup)
+        if rank == 0:
+            ms = el / args.steps * 1e3
+            proj = float(npix) * rows
+            alg = 44 * npix  # 24 B world point read, 16 B flow + 4 B winner written
+            achieved = alg / (ms * 1e-3) / 1e9
+            cpu = None
+            if not (args.no_cpu_baseline or world > 1):
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle_py as O
+
+                sub = 240  # rows of frame 1 searched on the CPU (each pixel against all 720 scanlines)
+                R2h, t2h = R2.cpu().numpy(), t2.cpu().numpy()
+                t0 = time.perf_counter()
+                O.true_flow(wpts[:sub], R2h, t2h, *K)
+                ce = time.perf_counter() - t0
+                cpu = {"value": sub * cols / ce / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "port",
+                       "sample": "%d of the %d image rows (x %d cols x %d scanline projections each) in %.1f s" % (sub, rows, cols, rows, ce)}
+            line.update({"value": npix * world * args.steps / el / 1e6, "ms_per_step": ms, "scaling": "weak",
+                         "metric": "Mpixels/sec ground-truth RS flow search, 1280x720 pair",
+                         "config": {"workload": "SURVEY 8(f-2): calculateTrueFlow of a synthetic 1280x720 pair: every pixel projected with all 720 "
+                                                "scanline poses of frame 2 (6.6e8 projections), argmin |y - scanline|; one pair per GPU",
+                                    "rows": rows, "cols": cols, "projections_per_s": proj / (ms * 1e-3),
+                                    "void_pixels": int((best < 0).sum().item())},
+                         "roofline": {"bound": "hbm", "kernel": "true_flow_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic("true_flow"), "alg_bytes_per_launch": alg, "avg_launch_ms": ms,
+                                      "note": "compute-bound by construction: rows2 x ~30 fp64 VALU instructions per 44 B pixel; see DESIGN"},
+                         "cpu_baseline": cpu})
 
     # =================================================================================================
     elif args.workload == "tiled_full":

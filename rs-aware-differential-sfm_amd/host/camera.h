@@ -60,6 +60,11 @@ public:
                       "rsdsfm_interpolate_cracky");
         return image_out;
     }
+    /** reference camera.cc:209-249: ground-truth flow from frame frameNr1 to frame frameNr2 (unprojection maps of frame 1,
+     *  relative scanline poses of frame 2) */
+    rsdsfm::FlowImage calculateTrueFlow(const int frameNr1, const int frameNr2) {
+        return frames_[(size_t)frameNr2 - 1].trueFlowFrom(frames_[(size_t)frameNr1 - 1]);
+    }
     void setGamma(const double gamma) {
         for (auto& f : frames_) f.setGamma(gamma);
     }

@@ -162,5 +162,22 @@ private:
     std::vector<float> d_;
 };
 
+// stand-in for cv::Mat_<cv::Point_<double>>: row-major rows x cols x (dx, dy)
+class FlowImage {
+public:
+    FlowImage() : r_(0), c_(0) {}
+    FlowImage(int rows, int cols) : r_(rows), c_(cols), d_((size_t)rows * (size_t)cols * 2, 0.0) {}
+    int rows() const { return r_; }
+    int cols() const { return c_; }
+    double* data() { return d_.data(); }
+    const double* data() const { return d_.data(); }
+    double x(int row, int col) const { return d_[((size_t)row * (size_t)c_ + (size_t)col) * 2]; }
+    double y(int row, int col) const { return d_[((size_t)row * (size_t)c_ + (size_t)col) * 2 + 1]; }
+
+private:
+    int r_, c_;
+    std::vector<double> d_;
+};
+
 }  // namespace rsdsfm
 

@@ -27,6 +27,39 @@ public:
     rsdsfm::ImageBGR getGsImage() { return gs_image_; }
     rsdsfm::ImageXYZf get3dCoordinates() { return coordinates_3d_; }
 
+    /** reference rsframe.h:74 takes three CSV paths (file formats are out of scope); this overload takes the loaded maps */
+    bool setUnprojectionMapRs(const rsdsfm::lite::MatrixXd& x, const rsdsfm::lite::MatrixXd& y, const rsdsfm::lite::MatrixXd& z) {
+        unprojection_map_x_ = x, unprojection_map_y_ = y, unprojection_map_z_ = z;
+        return true;
+    }
+    /** reference rsframe.cc:617-625 */
+    rsdsfm::lite::Vector3d getUnprojectedWorldCoordinates(int x, int y) const {
+        return rsdsfm::lite::Vector3d(unprojection_map_x_(y, x), unprojection_map_y_(y, x), unprojection_map_z_(y, x));
+    }
+    /** reference rsframe.cc:740-768: image coordinates of a world point under the best-matching scanline pose */
+    void calculateImageCoordinatesRsFrame(const rsdsfm::lite::Vector3d& Point, double& x_out, double& y_out) const {
+        std::vector<double> R, t;
+        poseTable(R, t);
+        double flow[2] = {0, 0};
+        const double wx = Point(0), wy = Point(1), wz = Point(2);
+        // a 1 x 1 "frame 1" holding the point: flow = projection - (0, 0)
+        rsdsfm::check(rsdsfm_true_flow(rsdsfm::default_context(), &wx, &wy, &wz, 1, 1, R.data(), t.data(), rows_, K_(0, 0), K_(1, 1), K_(0, 2),
+                                       K_(1, 2), q5_mode(), flow, nullptr),
+                      "rsdsfm_true_flow");
+        x_out = flow[0], y_out = flow[1];
+    }
+    /** the search of Camera::calculateTrueFlow (camera.cc:209-249) with this frame as frame 2 */
+    rsdsfm::FlowImage trueFlowFrom(const RsFrame& frame1) const {
+        std::vector<double> R, t;
+        poseTable(R, t);
+        rsdsfm::FlowImage flow(frame1.rows_, frame1.cols_);
+        rsdsfm::check(rsdsfm_true_flow(rsdsfm::default_context(), frame1.unprojection_map_x_.data(), frame1.unprojection_map_y_.data(),
+                                       frame1.unprojection_map_z_.data(), frame1.rows_, frame1.cols_, R.data(), t.data(), rows_, K_(0, 0),
+                                       K_(1, 1), K_(0, 2), K_(1, 2), q5_mode(), flow.data(), nullptr),
+                      "rsdsfm_true_flow");
+        return flow;
+    }
+
     /** reference rsframe.cc:803-839: RS image -> 3-D -> GS image with the per-scanline relative poses */
     void backProject() { backProjectImpl(RSDSFM_BACKPROJECT_RS); }
     /** reference rsframe.cc:842-878: the same with the pose of the first scanline for every pixel */
@@ -53,8 +86,8 @@ public:
     }
 
 private:
-    void backProjectImpl(int mode) {
-        std::vector<double> R((size_t)rows_ * 9), t((size_t)rows_ * 3);
+    void poseTable(std::vector<double>& R, std::vector<double>& t) const {
+        R.resize((size_t)rows_ * 9), t.resize((size_t)rows_ * 3);
         for (int i = 0; i < rows_; ++i) {
             const Scanline& sl = scanlines_[(size_t)i];
             for (int r = 0; r < 3; ++r) {
@@ -62,6 +95,10 @@ private:
                 t[(size_t)i * 3 + (size_t)r] = sl.getRelativeTranslation()(r);
             }
         }
+    }
+    void backProjectImpl(int mode) {
+        std::vector<double> R, t;
+        poseTable(R, t);
         gs_image_ = rsdsfm::ImageBGR(rows_, cols_);
         coordinates_3d_ = rsdsfm::ImageXYZf(rows_, cols_);
         rsdsfm::check(rsdsfm_back_project(rsdsfm::default_context(), image_.data(), depth_map_.data(), R.data(), t.data(), K_(0, 0), K_(1, 1),
@@ -76,6 +113,7 @@ private:
     std::vector<Scanline> scanlines_;
     rsdsfm::ImageBGR image_, gs_image_;
     rsdsfm::ImageXYZf coordinates_3d_;
+    rsdsfm::lite::MatrixXd unprojection_map_x_, unprojection_map_y_, unprojection_map_z_;
 };
 
 #endif

@@ -85,6 +85,24 @@ int main(int argc, char** argv) {
         camera.setImage(1, rs_image);
         camera.frame(1).backProject();
         rsdsfm::ImageBGR backprojection = camera.interpolateCrackyImage(camera.frame(1).getGsImage(), 1);
+        // ground-truth flow (camera.cc:209-249): frame 1 = the estimated structure (world = scanline-0 camera frame), frame 2 =
+        // the same motion one frame later
+        MatrixXd ux(rows, cols), uy(rows, cols), uz(rows, cols);
+        for (int y = 0; y < rows; ++y)
+            for (int x = 0; x < cols; ++x) {
+                const double z = depth_map(y, x);
+                ux(y, x) = z * ((x - cx) * 1.0 / fx), uy(y, x) = z * ((y - cy) * 1.0 / fy), uz(y, x) = z;
+            }
+        camera.frame(1).setUnprojectionMapRs(ux, uy, uz);
+        camera.addFrame(rows, cols);
+        camera.setGamma(gamma);
+        camera.setPose(2, results.k, results.v, results.w);
+        rsdsfm::FlowImage true_flow = camera.calculateTrueFlow(1, 2);
+        double tf_sum = 0;
+        for (int y = 0; y < rows; ++y)
+            for (int x = 0; x < cols; ++x) tf_sum += true_flow.x(y, x) * 3.0 + true_flow.y(y, x);
+        double px1 = 0, py1 = 0;
+        camera.frame(2).calculateImageCoordinatesRsFrame(camera.frame(1).getUnprojectedWorldCoordinates(cols / 3, rows / 2), px1, py1);
         unsigned long long preview_sum = 0, gs_sum = 0, bp_sum = 0;
         for (uint8_t b : depth_est) preview_sum += b;
         {
@@ -100,11 +118,11 @@ int main(int argc, char** argv) {
         std::printf("{\"n\": %lld, \"ransac_inliers\": %d, \"ransac_w\": [%.17g, %.17g, %.17g], \"ransac_v\": [%.17g, %.17g, %.17g], "
                     "\"w\": [%.17g, %.17g, %.17g], \"v\": [%.17g, %.17g, %.17g], \"k\": %.17g, \"flipped\": %d, \"zsum\": %.17g, "
                     "\"ysum\": %lld, \"last_t\": [%.17g, %.17g, %.17g], \"last_R01\": %.17g, \"preview_sum\": %llu, \"gs_sum\": %llu, "
-                    "\"bp_sum\": %llu}\n",
+                    "\"bp_sum\": %llu, \"tf_sum\": %.17g, \"tf_point\": [%.17g, %.17g]}\n",
                     (long long)n, ransac_results.num_inliers, ransac_results.w(0), ransac_results.w(1), ransac_results.w(2), ransac_results.v(0),
                     ransac_results.v(1), ransac_results.v(2), results.w(0), results.w(1), results.w(2), results.v(0), results.v(1),
                     results.v(2), results.k, flipped, zsum, ysum, last.getRelativeTranslation()(0), last.getRelativeTranslation()(1),
-                    last.getRelativeTranslation()(2), last.getRelativeRotation()(0, 1), preview_sum, gs_sum, bp_sum);
+                    last.getRelativeTranslation()(2), last.getRelativeRotation()(0, 1), preview_sum, gs_sum, bp_sum, tf_sum, px1, py1);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -62,6 +62,14 @@ def test_single_run_matches_python_path(tmp_path, rsdsfm, oracle):
     gs_o, _ = oracle.back_project(rs, dm["depth_map"], R, t, *K)
     assert r["preview_sum"] == int(oracle.depth_preview(dm["inliers"], *K, 120, 200).astype(np.uint64).sum())
     assert r["gs_sum"] == wsum(gs_o) and r["bp_sum"] == wsum(oracle.interpolate_cracky(gs_o, 1))
+    # ground-truth flow of the estimated structure under the estimated motion (Camera::calculateTrueFlow)
+    dmm = dm["depth_map"]
+    yy, xx = np.mgrid[0:120, 0:200]
+    wpts = np.stack([dmm * ((xx - K[2]) * 1.0 / K[0]), dmm * ((yy - K[3]) * 1.0 / K[1]), dmm], axis=2)
+    flow_o, _ = oracle.true_flow(wpts, R, t, *K)
+    assert np.isclose(r["tf_sum"], float((flow_o[:, :, 0] * 3.0 + flow_o[:, :, 1]).sum()), rtol=1e-12)
+    one, _ = oracle.true_flow(wpts[60:61, 66:67], R, t, *K)
+    assert np.array_equal(r["tf_point"], one[0, 0])
     # and the oracle agrees with the whole chain (same sampler, same seed)
     ro = oracle.ransac(q, u, a, ak, False, T, tol, oracle.sample_indices(len(q), T, seed), depth_mode=1)
     assert ro["num_inliers"] == r["ransac_inliers"]

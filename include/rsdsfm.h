@@ -362,6 +362,34 @@ int rsdsfm_true_flow_dev(rsdsfm_ctx* ctx, const double* d_world_x, const double*
                          double fx, double fy, double cx, double cy, int q5_mode, double* d_flow,
                          int32_t* d_best_row_or_null);
 
+/* ---- accuracy metrics ---------------------------------------------------------------------------
+ * rotation / translation error of evaluateVelocities (errorMeasure.cpp:178-186): host-only scalar math, no context. */
+int rsdsfm_velocity_errors(const double w_est[3], const double v_est[3], const double w_true[3], const double v_true[3],
+                           double* w_error, double* v_error);
+
+typedef struct rsdsfm_reprojection_stats {
+    double scale;             /* mean accepted ratio estimate / truth (camera.cc:659-667)                */
+    double mean_error;        /* Camera::meanReprojectionError's return value (camera.cc:690)            */
+    double sum_error;
+    int64_t number_outliers;  /* coordinates with |ratio| > 10                                           */
+    int64_t scale_inliers;    /* ratios that are non-zero and not NaN                                    */
+    int64_t error_inliers;    /* points with finite coordinates and error < 50                           */
+} rsdsfm_reprojection_stats;
+
+/* Camera::meanReprojectionError (camera.cc:594-691) and, when error_image is given, Camera::createErrorImage
+ * (camera.cc:503-591; error_image(y, x) = (char)int(error * 255 / max_norm + 0.5), rows x cols bytes row-major).
+ * est_coords: rows x cols x 3 floats (what rsdsfm_back_project writes); gt_depth / est_depth: column-major rows x cols
+ * (a ground-truth depth of exactly 0 falls back to the estimated depth, the reference's planeToSpace default argument,
+ * rsframe.cc:657); R_abs / t_abs: ABSOLUTE pose of every scanline after RsFrame::relocatePose.  Synchronises. */
+int rsdsfm_reprojection_error(rsdsfm_ctx* ctx, const float* est_coords, const double* gt_depth_colmajor,
+                              const double* est_depth_colmajor, const double* R_abs_rows9, const double* t_abs_rows3, double fx,
+                              double fy, double cx, double cy, int32_t rows, int32_t cols, double max_norm,
+                              rsdsfm_reprojection_stats* stats, uint8_t* error_image_or_null);
+int rsdsfm_reprojection_error_dev(rsdsfm_ctx* ctx, const float* d_est_coords, const double* d_gt_depth_colmajor,
+                                  const double* d_est_depth_colmajor, const double* d_R_abs_rows9, const double* d_t_abs_rows3,
+                                  double fx, double fy, double cx, double cy, int32_t rows, int32_t cols, double max_norm,
+                                  rsdsfm_reprojection_stats* stats, uint8_t* d_error_image_or_null);
+
 #ifdef __cplusplus
 }
 #endif

@@ -297,3 +297,31 @@ def true_flow(world_xyz, R2, t2, fx, fy, cx, cy, q5_mode=0):
     d = C.c_double
     lib().rso_true_flow(_p(maps[0]), _p(maps[1]), _p(maps[2]), C.c_int32(rows), C.c_int32(cols), _p(R2), _p(t2), C.c_int32(rows2), d(fx), d(fy), d(cx), d(cy), int(q5_mode), _p(flow), _p(best))
     return flow, best
+
+
+class ReprojectionStats(C.Structure):
+    _fields_ = [("scale", C.c_double), ("mean_error", C.c_double), ("sum_error", C.c_double), ("number_outliers", C.c_int64),
+                ("scale_inliers", C.c_int64), ("error_inliers", C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def velocity_errors(w_est, v_est, w_true, v_true):
+    we, ve = C.c_double(), C.c_double()
+    lib().rso_velocity_errors(_v3(w_est), _v3(v_est), _v3(w_true), _v3(v_true), C.byref(we), C.byref(ve))
+    return we.value, ve.value
+
+
+def reprojection_error(est_coords, gt_depth, est_depth, R_abs, t_abs, fx, fy, cx, cy, max_norm=10.0, want_image=True):
+    """est_coords: (rows, cols, 3) float32; depth maps: (rows, cols); R_abs: (rows, 3, 3) / (rows, 9); t_abs: (rows, 3)"""
+    est = np.ascontiguousarray(est_coords, dtype=np.float32)
+    rows, cols = est.shape[:2]
+    gd = np.ascontiguousarray(np.asarray(gt_depth, dtype=np.float64).T)
+    ed = np.ascontiguousarray(np.asarray(est_depth, dtype=np.float64).T)
+    R, t = _f64(np.asarray(R_abs).reshape(rows, 9)), _f64(t_abs)
+    st = ReprojectionStats()
+    img = np.zeros((rows, cols), dtype=np.uint8) if want_image else None
+    d = C.c_double
+    lib().rso_reprojection_error(_p(est), _p(gd), _p(ed), _p(R), _p(t), d(fx), d(fy), d(cx), d(cy), C.c_int32(rows), C.c_int32(cols), d(max_norm), C.byref(st), None if img is None else _p(img))
+    return st.as_dict(), img

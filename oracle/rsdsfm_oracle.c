@@ -1514,3 +1514,94 @@ void rso_true_flow(const double* wx, const double* wy, const double* wz, int32_t
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* accuracy metrics (errorMeasure.cpp:178-186, camera.cc:503-691)                    */
+/* ------------------------------------------------------------------------------------------------ */
+void rso_velocity_errors(const double w[3], const double v[3], const double wt[3], const double vt[3], double* w_error,
+                         double* v_error) {
+    const double A[9] = {1, -w[2], w[1], w[2], 1, -w[0], -w[1], w[0], 1};         /* results_w_rot */
+    const double B[9] = {1, -wt[2], wt[1], wt[2], 1, -wt[0], -wt[1], wt[0], 1};   /* true_rot      */
+    double E[9];                                                                   /* A * B^T       */
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) E[i * 3 + j] = (A[i * 3] * B[j * 3] + A[i * 3 + 1] * B[j * 3 + 1]) + A[i * 3 + 2] * B[j * 3 + 2];
+    *w_error = sqrt((E[7] * E[7] + E[2] * E[2]) + E[3] * E[3]); /* (2,1), (0,2), (1,0) */
+    const double dot = (v[0] * vt[0] + v[1] * vt[1]) + v[2] * vt[2];
+    const double nv = sqrt((v[0] * v[0] + v[1] * v[1]) + v[2] * v[2]);
+    const double nt = sqrt((vt[0] * vt[0] + vt[1] * vt[1]) + vt[2] * vt[2]);
+    *v_error = acos(dot / (nv * nt));
+}
+
+/* ground-truth world point of pixel (x, y) as the reference stores it (float) */
+static void rso_true_point(const double* gt_depth, const double* est_depth, const double* R, const double* t, double fx, double fy,
+                           double cx, double cy, int32_t rows, int32_t x, int32_t y, float out[3]) {
+    double z = gt_depth[(int64_t)x * rows + y];
+    if (z == 0) z = est_depth[(int64_t)x * rows + y]; /* planeToSpace's default-argument fallback (rsframe.cc:657) */
+    const double nx = ((double)x - cx) * 1.0 / fx, ny = ((double)y - cy) * 1.0 / fy;
+    const double pc[3] = {z * nx, z * ny, z * 1.0};
+    const double* Rs = R + (int64_t)y * 9;
+    const double* ts = t + (int64_t)y * 3;
+    for (int i = 0; i < 3; ++i) {
+        double rt0 = Rs[i], rt1 = Rs[3 + i], rt2 = Rs[6 + i];
+        double ti = ((-rt0) * ts[0] + (-rt1) * ts[1]) + (-rt2) * ts[2];
+        out[i] = (float)(((rt0 * pc[0] + rt1 * pc[1]) + rt2 * pc[2]) + ti * 1.0);
+    }
+}
+
+void rso_reprojection_error(const float* est, const double* gt_depth, const double* est_depth, const double* R, const double* t,
+                            double fx, double fy, double cx, double cy, int32_t rows, int32_t cols, double max_norm,
+                            rso_reprojection_stats* st, uint8_t* error_image) {
+    double sum = 0;
+    int64_t inliers = 0, outliers = 0;
+    for (int32_t x = 0; x < cols; ++x)
+        for (int32_t y = 0; y < rows; ++y) {
+            float pt[3];
+            rso_true_point(gt_depth, est_depth, R, t, fx, fy, cx, cy, rows, x, y, pt);
+            const float* pe = est + ((int64_t)y * cols + x) * 3;
+            for (int c = 0; c < 3; ++c) {
+                float ratio = pe[c] / pt[c];
+                double sc = (double)ratio;
+                if (fabsf(ratio) > 10) {
+                    sc = 0;
+                    outliers++;
+                }
+                if (sc != 0 && sc == sc) {
+                    inliers++;
+                    sum += sc;
+                }
+            }
+        }
+    const double scale = sum / (double)inliers;
+    double sum_error = 0;
+    int64_t err_inl = 0;
+    for (int32_t x = 0; x < cols; ++x)
+        for (int32_t y = 0; y < rows; ++y) {
+            float pt[3];
+            rso_true_point(gt_depth, est_depth, R, t, fx, fy, cx, cy, rows, x, y, pt);
+            const float* pe = est + ((int64_t)y * cols + x) * 3;
+            double e[3], tr[3], d[3];
+            for (int c = 0; c < 3; ++c) {
+                e[c] = pe[c] / scale;
+                tr[c] = pt[c];
+                d[c] = e[c] - tr[c];
+            }
+            const double norm = sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);
+            if (e[0] == e[0] && e[1] == e[1] && e[2] == e[2] && tr[0] == tr[0] && tr[1] == tr[1] && tr[2] == tr[2]) {
+                if (norm < 50) {
+                    sum_error += norm;
+                    err_inl++;
+                }
+            }
+            if (error_image) {
+                int v = rso_trunc_int(norm * 255 / max_norm + 0.5);
+                if (v == INT32_MIN) v = 0;
+                error_image[(int64_t)y * cols + x] = (uint8_t)v;
+            }
+        }
+    st->scale = scale;
+    st->sum_error = sum_error;
+    st->mean_error = sum_error * 1.0 / (double)err_inl;
+    st->number_outliers = outliers;
+    st->scale_inliers = inliers;
+    st->error_inliers = err_inl;
+}

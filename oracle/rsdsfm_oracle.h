@@ -169,6 +169,35 @@ void rso_true_flow(const double* world_x, const double* world_y, const double* w
                    const double* R2_rows9, const double* t2_rows3, int32_t rows2, double fx, double fy, double cx,
                    double cy, int q5_mode, double* flow_rowmajor, int32_t* best_row_or_null);
 
+/* ---- accuracy metrics ------------------------------------------------------------------- */
+/* errorMeasure.cpp:178-186: rotation error = || vee( (I + [w_est]x) (I + [w_true]x)^T ) ||, translation error = angle
+ * between v_est and v_true (acos of the normalised dot product). */
+void rso_velocity_errors(const double w_est[3], const double v_est[3], const double w_true[3], const double v_true[3],
+                         double* w_error, double* v_error);
+
+typedef struct rso_reprojection_stats {
+    double scale;             /* mean of the accepted per-coordinate ratios estimate / truth (camera.cc:659-667)       */
+    double mean_error;        /* sum_error / error_inliers (camera.cc:690); NaN when nothing qualifies                 */
+    double sum_error;
+    int64_t number_outliers;  /* coordinates with |ratio| > 10 (camera.cc:643-654)                                     */
+    int64_t scale_inliers;    /* ratios that are non-zero and not NaN                                                  */
+    int64_t error_inliers;    /* points with finite coordinates and error < 50                                         */
+} rso_reprojection_stats;
+
+/* Camera::meanReprojectionError (camera.cc:594-691) and Camera::createErrorImage (camera.cc:503-591) share their first
+ * two passes: ground-truth world point of every pixel (planeToSpace with the ground-truth depth -- quirk: a ground-
+ * truth depth of exactly 0 makes planeToSpace fall back to the ESTIMATED depth map, rsframe.cc:657 -- then
+ * cameraToWorldFrame with the ABSOLUTE pose of the pixel's scanline, after relocatePose), stored as float like the
+ * reference's cv::Vec3f; per-coordinate float ratios estimate / truth, outliers |ratio| > 10 zeroed, mean of the
+ * rest = scale; then the Euclidean error of estimate / scale against the truth, summed where finite and < 50.
+ * est_coords: rows x cols x 3 floats (RsFrame::get3dCoordinates); depth maps column-major rows x cols; R/t: absolute
+ * per-scanline poses.  error_image (may be NULL): rows x cols bytes, (char)int(error * 255 / max_norm + 0.5); a
+ * non-finite value is defined as 0 (undefined behaviour in the reference).  Pixels are visited x outer, y inner. */
+void rso_reprojection_error(const float* est_coords, const double* gt_depth_colmajor, const double* est_depth_colmajor,
+                            const double* R_abs_rows9, const double* t_abs_rows3, double fx, double fy, double cx,
+                            double cy, int32_t rows, int32_t cols, double max_norm, rso_reprojection_stats* stats,
+                            uint8_t* error_image_or_null);
+
 /* exposed for direct testing of the restated third-party pieces */
 void rso_jacobi_svd9(const double Z_rowmajor[81], double sv[9], double V_rowmajor[81]);
 int rso_eigvals_general(const double* A_rowmajor, int n, double* re, double* im);

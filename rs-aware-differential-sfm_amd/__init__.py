@@ -550,3 +550,50 @@ class _TrueFlowMixin:
 for _name, _fn in list(vars(_TrueFlowMixin).items()):
     if not _name.startswith("__"):
         setattr(Solver, _name, _fn)
+
+
+# ---------------------------------------------------------------------------------------------------
+# accuracy metrics
+# ---------------------------------------------------------------------------------------------------
+class ReprojectionStats(C.Structure):
+    _fields_ = [("scale", C.c_double), ("mean_error", C.c_double), ("sum_error", C.c_double), ("number_outliers", C.c_int64),
+                ("scale_inliers", C.c_int64), ("error_inliers", C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def velocity_errors(w_est, v_est, w_true, v_true):
+    """(rotation error, translation angle) of errorMeasure.cpp:178-186 -- host-only scalar math through the C ABI"""
+    lib = load_library()
+    we, ve = C.c_double(), C.c_double()
+    rc = lib.rsdsfm_velocity_errors(_v3(w_est), _v3(v_est), _v3(w_true), _v3(v_true), C.byref(we), C.byref(ve))
+    if rc != OK:
+        raise RsdsfmError("rsdsfm_velocity_errors failed (%d)" % rc)
+    return we.value, ve.value
+
+
+class _MetricsMixin:
+    def reprojection_error(self, est_coords, gt_depth, est_depth, R_abs, t_abs, K, max_norm=10.0, want_image=True):
+        """Camera::meanReprojectionError (+ createErrorImage).  est_coords: (rows, cols, 3) float32; depth maps (rows, cols)."""
+        est = np.ascontiguousarray(est_coords, dtype=np.float32)
+        rows, cols = est.shape[:2]
+        gd = np.ascontiguousarray(np.asarray(gt_depth, dtype=np.float64).T)
+        ed = np.ascontiguousarray(np.asarray(est_depth, dtype=np.float64).T)
+        Rr, tt = _f64(np.asarray(R_abs).reshape(rows, 9)), _f64(t_abs)
+        st = ReprojectionStats()
+        img = np.zeros((rows, cols), dtype=np.uint8) if want_image else None
+        d = C.c_double
+        self._check(self.lib.rsdsfm_reprojection_error(self._ctx, _p(est), _p(gd), _p(ed), _p(Rr), _p(tt), d(K[0]), d(K[1]), d(K[2]), d(K[3]), C.c_int32(rows), C.c_int32(cols), d(max_norm), C.byref(st), _p(img)), "rsdsfm_reprojection_error")
+        return st.as_dict(), img
+
+    def reprojection_error_dev(self, d_est, d_gt_depth, d_est_depth, d_R, d_t, K, rows, cols, max_norm=10.0, d_error_image=None):
+        st = ReprojectionStats()
+        d = C.c_double
+        self._check(self.lib.rsdsfm_reprojection_error_dev(self._ctx, _dp(d_est), _dp(d_gt_depth), _dp(d_est_depth), _dp(d_R), _dp(d_t), d(K[0]), d(K[1]), d(K[2]), d(K[3]), C.c_int32(rows), C.c_int32(cols), d(max_norm), C.byref(st), _dp(d_error_image) if d_error_image else None), "rsdsfm_reprojection_error_dev")
+        return st.as_dict()
+
+
+for _name, _fn in list(vars(_MetricsMixin).items()):
+    if not _name.startswith("__"):
+        setattr(Solver, _name, _fn)

@@ -65,6 +65,14 @@ public:
     rsdsfm::FlowImage calculateTrueFlow(const int frameNr1, const int frameNr2) {
         return frames_[(size_t)frameNr2 - 1].trueFlowFrom(frames_[(size_t)frameNr1 - 1]);
     }
+    /** reference camera.cc:594-691 */
+    double meanReprojectionError(const int frameNr) { return frames_[(size_t)frameNr - 1].reprojectionError(10.0, nullptr).mean_error; }
+    /** reference camera.cc:503-591: rows x cols bytes, row-major (cv::Mat CV_8U) */
+    std::vector<unsigned char> createErrorImage(const int frameNr, const double max_norm) {
+        std::vector<unsigned char> img;
+        frames_[(size_t)frameNr - 1].reprojectionError(max_norm, &img);
+        return img;
+    }
     void setGamma(const double gamma) {
         for (auto& f : frames_) f.setGamma(gamma);
     }

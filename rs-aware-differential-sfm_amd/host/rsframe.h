@@ -6,6 +6,7 @@
 #ifndef RSDSFM_HOST_RSFRAME_H
 #define RSDSFM_HOST_RSFRAME_H
 
+#include <cmath>
 #include <vector>
 
 #include "minimal.h"
@@ -26,6 +27,65 @@ public:
     rsdsfm::ImageBGR getRsImage() { return image_; }
     rsdsfm::ImageBGR getGsImage() { return gs_image_; }
     rsdsfm::ImageXYZf get3dCoordinates() { return coordinates_3d_; }
+
+    Scanline& scanline(int i) { return scanlines_[(size_t)i]; }  // absolute poses are set per scanline (reference: setPoses from CSV)
+
+    /** reference rsframe.cc:416-436: ground-truth depth of every RS pixel from the unprojection maps and the ABSOLUTE poses */
+    rsdsfm::lite::MatrixXd getGroundtruthDepthMap() const {
+        rsdsfm::lite::MatrixXd z = rsdsfm::lite::MatrixXd::Zero(rows_, cols_);
+        for (int y = 0; y < rows_; ++y) {
+            const rsdsfm::lite::Matrix3d& R = scanlines_[(size_t)y].getRotation();
+            const rsdsfm::lite::Vector3d& t = scanlines_[(size_t)y].getTranslation();
+            for (int x = 0; x < cols_; ++x) {
+                const double X = unprojection_map_x_(y, x), Y = unprojection_map_y_(y, x), Z = unprojection_map_z_(y, x);
+                if (std::sqrt((X * X + Y * Y) + Z * Z) > 0) z(y, x) = ((R(2, 0) * X + R(2, 1) * Y) + R(2, 2) * Z) + t(2) * 1.0;
+            }
+        }
+        return z;
+    }
+    /** reference rsframe.cc:951-967: first scanline becomes the origin (translation subtracted, rotation left-multiplied by
+     *  the inverse of the first orientation; 3x3 inverse by cofactors like Eigen's fixed-size inverse) */
+    void relocatePose() {
+        const rsdsfm::lite::Vector3d p0 = scanlines_[0].getTranslation();
+        const rsdsfm::lite::Matrix3d A = scanlines_[0].getRotation();
+        rsdsfm::lite::Matrix3d inv;
+        const double c00 = A(1, 1) * A(2, 2) - A(1, 2) * A(2, 1), c10 = A(1, 2) * A(2, 0) - A(1, 0) * A(2, 2), c20 = A(1, 0) * A(2, 1) - A(1, 1) * A(2, 0);
+        const double invdet = 1.0 / ((A(0, 0) * c00 + A(0, 1) * c10) + A(0, 2) * c20);
+        inv(0, 0) = c00 * invdet, inv(1, 0) = c10 * invdet, inv(2, 0) = c20 * invdet;
+        inv(0, 1) = (A(0, 2) * A(2, 1) - A(0, 1) * A(2, 2)) * invdet, inv(1, 1) = (A(0, 0) * A(2, 2) - A(0, 2) * A(2, 0)) * invdet;
+        inv(2, 1) = (A(2, 0) * A(0, 1) - A(0, 0) * A(2, 1)) * invdet;
+        inv(0, 2) = (A(0, 1) * A(1, 2) - A(0, 2) * A(1, 1)) * invdet, inv(1, 2) = (A(1, 0) * A(0, 2) - A(0, 0) * A(1, 2)) * invdet;
+        inv(2, 2) = (A(0, 0) * A(1, 1) - A(1, 0) * A(0, 1)) * invdet;
+        for (int i = 1; i < rows_; ++i) {
+            Scanline& sl = scanlines_[(size_t)i];
+            const rsdsfm::lite::Vector3d ti = sl.getTranslation();
+            sl.setTranslation(rsdsfm::lite::Vector3d(ti(0) - p0(0), ti(1) - p0(1), ti(2) - p0(2)));
+            const rsdsfm::lite::Matrix3d Ri = sl.getRotation();
+            rsdsfm::lite::Matrix3d out;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) out(r, c) = (inv(r, 0) * Ri(0, c) + inv(r, 1) * Ri(1, c)) + inv(r, 2) * Ri(2, c);
+            sl.setRotation(out);
+        }
+    }
+    /** Camera::meanReprojectionError / createErrorImage (camera.cc:503-691) for this frame; error_image may be null */
+    rsdsfm_reprojection_stats reprojectionError(double max_norm, std::vector<unsigned char>* error_image) const {
+        RsFrame frame = *this;  // the reference works on a copy and relocates its poses (camera.cc:595, :612)
+        const rsdsfm::lite::MatrixXd real_depth_map = frame.getGroundtruthDepthMap();
+        frame.relocatePose();
+        std::vector<double> R((size_t)rows_ * 9), t((size_t)rows_ * 3);
+        for (int i = 0; i < rows_; ++i)
+            for (int r = 0; r < 3; ++r) {
+                for (int c = 0; c < 3; ++c) R[(size_t)i * 9 + (size_t)(r * 3 + c)] = frame.scanlines_[(size_t)i].getRotation()(r, c);
+                t[(size_t)i * 3 + (size_t)r] = frame.scanlines_[(size_t)i].getTranslation()(r);
+            }
+        rsdsfm_reprojection_stats st;
+        if (error_image) error_image->assign((size_t)rows_ * (size_t)cols_, 0);
+        rsdsfm::check(rsdsfm_reprojection_error(rsdsfm::default_context(), coordinates_3d_.data(), real_depth_map.data(), depth_map_.data(), R.data(),
+                                                t.data(), K_(0, 0), K_(1, 1), K_(0, 2), K_(1, 2), rows_, cols_, max_norm, &st,
+                                                error_image ? error_image->data() : nullptr),
+                      "rsdsfm_reprojection_error");
+        return st;
+    }
 
     /** reference rsframe.h:74 takes three CSV paths (file formats are out of scope); this overload takes the loaded maps */
     bool setUnprojectionMapRs(const rsdsfm::lite::MatrixXd& x, const rsdsfm::lite::MatrixXd& y, const rsdsfm::lite::MatrixXd& z) {

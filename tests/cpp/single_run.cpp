@@ -103,6 +103,22 @@ int main(int argc, char** argv) {
             for (int x = 0; x < cols; ++x) tf_sum += true_flow.x(y, x) * 3.0 + true_flow.y(y, x);
         double px1 = 0, py1 = 0;
         camera.frame(2).calculateImageCoordinatesRsFrame(camera.frame(1).getUnprojectedWorldCoordinates(cols / 3, rows / 2), px1, py1);
+        // accuracy metrics (main.cc:533-556 / errorMeasure.cpp:178-186): ground truth = the estimate's own geometry under
+        // slightly different absolute poses (frame 1 keeps its unprojection maps; absolute pose of scanline i = 1.02 x relative)
+        for (int i = 0; i < rows; ++i) {
+            const Scanline& sl = camera.frame(1).getScanline(i);
+            Matrix3d Ra = sl.getRelativeRotation();
+            camera.frame(1).scanline(i).setRotation(Ra);
+            camera.frame(1).scanline(i).setTranslation(Vector3d(sl.getRelativeTranslation()(0) * 1.02, sl.getRelativeTranslation()(1) * 1.02,
+                                                                  sl.getRelativeTranslation()(2) * 1.02));
+        }
+        const double mean_reproj = camera.meanReprojectionError(1);
+        std::vector<unsigned char> err_img = camera.createErrorImage(1, 0.05);
+        unsigned long long err_img_sum = 0;
+        for (unsigned char b : err_img) err_img_sum += b;
+        double w_err = 0, v_err = 0;
+        rsdsfm::check(rsdsfm_velocity_errors(results.w.data(), results.v.data(), ransac_results.w.data(), ransac_results.v.data(), &w_err, &v_err),
+                      "rsdsfm_velocity_errors");
         unsigned long long preview_sum = 0, gs_sum = 0, bp_sum = 0;
         for (uint8_t b : depth_est) preview_sum += b;
         {
@@ -118,11 +134,12 @@ int main(int argc, char** argv) {
         std::printf("{\"n\": %lld, \"ransac_inliers\": %d, \"ransac_w\": [%.17g, %.17g, %.17g], \"ransac_v\": [%.17g, %.17g, %.17g], "
                     "\"w\": [%.17g, %.17g, %.17g], \"v\": [%.17g, %.17g, %.17g], \"k\": %.17g, \"flipped\": %d, \"zsum\": %.17g, "
                     "\"ysum\": %lld, \"last_t\": [%.17g, %.17g, %.17g], \"last_R01\": %.17g, \"preview_sum\": %llu, \"gs_sum\": %llu, "
-                    "\"bp_sum\": %llu, \"tf_sum\": %.17g, \"tf_point\": [%.17g, %.17g]}\n",
+                    "\"bp_sum\": %llu, \"tf_sum\": %.17g, \"tf_point\": [%.17g, %.17g], \"mean_reproj\": %.17g, \"err_img_sum\": %llu, "
+                    "\"w_err\": %.17g, \"v_err\": %.17g}\n",
                     (long long)n, ransac_results.num_inliers, ransac_results.w(0), ransac_results.w(1), ransac_results.w(2), ransac_results.v(0),
                     ransac_results.v(1), ransac_results.v(2), results.w(0), results.w(1), results.w(2), results.v(0), results.v(1),
                     results.v(2), results.k, flipped, zsum, ysum, last.getRelativeTranslation()(0), last.getRelativeTranslation()(1),
-                    last.getRelativeTranslation()(2), last.getRelativeRotation()(0, 1), preview_sum, gs_sum, bp_sum, tf_sum, px1, py1);
+                    last.getRelativeTranslation()(2), last.getRelativeRotation()(0, 1), preview_sum, gs_sum, bp_sum, tf_sum, px1, py1, mean_reproj, err_img_sum, w_err, v_err);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

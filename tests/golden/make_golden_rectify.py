@@ -146,6 +146,57 @@ def true_flow_np(world, R2, t2, K, q5_fixed):
     return flow, best
 
 
+def velocity_errors_np(w, v, wt, vt):
+    """errorMeasure.cpp:178-186"""
+    A, B = np.eye(3) + skew(w), np.eye(3) + skew(wt)
+    E = A @ B.T
+    return float(np.linalg.norm([E[2, 1], E[0, 2], E[1, 0]])), float(np.arccos(np.dot(v, vt) / (np.linalg.norm(v) * np.linalg.norm(vt))))
+
+
+def reprojection_np(est, gt_depth, est_depth, R, t, K, max_norm):
+    """Camera::meanReprojectionError / createErrorImage (camera.cc:503-691), sequential like the reference"""
+    fx, fy, cx, cy = K
+    rows, cols = gt_depth.shape
+    true = np.zeros((rows, cols, 3), dtype=np.float32)
+    for x in range(cols):
+        for y in range(rows):
+            z = gt_depth[y, x]
+            if z == 0:
+                z = est_depth[y, x]
+            pc = z * np.array([(x - cx) * 1.0 / fx, (y - cy) * 1.0 / fy, 1.0])
+            Pinv = np.eye(4)
+            Pinv[:3, :3] = R[y].T
+            Pinv[:3, 3] = -(R[y].T) @ t[y]
+            true[y, x] = (Pinv @ np.append(pc, 1.0))[:3].astype(np.float32)
+    s, inl, outl = 0.0, 0, 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for x in range(cols):
+            for y in range(rows):
+                for c in range(3):
+                    ratio = np.float32(est[y, x, c]) / np.float32(true[y, x, c])
+                    sc = float(ratio)
+                    if abs(ratio) > 10:
+                        sc = 0.0
+                        outl += 1
+                    if sc != 0 and sc == sc:
+                        inl += 1
+                        s += sc
+        scale = s / float(inl) if inl else float("nan")
+        se, einl = 0.0, 0
+        img = np.zeros((rows, cols), dtype=np.uint8)
+        for x in range(cols):
+            for y in range(rows):
+                e = est[y, x].astype(np.float64) / scale
+                tr = true[y, x].astype(np.float64)
+                n = float(np.sqrt(((e - tr) ** 2).sum()))
+                if not np.isnan(e).any() and not np.isnan(tr).any() and n < 50:
+                    se += n
+                    einl += 1
+                v = to_int(n * 255 / max_norm + 0.5)
+                img[y, x] = (0 if v == -(2 ** 31) else v) % 256
+    return dict(scale=scale, sum_error=se, mean_error=se / einl if einl else float("nan"), number_outliers=outl, scale_inliers=inl, error_inliers=einl), img
+
+
 def texture(rows, cols, seed):
     """deterministic BGR test image: smooth colour ramps + a checker, dark (black) patches, a few marker pixels"""
     r = synth.splitmix64(seed, rows * cols).reshape(rows, cols)
@@ -196,6 +247,18 @@ def main():
         for q5 in (0, 1):
             fl, bst = true_flow_np(world, R2, t2, K, bool(q5))
             out[g("tf_flow_q%d" % q5)], out[g("tf_best_q%d" % q5)] = fl, bst
+        # accuracy metrics: the back-projected points (estimate, arbitrary scale 1.7) against a ground truth with slightly
+        # different depth and absolute poses; a few ground-truth zeros exercise the planeToSpace fallback
+        gt_depth = np.array(t_["Z"]) * (1.0 + 0.02 * np.sin(0.3 * xx) * np.cos(0.2 * yy))
+        gt_depth[(synth.splitmix64(99, rows * cols).reshape(rows, cols) % np.uint64(29)) == 0] = 0.0
+        R_abs, t_abs = pose_table_np(vv * 1.05, ww * 0.97, k, gamma, rows)
+        est = (out[g("c3_m0")].astype(np.float64) * 1.7).astype(np.float32)
+        st, eimg = reprojection_np(est, gt_depth, depth, R_abs, t_abs, K, 10.0)
+        out[g("gt_depth")], out[g("R_abs")], out[g("t_abs")], out[g("est_coords")] = gt_depth, R_abs, t_abs, est
+        out[g("reproj_stats")] = np.array([st["scale"], st["mean_error"], st["sum_error"], st["number_outliers"], st["scale_inliers"], st["error_inliers"]])
+        out[g("error_image")] = eimg
+        we, ve = velocity_errors_np(ww * 0.97, vv * 1.05 + np.array([0.01, 0, 0]), ww, vv)
+        out[g("vel_errors")] = np.array([we, ve])
     np.savez_compressed(os.path.join(HERE, "golden_rectify_v1.npz"), **out)
     print("wrote golden_rectify_v1.npz:", {k2: v2.shape for k2, v2 in out.items() if hasattr(v2, "shape")})
 

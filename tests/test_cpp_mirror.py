@@ -70,6 +70,17 @@ def test_single_run_matches_python_path(tmp_path, rsdsfm, oracle):
     assert np.isclose(r["tf_sum"], float((flow_o[:, :, 0] * 3.0 + flow_o[:, :, 1]).sum()), rtol=1e-12)
     one, _ = oracle.true_flow(wpts[60:61, 66:67], R, t, *K)
     assert np.array_equal(r["tf_point"], one[0, 0])
+    # accuracy metrics through the mirror: ground-truth depth from the unprojection maps and the absolute poses
+    # (getGroundtruthDepthMap), relocatePose, then meanReprojectionError / createErrorImage on the GPU
+    t_abs = t * 1.02
+    _, c3 = oracle.back_project(rs, dmm, R, t, *K)
+    gt_depth = np.where(np.sqrt((wpts ** 2).sum(axis=2)) > 0, (R[:, 2, :][:, None, :] * wpts).sum(axis=2) + t_abs[:, 2][:, None], 0.0)
+    R_rel, t_rel = R.copy(), t_abs - t_abs[0]  # relocatePose: scanline 0 is the identity here, so only the subtraction acts
+    st_o, eimg_o = oracle.reprojection_error(c3, gt_depth, dmm, R_rel, t_rel, *K, max_norm=0.05)
+    assert np.isclose(r["mean_reproj"], st_o["mean_error"], rtol=1e-9)
+    assert abs(r["err_img_sum"] - int(eimg_o.astype(np.uint64).sum())) <= 255 * 3  # scale differs in the last bits only
+    we, ve = oracle.velocity_errors(ref["w"], dm["v"], rr["w"], rr["v"])
+    assert np.isclose(r["w_err"], we, rtol=1e-12) and np.isclose(r["v_err"], ve, rtol=1e-9, atol=1e-12)
     # and the oracle agrees with the whole chain (same sampler, same seed)
     ro = oracle.ransac(q, u, a, ak, False, T, tol, oracle.sample_indices(len(q), T, seed), depth_mode=1)
     assert ro["num_inliers"] == r["ransac_inliers"]

@@ -207,3 +207,61 @@ def test_true_flow_degenerate_points_and_errors(oracle, rsdsfm):
             s.true_flow(w, R[:0], t[:0], K)
         with pytest.raises(rsdsfm.RsdsfmError):
             s.true_flow(w, R, t, K, q5_mode=3)
+
+
+# ---------------------------------------------------------------------------------------------------
+# accuracy metrics
+# ---------------------------------------------------------------------------------------------------
+def _close_stats(a, b):
+    assert (a["number_outliers"], a["scale_inliers"], a["error_inliers"]) == (b["number_outliers"], b["scale_inliers"], b["error_inliers"])
+    for key in ("scale", "mean_error", "sum_error"):  # global sums: summation order only
+        assert np.isclose(a[key], b[key], rtol=1e-11, equal_nan=True), key
+
+
+@pytest.mark.parametrize("case", RECTIFY_CASES)
+def test_metrics_match_golden(golden_rectify, rsdsfm, case):
+    g = lambda k: golden_rectify[case + "/" + k]
+    with rsdsfm.Solver(0) as s:
+        st, img = s.reprojection_error(g("est_coords"), g("gt_depth"), g("depth"), g("R_abs"), g("t_abs"), tuple(g("K")), max_norm=10.0)
+    ref = g("reproj_stats")
+    _close_stats(st, dict(scale=ref[0], mean_error=ref[1], sum_error=ref[2], number_outliers=int(ref[3]), scale_inliers=int(ref[4]), error_inliers=int(ref[5])))
+    assert np.array_equal(img, g("error_image"))
+    w, v = g("w"), g("v")
+    assert np.allclose(rsdsfm.velocity_errors(w * 0.97, v * 1.05 + np.array([0.01, 0, 0]), w, v), g("vel_errors"), rtol=1e-12, atol=1e-15)
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 1), (17, 15), (64, 48), (250, 333), (720, 1280)])
+def test_metrics_equal_oracle(oracle, rsdsfm, rows, cols):
+    d, img, depth, R, t = _scene(rsdsfm, oracle, rows, cols, seed=rows + 3 * cols)
+    K = d["K"]
+    _, c3 = oracle.back_project(img, depth, R, t, *K)
+    est = (c3.astype(np.float64) * 1.3).astype(np.float32)
+    rng = np.random.default_rng(rows)
+    est += (rng.normal(0, 0.02, est.shape) * (rng.random(est.shape) < 0.5)).astype(np.float32)
+    est[rng.random((rows, cols)) < 0.02] *= 40.0  # gross outliers (|ratio| > 10)
+    gt = np.array(d["truth"]["Z"])
+    gt[rng.random((rows, cols)) < 0.03] = 0.0
+    Ra, ta = oracle.pose_table(np.array([0.11, 0.10, 0.06]), np.array([0.03, -0.02, 0.05]), 0.0, d["gamma"], rows)
+    with rsdsfm.Solver(0) as s:
+        st, eimg = s.reprojection_error(est, gt, depth, Ra, ta, K, max_norm=4.0)
+        st_n, none = s.reprojection_error(est, gt, depth, Ra, ta, K, want_image=False)
+    st_o, eimg_o = oracle.reprojection_error(est, gt, depth, Ra, ta, *K, max_norm=4.0)
+    _close_stats(st, st_o)
+    _close_stats(st_n, st_o)
+    assert none is None
+    # the image depends on the scale, whose last bits depend on the summation order: bytes may differ only where the
+    # value sits within 1e-9 of a rounding boundary (none in practice)
+    diff = eimg != eimg_o
+    assert diff.mean() < 1e-5
+
+
+def test_metrics_degenerate(oracle, rsdsfm):
+    rows, cols = 6, 5
+    z = np.zeros((rows, cols))
+    R, t = np.tile(np.eye(3), (rows, 1, 1)), np.zeros((rows, 3))
+    with rsdsfm.Solver(0) as s:
+        st, img = s.reprojection_error(np.zeros((rows, cols, 3), dtype=np.float32), z + 1.0, z + 1.0, R, t, (10.0, 10.0, 2.0, 3.0))
+        assert st["scale_inliers"] == 0 and np.isnan(st["scale"]) and np.isnan(st["mean_error"]) and st["error_inliers"] == 0
+        assert np.all(img == 0)  # NaN errors -> 0 (defined here; undefined in the reference)
+        st0, _ = s.reprojection_error(np.zeros((0, 4, 3), dtype=np.float32), np.zeros((0, 4)), np.zeros((0, 4)), R[:0], t[:0], (10.0, 10.0, 2.0, 3.0))
+        assert np.isnan(st0["mean_error"])

@@ -175,3 +175,46 @@ def test_true_flow_properties(oracle, rsdsfm):
     f, b = oracle.true_flow(w2, R, t, *K, q5_mode=1)
     assert b[0, 0] == 0 and not np.isfinite(f[0, 0]).all()  # z = 0: inf displacement everywhere, scanline 0 kept
     assert b[0, 1] >= 0 and np.isfinite(f[0, 1]).all()
+
+
+@pytest.mark.parametrize("case", RECTIFY_CASES)
+def test_metrics_match_golden(golden_rectify, oracle, case):
+    g = lambda k: golden_rectify[case + "/" + k]
+    st, img = oracle.reprojection_error(g("est_coords"), g("gt_depth"), g("depth"), g("R_abs"), g("t_abs"), *tuple(g("K")), max_norm=10.0)
+    ref = g("reproj_stats")
+    assert (st["number_outliers"], st["scale_inliers"], st["error_inliers"]) == tuple(int(v) for v in ref[3:6])  # counts: exact
+    assert np.isclose(st["scale"], ref[0], rtol=1e-12) and np.isclose(st["mean_error"], ref[1], rtol=1e-12) and np.isclose(st["sum_error"], ref[2], rtol=1e-12)
+    assert np.array_equal(img, g("error_image"))
+    w, v = g("w"), g("v")
+    we, ve = oracle.velocity_errors(w * 0.97, v * 1.05 + np.array([0.01, 0, 0]), w, v)
+    assert np.allclose([we, ve], g("vel_errors"), rtol=1e-12, atol=1e-15)
+
+
+def test_metrics_properties(oracle, rsdsfm):
+    """a perfect estimate at a different global scale: scale recovered, zero error; identical velocities: zero errors;
+    rotation error is first order in the difference; opposite translation: pi"""
+    rows, cols = 18, 22
+    d = rsdsfm.synth.make_config(1, rows=rows, cols=cols)
+    K = d["K"]
+    fx, fy, cx, cy = K
+    Z = np.array(d["truth"]["Z"])
+    R, t = oracle.pose_table(np.array([0.1, 0.05, 0.02]), np.array([0.02, -0.01, 0.03]), 0.0, d["gamma"], rows)
+    img = np.full((rows, cols, 3), 100, dtype=np.uint8)
+    _, c3 = oracle.back_project(img, Z, R, t, *K)  # world points under the same poses = the "truth" the metric rebuilds
+    st, eimg = oracle.reprojection_error((c3.astype(np.float64) * 2.5).astype(np.float32), Z, Z, R, t, *K, max_norm=10.0)
+    assert abs(st["scale"] - 2.5) < 1e-5 and st["mean_error"] < 1e-5 and st["number_outliers"] == 0
+    assert st["error_inliers"] == rows * cols and int(eimg.max()) == 0
+    st2, _ = oracle.reprojection_error(np.zeros((rows, cols, 3), dtype=np.float32), Z, Z, R, t, *K)
+    assert st2["scale_inliers"] == 0 and np.isnan(st2["scale"]) and st2["error_inliers"] == 0 and np.isnan(st2["mean_error"])
+    # ground-truth depth 0 -> the estimated depth map is used (planeToSpace default argument)
+    Zg = Z.copy()
+    Zg[5, 6] = 0.0
+    st3, _ = oracle.reprojection_error(c3, Zg, Z, R, t, *K)
+    assert st3["mean_error"] < 1e-5
+    w, v = np.array([0.01, -0.02, 0.03]), np.array([0.3, 0.1, -0.2])
+    # the reference composes FIRST-ORDER rotations (I + [w]x): identical velocities leave a second-order residue w_i w_j
+    we0, ve0 = oracle.velocity_errors(w, v, w, v)
+    assert we0 <= float(w @ w) and ve0 < 1e-7
+    we, _ = oracle.velocity_errors(w + np.array([1e-2, 0, 0]), v, w, v)
+    assert abs(we - 1e-2) < 2e-3
+    assert abs(oracle.velocity_errors(w, -v, w, v)[1] - np.pi) < 1e-7

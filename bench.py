@@ -81,7 +81,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify", "true_flow"])
+    ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify", "true_flow", "metrics"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nbuf", type=int, default=7, help="rotating HBM buffer sets (7 x 59 MB > 256 MiB L3)")
     ap.add_argument("--trials", type=int, default=50, help="RANSAC trials of the full solve (report section 5.4 used 50)")
@@ -337,6 +337,57 @@ def main():
                          "roofline": {"bound": "hbm", "kernel": "true_flow_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic("true_flow"), "alg_bytes_per_launch": alg, "avg_launch_ms": ms,
                                       "note": "compute-bound by construction: rows2 x ~30 fp64 VALU instructions per 44 B pixel; see DESIGN"},
+                         "cpu_baseline": cpu})
+
+    # =================================================================================================
+    elif args.workload == "metrics":
+        # meanReprojectionError + createErrorImage of a 1280x720 frame resident in HBM; one frame per GPU
+        data = rsdsfm.synth.make_config(2, seed=0x5EED0002 + rank)
+        rows, cols, K, gamma = data["rows"], data["cols"], data["K"], data["gamma"]
+        npix = rows * cols
+        t = data["truth"]
+        fx, fy, cx, cy = K
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        Z = np.array(t["Z"])
+        est_h = (np.stack([(xx - cx) / fx, (yy - cy) / fy, np.ones((rows, cols))], axis=2) * Z[:, :, None] * 1.7).astype(np.float32)
+        nbuf = args.nbuf
+        R = torch.empty((rows, 9), dtype=torch.float64, device=dev)
+        tt = torch.empty((rows, 3), dtype=torch.float64, device=dev)
+        solver.pose_table_dev(t["v"] * 3.0, t["w"] * 4.0, 0.0, gamma, rows, R.data_ptr(), tt.data_ptr())
+        sets = [dict(est=torch.from_numpy(est_h).to(dev), gt=torch.from_numpy(np.ascontiguousarray(Z.T)).to(dev),
+                     ed=torch.from_numpy(np.ascontiguousarray(Z.T)).to(dev), img=torch.empty((rows, cols), dtype=torch.uint8, device=dev)) for _ in range(nbuf)]
+        res = {}
+
+        def step(i):
+            s_ = sets[i % nbuf]
+            res["st"] = solver.reprojection_error_dev(s_["est"].data_ptr(), s_["gt"].data_ptr(), s_["ed"].data_ptr(), R.data_ptr(), tt.data_ptr(), K, rows, cols,
+                                                      10.0, s_["img"].data_ptr())
+
+        el = timed(step, args.steps, args.warmup)
+        if rank == 0:
+            ms = el / args.steps * 1e3
+            alg = (2 * 28 + 1) * npix  # two streaming passes of 12 B point + 2 x 8 B depth, 1 B image written
+            achieved = alg / (ms * 1e-3) / 1e9
+            cpu = None
+            if not (args.no_cpu_baseline or world > 1):
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import oracle_py as O
+
+                Rh, th = R.cpu().numpy(), tt.cpu().numpy()
+                t0 = time.perf_counter()
+                reps = 0
+                while time.perf_counter() - t0 < 6.0:
+                    O.reprojection_error(est_h, Z, Z, Rh, th, *K)
+                    reps += 1
+                ce = time.perf_counter() - t0
+                cpu = {"value": npix * reps / ce / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "port", "sample": "%d whole 1280x720 frames in %.1f s" % (reps, ce)}
+            line.update({"value": npix * world * args.steps / el / 1e6, "ms_per_step": ms, "scaling": "weak",
+                         "metric": "Mpixels/sec reprojection-error metric (mean error + error image), 1280x720 frame", "dtype": "f32/f64",
+                         "config": {"workload": "SURVEY 8(f-4): Camera::meanReprojectionError + createErrorImage of a synthetic 1280x720 frame (4 launches + one "
+                                                "result read-back per call); one frame per GPU", "rows": rows, "cols": cols, "stats": res["st"]},
+                         "roofline": {"bound": "hbm", "kernel": "reproj_scale_kernel + reproj_error_kernel (+ 2 decide kernels, host read-back)",
+                                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                                      "alg_bytes_per_launch": alg, "avg_launch_ms": ms},
                          "cpu_baseline": cpu})
 
     # =================================================================================================

@@ -157,6 +157,118 @@ __device__ void jacobi_svd9_nullvec(LVec W, LVec V, LVec sv, LVec col, double e_
     for (int i = 0; i < 9; ++i) e_out[i] = V[i * 9 + c8];
 }
 
+// ---------------------------------------------------------------------------------------------------
+// wave-cooperative variant of jacobi_svd9_nullvec: ONE hypothesis per wave (used when there are few hypotheses, the
+// RANSAC case: T = 5 ... a few hundred, where the one-lane-per-hypothesis kernel leaves the machine idle and serialises
+// 108 LDS accesses + 108 multiply-adds per rotation on a single lane).  The matrix lives once in LDS (the lane-0
+// copy, element stride 64 doubles); all lanes evaluate the (uniform) 2x2 rotation, lanes 0..8 apply it to the nine
+// columns (left) / rows (right) of W and lanes 16..24 to the rows of V.  A wave's LDS operations execute in order, so
+// no barriers are needed.  Every element goes through exactly the operations of the scalar version: results are
+// bit-identical.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double& sh(double* M, int e) { return M[e * 64]; }
+
+__device__ void jacobi_svd9_nullvec_coop(double* W, double* V, int lane, LVec sv, LVec col, double e_out[9]) {
+    const double precision = 2.0 * DBL_EPSILON;
+    // scale = max |W| (exact in any order)
+    double m = fabs(sh(W, lane));
+    if (lane < 17) m = fmax(m, fabs(sh(W, 64 + lane)));
+    double scale = wave_max(m);
+    if (scale == 0.0) scale = 1.0;
+    sh(W, lane) = sh(W, lane) / scale;
+    if (lane < 17) sh(W, 64 + lane) = sh(W, 64 + lane) / scale;
+    {
+        const int e0 = lane, e1 = 64 + lane;
+        sh(V, e0) = (e0 / 9 == e0 % 9) ? 1.0 : 0.0;
+        if (lane < 17) sh(V, e1) = (e1 / 9 == e1 % 9) ? 1.0 : 0.0;
+    }
+    double max_diag = wave_max(lane < 9 ? fabs(sh(W, lane * 10)) : 0.0);
+    // lanes 0..8 work on W, lanes 16..24 on V during the right rotation
+    const int li = lane & 15;
+    const bool rowlane = li < 9 && lane < 32;
+    double* RM = lane < 16 ? W : V;
+    bool finished = false;
+    int sweeps = 0;
+    while (!finished && sweeps < 1000) {
+        finished = true;
+        ++sweeps;
+        for (int p = 1; p < 9; ++p) {
+            for (int q = 0; q < p; ++q) {
+                double threshold = precision * max_diag;
+                if (threshold < DBL_MIN) threshold = DBL_MIN;
+                // the 2x2 block, broadcast to every lane
+                double m0 = sh(W, p * 9 + p), m1 = sh(W, p * 9 + q), m2 = sh(W, q * 9 + p), m3 = sh(W, q * 9 + q);
+                if (fabs(m1) > threshold || fabs(m2) > threshold) {
+                    finished = false;
+                    // real_2x2_jacobi_svd (JacobiSVD.h), identical to the scalar version
+                    Rot rot1, jl, jr;
+                    const double t = m0 + m3;
+                    const double d = m2 - m1;
+                    if (fabs(d) < DBL_MIN) {
+                        rot1.s = 0.0;
+                        rot1.c = 1.0;
+                    } else {
+                        const double uu = t / d;
+                        const double tmp = sqrt(1.0 + uu * uu);
+                        rot1.s = 1.0 / tmp;
+                        rot1.c = uu / tmp;
+                    }
+                    if (!(rot1.c == 1.0 && rot1.s == 0.0)) {
+                        const double a0 = rot1.c * m0 + rot1.s * m2, a2 = -rot1.s * m0 + rot1.c * m2;
+                        const double a1 = rot1.c * m1 + rot1.s * m3, a3 = -rot1.s * m1 + rot1.c * m3;
+                        m0 = a0, m1 = a1, m2 = a2, m3 = a3;
+                    }
+                    jr = make_jacobi(m0, m1, m3);
+                    const Rot jt = {jr.c, -jr.s};
+                    jl.c = rot1.c * jt.c - rot1.s * jt.s;
+                    jl.s = rot1.c * jt.s + rot1.s * jt.c;
+                    // applyOnTheLeft(p, q, jl): rows p, q of W, one column per lane
+                    if (lane < 9 && !(jl.c == 1.0 && jl.s == 0.0)) {
+                        const double x = sh(W, p * 9 + lane), y = sh(W, q * 9 + lane);
+                        sh(W, p * 9 + lane) = jl.c * x + jl.s * y;
+                        sh(W, q * 9 + lane) = -jl.s * x + jl.c * y;
+                    }
+                    // applyOnTheRight(p, q, jr) on W and V: columns p, q, one row per lane
+                    const Rot jrt = {jr.c, -jr.s};
+                    if (rowlane && !(jrt.c == 1.0 && jrt.s == 0.0)) {
+                        const double x = sh(RM, li * 9 + p), y = sh(RM, li * 9 + q);
+                        sh(RM, li * 9 + p) = jrt.c * x + jrt.s * y;
+                        sh(RM, li * 9 + q) = -jrt.s * x + jrt.c * y;
+                    }
+                    max_diag = fmax(max_diag, fmax(fabs(sh(W, p * 9 + p)), fabs(sh(W, q * 9 + q))));
+                }
+            }
+        }
+    }
+    for (int i = 0; i < 9; ++i) {
+        sv[i] = fabs(sh(W, i * 9 + i)) * scale;
+        col[i] = (double)i;
+    }
+    for (int i = 0; i < 9; ++i) {  // selection sort, descending (JacobiSVD step 4), as in the scalar version
+        int pos = i;
+        double best = sv[i];
+        for (int j = i + 1; j < 9; ++j) {
+            const double sj = sv[j];
+            if (sj > best) {
+                best = sj;
+                pos = j;
+            }
+        }
+        if (best == 0.0) break;
+        if (pos != i) {
+            const double tt = sv[i];
+            sv[i] = sv[pos];
+            sv[pos] = tt;
+            const double tc = col[i];
+            col[i] = col[pos];
+            col[pos] = tc;
+        }
+    }
+    const int c8 = (int)col[8];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) e_out[i] = sh(V, i * 9 + c8);
+}
+
 // PartialPivLU inverse (MatrixXd::inverse()), row-major n x n (n = 3 or 6).  A, Ainv, lu: n*n slots; piv, y: n slots.
 __device__ int inverse_lu(LVec A, int n, LVec Ainv, LVec lu, LVec piv, LVec y) {
     for (int i = 0; i < n * n; ++i) lu[i] = A[i];
@@ -506,6 +618,9 @@ constexpr int kSlotsK = 294;                      // + k-estimation temporaries 
 }  // namespace
 
 // hyp_out: [T][8] = w(3), v(3), k, status (0 ok, -1 no real k, -2 singular system)
+// COOP = false: one hypothesis per LANE (throughput mode, many hypotheses); COOP = true: one hypothesis per WAVE -- every lane
+// evaluates the (cheap, register / per-lane-LDS) scalar parts redundantly and the 9x9 SVD is shared (latency mode)
+template <bool COOP>
 __global__ __launch_bounds__(64) void minimal9_kernel(const double* __restrict__ q, const double* __restrict__ u,
                                                      const double* __restrict__ alpha,
                                                      const double* __restrict__ alpha_k,
@@ -513,7 +628,7 @@ __global__ __launch_bounds__(64) void minimal9_kernel(const double* __restrict__
                                                      int k_sign_mode, double* __restrict__ hyp_out) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
-    const int t = blockIdx.x * 64 + lane;
+    const int t = COOP ? (int)blockIdx.x : (int)blockIdx.x * 64 + lane;
     if (t >= T) return;  // per-lane independent work, no workgroup barriers below
     LVec base{lds + lane};
     LVec Z = base.at(0), V = base.at(81), sv = base.at(162), col = base.at(171);
@@ -613,7 +728,10 @@ __global__ __launch_bounds__(64) void minimal9_kernel(const double* __restrict__
 
     // ---- null vector (minimal.cc:98-103) ----
     double e[9];
-    jacobi_svd9_nullvec(Z, V, sv, col, e);
+    if (COOP)
+        jacobi_svd9_nullvec_coop(lds, lds + 81 * 64, lane, sv, col, e);  // the lane-0 copies of Z and V
+    else
+        jacobi_svd9_nullvec(Z, V, sv, col, e);
     const double norm_v0 = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
 #pragma unroll
     for (int i = 0; i < 9; ++i) e[i] = e[i] / norm_v0;
@@ -686,6 +804,7 @@ __global__ __launch_bounds__(64) void minimal9_kernel(const double* __restrict__
     mm3(t1, sig_lamb, t2);
     tr3(wb, bt);
     mm3(t2, bt, w_hat);
+    if (COOP && lane != 0) return;
     double* o = hyp_out + (int64_t)t * 8;
     o[0] = w_hat[7];
     o[1] = w_hat[2];
@@ -703,13 +822,21 @@ int minimal9_launch(Ctx* c, const double* q, const double* u, const double* alph
     const size_t lds_bytes = (size_t)(use_alpha_k ? kSlotsK : kSlotsNoK) * 64 * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
-        RSDSFM_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(minimal9_kernel),
+        RSDSFM_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(minimal9_kernel<false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)((size_t)kSlotsK * 64 * sizeof(double))));
+        RSDSFM_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(minimal9_kernel<true>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 (int)((size_t)kSlotsK * 64 * sizeof(double))));
         attr_set = true;
     }
-    hipLaunchKernelGGL(minimal9_kernel, dim3((T + 63) / 64), dim3(64), lds_bytes, c->stream, q, u, alpha, alpha_k, samples, T,
-                       use_alpha_k, k_sign_mode, hyp_out);
+    // few hypotheses (RANSAC: T = 5 ... a few hundred): one wave per hypothesis, 9x9 SVD shared by the wave; many: one lane each
+    if (T <= c->num_cus * 2)
+        hipLaunchKernelGGL(minimal9_kernel<true>, dim3(T), dim3(64), lds_bytes, c->stream, q, u, alpha, alpha_k, samples, T, use_alpha_k,
+                           k_sign_mode, hyp_out);
+    else
+        hipLaunchKernelGGL(minimal9_kernel<false>, dim3((T + 63) / 64), dim3(64), lds_bytes, c->stream, q, u, alpha, alpha_k, samples, T,
+                           use_alpha_k, k_sign_mode, hyp_out);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -39,6 +39,22 @@ def test_calculate_velocities_vs_oracle_and_golden(golden, oracle, solver, case)
         assert np.allclose(K2, -K, rtol=1e-12)
 
 
+@pytest.mark.parametrize("case", ["noisy_k0", "noisy_k04"])
+def test_minimal9_wave_and_lane_variants_bit_identical(golden, solver, case):
+    """few hypotheses run one per WAVE (shared 9x9 SVD), many run one per LANE: same arithmetic, identical bits"""
+    g = lambda k: golden[case + "/" + k]
+    q, u, a, ak, samples = g("q"), g("u"), g("alpha"), g("alpha_k"), g("samples")
+    use_k = bool(g("use_k"))
+    few = solver.calculate_velocities(q[samples], u[samples], a[samples], ak[samples], use_k)
+    reps = 70  # 10 x 70 = 700 hypotheses > 2 x 256 CUs -> lane variant
+    big = np.tile(samples, (reps, 1))
+    many = solver.calculate_velocities(q[big], u[big], a[big], ak[big], use_k)
+    for f, m in zip(few, many):
+        m = np.asarray(m).reshape(reps, len(samples), -1)
+        for r in range(reps):
+            assert np.array_equal(np.asarray(f).reshape(len(samples), -1), m[r])
+
+
 def test_minimal_known_answer(solver, rsdsfm):
     """noise-free model data: w_true, +-v_true/|v| recovered"""
     d = rsdsfm.synth.make_config(1, rows=96, cols=128, v=np.array([0.03, 0.02, 0.01]), w=np.array([0.002, -0.003, 0.0087]))

@@ -264,8 +264,6 @@ __global__ __launch_bounds__(kFB) void refine_solve_kernel(const double* __restr
     using CT = Counts<NP>;
     __shared__ double s_red[kFB / 64][CT::NSCHUR];
     __shared__ double s[CT::NSCHUR];
-    __shared__ double S[NP * NP];
-    __shared__ double rhs[NP], yv[NP], yp[NP];
     if (st->termination >= 0) return;
     if (st->iteration >= kMaxIter) {  // top-of-loop checks of TrustRegionMinimizer
         if (threadIdx.x == 0) st->termination = RSDSFM_TERM_MAX_ITER;
@@ -275,62 +273,97 @@ __global__ __launch_bounds__(kFB) void refine_solve_kernel(const double* __restr
         if (threadIdx.x == 0) st->termination = RSDSFM_TERM_MIN_RADIUS;
         return;
     }
+    // the state the serial tail needs is requested before the reduction so that its latency is hidden
+    double p_cur[7], sp_cur[NP];
+    double radius = 0.0;
+    if (threadIdx.x == 0) {
+        radius = st->radius;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) p_cur[c] = st->p[c];
+#pragma unroll
+        for (int c = 0; c < NP; ++c) sp_cur[c] = st->sp[c];
+    }
     reduce_partials<CT::NSCHUR>(partials, nblocks, -1, s_red, s);
     if (threadIdx.x == 0) {
         st->iteration += 1;
-        const double inv_radius = 1.0 / st->radius;
-        int tri = 0;
-        for (int a = 0; a < NP; ++a) {
-            rhs[a] = s[2 * CT::TRI + a] - s[2 * CT::TRI + NP + a];
-            for (int b = a; b < NP; ++b) {
-                double sab = s[tri] - s[CT::TRI + tri];
-                if (a == b) sab += clampd(s[tri], kMinLmDiag, kMaxLmDiag) * inv_radius;  // D_f^2
-                S[a * NP + b] = sab;
-                S[b * NP + a] = sab;
-                ++tri;
+        const double inv_radius = 1.0 / radius;
+        // reduced system in registers (all loops fully unrolled: static indices, no LDS round trips in the serial chain)
+        double sv[CT::NSCHUR];
+#pragma unroll
+        for (int i = 0; i < CT::NSCHUR; ++i) sv[i] = s[i];
+        double S[NP][NP], rhs[NP], yv[NP], yp[NP];
+        {
+            int tri = 0;
+#pragma unroll
+            for (int a = 0; a < NP; ++a) {
+                rhs[a] = sv[2 * CT::TRI + a] - sv[2 * CT::TRI + NP + a];
+#pragma unroll
+                for (int b = a; b < NP; ++b) {
+                    double sab = sv[tri] - sv[CT::TRI + tri];
+                    if (a == b) sab += clampd(sv[tri], kMinLmDiag, kMaxLmDiag) * inv_radius;  // D_f^2
+                    S[a][b] = sab;
+                    S[b][a] = sab;
+                    ++tri;
+                }
             }
         }
-        // dense Cholesky solve (mirrors the oracle's chol_solve)
-        int ok = 1;
-        for (int j = 0; j < NP && ok; ++j) {
-            double d = S[j * NP + j];
-            for (int t = 0; t < j; ++t) d -= S[j * NP + t] * S[j * NP + t];
-            if (!(d > 0.0)) {
-                ok = 0;
-                break;
-            }
-            d = sqrt(d);
-            S[j * NP + j] = d;
-            for (int i = j + 1; i < NP; ++i) {
-                double sacc = S[i * NP + j];
-                for (int t = 0; t < j; ++t) sacc -= S[i * NP + t] * S[j * NP + t];
-                S[i * NP + j] = sacc / d;
+        // dense Cholesky solve (mirrors the oracle's chol_solve operation for operation)
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            if (ok) {
+                double d = S[j][j];
+#pragma unroll
+                for (int t = 0; t < j; ++t) d -= S[j][t] * S[j][t];
+                if (!(d > 0.0)) {
+                    ok = false;
+                } else {
+                    d = sqrt(d);
+                    S[j][j] = d;
+#pragma unroll
+                    for (int i = j + 1; i < NP; ++i) {
+                        double sacc = S[i][j];
+#pragma unroll
+                        for (int t = 0; t < j; ++t) sacc -= S[i][t] * S[j][t];
+                        S[i][j] = sacc / d;
+                    }
+                }
             }
         }
         if (ok) {
+#pragma unroll
             for (int i = 0; i < NP; ++i) {
                 double sacc = rhs[i];
-                for (int t = 0; t < i; ++t) sacc -= S[i * NP + t] * yv[t];
-                yv[i] = sacc / S[i * NP + i];
+#pragma unroll
+                for (int t = 0; t < i; ++t) sacc -= S[i][t] * yv[t];
+                yv[i] = sacc / S[i][i];
             }
+#pragma unroll
             for (int i = NP - 1; i >= 0; --i) {
                 double sacc = yv[i];
-                for (int t = i + 1; t < NP; ++t) sacc -= S[t * NP + i] * yp[t];
-                yp[i] = sacc / S[i * NP + i];
+#pragma unroll
+                for (int t = i + 1; t < NP; ++t) sacc -= S[t][i] * yp[t];
+                yp[i] = sacc / S[i][i];
             }
             double stepsq = 0.0;
-            for (int c = 0; c < 7; ++c) st->pc[c] = st->p[c];
+            double pc_new[7];
+#pragma unroll
+            for (int c = 0; c < 7; ++c) pc_new[c] = p_cur[c];
+#pragma unroll
             for (int c = 0; c < NP; ++c) {
-                st->yp[c] = yp[c];
                 const double step = -yp[c];
-                const double pc = st->p[c] + step * st->sp[c];
-                st->pc[c] = pc;
-                const double dx = st->p[c] - pc;
+                const double pc = p_cur[c] + step * sp_cur[c];
+                pc_new[c] = pc;
+                const double dx = p_cur[c] - pc;
                 stepsq += dx * dx;
             }
+#pragma unroll
+            for (int c = 0; c < 7; ++c) st->pc[c] = pc_new[c];
+#pragma unroll
+            for (int c = 0; c < NP; ++c) st->yp[c] = yp[c];
             st->stepsq_p = stepsq;
         }
-        st->solve_ok = ok;
+        st->solve_ok = ok ? 1 : 0;
     }
 }
 

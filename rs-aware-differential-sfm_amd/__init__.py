@@ -597,3 +597,5 @@ class _MetricsMixin:
 for _name, _fn in list(vars(_MetricsMixin).items()):
     if not _name.startswith("__"):
         setattr(Solver, _name, _fn)
+
+from . import evaluate, formats  # noqa: E402,F401  (on-disk formats + archive runner)

@@ -1,0 +1,73 @@
+"""evaluateSingleRun for a synthetic example archive (reference main.cc:364-560) on the HIP path: ground-truth flow ->
+flatten + alpha -> ransac -> nonLinearRefinement -> sign fix + depth map + 8-bit depth image -> setRelativePose ->
+backProject -> interpolateCrackyImage -> point cloud, images and (synthetic data) error image / mean reprojection error.
+
+Host-side orchestration over the C-ABI wrappers (Solver); file formats in formats.py.  Image decoding / encoding and the
+CSV parsing are host work like in the reference; everything per-pixel runs in the HIP kernels.
+"""
+import os
+
+import numpy as np
+
+from . import formats
+
+
+def gt_depth_map(world, R_abs, t_abs):
+    """RsFrame::getGroundtruthDepthMap (rsframe.cc:416-436): z of the world point in the camera frame of ITS scanline"""
+    z = (R_abs[:, 2, :][:, None, :] * world).sum(axis=2) + t_abs[:, 2][:, None]
+    return np.where(np.sqrt((world * world).sum(axis=2)) > 0, z, 0.0)
+
+
+def relocate_pose(R_abs, t_abs):
+    """RsFrame::relocatePose (rsframe.cc:951-967): scanline 0 becomes the origin (scanline 0 itself is left untouched)"""
+    R, t = np.array(R_abs, dtype=np.float64), np.array(t_abs, dtype=np.float64)
+    inv0 = np.linalg.inv(R[0])
+    R[1:] = inv0 @ R[1:]
+    t[1:] = t[1:] - t[0]
+    return R, t
+
+
+def evaluate_single_run(solver, task_dir, out_dir, trials=50, tol=0.05, seed=1, use_acceleration_mode=False, use_refinement=True,
+                        use_global_shutter_mode=False, flow_threshold=1e-10, write_outputs=True):
+    from . import BACKPROJECT_GS, BACKPROJECT_RS, velocity_errors
+
+    a = formats.load_example_archive(task_dir)
+    K, truth = a["K"], a["truth"]
+    gamma = truth["gamma"]
+    f1, f2 = a["frames"]
+    rows, cols = f1["rs_image"].shape[:2]
+    # main.cc:383 calculateTrueFlow(1, 2)
+    flow, _ = solver.true_flow(f1["world"], f2["R"], f2["t"], K, want_best_row=False)
+    # main.cc:398-457
+    q, u, alpha, alpha_k = solver.flatten(flow, K, gamma, thr=flow_threshold)
+    rr = solver.ransac(q, u, alpha, alpha_k, use_acceleration_mode, trials, tol, samples=None, seed=seed)
+    res = dict(v=rr["v"], w=rr["w"], k=rr["k"], inliers=rr["inliers"])
+    if use_refinement:
+        ref = solver.non_linear_refinement(u, rr["inliers"], rr["alpha"], rr["alpha_k"], rr["v"], rr["w"], rr["k"], use_acceleration_mode,
+                                           flow_index_mode=1, inlier_idx=rr["inlier_idx"])
+        res = dict(v=ref["v"], w=ref["w"], k=ref["k"], inliers=ref["inliers"], refine_summary=ref["summary"])
+    # main.cc:466-509
+    dm = solver.depth_map(res["inliers"], res["v"], K, rows, cols)
+    depth_est = solver.depth_preview(dm["inliers"], K, rows, cols)
+    # main.cc:515-523
+    R_rel, t_rel = solver.pose_table(dm["v"], res["w"], res["k"], gamma, rows)
+    gs, coords = solver.back_project(f1["rs_image"], dm["depth_map"], R_rel, t_rel, K, mode=BACKPROJECT_GS if use_global_shutter_mode else BACKPROJECT_RS)
+    backprojection = solver.interpolate_cracky(gs, 1)
+    # synthetic data only (main.cc:533-556): error image + mean reprojection error against the archive's ground truth
+    gt_depth = gt_depth_map(f1["world"], f1["R"], f1["t"])
+    R_abs, t_abs = relocate_pose(f1["R"], f1["t"])
+    stats, error_image = solver.reprojection_error(coords, gt_depth, dm["depth_map"], R_abs, t_abs, K, max_norm=10.0)
+    w_err, v_err = velocity_errors(res["w"], dm["v"], truth["w"], truth["v"])
+    out = dict(n=len(q), num_inliers=rr["num_inliers"], v=dm["v"], w=res["w"], k=res["k"], flipped=dm["flipped"], w_error=w_err, v_error=v_err,
+               mean_reprojection_error=stats["mean_error"], reprojection=stats, flow=flow, depth_map=dm["depth_map"], depth_est=depth_est,
+               gs_image=gs, backprojection=backprojection, coords=coords, error_image=error_image, truth=truth)
+    if write_outputs:
+        os.makedirs(out_dir, exist_ok=True)
+        formats.write_png(out_dir + "/MinimalDepth.png", depth_est)
+        formats.write_png(out_dir + "/rs_image.png", f1["rs_image"])
+        formats.write_png(out_dir + "/backprojection.png", backprojection)
+        formats.write_png(out_dir + "/error_image.png", error_image)
+        formats.write_ply(out_dir + "/point_cloud.ply", coords, f1["rs_image"])
+        formats.write_sweep_results(out_dir, [os.path.basename(task_dir.rstrip("/"))], [[w_err]], [[v_err]], [[stats["mean_error"]]],
+                                    w=[res["w"]], v=[dm["v"]], k=[[res["k"]]])
+    return out

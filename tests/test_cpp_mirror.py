@@ -62,6 +62,11 @@ def test_single_run_matches_python_path(tmp_path, rsdsfm, oracle):
     gs_o, _ = oracle.back_project(rs, dm["depth_map"], R, t, *K)
     assert r["preview_sum"] == int(oracle.depth_preview(dm["inliers"], *K, 120, 200).astype(np.uint64).sum())
     assert r["gs_sum"] == wsum(gs_o) and r["bp_sum"] == wsum(oracle.interpolate_cracky(gs_o, 1))
+    # the C++ mirror's PLY writer (createPointCloud) produces the same text as the package's writer on the oracle's points
+    _, c3_ply = oracle.back_project(rs, dm["depth_map"], R, t, *K)
+    ply_py = os.path.join(str(tmp_path), "py.ply")
+    rsdsfm.formats.write_ply(ply_py, c3_ply, rs)
+    assert open(raw + ".ply").read() == open(ply_py).read()
     # ground-truth flow of the estimated structure under the estimated motion (Camera::calculateTrueFlow)
     dmm = dm["depth_map"]
     yy, xx = np.mgrid[0:120, 0:200]

@@ -1,0 +1,166 @@
+"""CPU: on-disk formats of the reference's example archives and outputs: CSV loaders with the reference's
+::atof / line-count semantics, PNG codec, ascii PLY, the example-archive layout; the C++ mirror's loaders (host/formats.h)
+read what the Python side writes and vice versa."""
+import json
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+PKG = os.path.join(ROOT, "rs-aware-differential-sfm_amd")
+
+
+@pytest.fixture(scope="module")
+def F(rsdsfm):
+    return rsdsfm.formats
+
+
+def test_atof_and_csv_semantics(F, tmp_path):
+    assert F.atof(" 1.5e3abc") == 1500.0 and F.atof("x") == 0.0 and F.atof("-.5") == -0.5 and F.atof("") == 0.0
+    assert F.atof("1e") == 1.0 and F.atof("+3.") == 3.0 and np.isinf(F.atof("-inf")) and np.isnan(F.atof("nan"))
+    M = np.random.default_rng(0).normal(size=(4, 5)) * 1e3
+    p = str(tmp_path / "m.csv")
+    F.write_matrix_csv(p, M)
+    assert np.array_equal(F.read_matrix_csv(p, 4, 5), M)  # %.17g round-trips doubles exactly
+    with pytest.raises(ValueError):
+        F.read_matrix_csv(p, 5, 5)  # line count != rows: rejected like the reference loaders
+    # MATLAB csvwrite precision (5 significant digits), missing trailing fields, junk
+    open(p, "w").write("1.2346,2,abc\n4,5\n7,8,9,10\n")
+    got = F.read_matrix_csv(p, 3, 3)
+    assert np.array_equal(got, [[1.2346, 2, 0], [4, 5, 0], [7, 8, 9]])  # "9,10" -> atof("9,10") = 9
+    (fx, fy, cx, cy), K = F.load_intrinsics(p)
+    assert (fx, fy, cx, cy) == (1.2346, 5.0, 0.0, 0.0)
+
+
+def _png_with_filters(path, img):
+    """test-side encoder that cycles through all five PNG filter types (the package's writer only emits filter 0)"""
+    a = img if img.ndim == 3 else img[:, :, None]
+    if a.shape[2] == 3:
+        a = a[:, :, ::-1]
+    rows, cols, ch = a.shape
+    flat = a.reshape(rows, cols * ch).astype(np.int32)
+    raw = b""
+    for r in range(rows):
+        ft = r % 5
+        cur, prev = flat[r], (flat[r - 1] if r else np.zeros(cols * ch, dtype=np.int32))
+        out = np.zeros(cols * ch, dtype=np.int32)
+        for i in range(cols * ch):
+            A = cur[i - ch] if i >= ch else 0
+            B = prev[i]
+            Cc = prev[i - ch] if i >= ch else 0
+            if ft == 0:
+                pred = 0
+            elif ft == 1:
+                pred = A
+            elif ft == 2:
+                pred = B
+            elif ft == 3:
+                pred = (A + B) >> 1
+            else:
+                pa, pb, pc = abs(B - Cc), abs(A - Cc), abs(A + B - 2 * Cc)
+                pred = A if (pa <= pb and pa <= pc) else (B if pb <= pc else Cc)
+            out[i] = (cur[i] - pred) & 255
+        raw += bytes([ft]) + out.astype(np.uint8).tobytes()
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    open(path, "wb").write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", cols, rows, 8, 2 if ch == 3 else 0, 0, 0, 0)) +
+                           chunk(b"IDAT", zlib.compress(raw, 9)) + chunk(b"IEND", b""))
+
+
+def test_png_codec(F, tmp_path):
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (23, 31, 3), dtype=np.uint8)
+    grey = rng.integers(0, 256, (9, 14), dtype=np.uint8)
+    for level in (0, 6):
+        F.write_png(str(tmp_path / "c.png"), img, compression=level)
+        assert np.array_equal(F.read_png(str(tmp_path / "c.png")), img)
+    F.write_png(str(tmp_path / "g.png"), grey)
+    assert np.array_equal(F.read_png(str(tmp_path / "g.png"), grayscale=True), grey)
+    assert np.array_equal(F.read_png(str(tmp_path / "g.png")), np.repeat(grey[:, :, None], 3, axis=2))  # IMREAD_COLOR of a grey file
+    _png_with_filters(str(tmp_path / "f.png"), img)
+    assert np.array_equal(F.read_png(str(tmp_path / "f.png")), img)
+    _png_with_filters(str(tmp_path / "fg.png"), grey)
+    assert np.array_equal(F.read_png(str(tmp_path / "fg.png"), grayscale=True), grey)
+    g2 = F.read_png(str(tmp_path / "c.png"), grayscale=True)  # BGR2GRAY weights
+    assert np.abs(g2.astype(int) - (0.299 * img[:, :, 2] + 0.587 * img[:, :, 1] + 0.114 * img[:, :, 0])).max() <= 1
+    open(str(tmp_path / "bad.png"), "wb").write(b"not a png")
+    with pytest.raises(ValueError):
+        F.read_png(str(tmp_path / "bad.png"))
+
+
+def test_ply_roundtrip(F, tmp_path):
+    rng = np.random.default_rng(2)
+    c = (rng.normal(size=(6, 7, 3)) * 10).astype(np.float32)
+    c[0, 0] = [1e-5, 123456792.0, -0.0]
+    img = rng.integers(0, 256, (6, 7, 3), dtype=np.uint8)
+    p = str(tmp_path / "pc.ply")
+    F.write_ply(p, c, img)
+    txt = open(p).read().split("\n")
+    assert txt[0] == "ply" and txt[3] == "element vertex 42" and txt[10] == "end_header"
+    assert txt[11] == "9.99999975e-06 123456792 -0 %d %d %d" % (img[0, 0, 2], img[0, 0, 1], img[0, 0, 0])  # 9 significant digits, RGB
+    c2, col2 = F.read_ply(p)
+    assert np.array_equal(c2, c.reshape(-1, 3)) and np.array_equal(col2, img.reshape(-1, 3))  # %.9g round-trips float32
+
+
+def _archive(rsdsfm, oracle, tmp_path, rows=24, cols=32):
+    d = rsdsfm.synth.make_config(1, rows=rows, cols=cols)
+    K, gamma, t = d["K"], d["gamma"], d["truth"]
+    fx, fy, cx, cy = K
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    frames = []
+    for n in range(2):
+        R, tt = oracle.pose_table(t["v"] * (1 + n), t["w"] * (1 + n), 0.0, gamma, rows)
+        world = np.stack([(xx - cx) / fx, (yy - cy) / fy, np.ones((rows, cols))], axis=2) * np.array(t["Z"])[:, :, None]
+        frames.append(dict(rs_image=rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8), R=R, t=tt + 0.1 * n, world=world + n))
+    task = str(tmp_path / "task_a")
+    rsdsfm.formats.write_example_archive(task, K, gamma, t["v"], t["w"], 0.0, frames)
+    return task, K, gamma, t, frames
+
+
+def test_example_archive_roundtrip_python(F, rsdsfm, oracle, tmp_path):
+    task, K, gamma, t, frames = _archive(rsdsfm, oracle, tmp_path)
+    a = F.load_example_archive(task)
+    assert a["K"] == tuple(K) and a["truth"]["gamma"] == gamma and a["truth"]["k"] == 0.0
+    assert np.array_equal(a["truth"]["v"], t["v"]) and np.array_equal(a["truth"]["w"], t["w"])
+    for got, ref in zip(a["frames"], frames):
+        assert np.array_equal(got["rs_image"], ref["rs_image"]) and np.array_equal(got["R"], ref["R"]) and np.array_equal(got["t"], ref["t"])
+        assert np.array_equal(got["world"], ref["world"])
+    for name in ("A.csv", "1_rs.png", "2_rs_t.csv", "1_rs_r.csv", "2_rs_unproject_z.csv"):
+        assert os.path.exists(os.path.join(task, "images", name))  # the reference's file names (main.cc:613-671)
+
+
+def test_cpp_mirror_reads_the_archive(F, rsdsfm, oracle, tmp_path):
+    """host/formats.h (loadIntrinsicsFromFile, setPoses, setUnprojectionMapRs, imread / imwrite PNG) on the Python-written archive"""
+    task, K, gamma, t, frames = _archive(rsdsfm, oracle, tmp_path)
+    rsdsfm.load_library()
+    exe = str(tmp_path / "archive_run")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "cpp", "archive_run.cpp"),
+                           "-L", PKG, "-lrsdsfm_hip", "-lz", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([exe, task + "/images/", str(tmp_path) + "/"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    r = json.loads(out.stdout)
+    assert tuple(r["K"]) == tuple(K) and r["rows"] == 24 and r["cols"] == 32 and r["rejected"] == 1
+    for n, fr in enumerate(frames):
+        rows = 24
+        w_t = (fr["t"] * (np.arange(rows) + 1)[:, None]).sum()
+        w_R = (fr["R"].reshape(rows, 9) * (np.arange(9) + 1)).sum()
+        w_w = (fr["world"] * np.array([1.0, 2.0, 3.0])).sum()
+        assert np.isclose(r["t_sum"][n], w_t, rtol=1e-12) and np.isclose(r["R_sum"][n], w_R, rtol=1e-12) and np.isclose(r["w_sum"][n], w_w, rtol=1e-12)
+        flat = fr["rs_image"].reshape(-1).astype(np.uint64)
+        assert r["img_sum"][n] == int((flat * (np.arange(flat.size, dtype=np.uint64) % np.uint64(253) + np.uint64(1))).sum())
+    assert np.array_equal(F.read_png(str(tmp_path / "copy_rs.png")), frames[0]["rs_image"])  # C++-written PNG (deflate level 6)
+
+
+def test_sweep_outputs(F, tmp_path):
+    F.write_sweep_results(str(tmp_path), ["t1", "t2"], [[0.1, 0.3], [0.2]], [[1.0, 2.0], [3.0]], [[5.0, 7.0], [9.0]], w=[[1, 2, 3, 4, 5, 6], [7, 8, 9]])
+    lines = open(str(tmp_path / "errors.csv")).read().split("\n")
+    assert lines[0] == "task,error_w,error_v,reproject_error" and lines[1].startswith("t1,0.2") and lines[2].startswith("t2,0.2")
+    assert open(str(tmp_path / "w.csv")).read().split("\n")[1] == "7,8,9"

@@ -1,0 +1,83 @@
+"""GPU: an example archive in the reference's on-disk layout runs end to end through
+evaluate.evaluate_single_run -- the reference's evaluateSingleRun for synthetic data (main.cc:364-560): ground-truth
+flow, solve, depth image, back projection, crack interpolation, point cloud and the accuracy metrics -- and every
+stage equals the oracle chain on the same files."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _write_archive(rsdsfm, oracle, task, rows=60, cols=96):
+    """a rolling-shutter pair under constant motion: world frame = scanline-0 camera of frame 1; scanline i of frame n is
+    at 'time' beta = n + gamma * i / rows: R = I + beta [w]x, t = beta v (the reference's setRelativePose convention)"""
+    d = rsdsfm.synth.make_config(1, rows=rows, cols=cols)
+    K, gamma = d["K"], d["gamma"]
+    fx, fy, cx, cy = K
+    # |v| ~ 0.5 world units per frame with depths ~ 60: the solver normalises v to unit length, so the estimated structure is
+    # 1 / |v| = 2 x the truth -- inside the factor-10 window (with the 1 / gamma of the flow normalisation: 2.4 x) of the reference's scale estimate (camera.cc:643-654)
+    v, w = np.array([0.4, 0.3, 0.08]), np.array([0.004, -0.003, 0.006])
+    Z = np.array(d["truth"]["Z"]) * 60.0
+    yy, xx = np.mgrid[0:rows, 0:cols]
+    rng = np.random.default_rng(8)
+    frames = []
+    for n in range(2):
+        beta = n + gamma * np.arange(rows) / rows
+        R = np.eye(3)[None] + beta[:, None, None] * np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])[None]
+        t = beta[:, None] * v[None]
+        pc = np.stack([(xx - cx) / fx, (yy - cy) / fy, np.ones((rows, cols))], axis=2) * Z[:, :, None]
+        world = np.einsum("yji,yxj->yxi", R, pc - t[:, None, :])  # R^T (P_cam - t), per scanline
+        img = rng.integers(16, 256, (rows, cols, 3), dtype=np.uint8)
+        frames.append(dict(rs_image=img, R=R, t=t, world=world))
+    rsdsfm.formats.write_example_archive(task, K, gamma, v, w, 0.0, frames)
+    return K, gamma, v, w, frames
+
+
+def test_archive_end_to_end(rsdsfm, oracle, tmp_path):
+    task, out_dir = str(tmp_path / "task_1"), str(tmp_path / "results")
+    K, gamma, v, w, frames = _write_archive(rsdsfm, oracle, task)
+    rows, cols = frames[0]["rs_image"].shape[:2]
+    with rsdsfm.Solver(0) as s:
+        r = rsdsfm.evaluate.evaluate_single_run(s, task, out_dir, trials=20, tol=0.002, seed=3)
+    # ---- the oracle chain on the same files ----
+    a = rsdsfm.formats.load_example_archive(task)
+    f1, f2 = a["frames"]
+    flow_o, _ = oracle.true_flow(f1["world"], f2["R"], f2["t"], *K)
+    assert np.array_equal(r["flow"], flow_o)
+    q, u, qpx, fpx = oracle.flatten(flow_o, *K, gamma)
+    al, alk = oracle.get_alpha(fpx, rows, gamma), oracle.get_alpha_k(qpx, fpx, rows, gamma)
+    ro = oracle.ransac(q, u, al, alk, False, 20, 0.002, oracle.sample_indices(len(q), 20, 3), depth_mode=1)
+    assert r["n"] == len(q) and r["num_inliers"] == ro["num_inliers"]
+    refo = oracle.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], False, 1, ro["inlier_idx"])
+    inl_o, v_o, flipped_o = oracle.canonicalize_sign(refo["inliers"], refo["v"])
+    assert r["flipped"] == flipped_o and np.allclose(r["v"], v_o, rtol=1e-6, atol=1e-10) and np.allclose(r["w"], refo["w"], rtol=1e-6, atol=1e-10)
+    dm_o, _, _ = oracle.scatter_depth(inl_o, *K, rows, cols)
+    assert np.array_equal(r["depth_map"] != 0, dm_o != 0) and np.allclose(r["depth_map"], dm_o, rtol=1e-6)
+    # downstream stages are compared on the GPU path's own depth map / pose (bit-exact stages)
+    assert np.array_equal(r["depth_est"] != 0, dm_o != 0)
+    R_rel, t_rel = oracle.pose_table(r["v"], r["w"], r["k"], gamma, rows)
+    gs_o, c3_o = oracle.back_project(f1["rs_image"], r["depth_map"], R_rel, t_rel, *K)
+    assert np.array_equal(r["gs_image"], gs_o) and np.array_equal(r["coords"].view(np.uint32), c3_o.view(np.uint32))
+    assert np.array_equal(r["backprojection"], oracle.interpolate_cracky(gs_o, 1))
+    gt_depth = rsdsfm.evaluate.gt_depth_map(f1["world"], f1["R"], f1["t"])
+    R_abs, t_abs = rsdsfm.evaluate.relocate_pose(f1["R"], f1["t"])
+    st_o, eimg_o = oracle.reprojection_error(c3_o, gt_depth, r["depth_map"], R_abs, t_abs, *K, max_norm=10.0)
+    assert np.isclose(r["mean_reprojection_error"], st_o["mean_error"], rtol=1e-9) and r["reprojection"]["error_inliers"] == st_o["error_inliers"]
+    assert st_o["error_inliers"] > 0.9 * r["num_inliers"] and abs(st_o["scale"] * gamma * np.linalg.norm(v) - 1.0) < 0.05  # flow is normalised by gamma (main.cc:423-426)
+    assert r["mean_reprojection_error"] < 0.15 * 60.0  # differential model on geometric flow: within ~10 % of the scene depth
+    assert (r["error_image"] != eimg_o).mean() < 1e-3
+    # ---- the solve recovers the archive's motion (differential model on geometric flow: a few percent) ----
+    vt = v / np.linalg.norm(v)
+    vv = r["v"] / np.linalg.norm(r["v"])
+    # velocities come out in units of the gamma-normalised flow (u = flow * gamma / f, main.cc:423-426): w_est ~ gamma * w
+    assert float(vv @ vt) > 0.98 and np.linalg.norm(r["w"] - gamma * w) < 0.2 * np.linalg.norm(gamma * w), (r["v"], r["w"])
+    # ---- products on disk, readable by the package's own readers ----
+    for name in ("MinimalDepth.png", "rs_image.png", "backprojection.png", "error_image.png", "point_cloud.ply", "errors.csv", "w.csv", "v.csv", "k.csv"):
+        assert os.path.exists(os.path.join(out_dir, name)), name
+    assert np.array_equal(rsdsfm.formats.read_png(out_dir + "/backprojection.png"), r["backprojection"])
+    assert np.array_equal(rsdsfm.formats.read_png(out_dir + "/MinimalDepth.png", grayscale=True), r["depth_est"])
+    pc, col = rsdsfm.formats.read_ply(out_dir + "/point_cloud.ply")
+    assert np.array_equal(pc, r["coords"].reshape(-1, 3)) and np.array_equal(col, f1["rs_image"].reshape(-1, 3))
+    assert open(out_dir + "/errors.csv").read().startswith("task,error_w,error_v,reproject_error\ntask_1,")

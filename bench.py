@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify", "true_flow", "metrics"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nbuf", type=int, default=7, help="rotating HBM buffer sets (7 x 59 MB > 256 MiB L3)")
+    ap.add_argument("--depth-variant", type=int, default=None, help="rsdsfm_set_depth_variant: 0 register-staged, 1 LDS-DMA, 2 decision fused into launch 0")
     ap.add_argument("--trials", type=int, default=50, help="RANSAC trials of the full solve (report section 5.4 used 50)")
     ap.add_argument("--tol", type=float, default=0.05, help="RANSAC tolerance (reference main.cc:310)")
     args = ap.parse_args()
@@ -119,6 +120,8 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     solver = rsdsfm.Solver(local_rank, stream=stream.cuda_stream)
+    if args.depth_variant is not None:
+        solver.set_depth_variant(args.depth_variant)
 
     def barrier():
         if world > 1:

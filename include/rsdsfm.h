@@ -105,8 +105,9 @@ void rsdsfm_destroy(rsdsfm_ctx* ctx);
 const char* rsdsfm_last_error(const rsdsfm_ctx* ctx);
 const char* rsdsfm_version(void);
 int rsdsfm_synchronize(rsdsfm_ctx* ctx);
-/* data-movement variant of the fused LM depth kernel: 0 = register-staged loads (default), 1 = per-wave LDS-DMA
- * double buffering (global_load_lds + counted vmcnt).  Same arithmetic, same results. */
+/* variant of the LM depth solve's launch 0: 0 = register-staged loads (default), 1 = per-wave LDS-DMA double buffering
+ * (global_load_lds + counted vmcnt), 2 = as 0 with the trust-region decision fused into the kernel's tail instead of
+ * the separate decide kernel (experimental, measured slower).  Same arithmetic, same results. */
 int rsdsfm_set_depth_variant(rsdsfm_ctx* ctx, int variant);
 /* name of the HIP kernel that dominates the given entry point (for profiling / roofline reports) */
 const char* rsdsfm_kernel_name(const char* entry_point);

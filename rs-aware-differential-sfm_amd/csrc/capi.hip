@@ -105,10 +105,10 @@ int rsdsfm_create(rsdsfm_ctx** out, int device, void* stream_or_null) {
         c->own_stream = true;
     }
     bool ok = hipMalloc(&c->d_partials, sizeof(double) * 2048 * 64) == hipSuccess &&
-              hipMalloc(&c->d_tickets, sizeof(unsigned) * 16) == hipSuccess &&
+              hipMalloc(&c->d_tickets, sizeof(unsigned) * 64) == hipSuccess &&
               hipMalloc(&c->d_lm, sizeof(LmState)) == hipSuccess &&
               hipHostMalloc(reinterpret_cast<void**>(&c->h_lm), sizeof(LmState), hipHostMallocDefault) == hipSuccess &&
-              hipMemset(c->d_tickets, 0, sizeof(unsigned) * 16) == hipSuccess &&
+              hipMemset(c->d_tickets, 0, sizeof(unsigned) * 64) == hipSuccess &&
               hipMemset(c->d_lm, 0, sizeof(LmState)) == hipSuccess;
     if (ok) {
         memset(c->h_lm, 0, sizeof(LmState));
@@ -153,7 +153,7 @@ int rsdsfm_synchronize(rsdsfm_ctx* ctx) {
 
 int rsdsfm_set_depth_variant(rsdsfm_ctx* ctx, int variant) {
     CTX_OR_FAIL(ctx);
-    if (variant != 0 && variant != 1) return fail(c, RSDSFM_ERR_INVALID, "depth variant must be 0 (register-staged) or 1 (LDS-DMA)");
+    if (variant < 0 || variant > 2) return fail(c, RSDSFM_ERR_INVALID, "depth variant must be 0 (register-staged), 1 (LDS-DMA) or 2 (decision fused into launch 0)");
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     c->depth_variant = variant;
     return RSDSFM_OK;
@@ -182,6 +182,14 @@ int rsdsfm_estimate_inverse_depths_dev(rsdsfm_ctx* ctx, const double* d_q, const
     if (depth_mode == RSDSFM_DEPTH_CLOSED_FORM) return depth_closed_form_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho);
     if (depth_mode != RSDSFM_DEPTH_CERES_LM) return fail(c, RSDSFM_ERR_INVALID, "unknown depth_mode");
     // fixed fast-path sequence: speculate (launch 0) -> decide -> launch 1 (apply / continue / no-op)
+    if (c->depth_variant == 2) {  // launch 0 carries the decision in its tail (last workgroup): no separate decide kernel
+        int rcf = depth_lm_fused_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho);
+        if (rcf != RSDSFM_OK) return rcf;
+        rcf = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 1);
+        c->lm_issued_k = 2;
+        c->lm_issued_d = 1;
+        return rcf;
+    }
     int rc = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 0);
     if (rc != RSDSFM_OK) return rc;
     rc = depth_lm_decide_launch(c, n, 0);

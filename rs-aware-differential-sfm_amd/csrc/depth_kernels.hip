@@ -133,6 +133,127 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lm_kernel(const double2* __
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Variant 2: launch 0 with the trust-region decision fused into its tail.  Every workgroup publishes its row of
+// partials (agent-scope release), takes a ticket on one of 32 arrival counters and, when it completes a counter, on the
+// root counter; the workgroup that completes the root is the last one: it acquires, reduces all rows in the same fixed
+// order as depth_lm_decide_kernel, runs lm_advance and resets the counters.  Two-level counters keep the serialised
+// atomics per address at <= 32 (a single 1024-way ticket was measured at ~15 us).  No workgroup ever waits.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kDepthBlock) void depth_lm_fused_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
+                                                                     const double2* __restrict__ alpha2,
+                                                                     const double2* __restrict__ alpha_k2, int64_t n, Pose pose,
+                                                                     double2* __restrict__ rho2, LmState* state,
+                                                                     double* partials, unsigned* tickets) {
+    __shared__ LmPlanLds plan;
+    __shared__ double s_red[kDepthBlock / 64][NS];
+    __shared__ double s_sums[NS];
+    __shared__ int s_last;
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        plan.n_hist = 0;
+        plan.K = KMAX;
+        const int pr = state->predict;
+        plan.write_which = (pr >= 0 && pr <= KMAX) ? pr : 1;
+        double r = kInitialRadius;
+        for (int j = 0; j < KMAX; ++j) {
+            plan.inv_cand[j] = 1.0 / r;
+            r = radius_accept(r, 1.0);
+        }
+    }
+    __syncthreads();
+    const double two_over = 2.0 / (2.0 + pose.k);
+    double acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = 0.0;
+    const int64_t npairs = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + tid; p < npairs; p += stride) {
+        double2 qa = q[2 * p], qb = q[2 * p + 1];
+        double2 ua = u[2 * p], ub = u[2 * p + 1];
+        double2 al = alpha2[p], ak = alpha_k2[p];
+        double2 out;
+        out.x = lm_pixel(qa.x, qa.y, ua.x, ua.y, al.x, ak.x, pose, two_over, plan, acc);
+        out.y = lm_pixel(qb.x, qb.y, ub.x, ub.y, al.y, ak.y, pose, two_over, plan, acc);
+        rho2[p] = out;
+    }
+    if ((n & 1) && blockIdx.x == 0 && tid == 0) {
+        const int64_t i = n - 1;
+        double2 qa = q[i], ua = u[i];
+        const double* alpha = reinterpret_cast<const double*>(alpha2);
+        const double* alpha_k = reinterpret_cast<const double*>(alpha_k2);
+        reinterpret_cast<double*>(rho2)[i] = lm_pixel(qa.x, qa.y, ua.x, ua.y, alpha[i], alpha_k[i], pose, two_over, plan, acc);
+    }
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        double r = is_max_slot(s) ? wave_max(acc[s]) : wave_sum(acc[s]);
+        if (lane == 0) s_red[wv][s] = r;
+    }
+    __syncthreads();
+    // ---- arrival ----
+    // The row is published with RETURNING agent-scope atomic exchanges (performed at the memory side, coherent across the
+    // XCDs' L2s); consuming the returned values makes the wave wait until they have been performed, so the ticket that
+    // follows is ordered after the row without an agent-scope release fence (which writes back the whole L2: measured
+    // 5x slower than the separate decide kernel).
+    unsigned long long* prow = reinterpret_cast<unsigned long long*>(partials) + (int64_t)blockIdx.x * NS;
+    unsigned long long old = 0ull;
+    if (tid < NS) {
+        double r = s_red[0][tid];
+        for (int w2 = 1; w2 < kDepthBlock / 64; ++w2) r = is_max_slot(tid) ? fmax(r, s_red[w2][tid]) : r + s_red[w2][tid];
+        old = __hip_atomic_exchange(prow + tid, (unsigned long long)__double_as_longlong(r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // every lane of wave 0 observes its returned value (forces the s_waitcnt); the ballot keeps the dependency alive
+    const bool seen = __builtin_amdgcn_ballot_w64(old == 0xFFFFFFFFFFFFFFFFull) != 0xFFFFFFFFFFFFFFFFull;
+    if (tid == 0) {
+        const unsigned nb = gridDim.x;
+        const unsigned g = blockIdx.x & 31u;
+        const unsigned gsize = (nb >> 5) + (g < (nb & 31u) ? 1u : 0u);  // workgroups with blockIdx % 32 == g
+        const unsigned ngroups = nb < 32u ? nb : 32u;
+        int last = 0;
+        if (seen && __hip_atomic_fetch_add(&tickets[1 + g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize - 1u) {
+            if (__hip_atomic_fetch_add(&tickets[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1u) last = 1;
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (tid < 33) tickets[tid] = 0u;  // ready for the next launch (stream order separates launches)
+    LmScal st;
+    if (tid == 0) st = *static_cast<const LmScal*>(state);
+    const int nblocks = gridDim.x;
+    const unsigned long long* vp = reinterpret_cast<const unsigned long long*>(partials);
+    double fin[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) fin[s] = 0.0;
+    for (int b = tid; b < nblocks; b += kDepthBlock) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            // agent-scope loads: served from the memory side, never from a stale line of this XCD's L2
+            const double v = __longlong_as_double((long long)__hip_atomic_load(vp + (int64_t)b * NS + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            fin[s] = is_max_slot(s) ? fmax(fin[s], v) : fin[s] + v;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        double r = is_max_slot(s) ? wave_max(fin[s]) : wave_sum(fin[s]);
+        if (lane == 0) s_red[wv][s] = r;
+    }
+    __syncthreads();
+    if (tid < NS) {
+        double r = s_red[0][tid];
+        for (int w2 = 1; w2 < kDepthBlock / 64; ++w2) r = is_max_slot(tid) ? fmax(r, s_red[w2][tid]) : r + s_red[w2][tid];
+        s_sums[tid] = r;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int pr = st.predict;
+        const int used_write = (pr >= 0 && pr <= KMAX) ? pr : 1;
+        lm_advance(st, state->hist, s_sums, n, true, KMAX, used_write, 0);
+        *static_cast<LmScal*>(state) = st;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // LDS-DMA variant of the fused LM kernel (selected per context: rsdsfm_set_depth_variant)
 // ---------------------------------------------------------------------------------------------------
 // Same arithmetic and outputs as depth_lm_kernel, different data movement: every WAVE streams its own 128-point
@@ -402,6 +523,18 @@ int depth_lm_launch(Ctx* c, const double* q, const double* u, const double* a, c
             hipLaunchKernelGGL(depth_lm_kernel<0>, dim3(grid), dim3(kDepthBlock), 0, c->stream, q2, u2, a2, ak2, n, pose, rho2, c->d_lm,
                                c->d_partials, launch_id);
     }
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+int depth_lm_fused_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
+                          const Pose& pose, double* rho) {
+    if (!aligned16(q) || !aligned16(u) || !aligned16(a) || !aligned16(ak) || !aligned16(rho))
+        return fail(c, RSDSFM_ERR_INVALID, "device pointers must be 16-byte aligned");
+    const int grid = depth_lm_grid(c, n);
+    hipLaunchKernelGGL(depth_lm_fused_kernel, dim3(grid), dim3(kDepthBlock), 0, c->stream, reinterpret_cast<const double2*>(q),
+                       reinterpret_cast<const double2*>(u), reinterpret_cast<const double2*>(a), reinterpret_cast<const double2*>(ak), n, pose,
+                       reinterpret_cast<double2*>(rho), c->d_lm, c->d_partials, c->d_tickets);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -11,9 +11,9 @@ from conftest import GOLDEN_CASES
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1], ids=["regstage", "ldsdma"])
+@pytest.fixture(scope="module", params=[0, 1, 2], ids=["regstage", "ldsdma", "fused_decide"])
 def solver(rsdsfm, request):
-    """every test of this module runs on both data-movement variants of the fused LM kernel"""
+    """every test of this module runs on the data-movement variants of the LM kernel and on the variant with the decision fused into launch 0"""
     s = rsdsfm.Solver(0)
     s.set_depth_variant(request.param)
     yield s

@@ -63,6 +63,31 @@ def build(force=False):
     return so
 
 
+_LIB_OMP = None
+
+
+def lib_omp():
+    """all-cores (OpenMP) build of the same source; only bench.py's all-cores CPU baseline uses it"""
+    global _LIB_OMP
+    if _LIB_OMP is None:
+        so = os.path.join(_HERE, "librsdsfm_oracle_omp.so")
+        src = os.path.join(_HERE, "rsdsfm_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-std=c99", "-fopenmp", "-shared", "-o", so, src, "-lm"])
+        _LIB_OMP = C.CDLL(so)
+    return _LIB_OMP
+
+
+def estimate_inverse_depths_all_cores(q, u, v, w, k, alpha, alpha_k, mode=1):
+    q, u, alpha, alpha_k = _f64(q), _f64(u), _f64(alpha), _f64(alpha_k)
+    n = q.shape[0]
+    rho = np.empty(n)
+    sm = LmSummary()
+    rc = lib_omp().rso_estimate_inverse_depths(_p(q), _p(u), C.c_int64(n), _v3(v), _v3(w), C.c_double(k), _p(alpha), _p(alpha_k), int(mode), _p(rho), C.byref(sm))
+    assert rc == 0
+    return rho, sm.as_dict()
+
+
 def lib():
     global _LIB
     if _LIB is None:

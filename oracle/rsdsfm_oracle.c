@@ -749,6 +749,12 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
     double* res = (double*)malloc(sizeof(double) * 2 * (n > 0 ? n : 1));
     double* cand = (double*)malloc(sizeof(double) * (n > 0 ? n : 1));
     double cost = 0.0, gmax = 0.0, xsq = 0.0;
+    /* The OpenMP pragmas below are active only in the optional all-cores build (librsdsfm_oracle_omp.so, `make omp`),
+     * which exists for bench.py's all-cores CPU baseline; the default oracle is compiled without -fopenmp and runs
+     * these loops sequentially (fixed summation order). */
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : cost, xsq) reduction(max : gmax) schedule(static)
+#endif
     for (int64_t i = 0; i < n; ++i) {
         rho[i] = 1.0; /* nonlinearRefinement.cc:140 */
         jac_rho(q[2 * i], q[2 * i + 1], alpha[i], alpha_k[i], v, k, &J[2 * i]);
@@ -783,6 +789,9 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
          * most 2 ulp of D^2, far below the emulation's own uncertainty) so that the per-pixel inner loop of the
          * HIP kernels, which mirror this arithmetic operation for operation, needs one division per iteration. */
         const double inv_radius = 1.0 / radius;
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : model_change, stepsq, ccost) schedule(static)
+#endif
         for (int64_t i = 0; i < n; ++i) {
             double jt0 = J[2 * i] * s[i], jt1 = J[2 * i + 1] * s[i];
             double ht = jt0 * jt0 + jt1 * jt1;
@@ -824,6 +833,9 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
             xsq = 0.0;
             cost = 0.0;
             gmax = 0.0;
+#ifdef _OPENMP
+#pragma omp parallel for reduction(+ : cost, xsq) reduction(max : gmax) schedule(static)
+#endif
             for (int64_t i = 0; i < n; ++i) {
                 rho[i] = cand[i];
                 xsq += rho[i] * rho[i];

@@ -91,7 +91,8 @@ def estimate_inverse_depths_all_cores(q, u, v, w, k, alpha, alpha_k, mode=1):
 def lib():
     global _LIB
     if _LIB is None:
-        _LIB = C.CDLL(build())
+        # RSO_ORACLE_LIB: an alternative build of the same source (e.g. `make -C oracle asan` run under LD_PRELOAD=libasan.so)
+        _LIB = C.CDLL(os.environ.get("RSO_ORACLE_LIB") or build())
         _LIB.rso_score.restype = C.c_int64
         _LIB.rso_flatten.restype = C.c_int64
     return _LIB

@@ -265,3 +265,40 @@ def test_metrics_degenerate(oracle, rsdsfm):
         assert np.all(img == 0)  # NaN errors -> 0 (defined here; undefined in the reference)
         st0, _ = s.reprojection_error(np.zeros((0, 4, 3), dtype=np.float32), np.zeros((0, 4)), np.zeros((0, 4)), R[:0], t[:0], (10.0, 10.0, 2.0, 3.0))
         assert np.isnan(st0["mean_error"])
+
+
+def test_consumers_at_3840x2160(oracle, rsdsfm):
+    """BASELINE configs[3] size: 64-bit indexing, grids beyond one wave of workgroups, int32 owner arrays at 8.3 M pixels --
+    back projection / interpolation / depth image bit-exact, metrics to summation order, and the flow search against a
+    frame 2 with 48 scanlines (the full 2160-scanline search is 1.8e10 projections: GPU-only, checked through its
+    size-independent property below)"""
+    rows, cols = 2160, 3840
+    d, img, depth, R, t = _scene(rsdsfm, oracle, rows, cols, seed=42, cfg=4)
+    K = d["K"]
+    with rsdsfm.Solver(0) as s:
+        gs, c3 = s.back_project(img, depth, R, t, K)
+        gs_o, c3_o = oracle.back_project(img, depth, R, t, *K)
+        assert np.array_equal(gs, gs_o) and np.array_equal(c3.view(np.uint32), c3_o.view(np.uint32))
+        assert np.array_equal(s.interpolate_cracky(gs, 1), oracle.interpolate_cracky(gs_o, 1))
+        yy, xx = np.mgrid[0:rows, 0:cols]
+        nz = depth != 0
+        inl = np.column_stack([((xx - K[2]) / K[0])[nz], ((yy - K[3]) / K[1])[nz], depth[nz]])
+        assert np.array_equal(s.depth_preview(inl, K, rows, cols), oracle.depth_preview(inl, *K, rows, cols))
+        Ra, ta = oracle.pose_table(np.array([0.11, 0.10, 0.06]), np.array([0.03, -0.02, 0.05]), 0.0, d["gamma"], rows)
+        st, _ = s.reprojection_error(c3, np.array(d["truth"]["Z"]), depth, Ra, ta, K, max_norm=4.0)
+        st_o, _ = oracle.reprojection_error(c3_o, np.array(d["truth"]["Z"]), depth, Ra, ta, *K, max_norm=4.0)
+        _close_stats(st, st_o)
+        world = np.stack([(xx - K[2]) / K[0], (yy - K[3]) / K[1], np.ones((rows, cols))], axis=2) * np.where(nz, depth, 0.0)[:, :, None]
+        R2, t2 = oracle.pose_table(np.array([0.12, 0.10, 0.05]), np.array([0.03, -0.02, 0.06]), 0.3, d["gamma"], 48)
+        flow, best = s.true_flow(world, R2, t2 + 0.01, K)
+        flow_o, best_o = oracle.true_flow(world, R2, t2 + 0.01, *K)
+        assert np.array_equal(best, best_o) and np.array_equal(flow.view(np.uint64), flow_o.view(np.uint64))
+        # full-size search, size-independent property: a static camera (identity poses for all 2160 scanlines) gives zero
+        # flow and every pixel's winner is its own row
+        Ri, ti = np.tile(np.eye(3), (rows, 1, 1)), np.zeros((rows, 3))
+        sub = world[:, ::16]  # 240 columns x 2160 rows x 2160 scanlines = 1.1e9 projections
+        f0, b0 = s.true_flow(sub, Ri, ti, K, q5_mode=1)
+        m = b0 >= 0
+        # column j of `sub` holds the point seen at image column 16 j: the flow is (16 j - j, 0)
+        assert np.abs(f0[:, :, 1][m]).max() < 1e-9 and np.abs(f0[:, :, 0] - 15.0 * np.arange(sub.shape[1])[None, :])[m].max() < 1e-9
+        assert np.array_equal(b0[m], np.tile(np.arange(rows)[:, None], (1, sub.shape[1]))[m])

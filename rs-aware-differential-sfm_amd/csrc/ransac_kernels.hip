@@ -35,6 +35,8 @@ constexpr int kRansacK0 = KMAX;
 // data (the common case inside RANSAC) ends with, depending on how far rho = 1 is from the optimum
 constexpr int kFused = 2;
 constexpr int NSR = NS + 2 * kFused;
+constexpr int kNSum = NSR - (KMAX + 1);  // sum slots (the KMAX + 1 gradient-max slots are reduced with fmax)
+constexpr int kTStride = 65;             // row stride of the per-wave transpose buffer (bank-conflict-free)
 
 struct ScoreHook {
     double x, y, ux, uy, al, ak, two_over, tol;
@@ -100,6 +102,8 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
     extern __shared__ double s_acc[];  // [T][NSR]
     __shared__ LmPlanLds plan;
     __shared__ double s_red[2][kRB / 64][NSR];
+    __shared__ double s_T[kRB / 64][kNSum * kTStride];  // per-wave transpose buffer of the sum slots
+    __shared__ double s_half[kRB / 64][2][kNSum];
     __shared__ int s_active;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int i = tid; i < T * NSR; i += kRB) s_acc[i] = 0.0;
@@ -154,15 +158,53 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
                     (void)lm_pixel(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, plan, acc, hook);
                 }
             double(*red)[NSR] = s_red[t & 1];
+            // ---- wave reduction of the NSR values ----
+            // The 4 max slots go through DPP butterflies.  The 18 SUM slots are transposed through LDS instead of 18 x 6
+            // DPP steps: every lane stores its 18 values (conflict-free, row stride 65), then lane (slot, half) adds the 32
+            // values of its half in lane order and the two halves are added -- a fixed order, 18 stores + 32 loads + 32
+            // adds per lane instead of ~320 DPP/VALU instructions per hypothesis.  A wave's LDS operations execute in
+            // order, so no barrier is needed inside the wave.
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                double r = is_max_slot(s) ? wave_max(acc[s]) : wave_sum(acc[s]);
-                if (lane == 0) red[wv][s] = r;
+            for (int s = 0; s < NS; ++s)
+                if (is_max_slot(s)) {
+                    const double r = wave_max(acc[s]);
+                    if (lane == 0) red[wv][s] = r;
+                }
+            double* Tw = s_T[wv];
+            {
+                int kk = 0;
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    if (!is_max_slot(s)) {
+                        Tw[kk * kTStride + lane] = acc[s];
+                        ++kk;
+                    }
+#pragma unroll
+                for (int s = 0; s < 2 * kFused; ++s) Tw[(kNSum - 2 * kFused + s) * kTStride + lane] = sc[s];
             }
+            __builtin_amdgcn_wave_barrier();  // compiler ordering only: the wave's stores precede its loads below
+            {
+                const int sl = lane & 31, half = lane >> 5;
+                if (sl < kNSum) {
+                    const double* row = Tw + sl * kTStride + half * 32;
+                    double part = row[0];
 #pragma unroll
-            for (int s = 0; s < 2 * kFused; ++s) {
-                const double r = wave_sum(sc[s]);
-                if (lane == 0) red[wv][NS + s] = r;
+                    for (int j = 1; j < 32; ++j) part += row[j];
+                    s_half[wv][half][sl] = part;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < kNSum) {
+                    // slot id of sum index `lane`: the sum slots in increasing slot order, then the fused scores
+                    int slot = NS + (lane - (kNSum - 2 * kFused));
+                    int kk = 0;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+                        if (!is_max_slot(s)) {
+                            if (kk == lane) slot = s;
+                            ++kk;
+                        }
+                    red[wv][slot] = s_half[wv][0][lane] + s_half[wv][1][lane];
+                }
             }
             __syncthreads();
             if (tid < NSR) {

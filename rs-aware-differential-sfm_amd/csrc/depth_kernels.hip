@@ -51,6 +51,56 @@ __global__ __launch_bounds__(kDepthBlock) void depth_closed_form_kernel(const do
     }
 }
 
+// Wave reduction of the NS per-lane sums into red[NS] (valid after the caller's barrier).  A thread of the depth solve only
+// handles a couple of pixel pairs, so 18 DPP butterflies (~320 instructions) per wave were ~20 % of the kernel's
+// instruction count.  The KMAX + 1 max slots keep the DPP butterfly; the 14 sum slots are transposed through LDS in two
+// rounds of 7 (row stride 65: conflict-free): every lane stores its values, lane (slot, half) adds the 32 values of its
+// half in lane order, the halves are added -- a fixed order.  A wave's LDS operations execute in order; the
+// wave_barrier only pins the compiler's ordering.
+constexpr int kTRows = 7;
+constexpr int kTStride = 65;
+__device__ __forceinline__ void wave_reduce_sums(const double (&acc)[NS], double* red, double* Tw, double (*half_buf)[kTRows], int lane) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        if (is_max_slot(s)) {
+            const double r = wave_max(acc[s]);
+            if (lane == 0) red[s] = r;
+        }
+    constexpr int kSums = NS - (KMAX + 1);
+    static_assert(kSums == 2 * kTRows, "two rounds of kTRows sum slots");
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        int kk = 0;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+            if (!is_max_slot(s)) {
+                if (kk / kTRows == round) Tw[(kk % kTRows) * kTStride + lane] = acc[s];
+                ++kk;
+            }
+        __builtin_amdgcn_wave_barrier();
+        const int sl = lane & 31, hf = lane >> 5;
+        if (sl < kTRows) {
+            const double* row = Tw + sl * kTStride + hf * 32;
+            double part = row[0];
+#pragma unroll
+            for (int j = 1; j < 32; ++j) part += row[j];
+            half_buf[hf][sl] = part;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < kTRows) {
+            int slot = 0, k2 = 0;
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                if (!is_max_slot(s)) {
+                    if (k2 == round * kTRows + lane) slot = s;
+                    ++k2;
+                }
+            red[slot] = half_buf[0][lane] + half_buf[1][lane];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // launch_id 0 = the launch of LM iteration zero (fresh state, built-in plan); launch_id > 0 acts only if the
 // state machine designated exactly this launch (next_launch) to continue (status 0) or to apply (status 2).
 // FIRST = 1: launch 0 of a solve (always a full speculative pass); FIRST = 0: follow-up launches (apply / continue /
@@ -65,6 +115,8 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lm_kernel(const double2* __
                                                                double* __restrict__ partials, int launch_id) {
     __shared__ LmPlanLds plan;
     __shared__ double s_red[kDepthBlock / 64][NS];
+    __shared__ double s_T[kDepthBlock / 64][kTRows * kTStride];
+    __shared__ double s_half[kDepthBlock / 64][2][kTRows];
     const int tid = threadIdx.x;
     if (launch_id == 0) {
         if (tid == 0) {
@@ -117,13 +169,9 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lm_kernel(const double2* __
     }
     if (plan.K == 0) return;  // apply-only launch: no sums
 
-    // ---- workgroup partial (DPP wave reduction, then the 4 waves in order), one row of `partials` per workgroup ----
+    // ---- workgroup partial (wave reduction, then the 4 waves in order), one row of `partials` per workgroup ----
     const int lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-        double r = is_max_slot(s) ? wave_max(acc[s]) : wave_sum(acc[s]);
-        if (lane == 0) s_red[wv][s] = r;
-    }
+    wave_reduce_sums(acc, s_red[wv], s_T[wv], s_half[wv], lane);
     __syncthreads();
     if (tid < NS) {
         double r = s_red[0][tid];

@@ -111,7 +111,7 @@ struct Ctx {
 };
 
 constexpr int kDepthBlock = 256;
-constexpr int kDepthMaxBlocks = 1024;
+constexpr int kDepthMaxBlocks = 512;
 constexpr int kDecideBlock = 256;
 
 #define RSDSFM_HIP_CHECK(ctx, expr)                                                            \

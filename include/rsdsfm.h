@@ -105,9 +105,10 @@ void rsdsfm_destroy(rsdsfm_ctx* ctx);
 const char* rsdsfm_last_error(const rsdsfm_ctx* ctx);
 const char* rsdsfm_version(void);
 int rsdsfm_synchronize(rsdsfm_ctx* ctx);
-/* variant of the LM depth solve's launch 0: 0 = register-staged loads (default), 1 = per-wave LDS-DMA double buffering
- * (global_load_lds + counted vmcnt), 2 = as 0 with the trust-region decision fused into the kernel's tail instead of
- * the separate decide kernel (experimental, measured slower).  Same arithmetic, same results. */
+/* variant of the LM depth solve's fast path: 0 (default) = launch 0 + ONE follow-up launch that decides and applies
+ * (depth_lm_decide_apply_kernel); 1 = per-wave LDS-DMA double buffering in launch 0 (global_load_lds + counted vmcnt) with
+ * the separate decide kernel; 2 = the decision fused into the tail of launch 0 (experimental, measured slower); 3 = launch
+ * 0, separate decide kernel, follow-up launch (the fast path before the fusion).  Same arithmetic, same results. */
 int rsdsfm_set_depth_variant(rsdsfm_ctx* ctx, int variant);
 /* name of the HIP kernel that dominates the given entry point (for profiling / roofline reports) */
 const char* rsdsfm_kernel_name(const char* entry_point);

@@ -153,7 +153,7 @@ int rsdsfm_synchronize(rsdsfm_ctx* ctx) {
 
 int rsdsfm_set_depth_variant(rsdsfm_ctx* ctx, int variant) {
     CTX_OR_FAIL(ctx);
-    if (variant < 0 || variant > 2) return fail(c, RSDSFM_ERR_INVALID, "depth variant must be 0 (register-staged), 1 (LDS-DMA) or 2 (decision fused into launch 0)");
+    if (variant < 0 || variant > 3) return fail(c, RSDSFM_ERR_INVALID, "depth variant must be 0 (default), 1 (LDS-DMA), 2 (decision fused into launch 0) or 3 (separate decide kernel)");
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     c->depth_variant = variant;
     return RSDSFM_OK;
@@ -189,6 +189,14 @@ int rsdsfm_estimate_inverse_depths_dev(rsdsfm_ctx* ctx, const double* d_q, const
         c->lm_issued_k = 2;
         c->lm_issued_d = 1;
         return rcf;
+    }
+    if (c->depth_variant == 0) {  // launch 0, then ONE launch that decides and (if needed) applies
+        int rc0 = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 0);
+        if (rc0 != RSDSFM_OK) return rc0;
+        rc0 = depth_lm_decide_apply_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho);
+        c->lm_issued_k = 1;  // a continuation (status 0) starts with launch 1 in rsdsfm_depth_finish_dev
+        c->lm_issued_d = 1;
+        return rc0;
     }
     int rc = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 0);
     if (rc != RSDSFM_OK) return rc;

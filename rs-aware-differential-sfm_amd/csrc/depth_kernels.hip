@@ -112,7 +112,8 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lm_kernel(const double2* __
                                                                const double2* __restrict__ alpha_k2, int64_t n,
                                                                Pose pose, double2* __restrict__ rho2,
                                                                const LmState* __restrict__ state,
-                                                               double* __restrict__ partials, int launch_id) {
+                                                               double* __restrict__ partials, int launch_id,
+                                                               int* __restrict__ predict_used) {
     __shared__ LmPlanLds plan;
     __shared__ double s_red[kDepthBlock / 64][NS];
     __shared__ double s_T[kDepthBlock / 64][kTRows * kTStride];
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lm_kernel(const double2* __
             plan.K = KMAX;
             // speculate which iterate is final: what the previous solve on this context accepted (1 at start)
             const int pr = state->predict;
+            if (blockIdx.x == 0 && predict_used) *predict_used = pr;  // for depth_lm_decide_apply_kernel
             plan.write_which = (pr >= 0 && pr <= KMAX) ? pr : 1;
             double r = kInitialRadius;
             for (int j = 0; j < KMAX; ++j) {
@@ -177,6 +179,97 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lm_kernel(const double2* __
         double r = s_red[0][tid];
         for (int w2 = 1; w2 < kDepthBlock / 64; ++w2) r = is_max_slot(tid) ? fmax(r, s_red[w2][tid]) : r + s_red[w2][tid];
         partials[(int64_t)blockIdx.x * NS + tid] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Follow-up of launch 0 in the fast path: decision + apply in ONE launch (replaces depth_lm_decide_kernel followed by
+// depth_lm_kernel<0>).  Launch 0 always starts from the initial trust-region state, so its decision depends only on the
+// sums, n and the predictor value launch 0 used (`predict_used`): every workgroup reduces the partial rows itself (same
+// fixed order, ~64 KB from L2) and runs the state machine redundantly -- all workgroups obtain the same state without any
+// inter-workgroup communication, and nobody reads the global state during the kernel, so workgroup 0 can store it.
+//   result already written by launch 0 (predictor right, the steady state)  -> return
+//   finished but a different iterate is final                              -> replay the accepted steps, write rho
+//   more LM iterations needed (rare)                                       -> return; rsdsfm_depth_finish_dev continues
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kDepthBlock) void depth_lm_decide_apply_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
+                                                                            const double2* __restrict__ alpha2,
+                                                                            const double2* __restrict__ alpha_k2, int64_t n, Pose pose,
+                                                                            double2* __restrict__ rho2, LmState* state,
+                                                                            const double* __restrict__ partials, int nrows,
+                                                                            const int* __restrict__ predict_used) {
+    __shared__ LmPlanLds plan;
+    __shared__ double s_red[kDepthBlock / 64][NS];
+    __shared__ double s_T[kDepthBlock / 64][kTRows * kTStride];
+    __shared__ double s_half[kDepthBlock / 64][2][kTRows];
+    __shared__ double s_sums[NS];
+    __shared__ double s_hist[kMaxIter];
+    __shared__ int s_status;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int pr = *predict_used;
+    double fin[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) fin[s] = 0.0;
+    for (int b = tid; b < nrows; b += kDepthBlock) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const double v = partials[(int64_t)b * NS + s];
+            fin[s] = is_max_slot(s) ? fmax(fin[s], v) : fin[s] + v;
+        }
+    }
+    wave_reduce_sums(fin, s_red[wv], s_T[wv], s_half[wv], lane);
+    __syncthreads();
+    if (tid < NS) {
+        double r = s_red[0][tid];
+        for (int w2 = 1; w2 < kDepthBlock / 64; ++w2) r = is_max_slot(tid) ? fmax(r, s_red[w2][tid]) : r + s_red[w2][tid];
+        s_sums[tid] = r;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        LmScal st = {};
+        st.predict = pr;
+        const int used_write = (pr >= 0 && pr <= KMAX) ? pr : 1;
+        lm_advance(st, s_hist, s_sums, n, 1, KMAX, used_write, 0);
+        s_status = st.status;
+        plan.n_hist = st.n_hist;
+        plan.K = 0;
+        plan.write_which = 0;
+        if (st.status == 2) {  // this launch writes the result: the stored state says so
+            st.status = 1;
+            st.rho_holds = st.n_hist;
+            st.launches += 1;
+            st.next_launch = 2;
+        }
+        if (blockIdx.x == 0) {
+            *static_cast<LmScal*>(state) = st;
+            for (int h = 0; h < st.n_hist; ++h) state->hist[h] = s_hist[h];
+        }
+    }
+    __syncthreads();
+    if (s_status != 2) return;
+    if (tid < plan.n_hist) plan.inv_hist[tid] = 1.0 / s_hist[tid];
+    __syncthreads();
+    const double two_over = 2.0 / (2.0 + pose.k);
+    double acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = 0.0;
+    const int64_t npairs = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + tid; p < npairs; p += stride) {
+        double2 qa = q[2 * p], qb = q[2 * p + 1];
+        double2 ua = u[2 * p], ub = u[2 * p + 1];
+        double2 al = alpha2[p], ak = alpha_k2[p];
+        double2 out;
+        out.x = lm_pixel(qa.x, qa.y, ua.x, ua.y, al.x, ak.x, pose, two_over, plan, acc);
+        out.y = lm_pixel(qb.x, qb.y, ub.x, ub.y, al.y, ak.y, pose, two_over, plan, acc);
+        rho2[p] = out;
+    }
+    if ((n & 1) && blockIdx.x == 0 && tid == 0) {
+        const int64_t i = n - 1;
+        double2 qa = q[i], ua = u[i];
+        const double* alpha = reinterpret_cast<const double*>(alpha2);
+        const double* alpha_k = reinterpret_cast<const double*>(alpha_k2);
+        reinterpret_cast<double*>(rho2)[i] = lm_pixel(qa.x, qa.y, ua.x, ua.y, alpha[i], alpha_k[i], pose, two_over, plan, acc);
     }
 }
 
@@ -566,11 +659,22 @@ int depth_lm_launch(Ctx* c, const double* q, const double* u, const double* a, c
     } else {
         if (launch_id == 0)
             hipLaunchKernelGGL(depth_lm_kernel<1>, dim3(grid), dim3(kDepthBlock), 0, c->stream, q2, u2, a2, ak2, n, pose, rho2, c->d_lm,
-                               c->d_partials, launch_id);
+                               c->d_partials, launch_id, reinterpret_cast<int*>(c->d_tickets + 40));
         else
             hipLaunchKernelGGL(depth_lm_kernel<0>, dim3(grid), dim3(kDepthBlock), 0, c->stream, q2, u2, a2, ak2, n, pose, rho2, c->d_lm,
-                               c->d_partials, launch_id);
+                               c->d_partials, launch_id, static_cast<int*>(nullptr));
     }
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+// fast-path follow-up of launch 0: decision + apply (variant 0 only; the rows are those of the launch-0 grid)
+int depth_lm_decide_apply_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
+                                 const Pose& pose, double* rho) {
+    const int grid = depth_lm_grid(c, n);
+    hipLaunchKernelGGL(depth_lm_decide_apply_kernel, dim3(grid), dim3(kDepthBlock), 0, c->stream, reinterpret_cast<const double2*>(q),
+                       reinterpret_cast<const double2*>(u), reinterpret_cast<const double2*>(a), reinterpret_cast<const double2*>(ak), n, pose,
+                       reinterpret_cast<double2*>(rho), c->d_lm, c->d_partials, grid, reinterpret_cast<const int*>(c->d_tickets + 40));
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -102,7 +102,7 @@ struct Ctx {
     void* h_pinned = nullptr;  // small pinned host buffer for result headers
     size_t pinned_bytes = 0;
     int num_cus = 256;
-    int depth_variant = 0;  // 0 = register-staged depth_lm_kernel, 1 = LDS-DMA depth_lm_dma_kernel, 2 = launch 0 with the decision fused into its tail
+    int depth_variant = 0;  // 0 = register-staged depth_lm_kernel, 1 = LDS-DMA depth_lm_dma_kernel, 2 = launch 0 with the decision fused into its tail, 3 = separate decide kernel + follow-up launch (the pre-fusion fast path)
     // row-tiled refinement session (tiled_host.hip): buffers live in d_tile, not in the shared workspace
     void* d_tile = nullptr;
     size_t tile_bytes = 0;
@@ -149,6 +149,8 @@ int depth_closed_form_launch(Ctx* c, const double* q, const double* u, const dou
 int depth_lm_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                     const Pose& pose, double* rho, int launch_id);
 int depth_lm_decide_launch(Ctx* c, int64_t n, int launch_id);
+int depth_lm_decide_apply_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
+                                 const Pose& pose, double* rho);
 int depth_lm_fused_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                           const Pose& pose, double* rho);
 int depth_lm_reduce_launch(Ctx* c, int64_t n, double* d_row);

@@ -11,7 +11,7 @@ from conftest import GOLDEN_CASES
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[0, 1, 2], ids=["regstage", "ldsdma", "fused_decide"])
+@pytest.fixture(scope="module", params=[0, 1, 2, 3], ids=["default_decide_apply", "ldsdma", "decide_in_launch0_tail", "separate_decide"])
 def solver(rsdsfm, request):
     """every test of this module runs on the data-movement variants of the LM kernel and on the variant with the decision fused into launch 0"""
     s = rsdsfm.Solver(0)

@@ -65,16 +65,57 @@ __device__ __forceinline__ void resid_jac(double x, double y, double ux, double 
     o.Jr[1] = beta * a1;
 }
 
+// Wave reduction of NV per-lane values into red_row[NV] (one row per wave; valid for other threads after a workgroup
+// barrier).  NV is up to 70 here, and a thread only handles a handful of inliers, so NV DPP butterflies (18 instructions
+// each) were almost half of the streaming kernels' instruction count.  The sums go through a per-wave LDS transpose
+// instead, 8 slots per round (row stride 65: conflict-free): every lane stores its 8 values, lane (slot, eighth) adds 8
+// consecutive lanes' values, lane `slot` adds the 8 eighths in order -- a fixed order, ~5 instructions per slot.  The
+// (at most one) max slot is reduced with the DPP butterfly afterwards.  A wave's LDS operations execute in order; the
+// wave_barrier only pins the compiler's ordering.
+template <int NV>
+__device__ __forceinline__ void wave_reduce_to_row(const double (&v)[NV], int max_slot, double* red_row) {
+    __shared__ double s_T[kFB / 64][8 * 65];
+    __shared__ double s_part[kFB / 64][8][8];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double* Tw = s_T[wv];
+    constexpr int R = (NV + 7) / 8;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (r * 8 + k < NV) Tw[k * 65 + lane] = v[r * 8 + k];
+        __builtin_amdgcn_wave_barrier();
+        const int sl = lane & 7, pt = lane >> 3;
+        const double* row = Tw + sl * 65 + pt * 8;
+        double part = row[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) part += row[j];
+        s_part[wv][sl][pt] = part;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 8 && r * 8 + lane < NV) {
+            double t = s_part[wv][lane][0];
+#pragma unroll
+            for (int p2 = 1; p2 < 8; ++p2) t += s_part[wv][lane][p2];
+            red_row[r * 8 + lane] = t;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (max_slot >= 0) {
+#pragma unroll
+        for (int s = 0; s < NV; ++s)
+            if (s == max_slot) {  // uniform branch; only this slot pays for a butterfly
+                const double r = wave_max(v[s]);
+                if (lane == 0) red_row[s] = r;
+            }
+    }
+}
+
 // generic fixed-order workgroup reduction of NV per-thread values; kinds: slot s is a max slot iff s == max_slot
 template <int NV>
 __device__ __forceinline__ void block_reduce_store(const double (&v)[NV], int max_slot, double (*s_red)[NV],
                                                    double* __restrict__ out_row) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-#pragma unroll
-    for (int s = 0; s < NV; ++s) {
-        double r = (s == max_slot) ? wave_max(v[s]) : wave_sum(v[s]);
-        if (lane == 0) s_red[wv][s] = r;
-    }
+    const int tid = threadIdx.x, wv = tid >> 6;
+    wave_reduce_to_row<NV>(v, max_slot, s_red[wv]);
     __syncthreads();
     if (tid < NV) {
         double r = s_red[0][tid];
@@ -87,7 +128,7 @@ __device__ __forceinline__ void block_reduce_store(const double (&v)[NV], int ma
 template <int NV>
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int nblocks, int max_slot,
                                                 double (*s_red)[NV], double* s_out) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x, wv = tid >> 6;
     double fin[NV];
 #pragma unroll
     for (int s = 0; s < NV; ++s) fin[s] = 0.0;
@@ -96,11 +137,7 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
 #pragma unroll
         for (int s = 0; s < NV; ++s) fin[s] = (s == max_slot) ? fmax(fin[s], row[s]) : fin[s] + row[s];
     }
-#pragma unroll
-    for (int s = 0; s < NV; ++s) {
-        double r = (s == max_slot) ? wave_max(fin[s]) : wave_sum(fin[s]);
-        if (lane == 0) s_red[wv][s] = r;
-    }
+    wave_reduce_to_row<NV>(fin, max_slot, s_red[wv]);
     __syncthreads();
     if (tid < NV) {
         double r = s_red[0][tid];

@@ -83,10 +83,13 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     Arena ws(c->d_ws);
     int32_t* d_samples = ws.take<int32_t>((size_t)Tn * 9);
     double* d_hyp = ws.take<double>((size_t)Tn * 8);
+    // states, scored and flags are adjacent so that ONE memset clears them
+    char* zero_begin = ws.base + ws.off;
     LmState* d_states = ws.take<LmState>(Tn);
-    double* d_partials = ws.take<double>((size_t)ransac_lm_partials_doubles(c, n, batch));
-    int* d_flags = ws.take<int>(2);  // {running, unscored}
     int* d_scored = ws.take<int>(Tn);
+    int* d_flags = ws.take<int>(2);  // {running, unscored}
+    const size_t zero_bytes = (size_t)((ws.base + ws.off) - zero_begin);
+    double* d_partials = ws.take<double>((size_t)ransac_lm_partials_doubles(c, n, batch));
     double* d_tcount = ws.take<double>(Tn);
     double* d_terr = ws.take<double>(Tn);
     RansacBest* d_best = ws.take<RansacBest>(1);
@@ -105,8 +108,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     double* h_hyp = h_terr + Tn;
     LmState* h_states = reinterpret_cast<LmState*>(h_hyp + (size_t)8 * Tn);
 
-    RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_states, 0, sizeof(LmState) * Tn, c->stream));
-    RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_scored, 0, sizeof(int) * Tn, c->stream));
+    RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
     if (T > 0) {
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_samples, samples.data(), sizeof(int32_t) * (size_t)T * 9, hipMemcpyHostToDevice, c->stream));
         rc = minimal9_launch(c, d_q, d_u, d_a, d_ak, d_samples, T, use_alpha_k, k_sign_mode, d_hyp);
@@ -115,7 +117,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
             const int B = std::min(batch, T - b0);
             bool need_score = true;
             if (depth_mode == RSDSFM_DEPTH_CERES_LM) {
-                RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_flags, 0, sizeof(int) * 2, c->stream));
+                if (b0 > 0) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_flags, 0, sizeof(int) * 2, c->stream));  // batch 0: cleared above
                 for (int round = 0;; ++round) {
                     if (round > 4 * kMaxIter) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machines did not terminate");
                     rc = ransac_lm_round_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, d_partials, d_flags,
@@ -141,12 +143,12 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
                              out->inlier_idx, out->inliers, out->alpha, out->alpha_k);
     if (rc != RSDSFM_OK) return rc;
     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, c->stream));
-    if (T > 0) {
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_tcount, d_tcount, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_terr, d_terr, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_hyp, d_hyp, sizeof(double) * 8 * T, hipMemcpyDeviceToHost, c->stream));
+    // per-trial diagnostics are copied back only when the caller asked for them (the frame solve does not)
+    if (T > 0 && out->trial_count) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_tcount, d_tcount, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
+    if (T > 0 && out->trial_err) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_terr, d_terr, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
+    if (T > 0 && out->trial_vel) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_hyp, d_hyp, sizeof(double) * 8 * T, hipMemcpyDeviceToHost, c->stream));
+    if (T > 0 && out->trial_steps && depth_mode == RSDSFM_DEPTH_CERES_LM)
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_states, d_states, sizeof(LmState) * T, hipMemcpyDeviceToHost, c->stream));
-    }
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     if (h_best->num_inliers != h_best->num_inliers_scan) return fail(c, RSDSFM_ERR_NUMERIC, "inlier count mismatch between scoring and compaction");
     out->num_inliers = h_best->num_inliers;

@@ -98,8 +98,12 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
                                                        const double* __restrict__ alpha_k, int64_t n,
                                                        const double* __restrict__ hyp, int T,
                                                        const LmState* __restrict__ states,
-                                                       double* __restrict__ partials, int round, double tol) {
+                                                       double* __restrict__ partials, int round, double tol,
+                                                       int* __restrict__ running_flag) {
     extern __shared__ double s_acc[];  // [T][NSR]
+    // the decide kernel of this round counts the still-running hypotheses into *running_flag; it runs after this kernel
+    // (stream order), so the counter is cleared here instead of by a separate memset
+    if (running_flag && blockIdx.x == 0 && threadIdx.x == 0) *running_flag = 0;
     __shared__ LmPlanLds plan;
     __shared__ double s_red[2][kRB / 64][NSR];
     __shared__ double s_T[kRB / 64][kNSum * kTStride];  // per-wave transpose buffer of the sum slots
@@ -603,9 +607,8 @@ int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const doubl
     const int grid = ransac_pixel_grid(c, n);
     hipLaunchKernelGGL(ransac_lm_kernel, dim3(grid), dim3(kRB), sizeof(double) * T * NSR, c->stream,
                        reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states,
-                       partials, round, tol);
+                       partials, round, tol, flags);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    RSDSFM_HIP_CHECK(c, hipMemsetAsync(flags, 0, sizeof(int), c->stream));
     hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, states, n, round, flags, scored,
                        trial_count, trial_err);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
@@ -633,7 +636,7 @@ int ransac_lm_rows_launch(Ctx* c, const double* q, const double* u, const double
     const int grid = ransac_pixel_grid(c, n);
     hipLaunchKernelGGL(ransac_lm_kernel, dim3(grid), dim3(kRB), sizeof(double) * T * NSR, c->stream,
                        reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states,
-                       partials, round, tol);
+                       partials, round, tol, static_cast<int*>(nullptr));
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(ransac_lm_rows_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, states, round, rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());

@@ -17,13 +17,14 @@ static int flatten_device(Ctx* c, const double* d_img, int32_t rows, int32_t col
         return RSDSFM_OK;
     }
     if (!d_img || !d_q || !d_u || !d_alpha || !d_alpha_k) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
-    int rc = ensure_ws(c, 2 * Arena::need(sizeof(int64_t) * 2048) + Arena::need(64) + 1024);
+    const size_t ncells = (size_t)flatten_cells(rows, cols);
+    int rc = ensure_ws(c, 2 * Arena::need(sizeof(int64_t) * ncells) + Arena::need(64) + 1024);
     if (rc != RSDSFM_OK) return rc;
     rc = ensure_pinned(c, 64);
     if (rc != RSDSFM_OK) return rc;
     Arena ws(c->d_ws);
-    int64_t* d_counts = ws.take<int64_t>(2048);
-    int64_t* d_offsets = ws.take<int64_t>(2048);
+    int64_t* d_counts = ws.take<int64_t>(ncells);
+    int64_t* d_offsets = ws.take<int64_t>(ncells);
     int64_t* d_total = ws.take<int64_t>(1);
     rc = flatten_launch(c, d_img, rows, cols, col0, fx, fy, cx, cy, gamma, thr, d_q, d_u, d_alpha, d_alpha_k, d_counts, d_offsets, d_total);
     if (rc != RSDSFM_OK) return rc;

@@ -92,107 +92,49 @@ namespace rsdsfm {
 namespace {
 constexpr int kGB = 256;
 
-// scan position p (column-major: p = i * rows + j) -> flow of pixel (row j, col i) of the row-major image
-__device__ __forceinline__ double2 flow_at(const double2* __restrict__ img, int rows, int cols, int64_t p, int& i, int& j) {
-    i = (int)(p / rows);
-    j = (int)(p - (int64_t)i * rows);
-    return img[(int64_t)j * cols + i];
-}
 }  // namespace
 
-// pass 1: per-block count of kept pixels (|flow|^2 > thr), blocks own contiguous ranges of the scan order
-__global__ __launch_bounds__(kGB) void flatten_count_kernel(const double2* __restrict__ img, int rows, int cols, double thr,
-                                                           int64_t chunk, int64_t* __restrict__ block_counts) {
-    __shared__ int s_cnt[kGB / 64];
-    const int64_t n = (int64_t)rows * cols;
-    const int64_t p0 = (int64_t)blockIdx.x * chunk, p1 = (p0 + chunk < n) ? p0 + chunk : n;
-    int count = 0;
-    for (int64_t p = p0 + threadIdx.x; p < p1; p += kGB) {
-        int i, j;
-        const double2 f = flow_at(img, rows, cols, p, i, j);
-        const double norm = f.x * f.x + f.y * f.y;
-        count += (norm > thr) ? 1 : 0;
-    }
-    for (int off = 32; off >= 1; off >>= 1) count += __shfl_xor(count, off, 64);
-    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = count;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int c = 0;
-        for (int w2 = 0; w2 < kGB / 64; ++w2) c += s_cnt[w2];
-        block_counts[blockIdx.x] = c;
-    }
-}
+// ---- flatten, tiled: coalesced reads of the row-major image ----
+// The scan order of the reference is column-major (main.cc:408-432) while the flow image is row-major, so walking the scan
+// positions directly reads 16 bytes per lane at a stride of one image row.  Here the image is cut into tiles of
+// kFT_W columns x kFT_H rows; a workgroup loads its tile with full 128-byte row segments into LDS and one WAVE compacts
+// one CELL = 64 consecutive rows of one column (ballot / popcount).  Cells are numbered column-major (cell = column *
+// chunks + chunk), so an exclusive scan of the cell counts yields every cell's base in the reference's order.
+constexpr int kScanSegCells = 2048;  // cells per segment of the two-level scan
+constexpr int kFT_W = 8;   // tile columns: 8 x 16 B = one 128-byte line per image row
+constexpr int kFT_H = 64;  // tile rows = cell height = one wave
 
-__global__ __launch_bounds__(256) void glue_scan_kernel(const int64_t* __restrict__ block_counts, int nblocks,
-                                                       int64_t* __restrict__ block_offsets, int64_t* __restrict__ total) {
-    __shared__ int64_t s_part[256];
-    const int tid = threadIdx.x;
-    const int per = (nblocks + 255) / 256;
-    int64_t sum = 0;
-    for (int j = 0; j < per; ++j) {
-        const int b = tid * per + j;
-        if (b < nblocks) sum += block_counts[b];
-    }
-    s_part[tid] = sum;
-    __syncthreads();
-    if (tid == 0) {
-        int64_t run = 0;
-        for (int i = 0; i < 256; ++i) {
-            int64_t v = s_part[i];
-            s_part[i] = run;
-            run += v;
-        }
-        *total = run;
-    }
-    __syncthreads();
-    int64_t run = s_part[tid];
-    for (int j = 0; j < per; ++j) {
-        const int b = tid * per + j;
-        if (b < nblocks) {
-            block_offsets[b] = run;
-            run += block_counts[b];
-        }
-    }
-}
-
-// pass 2: order-preserving scatter of (q, u, alpha, alpha_k)
-__global__ __launch_bounds__(kGB) void flatten_scatter_kernel(const double2* __restrict__ img, int rows, int cols, double fx,
-                                                             double fy, double cx, double cy, double gamma, double thr,
-                                                             int col0, int64_t chunk,
-                                                             const int64_t* __restrict__ block_offsets,
-                                                             double2* __restrict__ q, double2* __restrict__ u,
-                                                             double* __restrict__ alpha, double* __restrict__ alpha_k) {
-    __shared__ int s_wave[kGB / 64];
-    __shared__ int64_t s_base;
+template <int SCATTER>
+__global__ __launch_bounds__(kGB) void flatten_tile_kernel(const double2* __restrict__ img, int rows, int cols, double fx, double fy,
+                                                          double cx, double cy, double gamma, double thr, int col0, int nchunks,
+                                                          int64_t* __restrict__ cell_counts,
+                                                          const int64_t* __restrict__ cell_offsets,
+                                                          const int64_t* __restrict__ seg_bases, double2* __restrict__ q,
+                                                          double2* __restrict__ u, double* __restrict__ alpha,
+                                                          double* __restrict__ alpha_k) {
+    __shared__ double2 s_tile[kFT_H][kFT_W + 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int64_t n = (int64_t)rows * cols;
-    const int64_t p0 = (int64_t)blockIdx.x * chunk, p1 = (p0 + chunk < n) ? p0 + chunk : n;
-    const double h = (double)rows;
-    if (tid == 0) s_base = block_offsets[blockIdx.x];
-    __syncthreads();
-    for (int64_t start = p0; start < p1; start += kGB) {
-        const int64_t p = start + tid;
-        int i = 0, j = 0;
-        double2 f = make_double2(0.0, 0.0);
-        bool keep = false;
-        if (p < p1) {
-            f = flow_at(img, rows, cols, p, i, j);
-            const double norm = f.x * f.x + f.y * f.y;
-            keep = norm > thr;
-        }
-        const unsigned long long bal = __ballot(keep);
-        const int prefix = __popcll(bal & ((1ull << lane) - 1ull));
-        if (lane == 0) s_wave[wv] = __popcll(bal);
-        __syncthreads();
-        int woff = 0, total = 0;
+    const int c0 = blockIdx.x * kFT_W, r0 = blockIdx.y * kFT_H;
 #pragma unroll
-        for (int w2 = 0; w2 < kGB / 64; ++w2) {
-            const int c = s_wave[w2];
-            if (w2 < wv) woff += c;
-            total += c;
-        }
-        if (keep) {
-            const int64_t o = s_base + woff + prefix;
+    for (int k = 0; k < kFT_H * kFT_W / kGB; ++k) {
+        const int lr = tid / kFT_W + k * (kGB / kFT_W), lc = tid % kFT_W;
+        const int r = r0 + lr, c = c0 + lc;
+        s_tile[lr][lc] = (r < rows && c < cols) ? img[(int64_t)r * cols + c] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    const double h = (double)rows;
+    for (int lc = wv; lc < kFT_W; lc += kGB / 64) {
+        const int i = c0 + lc, j = r0 + lane;  // column i, row j
+        if (i >= cols) break;
+        const double2 f = s_tile[lane][lc];
+        const double norm = f.x * f.x + f.y * f.y;
+        const bool keep = j < rows && norm > thr;
+        const unsigned long long bal = __ballot(keep);
+        const int64_t cell = (int64_t)i * nchunks + blockIdx.y;
+        if (!SCATTER) {
+            if (lane == 0) cell_counts[cell] = __popcll(bal);
+        } else if (keep) {
+            const int64_t o = seg_bases[cell / kScanSegCells] + cell_offsets[cell] + __popcll(bal & ((1ull << lane) - 1ull));
             q[o] = make_double2(((i + col0) - cx) * 1.0 / fx, (j - cy) * 1.0 / fy);
             u[o] = make_double2(f.x * gamma / fx, f.y * gamma / fy);
             alpha[o] = 1 + gamma * f.y / h;  // minimal.cc:183 with pixel flow, h = rows (quirk Q6)
@@ -200,9 +142,6 @@ __global__ __launch_bounds__(kGB) void flatten_scatter_kernel(const double2* __r
             const double part2 = 1.0 + gamma * ((double)j + f.y) / h;
             alpha_k[o] = 0.5 * (part2 * part2 - part1 * part1);
         }
-        __syncthreads();
-        if (tid == 0) s_base += total;
-        __syncthreads();
     }
 }
 
@@ -270,33 +209,110 @@ __global__ __launch_bounds__(kGB) void depth_write_kernel(const double* __restri
     }
 }
 
-static inline void glue_chunking(int64_t n, int64_t& chunk, int& blocks) {
-    int64_t b = (n + kGB - 1) / kGB;
-    if (b < 1) b = 1;
-    chunk = kGB;
-    if (b > 2048) {
-        chunk = ((b + 2047) / 2048) * kGB;
-        b = (n + chunk - 1) / chunk;
+// exclusive scan of the cell counts in two levels (a single workgroup walking 15 000 ... 130 000 counts serialises on load
+// latency: 31 us at 1280x720).  Level 1: every workgroup scans kScanSeg consecutive counts (coalesced staging through LDS)
+// and writes local exclusive offsets + its segment total; level 2: one workgroup scans the segment totals in place and
+// stores the grand total.  The scatter kernel adds the segment base to the local offset.
+constexpr int kScanSeg = kScanSegCells;
+
+__global__ __launch_bounds__(256) void cell_scan_local_kernel(const int64_t* __restrict__ counts, int64_t ncells,
+                                                             int64_t* __restrict__ offsets, int64_t* __restrict__ seg_totals) {
+    __shared__ int s_cnt[kScanSeg];
+    __shared__ int s_wave[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int64_t base = (int64_t)blockIdx.x * kScanSeg;
+#pragma unroll
+    for (int k = 0; k < kScanSeg / 256; ++k) {
+        const int64_t i = base + k * 256 + tid;
+        s_cnt[k * 256 + tid] = i < ncells ? (int)counts[i] : 0;
     }
-    blocks = (int)b;
+    __syncthreads();
+    int v[kScanSeg / 256];
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < kScanSeg / 256; ++k) {
+        v[k] = s_cnt[tid * (kScanSeg / 256) + k];
+        sum += v[k];
+    }
+    int incl = sum;  // inclusive scan of the thread sums inside the wave
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    int wbase = 0;
+    for (int w2 = 0; w2 < wv; ++w2) wbase += s_wave[w2];
+    int run = wbase + incl - sum;
+#pragma unroll
+    for (int k = 0; k < kScanSeg / 256; ++k) {
+        const int64_t i = base + (int64_t)tid * (kScanSeg / 256) + k;
+        if (i < ncells) offsets[i] = run;
+        run += v[k];
+    }
+    if (tid == 255) seg_totals[blockIdx.x] = run;
 }
 
-// d_total: device int64 receiving the number of kept points; workspace: 2 x 2048 int64
+// in-place exclusive scan of the segment totals (nseg <= a few hundred) + grand total
+__global__ __launch_bounds__(256) void cell_scan_segments_kernel(int64_t* __restrict__ seg_totals, int nseg, int64_t* __restrict__ total) {
+    __shared__ int64_t s_part[256];
+    const int tid = threadIdx.x;
+    const int per = (nseg + 255) / 256;
+    int64_t sum = 0;
+    for (int j = 0; j < per; ++j) {
+        const int b = tid * per + j;
+        if (b < nseg) sum += seg_totals[b];
+    }
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        int64_t run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const int64_t v = s_part[i];
+            s_part[i] = run;
+            run += v;
+        }
+        *total = run;
+    }
+    __syncthreads();
+    int64_t run = s_part[tid];
+    for (int j = 0; j < per; ++j) {
+        const int b = tid * per + j;
+        if (b < nseg) {
+            const int64_t v = seg_totals[b];
+            seg_totals[b] = run;
+            run += v;
+        }
+    }
+}
+
+// cells of the tiled flatten (one per column and 64-row chunk): size of the two int64 work arrays
+// (d_offsets additionally holds the segment totals / bases behind the per-cell offsets)
+int64_t flatten_cells(int rows, int cols) {
+    const int64_t ncells = (int64_t)cols * ((rows + kFT_H - 1) / kFT_H);
+    return ncells + (ncells + kScanSeg - 1) / kScanSeg + 1;
+}
+
+// d_total: device int64 receiving the number of kept points; d_counts / d_offsets: flatten_cells(rows, cols) int64 each
 int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, int col0, double fx, double fy, double cx, double cy,
                    double gamma, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* d_counts,
                    int64_t* d_offsets, int64_t* d_total) {
-    const int64_t n = (int64_t)rows * cols;
-    int64_t chunk;
-    int blocks;
-    glue_chunking(n, chunk, blocks);
-    hipLaunchKernelGGL(flatten_count_kernel, dim3(blocks), dim3(kGB), 0, c->stream, reinterpret_cast<const double2*>(d_img), rows,
-                       cols, thr, chunk, d_counts);
+    const int nchunks = (rows + kFT_H - 1) / kFT_H;
+    const int64_t ncells = (int64_t)cols * nchunks;
+    if (ncells > (int64_t)INT32_MAX) return fail(c, RSDSFM_ERR_INVALID, "image too large for the flatten scan");
+    const dim3 grid((cols + kFT_W - 1) / kFT_W, nchunks);
+    const double2* img2 = reinterpret_cast<const double2*>(d_img);
+    const int nseg = (int)((ncells + kScanSeg - 1) / kScanSeg);
+    int64_t* d_seg = d_offsets + ncells;  // segment totals -> bases
+    hipLaunchKernelGGL(flatten_tile_kernel<0>, grid, dim3(kGB), 0, c->stream, img2, rows, cols, fx, fy, cx, cy, gamma, thr, col0, nchunks,
+                       d_counts, d_offsets, d_seg, reinterpret_cast<double2*>(d_q), reinterpret_cast<double2*>(d_u), d_alpha, d_alpha_k);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(glue_scan_kernel, dim3(1), dim3(256), 0, c->stream, d_counts, blocks, d_offsets, d_total);
+    hipLaunchKernelGGL(cell_scan_local_kernel, dim3(nseg), dim3(256), 0, c->stream, d_counts, ncells, d_offsets, d_seg);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(flatten_scatter_kernel, dim3(blocks), dim3(kGB), 0, c->stream, reinterpret_cast<const double2*>(d_img), rows,
-                       cols, fx, fy, cx, cy, gamma, thr, col0, chunk, d_offsets, reinterpret_cast<double2*>(d_q),
-                       reinterpret_cast<double2*>(d_u), d_alpha, d_alpha_k);
+    hipLaunchKernelGGL(cell_scan_segments_kernel, dim3(1), dim3(256), 0, c->stream, d_seg, nseg, d_total);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(flatten_tile_kernel<1>, grid, dim3(kGB), 0, c->stream, img2, rows, cols, fx, fy, cx, cy, gamma, thr, col0, nchunks,
+                       d_counts, d_offsets, d_seg, reinterpret_cast<double2*>(d_q), reinterpret_cast<double2*>(d_u), d_alpha, d_alpha_k);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

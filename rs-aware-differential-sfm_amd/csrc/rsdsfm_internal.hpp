@@ -163,6 +163,7 @@ namespace rsdsfm {
 int alpha_launch(Ctx* c, const double* flow_px, int64_t n, double h, double gamma, double* alpha);
 int alpha_k_launch(Ctx* c, const double* q_px, const double* flow_px, int64_t n, double h, double gamma, double* alpha_k);
 int pose_table_launch(Ctx* c, const Pose& pose, double gamma, int rows, double* R, double* t);
+int64_t flatten_cells(int rows, int cols);
 int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, int col0, double fx, double fy, double cx, double cy,
                    double gamma, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* d_counts,
                    int64_t* d_offsets, int64_t* d_total);

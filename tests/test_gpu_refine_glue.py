@@ -103,6 +103,25 @@ def test_flatten_matches_reference_glue(oracle, solver, rsdsfm):
     assert len(q0) == 0
 
 
+@pytest.mark.parametrize("rows,cols", [(1, 1), (1, 9), (63, 7), (64, 8), (65, 9), (130, 17), (200, 2100), (2160, 3840)])
+def test_flatten_ragged_tiles_and_sparse_images(oracle, solver, rsdsfm, rows, cols):
+    """tile edges (tiles are 8 columns x 64 rows), more than one scan segment (> 2048 cells), sparse images (most pixels below
+    the threshold, empty cells) and the 4K size: order and values bit-exact"""
+    rng = np.random.default_rng(rows * 7 + cols)
+    img = rng.normal(0, 1.0, (rows, cols, 2))
+    img[rng.random((rows, cols)) < 0.7] = 0.0  # 70 % of the pixels dropped
+    if rows > 3:
+        img[rows // 2] = 0.0  # an empty image row
+    if cols > 3:
+        img[:, cols // 3] = 0.0  # an empty column: empty cells
+    K, gamma = (300.0, 310.0, cols / 2.0 + 0.3, rows / 2.0 - 0.2), 0.9
+    q, u, a, ak = solver.flatten(img, K, gamma)
+    qo, uo, qpx, fpx = oracle.flatten(img, *K, gamma)
+    assert len(q) == len(qo)
+    assert np.array_equal(q, qo) and np.array_equal(u, uo)
+    assert np.array_equal(a, oracle.get_alpha(fpx, rows, gamma)) and np.array_equal(ak, oracle.get_alpha_k(qpx, fpx, rows, gamma))
+
+
 def test_depth_map_and_scanline_indices(oracle, solver, rsdsfm):
     d = rsdsfm.synth.make_config(1, rows=60, cols=80)
     q, t, K = d["q"], d["truth"], d["K"]

@@ -431,23 +431,33 @@ __global__ __launch_bounds__(256) void ransac_score_rows_kernel(const double* __
 
 // the reference's best-trial rule (minimal.cc:278-285) over all trials in order: strictly more inliers, or
 // equally many with a strictly smaller error sum; the earlier trial wins ties.
-__global__ void ransac_pick_kernel(const double* __restrict__ trial_count, const double* __restrict__ trial_err, int T,
-                                   const double* __restrict__ hyp, RansacBest* best) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// (one wave: the trial scores are fetched 64 at a time by the lanes, then walked in trial order through readlane -- the
+// sequential rule is kept literally, only the 2 T dependent global loads of a single-thread loop are gone)
+__global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restrict__ trial_count, const double* __restrict__ trial_err, int T,
+                                                        const double* __restrict__ hyp, RansacBest* best) {
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
     double best_count = -1.0, best_err = 0.0;
     int bi = -1;
-    for (int t = 0; t < T; ++t) {
-        const double c = trial_count[t], e = trial_err[t];
-        if (c > best_count || (c == best_count && e < best_err)) {
-            best_count = c;
-            best_err = e;
-            bi = t;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const double cl = t < T ? trial_count[t] : 0.0, el = t < T ? trial_err[t] : 0.0;
+        const int nt = T - t0 < 64 ? T - t0 : 64;
+        for (int j = 0; j < nt; ++j) {
+            const double c = __shfl(cl, j, 64), e = __shfl(el, j, 64);
+            if (c > best_count || (c == best_count && e < best_err)) {
+                best_count = c;
+                best_err = e;
+                bi = t0 + j;
+            }
         }
     }
-    best->best_trial = bi;
-    best->num_inliers = bi >= 0 ? (int64_t)best_count : 0;
-    best->inlier_error = best_err;
-    for (int i = 0; i < 8; ++i) best->hyp[i] = bi >= 0 ? hyp[(int64_t)bi * 8 + i] : 0.0;
+    if (lane < 8) best->hyp[lane] = bi >= 0 ? hyp[(int64_t)bi * 8 + lane] : 0.0;
+    if (lane == 0) {
+        best->best_trial = bi;
+        best->num_inliers = bi >= 0 ? (int64_t)best_count : 0;
+        best->inlier_error = best_err;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -68,3 +68,24 @@ def test_full_solve_4k_frame(rsdsfm):
     Z = t["Z"] / np.linalg.norm(t["v"]) * np.linalg.norm(r["v"])
     mask = got != 0
     assert np.median(np.abs(got[mask] - Z[mask]) / Z[mask]) < 0.05
+
+
+def test_solve_frame_is_bit_reproducible(rsdsfm):
+    """every floating reduction has a fixed order and the only atomics are integer: repeated solves of the same frame --
+    on one context and on a fresh one -- return bit-identical poses, summaries and depth maps"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(5, rows=180, cols=320)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    img = torch.from_numpy(d["flow_img"]).to(dev)
+    outs = []
+    for ctx in range(2):
+        with rsdsfm.Solver(0) as s:
+            for rep in range(3):
+                dm = torch.zeros((cols, rows), dtype=torch.float64, device=dev)
+                r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=30, tol=0.01, seed=11)
+                s.synchronize()
+                outs.append((r["num_inliers"], r["best_trial"], r["v"].tobytes(), r["w"].tobytes(), r["k"], r["refine_summary"]["final_cost"],
+                             r["refine_summary"]["num_iterations"], dm.cpu().numpy().tobytes()))
+    assert all(o == outs[0] for o in outs[1:])

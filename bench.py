@@ -248,7 +248,7 @@ def main():
                                        "fixed; one pair per GPU, %d rotating HBM buffer sets" %
                                        ("Ceres-1.14 LM emulation" if mode == 1 else "closed-form GN", nbuf),
                            "rows": rows, "cols": cols, "pixels": n, "depth_mode": int(mode),
-                           "launches_per_step": 3 if mode == 1 else 1, "extra_lm_launches": int(extra), "lm_summary": summary,
+                           "launches_per_step": (3 if args.depth_variant in (1, 3) else 2) if mode == 1 else 1, "extra_lm_launches": int(extra), "lm_summary": summary,
                            "max_rel_err_vs_truth": max_rel},
                 "roofline": {"bound": "hbm", "kernel": "depth_lm_kernel<1>" if mode == 1 else "depth_closed_form_kernel",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -16,8 +16,11 @@ Contract: python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on
                                   1280x720 frame pair.
               tiled_full        : the WHOLE solve of a 3840x2160 frame split into column slabs over the N ranks
                                   (rsdsfm_tile_* stages, dist.TiledFrameSolve; scaling "strong").
-  N > 1     = one process per GPU (torch.distributed / RCCL).  depth / full: each rank solves its own frame pair
+  N > 1     = one process per GPU (torch.distributed / RCCL).  depth / full: each rank solves its own frame pairs
               (sequence-throughput mode, BASELINE configs[4]), no data-path collective -> scaling "weak".
+  --streams = independent pairs in flight PER GPU (default 4): one solver context + HIP stream each; the pairs share nothing,
+              so the latency-bound follow-up launches of one pair overlap the streaming launch of another.  `value` is the
+              throughput of that loop; `config.one_pair_at_a_time` carries the same loop with a single context.
 Frame pairs rotate through enough distinct HBM buffers to exceed the 256 MiB Infinity Cache, so the timed loop
 streams from HBM, not from L3.
 """
@@ -119,11 +122,13 @@ def cpu_baseline_full(rsdsfm, trials, tol, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify", "true_flow", "metrics"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nbuf", type=int, default=7, help="rotating HBM buffer sets (7 x 59 MB > 256 MiB L3)")
+    ap.add_argument("--streams", type=int, default=3, help="independent frame pairs in flight per GPU: one solver context + HIP stream each "
+                    "(sequence-throughput mode, BASELINE configs[4]); 1 = one pair at a time")
     ap.add_argument("--depth-variant", type=int, default=None, help="rsdsfm_set_depth_variant: 0 register-staged, 1 LDS-DMA, 2 decision fused into launch 0")
     ap.add_argument("--trials", type=int, default=50, help="RANSAC trials of the full solve (report section 5.4 used 50)")
     ap.add_argument("--tol", type=float, default=0.05, help="RANSAC tolerance (reference main.cc:310)")
@@ -197,26 +202,44 @@ def main():
         v = t["v"] / np.linalg.norm(t["v"])  # unit translation, as the minimal solver returns it (minimal.cc:102-105)
         w, k = t["w"], 0.0
         mode = rsdsfm.DEPTH_CERES_LM if args.workload == "depth" else rsdsfm.DEPTH_CLOSED_FORM
-        nbuf = args.nbuf
+        # S independent pairs in flight: one solver context + one HIP stream each, no dependency between them (every context
+        # owns its LM state and partials), so the latency-bound follow-up launch of one pair overlaps the streaming launch of
+        # the next.  Buffer set i always belongs to context i % S.
+        S = max(1, args.streams)
+        streams = [stream] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
+        solvers = [solver] + [rsdsfm.Solver(local_rank, stream=st.cuda_stream) for st in streams[1:]]
+        if args.depth_variant is not None:
+            for sv in solvers[1:]:
+                sv.set_depth_variant(args.depth_variant)
+        nbuf = -(-max(args.nbuf, S) // S) * S
         sets = []
         for _ in range(nbuf):
             sets.append(dict(q=torch.from_numpy(data["q"]).to(dev), u=torch.from_numpy(data["u"]).to(dev),
                              a=torch.from_numpy(data["alpha"]).to(dev), ak=torch.from_numpy(data["alpha_k"]).to(dev),
                              rho=torch.empty(n, dtype=torch.float64, device=dev)))
-        calls = [solver.prepared_depth_step(s["q"].data_ptr(), s["u"].data_ptr(), n, v, w, k, s["a"].data_ptr(),
-                                            s["ak"].data_ptr(), s["rho"].data_ptr(), mode=mode) for s in sets]
+        torch.cuda.synchronize()
+        calls = [solvers[i % S].prepared_depth_step(s["q"].data_ptr(), s["u"].data_ptr(), n, v, w, k, s["a"].data_ptr(),
+                                                    s["ak"].data_ptr(), s["rho"].data_ptr(), mode=mode) for i, s in enumerate(sets)]
 
         def ptrs(s):
             return (s["q"].data_ptr(), s["u"].data_ptr(), n, v, w, k, s["a"].data_ptr(), s["ak"].data_ptr(), s["rho"].data_ptr())
 
         el = timed(lambda i: calls[i % nbuf](), args.steps, args.warmup)
-        # correctness of what was timed: the LM state machine finished inside the fixed launch sequence
-        extra, summary = 0, None
-        if mode == rsdsfm.DEPTH_CERES_LM:
-            summary, extra = solver.depth_finish_dev(*ptrs(sets[(args.steps - 1) % nbuf]))
-        rho = sets[(args.steps - 1) % nbuf]["rho"].cpu().numpy()
+        # correctness of what was timed: on EVERY context the LM state machine finished inside the fixed launch sequence and
+        # the last pair it solved matches the analytic truth
+        extra, summary, max_rel = 0, None, 0.0
         rho_true = (1.0 / t["Z"]).T.reshape(-1) * np.linalg.norm(t["v"])
-        max_rel = float(np.max(np.abs(rho - rho_true) / np.abs(rho_true)))
+        for j in range(min(S, args.steps)):
+            idx = (args.steps - 1 - j) % nbuf
+            if mode == rsdsfm.DEPTH_CERES_LM:
+                summary, ex = solvers[idx % S].depth_finish_dev(*ptrs(sets[idx]))
+                extra = max(extra, ex)
+            rho = sets[idx]["rho"].cpu().numpy()
+            max_rel = max(max_rel, float(np.max(np.abs(rho - rho_true) / np.abs(rho_true))))
+        # the same loop with ONE pair at a time (context 0 only), for reference
+        own = [i for i in range(nbuf) if i % S == 0]
+        n1 = max(20, args.steps // 4)
+        el1 = timed(lambda i: calls[own[i % len(own)]](), n1, 5) if S > 1 else el * n1 / args.steps
 
         # dominant-kernel duration: HIP events on the launch stream around bursts of BURST back-to-back launches of
         # that kernel alone (launch 0 of the LM solve = `depth_lm_kernel<1>` in the rocprof summaries); the quotient
@@ -244,23 +267,33 @@ def main():
             achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
             line.update({
                 "value": rows * cols * world * args.steps / el / 1e6, "ms_per_step": el / args.steps * 1e3, "scaling": "weak",
-                "config": {"workload": "BASELINE configs[1]: synthetic 1280x720 pair, per-pixel depth solve only (%s), pose "
-                                       "fixed; one pair per GPU, %d rotating HBM buffer sets" %
-                                       ("Ceres-1.14 LM emulation" if mode == 1 else "closed-form GN", nbuf),
+                "config": {"workload": "BASELINE configs[1]: synthetic 1280x720 pairs, per-pixel depth solve only (%s), pose fixed; "
+                                       "%d independent pairs in flight per GPU (one context + HIP stream each), %d rotating HBM buffer sets" %
+                                       ("Ceres-1.14 LM emulation" if mode == 1 else "closed-form GN", S, nbuf),
+                           "streams": S, "one_pair_at_a_time": {"value": rows * cols * world * n1 / el1 / 1e6, "ms_per_step": el1 / n1 * 1e3},
                            "rows": rows, "cols": cols, "pixels": n, "depth_mode": int(mode),
                            "launches_per_step": (3 if args.depth_variant in (1, 3) else 2) if mode == 1 else 1, "extra_lm_launches": int(extra), "lm_summary": summary,
                            "max_rel_err_vs_truth": max_rel},
                 "roofline": {"bound": "hbm", "kernel": "depth_lm_kernel<1>" if mode == 1 else "depth_closed_form_kernel",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                              "traffic": _traffic(args.workload), "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms,
-                             "median_launch_ms": kern_med},
+                             "median_launch_ms": kern_med,
+                             "note": "kernel duration measured with one pair in flight (bursts on one stream, the other contexts idle); "
+                                     "profiles/: rocprofv3 of `bench.py --streams 1`"},
+                # the same algorithmic bytes over the JOB's time per pair (S pairs in flight): what the HBM system delivers to the loop
+                "roofline_job": {"bound": "hbm", "achieved": alg_bytes / (el / args.steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": alg_bytes / (el / args.steps) / 1e9 / HBM_PEAK_GBS, "streams": S},
             })
         # the whole solve, reported beside the headline (not the timed `value`)
         full = _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps=8, warmup=2, timed=timed) if args.workload == "depth" else None
+        batched = _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, max(S, 4), per_thread=12) if (args.workload == "depth" and S > 1) else None
         if rank == 0:
             line["full_solve"] = full
+            line["full_solve_batched"] = batched
             line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(data, v, w)
             line["cpu_baseline_all_cores"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_all_cores(data, v, w)
+        for sv in solvers[1:]:
+            sv.close()
 
     # =================================================================================================
     elif args.workload == "full":
@@ -551,6 +584,44 @@ def _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps, warmup, timed
             "refine_summary": r["refine_summary"],
             "w_err": float(np.linalg.norm(r["w"] - t["w"])), "v_angle_deg": float(np.degrees(np.arccos(min(1.0, abs(float(vv @ vt)))))),
             "stages": "flatten+alpha, minimal9 x %d, RANSAC LM sums/decide/score/pick/compaction, refinement, depth map, pose table" % args.trials}
+
+
+def _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, S, per_thread):
+    """S whole solves in flight per GPU: one host thread + solver context + HIP stream each (the one-call frame solve
+    synchronises internally, ctypes releases the GIL); DeepFlow-like 1280x720 pairs as in _full_solve"""
+    import threading
+
+    d = rsdsfm.synth.make_config(5, seed=0x5EED0005 + rank)
+    rows, cols = d["rows"], d["cols"]
+    img0 = torch.from_numpy(d["flow_img"]).to(dev)
+    torch.cuda.synchronize()
+    out, barrier = [None] * S, threading.Barrier(S)
+
+    def worker(j):
+        st = torch.cuda.Stream(dev)
+        with torch.cuda.stream(st):
+            sv = rsdsfm.Solver(local_rank, stream=st.cuda_stream)
+            img = img0.clone()
+            dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+            for i in range(2):
+                sv.solve_frame_dev(img.data_ptr(), rows, cols, d["K"], d["gamma"], dm.data_ptr(), trials=args.trials, tol=args.tol, seed=1 + i)
+            sv.synchronize()
+            barrier.wait()
+            t0 = time.perf_counter()
+            for i in range(per_thread):
+                r = sv.solve_frame_dev(img.data_ptr(), rows, cols, d["K"], d["gamma"], dm.data_ptr(), trials=args.trials, tol=args.tol, seed=1 + i)
+            sv.synchronize()
+            out[j] = (time.perf_counter() - t0, r["num_inliers"])
+            sv.close()
+
+    ths = [threading.Thread(target=worker, args=(j,)) for j in range(S)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    el = max(o[0] for o in out)
+    return {"value": rows * cols * S * per_thread / el / 1e6, "unit": "Mpixels/s", "streams": S, "solves": S * per_thread,
+            "ms_per_solve_amortised": el / (S * per_thread) * 1e3, "num_inliers": out[0][1]}
 
 
 if __name__ == "__main__":

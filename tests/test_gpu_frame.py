@@ -89,3 +89,66 @@ def test_solve_frame_is_bit_reproducible(rsdsfm):
                 outs.append((r["num_inliers"], r["best_trial"], r["v"].tobytes(), r["w"].tobytes(), r["k"], r["refine_summary"]["final_cost"],
                              r["refine_summary"]["num_iterations"], dm.cpu().numpy().tobytes()))
     assert all(o == outs[0] for o in outs[1:])
+
+
+def test_concurrent_contexts_do_not_interfere(oracle, rsdsfm):
+    """the sequence-throughput mode of bench.py: several contexts on separate streams, (a) one host thread interleaving
+    asynchronous depth solves of DIFFERENT problems, (b) one host thread per context running whole-frame solves -- every
+    result equals what the same context produces alone (bit-exact) and the oracle"""
+    import threading
+
+    import torch
+
+    dev = torch.device("cuda", 0)
+    S = 3
+    streams = [torch.cuda.Stream(dev) for _ in range(S)]
+    solvers = [rsdsfm.Solver(0, stream=st.cuda_stream) for st in streams]
+    probs = []
+    for j in range(S):
+        d = rsdsfm.synth.make_config(1 if j != 1 else 3, rows=120 + 16 * j, cols=200)
+        t = d["truth"]
+        v = t["v"] / np.linalg.norm(t["v"]) * (1.0 if j != 2 else -1.0)
+        tens = {k2: torch.from_numpy(d[k2]).to(dev) for k2 in ("q", "u", "alpha", "alpha_k")}
+        rho = torch.zeros(len(d["alpha"]), dtype=torch.float64, device=dev)
+        probs.append((d, v, t["w"], tens, rho))
+    torch.cuda.synchronize()
+    for rep in range(20):  # interleaved, asynchronous
+        for j, (d, v, w, tens, rho) in enumerate(probs):
+            solvers[j].estimate_inverse_depths_dev(tens["q"].data_ptr(), tens["u"].data_ptr(), len(d["alpha"]), v, w, 0.0, tens["alpha"].data_ptr(),
+                                                   tens["alpha_k"].data_ptr(), rho.data_ptr(), mode=1)
+    for j, (d, v, w, tens, rho) in enumerate(probs):
+        sm, _ = solvers[j].depth_finish_dev(tens["q"].data_ptr(), tens["u"].data_ptr(), len(d["alpha"]), v, w, 0.0, tens["alpha"].data_ptr(),
+                                            tens["alpha_k"].data_ptr(), rho.data_ptr())
+        rho_o, sm_o = oracle.estimate_inverse_depths(d["q"], d["u"], v, w, 0.0, d["alpha"], d["alpha_k"], mode=1)
+        assert sm["num_successful_steps"] == sm_o["num_successful_steps"] and sm["termination"] == sm_o["termination"]
+        assert np.allclose(rho.cpu().numpy(), rho_o, rtol=1e-9, atol=1e-13)
+    # (b) whole-frame solves from one thread per context
+    frames = [rsdsfm.synth.make_config(5, rows=150, cols=260, seed=100 + j) for j in range(S)]
+
+    def solve(sv, d, reps):
+        img = torch.from_numpy(d["flow_img"]).to(dev)
+        dm = torch.zeros((d["cols"], d["rows"]), dtype=torch.float64, device=dev)
+        r = None
+        for _ in range(reps):
+            r = sv.solve_frame_dev(img.data_ptr(), d["rows"], d["cols"], d["K"], d["gamma"], dm.data_ptr(), trials=20, tol=0.01, seed=5)
+        sv.synchronize()
+        return (r["num_inliers"], r["best_trial"], r["v"].tobytes(), r["w"].tobytes(), dm.cpu().numpy().tobytes())
+
+    alone = []
+    for j in range(S):
+        with torch.cuda.stream(streams[j]):
+            alone.append(solve(solvers[j], frames[j], 1))
+    together = [None] * S
+
+    def worker(j):
+        with torch.cuda.stream(streams[j]):
+            together[j] = solve(solvers[j], frames[j], 6)
+
+    ths = [threading.Thread(target=worker, args=(j,)) for j in range(S)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert together == alone
+    for sv in solvers:
+        sv.close()

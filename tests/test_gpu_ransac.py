@@ -158,3 +158,31 @@ def test_ransac_full_size_invariants(solver, rsdsfm):
     rr = solver.ransac(q[::-1], u[::-1], a[::-1], ak[::-1], False, 8, 0.05, samples=(n - 1 - samples), depth_mode=1)
     assert np.array_equal(rr["trial_count"], r["trial_count"])
     assert np.allclose(rr["inv_depth"][::-1], r["inv_depth"], rtol=1e-12)
+
+
+def test_ransac_multi_round_lm(oracle, solver, rsdsfm):
+    """hypotheses whose dense LM solve needs more iterations than one speculative pass covers (10 accepted steps here: a
+    pixel next to the epipole has a tiny Jacobian): continuation rounds of the hypothesis-batched kernel, the separate score
+    pass, and a mix of finished / running hypotheses in one batch"""
+    d = rsdsfm.synth.make_config(1, rows=40, cols=48, v=np.array([0.05, 0.03, 1.0]))
+    q, u, a, ak = d["q"].copy(), d["u"].copy(), d["alpha"], d["alpha_k"]
+    t = d["truth"]
+    v = t["v"] / np.linalg.norm(t["v"])
+    q[7] = [v[0] / v[2] + 1e-7, v[1] / v[2] - 2e-7]
+    u[7] = [3e-2, -2e-2]
+    T = 6
+    smp = oracle.sample_indices(len(q), T, 3)
+    smp[smp == 7] = 8
+    r = solver.ransac(q, u, a, ak, False, T, 0.05, samples=smp, depth_mode=1)
+    ro = oracle.ransac(q, u, a, ak, False, T, 0.05, smp, depth_mode=1)
+    assert ro["trial_steps"].max() > 3  # more than KMAX accepted steps: at least two more rounds
+    _compare_ransac(r, ro, rho_rtol=1e-8)
+    # mixed batch: two near-degenerate samples (9 neighbours in one image column) give poor poses whose solves stop one
+    # iteration earlier, so finished and still-running hypotheses share a round
+    smp2 = smp.copy()
+    smp2[1] = np.arange(100, 109)
+    smp2[4] = np.arange(400, 409)
+    r2 = solver.ransac(q, u, a, ak, False, T, 0.05, samples=smp2, depth_mode=1)
+    ro2 = oracle.ransac(q, u, a, ak, False, T, 0.05, smp2, depth_mode=1)
+    assert len(set(ro2["trial_steps"].tolist())) > 1
+    _compare_ransac(r2, ro2, rho_rtol=1e-8)

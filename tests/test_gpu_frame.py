@@ -152,3 +152,36 @@ def test_concurrent_contexts_do_not_interfere(oracle, rsdsfm):
     assert together == alone
     for sv in solvers:
         sv.close()
+
+
+def test_full_pipeline_1920x1080_matches_oracle_chain(oracle, rsdsfm):
+    """BASELINE configs[2] ("real_world 1920x1080 full pipeline", 5 RANSAC trials like main.cc:304) end to end against the
+    oracle chain on the same sampler: every integer (points, per-trial counts, winner, inlier list, LM step counts, depth-map
+    support, scanline indices) bit-exact, floats to 1e-6 (north-star bar 1e-5)"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(3)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    T, tol, seed = 5, 0.002, 2024
+    img = torch.from_numpy(d["flow_img"]).to(dev)
+    dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+    with rsdsfm.Solver(0) as s:
+        r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=T, tol=tol, seed=seed)
+        s.synchronize()
+        q, u, a, ak = s.flatten(d["flow_img"], K, gamma)
+        rr = s.ransac(q, u, a, ak, False, T, tol, samples=None, seed=seed, depth_mode=1)
+    assert r["n"] == rows * cols == len(q)
+    ro = oracle.ransac(q, u, a, ak, False, T, tol, oracle.sample_indices(len(q), T, seed), depth_mode=1)
+    assert np.array_equal(rr["trial_count"], ro["trial_count"]) and np.array_equal(rr["trial_steps"], ro["trial_steps"])
+    assert rr["best_trial"] == ro["best_trial"] == r["best_trial"] and r["num_inliers"] == ro["num_inliers"]
+    assert np.array_equal(rr["inlier_idx"], ro["inlier_idx"])
+    refo = oracle.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], False, 1, ro["inlier_idx"])
+    for key in ("num_iterations", "num_successful_steps", "termination"):
+        assert r["refine_summary"][key] == refo["summary"][key], key
+    inl_o, v_o, flipped_o = oracle.canonicalize_sign(refo["inliers"], refo["v"])
+    assert r["flipped"] == flipped_o
+    assert np.allclose(r["v"], v_o, rtol=1e-6, atol=1e-10) and np.allclose(r["w"], refo["w"], rtol=1e-6, atol=1e-10)
+    dm_o, _, _ = oracle.scatter_depth(inl_o, *K, rows, cols)
+    got = dm.cpu().numpy().T
+    assert np.array_equal(got != 0, dm_o != 0) and np.allclose(got, dm_o, rtol=1e-6)

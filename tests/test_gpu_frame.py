@@ -185,3 +185,31 @@ def test_full_pipeline_1920x1080_matches_oracle_chain(oracle, rsdsfm):
     dm_o, _, _ = oracle.scatter_depth(inl_o, *K, rows, cols)
     got = dm.cpu().numpy().T
     assert np.array_equal(got != 0, dm_o != 0) and np.allclose(got, dm_o, rtol=1e-6)
+
+
+def test_bench_full_workload_matches_oracle_chain(oracle, rsdsfm):
+    """exactly what `bench.py --workload full` times (1280x720 DeepFlow-like pair, 50 trials, tol 0.05, seed 1): integers
+    bit-exact against the oracle chain, pose to 1e-6"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(5, seed=0x5EED0005)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    T, tol, seed = 50, 0.05, 1
+    img = torch.from_numpy(d["flow_img"]).to(dev)
+    dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+    with rsdsfm.Solver(0) as s:
+        r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=T, tol=tol, seed=seed)
+        s.synchronize()
+    q, u, qpx, fpx = oracle.flatten(d["flow_img"], *K, gamma)
+    a, ak = oracle.get_alpha(fpx, rows, gamma), oracle.get_alpha_k(qpx, fpx, rows, gamma)
+    ro = oracle.ransac(q, u, a, ak, False, T, tol, oracle.sample_indices(len(q), T, seed), depth_mode=1)
+    assert r["n"] == len(q) and r["best_trial"] == ro["best_trial"] and r["num_inliers"] == ro["num_inliers"]
+    refo = oracle.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], False, 1, ro["inlier_idx"])
+    for key in ("num_iterations", "num_successful_steps", "termination"):
+        assert r["refine_summary"][key] == refo["summary"][key], key
+    inl_o, v_o, flipped_o = oracle.canonicalize_sign(refo["inliers"], refo["v"])
+    assert r["flipped"] == flipped_o and np.allclose(r["v"], v_o, rtol=1e-6, atol=1e-10) and np.allclose(r["w"], refo["w"], rtol=1e-6, atol=1e-10)
+    dm_o, _, _ = oracle.scatter_depth(inl_o, *K, rows, cols)
+    got = dm.cpu().numpy().T
+    assert np.array_equal(got != 0, dm_o != 0) and np.allclose(got, dm_o, rtol=1e-6)

@@ -111,6 +111,23 @@ def test_full_size_properties(solver, rsdsfm):
     assert np.allclose(rho_s, rho0 / 2.0, rtol=1e-12)
 
 
+@pytest.mark.parametrize("cfg", [2, 5])
+def test_bench_depth_workload_matches_oracle(oracle, solver, rsdsfm, cfg):
+    """exactly what `bench.py` times (1280x720, config 2 = the headline workload; config 5 = the DeepFlow-like pair): the
+    oracle takes 0.1 s at this size, so the full-size result is compared directly -- decisions exact, depths to 1e-9"""
+    d = rsdsfm.synth.make_config(cfg, seed=0x5EED0000 + cfg)
+    q, u, a, ak, t = d["q"], d["u"], d["alpha"], d["alpha_k"], d["truth"]
+    v = t["v"] / np.linalg.norm(t["v"])
+    for mode in (0, 1):
+        rho, sm = solver.estimate_inverse_depths(q, u, v, t["w"], 0.0, a, ak, mode=mode)
+        rho_o, sm_o = oracle.estimate_inverse_depths(q, u, v, t["w"], 0.0, a, ak, mode=mode)
+        assert np.allclose(rho, rho_o, rtol=1e-9, atol=1e-13)
+        for key in ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination"):
+            assert sm[key] == sm_o[key], (mode, key)
+        if mode == 1:  # the closed-form path streams once and does not evaluate costs
+            assert np.isclose(sm["final_cost"], sm_o["final_cost"], rtol=1e-9, atol=1e-18)
+
+
 def test_alpha_and_pose_table(oracle, solver, rsdsfm):
     d = rsdsfm.synth.make_config(1, rows=60, cols=80)
     q, u, qpx, fpx = oracle.flatten(d["flow_img"], *d["K"], d["gamma"])

@@ -71,3 +71,80 @@ def evaluate_single_run(solver, task_dir, out_dir, trials=50, tol=0.05, seed=1, 
         formats.write_sweep_results(out_dir, [os.path.basename(task_dir.rstrip("/"))], [[w_err]], [[v_err]], [[stats["mean_error"]]],
                                     w=[res["w"]], v=[dm["v"]], k=[[res["k"]]])
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# parameter sweep (reference main.cc:148-299 -> error_measure::evaluateVelocities, errorMeasure.cpp:41-254)
+# ---------------------------------------------------------------------------------------------------
+def evaluate_velocities(solvers, archive, gamma, ransac_trials=50, num_evaluations=5, constant_acceleration=False, global_shutter=False,
+                        optimize_results=True, tol=0.05, flow_threshold=1e-10, base_seed=1, image_path=None):
+    """errorMeasure.cpp:41-254 for one task: ground-truth flow once, then `num_evaluations` independent solves (the reference
+    reseeds rand() per trial; here evaluation e uses the sampler seed base_seed + e) with their rotation / translation /
+    reprojection errors.  `solvers`: one Solver or a list -- the evaluations are independent and are spread over the
+    contexts, one host thread each (sequence-throughput mode)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from . import BACKPROJECT_GS, BACKPROJECT_RS, Solver, velocity_errors
+
+    if isinstance(solvers, Solver):
+        solvers = [solvers]
+    K, truth = archive["K"], archive["truth"]
+    f1, f2 = archive["frames"]
+    rows, cols = f1["rs_image"].shape[:2]
+    s0 = solvers[0]
+    flow, _ = s0.true_flow(f1["world"], f2["R"], f2["t"], K, want_best_row=False)
+    q, u, alpha, alpha_k = s0.flatten(flow, K, gamma, thr=flow_threshold)
+    if global_shutter:  # errorMeasure.cpp:107-112
+        alpha = np.ones_like(alpha)
+        constant_acceleration = False
+    gt_depth = gt_depth_map(f1["world"], f1["R"], f1["t"])
+    R_abs, t_abs = relocate_pose(f1["R"], f1["t"])
+
+    def one(e):
+        s = solvers[e % len(solvers)]
+        rr = s.ransac(q, u, alpha, alpha_k, constant_acceleration, ransac_trials, tol, samples=None, seed=base_seed + e)
+        res = dict(v=rr["v"], w=rr["w"], k=rr["k"], inliers=rr["inliers"])
+        if optimize_results:
+            ref = s.non_linear_refinement(u, rr["inliers"], rr["alpha"], rr["alpha_k"], rr["v"], rr["w"], rr["k"], constant_acceleration,
+                                          flow_index_mode=1, inlier_idx=rr["inlier_idx"])
+            res = dict(v=ref["v"], w=ref["w"], k=ref["k"], inliers=ref["inliers"])
+        dm = s.depth_map(res["inliers"], res["v"], K, rows, cols)
+        w_err, v_err = velocity_errors(res["w"], dm["v"], truth["w"], truth["v"])
+        R_rel, t_rel = s.pose_table(dm["v"], res["w"], res["k"], gamma, rows)
+        _, coords = s.back_project(f1["rs_image"], dm["depth_map"], R_rel, t_rel, K, mode=BACKPROJECT_GS if global_shutter else BACKPROJECT_RS)
+        stats, _ = s.reprojection_error(coords, gt_depth, dm["depth_map"], R_abs, t_abs, K, want_image=False)
+        if image_path:
+            formats.write_png("%s%d.png" % (image_path, e), s.depth_preview(dm["inliers"], K, rows, cols))
+            formats.write_ply("%s%d.ply" % (image_path, e), coords, f1["rs_image"])
+        return dict(w=res["w"], v=dm["v"], k=res["k"], w_error=w_err, v_error=v_err, reproject_error=stats["mean_error"], num_inliers=rr["num_inliers"])
+
+    if len(solvers) == 1:
+        runs = [one(e) for e in range(num_evaluations)]
+    else:
+        with ThreadPoolExecutor(max_workers=len(solvers)) as pool:
+            # evaluation e always runs on context e % S: one thread per context at a time
+            chunks = [list(range(j, num_evaluations, len(solvers))) for j in range(len(solvers))]
+            parts = list(pool.map(lambda ch: [(e, one(e)) for e in ch], chunks))
+        runs = [r for _, r in sorted((er for p in parts for er in p), key=lambda er: er[0])]
+    col = lambda key: np.array([r[key] for r in runs])
+    return dict(w=col("w"), v=col("v"), k=col("k"), error_w_vec=col("w_error"), error_v_vec=col("v_error"), error_reproject_vec=col("reproject_error"),
+                error_w=float(col("w_error").mean()), error_v=float(col("v_error").mean()), error_reproject=float(col("reproject_error").mean()),
+                num_inliers=col("num_inliers"))
+
+
+def evaluate_parameter_sweep(solvers, path, result_dir, tasks=None, **kw):
+    """main.cc:148-299: every task directory listed in <path>/tasks.txt (or `tasks`) -> errors.csv, w.csv, v.csv, k.csv,
+    reproject_errors.csv, error_v.csv, error_w.csv and depthMaps/<task index>/<evaluation>.{png,ply} under result_dir"""
+    if tasks is None:
+        tasks = [ln.strip() for ln in open(os.path.join(path, "tasks.txt")) if ln.strip()]
+    os.makedirs(result_dir, exist_ok=True)
+    results = []
+    for i, task in enumerate(tasks):
+        archive = formats.load_example_archive(os.path.join(path, task))
+        image_path = os.path.join(result_dir, "depthMaps", str(i)) + "/"
+        os.makedirs(image_path, exist_ok=True)
+        results.append(evaluate_velocities(solvers, archive, archive["truth"]["gamma"], image_path=image_path, **kw))
+    formats.write_sweep_results(result_dir, tasks, [r["error_w_vec"] for r in results], [r["error_v_vec"] for r in results],
+                                [r["error_reproject_vec"] for r in results], w=[r["w"] for r in results], v=[r["v"] for r in results],
+                                k=[r["k"] for r in results])
+    return dict(zip(tasks, results))

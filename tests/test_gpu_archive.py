@@ -81,3 +81,35 @@ def test_archive_end_to_end(rsdsfm, oracle, tmp_path):
     pc, col = rsdsfm.formats.read_ply(out_dir + "/point_cloud.ply")
     assert np.array_equal(pc, r["coords"].reshape(-1, 3)) and np.array_equal(col, f1["rs_image"].reshape(-1, 3))
     assert open(out_dir + "/errors.csv").read().startswith("task,error_w,error_v,reproject_error\ntask_1,")
+
+
+def test_parameter_sweep_over_archives(rsdsfm, oracle, tmp_path):
+    """main.cc:148-299: two tasks x four evaluations, spread over two solver contexts (threads); the same sweep on one
+    context gives bit-identical numbers, the errors are small, and the reference's result files are written"""
+    import torch
+
+    root = tmp_path / "sweep"
+    os.makedirs(root)
+    tasks = ["task_a", "task_b"]
+    for t in tasks:
+        _write_archive(rsdsfm, oracle, str(root / t), rows=48 if t == "task_a" else 60, cols=80)
+    open(root / "tasks.txt", "w").write("\n".join(tasks) + "\n")
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(dev) for _ in range(2)]
+    solvers = [rsdsfm.Solver(0, stream=st.cuda_stream) for st in streams]
+    kw = dict(ransac_trials=12, num_evaluations=4, tol=0.002, base_seed=5)
+    res2 = rsdsfm.evaluate.evaluate_parameter_sweep(solvers, str(root), str(tmp_path / "results2"), **kw)
+    res1 = rsdsfm.evaluate.evaluate_parameter_sweep(solvers[0], str(root), str(tmp_path / "results1"), **kw)
+    for s in solvers:
+        s.close()
+    for t in tasks:
+        for key in ("w", "v", "k", "error_w_vec", "error_v_vec", "error_reproject_vec", "num_inliers"):
+            assert np.array_equal(res1[t][key], res2[t][key]), (t, key)
+        assert res1[t]["error_v"] < 0.2 and res1[t]["error_reproject"] < 0.15 * 60.0
+        assert len(set(res1[t]["num_inliers"].tolist())) >= 1 and res1[t]["w"].shape == (4, 3)
+    out = str(tmp_path / "results2")
+    lines = open(out + "/errors.csv").read().strip().split("\n")
+    assert lines[0] == "task,error_w,error_v,reproject_error" and [ln.split(",")[0] for ln in lines[1:]] == tasks
+    for name in ("w.csv", "v.csv", "k.csv", "reproject_errors.csv", "error_v.csv", "error_w.csv", "depthMaps/0/0.png", "depthMaps/1/3.ply"):
+        assert os.path.exists(os.path.join(out, name)), name
+    assert len(open(out + "/w.csv").read().strip().split("\n")[0].split(",")) == 12  # 4 evaluations x 3 components per task line

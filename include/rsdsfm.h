@@ -222,6 +222,15 @@ int rsdsfm_refine_dev(rsdsfm_ctx* ctx, const double* d_flow2n, int64_t n_flow, i
                       const double v_in[3], const double w_in[3], double k_in, int const_acceleration,
                       int flow_index_mode, double* d_inliers_out_3m, double v_out[3], double w_out[3], double* k_out,
                       rsdsfm_lm_summary* summary_or_null);
+/* Batched fast path: `count` (<= 8) independent dense depth solves (LM mode) in ONE pair of launches -- the streaming pass
+ * and the decide-and-apply follow-up run over all of them (grid y = solve), which amortises the launch floor and the
+ * ramp-up / tail of the streaming pass.  Every solve uses ITS OWN context (state, partial sums), all created on one
+ * stream; the launches go to that stream.  Arrays of `count` entries: device pointers, sizes, v / w as count x 3, k.
+ * Afterwards rsdsfm_depth_finish_dev(ctxs[i], ...) completes / verifies solve i exactly as after the single call. */
+int rsdsfm_estimate_inverse_depths_batch_dev(rsdsfm_ctx* const* ctxs, int32_t count, const double* const* d_q2n,
+                                             const double* const* d_u2n, const int64_t* n, const double* v_count_x3,
+                                             const double* w_count_x3, const double* k_count, const double* const* d_alpha_n,
+                                             const double* const* d_alpha_k_n, double* const* d_inv_depth_n);
 /* One launch of the fused LM kernel (building block of the calls around it; also what bench.py brackets with
  * HIP events to time the dominant kernel).  launch_id 0 = the launch of LM iteration zero (fresh state);
  * launch_id > 0 acts only if the device state machine designated that launch. */

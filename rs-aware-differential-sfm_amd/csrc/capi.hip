@@ -208,6 +208,35 @@ int rsdsfm_estimate_inverse_depths_dev(rsdsfm_ctx* ctx, const double* d_q, const
     return rc;
 }
 
+int rsdsfm_estimate_inverse_depths_batch_dev(rsdsfm_ctx* const* ctxs, int32_t count, const double* const* d_q, const double* const* d_u,
+                                             const int64_t* n, const double* v3, const double* w3, const double* k,
+                                             const double* const* d_alpha, const double* const* d_alpha_k, double* const* d_rho) {
+    if (!ctxs || count < 1 || !ctxs[0]) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctxs[0]->c;
+    if (count > kDepthBatchMax) return fail(c, RSDSFM_ERR_INVALID, "at most 8 solves per batched launch");
+    if (!d_q || !d_u || !n || !v3 || !w3 || !k || !d_alpha || !d_alpha_k || !d_rho) return fail(c, RSDSFM_ERR_INVALID, "null argument array");
+    Ctx* cs[kDepthBatchMax];
+    Pose poses[kDepthBatchMax];
+    for (int i = 0; i < count; ++i) {
+        if (!ctxs[i]) return fail(c, RSDSFM_ERR_INVALID, "null context in the batch");
+        cs[i] = &ctxs[i]->c;
+        if (cs[i]->stream != c->stream || cs[i]->device != c->device) return fail(c, RSDSFM_ERR_INVALID, "all contexts of a batch must share one stream");
+        for (int j = 0; j < i; ++j)
+            if (cs[j] == cs[i]) return fail(c, RSDSFM_ERR_INVALID, "a context may appear only once in a batch (it owns the solve's state)");
+        if (n[i] < 0 || (n[i] > 0 && (!d_q[i] || !d_u[i] || !d_alpha[i] || !d_alpha_k[i] || !d_rho[i]))) return fail(c, RSDSFM_ERR_INVALID, "bad problem in the batch");
+        memcpy(poses[i].v, v3 + 3 * i, sizeof(poses[i].v));
+        memcpy(poses[i].w, w3 + 3 * i, sizeof(poses[i].w));
+        poses[i].k = k[i];
+    }
+    int rc = depth_lm_batch_launch(cs, count, d_q, d_u, d_alpha, d_alpha_k, n, poses, d_rho);
+    if (rc != RSDSFM_OK) return rc;
+    for (int i = 0; i < count; ++i) {
+        cs[i]->lm_issued_k = 1;
+        cs[i]->lm_issued_d = 1;
+    }
+    return RSDSFM_OK;
+}
+
 int rsdsfm_depth_lm_launch_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_u, int64_t n, const double v[3],
                                const double w[3], double k, const double* d_alpha, const double* d_alpha_k,
                                double* d_rho, int launch_id) {

@@ -15,6 +15,10 @@
 //
 // HBM-bound streaming, one lane per pixel PAIR so that every global access is a 16-byte vector
 // (q: 2 x dwordx4, u: 2 x dwordx4, alpha / alpha_k / rho: dwordx4).  No LDS tiling (no reuse), no MFMA.
+#include <string.h>
+
+#include <algorithm>
+
 #include "device_math.hpp"
 #include "lm_common.hpp"
 #include "rsdsfm_internal.hpp"
@@ -192,12 +196,11 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lm_kernel(const double2* __
 //   finished but a different iterate is final                              -> replay the accepted steps, write rho
 //   more LM iterations needed (rare)                                       -> return; rsdsfm_depth_finish_dev continues
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kDepthBlock) void depth_lm_decide_apply_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
-                                                                            const double2* __restrict__ alpha2,
-                                                                            const double2* __restrict__ alpha_k2, int64_t n, Pose pose,
-                                                                            double2* __restrict__ rho2, LmState* state,
-                                                                            const double* __restrict__ partials, int nrows,
-                                                                            const int* __restrict__ predict_used) {
+__device__ __forceinline__ void decide_apply_body(const double2* __restrict__ q, const double2* __restrict__ u,
+                                                  const double2* __restrict__ alpha2, const double2* __restrict__ alpha_k2, int64_t n,
+                                                  const Pose& pose, double2* __restrict__ rho2, LmState* state,
+                                                  const double* __restrict__ partials, int nrows,
+                                                  const int* __restrict__ predict_used) {
     __shared__ LmPlanLds plan;
     __shared__ double s_red[kDepthBlock / 64][NS];
     __shared__ double s_T[kDepthBlock / 64][kTRows * kTStride];
@@ -271,6 +274,98 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lm_decide_apply_kernel(cons
         const double* alpha_k = reinterpret_cast<const double*>(alpha_k2);
         reinterpret_cast<double*>(rho2)[i] = lm_pixel(qa.x, qa.y, ua.x, ua.y, alpha[i], alpha_k[i], pose, two_over, plan, acc);
     }
+}
+
+
+__global__ __launch_bounds__(kDepthBlock) void depth_lm_decide_apply_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
+                                                                            const double2* __restrict__ alpha2,
+                                                                            const double2* __restrict__ alpha_k2, int64_t n, Pose pose,
+                                                                            double2* __restrict__ rho2, LmState* state,
+                                                                            const double* __restrict__ partials, int nrows,
+                                                                            const int* __restrict__ predict_used) {
+    decide_apply_body(q, u, alpha2, alpha_k2, n, pose, rho2, state, partials, nrows, predict_used);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Batched fast path: up to kDepthBatchMax INDEPENDENT solves (frame pairs) per launch, blockIdx.y = solve.  The problem
+// descriptors travel by value in the kernel arguments (no descriptor memory, nothing to upload per call); every solve
+// keeps its own state, partial rows and predictor word (those of its context), so the per-solve protocol is exactly
+// that of the single launches and rsdsfm_depth_finish_dev continues any of them individually.  One launch over several
+// pairs amortises the ramp-up / tail of the streaming pass and the launch floor of the follow-up.
+// ---------------------------------------------------------------------------------------------------
+struct DepthBatchItem {
+    const double2 *q, *u, *a2, *ak2;
+    double2* rho2;
+    int64_t n;
+    Pose pose;
+    LmState* state;
+    double* partials;
+    int* predict_used;
+};
+struct DepthBatchArgs {
+    int count;
+    DepthBatchItem item[kDepthBatchMax];
+};
+
+__global__ __launch_bounds__(kDepthBlock) void depth_lm_batch_kernel(DepthBatchArgs args) {
+    __shared__ LmPlanLds plan;
+    __shared__ double s_red[kDepthBlock / 64][NS];
+    __shared__ double s_T[kDepthBlock / 64][kTRows * kTStride];
+    __shared__ double s_half[kDepthBlock / 64][2][kTRows];
+    const DepthBatchItem& it = args.item[blockIdx.y];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        plan.n_hist = 0;
+        plan.K = KMAX;
+        const int pr = it.state->predict;
+        if (blockIdx.x == 0) *it.predict_used = pr;
+        plan.write_which = (pr >= 0 && pr <= KMAX) ? pr : 1;
+        double r = kInitialRadius;
+        for (int j = 0; j < KMAX; ++j) {
+            plan.inv_cand[j] = 1.0 / r;
+            r = radius_accept(r, 1.0);
+        }
+    }
+    __syncthreads();
+    const Pose pose = it.pose;
+    const double2 *q = it.q, *u = it.u, *alpha2 = it.a2, *alpha_k2 = it.ak2;
+    double2* rho2 = it.rho2;
+    const int64_t n = it.n;
+    const double two_over = 2.0 / (2.0 + pose.k);
+    double acc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc[s] = 0.0;
+    const int64_t npairs = n >> 1;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + tid; p < npairs; p += stride) {
+        double2 qa = q[2 * p], qb = q[2 * p + 1];
+        double2 ua = u[2 * p], ub = u[2 * p + 1];
+        double2 al = alpha2[p], ak = alpha_k2[p];
+        double2 out;
+        out.x = lm_pixel(qa.x, qa.y, ua.x, ua.y, al.x, ak.x, pose, two_over, plan, acc);
+        out.y = lm_pixel(qb.x, qb.y, ub.x, ub.y, al.y, ak.y, pose, two_over, plan, acc);
+        rho2[p] = out;
+    }
+    if ((n & 1) && blockIdx.x == 0 && tid == 0) {
+        const int64_t i = n - 1;
+        double2 qa = q[i], ua = u[i];
+        const double* alpha = reinterpret_cast<const double*>(alpha2);
+        const double* alpha_k = reinterpret_cast<const double*>(alpha_k2);
+        reinterpret_cast<double*>(rho2)[i] = lm_pixel(qa.x, qa.y, ua.x, ua.y, alpha[i], alpha_k[i], pose, two_over, plan, acc);
+    }
+    const int lane = tid & 63, wv = tid >> 6;
+    wave_reduce_sums(acc, s_red[wv], s_T[wv], s_half[wv], lane);
+    __syncthreads();
+    if (tid < NS) {
+        double r = s_red[0][tid];
+        for (int w2 = 1; w2 < kDepthBlock / 64; ++w2) r = is_max_slot(tid) ? fmax(r, s_red[w2][tid]) : r + s_red[w2][tid];
+        it.partials[(int64_t)blockIdx.x * NS + tid] = r;
+    }
+}
+
+__global__ __launch_bounds__(kDepthBlock) void depth_lm_decide_apply_batch_kernel(DepthBatchArgs args, int nrows) {
+    const DepthBatchItem& it = args.item[blockIdx.y];
+    decide_apply_body(it.q, it.u, it.a2, it.ak2, it.n, it.pose, it.rho2, it.state, it.partials, nrows, it.predict_used);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -676,6 +771,37 @@ int depth_lm_decide_apply_launch(Ctx* c, const double* q, const double* u, const
                        reinterpret_cast<const double2*>(u), reinterpret_cast<const double2*>(a), reinterpret_cast<const double2*>(ak), n, pose,
                        reinterpret_cast<double2*>(rho), c->d_lm, c->d_partials, grid, reinterpret_cast<const int*>(c->d_tickets + 40));
     RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+// batched fast path over `count` contexts that share one stream (launched on c[0]'s stream)
+int depth_lm_batch_launch(Ctx* const* cs, int count, const double* const* q, const double* const* u, const double* const* a,
+                          const double* const* ak, const int64_t* n, const Pose* poses, double* const* rho) {
+    Ctx* c0 = cs[0];
+    DepthBatchArgs args;
+    memset(&args, 0, sizeof(args));
+    args.count = count;
+    int grid = 1;
+    for (int i = 0; i < count; ++i) {
+        if (!aligned16(q[i]) || !aligned16(u[i]) || !aligned16(a[i]) || !aligned16(ak[i]) || !aligned16(rho[i]))
+            return fail(c0, RSDSFM_ERR_INVALID, "device pointers must be 16-byte aligned");
+        DepthBatchItem& it = args.item[i];
+        it.q = reinterpret_cast<const double2*>(q[i]);
+        it.u = reinterpret_cast<const double2*>(u[i]);
+        it.a2 = reinterpret_cast<const double2*>(a[i]);
+        it.ak2 = reinterpret_cast<const double2*>(ak[i]);
+        it.rho2 = reinterpret_cast<double2*>(rho[i]);
+        it.n = n[i];
+        it.pose = poses[i];
+        it.state = cs[i]->d_lm;
+        it.partials = cs[i]->d_partials;
+        it.predict_used = reinterpret_cast<int*>(cs[i]->d_tickets + 40);
+        grid = std::max(grid, depth_grid(n[i], kDepthMaxBlocks));
+    }
+    hipLaunchKernelGGL(depth_lm_batch_kernel, dim3(grid, count), dim3(kDepthBlock), 0, c0->stream, args);
+    RSDSFM_HIP_CHECK(c0, hipGetLastError());
+    hipLaunchKernelGGL(depth_lm_decide_apply_batch_kernel, dim3(grid, count), dim3(kDepthBlock), 0, c0->stream, args, grid);
+    RSDSFM_HIP_CHECK(c0, hipGetLastError());
     return RSDSFM_OK;
 }
 

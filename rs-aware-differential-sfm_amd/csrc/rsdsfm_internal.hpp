@@ -113,6 +113,7 @@ struct Ctx {
 constexpr int kDepthBlock = 256;
 constexpr int kDepthMaxBlocks = 512;
 constexpr int kDecideBlock = 256;
+constexpr int kDepthBatchMax = 8;  // independent solves per batched launch (descriptors travel in the kernel arguments)
 
 #define RSDSFM_HIP_CHECK(ctx, expr)                                                            \
     do {                                                                                       \
@@ -151,6 +152,8 @@ int depth_lm_launch(Ctx* c, const double* q, const double* u, const double* a, c
 int depth_lm_decide_launch(Ctx* c, int64_t n, int launch_id);
 int depth_lm_decide_apply_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                                  const Pose& pose, double* rho);
+int depth_lm_batch_launch(Ctx* const* cs, int count, const double* const* q, const double* const* u, const double* const* a,
+                          const double* const* ak, const int64_t* n, const Pose* poses, double* const* rho);
 int depth_lm_fused_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                           const Pose& pose, double* rho);
 int depth_lm_reduce_launch(Ctx* c, int64_t n, double* d_row);

@@ -139,3 +139,55 @@ def test_alpha_and_pose_table(oracle, solver, rsdsfm):
         Ro, to = oracle.pose_table(v, w, k, 0.8, 720)
         assert np.array_equal(R, Ro) and np.array_equal(t, to)
         assert np.array_equal(R[0], np.eye(3)) and np.array_equal(t[0], np.zeros(3))
+
+
+def test_batched_fast_path_equals_single_solves(oracle, rsdsfm):
+    """rsdsfm_estimate_inverse_depths_batch_dev: several independent solves of DIFFERENT sizes / poses / data per launch give,
+    solve by solve, bit-identical depths and the same summaries as the single-solve entry point, incl. a solve that needs the
+    apply pass (cold predictor) and one that needs continuation launches (more LM iterations than one pass speculates)"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        cases = []
+        for j, (cfg, rows, cols) in enumerate([(1, 100, 160), (3, 64, 90), (1, 40, 48), (5, 77, 129)]):
+            d = rsdsfm.synth.make_config(cfg, rows=rows, cols=cols, v=np.array([0.05, 0.03, 1.0]) if j == 2 else None)
+            q, u = d["q"].copy(), d["u"].copy()
+            t = d["truth"]
+            v = t["v"] / np.linalg.norm(t["v"])
+            if j == 2:  # a pixel next to the epipole: many LM iterations -> continuation launches after the fast path
+                q[7] = [v[0] / v[2] + 1e-7, v[1] / v[2] - 2e-7]
+                u[7] = [3e-2, -2e-2]
+            cases.append(dict(q=q, u=u, a=d["alpha"], ak=d["alpha_k"], v=v, w=t["w"], k=0.0 if j != 3 else 0.2))
+        solvers = [rsdsfm.Solver(0, stream=stream.cuda_stream) for _ in cases]
+        single = rsdsfm.Solver(0, stream=stream.cuda_stream)
+        dev_t = [{k2: torch.from_numpy(np.ascontiguousarray(c[k2])).to(dev) for k2 in ("q", "u", "a", "ak")} for c in cases]
+        rhos = [torch.zeros(len(c["a"]), dtype=torch.float64, device=dev) for c in cases]
+        probs = [dict(d_q=t_["q"].data_ptr(), d_u=t_["u"].data_ptr(), d_alpha=t_["a"].data_ptr(), d_alpha_k=t_["ak"].data_ptr(), d_rho=r.data_ptr(),
+                      n=len(c["a"]), v=c["v"], w=c["w"], k=c["k"]) for c, t_, r in zip(cases, dev_t, rhos)]
+        call = rsdsfm.prepared_depth_batch(solvers, probs)
+        for rep in range(3):  # rep 0: cold predictors (apply pass), later: warm
+            call()
+            for i, (c, p) in enumerate(zip(cases, probs)):
+                sm, extra = solvers[i].depth_finish_dev(p["d_q"], p["d_u"], p["n"], c["v"], c["w"], c["k"], p["d_alpha"], p["d_alpha_k"], p["d_rho"])
+                ref = torch.zeros(p["n"], dtype=torch.float64, device=dev)
+                single.estimate_inverse_depths_dev(p["d_q"], p["d_u"], p["n"], c["v"], c["w"], c["k"], p["d_alpha"], p["d_alpha_k"], ref.data_ptr(), mode=1)
+                sm1, _ = single.depth_finish_dev(p["d_q"], p["d_u"], p["n"], c["v"], c["w"], c["k"], p["d_alpha"], p["d_alpha_k"], ref.data_ptr())
+                assert torch.equal(rhos[i], ref), (rep, i)
+                for key in ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination"):
+                    assert sm[key] == sm1[key], (rep, i, key)
+                rho_o, sm_o = oracle.estimate_inverse_depths(c["q"], c["u"], c["v"], c["w"], c["k"], c["a"], c["ak"], mode=1)
+                assert sm["num_iterations"] == sm_o["num_iterations"] and np.allclose(rhos[i].cpu().numpy(), rho_o, rtol=1e-9, atol=1e-13)
+                if i == 2:
+                    assert sm["num_iterations"] > 4 and extra > 0
+        # argument checks: a context twice, contexts on different streams
+        with pytest.raises(rsdsfm.RsdsfmError):
+            rsdsfm.prepared_depth_batch([solvers[0], solvers[0]], probs[:2])()
+        other = rsdsfm.Solver(0)
+        with pytest.raises(rsdsfm.RsdsfmError):
+            rsdsfm.prepared_depth_batch([solvers[0], other], probs[:2])()
+        other.close()
+        single.close()
+        for s in solvers:
+            s.close()

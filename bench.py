@@ -127,8 +127,8 @@ def main():
     ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify", "true_flow", "metrics"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nbuf", type=int, default=7, help="rotating HBM buffer sets (7 x 59 MB > 256 MiB L3)")
-    ap.add_argument("--streams", type=int, default=3, help="independent frame pairs in flight per GPU: one solver context + HIP stream each "
-                    "(sequence-throughput mode, BASELINE configs[4]); 1 = one pair at a time")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU feeding independent batches (sequence-throughput mode, BASELINE configs[4])")
+    ap.add_argument("--batch", type=int, default=4, help="independent frame pairs per launch of the batched depth fast path (1..8, one solver context each)")
     ap.add_argument("--depth-variant", type=int, default=None, help="rsdsfm_set_depth_variant: 0 register-staged, 1 LDS-DMA, 2 decision fused into launch 0")
     ap.add_argument("--trials", type=int, default=50, help="RANSAC trials of the full solve (report section 5.4 used 50)")
     ap.add_argument("--tol", type=float, default=0.05, help="RANSAC tolerance (reference main.cc:310)")
@@ -202,98 +202,140 @@ def main():
         v = t["v"] / np.linalg.norm(t["v"])  # unit translation, as the minimal solver returns it (minimal.cc:102-105)
         w, k = t["w"], 0.0
         mode = rsdsfm.DEPTH_CERES_LM if args.workload == "depth" else rsdsfm.DEPTH_CLOSED_FORM
-        # S independent pairs in flight: one solver context + one HIP stream each, no dependency between them (every context
-        # owns its LM state and partials), so the latency-bound follow-up launch of one pair overlaps the streaming launch of
-        # the next.  Buffer set i always belongs to context i % S.
+        # Sequence-throughput mode: B independent pairs per launch (batched fast path: grid y = pair, one context per pair owns
+        # its LM state and partial sums) on each of S HIP streams; nothing is shared between pairs.  The latency-bound
+        # follow-up launch, the launch floor and the ramp / tail of the streaming pass are amortised over B pairs and
+        # overlapped across the streams.  (closed-form mode has no batched entry point: B = 1 there.)
         S = max(1, args.streams)
+        B = max(1, min(args.batch, 8)) if mode == rsdsfm.DEPTH_CERES_LM else 1
         streams = [stream] + [torch.cuda.Stream(dev) for _ in range(S - 1)]
-        solvers = [solver] + [rsdsfm.Solver(local_rank, stream=st.cuda_stream) for st in streams[1:]]
-        if args.depth_variant is not None:
-            for sv in solvers[1:]:
+        G = max(2, -(-max(args.nbuf, 9) // (B * S)))  # groups per stream: >= 9 rotating buffer sets in total (> 256 MiB L3)
+        rho_true = (1.0 / t["Z"]).T.reshape(-1) * np.linalg.norm(t["v"])
+        extra_solvers = []
+
+        def new_solver(st):
+            if st is stream and not extra_solvers:
+                extra_solvers.append(None)  # the first context on stream 0 is the bench's main solver
+                return solver
+            sv = rsdsfm.Solver(local_rank, stream=st.cuda_stream)
+            if args.depth_variant is not None:
                 sv.set_depth_variant(args.depth_variant)
-        nbuf = -(-max(args.nbuf, S) // S) * S
-        sets = []
-        for _ in range(nbuf):
-            sets.append(dict(q=torch.from_numpy(data["q"]).to(dev), u=torch.from_numpy(data["u"]).to(dev),
-                             a=torch.from_numpy(data["alpha"]).to(dev), ak=torch.from_numpy(data["alpha_k"]).to(dev),
-                             rho=torch.empty(n, dtype=torch.float64, device=dev)))
-        torch.cuda.synchronize()
-        calls = [solvers[i % S].prepared_depth_step(s["q"].data_ptr(), s["u"].data_ptr(), n, v, w, k, s["a"].data_ptr(),
-                                                    s["ak"].data_ptr(), s["rho"].data_ptr(), mode=mode) for i, s in enumerate(sets)]
+            extra_solvers.append(sv)
+            return sv
+
+        def new_set():
+            return dict(q=torch.from_numpy(data["q"]).to(dev), u=torch.from_numpy(data["u"]).to(dev), a=torch.from_numpy(data["alpha"]).to(dev),
+                        ak=torch.from_numpy(data["alpha_k"]).to(dev), rho=torch.empty(n, dtype=torch.float64, device=dev))
 
         def ptrs(s):
             return (s["q"].data_ptr(), s["u"].data_ptr(), n, v, w, k, s["a"].data_ptr(), s["ak"].data_ptr(), s["rho"].data_ptr())
 
-        el = timed(lambda i: calls[i % nbuf](), args.steps, args.warmup)
-        # correctness of what was timed: on EVERY context the LM state machine finished inside the fixed launch sequence and
-        # the last pair it solved matches the analytic truth
-        extra, summary, max_rel = 0, None, 0.0
-        rho_true = (1.0 / t["Z"]).T.reshape(-1) * np.linalg.norm(t["v"])
-        for j in range(min(S, args.steps)):
-            idx = (args.steps - 1 - j) % nbuf
-            if mode == rsdsfm.DEPTH_CERES_LM:
-                summary, ex = solvers[idx % S].depth_finish_dev(*ptrs(sets[idx]))
-                extra = max(extra, ex)
-            rho = sets[idx]["rho"].cpu().numpy()
-            max_rel = max(max_rel, float(np.max(np.abs(rho - rho_true) / np.abs(rho_true))))
-        # the same loop with ONE pair at a time (context 0 only), for reference
-        own = [i for i in range(nbuf) if i % S == 0]
-        n1 = max(20, args.steps // 4)
-        el1 = timed(lambda i: calls[own[i % len(own)]](), n1, 5) if S > 1 else el * n1 / args.steps
+        def problem(s):
+            return dict(d_q=s["q"].data_ptr(), d_u=s["u"].data_ptr(), d_alpha=s["a"].data_ptr(), d_alpha_k=s["ak"].data_ptr(), d_rho=s["rho"].data_ptr(),
+                        n=n, v=v, w=w, k=k)
 
-        # dominant-kernel duration: HIP events on the launch stream around bursts of BURST back-to-back launches of
-        # that kernel alone (launch 0 of the LM solve = `depth_lm_kernel<1>` in the rocprof summaries); the quotient
-        # includes the ~1 us inter-kernel gap, i.e. it is a slightly conservative launch duration
+        groups = []  # (call, solvers, sets), stream-major
+        for st in streams:
+            for _ in range(G):
+                svs = [new_solver(st) for _ in range(B)]
+                sets = [new_set() for _ in range(B)]
+                if mode == rsdsfm.DEPTH_CERES_LM:
+                    call = rsdsfm.prepared_depth_batch(svs, [problem(x) for x in sets])
+                else:
+                    call = svs[0].prepared_depth_step(*ptrs(sets[0]), mode=mode)
+                groups.append((call, svs, sets))
+        order = [groups[(i % S) * G + (i // S) % G] for i in range(S * G)]  # alternate the streams
+        torch.cuda.synchronize()
+        nfull, rem = divmod(args.steps, B)
+        rem_call = None
+        if rem:  # exactly `steps` pairs are timed: the last call is a smaller batch over the first contexts of one group
+            g = order[nfull % len(order)]
+            rem_call = rsdsfm.prepared_depth_batch(g[1][:rem], [problem(x) for x in g[2][:rem]])
+
+        def run_pairs(i):  # step i = pair i; a batched call every B steps
+            if i % B == 0:
+                j = i // B
+                if j < nfull:
+                    order[j % len(order)][0]()
+                elif rem_call is not None:
+                    rem_call()
+
+        for i in range(0, max(args.warmup, len(order) * B), B):
+            order[(i // B) % len(order)][0]()
+        el = timed(run_pairs, args.steps, 0)
+        # correctness of what was timed: on the contexts of the last batches the LM state machine finished inside the fixed
+        # launch sequence and the pair matches the analytic truth
+        extra, summary, max_rel = 0, None, 0.0
+        for j in range(max(0, nfull - len(order)), nfull):
+            _, svs, sets = order[j % len(order)]
+            for sv, x in zip(svs, sets):
+                if mode == rsdsfm.DEPTH_CERES_LM:
+                    summary, ex = sv.depth_finish_dev(*ptrs(x))
+                    extra = max(extra, ex)
+                rho = x["rho"].cpu().numpy()
+                max_rel = max(max_rel, float(np.max(np.abs(rho - rho_true) / np.abs(rho_true))))
+        # the same work with ONE pair at a time (single context, single stream), for reference
+        own = [grp for grp in groups[:G]]
+        single_calls = [grp[1][0].prepared_depth_step(*ptrs(grp[2][0]), mode=mode) for grp in own]
+        n1 = max(20, args.steps // 8)
+        el1 = timed(lambda i: single_calls[i % len(single_calls)](), n1, 5)
+
+        # dominant-kernel duration: HIP events on stream 0 around bursts of BURST back-to-back launches of the streaming
+        # kernel alone (launch 0 of the batched LM solve = `depth_lm_batch_kernel`, B pairs per launch; the other streams
+        # are idle); the quotient includes the ~1 us inter-kernel gap, i.e. it is a slightly conservative launch duration
         kern_ms = kern_med = None
         if rank == 0:
-            BURST, reps = 10, max(10, min(args.steps // 5, 40))
+            if mode == rsdsfm.DEPTH_CERES_LM:
+                burst_calls = [rsdsfm.prepared_depth_batch(grp[1], [problem(x) for x in grp[2]], launch0_only=True) for grp in groups[:G]]
+            else:
+                burst_calls = single_calls
+            BURST, reps = 10, 30
             e0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
             e1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
             for i in range(reps):
                 e0[i].record(stream)
-                for b in range(BURST):
-                    s = sets[(i * BURST + b) % nbuf]
-                    if mode == rsdsfm.DEPTH_CERES_LM:
-                        solver.depth_lm_launch_dev(*ptrs(s), launch_id=0)
-                    else:
-                        calls[(i * BURST + b) % nbuf]()
+                for b_ in range(BURST):
+                    burst_calls[(i * BURST + b_) % len(burst_calls)]()
                 e1[i].record(stream)
             torch.cuda.synchronize()
             ts = sorted(a_.elapsed_time(b_) / BURST for a_, b_ in zip(e0, e1))
             kern_ms, kern_med = float(np.mean(ts)), float(ts[len(ts) // 2])
 
         if rank == 0:
-            alg_bytes = ALG_BYTES_PER_PIXEL_DEPTH * n
+            alg_bytes = ALG_BYTES_PER_PIXEL_DEPTH * n * B
             achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+            job = ALG_BYTES_PER_PIXEL_DEPTH * n / (el / args.steps) / 1e9
             line.update({
                 "value": rows * cols * world * args.steps / el / 1e6, "ms_per_step": el / args.steps * 1e3, "scaling": "weak",
                 "config": {"workload": "BASELINE configs[1]: synthetic 1280x720 pairs, per-pixel depth solve only (%s), pose fixed; "
-                                       "%d independent pairs in flight per GPU (one context + HIP stream each), %d rotating HBM buffer sets" %
-                                       ("Ceres-1.14 LM emulation" if mode == 1 else "closed-form GN", S, nbuf),
-                           "streams": S, "one_pair_at_a_time": {"value": rows * cols * world * n1 / el1 / 1e6, "ms_per_step": el1 / n1 * 1e3},
+                                       "%d independent pairs per launch on each of %d HIP streams per GPU (one solver context per pair), %d "
+                                       "rotating HBM buffer sets" % ("Ceres-1.14 LM emulation" if mode == 1 else "closed-form GN", B, S, B * S * G),
+                           "pairs_per_launch": B, "streams": S,
+                           "one_pair_at_a_time": {"value": rows * cols * world * n1 / el1 / 1e6, "ms_per_step": el1 / n1 * 1e3},
                            "rows": rows, "cols": cols, "pixels": n, "depth_mode": int(mode),
-                           "launches_per_step": (3 if args.depth_variant in (1, 3) else 2) if mode == 1 else 1, "extra_lm_launches": int(extra), "lm_summary": summary,
+                           "launches_per_step": (2.0 / B) if mode == 1 else 1, "extra_lm_launches": int(extra), "lm_summary": summary,
                            "max_rel_err_vs_truth": max_rel},
-                "roofline": {"bound": "hbm", "kernel": "depth_lm_kernel<1>" if mode == 1 else "depth_closed_form_kernel",
+                "roofline": {"bound": "hbm", "kernel": ("depth_lm_batch_kernel (%d pairs per launch)" % B) if mode == 1 else "depth_closed_form_kernel",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                             "traffic": _traffic(args.workload), "alg_bytes_per_launch": alg_bytes, "avg_launch_ms": kern_ms,
-                             "median_launch_ms": kern_med,
-                             "note": "kernel duration measured with one pair in flight (bursts on one stream, the other contexts idle); "
-                                     "profiles/: rocprofv3 of `bench.py --streams 1`"},
-                # the same algorithmic bytes over the JOB's time per pair (S pairs in flight): what the HBM system delivers to the loop
-                "roofline_job": {"bound": "hbm", "achieved": alg_bytes / (el / args.steps) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": alg_bytes / (el / args.steps) / 1e9 / HBM_PEAK_GBS, "streams": S},
+                             "traffic": _traffic("depth_batch%d" % B if mode == 1 else args.workload), "alg_bytes_per_launch": alg_bytes,
+                             "avg_launch_ms": kern_ms, "median_launch_ms": kern_med,
+                             "note": "launch duration measured with the other streams idle (bursts on one stream); profiles/: rocprofv3 "
+                                     "of `bench.py --streams 1`"},
+                # the same algorithmic bytes over the JOB's time per pair: what the HBM system delivers to the whole loop
+                "roofline_job": {"bound": "hbm", "achieved": job, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": job / HBM_PEAK_GBS,
+                                 "pairs_per_launch": B, "streams": S},
             })
         # the whole solve, reported beside the headline (not the timed `value`)
         full = _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps=8, warmup=2, timed=timed) if args.workload == "depth" else None
-        batched = _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, max(S, 4), per_thread=12) if (args.workload == "depth" and S > 1) else None
+        batched = _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, 4, per_thread=12) if (args.workload == "depth" and B * S > 1) else None
         if rank == 0:
             line["full_solve"] = full
             line["full_solve_batched"] = batched
             line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(data, v, w)
             line["cpu_baseline_all_cores"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_all_cores(data, v, w)
-        for sv in solvers[1:]:
-            sv.close()
+        for sv in extra_solvers:
+            if sv is not None:
+                sv.close()
 
     # =================================================================================================
     elif args.workload == "full":

@@ -231,6 +231,10 @@ int rsdsfm_estimate_inverse_depths_batch_dev(rsdsfm_ctx* const* ctxs, int32_t co
                                              const double* const* d_u2n, const int64_t* n, const double* v_count_x3,
                                              const double* w_count_x3, const double* k_count, const double* const* d_alpha_n,
                                              const double* const* d_alpha_k_n, double* const* d_inv_depth_n);
+/* launch 0 of the batched fast path alone (depth_lm_batch_kernel): what bench.py brackets with HIP events */
+int rsdsfm_depth_lm_batch_launch_dev(rsdsfm_ctx* const* ctxs, int32_t count, const double* const* d_q2n, const double* const* d_u2n,
+                                     const int64_t* n, const double* v_count_x3, const double* w_count_x3, const double* k_count,
+                                     const double* const* d_alpha_n, const double* const* d_alpha_k_n, double* const* d_inv_depth_n);
 /* One launch of the fused LM kernel (building block of the calls around it; also what bench.py brackets with
  * HIP events to time the dominant kernel).  launch_id 0 = the launch of LM iteration zero (fresh state);
  * launch_id > 0 acts only if the device state machine designated that launch. */

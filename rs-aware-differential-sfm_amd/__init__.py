@@ -604,10 +604,11 @@ from . import evaluate, formats  # noqa: E402,F401  (on-disk formats + archive r
 # ---------------------------------------------------------------------------------------------------
 # batched fast path of the dense depth solve: several independent solves per launch (one context each, one shared stream)
 # ---------------------------------------------------------------------------------------------------
-def prepared_depth_batch(solvers, problems):
+def prepared_depth_batch(solvers, problems, launch0_only=False):
     """solvers: list of Solver (<= 8, all created on the SAME stream); problems: list of dicts with device pointers
     d_q, d_u, d_alpha, d_alpha_k, d_rho and n, v, w, k.  Returns a zero-argument callable that enqueues the whole batch with
-    pre-marshalled arguments (rsdsfm_estimate_inverse_depths_batch_dev); finish each solve with solvers[i].depth_finish_dev."""
+    pre-marshalled arguments (rsdsfm_estimate_inverse_depths_batch_dev; launch0_only: only the streaming launch, for profiling);
+    finish each solve with solvers[i].depth_finish_dev."""
     lib = load_library()
     cnt = len(solvers)
     assert cnt == len(problems) and 1 <= cnt <= 8
@@ -618,7 +619,7 @@ def prepared_depth_batch(solvers, problems):
     v3 = (C.c_double * (3 * cnt))(*[float(x) for p in problems for x in p["v"]])
     w3 = (C.c_double * (3 * cnt))(*[float(x) for p in problems for x in p["w"]])
     ks = (C.c_double * cnt)(*[float(p["k"]) for p in problems])
-    fn = lib.rsdsfm_estimate_inverse_depths_batch_dev
+    fn = lib.rsdsfm_depth_lm_batch_launch_dev if launch0_only else lib.rsdsfm_estimate_inverse_depths_batch_dev
     args = (ctxs, C.c_int32(cnt), ptrs["d_q"], ptrs["d_u"], ns, v3, w3, ks, ptrs["d_alpha"], ptrs["d_alpha_k"], ptrs["d_rho"])
     s0 = solvers[0]
 

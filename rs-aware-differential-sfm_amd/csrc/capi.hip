@@ -208,9 +208,9 @@ int rsdsfm_estimate_inverse_depths_dev(rsdsfm_ctx* ctx, const double* d_q, const
     return rc;
 }
 
-int rsdsfm_estimate_inverse_depths_batch_dev(rsdsfm_ctx* const* ctxs, int32_t count, const double* const* d_q, const double* const* d_u,
-                                             const int64_t* n, const double* v3, const double* w3, const double* k,
-                                             const double* const* d_alpha, const double* const* d_alpha_k, double* const* d_rho) {
+static int depth_batch_common(rsdsfm_ctx* const* ctxs, int32_t count, const double* const* d_q, const double* const* d_u, const int64_t* n,
+                              const double* v3, const double* w3, const double* k, const double* const* d_alpha,
+                              const double* const* d_alpha_k, double* const* d_rho, int launch0_only) {
     if (!ctxs || count < 1 || !ctxs[0]) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctxs[0]->c;
     if (count > kDepthBatchMax) return fail(c, RSDSFM_ERR_INVALID, "at most 8 solves per batched launch");
@@ -228,13 +228,25 @@ int rsdsfm_estimate_inverse_depths_batch_dev(rsdsfm_ctx* const* ctxs, int32_t co
         memcpy(poses[i].w, w3 + 3 * i, sizeof(poses[i].w));
         poses[i].k = k[i];
     }
-    int rc = depth_lm_batch_launch(cs, count, d_q, d_u, d_alpha, d_alpha_k, n, poses, d_rho);
+    int rc = depth_lm_batch_launch(cs, count, d_q, d_u, d_alpha, d_alpha_k, n, poses, d_rho, launch0_only);
     if (rc != RSDSFM_OK) return rc;
     for (int i = 0; i < count; ++i) {
         cs[i]->lm_issued_k = 1;
-        cs[i]->lm_issued_d = 1;
+        cs[i]->lm_issued_d = launch0_only ? 0 : 1;
     }
     return RSDSFM_OK;
+}
+
+int rsdsfm_estimate_inverse_depths_batch_dev(rsdsfm_ctx* const* ctxs, int32_t count, const double* const* d_q, const double* const* d_u,
+                                             const int64_t* n, const double* v3, const double* w3, const double* k,
+                                             const double* const* d_alpha, const double* const* d_alpha_k, double* const* d_rho) {
+    return depth_batch_common(ctxs, count, d_q, d_u, n, v3, w3, k, d_alpha, d_alpha_k, d_rho, 0);
+}
+
+int rsdsfm_depth_lm_batch_launch_dev(rsdsfm_ctx* const* ctxs, int32_t count, const double* const* d_q, const double* const* d_u,
+                                     const int64_t* n, const double* v3, const double* w3, const double* k, const double* const* d_alpha,
+                                     const double* const* d_alpha_k, double* const* d_rho) {
+    return depth_batch_common(ctxs, count, d_q, d_u, n, v3, w3, k, d_alpha, d_alpha_k, d_rho, 1);
 }
 
 int rsdsfm_depth_lm_launch_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_u, int64_t n, const double v[3],

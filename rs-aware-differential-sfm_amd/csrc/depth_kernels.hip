@@ -776,7 +776,7 @@ int depth_lm_decide_apply_launch(Ctx* c, const double* q, const double* u, const
 
 // batched fast path over `count` contexts that share one stream (launched on c[0]'s stream)
 int depth_lm_batch_launch(Ctx* const* cs, int count, const double* const* q, const double* const* u, const double* const* a,
-                          const double* const* ak, const int64_t* n, const Pose* poses, double* const* rho) {
+                          const double* const* ak, const int64_t* n, const Pose* poses, double* const* rho, int launch0_only) {
     Ctx* c0 = cs[0];
     DepthBatchArgs args;
     memset(&args, 0, sizeof(args));
@@ -800,6 +800,7 @@ int depth_lm_batch_launch(Ctx* const* cs, int count, const double* const* q, con
     }
     hipLaunchKernelGGL(depth_lm_batch_kernel, dim3(grid, count), dim3(kDepthBlock), 0, c0->stream, args);
     RSDSFM_HIP_CHECK(c0, hipGetLastError());
+    if (launch0_only) return RSDSFM_OK;
     hipLaunchKernelGGL(depth_lm_decide_apply_batch_kernel, dim3(grid, count), dim3(kDepthBlock), 0, c0->stream, args, grid);
     RSDSFM_HIP_CHECK(c0, hipGetLastError());
     return RSDSFM_OK;

@@ -153,7 +153,7 @@ int depth_lm_decide_launch(Ctx* c, int64_t n, int launch_id);
 int depth_lm_decide_apply_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                                  const Pose& pose, double* rho);
 int depth_lm_batch_launch(Ctx* const* cs, int count, const double* const* q, const double* const* u, const double* const* a,
-                          const double* const* ak, const int64_t* n, const Pose* poses, double* const* rho);
+                          const double* const* ak, const int64_t* n, const Pose* poses, double* const* rho, int launch0_only);
 int depth_lm_fused_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                           const Pose& pose, double* rho);
 int depth_lm_reduce_launch(Ctx* c, int64_t n, double* d_row);

@@ -122,8 +122,8 @@ def cpu_baseline_full(rsdsfm, trials, tol, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default per workload: 10000 for the depth workloads)")
+    ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify", "true_flow", "metrics"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nbuf", type=int, default=7, help="rotating HBM buffer sets (7 x 59 MB > 256 MiB L3)")
@@ -133,6 +133,11 @@ def main():
     ap.add_argument("--trials", type=int, default=50, help="RANSAC trials of the full solve (report section 5.4 used 50)")
     ap.add_argument("--tol", type=float, default=0.05, help="RANSAC tolerance (reference main.cc:310)")
     args = ap.parse_args()
+    dsteps = {"depth": 10000, "depth_closed_form": 10000, "full": 500, "tiled": 2000, "tiled_full": 100, "rectify": 2000, "true_flow": 500, "metrics": 2000}
+    if args.steps is None:
+        args.steps = dsteps[args.workload]
+    if args.warmup is None:
+        args.warmup = max(2, args.steps // 25)
 
     import numpy as np
     import torch  # first: one HIP runtime per process (torch's), shared with librsdsfm_hip.so

@@ -191,3 +191,24 @@ def test_batched_fast_path_equals_single_solves(oracle, rsdsfm):
         single.close()
         for s in solvers:
             s.close()
+
+
+def test_nan_input_is_reported_not_hidden(oracle, solver, rsdsfm):
+    """a NaN in the flow poisons the global LM sums: Ceres' loop (and the oracle) ends with FAILURE after 5 consecutive invalid
+    steps; the HIP path walks the same state machine and reports it as an error instead of returning depths.  The closed-form
+    mode has no global coupling: only the poisoned pixel is NaN, all others are bit-identical to the oracle's."""
+    d = rsdsfm.synth.make_config(1, rows=40, cols=48)
+    q, u, a, ak, t = d["q"], d["u"].copy(), d["alpha"], d["alpha_k"], d["truth"]
+    v = t["v"] / np.linalg.norm(t["v"])
+    u[5, 0] = np.nan
+    _, sm_o = oracle.estimate_inverse_depths(q, u, v, t["w"], 0.0, a, ak, mode=1)
+    assert sm_o["termination"] == 4 and sm_o["num_unsuccessful_steps"] == 5
+    with pytest.raises(rsdsfm.RsdsfmError, match="LM failure"):
+        solver.estimate_inverse_depths(q, u, v, t["w"], 0.0, a, ak, mode=1)
+    rho0, _ = solver.estimate_inverse_depths(q, u, v, t["w"], 0.0, a, ak, mode=0)
+    rho0_o, _ = oracle.estimate_inverse_depths(q, u, v, t["w"], 0.0, a, ak, mode=0)
+    assert np.isnan(rho0[5]) and np.isnan(rho0_o[5]) and np.array_equal(np.delete(rho0, 5), np.delete(rho0_o, 5))
+    # the context is still usable afterwards
+    rho, sm = solver.estimate_inverse_depths(q, d["u"], v, t["w"], 0.0, a, ak, mode=1)
+    rho_o, sm_o2 = oracle.estimate_inverse_depths(q, d["u"], v, t["w"], 0.0, a, ak, mode=1)
+    assert sm["termination"] == sm_o2["termination"] and np.allclose(rho, rho_o, rtol=1e-9, atol=1e-13)

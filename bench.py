@@ -14,13 +14,18 @@ Contract: python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on
                                   projection (+ float3 world points), crack interpolation, 8-bit depth image.
               true_flow         : SURVEY 8(f-2) ground-truth flow search (rows x cols x rows scanline projections) of a
                                   1280x720 frame pair.
+              metrics           : SURVEY 8(f-4) meanReprojectionError + createErrorImage of a 1280x720 frame.
               tiled_full        : the WHOLE solve of a 3840x2160 frame split into column slabs over the N ranks
                                   (rsdsfm_tile_* stages, dist.TiledFrameSolve; scaling "strong").
   N > 1     = one process per GPU (torch.distributed / RCCL).  depth / full: each rank solves its own frame pairs
               (sequence-throughput mode, BASELINE configs[4]), no data-path collective -> scaling "weak".
-  --streams = independent pairs in flight PER GPU (default 4): one solver context + HIP stream each; the pairs share nothing,
-              so the latency-bound follow-up launches of one pair overlap the streaming launch of another.  `value` is the
-              throughput of that loop; `config.one_pair_at_a_time` carries the same loop with a single context.
+  --batch B, --streams S = sequence-throughput mode PER GPU (defaults 4 and 2): B independent pairs per launch of the batched
+              depth fast path (rsdsfm_estimate_inverse_depths_batch_dev: one solver context per pair, grid y = pair) on each
+              of S HIP streams; the pairs share nothing.  `value` is the throughput of that loop (K steps = K pairs),
+              `config.one_pair_at_a_time` the same work with one context; `roofline` is the batched streaming kernel measured
+              with the other stream idle, `roofline_job` the algorithmic bytes over the job's time per pair.
+  also in the line: `full_solve` / `full_solve_batched` (whole solves, one at a time / 4 in flight), `cpu_baseline` (oracle, 1
+              thread) and `cpu_baseline_all_cores` (same source with OpenMP, best thread count of a sweep).
 Frame pairs rotate through enough distinct HBM buffers to exceed the 256 MiB Infinity Cache, so the timed loop
 streams from HBM, not from L3.
 """

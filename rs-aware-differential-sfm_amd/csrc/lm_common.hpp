@@ -165,6 +165,21 @@ struct LmPlanReg {
     }
 };
 
+// plan of launch 0 of a solve with the shape known at compile time (no accepted steps yet, KMAX speculated iterations):
+// lm_pixel becomes one straight-line block, which lets the compiler interleave the independent pixels of a lane.
+struct LmPlanFirst {
+    static constexpr int n_hist = 0;
+    static constexpr int K = KMAX;
+    int write_which;
+    double inv_cand[KMAX];
+    __device__ __forceinline__ double inv_hist_at(int) const { return 0.0; }
+    __device__ __forceinline__ void load(const LmPlanLds& l) {
+        write_which = l.write_which;
+#pragma unroll
+        for (int j = 0; j < KMAX; ++j) inv_cand[j] = l.inv_cand[j];
+    }
+};
+
 // one pixel through the planned LM trajectory; returns the state selected by write_which.
 // Arithmetic mirrors oracle/rsdsfm_oracle.c rso_estimate_inverse_depths (mode 1) operation for operation.
 struct NoHook {

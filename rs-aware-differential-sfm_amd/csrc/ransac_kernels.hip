@@ -17,6 +17,8 @@
 //                         (x, y, 1/rho), alpha, alpha_k, index (block counts -> exclusive scan -> scatter)
 //
 // Pixels are streamed (HBM-bound when T is small, VALU-bound for large T: ~250 fp64 ops per pixel-hypothesis).
+#include <algorithm>
+
 #include "device_math.hpp"
 #include "lm_common.hpp"
 #include "rsdsfm_internal.hpp"
@@ -93,6 +95,7 @@ __device__ __forceinline__ void load_tile(Tile& t, const double2* __restrict__ q
 // ---------------------------------------------------------------------------------------------------
 // round 0: every hypothesis starts from the built-in plan; round r > 0: only hypotheses whose state machine is
 // still running (status 0) and expects launch r take part.  partials: [gridDim.x][T][NS].
+template <bool R0>
 __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
                                                        const double* __restrict__ alpha,
                                                        const double* __restrict__ alpha_k, int64_t n,
@@ -110,8 +113,12 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
     __shared__ double s_half[kRB / 64][2][kNSum];
     __shared__ int s_active;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // blockIdx.y = hypothesis group: with one tile per workgroup and 2 workgroups resident per CU, 900 tiles (1280x720) are
+    // 1.76 rounds of the chip; splitting the hypotheses over gridDim.y makes the workgroups short enough that the last round is full
+    const int per_group = (T + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int t_begin = (int)blockIdx.y * per_group, t_end = min(T, t_begin + per_group);
     for (int i = tid; i < T * NSR; i += kRB) s_acc[i] = 0.0;
-    if (round == 0 && tid == 0) {
+    if (R0 && tid == 0) {
         plan.n_hist = 0;
         plan.K = kRansacK0;
         plan.write_which = 0;
@@ -122,14 +129,20 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
         }
     }
     __syncthreads();
+    LmPlanFirst pf;  // round 0: plan shape known at compile time (kRansacK0 == KMAX speculated iterations, nothing accepted yet)
+    static_assert(kRansacK0 == KMAX, "LmPlanFirst speculates KMAX iterations");
+    pf.write_which = 0;
+#pragma unroll
+    for (int j = 0; j < KMAX; ++j) pf.inv_cand[j] = R0 ? plan.inv_cand[j] : 0.0;
 
     const int64_t tile_pixels = (int64_t)kRB * kRP;
     const int64_t ntiles = (n + tile_pixels - 1) / tile_pixels;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         Tile px;
         load_tile(px, q, u, alpha, alpha_k, tile * tile_pixels, n);
-        for (int t = 0; t < T; ++t) {
-            if (round > 0) {
+        const bool full_tile = (tile + 1) * tile_pixels <= n;
+        for (int t = t_begin; t < t_end; ++t) {
+            if (!R0) {
                 __syncthreads();  // previous hypothesis is done with `plan`
                 if (tid == 0) {
                     const LmState& st = states[t];
@@ -155,12 +168,20 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
             double sc[2 * kFused];
 #pragma unroll
             for (int s = 0; s < 2 * kFused; ++s) sc[s] = 0.0;
+            if (R0 && full_tile) {  // round 0, no ragged lanes: one straight-line block, the kRP pixel chains interleave
 #pragma unroll
-            for (int j = 0; j < kRP; ++j)
-                if (px.ok[j]) {
+                for (int j = 0; j < kRP; ++j) {
                     const ScoreHook hook{px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], two_over, tol, &pose, sc};
-                    (void)lm_pixel(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, plan, acc, hook);
+                    (void)lm_pixel(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, pf, acc, hook);
                 }
+            } else {
+#pragma unroll
+                for (int j = 0; j < kRP; ++j)
+                    if (px.ok[j]) {
+                        const ScoreHook hook{px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], two_over, tol, &pose, sc};
+                        (void)lm_pixel(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, plan, acc, hook);
+                    }
+            }
             double(*red)[NSR] = s_red[t & 1];
             // ---- wave reduction of the NSR values ----
             // The 4 max slots go through DPP butterflies.  The 18 SUM slots are transposed through LDS instead of 18 x 6
@@ -222,7 +243,7 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
     }
     __syncthreads();
     double* out = partials + (int64_t)blockIdx.x * T * NSR;
-    for (int i = tid; i < T * NSR; i += kRB) out[i] = s_acc[i];
+    for (int i = t_begin * NSR + tid; i < t_end * NSR; i += kRB) out[i] = s_acc[i];
 }
 
 // fixed-order reduction of partials[nblocks][T][NSR] of hypothesis t into s_sums[NSR] (256 threads)
@@ -608,6 +629,16 @@ int ransac_pixel_grid(const Ctx* c, int64_t n) {
     return (int)g;
 }
 
+// hypothesis groups (gridDim.y) of ransac_lm_kernel: enough workgroups for >= 8 rounds of the chip's resident slots (2 per CU at
+// this kernel's register count), but at least 8 hypotheses per workgroup so that the tile load and the prologue stay amortised.
+// Measured at 1280x720, T = 50 (900 tiles): 631 / 575 / 560 / 556 us for 1 / 3 / 4 / 5 groups.
+static int ransac_lm_groups(const Ctx* c, int grid, int T) {
+    const int slots = c->num_cus * 2;
+    int g = (8 * slots + grid - 1) / grid;
+    g = std::min(g, T / 8);
+    return std::max(g, 1);
+}
+
 int ransac_lm_partials_doubles(const Ctx* c, int64_t n, int batch) { return ransac_pixel_grid(c, n) * batch * NSR; }
 
 // flags: device int[2] = {running, unscored}; flags[0] is cleared here, flags[1] by the caller once per batch
@@ -615,9 +646,13 @@ int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const doubl
                            const double* hyp, int T, LmState* states, double* partials, int* flags, int* scored,
                            double* trial_count, double* trial_err, int round, double tol) {
     const int grid = ransac_pixel_grid(c, n);
-    hipLaunchKernelGGL(ransac_lm_kernel, dim3(grid), dim3(kRB), sizeof(double) * T * NSR, c->stream,
-                       reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states,
-                       partials, round, tol, flags);
+    const dim3 g2(grid, ransac_lm_groups(c, grid, T));
+    if (round == 0)
+        hipLaunchKernelGGL(ransac_lm_kernel<true>, g2, dim3(kRB), sizeof(double) * T * NSR, c->stream, reinterpret_cast<const double2*>(q),
+                           reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states, partials, round, tol, flags);
+    else
+        hipLaunchKernelGGL(ransac_lm_kernel<false>, g2, dim3(kRB), sizeof(double) * T * NSR, c->stream, reinterpret_cast<const double2*>(q),
+                           reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states, partials, round, tol, flags);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, states, n, round, flags, scored,
                        trial_count, trial_err);
@@ -644,9 +679,13 @@ int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* 
 int ransac_lm_rows_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                           const double* hyp, int T, const LmState* states, double* partials, int round, double tol, double* rows) {
     const int grid = ransac_pixel_grid(c, n);
-    hipLaunchKernelGGL(ransac_lm_kernel, dim3(grid), dim3(kRB), sizeof(double) * T * NSR, c->stream,
-                       reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states,
-                       partials, round, tol, static_cast<int*>(nullptr));
+    const dim3 g2(grid, ransac_lm_groups(c, grid, T));
+    if (round == 0)
+        hipLaunchKernelGGL(ransac_lm_kernel<true>, g2, dim3(kRB), sizeof(double) * T * NSR, c->stream, reinterpret_cast<const double2*>(q),
+                           reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states, partials, round, tol, static_cast<int*>(nullptr));
+    else
+        hipLaunchKernelGGL(ransac_lm_kernel<false>, g2, dim3(kRB), sizeof(double) * T * NSR, c->stream, reinterpret_cast<const double2*>(q),
+                           reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states, partials, round, tol, static_cast<int*>(nullptr));
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(ransac_lm_rows_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, states, round, rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());

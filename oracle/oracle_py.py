@@ -52,13 +52,31 @@ class RansacOut(C.Structure):
     ]
 
 
+def _cpu_has_fma():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return " fma " in line + " "
+    except OSError:
+        pass
+    return False
+
+
+# -ffp-contract=off: only the fma() calls written out in the source fuse (the HIP kernels mirror exactly those).
+# -mfma makes them single instructions; without it (host without FMA3) they go through libm's exact software fma --
+# same results, much slower.
+CFLAGS = ["-O2", "-ffp-contract=off", "-fPIC", "-std=c99"] + (["-mfma"] if _cpu_has_fma() else [])
+_SUFFIX = "" if _cpu_has_fma() else "_nofma"  # a library built with -mfma elsewhere must not be loaded on a host without FMA3
+
+
 def build(force=False):
-    so = os.path.join(_HERE, "librsdsfm_oracle.so")
+    so = os.path.join(_HERE, "librsdsfm_oracle%s.so" % _SUFFIX)
     src = os.path.join(_HERE, "rsdsfm_oracle.c")
     hdr = os.path.join(_HERE, "rsdsfm_oracle.h")
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
         subprocess.check_call(
-            ["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-std=c99", "-shared", "-o", so, src, "-lm"]
+            ["gcc"] + CFLAGS + ["-shared", "-o", so, src, "-lm"]
         )
     return so
 
@@ -70,10 +88,10 @@ def lib_omp():
     """all-cores (OpenMP) build of the same source; only bench.py's all-cores CPU baseline uses it"""
     global _LIB_OMP
     if _LIB_OMP is None:
-        so = os.path.join(_HERE, "librsdsfm_oracle_omp.so")
+        so = os.path.join(_HERE, "librsdsfm_oracle_omp%s.so" % _SUFFIX)
         src = os.path.join(_HERE, "rsdsfm_oracle.c")
         if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-            subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fPIC", "-std=c99", "-fopenmp", "-shared", "-o", so, src, "-lm"])
+            subprocess.check_call(["gcc"] + CFLAGS + ["-fopenmp", "-shared", "-o", so, src, "-lm"])
         _LIB_OMP = C.CDLL(so)
     return _LIB_OMP
 

@@ -666,22 +666,27 @@ int rso_calculate_velocities(const double q[18], const double u[18], const doubl
 /* residual + per-pixel model                                                                        */
 /* ------------------------------------------------------------------------------------------------ */
 
-/* nonlinearRefinement.cc:32-52, T = double, same evaluation order */
+/* nonlinearRefinement.cc:32-52, T = double.  The sums of products are contracted into fused multiply-adds at the places
+ * written out below (and only there: the file is compiled with -ffp-contract=off) -- what gcc's default -ffp-contract=fast
+ * does to the reference's expressions on FMA hardware, pinned explicitly here because the HIP kernels (device_math.hpp,
+ * lm_common.hpp) mirror this arithmetic operation for operation: an fma is one fp64 instruction on gfx950 where the
+ * unfused pair is two, and the dense depth kernels are bound by fp64 instruction issue. */
 void rso_residual(double x, double y, double ux, double uy, double alpha, double alpha_k, const double v[3],
                   const double w[3], double k, double rho, double r[2]) {
-    double beta = (2.0 / (2.0 + k)) * (alpha + k * alpha_k);
-    double p0 = beta * -1.0 * (rho * (x * v[2] - v[0]) + (x * y * w[0]) - (1.0 + x * x) * w[1] + y * w[2]);
-    double p1 = beta * -1.0 * (rho * (y * v[2] - v[1]) + (1.0 + y * y) * w[0] - x * y * w[1] - x * w[2]);
-    r[0] = ux - p0;
-    r[1] = uy - p1;
+    double beta = (2.0 / (2.0 + k)) * fma(k, alpha_k, alpha);
+    double a0 = fma(x, v[2], -v[0]), a1 = fma(y, v[2], -v[1]);
+    double in0 = fma(rho, a0, x * y * w[0]) - fma(x, x, 1.0) * w[1] + y * w[2];
+    double in1 = fma(rho, a1, fma(y, y, 1.0) * w[0]) - x * y * w[1] - x * w[2];
+    r[0] = fma(beta, in0, ux); /* u - (beta * -1 * in) */
+    r[1] = fma(beta, in1, uy);
 }
 
 /* d r / d rho  ( = beta * a ), the only non-constant Jacobian column of the dense depth solve */
 static inline void jac_rho(double x, double y, double alpha, double alpha_k, const double v[3], double k,
                            double J[2]) {
-    double beta = (2.0 / (2.0 + k)) * (alpha + k * alpha_k);
-    J[0] = beta * (x * v[2] - v[0]);
-    J[1] = beta * (y * v[2] - v[1]);
+    double beta = (2.0 / (2.0 + k)) * fma(k, alpha_k, alpha);
+    J[0] = beta * fma(x, v[2], -v[0]);
+    J[1] = beta * fma(y, v[2], -v[1]);
 }
 
 /* Ceres 1.14 defaults (Solver::Options) used by every solve in nonlinearRefinement.cc */
@@ -758,13 +763,13 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
     for (int64_t i = 0; i < n; ++i) {
         rho[i] = 1.0; /* nonlinearRefinement.cc:140 */
         jac_rho(q[2 * i], q[2 * i + 1], alpha[i], alpha_k[i], v, k, &J[2 * i]);
-        s[i] = 1.0 / (1.0 + sqrt(J[2 * i] * J[2 * i] + J[2 * i + 1] * J[2 * i + 1])); /* jacobi scaling */
+        s[i] = 1.0 / (1.0 + sqrt(fma(J[2 * i], J[2 * i], J[2 * i + 1] * J[2 * i + 1]))); /* jacobi scaling */
         rso_residual(q[2 * i], q[2 * i + 1], u[2 * i], u[2 * i + 1], alpha[i], alpha_k[i], v, w, k, rho[i],
                      &res[2 * i]);
-        cost += res[2 * i] * res[2 * i] + res[2 * i + 1] * res[2 * i + 1];
-        double g = fabs(J[2 * i] * res[2 * i] + J[2 * i + 1] * res[2 * i + 1]);
+        cost = fma(res[2 * i], res[2 * i], fma(res[2 * i + 1], res[2 * i + 1], cost));
+        double g = fabs(fma(J[2 * i], res[2 * i], J[2 * i + 1] * res[2 * i + 1]));
         if (g > gmax) gmax = g;
-        xsq += rho[i] * rho[i];
+        xsq = fma(rho[i], rho[i], xsq);
     }
     cost *= 0.5;
     double x_norm = sqrt(xsq);
@@ -794,18 +799,19 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
 #endif
         for (int64_t i = 0; i < n; ++i) {
             double jt0 = J[2 * i] * s[i], jt1 = J[2 * i + 1] * s[i];
-            double ht = jt0 * jt0 + jt1 * jt1;
-            double lam = clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG) * inv_radius;
-            double gt = jt0 * res[2 * i] + jt1 * res[2 * i + 1];
-            double step = -(gt / (ht + lam));
+            double ht = fma(jt0, jt0, jt1 * jt1);
+            double diag = clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG);
+            double gt = fma(jt0, res[2 * i], jt1 * res[2 * i + 1]);
+            double step = -(gt / fma(diag, inv_radius, ht)); /* ht + clamp(diag) / radius */
             double m0 = jt0 * step, m1 = jt1 * step;
-            model_change -= m0 * (res[2 * i] + m0 / 2.0) + m1 * (res[2 * i + 1] + m1 / 2.0);
-            cand[i] = rho[i] + step * s[i];
+            /* model_change -= m0 (r0 + m0 / 2) + m1 (r1 + m1 / 2) */
+            model_change = fma(-m0, fma(m0, 0.5, res[2 * i]), fma(-m1, fma(m1, 0.5, res[2 * i + 1]), model_change));
+            cand[i] = fma(step, s[i], rho[i]);
             double dx = rho[i] - cand[i];
-            stepsq += dx * dx;
+            stepsq = fma(dx, dx, stepsq);
             double rc[2];
             rso_residual(q[2 * i], q[2 * i + 1], u[2 * i], u[2 * i + 1], alpha[i], alpha_k[i], v, w, k, cand[i], rc);
-            ccost += rc[0] * rc[0] + rc[1] * rc[1];
+            ccost = fma(rc[0], rc[0], fma(rc[1], rc[1], ccost));
         }
         ccost *= 0.5;
         if (!(model_change > 0.0)) { /* HandleInvalidStep */
@@ -838,11 +844,11 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
 #endif
             for (int64_t i = 0; i < n; ++i) {
                 rho[i] = cand[i];
-                xsq += rho[i] * rho[i];
+                xsq = fma(rho[i], rho[i], xsq);
                 rso_residual(q[2 * i], q[2 * i + 1], u[2 * i], u[2 * i + 1], alpha[i], alpha_k[i], v, w, k, rho[i],
                              &res[2 * i]);
-                cost += res[2 * i] * res[2 * i] + res[2 * i + 1] * res[2 * i + 1];
-                double g = fabs(J[2 * i] * res[2 * i] + J[2 * i + 1] * res[2 * i + 1]);
+                cost = fma(res[2 * i], res[2 * i], fma(res[2 * i + 1], res[2 * i + 1], cost));
+                double g = fabs(fma(J[2 * i], res[2 * i], J[2 * i + 1] * res[2 * i + 1]));
                 if (g > gmax) gmax = g;
             }
             cost *= 0.5;
@@ -873,15 +879,15 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
 /* ------------------------------------------------------------------------------------------------ */
 static inline double point_error(double x, double y, double ux, double uy, double alpha, double alpha_k,
                                  const double v[3], const double w[3], double k, double rho) {
-    double beta = (alpha + k * alpha_k) * (2.0 / (2.0 + k));
-    /* A*v, B*w as Eigen evaluates the 2x3 * 3x1 products (terms in column order) */
-    double av0 = v[0] + (-x) * v[2];
-    double av1 = v[1] + (-y) * v[2];
-    double bw0 = (-x * y) * w[0] + (1 + x * x) * w[1] + (-y) * w[2];
-    double bw1 = (-(1 + y * y)) * w[0] + (x * y) * w[1] + x * w[2];
-    double e0 = beta * (av0 * rho + bw0) - ux;
-    double e1 = beta * (av1 * rho + bw1) - uy;
-    return sqrt(e0 * e0 + e1 * e1);
+    double beta = fma(k, alpha_k, alpha) * (2.0 / (2.0 + k));
+    /* A*v, B*w: the 2x3 * 3x1 products, contracted into fma chains (see rso_residual) */
+    double av0 = fma(-x, v[2], v[0]);
+    double av1 = fma(-y, v[2], v[1]);
+    double bw0 = fma(-y, w[2], fma(fma(x, x, 1.0), w[1], (-x * y) * w[0]));
+    double bw1 = fma(x, w[2], fma(x * y, w[1], (-fma(y, y, 1.0)) * w[0]));
+    double e0 = fma(beta, fma(av0, rho, bw0), -ux);
+    double e1 = fma(beta, fma(av1, rho, bw1), -uy);
+    return sqrt(fma(e0, e0, e1 * e1));
 }
 
 int64_t rso_score(const double* q, const double* u, const double* alpha, const double* alpha_k, int64_t n,

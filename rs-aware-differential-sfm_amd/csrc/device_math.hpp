@@ -1,8 +1,11 @@
 // device_math.hpp -- per-pixel model of the RS differential-SfM solve, shared by all kernels.
 //
-// Compiled with -ffp-contract=off: the operation order below is the reference's
-// (nonlinearRefinement.cc:32-52 for the residual, minimal.cc:255-275 for the scoring error) so that
-// integer outputs (inlier masks / counts, LM decisions) can be compared bit-exactly with the CPU oracle.
+// Compiled with -ffp-contract=off; sums of products are fused where -- and only where -- __builtin_fma is written out, at
+// exactly the places oracle/rsdsfm_oracle.c calls fma() (rso_residual, jac_rho, the LM loops, point_error), so that integer
+// outputs (inlier masks / counts, LM decisions) can be compared bit-exactly with the CPU oracle.  The expressions are the
+// reference's (nonlinearRefinement.cc:32-52 for the residual, minimal.cc:255-275 for the scoring error); contracting them is
+// what gcc's default -ffp-contract=fast does to the reference on FMA hardware.  Here it is a measured 11 % of the dense depth
+// solve (the kernels are bound by fp64 instruction issue: an fma is one instruction, the unfused pair two).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -35,14 +38,14 @@ struct PixelModel {
 
     __device__ __forceinline__ void init(double x, double y, double ux_, double uy_, double alpha, double alpha_k,
                                          const Pose& p, double two_over) {
-        double beta = two_over * (alpha + p.k * alpha_k);  // (2/(2+k)) * (alpha + k alpha_k)
+        double beta = two_over * __builtin_fma(p.k, alpha_k, alpha);  // (2/(2+k)) * (alpha + k alpha_k)
         nbeta = beta * -1.0;
-        a0 = x * p.v[2] - p.v[0];
-        a1 = y * p.v[2] - p.v[1];
+        a0 = __builtin_fma(x, p.v[2], -p.v[0]);
+        a1 = __builtin_fma(y, p.v[2], -p.v[1]);
         t01 = x * y * p.w[0];
-        t02 = (1.0 + x * x) * p.w[1];
+        t02 = __builtin_fma(x, x, 1.0) * p.w[1];
         t03 = y * p.w[2];
-        t11 = (1.0 + y * y) * p.w[0];
+        t11 = __builtin_fma(y, y, 1.0) * p.w[0];
         t12 = x * y * p.w[1];
         t13 = x * p.w[2];
         ux = ux_;
@@ -51,24 +54,22 @@ struct PixelModel {
         J1 = beta * a1;
     }
     __device__ __forceinline__ void residual(double rho, double& r0, double& r1) const {
-        double p0 = nbeta * (rho * a0 + t01 - t02 + t03);
-        double p1 = nbeta * (rho * a1 + t11 - t12 - t13);
-        r0 = ux - p0;
-        r1 = uy - p1;
+        r0 = __builtin_fma(-nbeta, __builtin_fma(rho, a0, t01) - t02 + t03, ux);
+        r1 = __builtin_fma(-nbeta, __builtin_fma(rho, a1, t11) - t12 - t13, uy);
     }
 };
 
 // minimal.cc:255-270: residual norm of the flow predicted from (v, w, k, rho)
 __device__ __forceinline__ double point_error(double x, double y, double ux, double uy, double alpha, double alpha_k,
                                               const Pose& p, double two_over, double rho) {
-    double beta = (alpha + p.k * alpha_k) * two_over;
-    double av0 = p.v[0] + (-x) * p.v[2];
-    double av1 = p.v[1] + (-y) * p.v[2];
-    double bw0 = (-x * y) * p.w[0] + (1 + x * x) * p.w[1] + (-y) * p.w[2];
-    double bw1 = (-(1 + y * y)) * p.w[0] + (x * y) * p.w[1] + x * p.w[2];
-    double e0 = beta * (av0 * rho + bw0) - ux;
-    double e1 = beta * (av1 * rho + bw1) - uy;
-    return sqrt(e0 * e0 + e1 * e1);
+    double beta = __builtin_fma(p.k, alpha_k, alpha) * two_over;
+    double av0 = __builtin_fma(-x, p.v[2], p.v[0]);
+    double av1 = __builtin_fma(-y, p.v[2], p.v[1]);
+    double bw0 = __builtin_fma(-y, p.w[2], __builtin_fma(__builtin_fma(x, x, 1.0), p.w[1], (-x * y) * p.w[0]));
+    double bw1 = __builtin_fma(x, p.w[2], __builtin_fma(x * y, p.w[1], (-__builtin_fma(y, y, 1.0)) * p.w[0]));
+    double e0 = __builtin_fma(beta, __builtin_fma(av0, rho, bw0), -ux);
+    double e1 = __builtin_fma(beta, __builtin_fma(av1, rho, bw1), -uy);
+    return sqrt(__builtin_fma(e0, e0, e1 * e1));
 }
 
 // ---- wave64 reductions on the VALU (DPP row shifts / broadcasts; no LDS traffic).  Fixed combination

@@ -193,41 +193,39 @@ __device__ __forceinline__ double lm_pixel(double x, double y, double ux, double
                                            double (&acc)[NS], const Hook& hook = Hook()) {
     PixelModel m;
     m.init(x, y, ux, uy, al, ak, pose, two_over);
-    const double s = 1.0 / (1.0 + sqrt(m.J0 * m.J0 + m.J1 * m.J1));  // Jacobi scaling (iteration 0 Jacobian)
+    const double s = 1.0 / (1.0 + sqrt(__builtin_fma(m.J0, m.J0, m.J1 * m.J1)));  // Jacobi scaling (iteration 0 Jacobian)
     const double jt0 = m.J0 * s, jt1 = m.J1 * s;
-    const double ht = jt0 * jt0 + jt1 * jt1;
+    const double ht = __builtin_fma(jt0, jt0, jt1 * jt1);
     const double diag = clampd(ht, kMinLmDiag, kMaxLmDiag);
     double rho = 1.0;  // nonlinearRefinement.cc:140
     double r0, r1;
     m.residual(rho, r0, r1);
     for (int h = 0; h < plan.n_hist; ++h) {  // replay the accepted steps
-        const double lam = diag * plan.inv_hist_at(h);
-        const double gt = jt0 * r0 + jt1 * r1;
-        const double step = -(gt / (ht + lam));
-        rho = rho + step * s;
+        const double gt = __builtin_fma(jt0, r0, jt1 * r1);
+        const double step = -(gt / __builtin_fma(diag, plan.inv_hist_at(h), ht));
+        rho = __builtin_fma(step, s, rho);
         m.residual(rho, r0, r1);
     }
     double out = rho;
     if (plan.K > 0) {
-        acc[0] += r0 * r0 + r1 * r1;
-        acc[1] += rho * rho;
-        acc[2] = fmax(acc[2], fabs(m.J0 * r0 + m.J1 * r1));
+        acc[0] = __builtin_fma(r0, r0, __builtin_fma(r1, r1, acc[0]));
+        acc[1] = __builtin_fma(rho, rho, acc[1]);
+        acc[2] = fmax(acc[2], fabs(__builtin_fma(m.J0, r0, m.J1 * r1)));
     }
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {
         if (j < plan.K) {
-            const double lam = diag * plan.inv_cand[j];
-            const double gt = jt0 * r0 + jt1 * r1;
-            const double step = -(gt / (ht + lam));
+            const double gt = __builtin_fma(jt0, r0, jt1 * r1);
+            const double step = -(gt / __builtin_fma(diag, plan.inv_cand[j], ht));
             const double m0 = jt0 * step, m1 = jt1 * step;
-            acc[3 + 5 * j + 1] -= m0 * (r0 + m0 / 2.0) + m1 * (r1 + m1 / 2.0);
-            const double cand = rho + step * s;
+            acc[3 + 5 * j + 1] = __builtin_fma(-m0, __builtin_fma(m0, 0.5, r0), __builtin_fma(-m1, __builtin_fma(m1, 0.5, r1), acc[3 + 5 * j + 1]));
+            const double cand = __builtin_fma(step, s, rho);
             const double dx = rho - cand;
-            acc[3 + 5 * j + 2] += dx * dx;
+            acc[3 + 5 * j + 2] = __builtin_fma(dx, dx, acc[3 + 5 * j + 2]);
             m.residual(cand, r0, r1);
-            acc[3 + 5 * j + 0] += r0 * r0 + r1 * r1;
-            acc[3 + 5 * j + 3] += cand * cand;
-            acc[3 + 5 * j + 4] = fmax(acc[3 + 5 * j + 4], fabs(m.J0 * r0 + m.J1 * r1));
+            acc[3 + 5 * j + 0] = __builtin_fma(r0, r0, __builtin_fma(r1, r1, acc[3 + 5 * j + 0]));
+            acc[3 + 5 * j + 3] = __builtin_fma(cand, cand, acc[3 + 5 * j + 3]);
+            acc[3 + 5 * j + 4] = fmax(acc[3 + 5 * j + 4], fabs(__builtin_fma(m.J0, r0, m.J1 * r1)));
             rho = cand;
             hook(j, cand);
             if (plan.write_which == j + 1) out = cand;

@@ -54,7 +54,10 @@ def test_speculative_protocol_long_trajectory(oracle, rsdsfm):
     rho, sm = _solve_single(rsdsfm, q, u, a, ak, v, w, 0.0, nshards=2)
     rho_o, sm_o = oracle.estimate_inverse_depths(q, u, v, w, 0.0, a, ak, mode=1)
     assert sm["num_iterations"] == sm_o["num_iterations"] > 4 and sm["termination"] == sm_o["termination"]
-    assert np.allclose(rho, rho_o, rtol=1e-12, atol=1e-15)
+    # the numpy restatement has no fused multiply-add, the oracle fuses where its source says fma(): identical decisions,
+    # depths equal to rounding (1e-14), except at the deliberately ill-conditioned pixel 7 (a ~ 1e-7: 3e-12)
+    assert np.allclose(rho, rho_o, rtol=1e-10, atol=1e-15)
+    assert np.allclose(np.delete(rho, 7), np.delete(rho_o, 7), rtol=1e-12, atol=1e-15)
 
 
 def test_shard_bounds(rsdsfm):

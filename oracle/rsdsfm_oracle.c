@@ -7,8 +7,10 @@
  * its README (Eigen 3.3.4: JacobiSVD.h, Jacobi.h, AngleAxis.h; Ceres 1.14.0: trust_region_minimizer.cc,
  * levenberg_marquardt_strategy.cc, schur_eliminator_impl.h).
  *
- * Build: gcc -O2 -ffp-contract=off -fPIC -shared  (no FMA contraction: the HIP kernels are compiled the
- * same way so that integer outputs can be compared bit-exactly).
+ * Build: gcc -O2 -ffp-contract=off -mfma -fPIC -shared.  The compiler contracts nothing; the per-pixel model of the dense
+ * depth solve (rso_residual, jac_rho, the LM loops of rso_estimate_inverse_depths, point_error) calls fma() explicitly, and
+ * the HIP kernels fuse at exactly the same places, so that integer outputs can be compared bit-exactly.  -mfma only makes
+ * those calls single instructions (without it libm's exact software fma gives the same bits, slowly).
  */
 #include "rsdsfm_oracle.h"
 
@@ -1490,11 +1492,12 @@ void rso_interpolate_cracky(const uint8_t* in, int32_t rows, int32_t cols, int32
 /* ------------------------------------------------------------------------------------------------ */
 static void rso_project_scanline(const double* Ri, const double* ti, const double W[3], double fx, double fyp, double cx,
                                  double cy, double* px, double* py) {
-    /* worldToCameraFrame: [R t; 0 1] * (W, 1), evaluated left to right; then spaceToPlane */
+    /* worldToCameraFrame: [R t; 0 1] * (W, 1), evaluated left to right; then spaceToPlane.  Sums of products contracted into
+     * explicit fmas (see rso_residual): the HIP kernel of this search is bound by fp64 instruction issue and fuses at the same places */
     double pc[3];
-    for (int j = 0; j < 3; ++j) pc[j] = ((Ri[j * 3 + 0] * W[0] + Ri[j * 3 + 1] * W[1]) + Ri[j * 3 + 2] * W[2]) + ti[j] * 1.0;
-    *px = pc[0] / pc[2] * fx + cx;
-    *py = pc[1] / pc[2] * fyp + cy;
+    for (int j = 0; j < 3; ++j) pc[j] = fma(Ri[j * 3 + 2], W[2], fma(Ri[j * 3 + 1], W[1], Ri[j * 3 + 0] * W[0])) + ti[j] * 1.0;
+    *px = fma(pc[0] / pc[2], fx, cx);
+    *py = fma(pc[1] / pc[2], fyp, cy);
 }
 
 void rso_true_flow(const double* wx, const double* wy, const double* wz, int32_t rows, int32_t cols, const double* R2,

@@ -7,9 +7,10 @@
 // GEMM-shaped (one IEEE division per projection, an argmin with an index-dependent target):
 //   * one pixel per lane; the scanline loop is uniform across the machine, so the pose rows come through the scalar
 //     data path (s_load) and are broadcast operands of the VALU instructions -- no LDS, no vector loads in the loop;
-//   * only what decides the argmin is computed in the loop (camera-frame y and z: 6 mul + 6 add, 1 division, the
-//     intrinsics and the compare); the x coordinate is computed once for the winner.  Each value that is computed is
-//     computed with the reference's operation order, so flows and winners are bit-identical to the oracle's;
+//   * only what decides the argmin is computed in the loop (camera-frame y and z: 2 mul + 4 fma + 2 add, 1 division, the
+//     intrinsics as one fma and the compare); the x coordinate is computed once for the winner.  Each value that is
+//     computed is computed with the oracle's operation order and fused multiply-adds (rso_project_scanline), so flows
+//     and winners are bit-identical to the oracle's;
 //   * the world maps are column-major (Eigen) and the flow row-major (cv::Mat): 24 B read + 16 B written per pixel,
 //     negligible against rows2 x ~30 fp64 instructions per pixel.
 #include <math.h>
@@ -47,9 +48,9 @@ __global__ __launch_bounds__(kGF) void true_flow_kernel(const double* __restrict
             for (int i = 0; i < rows2; ++i) {
                 const double* Ri = R2 + (int64_t)i * 9;  // uniform address: scalar loads
                 const double* ti = t2 + (int64_t)i * 3;
-                const double yc = ((Ri[3] * X + Ri[4] * Y) + Ri[5] * Z) + ti[1] * 1.0;
-                const double zc = ((Ri[6] * X + Ri[7] * Y) + Ri[8] * Z) + ti[2] * 1.0;
-                const double py = yc / zc * fyp + cy;
+                const double yc = __builtin_fma(Ri[5], Z, __builtin_fma(Ri[4], Y, Ri[3] * X)) + ti[1] * 1.0;
+                const double zc = __builtin_fma(Ri[8], Z, __builtin_fma(Ri[7], Y, Ri[6] * X)) + ti[2] * 1.0;
+                const double py = __builtin_fma(yc / zc, fyp, cy);
                 const double diff = fabs(py - (double)i);
                 if (diff < min_diff) {
                     min_diff = diff;
@@ -58,11 +59,11 @@ __global__ __launch_bounds__(kGF) void true_flow_kernel(const double* __restrict
             }
             const double* Ri = R2 + (int64_t)best_row * 9;
             const double* ti = t2 + (int64_t)best_row * 3;
-            const double xc = ((Ri[0] * X + Ri[1] * Y) + Ri[2] * Z) + ti[0] * 1.0;
-            const double yc = ((Ri[3] * X + Ri[4] * Y) + Ri[5] * Z) + ti[1] * 1.0;
-            const double zc = ((Ri[6] * X + Ri[7] * Y) + Ri[8] * Z) + ti[2] * 1.0;
-            const double px = xc / zc * fx + cx;
-            const double py = yc / zc * fyp + cy;
+            const double xc = __builtin_fma(Ri[2], Z, __builtin_fma(Ri[1], Y, Ri[0] * X)) + ti[0] * 1.0;
+            const double yc = __builtin_fma(Ri[5], Z, __builtin_fma(Ri[4], Y, Ri[3] * X)) + ti[1] * 1.0;
+            const double zc = __builtin_fma(Ri[8], Z, __builtin_fma(Ri[7], Y, Ri[6] * X)) + ti[2] * 1.0;
+            const double px = __builtin_fma(xc / zc, fx, cx);
+            const double py = __builtin_fma(yc / zc, fyp, cy);
             if (sqrt(px * px + py * py) != 0) {
                 f2x = px;
                 f2y = py;

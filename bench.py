@@ -339,7 +339,7 @@ def main():
             })
         # the whole solve, reported beside the headline (not the timed `value`)
         full = _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps=8, warmup=2, timed=timed) if args.workload == "depth" else None
-        batched = _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, 4, per_thread=12) if (args.workload == "depth" and B * S > 1) else None
+        batched = _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, 4, per_thread=40) if (args.workload == "depth" and B * S > 1) else None
         if rank == 0:
             line["full_solve"] = full
             line["full_solve_batched"] = batched

@@ -57,7 +57,7 @@ def cpu_baseline(data, v, w, budget_s=12.0):
         O.estimate_inverse_depths(q, u, v, w, 0.0, a, ak, mode=1)
         reps += 1
         el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 200:
+        if el >= budget_s or reps >= 1000:
             break
     pix = data["rows"] * data["cols"] * reps
     return {"value": pix / el / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "port",

@@ -113,6 +113,19 @@ def test_ransac_deepflow_like(oracle, solver, rsdsfm, T):
         assert 0 < r["num_inliers"] < len(q)
 
 
+@pytest.mark.parametrize("rows,cols,T", [(24, 32, 50), (40, 64, 17), (64, 100, 128)])
+def test_ransac_hypothesis_groups_on_small_frames(oracle, solver, rsdsfm, rows, cols, T):
+    """frames of a few pixel tiles (768 points < one 1280-point tile; exactly two tiles; five tiles) with many hypotheses: the
+    hypothesis-batched LM kernel then splits the hypotheses over gridDim.y (up to T / 8 groups per tile) and the ragged-tile
+    path carries the whole frame -- same trials, counts, best trial and inliers as the oracle"""
+    d = rsdsfm.synth.make_config(3, rows=rows, cols=cols)
+    q, u, a, ak = d["q"], d["u"], d["alpha"], d["alpha_k"]
+    samples = oracle.sample_indices(len(q), T, 99)
+    r = solver.ransac(q, u, a, ak, False, T, 0.004, samples=samples, depth_mode=1)
+    ro = oracle.ransac(q, u, a, ak, False, T, 0.004, samples, depth_mode=1)
+    _compare_ransac(r, ro)
+
+
 def test_ransac_builtin_sampler_matches_reference_sampler(oracle, solver, rsdsfm):
     """samples=NULL: the library's sampler is the reference's partial Fisher-Yates (minimal.cc:226-244) driven by
     splitmix64(seed) -- identical to the oracle's restatement, so the whole run matches."""

@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Randomised GPU-vs-oracle parity campaign (not collected by pytest: run  python tests/fuzz_gpu.py [cases] [seed]  on a GPU box).
+
+Each case draws a frame size, motion, shutter parameter, noise / outlier level, RANSAC tolerance and trial count, then
+compares through the C ABI against the CPU oracle: the dense depth solve for a random pose (closed form + LM: depths,
+iteration counts, termination), RANSAC (per-trial counts and accepted LM steps, best trial, mask, index list: bit-exact)
+and the refinement started from the RANSAC result (iteration counts and termination exact, values 1e-6).  Prints one
+line per failing case and a summary; exit code 1 if anything differed."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main(cases=None, seed0=None):
+    import oracle_py as O
+    import rsdsfm
+
+    if cases is None:
+        cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    if seed0 is None:
+        seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    bad = ties = splits = 0
+    with rsdsfm.Solver(0) as s:
+        for c in range(cases):
+            rng = np.random.default_rng(seed0 * 100003 + c)
+            rows, cols = int(rng.integers(9, 90)), int(rng.integers(9, 130))
+            cfg = int(rng.choice([1, 3]))
+            v = rng.normal(size=3) * np.array([0.03, 0.03, 0.02])
+            w = rng.normal(size=3) * 0.004
+            k = float(rng.choice([0.0, 0.0, rng.uniform(-0.5, 0.8)]))
+            d = rsdsfm.synth.make_config(cfg, seed=int(rng.integers(1 << 30)), v=v, w=w, k=k, rows=rows, cols=cols)
+            q, u, a, ak = d["q"], d["u"], d["alpha"], d["alpha_k"]
+            n = len(q)
+            tag = "case %d (%dx%d cfg %d n %d k %.3f)" % (c, rows, cols, cfg, n, k)
+            try:
+                if n < 9:
+                    continue
+                # dense depth solve at a random (not the true) pose
+                pv = v + rng.normal(size=3) * 0.005
+                pv /= np.linalg.norm(pv)
+                pw = w + rng.normal(size=3) * 0.001
+                pk = float(rng.choice([0.0, k]))
+                if not (np.all(np.isfinite(q)) and np.all(np.isfinite(u))):
+                    continue  # degenerate intrinsics of a sliver-shaped frame: not a parity case (NaN handling has its own test)
+                for mode in (0, 1):
+                    rho, sm = s.estimate_inverse_depths(q, u, pv, pw, pk, a, ak, mode=mode)
+                    rho_o, sm_o = O.estimate_inverse_depths(q, u, pv, pw, pk, a, ak, mode=mode)
+                    assert np.allclose(rho, rho_o, rtol=1e-9, atol=1e-13), "depth values mode %d" % mode
+                    if mode == 1:
+                        for key in ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination"):
+                            assert sm[key] == sm_o[key], ("depth " + key, sm, sm_o)
+                # RANSAC
+                T = int(rng.choice([1, 3, 8, 20, 50]))
+                tol = float(rng.choice([0.05, 0.01, 0.003, 0.001]))
+                use_k = bool(rng.integers(2)) and k != 0.0
+                samples = O.sample_indices(n, T, int(rng.integers(1 << 30)))
+                dm = int(rng.integers(2))
+                r = s.ransac(q, u, a, ak, use_k, T, tol, samples=samples, depth_mode=dm)
+                ro = O.ransac(q, u, a, ak, use_k, T, tol, samples, depth_mode=dm)
+                assert np.array_equal(r["trial_count"], ro["trial_count"]), "trial_count"
+                assert np.array_equal(r["trial_steps"], ro["trial_steps"]), "trial_steps"
+                if r["best_trial"] != ro["best_trial"]:
+                    # minimal.cc:278-285 breaks ties in the inlier count by the SUM of the inlier errors.  With noise-free data every
+                    # trial explains every point and each point's error is the rounding noise of the arithmetic itself (1e-14),
+                    # which depends on the last bits of the trust-region radius (a ratio of global sums whose rounding depends on
+                    # the summation order: sequential on the CPU, a tree on the GPU): the sums of two all-inlier trials differ by
+                    # 1e-7 .. 1e-5 relative and their order is arbitrary on both sides.  Counted, not failed.
+                    tg, to = r["best_trial"], ro["best_trial"]
+                    cnt = max(int(r["trial_count"][to]), 1)
+                    tie = (r["trial_count"][tg] == r["trial_count"][to]
+                           and (abs(r["trial_err"][tg] - r["trial_err"][to]) <= 1e-3 * max(abs(r["trial_err"][to]), 1e-300)
+                                or max(r["trial_err"][tg], r["trial_err"][to]) / cnt < 1e-11))  # per-point error = rounding noise
+                    if tie:
+                        ties += 1
+                        continue
+                    raise AssertionError("best trial %d vs %d, counts %s, errs %.17g %.17g" % (tg, to, r["trial_count"][[tg, to]], r["trial_err"][tg], r["trial_err"][to]))
+                assert r["num_inliers"] == ro["num_inliers"], "num_inliers"
+                assert np.array_equal(r["mask"], ro["mask"]) and np.array_equal(r["inlier_idx"], ro["inlier_idx"]), "mask"
+                if not np.allclose(r["inv_depth"], ro["inv_depth"], rtol=1e-9, atol=1e-13, equal_nan=True):
+                    rel = np.abs(r["inv_depth"] - ro["inv_depth"]) / np.maximum(np.abs(ro["inv_depth"]), 1e-300)
+                    i = int(np.argmax(rel))
+                    raise AssertionError("inv_depth: %d of %d points beyond 1e-9, worst %.3e at %d (%.17g vs %.17g), q %s" % (
+                        int(np.sum(rel > 1e-9)), n, rel[i], i, r["inv_depth"][i], ro["inv_depth"][i], q[i]))
+                if not np.allclose(r["trial_vel"], ro["trial_vel"], rtol=1e-8, atol=1e-10, equal_nan=True):  # degenerate samples give NaN poses on both sides
+                    dv = np.nan_to_num(np.abs(r["trial_vel"] - ro["trial_vel"])).reshape(T, -1)
+                    t_bad = int(np.argmax(dv.max(axis=1)))
+                    raise AssertionError("trial_vel: trial %d max abs diff %.3e, gpu %s oracle %s, count %d of %d" % (
+                        t_bad, dv.max(), np.array2string(r["trial_vel"].reshape(T, -1)[t_bad], precision=12),
+                        np.array2string(ro["trial_vel"].reshape(T, -1)[t_bad], precision=12), int(r["trial_count"][t_bad]), n))
+                # refinement from the RANSAC result
+                if r["num_inliers"] >= 12:
+                    out = s.non_linear_refinement(u, r["inliers"], r["alpha"], r["alpha_k"], r["v"], r["w"], r["k"], use_k,
+                                                  flow_index_mode=1, inlier_idx=r["inlier_idx"])
+                    ref = O.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], use_k, 1, ro["inlier_idx"])
+                    so, sr = out["summary"], ref["summary"]
+                    same = all(so[key] == sr[key] for key in ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination"))
+                    hard = max(so["num_iterations"], sr["num_iterations"]) >= 15 or max(so["num_unsuccessful_steps"], sr["num_unsuccessful_steps"]) >= 5
+                    if hard:
+                        # ill-conditioned: tiny or sliver-shaped frames / acceleration mode that wander for 15+ iterations or reject steps (often to
+                        # the 50-iteration cap).  Every accept / reject there sits close to its threshold, the two runs differ by the
+                        # rounding of their Schur sums, and the trajectories are chaotic; only the outcome is compared.  Counted.
+                        assert np.isclose(so["final_cost"], sr["final_cost"], rtol=2e-2), ("ill-conditioned refinement", so, sr)
+                        splits += 1
+                        continue
+                    if not same:
+                        # a long, ill-conditioned trajectory (tiny frame, acceleration mode, unsuccessful steps) can split when one
+                        # accept / reject test falls within the rounding of the Schur sums; both runs must then end with the same
+                        # termination type at the same cost (1e-4).  Counted, not failed.
+                        assert so["termination"] == sr["termination"] and np.isclose(so["final_cost"], sr["final_cost"], rtol=1e-4), ("refine trajectory", so, sr)
+                        splits += 1
+                        continue
+                    # values at the north-star tolerance (1e-5; the committed tests assert 1e-6 on well-conditioned cases), compared
+                    # modulo the scale gauge of the problem: the residual only sees rho * v, the refinement does not normalise v,
+                    # and a long trajectory drifts along that flat direction by accumulated rounding (|v| differed by 1e-3 in one
+                    # 41-iteration case while the cost agreed to 4e-10)
+                    ng, nr = np.linalg.norm(out["v"]), np.linalg.norm(ref["v"])
+                    assert np.allclose(out["v"] / ng, ref["v"] / nr, rtol=1e-5, atol=1e-7) and np.allclose(out["w"], ref["w"], rtol=1e-5, atol=1e-8), (
+                        "refine pose", out["v"], ref["v"], out["w"], ref["w"], so, sr)
+                    assert np.array_equal(out["inliers"][:, :2], ref["inliers"][:, :2]), "refine inlier coordinates"
+                    zg, zr = out["inliers"][:, 2] / ng, ref["inliers"][:, 2] / nr
+                    # single points whose depth the data barely constrains (next to the epipole) may differ more after a long run
+                    if not (np.mean(np.isclose(zg, zr, rtol=1e-5, atol=1e-9)) >= 0.995 and np.allclose(zg, zr, rtol=1e-2, atol=1e-6)):
+                        rel = np.abs(zg - zr) / np.maximum(np.abs(zr), 1e-300)
+                        i = int(np.argmax(rel))
+                        raise AssertionError("refine depths: %d of %d beyond 1e-5, worst %.3e at %d (%.12g vs %.12g; before refinement %.12g) %s" % (
+                            int(np.sum(rel > 1e-5)), len(zr), rel[i], i, zg[i], zr[i], r["inliers"][i, 2], so))
+                    assert np.isclose(so["final_cost"], sr["final_cost"], rtol=1e-7, atol=1e-25), "refine cost"
+            except AssertionError as e:
+                bad += 1
+                print("MISMATCH", tag, e.args[0] if e.args else "", flush=True)
+            except rsdsfm.RsdsfmError as e:
+                bad += 1
+                print("ERROR", tag, e, flush=True)
+    print("fuzz: %d cases, %d mismatches; %d all-inlier ties decided by rounding noise, %d ill-conditioned / split refinement trajectories (outcome compared)" % (cases, bad, ties, splits))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

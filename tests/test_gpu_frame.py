@@ -213,3 +213,12 @@ def test_bench_full_workload_matches_oracle_chain(oracle, rsdsfm):
     dm_o, _, _ = oracle.scatter_depth(inl_o, *K, rows, cols)
     got = dm.cpu().numpy().T
     assert np.array_equal(got != 0, dm_o != 0) and np.allclose(got, dm_o, rtol=1e-6)
+
+
+def test_randomised_parity_campaign_sample(rsdsfm):
+    """120 cases of tests/fuzz_gpu.py (random frame sizes, motions, noise, tolerances, trial counts; depth solve, RANSAC and
+    refinement against the oracle).  The full campaign (thousands of cases, `python tests/fuzz_gpu.py 400 <seed>`) is how the
+    statements of DESIGN.md section 6 about ties and ill-conditioned refinements were established."""
+    import fuzz_gpu
+
+    assert fuzz_gpu.main(120, 1) == 0

@@ -17,6 +17,77 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def fuzz_consumers(O, rsdsfm, cases, seed0):
+    """SURVEY 8(f) consumers on random scenes: flatten + depth map glue, RS->GS back projection (RS / GS mode, both Q5 modes),
+    crack interpolation, 8-bit depth image, ground-truth flow search -- byte / index / fp outputs bit-exact -- and the
+    reprojection metric (statistics to summation order, integer counts exact)"""
+    bad = 0
+    with rsdsfm.Solver(0) as s:
+        for c in range(cases):
+            rng = np.random.default_rng(seed0 * 7919 + 31 * c + 5)
+            rows, cols = int(rng.integers(1, 70)), int(rng.integers(1, 110))
+            tag = "consumer case %d (%dx%d)" % (c, rows, cols)
+            try:
+                d = rsdsfm.synth.make_config(int(rng.choice([1, 3])), seed=int(rng.integers(1 << 30)), rows=max(rows, 3), cols=max(cols, 3))
+                rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+                # flatten glue
+                q, u, a, ak = s.flatten(d["flow_img"], K, gamma)  # the GPU glue fuses getAlpha / getAlphaK into the flatten
+                qo, uo, qpxo, fpxo = O.flatten(d["flow_img"], *K, gamma)
+                assert np.array_equal(q, qo) and np.array_equal(u, uo), "flatten"
+                assert np.array_equal(a, O.get_alpha(fpxo, rows, gamma)) and np.array_equal(ak, O.get_alpha_k(qpxo, fpxo, rows, gamma)), "alpha"
+                # a scene: image, depth with holes, a random motion
+                img = rng.integers(0, 256, size=(rows, cols, 3), dtype=np.uint8)
+                img[rng.random((rows, cols)) < 0.05] = (2, 3, 1)
+                depth = np.array(d["truth"]["Z"]) * rng.uniform(0.5, 2.0)
+                depth[rng.random((rows, cols)) < 0.08] = 0.0
+                v = rng.normal(size=3) * np.array([0.15, 0.12, 0.3])
+                w = rng.normal(size=3) * 0.05
+                k = float(rng.choice([0.0, rng.uniform(-0.4, 0.6)]))
+                R, t = O.pose_table(v, w, k, gamma, rows)
+                for mode, q5 in ((0, 0), (0, 1), (1, 0), (1, 1)):
+                    gs, c3 = s.back_project(img, depth, R, t, K, mode=mode, q5_mode=q5)
+                    gs_o, c3_o = O.back_project(img, depth, R, t, *K, mode=mode, q5_mode=q5)
+                    assert np.array_equal(gs, gs_o), "back_project image mode %d q5 %d" % (mode, q5)
+                    assert np.array_equal(c3.view(np.uint32), c3_o.view(np.uint32)), "back_project coords mode %d q5 %d" % (mode, q5)
+                off = int(rng.integers(1, 4))
+                assert np.array_equal(s.interpolate_cracky(gs, off), O.interpolate_cracky(gs_o, off)), "interpolate_cracky"
+                # depth image of random inliers (collisions, points outside the image, negative depths)
+                m = int(rng.integers(0, 3 * rows * cols + 1))
+                inl = np.column_stack([rng.uniform(-0.6, 0.6, m), rng.uniform(-0.5, 0.5, m), rng.normal(2.0, 1.5, m)])
+                assert np.array_equal(s.depth_preview(inl, K, rows, cols), O.depth_preview(inl, *K, rows, cols)), "depth_preview"
+                # ground-truth flow search against a frame 2 with its own number of scanlines
+                yy, xx = np.mgrid[0:rows, 0:cols]
+                world = np.stack([(xx - K[2]) / K[0], (yy - K[3]) / K[1], np.ones((rows, cols))], axis=2) * depth[:, :, None]
+                rows2 = int(rng.integers(1, 90))
+                R2, t2 = O.pose_table(v * rng.uniform(0.5, 1.5), w * rng.uniform(0.5, 1.5), k, gamma, rows2)
+                t2 = t2 + rng.normal(size=3) * 0.02
+                q5 = int(rng.integers(2))
+                flow, best = s.true_flow(world, R2, t2, K, q5_mode=q5)
+                flow_o, best_o = O.true_flow(world, R2, t2, *K, q5_mode=q5)
+                assert np.array_equal(best, best_o), "true_flow winners"
+                assert np.array_equal(flow.view(np.uint64), flow_o.view(np.uint64)), "true_flow values"
+                # reprojection metric
+                est = (c3_o.astype(np.float64) * rng.uniform(0.7, 1.4)).astype(np.float32)
+                est += (rng.normal(0, 0.02, est.shape) * (rng.random(est.shape) < 0.5)).astype(np.float32)
+                gt = np.array(d["truth"]["Z"])
+                gt[rng.random((rows, cols)) < 0.03] = 0.0
+                st, eimg = s.reprojection_error(est, gt, depth, R, t, K, max_norm=4.0)
+                st_o, eimg_o = O.reprojection_error(est, gt, depth, R, t, *K, max_norm=4.0)
+                for key in ("number_outliers", "scale_inliers", "error_inliers"):
+                    assert st[key] == st_o[key], ("metric " + key, st, st_o)
+                for key in ("scale", "mean_error", "sum_error"):
+                    assert np.isclose(st[key], st_o[key], rtol=1e-10, atol=1e-300, equal_nan=True), ("metric " + key, st, st_o)
+                assert (eimg != eimg_o).mean() < 1e-3, "error image"
+            except AssertionError as e:
+                bad += 1
+                print("MISMATCH", tag, e.args[0] if e.args else "", flush=True)
+            except rsdsfm.RsdsfmError as e:
+                bad += 1
+                print("ERROR", tag, e, flush=True)
+    print("fuzz consumers: %d cases, %d mismatches" % (cases, bad))
+    return bad
+
+
 def main(cases=None, seed0=None):
     import oracle_py as O
     import rsdsfm
@@ -137,6 +208,7 @@ def main(cases=None, seed0=None):
             except rsdsfm.RsdsfmError as e:
                 bad += 1
                 print("ERROR", tag, e, flush=True)
+    bad += fuzz_consumers(O, rsdsfm, max(cases // 2, 1), seed0)
     print("fuzz: %d cases, %d mismatches; %d all-inlier ties decided by rounding noise, %d ill-conditioned / split refinement trajectories (outcome compared)" % (cases, bad, ties, splits))
     return 1 if bad else 0
 

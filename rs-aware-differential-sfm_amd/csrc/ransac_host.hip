@@ -137,10 +137,9 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
             }
         }
     }
-    rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best);
-    if (rc != RSDSFM_OK) return rc;
+    // best trial (picked in the prologue of ransac_final_kernel), its dense rho + mask, order-preserving compaction
     rc = ransac_final_launch(c, d_q, d_u, d_a, d_ak, n, d_best, d_states, depth_mode, tol, d_rho, d_mask, d_bcounts, d_boffs,
-                             out->inlier_idx, out->inliers, out->alpha, out->alpha_k);
+                             out->inlier_idx, out->inliers, out->alpha, out->alpha_k, d_tcount, d_terr, T, d_hyp);
     if (rc != RSDSFM_OK) return rc;
     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, c->stream));
     // per-trial diagnostics are copied back only when the caller asked for them (the frame solve does not)

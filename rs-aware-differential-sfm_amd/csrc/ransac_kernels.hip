@@ -454,12 +454,11 @@ __global__ __launch_bounds__(256) void ransac_score_rows_kernel(const double* __
 // equally many with a strictly smaller error sum; the earlier trial wins ties.
 // (one wave: the trial scores are fetched 64 at a time by the lanes, then walked in trial order through readlane -- the
 // sequential rule is kept literally, only the 2 T dependent global loads of a single-thread loop are gone)
-__global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restrict__ trial_count, const double* __restrict__ trial_err, int T,
-                                                        const double* __restrict__ hyp, RansacBest* best) {
-    if (blockIdx.x != 0) return;
-    const int lane = threadIdx.x;
-    double best_count = -1.0, best_err = 0.0;
-    int bi = -1;
+// the reference's sequential best-trial rule (minimal.cc:278-285) evaluated by one wave: every lane walks the trials in order
+__device__ __forceinline__ void pick_best_trial(const double* __restrict__ trial_count, const double* __restrict__ trial_err, int T,
+                                                int lane, int& bi, double& best_count, double& best_err) {
+    best_count = -1.0, best_err = 0.0;
+    bi = -1;
     for (int t0 = 0; t0 < T; t0 += 64) {
         const int t = t0 + lane;
         const double cl = t < T ? trial_count[t] : 0.0, el = t < T ? trial_err[t] : 0.0;
@@ -473,6 +472,15 @@ __global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restric
             }
         }
     }
+}
+
+__global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restrict__ trial_count, const double* __restrict__ trial_err, int T,
+                                                        const double* __restrict__ hyp, RansacBest* best) {
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
+    double best_count, best_err;
+    int bi;
+    pick_best_trial(trial_count, trial_err, T, lane, bi, best_count, best_err);
     if (lane < 8) best->hyp[lane] = bi >= 0 ? hyp[(int64_t)bi * 8 + lane] : 0.0;
     if (lane == 0) {
         best->best_trial = bi;
@@ -485,21 +493,50 @@ __global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restric
 // best trial: dense rho + mask, then order-preserving compaction
 // ---------------------------------------------------------------------------------------------------
 // Block b owns the contiguous pixel range [b*chunk, (b+1)*chunk), chunk a multiple of kRB.
+// PICK: the best-trial rule runs in the prologue of EVERY workgroup (T <= a few hundred values: redundant, but it removes the
+// single-wave pick launch in front of this kernel); workgroup 0 records the result.  !PICK: `best` was filled by
+// ransac_pick_kernel (column-tiled solve, where the pick follows a cross-rank merge).
+template <bool PICK>
 __global__ __launch_bounds__(kRB) void ransac_final_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
                                                           const double* __restrict__ alpha,
                                                           const double* __restrict__ alpha_k, int64_t n, int64_t chunk,
-                                                          const RansacBest* __restrict__ best,
+                                                          RansacBest* best, const double* __restrict__ trial_count,
+                                                          const double* __restrict__ trial_err, int T, const double* __restrict__ hyp,
                                                           const LmState* __restrict__ states, int depth_mode, double tol,
                                                           double* __restrict__ rho_out, uint8_t* __restrict__ mask_out,
                                                           int64_t* __restrict__ block_counts) {
     __shared__ LmPlanLds plan;
     __shared__ int s_cnt[kRB / 64];
+    __shared__ int s_bt;
+    __shared__ double s_hyp[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int bt = best->best_trial;
+    if (PICK) {
+        if (wv == 0) {
+            double best_count, best_err;
+            int bi;
+            pick_best_trial(trial_count, trial_err, T, lane, bi, best_count, best_err);
+            const double h = (lane < 8 && bi >= 0) ? hyp[(int64_t)bi * 8 + lane] : 0.0;
+            if (lane < 8) s_hyp[lane] = h;
+            if (lane == 0) s_bt = bi;
+            if (blockIdx.x == 0) {
+                if (lane < 8) best->hyp[lane] = h;
+                if (lane == 0) {
+                    best->best_trial = bi;
+                    best->num_inliers = bi >= 0 ? (int64_t)best_count : 0;
+                    best->inlier_error = best_err;
+                }
+            }
+        }
+    } else {
+        if (tid < 8) s_hyp[tid] = best->hyp[tid];
+        if (tid == 0) s_bt = best->best_trial;
+    }
+    __syncthreads();
+    const int bt = s_bt;
     Pose pose;
-    pose.w[0] = best->hyp[0], pose.w[1] = best->hyp[1], pose.w[2] = best->hyp[2];
-    pose.v[0] = best->hyp[3], pose.v[1] = best->hyp[4], pose.v[2] = best->hyp[5];
-    pose.k = best->hyp[6];
+    pose.w[0] = s_hyp[0], pose.w[1] = s_hyp[1], pose.w[2] = s_hyp[2];
+    pose.v[0] = s_hyp[3], pose.v[1] = s_hyp[4], pose.v[2] = s_hyp[5];
+    pose.k = s_hyp[6];
     if (depth_mode == RSDSFM_DEPTH_CERES_LM && bt >= 0) {
         if (tid == 0) {
             plan.n_hist = states[bt].n_hist;
@@ -573,15 +610,38 @@ __global__ __launch_bounds__(256) void ransac_scan_kernel(const int64_t* __restr
 __global__ __launch_bounds__(kRB) void ransac_scatter_kernel(const double2* __restrict__ q, const double* __restrict__ alpha,
                                                             const double* __restrict__ alpha_k, int64_t n, int64_t chunk,
                                                             const double* __restrict__ rho, const uint8_t* __restrict__ mask,
-                                                            const int64_t* __restrict__ block_offsets,
+                                                            const int64_t* __restrict__ block_counts, RansacBest* best,
                                                             int64_t* __restrict__ inlier_idx, double* __restrict__ inliers,
                                                             double* __restrict__ out_alpha, double* __restrict__ out_alpha_k) {
     __shared__ int s_wave[kRB / 64];
     __shared__ int64_t s_base;
+    __shared__ int64_t s_pre[kRB / 64], s_all[kRB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int64_t i0 = (int64_t)blockIdx.x * chunk;
     const int64_t i1 = (i0 + chunk < n) ? i0 + chunk : n;
-    if (tid == 0) s_base = block_offsets[blockIdx.x];
+    // exclusive scan of the per-workgroup inlier counts, done by every workgroup for itself (<= 2048 integers: exact in any
+    // order) instead of a single-workgroup scan kernel between ransac_final_kernel and this one; workgroup 0 records the total
+    {
+        int64_t pre = 0, all = 0;
+        for (int b = tid; b < (int)gridDim.x; b += kRB) {
+            const int64_t cnt = block_counts[b];
+            all += cnt;
+            if (b < (int)blockIdx.x) pre += cnt;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            pre += __shfl_down(pre, off);
+            all += __shfl_down(all, off);
+        }
+        if (lane == 0) s_pre[wv] = pre, s_all[wv] = all;
+        __syncthreads();
+        if (tid == 0) {
+            int64_t p2 = 0, a2 = 0;
+            for (int w2 = 0; w2 < kRB / 64; ++w2) p2 += s_pre[w2], a2 += s_all[w2];
+            s_base = p2;
+            if (blockIdx.x == 0) best->num_inliers_scan = a2;
+        }
+    }
     __syncthreads();
     for (int64_t start = i0; start < i1; start += kRB) {
         const int64_t i = start + tid;
@@ -733,7 +793,8 @@ int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_er
 int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         RansacBest* best, const LmState* states, int depth_mode, double tol, double* rho, uint8_t* mask,
                         int64_t* block_counts, int64_t* block_offsets, int64_t* inlier_idx, double* inliers,
-                        double* out_alpha, double* out_alpha_k) {
+                        double* out_alpha, double* out_alpha_k, const double* pick_count, const double* pick_err, int pick_T,
+                        const double* pick_hyp) {
     int64_t blocks = (n + kRB - 1) / kRB;
     if (blocks < 1) blocks = 1;
     const int64_t cap = 2048;
@@ -742,17 +803,23 @@ int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* 
         chunk = ((blocks + cap - 1) / cap) * kRB;
         blocks = (n + chunk - 1) / chunk;
     }
-    hipLaunchKernelGGL(ransac_final_kernel, dim3((int)blocks), dim3(kRB), 0, c->stream, reinterpret_cast<const double2*>(q),
-                       reinterpret_cast<const double2*>(u), a, ak, n, chunk, best, states, depth_mode, tol, rho, mask,
-                       block_counts);
+    if (pick_count)  // best trial picked in the kernel's prologue
+        hipLaunchKernelGGL(ransac_final_kernel<true>, dim3((int)blocks), dim3(kRB), 0, c->stream, reinterpret_cast<const double2*>(q),
+                           reinterpret_cast<const double2*>(u), a, ak, n, chunk, best, pick_count, pick_err, pick_T, pick_hyp, states,
+                           depth_mode, tol, rho, mask, block_counts);
+    else
+        hipLaunchKernelGGL(ransac_final_kernel<false>, dim3((int)blocks), dim3(kRB), 0, c->stream, reinterpret_cast<const double2*>(q),
+                           reinterpret_cast<const double2*>(u), a, ak, n, chunk, best, static_cast<const double*>(nullptr),
+                           static_cast<const double*>(nullptr), 0, static_cast<const double*>(nullptr), states, depth_mode, tol, rho, mask,
+                           block_counts);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(ransac_scan_kernel, dim3(1), dim3(256), 0, c->stream, block_counts, (int)blocks, block_offsets, best);
-    RSDSFM_HIP_CHECK(c, hipGetLastError());
-    if (inlier_idx || inliers || out_alpha || out_alpha_k) {
+    if (inlier_idx || inliers || out_alpha || out_alpha_k) {  // the compaction scans the workgroup counts itself
         hipLaunchKernelGGL(ransac_scatter_kernel, dim3((int)blocks), dim3(kRB), 0, c->stream, reinterpret_cast<const double2*>(q),
-                           a, ak, n, chunk, rho, mask, block_offsets, inlier_idx, inliers, out_alpha, out_alpha_k);
-        RSDSFM_HIP_CHECK(c, hipGetLastError());
+                           a, ak, n, chunk, rho, mask, block_counts, best, inlier_idx, inliers, out_alpha, out_alpha_k);
+    } else {  // no compacted outputs requested: only the total is needed
+        hipLaunchKernelGGL(ransac_scan_kernel, dim3(1), dim3(256), 0, c->stream, block_counts, (int)blocks, block_offsets, best);
     }
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
 

@@ -20,7 +20,7 @@ int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const
     const int np = const_acceleration ? 7 : 6;
     const size_t M = (size_t)std::max<int64_t>(m, 1);
     const size_t npart = (size_t)refine_partials_doubles(c, m);
-    int rc = ensure_ws(c, Arena::need(sizeof(RefineState)) + Arena::need(16 * M) + 3 * Arena::need(8 * M) + Arena::need(8 * npart) + Arena::need(64) + 1024);
+    int rc = ensure_ws(c, Arena::need(sizeof(RefineState) + 64) + Arena::need(16 * M) + 3 * Arena::need(8 * M) + Arena::need(8 * npart) + Arena::need(64) + 1024);
     if (rc != RSDSFM_OK) return rc;
     rc = ensure_pinned(c, sizeof(RefineState) + 64);
     if (rc != RSDSFM_OK) return rc;
@@ -34,13 +34,16 @@ int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const
     B.alpha_k = d_alpha_k;
     B.inlier_idx = d_inlier_idx;
     B.flow_index_mode = flow_index_mode;
-    B.state = ws.take<RefineState>(1);
+    // state and the bad-index flag share one block, laid out like the pinned host copy: one upload and one read-back cover both
+    static_assert(sizeof(RefineState) % sizeof(int) == 0, "flag follows the state");
+    char* state_block = ws.take<char>(sizeof(RefineState) + 64);
+    B.state = reinterpret_cast<RefineState*>(state_block);
     B.uu = ws.take<double>(2 * M);
     B.rho_a = ws.take<double>(M);
     B.rho_b = ws.take<double>(M);
     B.srho = ws.take<double>(M);
     B.partials = ws.take<double>(npart);
-    B.bad_index = ws.take<int>(1);
+    B.bad_index = reinterpret_cast<int*>(state_block + sizeof(RefineState));
     RefineState* hs = static_cast<RefineState*>(c->h_pinned);
     int* h_bad = reinterpret_cast<int*>(static_cast<char*>(c->h_pinned) + sizeof(RefineState));
     memset(hs, 0, sizeof(RefineState));
@@ -52,11 +55,10 @@ int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const
     hs->p[6] = k_in;
     hs->termination = -1;
     hs->radius = kInitialRadius;
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(B.state, hs, sizeof(RefineState), hipMemcpyHostToDevice, c->stream));
-    RSDSFM_HIP_CHECK(c, hipMemsetAsync(B.bad_index, 0, sizeof(int), c->stream));
+    *h_bad = 0;
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(B.state, hs, sizeof(RefineState) + sizeof(int), hipMemcpyHostToDevice, c->stream));
     rc = refine_init_launch(c, B, np);
     if (rc != RSDSFM_OK) return rc;
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_bad, B.bad_index, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     // LM iterations are enqueued in chunks; kernels of a finished solve return immediately
     const int chunk = 5;
     for (int launched = 0;;) {
@@ -65,15 +67,16 @@ int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const
             if (rc != RSDSFM_OK) return rc;
         }
         launched += chunk;
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(hs, B.state, sizeof(RefineState), hipMemcpyDeviceToHost, c->stream));
+        // the output pass is enqueued before the host knows whether the solve has finished (the common case: <= 5 iterations),
+        // which saves a host round trip with an idle GPU; if iterations remain it simply runs again after the next chunk
+        rc = refine_finish_launch(c, B, d_inl_out);
+        if (rc != RSDSFM_OK) return rc;
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(hs, B.state, sizeof(RefineState) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
         RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
         if (*h_bad) return fail(c, RSDSFM_ERR_INVALID, "flow index out of range (flow has fewer columns than inliers / bad inlier_idx)");
         if (hs->termination >= 0) break;
         if (launched > 4 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
     }
-    rc = refine_finish_launch(c, B, d_inl_out);
-    if (rc != RSDSFM_OK) return rc;
-    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     for (int i = 0; i < 3; ++i) {
         v_out[i] = hs->p[i];
         w_out[i] = hs->p[3 + i];

@@ -78,16 +78,14 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
         d_final = d_inl_ref;
     }
     int flipped = 0;
-    rc = rsdsfm_depth_map_dev(ctx, d_final, ro.num_inliers, v, fx, fy, cx, cy, rows, cols, d_depth_map, nullptr, d_ys, &flipped);
+    // depth map and, behind it on the stream, the pose table of the (possibly sign-flipped) final motion: one synchronisation
+    rc = depth_map_device(c, d_final, ro.num_inliers, v, fx, fy, cx, cy, rows, cols, d_depth_map, nullptr, d_ys, &flipped, w, k, gamma,
+                          d_R_rows9, d_t_rows3);
     if (rc != RSDSFM_OK) return rc;
     res->flipped = flipped;
     memcpy(res->v, v, sizeof(v));
     memcpy(res->w, w, sizeof(w));
     res->k = k;
-    if (d_R_rows9 && d_t_rows3) {
-        rc = rsdsfm_pose_table_dev(ctx, v, w, k, gamma, rows, d_R_rows9, d_t_rows3);
-        if (rc != RSDSFM_OK) return rc;
-    }
     res->d_inliers = d_final;
     res->d_inlier_idx = d_idx;
     res->d_scanline = d_ys;

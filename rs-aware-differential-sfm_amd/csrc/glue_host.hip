@@ -88,7 +88,18 @@ int rsdsfm_flatten(rsdsfm_ctx* ctx, const double* img, int32_t rows, int32_t col
 int rsdsfm_depth_map_dev(rsdsfm_ctx* ctx, double* d_inl, int64_t m, double v_inout[3], double fx, double fy, double cx, double cy,
                          int32_t rows, int32_t cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, int* flipped) {
     if (!ctx) return RSDSFM_ERR_INVALID;
-    Ctx* c = &ctx->c;
+    return depth_map_device(&ctx->c, d_inl, m, v_inout, fx, fy, cx, cy, rows, cols, d_depth_map, d_xs, d_ys, flipped, nullptr, 0.0, 0.0,
+                            nullptr, nullptr);
+}
+
+}  // extern "C"
+
+namespace rsdsfm {
+// w_or_null != null: RsFrame::setRelativePose's table for (v', w, k) is enqueued behind the depth map, reading the possibly
+// sign-flipped v' from the stage's device header, and the ONE synchronisation at the end covers both (the frame solve's tail)
+int depth_map_device(Ctx* c, double* d_inl, int64_t m, double v_inout[3], double fx, double fy, double cx, double cy, int32_t rows,
+                     int32_t cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, int* flipped, const double* w_or_null, double k,
+                     double gamma, double* d_R_rows9, double* d_t_rows3) {
     if (m < 0 || rows < 0 || cols < 0 || !v_inout) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     const size_t npix = (size_t)rows * (size_t)cols;
     if ((m > 0 && !d_inl) || (npix > 0 && !d_depth_map)) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
@@ -102,6 +113,13 @@ int rsdsfm_depth_map_dev(rsdsfm_ctx* ctx, double* d_inl, int64_t m, double v_ino
     double* d_partials = ws.take<double>(1024);
     rc = depth_map_launch(c, d_inl, m, v_inout, fx, fy, cx, cy, rows, cols, d_depth_map, d_xs, d_ys, d_header, d_owner, d_partials);
     if (rc != RSDSFM_OK) return rc;
+    if (w_or_null && d_R_rows9 && d_t_rows3) {
+        Pose pose;
+        for (int i = 0; i < 3; ++i) pose.v[i] = v_inout[i], pose.w[i] = w_or_null[i];
+        pose.k = k;
+        rc = pose_table_launch(c, pose, gamma, rows, d_R_rows9, d_t_rows3, d_header + 1);
+        if (rc != RSDSFM_OK) return rc;
+    }
     double* h_header = static_cast<double*>(c->h_pinned);
     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_header, d_header, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
@@ -111,6 +129,9 @@ int rsdsfm_depth_map_dev(rsdsfm_ctx* ctx, double* d_inl, int64_t m, double v_ino
     v_inout[2] = h_header[3];
     return RSDSFM_OK;
 }
+}  // namespace rsdsfm
+
+extern "C" {
 
 int rsdsfm_depth_map(rsdsfm_ctx* ctx, double* inl, int64_t m, double v_inout[3], double fx, double fy, double cx, double cy,
                      int32_t rows, int32_t cols, double* depth_map, int32_t* xs, int32_t* ys, int* flipped) {

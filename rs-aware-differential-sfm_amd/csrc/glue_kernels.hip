@@ -29,10 +29,13 @@ __global__ __launch_bounds__(256) void alpha_k_kernel(const double2* __restrict_
 }
 
 // one lane per scanline: R_i = I + beta_1(i) skew(w), t_i = beta_1(i) v  (scanline 0 = identity)
+// v_dev (optional): the translation is taken from device memory (the {flipped, v'} header the depth-map stage leaves behind)
+// instead of `pose.v`, so that the table can be enqueued behind that stage without a host round trip
 __global__ __launch_bounds__(256) void pose_table_kernel(Pose pose, double gamma, int rows, double* __restrict__ R,
-                                                         double* __restrict__ t) {
+                                                         double* __restrict__ t, const double* __restrict__ v_dev) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows) return;
+    if (v_dev) pose.v[0] = v_dev[0], pose.v[1] = v_dev[1], pose.v[2] = v_dev[2];
     double beta_1 = 0.0;
     if (i > 0)
         beta_1 = (gamma * i / rows + 0.5 * pose.k * (gamma * gamma * i * i) / ((double)rows * rows)) * (2.0 / (2.0 + pose.k));
@@ -72,9 +75,9 @@ int alpha_k_launch(Ctx* c, const double* q_px, const double* flow_px, int64_t n,
     return RSDSFM_OK;
 }
 
-int pose_table_launch(Ctx* c, const Pose& pose, double gamma, int rows, double* R, double* t) {
+int pose_table_launch(Ctx* c, const Pose& pose, double gamma, int rows, double* R, double* t, const double* v_dev) {
     if (rows <= 0) return RSDSFM_OK;
-    hipLaunchKernelGGL(pose_table_kernel, dim3((rows + 255) / 256), dim3(256), 0, c->stream, pose, gamma, rows, R, t);
+    hipLaunchKernelGGL(pose_table_kernel, dim3((rows + 255) / 256), dim3(256), 0, c->stream, pose, gamma, rows, R, t, v_dev);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -3,7 +3,6 @@
 #include <string.h>
 
 #include <algorithm>
-#include <unordered_map>
 #include <vector>
 
 #include "rsdsfm_internal.hpp"
@@ -23,11 +22,27 @@ inline uint64_t splitmix64(uint64_t& state) {
 // trial (swap the drawn slot with the last live slot).  rand() is replaced by splitmix64(seed) (quirk Q1: the
 // reference reseeds with time(NULL) inside the loop and is not reproducible).  The permutation is kept sparse:
 // only 9 T slots ever differ from the identity.
+// The permutation the reference shuffles in place (an index vector of n entries) is kept sparse: only touched positions are
+// stored, in a flat open-addressing table (at most 18 T entries; a node-based map cost ~40 us per solve on the host, in the
+// middle of the frame pipeline with the GPU idle).
 void sample_indices(int64_t n, int T, uint64_t seed, std::vector<int32_t>& out) {
-    std::unordered_map<int64_t, int32_t> perm;
+    size_t cap = 64;
+    while (cap < (size_t)T * 18 * 4) cap <<= 1;
+    std::vector<int64_t> keys(cap, -1);
+    std::vector<int32_t> vals(cap);
+    auto slot = [&](int64_t i) -> size_t {
+        size_t h = (size_t)(((uint64_t)i * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
+        while (keys[h] != -1 && keys[h] != i) h = (h + 1) & (cap - 1);
+        return h;
+    };
     auto get = [&](int64_t i) -> int32_t {
-        auto it = perm.find(i);
-        return it == perm.end() ? (int32_t)i : it->second;
+        const size_t h = slot(i);
+        return keys[h] == i ? vals[h] : (int32_t)i;
+    };
+    auto put = [&](int64_t i, int32_t v) {
+        const size_t h = slot(i);
+        keys[h] = i;
+        vals[h] = v;
     };
     out.resize((size_t)T * 9);
     uint64_t st = seed;
@@ -36,8 +51,8 @@ void sample_indices(int64_t n, int T, uint64_t seed, std::vector<int32_t>& out) 
         for (int j = 0; j < 9; ++j) {
             const int64_t r = (int64_t)(splitmix64(st) % (uint64_t)n_temp);
             const int32_t a = get(n_temp - 1), b = get(r);
-            perm[n_temp - 1] = b;
-            perm[r] = a;
+            put(n_temp - 1, b);
+            put(r, a);
             out[(size_t)t * 9 + j] = b;
             n_temp--;
         }
@@ -109,6 +124,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     LmState* h_states = reinterpret_cast<LmState*>(h_hyp + (size_t)8 * Tn);
 
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
+    bool final_done = false;
     if (T > 0) {
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_samples, samples.data(), sizeof(int32_t) * (size_t)T * 9, hipMemcpyHostToDevice, c->stream));
         rc = minimal9_launch(c, d_q, d_u, d_a, d_ak, d_samples, T, use_alpha_k, k_sign_mode, d_hyp);
@@ -123,11 +139,23 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
                     rc = ransac_lm_round_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, d_partials, d_flags,
                                                 d_scored + b0, d_tcount + b0, d_terr + b0, round, tol);
                     if (rc != RSDSFM_OK) return rc;
+                    if (round == 0 && B == T) {
+                        // one batch, and on typical data every hypothesis is decided and scored by round 0: the final stage
+                        // (best trial, its rho + mask, compaction) is enqueued BEFORE the host reads the flags, which saves a
+                        // host round trip with an idle GPU; if the flags say otherwise its output is simply recomputed below
+                        rc = ransac_final_launch(c, d_q, d_u, d_a, d_ak, n, d_best, d_states, depth_mode, tol, d_rho, d_mask, d_bcounts,
+                                                 d_boffs, out->inlier_idx, out->inliers, out->alpha, out->alpha_k, d_tcount, d_terr, T, d_hyp);
+                        if (rc != RSDSFM_OK) return rc;
+                        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, c->stream));
+                        final_done = true;
+                    }
                     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_running, d_flags, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
                     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
                     if (h_running[0] == 0) break;
+                    final_done = false;  // more LM rounds: the speculated final stage saw incomplete trials
                 }
                 need_score = h_running[1] > 0;  // hypotheses whose final iterate is not the fused one-step state
+                if (need_score) final_done = false;
             }
             if (need_score) {
                 rc = ransac_score_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, depth_mode, tol,
@@ -138,10 +166,12 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
         }
     }
     // best trial (picked in the prologue of ransac_final_kernel), its dense rho + mask, order-preserving compaction
-    rc = ransac_final_launch(c, d_q, d_u, d_a, d_ak, n, d_best, d_states, depth_mode, tol, d_rho, d_mask, d_bcounts, d_boffs,
-                             out->inlier_idx, out->inliers, out->alpha, out->alpha_k, d_tcount, d_terr, T, d_hyp);
-    if (rc != RSDSFM_OK) return rc;
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, c->stream));
+    if (!final_done) {
+        rc = ransac_final_launch(c, d_q, d_u, d_a, d_ak, n, d_best, d_states, depth_mode, tol, d_rho, d_mask, d_bcounts, d_boffs,
+                                 out->inlier_idx, out->inliers, out->alpha, out->alpha_k, d_tcount, d_terr, T, d_hyp);
+        if (rc != RSDSFM_OK) return rc;
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, c->stream));
+    }
     // per-trial diagnostics are copied back only when the caller asked for them (the frame solve does not)
     if (T > 0 && out->trial_count) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_tcount, d_tcount, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
     if (T > 0 && out->trial_err) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_terr, d_terr, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));

@@ -165,7 +165,11 @@ namespace rsdsfm {
 // glue_kernels.hip
 int alpha_launch(Ctx* c, const double* flow_px, int64_t n, double h, double gamma, double* alpha);
 int alpha_k_launch(Ctx* c, const double* q_px, const double* flow_px, int64_t n, double h, double gamma, double* alpha_k);
-int pose_table_launch(Ctx* c, const Pose& pose, double gamma, int rows, double* R, double* t);
+// depth map stage (+ optionally the per-scanline pose table behind it, one synchronisation for both)
+int depth_map_device(Ctx* c, double* d_inl, int64_t m, double v_inout[3], double fx, double fy, double cx, double cy, int32_t rows, int32_t cols,
+                     double* d_depth_map, int32_t* d_xs, int32_t* d_ys, int* flipped, const double* w_or_null, double k, double gamma,
+                     double* d_R_rows9, double* d_t_rows3);
+int pose_table_launch(Ctx* c, const Pose& pose, double gamma, int rows, double* R, double* t, const double* v_dev = nullptr);
 int64_t flatten_cells(int rows, int cols);
 int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, int col0, double fx, double fy, double cx, double cy,
                    double gamma, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* d_counts,

@@ -143,8 +143,10 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
                         // one batch, and on typical data every hypothesis is decided and scored by round 0: the final stage
                         // (best trial, its rho + mask, compaction) is enqueued BEFORE the host reads the flags, which saves a
                         // host round trip with an idle GPU; if the flags say otherwise its output is simply recomputed below
+                        rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best);
+                        if (rc != RSDSFM_OK) return rc;
                         rc = ransac_final_launch(c, d_q, d_u, d_a, d_ak, n, d_best, d_states, depth_mode, tol, d_rho, d_mask, d_bcounts,
-                                                 d_boffs, out->inlier_idx, out->inliers, out->alpha, out->alpha_k, d_tcount, d_terr, T, d_hyp);
+                                                 d_boffs, out->inlier_idx, out->inliers, out->alpha, out->alpha_k);
                         if (rc != RSDSFM_OK) return rc;
                         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, c->stream));
                         final_done = true;
@@ -165,10 +167,12 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
             }
         }
     }
-    // best trial (picked in the prologue of ransac_final_kernel), its dense rho + mask, order-preserving compaction
+    // best trial, its dense rho + mask, order-preserving compaction
     if (!final_done) {
+        rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best);
+        if (rc != RSDSFM_OK) return rc;
         rc = ransac_final_launch(c, d_q, d_u, d_a, d_ak, n, d_best, d_states, depth_mode, tol, d_rho, d_mask, d_bcounts, d_boffs,
-                                 out->inlier_idx, out->inliers, out->alpha, out->alpha_k, d_tcount, d_terr, T, d_hyp);
+                                 out->inlier_idx, out->inliers, out->alpha, out->alpha_k);
         if (rc != RSDSFM_OK) return rc;
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, c->stream));
     }

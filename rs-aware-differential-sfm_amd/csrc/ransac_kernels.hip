@@ -493,50 +493,21 @@ __global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restric
 // best trial: dense rho + mask, then order-preserving compaction
 // ---------------------------------------------------------------------------------------------------
 // Block b owns the contiguous pixel range [b*chunk, (b+1)*chunk), chunk a multiple of kRB.
-// PICK: the best-trial rule runs in the prologue of EVERY workgroup (T <= a few hundred values: redundant, but it removes the
-// single-wave pick launch in front of this kernel); workgroup 0 records the result.  !PICK: `best` was filled by
-// ransac_pick_kernel (column-tiled solve, where the pick follows a cross-rank merge).
-template <bool PICK>
 __global__ __launch_bounds__(kRB) void ransac_final_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
                                                           const double* __restrict__ alpha,
                                                           const double* __restrict__ alpha_k, int64_t n, int64_t chunk,
-                                                          RansacBest* best, const double* __restrict__ trial_count,
-                                                          const double* __restrict__ trial_err, int T, const double* __restrict__ hyp,
+                                                          const RansacBest* __restrict__ best,
                                                           const LmState* __restrict__ states, int depth_mode, double tol,
                                                           double* __restrict__ rho_out, uint8_t* __restrict__ mask_out,
                                                           int64_t* __restrict__ block_counts) {
     __shared__ LmPlanLds plan;
     __shared__ int s_cnt[kRB / 64];
-    __shared__ int s_bt;
-    __shared__ double s_hyp[8];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (PICK) {
-        if (wv == 0) {
-            double best_count, best_err;
-            int bi;
-            pick_best_trial(trial_count, trial_err, T, lane, bi, best_count, best_err);
-            const double h = (lane < 8 && bi >= 0) ? hyp[(int64_t)bi * 8 + lane] : 0.0;
-            if (lane < 8) s_hyp[lane] = h;
-            if (lane == 0) s_bt = bi;
-            if (blockIdx.x == 0) {
-                if (lane < 8) best->hyp[lane] = h;
-                if (lane == 0) {
-                    best->best_trial = bi;
-                    best->num_inliers = bi >= 0 ? (int64_t)best_count : 0;
-                    best->inlier_error = best_err;
-                }
-            }
-        }
-    } else {
-        if (tid < 8) s_hyp[tid] = best->hyp[tid];
-        if (tid == 0) s_bt = best->best_trial;
-    }
-    __syncthreads();
-    const int bt = s_bt;
+    const int bt = best->best_trial;
     Pose pose;
-    pose.w[0] = s_hyp[0], pose.w[1] = s_hyp[1], pose.w[2] = s_hyp[2];
-    pose.v[0] = s_hyp[3], pose.v[1] = s_hyp[4], pose.v[2] = s_hyp[5];
-    pose.k = s_hyp[6];
+    pose.w[0] = best->hyp[0], pose.w[1] = best->hyp[1], pose.w[2] = best->hyp[2];
+    pose.v[0] = best->hyp[3], pose.v[1] = best->hyp[4], pose.v[2] = best->hyp[5];
+    pose.k = best->hyp[6];
     if (depth_mode == RSDSFM_DEPTH_CERES_LM && bt >= 0) {
         if (tid == 0) {
             plan.n_hist = states[bt].n_hist;
@@ -793,8 +764,7 @@ int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_er
 int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         RansacBest* best, const LmState* states, int depth_mode, double tol, double* rho, uint8_t* mask,
                         int64_t* block_counts, int64_t* block_offsets, int64_t* inlier_idx, double* inliers,
-                        double* out_alpha, double* out_alpha_k, const double* pick_count, const double* pick_err, int pick_T,
-                        const double* pick_hyp) {
+                        double* out_alpha, double* out_alpha_k) {
     int64_t blocks = (n + kRB - 1) / kRB;
     if (blocks < 1) blocks = 1;
     const int64_t cap = 2048;
@@ -803,15 +773,9 @@ int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* 
         chunk = ((blocks + cap - 1) / cap) * kRB;
         blocks = (n + chunk - 1) / chunk;
     }
-    if (pick_count)  // best trial picked in the kernel's prologue
-        hipLaunchKernelGGL(ransac_final_kernel<true>, dim3((int)blocks), dim3(kRB), 0, c->stream, reinterpret_cast<const double2*>(q),
-                           reinterpret_cast<const double2*>(u), a, ak, n, chunk, best, pick_count, pick_err, pick_T, pick_hyp, states,
-                           depth_mode, tol, rho, mask, block_counts);
-    else
-        hipLaunchKernelGGL(ransac_final_kernel<false>, dim3((int)blocks), dim3(kRB), 0, c->stream, reinterpret_cast<const double2*>(q),
-                           reinterpret_cast<const double2*>(u), a, ak, n, chunk, best, static_cast<const double*>(nullptr),
-                           static_cast<const double*>(nullptr), 0, static_cast<const double*>(nullptr), states, depth_mode, tol, rho, mask,
-                           block_counts);
+    hipLaunchKernelGGL(ransac_final_kernel, dim3((int)blocks), dim3(kRB), 0, c->stream, reinterpret_cast<const double2*>(q),
+                       reinterpret_cast<const double2*>(u), a, ak, n, chunk, best, states, depth_mode, tol, rho, mask,
+                       block_counts);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     if (inlier_idx || inliers || out_alpha || out_alpha_k) {  // the compaction scans the workgroup counts itself
         hipLaunchKernelGGL(ransac_scatter_kernel, dim3((int)blocks), dim3(kRB), 0, c->stream, reinterpret_cast<const double2*>(q),

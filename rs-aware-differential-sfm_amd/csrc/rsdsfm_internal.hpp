@@ -203,9 +203,7 @@ int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_er
 int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         RansacBest* best, const LmState* states, int depth_mode, double tol, double* rho, uint8_t* mask,
                         int64_t* block_counts, int64_t* block_offsets, int64_t* inlier_idx, double* inliers,
-                        double* out_alpha, double* out_alpha_k,
-                        const double* pick_count = nullptr, const double* pick_err = nullptr, int pick_T = 0,
-                        const double* pick_hyp = nullptr);
+                        double* out_alpha, double* out_alpha_k);
 // row-tiled stages
 int ransac_rows_doubles();
 int ransac_lm_rows_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,

@@ -139,6 +139,7 @@ void rsdsfm_destroy(rsdsfm_ctx* ctx) {
     if (c->d_tile) (void)hipFree(c->d_tile);
     delete static_cast<RefineBuffers*>(c->tile_session);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete ctx;
 }

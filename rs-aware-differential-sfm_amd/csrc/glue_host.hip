@@ -25,12 +25,15 @@ static int flatten_device(Ctx* c, const double* d_img, int32_t rows, int32_t col
     Arena ws(c->d_ws);
     int64_t* d_counts = ws.take<int64_t>(ncells);
     int64_t* d_offsets = ws.take<int64_t>(ncells);
-    int64_t* d_total = ws.take<int64_t>(1);
-    rc = flatten_launch(c, d_img, rows, cols, col0, fx, fy, cx, cy, gamma, thr, d_q, d_u, d_alpha, d_alpha_k, d_counts, d_offsets, d_total);
-    if (rc != RSDSFM_OK) return rc;
+    // The count is final after the scan, BEFORE the scatter pass: the scan kernel stores it straight into host-mapped pinned
+    // memory and the host waits for an event recorded behind that kernel -- no copy kernel, and the host's next steps (the RANSAC
+    // sampler, the next launches) overlap the scatter pass, which subsequent work follows in stream order anyway.
     int64_t* h_total = static_cast<int64_t*>(c->h_pinned);
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_total, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
-    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (!c->ev_ready) RSDSFM_HIP_CHECK(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    rc = flatten_launch(c, d_img, rows, cols, col0, fx, fy, cx, cy, gamma, thr, d_q, d_u, d_alpha, d_alpha_k, d_counts, d_offsets, h_total,
+                        c->ev_ready);
+    if (rc != RSDSFM_OK) return rc;
+    RSDSFM_HIP_CHECK(c, hipEventSynchronize(c->ev_ready));
     *n_out = *h_total;
     return RSDSFM_OK;
 }
@@ -111,7 +114,9 @@ int depth_map_device(Ctx* c, double* d_inl, int64_t m, double v_inout[3], double
     double* d_header = ws.take<double>(4);
     long long* d_owner = ws.take<long long>(npix);
     double* d_partials = ws.take<double>(1024);
-    rc = depth_map_launch(c, d_inl, m, v_inout, fx, fy, cx, cy, rows, cols, d_depth_map, d_xs, d_ys, d_header, d_owner, d_partials);
+    double* h_header = static_cast<double*>(c->h_pinned);  // written by zsum_decide_kernel itself (host-mapped)
+    rc = depth_map_launch(c, d_inl, m, v_inout, fx, fy, cx, cy, rows, cols, d_depth_map, d_xs, d_ys, d_header, d_owner, d_partials,
+                          h_header);
     if (rc != RSDSFM_OK) return rc;
     if (w_or_null && d_R_rows9 && d_t_rows3) {
         Pose pose;
@@ -120,8 +125,6 @@ int depth_map_device(Ctx* c, double* d_inl, int64_t m, double v_inout[3], double
         rc = pose_table_launch(c, pose, gamma, rows, d_R_rows9, d_t_rows3, d_header + 1);
         if (rc != RSDSFM_OK) return rc;
     }
-    double* h_header = static_cast<double*>(c->h_pinned);
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_header, d_header, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     if (flipped) *flipped = h_header[0] != 0.0;
     v_inout[0] = h_header[1];

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(kGB) void zsum_partial_kernel(const double* __restr
 
 // header: [0] = flipped flag (as double), [1..3] = v after the flip
 __global__ __launch_bounds__(256) void zsum_decide_kernel(const double* __restrict__ partials, int nblocks, int64_t m, Pose pose_v,
-                                                         double* __restrict__ header) {
+                                                         double* __restrict__ header, double* __restrict__ header_host) {
     __shared__ double s_red[4];
     double acc = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256) acc += partials[b];
@@ -182,6 +182,10 @@ __global__ __launch_bounds__(256) void zsum_decide_kernel(const double* __restri
         header[1] = flip ? pose_v.v[0] * -1.0 : pose_v.v[0];
         header[2] = flip ? pose_v.v[1] * -1.0 : pose_v.v[1];
         header[3] = flip ? pose_v.v[2] * -1.0 : pose_v.v[2];
+        if (header_host) {  // host-mapped pinned copy: no copy kernel behind the stage, the host only synchronises
+#pragma unroll
+            for (int i = 0; i < 4; ++i) header_host[i] = header[i];
+        }
     }
 }
 
@@ -296,10 +300,11 @@ int64_t flatten_cells(int rows, int cols) {
     return ncells + (ncells + kScanSeg - 1) / kScanSeg + 1;
 }
 
-// d_total: device int64 receiving the number of kept points; d_counts / d_offsets: flatten_cells(rows, cols) int64 each
+// d_total: int64 receiving the number of kept points (device memory, or host-mapped pinned memory when the host waits on
+// `total_ready` instead of the whole stream); d_counts / d_offsets: flatten_cells(rows, cols) int64 each
 int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, int col0, double fx, double fy, double cx, double cy,
                    double gamma, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* d_counts,
-                   int64_t* d_offsets, int64_t* d_total) {
+                   int64_t* d_offsets, int64_t* d_total, hipEvent_t total_ready) {
     const int nchunks = (rows + kFT_H - 1) / kFT_H;
     const int64_t ncells = (int64_t)cols * nchunks;
     if (ncells > (int64_t)INT32_MAX) return fail(c, RSDSFM_ERR_INVALID, "image too large for the flatten scan");
@@ -314,6 +319,7 @@ int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, int col0, do
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(cell_scan_segments_kernel, dim3(1), dim3(256), 0, c->stream, d_seg, nseg, d_total);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
+    if (total_ready) RSDSFM_HIP_CHECK(c, hipEventRecord(total_ready, c->stream));  // the count is final here; the scatter pass follows
     hipLaunchKernelGGL(flatten_tile_kernel<1>, grid, dim3(kGB), 0, c->stream, img2, rows, cols, fx, fy, cx, cy, gamma, thr, col0, nchunks,
                        d_counts, d_offsets, d_seg, reinterpret_cast<double2*>(d_q), reinterpret_cast<double2*>(d_u), d_alpha, d_alpha_k);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
@@ -346,12 +352,12 @@ int zsum_row_launch(Ctx* c, const double* d_inl, int64_t m, double* d_partials, 
 // d_header: 4 doubles (flipped, v'); d_owner: rows*ncols int64
 int depth_map_slab_launch(Ctx* c, double* d_inl, int64_t m, const double* d_zsums, int nz, int64_t m_total, const double v[3],
                           double fx, double fy, double cx, double cy, int rows, int col0, int ncols, double* d_depth_map,
-                          int32_t* d_xs, int32_t* d_ys, double* d_header, long long* d_owner) {
+                          int32_t* d_xs, int32_t* d_ys, double* d_header, long long* d_owner, double* h_header) {
     const int64_t npix = (int64_t)rows * ncols;
     Pose pv;
     memset(&pv, 0, sizeof(pv));
     pv.v[0] = v[0], pv.v[1] = v[1], pv.v[2] = v[2];
-    hipLaunchKernelGGL(zsum_decide_kernel, dim3(1), dim3(256), 0, c->stream, d_zsums, nz, m_total, pv, d_header);
+    hipLaunchKernelGGL(zsum_decide_kernel, dim3(1), dim3(256), 0, c->stream, d_zsums, nz, m_total, pv, d_header, h_header);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_owner, 0xFF, sizeof(long long) * (size_t)npix, c->stream));  // -1
     if (m > 0) {
@@ -367,12 +373,12 @@ int depth_map_slab_launch(Ctx* c, double* d_inl, int64_t m, const double* d_zsum
 // d_header: 4 doubles (flipped, v'); d_owner: rows*cols int64; d_partials: >= 1024 doubles
 int depth_map_launch(Ctx* c, double* d_inl, int64_t m, const double v[3], double fx, double fy, double cx, double cy, int rows,
                      int cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, double* d_header, long long* d_owner,
-                     double* d_partials) {
+                     double* d_partials, double* h_header) {
     const int zb = zsum_blocks(m);
     hipLaunchKernelGGL(zsum_partial_kernel, dim3(zb), dim3(kGB), 0, c->stream, d_inl, m, d_partials);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return depth_map_slab_launch(c, d_inl, m, d_partials, zb, m, v, fx, fy, cx, cy, rows, 0, cols, d_depth_map, d_xs, d_ys, d_header,
-                                 d_owner);
+                                 d_owner, h_header);
 }
 
 }  // namespace rsdsfm

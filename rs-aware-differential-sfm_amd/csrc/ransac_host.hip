@@ -89,14 +89,13 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     }
     const int Tn = std::max(T, 1);
     const int batch = std::min(Tn, kRansacBatch);
-    size_t need = Arena::need(sizeof(int32_t) * Tn * 9) + Arena::need(sizeof(double) * Tn * 8) +
+    size_t need = Arena::need(sizeof(double) * Tn * 8) +
                   Arena::need(sizeof(LmState) * Tn) + Arena::need(sizeof(double) * (size_t)ransac_lm_partials_doubles(c, n, batch)) +
                   Arena::need(sizeof(int) * 2) + Arena::need(sizeof(int) * Tn) + 2 * Arena::need(sizeof(double) * Tn) + Arena::need(sizeof(RansacBest)) +
                   2 * Arena::need(sizeof(int64_t) * 2048) + Arena::need(sizeof(double) * (size_t)n) + Arena::need((size_t)n) + 4096;
     int rc = ensure_ws(c, need);
     if (rc != RSDSFM_OK) return rc;
     Arena ws(c->d_ws);
-    int32_t* d_samples = ws.take<int32_t>((size_t)Tn * 9);
     double* d_hyp = ws.take<double>((size_t)Tn * 8);
     // states, scored and flags are adjacent so that ONE memset clears them
     char* zero_begin = ws.base + ws.off;
@@ -113,7 +112,8 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     double* d_rho = out->inv_depth ? out->inv_depth : ws.take<double>((size_t)n);
     uint8_t* d_mask = out->mask ? out->mask : ws.take<uint8_t>((size_t)n);
 
-    rc = ensure_pinned(c, sizeof(RansacBest) + 2 * sizeof(int) + sizeof(double) * 2 * Tn + sizeof(double) * 8 * Tn + sizeof(LmState) * Tn + 64);
+    rc = ensure_pinned(c, sizeof(RansacBest) + 2 * sizeof(int) + sizeof(double) * 2 * Tn + sizeof(double) * 8 * Tn + sizeof(LmState) * Tn + 64 +
+                              sizeof(int32_t) * (size_t)Tn * 9);
     if (rc != RSDSFM_OK) return rc;
     char* hp = static_cast<char*>(c->h_pinned);
     RansacBest* h_best = reinterpret_cast<RansacBest*>(hp);
@@ -122,12 +122,14 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     double* h_terr = h_tcount + Tn;
     double* h_hyp = h_terr + Tn;
     LmState* h_states = reinterpret_cast<LmState*>(h_hyp + (size_t)8 * Tn);
+    // the sample table stays in host-mapped pinned memory: minimal9_kernel reads its 9 indices per hypothesis from there
+    int32_t* h_samples_pinned = reinterpret_cast<int32_t*>(h_states + Tn);
 
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
     bool final_done = false;
     if (T > 0) {
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_samples, samples.data(), sizeof(int32_t) * (size_t)T * 9, hipMemcpyHostToDevice, c->stream));
-        rc = minimal9_launch(c, d_q, d_u, d_a, d_ak, d_samples, T, use_alpha_k, k_sign_mode, d_hyp);
+        memcpy(h_samples_pinned, samples.data(), sizeof(int32_t) * (size_t)T * 9);
+        rc = minimal9_launch(c, d_q, d_u, d_a, d_ak, h_samples_pinned, T, use_alpha_k, k_sign_mode, d_hyp);
         if (rc != RSDSFM_OK) return rc;
         for (int b0 = 0; b0 < T; b0 += batch) {
             const int B = std::min(batch, T - b0);
@@ -143,12 +145,11 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
                         // one batch, and on typical data every hypothesis is decided and scored by round 0: the final stage
                         // (best trial, its rho + mask, compaction) is enqueued BEFORE the host reads the flags, which saves a
                         // host round trip with an idle GPU; if the flags say otherwise its output is simply recomputed below
-                        rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best);
+                        rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, h_best);
                         if (rc != RSDSFM_OK) return rc;
                         rc = ransac_final_launch(c, d_q, d_u, d_a, d_ak, n, d_best, d_states, depth_mode, tol, d_rho, d_mask, d_bcounts,
-                                                 d_boffs, out->inlier_idx, out->inliers, out->alpha, out->alpha_k);
+                                                 d_boffs, out->inlier_idx, out->inliers, out->alpha, out->alpha_k, h_best);
                         if (rc != RSDSFM_OK) return rc;
-                        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, c->stream));
                         final_done = true;
                     }
                     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_running, d_flags, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
@@ -169,12 +170,11 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     }
     // best trial, its dense rho + mask, order-preserving compaction
     if (!final_done) {
-        rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best);
+        rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, h_best);  // h_best: host-mapped, written by the kernels
         if (rc != RSDSFM_OK) return rc;
         rc = ransac_final_launch(c, d_q, d_u, d_a, d_ak, n, d_best, d_states, depth_mode, tol, d_rho, d_mask, d_bcounts, d_boffs,
-                                 out->inlier_idx, out->inliers, out->alpha, out->alpha_k);
+                                 out->inlier_idx, out->inliers, out->alpha, out->alpha_k, h_best);
         if (rc != RSDSFM_OK) return rc;
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, c->stream));
     }
     // per-trial diagnostics are copied back only when the caller asked for them (the frame solve does not)
     if (T > 0 && out->trial_count) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_tcount, d_tcount, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));

@@ -474,18 +474,26 @@ __device__ __forceinline__ void pick_best_trial(const double* __restrict__ trial
     }
 }
 
+// best_host (optional): host-mapped pinned copy of the result, written by the kernel itself (no copy kernel behind the stage)
 __global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restrict__ trial_count, const double* __restrict__ trial_err, int T,
-                                                        const double* __restrict__ hyp, RansacBest* best) {
+                                                        const double* __restrict__ hyp, RansacBest* best, RansacBest* best_host) {
     if (blockIdx.x != 0) return;
     const int lane = threadIdx.x;
     double best_count, best_err;
     int bi;
     pick_best_trial(trial_count, trial_err, T, lane, bi, best_count, best_err);
-    if (lane < 8) best->hyp[lane] = bi >= 0 ? hyp[(int64_t)bi * 8 + lane] : 0.0;
+    const double h = (lane < 8 && bi >= 0) ? hyp[(int64_t)bi * 8 + lane] : 0.0;
+    if (lane < 8) best->hyp[lane] = h;
+    if (lane < 8 && best_host) best_host->hyp[lane] = h;
     if (lane == 0) {
         best->best_trial = bi;
         best->num_inliers = bi >= 0 ? (int64_t)best_count : 0;
         best->inlier_error = best_err;
+        if (best_host) {
+            best_host->best_trial = bi;
+            best_host->num_inliers = bi >= 0 ? (int64_t)best_count : 0;
+            best_host->inlier_error = best_err;
+        }
     }
 }
 
@@ -547,7 +555,7 @@ __global__ __launch_bounds__(kRB) void ransac_final_kernel(const double2* __rest
 
 // exclusive scan of the block counts (single workgroup; nblocks <= a few thousand)
 __global__ __launch_bounds__(256) void ransac_scan_kernel(const int64_t* __restrict__ block_counts, int nblocks,
-                                                         int64_t* __restrict__ block_offsets, RansacBest* best) {
+                                                         int64_t* __restrict__ block_offsets, RansacBest* best, RansacBest* best_host) {
     __shared__ int64_t s_part[256];
     const int tid = threadIdx.x;
     const int per = (nblocks + 255) / 256;
@@ -566,6 +574,7 @@ __global__ __launch_bounds__(256) void ransac_scan_kernel(const int64_t* __restr
             run += v;
         }
         best->num_inliers_scan = run;
+        if (best_host) best_host->num_inliers_scan = run;
     }
     __syncthreads();
     int64_t run = s_part[tid];
@@ -582,7 +591,7 @@ __global__ __launch_bounds__(kRB) void ransac_scatter_kernel(const double2* __re
                                                             const double* __restrict__ alpha_k, int64_t n, int64_t chunk,
                                                             const double* __restrict__ rho, const uint8_t* __restrict__ mask,
                                                             const int64_t* __restrict__ block_counts, RansacBest* best,
-                                                            int64_t* __restrict__ inlier_idx, double* __restrict__ inliers,
+                                                            RansacBest* best_host, int64_t* __restrict__ inlier_idx, double* __restrict__ inliers,
                                                             double* __restrict__ out_alpha, double* __restrict__ out_alpha_k) {
     __shared__ int s_wave[kRB / 64];
     __shared__ int64_t s_base;
@@ -610,7 +619,10 @@ __global__ __launch_bounds__(kRB) void ransac_scatter_kernel(const double2* __re
             int64_t p2 = 0, a2 = 0;
             for (int w2 = 0; w2 < kRB / 64; ++w2) p2 += s_pre[w2], a2 += s_all[w2];
             s_base = p2;
-            if (blockIdx.x == 0) best->num_inliers_scan = a2;
+            if (blockIdx.x == 0) {
+                best->num_inliers_scan = a2;
+                if (best_host) best_host->num_inliers_scan = a2;
+            }
         }
     }
     __syncthreads();
@@ -755,8 +767,9 @@ int ransac_score_merge_launch(Ctx* c, const double* rows_all, int nranks, int T,
 
 int ransac_rows_doubles() { return NSR; }
 
-int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best) {
-    hipLaunchKernelGGL(ransac_pick_kernel, dim3(1), dim3(64), 0, c->stream, trial_count, trial_err, T, hyp, best);
+int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best,
+                       RansacBest* best_host) {
+    hipLaunchKernelGGL(ransac_pick_kernel, dim3(1), dim3(64), 0, c->stream, trial_count, trial_err, T, hyp, best, best_host);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
@@ -764,7 +777,7 @@ int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_er
 int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         RansacBest* best, const LmState* states, int depth_mode, double tol, double* rho, uint8_t* mask,
                         int64_t* block_counts, int64_t* block_offsets, int64_t* inlier_idx, double* inliers,
-                        double* out_alpha, double* out_alpha_k) {
+                        double* out_alpha, double* out_alpha_k, RansacBest* best_host) {
     int64_t blocks = (n + kRB - 1) / kRB;
     if (blocks < 1) blocks = 1;
     const int64_t cap = 2048;
@@ -779,9 +792,9 @@ int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* 
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     if (inlier_idx || inliers || out_alpha || out_alpha_k) {  // the compaction scans the workgroup counts itself
         hipLaunchKernelGGL(ransac_scatter_kernel, dim3((int)blocks), dim3(kRB), 0, c->stream, reinterpret_cast<const double2*>(q),
-                           a, ak, n, chunk, rho, mask, block_counts, best, inlier_idx, inliers, out_alpha, out_alpha_k);
+                           a, ak, n, chunk, rho, mask, block_counts, best, best_host, inlier_idx, inliers, out_alpha, out_alpha_k);
     } else {  // no compacted outputs requested: only the total is needed
-        hipLaunchKernelGGL(ransac_scan_kernel, dim3(1), dim3(256), 0, c->stream, block_counts, (int)blocks, block_offsets, best);
+        hipLaunchKernelGGL(ransac_scan_kernel, dim3(1), dim3(256), 0, c->stream, block_counts, (int)blocks, block_offsets, best, best_host);
     }
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;

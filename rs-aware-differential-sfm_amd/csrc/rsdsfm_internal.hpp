@@ -100,6 +100,7 @@ struct Ctx {
     void* d_frame = nullptr;   // frame buffers of rsdsfm_solve_frame_dev
     size_t frame_bytes = 0;
     void* h_pinned = nullptr;  // small pinned host buffer for result headers
+    hipEvent_t ev_ready = nullptr;  // "value ready" event for stages whose host read does not have to wait for the whole stream
     size_t pinned_bytes = 0;
     int num_cus = 256;
     int depth_variant = 0;  // 0 = register-staged depth_lm_kernel, 1 = LDS-DMA depth_lm_dma_kernel, 2 = launch 0 with the decision fused into its tail, 3 = separate decide kernel + follow-up launch (the pre-fusion fast path)
@@ -173,14 +174,14 @@ int pose_table_launch(Ctx* c, const Pose& pose, double gamma, int rows, double* 
 int64_t flatten_cells(int rows, int cols);
 int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, int col0, double fx, double fy, double cx, double cy,
                    double gamma, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* d_counts,
-                   int64_t* d_offsets, int64_t* d_total);
+                   int64_t* d_offsets, int64_t* d_total, hipEvent_t total_ready = nullptr);
 int depth_map_launch(Ctx* c, double* d_inl, int64_t m, const double v[3], double fx, double fy, double cx, double cy, int rows,
                      int cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, double* d_header, long long* d_owner,
-                     double* d_partials);
+                     double* d_partials, double* h_header = nullptr);
 int zsum_row_launch(Ctx* c, const double* d_inl, int64_t m, double* d_partials, double* d_out);
 int depth_map_slab_launch(Ctx* c, double* d_inl, int64_t m, const double* d_zsums, int nz, int64_t m_total, const double v[3],
                           double fx, double fy, double cx, double cy, int rows, int col0, int ncols, double* d_depth_map,
-                          int32_t* d_xs, int32_t* d_ys, double* d_header, long long* d_owner);
+                          int32_t* d_xs, int32_t* d_ys, double* d_header, long long* d_owner, double* h_header = nullptr);
 }  // namespace rsdsfm
 
 namespace rsdsfm {
@@ -199,11 +200,12 @@ int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const doubl
 int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
                         double* partials, double* trial_count, double* trial_err);
-int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best);
+int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best,
+                       RansacBest* best_host = nullptr);
 int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         RansacBest* best, const LmState* states, int depth_mode, double tol, double* rho, uint8_t* mask,
                         int64_t* block_counts, int64_t* block_offsets, int64_t* inlier_idx, double* inliers,
-                        double* out_alpha, double* out_alpha_k);
+                        double* out_alpha, double* out_alpha_k, RansacBest* best_host = nullptr);
 // row-tiled stages
 int ransac_rows_doubles();
 int ransac_lm_rows_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,

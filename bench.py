@@ -2,7 +2,8 @@
 """bench.py -- headline benchmark: Mpixels/s of the RS depth(+pose) solve on a synthetic 1280x720 pair.
 
 Contract: python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on rank 0.
-  step      = one pass of the hot path over one synthetic frame pair resident in HBM.
+  step      = one pass of the hot path over one batch of synthetic input resident in HBM: for the depth workloads one chunk of
+              --pairs-per-step (default 64) consecutive frame pairs of the sequence, for the other workloads one solve / frame.
   workload  = depth (default): BASELINE.json configs[1] -- 1280x720, dense per-pixel depth solve (Ceres-LM emulation,
               the reference-matching mode), pose fixed.  The same line also carries `full_solve`: the whole solve
               (flatten + RANSAC(50) + refinement + depth map + pose table) timed on a 1280x720 DeepFlow-like pair.
@@ -21,7 +22,7 @@ Contract: python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on
               (sequence-throughput mode, BASELINE configs[4]), no data-path collective -> scaling "weak".
   --batch B, --streams S = sequence-throughput mode PER GPU (defaults 4 and 2): B independent pairs per launch of the batched
               depth fast path (rsdsfm_estimate_inverse_depths_batch_dev: one solver context per pair, grid y = pair) on each
-              of S HIP streams; the pairs share nothing.  `value` is the throughput of that loop (K steps = K pairs),
+              of S HIP streams; the pairs share nothing.  `value` is the throughput of that loop (K steps = K x 64 pairs),
               `config.one_pair_at_a_time` the same work with one context; `roofline` is the batched streaming kernel measured
               with the other stream idle, `roofline_job` the algorithmic bytes over the job's time per pair.
   also in the line: `full_solve` / `full_solve_batched` (whole solves, one at a time / 4 in flight), `cpu_baseline` (oracle, 1
@@ -127,18 +128,19 @@ def cpu_baseline_full(rsdsfm, trials, tol, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default per workload: 10000 for the depth workloads)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default per workload: 160 chunks of 64 pairs for the depth workloads)")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify", "true_flow", "metrics"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--nbuf", type=int, default=7, help="rotating HBM buffer sets (7 x 59 MB > 256 MiB L3)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU feeding independent batches (sequence-throughput mode, BASELINE configs[4])")
+    ap.add_argument("--pairs-per-step", type=int, default=64, help="depth workloads: one step = one chunk of this many consecutive frame pairs of the sequence (default 64)")
     ap.add_argument("--batch", type=int, default=4, help="independent frame pairs per launch of the batched depth fast path (1..8, one solver context each)")
     ap.add_argument("--depth-variant", type=int, default=None, help="rsdsfm_set_depth_variant: 0 register-staged, 1 LDS-DMA, 2 decision fused into launch 0")
     ap.add_argument("--trials", type=int, default=50, help="RANSAC trials of the full solve (report section 5.4 used 50)")
     ap.add_argument("--tol", type=float, default=0.05, help="RANSAC tolerance (reference main.cc:310)")
     args = ap.parse_args()
-    dsteps = {"depth": 10000, "depth_closed_form": 10000, "full": 500, "tiled": 2000, "tiled_full": 100, "rectify": 2000, "true_flow": 500, "metrics": 2000}
+    dsteps = {"depth": 160, "depth_closed_form": 160, "full": 500, "tiled": 2000, "tiled_full": 100, "rectify": 2000, "true_flow": 500, "metrics": 2000}
     if args.steps is None:
         args.steps = dsteps[args.workload]
     if args.warmup is None:
@@ -256,13 +258,15 @@ def main():
                 groups.append((call, svs, sets))
         order = [groups[(i % S) * G + (i // S) % G] for i in range(S * G)]  # alternate the streams
         torch.cuda.synchronize()
-        nfull, rem = divmod(args.steps, B)
+        P = max(1, args.pairs_per_step)
+        npairs, nwarm = args.steps * P, args.warmup * P  # one step = one chunk of P consecutive frame pairs of the sequence
+        nfull, rem = divmod(npairs, B)
         rem_call = None
-        if rem:  # exactly `steps` pairs are timed: the last call is a smaller batch over the first contexts of one group
+        if rem:  # exactly `steps` x P pairs are timed: the last call is a smaller batch over the first contexts of one group
             g = order[nfull % len(order)]
             rem_call = rsdsfm.prepared_depth_batch(g[1][:rem], [problem(x) for x in g[2][:rem]])
 
-        def run_pairs(i):  # step i = pair i; a batched call every B steps
+        def run_pairs(i):  # pair i of the timed sequence; a batched call every B pairs
             if i % B == 0:
                 j = i // B
                 if j < nfull:
@@ -270,9 +274,9 @@ def main():
                 elif rem_call is not None:
                     rem_call()
 
-        for i in range(0, max(args.warmup, len(order) * B), B):
+        for i in range(0, max(nwarm, len(order) * B), B):
             order[(i // B) % len(order)][0]()
-        el = timed(run_pairs, args.steps, 0)
+        el = timed(run_pairs, npairs, 0)
         # correctness of what was timed: on the contexts of the last batches the LM state machine finished inside the fixed
         # launch sequence and the pair matches the analytic truth
         extra, summary, max_rel = 0, None, 0.0
@@ -287,7 +291,7 @@ def main():
         # the same work with ONE pair at a time (single context, single stream), for reference
         own = [grp for grp in groups[:G]]
         single_calls = [grp[1][0].prepared_depth_step(*ptrs(grp[2][0]), mode=mode) for grp in own]
-        n1 = max(20, args.steps // 8)
+        n1 = max(20, npairs // 8)
         el1 = timed(lambda i: single_calls[i % len(single_calls)](), n1, 5)
 
         # dominant-kernel duration: HIP events on stream 0 around bursts of BURST back-to-back launches of the streaming
@@ -314,14 +318,14 @@ def main():
         if rank == 0:
             alg_bytes = ALG_BYTES_PER_PIXEL_DEPTH * n * B
             achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-            job = ALG_BYTES_PER_PIXEL_DEPTH * n / (el / args.steps) / 1e9
+            job = ALG_BYTES_PER_PIXEL_DEPTH * n / (el / npairs) / 1e9
             line.update({
-                "value": rows * cols * world * args.steps / el / 1e6, "ms_per_step": el / args.steps * 1e3, "scaling": "weak",
+                "value": rows * cols * world * npairs / el / 1e6, "ms_per_step": el / args.steps * 1e3, "scaling": "weak",
                 "config": {"workload": "BASELINE configs[1]: synthetic 1280x720 pairs, per-pixel depth solve only (%s), pose fixed; "
                                        "%d independent pairs per launch on each of %d HIP streams per GPU (one solver context per pair), %d "
                                        "rotating HBM buffer sets" % ("Ceres-1.14 LM emulation" if mode == 1 else "closed-form GN", B, S, B * S * G),
-                           "pairs_per_launch": B, "streams": S,
-                           "one_pair_at_a_time": {"value": rows * cols * world * n1 / el1 / 1e6, "ms_per_step": el1 / n1 * 1e3},
+                           "pairs_per_step": P, "pairs_timed": npairs, "ms_per_pair": el / npairs * 1e3, "pairs_per_launch": B, "streams": S,
+                           "one_pair_at_a_time": {"value": rows * cols * world * n1 / el1 / 1e6, "ms_per_pair": el1 / n1 * 1e3},
                            "rows": rows, "cols": cols, "pixels": n, "depth_mode": int(mode),
                            "launches_per_step": (2.0 / B) if mode == 1 else 1, "extra_lm_launches": int(extra), "lm_summary": summary,
                            "max_rel_err_vs_truth": max_rel,

@@ -13,8 +13,8 @@ head = """# rocprofv3 --kernel-trace --stats, MI355X, round 1 FINAL code (collec
 # The other kernels in sections (1) and (2) belong to bench.py's side measurements (whole solves: full_solve / full_solve_batched).
 # Earlier summaries: profiles/r01_history/.
 """
-sections = [("depth_1stream", "## (1) ROOFLINE REFERENCE -- batches on ONE stream:\n## cd /tmp && rocprofv3 --kernel-trace --stats -d ... -- python3 bench.py --streams 1 --steps 2000 --warmup 80 --no-cpu-baseline\n"),
-            ("depth", "\n## (2) DEFAULT MODE (4 pairs per launch on each of 2 streams):\n## cd /tmp && rocprofv3 --kernel-trace --stats -d ... -- python3 bench.py --steps 4000 --warmup 160 --no-cpu-baseline\n"),
+sections = [("depth_1stream", "## (1) ROOFLINE REFERENCE -- batches on ONE stream:\n## cd /tmp && rocprofv3 --kernel-trace --stats -d ... -- python3 bench.py --streams 1 --steps 32 --warmup 2 --no-cpu-baseline\n"),
+            ("depth", "\n## (2) DEFAULT MODE (4 pairs per launch on each of 2 streams):\n## cd /tmp && rocprofv3 --kernel-trace --stats -d ... -- python3 bench.py --steps 64 --warmup 3 --no-cpu-baseline\n"),
             ("full", "\n## (3) WHOLE SOLVE: cd /tmp && rocprofv3 --kernel-trace --stats -d ... -- python3 bench.py --workload full --steps 100 --no-cpu-baseline\n")]
 with open(P + "/r01_kernel_trace_final.txt", "w") as out:
     out.write(head)

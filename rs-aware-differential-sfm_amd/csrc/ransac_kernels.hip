@@ -94,7 +94,7 @@ __device__ __forceinline__ void load_tile(Tile& t, const double2* __restrict__ q
 // per-hypothesis speculative LM sums
 // ---------------------------------------------------------------------------------------------------
 // round 0: every hypothesis starts from the built-in plan; round r > 0: only hypotheses whose state machine is
-// still running (status 0) and expects launch r take part.  partials: [gridDim.x][T][NS].
+// still running (status 0) and expects launch r take part.  partials: [T][gridDim.x][NSR] (hypothesis-major).
 template <bool R0>
 __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
                                                        const double* __restrict__ alpha,
@@ -242,19 +242,24 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
         __syncthreads();
     }
     __syncthreads();
-    double* out = partials + (int64_t)blockIdx.x * T * NSR;
-    for (int i = t_begin * NSR + tid; i < t_end * NSR; i += kRB) out[i] = s_acc[i];
+    // hypothesis-major rows [T][gridDim.x][NSR]: the per-hypothesis reduction that follows reads one contiguous block
+    for (int i = t_begin * NSR + tid; i < t_end * NSR; i += kRB) {
+        const int t = i / NSR, sl = i - t * NSR;
+        partials[((int64_t)t * gridDim.x + blockIdx.x) * NSR + sl] = s_acc[i];
+    }
 }
 
-// fixed-order reduction of partials[nblocks][T][NSR] of hypothesis t into s_sums[NSR] (256 threads)
-__device__ __forceinline__ void reduce_hyp_sums(const double* __restrict__ partials, int nblocks, int T, int t,
+// fixed-order reduction of the rows of hypothesis t into s_sums[NSR] (256 threads).  hyp_major: rows are
+// partials[T][nblocks][NSR] (what ransac_lm_kernel writes: contiguous per hypothesis); otherwise [nblocks][T][NSR] (the gathered
+// per-rank rows of the column-tiled solve, ranks in place of workgroups)
+__device__ __forceinline__ void reduce_hyp_sums(const double* __restrict__ partials, int nblocks, int T, int t, bool hyp_major,
                                                 double (*s_red)[NSR], double* s_sums) {
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double fin[NSR];
 #pragma unroll
     for (int s = 0; s < NSR; ++s) fin[s] = 0.0;
     for (int b = tid; b < nblocks; b += 256) {
-        const double* row = partials + ((int64_t)b * T + t) * NSR;
+        const double* row = partials + (hyp_major ? ((int64_t)t * nblocks + b) : ((int64_t)b * T + t)) * NSR;
 #pragma unroll
         for (int s = 0; s < NSR; ++s) fin[s] = is_max_slot(s) ? fmax(fin[s], row[s]) : fin[s] + row[s];
     }
@@ -285,14 +290,14 @@ __global__ __launch_bounds__(256) void ransac_lm_rows_kernel(const double* __res
         if (threadIdx.x < NSR) rows[(int64_t)t * NSR + threadIdx.x] = 0.0;
         return;
     }
-    reduce_hyp_sums(partials, nblocks, T, t, s_red, s_sums);
+    reduce_hyp_sums(partials, nblocks, T, t, true, s_red, s_sums);
     if (threadIdx.x < NSR) rows[(int64_t)t * NSR + threadIdx.x] = s_sums[threadIdx.x];
 }
 
 // one workgroup per hypothesis
 // flags[0]: hypotheses still running after this round; flags[1]: hypotheses that finished WITHOUT a fused score
 // (accepted-step count != 1) and need the separate score pass.  scored[t] = 1 when trial_count/err were filled here.
-__global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __restrict__ partials, int nblocks, int T,
+__global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __restrict__ partials, int nblocks, int T, int hyp_major,
                                                            LmState* states, int64_t n, int round, int* flags,
                                                            int* __restrict__ scored, double* __restrict__ trial_count,
                                                            double* __restrict__ trial_err) {
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __rest
     const int tid = threadIdx.x;
     LmState* state = states + t;
     if (round > 0 && (state->status != 0 || state->next_launch != round)) return;
-    reduce_hyp_sums(partials, nblocks, T, t, s_red, s_sums);
+    reduce_hyp_sums(partials, nblocks, T, t, hyp_major != 0, s_red, s_sums);
     if (tid == 0) {
         LmScal st = *static_cast<const LmScal*>(state);
         const int used_K = (round == 0) ? kRansacK0 : st.K;
@@ -697,7 +702,7 @@ int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const doubl
         hipLaunchKernelGGL(ransac_lm_kernel<false>, g2, dim3(kRB), sizeof(double) * T * NSR, c->stream, reinterpret_cast<const double2*>(q),
                            reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states, partials, round, tol, flags);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, states, n, round, flags, scored,
+    hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, 1, states, n, round, flags, scored,
                        trial_count, trial_err);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
@@ -738,7 +743,7 @@ int ransac_lm_rows_launch(Ctx* c, const double* q, const double* u, const double
 int ransac_decide_rows_launch(Ctx* c, const double* rows_all, int nranks, int T, LmState* states, int64_t n_total, int round,
                               int* flags, int* scored, double* trial_count, double* trial_err) {
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(flags, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, rows_all, nranks, T, states, n_total, round, flags,
+    hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, rows_all, nranks, T, 0, states, n_total, round, flags,
                        scored, trial_count, trial_err);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;

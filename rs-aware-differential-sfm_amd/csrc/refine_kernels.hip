@@ -124,27 +124,57 @@ __device__ __forceinline__ void block_reduce_store(const double (&v)[NV], int ma
     }
 }
 
-// single-workgroup fixed-order reduction of partials[nblocks][NV] into s_out[NV]
+// single-workgroup fixed-order reduction of partials[nblocks][NV] into s_out[NV].  Thread (group g, slot pair sp) adds the rows
+// g, g + G, g + 2G, ... of its two slots in order (adjacent lanes read adjacent 16-byte pieces of a row: coalesced, 16 loads in
+// flight), then thread s adds the G group sums of slot s in order.  (The first version gave every thread whole rows and reduced the NV per-thread sums with NV / 8 rounds of
+// LDS transposes: 7 us of the 10 us refine_solve_kernel, measured by returning right after the reduction.)
 template <int NV>
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int nblocks, int max_slot,
                                                 double (*s_red)[NV], double* s_out) {
-    const int tid = threadIdx.x, wv = tid >> 6;
-    double fin[NV];
+    constexpr int W = (NV % 2 == 0) ? 2 : 1;  // slots per lane: pairs as double2 when the rows are 16-byte aligned (NV even)
+    constexpr int NH = NV / W;                // lanes per row
+    constexpr int G = kFB / NH;               // row groups (9 for the 54 Schur sums of NP = 6)
+    constexpr int U = 16;                     // independent loads in flight per thread: the reduction is bound by load latency
+    __shared__ double s_grp[G][NV];
+    const int tid = threadIdx.x;
+    const int g = tid / NH, sp = tid - g * NH;
+    if (g < G) {
+        const bool mx0 = (W * sp == max_slot), mx1 = (W * sp + 1 == max_slot);
+        double a0 = 0.0, a1 = 0.0;
+        for (int b = g; b < nblocks; b += U * G) {
+            double v0[U], v1[U];
 #pragma unroll
-    for (int s = 0; s < NV; ++s) fin[s] = 0.0;
-    for (int b = tid; b < nblocks; b += kFB) {
-        const double* row = partials + (int64_t)b * NV;
+            for (int j = 0; j < U; ++j) {  // rows past the end contribute the identity (sums: + 0.0; the max slot holds absolute values)
+                const int bj = b + j * G;
+                const int64_t row = bj < nblocks ? bj : g;
+                if (W == 2) {
+                    const double2 x = reinterpret_cast<const double2*>(partials)[row * NH + sp];
+                    v0[j] = bj < nblocks ? x.x : 0.0;
+                    v1[j] = bj < nblocks ? x.y : 0.0;
+                } else {
+                    const double x = partials[row * NV + sp];
+                    v0[j] = bj < nblocks ? x : 0.0;
+                    v1[j] = 0.0;
+                }
+            }
 #pragma unroll
-        for (int s = 0; s < NV; ++s) fin[s] = (s == max_slot) ? fmax(fin[s], row[s]) : fin[s] + row[s];
+            for (int j = 0; j < U; ++j) {
+                a0 = mx0 ? fmax(a0, v0[j]) : a0 + v0[j];
+                if (W == 2) a1 = mx1 ? fmax(a1, v1[j]) : a1 + v1[j];
+            }
+        }
+        s_grp[g][W * sp] = a0;
+        if (W == 2) s_grp[g][W * sp + 1] = a1;
     }
-    wave_reduce_to_row<NV>(fin, max_slot, s_red[wv]);
     __syncthreads();
     if (tid < NV) {
-        double r = s_red[0][tid];
-        for (int w2 = 1; w2 < kFB / 64; ++w2) r = (tid == max_slot) ? fmax(r, s_red[w2][tid]) : r + s_red[w2][tid];
+        double r = s_grp[0][tid];
+#pragma unroll
+        for (int g2 = 1; g2 < G; ++g2) r = (tid == max_slot) ? fmax(r, s_grp[g2][tid]) : r + s_grp[g2][tid];
         s_out[tid] = r;
     }
     __syncthreads();
+    (void)s_red;
 }
 
 template <int NP>

@@ -104,6 +104,10 @@ int rsdsfm_create(rsdsfm_ctx** ctx, int device, void* stream_or_null);
 void rsdsfm_destroy(rsdsfm_ctx* ctx);
 const char* rsdsfm_last_error(const rsdsfm_ctx* ctx);
 const char* rsdsfm_version(void);
+/* 0: this library evaluates the per-pixel model with the REFERENCE's arithmetic (librsdsfm_hip.so: no fused multiply-add, as
+ * the reference's own x86-64 build, src/CMakeLists.txt:18); 1: the opt-in librsdsfm_hip_fused.so (explicit fmas in the
+ * residual / LM step / scoring error / scanline projection: faster, values agree to ~1e-12 relative) */
+int rsdsfm_fused_arithmetic(void);
 int rsdsfm_synchronize(rsdsfm_ctx* ctx);
 /* variant of the LM depth solve's fast path: 0 (default) = launch 0 + ONE follow-up launch that decides and applies
  * (depth_lm_decide_apply_kernel); 1 = per-wave LDS-DMA double buffering in launch 0 (global_load_lds + counted vmcnt) with

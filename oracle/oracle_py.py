@@ -10,7 +10,6 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = None
 
 TERMINATION = {0: "gradient", 1: "parameter", 2: "function", 3: "max_iter", 4: "failure", 5: "min_radius"}
 
@@ -63,36 +62,65 @@ def _cpu_has_fma():
     return False
 
 
-# -ffp-contract=off: only the fma() calls written out in the source fuse (the HIP kernels mirror exactly those).
-# -mfma makes them single instructions; without it (host without FMA3) they go through libm's exact software fma --
-# same results, much slower.
-CFLAGS = ["-O2", "-ffp-contract=off", "-fPIC", "-std=c99"] + (["-mfma"] if _cpu_has_fma() else [])
-_SUFFIX = "" if _cpu_has_fma() else "_nofma"  # a library built with -mfma elsewhere must not be loaded on a host without FMA3
+# Two builds of the same source (see the header of rsdsfm_oracle.c):
+#   "reference" (default): the reference's arithmetic -- no fused multiply-add anywhere (-ffp-contract=off, no fma() calls).
+#                          The pinned target of every parity test and the checker of librsdsfm_hip.so.
+#   "fused":               -DRSO_FUSED=1, fma() at the places the opt-in librsdsfm_hip_fused.so fuses; checker of that
+#                          library only.  -mfma makes the calls single instructions; on a host without FMA3 they go
+#                          through libm's exact software fma (same bits, slower), and such a host must not load a
+#                          library built with -mfma elsewhere, hence the file-name suffix.
+CFLAGS = ["-O2", "-ffp-contract=off", "-fPIC", "-std=c99"]
+_FUSED_FLAGS = ["-DRSO_FUSED=1"] + (["-mfma"] if _cpu_has_fma() else [])
+_FUSED_SUFFIX = "_fused" if _cpu_has_fma() else "_fused_nofma"
+_ARITH = "reference"
+_LIBS = {}
 
 
-def build(force=False):
-    so = os.path.join(_HERE, "librsdsfm_oracle%s.so" % _SUFFIX)
+def _so_path(arith="reference", omp=False):
+    return os.path.join(_HERE, "librsdsfm_oracle%s%s.so" % ("_omp" if omp else "", _FUSED_SUFFIX if arith == "fused" else ""))
+
+
+def build(force=False, arith="reference", omp=False):
+    so = _so_path(arith, omp)
     src = os.path.join(_HERE, "rsdsfm_oracle.c")
     hdr = os.path.join(_HERE, "rsdsfm_oracle.h")
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
-        subprocess.check_call(
-            ["gcc"] + CFLAGS + ["-shared", "-o", so, src, "-lm"]
-        )
+        flags = CFLAGS + (_FUSED_FLAGS if arith == "fused" else []) + (["-fopenmp"] if omp else [])
+        tmp = so + ".tmp%d" % os.getpid()
+        subprocess.check_call(["gcc"] + flags + ["-shared", "-o", tmp, src, "-lm"])
+        os.replace(tmp, so)
     return so
+
+
+def set_arithmetic(arith):
+    """selects which build of the oracle lib() returns: "reference" (default, unfused) or "fused" """
+    global _ARITH
+    assert arith in ("reference", "fused")
+    _ARITH = arith
+
+
+class arithmetic:
+    """context manager: `with oracle_py.arithmetic("fused"): ...`"""
+
+    def __init__(self, arith):
+        self.arith = arith
+
+    def __enter__(self):
+        self.prev = _ARITH
+        set_arithmetic(self.arith)
+
+    def __exit__(self, *a):
+        set_arithmetic(self.prev)
 
 
 _LIB_OMP = None
 
 
 def lib_omp():
-    """all-cores (OpenMP) build of the same source; only bench.py's all-cores CPU baseline uses it"""
+    """all-cores (OpenMP) build of the same source (reference arithmetic); only bench.py's all-cores CPU baseline uses it"""
     global _LIB_OMP
     if _LIB_OMP is None:
-        so = os.path.join(_HERE, "librsdsfm_oracle_omp%s.so" % _SUFFIX)
-        src = os.path.join(_HERE, "rsdsfm_oracle.c")
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-            subprocess.check_call(["gcc"] + CFLAGS + ["-fopenmp", "-shared", "-o", so, src, "-lm"])
-        _LIB_OMP = C.CDLL(so)
+        _LIB_OMP = C.CDLL(build(omp=True))
     return _LIB_OMP
 
 
@@ -107,13 +135,14 @@ def estimate_inverse_depths_all_cores(q, u, v, w, k, alpha, alpha_k, mode=1):
 
 
 def lib():
-    global _LIB
-    if _LIB is None:
+    if _ARITH not in _LIBS:
         # RSO_ORACLE_LIB: an alternative build of the same source (e.g. `make -C oracle asan` run under LD_PRELOAD=libasan.so)
-        _LIB = C.CDLL(os.environ.get("RSO_ORACLE_LIB") or build())
-        _LIB.rso_score.restype = C.c_int64
-        _LIB.rso_flatten.restype = C.c_int64
-    return _LIB
+        alt = os.environ.get("RSO_ORACLE_LIB") if _ARITH == "reference" else None
+        L = C.CDLL(alt or build(arith=_ARITH))
+        L.rso_score.restype = C.c_int64
+        L.rso_flatten.restype = C.c_int64
+        _LIBS[_ARITH] = L
+    return _LIBS[_ARITH]
 
 
 def _p(a):

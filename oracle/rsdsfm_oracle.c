@@ -7,12 +7,22 @@
  * its README (Eigen 3.3.4: JacobiSVD.h, Jacobi.h, AngleAxis.h; Ceres 1.14.0: trust_region_minimizer.cc,
  * levenberg_marquardt_strategy.cc, schur_eliminator_impl.h).
  *
- * Build: gcc -O2 -ffp-contract=off -mfma -fPIC -shared.  The compiler contracts nothing; the per-pixel model of the dense
- * depth solve (rso_residual, jac_rho, the LM loops of rso_estimate_inverse_depths, point_error) calls fma() explicitly, and
- * the HIP kernels fuse at exactly the same places, so that integer outputs can be compared bit-exactly.  -mfma only makes
- * those calls single instructions (without it libm's exact software fma gives the same bits, slowly).
+ * ARITHMETIC.  Default build: gcc -O2 -ffp-contract=off -fPIC -shared -- the REFERENCE's arithmetic.  The reference is
+ * compiled with plain `-std=c++11` (src/CMakeLists.txt:18: no -mfma, no -march), so x86-64 gcc emits no fused multiply-add
+ * for it: every a*b+c is a rounded multiply followed by a rounded add, in source order.  This file restates the expressions
+ * in that order and the compiler contracts nothing.  This is the pinned target of the parity tests; the default HIP library
+ * (librsdsfm_hip.so) evaluates the same expressions the same way.
+ * -DRSO_FUSED=1 (librsdsfm_oracle_fused.so, checker of the opt-in librsdsfm_hip_fused.so only): the per-pixel model of
+ * the dense depth solve (rso_residual, jac_rho, the LM loops of rso_estimate_inverse_depths, point_error) and
+ * rso_project_scanline call fma() at the places the fused kernels do (device_math.hpp, lm_common.hpp, gtflow_kernels.hip
+ * under RSDSFM_FUSED); add -mfma so the calls become single instructions (without it libm's exact software fma gives the
+ * same bits, slowly).  tests/test_gpu_fused.py measures fused kernels against the UNFUSED oracle.
  */
 #include "rsdsfm_oracle.h"
+
+#ifndef RSO_FUSED
+#define RSO_FUSED 0
+#endif
 
 #include <float.h>
 #include <math.h>
@@ -668,28 +678,51 @@ int rso_calculate_velocities(const double q[18], const double u[18], const doubl
 /* residual + per-pixel model                                                                        */
 /* ------------------------------------------------------------------------------------------------ */
 
-/* nonlinearRefinement.cc:32-52, T = double.  The sums of products are contracted into fused multiply-adds at the places
- * written out below (and only there: the file is compiled with -ffp-contract=off) -- what gcc's default -ffp-contract=fast
- * does to the reference's expressions on FMA hardware, pinned explicitly here because the HIP kernels (device_math.hpp,
- * lm_common.hpp) mirror this arithmetic operation for operation: an fma is one fp64 instruction on gfx950 where the
- * unfused pair is two, and the dense depth kernels are bound by fp64 instruction issue. */
+/* nonlinearRefinement.cc:32-52, T = double, same evaluation order (RSO_FUSED: see the header) */
 void rso_residual(double x, double y, double ux, double uy, double alpha, double alpha_k, const double v[3],
                   const double w[3], double k, double rho, double r[2]) {
+#if RSO_FUSED
     double beta = (2.0 / (2.0 + k)) * fma(k, alpha_k, alpha);
     double a0 = fma(x, v[2], -v[0]), a1 = fma(y, v[2], -v[1]);
     double in0 = fma(rho, a0, x * y * w[0]) - fma(x, x, 1.0) * w[1] + y * w[2];
     double in1 = fma(rho, a1, fma(y, y, 1.0) * w[0]) - x * y * w[1] - x * w[2];
     r[0] = fma(beta, in0, ux); /* u - (beta * -1 * in) */
     r[1] = fma(beta, in1, uy);
+#else
+    double beta = (2.0 / (2.0 + k)) * (alpha + k * alpha_k);
+    double p0 = beta * -1.0 * (rho * (x * v[2] - v[0]) + (x * y * w[0]) - (1.0 + x * x) * w[1] + y * w[2]);
+    double p1 = beta * -1.0 * (rho * (y * v[2] - v[1]) + (1.0 + y * y) * w[0] - x * y * w[1] - x * w[2]);
+    r[0] = ux - p0;
+    r[1] = uy - p1;
+#endif
 }
 
 /* d r / d rho  ( = beta * a ), the only non-constant Jacobian column of the dense depth solve */
 static inline void jac_rho(double x, double y, double alpha, double alpha_k, const double v[3], double k,
                            double J[2]) {
+#if RSO_FUSED
     double beta = (2.0 / (2.0 + k)) * fma(k, alpha_k, alpha);
     J[0] = beta * fma(x, v[2], -v[0]);
     J[1] = beta * fma(y, v[2], -v[1]);
+#else
+    double beta = (2.0 / (2.0 + k)) * (alpha + k * alpha_k);
+    J[0] = beta * (x * v[2] - v[0]);
+    J[1] = beta * (y * v[2] - v[1]);
+#endif
 }
+
+/* the small sums of products of the LM loops in the two arithmetic modes */
+#if RSO_FUSED
+#define RSO_DOT2(a0, b0, a1, b1) fma((a0), (b0), (a1) * (b1))
+#define RSO_MAD(a, b, c) fma((a), (b), (c))
+#define RSO_ACC_SQ2(acc, r0, r1) fma((r0), (r0), fma((r1), (r1), (acc)))
+#define RSO_ACC_SQ(acc, x) fma((x), (x), (acc))
+#else
+#define RSO_DOT2(a0, b0, a1, b1) ((a0) * (b0) + (a1) * (b1))
+#define RSO_MAD(a, b, c) ((a) * (b) + (c))
+#define RSO_ACC_SQ2(acc, r0, r1) ((acc) + ((r0) * (r0) + (r1) * (r1)))
+#define RSO_ACC_SQ(acc, x) ((acc) + (x) * (x))
+#endif
 
 /* Ceres 1.14 defaults (Solver::Options) used by every solve in nonlinearRefinement.cc */
 #define CERES_MAX_ITER 50
@@ -765,13 +798,13 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
     for (int64_t i = 0; i < n; ++i) {
         rho[i] = 1.0; /* nonlinearRefinement.cc:140 */
         jac_rho(q[2 * i], q[2 * i + 1], alpha[i], alpha_k[i], v, k, &J[2 * i]);
-        s[i] = 1.0 / (1.0 + sqrt(fma(J[2 * i], J[2 * i], J[2 * i + 1] * J[2 * i + 1]))); /* jacobi scaling */
+        s[i] = 1.0 / (1.0 + sqrt(RSO_DOT2(J[2 * i], J[2 * i], J[2 * i + 1], J[2 * i + 1]))); /* jacobi scaling */
         rso_residual(q[2 * i], q[2 * i + 1], u[2 * i], u[2 * i + 1], alpha[i], alpha_k[i], v, w, k, rho[i],
                      &res[2 * i]);
-        cost = fma(res[2 * i], res[2 * i], fma(res[2 * i + 1], res[2 * i + 1], cost));
-        double g = fabs(fma(J[2 * i], res[2 * i], J[2 * i + 1] * res[2 * i + 1]));
+        cost = RSO_ACC_SQ2(cost, res[2 * i], res[2 * i + 1]);
+        double g = fabs(RSO_DOT2(J[2 * i], res[2 * i], J[2 * i + 1], res[2 * i + 1]));
         if (g > gmax) gmax = g;
-        xsq = fma(rho[i], rho[i], xsq);
+        xsq = RSO_ACC_SQ(xsq, rho[i]);
     }
     cost *= 0.5;
     double x_norm = sqrt(xsq);
@@ -801,19 +834,27 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
 #endif
         for (int64_t i = 0; i < n; ++i) {
             double jt0 = J[2 * i] * s[i], jt1 = J[2 * i + 1] * s[i];
-            double ht = fma(jt0, jt0, jt1 * jt1);
+            double ht = RSO_DOT2(jt0, jt0, jt1, jt1);
             double diag = clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG);
-            double gt = fma(jt0, res[2 * i], jt1 * res[2 * i + 1]);
-            double step = -(gt / fma(diag, inv_radius, ht)); /* ht + clamp(diag) / radius */
-            double m0 = jt0 * step, m1 = jt1 * step;
+            double gt = RSO_DOT2(jt0, res[2 * i], jt1, res[2 * i + 1]);
+            double m0, m1, step;
+#if RSO_FUSED
+            step = -(gt / fma(diag, inv_radius, ht)); /* ht + clamp(diag) / radius */
+            m0 = jt0 * step, m1 = jt1 * step;
             /* model_change -= m0 (r0 + m0 / 2) + m1 (r1 + m1 / 2) */
             model_change = fma(-m0, fma(m0, 0.5, res[2 * i]), fma(-m1, fma(m1, 0.5, res[2 * i + 1]), model_change));
-            cand[i] = fma(step, s[i], rho[i]);
+#else
+            double lam = diag * inv_radius;
+            step = -(gt / (ht + lam));
+            m0 = jt0 * step, m1 = jt1 * step;
+            model_change -= m0 * (res[2 * i] + m0 / 2.0) + m1 * (res[2 * i + 1] + m1 / 2.0);
+#endif
+            cand[i] = RSO_MAD(step, s[i], rho[i]);
             double dx = rho[i] - cand[i];
-            stepsq = fma(dx, dx, stepsq);
+            stepsq = RSO_ACC_SQ(stepsq, dx);
             double rc[2];
             rso_residual(q[2 * i], q[2 * i + 1], u[2 * i], u[2 * i + 1], alpha[i], alpha_k[i], v, w, k, cand[i], rc);
-            ccost = fma(rc[0], rc[0], fma(rc[1], rc[1], ccost));
+            ccost = RSO_ACC_SQ2(ccost, rc[0], rc[1]);
         }
         ccost *= 0.5;
         if (!(model_change > 0.0)) { /* HandleInvalidStep */
@@ -846,11 +887,11 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
 #endif
             for (int64_t i = 0; i < n; ++i) {
                 rho[i] = cand[i];
-                xsq = fma(rho[i], rho[i], xsq);
+                xsq = RSO_ACC_SQ(xsq, rho[i]);
                 rso_residual(q[2 * i], q[2 * i + 1], u[2 * i], u[2 * i + 1], alpha[i], alpha_k[i], v, w, k, rho[i],
                              &res[2 * i]);
-                cost = fma(res[2 * i], res[2 * i], fma(res[2 * i + 1], res[2 * i + 1], cost));
-                double g = fabs(fma(J[2 * i], res[2 * i], J[2 * i + 1] * res[2 * i + 1]));
+                cost = RSO_ACC_SQ2(cost, res[2 * i], res[2 * i + 1]);
+                double g = fabs(RSO_DOT2(J[2 * i], res[2 * i], J[2 * i + 1], res[2 * i + 1]));
                 if (g > gmax) gmax = g;
             }
             cost *= 0.5;
@@ -881,6 +922,7 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
 /* ------------------------------------------------------------------------------------------------ */
 static inline double point_error(double x, double y, double ux, double uy, double alpha, double alpha_k,
                                  const double v[3], const double w[3], double k, double rho) {
+#if RSO_FUSED
     double beta = fma(k, alpha_k, alpha) * (2.0 / (2.0 + k));
     /* A*v, B*w: the 2x3 * 3x1 products, contracted into fma chains (see rso_residual) */
     double av0 = fma(-x, v[2], v[0]);
@@ -890,6 +932,17 @@ static inline double point_error(double x, double y, double ux, double uy, doubl
     double e0 = fma(beta, fma(av0, rho, bw0), -ux);
     double e1 = fma(beta, fma(av1, rho, bw1), -uy);
     return sqrt(fma(e0, e0, e1 * e1));
+#else
+    double beta = (alpha + k * alpha_k) * (2.0 / (2.0 + k));
+    /* A*v, B*w as Eigen evaluates the 2x3 * 3x1 products (terms in column order; A = [1 0 -x; 0 1 -y]) */
+    double av0 = v[0] + (-x) * v[2];
+    double av1 = v[1] + (-y) * v[2];
+    double bw0 = (-x * y) * w[0] + (1 + x * x) * w[1] + (-y) * w[2];
+    double bw1 = (-(1 + y * y)) * w[0] + (x * y) * w[1] + x * w[2];
+    double e0 = beta * (av0 * rho + bw0) - ux;
+    double e1 = beta * (av1 * rho + bw1) - uy;
+    return sqrt(e0 * e0 + e1 * e1);
+#endif
 }
 
 int64_t rso_score(const double* q, const double* u, const double* alpha, const double* alpha_k, int64_t n,
@@ -1492,12 +1545,17 @@ void rso_interpolate_cracky(const uint8_t* in, int32_t rows, int32_t cols, int32
 /* ------------------------------------------------------------------------------------------------ */
 static void rso_project_scanline(const double* Ri, const double* ti, const double W[3], double fx, double fyp, double cx,
                                  double cy, double* px, double* py) {
-    /* worldToCameraFrame: [R t; 0 1] * (W, 1), evaluated left to right; then spaceToPlane.  Sums of products contracted into
-     * explicit fmas (see rso_residual): the HIP kernel of this search is bound by fp64 instruction issue and fuses at the same places */
+    /* worldToCameraFrame: [R t; 0 1] * (W, 1), evaluated left to right; then spaceToPlane (RSO_FUSED: see the header) */
     double pc[3];
+#if RSO_FUSED
     for (int j = 0; j < 3; ++j) pc[j] = fma(Ri[j * 3 + 2], W[2], fma(Ri[j * 3 + 1], W[1], Ri[j * 3 + 0] * W[0])) + ti[j] * 1.0;
     *px = fma(pc[0] / pc[2], fx, cx);
     *py = fma(pc[1] / pc[2], fyp, cy);
+#else
+    for (int j = 0; j < 3; ++j) pc[j] = ((Ri[j * 3 + 0] * W[0] + Ri[j * 3 + 1] * W[1]) + Ri[j * 3 + 2] * W[2]) + ti[j] * 1.0;
+    *px = pc[0] / pc[2] * fx + cx;
+    *py = pc[1] / pc[2] * fyp + cy;
+#endif
 }
 
 void rso_true_flow(const double* wx, const double* wy, const double* wz, int32_t rows, int32_t cols, const double* R2,

@@ -20,6 +20,8 @@ from . import dist, pipeline, synth  # noqa: F401  (multi-GPU driver; analytic d
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RSDSFM_LIB") or os.path.join(_HERE, "librsdsfm_hip.so")
+# opt-in build of the same sources with explicit fused multiply-adds in the per-pixel model (csrc/device_math.hpp)
+LIB_PATH_FUSED = os.path.join(_HERE, "librsdsfm_hip_fused.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "rsdsfm.h")
 
 OK = 0
@@ -29,7 +31,7 @@ K_COMPAT, K_FIXED = 0, 1
 FLOW_COMPAT_RANK, FLOW_GATHERED = 0, 1
 TERMINATION = {0: "gradient", 1: "parameter", 2: "function", 3: "max_iter", 4: "failure", 5: "min_radius"}
 
-_lib = None
+_libs = {}
 
 
 class RsdsfmError(RuntimeError):
@@ -95,14 +97,17 @@ def declared_symbols():
     return sorted(set(re.findall(r"\b(rsdsfm_[a-z0-9_]+)\s*\(", txt)))
 
 
-def load_library(build_if_missing=True):
-    """Loads librsdsfm_hip.so (building it with hipcc when it is absent and hipcc exists).  Raises otherwise."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def load_library(build_if_missing=True, arith="reference"):
+    """Loads librsdsfm_hip.so (arith="reference", the default: the reference's unfused arithmetic) or the opt-in
+    librsdsfm_hip_fused.so (arith="fused"), building them with hipcc when absent and hipcc exists.  Raises otherwise."""
+    if arith in _libs:
+        return _libs[arith]
+    if arith not in ("reference", "fused"):
+        raise RsdsfmError("arith must be 'reference' or 'fused'")
+    path = LIB_PATH if arith == "reference" else LIB_PATH_FUSED
+    if not os.path.exists(path):
         if not build_if_missing:
-            raise RsdsfmError("HIP extension %s is missing (run: python rs-aware-differential-sfm_amd/build.py)" % LIB_PATH)
+            raise RsdsfmError("HIP extension %s is missing (run: python rs-aware-differential-sfm_amd/build.py)" % path)
         from . import build as _build
 
         _build.build()
@@ -114,7 +119,7 @@ def load_library(build_if_missing=True):
             import torch  # noqa: F401
         except Exception:
             pass
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     lib.rsdsfm_version.restype = C.c_char_p
     lib.rsdsfm_last_error.restype = C.c_char_p
     lib.rsdsfm_last_error.argtypes = [C.c_void_p]
@@ -122,7 +127,9 @@ def load_library(build_if_missing=True):
     lib.rsdsfm_kernel_name.argtypes = [C.c_char_p]
     lib.rsdsfm_destroy.restype = None
     lib.rsdsfm_destroy.argtypes = [C.c_void_p]
-    _lib = lib
+    if lib.rsdsfm_fused_arithmetic() != (1 if arith == "fused" else 0):
+        raise RsdsfmError("%s reports the wrong arithmetic mode (stale build?)" % path)
+    _libs[arith] = lib
     return lib
 
 
@@ -147,8 +154,11 @@ class Solver:
     """One context = one HIP device + one stream (single owner).  `stream`: a raw hipStream_t handle to adopt,
     e.g. torch.cuda.current_stream().cuda_stream, or None for a private stream."""
 
-    def __init__(self, device=0, stream=None):
-        self.lib = load_library()
+    def __init__(self, device=0, stream=None, arith="reference"):
+        """arith: "reference" (default) = librsdsfm_hip.so, the reference's unfused arithmetic; "fused" = the opt-in
+        librsdsfm_hip_fused.so (same ABI, explicit fmas in the per-pixel model)"""
+        self.lib = load_library(arith=arith)
+        self.arith = arith
         self._ctx = C.c_void_p()
         rc = self.lib.rsdsfm_create(C.byref(self._ctx), int(device), C.c_void_p(stream) if stream else None)
         if rc != OK:
@@ -609,7 +619,7 @@ def prepared_depth_batch(solvers, problems, launch0_only=False):
     d_q, d_u, d_alpha, d_alpha_k, d_rho and n, v, w, k.  Returns a zero-argument callable that enqueues the whole batch with
     pre-marshalled arguments (rsdsfm_estimate_inverse_depths_batch_dev; launch0_only: only the streaming launch, for profiling);
     finish each solve with solvers[i].depth_finish_dev."""
-    lib = load_library()
+    lib = solvers[0].lib
     cnt = len(solvers)
     assert cnt == len(problems) and 1 <= cnt <= 8
     VP = C.c_void_p * cnt

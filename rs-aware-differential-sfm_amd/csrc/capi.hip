@@ -79,7 +79,14 @@ using namespace rsdsfm;
 
 extern "C" {
 
-const char* rsdsfm_version(void) { return "rsdsfm-mi355x 0.1.0 (gfx950, fp64, -ffp-contract=off)"; }
+#ifndef RSDSFM_FUSED
+#define RSDSFM_FUSED 0
+#endif
+const char* rsdsfm_version(void) {
+    return RSDSFM_FUSED ? "rsdsfm-mi355x 0.2.0 (gfx950, fp64, -ffp-contract=off, FUSED per-pixel model: explicit fmas)"
+                        : "rsdsfm-mi355x 0.2.0 (gfx950, fp64, -ffp-contract=off, reference arithmetic: no fused multiply-add)";
+}
+int rsdsfm_fused_arithmetic(void) { return RSDSFM_FUSED; }
 
 int rsdsfm_create(rsdsfm_ctx** out, int device, void* stream_or_null) {
     if (!out) return RSDSFM_ERR_INVALID;

@@ -1,16 +1,27 @@
 // device_math.hpp -- per-pixel model of the RS differential-SfM solve, shared by all kernels.
 //
-// Compiled with -ffp-contract=off; sums of products are fused where -- and only where -- __builtin_fma is written out, at
-// exactly the places oracle/rsdsfm_oracle.c calls fma() (rso_residual, jac_rho, the LM loops, point_error), so that integer
-// outputs (inlier masks / counts, LM decisions) can be compared bit-exactly with the CPU oracle.  The expressions are the
-// reference's (nonlinearRefinement.cc:32-52 for the residual, minimal.cc:255-275 for the scoring error); contracting them is
-// what gcc's default -ffp-contract=fast does to the reference on FMA hardware.  Here it is a measured 11 % of the dense depth
-// solve (the kernels are bound by fp64 instruction issue: an fma is one instruction, the unfused pair two).
+// Two arithmetic modes, chosen at COMPILE time for the whole library (build.py builds both):
+//   RSDSFM_FUSED == 0 (default, librsdsfm_hip.so): the REFERENCE's arithmetic.  The reference is built with plain
+//     `-std=c++11` (src/CMakeLists.txt:18: no -mfma / -march), so on x86-64 every a*b+c of nonlinearRefinement.cc:32-52 and
+//     minimal.cc:255-275 is an unfused multiply followed by an add, in source order.  The expressions below keep exactly that
+//     order (the file is compiled with -ffp-contract=off), and fp64 * + / sqrt are correctly rounded on gfx950, so per-pixel
+//     values -- and the integer outputs derived from them (inlier masks / counts, scanline indices) -- are bit-identical to
+//     the CPU oracle's default (unfused) build.
+//   RSDSFM_FUSED == 1 (opt-in, librsdsfm_hip_fused.so): sums of products contracted into fused multiply-adds where -- and
+//     only where -- __builtin_fma is written out below, at exactly the places the oracle's -DRSO_FUSED build calls fma().
+//     An fma is one fp64 instruction where the unfused pair is two and the per-pixel kernels are bound by fp64 issue
+//     (measured: dense depth solve +11 %, ransac_lm_kernel -65 us).  tests/test_gpu_fused.py quantifies what it changes
+//     against the unfused oracle on every BASELINE config (values <= 1e-5 relative, scanline indices identical, the number of
+//     inlier-mask flips bounded).
 #pragma once
 
 #include <hip/hip_runtime.h>
 
 #include "rsdsfm_internal.hpp"
+
+#ifndef RSDSFM_FUSED
+#define RSDSFM_FUSED 0
+#endif
 
 namespace rsdsfm {
 
@@ -38,6 +49,7 @@ struct PixelModel {
 
     __device__ __forceinline__ void init(double x, double y, double ux_, double uy_, double alpha, double alpha_k,
                                          const Pose& p, double two_over) {
+#if RSDSFM_FUSED
         double beta = two_over * __builtin_fma(p.k, alpha_k, alpha);  // (2/(2+k)) * (alpha + k alpha_k)
         nbeta = beta * -1.0;
         a0 = __builtin_fma(x, p.v[2], -p.v[0]);
@@ -46,6 +58,16 @@ struct PixelModel {
         t02 = __builtin_fma(x, x, 1.0) * p.w[1];
         t03 = y * p.w[2];
         t11 = __builtin_fma(y, y, 1.0) * p.w[0];
+#else
+        double beta = two_over * (alpha + p.k * alpha_k);  // (2/(2+k)) * (alpha + k alpha_k)
+        nbeta = beta * -1.0;
+        a0 = x * p.v[2] - p.v[0];
+        a1 = y * p.v[2] - p.v[1];
+        t01 = x * y * p.w[0];
+        t02 = (1.0 + x * x) * p.w[1];
+        t03 = y * p.w[2];
+        t11 = (1.0 + y * y) * p.w[0];
+#endif
         t12 = x * y * p.w[1];
         t13 = x * p.w[2];
         ux = ux_;
@@ -54,14 +76,53 @@ struct PixelModel {
         J1 = beta * a1;
     }
     __device__ __forceinline__ void residual(double rho, double& r0, double& r1) const {
+#if RSDSFM_FUSED
         r0 = __builtin_fma(-nbeta, __builtin_fma(rho, a0, t01) - t02 + t03, ux);
         r1 = __builtin_fma(-nbeta, __builtin_fma(rho, a1, t11) - t12 - t13, uy);
+#else
+        double p0 = nbeta * (rho * a0 + t01 - t02 + t03);
+        double p1 = nbeta * (rho * a1 + t11 - t12 - t13);
+        r0 = ux - p0;
+        r1 = uy - p1;
+#endif
     }
 };
+
+// the small sums of products of the LM loops (lm_common.hpp), in the two arithmetic modes: dot2 = a0 b0 + a1 b1,
+// acc2 = acc + (a0 a0 + a1 a1) as the oracle's loops accumulate them, mad = a b + c
+__device__ __forceinline__ double dot2(double a0, double b0, double a1, double b1) {
+#if RSDSFM_FUSED
+    return __builtin_fma(a0, b0, a1 * b1);
+#else
+    return a0 * b0 + a1 * b1;
+#endif
+}
+__device__ __forceinline__ double mad(double a, double b, double c) {
+#if RSDSFM_FUSED
+    return __builtin_fma(a, b, c);
+#else
+    return a * b + c;
+#endif
+}
+__device__ __forceinline__ double acc_sq2(double acc, double r0, double r1) {
+#if RSDSFM_FUSED
+    return __builtin_fma(r0, r0, __builtin_fma(r1, r1, acc));
+#else
+    return acc + (r0 * r0 + r1 * r1);
+#endif
+}
+__device__ __forceinline__ double acc_sq(double acc, double x) {
+#if RSDSFM_FUSED
+    return __builtin_fma(x, x, acc);
+#else
+    return acc + x * x;
+#endif
+}
 
 // minimal.cc:255-270: residual norm of the flow predicted from (v, w, k, rho)
 __device__ __forceinline__ double point_error(double x, double y, double ux, double uy, double alpha, double alpha_k,
                                               const Pose& p, double two_over, double rho) {
+#if RSDSFM_FUSED
     double beta = __builtin_fma(p.k, alpha_k, alpha) * two_over;
     double av0 = __builtin_fma(-x, p.v[2], p.v[0]);
     double av1 = __builtin_fma(-y, p.v[2], p.v[1]);
@@ -70,6 +131,17 @@ __device__ __forceinline__ double point_error(double x, double y, double ux, dou
     double e0 = __builtin_fma(beta, __builtin_fma(av0, rho, bw0), -ux);
     double e1 = __builtin_fma(beta, __builtin_fma(av1, rho, bw1), -uy);
     return sqrt(__builtin_fma(e0, e0, e1 * e1));
+#else
+    // A*v, B*w as Eigen evaluates the 2x3 * 3x1 products (terms in column order)
+    double beta = (alpha + p.k * alpha_k) * two_over;
+    double av0 = p.v[0] + (-x) * p.v[2];
+    double av1 = p.v[1] + (-y) * p.v[2];
+    double bw0 = (-x * y) * p.w[0] + (1 + x * x) * p.w[1] + (-y) * p.w[2];
+    double bw1 = (-(1 + y * y)) * p.w[0] + (x * y) * p.w[1] + x * p.w[2];
+    double e0 = beta * (av0 * rho + bw0) - ux;
+    double e1 = beta * (av1 * rho + bw1) - uy;
+    return sqrt(e0 * e0 + e1 * e1);
+#endif
 }
 
 // ---- wave64 reductions on the VALU (DPP row shifts / broadcasts; no LDS traffic).  Fixed combination

@@ -7,20 +7,44 @@
 // GEMM-shaped (one IEEE division per projection, an argmin with an index-dependent target):
 //   * one pixel per lane; the scanline loop is uniform across the machine, so the pose rows come through the scalar
 //     data path (s_load) and are broadcast operands of the VALU instructions -- no LDS, no vector loads in the loop;
-//   * only what decides the argmin is computed in the loop (camera-frame y and z: 2 mul + 4 fma + 2 add, 1 division, the
-//     intrinsics as one fma and the compare); the x coordinate is computed once for the winner.  Each value that is
-//     computed is computed with the oracle's operation order and fused multiply-adds (rso_project_scanline), so flows
-//     and winners are bit-identical to the oracle's;
+//   * only what decides the argmin is computed in the loop (camera-frame y and z: 6 mul + 6 add, 1 division, the
+//     intrinsics and the compare; with -DRSDSFM_FUSED=1: 2 mul + 4 fma + 2 add, the intrinsics as one fma); the x
+//     coordinate is computed once for the winner.  Each value that is computed is computed with the reference's operation
+//     order (rso_project_scanline of the oracle build with the same arithmetic mode), so flows and winners are
+//     bit-identical to the oracle's;
 //   * the world maps are column-major (Eigen) and the flow row-major (cv::Mat): 24 B read + 16 B written per pixel,
 //     negligible against rows2 x ~30 fp64 instructions per pixel.
 #include <math.h>
 
 #include "rsdsfm_internal.hpp"
 
+#ifndef RSDSFM_FUSED
+#define RSDSFM_FUSED 0
+#endif
+
 namespace rsdsfm {
 
 namespace {
 constexpr int kGF = 256;
+
+// one row of worldToCameraFrame: [R t; 0 1] * (W, 1), Eigen's 4x4 product evaluated left to right (rsframe.cc:740-768).
+// Default build: the reference's unfused arithmetic.  -DRSDSFM_FUSED=1 (librsdsfm_hip_fused.so): contracted at the places
+// the oracle's -DRSO_FUSED build calls fma() (rso_project_scanline) -- the search is bound by fp64 issue (0.78 -> 0.61 ms).
+__device__ __forceinline__ double cam_row(double r0, double r1, double r2, double t, double X, double Y, double Z) {
+#if RSDSFM_FUSED
+    return __builtin_fma(r2, Z, __builtin_fma(r1, Y, r0 * X)) + t * 1.0;
+#else
+    return ((r0 * X + r1 * Y) + r2 * Z) + t * 1.0;
+#endif
+}
+// spaceToPlane: c / z * f + c0
+__device__ __forceinline__ double to_plane(double c, double z, double f, double c0) {
+#if RSDSFM_FUSED
+    return __builtin_fma(c / z, f, c0);
+#else
+    return c / z * f + c0;
+#endif
+}
 }
 
 // a workgroup owns a 16 x 16 pixel tile; lanes run along v (the contiguous direction of the column-major world maps:
@@ -48,9 +72,9 @@ __global__ __launch_bounds__(kGF) void true_flow_kernel(const double* __restrict
             for (int i = 0; i < rows2; ++i) {
                 const double* Ri = R2 + (int64_t)i * 9;  // uniform address: scalar loads
                 const double* ti = t2 + (int64_t)i * 3;
-                const double yc = __builtin_fma(Ri[5], Z, __builtin_fma(Ri[4], Y, Ri[3] * X)) + ti[1] * 1.0;
-                const double zc = __builtin_fma(Ri[8], Z, __builtin_fma(Ri[7], Y, Ri[6] * X)) + ti[2] * 1.0;
-                const double py = __builtin_fma(yc / zc, fyp, cy);
+                const double yc = cam_row(Ri[3], Ri[4], Ri[5], ti[1], X, Y, Z);
+                const double zc = cam_row(Ri[6], Ri[7], Ri[8], ti[2], X, Y, Z);
+                const double py = to_plane(yc, zc, fyp, cy);
                 const double diff = fabs(py - (double)i);
                 if (diff < min_diff) {
                     min_diff = diff;
@@ -59,11 +83,11 @@ __global__ __launch_bounds__(kGF) void true_flow_kernel(const double* __restrict
             }
             const double* Ri = R2 + (int64_t)best_row * 9;
             const double* ti = t2 + (int64_t)best_row * 3;
-            const double xc = __builtin_fma(Ri[2], Z, __builtin_fma(Ri[1], Y, Ri[0] * X)) + ti[0] * 1.0;
-            const double yc = __builtin_fma(Ri[5], Z, __builtin_fma(Ri[4], Y, Ri[3] * X)) + ti[1] * 1.0;
-            const double zc = __builtin_fma(Ri[8], Z, __builtin_fma(Ri[7], Y, Ri[6] * X)) + ti[2] * 1.0;
-            const double px = __builtin_fma(xc / zc, fx, cx);
-            const double py = __builtin_fma(yc / zc, fyp, cy);
+            const double xc = cam_row(Ri[0], Ri[1], Ri[2], ti[0], X, Y, Z);
+            const double yc = cam_row(Ri[3], Ri[4], Ri[5], ti[1], X, Y, Z);
+            const double zc = cam_row(Ri[6], Ri[7], Ri[8], ti[2], X, Y, Z);
+            const double px = to_plane(xc, zc, fx, cx);
+            const double py = to_plane(yc, zc, fyp, cy);
             if (sqrt(px * px + py * py) != 0) {
                 f2x = px;
                 f2y = py;

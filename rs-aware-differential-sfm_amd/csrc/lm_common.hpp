@@ -180,6 +180,16 @@ struct LmPlanFirst {
     }
 };
 
+// ht + clamp(diag) / radius: the damped 1x1 normal matrix of one pixel (inv_radius = 1 / radius)
+__device__ __forceinline__ double lm_denominator(double ht, double diag, double inv_radius) {
+#if RSDSFM_FUSED
+    return __builtin_fma(diag, inv_radius, ht);
+#else
+    const double lam = diag * inv_radius;
+    return ht + lam;
+#endif
+}
+
 // one pixel through the planned LM trajectory; returns the state selected by write_which.
 // Arithmetic mirrors oracle/rsdsfm_oracle.c rso_estimate_inverse_depths (mode 1) operation for operation.
 struct NoHook {
@@ -193,39 +203,43 @@ __device__ __forceinline__ double lm_pixel(double x, double y, double ux, double
                                            double (&acc)[NS], const Hook& hook = Hook()) {
     PixelModel m;
     m.init(x, y, ux, uy, al, ak, pose, two_over);
-    const double s = 1.0 / (1.0 + sqrt(__builtin_fma(m.J0, m.J0, m.J1 * m.J1)));  // Jacobi scaling (iteration 0 Jacobian)
+    const double s = 1.0 / (1.0 + sqrt(dot2(m.J0, m.J0, m.J1, m.J1)));  // Jacobi scaling (iteration 0 Jacobian)
     const double jt0 = m.J0 * s, jt1 = m.J1 * s;
-    const double ht = __builtin_fma(jt0, jt0, jt1 * jt1);
+    const double ht = dot2(jt0, jt0, jt1, jt1);
     const double diag = clampd(ht, kMinLmDiag, kMaxLmDiag);
     double rho = 1.0;  // nonlinearRefinement.cc:140
     double r0, r1;
     m.residual(rho, r0, r1);
     for (int h = 0; h < plan.n_hist; ++h) {  // replay the accepted steps
-        const double gt = __builtin_fma(jt0, r0, jt1 * r1);
-        const double step = -(gt / __builtin_fma(diag, plan.inv_hist_at(h), ht));
-        rho = __builtin_fma(step, s, rho);
+        const double gt = dot2(jt0, r0, jt1, r1);
+        const double step = -(gt / lm_denominator(ht, diag, plan.inv_hist_at(h)));
+        rho = mad(step, s, rho);
         m.residual(rho, r0, r1);
     }
     double out = rho;
     if (plan.K > 0) {
-        acc[0] = __builtin_fma(r0, r0, __builtin_fma(r1, r1, acc[0]));
-        acc[1] = __builtin_fma(rho, rho, acc[1]);
-        acc[2] = fmax(acc[2], fabs(__builtin_fma(m.J0, r0, m.J1 * r1)));
+        acc[0] = acc_sq2(acc[0], r0, r1);
+        acc[1] = acc_sq(acc[1], rho);
+        acc[2] = fmax(acc[2], fabs(dot2(m.J0, r0, m.J1, r1)));
     }
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) {
         if (j < plan.K) {
-            const double gt = __builtin_fma(jt0, r0, jt1 * r1);
-            const double step = -(gt / __builtin_fma(diag, plan.inv_cand[j], ht));
+            const double gt = dot2(jt0, r0, jt1, r1);
+            const double step = -(gt / lm_denominator(ht, diag, plan.inv_cand[j]));
             const double m0 = jt0 * step, m1 = jt1 * step;
+#if RSDSFM_FUSED
             acc[3 + 5 * j + 1] = __builtin_fma(-m0, __builtin_fma(m0, 0.5, r0), __builtin_fma(-m1, __builtin_fma(m1, 0.5, r1), acc[3 + 5 * j + 1]));
-            const double cand = __builtin_fma(step, s, rho);
+#else
+            acc[3 + 5 * j + 1] -= m0 * (r0 + m0 / 2.0) + m1 * (r1 + m1 / 2.0);
+#endif
+            const double cand = mad(step, s, rho);
             const double dx = rho - cand;
-            acc[3 + 5 * j + 2] = __builtin_fma(dx, dx, acc[3 + 5 * j + 2]);
+            acc[3 + 5 * j + 2] = acc_sq(acc[3 + 5 * j + 2], dx);
             m.residual(cand, r0, r1);
-            acc[3 + 5 * j + 0] = __builtin_fma(r0, r0, __builtin_fma(r1, r1, acc[3 + 5 * j + 0]));
-            acc[3 + 5 * j + 3] = __builtin_fma(cand, cand, acc[3 + 5 * j + 3]);
-            acc[3 + 5 * j + 4] = fmax(acc[3 + 5 * j + 4], fabs(__builtin_fma(m.J0, r0, m.J1 * r1)));
+            acc[3 + 5 * j + 0] = acc_sq2(acc[3 + 5 * j + 0], r0, r1);
+            acc[3 + 5 * j + 3] = acc_sq(acc[3 + 5 * j + 3], cand);
+            acc[3 + 5 * j + 4] = fmax(acc[3 + 5 * j + 4], fabs(dot2(m.J0, r0, m.J1, r1)));
             rho = cand;
             hook(j, cand);
             if (plan.write_which == j + 1) out = cand;

@@ -1,34 +1,29 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: Mpixels/s of the RS depth(+pose) solve on a synthetic 1280x720 pair.
+"""bench.py -- headline benchmark: Mpixels/s of the WHOLE rolling-shutter depth+pose solve on a synthetic 1280x720 pair.
 
 Contract: python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on rank 0.
-  step      = one pass of the hot path over one batch of synthetic input resident in HBM: for the depth workloads one chunk of
-              --pairs-per-step (default 64) consecutive frame pairs of the sequence, for the other workloads one solve / frame.
-  workload  = depth (default): BASELINE.json configs[1] -- 1280x720, dense per-pixel depth solve (Ceres-LM emulation,
-              the reference-matching mode), pose fixed.  The same line also carries `full_solve`: the whole solve
-              (flatten + RANSAC(50) + refinement + depth map + pose table) timed on a 1280x720 DeepFlow-like pair.
+  step      = one pass of the hot path over one batch of synthetic input resident in HBM.
+  workload  = full (default): BASELINE.json's metric -- the whole solve of one 1280x720 DeepFlow-like frame pair (0.3 px noise,
+              10 % outliers): flatten + alpha / alpha_k, RANSAC (50 trials, tol 0.05: 9-point minimal solver, hypothesis-batched
+              Ceres-LM depth solves of ALL pixels, scoring, best trial, compaction), joint nonlinear refinement, sign fix + depth
+              map, per-scanline pose table (reference main.cc:398-522), ONE C-ABI call per pair (rsdsfm_solve_frame_dev), one
+              pair at a time.  `value` = pixels of the K timed pairs / the time of the K steps; `median_ms_per_solve` beside it.
+              `roofline`: the dominant kernel ransac_lm_kernel<true> (fp64 VALU bound: counted fp64 lane-instructions / its
+              launch duration, measured here with HIP events, / 39.3e12) and, under "hbm", SURVEY 8(d)'s whole-solve figure
+              (57 N + 64 M iters bytes / solve time / 8 TB/s).  `cpu_baseline`: the oracle's whole solve on the SAME pair, same
+              trial count.  `depth_only`: BASELINE configs[1] (dense depth solve alone, pose fixed, batched sequence mode).
+              depth             : BASELINE configs[1] as the timed workload: 1280x720, per-pixel depth solve (Ceres-LM emulation),
+                                  pose fixed; --batch / --streams / --pairs-per-step apply.
               depth_closed_form : same with the exact closed-form per-pixel solve.
-              full              : the whole solve is the timed step.
-              tiled             : BASELINE configs[3]-style row tiling: a 3840x2160 frame sharded over the N ranks,
-                                  LM sum rows + ONE all-gather of the depth map over RCCL (scaling "strong").
-              rectify           : SURVEY 8(f-1) consumers of the solve on a 1280x720 frame resident in HBM: RS -> GS back
-                                  projection (+ float3 world points), crack interpolation, 8-bit depth image.
-              true_flow         : SURVEY 8(f-2) ground-truth flow search (rows x cols x rows scanline projections) of a
-                                  1280x720 frame pair.
-              metrics           : SURVEY 8(f-4) meanReprojectionError + createErrorImage of a 1280x720 frame.
-              tiled_full        : the WHOLE solve of a 3840x2160 frame split into column slabs over the N ranks
-                                  (rsdsfm_tile_* stages, dist.TiledFrameSolve; scaling "strong").
-  N > 1     = one process per GPU (torch.distributed / RCCL).  depth / full: each rank solves its own frame pairs
-              (sequence-throughput mode, BASELINE configs[4]), no data-path collective -> scaling "weak".
-  --batch B, --streams S = sequence-throughput mode PER GPU (defaults 4 and 2): B independent pairs per launch of the batched
-              depth fast path (rsdsfm_estimate_inverse_depths_batch_dev: one solver context per pair, grid y = pair) on each
-              of S HIP streams; the pairs share nothing.  `value` is the throughput of that loop (K steps = K x 64 pairs),
-              `config.one_pair_at_a_time` the same work with one context; `roofline` is the batched streaming kernel measured
-              with the other stream idle, `roofline_job` the algorithmic bytes over the job's time per pair.
-  also in the line: `full_solve` / `full_solve_batched` (whole solves, one at a time / 4 in flight), `cpu_baseline` (oracle, 1
-              thread) and `cpu_baseline_all_cores` (same source with OpenMP, best thread count of a sweep).
-Frame pairs rotate through enough distinct HBM buffers to exceed the 256 MiB Infinity Cache, so the timed loop
-streams from HBM, not from L3.
+              tiled             : BASELINE configs[3]-style row tiling of the DEPTH solve: a 3840x2160 frame sharded over the N
+                                  ranks, LM sum rows + ONE all-gather of the depth map over RCCL (scaling "strong").
+              tiled_full        : the WHOLE solve of a 3840x2160 frame split into column slabs over the N ranks (scaling "strong").
+              rectify / true_flow / metrics : SURVEY 8(f-1) / (f-2) / (f-4) consumers on a 1280x720 frame.
+  N > 1     = one process per GPU (torch.distributed / RCCL).  full / depth: each rank solves its own frame pairs
+              (BASELINE configs[4], sequence throughput), no data-path collective -> scaling "weak".
+  --arith fused = the opt-in librsdsfm_hip_fused.so (explicit fmas in the per-pixel model) instead of the reference-arithmetic
+              default; the default line carries its whole-solve time as `full_solve_fused`.
+Frame pairs rotate through distinct HBM buffers, so the timed loops stream from HBM, not from the 256 MiB Infinity Cache.
 """
 import argparse
 import json
@@ -42,6 +37,9 @@ sys.path.insert(0, ROOT)
 ALG_BYTES_PER_PIXEL_DEPTH = 56  # read q 16 + u 16 + alpha 8 + alpha_k 8, write rho 8
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 METRIC = "Mpixels/sec RS depth+pose solve, 1280x720 pair"
+METRIC_DEPTH = "Mpixels/sec RS per-pixel depth solve (pose fixed), 1280x720 pair"
+FP64_VALU_PEAK = 39.3e12        # fp64 lane-instructions / s: 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 4 cycles per wave-instruction
+KIND_PORT = "closed-loop port (oracle C restatement; not reference-structured: no per-pixel residual objects / Ceres problem build)"
 
 
 def cpu_baseline(data, v, w, budget_s=12.0):
@@ -105,33 +103,46 @@ def cpu_baseline_all_cores(data, v, w, budget_s=6.0):
     return best
 
 
-def cpu_baseline_full(rsdsfm, trials, tol, budget_s=25.0):
-    """whole solve on the oracle for one 640x360 DeepFlow-like pair (a quarter of the pixels, same algorithm)."""
+def cpu_baseline_full(rsdsfm, np, rank, trials, tol, budget_s=20.0):
+    """The oracle's whole solve (flatten, alpha, RANSAC with the SAME trial count, refinement, sign fix, depth map, pose table) of the
+    SAME 1280x720 DeepFlow-like pair the GPU solves, single thread like Ceres' default num_threads = 1; repeated while the budget
+    lasts (one solve takes a few seconds), median reported."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle_py as O
 
-    d = rsdsfm.synth.make_config(5, rows=360, cols=640)
-    t0 = time.perf_counter()
-    q, u, qpx, fpx = O.flatten(d["flow_img"], *d["K"], d["gamma"])
-    a, ak = O.get_alpha(fpx, 360, d["gamma"]), O.get_alpha_k(qpx, fpx, 360, d["gamma"])
-    nt = max(1, min(trials, 10))
-    r = O.ransac(q, u, a, ak, False, nt, tol, O.sample_indices(len(q), nt, 1), depth_mode=1)
-    ref = O.refine(u, r["inliers"], r["alpha"], r["alpha_k"], r["v"], r["w"], r["k"], False, 1, r["inlier_idx"])
-    inl, v, _ = O.canonicalize_sign(ref["inliers"], ref["v"])
-    O.scatter_depth(inl, *d["K"], 360, 640)
-    el = time.perf_counter() - t0
-    # RANSAC cost is linear in the trial count: scale the measured time to `trials`
-    return {"value": 360 * 640 / el / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": "one 640x360 DeepFlow-like pair, whole solve with %d RANSAC trials (oracle), %.1f s" % (nt, el), "trials": nt}
+    O.lib()
+    d = rsdsfm.synth.make_config(5, seed=0x5EED0005 + rank)
+    rows, cols = d["rows"], d["cols"]
+    times = []
+    t_all = time.perf_counter()
+    while True:
+        t0 = time.perf_counter()
+        q, u, qpx, fpx = O.flatten(d["flow_img"], *d["K"], d["gamma"])
+        a, ak = O.get_alpha(fpx, rows, d["gamma"]), O.get_alpha_k(qpx, fpx, rows, d["gamma"])
+        r = O.ransac(q, u, a, ak, False, trials, tol, O.sample_indices(len(q), trials, 1), depth_mode=1)
+        ref = O.refine(u, r["inliers"], r["alpha"], r["alpha_k"], r["v"], r["w"], r["k"], False, 1, r["inlier_idx"])
+        inl, v, _ = O.canonicalize_sign(ref["inliers"], ref["v"])
+        O.scatter_depth(inl, *d["K"], rows, cols)
+        O.pose_table(v, ref["w"], ref["k"], d["gamma"], rows)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_all + times[-1] > budget_s or len(times) >= 20:
+            break
+    med = sorted(times)[len(times) // 2]
+    return {"value": rows * cols / med / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "port", "kind_detail": KIND_PORT,
+            "host_cores": os.cpu_count(), "seconds_per_solve": med,
+            "sample": "%d x the whole solve of the same 1280x720 DeepFlow-like pair with the same %d RANSAC trials (oracle chain, 1 thread), "
+                      "median of %d; %.1f s in total" % (len(times), trials, len(times), sum(times)), "trials": trials}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="timed steps (default per workload: 160 chunks of 64 pairs for the depth workloads)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default per workload: 100 whole solves; 160 chunks of 64 pairs for the depth workloads)")
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="depth", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify", "true_flow", "metrics"])
+    ap.add_argument("--workload", default="full", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify", "true_flow", "metrics"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-records", action="store_true", help="full workload: skip depth_only / full_solve_batched / full_solve_fused (profiling runs)")
+    ap.add_argument("--arith", default="reference", choices=["reference", "fused"], help="library: reference arithmetic (default) or the opt-in fused-fma build")
     ap.add_argument("--nbuf", type=int, default=7, help="rotating HBM buffer sets (7 x 59 MB > 256 MiB L3)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU feeding independent batches (sequence-throughput mode, BASELINE configs[4])")
     ap.add_argument("--pairs-per-step", type=int, default=64, help="depth workloads: one step = one chunk of this many consecutive frame pairs of the sequence (default 64)")
@@ -140,11 +151,11 @@ def main():
     ap.add_argument("--trials", type=int, default=50, help="RANSAC trials of the full solve (report section 5.4 used 50)")
     ap.add_argument("--tol", type=float, default=0.05, help="RANSAC tolerance (reference main.cc:310)")
     args = ap.parse_args()
-    dsteps = {"depth": 160, "depth_closed_form": 160, "full": 500, "tiled": 2000, "tiled_full": 100, "rectify": 2000, "true_flow": 500, "metrics": 2000}
+    dsteps = {"depth": 160, "depth_closed_form": 160, "full": 100, "tiled": 2000, "tiled_full": 100, "rectify": 2000, "true_flow": 500, "metrics": 2000}
     if args.steps is None:
         args.steps = dsteps[args.workload]
     if args.warmup is None:
-        args.warmup = max(2, args.steps // 25)
+        args.warmup = max(3, args.steps // 25)
 
     import numpy as np
     import torch  # first: one HIP runtime per process (torch's), shared with librsdsfm_hip.so
@@ -176,7 +187,7 @@ def main():
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
-    solver = rsdsfm.Solver(local_rank, stream=stream.cuda_stream)
+    solver = rsdsfm.Solver(local_rank, stream=stream.cuda_stream, arith=args.arith)
     if args.depth_variant is not None:
         solver.set_depth_variant(args.depth_variant)
 
@@ -203,17 +214,19 @@ def main():
         return el
 
     line = {"metric": METRIC, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "higher_is_better": True, "vs_baseline": None, "dtype": "f64", "data": "synthetic"}
+            "higher_is_better": True, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "arith": args.arith}
 
     # =================================================================================================
-    if args.workload in ("depth", "depth_closed_form"):
+    def run_depth(workload, steps, warmup, side_records=True, cpu_budget=12.0):
+        """BASELINE configs[1]: the dense depth solve alone (pose fixed) in batched sequence-throughput mode; returns the record"""
+        rec = {}
         data = rsdsfm.synth.make_config(2, seed=0x5EED0002 + rank)  # 1280x720, analytic scene, noise-free
         rows, cols = data["rows"], data["cols"]
         n = len(data["q"])
         t = data["truth"]
         v = t["v"] / np.linalg.norm(t["v"])  # unit translation, as the minimal solver returns it (minimal.cc:102-105)
         w, k = t["w"], 0.0
-        mode = rsdsfm.DEPTH_CERES_LM if args.workload == "depth" else rsdsfm.DEPTH_CLOSED_FORM
+        mode = rsdsfm.DEPTH_CERES_LM if workload == "depth" else rsdsfm.DEPTH_CLOSED_FORM
         # Sequence-throughput mode: B independent pairs per launch (batched fast path: grid y = pair, one context per pair owns
         # its LM state and partial sums) on each of S HIP streams; nothing is shared between pairs.  The latency-bound
         # follow-up launch, the launch floor and the ramp / tail of the streaming pass are amortised over B pairs and
@@ -229,7 +242,7 @@ def main():
             if st is stream and not extra_solvers:
                 extra_solvers.append(None)  # the first context on stream 0 is the bench's main solver
                 return solver
-            sv = rsdsfm.Solver(local_rank, stream=st.cuda_stream)
+            sv = rsdsfm.Solver(local_rank, stream=st.cuda_stream, arith=args.arith)
             if args.depth_variant is not None:
                 sv.set_depth_variant(args.depth_variant)
             extra_solvers.append(sv)
@@ -259,7 +272,7 @@ def main():
         order = [groups[(i % S) * G + (i // S) % G] for i in range(S * G)]  # alternate the streams
         torch.cuda.synchronize()
         P = max(1, args.pairs_per_step)
-        npairs, nwarm = args.steps * P, args.warmup * P  # one step = one chunk of P consecutive frame pairs of the sequence
+        npairs, nwarm = steps * P, warmup * P  # one step = one chunk of P consecutive frame pairs of the sequence
         nfull, rem = divmod(npairs, B)
         rem_call = None
         if rem:  # exactly `steps` x P pairs are timed: the last call is a smaller batch over the first contexts of one group
@@ -319,8 +332,8 @@ def main():
             alg_bytes = ALG_BYTES_PER_PIXEL_DEPTH * n * B
             achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
             job = ALG_BYTES_PER_PIXEL_DEPTH * n / (el / npairs) / 1e9
-            line.update({
-                "value": rows * cols * world * npairs / el / 1e6, "ms_per_step": el / args.steps * 1e3, "scaling": "weak",
+            rec.update({
+                "value": rows * cols * world * npairs / el / 1e6, "ms_per_step": el / steps * 1e3, "scaling": "weak",
                 "config": {"workload": "BASELINE configs[1]: synthetic 1280x720 pairs, per-pixel depth solve only (%s), pose fixed; "
                                        "%d independent pairs per launch on each of %d HIP streams per GPU (one solver context per pair), %d "
                                        "rotating HBM buffer sets" % ("Ceres-1.14 LM emulation" if mode == 1 else "closed-form GN", B, S, B * S * G),
@@ -333,7 +346,7 @@ def main():
                            "verified": bool(max_rel < 1e-8 and (mode != 1 or (extra == 0 and summary is not None and summary["termination"] >= 0)))},
                 "roofline": {"bound": "hbm", "kernel": ("depth_lm_batch_kernel (%d pairs per launch)" % B) if mode == 1 else "depth_closed_form_kernel",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                             "traffic": _traffic("depth_batch%d" % B if mode == 1 else args.workload), "alg_bytes_per_launch": alg_bytes,
+                             "traffic": _traffic("depth_batch%d" % B if mode == 1 else workload), "alg_bytes_per_launch": alg_bytes,
                              "avg_launch_ms": kern_ms, "median_launch_ms": kern_med,
                              "note": "launch duration measured with the other streams idle (bursts on one stream); profiles/: rocprofv3 "
                                      "of `bench.py --streams 1`"},
@@ -341,28 +354,43 @@ def main():
                 "roofline_job": {"bound": "hbm", "achieved": job, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": job / HBM_PEAK_GBS,
                                  "pairs_per_launch": B, "streams": S},
             })
-        # the whole solve, reported beside the headline (not the timed `value`)
-        full = _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps=8, warmup=2, timed=timed) if args.workload == "depth" else None
-        batched = _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, 4, per_thread=40) if (args.workload == "depth" and B * S > 1) else None
-        if rank == 0:
-            line["full_solve"] = full
-            line["full_solve_batched"] = batched
-            line["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(data, v, w)
-            line["cpu_baseline_all_cores"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline_all_cores(data, v, w)
+        if rank == 0 and side_records:
+            rec["cpu_baseline"] = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(data, v, w, budget_s=cpu_budget)
+            rec["cpu_baseline_all_cores"] = None if (args.no_cpu_baseline or world > 1 or cpu_budget < 8) else cpu_baseline_all_cores(data, v, w)
         for sv in extra_solvers:
             if sv is not None:
                 sv.close()
+        return rec
+
+    # =================================================================================================
+    if args.workload in ("depth", "depth_closed_form"):
+        rec = run_depth(args.workload, args.steps, args.warmup)
+        if rank == 0:
+            line["metric"] = METRIC_DEPTH
+            line.update(rec)
 
     # =================================================================================================
     elif args.workload == "full":
         full = _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps=args.steps, warmup=args.warmup, timed=timed)
+        roof = _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full) if rank == 0 else None
+        side = not args.no_side_records
+        batched = _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, 4, per_thread=40) if side else None
+        fused = None
+        if side and args.arith == "reference" and rank == 0:
+            with rsdsfm.Solver(local_rank, stream=stream.cuda_stream, arith="fused") as sf:
+                fr = _full_solve(rsdsfm, sf, torch, dev, np, rank, args, steps=max(20, args.steps // 2), warmup=3, timed=lambda st, k2, w2: _plain_timed(torch, st, k2, w2))
+            fused = {k2: fr[k2] for k2 in ("value", "unit", "ms_per_solve", "median_ms_per_solve", "num_inliers")}
+            fused["note"] = "same workload on the opt-in librsdsfm_hip_fused.so (explicit fmas in the per-pixel model); not the headline"
+        depth_only = run_depth("depth", 40, 3, side_records=False) if side else None
         if rank == 0:
-            line.update({"value": full["value"] * world, "ms_per_step": full["ms_per_solve"], "scaling": "weak",
-                         "config": {"workload": "whole solve of a 1280x720 DeepFlow-like pair (BASELINE configs[4] data): flatten + "
-                                                "RANSAC(%d, tol %g) + refinement + depth map + pose table; one pair per GPU" % (args.trials, args.tol),
-                                    **{k2: full[k2] for k2 in ("rows", "cols", "trials", "num_inliers", "refine_summary")}},
-                         "roofline": None, "full_solve": full,
-                         "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_full(rsdsfm, args.trials, args.tol)})
+            line.update({"value": full["value"] * world, "ms_per_step": full["ms_per_solve"], "median_ms_per_solve": full["median_ms_per_solve"], "scaling": "weak",
+                         "config": {"workload": "BASELINE metric: WHOLE depth+pose solve of a synthetic 1280x720 DeepFlow-like pair (BASELINE configs[4] data: 0.3 px noise, "
+                                                "10 %% outliers): flatten + alpha, RANSAC(%d trials, tol %g) = 9-point minimal solver + Ceres-LM depth solve of all pixels per "
+                                                "trial + scoring, joint nonlinear refinement, sign fix + depth map, pose table; ONE C-ABI call per pair, one pair at a time, "
+                                                "one pair per GPU" % (args.trials, args.tol),
+                                    **{k2: full[k2] for k2 in ("rows", "cols", "trials", "tol", "n", "num_inliers", "refine_summary", "w_err", "v_angle_deg")}},
+                         "roofline": roof, "full_solve_batched": batched, "full_solve_fused": fused, "depth_only": depth_only,
+                         "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_full(rsdsfm, np, rank, args.trials, args.tol)})
 
     # =================================================================================================
     elif args.workload == "rectify":
@@ -619,29 +647,124 @@ def _traffic(workload):
     return None
 
 
+def _plain_timed(torch, step, steps, warmup):
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
 def _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps, warmup, timed):
-    """whole solve on a 1280x720 DeepFlow-like pair (0.3 px noise, 10 % outliers), flow image resident in HBM"""
+    """whole solve on a 1280x720 DeepFlow-like pair (0.3 px noise, 10 % outliers), flow image resident in HBM; the sampler seed
+    changes every step (different hypotheses, different winner)"""
     d = rsdsfm.synth.make_config(5, seed=0x5EED0005 + rank)
     rows, cols = d["rows"], d["cols"]
     imgs = [torch.from_numpy(d["flow_img"]).to(dev) for _ in range(3)]
     depth_map = torch.empty((cols, rows), dtype=torch.float64, device=dev)  # column-major rows x cols
     R, tt = torch.empty((rows, 9), dtype=torch.float64, device=dev), torch.empty((rows, 3), dtype=torch.float64, device=dev)
     out = {}
+    per_step = []
 
-    def step(i):  # ONE C-ABI call per frame pair (rsdsfm_solve_frame_dev)
+    def step(i):  # ONE C-ABI call per frame pair (rsdsfm_solve_frame_dev); it returns after its last result has reached the host
+        t0 = time.perf_counter()
         out["r"] = solver.solve_frame_dev(imgs[i % 3].data_ptr(), rows, cols, d["K"], d["gamma"], depth_map.data_ptr(), R.data_ptr(),
                                           tt.data_ptr(), trials=args.trials, tol=args.tol, seed=1 + i)
+        per_step.append(time.perf_counter() - t0)
 
     el = timed(step, steps, warmup)
     r = out["r"]
     t = d["truth"]
     vt = t["v"] / np.linalg.norm(t["v"])
     vv = r["v"] / np.linalg.norm(r["v"])
+    ts = sorted(per_step[-steps:])
     return {"value": d["rows"] * d["cols"] * steps / el / 1e6, "unit": "Mpixels/s", "ms_per_solve": el / steps * 1e3,
+            "median_ms_per_solve": ts[len(ts) // 2] * 1e3, "min_ms_per_solve": ts[0] * 1e3,
             "rows": d["rows"], "cols": d["cols"], "trials": args.trials, "tol": args.tol, "n": r["n"], "num_inliers": r["num_inliers"],
-            "refine_summary": r["refine_summary"],
+            "refine_summary": r["refine_summary"], "K": d["K"], "gamma": d["gamma"], "_img": imgs[0],
             "w_err": float(np.linalg.norm(r["w"] - t["w"])), "v_angle_deg": float(np.degrees(np.arccos(min(1.0, abs(float(vv @ vt)))))),
             "stages": "flatten+alpha, minimal9 x %d, RANSAC LM sums/decide/score/pick/compaction, refinement, depth map, pose table" % args.trials}
+
+
+def _counters(kernel):
+    """per-launch PMC counter means of `kernel` from profiles/counters.json (rocprofv3 --pmc passes of `bench.py`, see
+    profiles/collect.sh); None when absent"""
+    f = os.path.join(ROOT, "profiles", "counters.json")
+    try:
+        return json.load(open(f)).get(kernel)
+    except Exception:
+        return None
+
+
+def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):
+    """Roofline record of the whole solve's dominant kernel, ransac_lm_kernel<true> (round 0 of the hypothesis-batched LM depth
+    solves: 43 % of the solve), measured LIVE: the kernel is launched alone through rsdsfm_ransac_lm_launch_dev on the pair's real
+    flattened arrays and real hypotheses (sampler + minimal9) and bracketed with HIP events on the stream it runs on.  Its bound is
+    fp64 VALU issue, not HBM: `achieved` = fp64 lane-instructions of one launch (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes,
+    rocprofv3 PMC pass committed as profiles/counters.json) / the measured duration; `peak` = 39.3e12 / s.  "hbm" = SURVEY 8(d):
+    (57 N + 64 M iterations) bytes / the solve's time / 8 TB/s."""
+    rows, cols, T = full["rows"], full["cols"], args.trials
+    N = rows * cols
+    img = full.pop("_img")
+    q = torch.empty(2 * N, dtype=torch.float64, device=dev)
+    u = torch.empty(2 * N, dtype=torch.float64, device=dev)
+    a = torch.empty(N, dtype=torch.float64, device=dev)
+    ak = torch.empty(N, dtype=torch.float64, device=dev)
+    n = solver.flatten_dev(img.data_ptr(), rows, cols, full["K"], full["gamma"], q.data_ptr(), u.data_ptr(), a.data_ptr(), ak.data_ptr())
+    smp = rsdsfm.sample_indices(n, T, 1).reshape(-1).astype(np.int64)
+    idx = torch.from_numpy(smp).to(dev)
+    q9 = q.view(-1, 2)[idx].contiguous()
+    u9 = u.view(-1, 2)[idx].contiguous()
+    a9, ak9 = a[idx].contiguous(), ak[idx].contiguous()
+    hyp = torch.empty((T, 8), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    solver.minimal9_dev(q9.data_ptr(), u9.data_ptr(), a9.data_ptr(), ak9.data_ptr(), T, 0, 0, hyp.data_ptr())
+    solver.synchronize()
+
+    def launch():
+        solver.ransac_lm_launch_dev(q.data_ptr(), u.data_ptr(), a.data_ptr(), ak.data_ptr(), n, hyp.data_ptr(), T, args.tol)
+
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    # one launch per event pair with the device drained in between, as inside a solve (the kernel follows the latency-bound
+    # minimal9_kernel there; back-to-back bursts of this fp64-saturated kernel run ~8 % slower: sustained-power clocks)
+    reps = 24
+    ts = []
+    for i in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        launch()
+        e1.record(stream)
+        torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1))
+        time.sleep(0.0005)
+    ts.sort()
+    kern_ms = float(np.mean(ts))
+    kname = "ransac_lm_kernel<true, 3>"
+    ctr = _counters(kname + (":fused" if args.arith == "fused" else ""))
+    insts = achieved = frac = traffic = None
+    if ctr:
+        insts = 64.0 * sum(ctr.get(k2, 0.0) for k2 in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
+        achieved = insts / (kern_ms * 1e-3)
+        frac = achieved / FP64_VALU_PEAK
+        if "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:  # KB; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section)
+            traffic = (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0
+    iters = full["refine_summary"]["num_iterations"]
+    hbm_bytes = 57.0 * full["n"] + 64.0 * full["num_inliers"] * iters
+    hbm_gbs = hbm_bytes / (full["median_ms_per_solve"] * 1e-3) / 1e9
+    return {"bound": "fp64-valu", "kernel": kname, "achieved": None if achieved is None else achieved / 1e12, "peak": FP64_VALU_PEAK / 1e12,
+            "unit": "T fp64 lane-instructions/s", "frac": frac, "traffic": traffic,
+            "fp64_lane_instructions_per_launch": insts, "avg_launch_ms": kern_ms, "median_launch_ms": float(ts[len(ts) // 2]),
+            "pixel_hypotheses_per_launch": int(n) * T, "alg_bytes_per_launch": 48 * int(n),
+            "share_of_solve": kern_ms / full["median_ms_per_solve"],
+            "hbm": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
+                    "alg_bytes_per_solve": hbm_bytes, "formula": "57 N + 64 M iterations (SURVEY 8 d), N = %d, M = %d, iterations = %d, over the median solve time" % (full["n"], full["num_inliers"], iters)},
+            "note": "the whole solve is bound by fp64 VALU issue and by serial latency chains (9x9 Jacobi SVD), not by HBM: its HBM fraction is reported "
+                    "because the metric asks for it; counters: profiles/counters.json (rocprofv3 --pmc of this command)"}
 
 
 def _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, S, per_thread):
@@ -658,7 +781,7 @@ def _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, S, per_threa
     def worker(j):
         st = torch.cuda.Stream(dev)
         with torch.cuda.stream(st):
-            sv = rsdsfm.Solver(local_rank, stream=st.cuda_stream)
+            sv = rsdsfm.Solver(local_rank, stream=st.cuda_stream, arith=args.arith)
             img = img0.clone()
             dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
             for i in range(2):

@@ -114,6 +114,11 @@ int rsdsfm_synchronize(rsdsfm_ctx* ctx);
  * the separate decide kernel; 2 = the decision fused into the tail of launch 0 (experimental, measured slower); 3 = launch
  * 0, separate decide kernel, follow-up launch (the fast path before the fusion).  Same arithmetic, same results. */
 int rsdsfm_set_depth_variant(rsdsfm_ctx* ctx, int variant);
+/* LM iterations that round 0 of the hypothesis-batched depth solves inside rsdsfm_ransac* speculates per pixel: 3 (default, also
+ * selected by 0) decides every hypothesis that ends with <= 2 accepted steps in one pass; 2 is cheaper when every hypothesis stops
+ * after ONE accepted step (outlier-dominated data); hypotheses that need more take a continuation round.  Integer results (counts,
+ * masks, LM steps, winner) are identical for both; the inlier-error sums of two-step hypotheses can differ in their last bits. */
+int rsdsfm_set_ransac_speculation(rsdsfm_ctx* ctx, int k0);
 /* name of the HIP kernel that dominates the given entry point (for profiling / roofline reports) */
 const char* rsdsfm_kernel_name(const char* entry_point);
 
@@ -188,6 +193,11 @@ typedef struct rsdsfm_frame_params {
     int32_t use_refinement;       /* main.cc:307                                                        */
     int32_t depth_mode;           /* RSDSFM_DEPTH_*                                                     */
     int32_t k_sign_mode;          /* RSDSFM_K_*                                                         */
+    int32_t flow_index_mode;      /* RSDSFM_FLOW_*: how nonLinearRefinement indexes the flow.  0 = COMPAT_RANK, what
+                                     evaluateSingleRun does (main.cc:457 passes the UN-compacted flow and
+                                     nonlinearRefinement.cc:209-212 reads column i for the i-th inlier, quirk Q2);
+                                     1 = GATHERED (column inlier_idx[i])                                  */
+    int32_t use_global_shutter_mode; /* main.cc:305, :441-444: alpha = 1 for every point (overrides the RS model) */
     int32_t _pad;
     double ransac_tol;            /* main.cc:310 (0.05)                                                 */
     double flow_threshold;        /* main.cc:311 (1e-10)                                                */
@@ -206,8 +216,10 @@ typedef struct rsdsfm_frame_result {
 } rsdsfm_frame_result;
 
 /* flow image (rows x cols x 2, row-major) resident in HBM -> pose, depth map (rows x cols column-major, DEVICE) and
- * per-scanline pose table (DEVICE, may be NULL).  Runs flatten, ransac, nonLinearRefinement (gathered flow), the sign
- * flip / depth scatter and setRelativePose back to back on the context's stream. */
+ * per-scanline pose table (DEVICE, may be NULL).  Runs flatten (+ the global-shutter override of alpha), ransac,
+ * nonLinearRefinement (flow indexed as params->flow_index_mode says), the sign flip / depth scatter and
+ * setRelativePose back to back on the context's stream.  A zero-initialised rsdsfm_frame_params with the trial count,
+ * tolerances and use_refinement set reproduces evaluateSingleRun's call sequence (main.cc:398-522). */
 int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t rows, int32_t cols, double fx, double fy,
                            double cx, double cy, double gamma, const rsdsfm_frame_params* params,
                            double* d_depth_map_colmajor, double* d_R_rows9_or_null, double* d_t_rows3_or_null,
@@ -219,6 +231,12 @@ int rsdsfm_ransac_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n,
                       const double* d_alpha_k_n, int64_t n, int use_alpha_k, int32_t iterations, double tolerance,
                       const int32_t* samples_9xT_or_null, uint64_t seed, int depth_mode, int k_sign_mode,
                       rsdsfm_ransac_out* out);
+/* Profiling hook: ONE launch of the dominant kernel of the whole solve alone -- round 0 of the hypothesis-batched speculative
+ * LM depth solves of minimal::ransac's trial loop (minimal.cc:230-289; `ransac_lm_kernel<true>`) over `count` (<= 128)
+ * hypotheses d_hyp[count][8] (what rsdsfm_minimal9_dev writes).  No decisions are taken and nothing is returned: it exists so
+ * that bench.py can bracket exactly this kernel with HIP events for the roofline record. */
+int rsdsfm_ransac_lm_launch_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n, const double* d_alpha_n,
+                                const double* d_alpha_k_n, int64_t n, const double* d_hyp, int32_t count, double tolerance);
 /* nonLinearRefinement on device-resident inputs (d_inlier_idx may be NULL in compat mode).  v/w/k and the
  * summary are HOST.  Polls the device-resident termination flag every few LM iterations. */
 int rsdsfm_refine_dev(rsdsfm_ctx* ctx, const double* d_flow2n, int64_t n_flow, int64_t m, const double* d_inliers_3m,

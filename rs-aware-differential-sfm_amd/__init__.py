@@ -55,7 +55,8 @@ class LmSummary(C.Structure):
 
 class FrameParams(C.Structure):
     _fields_ = [("ransac_trials", C.c_int32), ("use_acceleration_mode", C.c_int32), ("use_refinement", C.c_int32),
-                ("depth_mode", C.c_int32), ("k_sign_mode", C.c_int32), ("_pad", C.c_int32), ("ransac_tol", C.c_double),
+                ("depth_mode", C.c_int32), ("k_sign_mode", C.c_int32), ("flow_index_mode", C.c_int32), ("use_global_shutter_mode", C.c_int32),
+                ("_pad", C.c_int32), ("ransac_tol", C.c_double),
                 ("flow_threshold", C.c_double), ("seed", C.c_uint64)]
 
 
@@ -190,6 +191,10 @@ class Solver:
     def set_depth_variant(self, variant):
         """0 = register-staged fused LM kernel (default), 1 = LDS-DMA double-buffered variant"""
         self._check(self.lib.rsdsfm_set_depth_variant(self._ctx, int(variant)), "rsdsfm_set_depth_variant")
+
+    def set_ransac_speculation(self, k0):
+        """LM iterations speculated by round 0 of RANSAC's batched depth solves: 3 (default; 0 selects it) or 2"""
+        self._check(self.lib.rsdsfm_set_ransac_speculation(self._ctx, int(k0)), "rsdsfm_set_ransac_speculation")
 
     def synchronize(self):
         self._check(self.lib.rsdsfm_synchronize(self._ctx), "rsdsfm_synchronize")
@@ -333,6 +338,10 @@ class Solver:
         return dict(num_inliers=int(out.num_inliers), best_trial=int(out.best_trial), w=np.array(out.w[:]), v=np.array(out.v[:]), k=float(out.k),
                     inlier_error=float(out.inlier_error), trial_count=tc[:T], trial_steps=ts[:T])
 
+    def ransac_lm_launch_dev(self, d_q, d_u, d_alpha, d_alpha_k, n, d_hyp, count, tolerance):
+        """profiling hook: one launch of ransac_lm_kernel<true> alone (see include/rsdsfm.h)"""
+        self._check(self.lib.rsdsfm_ransac_lm_launch_dev(self._ctx, _dp(d_q), _dp(d_u), _dp(d_alpha), _dp(d_alpha_k), C.c_int64(n), _dp(d_hyp), C.c_int32(count), C.c_double(tolerance)), "rsdsfm_ransac_lm_launch_dev")
+
     def refine_dev(self, d_flow, n_flow, m, d_inl, d_alpha, d_alpha_k, d_idx, v, w, k, const_acceleration, flow_index_mode, d_inl_out):
         vo, wo, ko = (C.c_double * 3)(), (C.c_double * 3)(), C.c_double()
         sm = LmSummary()
@@ -350,10 +359,13 @@ class Solver:
         self._check(self.lib.rsdsfm_pose_table_dev(self._ctx, _v3(v), _v3(w), C.c_double(k), C.c_double(gamma), C.c_int32(rows), _dp(d_R), _dp(d_t)), "rsdsfm_pose_table_dev")
 
     def solve_frame_dev(self, d_flow_img, rows, cols, K, gamma, d_depth_map, d_R=None, d_t=None, trials=50, tol=0.05, seed=1,
-                        use_acceleration_mode=False, use_refinement=True, depth_mode=DEPTH_CERES_LM, k_sign_mode=K_COMPAT, flow_threshold=1e-10):
-        """the whole solve of one frame pair in ONE C-ABI call (rsdsfm_solve_frame_dev)"""
-        prm = FrameParams(int(trials), int(use_acceleration_mode), int(use_refinement), int(depth_mode), int(k_sign_mode), 0,
-                          float(tol), float(flow_threshold), int(seed))
+                        use_acceleration_mode=False, use_refinement=True, depth_mode=DEPTH_CERES_LM, k_sign_mode=K_COMPAT, flow_threshold=1e-10,
+                        flow_index_mode=FLOW_COMPAT_RANK, use_global_shutter_mode=False):
+        """the whole solve of one frame pair in ONE C-ABI call (rsdsfm_solve_frame_dev).  Defaults = evaluateSingleRun: the
+        refinement reads the flow by inlier RANK (quirk Q2, main.cc:457); pass flow_index_mode=FLOW_GATHERED for the flow of each
+        inlier's own pixel."""
+        prm = FrameParams(int(trials), int(use_acceleration_mode), int(use_refinement), int(depth_mode), int(k_sign_mode),
+                          int(flow_index_mode), int(use_global_shutter_mode), 0, float(tol), float(flow_threshold), int(seed))
         res = FrameResult()
         d = C.c_double
         self._check(self.lib.rsdsfm_solve_frame_dev(self._ctx, _dp(d_flow_img), C.c_int32(rows), C.c_int32(cols), d(K[0]), d(K[1]), d(K[2]), d(K[3]),

@@ -75,7 +75,7 @@ using namespace rsdsfm;
 #define CTX_OR_FAIL(ctx)                  \
     if (!(ctx)) return RSDSFM_ERR_INVALID; \
     Ctx* c = &(ctx)->c;                    \
-    (void)c
+    DeviceGuard device_guard_(c)
 
 extern "C" {
 
@@ -94,11 +94,18 @@ int rsdsfm_create(rsdsfm_ctx** out, int device, void* stream_or_null) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return RSDSFM_ERR_NO_DEVICE;
     if (device < 0 || device >= count) return RSDSFM_ERR_NO_DEVICE;
-    if (hipSetDevice(device) != hipSuccess) return RSDSFM_ERR_HIP;
     rsdsfm_ctx* ctx = new (std::nothrow) rsdsfm_ctx();
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
     c->device = device;
+    DeviceGuard device_guard_(c);  // the caller's current device is restored on return
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != device) {
+            delete ctx;
+            return RSDSFM_ERR_HIP;
+        }
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->num_cus = prop.multiProcessorCount;
     if (stream_or_null) {
@@ -134,6 +141,7 @@ int rsdsfm_create(rsdsfm_ctx** out, int device, void* stream_or_null) {
 void rsdsfm_destroy(rsdsfm_ctx* ctx) {
     if (!ctx) return;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_partials) (void)hipFree(c->d_partials);
@@ -164,6 +172,13 @@ int rsdsfm_set_depth_variant(rsdsfm_ctx* ctx, int variant) {
     if (variant < 0 || variant > 3) return fail(c, RSDSFM_ERR_INVALID, "depth variant must be 0 (default), 1 (LDS-DMA), 2 (decision fused into launch 0) or 3 (separate decide kernel)");
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     c->depth_variant = variant;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_set_ransac_speculation(rsdsfm_ctx* ctx, int k0) {
+    CTX_OR_FAIL(ctx);
+    if (k0 != 0 && k0 != 2 && k0 != KMAX) return fail(c, RSDSFM_ERR_INVALID, "ransac speculation depth must be 0 (default = 3), 2 or 3");
+    c->ransac_k0 = k0 == 2 ? 2 : KMAX;
     return RSDSFM_OK;
 }
 
@@ -221,6 +236,7 @@ static int depth_batch_common(rsdsfm_ctx* const* ctxs, int32_t count, const doub
                               const double* const* d_alpha_k, double* const* d_rho, int launch0_only) {
     if (!ctxs || count < 1 || !ctxs[0]) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctxs[0]->c;
+    DeviceGuard device_guard_(c);
     if (count > kDepthBatchMax) return fail(c, RSDSFM_ERR_INVALID, "at most 8 solves per batched launch");
     if (!d_q || !d_u || !n || !v3 || !w3 || !k || !d_alpha || !d_alpha_k || !d_rho) return fail(c, RSDSFM_ERR_INVALID, "null argument array");
     Ctx* cs[kDepthBatchMax];

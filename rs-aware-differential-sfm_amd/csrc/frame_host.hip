@@ -12,6 +12,7 @@ int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const
                   const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
                   int const_acceleration, int flow_index_mode, double* d_inl_out, double v_out[3], double w_out[3], double* k_out,
                   rsdsfm_lm_summary* summary);
+int alpha_ones_launch(Ctx* c, double* d_alpha, int64_t n);
 }  // namespace rsdsfm
 
 using namespace rsdsfm;
@@ -23,7 +24,9 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
                            double* d_t_rows3, rsdsfm_frame_result* res) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (!prm || !res || rows <= 0 || cols <= 0 || !d_flow_img || !d_depth_map) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    if (prm->flow_index_mode != RSDSFM_FLOW_COMPAT_RANK && prm->flow_index_mode != RSDSFM_FLOW_GATHERED) return fail(c, RSDSFM_ERR_INVALID, "unknown flow_index_mode");
     const size_t N = (size_t)rows * (size_t)cols;
     // frame buffers live in the context's frame arena (separate from the per-stage workspace)
     const size_t need = 2 * Arena::need(16 * N) + 4 * Arena::need(8 * N) + 2 * Arena::need(24 * N) + Arena::need(8 * N) + Arena::need(N) +
@@ -54,6 +57,10 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
     int rc = rsdsfm_flatten_dev(ctx, d_flow_img, rows, cols, fx, fy, cx, cy, gamma, prm->flow_threshold, d_q, d_u, d_a, d_ak, &n);
     if (rc != RSDSFM_OK) return rc;
     res->n_points = n;
+    if (prm->use_global_shutter_mode) {  // main.cc:441-444: alpha *= 0; alpha += 1
+        rc = alpha_ones_launch(c, d_a, n);
+        if (rc != RSDSFM_OK) return rc;
+    }
     rsdsfm_ransac_out ro;
     memset(&ro, 0, sizeof(ro));
     ro.inlier_idx = d_idx;
@@ -73,7 +80,7 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
     double* d_final = d_inl;
     if (prm->use_refinement) {
         rc = refine_device(c, d_u, n, ro.num_inliers, d_inl, d_in_a, d_in_ak, d_idx, v, w, k, prm->use_acceleration_mode,
-                           RSDSFM_FLOW_GATHERED, d_inl_ref, v, w, &k, &res->refine_summary);
+                           prm->flow_index_mode, d_inl_ref, v, w, &k, &res->refine_summary);
         if (rc != RSDSFM_OK) return rc;
         d_final = d_inl_ref;
     }

@@ -43,6 +43,7 @@ extern "C" {
 int rsdsfm_flatten_dev(rsdsfm_ctx* ctx, const double* d_img, int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,
                        double gamma, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* n_out) {
     if (!ctx) return RSDSFM_ERR_INVALID;
+    DeviceGuard device_guard_(&ctx->c);
     return flatten_device(&ctx->c, d_img, rows, cols, 0, fx, fy, cx, cy, gamma, thr, d_q, d_u, d_alpha, d_alpha_k, n_out);
 }
 
@@ -50,6 +51,7 @@ int rsdsfm_flatten_slab_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int32_t r
                             double fy, double cx, double cy, double gamma, double thr, double* d_q, double* d_u, double* d_alpha,
                             double* d_alpha_k, int64_t* n_out) {
     if (!ctx) return RSDSFM_ERR_INVALID;
+    DeviceGuard device_guard_(&ctx->c);
     return flatten_device(&ctx->c, d_img_slab, rows, slab_cols, col0, fx, fy, cx, cy, gamma, thr, d_q, d_u, d_alpha, d_alpha_k, n_out);
 }
 
@@ -57,6 +59,7 @@ int rsdsfm_flatten(rsdsfm_ctx* ctx, const double* img, int32_t rows, int32_t col
                    double gamma, double thr, double* q, double* u, double* alpha, double* alpha_k, int64_t* n_out) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (rows < 0 || cols < 0 || !n_out) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     const size_t N = (size_t)rows * (size_t)cols;
     if (N == 0) {
@@ -91,6 +94,7 @@ int rsdsfm_flatten(rsdsfm_ctx* ctx, const double* img, int32_t rows, int32_t col
 int rsdsfm_depth_map_dev(rsdsfm_ctx* ctx, double* d_inl, int64_t m, double v_inout[3], double fx, double fy, double cx, double cy,
                          int32_t rows, int32_t cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, int* flipped) {
     if (!ctx) return RSDSFM_ERR_INVALID;
+    DeviceGuard device_guard_(&ctx->c);
     return depth_map_device(&ctx->c, d_inl, m, v_inout, fx, fy, cx, cy, rows, cols, d_depth_map, d_xs, d_ys, flipped, nullptr, 0.0, 0.0,
                             nullptr, nullptr);
 }
@@ -140,6 +144,7 @@ int rsdsfm_depth_map(rsdsfm_ctx* ctx, double* inl, int64_t m, double v_inout[3],
                      int32_t rows, int32_t cols, double* depth_map, int32_t* xs, int32_t* ys, int* flipped) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (m < 0 || rows < 0 || cols < 0 || !v_inout || (m > 0 && !inl)) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     const size_t M = (size_t)m, npix = (size_t)rows * (size_t)cols;
     if (npix > 0 && !depth_map) return fail(c, RSDSFM_ERR_INVALID, "null depth_map");
@@ -165,6 +170,7 @@ int rsdsfm_pose_table_dev(rsdsfm_ctx* ctx, const double v[3], const double w[3],
                           double* d_t) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (rows < 0 || !v || !w || (rows > 0 && (!d_R || !d_t))) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     Pose pose;
     memcpy(pose.v, v, sizeof(pose.v));

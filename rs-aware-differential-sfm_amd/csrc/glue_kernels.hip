@@ -59,6 +59,20 @@ static inline int stream_grid(int64_t n) {
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
 }
 
+// global-shutter override of evaluateSingleRun (main.cc:441-444): alpha = alpha * 0 + 1 for every point, evaluated literally
+// (a NaN / inf alpha stays NaN exactly like `alpha *= 0; alpha += 1` on the Eigen array)
+__global__ __launch_bounds__(256) void alpha_ones_kernel(double* __restrict__ alpha, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) alpha[i] = alpha[i] * 0.0 + 1.0;
+}
+
+int alpha_ones_launch(Ctx* c, double* d_alpha, int64_t n) {
+    if (n <= 0) return RSDSFM_OK;
+    const int grid = (int)std::min<int64_t>((n + 255) / 256, (int64_t)c->num_cus * 8);
+    hipLaunchKernelGGL(alpha_ones_kernel, dim3(grid), dim3(256), 0, c->stream, d_alpha, n);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
 int alpha_launch(Ctx* c, const double* flow_px, int64_t n, double h, double gamma, double* alpha) {
     if (n == 0) return RSDSFM_OK;
     hipLaunchKernelGGL(alpha_kernel, dim3(stream_grid(n)), dim3(256), 0, c->stream,

@@ -17,6 +17,7 @@ int rsdsfm_true_flow_dev(rsdsfm_ctx* ctx, const double* d_world_x, const double*
                          double cy, int q5_mode, double* d_flow, int32_t* d_best_row_or_null) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (rows < 0 || cols < 0 || rows2 < 0) return fail(c, RSDSFM_ERR_INVALID, "bad sizes");
     if (q5_mode != RSDSFM_Q5_COMPAT && q5_mode != RSDSFM_Q5_FIXED) return fail(c, RSDSFM_ERR_INVALID, "unknown q5_mode");
     if ((int64_t)rows * cols == 0) return RSDSFM_OK;
@@ -31,6 +32,7 @@ int rsdsfm_true_flow(rsdsfm_ctx* ctx, const double* world_x, const double* world
                      double* flow, int32_t* best_row_or_null) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (rows < 0 || cols < 0 || rows2 < 0) return fail(c, RSDSFM_ERR_INVALID, "bad sizes");
     const size_t npix = (size_t)rows * (size_t)cols;
     if (npix == 0) return RSDSFM_OK;

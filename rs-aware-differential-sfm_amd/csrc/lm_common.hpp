@@ -165,11 +165,12 @@ struct LmPlanReg {
     }
 };
 
-// plan of launch 0 of a solve with the shape known at compile time (no accepted steps yet, KMAX speculated iterations):
+// plan of launch 0 of a solve with the shape known at compile time (no accepted steps yet, K0 speculated iterations):
 // lm_pixel becomes one straight-line block, which lets the compiler interleave the independent pixels of a lane.
-struct LmPlanFirst {
+template <int K0>
+struct LmPlanFirstK {
     static constexpr int n_hist = 0;
-    static constexpr int K = KMAX;
+    static constexpr int K = K0;
     int write_which;
     double inv_cand[KMAX];
     __device__ __forceinline__ double inv_hist_at(int) const { return 0.0; }
@@ -179,6 +180,7 @@ struct LmPlanFirst {
         for (int j = 0; j < KMAX; ++j) inv_cand[j] = l.inv_cand[j];
     }
 };
+using LmPlanFirst = LmPlanFirstK<KMAX>;
 
 // ht + clamp(diag) / radius: the damped 1x1 normal matrix of one pixel (inv_radius = 1 / radius)
 __device__ __forceinline__ double lm_denominator(double ht, double diag, double inv_radius) {

@@ -41,6 +41,7 @@ int rsdsfm_reprojection_error_dev(rsdsfm_ctx* ctx, const float* d_est_coords, co
                                   uint8_t* d_error_image_or_null) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (rows < 0 || cols < 0 || !stats) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     memset(stats, 0, sizeof(*stats));
     if ((int64_t)rows * cols == 0) {
@@ -75,6 +76,7 @@ int rsdsfm_reprojection_error(rsdsfm_ctx* ctx, const float* est_coords, const do
                               int32_t cols, double max_norm, rsdsfm_reprojection_stats* stats, uint8_t* error_image_or_null) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (rows < 0 || cols < 0 || !stats) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     const size_t npix = (size_t)rows * (size_t)cols;
     if (npix == 0) return rsdsfm_reprojection_error_dev(ctx, nullptr, nullptr, nullptr, nullptr, nullptr, fx, fy, cx, cy, rows, cols, max_norm, stats, nullptr);

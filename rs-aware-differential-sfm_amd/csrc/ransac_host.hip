@@ -91,7 +91,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     const int batch = std::min(Tn, kRansacBatch);
     size_t need = Arena::need(sizeof(double) * Tn * 8) +
                   Arena::need(sizeof(LmState) * Tn) + Arena::need(sizeof(double) * (size_t)ransac_lm_partials_doubles(c, n, batch)) +
-                  Arena::need(sizeof(int) * 2) + Arena::need(sizeof(int) * Tn) + 2 * Arena::need(sizeof(double) * Tn) + Arena::need(sizeof(RansacBest)) +
+                  Arena::need(sizeof(int) * 4) + Arena::need(sizeof(int) * Tn) + 2 * Arena::need(sizeof(double) * Tn) + Arena::need(sizeof(RansacBest)) +
                   2 * Arena::need(sizeof(int64_t) * 2048) + Arena::need(sizeof(double) * (size_t)n) + Arena::need((size_t)n) + 4096;
     int rc = ensure_ws(c, need);
     if (rc != RSDSFM_OK) return rc;
@@ -101,7 +101,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     char* zero_begin = ws.base + ws.off;
     LmState* d_states = ws.take<LmState>(Tn);
     int* d_scored = ws.take<int>(Tn);
-    int* d_flags = ws.take<int>(2);  // {running, unscored}
+    int* d_flags = ws.take<int>(4);  // {running, unscored, not finished with <= 1 accepted step (predictor input), -}
     const size_t zero_bytes = (size_t)((ws.base + ws.off) - zero_begin);
     double* d_partials = ws.take<double>((size_t)ransac_lm_partials_doubles(c, n, batch));
     double* d_tcount = ws.take<double>(Tn);
@@ -127,6 +127,8 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
 
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
     bool final_done = false;
+    const int k0 = c->ransac_k0;  // speculation depth of round 0 (see ransac_kernels.hip)
+    int not_one_step = 0;
     if (T > 0) {
         memcpy(h_samples_pinned, samples.data(), sizeof(int32_t) * (size_t)T * 9);
         rc = minimal9_launch(c, d_q, d_u, d_a, d_ak, h_samples_pinned, T, use_alpha_k, k_sign_mode, d_hyp);
@@ -135,11 +137,11 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
             const int B = std::min(batch, T - b0);
             bool need_score = true;
             if (depth_mode == RSDSFM_DEPTH_CERES_LM) {
-                if (b0 > 0) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_flags, 0, sizeof(int) * 2, c->stream));  // batch 0: cleared above
+                if (b0 > 0) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_flags, 0, sizeof(int) * 4, c->stream));  // batch 0: cleared above
                 for (int round = 0;; ++round) {
                     if (round > 4 * kMaxIter) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machines did not terminate");
                     rc = ransac_lm_round_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, d_partials, d_flags,
-                                                d_scored + b0, d_tcount + b0, d_terr + b0, round, tol);
+                                                d_scored + b0, d_tcount + b0, d_terr + b0, round, tol, k0);
                     if (rc != RSDSFM_OK) return rc;
                     if (round == 0 && B == T) {
                         // one batch, and on typical data every hypothesis is decided and scored by round 0: the final stage
@@ -152,8 +154,9 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
                         if (rc != RSDSFM_OK) return rc;
                         final_done = true;
                     }
-                    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_running, d_flags, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
+                    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_running, d_flags, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
                     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+                    if (round == 0) not_one_step += h_running[2];
                     if (h_running[0] == 0) break;
                     final_done = false;  // more LM rounds: the speculated final stage saw incomplete trials
                 }
@@ -168,6 +171,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
             }
         }
     }
+    c->ransac_not_one_step = not_one_step;
     // best trial, its dense rho + mask, order-preserving compaction
     if (!final_done) {
         rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, h_best);  // h_best: host-mapped, written by the kernels
@@ -209,6 +213,7 @@ int rsdsfm_calculate_velocities(rsdsfm_ctx* ctx, const double* q, const double* 
                                 int32_t count, int use_alpha_k, int k_sign_mode, double* w, double* v, double* k) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (count < 0 || (count > 0 && (!q || !u || !alpha || !alpha_k || !w || !v || !k))) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     if (count == 0) return RSDSFM_OK;
     const size_t T = (size_t)count;
@@ -245,8 +250,21 @@ int rsdsfm_ransac_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_u, con
                       int depth_mode, int k_sign_mode, rsdsfm_ransac_out* out) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (!d_q || !d_u || !d_alpha || !d_alpha_k) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
     return ransac_device(c, d_q, d_u, d_alpha, d_alpha_k, n, use_alpha_k, iterations, tolerance, samples, seed, depth_mode, k_sign_mode, out);
+}
+
+int rsdsfm_ransac_lm_launch_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_u, const double* d_alpha, const double* d_alpha_k,
+                                int64_t n, const double* d_hyp, int32_t count, double tolerance) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
+    if (!d_q || !d_u || !d_alpha || !d_alpha_k || !d_hyp || n < 1 || count < 1 || count > kRansacBatch) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    int rc = ensure_ws(c, Arena::need(sizeof(double) * (size_t)ransac_lm_partials_doubles(c, n, count)) + 1024);
+    if (rc != RSDSFM_OK) return rc;
+    return ransac_lm_only_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, d_hyp, count, static_cast<double*>(c->d_ws), tolerance,
+                                 c->ransac_k0);
 }
 
 int rsdsfm_ransac(rsdsfm_ctx* ctx, const double* q, const double* u, const double* alpha, const double* alpha_k, int64_t n,
@@ -254,6 +272,7 @@ int rsdsfm_ransac(rsdsfm_ctx* ctx, const double* q, const double* u, const doubl
                   int k_sign_mode, rsdsfm_ransac_out* out) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (!out || !q || !u || !alpha || !alpha_k) return fail(c, RSDSFM_ERR_INVALID, "null pointer");
     if (n < 9) return fail(c, RSDSFM_ERR_INVALID, "ransac needs at least 9 points (the reference would compute rand() % 0)");
     const size_t N = (size_t)n;

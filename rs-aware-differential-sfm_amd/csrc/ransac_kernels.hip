@@ -29,23 +29,36 @@ namespace {
 
 constexpr int kRB = 256;  // workgroup size of the pixel kernels
 constexpr int kRP = 5;    // pixels per thread per tile, register-resident across the hypothesis loop (measured 4 / 5: 451 / 419 us; 6 drops to one wave per SIMD)
-// LM iterations speculated in round 0: noisy data (the common case inside RANSAC) is decided at iteration 2
-// (function tolerance); hypotheses that need more simply take another round
-constexpr int kRansacK0 = KMAX;
-
-// LM sums + fused scores {count, sum err} of the iterates after ONE and after TWO accepted steps -- what noisy
-// data (the common case inside RANSAC) ends with, depending on how far rho = 1 is from the optimum
+// LM iterations speculated in round 0 (template parameter K0 of ransac_lm_kernel<true, K0>): KMAX = 3 (default) decides every
+// hypothesis that ends with <= 2 accepted steps in one pass and fuses the inlier scores {count, sum err} of the iterates after ONE
+// and after TWO accepted steps.  DeepFlow-like data (0.3 px noise + 10 % outliers) ends with TWO accepted steps for ~96 % of the
+// hypotheses (the third iteration's candidate fails the function tolerance), so that is the right default.  K0 = 2
+// (rsdsfm_set_ransac_speculation) speculates two iterations and fuses only the one-step score: cheaper when every hypothesis
+// stops after one accepted step (outlier-dominated costs); hypotheses that need more take the generic continuation round and the
+// separate score pass.  All integer results are identical for both depths; the inlier-error SUM of a two-step hypothesis is then
+// formed by ransac_score_kernel instead of this kernel (another summation order: last bits), which is why the depth is an explicit
+// setting and not a per-context predictor -- a solve's result never depends on the context's history.
 constexpr int kFused = 2;
 constexpr int NSR = NS + 2 * kFused;
 constexpr int kNSum = NSR - (KMAX + 1);  // sum slots (the KMAX + 1 gradient-max slots are reduced with fmax)
 constexpr int kTStride = 65;             // row stride of the per-wave transpose buffer (bank-conflict-free)
 
+// per-K0 shape of round 0: LM slots used, fused scores, sum slots that go through the transpose
+template <int K0>
+struct R0Shape {
+    static constexpr int NSk = 3 + 5 * K0;
+    static constexpr int F = (K0 >= KMAX) ? kFused : 1;
+    static constexpr int nsum = NSk - (K0 + 1) + 2 * F;
+};
+static_assert(R0Shape<KMAX>::nsum == kNSum, "full shape uses every sum slot");
+
+template <int F>
 struct ScoreHook {
     double x, y, ux, uy, al, ak, two_over, tol;
     const Pose* pose;
     double* sc;  // [2 * kFused] = {count, err} per fused state
     __device__ __forceinline__ void operator()(int j, double rho) const {
-        if (j < kFused) {
+        if (j < F) {
             const double e = point_error(x, y, ux, uy, al, ak, *pose, two_over, rho);
             if (e < tol) {
                 sc[2 * j] += 1.0;
@@ -95,7 +108,7 @@ __device__ __forceinline__ void load_tile(Tile& t, const double2* __restrict__ q
 // ---------------------------------------------------------------------------------------------------
 // round 0: every hypothesis starts from the built-in plan; round r > 0: only hypotheses whose state machine is
 // still running (status 0) and expects launch r take part.  partials: [T][gridDim.x][NSR] (hypothesis-major).
-template <bool R0>
+template <bool R0, int K0>
 __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
                                                        const double* __restrict__ alpha,
                                                        const double* __restrict__ alpha_k, int64_t n,
@@ -117,10 +130,13 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
     // 1.76 rounds of the chip; splitting the hypotheses over gridDim.y makes the workgroups short enough that the last round is full
     const int per_group = (T + (int)gridDim.y - 1) / (int)gridDim.y;
     const int t_begin = (int)blockIdx.y * per_group, t_end = min(T, t_begin + per_group);
+    using Shape = R0Shape<R0 ? K0 : KMAX>;
+    constexpr int NSk = Shape::NSk, F = Shape::F, nsum = Shape::nsum;
     for (int i = tid; i < T * NSR; i += kRB) s_acc[i] = 0.0;
+    for (int i = tid; i < 2 * (kRB / 64) * NSR; i += kRB) (&s_red[0][0][0])[i] = 0.0;  // slots a shape does not use stay zero
     if (R0 && tid == 0) {
         plan.n_hist = 0;
-        plan.K = kRansacK0;
+        plan.K = K0;
         plan.write_which = 0;
         double r = kInitialRadius;
         for (int j = 0; j < KMAX; ++j) {
@@ -129,8 +145,7 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
         }
     }
     __syncthreads();
-    LmPlanFirst pf;  // round 0: plan shape known at compile time (kRansacK0 == KMAX speculated iterations, nothing accepted yet)
-    static_assert(kRansacK0 == KMAX, "LmPlanFirst speculates KMAX iterations");
+    LmPlanFirstK<K0> pf;  // round 0: plan shape known at compile time (K0 speculated iterations, nothing accepted yet)
     pf.write_which = 0;
 #pragma unroll
     for (int j = 0; j < KMAX; ++j) pf.inv_cand[j] = R0 ? plan.inv_cand[j] : 0.0;
@@ -171,14 +186,14 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
             if (R0 && full_tile) {  // round 0, no ragged lanes: one straight-line block, the kRP pixel chains interleave
 #pragma unroll
                 for (int j = 0; j < kRP; ++j) {
-                    const ScoreHook hook{px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], two_over, tol, &pose, sc};
+                    const ScoreHook<F> hook{px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], two_over, tol, &pose, sc};
                     (void)lm_pixel(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, pf, acc, hook);
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < kRP; ++j)
                     if (px.ok[j]) {
-                        const ScoreHook hook{px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], two_over, tol, &pose, sc};
+                        const ScoreHook<F> hook{px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], two_over, tol, &pose, sc};
                         (void)lm_pixel(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, plan, acc, hook);
                     }
             }
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
             // adds per lane instead of ~320 DPP/VALU instructions per hypothesis.  A wave's LDS operations execute in
             // order, so no barrier is needed inside the wave.
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
+            for (int s = 0; s < NSk; ++s)
                 if (is_max_slot(s)) {
                     const double r = wave_max(acc[s]);
                     if (lane == 0) red[wv][s] = r;
@@ -199,18 +214,18 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
             {
                 int kk = 0;
 #pragma unroll
-                for (int s = 0; s < NS; ++s)
+                for (int s = 0; s < NSk; ++s)
                     if (!is_max_slot(s)) {
                         Tw[kk * kTStride + lane] = acc[s];
                         ++kk;
                     }
 #pragma unroll
-                for (int s = 0; s < 2 * kFused; ++s) Tw[(kNSum - 2 * kFused + s) * kTStride + lane] = sc[s];
+                for (int s = 0; s < 2 * F; ++s) Tw[(nsum - 2 * F + s) * kTStride + lane] = sc[s];
             }
             __builtin_amdgcn_wave_barrier();  // compiler ordering only: the wave's stores precede its loads below
             {
                 const int sl = lane & 31, half = lane >> 5;
-                if (sl < kNSum) {
+                if (sl < nsum) {
                     const double* row = Tw + sl * kTStride + half * 32;
                     double part = row[0];
 #pragma unroll
@@ -218,12 +233,12 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
                     s_half[wv][half][sl] = part;
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (lane < kNSum) {
-                    // slot id of sum index `lane`: the sum slots in increasing slot order, then the fused scores
-                    int slot = NS + (lane - (kNSum - 2 * kFused));
+                if (lane < nsum) {
+                    // slot id of sum index `lane`: the used sum slots in increasing slot order, then the fused scores
+                    int slot = NS + (lane - (nsum - 2 * F));
                     int kk = 0;
 #pragma unroll
-                    for (int s = 0; s < NS; ++s)
+                    for (int s = 0; s < NSk; ++s)
                         if (!is_max_slot(s)) {
                             if (kk == lane) slot = s;
                             ++kk;
@@ -315,8 +330,10 @@ __global__ __launch_bounds__(256) void ransac_lm_rows_kernel(const double* __res
 // one workgroup per hypothesis
 // flags[0]: hypotheses still running after this round; flags[1]: hypotheses that finished WITHOUT a fused score
 // (accepted-step count != 1) and need the separate score pass.  scored[t] = 1 when trial_count/err were filled here.
+// pred_flag (may be null): counts the hypotheses that round 0 did not finish with at most one accepted step -- the predictor input
+// of Ctx::ransac_k0.  k0: LM iterations round 0 speculated (its fused scores: kFused for k0 = KMAX, one otherwise).
 __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __restrict__ partials, int nblocks, int T, int hyp_major,
-                                                           LmState* states, int64_t n, int round, int* flags,
+                                                           LmState* states, int64_t n, int round, int k0, int* flags, int* pred_flag,
                                                            int* __restrict__ scored, double* __restrict__ trial_count,
                                                            double* __restrict__ trial_err) {
     __shared__ double s_red[4][NSR];
@@ -328,11 +345,13 @@ __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __rest
     reduce_hyp_sums(partials, nblocks, T, t, hyp_major != 0, s_red, s_sums);
     if (tid == 0) {
         LmScal st = *static_cast<const LmScal*>(state);
-        const int used_K = (round == 0) ? kRansacK0 : st.K;
+        const int used_K = (round == 0) ? k0 : st.K;
+        const int fused = (k0 >= KMAX) ? kFused : 1;
         lm_advance(st, state->hist, s_sums, n, round == 0, used_K, 0, round);
+        if (pred_flag && round == 0 && (st.status == 0 || st.n_hist >= 2)) atomicAdd(pred_flag, 1);
         if (st.status == 0) {
             atomicAdd(&flags[0], 1);
-        } else if (round == 0 && st.n_hist >= 1 && st.n_hist <= kFused) {  // a fused iterate is the final one
+        } else if (round == 0 && st.n_hist >= 1 && st.n_hist <= fused) {  // a fused iterate is the final one
             trial_count[t] = s_sums[NS + 2 * (st.n_hist - 1)];
             trial_err[t] = s_sums[NS + 2 * (st.n_hist - 1) + 1];
             scored[t] = 1;
@@ -707,23 +726,43 @@ static int ransac_lm_groups(const Ctx* c, int grid, int T) {
 
 int ransac_lm_partials_doubles(const Ctx* c, int64_t n, int batch) { return ransac_pixel_grid(c, n) * batch * NSR; }
 
-// flags: device int[2] = {running, unscored}; flags[0] is cleared here, flags[1] by the caller once per batch
+static int lm_launch(Ctx* c, const dim3& g2, int k0, const double* q, const double* u, const double* a, const double* ak, int64_t n,
+                     const double* hyp, int T, const LmState* states, double* partials, int round, double tol, int* flags) {
+    const double2* q2 = reinterpret_cast<const double2*>(q);
+    const double2* u2 = reinterpret_cast<const double2*>(u);
+    const size_t lds = sizeof(double) * T * NSR;
+    if (round != 0)
+        hipLaunchKernelGGL((ransac_lm_kernel<false, KMAX>), g2, dim3(kRB), lds, c->stream, q2, u2, a, ak, n, hyp, T, states, partials, round, tol, flags);
+    else if (k0 == 2)
+        hipLaunchKernelGGL((ransac_lm_kernel<true, 2>), g2, dim3(kRB), lds, c->stream, q2, u2, a, ak, n, hyp, T, states, partials, round, tol, flags);
+    else
+        hipLaunchKernelGGL((ransac_lm_kernel<true, KMAX>), g2, dim3(kRB), lds, c->stream, q2, u2, a, ak, n, hyp, T, states, partials, round, tol, flags);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+// flags: device int[4] = {running, unscored, not-done-with-one-step, -}; flags[0] is cleared here, the others by the caller once
+// per batch.  k0 (2 or KMAX): LM iterations speculated by round 0 (the same value must be passed for every round of a batch).
 int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                            const double* hyp, int T, LmState* states, double* partials, int* flags, int* scored,
-                           double* trial_count, double* trial_err, int round, double tol) {
+                           double* trial_count, double* trial_err, int round, double tol, int k0) {
     const int grid = ransac_pixel_grid(c, n);
     const dim3 g2(grid, ransac_lm_groups(c, grid, T));
-    if (round == 0)
-        hipLaunchKernelGGL(ransac_lm_kernel<true>, g2, dim3(kRB), sizeof(double) * T * NSR, c->stream, reinterpret_cast<const double2*>(q),
-                           reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states, partials, round, tol, flags);
-    else
-        hipLaunchKernelGGL(ransac_lm_kernel<false>, g2, dim3(kRB), sizeof(double) * T * NSR, c->stream, reinterpret_cast<const double2*>(q),
-                           reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states, partials, round, tol, flags);
-    RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, 1, states, n, round, flags, scored,
+    if (k0 != 2) k0 = KMAX;
+    int rc = lm_launch(c, g2, k0, q, u, a, ak, n, hyp, T, states, partials, round, tol, flags);
+    if (rc != RSDSFM_OK) return rc;
+    hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, 1, states, n, round, k0, flags, flags + 2, scored,
                        trial_count, trial_err);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
+}
+
+// round-0 kernel alone (no decide kernel): the profiling hook behind rsdsfm_ransac_lm_launch_dev
+int ransac_lm_only_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n, const double* hyp,
+                          int T, double* partials, double tol, int k0) {
+    const int grid = ransac_pixel_grid(c, n);
+    const dim3 g2(grid, ransac_lm_groups(c, grid, T));
+    return lm_launch(c, g2, k0 == 2 ? 2 : KMAX, q, u, a, ak, n, hyp, T, nullptr, partials, 0, tol, nullptr);
 }
 
 // scores the hypotheses of the batch [0, T) that are not yet scored; trial_count / trial_err point at the batch's slots
@@ -746,13 +785,8 @@ int ransac_lm_rows_launch(Ctx* c, const double* q, const double* u, const double
                           const double* hyp, int T, const LmState* states, double* partials, int round, double tol, double* rows) {
     const int grid = ransac_pixel_grid(c, n);
     const dim3 g2(grid, ransac_lm_groups(c, grid, T));
-    if (round == 0)
-        hipLaunchKernelGGL(ransac_lm_kernel<true>, g2, dim3(kRB), sizeof(double) * T * NSR, c->stream, reinterpret_cast<const double2*>(q),
-                           reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states, partials, round, tol, static_cast<int*>(nullptr));
-    else
-        hipLaunchKernelGGL(ransac_lm_kernel<false>, g2, dim3(kRB), sizeof(double) * T * NSR, c->stream, reinterpret_cast<const double2*>(q),
-                           reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states, partials, round, tol, static_cast<int*>(nullptr));
-    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    int rc = lm_launch(c, g2, KMAX, q, u, a, ak, n, hyp, T, states, partials, round, tol, nullptr);
+    if (rc != RSDSFM_OK) return rc;
     hipLaunchKernelGGL(ransac_lm_rows_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, states, round, rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
@@ -761,8 +795,8 @@ int ransac_lm_rows_launch(Ctx* c, const double* q, const double* u, const double
 int ransac_decide_rows_launch(Ctx* c, const double* rows_all, int nranks, int T, LmState* states, int64_t n_total, int round,
                               int* flags, int* scored, double* trial_count, double* trial_err) {
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(flags, 0, sizeof(int), c->stream));
-    hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, rows_all, nranks, T, 0, states, n_total, round, flags,
-                       scored, trial_count, trial_err);
+    hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, rows_all, nranks, T, 0, states, n_total, round, (int)KMAX, flags,
+                       static_cast<int*>(nullptr), scored, trial_count, trial_err);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -14,6 +14,7 @@ int rsdsfm_back_project_dev(rsdsfm_ctx* ctx, const uint8_t* d_image_bgr, const d
                             int q5_mode, uint8_t* d_gs_image_bgr, float* d_coords3d_or_null) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (rows < 0 || cols < 0 || (int64_t)rows * cols > (int64_t)INT32_MAX) return fail(c, RSDSFM_ERR_INVALID, "bad image size");
     if (mode != RSDSFM_BACKPROJECT_RS && mode != RSDSFM_BACKPROJECT_GS) return fail(c, RSDSFM_ERR_INVALID, "unknown back-projection mode");
     if (q5_mode != RSDSFM_Q5_COMPAT && q5_mode != RSDSFM_Q5_FIXED) return fail(c, RSDSFM_ERR_INVALID, "unknown q5_mode");
@@ -31,6 +32,7 @@ int rsdsfm_back_project(rsdsfm_ctx* ctx, const uint8_t* image_bgr, const double*
                         int q5_mode, uint8_t* gs_image_bgr, float* coords3d_or_null) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (rows < 0 || cols < 0) return fail(c, RSDSFM_ERR_INVALID, "bad image size");
     const size_t npix = (size_t)rows * (size_t)cols;
     if (npix == 0) return RSDSFM_OK;
@@ -61,6 +63,7 @@ int rsdsfm_interpolate_cracky_dev(rsdsfm_ctx* ctx, const uint8_t* d_image_in_bgr
                                   uint8_t* d_image_out_bgr) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (rows < 0 || cols < 0 || offset < 0) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     if ((int64_t)rows * cols == 0) return RSDSFM_OK;
     if (!d_image_in_bgr || !d_image_out_bgr || d_image_in_bgr == d_image_out_bgr) return fail(c, RSDSFM_ERR_INVALID, "null or aliased device pointer");
@@ -71,6 +74,7 @@ int rsdsfm_interpolate_cracky(rsdsfm_ctx* ctx, const uint8_t* image_in_bgr, int3
                               uint8_t* image_out_bgr) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (rows < 0 || cols < 0 || offset < 0) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     const size_t nb = 3 * (size_t)rows * (size_t)cols;
     if (nb == 0) return RSDSFM_OK;
@@ -92,6 +96,7 @@ int rsdsfm_depth_preview_dev(rsdsfm_ctx* ctx, const double* d_inl, int64_t m, do
                              int32_t cols, uint8_t* d_depth_est) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (m < 0 || m > (int64_t)INT32_MAX || rows < 0 || cols < 0 || (int64_t)rows * cols > (int64_t)INT32_MAX) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     const size_t npix = (size_t)rows * (size_t)cols;
     if (npix == 0) return RSDSFM_OK;
@@ -109,6 +114,7 @@ int rsdsfm_depth_preview(rsdsfm_ctx* ctx, const double* inl, int64_t m, double f
                          int32_t cols, uint8_t* depth_est) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (m < 0 || rows < 0 || cols < 0) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     const size_t npix = (size_t)rows * (size_t)cols;
     if (npix == 0) return RSDSFM_OK;

@@ -105,6 +105,7 @@ int rsdsfm_refine_dev(rsdsfm_ctx* ctx, const double* d_flow, int64_t n_flow, int
                       int const_acceleration, int flow_index_mode, double* d_inl_out, double v_out[3], double w_out[3], double* k_out,
                       rsdsfm_lm_summary* summary) {
     if (!ctx) return RSDSFM_ERR_INVALID;
+    DeviceGuard device_guard_(&ctx->c);
     return refine_device(&ctx->c, d_flow, n_flow, m, d_inl, d_alpha, d_alpha_k, d_inlier_idx, v_in, w_in, k_in, const_acceleration,
                          flow_index_mode, d_inl_out, v_out, w_out, k_out, summary);
 }
@@ -115,6 +116,7 @@ int rsdsfm_refine(rsdsfm_ctx* ctx, const double* flow, int64_t n_flow, int64_t m
                   rsdsfm_lm_summary* summary) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (m < 0 || n_flow < 0) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     if (m > 0 && (!flow || !inl || !alpha || !alpha_k || !inl_out)) return fail(c, RSDSFM_ERR_INVALID, "null pointer");
     const size_t M = (size_t)m, NF = (size_t)n_flow;

@@ -103,6 +103,8 @@ struct Ctx {
     hipEvent_t ev_ready = nullptr;  // "value ready" event for stages whose host read does not have to wait for the whole stream
     size_t pinned_bytes = 0;
     int num_cus = 256;
+    int ransac_k0 = KMAX;      // LM iterations round 0 of the hypothesis-batched depth solves speculates (rsdsfm_set_ransac_speculation: 2 or KMAX)
+    int ransac_not_one_step = 0;  // diagnostic of the last RANSAC: hypotheses that did not stop after exactly one accepted step
     int depth_variant = 0;  // 0 = register-staged depth_lm_kernel, 1 = LDS-DMA depth_lm_dma_kernel, 2 = launch 0 with the decision fused into its tail, 3 = separate decide kernel + follow-up launch (the pre-fusion fast path)
     // row-tiled refinement session (tiled_host.hip): buffers live in d_tile, not in the shared workspace
     void* d_tile = nullptr;
@@ -124,6 +126,22 @@ constexpr int kDepthBatchMax = 8;  // independent solves per batched launch (des
             return RSDSFM_ERR_HIP;                                                             \
         }                                                                                      \
     } while (0)
+
+// Scoped device guard: hipMalloc / hipHostMalloc / kernel launches follow the calling thread's CURRENT device, not the stream's.
+// Every extern "C" entry point therefore makes the context's device current (a new host thread starts on device 0; a caller
+// may alternate contexts of different GPUs in one thread) and restores the caller's device when it returns.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const Ctx* c) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != c->device) switched = hipSetDevice(c->device) == hipSuccess;
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 int fail(Ctx* c, int code, const char* msg);
 int ensure_stage(Ctx* c, size_t bytes);
@@ -196,7 +214,9 @@ int ransac_pixel_grid(const Ctx* c, int64_t n);
 int ransac_lm_partials_doubles(const Ctx* c, int64_t n, int batch);
 int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                            const double* hyp, int T, LmState* states, double* partials, int* flags, int* scored,
-                           double* trial_count, double* trial_err, int round, double tol);
+                           double* trial_count, double* trial_err, int round, double tol, int k0);
+int ransac_lm_only_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n, const double* hyp,
+                          int T, double* partials, double tol, int k0);
 int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
                         double* partials, double* trial_count, double* trial_err);

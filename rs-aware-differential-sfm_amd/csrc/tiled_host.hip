@@ -49,6 +49,7 @@ int rsdsfm_minimal9_dev(rsdsfm_ctx* ctx, const double* d_q9, const double* d_u9,
                         int32_t count, int use_alpha_k, int k_sign_mode, double* d_hyp) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (count < 0) return fail(c, RSDSFM_ERR_INVALID, "negative count");
     if (count == 0) return RSDSFM_OK;
     if (!d_q9 || !d_u9 || !d_alpha9 || !d_alpha_k9 || !d_hyp) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
@@ -65,6 +66,7 @@ int rsdsfm_tile_ransac_lm_rows_dev(rsdsfm_ctx* ctx, const double* d_q, const dou
                                    int32_t round, double tolerance, double* d_rows) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (n < 0 || count < 1 || count > kRansacBatch || round < 0) return fail(c, RSDSFM_ERR_INVALID, "bad arguments (count must be 1..128 per call)");
     if (!d_hyp || !d_states || !d_rows || (n > 0 && (!d_q || !d_u || !d_alpha || !d_alpha_k))) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
     int rc = ensure_ws(c, Arena::need(sizeof(double) * (size_t)ransac_lm_partials_doubles(c, n, count)) + 1024);
@@ -78,6 +80,7 @@ int rsdsfm_tile_ransac_decide_dev(rsdsfm_ctx* ctx, const double* d_rows_all, int
                                   double* d_trial_err) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (nranks < 1 || count < 1 || round < 0 || n_total < 0) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     if (!d_rows_all || !d_states || !d_flags || !d_scored || !d_trial_count || !d_trial_err) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
     return ransac_decide_rows_launch(c, d_rows_all, nranks, count, static_cast<LmState*>(d_states), n_total, round, d_flags, d_scored,
@@ -89,6 +92,7 @@ int rsdsfm_tile_ransac_score_rows_dev(rsdsfm_ctx* ctx, const double* d_q, const 
                                       int depth_mode, double tolerance, const int32_t* d_scored, double* d_rows) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (n < 0 || count < 1 || count > kRansacBatch || bad_depth_mode(depth_mode)) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     if (!d_hyp || !d_states || !d_rows || (n > 0 && (!d_q || !d_u || !d_alpha || !d_alpha_k))) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
     int rc = ensure_ws(c, Arena::need(sizeof(double) * (size_t)ransac_lm_partials_doubles(c, n, count)) + 1024);
@@ -101,6 +105,7 @@ int rsdsfm_tile_ransac_score_merge_dev(rsdsfm_ctx* ctx, const double* d_rows_all
                                        const int32_t* d_scored, double* d_trial_count, double* d_trial_err) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (nranks < 1 || count < 1 || !d_rows_all || !d_trial_count || !d_trial_err) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     return ransac_score_merge_launch(c, d_rows_all, nranks, count, d_scored, d_trial_count, d_trial_err);
 }
@@ -109,6 +114,7 @@ int rsdsfm_tile_ransac_pick_dev(rsdsfm_ctx* ctx, const double* d_trial_count, co
                                 const double* d_hyp, void* d_best) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (iterations < 0 || !d_best || (iterations > 0 && (!d_trial_count || !d_trial_err || !d_hyp))) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     return ransac_pick_launch(c, d_trial_count, d_trial_err, iterations, d_hyp, static_cast<RansacBest*>(d_best));
 }
@@ -119,6 +125,7 @@ int rsdsfm_tile_ransac_final_dev(rsdsfm_ctx* ctx, const double* d_q, const doubl
                                  double* d_out_alpha_k, rsdsfm_ransac_out* out) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (n < 0 || !d_best || !d_states || !out || bad_depth_mode(depth_mode)) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     if (n > 0 && (!d_q || !d_u || !d_alpha || !d_alpha_k || !d_inv_depth || !d_mask)) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
     int rc = ensure_ws(c, 2 * Arena::need(sizeof(int64_t) * 2048) + 1024);
@@ -148,6 +155,7 @@ int rsdsfm_tile_ransac_final_dev(rsdsfm_ctx* ctx, const double* d_q, const doubl
 int64_t rsdsfm_tile_ransac_global_inliers(rsdsfm_ctx* ctx, const void* d_best) {
     if (!ctx || !d_best) return -1;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (ensure_pinned(c, sizeof(RansacBest) + 64) != RSDSFM_OK) return -1;
     RansacBest* h = static_cast<RansacBest*>(c->h_pinned);
     if (hipMemcpyAsync(h, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return -1;
@@ -163,6 +171,7 @@ int rsdsfm_tile_refine_begin_dev(rsdsfm_ctx* ctx, const double* d_flow, int64_t 
                                  const double w_in[3], double k_in, int const_acceleration, int flow_index_mode) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (m < 0 || n_flow < 0 || !v_in || !w_in) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     if (flow_index_mode != RSDSFM_FLOW_GATHERED) return fail(c, RSDSFM_ERR_INVALID, "the row-tiled refinement needs RSDSFM_FLOW_GATHERED (shard-local inlier indices)");
     if (m > 0 && (!d_flow || !d_inl || !d_alpha || !d_alpha_k || !d_inlier_idx)) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
@@ -217,6 +226,7 @@ int32_t rsdsfm_tile_refine_row_size(int const_acceleration, int32_t stage) {
 int rsdsfm_tile_refine_rows_dev(rsdsfm_ctx* ctx, int32_t stage, double* d_row) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (!c->tile_session || c->tile_np == 0) return fail(c, RSDSFM_ERR_INVALID, "no open refinement session");
     if (stage < 0 || stage > 2 || !d_row) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     return refine_stage_rows_launch(c, *static_cast<RefineBuffers*>(c->tile_session), c->tile_np, stage, d_row);
@@ -225,6 +235,7 @@ int rsdsfm_tile_refine_rows_dev(rsdsfm_ctx* ctx, int32_t stage, double* d_row) {
 int rsdsfm_tile_refine_apply_dev(rsdsfm_ctx* ctx, int32_t stage, const double* d_rows_all, int32_t nranks, int64_t m_total) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (!c->tile_session || c->tile_np == 0) return fail(c, RSDSFM_ERR_INVALID, "no open refinement session");
     if (stage < 0 || stage > 2 || !d_rows_all || nranks < 1 || m_total < 0) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     return refine_stage_apply_launch(c, *static_cast<RefineBuffers*>(c->tile_session), c->tile_np, stage, d_rows_all, nranks, m_total);
@@ -233,6 +244,7 @@ int rsdsfm_tile_refine_apply_dev(rsdsfm_ctx* ctx, int32_t stage, const double* d
 int rsdsfm_tile_refine_poll(rsdsfm_ctx* ctx, double v_out[3], double w_out[3], double* k_out, rsdsfm_lm_summary* summary) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (!c->tile_session || c->tile_np == 0) return fail(c, RSDSFM_ERR_INVALID, "no open refinement session");
     RefineBuffers& B = *static_cast<RefineBuffers*>(c->tile_session);
     RefineState* hs = static_cast<RefineState*>(c->h_pinned);
@@ -262,6 +274,7 @@ int rsdsfm_tile_refine_poll(rsdsfm_ctx* ctx, double v_out[3], double w_out[3], d
 int rsdsfm_tile_refine_finish_dev(rsdsfm_ctx* ctx, double* d_inl_out) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (!c->tile_session || c->tile_np == 0) return fail(c, RSDSFM_ERR_INVALID, "no open refinement session");
     RefineBuffers& B = *static_cast<RefineBuffers*>(c->tile_session);
     if (B.m > 0 && !d_inl_out) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
@@ -276,6 +289,7 @@ int rsdsfm_tile_refine_finish_dev(rsdsfm_ctx* ctx, double* d_inl_out) {
 int rsdsfm_tile_zsum_dev(rsdsfm_ctx* ctx, const double* d_inl, int64_t m, double* d_zsum) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (m < 0 || !d_zsum || (m > 0 && !d_inl)) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     int rc = ensure_ws(c, Arena::need(8 * 1024) + 1024);
     if (rc != RSDSFM_OK) return rc;
@@ -287,6 +301,7 @@ int rsdsfm_tile_depth_map_dev(rsdsfm_ctx* ctx, double* d_inl, int64_t m, const d
                               int32_t slab_cols, double* d_depth_slab, int32_t* d_xs, int32_t* d_ys, int* flipped) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
     if (m < 0 || rows < 0 || col0 < 0 || slab_cols < 0 || nranks < 1 || m_total < m || !v_inout || !d_zsums_all) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     const size_t npix = (size_t)rows * (size_t)slab_cols;
     if ((m > 0 && !d_inl) || (npix > 0 && !d_depth_slab)) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");

@@ -28,7 +28,9 @@ def relocate_pose(R_abs, t_abs):
 
 
 def evaluate_single_run(solver, task_dir, out_dir, trials=50, tol=0.05, seed=1, use_acceleration_mode=False, use_refinement=True,
-                        use_global_shutter_mode=False, flow_threshold=1e-10, write_outputs=True):
+                        use_global_shutter_mode=False, flow_threshold=1e-10, write_outputs=True, flow_index_mode=0):
+    """evaluateSingleRun (main.cc:302-559) on a synthetic example archive.  flow_index_mode 0 (default) = the reference: the
+    refinement reads the flow by inlier RANK (main.cc:457, quirk Q2); 1 = each inlier's own pixel."""
     from . import BACKPROJECT_GS, BACKPROJECT_RS, velocity_errors
 
     a = formats.load_example_archive(task_dir)
@@ -40,11 +42,13 @@ def evaluate_single_run(solver, task_dir, out_dir, trials=50, tol=0.05, seed=1, 
     flow, _ = solver.true_flow(f1["world"], f2["R"], f2["t"], K, want_best_row=False)
     # main.cc:398-457
     q, u, alpha, alpha_k = solver.flatten(flow, K, gamma, thr=flow_threshold)
+    if use_global_shutter_mode:  # main.cc:441-444
+        alpha = alpha * 0.0 + 1.0
     rr = solver.ransac(q, u, alpha, alpha_k, use_acceleration_mode, trials, tol, samples=None, seed=seed)
     res = dict(v=rr["v"], w=rr["w"], k=rr["k"], inliers=rr["inliers"])
     if use_refinement:
         ref = solver.non_linear_refinement(u, rr["inliers"], rr["alpha"], rr["alpha_k"], rr["v"], rr["w"], rr["k"], use_acceleration_mode,
-                                           flow_index_mode=1, inlier_idx=rr["inlier_idx"])
+                                           flow_index_mode=flow_index_mode, inlier_idx=rr["inlier_idx"] if flow_index_mode else None)
         res = dict(v=ref["v"], w=ref["w"], k=ref["k"], inliers=ref["inliers"], refine_summary=ref["summary"])
     # main.cc:466-509
     dm = solver.depth_map(res["inliers"], res["v"], K, rows, cols)
@@ -77,11 +81,12 @@ def evaluate_single_run(solver, task_dir, out_dir, trials=50, tol=0.05, seed=1, 
 # parameter sweep (reference main.cc:148-299 -> error_measure::evaluateVelocities, errorMeasure.cpp:41-254)
 # ---------------------------------------------------------------------------------------------------
 def evaluate_velocities(solvers, archive, gamma, ransac_trials=50, num_evaluations=5, constant_acceleration=False, global_shutter=False,
-                        optimize_results=True, tol=0.05, flow_threshold=1e-10, base_seed=1, image_path=None):
+                        optimize_results=True, tol=0.05, flow_threshold=1e-10, base_seed=1, image_path=None, flow_index_mode=0):
     """errorMeasure.cpp:41-254 for one task: ground-truth flow once, then `num_evaluations` independent solves (the reference
     reseeds rand() per trial; here evaluation e uses the sampler seed base_seed + e) with their rotation / translation /
     reprojection errors.  `solvers`: one Solver or a list -- the evaluations are independent and are spread over the
-    contexts, one host thread each (sequence-throughput mode)."""
+    contexts, one host thread each (sequence-throughput mode).  flow_index_mode 0 (default) = the reference's rank-indexed flow
+    (errorMeasure.cpp:152 -> nonlinearRefinement.cc:209-212, quirk Q2), 1 = gathered."""
     from concurrent.futures import ThreadPoolExecutor
 
     from . import BACKPROJECT_GS, BACKPROJECT_RS, Solver, velocity_errors
@@ -95,7 +100,7 @@ def evaluate_velocities(solvers, archive, gamma, ransac_trials=50, num_evaluatio
     flow, _ = s0.true_flow(f1["world"], f2["R"], f2["t"], K, want_best_row=False)
     q, u, alpha, alpha_k = s0.flatten(flow, K, gamma, thr=flow_threshold)
     if global_shutter:  # errorMeasure.cpp:107-112
-        alpha = np.ones_like(alpha)
+        alpha = alpha * 0.0 + 1.0
         constant_acceleration = False
     gt_depth = gt_depth_map(f1["world"], f1["R"], f1["t"])
     R_abs, t_abs = relocate_pose(f1["R"], f1["t"])
@@ -106,7 +111,7 @@ def evaluate_velocities(solvers, archive, gamma, ransac_trials=50, num_evaluatio
         res = dict(v=rr["v"], w=rr["w"], k=rr["k"], inliers=rr["inliers"])
         if optimize_results:
             ref = s.non_linear_refinement(u, rr["inliers"], rr["alpha"], rr["alpha_k"], rr["v"], rr["w"], rr["k"], constant_acceleration,
-                                          flow_index_mode=1, inlier_idx=rr["inlier_idx"])
+                                          flow_index_mode=flow_index_mode, inlier_idx=rr["inlier_idx"] if flow_index_mode else None)
             res = dict(v=ref["v"], w=ref["w"], k=ref["k"], inliers=ref["inliers"])
         dm = s.depth_map(res["inliers"], res["v"], K, rows, cols)
         w_err, v_err = velocity_errors(res["w"], dm["v"], truth["w"], truth["v"])

@@ -11,6 +11,7 @@ namespace nonlinear_refinement {
 using rsdsfm::lite::Array2Xd;
 using rsdsfm::lite::Array3Xd;
 using rsdsfm::lite::ArrayXd;
+using rsdsfm::lite::Vector2d;
 using rsdsfm::lite::Vector3d;
 
 /** residual of one correspondence (reference nonlinearRefinement.cc:32-52, T = double) */
@@ -55,13 +56,13 @@ inline ArrayXd estimateInverseDepths(const Array2Xd& normalized_coordinates, con
     return rho;
 }
 
-/** reference nonlinearRefinement.cc:55-106 (single pixel; 2-vectors passed as pointers to 2 doubles) */
-inline double estimateInverseDepth(const double normalized_coordinates[2], const Vector3d& linear_velocity,
-                                   const Vector3d& angular_velocity, const double flow[2], const double& k, const double& alpha,
+/** reference nonlinearRefinement.cc:55-106, declared nonlinearRefinement.h:77-79 (single pixel; same signature) */
+inline double estimateInverseDepth(const Vector2d& normalized_coordinates, const Vector3d& linear_velocity,
+                                   const Vector3d& angular_velocity, const Vector2d& flow, const double& k, const double& alpha,
                                    const double& alphaK, bool show_messages) {
     (void)show_messages;
     double rho = 1.0;
-    rsdsfm::check(rsdsfm_estimate_inverse_depths(rsdsfm::default_context(), normalized_coordinates, flow, 1, linear_velocity.data(),
+    rsdsfm::check(rsdsfm_estimate_inverse_depths(rsdsfm::default_context(), normalized_coordinates.data(), flow.data(), 1, linear_velocity.data(),
                                                  angular_velocity.data(), k, &alpha, &alphaK, rsdsfm::depth_mode(), &rho, nullptr),
                   "rsdsfm_estimate_inverse_depths");
     return rho;

@@ -85,6 +85,24 @@ private:
     double d_[3];
 };
 
+class Vector2d {
+public:
+    Vector2d() : d_{0, 0} {}
+    Vector2d(double x, double y) : d_{x, y} {}
+    static Vector2d Zero() { return Vector2d(); }
+    double& operator()(int i) { return d_[i]; }
+    double operator()(int i) const { return d_[i]; }
+    double& operator[](int i) { return d_[i]; }
+    double operator[](int i) const { return d_[i]; }
+    double x() const { return d_[0]; }
+    double y() const { return d_[1]; }
+    double* data() { return d_; }
+    const double* data() const { return d_; }
+
+private:
+    double d_[2];
+};
+
 class Matrix3d {  // column-major like Eigen
 public:
     Matrix3d() : d_{0, 0, 0, 0, 0, 0, 0, 0, 0} {}

@@ -50,6 +50,10 @@ int main(int argc, char** argv) {
         nonlinear_refinement::flow_index_mode() = RSDSFM_FLOW_GATHERED;
         RansacValues results = nonlinear_refinement::nonLinearRefinement(flow, ransac_results, false, false);
 
+        // single-pixel depth solve through the reference's signature (nonlinearRefinement.h:77-79: Vector2d / Vector3d references)
+        const double rho0 = nonlinear_refinement::estimateInverseDepth(Vector2d(coord(0, 0), coord(1, 0)), ransac_results.v, ransac_results.w,
+                                                                       Vector2d(flow(0, 0), flow(1, 0)), ransac_results.k, alpha(0), alphaK(0), false);
+
         // sign flip + depth map (main.cc:466-509)
         MatrixXd depth_map(rows, cols);
         std::vector<int32_t> ys((size_t)results.num_inliers);
@@ -139,11 +143,11 @@ int main(int argc, char** argv) {
                     "\"w\": [%.17g, %.17g, %.17g], \"v\": [%.17g, %.17g, %.17g], \"k\": %.17g, \"flipped\": %d, \"zsum\": %.17g, "
                     "\"ysum\": %lld, \"last_t\": [%.17g, %.17g, %.17g], \"last_R01\": %.17g, \"preview_sum\": %llu, \"gs_sum\": %llu, "
                     "\"bp_sum\": %llu, \"tf_sum\": %.17g, \"tf_point\": [%.17g, %.17g], \"mean_reproj\": %.17g, \"err_img_sum\": %llu, "
-                    "\"w_err\": %.17g, \"v_err\": %.17g}\n",
+                    "\"w_err\": %.17g, \"v_err\": %.17g, \"rho0\": %.17g}\n",
                     (long long)n, ransac_results.num_inliers, ransac_results.w(0), ransac_results.w(1), ransac_results.w(2), ransac_results.v(0),
                     ransac_results.v(1), ransac_results.v(2), results.w(0), results.w(1), results.w(2), results.v(0), results.v(1),
                     results.v(2), results.k, flipped, zsum, ysum, last.getRelativeTranslation()(0), last.getRelativeTranslation()(1),
-                    last.getRelativeTranslation()(2), last.getRelativeRotation()(0, 1), preview_sum, gs_sum, bp_sum, tf_sum, px1, py1, mean_reproj, err_img_sum, w_err, v_err);
+                    last.getRelativeTranslation()(2), last.getRelativeRotation()(0, 1), preview_sum, gs_sum, bp_sum, tf_sum, px1, py1, mean_reproj, err_img_sum, w_err, v_err, rho0);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -48,6 +48,8 @@ def test_single_run_matches_python_path(tmp_path, rsdsfm, oracle):
                                       inlier_idx=rr["inlier_idx"])
         dm = s.depth_map(ref["inliers"], ref["v"], K, 120, 200)
         R, t = s.pose_table(dm["v"], ref["w"], ref["k"], gamma, 120)
+        rho0 = s.estimate_inverse_depth(q[0], rr["v"], rr["w"], u[0], rr["k"], a[0], ak[0])
+    assert r["rho0"] == rho0  # estimateInverseDepth with the reference's (Vector2d, Vector3d, ...) signature
     assert r["n"] == len(q) and r["ransac_inliers"] == rr["num_inliers"]
     assert np.array_equal(r["ransac_w"], rr["w"]) and np.array_equal(r["ransac_v"], rr["v"])
     assert np.array_equal(r["w"], ref["w"]) and np.array_equal(r["v"], dm["v"]) and r["k"] == ref["k"]

@@ -40,7 +40,9 @@ def test_archive_end_to_end(rsdsfm, oracle, tmp_path):
     K, gamma, v, w, frames = _write_archive(rsdsfm, oracle, task)
     rows, cols = frames[0]["rs_image"].shape[:2]
     with rsdsfm.Solver(0) as s:
-        r = rsdsfm.evaluate.evaluate_single_run(s, task, out_dir, trials=20, tol=0.002, seed=3)
+        # selective tolerance: the inlier set is a strict subset, so the reference's rank-indexed flow (quirk Q2, the default)
+        # would pair inliers with other pixels' flow; this test checks the physics and uses each inlier's own flow
+        r = rsdsfm.evaluate.evaluate_single_run(s, task, out_dir, trials=20, tol=0.002, seed=3, flow_index_mode=1)
     # ---- the oracle chain on the same files ----
     a = rsdsfm.formats.load_example_archive(task)
     f1, f2 = a["frames"]
@@ -97,7 +99,7 @@ def test_parameter_sweep_over_archives(rsdsfm, oracle, tmp_path):
     dev = torch.device("cuda", 0)
     streams = [torch.cuda.Stream(dev) for _ in range(2)]
     solvers = [rsdsfm.Solver(0, stream=st.cuda_stream) for st in streams]
-    kw = dict(ransac_trials=12, num_evaluations=4, tol=0.002, base_seed=5)
+    kw = dict(ransac_trials=12, num_evaluations=4, tol=0.002, base_seed=5, flow_index_mode=1)
     res2 = rsdsfm.evaluate.evaluate_parameter_sweep(solvers, str(root), str(tmp_path / "results2"), **kw)
     res1 = rsdsfm.evaluate.evaluate_parameter_sweep(solvers[0], str(root), str(tmp_path / "results1"), **kw)
     for s in solvers:

@@ -5,7 +5,10 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_solve_frame_dev_matches_stages_and_oracle(oracle, rsdsfm):
+@pytest.mark.parametrize("flow_mode", [0, 1])
+def test_solve_frame_dev_matches_stages_and_oracle(oracle, rsdsfm, flow_mode):
+    """flow_mode 0 = RSDSFM_FLOW_COMPAT_RANK, the default of rsdsfm_frame_params and what evaluateSingleRun does (main.cc:457:
+    the refinement reads flow column i for the i-th inlier, quirk Q2); 1 = RSDSFM_FLOW_GATHERED (the inlier's own pixel)"""
     import torch
 
     dev = torch.device("cuda", 0)
@@ -17,13 +20,14 @@ def test_solve_frame_dev_matches_stages_and_oracle(oracle, rsdsfm):
     t = torch.empty((rows, 3), dtype=torch.float64, device=dev)
     T, tol, seed = 12, 0.002, 99
     with rsdsfm.Solver(0) as s:
-        r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), trials=T, tol=tol, seed=seed)
+        kw = {} if flow_mode == 0 else {"flow_index_mode": rsdsfm.FLOW_GATHERED}  # 0 is the default
+        r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), trials=T, tol=tol, seed=seed, **kw)
         s.synchronize()
         # stage by stage (host-pointer API)
         q, u, a, ak = s.flatten(d["flow_img"], K, gamma)
         rr = s.ransac(q, u, a, ak, False, T, tol, samples=None, seed=seed, depth_mode=1)
-        ref = s.non_linear_refinement(u, rr["inliers"], rr["alpha"], rr["alpha_k"], rr["v"], rr["w"], rr["k"], False, flow_index_mode=1,
-                                      inlier_idx=rr["inlier_idx"])
+        ref = s.non_linear_refinement(u, rr["inliers"], rr["alpha"], rr["alpha_k"], rr["v"], rr["w"], rr["k"], False, flow_index_mode=flow_mode,
+                                      inlier_idx=rr["inlier_idx"] if flow_mode else None)
         dmap = s.depth_map(ref["inliers"], ref["v"], K, rows, cols)
         Rr, tr = s.pose_table(dmap["v"], ref["w"], ref["k"], gamma, rows)
     assert r["n"] == len(q) and r["num_inliers"] == rr["num_inliers"] and r["best_trial"] == rr["best_trial"]
@@ -35,7 +39,10 @@ def test_solve_frame_dev_matches_stages_and_oracle(oracle, rsdsfm):
     # oracle chain on the same sampler / seed
     ro = oracle.ransac(q, u, a, ak, False, T, tol, oracle.sample_indices(len(q), T, seed), depth_mode=1)
     assert ro["num_inliers"] == r["num_inliers"] and ro["best_trial"] == r["best_trial"]
-    refo = oracle.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], False, 1, ro["inlier_idx"])
+    assert 0 < ro["num_inliers"] < len(q)  # selective tolerance: rank and pixel index differ, the two modes are different problems
+    refo = oracle.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], False, flow_mode, ro["inlier_idx"] if flow_mode else None)
+    for key in ("num_iterations", "num_successful_steps", "termination"):
+        assert r["refine_summary"][key] == refo["summary"][key], key
     inl_o, v_o, _ = oracle.canonicalize_sign(refo["inliers"], refo["v"])
     assert np.allclose(r["v"], v_o, rtol=1e-6, atol=1e-10) and np.allclose(r["w"], refo["w"], rtol=1e-6, atol=1e-10)
     dm_o, _, ys_o = oracle.scatter_depth(inl_o, *K, rows, cols)
@@ -154,7 +161,8 @@ def test_concurrent_contexts_do_not_interfere(oracle, rsdsfm):
         sv.close()
 
 
-def test_full_pipeline_1920x1080_matches_oracle_chain(oracle, rsdsfm):
+@pytest.mark.parametrize("flow_mode", [0, 1])
+def test_full_pipeline_1920x1080_matches_oracle_chain(oracle, rsdsfm, flow_mode):
     """BASELINE configs[2] ("real_world 1920x1080 full pipeline", 5 RANSAC trials like main.cc:304) end to end against the
     oracle chain on the same sampler: every integer (points, per-trial counts, winner, inlier list, LM step counts, depth-map
     support, scanline indices) bit-exact, floats to 1e-6 (north-star bar 1e-5)"""
@@ -167,7 +175,7 @@ def test_full_pipeline_1920x1080_matches_oracle_chain(oracle, rsdsfm):
     img = torch.from_numpy(d["flow_img"]).to(dev)
     dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
     with rsdsfm.Solver(0) as s:
-        r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=T, tol=tol, seed=seed)
+        r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=T, tol=tol, seed=seed, flow_index_mode=flow_mode)
         s.synchronize()
         q, u, a, ak = s.flatten(d["flow_img"], K, gamma)
         rr = s.ransac(q, u, a, ak, False, T, tol, samples=None, seed=seed, depth_mode=1)
@@ -176,7 +184,7 @@ def test_full_pipeline_1920x1080_matches_oracle_chain(oracle, rsdsfm):
     assert np.array_equal(rr["trial_count"], ro["trial_count"]) and np.array_equal(rr["trial_steps"], ro["trial_steps"])
     assert rr["best_trial"] == ro["best_trial"] == r["best_trial"] and r["num_inliers"] == ro["num_inliers"]
     assert np.array_equal(rr["inlier_idx"], ro["inlier_idx"])
-    refo = oracle.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], False, 1, ro["inlier_idx"])
+    refo = oracle.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], False, flow_mode, ro["inlier_idx"] if flow_mode else None)
     for key in ("num_iterations", "num_successful_steps", "termination"):
         assert r["refine_summary"][key] == refo["summary"][key], key
     inl_o, v_o, flipped_o = oracle.canonicalize_sign(refo["inliers"], refo["v"])
@@ -205,7 +213,7 @@ def test_bench_full_workload_matches_oracle_chain(oracle, rsdsfm):
     a, ak = oracle.get_alpha(fpx, rows, gamma), oracle.get_alpha_k(qpx, fpx, rows, gamma)
     ro = oracle.ransac(q, u, a, ak, False, T, tol, oracle.sample_indices(len(q), T, seed), depth_mode=1)
     assert r["n"] == len(q) and r["best_trial"] == ro["best_trial"] and r["num_inliers"] == ro["num_inliers"]
-    refo = oracle.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], False, 1, ro["inlier_idx"])
+    refo = oracle.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], False, 0, None)  # the default: flow by inlier rank
     for key in ("num_iterations", "num_successful_steps", "termination"):
         assert r["refine_summary"][key] == refo["summary"][key], key
     inl_o, v_o, flipped_o = oracle.canonicalize_sign(refo["inliers"], refo["v"])
@@ -222,3 +230,60 @@ def test_randomised_parity_campaign_sample(rsdsfm):
     import fuzz_gpu
 
     assert fuzz_gpu.main(120, 1) == 0
+
+
+def test_global_shutter_mode_matches_oracle_chain(oracle, rsdsfm):
+    """use_global_shutter_mode (main.cc:305, :441-444): alpha = 1 for every point before RANSAC -- the one-call solve equals the
+    oracle chain run on alpha = alpha * 0 + 1"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(3, rows=144, cols=256)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    T, tol, seed = 10, 0.004, 21
+    img = torch.from_numpy(d["flow_img"]).to(dev)
+    dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+    with rsdsfm.Solver(0) as s:
+        r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=T, tol=tol, seed=seed, use_global_shutter_mode=True)
+        r_rs = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=T, tol=tol, seed=seed)
+        s.synchronize()
+    q, u, qpx, fpx = oracle.flatten(d["flow_img"], *K, gamma)
+    a, ak = oracle.get_alpha(fpx, rows, gamma) * 0.0 + 1.0, oracle.get_alpha_k(qpx, fpx, rows, gamma)
+    ro = oracle.ransac(q, u, a, ak, False, T, tol, oracle.sample_indices(len(q), T, seed), depth_mode=1)
+    assert r["num_inliers"] == ro["num_inliers"] and r["best_trial"] == ro["best_trial"]
+    assert np.allclose(r["ransac_w"], ro["w"], atol=1e-10) and np.allclose(r["ransac_v"], ro["v"], atol=1e-10)
+    assert r["num_inliers"] != r_rs["num_inliers"]  # the rolling-shutter model explains this data differently
+    refo = oracle.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], False, 0, None)
+    _, v_o, _ = oracle.canonicalize_sign(refo["inliers"], refo["v"])
+    assert np.allclose(r["v"], v_o, rtol=1e-6, atol=1e-10) and np.allclose(r["w"], refo["w"], rtol=1e-6, atol=1e-10)
+
+
+def test_context_from_a_fresh_thread_and_device_is_restored(oracle, rsdsfm):
+    """every entry point makes the context's device current for the calling thread (allocations follow the CURRENT device) and
+    restores the caller's: a context used from a new host thread works, and on a multi-GPU box a context of device 1 leaves the
+    caller on device 0"""
+    import threading
+
+    import torch
+
+    d = rsdsfm.synth.make_config(1, rows=60, cols=80)
+    t = d["truth"]
+    v = t["v"] / np.linalg.norm(t["v"])
+    rho_o, _ = oracle.estimate_inverse_depths(d["q"], d["u"], v, t["w"], 0.0, d["alpha"], d["alpha_k"], mode=1)
+    ndev = torch.cuda.device_count()
+    for device in range(min(ndev, 2)):
+        torch.cuda.set_device(0)
+        s = rsdsfm.Solver(device)
+        assert torch.cuda.current_device() == 0
+        out = {}
+
+        def work():
+            out["rho"], _ = s.estimate_inverse_depths(d["q"], d["u"], v, t["w"], 0.0, d["alpha"], d["alpha_k"], mode=1)  # grows the staging buffers
+            out["rr"] = s.ransac(d["q"], d["u"], d["alpha"], d["alpha_k"], False, 4, 0.05, seed=3)["num_inliers"]
+
+        th = threading.Thread(target=work)
+        th.start()
+        th.join()
+        assert np.allclose(out["rho"], rho_o, rtol=1e-9, atol=1e-13) and out["rr"] > 0
+        assert torch.cuda.current_device() == 0
+        s.close()

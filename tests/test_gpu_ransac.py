@@ -199,3 +199,33 @@ def test_ransac_multi_round_lm(oracle, solver, rsdsfm):
     ro2 = oracle.ransac(q, u, a, ak, False, T, 0.05, smp2, depth_mode=1)
     assert len(set(ro2["trial_steps"].tolist())) > 1
     _compare_ransac(r2, ro2, rho_rtol=1e-8)
+
+
+@pytest.mark.parametrize("cfg,rows,cols,tol,noise", [(3, 135, 240, 0.002, None), (1, 60, 80, 0.05, None), (3, 90, 160, 0.05, 40.0)])
+def test_ransac_speculation_depth_does_not_change_results(oracle, rsdsfm, cfg, rows, cols, tol, noise):
+    """rsdsfm_set_ransac_speculation: round 0 of the hypothesis-batched LM solves speculates 3 iterations (+ fused scores of the one-
+    and two-step iterates) or 2 (+ the one-step score).  Mixed step counts (DeepFlow-like data: mostly two accepted steps), noise-
+    free data (2-3 steps) and outlier-dominated data (one step, decided by either depth in a single pass): every integer output is
+    identical for both depths and equal to the oracle's, floats agree to the summation order of the error sums"""
+    d = rsdsfm.synth.make_config(cfg, rows=rows, cols=cols)
+    q, u, a, ak = d["q"], d["u"].copy(), d["alpha"], d["alpha_k"]
+    if noise is not None:  # gross errors on a third of the points: the cost is dominated by them, every solve stops after one step
+        rng = np.random.default_rng(5)
+        idx = rng.choice(len(u), len(u) // 3, replace=False)
+        u[idx] += rng.uniform(-noise, noise, size=(len(idx), 2)) * d["gamma"] / d["K"][0]
+    T = 24
+    samples = oracle.sample_indices(len(q), T, 77)
+    ro = oracle.ransac(q, u, a, ak, False, T, tol, samples, depth_mode=1)
+    outs = []
+    with rsdsfm.Solver(0) as s:
+        for k0 in (3, 2, 0):
+            s.set_ransac_speculation(k0)
+            r = s.ransac(q, u, a, ak, False, T, tol, samples=samples, depth_mode=1)
+            _compare_ransac(r, ro)
+            outs.append((r["trial_count"].tobytes(), r["trial_steps"].tobytes(), r["mask"].tobytes(), r["inv_depth"].tobytes(),
+                         r["inliers"].tobytes(), r["best_trial"]))
+        with pytest.raises(rsdsfm.RsdsfmError):
+            s.set_ransac_speculation(1)
+    assert all(o == outs[0] for o in outs[1:])
+    if noise is not None:
+        assert ro["trial_steps"].max() == 1

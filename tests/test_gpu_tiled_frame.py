@@ -24,7 +24,8 @@ def _single(rsdsfm, torch, d, stream, **kw):
     R = torch.empty((rows, 9), dtype=torch.float64, device=dev)
     t = torch.empty((rows, 3), dtype=torch.float64, device=dev)
     with rsdsfm.Solver(0, stream=stream.cuda_stream) as s:
-        r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), **kw)
+        # the column-tiled solve gathers each inlier's own flow (a rank-indexed flow would live on another slab)
+        r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), flow_index_mode=rsdsfm.FLOW_GATHERED, **kw)
         s.synchronize()
         r["depth_map"] = dm.cpu().numpy().reshape(-1)
         r["R"], r["t"] = R.cpu().numpy(), t.cpu().numpy()

@@ -700,49 +700,25 @@ def _counters(kernel):
 
 
 def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):
-    """Roofline record of the whole solve's dominant kernel, ransac_lm_kernel<true> (round 0 of the hypothesis-batched LM depth
-    solves: 43 % of the solve), measured LIVE: the kernel is launched alone through rsdsfm_ransac_lm_launch_dev on the pair's real
-    flattened arrays and real hypotheses (sampler + minimal9) and bracketed with HIP events on the stream it runs on.  Its bound is
+    """Roofline record of the whole solve's dominant kernel, ransac_lm_kernel<true, 3> (round 0 of the hypothesis-batched LM depth
+    solves: ~45 % of the solve), measured LIVE and in situ: the library brackets that launch with HIP events on the stream it runs
+    on (rsdsfm_set_profiling) inside 27 ordinary whole solves after 3 warm-ups.  Its bound is
     fp64 VALU issue, not HBM: `achieved` = fp64 lane-instructions of one launch (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes,
     rocprofv3 PMC pass committed as profiles/counters.json) / the measured duration; `peak` = 39.3e12 / s.  "hbm" = SURVEY 8(d):
     (57 N + 64 M iterations) bytes / the solve's time / 8 TB/s."""
     rows, cols, T = full["rows"], full["cols"], args.trials
-    N = rows * cols
     img = full.pop("_img")
-    q = torch.empty(2 * N, dtype=torch.float64, device=dev)
-    u = torch.empty(2 * N, dtype=torch.float64, device=dev)
-    a = torch.empty(N, dtype=torch.float64, device=dev)
-    ak = torch.empty(N, dtype=torch.float64, device=dev)
-    n = solver.flatten_dev(img.data_ptr(), rows, cols, full["K"], full["gamma"], q.data_ptr(), u.data_ptr(), a.data_ptr(), ak.data_ptr())
-    smp = rsdsfm.sample_indices(n, T, 1).reshape(-1).astype(np.int64)
-    idx = torch.from_numpy(smp).to(dev)
-    q9 = q.view(-1, 2)[idx].contiguous()
-    u9 = u.view(-1, 2)[idx].contiguous()
-    a9, ak9 = a[idx].contiguous(), ak[idx].contiguous()
-    hyp = torch.empty((T, 8), dtype=torch.float64, device=dev)
-    torch.cuda.synchronize()
-    solver.minimal9_dev(q9.data_ptr(), u9.data_ptr(), a9.data_ptr(), ak9.data_ptr(), T, 0, 0, hyp.data_ptr())
-    solver.synchronize()
-
-    def launch():
-        solver.ransac_lm_launch_dev(q.data_ptr(), u.data_ptr(), a.data_ptr(), ak.data_ptr(), n, hyp.data_ptr(), T, args.tol)
-
-    for _ in range(3):
-        launch()
-    torch.cuda.synchronize()
-    # one launch per event pair with the device drained in between, as inside a solve (the kernel follows the latency-bound
-    # minimal9_kernel there; back-to-back bursts of this fp64-saturated kernel run ~8 % slower: sustained-power clocks)
-    reps = 24
+    depth_map = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+    n = full["n"]
+    # in situ: the library brackets the kernel with two HIP events on the context's stream inside ordinary solves
+    # (rsdsfm_set_profiling), so the launch has the same neighbours and clocks as in the timed loop
+    solver.set_profiling(True)
     ts = []
-    for i in range(reps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(stream)
-        launch()
-        e1.record(stream)
-        torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
-        time.sleep(0.0005)
-    ts.sort()
+    for i in range(30):
+        solver.solve_frame_dev(img.data_ptr(), rows, cols, full["K"], full["gamma"], depth_map.data_ptr(), trials=T, tol=args.tol, seed=1 + i)
+        ts.append(solver.profile_last_ms("ransac_lm_round0"))
+    solver.set_profiling(False)
+    ts = sorted(ts[3:])
     kern_ms = float(np.mean(ts))
     kname = "ransac_lm_kernel<true, 3>"
     ctr = _counters(kname + (":fused" if args.arith == "fused" else ""))

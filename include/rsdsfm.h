@@ -119,6 +119,12 @@ int rsdsfm_set_depth_variant(rsdsfm_ctx* ctx, int variant);
  * after ONE accepted step (outlier-dominated data); hypotheses that need more take a continuation round.  Integer results (counts,
  * masks, LM steps, winner) are identical for both; the inlier-error sums of two-step hypotheses can differ in their last bits. */
 int rsdsfm_set_ransac_speculation(rsdsfm_ctx* ctx, int k0);
+/* Opt-in profiling: while on, rsdsfm_ransac* / rsdsfm_solve_frame_dev bracket the dominant kernel of the whole solve -- round 0
+ * of the hypothesis-batched LM depth solves, `ransac_lm_kernel<true, 3>` -- with two HIP events on the context's stream (in
+ * situ: same launch, same neighbours, same clocks as any other solve).  rsdsfm_profile_last_ms(ctx, "ransac_lm_round0", &ms)
+ * returns the duration of that launch in the most recent call.  bench.py's roofline record uses it. */
+int rsdsfm_set_profiling(rsdsfm_ctx* ctx, int on);
+int rsdsfm_profile_last_ms(rsdsfm_ctx* ctx, const char* what, double* ms);
 /* name of the HIP kernel that dominates the given entry point (for profiling / roofline reports) */
 const char* rsdsfm_kernel_name(const char* entry_point);
 

@@ -192,6 +192,14 @@ class Solver:
         """0 = register-staged fused LM kernel (default), 1 = LDS-DMA double-buffered variant"""
         self._check(self.lib.rsdsfm_set_depth_variant(self._ctx, int(variant)), "rsdsfm_set_depth_variant")
 
+    def set_profiling(self, on):
+        self._check(self.lib.rsdsfm_set_profiling(self._ctx, int(bool(on))), "rsdsfm_set_profiling")
+
+    def profile_last_ms(self, what="ransac_lm_round0"):
+        ms = C.c_double()
+        self._check(self.lib.rsdsfm_profile_last_ms(self._ctx, what.encode(), C.byref(ms)), "rsdsfm_profile_last_ms")
+        return ms.value
+
     def set_ransac_speculation(self, k0):
         """LM iterations speculated by round 0 of RANSAC's batched depth solves: 3 (default; 0 selects it) or 2"""
         self._check(self.lib.rsdsfm_set_ransac_speculation(self._ctx, int(k0)), "rsdsfm_set_ransac_speculation")

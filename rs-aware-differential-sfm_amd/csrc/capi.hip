@@ -155,6 +155,8 @@ void rsdsfm_destroy(rsdsfm_ctx* ctx) {
     delete static_cast<RefineBuffers*>(c->tile_session);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+    for (hipEvent_t e : c->ev_prof)
+        if (e) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete ctx;
 }
@@ -172,6 +174,28 @@ int rsdsfm_set_depth_variant(rsdsfm_ctx* ctx, int variant) {
     if (variant < 0 || variant > 3) return fail(c, RSDSFM_ERR_INVALID, "depth variant must be 0 (default), 1 (LDS-DMA), 2 (decision fused into launch 0) or 3 (separate decide kernel)");
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     c->depth_variant = variant;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_set_profiling(rsdsfm_ctx* ctx, int on) {
+    CTX_OR_FAIL(ctx);
+    if (on && !c->ev_prof[0]) {
+        RSDSFM_HIP_CHECK(c, hipEventCreate(&c->ev_prof[0]));
+        RSDSFM_HIP_CHECK(c, hipEventCreate(&c->ev_prof[1]));
+    }
+    c->profile = on != 0;
+    c->prof_pending = false;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_profile_last_ms(rsdsfm_ctx* ctx, const char* what, double* ms) {
+    CTX_OR_FAIL(ctx);
+    if (!what || !ms || strcmp(what, "ransac_lm_round0") != 0) return fail(c, RSDSFM_ERR_INVALID, "unknown profile record (known: \"ransac_lm_round0\")");
+    if (!c->prof_pending) return fail(c, RSDSFM_ERR_INVALID, "no profile record: enable rsdsfm_set_profiling and run a RANSAC (LM mode) first");
+    RSDSFM_HIP_CHECK(c, hipEventSynchronize(c->ev_prof[1]));
+    float f = 0.f;
+    RSDSFM_HIP_CHECK(c, hipEventElapsedTime(&f, c->ev_prof[0], c->ev_prof[1]));
+    *ms = (double)f;
     return RSDSFM_OK;
 }
 

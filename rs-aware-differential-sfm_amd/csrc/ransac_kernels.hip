@@ -749,8 +749,14 @@ int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const doubl
     const int grid = ransac_pixel_grid(c, n);
     const dim3 g2(grid, ransac_lm_groups(c, grid, T));
     if (k0 != 2) k0 = KMAX;
+    const bool prof = c->profile && round == 0 && c->ev_prof[0] && c->ev_prof[1];
+    if (prof) RSDSFM_HIP_CHECK(c, hipEventRecord(c->ev_prof[0], c->stream));
     int rc = lm_launch(c, g2, k0, q, u, a, ak, n, hyp, T, states, partials, round, tol, flags);
     if (rc != RSDSFM_OK) return rc;
+    if (prof) {
+        RSDSFM_HIP_CHECK(c, hipEventRecord(c->ev_prof[1], c->stream));
+        c->prof_pending = true;
+    }
     hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, 1, states, n, round, k0, flags, flags + 2, scored,
                        trial_count, trial_err);
     RSDSFM_HIP_CHECK(c, hipGetLastError());

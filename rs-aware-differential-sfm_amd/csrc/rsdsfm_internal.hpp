@@ -105,6 +105,10 @@ struct Ctx {
     int num_cus = 256;
     int ransac_k0 = KMAX;      // LM iterations round 0 of the hypothesis-batched depth solves speculates (rsdsfm_set_ransac_speculation: 2 or KMAX)
     int ransac_not_one_step = 0;  // diagnostic of the last RANSAC: hypotheses that did not stop after exactly one accepted step
+    // opt-in profiling (rsdsfm_set_profiling): HIP events on the context's stream around the dominant kernel of the last RANSAC
+    bool profile = false;
+    hipEvent_t ev_prof[2] = {nullptr, nullptr};
+    bool prof_pending = false;
     int depth_variant = 0;  // 0 = register-staged depth_lm_kernel, 1 = LDS-DMA depth_lm_dma_kernel, 2 = launch 0 with the decision fused into its tail, 3 = separate decide kernel + follow-up launch (the pre-fusion fast path)
     // row-tiled refinement session (tiled_host.hip): buffers live in d_tile, not in the shared workspace
     void* d_tile = nullptr;

@@ -48,7 +48,14 @@ def test_solve_frame_dev_matches_stages_and_oracle(oracle, rsdsfm, flow_mode):
     dm_o, _, ys_o = oracle.scatter_depth(inl_o, *K, rows, cols)
     got = dm.cpu().numpy().T
     assert np.array_equal(got != 0, dm_o != 0)
-    assert np.allclose(got, dm_o, rtol=1e-6)
+    if flow_mode == 1:
+        assert np.allclose(got, dm_o, rtol=1e-6)
+    else:
+        # rank-indexed flow with a strict inlier subset pairs points with other pixels' flow (the reference's quirk Q2): a
+        # well-defined but physically meaningless problem whose optimum has points with 1/depth ~ 0 -- compare the solver's
+        # own variable (1/depth) with an absolute floor instead of the reciprocal
+        m = dm_o != 0
+        assert np.allclose(1.0 / got[m], 1.0 / dm_o[m], rtol=1e-6, atol=1e-9)
 
 
 def test_full_solve_4k_frame(rsdsfm):
@@ -62,7 +69,7 @@ def test_full_solve_4k_frame(rsdsfm):
     img = torch.from_numpy(d["flow_img"]).to(dev)
     dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
     with rsdsfm.Solver(0) as s:
-        r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=8, tol=0.002, seed=5)
+        r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=8, tol=0.002, seed=5, flow_index_mode=rsdsfm.FLOW_GATHERED)
         s.synchronize()
     n = rows * cols
     assert r["n"] == n and 0.5 * n < r["num_inliers"] < 0.95 * n  # 10 % outliers + noise tail rejected

@@ -171,19 +171,24 @@ def main(cases=None, seed0=None):
                     ref = O.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], use_k, 1, ro["inlier_idx"])
                     so, sr = out["summary"], ref["summary"]
                     same = all(so[key] == sr[key] for key in ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination"))
-                    hard = max(so["num_iterations"], sr["num_iterations"]) >= 15 or max(so["num_unsuccessful_steps"], sr["num_unsuccessful_steps"]) >= 5
-                    if hard:
-                        # ill-conditioned: tiny or sliver-shaped frames / acceleration mode that wander for 15+ iterations or reject steps (often to
-                        # the 50-iteration cap).  Every accept / reject there sits close to its threshold, the two runs differ by the
-                        # rounding of their Schur sums, and the trajectories are chaotic; only the outcome is compared.  Counted.
-                        assert np.isclose(so["final_cost"], sr["final_cost"], rtol=2e-2), ("ill-conditioned refinement", so, sr)
-                        splits += 1
-                        continue
                     if not same:
-                        # a long, ill-conditioned trajectory (tiny frame, acceleration mode, unsuccessful steps) can split when one
-                        # accept / reject test falls within the rounding of the Schur sums; both runs must then end with the same
-                        # termination type at the same cost (1e-4).  Counted, not failed.
-                        assert so["termination"] == sr["termination"] and np.isclose(so["final_cost"], sr["final_cost"], rtol=1e-4), ("refine trajectory", so, sr)
+                        # The accept / reject / converge decisions differ.  Both sides evaluate the same per-point terms; what differs is
+                        # the ORDER in which the global Schur / cost sums are added (sequential on the CPU, tree-shaped on the GPU).
+                        # Characterise the case with the oracle alone: re-run it on the reversed point list -- the same problem, its
+                        # own sums merely added in another order.  If the oracle reproduces its decisions, the trajectory is stable
+                        # under summation order and the GPU's deviation is a real mismatch: FAIL.  If the oracle splits from itself
+                        # (an accept / reject test sits within the rounding of a sum: tiny or sliver-shaped frames, acceleration mode,
+                        # 15+ iterations), the reference's own result is not defined beyond that spread; the GPU must then end with
+                        # the same termination type, inside the oracle's own spread of the final cost.  Counted, not failed.
+                        rev = slice(None, None, -1)
+                        ref2 = O.refine(u, ro["inliers"][rev], ro["alpha"][rev], ro["alpha_k"][rev], ro["v"], ro["w"], ro["k"], use_k, 1, ro["inlier_idx"][rev])
+                        s2 = ref2["summary"]
+                        oracle_stable = all(s2[key] == sr[key] for key in ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination"))
+                        assert not oracle_stable, ("refinement decisions differ although the oracle's trajectory is stable under re-ordering its sums", so, sr)
+                        spread = abs(s2["final_cost"] - sr["final_cost"])
+                        assert so["termination"] in (sr["termination"], s2["termination"]), ("termination type of a split trajectory", so, sr, s2)
+                        assert abs(so["final_cost"] - sr["final_cost"]) <= 4.0 * spread + 1e-9 * abs(sr["final_cost"]), (
+                            "split trajectory ends outside the oracle's own spread", so, sr, s2)
                         splits += 1
                         continue
                     # values at the north-star tolerance (1e-5; the committed tests assert 1e-6 on well-conditioned cases), compared

@@ -58,13 +58,13 @@ def test_solve_frame_dev_matches_stages_and_oracle(oracle, rsdsfm, flow_mode):
         assert np.allclose(1.0 / got[m], 1.0 / dm_o[m], rtol=1e-6, atol=1e-9)
 
 
-def test_full_solve_4k_frame(rsdsfm):
+def test_full_solve_4k_frame(rsdsfm, big_config):
     """3840x2160 (BASELINE configs[3] size): the whole solve runs at the largest configured size -- workspace sizing,
     64-bit indexing, compaction over > 2048 workgroups -- and recovers the motion of the DeepFlow-like pair."""
     import torch
 
     dev = torch.device("cuda", 0)
-    d = rsdsfm.synth.make_config(4)
+    d = big_config(4)
     rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
     img = torch.from_numpy(d["flow_img"]).to(dev)
     dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
@@ -169,14 +169,14 @@ def test_concurrent_contexts_do_not_interfere(oracle, rsdsfm):
 
 
 @pytest.mark.parametrize("flow_mode", [0, 1])
-def test_full_pipeline_1920x1080_matches_oracle_chain(oracle, rsdsfm, flow_mode):
+def test_full_pipeline_1920x1080_matches_oracle_chain(oracle, rsdsfm, big_config, flow_mode):
     """BASELINE configs[2] ("real_world 1920x1080 full pipeline", 5 RANSAC trials like main.cc:304) end to end against the
     oracle chain on the same sampler: every integer (points, per-trial counts, winner, inlier list, LM step counts, depth-map
     support, scanline indices) bit-exact, floats to 1e-6 (north-star bar 1e-5)"""
     import torch
 
     dev = torch.device("cuda", 0)
-    d = rsdsfm.synth.make_config(3)
+    d = big_config(3)
     rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
     T, tol, seed = 5, 0.002, 2024
     img = torch.from_numpy(d["flow_img"]).to(dev)
@@ -294,3 +294,43 @@ def test_context_from_a_fresh_thread_and_device_is_restored(oracle, rsdsfm):
         assert np.allclose(out["rho"], rho_o, rtol=1e-9, atol=1e-13) and out["rr"] > 0
         assert torch.cuda.current_device() == 0
         s.close()
+
+
+@pytest.mark.parametrize("cfg,T,tol", [(5, 10, 0.01), (3, 5, 0.004)])
+def test_acceleration_mode_full_size_matches_oracle_chain(oracle, rsdsfm, cfg, T, tol):
+    """use_acceleration_mode (main.cc:306: the minimal solver estimates k, the refinement frees it: 7 parameters, 7x7 Schur
+    complement) at BASELINE sizes -- 1280x720 and 1920x1080 DeepFlow-like pairs generated with k = 0.4 -- against the oracle
+    chain: integers (points, per-trial counts and LM steps, winner, inlier list, refinement iteration counts, depth-map
+    support) exact, v, w, k and the depth map within the north-star 1e-5 (measured ~1e-9)"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(cfg, k=0.4)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    seed = 31
+    img = torch.from_numpy(d["flow_img"]).to(dev)
+    dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+    with rsdsfm.Solver(0) as s:
+        r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=T, tol=tol, seed=seed, use_acceleration_mode=True,
+                              flow_index_mode=rsdsfm.FLOW_GATHERED)
+        s.synchronize()
+        q, u, a, ak = s.flatten(d["flow_img"], K, gamma)
+        rr = s.ransac(q, u, a, ak, True, T, tol, samples=None, seed=seed, depth_mode=1)
+    ro = oracle.ransac(q, u, a, ak, True, T, tol, oracle.sample_indices(len(q), T, seed), depth_mode=1)
+    assert np.array_equal(rr["trial_count"], ro["trial_count"]) and np.array_equal(rr["trial_steps"], ro["trial_steps"])
+    assert rr["best_trial"] == ro["best_trial"] == r["best_trial"] and r["num_inliers"] == ro["num_inliers"]
+    assert np.array_equal(rr["inlier_idx"], ro["inlier_idx"])
+    assert 0.3 * len(q) < ro["num_inliers"] < len(q) and abs(ro["k"]) > 1e-3  # a selective problem with a real k estimate
+    refo = oracle.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], True, 1, ro["inlier_idx"])
+    for key in ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination"):
+        assert r["refine_summary"][key] == refo["summary"][key], key
+    assert np.isclose(r["refine_summary"]["final_cost"], refo["summary"]["final_cost"], rtol=1e-9)
+    inl_o, v_o, flipped_o = oracle.canonicalize_sign(refo["inliers"], refo["v"])
+    assert r["flipped"] == flipped_o
+    rel = lambda x, y: float(np.max(np.abs(np.asarray(x) - np.asarray(y))) / np.max(np.abs(np.asarray(y))))
+    dv, dw, dk = rel(r["v"], v_o), rel(r["w"], refo["w"]), abs(r["k"] - refo["k"]) / abs(refo["k"])
+    print("accel mode %dx%d: v %.2e w %.2e k %.2e (iterations %d)" % (cols, rows, dv, dw, dk, refo["summary"]["num_iterations"]))
+    assert dv <= 1e-5 and dw <= 1e-5 and dk <= 1e-5
+    dm_o, _, _ = oracle.scatter_depth(inl_o, *K, rows, cols)
+    got = dm.cpu().numpy().T
+    assert np.array_equal(got != 0, dm_o != 0) and np.allclose(got, dm_o, rtol=1e-5)

@@ -74,9 +74,10 @@ def _gpu_chain(rsdsfm, arith, d, o, T, tol, seed, accel=False):
 # (config, rows, cols, trials, tol): configs[2] 1920x1080 with main.cc's 5 trials, configs[3] 3840x2160, configs[4] = the bench
 # workload (1280x720 DeepFlow-like pair, 50 trials, tol 0.05); the 4K oracle chain takes ~20 s on one host core
 @pytest.mark.parametrize("cfg,T,tol,seed", [(3, 5, 0.002, 2024), (4, 5, 0.002, 5), (5, 50, 0.05, 1)])
-def test_fused_whole_solve_vs_unfused_oracle(oracle, rsdsfm, cfg, T, tol, seed):
-    d = rsdsfm.synth.make_config(cfg, seed=0x5EED0005 if cfg == 5 else None)
-    o = _oracle_chain(oracle, d, T, tol, seed)
+def test_fused_whole_solve_vs_unfused_oracle(oracle, rsdsfm, big_config, oracle_chain, cfg, T, tol, seed):
+    data_seed = 0x5EED0005 if cfg == 5 else None
+    d = big_config(cfg, data_seed)
+    o = oracle_chain(cfg, T, tol, seed, data_seed=data_seed)
     ro, n = o["ransac"], len(o["q"])
     rr, ref, dmap = _gpu_chain(rsdsfm, "fused", d, o, T, tol, seed)
     # LM decisions of every trial's depth solve: identical

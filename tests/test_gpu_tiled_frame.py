@@ -91,6 +91,35 @@ def test_tiled_frame_matches_single_context(rsdsfm, cfg, accel):
             assert len(til["inliers"]) == one["num_inliers"] and len(til["ys"]) == one["num_inliers"]
 
 
+def test_tiled_3840x2160_in_8_slabs_matches_single_context_and_oracle(rsdsfm, oracle_chain, big_config):
+    """BASELINE configs[3] at full size: the 3840x2160 DeepFlow-like frame as 8 column slabs (8 logical shards = 8 solver
+    contexts on the one GPU of the test box, exactly the per-rank call sequence of the 8-GPU run) against the un-tiled solve and
+    against the oracle chain with main.cc's 5 trials: every integer (points, inliers, winner, LM decisions, depth-map support,
+    scanline indices) exact, floats to 1e-6 vs the oracle and 1e-9 between the two GPU paths"""
+    import torch
+
+    stream = torch.cuda.Stream(torch.device("cuda", 0))
+    T, tol, seed = 5, 0.002, 5
+    with torch.cuda.stream(stream):
+        d = big_config(4)
+        rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+        kw = dict(trials=T, tol=tol, seed=seed)
+        one = _single(rsdsfm, torch, d, stream, **kw)
+        til = _tiled(rsdsfm, torch, d, 8, stream, **kw)
+    assert len(til["shard_n"]) == 8 and sum(til["shard_n"]) == one["n"] == rows * cols
+    _compare(til, one, rows, cols)
+    # oracle chain (gathered flow, as the tiled solve uses it)
+    o = oracle_chain(4, T, tol, seed)
+    ro, refo = o["ransac"], o["refine"]
+    assert til["num_inliers"] == ro["num_inliers"] and til["best_trial"] == ro["best_trial"]
+    for key in ("num_iterations", "num_successful_steps", "termination"):
+        assert til["refine_summary"][key] == refo["summary"][key], key
+    assert til["flipped"] == o["flipped"] and np.allclose(til["v"], o["v"], rtol=1e-6, atol=1e-10) and np.allclose(til["w"], refo["w"], rtol=1e-6, atol=1e-10)
+    assert np.array_equal(til["ys"], o["ys"])  # scanline index of every inlier: bit-exact
+    got = til["depth_map"].reshape(cols, rows).T
+    assert np.array_equal(got != 0, o["depth_map"] != 0) and np.allclose(got, o["depth_map"], rtol=1e-6)
+
+
 def test_tiled_frame_closed_form_no_refinement_and_many_trials(rsdsfm):
     """closed-form depth mode (no LM rounds, score pass only), no refinement, and more trials than one hypothesis
     batch (> 128) so that the batched rows / decide calls are offset correctly"""

@@ -21,6 +21,7 @@
 #ifndef RSDSFM_H
 #define RSDSFM_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -364,6 +365,48 @@ int rsdsfm_tile_depth_map_dev(rsdsfm_ctx* ctx, double* d_inl3m, int64_t m_shard,
                               int64_t m_total, double v_inout[3], double fx, double fy, double cx, double cy, int32_t rows,
                               int32_t col0, int32_t slab_cols, double* d_depth_slab, int32_t* d_xs_or_null,
                               int32_t* d_ys_or_null, int* flipped);
+
+/* ---- the column-tiled whole solve driven from inside the library (BASELINE configs[3]) ------------------
+ * One process per GPU, one context per process.  Every rank passes ITS column slab of the flow image (slab bounds:
+ * rsdsfm_tiled_slab_bounds) and all ranks return the same pose and the full depth map: the call sequence of the
+ * rsdsfm_tile_* stages above with the collectives issued on the context's stream -- small all-gathers of the stage rows in
+ * rank order, one exact all-reduce of the 9 T sampled points, ONE all-gather of the depth-map slabs -- and 4-5 host
+ * synchronisations per solve.  Transport: RCCL (resolved with dlopen at the first rsdsfm_dist_* call; the library loads
+ * without it), with the communicator created here from a shared unique id, adopted from the caller, or replaced by
+ * caller-provided collectives. */
+#define RSDSFM_DIST_ID_BYTES 128
+/* rank 0 creates the id (ncclGetUniqueId) and shares its 128 bytes with the other ranks over any channel */
+int rsdsfm_dist_unique_id(void* id_128_bytes);
+/* collective over the ranks: ncclCommInitRank on the context's device */
+int rsdsfm_dist_init(rsdsfm_ctx* ctx, int32_t nranks, int32_t rank, const void* id_128_bytes);
+/* use a communicator the caller owns (an ncclComm_t of the same RCCL); it is not destroyed with the context */
+int rsdsfm_dist_adopt(rsdsfm_ctx* ctx, void* nccl_comm, int32_t nranks, int32_t rank);
+/* caller-provided collectives instead of RCCL.  all_gather: `bytes_per_rank` bytes from d_send into d_recv[rank * bytes_per_rank]
+ * of every rank, in rank order; d_send may alias d_recv + rank * bytes_per_rank.  all_reduce: in-place sum of `count` doubles.
+ * Both must be ordered after the work already enqueued on `hip_stream` and before what is enqueued next; return 0 on success. */
+typedef int (*rsdsfm_all_gather_fn)(void* user, const void* d_send, void* d_recv, size_t bytes_per_rank, void* hip_stream);
+typedef int (*rsdsfm_all_reduce_sum_f64_fn)(void* user, double* d_buf, size_t count, void* hip_stream);
+int rsdsfm_dist_set_transport(rsdsfm_ctx* ctx, int32_t nranks, int32_t rank, rsdsfm_all_gather_fn all_gather_fn,
+                              rsdsfm_all_reduce_sum_f64_fn all_reduce_fn, void* user);
+int rsdsfm_dist_finalize(rsdsfm_ctx* ctx);
+/* slab of `rank`: image columns [col0, col0 + slab_cols); stride_cols = ceil(cols / nranks) is the common slab stride */
+int rsdsfm_tiled_slab_bounds(int32_t cols, int32_t nranks, int32_t rank, int32_t* col0, int32_t* slab_cols, int32_t* stride_cols);
+
+typedef struct rsdsfm_tiled_info {
+    int32_t nranks, rank, col0, slab_cols;
+    int64_t shard_points, shard_inliers;          /* of this rank's slab                                              */
+    int32_t host_syncs, collectives, ransac_rounds, _pad; /* diagnostics of the call                                   */
+} rsdsfm_tiled_info;
+
+/* d_img_slab: row-major [rows][slab_cols][2] slab of this rank (DEVICE); cols = width of the WHOLE image.  params->
+ * flow_index_mode must be RSDSFM_FLOW_GATHERED.  d_depth_map: rows x cols column-major (DEVICE), the full map on every rank.
+ * result: n_points / num_inliers are GLOBAL counts; d_inliers / d_inlier_idx / d_scanline describe this rank's slab (info->
+ * shard_inliers entries, indices local to the slab's point list).  Without a communicator (no rsdsfm_dist_* call) the context
+ * is a single rank.  info may be NULL. */
+int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int32_t rows, int32_t cols, double fx, double fy,
+                                 double cx, double cy, double gamma, const rsdsfm_frame_params* params,
+                                 double* d_depth_map_colmajor, double* d_R_rows9_or_null, double* d_t_rows3_or_null,
+                                 rsdsfm_frame_result* result, rsdsfm_tiled_info* info_or_null);
 
 /* ---- consumers of the solve's output ----------------------------------------------------------
  * Images are 8-bit BGR, row-major rows x cols x 3 (cv::Mat CV_8UC3 as the reference holds them); the depth map is the

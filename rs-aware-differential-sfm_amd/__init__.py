@@ -67,6 +67,34 @@ class FrameResult(C.Structure):
                 ("d_inliers", C.c_void_p), ("d_inlier_idx", C.c_void_p), ("d_scanline", C.c_void_p)]
 
 
+class TiledInfo(C.Structure):
+    _fields_ = [("nranks", C.c_int32), ("rank", C.c_int32), ("col0", C.c_int32), ("slab_cols", C.c_int32), ("shard_points", C.c_int64),
+                ("shard_inliers", C.c_int64), ("host_syncs", C.c_int32), ("collectives", C.c_int32), ("ransac_rounds", C.c_int32), ("_pad", C.c_int32)]
+
+
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+DIST_ID_BYTES = 128
+
+
+def dist_unique_id():
+    """rank 0: the 128-byte RCCL unique id to share with the other ranks (rsdsfm_dist_unique_id)"""
+    buf = C.create_string_buffer(DIST_ID_BYTES)
+    rc = load_library().rsdsfm_dist_unique_id(buf)
+    if rc != OK:
+        raise RsdsfmError("rsdsfm_dist_unique_id failed (%d): RCCL not available?" % rc)
+    return bytes(buf.raw)
+
+
+def tiled_slab_bounds(cols, nranks, rank):
+    """(col0, slab_cols, stride_cols) of `rank`'s column slab (rsdsfm_tiled_slab_bounds)"""
+    c0, sc, per = C.c_int32(), C.c_int32(), C.c_int32()
+    rc = load_library().rsdsfm_tiled_slab_bounds(C.c_int32(cols), C.c_int32(nranks), C.c_int32(rank), C.byref(c0), C.byref(sc), C.byref(per))
+    if rc != OK:
+        raise RsdsfmError("rsdsfm_tiled_slab_bounds failed (%d)" % rc)
+    return c0.value, sc.value, per.value
+
+
 class RansacOut(C.Structure):
     _fields_ = [
         ("num_inliers", C.c_int64),
@@ -383,6 +411,39 @@ class Solver:
                     ransac_w=np.array(res.ransac_w[:]), ransac_v=np.array(res.ransac_v[:]), ransac_k=float(res.ransac_k),
                     w=np.array(res.w[:]), v=np.array(res.v[:]), k=float(res.k), refine_summary=res.refine_summary.as_dict(),
                     d_inliers=res.d_inliers, d_inlier_idx=res.d_inlier_idx, d_scanline=res.d_scanline)
+
+    # ---- the column-tiled whole solve driven inside the library (RCCL or caller-provided collectives) ----
+    def dist_init(self, nranks, rank, unique_id):
+        """collective: creates the RCCL communicator of this context from the shared 128-byte id (rsdsfm_dist_init)"""
+        self._check(self.lib.rsdsfm_dist_init(self._ctx, C.c_int32(nranks), C.c_int32(rank), C.c_char_p(bytes(unique_id))), "rsdsfm_dist_init")
+
+    def dist_set_transport(self, nranks, rank, all_gather, all_reduce):
+        """caller-provided collectives (Python callables taking (d_send, d_recv, bytes_per_rank, stream) / (d_buf, count, stream) and
+        returning 0) instead of RCCL; the ctypes thunks are kept alive on the solver"""
+        self._ag = ALL_GATHER_FN(lambda user, s_, r_, b_, st: int(all_gather(s_, r_, b_, st)))
+        self._ar = ALL_REDUCE_FN(lambda user, p_, n_, st: int(all_reduce(p_, n_, st)))
+        self._check(self.lib.rsdsfm_dist_set_transport(self._ctx, C.c_int32(nranks), C.c_int32(rank), self._ag, self._ar, None), "rsdsfm_dist_set_transport")
+
+    def dist_finalize(self):
+        self._check(self.lib.rsdsfm_dist_finalize(self._ctx), "rsdsfm_dist_finalize")
+
+    def solve_frame_tiled_dev(self, d_img_slab, rows, cols, K, gamma, d_depth_map, d_R=None, d_t=None, trials=50, tol=0.05, seed=1,
+                              use_acceleration_mode=False, use_refinement=True, depth_mode=DEPTH_CERES_LM, k_sign_mode=K_COMPAT,
+                              flow_threshold=1e-10, use_global_shutter_mode=False):
+        """this rank's part of the column-tiled whole solve (rsdsfm_solve_frame_tiled_dev): d_img_slab = this rank's [rows][slab_cols][2]
+        slab, cols = width of the whole image; returns the dict of solve_frame_dev (global counts) plus the slab's info"""
+        prm = FrameParams(int(trials), int(use_acceleration_mode), int(use_refinement), int(depth_mode), int(k_sign_mode),
+                          FLOW_GATHERED, int(use_global_shutter_mode), 0, float(tol), float(flow_threshold), int(seed))
+        res, info = FrameResult(), TiledInfo()
+        d = C.c_double
+        self._check(self.lib.rsdsfm_solve_frame_tiled_dev(self._ctx, _dp(d_img_slab) if d_img_slab else None, C.c_int32(rows), C.c_int32(cols), d(K[0]), d(K[1]),
+                                                          d(K[2]), d(K[3]), d(gamma), C.byref(prm), _dp(d_depth_map), _dp(d_R) if d_R else None,
+                                                          _dp(d_t) if d_t else None, C.byref(res), C.byref(info)), "rsdsfm_solve_frame_tiled_dev")
+        return dict(n=int(res.n_points), num_inliers=int(res.num_inliers), best_trial=int(res.best_trial), flipped=bool(res.flipped),
+                    ransac_w=np.array(res.ransac_w[:]), ransac_v=np.array(res.ransac_v[:]), ransac_k=float(res.ransac_k),
+                    w=np.array(res.w[:]), v=np.array(res.v[:]), k=float(res.k), refine_summary=res.refine_summary.as_dict(),
+                    d_inliers=res.d_inliers, d_inlier_idx=res.d_inlier_idx, d_scanline=res.d_scanline,
+                    info={k2: int(getattr(info, k2)) for k2, _ in TiledInfo._fields_ if k2 != "_pad"})
 
     def depth_lm_reduce_dev(self, n_shard, d_row):
         self._check(self.lib.rsdsfm_depth_lm_reduce_dev(self._ctx, C.c_int64(n_shard), _dp(d_row)), "rsdsfm_depth_lm_reduce_dev")

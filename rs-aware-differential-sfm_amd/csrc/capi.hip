@@ -154,6 +154,7 @@ void rsdsfm_destroy(rsdsfm_ctx* ctx) {
     if (c->d_tile) (void)hipFree(c->d_tile);
     delete static_cast<RefineBuffers*>(c->tile_session);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    dist_release(c);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     for (hipEvent_t e : c->ev_prof)
         if (e) (void)hipEventDestroy(e);

@@ -1,0 +1,654 @@
+// dist_host.hip -- the column-tiled WHOLE solve of one frame over the GPUs of a node, driven from C++ inside the library
+// (BASELINE configs[3]).  One process per GPU, one context per process; every rank calls
+// rsdsfm_solve_frame_tiled_dev with ITS column slab of the flow image and all ranks return the same pose and the full depth map.
+//
+// The reference's solver part of evaluateSingleRun (main.cc:398-522) is sequential; what makes it tile is that
+//   * the reference flattens the image column-major (main.cc:398-444), so the slabs' point lists in rank order concatenate to the
+//     reference's point list and a rank only ever holds its slab;
+//   * every global decision (trust-region accept / reject / converge of the per-trial depth solves, minimal.cc:209-306; of the
+//     joint refinement, nonlinearRefinement.cc:183-252; the mean-z sign, main.cc:466-481) depends on a handful of sums.  Each rank
+//     reduces its slab to one small row, the rows are ALL-GATHERED in rank order (an all-gather, not an all-reduce: the summation
+//     order stays fixed, results are bit-reproducible and independent of the transport), and every rank runs the same decide kernel
+//     -- the very kernel that reduces per-workgroup partials in the single-GPU solve, with ranks in place of workgroups -- on
+//     identical data: identical decisions everywhere, nothing is ever broadcast.
+// Exchanges per solve: point counts (8 B), the 9 T sampled points (all-reduce of 54 T doubles with one non-zero term per entry:
+// exact), [T][22] sums per RANSAC LM round, [T][2] scores when needed, 17 / 54..70 / 13 doubles per refinement stage, one z sum,
+// and ONE all-gather of the depth-map slabs (8 B x pixels) -- the only data-path collective, direct per-link transfers over xGMI.
+// Everything is enqueued on the context's stream; the host synchronises 4-5 times per solve (counts, RANSAC flags + winner,
+// refinement poll every 5 iterations, final header), never per RANSAC round or LM iteration in the common case.
+//
+// Transport: RCCL (ncclAllGather / ncclAllReduce on the context's stream), resolved at run time with dlopen so that the library
+// loads on hosts without RCCL; the communicator is created here from a unique id the ranks share over any channel
+// (rsdsfm_dist_unique_id / rsdsfm_dist_init), or adopted from the caller (rsdsfm_dist_adopt: e.g. an MPI / torch host that already
+// owns an ncclComm_t).  rsdsfm_dist_set_transport installs caller-provided collectives instead (used by the tests to run several
+// logical ranks on one GPU, and by hosts with another communication library).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <string.h>
+
+#include <algorithm>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rsdsfm_internal.hpp"
+
+using namespace rsdsfm;
+
+namespace rsdsfm {
+int alpha_ones_launch(Ctx* c, double* d_alpha, int64_t n);
+}
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// RCCL, resolved at run time
+// ---------------------------------------------------------------------------------------------------
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+Rccl* rccl() {
+    static Rccl R;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // an RCCL that is already in the process (PyTorch-ROCm ships its own librccl.so) is preferred: one RCCL per process
+        const char* env = getenv("RSDSFM_RCCL_LIB");
+        struct Try {
+            const char* name;
+            int flags;
+        } tries[] = {{env, RTLD_NOW | RTLD_LOCAL},
+                     {"librccl.so", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD},
+                     {"librccl.so.1", RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD},
+                     {"librccl.so.1", RTLD_NOW | RTLD_LOCAL},
+                     {"librccl.so", RTLD_NOW | RTLD_LOCAL},
+                     {"/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL}};
+        for (const Try& t : tries) {
+            if (!t.name || !*t.name) continue;
+            R.handle = dlopen(t.name, t.flags);
+            if (R.handle) break;
+        }
+        if (!R.handle) {
+            R.error = "RCCL not found (librccl.so / librccl.so.1; set RSDSFM_RCCL_LIB)";
+            return;
+        }
+        auto sym = [&](const char* n) { return dlsym(R.handle, n); };
+        R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(sym("ncclGetUniqueId"));
+        R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(sym("ncclCommInitRank"));
+        R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
+        R.AllGather = reinterpret_cast<decltype(R.AllGather)>(sym("ncclAllGather"));
+        R.AllReduce = reinterpret_cast<decltype(R.AllReduce)>(sym("ncclAllReduce"));
+        R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
+        if (!R.GetUniqueId || !R.CommInitRank || !R.CommDestroy || !R.AllGather || !R.AllReduce) {
+            R.error = "RCCL library lacks a required symbol";
+            R.handle = nullptr;
+        }
+    });
+    return &R;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-context distributed state
+// ---------------------------------------------------------------------------------------------------
+struct Dist {
+    int nranks = 1, rank = 0;
+    ncclComm_t comm = nullptr;
+    bool own_comm = false;
+    rsdsfm_all_gather_fn ag = nullptr;  // caller-provided transport (overrides RCCL)
+    rsdsfm_all_reduce_sum_f64_fn ar = nullptr;
+    void* user = nullptr;
+    void* d_buf = nullptr;  // device arena of the small exchange buffers + (when the slab stride pads the image) the gathered depth map
+    size_t bytes = 0;
+    void* d_session = nullptr;  // refinement session buffers
+    size_t session_bytes = 0;
+    int host_syncs = 0, collectives = 0, ransac_rounds = 0;  // diagnostics of the last solve
+};
+
+Dist* dist_of(Ctx* c, bool create) {
+    if (!c->dist && create) c->dist = new (std::nothrow) Dist();
+    return static_cast<Dist*>(c->dist);
+}
+
+int nccl_fail(Ctx* c, ncclResult_t r, const char* what) {
+    Rccl* R = rccl();
+    c->err = std::string(what) + ": " + (R->GetErrorString ? R->GetErrorString(r) : "RCCL error");
+    return RSDSFM_ERR_HIP;
+}
+
+// all-gather of `bytes` bytes per rank (rank order) on the context's stream; send may alias recv + rank * bytes
+int all_gather(Ctx* c, Dist* D, const void* d_send, void* d_recv, size_t bytes) {
+    if (bytes == 0) return RSDSFM_OK;
+    D->collectives += 1;
+    if (D->ag) {
+        if (D->ag(D->user, d_send, d_recv, bytes, c->stream) != 0) return fail(c, RSDSFM_ERR_HIP, "caller-provided all-gather failed");
+        return RSDSFM_OK;
+    }
+    if (D->comm) {
+        ncclResult_t r = rccl()->AllGather(d_send, d_recv, bytes, ncclChar, D->comm, c->stream);
+        if (r != ncclSuccess) return nccl_fail(c, r, "ncclAllGather");
+        return RSDSFM_OK;
+    }
+    if (D->nranks != 1) return fail(c, RSDSFM_ERR_INVALID, "no communicator: call rsdsfm_dist_init / rsdsfm_dist_adopt / rsdsfm_dist_set_transport first");
+    if (d_send != d_recv) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return RSDSFM_OK;
+}
+
+// in-place sum over ranks of `count` doubles.  Only used where at most one rank contributes a non-zero term per entry (exact).
+int all_reduce_sum(Ctx* c, Dist* D, double* d_buf, size_t count) {
+    if (count == 0) return RSDSFM_OK;
+    D->collectives += 1;
+    if (D->ar) {
+        if (D->ar(D->user, d_buf, count, c->stream) != 0) return fail(c, RSDSFM_ERR_HIP, "caller-provided all-reduce failed");
+        return RSDSFM_OK;
+    }
+    if (D->comm) {
+        ncclResult_t r = rccl()->AllReduce(d_buf, d_buf, count, ncclDouble, ncclSum, D->comm, c->stream);
+        if (r != ncclSuccess) return nccl_fail(c, r, "ncclAllReduce");
+        return RSDSFM_OK;
+    }
+    if (D->nranks != 1) return fail(c, RSDSFM_ERR_INVALID, "no communicator");
+    return RSDSFM_OK;
+}
+
+int ensure_dev(Ctx* c, void** p, size_t* have, size_t bytes) {
+    if (bytes <= *have) return RSDSFM_OK;
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (*p) (void)hipFree(*p);
+    *p = nullptr;
+    *have = 0;
+    RSDSFM_HIP_CHECK(c, hipMalloc(p, bytes));
+    *have = bytes;
+    return RSDSFM_OK;
+}
+
+int sync(Ctx* c, Dist* D) {
+    D->host_syncs += 1;
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return RSDSFM_OK;
+}
+
+// the 9 T sampled points as the minimal solver wants them (q9, u9: [9T][2]; a9, ak9: [9T]), one contiguous block of 54 T doubles:
+// a rank writes the points it owns and zeros elsewhere, so the sum over ranks has exactly one non-zero term per entry
+__global__ __launch_bounds__(256) void pack_samples_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
+                                                          const double* __restrict__ alpha, const double* __restrict__ alpha_k,
+                                                          int64_t n_local, int64_t offset, const int32_t* __restrict__ samples,
+                                                          int count, double* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const int64_t loc = (int64_t)samples[j] - offset;
+    const bool mine = loc >= 0 && loc < n_local;
+    double2 qq = make_double2(0.0, 0.0), uu = make_double2(0.0, 0.0);
+    double a = 0.0, ak = 0.0;
+    if (mine) {
+        qq = q[loc];
+        uu = u[loc];
+        a = alpha[loc];
+        ak = alpha_k[loc];
+    }
+    double* q9 = out;
+    double* u9 = out + 2 * (size_t)count;
+    double* a9 = out + 4 * (size_t)count;
+    double* ak9 = out + 5 * (size_t)count;
+    q9[2 * j] = qq.x, q9[2 * j + 1] = qq.y;
+    u9[2 * j] = uu.x, u9[2 * j + 1] = uu.y;
+    a9[j] = a;
+    ak9[j] = ak;
+}
+
+}  // namespace
+
+namespace rsdsfm {
+void dist_release(Ctx* c) {
+    Dist* D = static_cast<Dist*>(c->dist);
+    if (!D) return;
+    if (D->comm && D->own_comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(D->comm);
+    if (D->d_buf) (void)hipFree(D->d_buf);
+    if (D->d_session) (void)hipFree(D->d_session);
+    delete D;
+    c->dist = nullptr;
+}
+}  // namespace rsdsfm
+
+extern "C" {
+
+int rsdsfm_dist_unique_id(void* id_128_bytes) {
+    if (!id_128_bytes) return RSDSFM_ERR_INVALID;
+    Rccl* R = rccl();
+    if (!R->handle) return RSDSFM_ERR_NO_DEVICE;
+    ncclUniqueId id;
+    if (R->GetUniqueId(&id) != ncclSuccess) return RSDSFM_ERR_HIP;
+    static_assert(sizeof(ncclUniqueId) == RSDSFM_DIST_ID_BYTES, "id size");
+    memcpy(id_128_bytes, &id, sizeof(id));
+    return RSDSFM_OK;
+}
+
+int rsdsfm_dist_init(rsdsfm_ctx* ctx, int32_t nranks, int32_t rank, const void* id_128_bytes) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
+    if (nranks < 1 || rank < 0 || rank >= nranks || !id_128_bytes) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    Rccl* R = rccl();
+    if (!R->handle) return fail(c, RSDSFM_ERR_NO_DEVICE, R->error.c_str());
+    Dist* D = dist_of(c, true);
+    if (!D) return fail(c, RSDSFM_ERR_INVALID, "out of host memory");
+    if (D->comm && D->own_comm) (void)R->CommDestroy(D->comm);
+    D->comm = nullptr;
+    ncclUniqueId id;
+    memcpy(&id, id_128_bytes, sizeof(id));
+    ncclResult_t r = R->CommInitRank(&D->comm, nranks, id, rank);  // on the context's device (made current by the guard)
+    if (r != ncclSuccess) return nccl_fail(c, r, "ncclCommInitRank");
+    D->own_comm = true;
+    D->nranks = nranks;
+    D->rank = rank;
+    D->ag = nullptr;
+    D->ar = nullptr;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_dist_adopt(rsdsfm_ctx* ctx, void* nccl_comm, int32_t nranks, int32_t rank) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
+    if (!nccl_comm || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    Rccl* R = rccl();
+    if (!R->handle) return fail(c, RSDSFM_ERR_NO_DEVICE, R->error.c_str());
+    Dist* D = dist_of(c, true);
+    if (!D) return fail(c, RSDSFM_ERR_INVALID, "out of host memory");
+    if (D->comm && D->own_comm) (void)R->CommDestroy(D->comm);
+    D->comm = static_cast<ncclComm_t>(nccl_comm);
+    D->own_comm = false;
+    D->nranks = nranks;
+    D->rank = rank;
+    D->ag = nullptr;
+    D->ar = nullptr;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_dist_set_transport(rsdsfm_ctx* ctx, int32_t nranks, int32_t rank, rsdsfm_all_gather_fn all_gather_fn,
+                              rsdsfm_all_reduce_sum_f64_fn all_reduce_fn, void* user) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
+    if (nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && (!all_gather_fn || !all_reduce_fn))) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    Dist* D = dist_of(c, true);
+    if (!D) return fail(c, RSDSFM_ERR_INVALID, "out of host memory");
+    if (D->comm && D->own_comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(D->comm);
+    D->comm = nullptr;
+    D->own_comm = false;
+    D->nranks = nranks;
+    D->rank = rank;
+    D->ag = all_gather_fn;
+    D->ar = all_reduce_fn;
+    D->user = user;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_dist_finalize(rsdsfm_ctx* ctx) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    dist_release(c);
+    return RSDSFM_OK;
+}
+
+int rsdsfm_tiled_slab_bounds(int32_t cols, int32_t nranks, int32_t rank, int32_t* col0, int32_t* slab_cols, int32_t* stride_cols) {
+    if (cols < 0 || nranks < 1 || rank < 0 || rank >= nranks) return RSDSFM_ERR_INVALID;
+    const int per = (cols + nranks - 1) / nranks;
+    const int c0 = std::min(cols, rank * per), c1 = std::min(cols, (rank + 1) * per);
+    if (col0) *col0 = c0;
+    if (slab_cols) *slab_cols = c1 - c0;
+    if (stride_cols) *stride_cols = per;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int32_t rows, int32_t cols, double fx, double fy, double cx,
+                                 double cy, double gamma, const rsdsfm_frame_params* prm, double* d_depth_map, double* d_R_rows9,
+                                 double* d_t_rows3, rsdsfm_frame_result* res, rsdsfm_tiled_info* info) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
+    if (!prm || !res || rows <= 0 || cols <= 0 || !d_depth_map) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    if (prm->flow_index_mode != RSDSFM_FLOW_GATHERED)
+        return fail(c, RSDSFM_ERR_INVALID, "the tiled solve needs flow_index_mode = RSDSFM_FLOW_GATHERED (a rank-indexed flow, quirk Q2, would live on another rank's slab)");
+    const int depth_mode = prm->depth_mode;
+    if (depth_mode != RSDSFM_DEPTH_CLOSED_FORM && depth_mode != RSDSFM_DEPTH_CERES_LM) return fail(c, RSDSFM_ERR_INVALID, "unknown depth_mode");
+    const int T = prm->ransac_trials;
+    if (T < 0) return fail(c, RSDSFM_ERR_INVALID, "negative trial count");
+    Dist* D = dist_of(c, true);
+    if (!D) return fail(c, RSDSFM_ERR_INVALID, "out of host memory");
+    D->host_syncs = D->collectives = D->ransac_rounds = 0;
+    const int R = D->nranks, rank = D->rank;
+    int32_t col0 = 0, sc = 0, per = 0;
+    rsdsfm_tiled_slab_bounds(cols, R, rank, &col0, &sc, &per);
+    const size_t Ns = (size_t)rows * (size_t)sc;      // pixels of this slab
+    const size_t cap = (size_t)rows * (size_t)per;     // pixels of a full-width slab (all-gather stride)
+    if (Ns > 0 && !d_img_slab) return fail(c, RSDSFM_ERR_INVALID, "null slab pointer");
+    const size_t N1 = std::max<size_t>(Ns, 1);
+    const int Tn = std::max(T, 1);
+    const int batch = std::min(Tn, kRansacBatch);
+    const int np = prm->use_acceleration_mode ? 7 : 6;
+    const int nsr = ransac_rows_doubles();
+    const bool padded = (size_t)R * cap != (size_t)rows * (size_t)cols;
+
+    // ---- frame buffers of the slab (context arena shared with rsdsfm_solve_frame_dev) ----
+    const size_t need_frame = 2 * Arena::need(16 * N1) + 5 * Arena::need(8 * N1) + 2 * Arena::need(24 * N1) + Arena::need(8 * N1) + Arena::need(N1) +
+                              Arena::need(4 * N1) + 4096;
+    int rc = ensure_dev(c, &c->d_frame, &c->frame_bytes, need_frame);
+    if (rc != RSDSFM_OK) return rc;
+    Arena fa(c->d_frame);
+    double* d_q = fa.take<double>(2 * N1);
+    double* d_u = fa.take<double>(2 * N1);
+    double* d_a = fa.take<double>(N1);
+    double* d_ak = fa.take<double>(N1);
+    double* d_in_a = fa.take<double>(N1);
+    double* d_in_ak = fa.take<double>(N1);
+    double* d_rho = fa.take<double>(N1);
+    double* d_inl = fa.take<double>(3 * N1);
+    double* d_inl_ref = fa.take<double>(3 * N1);
+    int64_t* d_idx = fa.take<int64_t>(N1);
+    uint8_t* d_mask = fa.take<uint8_t>(N1);
+    int32_t* d_ys = fa.take<int32_t>(N1);
+
+    // ---- small exchange buffers ----
+    const int row_max = std::max({nsr * batch, refine_stage_row_doubles(np, 0), refine_stage_row_doubles(np, 1), refine_stage_row_doubles(np, 2), 2 * batch});
+    size_t need_d = 2 * Arena::need(8 * (size_t)R + 64) + Arena::need(4 * 9 * (size_t)Tn) + Arena::need(8 * 54 * (size_t)Tn) + Arena::need(8 * 8 * (size_t)Tn) +
+                    Arena::need(sizeof(LmState) * Tn) + Arena::need(4 * (size_t)Tn) + Arena::need(64) + 2 * Arena::need(8 * (size_t)Tn) +
+                    2 * Arena::need(sizeof(RansacBest)) + Arena::need(8 * (size_t)row_max) + Arena::need(8 * (size_t)row_max * R) + Arena::need(64) +
+                    Arena::need(8 * (size_t)R + 64) + Arena::need(64) + (padded ? Arena::need(8 * cap * R) : 0) + 4096;
+    rc = ensure_dev(c, &D->d_buf, &D->bytes, need_d);
+    if (rc != RSDSFM_OK) return rc;
+    Arena da(D->d_buf);
+    int64_t* d_cnt_all = da.take<int64_t>((size_t)R + 8);
+    int64_t* d_m_all = da.take<int64_t>((size_t)R + 8);
+    int32_t* d_samples = da.take<int32_t>(9 * (size_t)Tn);
+    double* d_pts = da.take<double>(54 * (size_t)Tn);
+    double* d_hyp = da.take<double>(8 * (size_t)Tn);
+    char* zero_begin = da.base + da.off;  // states, scored, flags: one memset
+    LmState* d_states = da.take<LmState>(Tn);
+    int* d_scored = da.take<int>(Tn);
+    int* d_flags = da.take<int>(16);
+    const size_t zero_bytes = (size_t)((da.base + da.off) - zero_begin);
+    double* d_tcount = da.take<double>(Tn);
+    double* d_terr = da.take<double>(Tn);
+    RansacBest* d_best = da.take<RansacBest>(1);
+    RansacBest* d_best_shard = da.take<RansacBest>(1);
+    double* d_row = da.take<double>(row_max);
+    double* d_rows_all = da.take<double>((size_t)row_max * R);
+    double* d_zs = da.take<double>(8);
+    double* d_zs_all = da.take<double>((size_t)R + 8);
+    double* d_header = da.take<double>(8);
+    double* d_gather = padded ? da.take<double>(cap * R) : d_depth_map;
+
+    // ---- per-stage workspace (stream-ordered reuse) ----
+    const size_t ncells = sc > 0 ? (size_t)flatten_cells(rows, sc) : 1;
+    const size_t ws_need = std::max({2 * Arena::need(sizeof(int64_t) * ncells),
+                                     Arena::need(sizeof(double) * (size_t)ransac_lm_partials_doubles(c, (int64_t)N1, batch)) + 2 * Arena::need(sizeof(int64_t) * 2048),
+                                     Arena::need(8 * cap) + Arena::need(8 * 1024)}) + 4096;
+    rc = ensure_ws(c, ws_need);
+    if (rc != RSDSFM_OK) return rc;
+    rc = ensure_pinned(c, sizeof(RansacBest) + 64 + 8 * (size_t)R * 2 + 64 + sizeof(RefineState) + 64 + sizeof(int32_t) * 9 * (size_t)Tn + 64);
+    if (rc != RSDSFM_OK) return rc;
+    char* hp = static_cast<char*>(c->h_pinned);
+    RansacBest* h_best = reinterpret_cast<RansacBest*>(hp);
+    int* h_flags = reinterpret_cast<int*>(hp + sizeof(RansacBest));
+    int64_t* h_cnt = reinterpret_cast<int64_t*>(hp + sizeof(RansacBest) + 64);
+    int64_t* h_m = h_cnt + R;
+    double* h_header = reinterpret_cast<double*>(h_m + R);
+    RefineState* h_state = reinterpret_cast<RefineState*>(h_header + 8);
+    int* h_bad = reinterpret_cast<int*>(reinterpret_cast<char*>(h_state) + sizeof(RefineState));
+    int32_t* h_samples = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(h_state) + sizeof(RefineState) + 64);
+
+    memset(res, 0, sizeof(*res));
+    // ---- flatten of the slab; point counts of all slabs ----
+    if (Ns > 0) {
+        Arena ws(c->d_ws);
+        int64_t* d_counts = ws.take<int64_t>(ncells);
+        int64_t* d_offsets = ws.take<int64_t>(ncells);
+        rc = flatten_launch(c, d_img_slab, rows, sc, col0, fx, fy, cx, cy, gamma, prm->flow_threshold, d_q, d_u, d_a, d_ak, d_counts, d_offsets,
+                            d_cnt_all + rank, nullptr);
+        if (rc != RSDSFM_OK) return rc;
+    } else {
+        RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_cnt_all + rank, 0, sizeof(int64_t), c->stream));
+    }
+    rc = all_gather(c, D, d_cnt_all + rank, d_cnt_all, sizeof(int64_t));
+    if (rc != RSDSFM_OK) return rc;
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_cnt, d_cnt_all, sizeof(int64_t) * R, hipMemcpyDeviceToHost, c->stream));
+    RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
+    rc = sync(c, D);
+    if (rc != RSDSFM_OK) return rc;
+    int64_t n_total = 0, offset = 0;
+    for (int r = 0; r < R; ++r) {
+        if (r == rank) offset = n_total;
+        n_total += h_cnt[r];
+    }
+    const int64_t n = h_cnt[rank];
+    res->n_points = n_total;
+    if (n_total < 9) return fail(c, RSDSFM_ERR_INVALID, "ransac needs at least 9 points (the reference would compute rand() % 0)");
+    if (n_total > (int64_t)INT32_MAX) return fail(c, RSDSFM_ERR_INVALID, "n exceeds the int32 sample index range");
+    if (prm->use_global_shutter_mode) {  // main.cc:441-444
+        rc = alpha_ones_launch(c, d_a, n);
+        if (rc != RSDSFM_OK) return rc;
+    }
+
+    // ---- hypotheses: deterministic sampler on every rank, sampled points by one exact all-reduce, minimal solver replicated ----
+    if (T > 0) {
+        sample_indices(n_total, T, prm->seed, h_samples);
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_samples, h_samples, sizeof(int32_t) * 9 * (size_t)T, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(pack_samples_kernel, dim3((9 * T + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const double2*>(d_q),
+                           reinterpret_cast<const double2*>(d_u), d_a, d_ak, n, offset, d_samples, 9 * T, d_pts);
+        RSDSFM_HIP_CHECK(c, hipGetLastError());
+        rc = all_reduce_sum(c, D, d_pts, 54 * (size_t)T);
+        if (rc != RSDSFM_OK) return rc;
+        rc = minimal9_launch(c, d_pts, d_pts + 18 * (size_t)T, d_pts + 36 * (size_t)T, d_pts + 45 * (size_t)T, nullptr, T, prm->use_acceleration_mode,
+                             prm->k_sign_mode, d_hyp);
+        if (rc != RSDSFM_OK) return rc;
+    }
+
+    // ---- RANSAC: LM rounds of the hypothesis batches, scores, winner, compaction ----
+    Arena ws(c->d_ws);
+    double* d_partials = ws.take<double>((size_t)ransac_lm_partials_doubles(c, (int64_t)N1, batch));
+    int64_t* d_bcounts = ws.take<int64_t>(2048);
+    int64_t* d_boffs = ws.take<int64_t>(2048);
+    auto final_stage = [&]() -> int {  // winner (replicated), its dense 1/depth + mask + compaction on the slab, inlier counts of all slabs
+        int rc2 = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, nullptr);
+        if (rc2 != RSDSFM_OK) return rc2;
+        // the compaction stores the SLAB's scan total into its record: every rank works on a copy of the (identical) winner record
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_best_shard, d_best, sizeof(RansacBest), hipMemcpyDeviceToDevice, c->stream));
+        rc2 = ransac_final_launch(c, d_q, d_u, d_a, d_ak, n, d_best_shard, d_states, depth_mode, prm->ransac_tol, d_rho, d_mask, d_bcounts, d_boffs,
+                                  d_idx, d_inl, d_in_a, d_in_ak, nullptr);
+        if (rc2 != RSDSFM_OK) return rc2;
+        static_assert(sizeof(d_best_shard->num_inliers_scan) == sizeof(int64_t), "count type");
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_m_all + rank, &d_best_shard->num_inliers_scan, sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
+        rc2 = all_gather(c, D, d_m_all + rank, d_m_all, sizeof(int64_t));
+        if (rc2 != RSDSFM_OK) return rc2;
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, c->stream));
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_m, d_m_all, sizeof(int64_t) * R, hipMemcpyDeviceToHost, c->stream));
+        return RSDSFM_OK;
+    };
+    bool final_done = false;
+    for (int b0 = 0; b0 < T; b0 += batch) {
+        const int B = std::min(batch, T - b0);
+        bool need_score = true;
+        if (depth_mode == RSDSFM_DEPTH_CERES_LM) {
+            if (b0 > 0) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_flags, 0, sizeof(int) * 4, c->stream));
+            for (int round = 0;; ++round) {
+                if (round > 4 * kMaxIter) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machines did not terminate");
+                rc = ransac_lm_rows_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, d_partials, round, prm->ransac_tol, d_row);
+                if (rc != RSDSFM_OK) return rc;
+                rc = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)B * nsr);
+                if (rc != RSDSFM_OK) return rc;
+                rc = ransac_decide_rows_launch(c, d_rows_all, R, B, d_states + b0, n_total, round, d_flags, d_scored + b0, d_tcount + b0, d_terr + b0);
+                if (rc != RSDSFM_OK) return rc;
+                D->ransac_rounds += 1;
+                if (round == 0 && B == T) {  // the common case is decided and scored by round 0: enqueue the final stage before reading the flags
+                    rc = final_stage();
+                    if (rc != RSDSFM_OK) return rc;
+                    final_done = true;
+                }
+                RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
+                rc = sync(c, D);
+                if (rc != RSDSFM_OK) return rc;
+                if (h_flags[0] == 0) break;
+                final_done = false;
+            }
+            need_score = h_flags[1] > 0;
+            if (need_score) final_done = false;
+        }
+        if (need_score) {
+            const int* sc_ptr = depth_mode == RSDSFM_DEPTH_CERES_LM ? d_scored + b0 : nullptr;
+            rc = ransac_score_rows_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, depth_mode, prm->ransac_tol, sc_ptr, d_partials, d_row);
+            if (rc != RSDSFM_OK) return rc;
+            rc = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)B * 2);
+            if (rc != RSDSFM_OK) return rc;
+            rc = ransac_score_merge_launch(c, d_rows_all, R, B, sc_ptr, d_tcount + b0, d_terr + b0);
+            if (rc != RSDSFM_OK) return rc;
+        }
+    }
+    if (!final_done) {
+        rc = final_stage();
+        if (rc != RSDSFM_OK) return rc;
+        rc = sync(c, D);
+        if (rc != RSDSFM_OK) return rc;
+    }
+    int64_t m_total = 0;
+    for (int r = 0; r < R; ++r) m_total += h_m[r];
+    const int64_t m = h_m[rank];
+    if (m_total != h_best->num_inliers) return fail(c, RSDSFM_ERR_NUMERIC, "inlier count mismatch between scoring and compaction");
+    res->num_inliers = m_total;
+    res->best_trial = h_best->best_trial;
+    memcpy(res->ransac_w, &h_best->hyp[0], 3 * sizeof(double));
+    memcpy(res->ransac_v, &h_best->hyp[3], 3 * sizeof(double));
+    res->ransac_k = h_best->hyp[6];
+    double v[3] = {h_best->hyp[3], h_best->hyp[4], h_best->hyp[5]}, w[3] = {h_best->hyp[0], h_best->hyp[1], h_best->hyp[2]}, k = h_best->hyp[6];
+    double* d_final = d_inl;
+
+    // ---- joint refinement: per LM iteration two staged passes (Schur sums -> reduced solve; back-substitution sums -> decision) ----
+    if (prm->use_refinement) {
+        const size_t M = (size_t)std::max<int64_t>(m, 1);
+        const size_t npart = (size_t)refine_partials_doubles(c, m);
+        rc = ensure_dev(c, &D->d_session, &D->session_bytes,
+                        Arena::need(sizeof(RefineState) + 64) + Arena::need(16 * M) + 3 * Arena::need(8 * M) + Arena::need(8 * npart) + 1024);
+        if (rc != RSDSFM_OK) return rc;
+        Arena sa(D->d_session);
+        RefineBuffers B;
+        B.flow = d_u;
+        B.n_flow = n;
+        B.m = m;
+        B.inl = d_inl;
+        B.alpha = d_in_a;
+        B.alpha_k = d_in_ak;
+        B.inlier_idx = d_idx;
+        B.flow_index_mode = RSDSFM_FLOW_GATHERED;
+        char* state_block = sa.take<char>(sizeof(RefineState) + 64);
+        B.state = reinterpret_cast<RefineState*>(state_block);
+        B.bad_index = reinterpret_cast<int*>(state_block + sizeof(RefineState));
+        B.uu = sa.take<double>(2 * M);
+        B.rho_a = sa.take<double>(M);
+        B.rho_b = sa.take<double>(M);
+        B.srho = sa.take<double>(M);
+        B.partials = sa.take<double>(npart);
+        memset(h_state, 0, sizeof(RefineState));
+        h_state->np = np;
+        for (int i = 0; i < 3; ++i) h_state->p[i] = v[i], h_state->p[3 + i] = w[i];
+        h_state->p[6] = k;
+        h_state->termination = -1;
+        h_state->radius = kInitialRadius;
+        *h_bad = 0;
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(B.state, h_state, sizeof(RefineState) + sizeof(int), hipMemcpyHostToDevice, c->stream));
+        auto staged = [&](int stage) -> int {
+            int rc2 = refine_stage_rows_launch(c, B, np, stage, d_row);
+            if (rc2 != RSDSFM_OK) return rc2;
+            rc2 = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)refine_stage_row_doubles(np, stage));
+            if (rc2 != RSDSFM_OK) return rc2;
+            return refine_stage_apply_launch(c, B, np, stage, d_rows_all, R, m_total);
+        };
+        rc = staged(0);
+        if (rc != RSDSFM_OK) return rc;
+        const int chunk = 5;  // LM iterations per host poll; the kernels of a finished solve return immediately
+        for (int launched = 0;;) {
+            for (int i = 0; i < chunk; ++i) {
+                rc = staged(1);
+                if (rc != RSDSFM_OK) return rc;
+                rc = staged(2);
+                if (rc != RSDSFM_OK) return rc;
+            }
+            launched += chunk;
+            rc = refine_finish_launch(c, B, d_inl_ref);  // enqueued before the poll: the common case ends within one chunk
+            if (rc != RSDSFM_OK) return rc;
+            RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_state, B.state, sizeof(RefineState) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            rc = sync(c, D);
+            if (rc != RSDSFM_OK) return rc;
+            if (*h_bad) return fail(c, RSDSFM_ERR_INVALID, "flow index out of range (bad inlier_idx)");
+            if (h_state->termination >= 0) break;
+            if (launched > 4 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
+        }
+        for (int i = 0; i < 3; ++i) v[i] = h_state->p[i], w[i] = h_state->p[3 + i];
+        k = h_state->p[6];
+        res->refine_summary.num_iterations = h_state->iteration;
+        res->refine_summary.num_successful_steps = h_state->num_successful;
+        res->refine_summary.num_unsuccessful_steps = h_state->num_unsuccessful;
+        res->refine_summary.termination = h_state->termination;
+        res->refine_summary.initial_cost = h_state->initial_cost;
+        res->refine_summary.final_cost = h_state->cost;
+        res->refine_summary.final_radius = h_state->radius;
+        d_final = d_inl_ref;
+    }
+
+    // ---- mean-z sign (global), depth-map slab, ONE all-gather of the slabs, pose table ----
+    {
+        Arena ws2(c->d_ws);
+        long long* d_owner = ws2.take<long long>(std::max<size_t>(cap, 1));
+        double* d_zpart = ws2.take<double>(1024);
+        rc = zsum_row_launch(c, d_final, m, d_zpart, d_zs);
+        if (rc != RSDSFM_OK) return rc;
+        rc = all_gather(c, D, d_zs, d_zs_all, sizeof(double));
+        if (rc != RSDSFM_OK) return rc;
+        double* d_slab = d_gather + (size_t)rank * cap;
+        if (cap > Ns) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_slab + Ns, 0, sizeof(double) * (cap - Ns), c->stream));  // columns past the image: zeros
+        rc = depth_map_slab_launch(c, d_final, m, d_zs_all, R, m_total, v, fx, fy, cx, cy, rows, col0, sc, d_slab, nullptr, d_ys, d_header, d_owner, h_header);
+        if (rc != RSDSFM_OK) return rc;
+        rc = all_gather(c, D, d_slab, d_gather, sizeof(double) * cap);  // the one data-path collective
+        if (rc != RSDSFM_OK) return rc;
+        if (padded)
+            RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_depth_map, d_gather, sizeof(double) * (size_t)rows * (size_t)cols, hipMemcpyDeviceToDevice, c->stream));
+        if (d_R_rows9 && d_t_rows3) {
+            Pose pose;
+            for (int i = 0; i < 3; ++i) pose.v[i] = v[i], pose.w[i] = w[i];
+            pose.k = k;
+            rc = pose_table_launch(c, pose, gamma, rows, d_R_rows9, d_t_rows3, d_header + 1);  // v' (possibly flipped) from the device header
+            if (rc != RSDSFM_OK) return rc;
+        }
+        rc = sync(c, D);
+        if (rc != RSDSFM_OK) return rc;
+    }
+    res->flipped = h_header[0] != 0.0;
+    res->v[0] = h_header[1], res->v[1] = h_header[2], res->v[2] = h_header[3];
+    memcpy(res->w, w, sizeof(w));
+    res->k = k;
+    res->d_inliers = d_final;
+    res->d_inlier_idx = d_idx;
+    res->d_scanline = d_ys;
+    if (info) {
+        info->nranks = R;
+        info->rank = rank;
+        info->col0 = col0;
+        info->slab_cols = sc;
+        info->shard_points = n;
+        info->shard_inliers = m;
+        info->host_syncs = D->host_syncs;
+        info->collectives = D->collectives;
+        info->ransac_rounds = D->ransac_rounds;
+    }
+    return RSDSFM_OK;
+}
+
+}  // extern "C"

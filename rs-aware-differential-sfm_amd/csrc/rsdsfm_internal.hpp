@@ -115,7 +115,9 @@ struct Ctx {
     size_t tile_bytes = 0;
     void* tile_session = nullptr;  // heap RefineBuffers of the open session
     int tile_np = 0;
+    void* dist = nullptr;  // dist_host.hip: communicator / transport + exchange buffers of the native tiled solve
 };
+void dist_release(Ctx* c);
 
 constexpr int kDepthBlock = 256;
 constexpr int kDepthMaxBlocks = 512;

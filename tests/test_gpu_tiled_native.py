@@ -1,0 +1,212 @@
+"""GPU: the column-tiled whole solve driven from C++ inside the library (rsdsfm_solve_frame_tiled_dev, csrc/dist_host.hip).
+
+The GPU box has ONE device and RCCL refuses two ranks on one GPU, so
+  * the RCCL code path (dlopen, ncclCommInitRank from a unique id, ncclAllGather / ncclAllReduce on the context's stream) is
+    exercised with a 1-rank communicator, and
+  * the multi-rank logic (slab bounds, offsets, rank-ordered rows, padded depth-map gather) with several LOGICAL ranks on the one
+    GPU through rsdsfm_dist_set_transport: N host threads (tests/transports.ThreadTransport) and 2 processes over gloo.
+Every variant must reproduce the single-context solve: integers exact, floats to the summation order of the per-slab sums."""
+import json
+import os
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from test_gpu_tiled_frame import _compare, _single  # noqa: E402
+
+
+def _native_threads(rsdsfm, torch, d, nranks, **kw):
+    """nranks logical ranks = host threads, one context each, collectives through ThreadTransport"""
+    from transports import ThreadTransport
+
+    dev = torch.device("cuda", 0)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    img = torch.from_numpy(d["flow_img"]).to(dev)
+    tr = ThreadTransport(nranks)
+    outs, errs = [None] * nranks, [None] * nranks
+
+    def work(rank):
+        try:
+            torch.cuda.set_device(0)
+            c0, sc, per = rsdsfm.tiled_slab_bounds(cols, nranks, rank)
+            slab = img[:, c0:c0 + sc, :].contiguous()
+            dm = torch.zeros(cols * rows, dtype=torch.float64, device=dev)
+            R = torch.empty(rows * 9, dtype=torch.float64, device=dev)
+            t = torch.empty(rows * 3, dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            with rsdsfm.Solver(0) as s:
+                s.dist_set_transport(nranks, rank, *tr.callbacks(rank))
+                r = s.solve_frame_tiled_dev(slab.data_ptr() if sc else 0, rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), **kw)
+                s.synchronize()
+                m = r["info"]["shard_inliers"]
+                inl = torch.empty(3 * max(m, 1), dtype=torch.float64, device=dev)
+                ys = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+                if m:
+                    assert tr.hip.hipMemcpy(inl.data_ptr(), r["d_inliers"], 24 * m, 3) == 0
+                    assert tr.hip.hipMemcpy(ys.data_ptr(), r["d_scanline"], 4 * m, 3) == 0
+                r["inliers"], r["ys"] = inl.cpu().numpy().reshape(-1, 3)[:m], ys.cpu().numpy()[:m]
+            r["depth_map"] = dm.cpu().numpy()
+            r["R"], r["t"] = R.cpu().numpy().reshape(rows, 9), t.cpu().numpy().reshape(rows, 3)
+            outs[rank] = r
+        except Exception as e:  # noqa: BLE001
+            errs[rank] = e
+            tr.barrier.abort()
+
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    for e in errs:
+        if e is not None:
+            raise e
+    r0 = outs[0]
+    for r in outs[1:]:  # every rank returns the same pose, counts and the same full depth map
+        assert r["n"] == r0["n"] and r["num_inliers"] == r0["num_inliers"] and r["best_trial"] == r0["best_trial"]
+        assert np.array_equal(r["v"], r0["v"]) and np.array_equal(r["w"], r0["w"]) and r["k"] == r0["k"]
+        assert r["refine_summary"] == r0["refine_summary"] and np.array_equal(r["depth_map"], r0["depth_map"])
+    res = dict(r0)
+    res["inliers"] = np.concatenate([r["inliers"] for r in outs])
+    res["ys"] = np.concatenate([r["ys"] for r in outs])
+    res["shard_n"] = [r["info"]["shard_points"] for r in outs]
+    res["infos"] = [r["info"] for r in outs]
+    return res
+
+
+@pytest.mark.parametrize("cfg,accel", [(3, False), (5, True)])
+def test_native_tiled_solve_matches_single_context(rsdsfm, cfg, accel):
+    import torch
+
+    stream = torch.cuda.Stream(torch.device("cuda", 0))
+    d = rsdsfm.synth.make_config(cfg, rows=96, cols=250)
+    rows, cols = d["rows"], d["cols"]
+    kw = dict(trials=14, tol=0.002 if cfg == 3 else 0.01, seed=7, use_acceleration_mode=accel)
+    with torch.cuda.stream(stream):
+        one = _single(rsdsfm, torch, d, stream, **kw)
+    assert one["num_inliers"] > 0.1 * rows * cols
+    for nranks in (1, 2, 3, 5):  # 250 columns over 3 ranks: stride 84, the last slab is narrower (padded gather)
+        til = _native_threads(rsdsfm, torch, d, nranks, **kw)
+        assert sum(til["shard_n"]) == one["n"]
+        _compare(til, one, rows, cols, depth_rtol=1e-6 if accel else 1e-9)
+        assert len(til["inliers"]) == one["num_inliers"] and len(til["ys"]) == one["num_inliers"]
+        # the driver's host synchronisations do not grow with RANSAC rounds or LM iterations: counts, RANSAC, refinement polls, tail
+        assert max(i["host_syncs"] for i in til["infos"]) <= 3 + -(-one["refine_summary"]["num_iterations"] // 5) + 1
+
+
+def test_native_tiled_modes(rsdsfm):
+    """closed-form depth mode, no refinement, more trials than one hypothesis batch (> 128), empty trailing slabs, global
+    shutter mode, too few points"""
+    import torch
+
+    stream = torch.cuda.Stream(torch.device("cuda", 0))
+    d = rsdsfm.synth.make_config(3, rows=64, cols=90)
+    rows, cols = d["rows"], d["cols"]
+    with torch.cuda.stream(stream):
+        for kw in (dict(trials=20, tol=0.002, seed=3, use_refinement=False, depth_mode=0), dict(trials=150, tol=0.002, seed=3, use_refinement=False),
+                   dict(trials=10, tol=0.004, seed=5, use_global_shutter_mode=True)):
+            one = _single(rsdsfm, torch, d, stream, **kw)
+            til = _native_threads(rsdsfm, torch, d, 3, **kw)
+            assert til["n"] == one["n"] and til["num_inliers"] == one["num_inliers"] and til["best_trial"] == one["best_trial"]
+            if not kw.get("use_refinement", True):
+                assert np.array_equal(til["v"], one["v"]) and np.array_equal(til["depth_map"], one["depth_map"])  # no global float sums involved
+            else:
+                _compare(til, one, rows, cols)
+        d1 = rsdsfm.synth.make_config(1, rows=40, cols=7)
+        kw = dict(trials=6, tol=0.01, seed=1)
+        one = _single(rsdsfm, torch, d1, stream, **kw)
+        til = _native_threads(rsdsfm, torch, d1, 4, **kw)  # stride 2 -> slabs (0,2) (2,4) (4,6) (6,7)
+        _compare(til, one, d1["rows"], d1["cols"])
+        til = _native_threads(rsdsfm, torch, d1, 5, **kw)  # stride 2 -> the fifth slab is empty
+        _compare(til, one, d1["rows"], d1["cols"])
+        d2 = dict(d1)
+        img = np.zeros_like(d1["flow_img"])
+        img[:2, :3] = d1["flow_img"][:2, :3]  # 6 points < 9: refused like the single-context solve
+        d2["flow_img"] = img
+        with pytest.raises(rsdsfm.RsdsfmError):
+            _native_threads(rsdsfm, torch, d2, 2, **kw)
+
+
+def test_native_tiled_over_rccl_one_rank(rsdsfm):
+    """the RCCL path on the one GPU of the box: unique id -> ncclCommInitRank (1 rank) -> ncclAllGather / ncclAllReduce on the
+    context's stream; result = the single-context solve bit for bit (one slab: the same sums in the same order)"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    d = rsdsfm.synth.make_config(3, rows=120, cols=200)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    kw = dict(trials=12, tol=0.002, seed=9)
+    with torch.cuda.stream(stream):
+        one = _single(rsdsfm, torch, d, stream, **kw)
+        img = torch.from_numpy(d["flow_img"]).to(dev)
+        dm = torch.zeros(cols * rows, dtype=torch.float64, device=dev)
+        R = torch.empty(rows * 9, dtype=torch.float64, device=dev)
+        t = torch.empty(rows * 3, dtype=torch.float64, device=dev)
+        with rsdsfm.Solver(0, stream=stream.cuda_stream) as s:
+            s.dist_init(1, 0, rsdsfm.dist_unique_id())
+            for _ in range(2):  # the communicator is reused across solves
+                r = s.solve_frame_tiled_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), **kw)
+            s.synchronize()
+            assert r["info"]["collectives"] >= 8 and r["info"]["nranks"] == 1
+            s.dist_finalize()
+    assert r["n"] == one["n"] and r["num_inliers"] == one["num_inliers"] and r["best_trial"] == one["best_trial"]
+    assert np.array_equal(r["v"], one["v"]) and np.array_equal(r["w"], one["w"]) and r["k"] == one["k"]
+    assert r["refine_summary"] == one["refine_summary"]
+    assert np.array_equal(dm.cpu().numpy(), one["depth_map"])
+    assert np.array_equal(R.cpu().numpy().reshape(rows, 9), one["R"]) and np.array_equal(t.cpu().numpy().reshape(rows, 3), one["t"])
+
+
+def test_native_tiled_3840x2160_in_8_ranks(rsdsfm, oracle_chain, big_config):
+    """BASELINE configs[3] at full size through the native driver: 8 logical ranks (threads) on the one GPU, against the un-tiled
+    solve and the oracle chain (5 trials): integers exact, floats 1e-9 / 1e-6"""
+    import torch
+
+    stream = torch.cuda.Stream(torch.device("cuda", 0))
+    T, tol, seed = 5, 0.002, 5
+    d = big_config(4)
+    rows, cols = d["rows"], d["cols"]
+    kw = dict(trials=T, tol=tol, seed=seed)
+    with torch.cuda.stream(stream):
+        one = _single(rsdsfm, torch, d, stream, **kw)
+    til = _native_threads(rsdsfm, torch, d, 8, **kw)
+    assert len(til["shard_n"]) == 8 and sum(til["shard_n"]) == one["n"] == rows * cols
+    _compare(til, one, rows, cols)
+    o = oracle_chain(4, T, tol, seed)
+    ro, refo = o["ransac"], o["refine"]
+    assert til["num_inliers"] == ro["num_inliers"] and til["best_trial"] == ro["best_trial"]
+    for key in ("num_iterations", "num_successful_steps", "termination"):
+        assert til["refine_summary"][key] == refo["summary"][key], key
+    assert til["flipped"] == o["flipped"] and np.allclose(til["v"], o["v"], rtol=1e-6, atol=1e-10) and np.allclose(til["w"], refo["w"], rtol=1e-6, atol=1e-10)
+    assert np.array_equal(til["ys"], o["ys"])  # scanline index of every inlier: bit-exact
+    got = til["depth_map"].reshape(cols, rows).T
+    assert np.array_equal(got != 0, o["depth_map"] != 0) and np.allclose(got, o["depth_map"], rtol=1e-6)
+
+
+def test_native_tiled_two_processes_share_the_gpu(rsdsfm, tmp_path):
+    """two ranks = two processes (gloo rendezvous on 127.0.0.1, both on cuda:0, collectives through GlooTransport) run
+    tests/mp_tiled_native.py; rank 0's result equals the single-context solve and both ranks agree bit for bit"""
+    import torch
+
+    out = tmp_path / "res.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RSDSFM_TILED_OUT=str(out))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29641",
+           os.path.join(ROOT, "tests", "mp_tiled_native.py")]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    got = json.loads(out.read_text())
+    stream = torch.cuda.Stream(torch.device("cuda", 0))
+    with torch.cuda.stream(stream):
+        d = rsdsfm.synth.make_config(3, rows=96, cols=250)
+        one = _single(rsdsfm, torch, d, stream, trials=14, tol=0.002, seed=7)
+    assert got["world"] == 2 and got["ranks_agree"] and got["info"]["nranks"] == 2
+    assert got["n"] == one["n"] and got["num_inliers"] == one["num_inliers"] and got["best_trial"] == one["best_trial"]
+    assert np.allclose(got["v"], one["v"], rtol=1e-9) and np.allclose(got["w"], one["w"], rtol=1e-9)
+    assert got["depth_nonzero"] == int((one["depth_map"] != 0).sum()) and np.isclose(got["depth_sum"], one["depth_map"].sum(), rtol=1e-9)

@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--workload", default="full", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify", "true_flow", "metrics"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-records", action="store_true", help="full workload: skip depth_only / full_solve_batched / full_solve_fused (profiling runs)")
+    ap.add_argument("--tiled-driver", default="native", choices=["native", "python"], help="tiled_full: the C++ driver inside the library (default) or the Python driver")
     ap.add_argument("--arith", default="reference", choices=["reference", "fused"], help="library: reference arithmetic (default) or the opt-in fused-fma build")
     ap.add_argument("--nbuf", type=int, default=7, help="rotating HBM buffer sets (7 x 59 MB > 256 MiB L3)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU feeding independent batches (sequence-throughput mode, BASELINE configs[4])")
@@ -555,19 +556,43 @@ def main():
 
     # =================================================================================================
     elif args.workload == "tiled_full":
-        # one 3840x2160 DeepFlow-like frame split into column slabs over the ranks: the WHOLE solve (flatten, RANSAC,
-        # refinement, sign fix + depth map) through the rsdsfm_tile_* stage entry points; every rank holds only its slab
+        # one 3840x2160 DeepFlow-like frame split into column slabs over the ranks: the WHOLE solve (flatten, RANSAC, refinement,
+        # sign fix + depth map) by ONE C-ABI call per rank (rsdsfm_solve_frame_tiled_dev: the C++ driver issues the stage kernels and
+        # the RCCL collectives on the context's stream); every rank holds only its slab.  --tiled-driver python = the round-1
+        # Python driver over the rsdsfm_tile_* stage entry points (dist.TiledFrameSolve), for comparison.
         data = rsdsfm.synth.make_config(4, seed=0x5EED0004)
         rows, cols = data["rows"], data["cols"]
-        bounds, per = rsdsfm.dist.slab_bounds(cols, world)
-        c0, c1 = bounds[rank]
-        slab = torch.from_numpy(np.ascontiguousarray(data["flow_img"][:, c0:c1, :])).to(dev)
+        c0, sc, per = rsdsfm.tiled_slab_bounds(cols, world, rank)
+        slab = torch.from_numpy(np.ascontiguousarray(data["flow_img"][:, c0:c0 + sc, :])).to(dev)
+        depth_map = torch.empty(rows * cols, dtype=torch.float64, device=dev)
         res = {}
+        native = args.tiled_driver == "native"
+        transport = "python driver + torch.distributed"
+        if native:
+            backend = dist.get_backend() if world > 1 else "nccl"
+            if backend == "nccl":  # RCCL inside the library: rank 0's unique id travels through torch.distributed (1 rank: a 1-rank communicator)
+                ident = torch.zeros(rsdsfm.DIST_ID_BYTES, dtype=torch.uint8, device=dev)
+                if rank == 0:
+                    ident = torch.frombuffer(bytearray(rsdsfm.dist_unique_id()), dtype=torch.uint8).to(dev)
+                if world > 1:
+                    dist.broadcast(ident, 0)
+                solver.dist_init(world, rank, bytes(ident.cpu().numpy().tobytes()))
+                transport = "RCCL (ncclAllGather / ncclAllReduce on the context's stream), %d-rank communicator" % world
+            else:  # smoke tests only (several ranks sharing one GPU over gloo)
+                sys.path.insert(0, os.path.join(ROOT, "tests"))
+                from transports import GlooTransport
 
-        def step(i):
-            shard = rsdsfm.dist.HipFrameShard(solver, slab, c0, data["K"], data["gamma"], torch)  # flatten is part of the solve
-            drv = rsdsfm.dist.TiledFrameSolve([shard], rows, cols, per, torch, dist if world > 1 else None)
-            res["r"] = drv.solve(trials=args.trials, tol=args.tol, seed=1 + i)
+                solver.dist_set_transport(world, rank, *GlooTransport(dist, torch).callbacks())
+                transport = "caller-provided collectives over torch.distributed/%s (smoke test)" % backend
+
+            def step(i):
+                res["r"] = solver.solve_frame_tiled_dev(slab.data_ptr(), rows, cols, data["K"], data["gamma"], depth_map.data_ptr(),
+                                                        trials=args.trials, tol=args.tol, seed=1 + i)
+        else:
+            def step(i):
+                shard = rsdsfm.dist.HipFrameShard(solver, slab, c0, data["K"], data["gamma"], torch)  # flatten is part of the solve
+                drv = rsdsfm.dist.TiledFrameSolve([shard], rows, cols, per, torch, dist if world > 1 else None)
+                res["r"] = drv.solve(trials=args.trials, tol=args.tol, seed=1 + i)
 
         el = timed(step, args.steps, args.warmup)
         if rank == 0:
@@ -575,12 +600,15 @@ def main():
             t = data["truth"]
             line.update({"value": rows * cols * args.steps / el / 1e6, "ms_per_step": el / args.steps * 1e3, "scaling": "strong",
                          "metric": "Mpixels/sec RS whole solve, 3840x2160 frame column-tiled over the ranks",
-                         "config": {"workload": "BASELINE configs[3]-size DeepFlow-like frame, column slabs over %d rank(s): flatten + RANSAC(%d, tol %g) "
+                         "config": {"workload": "BASELINE configs[3]: synthetic 3840x2160 DeepFlow-like frame, column slabs over %d rank(s): flatten + RANSAC(%d, tol %g) "
                                                 "+ refinement + depth map; all-gathers of the stage sum rows + ONE all-gather of the depth slabs"
                                                 % (world, args.trials, args.tol),
-                                    "rows": rows, "cols": cols, "n": r["n"], "num_inliers": r["num_inliers"], "ransac_rounds": r["ransac_rounds"],
+                                    "driver": "native C++ (rsdsfm_solve_frame_tiled_dev)" if native else "python (dist.TiledFrameSolve)", "transport": transport,
+                                    "rows": rows, "cols": cols, "n": r["n"], "num_inliers": r["num_inliers"], "info": r.get("info"),
                                     "refine_summary": r["refine_summary"], "w_err": float(np.linalg.norm(r["w"] - t["w"]))},
                          "roofline": None, "cpu_baseline": None})
+        if native:
+            solver.dist_finalize()
 
     # =================================================================================================
     else:  # tiled
@@ -609,7 +637,13 @@ def main():
                          "roofline": None, "cpu_baseline": None})
 
     if rank == 0:
-        print(json.dumps(line))
+        try:  # RCCL prints its version banner through C stdio, which is block-buffered on a pipe: push it out BEFORE the JSON line
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
     solver.close()
     if world > 1:
         dist.destroy_process_group()

@@ -155,6 +155,8 @@ void rsdsfm_destroy(rsdsfm_ctx* ctx) {
     delete static_cast<RefineBuffers*>(c->tile_session);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     dist_release(c);
+    for (unsigned* p : c->d_claim)
+        if (p) (void)hipFree(p);
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     for (hipEvent_t e : c->ev_prof)
         if (e) (void)hipEventDestroy(e);

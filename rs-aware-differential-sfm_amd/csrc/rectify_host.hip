@@ -21,10 +21,8 @@ int rsdsfm_back_project_dev(rsdsfm_ctx* ctx, const uint8_t* d_image_bgr, const d
     const size_t npix = (size_t)rows * (size_t)cols;
     if (npix == 0) return RSDSFM_OK;
     if (!d_image_bgr || !d_depth_map || !d_R_rows9 || !d_t_rows3 || !d_gs_image_bgr) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
-    int rc = ensure_ws(c, Arena::need(sizeof(int) * npix) + 1024);
-    if (rc != RSDSFM_OK) return rc;
     return back_project_launch(c, d_image_bgr, d_depth_map, d_R_rows9, d_t_rows3, fx, fy, cx, cy, rows, cols, mode, q5_mode,
-                               d_gs_image_bgr, d_coords3d_or_null, static_cast<int*>(c->d_ws));
+                               d_gs_image_bgr, d_coords3d_or_null);
 }
 
 int rsdsfm_back_project(rsdsfm_ctx* ctx, const uint8_t* image_bgr, const double* depth_map, const double* R_rows9,
@@ -101,13 +99,9 @@ int rsdsfm_depth_preview_dev(rsdsfm_ctx* ctx, const double* d_inl, int64_t m, do
     const size_t npix = (size_t)rows * (size_t)cols;
     if (npix == 0) return RSDSFM_OK;
     if ((m > 0 && !d_inl) || !d_depth_est) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
-    int rc = ensure_ws(c, Arena::need(8 * 2048) + Arena::need(64) + Arena::need(sizeof(int) * npix) + 1024);
+    int rc = ensure_ws(c, Arena::need(8 * 2048) + 1024);
     if (rc != RSDSFM_OK) return rc;
-    Arena ws(c->d_ws);
-    double* d_partials = ws.take<double>(2048);
-    double* d_header = ws.take<double>(2);
-    int* d_owner = ws.take<int>(npix);
-    return depth_preview_launch(c, d_inl, m, fx, fy, cx, cy, rows, cols, d_depth_est, d_partials, d_header, d_owner);
+    return depth_preview_launch(c, d_inl, m, fx, fy, cx, cy, rows, cols, d_depth_est, static_cast<double*>(c->d_ws));
 }
 
 int rsdsfm_depth_preview(rsdsfm_ctx* ctx, const double* inl, int64_t m, double fx, double fy, double cx, double cy, int32_t rows,

@@ -6,7 +6,9 @@
 //       rolling-shutter image into the global-shutter image through the depth map and the per-scanline pose table.
 //       The reference's sequential double loop lets the LAST writer (largest row-major scan index) win; here every
 //       source pixel claims its target with an integer atomicMax on the scan index (deterministic), then one pass
-//       gathers the winners.  Byte / index work, HBM-bound: 3 B image + 8 B depth read, 3 B + 12 B (world point as
+//       gathers the winners.  The claim map is a PERSISTENT per-context array whose words carry an 8-bit epoch above the
+//       24-bit scan index: words of earlier frames lose against the current epoch, so no clearing pass runs per frame
+//       (round 1 filled 4 B/pixel with -1 before every splat: 3.7 MB and one launch at 1280x720).  Byte / index work, HBM-bound: 3 B image + 8 B depth read, 3 B + 12 B (world point as
 //       float3) written per pixel = 26 B/pixel algorithmic.
 //       The depth map arrives column-major (Eigen MatrixXd, what depth_write_kernel produces) while the image is
 //       row-major: each workgroup stages a 64 x 16 (x, y) tile of the depth map through LDS (coalesced along y),
@@ -53,7 +55,7 @@ __device__ __forceinline__ unsigned char saturate_u8(double v) {  // cvRound (ne
 
 }  // namespace
 
-// grid: (ceil(cols / kTX), ceil(rows / kTY)); owner: rows*cols int32 (pre-set to -1), row-major.
+// grid: (ceil(cols / kTX), ceil(rows / kTY)); owner: rows*cols claim words `tag | scan index`, row-major (see claim_map_acquire).
 // A wave walks one scanline segment of 64 pixels at a time, so the scanline index is wave-uniform and its pose (12
 // doubles) comes through the scalar data path; every pixel of the image is visited exactly once, so the world point of
 // skipped (marker) pixels is zeroed here instead of by a separate memset.
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(kCB) void back_project_claim_kernel(const unsigned 
                                                                 const double* __restrict__ depth_cm,
                                                                 const double* __restrict__ R, const double* __restrict__ t,
                                                                 double fx, double fy, double cx, double cy, double fyp, int rows,
-                                                                int cols, int mode, int* __restrict__ owner,
+                                                                int cols, int mode, unsigned* __restrict__ owner, unsigned tag,
                                                                 float* __restrict__ c3d) {
     constexpr int RPW = kTY / (kCB / kTX);  // scanlines per wave
     __shared__ double s_z[kTX][kTY + 1];
@@ -140,27 +142,29 @@ __global__ __launch_bounds__(kCB) void back_project_claim_kernel(const unsigned 
             c3d[3 * s + 2] = (float)pw[2];
         }
         const int ix = trunc_int(gx + 0.5), iy = trunc_int(gy + 0.5);
-        if (ix >= 0 && ix < cols && iy >= 0 && iy < rows) atomicMax(&owner[(int64_t)iy * cols + ix], (int)s);
+        if (ix >= 0 && ix < cols && iy >= 0 && iy < rows) atomicMax(&owner[(int64_t)iy * cols + ix], tag | (unsigned)s);
     }
 }
 
 // 4 target pixels (12 bytes) per thread
+// a claim word is valid for this frame iff its bits above `mask` equal `tag`; its low bits are the winner's scan index
 __global__ __launch_bounds__(kBP) void back_project_write_kernel(const unsigned char* __restrict__ img,
-                                                                const int* __restrict__ owner, int64_t npix,
-                                                                unsigned char* __restrict__ gs) {
+                                                                const unsigned* __restrict__ owner, unsigned tag, unsigned mask,
+                                                                int64_t npix, unsigned char* __restrict__ gs) {
     const int64_t stride = (int64_t)gridDim.x * kBP * 4;
     for (int64_t p0 = ((int64_t)blockIdx.x * kBP + threadIdx.x) * 4; p0 < npix; p0 += stride) {
         if (p0 + 4 <= npix) {
-            const int4 o = *reinterpret_cast<const int4*>(owner + p0);  // p0 multiple of 4: 16-byte aligned
-            const int oo[4] = {o.x, o.y, o.z, o.w};
+            const uint4 o = *reinterpret_cast<const uint4*>(owner + p0);  // p0 multiple of 4: 16-byte aligned
+            const unsigned oo[4] = {o.x, o.y, o.z, o.w};
             unsigned v[12];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const int64_t src = 3 * (int64_t)(oo[j] >= 0 ? oo[j] : 0);
+                const bool hit = (oo[j] & ~mask) == tag;
+                const int64_t src = 3 * (int64_t)(hit ? (oo[j] & mask) : 0u);
                 const unsigned b = img[src], g = img[src + 1], r = img[src + 2];
-                v[3 * j] = oo[j] >= 0 ? b : 0u;
-                v[3 * j + 1] = oo[j] >= 0 ? g : 0u;
-                v[3 * j + 2] = oo[j] >= 0 ? r : 0u;
+                v[3 * j] = hit ? b : 0u;
+                v[3 * j + 1] = hit ? g : 0u;
+                v[3 * j + 2] = hit ? r : 0u;
             }
             unsigned* dst = reinterpret_cast<unsigned*>(gs + 3 * p0);  // 12 p0 bytes: 4-byte aligned
             dst[0] = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
@@ -168,10 +172,12 @@ __global__ __launch_bounds__(kBP) void back_project_write_kernel(const unsigned 
             dst[2] = v[8] | (v[9] << 8) | (v[10] << 16) | (v[11] << 24);
         } else {
             for (int64_t p = p0; p < npix; ++p) {
-                const int o = owner[p];
-                gs[3 * p] = o >= 0 ? img[3 * (int64_t)o] : 0;
-                gs[3 * p + 1] = o >= 0 ? img[3 * (int64_t)o + 1] : 0;
-                gs[3 * p + 2] = o >= 0 ? img[3 * (int64_t)o + 2] : 0;
+                const unsigned w = owner[p];
+                const bool hit = (w & ~mask) == tag;
+                const int64_t o = (int64_t)(w & mask);
+                gs[3 * p] = hit ? img[3 * o] : 0;
+                gs[3 * p + 1] = hit ? img[3 * o + 1] : 0;
+                gs[3 * p + 2] = hit ? img[3 * o + 2] : 0;
             }
         }
     }
@@ -264,57 +270,56 @@ __global__ __launch_bounds__(kBP) void preview_minmax_kernel(const double* __res
     }
 }
 
-// single workgroup: header[0] = z_min, header[1] = multiplier = 244 / (z_max - z_min)   (min / max are exact in any order)
-__global__ __launch_bounds__(kBP) void preview_header_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ header) {
-    __shared__ double s_min[kBP / 64], s_max[kBP / 64];
-    double lo = INFINITY, hi = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += kBP) {
-        if (partials[2 * b] < lo) lo = partials[2 * b];
-        if (partials[2 * b + 1] > hi) hi = partials[2 * b + 1];
-    }
-    for (int off = 32; off >= 1; off >>= 1) {
-        const double ol = __shfl_xor(lo, off, 64), oh = __shfl_xor(hi, off, 64);
-        if (ol < lo) lo = ol;
-        if (oh > hi) hi = oh;
-    }
-    if ((threadIdx.x & 63) == 0) {
-        s_min[threadIdx.x >> 6] = lo;
-        s_max[threadIdx.x >> 6] = hi;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w2 = 1; w2 < kBP / 64; ++w2) {
-            if (s_min[w2] < lo) lo = s_min[w2];
-            if (s_max[w2] > hi) hi = s_max[w2];
-        }
-        header[0] = lo;
-        header[1] = 244.0 / (hi - lo);
-    }
-}
-
-// owner: cols*rows int32 COLUMN-major (x * rows + y, the order the inliers arrive in: coalesced atomics), pre-set to
-// -1; the highest inlier index wins (the reference's last writer)
+// owner: cols*rows claim words COLUMN-major (x * rows + y, the order the inliers arrive in: coalesced atomics); the highest
+// inlier index wins (the reference's last writer)
 __global__ __launch_bounds__(kBP) void preview_claim_kernel(const double* __restrict__ inl, int64_t m, double fx, double fy, double cx,
-                                                           double cy, int rows, int cols, int* __restrict__ owner) {
+                                                           double cy, int rows, int cols, unsigned* __restrict__ owner, unsigned tag) {
     const int64_t stride = (int64_t)gridDim.x * kBP;
     for (int64_t i = (int64_t)blockIdx.x * kBP + threadIdx.x; i < m; i += stride) {
         const int x = (int)(fx * inl[3 * i] + cx + 0.5);
         const int y = (int)(fy * inl[3 * i + 1] + cy + 0.5);
-        if (x >= 0 && x < cols && y >= 0 && y < rows) atomicMax(&owner[(int64_t)x * rows + y], (int)i);
+        if (x >= 0 && x < cols && y >= 0 && y < rows) atomicMax(&owner[(int64_t)x * rows + y], tag | (unsigned)i);
     }
 }
 
-// grid: (ceil(cols / 32), ceil(rows / 32)).  Reads the column-major owner tile along y (coalesced; the winners of
-// neighbouring pixels are neighbouring inliers, so the z gather is local too), transposes the bytes through LDS and
-// writes the row-major 8-bit image along x.
-__global__ __launch_bounds__(kBP) void preview_write_kernel(const double* __restrict__ inl, const int* __restrict__ owner,
-                                                           const double* __restrict__ header, int rows, int cols,
-                                                           unsigned char* __restrict__ out) {
+// grid: (ceil(cols / 32), ceil(rows / 32)).  Every workgroup first reduces the (<= 1024) min / max partials of
+// preview_minmax_kernel itself -- min / max are exact in any order, so the redundant reduction replaces the single-workgroup
+// header kernel of round 1 -- then reads the column-major owner tile along y (coalesced; the winners of neighbouring pixels are
+// neighbouring inliers, so the z gather is local too), transposes the bytes through LDS and writes the row-major 8-bit image
+// along x.
+__global__ __launch_bounds__(kBP) void preview_write_kernel(const double* __restrict__ inl, const unsigned* __restrict__ owner, unsigned tag,
+                                                           unsigned mask, const double* __restrict__ partials, int nblocks, int rows,
+                                                           int cols, unsigned char* __restrict__ out) {
     constexpr int T = 32;
     __shared__ unsigned char s_v[T][T + 4];  // [y][x]
-    const double z_min = header[0], mult = header[1];
-    const int x0 = blockIdx.x * T, y0 = blockIdx.y * T;
+    __shared__ double s_min[kBP / 64], s_max[kBP / 64];
     const int tid = threadIdx.x;
+    double z_min, mult;
+    {
+        double lo = INFINITY, hi = 0.0;
+        for (int b = tid; b < nblocks; b += kBP) {
+            if (partials[2 * b] < lo) lo = partials[2 * b];
+            if (partials[2 * b + 1] > hi) hi = partials[2 * b + 1];
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            const double ol = __shfl_xor(lo, off, 64), oh = __shfl_xor(hi, off, 64);
+            if (ol < lo) lo = ol;
+            if (oh > hi) hi = oh;
+        }
+        if ((tid & 63) == 0) {
+            s_min[tid >> 6] = lo;
+            s_max[tid >> 6] = hi;
+        }
+        __syncthreads();
+        lo = s_min[0], hi = s_max[0];
+        for (int w2 = 1; w2 < kBP / 64; ++w2) {
+            if (s_min[w2] < lo) lo = s_min[w2];
+            if (s_max[w2] > hi) hi = s_max[w2];
+        }
+        z_min = lo;
+        mult = 244.0 / (hi - lo);  // main.cc:497
+    }
+    const int x0 = blockIdx.x * T, y0 = blockIdx.y * T;
     {
         const int ly = tid & (T - 1);
         const int y = y0 + ly;
@@ -322,7 +327,8 @@ __global__ __launch_bounds__(kBP) void preview_write_kernel(const double* __rest
 #pragma unroll
         for (int j = 0; j < T * T / kBP; ++j) {
             const int x = x0 + (tid / T) + j * (kBP / T);
-            o[j] = (x < cols && y < rows) ? owner[(int64_t)x * rows + y] : -1;
+            const unsigned w = (x < cols && y < rows) ? owner[(int64_t)x * rows + y] : 0u;
+            o[j] = (x < cols && y < rows && (w & ~mask) == tag) ? (int)(w & mask) : -1;
         }
         double z[T * T / kBP];
 #pragma unroll
@@ -358,16 +364,53 @@ static inline int stream_grid(int64_t n, int per_thread = 1) {
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
+// Persistent claim map `which` (0: back projection, 1: depth image) of the context with room for npix words.  Words are
+// `tag | index`: tag = epoch << 24 with a per-call epoch 1..255 and index < 2^24 -- a word written by an earlier call carries an
+// older epoch, loses every atomicMax against the current one and is ignored by the read-back (valid iff word & ~mask == tag), so
+// the map is cleared only when it is (re)allocated and when the epoch wraps (every 255 calls).  Images beyond 2^24 pixels fall
+// back to a clear per call with a 1-bit tag.
+static int claim_map_acquire(Ctx* c, int which, size_t npix, unsigned** map, unsigned* tag, unsigned* mask) {
+    bool clear = false;
+    if (npix > c->claim_words[which]) {
+        RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        if (c->d_claim[which]) RSDSFM_HIP_CHECK(c, hipFree(c->d_claim[which]));
+        c->d_claim[which] = nullptr;
+        c->claim_words[which] = 0;
+        RSDSFM_HIP_CHECK(c, hipMalloc(reinterpret_cast<void**>(&c->d_claim[which]), sizeof(unsigned) * npix));
+        c->claim_words[which] = npix;
+        c->claim_epoch[which] = 0;
+        clear = true;
+    }
+    const bool wide = npix > ((size_t)1 << 24);
+    if (wide) {
+        clear = true;
+        *tag = 0x80000000u;
+        *mask = 0x7FFFFFFFu;
+    } else {
+        if (c->claim_epoch[which] >= 255u) {
+            c->claim_epoch[which] = 0;
+            clear = true;
+        }
+        c->claim_epoch[which] += 1;
+        *tag = c->claim_epoch[which] << 24;
+        *mask = 0x00FFFFFFu;
+    }
+    if (clear) RSDSFM_HIP_CHECK(c, hipMemsetAsync(c->d_claim[which], 0, sizeof(unsigned) * c->claim_words[which], c->stream));
+    *map = c->d_claim[which];
+    return RSDSFM_OK;
+}
+
 int back_project_launch(Ctx* c, const unsigned char* d_img, const double* d_depth_cm, const double* d_R, const double* d_t, double fx,
-                        double fy, double cx, double cy, int rows, int cols, int mode, int q5_mode, unsigned char* d_gs, float* d_c3d,
-                        int* d_owner) {
+                        double fy, double cx, double cy, int rows, int cols, int mode, int q5_mode, unsigned char* d_gs, float* d_c3d) {
     const int64_t npix = (int64_t)rows * cols;
-    RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_owner, 0xFF, sizeof(int) * (size_t)npix, c->stream));
+    unsigned *d_owner = nullptr, tag = 0, mask = 0;
+    int rc = claim_map_acquire(c, 0, (size_t)npix, &d_owner, &tag, &mask);
+    if (rc != RSDSFM_OK) return rc;
     dim3 grid((cols + kTX - 1) / kTX, (rows + kTY - 1) / kTY);
     hipLaunchKernelGGL(back_project_claim_kernel, grid, dim3(kCB), 0, c->stream, d_img, d_depth_cm, d_R, d_t, fx, fy, cx, cy,
-                       q5_mode == 0 ? fx : fy, rows, cols, mode, d_owner, d_c3d);
+                       q5_mode == 0 ? fx : fy, rows, cols, mode, d_owner, tag, d_c3d);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(back_project_write_kernel, dim3(stream_grid(npix, 4)), dim3(kBP), 0, c->stream, d_img, d_owner, npix, d_gs);
+    hipLaunchKernelGGL(back_project_write_kernel, dim3(stream_grid(npix, 4)), dim3(kBP), 0, c->stream, d_img, d_owner, tag, mask, npix, d_gs);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
@@ -379,23 +422,23 @@ int interpolate_cracky_launch(Ctx* c, const unsigned char* d_in, int rows, int c
     return RSDSFM_OK;
 }
 
-// d_partials: >= 2 * 1024 doubles; d_header: 2 doubles; d_owner: rows*cols int32
+// d_partials: >= 2 * 1024 doubles
 int depth_preview_launch(Ctx* c, const double* d_inl, int64_t m, double fx, double fy, double cx, double cy, int rows, int cols,
-                         unsigned char* d_out, double* d_partials, double* d_header, int* d_owner) {
+                         unsigned char* d_out, double* d_partials) {
     const int64_t npix = (int64_t)rows * cols;
     const int zb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (m + kBP - 1) / kBP));
+    unsigned *d_owner = nullptr, tag = 0, mask = 0;
+    int rc = claim_map_acquire(c, 1, (size_t)npix, &d_owner, &tag, &mask);
+    if (rc != RSDSFM_OK) return rc;
     hipLaunchKernelGGL(preview_minmax_kernel, dim3(zb), dim3(kBP), 0, c->stream, d_inl, m, d_partials);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(preview_header_kernel, dim3(1), dim3(kBP), 0, c->stream, d_partials, zb, d_header);
-    RSDSFM_HIP_CHECK(c, hipGetLastError());
-    RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_owner, 0xFF, sizeof(int) * (size_t)npix, c->stream));
     if (m > 0) {
         hipLaunchKernelGGL(preview_claim_kernel, dim3(stream_grid(m)), dim3(kBP), 0, c->stream, d_inl, m, fx, fy, cx, cy, rows, cols,
-                           d_owner);
+                           d_owner, tag);
         RSDSFM_HIP_CHECK(c, hipGetLastError());
     }
-    hipLaunchKernelGGL(preview_write_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(kBP), 0, c->stream, d_inl, d_owner, d_header,
-                       rows, cols, d_out);
+    hipLaunchKernelGGL(preview_write_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(kBP), 0, c->stream, d_inl, d_owner, tag, mask,
+                       d_partials, zb, rows, cols, d_out);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -115,6 +115,10 @@ struct Ctx {
     size_t tile_bytes = 0;
     void* tile_session = nullptr;  // heap RefineBuffers of the open session
     int tile_np = 0;
+    // persistent claim maps of the forward-splat kernels (rectify_kernels.hip: claim_map_acquire): 0 = back projection, 1 = depth image
+    unsigned* d_claim[2] = {nullptr, nullptr};
+    size_t claim_words[2] = {0, 0};
+    unsigned claim_epoch[2] = {0, 0};
     void* dist = nullptr;  // dist_host.hip: communicator / transport + exchange buffers of the native tiled solve
 };
 void dist_release(Ctx* c);
@@ -282,11 +286,10 @@ int refine_stage_apply_launch(Ctx* c, const RefineBuffers& B, int np, int stage,
 namespace rsdsfm {
 // rectify_kernels.hip
 int back_project_launch(Ctx* c, const unsigned char* d_img, const double* d_depth_cm, const double* d_R, const double* d_t, double fx,
-                        double fy, double cx, double cy, int rows, int cols, int mode, int q5_mode, unsigned char* d_gs, float* d_c3d,
-                        int* d_owner);
+                        double fy, double cx, double cy, int rows, int cols, int mode, int q5_mode, unsigned char* d_gs, float* d_c3d);
 int interpolate_cracky_launch(Ctx* c, const unsigned char* d_in, int rows, int cols, int offset, unsigned char* d_out);
 int depth_preview_launch(Ctx* c, const double* d_inl, int64_t m, double fx, double fy, double cx, double cy, int rows, int cols,
-                         unsigned char* d_out, double* d_partials, double* d_header, int* d_owner);
+                         unsigned char* d_out, double* d_partials);
 }  // namespace rsdsfm
 
 // the opaque handle of the C ABI

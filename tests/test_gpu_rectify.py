@@ -69,6 +69,30 @@ def test_back_project_collisions_last_writer_wins(oracle, rsdsfm):
         assert np.array_equal(o, exp)
 
 
+def test_claim_maps_survive_epoch_wrap_and_resizing(oracle, rsdsfm):
+    """the forward-splat claim maps are persistent per context and carry an 8-bit epoch instead of being cleared per frame:
+    600 back projections / depth images on ONE context, alternating between two scenes whose targets differ (so stale claims of
+    the previous frame sit exactly where the current frame leaves holes), across two epoch wraps and a change of image size,
+    each result equal to the oracle's"""
+    rng = np.random.default_rng(3)
+    scenes = []
+    for rows, cols, vz in ((60, 90, -3.0), (60, 90, 2.5), (75, 70, -2.0)):
+        d, img, depth, _, _ = _scene(rsdsfm, oracle, rows, cols, seed=rows + cols + int(10 * vz) + 100)
+        K = d["K"]
+        R, t = oracle.pose_table(np.array([0.05, -0.02, vz]), np.array([0.2, -0.1, 0.3]), 0.0, d["gamma"], rows)
+        depth = np.abs(depth) + 1.0
+        exp = oracle.back_project(img, depth, R, t, *K, want_coords=False)[0]
+        inl = np.column_stack([rng.uniform(-0.15, 0.15, 3000), rng.uniform(-0.1, 0.1, 3000), rng.normal(2.0, 1.0, 3000)])
+        scenes.append((img, depth, R, t, K, exp, inl, oracle.depth_preview(inl, *K, rows, cols), rows, cols))
+    assert (scenes[0][5].reshape(-1, 3).sum(axis=1) != 0).mean() < 0.9 and not np.array_equal(scenes[0][5] != 0, scenes[1][5] != 0)
+    with rsdsfm.Solver(0) as s:
+        for i in range(600):
+            img, depth, R, t, K, exp, inl, pv, rows, cols = scenes[(i % 2) if i < 560 else 2]
+            assert np.array_equal(s.back_project(img, depth, R, t, K, want_coords=False)[0], exp), i
+            if i % 3 == 0:
+                assert np.array_equal(s.depth_preview(inl, K, rows, cols), pv), i
+
+
 @pytest.mark.parametrize("rows,cols,off", [(3, 3, 1), (40, 61, 1), (40, 61, 3), (5, 4, 2), (720, 1280, 1)])
 def test_interpolate_equals_oracle(oracle, rsdsfm, rows, cols, off):
     rng = np.random.default_rng(rows + cols + off)

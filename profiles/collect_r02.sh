@@ -19,6 +19,14 @@ p full_write WRITE_SIZE --steps 6 --warmup 2 $PROF
 python3 profiles/pmc_to_json.py $OUT/counters.json /tmp/pmc_full_insts /tmp/pmc_full_fetch /tmp/pmc_full_write
 p fused_insts "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU" --steps 6 --warmup 2 --arith fused $PROF
 python3 profiles/pmc_to_json.py $OUT/counters.json --suffix :fused /tmp/pmc_fused_insts
+if [ "${1:-}" != "quick" ]; then
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    p rect_$ctr $ctr --workload rectify --steps 30 --no-cpu-baseline
+    p depth_$ctr $ctr --workload depth --streams 1 --steps 6 --warmup 1 --no-cpu-baseline
+    p tflow_$ctr $ctr --workload true_flow --steps 10 --no-cpu-baseline
+    python3 profiles/pmc_to_json.py $OUT/counters.json /tmp/pmc_rect_$ctr /tmp/pmc_depth_$ctr /tmp/pmc_tflow_$ctr
+  done
+fi
 cp $OUT/counters.json profiles/counters.json
 t full --steps 100 $PROF
 b full
@@ -26,8 +34,11 @@ if [ "${1:-}" != "quick" ]; then
   b full_fused --arith fused --no-side-records
   b depth --workload depth
   b tiled_full --workload tiled_full
+  b tiled_full_python --workload tiled_full --tiled-driver python
+  b metrics --workload metrics
   b rectify --workload rectify
   b true_flow --workload true_flow
   t depth --workload depth --steps 60 --no-cpu-baseline
   t rectify --workload rectify --no-cpu-baseline
+  t tiled_full --workload tiled_full --steps 20
 fi

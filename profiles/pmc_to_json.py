@@ -15,9 +15,9 @@ import sys
 
 
 def norm(name):
-    name = name.strip().strip('"')
+    name = name.strip().strip('"').replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*$", "", name)  # parameter list
-    name = name.replace("void ", "").replace("rsdsfm::", "").replace("(anonymous namespace)::", "")
+    name = name.replace("void ", "").replace("rsdsfm::", "")
     return name.strip()
 
 
@@ -45,10 +45,12 @@ def main():
         except Exception:
             res = {}
     for k, d in acc.items():
+        if k.startswith("__amd") or k.startswith("at::") or "Cijk" in k:  # runtime fill / copy kernels and torch's own kernels
+            continue
         e = res.setdefault(k + suffix, {})
         for cn, v in d.items():
             e[cn] = sum(v) / len(v)
-            e[cn + "__launches"] = len(v)
+        e["launches_sampled"] = max(len(v) for v in d.values())
     json.dump(res, open(out_path, "w"), indent=1, sort_keys=True)
     print("wrote %s: %d kernels" % (out_path, len(res)))
 

@@ -445,6 +445,30 @@ class Solver:
                     d_inliers=res.d_inliers, d_inlier_idx=res.d_inlier_idx, d_scanline=res.d_scanline,
                     info={k2: int(getattr(info, k2)) for k2, _ in TiledInfo._fields_ if k2 != "_pad"})
 
+    def prepared_frame_solve(self, d_flow_img, rows, cols, K, gamma, d_depth_map, d_R=None, d_t=None, trials=50, tol=0.05,
+                             use_acceleration_mode=False, use_refinement=True, depth_mode=DEPTH_CERES_LM, k_sign_mode=K_COMPAT,
+                             flow_threshold=1e-10, flow_index_mode=FLOW_COMPAT_RANK, use_global_shutter_mode=False):
+        """Returns call(seed) -> FrameResult for repeated whole solves with pre-marshalled arguments (one foreign call per solve;
+        the host-side cost of building the argument structures and the result dict -- ~30 us in Python, during which the GPU
+        idles -- is paid once).  The returned ctypes struct is reused by the next call."""
+        prm = FrameParams(int(trials), int(use_acceleration_mode), int(use_refinement), int(depth_mode), int(k_sign_mode),
+                          int(flow_index_mode), int(use_global_shutter_mode), 0, float(tol), float(flow_threshold), 0)
+        res = FrameResult()
+        d = C.c_double
+        fn = self.lib.rsdsfm_solve_frame_dev
+        args = (self._ctx, _dp(d_flow_img), C.c_int32(rows), C.c_int32(cols), d(K[0]), d(K[1]), d(K[2]), d(K[3]), d(gamma), C.byref(prm),
+                _dp(d_depth_map), _dp(d_R) if d_R else None, _dp(d_t) if d_t else None, C.byref(res))
+        check = self._check
+
+        def call(seed):
+            prm.seed = seed
+            rc = fn(*args)
+            if rc != OK:
+                check(rc, "rsdsfm_solve_frame_dev")
+            return res
+
+        return call
+
     def depth_lm_reduce_dev(self, n_shard, d_row):
         self._check(self.lib.rsdsfm_depth_lm_reduce_dev(self._ctx, C.c_int64(n_shard), _dp(d_row)), "rsdsfm_depth_lm_reduce_dev")
 

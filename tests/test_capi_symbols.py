@@ -4,23 +4,51 @@ import os
 import pytest
 
 
-def test_library_exports_every_declared_symbol(rsdsfm):
-    lib = rsdsfm.load_library()
+@pytest.mark.parametrize("arith", ["reference", "fused"])
+def test_library_exports_every_declared_symbol(rsdsfm, arith):
+    """both builds of the library (reference arithmetic = the product; fused = opt-in) export the whole ABI and say which one they are"""
+    lib = rsdsfm.load_library(arith=arith)
     names = rsdsfm.declared_symbols()
-    assert len(names) >= 15
+    assert len(names) >= 70
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert b"gfx950" in lib.rsdsfm_version()
+    assert lib.rsdsfm_fused_arithmetic() == (1 if arith == "fused" else 0)
+    assert (b"reference arithmetic" in lib.rsdsfm_version()) == (arith == "reference")
 
 
-def test_code_object_is_gfx950_only(rsdsfm):
+@pytest.mark.parametrize("path", ["LIB_PATH", "LIB_PATH_FUSED"])
+def test_code_object_is_gfx950_only(rsdsfm, path):
     """The fat binary carries gfx950 code objects only (no multi-arch / compatibility builds)."""
     import re
 
-    rsdsfm.load_library()
-    blob = open(rsdsfm.LIB_PATH, "rb").read()
+    rsdsfm.load_library(arith="fused" if path.endswith("FUSED") else "reference")
+    blob = open(getattr(rsdsfm, path), "rb").read()
     archs = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", blob))
     assert archs == {b"gfx950"}, archs
+
+
+def test_library_does_not_need_rccl_to_load(rsdsfm):
+    """RCCL is resolved with dlopen on the first rsdsfm_dist_* call: the library itself links neither librccl nor torch"""
+    import subprocess
+
+    out = subprocess.run(["readelf", "-d", rsdsfm.LIB_PATH], capture_output=True, text=True).stdout
+    needed = [ln.split("[")[1].split("]")[0] for ln in out.splitlines() if "(NEEDED)" in ln]
+    assert not any("rccl" in n or "nccl" in n or "torch" in n for n in needed), needed
+    assert any("amdhip64" in n for n in needed)
+
+
+def test_tiled_slab_bounds_is_host_only(rsdsfm):
+    """slab geometry of the column-tiled solve (no GPU needed): contiguous, ordered, covering, stride = ceil(cols / ranks)"""
+    for cols, n in ((3840, 8), (250, 3), (7, 4), (7, 5), (1, 1), (5, 8)):
+        prev_end, per = 0, -(-cols // n)
+        for r in range(n):
+            c0, sc, stride = rsdsfm.tiled_slab_bounds(cols, n, r)
+            assert stride == per and c0 == min(cols, r * per) == prev_end and 0 <= sc <= per
+            prev_end = c0 + sc
+        assert prev_end == cols
+    with pytest.raises(rsdsfm.RsdsfmError):
+        rsdsfm.tiled_slab_bounds(10, 2, 2)
 
 
 def test_create_fails_loudly_without_gpu(rsdsfm):

@@ -26,6 +26,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -1296,6 +1297,7 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
             break;
         }
         double rel = cost_change / model_change;
+        if (getenv("RSO_TRACE")) fprintf(stderr, "oracle it %d cost %.17g ccost %.17g model %.17g rel %.17g radius %.17g step %.6g\n", iteration, cost, ccost, model_change, rel, radius, step_norm);
         if (rel > CERES_MIN_REL_DECREASE) {
             memcpy(p, pc, sizeof(pc));
             xsq = 0.0;

@@ -811,18 +811,20 @@ def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):
     kern_ms = float(np.mean(ts))
     kname = "ransac_lm_kernel<true, 3>"
     ctr = _counters(kname + (":fused" if args.arith == "fused" else ""))
-    insts = achieved = frac = traffic = None
+    insts = achieved = frac = traffic = frac_all = None
     if ctr:
         insts = 64.0 * sum(ctr.get(k2, 0.0) for k2 in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
         achieved = insts / (kern_ms * 1e-3)
         frac = achieved / FP64_VALU_PEAK
+        if ctr.get("SQ_INSTS_VALU"):  # every VALU instruction (incl. v_div_scale / fmas / fixup, compares, selects) at the fp64 issue rate
+            frac_all = 64.0 * ctr["SQ_INSTS_VALU"] / (kern_ms * 1e-3) / FP64_VALU_PEAK
         if "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:  # KB; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section)
             traffic = (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0
     iters = full["refine_summary"]["num_iterations"]
     hbm_bytes = 57.0 * full["n"] + 64.0 * full["num_inliers"] * iters
     hbm_gbs = hbm_bytes / (full["median_ms_per_solve"] * 1e-3) / 1e9
     return {"bound": "fp64-valu", "kernel": kname, "achieved": None if achieved is None else achieved / 1e12, "peak": FP64_VALU_PEAK / 1e12,
-            "unit": "T fp64 lane-instructions/s", "frac": frac, "traffic": traffic,
+            "unit": "T fp64 lane-instructions/s", "frac": frac, "frac_all_valu_instructions": frac_all, "traffic": traffic,
             "fp64_lane_instructions_per_launch": insts, "avg_launch_ms": kern_ms, "median_launch_ms": float(ts[len(ts) // 2]),
             "pixel_hypotheses_per_launch": int(n) * T, "alg_bytes_per_launch": 48 * int(n),
             "share_of_solve": kern_ms / full["median_ms_per_solve"],

@@ -91,12 +91,32 @@ def fuzz_consumers(O, rsdsfm, cases, seed0):
 DECISION_KEYS = ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination")
 
 
+def _refine_deviation(x, ref):
+    """deviation of one refinement result from another, modulo the scale gauge of the problem (the residual only sees rho * v, the
+    refinement does not normalise v, and a long trajectory drifts along that flat direction by accumulated rounding)"""
+    nx, nr = np.linalg.norm(x["v"]), np.linalg.norm(ref["v"])
+    dv = np.abs(x["v"] / nx - ref["v"] / nr) / np.maximum(np.abs(ref["v"] / nr), 1e-2)  # relative, floor 1e-7 / 1e-5
+    dw = np.abs(x["w"] - ref["w"]) / np.maximum(np.abs(ref["w"]), 1e-3)               # relative, floor 1e-8 / 1e-5
+    zg, zr = x["inliers"][:, 2] / nx, ref["inliers"][:, 2] / nr
+    rel = np.abs(zg - zr) / np.maximum(np.abs(zr), 1e-4)                                # relative, floor 1e-9 / 1e-5
+    cx, cr = x["summary"]["final_cost"], ref["summary"]["final_cost"]
+    return dict(pose=float(max(dv.max(), dw.max())), depth_q995=float(np.quantile(rel, 0.995)) if len(rel) else 0.0,
+                depth_max=float(rel.max()) if len(rel) else 0.0, cost=abs(cx - cr) / max(abs(cr), 1e-18))
+
+
 def _oracle_reorderings(O, u, ro, use_k):
     """the oracle's refinement of the same problem with its inlier list re-ordered (reversed + 3 seeded random permutations): its
     own sums added in other orders.  What these runs disagree about is not defined by the reference's arithmetic."""
     m = len(ro["inlier_idx"])
     perms = [np.arange(m)[::-1]] + [np.random.default_rng(100 + t).permutation(m) for t in range(3)]
-    return [O.refine(u, ro["inliers"][pm], ro["alpha"][pm], ro["alpha_k"][pm], ro["v"], ro["w"], ro["k"], use_k, 1, ro["inlier_idx"][pm]) for pm in perms]
+    outs = []
+    for pm in perms:
+        o2 = O.refine(u, ro["inliers"][pm], ro["alpha"][pm], ro["alpha_k"][pm], ro["v"], ro["w"], ro["k"], use_k, 1, ro["inlier_idx"][pm])
+        inv = np.empty(m, dtype=np.int64)
+        inv[pm] = np.arange(m)
+        o2["inliers"] = o2["inliers"][inv]  # back in the original order
+        outs.append(o2)
+    return outs
 
 
 def main(cases=None, seed0=None):
@@ -207,30 +227,23 @@ def main(cases=None, seed0=None):
                     # modulo the scale gauge of the problem: the residual only sees rho * v, the refinement does not normalise v,
                     # and a long trajectory drifts along that flat direction by accumulated rounding (|v| differed by 1e-3 in one
                     # 41-iteration case while the cost agreed to 4e-10)
-                    ng, nr = np.linalg.norm(out["v"]), np.linalg.norm(ref["v"])
-                    pose_ok = np.allclose(out["v"] / ng, ref["v"] / nr, rtol=1e-5, atol=1e-7) and np.allclose(out["w"], ref["w"], rtol=1e-5, atol=1e-8)
-                    if not pose_ok:
-                        # same decisions, different values: a long trajectory with rejected steps (50 iterations here and there) amplifies
-                        # the rounding of its sums chaotically.  Same characterisation as above: the oracle on the reversed point list.
-                        # Accepted only if the oracle's own re-ordering moves the pose at least a quarter as far as the GPU is away from
-                        # it; a deviation the reference's arithmetic does not exhibit itself is a mismatch.
-                        others = _oracle_reorderings(O, u, ro, use_k)
-                        own = max(max(np.abs(o2["v"] / np.linalg.norm(o2["v"]) - ref["v"] / nr).max(), np.abs(o2["w"] - ref["w"]).max()) for o2 in others)
-                        dev = max(np.abs(out["v"] / ng - ref["v"] / nr).max(), np.abs(out["w"] - ref["w"]).max())
-                        assert dev <= 4.0 * own, ("refine pose", out["v"], ref["v"], out["w"], ref["w"], so, sr, "oracle's own spread", own)
-                        spread = max(abs(o2["summary"]["final_cost"] - sr["final_cost"]) for o2 in others)
-                        assert abs(so["final_cost"] - sr["final_cost"]) <= 4.0 * spread + 1e-9 * abs(sr["final_cost"]), "refine cost (chaotic)"
-                        splits += 1
-                        continue
                     assert np.array_equal(out["inliers"][:, :2], ref["inliers"][:, :2]), "refine inlier coordinates"
-                    zg, zr = out["inliers"][:, 2] / ng, ref["inliers"][:, 2] / nr
-                    # single points whose depth the data barely constrains (next to the epipole) may differ more after a long run
-                    if not (np.mean(np.isclose(zg, zr, rtol=1e-5, atol=1e-9)) >= 0.995 and np.allclose(zg, zr, rtol=1e-2, atol=1e-6)):
-                        rel = np.abs(zg - zr) / np.maximum(np.abs(zr), 1e-300)
-                        i = int(np.argmax(rel))
-                        raise AssertionError("refine depths: %d of %d beyond 1e-5, worst %.3e at %d (%.12g vs %.12g; before refinement %.12g) %s" % (
-                            int(np.sum(rel > 1e-5)), len(zr), rel[i], i, zg[i], zr[i], r["inliers"][i, 2], so))
-                    assert np.isclose(so["final_cost"], sr["final_cost"], rtol=1e-7, atol=1e-25), "refine cost"
+                    dev = _refine_deviation(out, ref)
+                    # bars: pose 1e-5 (north star; absolute floors 1e-7 / 1e-8 as before), 99.5 % of the depths within 1e-5 and all within
+                    # 1e-2 (single points whose depth the data barely constrains, 1/depth ~ 0, may differ more after a long run), cost 1e-7
+                    bars = dict(pose=1e-5, depth_q995=1e-5, depth_max=1e-2, cost=1e-7)
+                    over = [key for key in bars if dev[key] > bars[key]]
+                    if over:
+                        # same decisions, different values: a long trajectory (tens of iterations, a trust-region radius of 1e15 where the
+                        # undamped Schur system is singular along the scale gauge) amplifies the rounding of its sums.  Same
+                        # characterisation as above: the oracle on re-ordered point lists.  Accepted only if the oracle's own re-ordering
+                        # moves the quantity at least a quarter as far as the GPU is away from it; a deviation the reference's arithmetic
+                        # does not exhibit itself is a mismatch.
+                        others = [_refine_deviation(o2, ref) for o2 in _oracle_reorderings(O, u, ro, use_k)]
+                        for key in over:
+                            own = max(o2[key] for o2 in others)
+                            assert dev[key] <= 4.0 * own, ("refine " + key, dev[key], "oracle's own spread", own, so, sr)
+                        splits += 1
             except AssertionError as e:
                 bad += 1
                 print("MISMATCH", tag, e.args[0] if e.args else "", flush=True)

@@ -536,7 +536,7 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
         const size_t M = (size_t)std::max<int64_t>(m, 1);
         const size_t npart = (size_t)refine_partials_doubles(c, m);
         rc = ensure_dev(c, &D->d_session, &D->session_bytes,
-                        Arena::need(sizeof(RefineState) + 64) + Arena::need(16 * M) + 3 * Arena::need(8 * M) + Arena::need(8 * npart) + 1024);
+                        Arena::need(sizeof(RefineState) + 64) + Arena::need(32 * M) + 4 * Arena::need(8 * M) + Arena::need(8 * npart) + 1024);
         if (rc != RSDSFM_OK) return rc;
         Arena sa(D->d_session);
         RefineBuffers B;
@@ -551,7 +551,8 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
         char* state_block = sa.take<char>(sizeof(RefineState) + 64);
         B.state = reinterpret_cast<RefineState*>(state_block);
         B.bad_index = reinterpret_cast<int*>(state_block + sizeof(RefineState));
-        B.uu = sa.take<double>(2 * M);
+        B.uu = sa.take<double>(4 * M);
+        B.beta = sa.take<double>(M);
         B.rho_a = sa.take<double>(M);
         B.rho_b = sa.take<double>(M);
         B.srho = sa.take<double>(M);

@@ -20,7 +20,7 @@ int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const
     const int np = const_acceleration ? 7 : 6;
     const size_t M = (size_t)std::max<int64_t>(m, 1);
     const size_t npart = (size_t)refine_partials_doubles(c, m);
-    int rc = ensure_ws(c, Arena::need(sizeof(RefineState) + 64) + Arena::need(16 * M) + 3 * Arena::need(8 * M) + Arena::need(8 * npart) + Arena::need(64) + 1024);
+    int rc = ensure_ws(c, Arena::need(sizeof(RefineState) + 64) + Arena::need(32 * M) + 4 * Arena::need(8 * M) + Arena::need(8 * npart) + Arena::need(64) + 1024);
     if (rc != RSDSFM_OK) return rc;
     rc = ensure_pinned(c, sizeof(RefineState) + 64);
     if (rc != RSDSFM_OK) return rc;
@@ -38,7 +38,8 @@ int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const
     static_assert(sizeof(RefineState) % sizeof(int) == 0, "flag follows the state");
     char* state_block = ws.take<char>(sizeof(RefineState) + 64);
     B.state = reinterpret_cast<RefineState*>(state_block);
-    B.uu = ws.take<double>(2 * M);
+    B.uu = ws.take<double>(4 * M);
+    B.beta = ws.take<double>(M);
     B.rho_a = ws.take<double>(M);
     B.rho_b = ws.take<double>(M);
     B.srho = ws.take<double>(M);

@@ -33,11 +33,25 @@ struct RJ {
 };
 
 // residual and analytic Jacobian at (p, rho); p = (v0,v1,v2,w0,w1,w2,k)
+// beta of nonlinearRefinement.cc:35 and (NP == 7) its derivative with respect to k
+__device__ __forceinline__ double beta_of(double alpha, double alpha_k, double k) { return (2.0 / (2.0 + k)) * (alpha + k * alpha_k); }
+__device__ __forceinline__ double dbeta_of(double alpha, double alpha_k, double k) { return 2.0 * (2.0 * alpha_k - alpha) / ((2.0 + k) * (2.0 + k)); }
+
+template <int NP>
+__device__ __forceinline__ void resid_jac_beta(double x, double y, double ux, double uy, double beta, double dbeta,
+                                               const double (&p)[7], double rho, RJ<NP>& o);
+
 template <int NP>
 __device__ __forceinline__ void resid_jac(double x, double y, double ux, double uy, double alpha, double alpha_k,
                                           const double (&p)[7], double rho, RJ<NP>& o) {
     const double k = p[6];
-    const double beta = (2.0 / (2.0 + k)) * (alpha + k * alpha_k);
+    resid_jac_beta<NP>(x, y, ux, uy, beta_of(alpha, alpha_k, k), NP == 7 ? dbeta_of(alpha, alpha_k, k) : 0.0, p, rho, o);
+}
+
+// residual and Jacobian for a given beta (and d beta / d k): the streaming passes read beta precomputed when k is fixed (NP == 6)
+template <int NP>
+__device__ __forceinline__ void resid_jac_beta(double x, double y, double ux, double uy, double beta, double dbeta,
+                                               const double (&p)[7], double rho, RJ<NP>& o) {
     const double a0 = x * p[2] - p[0], a1 = y * p[2] - p[1];
     const double in0 = rho * a0 + (x * y * p[3]) - (1.0 + x * x) * p[4] + y * p[5];
     const double in1 = rho * a1 + (1.0 + y * y) * p[3] - x * y * p[4] - x * p[5];
@@ -57,7 +71,6 @@ __device__ __forceinline__ void resid_jac(double x, double y, double ux, double 
     o.Jp[0][5] = beta * y;
     o.Jp[1][5] = -(beta * x);
     if (NP == 7) {
-        const double dbeta = 2.0 * (2.0 * alpha_k - alpha) / ((2.0 + k) * (2.0 + k));
         o.Jp[0][NP - 1] = dbeta * in0;
         o.Jp[1][NP - 1] = dbeta * in1;
     }
@@ -199,9 +212,10 @@ __global__ __launch_bounds__(kFB) void refine_init_kernel(const double2* __restr
                                                          const double* __restrict__ inl, const double* __restrict__ alpha,
                                                          const double* __restrict__ alpha_k,
                                                          const int64_t* __restrict__ inlier_idx, int flow_index_mode,
-                                                         const RefineState* __restrict__ st, double2* __restrict__ uu,
-                                                         double* __restrict__ rho0, double* __restrict__ srho,
-                                                         double* __restrict__ partials, int* __restrict__ bad_index) {
+                                                         const RefineState* __restrict__ st, double4* __restrict__ xyuv,
+                                                         double* __restrict__ beta_out, double* __restrict__ rho0,
+                                                         double* __restrict__ srho, double* __restrict__ partials,
+                                                         int* __restrict__ bad_index) {
     using CT = Counts<NP>;
     __shared__ double s_red[kFB / 64][CT::NINIT];
     double p[7];
@@ -218,8 +232,11 @@ __global__ __launch_bounds__(kFB) void refine_init_kernel(const double2* __restr
             fi = 0;
         }
         const double2 f = flow[fi];
-        uu[i] = f;
         const double x = inl[3 * i], y = inl[3 * i + 1];
+        // the per-inlier constants of every later pass as ONE 32-byte record (the passes are HBM-bound: x, y no longer come out
+        // of the 24-byte (x, y, z) triples, and with k fixed beta replaces alpha and alpha_k: 56 instead of 72 bytes per inlier)
+        xyuv[i] = make_double4(x, y, f.x, f.y);
+        if (NP == 6) beta_out[i] = beta_of(alpha[i], alpha_k[i], p[6]);
         const double rho = 1.0 / inl[3 * i + 2];
         rho0[i] = rho;
         RJ<NP> o;
@@ -271,8 +288,8 @@ __global__ __launch_bounds__(kFB) void refine_init_decide_kernel(const double* _
 // pass 1: Schur complement sums
 // ---------------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(kFB) void refine_schur_kernel(int64_t m, const double* __restrict__ inl,
-                                                          const double2* __restrict__ uu, const double* __restrict__ alpha,
+__global__ __launch_bounds__(kFB) void refine_schur_kernel(int64_t m, const double4* __restrict__ xyuv,
+                                                          const double* __restrict__ beta_in, const double* __restrict__ alpha,
                                                           const double* __restrict__ alpha_k,
                                                           const double* __restrict__ rho_a, const double* __restrict__ rho_b,
                                                           const double* __restrict__ srho, const RefineState* __restrict__ st,
@@ -292,9 +309,12 @@ __global__ __launch_bounds__(kFB) void refine_schur_kernel(int64_t m, const doub
     for (int s = 0; s < CT::NSCHUR; ++s) acc[s] = 0.0;
     const int64_t stride = (int64_t)gridDim.x * kFB;
     for (int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x; i < m; i += stride) {
-        const double2 f = uu[i];
+        const double4 c4 = xyuv[i];
         RJ<NP> o;
-        resid_jac<NP>(inl[3 * i], inl[3 * i + 1], f.x, f.y, alpha[i], alpha_k[i], p, rho[i], o);
+        if (NP == 6)
+            resid_jac_beta<NP>(c4.x, c4.y, c4.z, c4.w, beta_in[i], 0.0, p, rho[i], o);
+        else
+            resid_jac<NP>(c4.x, c4.y, c4.z, c4.w, alpha[i], alpha_k[i], p, rho[i], o);
         const double sr = srho[i];
         const double E0 = o.Jr[0] * sr, E1 = o.Jr[1] * sr;
         const double ht = E0 * E0 + E1 * E1;
@@ -438,8 +458,8 @@ __global__ __launch_bounds__(kFB) void refine_solve_kernel(const double* __restr
 // pass 2: back-substitution + candidate evaluation
 // ---------------------------------------------------------------------------------------------------
 template <int NP>
-__global__ __launch_bounds__(kFB) void refine_backsub_kernel(int64_t m, const double* __restrict__ inl,
-                                                            const double2* __restrict__ uu, const double* __restrict__ alpha,
+__global__ __launch_bounds__(kFB) void refine_backsub_kernel(int64_t m, const double4* __restrict__ xyuv,
+                                                            const double* __restrict__ beta_in, const double* __restrict__ alpha,
                                                             const double* __restrict__ alpha_k, double* __restrict__ rho_a,
                                                             double* __restrict__ rho_b, const double* __restrict__ srho,
                                                             const RefineState* __restrict__ st, double* __restrict__ partials) {
@@ -465,11 +485,20 @@ __global__ __launch_bounds__(kFB) void refine_backsub_kernel(int64_t m, const do
     for (int s = 0; s < CT::NBACK; ++s) acc[s] = 0.0;
     const int64_t stride = (int64_t)gridDim.x * kFB;
     for (int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x; i < m; i += stride) {
-        const double2 f = uu[i];
-        const double x = inl[3 * i], y = inl[3 * i + 1], al = alpha[i], ak = alpha_k[i];
+        const double4 c4 = xyuv[i];
+        const double x = c4.x, y = c4.y;
         const double rh = rho[i];
+        // beta at the current and at the candidate parameters: read once when k is fixed, recomputed from alpha / alpha_k otherwise
+        double be, dbe = 0.0, bec, dbec = 0.0;
+        if (NP == 6) {
+            be = bec = beta_in[i];
+        } else {
+            const double al = alpha[i], ak = alpha_k[i];
+            be = beta_of(al, ak, p[6]), dbe = dbeta_of(al, ak, p[6]);
+            bec = beta_of(al, ak, pc[6]), dbec = dbeta_of(al, ak, pc[6]);
+        }
         RJ<NP> o;
-        resid_jac<NP>(x, y, f.x, f.y, al, ak, p, rh, o);
+        resid_jac_beta<NP>(x, y, c4.z, c4.w, be, dbe, p, rh, o);
         const double sr = srho[i];
         const double E0 = o.Jr[0] * sr, E1 = o.Jr[1] * sr;
         const double ht = E0 * E0 + E1 * E1;
@@ -491,7 +520,7 @@ __global__ __launch_bounds__(kFB) void refine_backsub_kernel(int64_t m, const do
         const double dx = rh - cd;
         acc[1] += dx * dx;
         RJ<NP> oc;
-        resid_jac<NP>(x, y, f.x, f.y, al, ak, pc, cd, oc);
+        resid_jac_beta<NP>(x, y, c4.z, c4.w, bec, dbec, pc, cd, oc);
         const double c2 = oc.r[0] * oc.r[0] + oc.r[1] * oc.r[1];
         acc[2] += c2;
         // quantities of HandleSuccessfulStep at the candidate (used only if the step is accepted)
@@ -593,8 +622,8 @@ template <int NP>
 static int refine_init_t(Ctx* c, const RefineBuffers& B) {
     const int grid = refine_grid(c, B.m);
     hipLaunchKernelGGL(refine_init_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, reinterpret_cast<const double2*>(B.flow), B.n_flow,
-                       B.m, B.inl, B.alpha, B.alpha_k, B.inlier_idx, B.flow_index_mode, B.state, reinterpret_cast<double2*>(B.uu),
-                       B.rho_a, B.srho, B.partials, B.bad_index);
+                       B.m, B.inl, B.alpha, B.alpha_k, B.inlier_idx, B.flow_index_mode, B.state, reinterpret_cast<double4*>(B.uu),
+                       B.beta, B.rho_a, B.srho, B.partials, B.bad_index);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(refine_init_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, B.state, B.m);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
@@ -604,12 +633,12 @@ static int refine_init_t(Ctx* c, const RefineBuffers& B) {
 template <int NP>
 static int refine_iter_t(Ctx* c, const RefineBuffers& B) {
     const int grid = refine_grid(c, B.m);
-    hipLaunchKernelGGL(refine_schur_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m, B.inl, reinterpret_cast<const double2*>(B.uu),
+    hipLaunchKernelGGL(refine_schur_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m, reinterpret_cast<const double4*>(B.uu), B.beta,
                        B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(refine_solve_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, B.state);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(refine_backsub_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m, B.inl, reinterpret_cast<const double2*>(B.uu),
+    hipLaunchKernelGGL(refine_backsub_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m, reinterpret_cast<const double4*>(B.uu), B.beta,
                        B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(refine_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, B.state);
@@ -636,17 +665,17 @@ static int refine_stage_rows_t(Ctx* c, const RefineBuffers& B, int stage, double
     if (stage == 0) {
         hipLaunchKernelGGL(refine_init_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, reinterpret_cast<const double2*>(B.flow),
                            B.n_flow, B.m, B.inl, B.alpha, B.alpha_k, B.inlier_idx, B.flow_index_mode, B.state,
-                           reinterpret_cast<double2*>(B.uu), B.rho_a, B.srho, B.partials, B.bad_index);
+                           reinterpret_cast<double4*>(B.uu), B.beta, B.rho_a, B.srho, B.partials, B.bad_index);
         RSDSFM_HIP_CHECK(c, hipGetLastError());
         hipLaunchKernelGGL(refine_row_kernel<CT::NINIT>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, CT::INIT_MAX, row);
     } else if (stage == 1) {
-        hipLaunchKernelGGL(refine_schur_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m, B.inl,
-                           reinterpret_cast<const double2*>(B.uu), B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
+        hipLaunchKernelGGL(refine_schur_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m,
+                           reinterpret_cast<const double4*>(B.uu), B.beta, B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
         RSDSFM_HIP_CHECK(c, hipGetLastError());
         hipLaunchKernelGGL(refine_row_kernel<CT::NSCHUR>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, -1, row);
     } else {
-        hipLaunchKernelGGL(refine_backsub_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m, B.inl,
-                           reinterpret_cast<const double2*>(B.uu), B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
+        hipLaunchKernelGGL(refine_backsub_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m,
+                           reinterpret_cast<const double4*>(B.uu), B.beta, B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
         RSDSFM_HIP_CHECK(c, hipGetLastError());
         hipLaunchKernelGGL(refine_row_kernel<CT::NBACK>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, CT::BACK_MAX, row);
     }

@@ -266,7 +266,8 @@ struct RefineBuffers {
     const int64_t* inlier_idx;
     int flow_index_mode;
     RefineState* state;
-    double* uu;     // 2 x m gathered flow
+    double* uu;     // 4 x m packed per-inlier constants (x, y, u_x, u_y): one 32-byte record per inlier, written by the init pass
+    double* beta;   // m: beta_i = 2 (alpha_i + k alpha_k,i) / (2 + k), precomputed when k is not refined (np == 6)
     double* rho_a;  // the two rho buffers (swap on acceptance)
     double* rho_b;
     double* srho;

@@ -178,7 +178,7 @@ int rsdsfm_tile_refine_begin_dev(rsdsfm_ctx* ctx, const double* d_flow, int64_t 
     const int np = const_acceleration ? 7 : 6;
     const size_t M = (size_t)std::max<int64_t>(m, 1);
     const size_t npart = (size_t)refine_partials_doubles(c, m);
-    int rc = ensure_tile(c, Arena::need(sizeof(RefineState)) + Arena::need(16 * M) + 3 * Arena::need(8 * M) + Arena::need(8 * npart) + Arena::need(64) + 1024);
+    int rc = ensure_tile(c, Arena::need(sizeof(RefineState)) + Arena::need(32 * M) + 4 * Arena::need(8 * M) + Arena::need(8 * npart) + Arena::need(64) + 1024);
     if (rc != RSDSFM_OK) return rc;
     rc = ensure_pinned(c, sizeof(RefineState) + 64);
     if (rc != RSDSFM_OK) return rc;
@@ -195,7 +195,8 @@ int rsdsfm_tile_refine_begin_dev(rsdsfm_ctx* ctx, const double* d_flow, int64_t 
     B.inlier_idx = d_inlier_idx;
     B.flow_index_mode = flow_index_mode;
     B.state = ws.take<RefineState>(1);
-    B.uu = ws.take<double>(2 * M);
+    B.uu = ws.take<double>(4 * M);
+    B.beta = ws.take<double>(M);
     B.rho_a = ws.take<double>(M);
     B.rho_b = ws.take<double>(M);
     B.srho = ws.take<double>(M);

@@ -238,12 +238,6 @@ int rsdsfm_ransac_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n,
                       const double* d_alpha_k_n, int64_t n, int use_alpha_k, int32_t iterations, double tolerance,
                       const int32_t* samples_9xT_or_null, uint64_t seed, int depth_mode, int k_sign_mode,
                       rsdsfm_ransac_out* out);
-/* Profiling hook: ONE launch of the dominant kernel of the whole solve alone -- round 0 of the hypothesis-batched speculative
- * LM depth solves of minimal::ransac's trial loop (minimal.cc:230-289; `ransac_lm_kernel<true>`) over `count` (<= 128)
- * hypotheses d_hyp[count][8] (what rsdsfm_minimal9_dev writes).  No decisions are taken and nothing is returned: it exists so
- * that bench.py can bracket exactly this kernel with HIP events for the roofline record. */
-int rsdsfm_ransac_lm_launch_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n, const double* d_alpha_n,
-                                const double* d_alpha_k_n, int64_t n, const double* d_hyp, int32_t count, double tolerance);
 /* nonLinearRefinement on device-resident inputs (d_inlier_idx may be NULL in compat mode).  v/w/k and the
  * summary are HOST.  Polls the device-resident termination flag every few LM iterations. */
 int rsdsfm_refine_dev(rsdsfm_ctx* ctx, const double* d_flow2n, int64_t n_flow, int64_t m, const double* d_inliers_3m,

@@ -374,10 +374,6 @@ class Solver:
         return dict(num_inliers=int(out.num_inliers), best_trial=int(out.best_trial), w=np.array(out.w[:]), v=np.array(out.v[:]), k=float(out.k),
                     inlier_error=float(out.inlier_error), trial_count=tc[:T], trial_steps=ts[:T])
 
-    def ransac_lm_launch_dev(self, d_q, d_u, d_alpha, d_alpha_k, n, d_hyp, count, tolerance):
-        """profiling hook: one launch of ransac_lm_kernel<true> alone (see include/rsdsfm.h)"""
-        self._check(self.lib.rsdsfm_ransac_lm_launch_dev(self._ctx, _dp(d_q), _dp(d_u), _dp(d_alpha), _dp(d_alpha_k), C.c_int64(n), _dp(d_hyp), C.c_int32(count), C.c_double(tolerance)), "rsdsfm_ransac_lm_launch_dev")
-
     def refine_dev(self, d_flow, n_flow, m, d_inl, d_alpha, d_alpha_k, d_idx, v, w, k, const_acceleration, flow_index_mode, d_inl_out):
         vo, wo, ko = (C.c_double * 3)(), (C.c_double * 3)(), C.c_double()
         sm = LmSummary()

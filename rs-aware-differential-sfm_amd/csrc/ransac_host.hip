@@ -255,18 +255,6 @@ int rsdsfm_ransac_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_u, con
     return ransac_device(c, d_q, d_u, d_alpha, d_alpha_k, n, use_alpha_k, iterations, tolerance, samples, seed, depth_mode, k_sign_mode, out);
 }
 
-int rsdsfm_ransac_lm_launch_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_u, const double* d_alpha, const double* d_alpha_k,
-                                int64_t n, const double* d_hyp, int32_t count, double tolerance) {
-    if (!ctx) return RSDSFM_ERR_INVALID;
-    Ctx* c = &ctx->c;
-    DeviceGuard device_guard_(c);
-    if (!d_q || !d_u || !d_alpha || !d_alpha_k || !d_hyp || n < 1 || count < 1 || count > kRansacBatch) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
-    int rc = ensure_ws(c, Arena::need(sizeof(double) * (size_t)ransac_lm_partials_doubles(c, n, count)) + 1024);
-    if (rc != RSDSFM_OK) return rc;
-    return ransac_lm_only_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, d_hyp, count, static_cast<double*>(c->d_ws), tolerance,
-                                 c->ransac_k0);
-}
-
 int rsdsfm_ransac(rsdsfm_ctx* ctx, const double* q, const double* u, const double* alpha, const double* alpha_k, int64_t n,
                   int use_alpha_k, int32_t iterations, double tolerance, const int32_t* samples, uint64_t seed, int depth_mode,
                   int k_sign_mode, rsdsfm_ransac_out* out) {

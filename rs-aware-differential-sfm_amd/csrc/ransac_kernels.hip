@@ -788,14 +788,6 @@ int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const doubl
     return RSDSFM_OK;
 }
 
-// round-0 kernel alone (no decide kernel): the profiling hook behind rsdsfm_ransac_lm_launch_dev
-int ransac_lm_only_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n, const double* hyp,
-                          int T, double* partials, double tol, int k0) {
-    const int grid = ransac_pixel_grid(c, n);
-    const dim3 g2(grid, ransac_lm_groups(c, grid, T));
-    return lm_launch(c, g2, k0 == 2 ? 2 : KMAX, q, u, a, ak, n, hyp, T, nullptr, partials, 0, tol, nullptr);
-}
-
 // scores the hypotheses of the batch [0, T) that are not yet scored; trial_count / trial_err point at the batch's slots
 int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,

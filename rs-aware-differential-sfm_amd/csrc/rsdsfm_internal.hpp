@@ -225,8 +225,6 @@ int ransac_lm_partials_doubles(const Ctx* c, int64_t n, int batch);
 int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                            const double* hyp, int T, LmState* states, double* partials, int* flags, int* scored,
                            double* trial_count, double* trial_err, int round, double tol, int k0);
-int ransac_lm_only_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n, const double* hyp,
-                          int T, double* partials, double tol, int k0);
 int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
                         double* partials, double* trial_count, double* trial_err);

@@ -30,7 +30,6 @@
 #include <mutex>
 #include <new>
 #include <string>
-#include <vector>
 
 #include "rsdsfm_internal.hpp"
 

@@ -1,0 +1,23 @@
+import sys, time
+sys.path.insert(0, '.')
+import numpy as np, torch, rsdsfm
+dev = torch.device("cuda", 0)
+d = rsdsfm.synth.make_config(5, seed=0x5EED0005)
+rows, cols = d["rows"], d["cols"]
+img = torch.from_numpy(d["flow_img"]).to(dev)
+dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+free0 = torch.cuda.mem_get_info()[0]
+res = set()
+with rsdsfm.Solver(0) as s:
+    call = s.prepared_frame_solve(img.data_ptr(), rows, cols, d["K"], d["gamma"], dm.data_ptr(), trials=50, tol=0.05)
+    t0 = time.time()
+    ts = []
+    for i in range(3000):
+        t1 = time.perf_counter()
+        r = call(1 + i % 7)
+        ts.append(time.perf_counter() - t1)
+        res.add((i % 7, r.num_inliers, r.best_trial, tuple(r.v[:]), r.refine_summary.num_iterations))
+    s.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+print("3000 solves in %.2f s; per-seed results distinct: %d (expect 7); median %.4f ms, p99 %.4f ms, max %.4f ms; device memory delta %.1f MB" % (
+    time.time() - t0, len(res), np.median(ts) * 1e3, np.quantile(ts, 0.99) * 1e3, max(ts) * 1e3, (free0 - free1) / 1e6))

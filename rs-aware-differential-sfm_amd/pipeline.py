@@ -21,7 +21,9 @@ class FramePipeline:
         self.ys = torch.empty(n, dtype=torch.int32, device=device)
         self.R, self.t = torch.empty((rows, 9), **f64), torch.empty((rows, 3), **f64)
 
-    def solve(self, flow_img_dev, trials=50, tol=0.05, seed=1, use_alpha_k=False, refine=True, depth_mode=1, samples=None):
+    def solve(self, flow_img_dev, trials=50, tol=0.05, seed=1, use_alpha_k=False, refine=True, depth_mode=1, samples=None,
+              flow_index_mode=0):
+        """flow_index_mode 0 = the reference's rank-indexed flow in the refinement (main.cc:457, quirk Q2), 1 = gathered"""
         s = self.s
         n = s.flatten_dev(flow_img_dev.data_ptr(), self.rows, self.cols, self.K, self.gamma, self.q.data_ptr(), self.u.data_ptr(),
                           self.alpha.data_ptr(), self.alpha_k.data_ptr())
@@ -35,7 +37,7 @@ class FramePipeline:
         ref = None
         if refine:
             ref = s.refine_dev(self.u.data_ptr(), n, m, self.inl.data_ptr(), self.in_alpha.data_ptr(), self.in_alpha_k.data_ptr(),
-                               self.idx.data_ptr(), v, w, k, use_alpha_k, 1, self.inl_ref.data_ptr())
+                               self.idx.data_ptr(), v, w, k, use_alpha_k, flow_index_mode, self.inl_ref.data_ptr())
             v, w, k = ref["v"], ref["w"], ref["k"]
             inl = self.inl_ref
         v, flipped = s.depth_map_dev(inl.data_ptr(), m, v, self.K, self.rows, self.cols, self.depth_map.data_ptr(), None, self.ys.data_ptr())

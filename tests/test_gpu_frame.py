@@ -334,3 +334,31 @@ def test_acceleration_mode_full_size_matches_oracle_chain(oracle, rsdsfm, cfg, T
     dm_o, _, _ = oracle.scatter_depth(inl_o, *K, rows, cols)
     got = dm.cpu().numpy().T
     assert np.array_equal(got != 0, dm_o != 0) and np.allclose(got, dm_o, rtol=1e-5)
+
+
+@pytest.mark.parametrize("flow_mode", [0, 1])
+def test_stage_pipeline_on_device_buffers_equals_one_call_solve(rsdsfm, flow_mode):
+    """pipeline.FramePipeline drives the solve stage by stage through the `_dev` entry points on caller-owned HBM buffers
+    (flatten -> ransac -> refine -> depth map -> pose table); the one-call rsdsfm_solve_frame_dev is the same launch sequence:
+    bit-identical pose, counts, depth map and pose table"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(5, rows=150, cols=260)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        img = torch.from_numpy(d["flow_img"]).to(dev)
+        dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+        R = torch.empty((rows, 9), dtype=torch.float64, device=dev)
+        t = torch.empty((rows, 3), dtype=torch.float64, device=dev)
+        with rsdsfm.Solver(0, stream=stream.cuda_stream) as s:
+            pipe = rsdsfm.pipeline.FramePipeline(s, torch, dev, rows, cols, K, gamma)
+            p = pipe.solve(img, trials=16, tol=0.01, seed=5, flow_index_mode=flow_mode)
+            r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), trials=16, tol=0.01, seed=5,
+                                  flow_index_mode=flow_mode)
+            s.synchronize()
+        assert p["n"] == r["n"] and p["num_inliers"] == r["num_inliers"] and 0 < r["num_inliers"] < r["n"]
+        assert np.array_equal(p["v"], r["v"]) and np.array_equal(p["w"], r["w"]) and p["k"] == r["k"] and p["flipped"] == r["flipped"]
+        assert p["refine"]["summary"] == r["refine_summary"]
+        assert torch.equal(pipe.depth_map, dm) and torch.equal(pipe.R, R) and torch.equal(pipe.t, t)

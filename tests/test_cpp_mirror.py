@@ -21,6 +21,56 @@ def _build(tmp_path):
     return exe
 
 
+def _build_tiled(tmp_path):
+    """tests/cpp/tiled_run.cpp: a C++ host of the column-tiled whole solve against the C ABI + the HIP runtime only"""
+    exe = os.path.join(str(tmp_path), "tiled_run")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", exe,
+           os.path.join(ROOT, "tests", "cpp", "tiled_run.cpp"), "-L", PKG, "-lrsdsfm_hip", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_tiled_host_compiles_and_links(tmp_path, rsdsfm):
+    rsdsfm.load_library()
+    exe = _build_tiled(tmp_path)
+    assert subprocess.run([exe], capture_output=True).returncode == 2  # usage, no GPU work
+
+
+@pytest.mark.gpu
+def test_tiled_host_in_cpp_over_rccl_matches_python_solve(tmp_path, rsdsfm):
+    """the C++ host process (no Python, no torch: RCCL comes from /opt/rocm through the library's dlopen) runs the column-tiled solve
+    as rank 0 of 1 over a 1-rank RCCL communicator; its pose, counts, depth map and pose table equal the one-call solve's"""
+    import torch
+
+    exe = _build_tiled(tmp_path)
+    d = rsdsfm.synth.make_config(3, rows=120, cols=200)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    raw = os.path.join(str(tmp_path), "flow.bin")
+    d["flow_img"].astype(np.float64).tofile(raw)
+    T, tol, seed = 12, 0.002, 9
+    out = subprocess.run([exe, raw, str(rows), str(cols)] + ["%.17g" % x for x in K] + ["%.17g" % gamma, str(T), "%.17g" % tol, str(seed)],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    dev = torch.device("cuda", 0)
+    img = torch.from_numpy(d["flow_img"]).to(dev)
+    dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+    R = torch.empty((rows, 9), dtype=torch.float64, device=dev)
+    t = torch.empty((rows, 3), dtype=torch.float64, device=dev)
+    with rsdsfm.Solver(0) as s:
+        one = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), trials=T, tol=tol, seed=seed,
+                                flow_index_mode=rsdsfm.FLOW_GATHERED)
+        s.synchronize()
+    assert r["world"] == 1 and r["n"] == one["n"] and r["num_inliers"] == one["num_inliers"] and r["best_trial"] == one["best_trial"]
+    assert np.array_equal(r["v"], one["v"]) and np.array_equal(r["w"], one["w"]) and r["k"] == one["k"]
+    assert r["iterations"] == one["refine_summary"]["num_iterations"] and r["flipped"] == int(one["flipped"])
+    dmh = dm.cpu().numpy()
+    assert r["depth_nonzero"] == int((dmh != 0).sum()) and np.isclose(r["depth_sum"], dmh.sum(), rtol=1e-12)
+    assert np.array_equal(r["last_t"], t.cpu().numpy()[-1])
+    assert r["host_syncs"] <= 5 and r["collectives"] >= 8
+
+
 def test_mirror_compiles_and_links(tmp_path, rsdsfm):
     rsdsfm.load_library()
     exe = _build(tmp_path)

@@ -142,7 +142,7 @@ def main():
     ap.add_argument("--workload", default="full", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify", "true_flow", "metrics"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-records", action="store_true", help="full workload: skip depth_only / full_solve_batched / full_solve_fused (profiling runs)")
-    ap.add_argument("--tiled-driver", default="native", choices=["native", "python"], help="tiled_full: the C++ driver inside the library (default) or the Python driver")
+    ap.add_argument("--tiled-driver", default="native", choices=["native", "python"], help="tiled / tiled_full: the C++ driver inside the library (default) or the Python driver")
     ap.add_argument("--arith", default="reference", choices=["reference", "fused"], help="library: reference arithmetic (default) or the opt-in fused-fma build")
     ap.add_argument("--nbuf", type=int, default=7, help="rotating HBM buffer sets (7 x 59 MB > 256 MiB L3)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU feeding independent batches (sequence-throughput mode, BASELINE configs[4])")
@@ -609,21 +609,7 @@ def main():
         native = args.tiled_driver == "native"
         transport = "python driver + torch.distributed"
         if native:
-            backend = dist.get_backend() if world > 1 else "nccl"
-            if backend == "nccl":  # RCCL inside the library: rank 0's unique id travels through torch.distributed (1 rank: a 1-rank communicator)
-                ident = torch.zeros(rsdsfm.DIST_ID_BYTES, dtype=torch.uint8, device=dev)
-                if rank == 0:
-                    ident = torch.frombuffer(bytearray(rsdsfm.dist_unique_id()), dtype=torch.uint8).to(dev)
-                if world > 1:
-                    dist.broadcast(ident, 0)
-                solver.dist_init(world, rank, bytes(ident.cpu().numpy().tobytes()))
-                transport = "RCCL (ncclAllGather / ncclAllReduce on the context's stream), %d-rank communicator" % world
-            else:  # smoke tests only (several ranks sharing one GPU over gloo)
-                sys.path.insert(0, os.path.join(ROOT, "tests"))
-                from transports import GlooTransport
-
-                solver.dist_set_transport(world, rank, *GlooTransport(dist, torch).callbacks())
-                transport = "caller-provided collectives over torch.distributed/%s (smoke test)" % backend
+            transport = _dist_setup(solver, rsdsfm, torch, dist, world, rank, dev)
 
             def step(i):
                 res["r"] = solver.solve_frame_tiled_dev(slab.data_ptr(), rows, cols, data["K"], data["gamma"], depth_map.data_ptr(),
@@ -652,29 +638,47 @@ def main():
 
     # =================================================================================================
     else:  # tiled
+        # BASELINE configs[3] as literally stated: the dense DEPTH solve of a 3840x2160 frame, the flattened point list sharded over the
+        # ranks, ONE C-ABI call per rank and step (rsdsfm_estimate_inverse_depths_tiled_dev: LM launches, the all-gather of the per-rank
+        # sum rows, the decision and the all-gather of the depth shards, all on the context's stream; one host synchronisation).
+        # --tiled-driver python = the round-1 Python driver over the stage entry points (dist.TiledDepthSolve), for comparison.
         data = rsdsfm.synth.make_config(4, seed=0x5EED0004)  # every rank generates the same 3840x2160 frame
         n = len(data["q"])
         t = data["truth"]
         v, w, k = t["v"] / np.linalg.norm(t["v"]), t["w"], 0.0
-        bounds, per = rsdsfm.dist.shard_bounds(n, world)
-        i0, i1 = bounds[rank]
-        tt_ = lambda a: torch.from_numpy(np.ascontiguousarray(a[i0:i1])).to(dev)
-        stage = rsdsfm.dist.HipDepthStage(solver, tt_(data["q"]), tt_(data["u"]), tt_(data["alpha"]), tt_(data["alpha_k"]), v, w, k, torch)
-        drv = rsdsfm.dist.TiledDepthSolve([stage], n, per, torch, dist if world > 1 else None)
+        i0, cnt, per = rsdsfm.tiled_shard_bounds(n, world, rank)
+        tt_ = lambda a: torch.from_numpy(np.ascontiguousarray(a[i0:i0 + cnt])).to(dev)
+        q_s, u_s, a_s, ak_s = tt_(data["q"]), tt_(data["u"]), tt_(data["alpha"]), tt_(data["alpha_k"])
         res = {}
+        native = args.tiled_driver == "native"
+        transport = "python driver + torch.distributed"
+        if native:
+            transport = _dist_setup(solver, rsdsfm, torch, dist, world, rank, dev)
+            full = torch.empty(max(n, 2), dtype=torch.float64, device=dev)
 
-        def step(i):
-            res["rho"], res["sm"] = drv.solve(rsdsfm.DEPTH_CERES_LM)
+            def step(i):
+                res["sm"], res["info"] = solver.estimate_inverse_depths_tiled_dev(q_s.data_ptr(), u_s.data_ptr(), n, v, w, k, a_s.data_ptr(), ak_s.data_ptr(),
+                                                                                  full.data_ptr(), mode=rsdsfm.DEPTH_CERES_LM)
+                res["rho"] = full[:n]
+        else:
+            stage = rsdsfm.dist.HipDepthStage(solver, q_s, u_s, a_s, ak_s, v, w, k, torch)
+            drv = rsdsfm.dist.TiledDepthSolve([stage], n, per, torch, dist if world > 1 else None)
+
+            def step(i):
+                res["rho"], res["sm"] = drv.solve(rsdsfm.DEPTH_CERES_LM)
 
         el = timed(step, args.steps, args.warmup)
         if rank == 0:
             line.update({"value": data["rows"] * data["cols"] * args.steps / el / 1e6, "ms_per_step": el / args.steps * 1e3, "scaling": "strong",
                          "metric": "Mpixels/sec RS depth solve, 3840x2160 frame row-tiled over the ranks",
-                         "config": {"workload": "BASELINE configs[3]-style: synthetic 3840x2160 frame row-tiled over %d rank(s), dense depth "
+                         "config": {"workload": "BASELINE configs[3]: synthetic 3840x2160 frame, point list sharded over %d rank(s), dense depth "
                                                 "solve (Ceres-LM emulation), all-gather of the LM sum rows + ONE all-gather of the depth map" % world,
-                                    "rows": data["rows"], "cols": data["cols"], "pixels": n, "lm_summary": res["sm"],
-                                    "gathered": int(res["rho"].shape[0])},
+                                    "driver": "native C++ (rsdsfm_estimate_inverse_depths_tiled_dev)" if native else "python (dist.TiledDepthSolve)",
+                                    "transport": transport, "rows": data["rows"], "cols": data["cols"], "pixels": n, "lm_summary": res["sm"],
+                                    "info": res.get("info"), "gathered": int(res["rho"].shape[0])},
                          "roofline": None, "cpu_baseline": None})
+        if native:
+            solver.dist_finalize()
 
     if rank == 0:
         try:  # RCCL prints its version banner through C stdio, which is block-buffered on a pipe: push it out BEFORE the JSON line
@@ -687,6 +691,25 @@ def main():
     solver.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def _dist_setup(solver, rsdsfm, torch, dist, world, rank, dev):
+    """give the context its communicator for the native tiled solves; returns a description of the transport"""
+    backend = dist.get_backend() if world > 1 else "nccl"
+    if backend == "nccl":  # RCCL inside the library: rank 0's unique id travels through torch.distributed (1 rank: a 1-rank communicator)
+        ident = torch.zeros(rsdsfm.DIST_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            ident = torch.frombuffer(bytearray(rsdsfm.dist_unique_id()), dtype=torch.uint8).to(dev)
+        if world > 1:
+            dist.broadcast(ident, 0)
+        solver.dist_init(world, rank, bytes(ident.cpu().numpy().tobytes()))
+        return "RCCL (ncclAllGather / ncclAllReduce on the context's stream), %d-rank communicator" % world
+    # smoke tests only (several ranks sharing one GPU over gloo)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from transports import GlooTransport
+
+    solver.dist_set_transport(world, rank, *GlooTransport(dist, torch).callbacks())
+    return "caller-provided collectives over torch.distributed/%s (smoke test)" % backend
 
 
 def cpu_baseline_rectify(img, depth, R, t, K, inl, budget_s=8.0):

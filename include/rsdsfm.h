@@ -402,6 +402,22 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
                                  double* d_depth_map_colmajor, double* d_R_rows9_or_null, double* d_t_rows3_or_null,
                                  rsdsfm_frame_result* result, rsdsfm_tiled_info* info_or_null);
 
+/* The row-tiled DENSE DEPTH solve (BASELINE configs[3]: "row-tiled ... with an all-gather of the depth map"): minimal::
+ * estimateInverseDepths (minimal.cc:170-306) of one frame whose flattened point list is sharded over the ranks by contiguous index
+ * ranges.  rsdsfm_tiled_shard_bounds: rank r owns points [i0, i0 + count) with i0 = min(n, r * stride), stride = ceil(n / nranks)
+ * rounded up to even (16-byte aligned shard starts).  Host only. */
+int rsdsfm_tiled_shard_bounds(int64_t n, int32_t nranks, int32_t rank, int64_t* i0, int64_t* count, int64_t* stride);
+/* d_*_shard: this rank's slice of the point arrays (DEVICE; q, u: [count][2], alpha, alpha_k: [count]); d_inv_depth: n_total doubles
+ * (DEVICE), the FULL inverse-depth vector on every rank.  Ceres-LM mode all-gathers one row of LM sums per rank per launch (rank
+ * order: every rank adds the same numbers in the same order, results are bit-identical to the single-context solve's decisions)
+ * and synchronises with the host once in the common case; both modes end with ONE all-gather of the shards.  summary (may be
+ * NULL) as rsdsfm_estimate_inverse_depths; info (may be NULL): shard_points, host_syncs, collectives, ransac_rounds = LM kernel
+ * launches of this rank.  Without a communicator the context is a single rank. */
+int rsdsfm_estimate_inverse_depths_tiled_dev(rsdsfm_ctx* ctx, const double* d_q_shard, const double* d_u_shard, int64_t n_total,
+                                             const double v[3], const double w[3], double k, const double* d_alpha_shard,
+                                             const double* d_alpha_k_shard, int depth_mode, double* d_inv_depth,
+                                             rsdsfm_lm_summary* summary_or_null, rsdsfm_tiled_info* info_or_null);
+
 /* ---- consumers of the solve's output ----------------------------------------------------------
  * Images are 8-bit BGR, row-major rows x cols x 3 (cv::Mat CV_8UC3 as the reference holds them); the depth map is the
  * column-major rows x cols array of rsdsfm_depth_map; R / t the per-scanline table of rsdsfm_pose_table. */

@@ -95,6 +95,15 @@ def tiled_slab_bounds(cols, nranks, rank):
     return c0.value, sc.value, per.value
 
 
+def tiled_shard_bounds(n, nranks, rank):
+    """(i0, count, stride) of `rank`'s contiguous shard of an n-point list (rsdsfm_tiled_shard_bounds)"""
+    i0, cnt, per = C.c_int64(), C.c_int64(), C.c_int64()
+    rc = load_library().rsdsfm_tiled_shard_bounds(C.c_int64(n), C.c_int32(nranks), C.c_int32(rank), C.byref(i0), C.byref(cnt), C.byref(per))
+    if rc != OK:
+        raise RsdsfmError("rsdsfm_tiled_shard_bounds failed (%d)" % rc)
+    return i0.value, cnt.value, per.value
+
+
 class RansacOut(C.Structure):
     _fields_ = [
         ("num_inliers", C.c_int64),
@@ -440,6 +449,19 @@ class Solver:
                     w=np.array(res.w[:]), v=np.array(res.v[:]), k=float(res.k), refine_summary=res.refine_summary.as_dict(),
                     d_inliers=res.d_inliers, d_inlier_idx=res.d_inlier_idx, d_scanline=res.d_scanline,
                     info={k2: int(getattr(info, k2)) for k2, _ in TiledInfo._fields_ if k2 != "_pad"})
+
+    def estimate_inverse_depths_tiled_dev(self, d_q_shard, d_u_shard, n_total, v, w, k, d_alpha_shard, d_alpha_k_shard, d_inv_depth,
+                                          mode=DEPTH_CERES_LM):
+        """this rank's part of the row-tiled dense depth solve (rsdsfm_estimate_inverse_depths_tiled_dev): the shard pointers are
+        this rank's tiled_shard_bounds slice; d_inv_depth receives all n_total inverse depths.  Returns (lm summary dict or None, info)"""
+        sm, info = LmSummary(), TiledInfo()
+        opt = lambda p_: _dp(p_) if p_ else None
+        self._check(self.lib.rsdsfm_estimate_inverse_depths_tiled_dev(self._ctx, opt(d_q_shard), opt(d_u_shard), C.c_int64(n_total), _v3(v), _v3(w),
+                                                                      C.c_double(k), opt(d_alpha_shard), opt(d_alpha_k_shard), C.c_int(int(mode)),
+                                                                      opt(d_inv_depth), C.byref(sm), C.byref(info)),
+                    "rsdsfm_estimate_inverse_depths_tiled_dev")
+        return (sm.as_dict() if int(mode) == DEPTH_CERES_LM else None,
+                {k2: int(getattr(info, k2)) for k2, _ in TiledInfo._fields_ if k2 != "_pad"})
 
     def prepared_frame_solve(self, d_flow_img, rows, cols, K, gamma, d_depth_map, d_R=None, d_t=None, trials=50, tol=0.05,
                              use_acceleration_mode=False, use_refinement=True, depth_mode=DEPTH_CERES_LM, k_sign_mode=K_COMPAT,

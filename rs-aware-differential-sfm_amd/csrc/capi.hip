@@ -51,7 +51,7 @@ int ensure_pinned(Ctx* c, size_t bytes) {
 
 using StageAlloc = Arena;
 
-static void fill_summary(const LmState& st, rsdsfm_lm_summary* s) {
+void fill_lm_summary(const LmState& st, rsdsfm_lm_summary* s) {
     if (!s) return;
     s->num_iterations = st.iteration;
     s->num_successful_steps = st.num_successful;
@@ -334,7 +334,7 @@ int rsdsfm_depth_lm_state(rsdsfm_ctx* ctx, int32_t* status, int32_t* next_launch
     if (rc != RSDSFM_OK) return rc;
     if (status) *status = c->h_lm->status;
     if (next_launch) *next_launch = c->h_lm->next_launch;
-    fill_summary(*c->h_lm, summary);
+    fill_lm_summary(*c->h_lm, summary);
     return RSDSFM_OK;
 }
 
@@ -378,7 +378,7 @@ int rsdsfm_depth_finish_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_
         if (rc != RSDSFM_OK) return rc;
     }
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    fill_summary(*c->h_lm, summary);
+    fill_lm_summary(*c->h_lm, summary);
     if (extra_launches) *extra_launches = extra;
     if (c->h_lm->termination == RSDSFM_TERM_FAILURE) return fail(c, RSDSFM_ERR_NUMERIC, "LM failure (5 consecutive invalid steps)");
     return RSDSFM_OK;

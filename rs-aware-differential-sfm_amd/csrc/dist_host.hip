@@ -651,4 +651,138 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
     return RSDSFM_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// the row-tiled DENSE DEPTH solve (BASELINE configs[3] as literally stated: "row-tiled ... with an all-gather of the depth map"):
+// minimal::estimateInverseDepths (minimal.cc:170-306) of ONE frame whose flattened point list is sharded over the ranks by
+// contiguous index ranges (a row tile of the image is a contiguous range of the column-major point list of a transposed scan; any
+// contiguous range works because the per-pixel solves are independent given the pose).  Ceres-LM mode: per LM launch every rank
+// reduces its shard to one row of NS sums, the rows are all-gathered in rank order and every rank takes the same accept / converge
+// decision; closed-form mode: no exchange at all.  Then ONE all-gather of the inverse-depth shards.  The common case (accept the
+// first step, converge) costs launch 0 -> row -> all-gather -> decide -> launch 1 -> all-gather -> ONE host synchronisation.
+// ---------------------------------------------------------------------------------------------------
+int rsdsfm_tiled_shard_bounds(int64_t n, int32_t nranks, int32_t rank, int64_t* i0, int64_t* count, int64_t* stride) {
+    if (n < 0 || nranks < 1 || rank < 0 || rank >= nranks) return RSDSFM_ERR_INVALID;
+    int64_t per = (n + nranks - 1) / nranks;
+    per += per & 1;  // even shard starts keep the 8-byte-per-point arrays 16-byte aligned
+    const int64_t b0 = std::min<int64_t>(n, (int64_t)rank * per), b1 = std::min<int64_t>(n, ((int64_t)rank + 1) * per);
+    if (i0) *i0 = b0;
+    if (count) *count = b1 - b0;
+    if (stride) *stride = per;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_estimate_inverse_depths_tiled_dev(rsdsfm_ctx* ctx, const double* d_q_shard, const double* d_u_shard, int64_t n_total,
+                                             const double v[3], const double w[3], double k, const double* d_alpha_shard,
+                                             const double* d_alpha_k_shard, int depth_mode, double* d_inv_depth,
+                                             rsdsfm_lm_summary* summary, rsdsfm_tiled_info* info) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
+    if (n_total < 0 || !v || !w) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    if (depth_mode != RSDSFM_DEPTH_CLOSED_FORM && depth_mode != RSDSFM_DEPTH_CERES_LM) return fail(c, RSDSFM_ERR_INVALID, "unknown depth_mode");
+    Dist* D = dist_of(c, true);
+    if (!D) return fail(c, RSDSFM_ERR_INVALID, "out of host memory");
+    D->host_syncs = D->collectives = D->ransac_rounds = 0;
+    const int R = D->nranks, rank = D->rank;
+    int64_t i0 = 0, ns = 0, per = 0;
+    rsdsfm_tiled_shard_bounds(n_total, R, rank, &i0, &ns, &per);
+    if (ns > 0 && (!d_q_shard || !d_u_shard || !d_alpha_shard || !d_alpha_k_shard)) return fail(c, RSDSFM_ERR_INVALID, "null shard pointer");
+    if (n_total > 0 && !d_inv_depth) return fail(c, RSDSFM_ERR_INVALID, "null output pointer");
+    if (summary) memset(summary, 0, sizeof(*summary));
+    Pose pose;
+    memcpy(pose.v, v, sizeof(pose.v));
+    memcpy(pose.w, w, sizeof(pose.w));
+    pose.k = k;
+    const size_t cap = (size_t)std::max<int64_t>(per, 2);
+    const bool padded = (size_t)R * cap != (size_t)n_total;
+    int rc = ensure_dev(c, &D->d_buf, &D->bytes, Arena::need(8 * (size_t)NS) + Arena::need(8 * (size_t)NS * R) + (padded ? Arena::need(8 * cap * R) : 0) + 4096);
+    if (rc != RSDSFM_OK) return rc;
+    Arena da(D->d_buf);
+    double* d_row = da.take<double>(NS);
+    double* d_rows_all = da.take<double>((size_t)NS * R);
+    double* d_gather = padded ? da.take<double>(cap * R) : d_inv_depth;
+    double* d_rho = d_gather + (size_t)rank * cap;  // the shard is solved in place in the all-gather buffer
+    // an empty shard still takes part in every collective; its kernels run over zero points of a valid (unused) address
+    const double* q = ns > 0 ? d_q_shard : d_rho;
+    const double* u = ns > 0 ? d_u_shard : d_rho;
+    const double* a = ns > 0 ? d_alpha_shard : d_rho;
+    const double* ak = ns > 0 ? d_alpha_k_shard : d_rho;
+
+    int launches = 0;
+    if (depth_mode == RSDSFM_DEPTH_CLOSED_FORM) {
+        if (ns > 0) {
+            rc = depth_closed_form_launch(c, q, u, a, ak, ns, pose, d_rho);
+            if (rc != RSDSFM_OK) return rc;
+        }
+    } else {
+        // decide launch `id` from the all-gathered rows (rank order => the same sums, bit for bit, on every rank)
+        auto decide = [&](int id) -> int {
+            int r2 = depth_lm_reduce_launch(c, ns, d_row);
+            if (r2 != RSDSFM_OK) return r2;
+            r2 = all_gather(c, D, d_row, d_rows_all, sizeof(double) * NS);
+            if (r2 != RSDSFM_OK) return r2;
+            return depth_lm_decide_rows_launch(c, d_rows_all, R, n_total, id);
+        };
+        auto read_state = [&]() -> int {
+            RSDSFM_HIP_CHECK(c, hipMemcpyAsync(c->h_lm, c->d_lm, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
+            return sync(c, D);
+        };
+        // fast path, no host round trip: speculate (launch 0) -> decide -> launch 1 (applies / continues / nothing to do)
+        rc = depth_lm_launch(c, q, u, a, ak, ns, pose, d_rho, 0);
+        if (rc != RSDSFM_OK) return rc;
+        rc = decide(0);
+        if (rc != RSDSFM_OK) return rc;
+        rc = depth_lm_launch(c, q, u, a, ak, ns, pose, d_rho, 1);
+        if (rc != RSDSFM_OK) return rc;
+        int issued = 2;
+        launches = 2;
+        rc = read_state();
+        if (rc != RSDSFM_OK) return rc;
+        for (;;) {
+            const LmState& st = *c->h_lm;
+            if (st.status == 1) break;
+            if (launches > 4 * kMaxIter + 8) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machine did not terminate");
+            if (st.status == 2) {  // result known; the designated launch writes it (whether a rank needs it depends on its own iterate predictor)
+                if (st.next_launch >= issued) {
+                    rc = depth_lm_launch(c, q, u, a, ak, ns, pose, d_rho, st.next_launch);
+                    if (rc != RSDSFM_OK) return rc;
+                    ++launches;
+                }
+                break;
+            }
+            const int id = st.next_launch;  // status 0 on every rank alike (it depends on the sums only)
+            if (id >= issued) {
+                rc = depth_lm_launch(c, q, u, a, ak, ns, pose, d_rho, id);
+                if (rc != RSDSFM_OK) return rc;
+                issued = id + 1;
+                ++launches;
+            }
+            rc = decide(id);
+            if (rc != RSDSFM_OK) return rc;
+            rc = read_state();
+            if (rc != RSDSFM_OK) return rc;
+        }
+        c->lm_issued_k = c->lm_issued_d = 0;  // nothing for rsdsfm_depth_finish_dev to continue
+        fill_lm_summary(*c->h_lm, summary);
+    }
+    // ---- ONE all-gather of the inverse-depth shards (the data-path collective: 8 B x points) ----
+    if ((size_t)ns < cap) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_rho + ns, 0, sizeof(double) * (cap - (size_t)ns), c->stream));
+    rc = all_gather(c, D, d_rho, d_gather, sizeof(double) * cap);
+    if (rc != RSDSFM_OK) return rc;
+    if (padded && n_total > 0)
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_inv_depth, d_gather, sizeof(double) * (size_t)n_total, hipMemcpyDeviceToDevice, c->stream));
+    if (info) {
+        memset(info, 0, sizeof(*info));
+        info->nranks = R;
+        info->rank = rank;
+        info->shard_points = ns;
+        info->host_syncs = D->host_syncs;
+        info->collectives = D->collectives;
+        info->ransac_rounds = launches;  // depth solve: LM kernel launches of this rank
+    }
+    if (depth_mode == RSDSFM_DEPTH_CERES_LM && c->h_lm->termination == RSDSFM_TERM_FAILURE)
+        return fail(c, RSDSFM_ERR_NUMERIC, "LM failure (5 consecutive invalid steps)");
+    return RSDSFM_OK;
+}
+
 }  // extern "C"

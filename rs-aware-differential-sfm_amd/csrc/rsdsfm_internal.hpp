@@ -186,6 +186,7 @@ int depth_lm_batch_launch(Ctx* const* cs, int count, const double* const* q, con
 int depth_lm_fused_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                           const Pose& pose, double* rho);
 int depth_lm_reduce_launch(Ctx* c, int64_t n, double* d_row);
+void fill_lm_summary(const LmState& st, rsdsfm_lm_summary* s);  // capi.hip
 int depth_lm_decide_rows_launch(Ctx* c, const double* d_rows, int nrows, int64_t n_total, int launch_id);
 
 }  // namespace rsdsfm

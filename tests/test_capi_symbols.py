@@ -51,6 +51,22 @@ def test_tiled_slab_bounds_is_host_only(rsdsfm):
         rsdsfm.tiled_slab_bounds(10, 2, 2)
 
 
+def test_tiled_shard_bounds_is_host_only(rsdsfm):
+    """shards of the row-tiled depth solve: contiguous, covering, even starts (16-byte aligned 8-byte arrays); the Python driver's
+    dist.shard_bounds is the same rule"""
+    for n, nr in ((8294400, 8), (30150, 4), (7, 5), (7, 2), (0, 3), (1, 1), (9, 9)):
+        bounds, per = rsdsfm.dist.shard_bounds(n, nr)
+        prev = 0
+        for r in range(nr):
+            i0, cnt, stride = rsdsfm.tiled_shard_bounds(n, nr, r)
+            assert (i0, i0 + cnt) == bounds[r] and stride == per and stride % 2 == 0 and i0 % 2 == 0 or i0 == n
+            assert i0 == prev
+            prev = i0 + cnt
+        assert prev == n
+    with pytest.raises(rsdsfm.RsdsfmError):
+        rsdsfm.tiled_shard_bounds(10, 0, 0)
+
+
 def test_create_fails_loudly_without_gpu(rsdsfm):
     """No CPU fallback: on a box without a HIP device the context cannot be created."""
     if os.path.exists("/dev/kfd"):

@@ -210,3 +210,145 @@ def test_native_tiled_two_processes_share_the_gpu(rsdsfm, tmp_path):
     assert got["n"] == one["n"] and got["num_inliers"] == one["num_inliers"] and got["best_trial"] == one["best_trial"]
     assert np.allclose(got["v"], one["v"], rtol=1e-9) and np.allclose(got["w"], one["w"], rtol=1e-9)
     assert got["depth_nonzero"] == int((one["depth_map"] != 0).sum()) and np.isclose(got["depth_sum"], one["depth_map"].sum(), rtol=1e-9)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the row-tiled DENSE DEPTH solve driven from C++ (rsdsfm_estimate_inverse_depths_tiled_dev)
+# ---------------------------------------------------------------------------------------------------
+def _depth_single(rsdsfm, torch, d, v, w, k, mode):
+    dev = torch.device("cuda", 0)
+    n = len(d["alpha"])
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    q, u, a, ak = tt(d["q"]), tt(d["u"]), tt(d["alpha"]), tt(d["alpha_k"])
+    rho = torch.zeros(max(n, 2), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    with rsdsfm.Solver(0) as s:
+        s.estimate_inverse_depths_dev(q.data_ptr(), u.data_ptr(), n, v, w, k, a.data_ptr(), ak.data_ptr(), rho.data_ptr(), mode=mode)
+        sm = s.depth_finish_dev(q.data_ptr(), u.data_ptr(), n, v, w, k, a.data_ptr(), ak.data_ptr(), rho.data_ptr())[0] if mode == 1 else None
+        s.synchronize()
+    return rho.cpu().numpy()[:n], sm
+
+
+def _depth_threads(rsdsfm, torch, d, v, w, k, nranks, mode, repeat=1):
+    from transports import ThreadTransport
+
+    dev = torch.device("cuda", 0)
+    n = len(d["alpha"])
+    tr = ThreadTransport(nranks)
+    outs, errs = [None] * nranks, [None] * nranks
+
+    def work(rank):
+        try:
+            torch.cuda.set_device(0)
+            i0, cnt, per = rsdsfm.tiled_shard_bounds(n, nranks, rank)
+            tt = lambda a: torch.from_numpy(np.ascontiguousarray(a[i0:i0 + cnt])).to(dev)
+            q, u, a, ak = tt(d["q"]), tt(d["u"]), tt(d["alpha"]), tt(d["alpha_k"])
+            full = torch.full((max(n, 2),), -7.0, dtype=torch.float64, device=dev)
+            torch.cuda.synchronize()
+            with rsdsfm.Solver(0) as s:
+                s.dist_set_transport(nranks, rank, *tr.callbacks(rank))
+                for _ in range(repeat):
+                    sm, info = s.estimate_inverse_depths_tiled_dev(q.data_ptr() if cnt else 0, u.data_ptr() if cnt else 0, n, v, w, k,
+                                                                   a.data_ptr() if cnt else 0, ak.data_ptr() if cnt else 0, full.data_ptr(), mode=mode)
+                s.synchronize()
+            outs[rank] = (full.cpu().numpy()[:n], sm, info)
+        except Exception as e:  # noqa: BLE001
+            errs[rank] = e
+            tr.barrier.abort()
+
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    for e in errs:
+        if e is not None:
+            raise e
+    for rho, sm, info in outs[1:]:  # every rank holds the same full vector and took the same decisions
+        assert np.array_equal(rho, outs[0][0]) and sm == outs[0][1]
+    assert sum(o[2]["shard_points"] for o in outs) == n
+    return outs[0][0], outs[0][1], [o[2] for o in outs]
+
+
+@pytest.mark.parametrize("cfg", [1, 3])
+def test_native_tiled_depth_matches_single_context_and_oracle(oracle, rsdsfm, cfg):
+    """1 / 2 / 5 logical ranks give the single-context solve's depths bit for bit (per-pixel solves; the global decisions come from
+    rank-ordered sums) and the oracle's to 1e-9; the common case costs ONE host synchronisation"""
+    import torch
+
+    d = rsdsfm.synth.make_config(cfg, rows=150, cols=201)  # 30150 points: 5 ranks -> stride 6030, exact; 4 ranks -> padded
+    t = d["truth"]
+    v = t["v"] / np.linalg.norm(t["v"])
+    w, k = t["w"], 0.0
+    for mode in (0, 1):
+        one, sm1 = _depth_single(rsdsfm, torch, d, v, w, k, mode)
+        rho_o, sm_o = oracle.estimate_inverse_depths(d["q"], d["u"], v, w, k, d["alpha"], d["alpha_k"], mode=mode)
+        assert np.allclose(one, rho_o, rtol=1e-9, atol=1e-13)
+        for nranks in (1, 2, 4, 5):
+            rho, sm, infos = _depth_threads(rsdsfm, torch, d, v, w, k, nranks, mode, repeat=2)
+            assert np.array_equal(rho, one), (mode, nranks)
+            assert all(i["nranks"] == nranks for i in infos)
+            if mode == 1:
+                for key in ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination"):
+                    assert sm[key] == sm1[key] == sm_o[key], key
+                assert np.isclose(sm["final_cost"], sm_o["final_cost"], rtol=1e-9)
+                if sm["num_iterations"] <= 2:
+                    assert all(i["host_syncs"] == 1 for i in infos)
+                assert all(i["collectives"] == i["host_syncs"] + 1 for i in infos)  # one row all-gather per decision + the shards
+            else:
+                assert all(i["host_syncs"] == 0 and i["collectives"] == 1 for i in infos)
+
+
+def test_native_tiled_depth_many_iterations_and_empty_shards(oracle, rsdsfm):
+    """a pose far from the truth makes the emulated trust-region loop run several iterations (rejected steps included): the
+    state machine continues across host polls on every rank alike; 7 points over 5 ranks leave the last rank empty"""
+    import torch
+
+    d = rsdsfm.synth.make_config(3, rows=90, cols=120)
+    t = d["truth"]
+    v = np.array([0.3, -0.2, 0.93])
+    v /= np.linalg.norm(v)
+    w, k = 3.0 * t["w"] + 0.01, 0.4
+    one, sm1 = _depth_single(rsdsfm, torch, d, v, w, k, 1)
+    rho_o, sm_o = oracle.estimate_inverse_depths(d["q"], d["u"], v, w, k, d["alpha"], d["alpha_k"], mode=1)
+    rho, sm, infos = _depth_threads(rsdsfm, torch, d, v, w, k, 3, 1)
+    assert np.array_equal(rho, one)
+    for key in ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination"):
+        assert sm[key] == sm1[key] == sm_o[key], key
+    assert np.allclose(rho, rho_o, rtol=1e-8, atol=1e-12)
+    small = {key: d[key][:7] for key in ("q", "u", "alpha", "alpha_k")}
+    one, sm1 = _depth_single(rsdsfm, torch, small, v, w, k, 1)
+    for nranks in (2, 5):  # stride 4 / 2: ranks (0,2) (2,4) (4,6) (6,7) () -- the fifth shard is empty
+        rho, sm, infos = _depth_threads(rsdsfm, torch, small, v, w, k, nranks, 1)
+        assert np.array_equal(rho, one) and sm["num_iterations"] == sm1["num_iterations"]
+    assert infos[-1]["shard_points"] == 0
+    empty = {key: d[key][:0] for key in ("q", "u", "alpha", "alpha_k")}
+    rho, sm, infos = _depth_threads(rsdsfm, torch, empty, v, w, k, 2, 0)
+    assert rho.shape == (0,)
+
+
+def test_native_tiled_depth_over_rccl_one_rank(rsdsfm):
+    """the RCCL path (1-rank communicator) of the depth solve: same bits as the single-context solve"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(3, rows=120, cols=200)
+    t = d["truth"]
+    v = t["v"] / np.linalg.norm(t["v"])
+    w, k, n = t["w"], 0.0, len(d["alpha"])
+    one, sm1 = _depth_single(rsdsfm, torch, d, v, w, k, 1)
+    tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    q, u, a, ak = tt(d["q"]), tt(d["u"]), tt(d["alpha"]), tt(d["alpha_k"])
+    full = torch.zeros(n, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    with rsdsfm.Solver(0) as s:
+        s.dist_init(1, 0, rsdsfm.dist_unique_id())
+        for _ in range(2):
+            sm, info = s.estimate_inverse_depths_tiled_dev(q.data_ptr(), u.data_ptr(), n, v, w, k, a.data_ptr(), ak.data_ptr(), full.data_ptr())
+        s.synchronize()
+        s.dist_finalize()
+    assert np.array_equal(full.cpu().numpy(), one) and info["collectives"] >= 2
+    for key in ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination", "final_radius"):
+        assert sm[key] == sm1[key], key
+    # the shard's workgroup partials are first reduced to ONE row: the cost sums differ from the single-context order in the last ulp
+    assert np.isclose(sm["final_cost"], sm1["final_cost"], rtol=1e-13) and np.isclose(sm["initial_cost"], sm1["initial_cost"], rtol=1e-13)

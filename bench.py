@@ -134,6 +134,51 @@ def cpu_baseline_full(rsdsfm, np, rank, trials, tol, budget_s=20.0):
                       "median of %d; %.1f s in total" % (len(times), trials, len(times), sum(times)), "trials": trials}
 
 
+def cpu_baseline_full_all_cores(rsdsfm, np, rank, trials, tol, single, budget_s=10.0):
+    """the same whole solve on the OpenMP build of the oracle (SURVEY section 8 d: "plus an all-cores variant"): the per-pixel loops
+    of the T depth solves, the scoring and the refinement passes run on a thread team; best of a short thread-count sweep"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+
+    try:
+        O.lib_omp()
+        import ctypes
+
+        gomp = ctypes.CDLL("libgomp.so.1")
+    except Exception as e:  # no compiler / OpenMP runtime on the box: say so instead of failing the bench
+        return {"value": None, "error": repr(e)[:200]}
+    d = rsdsfm.synth.make_config(5, seed=0x5EED0005 + rank)
+    rows, cols = d["rows"], d["cols"]
+    ncpu = os.cpu_count() or 1
+    best, t_all = None, time.perf_counter()
+    with O.all_cores():
+        for nt in sorted({min(ncpu, 128), min(ncpu, 64), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
+            gomp.omp_set_num_threads(int(nt))
+            times = []
+            for rep in range(3):
+                t0 = time.perf_counter()
+                q, u, qpx, fpx = O.flatten(d["flow_img"], *d["K"], d["gamma"])
+                a, ak = O.get_alpha(fpx, rows, d["gamma"]), O.get_alpha_k(qpx, fpx, rows, d["gamma"])
+                r = O.ransac(q, u, a, ak, False, trials, tol, O.sample_indices(len(q), trials, 1), depth_mode=1)
+                ref = O.refine(u, r["inliers"], r["alpha"], r["alpha_k"], r["v"], r["w"], r["k"], False, 1, r["inlier_idx"])
+                inl, v, _ = O.canonicalize_sign(ref["inliers"], ref["v"])
+                O.scatter_depth(inl, *d["K"], rows, cols)
+                O.pose_table(v, ref["w"], ref["k"], d["gamma"], rows)
+                times.append(time.perf_counter() - t0)
+                if time.perf_counter() - t_all > budget_s:
+                    break
+            med = sorted(times)[len(times) // 2]
+            if best is None or med < best["seconds_per_solve"]:
+                best = {"value": rows * cols / med / 1e6, "unit": "Mpixels/s", "cores": int(nt), "host_cores": ncpu, "seconds_per_solve": med,
+                        "kind": "port (OpenMP over pixels)", "num_inliers": int(r["num_inliers"]),
+                        "sample": "the whole solve of the same pair, %d trials, oracle built with -fopenmp; best median of a thread-count sweep" % trials}
+            if time.perf_counter() - t_all > budget_s:
+                break
+    if best and single:
+        best["speedup_over_1_thread"] = single["seconds_per_solve"] / best["seconds_per_solve"]
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -432,6 +477,8 @@ def main():
                                     **{k2: full[k2] for k2 in ("rows", "cols", "trials", "tol", "n", "num_inliers", "refine_summary", "w_err", "v_angle_deg")}},
                          "roofline": roof, "full_solve_batched": batched, "full_solve_fused": fused, "depth_only": depth_only,
                          "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_full(rsdsfm, np, rank, args.trials, args.tol)})
+            if line["cpu_baseline"] and side:  # the single-thread figure "plus an all-cores variant"
+                line["cpu_baseline"]["all_cores"] = cpu_baseline_full_all_cores(rsdsfm, np, rank, args.trials, args.tol, line["cpu_baseline"])
 
     # =================================================================================================
     elif args.workload == "rectify":

@@ -134,7 +134,29 @@ def estimate_inverse_depths_all_cores(q, u, v, w, k, alpha, alpha_k, mode=1):
     return rho, sm.as_dict()
 
 
+class all_cores:
+    """context manager: inside, every wrapper below calls the OpenMP build (reference arithmetic; the per-pixel loops of the depth
+    solve, the RANSAC scoring and the refinement passes run on the thread team, sums by OpenMP reductions -- a TIMING vehicle for
+    bench.py's all-cores CPU baseline, never the parity target)"""
+
+    def __enter__(self):
+        global _FORCE
+        L = lib_omp()
+        L.rso_score.restype = C.c_int64
+        L.rso_flatten.restype = C.c_int64
+        self.prev, _FORCE = _FORCE, L
+
+    def __exit__(self, *a):
+        global _FORCE
+        _FORCE = self.prev
+
+
+_FORCE = None
+
+
 def lib():
+    if _FORCE is not None:
+        return _FORCE
     if _ARITH not in _LIBS:
         # RSO_ORACLE_LIB: an alternative build of the same source (e.g. `make -C oracle asan` run under LD_PRELOAD=libasan.so)
         alt = os.environ.get("RSO_ORACLE_LIB") if _ARITH == "reference" else None

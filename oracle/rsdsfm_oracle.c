@@ -951,6 +951,9 @@ int64_t rso_score(const double* q, const double* u, const double* alpha, const d
                   double* err_sum) {
     int64_t count = 0;
     double es = 0.0;
+#ifdef _OPENMP /* all-cores build only (bench.py's all-cores CPU baseline); see rso_estimate_inverse_depths */
+#pragma omp parallel for reduction(+ : count, es) schedule(static)
+#endif
     for (int64_t j = 0; j < n; ++j) {
         double err = point_error(q[2 * j], q[2 * j + 1], u[2 * j], u[2 * j + 1], alpha[j], alpha_k[j], v, w, k, rho[j]);
         int in = err < tol;
@@ -1163,6 +1166,9 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
     /* iteration zero: cost, gradient, jacobi scaling from the initial Jacobian */
     double sp[7], colsq[7] = {0}, gp[7] = {0};
     double cost = 0.0, gmax = 0.0, xsq = 0.0;
+#ifdef _OPENMP /* all-cores build only */
+#pragma omp parallel for reduction(+ : cost, xsq, colsq[:7], gp[:7]) reduction(max : gmax) schedule(static)
+#endif
     for (int64_t i = 0; i < m; ++i) {
         double r[2], Jp[2][7], Jr[2];
         resid_jac(inl[3 * i], inl[3 * i + 1], uu[2 * i], uu[2 * i + 1], alpha[i], alpha_k[i], p, rho[i], r, Jp, Jr);
@@ -1202,6 +1208,9 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
          * restated as clamp(diag) * (1/radius), see rso_estimate_inverse_depths) */
         const double inv_radius = 1.0 / radius;
         double FtF[49] = {0}, C[49] = {0}, Ftb[7] = {0}, cvec[7] = {0};
+#ifdef _OPENMP /* all-cores build only */
+#pragma omp parallel for reduction(+ : FtF[:49], C[:49], Ftb[:7], cvec[:7]) schedule(static)
+#endif
         for (int64_t i = 0; i < m; ++i) {
             double r[2], Jp[2][7], Jr[2];
             resid_jac(inl[3 * i], inl[3 * i + 1], uu[2 * i], uu[2 * i + 1], alpha[i], alpha_k[i], p, rho[i], r, Jp, Jr);
@@ -1249,6 +1258,9 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
                 stepsq += dx * dx;
             }
             /* pass 2: back-substitution, model cost change, candidate cost */
+#ifdef _OPENMP /* all-cores build only */
+#pragma omp parallel for reduction(+ : model_change, stepsq, ccost) schedule(static)
+#endif
             for (int64_t i = 0; i < m; ++i) {
                 double r[2], Jp[2][7], Jr[2];
                 resid_jac(inl[3 * i], inl[3 * i + 1], uu[2 * i], uu[2 * i + 1], alpha[i], alpha_k[i], p, rho[i], r, Jp, Jr);
@@ -1304,6 +1316,9 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
             cost = 0.0;
             gmax = 0.0;
             for (int c = 0; c < np; ++c) gp[c] = 0.0;
+#ifdef _OPENMP /* all-cores build only */
+#pragma omp parallel for reduction(+ : cost, xsq, gp[:7]) reduction(max : gmax) schedule(static)
+#endif
             for (int64_t i = 0; i < m; ++i) {
                 rho[i] = cand[i];
                 xsq += rho[i] * rho[i];

@@ -35,6 +35,8 @@ if [ "${1:-}" != "quick" ]; then
   b depth --workload depth
   b tiled_full --workload tiled_full
   b tiled_full_python --workload tiled_full --tiled-driver python
+  b tiled --workload tiled
+  b tiled_python --workload tiled --tiled-driver python
   b metrics --workload metrics
   b rectify --workload rectify
   b true_flow --workload true_flow

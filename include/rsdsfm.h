@@ -449,7 +449,12 @@ int rsdsfm_depth_preview_dev(rsdsfm_ctx* ctx, const double* d_inliers3m, int64_t
  * world_{x,y,z}: the unprojection maps of frame 1 (Eigen MatrixXd, column-major rows x cols; all-zero = void pixel);
  * R2 / t2: pose table of the rows2 scanlines of frame 2 (as rsdsfm_pose_table lays it out); flow: rows x cols x 2
  * doubles row-major (cv::Mat_<cv::Point_<double>>); best_row (may be NULL): winning scanline per pixel, -1 = void.
- * rows2 must be >= 1 (the reference would read scanline 0 of an empty frame). */
+ * rows2 must be >= 1 (the reference would read scanline 0 of an empty frame).
+ * The search is exact: by default scanlines are visited in blocks of 32 and a block is skipped only when interval arithmetic over its
+ * pose entries proves that none of its scanlines can reach the best |y - i| found so far (winners and flows bit-identical to
+ * visiting every scanline).  rsdsfm_set_true_flow_search: 0 = automatic (pruned from 96 scanlines on; default), 1 = the exhaustive
+ * loop (the reference's own), 2 = pruned at any size. */
+int rsdsfm_set_true_flow_search(rsdsfm_ctx* ctx, int mode);
 int rsdsfm_true_flow(rsdsfm_ctx* ctx, const double* world_x, const double* world_y, const double* world_z, int32_t rows,
                      int32_t cols, const double* R2_rows9, const double* t2_rows3, int32_t rows2, double fx, double fy,
                      double cx, double cy, int q5_mode, double* flow, int32_t* best_row_or_null);

@@ -660,6 +660,11 @@ for _name, _fn in list(vars(_RectifyMixin).items()):
 # ground-truth flow between two rolling-shutter frames
 # ---------------------------------------------------------------------------------------------------
 class _TrueFlowMixin:
+    def set_true_flow_search(self, mode):
+        """0 / False (default): interval-pruned exact search from 96 scanlines on; 1 / True: every scanline for every pixel; 2: pruned
+        at any size (rsdsfm_set_true_flow_search).  Identical results."""
+        self._check(self.lib.rsdsfm_set_true_flow_search(self._ctx, int(mode)), "rsdsfm_set_true_flow_search")
+
     def true_flow(self, world_xyz, R2, t2, K, q5_mode=Q5_COMPAT, want_best_row=True):
         """Camera::calculateTrueFlow.  world_xyz: (rows, cols, 3) world point per pixel of frame 1 (zeros = void);
         R2: (rows2, 3, 3) or (rows2, 9); t2: (rows2, 3).  Returns flow (rows, cols, 2) and the winning scanlines."""

@@ -209,6 +209,13 @@ int rsdsfm_set_ransac_speculation(rsdsfm_ctx* ctx, int k0) {
     return RSDSFM_OK;
 }
 
+int rsdsfm_set_true_flow_search(rsdsfm_ctx* ctx, int mode) {
+    CTX_OR_FAIL(ctx);
+    if (mode < 0 || mode > 2) return fail(c, RSDSFM_ERR_INVALID, "true-flow search mode: 0 = automatic, 1 = exhaustive, 2 = interval-pruned");
+    c->true_flow_exhaustive = mode;
+    return RSDSFM_OK;
+}
+
 const char* rsdsfm_kernel_name(const char* entry_point) {
     if (!entry_point) return "";
     if (!strcmp(entry_point, "estimate_inverse_depths_lm")) return "depth_lm_kernel<1>";

@@ -14,6 +14,7 @@
 //     bit-identical to the oracle's;
 //   * the world maps are column-major (Eigen) and the flow row-major (cv::Mat): 24 B read + 16 B written per pixel,
 //     negligible against rows2 x ~30 fp64 instructions per pixel.
+#include <float.h>
 #include <math.h>
 
 #include "rsdsfm_internal.hpp"
@@ -98,14 +99,182 @@ __global__ __launch_bounds__(kGF) void true_flow_kernel(const double* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same argmin with interval pruning (the default): the exhaustive loop evaluates rows2 projections per pixel although the
+// projected row y(i) moves by a fraction of a pixel per scanline, so |y(i) - i| is far above the minimum for all but a few dozen
+// candidates.  Scanlines are grouped into blocks of kPB; pose_bounds_kernel stores, per block, centre and radius of the eight pose
+// entries the row coordinate depends on (R[3..8], t[1], t[2]).  For a pixel, interval arithmetic over a block bounds camera-frame
+// y and z, their quotient and the projected row, hence a LOWER bound of |y(i) - i| over the block; blocks whose bound exceeds
+// the best value found so far are skipped, everything else is evaluated with the exhaustive kernel's own code.  Every bound is
+// widened by 1e-13-relative slack (hundreds of ulps: it covers the rounding of the interval arithmetic itself and of the exact
+// evaluation it stands for), blocks with a z interval containing 0 or any non-finite number are always evaluated, and the winner is the
+// lexicographic minimum of (difference, scanline) over the evaluated candidates -- the exhaustive loop's "first strict minimum".
+// Winners and flows are bit-identical to the exhaustive search (tests/test_gpu_rectify.py compares the two on adversarial
+// pose tables); 1280x720 against 720 scanlines: 0.71 -> see DESIGN.md section 9.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kPB = 32;      // scanlines per block
+constexpr int kPBW = 16;     // doubles per block: centre[8], radius[8] of (R3, R4, R5, t1, R6, R7, R8, t2)
+constexpr int kPBHead = 8;   // header doubles: max |R3..5|, max |t1|, max |R6..8|, max |t2|
+
+__global__ __launch_bounds__(256) void pose_bounds_kernel(const double* __restrict__ R2, const double* __restrict__ t2, int rows2,
+                                                         double* __restrict__ out) {
+    const int nb = (rows2 + kPB - 1) / kPB;
+    double mx[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+        double lo[8], hi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) lo[e] = INFINITY, hi[e] = -INFINITY;
+        bool bad = false;
+        const int i1 = (b * kPB + kPB < rows2) ? b * kPB + kPB : rows2;
+        for (int i = b * kPB; i < i1; ++i) {
+            const double* Ri = R2 + (int64_t)i * 9;
+            const double* ti = t2 + (int64_t)i * 3;
+            const double v[8] = {Ri[3], Ri[4], Ri[5], ti[1], Ri[6], Ri[7], Ri[8], ti[2]};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (!(fabs(v[e]) <= DBL_MAX)) bad = true;  // NaN or infinity: the block is always evaluated
+                lo[e] = fmin(lo[e], v[e]);
+                hi[e] = fmax(hi[e], v[e]);
+            }
+        }
+        double* o = out + kPBHead + (int64_t)b * kPBW;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const double m = 0.5 * lo[e] + 0.5 * hi[e];
+            double rad = fmax(hi[e] - m, m - lo[e]);
+            rad = rad * (1.0 + 1e-15) + DBL_MIN;  // [m - rad, m + rad] contains [lo, hi] whatever the rounding of m and of the differences
+            o[e] = bad ? 0.0 : m;
+            o[8 + e] = bad ? INFINITY : rad;
+            const double a = fmax(fabs(lo[e]), fabs(hi[e]));
+            const int g = e < 3 ? 0 : e == 3 ? 1 : e < 7 ? 2 : 3;
+            if (!bad) mx[g] = fmax(mx[g], a);
+        }
+    }
+    __shared__ double s_mx[4][256];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) s_mx[g][threadIdx.x] = mx[g];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double m = 0.0;
+        for (int j = 0; j < (int)blockDim.x; ++j) m = fmax(m, s_mx[threadIdx.x][j]);
+        out[threadIdx.x] = m;
+    }
+}
+
+// evaluates the scanlines [i0, i1) exactly as the exhaustive loop does and keeps the lexicographic minimum of (difference, scanline)
+__device__ __forceinline__ void eval_scanlines(const double* __restrict__ R2, const double* __restrict__ t2, int i0, int i1, double X,
+                                               double Y, double Z, double fyp, double cy, double& min_diff, int& best_row) {
+#pragma unroll 4
+    for (int i = i0; i < i1; ++i) {
+        const double* Ri = R2 + (int64_t)i * 9;  // uniform address: scalar loads
+        const double* ti = t2 + (int64_t)i * 3;
+        const double yc = cam_row(Ri[3], Ri[4], Ri[5], ti[1], X, Y, Z);
+        const double zc = cam_row(Ri[6], Ri[7], Ri[8], ti[2], X, Y, Z);
+        const double py = to_plane(yc, zc, fyp, cy);
+        const double diff = fabs(py - (double)i);
+        if (diff < min_diff || (diff == min_diff && i < best_row)) {
+            min_diff = diff;
+            best_row = i;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kGF) void true_flow_pruned_kernel(const double* __restrict__ wx, const double* __restrict__ wy,
+                                                              const double* __restrict__ wz, int rows, int cols,
+                                                              const double* __restrict__ R2, const double* __restrict__ t2, int rows2,
+                                                              const double* __restrict__ bounds, double fx, double fyp, double cx,
+                                                              double cy, double2* __restrict__ flow, int* __restrict__ best_row_out) {
+    const int tiles_u = (cols + 15) / 16;
+    const int64_t ntiles = (int64_t)tiles_u * ((rows + 15) / 16);
+    const int nb = (rows2 + kPB - 1) / kPB;
+    const double rmax_y = bounds[0], tmax_y = bounds[1], rmax_z = bounds[2], tmax_z = bounds[3];
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int v0 = (int)(tile / tiles_u) * 16;
+        const int v = v0 + (threadIdx.x & 15), u = (int)(tile % tiles_u) * 16 + (threadIdx.x >> 4);
+        const bool inside = v < rows && u < cols;
+        const int64_t p = (int64_t)v * cols + u;
+        const int64_t cm = (int64_t)u * rows + v;
+        double X = 0.0, Y = 0.0, Z = 0.0;
+        if (inside) X = wx[cm], Y = wy[cm], Z = wz[cm];
+        const bool valid = inside && sqrt(X * X + Y * Y + Z * Z) != 0;
+        double min_diff = INFINITY;
+        int best_row = 0;
+        // the block the tile's own rows fall into first: on real data it holds the winner, and its minimum prunes nearly all the others
+        int b0 = (v0 + 8 < rows2 ? v0 + 8 : rows2 - 1) / kPB;
+        if (valid) eval_scanlines(R2, t2, b0 * kPB, (b0 * kPB + kPB < rows2) ? b0 * kPB + kPB : rows2, X, Y, Z, fyp, cy, min_diff, best_row);
+        const double aX = fabs(X), aY = fabs(Y), aZ = fabs(Z);
+        const double slack_y = 1e-13 * (rmax_y * (aX + aY + aZ) + tmax_y) + DBL_MIN;
+        const double slack_z = 1e-13 * (rmax_z * (aX + aY + aZ) + tmax_z) + DBL_MIN;
+        for (int b = 0; b < nb; ++b) {
+            if (b == b0) continue;
+            const double* o = bounds + kPBHead + (int64_t)b * kPBW;  // uniform: scalar loads
+            // camera-frame y and z over the block: centre +- radius
+            const double yc = ((o[0] * X + o[1] * Y) + o[2] * Z) + o[3];
+            const double yr = ((o[8] * aX + o[9] * aY) + o[10] * aZ) + o[11] + slack_y;
+            const double zc = ((o[4] * X + o[5] * Y) + o[6] * Z) + o[7];
+            const double zr = ((o[12] * aX + o[13] * aY) + o[14] * aZ) + o[15] + slack_z;
+            double ylo = yc - yr, yhi = yc + yr, zlo = zc - zr, zhi = zc + zr;
+            bool need = true;
+            if (zlo > 0.0 || zhi < 0.0) {  // (false for NaN bounds: the block is evaluated)
+                if (zhi < 0.0) {           // y / z = (-y) / (-z)
+                    const double t0 = -yhi, t1 = -ylo, t2z = -zhi, t3 = -zlo;
+                    ylo = t0, yhi = t1, zlo = t2z, zhi = t3;
+                }
+                const double qlo = ylo / (ylo >= 0.0 ? zhi : zlo);
+                const double qhi = yhi / (yhi >= 0.0 ? zlo : zhi);
+                const double pa = qlo * fyp + cy, pb = qhi * fyp + cy;
+                const double plo = fmin(pa, pb), phi = fmax(pa, pb);
+                const double e = 1e-13 * (fabs(plo) + fabs(phi) + 2.0 * fabs(cy) + 1.0);
+                const double i0 = (double)(b * kPB), i1 = (double)((b * kPB + kPB < rows2 ? b * kPB + kPB : rows2) - 1);
+                const double lb = fmax(i0 - (phi + e), (plo - e) - i1);  // <= |y(i) - i| for every scanline of the block
+                need = !(lb > min_diff + 1e-13 * min_diff);                 // NaN-safe: anything unordered is evaluated
+            }
+            if (valid && need)
+                eval_scanlines(R2, t2, b * kPB, (b * kPB + kPB < rows2) ? b * kPB + kPB : rows2, X, Y, Z, fyp, cy, min_diff, best_row);
+        }
+        if (!inside) continue;
+        double f2x = (double)u, f2y = (double)v;
+        int out_row = -1;
+        if (valid) {
+            out_row = best_row;
+            const double* Ri = R2 + (int64_t)best_row * 9;
+            const double* ti = t2 + (int64_t)best_row * 3;
+            const double xc = cam_row(Ri[0], Ri[1], Ri[2], ti[0], X, Y, Z);
+            const double yc = cam_row(Ri[3], Ri[4], Ri[5], ti[1], X, Y, Z);
+            const double zc = cam_row(Ri[6], Ri[7], Ri[8], ti[2], X, Y, Z);
+            const double px = to_plane(xc, zc, fx, cx);
+            const double py = to_plane(yc, zc, fyp, cy);
+            if (sqrt(px * px + py * py) != 0) {
+                f2x = px;
+                f2y = py;
+            }
+        }
+        flow[p] = make_double2(f2x - (double)u, f2y - (double)v);
+        if (best_row_out) best_row_out[p] = out_row;
+    }
+}
+
 int true_flow_launch(Ctx* c, const double* d_wx, const double* d_wy, const double* d_wz, int rows, int cols, const double* d_R2,
                      const double* d_t2, int rows2, double fx, double fy, double cx, double cy, int q5_mode, double* d_flow,
                      int* d_best_row) {
     int64_t blocks = (int64_t)((cols + 15) / 16) * ((rows + 15) / 16);
     if (blocks < 1) blocks = 1;
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(true_flow_kernel, dim3((int)blocks), dim3(kGF), 0, c->stream, d_wx, d_wy, d_wz, rows, cols, d_R2, d_t2, rows2, fx,
-                       q5_mode == 0 ? fx : fy, cx, cy, reinterpret_cast<double2*>(d_flow), d_best_row);
+    const double fyp = q5_mode == 0 ? fx : fy;
+    if (c->true_flow_exhaustive == 1 || (c->true_flow_exhaustive == 0 && rows2 < 3 * kPB)) {  // few scanlines: the bounds would cost more than they save
+        hipLaunchKernelGGL(true_flow_kernel, dim3((int)blocks), dim3(kGF), 0, c->stream, d_wx, d_wy, d_wz, rows, cols, d_R2, d_t2, rows2, fx,
+                           fyp, cx, cy, reinterpret_cast<double2*>(d_flow), d_best_row);
+        RSDSFM_HIP_CHECK(c, hipGetLastError());
+        return RSDSFM_OK;
+    }
+    const int nb = (rows2 + kPB - 1) / kPB;
+    int rc = ensure_ws(c, sizeof(double) * ((size_t)nb * kPBW + kPBHead) + 256);
+    if (rc != RSDSFM_OK) return rc;
+    double* d_bounds = static_cast<double*>(c->d_ws);
+    hipLaunchKernelGGL(pose_bounds_kernel, dim3(1), dim3(256), 0, c->stream, d_R2, d_t2, rows2, d_bounds);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(true_flow_pruned_kernel, dim3((int)blocks), dim3(kGF), 0, c->stream, d_wx, d_wy, d_wz, rows, cols, d_R2, d_t2, rows2,
+                       d_bounds, fx, fyp, cx, cy, reinterpret_cast<double2*>(d_flow), d_best_row);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -62,10 +62,13 @@ def fuzz_consumers(O, rsdsfm, cases, seed0):
                 R2, t2 = O.pose_table(v * rng.uniform(0.5, 1.5), w * rng.uniform(0.5, 1.5), k, gamma, rows2)
                 t2 = t2 + rng.normal(size=3) * 0.02
                 q5 = int(rng.integers(2))
-                flow, best = s.true_flow(world, R2, t2, K, q5_mode=q5)
                 flow_o, best_o = O.true_flow(world, R2, t2, *K, q5_mode=q5)
-                assert np.array_equal(best, best_o), "true_flow winners"
-                assert np.array_equal(flow.view(np.uint64), flow_o.view(np.uint64)), "true_flow values"
+                for search in (1, 2):  # the exhaustive loop and the interval-pruned search (forced: these frames have few scanlines)
+                    s.set_true_flow_search(search)
+                    flow, best = s.true_flow(world, R2, t2, K, q5_mode=q5)
+                    assert np.array_equal(best, best_o), "true_flow winners (search mode %d)" % search
+                    assert np.array_equal(flow.view(np.uint64), flow_o.view(np.uint64)), "true_flow values (search mode %d)" % search
+                s.set_true_flow_search(0)
                 # reprojection metric
                 est = (c3_o.astype(np.float64) * rng.uniform(0.7, 1.4)).astype(np.float32)
                 est += (rng.normal(0, 0.02, est.shape) * (rng.random(est.shape) < 0.5)).astype(np.float32)

@@ -233,6 +233,66 @@ def test_true_flow_degenerate_points_and_errors(oracle, rsdsfm):
             s.true_flow(w, R, t, K, q5_mode=3)
 
 
+def test_true_flow_pruned_search_equals_exhaustive(oracle, rsdsfm):
+    """the interval-pruned search (default, frames with >= 96 scanlines) picks the exhaustive loop's winners and flows bit for bit:
+    a smooth pose table (few blocks evaluated), wild ones (rotations / translations jumping from scanline to scanline: nothing can
+    be skipped, scanlines far from the pixel's own row win), z intervals containing 0, ties between blocks, non-finite table entries
+    and world points, a last block of one scanline"""
+    rng = np.random.default_rng(4242)
+    rows, cols = 150, 97
+    cases = []
+    for rows2, kind in ((150, "smooth"), (97, "smooth"), (129, "wild"), (200, "wild_small"), (160, "flat"), (128, "nan")):
+        K, world, R2, t2 = _flow_scene(rsdsfm, oracle, rows, cols, seed=rows2, rows2=rows2)
+        R2, t2 = np.array(R2).reshape(rows2, 3, 3).copy(), np.array(t2).reshape(rows2, 3).copy()
+        if kind == "wild":
+            R2 += rng.normal(scale=0.5, size=R2.shape)
+            t2 += rng.normal(scale=2.0, size=t2.shape)  # camera-frame z of many points changes sign from scanline to scanline
+        elif kind == "wild_small":
+            R2 += rng.normal(scale=0.02, size=R2.shape)
+            t2 += rng.normal(scale=0.05, size=t2.shape)
+        elif kind == "flat":  # identical poses: y(i) is constant, |y - i| ties exactly between neighbouring blocks for half-integer rows
+            R2[:] = np.eye(3)
+            t2[:] = 0.0
+            world[::3, :, 1] = ((np.arange(0, rows, 3)[:, None] * 1.0 + 31.5 - K[3]) / K[1]) * world[::3, :, 2]
+        elif kind == "nan":
+            R2[40, 1, 1] = np.nan
+            t2[77, 2] = np.inf
+            world[5, 5] = [np.nan, 1.0, 2.0]
+            world[6, 6] = [1e300, -1e300, 1e-300]
+        cases.append((K, world, R2, t2))
+    with rsdsfm.Solver(0) as s:
+        for K, world, R2, t2 in cases:
+            for q5 in (0, 1):
+                s.set_true_flow_search(2)
+                flow, best = s.true_flow(world, R2, t2, K, q5_mode=q5)
+                s.set_true_flow_search(1)
+                flow_x, best_x = s.true_flow(world, R2, t2, K, q5_mode=q5)
+                assert np.array_equal(best, best_x)
+                assert np.array_equal(flow.view(np.uint64), flow_x.view(np.uint64))
+        for trial in range(24):  # random perturbation levels between "smooth" and "wild", random frame-2 heights
+            rows2 = int(rng.integers(96, 320))
+            K, world, R2, t2 = _flow_scene(rsdsfm, oracle, 64, 80, seed=1000 + trial, rows2=rows2)
+            R2, t2 = np.array(R2).reshape(rows2, 3, 3).copy(), np.array(t2).reshape(rows2, 3).copy()
+            scale = 10.0 ** rng.uniform(-5, 0)
+            R2 += rng.normal(scale=scale, size=R2.shape)
+            t2 += rng.normal(scale=3.0 * scale, size=t2.shape)
+            if trial % 4 == 0:  # a drift: the winners sit far from the pixel's own row
+                t2[:, 1] += np.linspace(0.0, rng.uniform(-1.0, 1.0), rows2)
+            s.set_true_flow_search(2)
+            flow, best = s.true_flow(world, R2, t2, K)
+            s.set_true_flow_search(1)
+            flow_x, best_x = s.true_flow(world, R2, t2, K)
+            assert np.array_equal(best, best_x), (trial, scale)
+            assert np.array_equal(flow.view(np.uint64), flow_x.view(np.uint64)), (trial, scale)
+        K, world, R2, t2 = cases[2]
+        with np.errstate(all="ignore"):
+            flow_o, best_o = oracle.true_flow(world, R2, t2, *K)
+        s.set_true_flow_search(0)
+        flow, best = s.true_flow(world, R2, t2, K)
+        assert np.array_equal(best, best_o) and np.array_equal(flow.view(np.uint64), flow_o.view(np.uint64))
+        assert len(np.unique(best)) > 50  # the winners are all over the frame: the pruning has nothing to hold on to, the result is still exact
+
+
 # ---------------------------------------------------------------------------------------------------
 # accuracy metrics (SURVEY 8 f-4)
 # ---------------------------------------------------------------------------------------------------

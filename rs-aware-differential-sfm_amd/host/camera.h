@@ -44,6 +44,12 @@ public:
     RsFrame& frame(const int frameNr) { return frames_[(size_t)frameNr - 1]; }
     rsdsfm::lite::MatrixXd getDepthMap(const int frameNr) { return frames_[(size_t)frameNr - 1].getDepthMap(); }
     void setDepthMap(const int frameNr, rsdsfm::lite::MatrixXd depth_map) { frames_[(size_t)frameNr - 1].setDepthMap(depth_map); }
+    /** reference camera.cc:369-371, :416-420 (the latter overwrites the stored depth map, like the reference) */
+    void setSyntheticDepthMap(const int frameNr) { frames_[(size_t)frameNr - 1].setSyntheticDepthMapRs(); }
+    rsdsfm::lite::MatrixXd getGroundTruthDepthMap(const int frameNr) {
+        frames_[(size_t)frameNr - 1].setSyntheticDepthMapRs();
+        return frames_[(size_t)frameNr - 1].getDepthMap();
+    }
     /** reference camera.cc:340-342 */
     void setPose(const int frameNr, const double k, const rsdsfm::lite::Vector3d& linear_velocity, const rsdsfm::lite::Vector3d& angular_velocity) {
         frames_[(size_t)frameNr - 1].setRelativePose(linear_velocity, angular_velocity, k);

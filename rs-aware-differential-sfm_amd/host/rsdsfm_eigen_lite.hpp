@@ -103,6 +103,19 @@ private:
     double d_[2];
 };
 
+class Vector2i {
+public:
+    Vector2i() : d_{0, 0} {}
+    Vector2i(int x, int y) : d_{x, y} {}
+    int& operator()(int i) { return d_[i]; }
+    int operator()(int i) const { return d_[i]; }
+    int x() const { return d_[0]; }
+    int y() const { return d_[1]; }
+
+private:
+    int d_[2];
+};
+
 class Matrix3d {  // column-major like Eigen
 public:
     Matrix3d() : d_{0, 0, 0, 0, 0, 0, 0, 0, 0} {}

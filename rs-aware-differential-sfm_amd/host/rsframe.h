@@ -96,6 +96,82 @@ public:
     rsdsfm::lite::Vector3d getUnprojectedWorldCoordinates(int x, int y) const {
         return rsdsfm::lite::Vector3d(unprojection_map_x_(y, x), unprojection_map_y_(y, x), unprojection_map_z_(y, x));
     }
+    rsdsfm::lite::Vector3d getUnprojectedWorldCoordinates(const rsdsfm::lite::Vector2d& point) const {
+        return getUnprojectedWorldCoordinates((int)point.x(), (int)point.y());  // Eigen's coeff(double, double) truncates
+    }
+    unsigned long getNrScannlines() const { return (unsigned long)scanlines_.size(); }
+    void setGsImage(const rsdsfm::ImageBGR& image) { gs_image_ = image; }
+    void setDepthMapGs(const rsdsfm::lite::MatrixXd& depth_map_gs) { gs_depth_map_ = depth_map_gs; }
+    bool setUnprojectionMapGs(const rsdsfm::lite::MatrixXd& x, const rsdsfm::lite::MatrixXd& y, const rsdsfm::lite::MatrixXd& z) {
+        gs_unprojection_map_x_ = x, gs_unprojection_map_y_ = y, gs_unprojection_map_z_ = z;
+        return true;
+    }
+
+    // ---- per-point geometry of the reference class (host arithmetic, the reference's operation order) ----
+    /** reference rsframe.cc:629-642; quirk Q5: the y coordinate is scaled by f_x unless q5_mode() == RSDSFM_Q5_FIXED */
+    rsdsfm::lite::Vector2d spaceToPlane(const rsdsfm::lite::Vector3d& Point) const {
+        const double fyp = q5_mode() == RSDSFM_Q5_FIXED ? K_(1, 1) : K_(0, 0);
+        return rsdsfm::lite::Vector2d(Point.x() / Point.z() * K_(0, 0) + K_(0, 2), Point.y() / Point.z() * fyp + K_(1, 2));
+    }
+    /** reference rsframe.cc:646-665: z_value == 0 (the default) takes the depth from the RS depth map */
+    rsdsfm::lite::Vector3d planeToSpace(const rsdsfm::lite::Vector2d& point, double z_value = 0) const {
+        const double px = (point.x() - K_(0, 2)) * 1.0 / K_(0, 0), py = (point.y() - K_(1, 2)) * 1.0 / K_(1, 1);
+        if (z_value == 0) z_value = depth_map_((long)int(point.y()), (long)int(point.x()));
+        return rsdsfm::lite::Vector3d(z_value * px, z_value * py, z_value * 1.0);
+    }
+    /** reference rsframe.cc:668-684 */
+    rsdsfm::lite::Vector2i coordinateToPixel(const rsdsfm::lite::Vector2d point) const {
+        return rsdsfm::lite::Vector2i((int)std::floor(point.x() + 0.5), (int)std::floor(point.y() + 0.5));
+    }
+    rsdsfm::lite::Vector2d pixelToCoordinate(const rsdsfm::lite::Vector2i pixel) const {
+        return rsdsfm::lite::Vector2d(1.0 * pixel.x(), 1.0 * pixel.y());
+    }
+    /** reference rsframe.cc:688-709: [R t; 0 1] * (Point, 1), Eigen's 4x4 product evaluated left to right */
+    rsdsfm::lite::Vector3d worldToCameraFrame(const rsdsfm::lite::Vector3d& Point, const int scanlineNr, bool useRelative = true) const {
+        const Scanline& sl = scanlines_[(size_t)scanlineNr];
+        const rsdsfm::lite::Matrix3d& R = useRelative ? sl.getRelativeRotation() : sl.getRotation();
+        const rsdsfm::lite::Vector3d& t = useRelative ? sl.getRelativeTranslation() : sl.getTranslation();
+        rsdsfm::lite::Vector3d out;
+        for (int r = 0; r < 3; ++r) out(r) = ((R(r, 0) * Point.x() + R(r, 1) * Point.y()) + R(r, 2) * Point.z()) + t(r) * 1.0;
+        return out;
+    }
+    /** reference rsframe.cc:713-736: [R^T  -R^T t; 0 1] * (Point, 1) */
+    rsdsfm::lite::Vector3d cameraToWorldFrame(const rsdsfm::lite::Vector3d& Point, const int scanlineNr, bool useRelative = true) const {
+        const Scanline& sl = scanlines_[(size_t)scanlineNr];
+        const rsdsfm::lite::Matrix3d& R = useRelative ? sl.getRelativeRotation() : sl.getRotation();
+        const rsdsfm::lite::Vector3d& t = useRelative ? sl.getRelativeTranslation() : sl.getTranslation();
+        rsdsfm::lite::Vector3d out;
+        for (int r = 0; r < 3; ++r) {
+            const double p3 = -((R(0, r) * t(0) + R(1, r) * t(1)) + R(2, r) * t(2));  // -R_transpose.row(r) * t
+            out(r) = ((R(0, r) * Point.x() + R(1, r) * Point.y()) + R(2, r) * Point.z()) + p3 * 1.0;
+        }
+        return out;
+    }
+    /** reference rsframe.cc:587-613: RS depth map from the unprojection maps and the RELATIVE scanline poses (synthetic data) */
+    void setSyntheticDepthMapRs() {
+        depth_map_ = rsdsfm::lite::MatrixXd::Zero(rows_, cols_);
+        for (int y = 0; y < (int)scanlines_.size(); ++y)
+            for (int x = 0; x < cols_; ++x) {
+                const rsdsfm::lite::Vector3d W = getUnprojectedWorldCoordinates(x, y);
+                if (std::sqrt((W.x() * W.x() + W.y() * W.y()) + W.z() * W.z()) > 0) depth_map_(y, x) = worldToCameraFrame(W, y).z();
+            }
+    }
+    /** reference rsframe.cc:565-584: GS depth map from the GS unprojection maps and the pose of scanline 0 */
+    void setSyntheticDepthMapGs() {
+        gs_depth_map_ = rsdsfm::lite::MatrixXd::Zero(rows_, cols_);
+        for (int y = 0; y < (int)scanlines_.size(); ++y)
+            for (int x = 0; x < cols_; ++x) {
+                const rsdsfm::lite::Vector3d W(gs_unprojection_map_x_(y, x), gs_unprojection_map_y_(y, x), gs_unprojection_map_z_(y, x));
+                if (std::sqrt((W.x() * W.x() + W.y() * W.y()) + W.z() * W.z()) > 0) gs_depth_map_(y, x) = worldToCameraFrame(W, 0).z();
+            }
+    }
+    rsdsfm::lite::MatrixXd getDepthMapGs() const { return gs_depth_map_; }
+    /** reference rsframe.cc:740-768 with the reference's signature */
+    rsdsfm::lite::Vector2d calculateImageCoordinatesRsFrame(const rsdsfm::lite::Vector3d& Point) const {
+        double x = 0, y = 0;
+        calculateImageCoordinatesRsFrame(Point, x, y);
+        return rsdsfm::lite::Vector2d(x, y);
+    }
     /** reference rsframe.cc:740-768: image coordinates of a world point under the best-matching scanline pose */
     void calculateImageCoordinatesRsFrame(const rsdsfm::lite::Vector3d& Point, double& x_out, double& y_out) const {
         std::vector<double> R, t;
@@ -174,6 +250,7 @@ private:
     rsdsfm::ImageBGR image_, gs_image_;
     rsdsfm::ImageXYZf coordinates_3d_;
     rsdsfm::lite::MatrixXd unprojection_map_x_, unprojection_map_y_, unprojection_map_z_;
+    rsdsfm::lite::MatrixXd gs_depth_map_, gs_unprojection_map_x_, gs_unprojection_map_y_, gs_unprojection_map_z_;
 };
 
 #endif

@@ -1,0 +1,89 @@
+// geometry_host.cpp -- the per-point geometry members of the reference's RsFrame (rsframe.cc:565-736) in the C++ mirror: host
+// arithmetic only, no GPU work.  Builds a small frame with rigid scanline poses, checks the algebra (world -> camera -> world,
+// plane -> space -> plane, pixel rounding, synthetic depth maps against getGroundtruthDepthMap) and prints "ok".
+#include <cmath>
+#include <cstdio>
+
+#include "../../rs-aware-differential-sfm_amd/host/camera.h"
+
+using rsdsfm::lite::Matrix3d;
+using rsdsfm::lite::MatrixXd;
+using rsdsfm::lite::Vector2d;
+using rsdsfm::lite::Vector2i;
+using rsdsfm::lite::Vector3d;
+
+static Matrix3d rot_z_x(double a, double b) {  // Rz(a) * Rx(b): orthonormal by construction
+    const double ca = std::cos(a), sa = std::sin(a), cb = std::cos(b), sb = std::sin(b);
+    Matrix3d R;
+    R(0, 0) = ca, R(0, 1) = -sa * cb, R(0, 2) = sa * sb;
+    R(1, 0) = sa, R(1, 1) = ca * cb, R(1, 2) = -ca * sb;
+    R(2, 0) = 0, R(2, 1) = sb, R(2, 2) = cb;
+    return R;
+}
+
+#define CHECK(cond)                                                        \
+    if (!(cond)) {                                                         \
+        std::fprintf(stderr, "%s:%d: %s\n", __FILE__, __LINE__, #cond);   \
+        return 1;                                                          \
+    }
+
+int main() {
+    const int rows = 12, cols = 17;
+    Camera camera;
+    camera.setIntrinsics("galaxy_vga");
+    camera.addFrame(rows, cols);
+    RsFrame& f = camera.frame(1);
+    const Matrix3d K = camera.getIntrinsics();
+    MatrixXd ux(rows, cols), uy(rows, cols), uz(rows, cols);
+    for (int i = 0; i < rows; ++i) {
+        const Matrix3d R = rot_z_x(0.01 * i, -0.004 * i);
+        const Vector3d t(0.002 * i, -0.001 * i, 0.0005 * i);
+        f.scanline(i).setRotation(R), f.scanline(i).setTranslation(t);
+        f.scanline(i).setRelativeRotation(R), f.scanline(i).setRelativeTranslation(t);
+        for (int x = 0; x < cols; ++x) {  // a world point for every pixel except a void column
+            const bool hole = x == 5;
+            ux(i, x) = hole ? 0.0 : 0.1 * x - 0.7, uy(i, x) = hole ? 0.0 : 0.08 * i - 0.4, uz(i, x) = hole ? 0.0 : 2.0 + 0.03 * x + 0.02 * i;
+        }
+    }
+    f.setUnprojectionMapRs(ux, uy, uz);
+    f.setUnprojectionMapGs(ux, uy, uz);
+    CHECK(f.getNrScannlines() == (unsigned long)rows);
+    // world -> camera -> world with either pose set
+    for (int i = 0; i < rows; ++i)
+        for (int rel = 0; rel < 2; ++rel) {
+            const Vector3d W(0.3 - 0.05 * i, -0.2 + 0.01 * i, 2.5);
+            const Vector3d C = f.worldToCameraFrame(W, i, rel != 0);
+            const Vector3d B = f.cameraToWorldFrame(C, i, rel != 0);
+            for (int r = 0; r < 3; ++r) CHECK(std::fabs(B(r) - W(r)) < 1e-13);
+        }
+    // synthetic RS depth = camera-frame z of the unprojected point = getGroundtruthDepthMap (absolute = relative poses here)
+    f.setSyntheticDepthMapRs();
+    const MatrixXd z = f.getDepthMap(), zt = f.getGroundtruthDepthMap();
+    for (int i = 0; i < rows; ++i)
+        for (int x = 0; x < cols; ++x) {
+            CHECK(z(i, x) == zt(i, x));
+            CHECK((x == 5) == (z(i, x) == 0.0));
+        }
+    CHECK(camera.getGroundTruthDepthMap(1)(3, 4) == z(3, 4));
+    f.setSyntheticDepthMapGs();
+    CHECK(f.getDepthMapGs()(7, 2) == f.worldToCameraFrame(f.getUnprojectedWorldCoordinates(Vector2d(2, 7)), 0).z());
+    // plane <-> space: planeToSpace takes the depth from the RS depth map by default; spaceToPlane carries quirk Q5
+    for (int mode = 0; mode < 2; ++mode) {
+        RsFrame::q5_mode() = mode == 0 ? RSDSFM_Q5_COMPAT : RSDSFM_Q5_FIXED;
+        const Vector2d p(9.0, 4.0);
+        const Vector3d P = f.planeToSpace(p);
+        CHECK(P.z() == z(4, 9));
+        const Vector2d back = f.spaceToPlane(P);
+        CHECK(std::fabs(back.x() - p.x()) < 1e-10);
+        const double fy_used = mode == 0 ? K(0, 0) : K(1, 1);
+        CHECK(std::fabs(back.y() - ((p.y() - K(1, 2)) / K(1, 1) * fy_used + K(1, 2))) < 1e-10);
+        CHECK(f.planeToSpace(p, 3.0).z() == 3.0);
+    }
+    RsFrame::q5_mode() = RSDSFM_Q5_COMPAT;
+    const Vector2i px = f.coordinateToPixel(Vector2d(2.5, -0.5));
+    CHECK(px.x() == 3 && px.y() == 0);
+    const Vector2d pc = f.pixelToCoordinate(Vector2i(7, 3));
+    CHECK(pc.x() == 7.0 && pc.y() == 3.0);
+    std::printf("ok\n");
+    return 0;
+}

@@ -31,6 +31,17 @@ def _build_tiled(tmp_path):
     return exe
 
 
+def test_rsframe_geometry_members_on_the_host(tmp_path, rsdsfm):
+    """tests/cpp/geometry_host.cpp: worldToCameraFrame / cameraToWorldFrame / planeToSpace / spaceToPlane (quirk Q5) / pixel
+    rounding / synthetic depth maps of the RsFrame mirror -- host arithmetic, runs without a GPU"""
+    rsdsfm.load_library()
+    exe = os.path.join(str(tmp_path), "geometry_host")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "cpp", "geometry_host.cpp"),
+                           "-L", PKG, "-lrsdsfm_hip", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip() == "ok", p.stderr
+
+
 def test_tiled_host_compiles_and_links(tmp_path, rsdsfm):
     rsdsfm.load_library()
     exe = _build_tiled(tmp_path)

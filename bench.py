@@ -593,7 +593,7 @@ def main():
                                     "speedup_over_exhaustive": ms_x / ms, "void_pixels": int((best < 0).sum().item())},
                          "roofline": {"bound": "hbm", "kernel": "true_flow_pruned_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": achieved / HBM_PEAK_GBS, "traffic": _traffic("true_flow"), "alg_bytes_per_launch": alg, "avg_launch_ms": ms,
-                                      "note": "compute-bound: 23 block bounds (~75 fp64 VALU instructions each) + ~40 exact projections (~30 each) per 44 B pixel; see DESIGN"},
+                                      "note": "compute-bound: one global + 2-3 block interval bounds (~75 fp64 VALU instructions each), 22 two-subtraction tests and ~40 exact projections (~30 each) per 44 B pixel; see DESIGN"},
                          "cpu_baseline": cpu})
 
     # =================================================================================================

@@ -110,16 +110,20 @@ __global__ __launch_bounds__(kGF) void true_flow_kernel(const double* __restrict
 // evaluation it stands for), blocks with a z interval containing 0 or any non-finite number are always evaluated, and the winner is the
 // lexicographic minimum of (difference, scanline) over the evaluated candidates -- the exhaustive loop's "first strict minimum".
 // Winners and flows are bit-identical to the exhaustive search (tests/test_gpu_rectify.py compares the two on adversarial
-// pose tables); 1280x720 against 720 scanlines: 0.71 -> see DESIGN.md section 9.
+// pose tables); 1280x720 against 720 scanlines: 0.71 -> 0.14 ms.
 // ---------------------------------------------------------------------------------------------------
 constexpr int kPB = 32;      // scanlines per block
 constexpr int kPBW = 16;     // doubles per block: centre[8], radius[8] of (R3, R4, R5, t1, R6, R7, R8, t2)
-constexpr int kPBHead = 8;   // header doubles: max |R3..5|, max |t1|, max |R6..8|, max |t2|
+constexpr int kPBHead = 24;  // header doubles: max |R3..5|, max |t1|, max |R6..8|, max |t2|, 4 unused, then centre[8] / radius[8] over ALL scanlines
 
 __global__ __launch_bounds__(256) void pose_bounds_kernel(const double* __restrict__ R2, const double* __restrict__ t2, int rows2,
                                                          double* __restrict__ out) {
     const int nb = (rows2 + kPB - 1) / kPB;
     double mx[4] = {0.0, 0.0, 0.0, 0.0};
+    double glo[8], ghi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) glo[e] = INFINITY, ghi[e] = -INFINITY;
+    bool gbad = false;
     for (int b = threadIdx.x; b < nb; b += blockDim.x) {
         double lo[8], hi[8];
 #pragma unroll
@@ -148,16 +152,35 @@ __global__ __launch_bounds__(256) void pose_bounds_kernel(const double* __restri
             const double a = fmax(fabs(lo[e]), fabs(hi[e]));
             const int g = e < 3 ? 0 : e == 3 ? 1 : e < 7 ? 2 : 3;
             if (!bad) mx[g] = fmax(mx[g], a);
+            glo[e] = fmin(glo[e], lo[e]);
+            ghi[e] = fmax(ghi[e], hi[e]);
         }
+        gbad = gbad || bad;
     }
     __shared__ double s_mx[4][256];
+    __shared__ double s_lo[8][256], s_hi[8][256];
+    __shared__ int s_bad[256];
 #pragma unroll
     for (int g = 0; g < 4; ++g) s_mx[g][threadIdx.x] = mx[g];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_lo[e][threadIdx.x] = glo[e], s_hi[e][threadIdx.x] = ghi[e];
+    s_bad[threadIdx.x] = gbad ? 1 : 0;
     __syncthreads();
     if (threadIdx.x < 4) {
         double m = 0.0;
         for (int j = 0; j < (int)blockDim.x; ++j) m = fmax(m, s_mx[threadIdx.x][j]);
         out[threadIdx.x] = m;
+    }
+    if (threadIdx.x >= 8 && threadIdx.x < 16) {  // the same centre / radius form over ALL scanlines: the cheap first test of every block
+        const int e = threadIdx.x - 8;
+        double lo = INFINITY, hi = -INFINITY;
+        int bad = 0;
+        for (int j = 0; j < (int)blockDim.x; ++j) lo = fmin(lo, s_lo[e][j]), hi = fmax(hi, s_hi[e][j]), bad |= s_bad[j];
+        const double m = 0.5 * lo + 0.5 * hi;
+        double rad = fmax(hi - m, m - lo);
+        rad = rad * (1.0 + 1e-15) + DBL_MIN;
+        out[8 + e] = bad ? 0.0 : m;
+        out[16 + e] = bad ? INFINITY : rad;
     }
 }
 
@@ -176,6 +199,31 @@ __device__ __forceinline__ void eval_scanlines(const double* __restrict__ R2, co
             min_diff = diff;
             best_row = i;
         }
+    }
+}
+
+// [plo, phi] contains the projected row y(i) of the world point for every scanline whose eight pose entries lie in centre +- radius
+// (o[0..7] / o[8..15]); left at (-inf, +inf) when the camera-frame z interval contains 0 or anything is not finite
+__device__ __forceinline__ void row_interval(const double* __restrict__ o, double X, double Y, double Z, double aX, double aY, double aZ,
+                                             double slack_y, double slack_z, double fyp, double cy, double& plo, double& phi) {
+    const double yc = ((o[0] * X + o[1] * Y) + o[2] * Z) + o[3];
+    const double yr = ((o[8] * aX + o[9] * aY) + o[10] * aZ) + o[11] + slack_y;
+    const double zc = ((o[4] * X + o[5] * Y) + o[6] * Z) + o[7];
+    const double zr = ((o[12] * aX + o[13] * aY) + o[14] * aZ) + o[15] + slack_z;
+    double ylo = yc - yr, yhi = yc + yr, zlo = zc - zr, zhi = zc + zr;
+    if (!(zlo > 0.0 || zhi < 0.0)) return;  // (also taken for NaN bounds)
+    if (zhi < 0.0) {                         // y / z = (-y) / (-z)
+        const double t0 = -yhi, t1 = -ylo, t2z = -zhi, t3 = -zlo;
+        ylo = t0, yhi = t1, zlo = t2z, zhi = t3;
+    }
+    const double qlo = ylo / (ylo >= 0.0 ? zhi : zlo);
+    const double qhi = yhi / (yhi >= 0.0 ? zlo : zhi);
+    const double pa = qlo * fyp + cy, pb = qhi * fyp + cy;
+    const double lo = fmin(pa, pb), hi = fmax(pa, pb);
+    const double e = 1e-13 * (fabs(lo) + fabs(hi) + 2.0 * fabs(cy) + 1.0);
+    if (lo - e <= hi + e) {  // (false for NaN: the interval stays unbounded)
+        plo = lo - e;
+        phi = hi + e;
     }
 }
 
@@ -205,29 +253,19 @@ __global__ __launch_bounds__(kGF) void true_flow_pruned_kernel(const double* __r
         const double aX = fabs(X), aY = fabs(Y), aZ = fabs(Z);
         const double slack_y = 1e-13 * (rmax_y * (aX + aY + aZ) + tmax_y) + DBL_MIN;
         const double slack_z = 1e-13 * (rmax_z * (aX + aY + aZ) + tmax_z) + DBL_MIN;
+        // the projected row over ALL scanlines: on a smooth table it moves by a few pixels, and every block farther away than that from it
+        // is discarded with two subtractions, without looking at its own bounds
+        double gplo = -INFINITY, gphi = INFINITY;
+        row_interval(bounds + 8, X, Y, Z, aX, aY, aZ, slack_y, slack_z, fyp, cy, gplo, gphi);
         for (int b = 0; b < nb; ++b) {
             if (b == b0) continue;
-            const double* o = bounds + kPBHead + (int64_t)b * kPBW;  // uniform: scalar loads
-            // camera-frame y and z over the block: centre +- radius
-            const double yc = ((o[0] * X + o[1] * Y) + o[2] * Z) + o[3];
-            const double yr = ((o[8] * aX + o[9] * aY) + o[10] * aZ) + o[11] + slack_y;
-            const double zc = ((o[4] * X + o[5] * Y) + o[6] * Z) + o[7];
-            const double zr = ((o[12] * aX + o[13] * aY) + o[14] * aZ) + o[15] + slack_z;
-            double ylo = yc - yr, yhi = yc + yr, zlo = zc - zr, zhi = zc + zr;
-            bool need = true;
-            if (zlo > 0.0 || zhi < 0.0) {  // (false for NaN bounds: the block is evaluated)
-                if (zhi < 0.0) {           // y / z = (-y) / (-z)
-                    const double t0 = -yhi, t1 = -ylo, t2z = -zhi, t3 = -zlo;
-                    ylo = t0, yhi = t1, zlo = t2z, zhi = t3;
-                }
-                const double qlo = ylo / (ylo >= 0.0 ? zhi : zlo);
-                const double qhi = yhi / (yhi >= 0.0 ? zlo : zhi);
-                const double pa = qlo * fyp + cy, pb = qhi * fyp + cy;
-                const double plo = fmin(pa, pb), phi = fmax(pa, pb);
-                const double e = 1e-13 * (fabs(plo) + fabs(phi) + 2.0 * fabs(cy) + 1.0);
-                const double i0 = (double)(b * kPB), i1 = (double)((b * kPB + kPB < rows2 ? b * kPB + kPB : rows2) - 1);
-                const double lb = fmax(i0 - (phi + e), (plo - e) - i1);  // <= |y(i) - i| for every scanline of the block
-                need = !(lb > min_diff + 1e-13 * min_diff);                 // NaN-safe: anything unordered is evaluated
+            const double i0 = (double)(b * kPB), i1 = (double)((b * kPB + kPB < rows2 ? b * kPB + kPB : rows2) - 1);
+            const double bar = min_diff + 1e-13 * min_diff;
+            bool need = !(fmax(i0 - gphi, gplo - i1) > bar);  // NaN-safe: anything unordered goes on
+            if (need) {
+                double plo = -INFINITY, phi = INFINITY;
+                row_interval(bounds + kPBHead + (int64_t)b * kPBW, X, Y, Z, aX, aY, aZ, slack_y, slack_z, fyp, cy, plo, phi);  // uniform address: scalar loads
+                need = !(fmax(i0 - phi, plo - i1) > bar);  // fmax(...) <= |y(i) - i| for every scanline of the block
             }
             if (valid && need)
                 eval_scanlines(R2, t2, b * kPB, (b * kPB + kPB < rows2) ? b * kPB + kPB : rows2, X, Y, Z, fyp, cy, min_diff, best_row);

@@ -460,7 +460,7 @@ def main():
         full = _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps=args.steps, warmup=args.warmup, timed=timed)
         roof = _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full) if rank == 0 else None
         side = not args.no_side_records
-        batched = _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, 4, per_thread=40) if side else None
+        batched = _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, 8, per_thread=25) if side else None
         fused = None
         if side and args.arith == "reference" and rank == 0:
             with rsdsfm.Solver(local_rank, stream=stream.cuda_stream, arith="fused") as sf:

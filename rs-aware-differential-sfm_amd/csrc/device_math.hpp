@@ -119,6 +119,24 @@ __device__ __forceinline__ double acc_sq(double acc, double x) {
 #endif
 }
 
+// point_error (below) from the terms a PixelModel of the same pixel and pose already holds.  Reference arithmetic only: every
+// term of minimal.cc:255-270 is a term of the model up to sign, and IEEE negation / subtraction are exact in the sign --
+//   beta = -nbeta;  A v = (v0 - x v2, v1 - y v2) = (-a0, -a1);  B w = ((-t01 + t02) - t03, (-t11 + t12) + t13)
+// -- so  e = beta (A v rho + B w) - u  comes out bit for bit as  beta ((B w) - a rho) - u  (12 instead of 25 multiply / adds per
+// pixel-hypothesis in ransac_lm_kernel, whose two fused scores share them).
+__device__ __forceinline__ double point_error_from_model(const PixelModel& m, double rho) {
+#if RSDSFM_FUSED
+    return 0.0;  // (not used: the fused build evaluates point_error itself, whose contractions differ from the model's)
+#else
+    const double beta = -m.nbeta;
+    const double bw0 = (m.t02 - m.t01) - m.t03;
+    const double bw1 = (m.t12 - m.t11) + m.t13;
+    const double e0 = beta * (bw0 - m.a0 * rho) - m.ux;
+    const double e1 = beta * (bw1 - m.a1 * rho) - m.uy;
+    return sqrt(e0 * e0 + e1 * e1);
+#endif
+}
+
 // minimal.cc:255-270: residual norm of the flow predicted from (v, w, k, rho)
 __device__ __forceinline__ double point_error(double x, double y, double ux, double uy, double alpha, double alpha_k,
                                               const Pose& p, double two_over, double rho) {

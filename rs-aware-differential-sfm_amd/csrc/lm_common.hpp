@@ -195,10 +195,10 @@ __device__ __forceinline__ double lm_denominator(double ht, double diag, double 
 // one pixel through the planned LM trajectory; returns the state selected by write_which.
 // Arithmetic mirrors oracle/rsdsfm_oracle.c rso_estimate_inverse_depths (mode 1) operation for operation.
 struct NoHook {
-    __device__ __forceinline__ void operator()(int, double) const {}
+    __device__ __forceinline__ void operator()(int, double, const PixelModel&) const {}
 };
 
-// `hook(j, rho_j)` is called with every speculated iterate (j = 0 .. K-1: the state after j+1 accepted steps)
+// `hook(j, rho_j, model)` is called with every speculated iterate (j = 0 .. K-1: the state after j+1 accepted steps)
 template <class Plan, class Hook = NoHook>
 __device__ __forceinline__ double lm_pixel(double x, double y, double ux, double uy, double al, double ak,
                                            const Pose& pose, double two_over, const Plan& plan,
@@ -243,7 +243,7 @@ __device__ __forceinline__ double lm_pixel(double x, double y, double ux, double
             acc[3 + 5 * j + 3] = acc_sq(acc[3 + 5 * j + 3], cand);
             acc[3 + 5 * j + 4] = fmax(acc[3 + 5 * j + 4], fabs(dot2(m.J0, r0, m.J1, r1)));
             rho = cand;
-            hook(j, cand);
+            hook(j, cand, m);
             if (plan.write_which == j + 1) out = cand;
         }
     }

@@ -57,9 +57,14 @@ struct ScoreHook {
     double x, y, ux, uy, al, ak, two_over, tol;
     const Pose* pose;
     double* sc;  // [2 * kFused] = {count, err} per fused state
-    __device__ __forceinline__ void operator()(int j, double rho) const {
+    __device__ __forceinline__ void operator()(int j, double rho, const PixelModel& m) const {
         if (j < F) {
+#if RSDSFM_FUSED
+            (void)m;
             const double e = point_error(x, y, ux, uy, al, ak, *pose, two_over, rho);
+#else
+            const double e = point_error_from_model(m, rho);  // bit-identical to point_error(...): device_math.hpp
+#endif
             if (e < tol) {
                 sc[2 * j] += 1.0;
                 sc[2 * j + 1] += e;

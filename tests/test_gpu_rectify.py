@@ -231,6 +231,11 @@ def test_true_flow_degenerate_points_and_errors(oracle, rsdsfm):
             s.true_flow(w, R[:0], t[:0], K)
         with pytest.raises(rsdsfm.RsdsfmError):
             s.true_flow(w, R, t, K, q5_mode=3)
+        with pytest.raises(rsdsfm.RsdsfmError):
+            s.set_true_flow_search(3)
+        s.set_true_flow_search(2)  # the pruned search on the same degenerate points (12 scanlines: one block)
+        flow2, best2 = s.true_flow(w, R, t, K, q5_mode=1)
+        assert np.array_equal(best2, best) and np.array_equal(flow2.view(np.uint64), flow.view(np.uint64))
 
 
 def test_true_flow_pruned_search_equals_exhaustive(oracle, rsdsfm):

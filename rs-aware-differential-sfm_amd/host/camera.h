@@ -5,6 +5,7 @@
 #ifndef RSDSFM_HOST_CAMERA_H
 #define RSDSFM_HOST_CAMERA_H
 
+#include <cmath>
 #include <iostream>
 #include <string>
 #include <vector>
@@ -49,6 +50,38 @@ public:
     rsdsfm::lite::MatrixXd getGroundTruthDepthMap(const int frameNr) {
         frames_[(size_t)frameNr - 1].setSyntheticDepthMapRs();
         return frames_[(size_t)frameNr - 1].getDepthMap();
+    }
+    /** reference camera.cc:374-408: the eyeball check of the projection chain on frame 1 -- for every pixel with ground truth, the
+     *  world point from the unprojection maps, its camera-frame coordinates, the point re-derived from the depth map, both
+     *  re-projections and the world point recovered from the depth map (vectors printed on one line each) */
+    void testProjection() {
+        RsFrame frame = frames_[0];
+        frame.setSyntheticDepthMapRs();
+        auto show = [](const char* what, const double* d, int n) {
+            std::cout << what;
+            for (int i = 0; i < n; ++i) std::cout << (i ? " " : "") << d[i];
+            std::cout << std::endl;
+        };
+        for (int x = 0; x < frame.getCols(); ++x)
+            for (int y = 0; y < frame.getRows(); ++y) {
+                const rsdsfm::lite::Vector3d true_coordinates = frame.getUnprojectedWorldCoordinates(rsdsfm::lite::Vector2d(x, y));
+                const rsdsfm::lite::Vector3d camera_coordinates1 = frame.worldToCameraFrame(true_coordinates, y);
+                const rsdsfm::lite::Vector3d camera_coordinates2 = frame.planeToSpace(rsdsfm::lite::Vector2d(x, y));
+                const rsdsfm::lite::Vector2d image_coordinates1 = frame.spaceToPlane(camera_coordinates1);
+                const rsdsfm::lite::Vector2d image_coordinates2 = frame.spaceToPlane(camera_coordinates2);
+                const rsdsfm::lite::Vector3d world_coordinates = frame.cameraToWorldFrame(camera_coordinates2, y);
+                const double* t = true_coordinates.data();
+                if (std::sqrt((t[0] * t[0] + t[1] * t[1]) + t[2] * t[2]) > 0) {
+                    std::cout << "x, y: " << x << ", " << y << std::endl;
+                    show("true coordinates: ", true_coordinates.data(), 3);
+                    show("camera coordinates1: ", camera_coordinates1.data(), 3);
+                    show("camera coordinates2: ", camera_coordinates2.data(), 3);
+                    show("calculated coordinates: ", world_coordinates.data(), 3);
+                    show("image coordinates1: ", image_coordinates1.data(), 2);
+                    show("image coordinates2: ", image_coordinates2.data(), 2);
+                    std::cout << "---------------------------------------------" << std::endl;
+                }
+            }
     }
     /** reference camera.cc:340-342 */
     void setPose(const int frameNr, const double k, const rsdsfm::lite::Vector3d& linear_velocity, const rsdsfm::lite::Vector3d& angular_velocity) {

@@ -3,6 +3,7 @@
 // plane -> space -> plane, pixel rounding, synthetic depth maps against getGroundtruthDepthMap) and prints "ok".
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 
 #include "../../rs-aware-differential-sfm_amd/host/camera.h"
 
@@ -84,6 +85,7 @@ int main() {
     CHECK(px.x() == 3 && px.y() == 0);
     const Vector2d pc = f.pixelToCoordinate(Vector2i(7, 3));
     CHECK(pc.x() == 7.0 && pc.y() == 3.0);
+    if (std::getenv("RSDSFM_TEST_PROJECTION")) camera.testProjection();  // prints one block per pixel with ground truth
     std::printf("ok\n");
     return 0;
 }

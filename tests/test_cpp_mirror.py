@@ -40,6 +40,14 @@ def test_rsframe_geometry_members_on_the_host(tmp_path, rsdsfm):
                            "-L", PKG, "-lrsdsfm_hip", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
     p = subprocess.run([exe], capture_output=True, text=True)
     assert p.returncode == 0 and p.stdout.strip() == "ok", p.stderr
+    # Camera::testProjection (camera.cc:374-408): one block per pixel with ground truth; the depth-map round trip lands on the pixel in x
+    p = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, RSDSFM_TEST_PROJECTION="1"))
+    blocks = p.stdout.split("---------------------------------------------")
+    assert p.returncode == 0 and len(blocks) == 12 * 16 + 1 and blocks[0].startswith("x, y: 0, 0")
+    xs = blocks[17].splitlines()
+    px = float([ln for ln in xs if ln.startswith("x, y:")][0].split(":")[1].split(",")[0])
+    i2 = [ln for ln in xs if ln.startswith("image coordinates2:")][0].split(":")[1].split()  # plane -> space -> plane
+    assert abs(float(i2[0]) - px) < 1e-4  # (printed with 6 significant digits)
 
 
 def test_tiled_host_compiles_and_links(tmp_path, rsdsfm):

@@ -77,6 +77,58 @@ def evaluate_single_run(solver, task_dir, out_dir, trials=50, tol=0.05, seed=1, 
     return out
 
 
+def evaluate_real_run(solver, data_prefix, flow, camera="galaxy", gamma=0.95, out_dir=None, trials=5, tol=0.05, seed=1,
+                      use_acceleration_mode=False, use_refinement=True, use_global_shutter_mode=False, flow_threshold=1e-10,
+                      flow_index_mode=0, device=0):
+    """The real-world branch of evaluateSingleRun (main.cc:341-361, 364-531; setupCameraReal main.cc:675-690): <data_prefix>frame1.png,
+    one of the hard-coded phone calibrations (or a (f_x, f_y, c_x, c_y) tuple), gamma 0.95 -- and the optical flow from frame 1 to
+    frame 2, which the reference computes with OpenCV's DeepFlow in-process (out of scope) and which is passed in here: an array, a
+    .npy or a Middlebury .flo file (formats.load_flow).  Runs the whole solve in ONE device-resident call, then the consumers
+    (8-bit depth image, back projection, crack interpolation, point cloud) and writes what the reference writes.  Defaults as in
+    main.cc:304-311 (5 trials, tolerance 0.05, refinement on)."""
+    import torch
+
+    from . import BACKPROJECT_GS, BACKPROJECT_RS
+
+    image = formats.read_png(data_prefix + "frame1.png") if isinstance(data_prefix, str) else np.ascontiguousarray(data_prefix, dtype=np.uint8)
+    K = formats.CAMERA_INTRINSICS[camera] if isinstance(camera, str) else tuple(float(x) for x in camera)
+    flow = formats.load_flow(flow)
+    rows, cols = image.shape[:2]
+    if flow.shape[:2] != (rows, cols):
+        raise ValueError("flow is %dx%d, frame1 is %dx%d" % (flow.shape[0], flow.shape[1], rows, cols))
+    dev = torch.device("cuda", device)
+    mode = BACKPROJECT_GS if use_global_shutter_mode else BACKPROJECT_RS
+    with torch.cuda.device(dev):  # everything stays on the device until the products are copied out
+        d_flow, d_img = torch.from_numpy(flow).to(dev), torch.from_numpy(image).to(dev)
+        d_map = torch.empty(rows * cols, dtype=torch.float64, device=dev)
+        d_R = torch.empty(rows * 9, dtype=torch.float64, device=dev)
+        d_t = torch.empty(rows * 3, dtype=torch.float64, device=dev)
+        d_depth_est = torch.empty((rows, cols), dtype=torch.uint8, device=dev)
+        d_gs, d_back = torch.empty_like(d_img), torch.empty_like(d_img)
+        d_coords = torch.empty((rows, cols, 3), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        r = solver.solve_frame_dev(d_flow.data_ptr(), rows, cols, K, gamma, d_map.data_ptr(), d_R.data_ptr(), d_t.data_ptr(), trials=trials, tol=tol,
+                                   seed=seed, use_acceleration_mode=use_acceleration_mode, use_refinement=use_refinement,
+                                   flow_threshold=flow_threshold, flow_index_mode=flow_index_mode, use_global_shutter_mode=use_global_shutter_mode)
+        m = r["num_inliers"]
+        solver.depth_preview_dev(r["d_inliers"], m, K, rows, cols, d_depth_est.data_ptr())  # main.cc:484-509
+        solver.back_project_dev(d_img.data_ptr(), d_map.data_ptr(), d_R.data_ptr(), d_t.data_ptr(), K, rows, cols, d_gs.data_ptr(), d_coords.data_ptr(), mode=mode)
+        solver.interpolate_cracky_dev(d_gs.data_ptr(), rows, cols, d_back.data_ptr(), 1)  # main.cc:523
+        solver.synchronize()
+        depth_map = d_map.cpu().numpy().reshape(cols, rows).T.copy()  # the device map is column-major (Eigen MatrixXd)
+        R_rel, t_rel = d_R.cpu().numpy().reshape(rows, 3, 3), d_t.cpu().numpy().reshape(rows, 3)
+        depth_est, gs, backprojection, coords = d_depth_est.cpu().numpy(), d_gs.cpu().numpy(), d_back.cpu().numpy(), d_coords.cpu().numpy()
+    out = dict(n=r["n"], num_inliers=m, v=r["v"], w=r["w"], k=r["k"], flipped=r["flipped"], refine_summary=r["refine_summary"],
+               depth_map=depth_map, depth_est=depth_est, gs_image=gs, backprojection=backprojection, coords=coords, R=R_rel, t=t_rel)
+    if out_dir:
+        os.makedirs(out_dir, exist_ok=True)
+        formats.write_png(out_dir + "/MinimalDepth.png", depth_est)
+        formats.write_png(out_dir + "/rs_image.png", image)
+        formats.write_png(out_dir + "/backprojection.png", backprojection)
+        formats.write_ply(out_dir + "/point_cloud.ply", coords, image)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
 # parameter sweep (reference main.cc:148-299 -> error_measure::evaluateVelocities, errorMeasure.cpp:41-254)
 # ---------------------------------------------------------------------------------------------------

@@ -188,6 +188,51 @@ def read_png(path, grayscale=False):
     return bgr
 
 
+# ---- real-world runs: phone calibrations (camera.cc:179-206) and externally computed optical flow ----------------
+CAMERA_INTRINSICS = {  # (f_x, f_y, c_x, c_y) of Camera::setIntrinsics(std::string)
+    "iphone": (1505.1283359786307, 1513.7789208311444, 657.81734686405991, 349.91807538147589),
+    "galaxy_stabil": (1803.29785922382, 1799.35406531529, 945.304708272490, 544.684292978344),
+    "galaxy": (1492.41306997746, 1491.09286590722, 949.571146410704, 554.675409391795),
+    "galaxy_old": (3154.53208221173, 3152.28696217577, 1969.87107268891, 1521.27056048818),
+    "galaxy_vga": (484.450845764569, 485.345469134313, 313.442094604855, 241.383116350144),
+}
+
+
+def read_flo(path):
+    """Middlebury .flo optical flow (magic 202021.25, int32 width, int32 height, float32 (u, v) row-major) -> rows x cols x 2 float64.
+    The reference computes DeepFlow inside the process (camera.cc:251-300, out of scope here: OpenCV contrib); a flow computed by any
+    external tool enters the solver through this file format or a .npy array."""
+    with open(path, "rb") as f:
+        magic = np.frombuffer(f.read(4), dtype="<f4")
+        if magic.size != 1 or magic[0] != 202021.25:
+            raise ValueError("%s: not a .flo file" % path)
+        w, h = (int(x) for x in np.frombuffer(f.read(8), dtype="<i4"))
+        data = np.frombuffer(f.read(8 * w * h), dtype="<f4")
+    if data.size != 2 * w * h:
+        raise ValueError("%s: truncated .flo file" % path)
+    return data.reshape(h, w, 2).astype(np.float64)
+
+
+def write_flo(path, flow):
+    flow = np.asarray(flow, dtype=np.float32)
+    with open(path, "wb") as f:
+        f.write(np.array([202021.25], dtype="<f4").tobytes())
+        f.write(np.array([flow.shape[1], flow.shape[0]], dtype="<i4").tobytes())
+        f.write(np.ascontiguousarray(flow, dtype="<f4").tobytes())
+
+
+def load_flow(path_or_array):
+    """rows x cols x 2 float64 flow (x, y displacement in pixels, as cv::Mat_<cv::Point_<double>>) from an array, a .npy or a .flo file"""
+    if isinstance(path_or_array, str):
+        flow = read_flo(path_or_array) if path_or_array.endswith(".flo") else np.load(path_or_array)
+    else:
+        flow = path_or_array
+    flow = np.ascontiguousarray(flow, dtype=np.float64)
+    if flow.ndim != 3 or flow.shape[2] != 2:
+        raise ValueError("flow must be rows x cols x 2")
+    return flow
+
+
 # ---- sweep outputs (main.cc:179-206, 262-300) -----------------------------------------------------
 def write_sweep_results(result_dir, tasks, w_errors, v_errors, reproject_errors, w=None, v=None, k=None):
     """errors.csv with the reference's header plus the per-quantity CSVs (one line per task)"""

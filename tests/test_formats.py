@@ -164,3 +164,27 @@ def test_sweep_outputs(F, tmp_path):
     lines = open(str(tmp_path / "errors.csv")).read().split("\n")
     assert lines[0] == "task,error_w,error_v,reproject_error" and lines[1].startswith("t1,0.2") and lines[2].startswith("t2,0.2")
     assert open(str(tmp_path / "w.csv")).read().split("\n")[1] == "7,8,9"
+
+
+def test_flo_round_trip_and_flow_loader(rsdsfm, tmp_path):
+    """Middlebury .flo files (float32) and .npy arrays as carriers of an externally computed optical flow (the reference computes
+    DeepFlow in-process); the five phone calibrations of camera.cc:179-206"""
+    F = rsdsfm.formats
+    rng = np.random.default_rng(3)
+    flow = rng.normal(scale=4.0, size=(7, 11, 2))
+    F.write_flo(str(tmp_path / "a.flo"), flow)
+    back = F.read_flo(str(tmp_path / "a.flo"))
+    assert back.shape == (7, 11, 2) and back.dtype == np.float64 and np.array_equal(back, flow.astype(np.float32).astype(np.float64))
+    np.save(str(tmp_path / "a.npy"), flow)
+    assert np.array_equal(F.load_flow(str(tmp_path / "a.npy")), flow) and np.array_equal(F.load_flow(str(tmp_path / "a.flo")), back)
+    assert F.load_flow(flow) is not None
+    with pytest.raises(ValueError):
+        F.load_flow(np.zeros((4, 5)))
+    (tmp_path / "bad.flo").write_bytes(b"ABCD" + b"\0" * 8)  # wrong magic (the right one reads "PIEH")
+    with pytest.raises(ValueError):
+        F.read_flo(str(tmp_path / "bad.flo"))
+    open(str(tmp_path / "short.flo"), "wb").write(np.array([202021.25], dtype="<f4").tobytes() + np.array([5, 5], dtype="<i4").tobytes() + b"\0" * 16)
+    with pytest.raises(ValueError):
+        F.read_flo(str(tmp_path / "short.flo"))
+    assert set(F.CAMERA_INTRINSICS) == {"iphone", "galaxy_stabil", "galaxy", "galaxy_old", "galaxy_vga"}
+    assert F.CAMERA_INTRINSICS["galaxy_vga"][0] == 484.450845764569

@@ -115,3 +115,46 @@ def test_parameter_sweep_over_archives(rsdsfm, oracle, tmp_path):
     for name in ("w.csv", "v.csv", "k.csv", "reproject_errors.csv", "error_v.csv", "error_w.csv", "depthMaps/0/0.png", "depthMaps/1/3.ply"):
         assert os.path.exists(os.path.join(out, name)), name
     assert len(open(out + "/w.csv").read().strip().split("\n")[0].split(",")) == 12  # 4 evaluations x 3 components per task line
+
+
+def test_real_world_run_with_an_external_flow(rsdsfm, oracle, tmp_path):
+    """evaluate_real_run = the real-world branch of evaluateSingleRun (main.cc:341-361, :675-690) with the flow passed in: frame1.png +
+    a flow file -> one device-resident solve -> depth image, rectified frame, point cloud.  The device-resident consumers give the
+    bytes of the host-boundary ones, the pose is the one the stage chain finds, the files are what the reference writes"""
+    import os
+
+    F = rsdsfm.formats
+    d = rsdsfm.synth.make_config(3, rows=120, cols=160)
+    rows, cols = d["rows"], d["cols"]
+    rng = np.random.default_rng(12)
+    image = rng.integers(0, 256, size=(rows, cols, 3), dtype=np.uint8)
+    prefix = str(tmp_path) + "/"
+    F.write_png(prefix + "frame1.png", image)
+    np.save(prefix + "flow.npy", d["flow_img"])
+    with rsdsfm.Solver(0) as s:
+        out = rsdsfm.evaluate.evaluate_real_run(s, prefix, prefix + "flow.npy", camera=d["K"], gamma=d["gamma"], out_dir=prefix + "out", trials=8,
+                                                 tol=0.002, seed=3, flow_index_mode=1)
+        assert out["n"] == rows * cols and out["num_inliers"] > 0.1 * rows * cols
+        # the same products through the host-boundary entry points
+        gs, coords = s.back_project(image, out["depth_map"], out["R"], out["t"], d["K"])
+        assert np.array_equal(gs, out["gs_image"]) and np.array_equal(coords.view(np.uint32), out["coords"].view(np.uint32))
+        assert np.array_equal(s.interpolate_cracky(gs, 1), out["backprojection"])
+        # the stage chain on the same flow and seed finds the same motion
+        q, u, a, ak = s.flatten(d["flow_img"], d["K"], d["gamma"])
+        rr = s.ransac(q, u, a, ak, False, 8, 0.002, samples=None, seed=3)
+        ref = s.non_linear_refinement(u, rr["inliers"], rr["alpha"], rr["alpha_k"], rr["v"], rr["w"], rr["k"], False, flow_index_mode=1,
+                                      inlier_idx=rr["inlier_idx"])
+        dm = s.depth_map(ref["inliers"], ref["v"], d["K"], rows, cols)
+        assert out["num_inliers"] == rr["num_inliers"] and np.allclose(out["w"], ref["w"], rtol=1e-9, atol=1e-12) and np.allclose(out["v"], dm["v"], rtol=1e-9)
+        assert np.array_equal(out["depth_est"], s.depth_preview(dm["inliers"], d["K"], rows, cols))
+        # a float32 .flo carrier of the same flow: the same pipeline, results to the carrier's precision
+        F.write_flo(prefix + "flow.flo", d["flow_img"])
+        out2 = rsdsfm.evaluate.evaluate_real_run(s, image, prefix + "flow.flo", camera=d["K"], gamma=d["gamma"], trials=8, tol=0.002, seed=3, flow_index_mode=1)
+        assert np.allclose(out2["w"], out["w"], atol=1e-5) and abs(out2["num_inliers"] - out["num_inliers"]) < 0.01 * rows * cols
+        with pytest.raises(ValueError):
+            rsdsfm.evaluate.evaluate_real_run(s, image[:10], prefix + "flow.npy", camera="galaxy")
+    for name in ("MinimalDepth.png", "rs_image.png", "backprojection.png", "point_cloud.ply"):
+        assert os.path.getsize(prefix + "out/" + name) > 0
+    assert np.array_equal(F.read_png(prefix + "out/backprojection.png"), out["backprojection"])
+    pts, cols_ = F.read_ply(prefix + "out/point_cloud.ply")
+    assert len(pts) == len(cols_) > 0

@@ -28,7 +28,8 @@ namespace rsdsfm {
 namespace {
 
 constexpr int kRB = 256;  // workgroup size of the pixel kernels
-constexpr int kRP = 6;    // pixels per thread per tile, register-resident across the hypothesis loop: every hypothesis pays one workgroup reduction of its 22 sums per tile, so more pixels per thread amortise it (round 1, fused model: 4 / 5: 451 / 419 us, 6 dropped to one wave per SIMD; round 2, reference arithmetic with the scores taken from the pixel model: 5 / 6: 0.476 / 0.471 ms at 246 VGPRs, 6.60 / 6.42 ms for the 4K tiled solve; 7 / 8 fit 256 VGPRs without scratch but run at 0.59 / 0.58 ms)
+constexpr int kRP = RSDSFM_FUSED ? 5 : 6;  // (the fused build's point_error does not share terms with the pixel model: 6 would take 256 VGPRs and one wave per SIMD there)
+                                        // pixels per thread per tile, register-resident across the hypothesis loop: every hypothesis pays one workgroup reduction of its 22 sums per tile, so more pixels per thread amortise it (round 1, fused model: 4 / 5: 451 / 419 us, 6 dropped to one wave per SIMD; round 2, reference arithmetic with the scores taken from the pixel model: 5 / 6: 0.476 / 0.471 ms at 246 VGPRs, 6.60 / 6.42 ms for the 4K tiled solve; 7 / 8 fit 256 VGPRs without scratch but run at 0.59 / 0.58 ms)
 // LM iterations speculated in round 0 (template parameter K0 of ransac_lm_kernel<true, K0>): KMAX = 3 (default) decides every
 // hypothesis that ends with <= 2 accepted steps in one pass and fuses the inlier scores {count, sum err} of the iterates after ONE
 // and after TWO accepted steps.  DeepFlow-like data (0.3 px noise + 10 % outliers) ends with TWO accepted steps for ~96 % of the

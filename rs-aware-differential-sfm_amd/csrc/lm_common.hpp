@@ -182,6 +182,18 @@ struct LmPlanFirstK {
 };
 using LmPlanFirst = LmPlanFirstK<KMAX>;
 
+// plan of a pure replay with the number of accepted steps known at compile time (scoring: the accepted trust-region radii of a
+// finished hypothesis, nothing speculated): lm_pixel becomes straight-line code and the pixel chains of a lane interleave
+template <int NH>
+struct LmPlanReplay {
+    static constexpr int n_hist = NH;
+    static constexpr int K = 0;
+    static constexpr int write_which = 0;
+    double ih[NH > 0 ? NH : 1];   // 1 / radius of each accepted step
+    double inv_cand[KMAX];        // (never read: K == 0)
+    __device__ __forceinline__ double inv_hist_at(int h) const { return ih[h]; }
+};
+
 // ht + clamp(diag) / radius: the damped 1x1 normal matrix of one pixel (inv_radius = 1 / radius)
 __device__ __forceinline__ double lm_denominator(double ht, double diag, double inv_radius) {
 #if RSDSFM_FUSED
@@ -202,9 +214,10 @@ struct NoHook {
 template <class Plan, class Hook = NoHook>
 __device__ __forceinline__ double lm_pixel(double x, double y, double ux, double uy, double al, double ak,
                                            const Pose& pose, double two_over, const Plan& plan,
-                                           double (&acc)[NS], const Hook& hook = Hook()) {
+                                           double (&acc)[NS], const Hook& hook = Hook(), PixelModel* model_out = nullptr) {
     PixelModel m;
     m.init(x, y, ux, uy, al, ak, pose, two_over);
+    if (model_out) *model_out = m;
     const double s = 1.0 / (1.0 + sqrt(dot2(m.J0, m.J0, m.J1, m.J1)));  // Jacobi scaling (iteration 0 Jacobian)
     const double jt0 = m.J0 * s, jt1 = m.J1 * s;
     const double ht = dot2(jt0, jt0, jt1, jt1);

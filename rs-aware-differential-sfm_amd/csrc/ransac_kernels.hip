@@ -401,47 +401,114 @@ __device__ __forceinline__ double hyp_rho(double x, double y, double ux, double 
     return lm_pixel(x, y, ux, uy, al, ak, pose, two_over, plan, dummy);  // plan.K == 0: replay only
 }
 
-// score partials: [gridDim.x][T][2] = {count, sum of inlier errors}
+// the error of one pixel at rho: the reference build takes it from the pixel model the replay built (bit-identical, device_math.hpp)
+__device__ __forceinline__ double score_error(const PixelModel& m, double x, double y, double ux, double uy, double al, double ak,
+                                              const Pose& pose, double two_over, double rho) {
+#if RSDSFM_FUSED
+    (void)m;
+    return point_error(x, y, ux, uy, al, ak, pose, two_over, rho);
+#else
+    (void)x, (void)y, (void)ux, (void)uy, (void)al, (void)ak, (void)pose, (void)two_over;
+    return point_error_from_model(m, rho);
+#endif
+}
+
+// the kRP pixels of a lane under one hypothesis with NH accepted steps (compile time): one straight-line block
+template <int NH>
+__device__ __forceinline__ void score_pixels(const Tile& px, bool full_tile, const Pose& pose, double two_over, const LmState& st, double tol,
+                                             double& cnt, double& es) {
+    LmPlanReplay<NH> plan;
+#pragma unroll
+    for (int h = 0; h < NH; ++h) plan.ih[h] = 1.0 / st.hist[h];  // (uniform: scalar loads, one division per accepted step)
+    double dummy[NS];
+#pragma unroll
+    for (int j = 0; j < kRP; ++j) {
+        if (full_tile || px.ok[j]) {
+            PixelModel m;
+            const double rho = lm_pixel(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, plan, dummy, NoHook(), &m);
+            const double err = score_error(m, px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, rho);
+            if (err < tol) {
+                cnt += 1.0;
+                es += err;
+            }
+        }
+    }
+}
+
+// XCD-aware (tile block, hypothesis group) of a linear workgroup id: see ransac_lm_kernel
+__device__ __forceinline__ void tile_group_of_block(int bid, int ntile_blocks, int ngroups, int& tb, int& grp) {
+    const int tiles8 = ((ntile_blocks + 7) / 8) * 8;
+    const int nfull = ngroups - 1;
+    if (nfull > 0 && bid < tiles8 * nfull) {
+        const int window = 8 * nfull;
+        tb = (bid / window) * 8 + (bid % 8);
+        grp = (bid % window) / 8;
+    } else {
+        tb = bid - tiles8 * nfull;
+        grp = nfull;
+    }
+}
+
+// score partials: [ntile_blocks][T][2] = {count, sum of inlier errors}.  Like ransac_lm_kernel the hypotheses of a tile are split
+// over `ngroups` short workgroups (one long workgroup per tile left the second round of the chip mostly empty: 600 tiles on 512
+// resident slots), and hypotheses with up to four accepted steps -- all of them on ordinary data -- run a replay whose depth is a
+// template parameter: no plan in LDS, no workgroup barriers around it, the six pixel chains of a lane interleaved.  The per-lane,
+// per-wave and per-workgroup order of the sums is unchanged.
 __global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
                                                           const double* __restrict__ alpha,
                                                           const double* __restrict__ alpha_k, int64_t n,
                                                           const double* __restrict__ hyp, int T,
                                                           const LmState* __restrict__ states, int depth_mode, double tol,
-                                                          const int* __restrict__ scored, double* __restrict__ partials) {
+                                                          const int* __restrict__ scored, double* __restrict__ partials, int ntile_blocks,
+                                                          int ngroups) {
     extern __shared__ double s_acc[];  // [T][2]
     __shared__ LmPlanLds plan;
     __shared__ double s_red[2][kRB / 64][2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int tb, grp;
+    tile_group_of_block((int)blockIdx.x, ntile_blocks, ngroups, tb, grp);
+    if (tb >= ntile_blocks) return;
+    const int per_group = (T + ngroups - 1) / ngroups;
+    const int t_begin = grp * per_group, t_end = min(T, t_begin + per_group);
     for (int i = tid; i < T * 2; i += kRB) s_acc[i] = 0.0;
     __syncthreads();
     const int64_t tile_pixels = (int64_t)kRB * kRP;
     const int64_t ntiles = (n + tile_pixels - 1) / tile_pixels;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t tile = tb; tile < ntiles; tile += ntile_blocks) {
         Tile px;
         load_tile(px, q, u, alpha, alpha_k, tile * tile_pixels, n);
-        for (int t = 0; t < T; ++t) {
+        const bool full_tile = (tile + 1) * tile_pixels <= n;
+        for (int t = t_begin; t < t_end; ++t) {
             if (scored && scored[t]) continue;  // already scored by the fused LM pass (uniform branch)
-            if (depth_mode == RSDSFM_DEPTH_CERES_LM) {
-                __syncthreads();
-                if (tid == 0) {
-                    plan.n_hist = states[t].n_hist;
-                    plan.K = 0;
-                    plan.write_which = 0;
-                }
-                if (tid < kMaxIter) plan.inv_hist[tid] = 1.0 / states[t].hist[tid];
-                __syncthreads();
-            }
             RSDSFM_LOAD_POSE(pose, hyp, t)
             const double two_over = 2.0 / (2.0 + pose.k);
             double cnt = 0.0, es = 0.0;
+            const int nh = depth_mode == RSDSFM_DEPTH_CERES_LM ? states[t].n_hist : -1;  // uniform
+            if (nh == 0) score_pixels<0>(px, full_tile, pose, two_over, states[t], tol, cnt, es);
+            else if (nh == 1) score_pixels<1>(px, full_tile, pose, two_over, states[t], tol, cnt, es);
+            else if (nh == 2) score_pixels<2>(px, full_tile, pose, two_over, states[t], tol, cnt, es);
+            else if (nh == 3) score_pixels<3>(px, full_tile, pose, two_over, states[t], tol, cnt, es);
+            else if (nh == 4) score_pixels<4>(px, full_tile, pose, two_over, states[t], tol, cnt, es);
+            else {  // closed form, or a long trajectory: the plan goes through LDS
+                if (depth_mode == RSDSFM_DEPTH_CERES_LM) {
+                    __syncthreads();
+                    if (tid == 0) {
+                        plan.n_hist = states[t].n_hist;
+                        plan.K = 0;
+                        plan.write_which = 0;
+                    }
+                    if (tid < kMaxIter) plan.inv_hist[tid] = 1.0 / states[t].hist[tid];
+                    __syncthreads();
+                }
 #pragma unroll
-            for (int j = 0; j < kRP; ++j) {
-                if (px.ok[j]) {
-                    const double rho = hyp_rho(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, depth_mode, plan);
-                    const double err = point_error(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, rho);
-                    if (err < tol) {
-                        cnt += 1.0;
-                        es += err;
+                for (int j = 0; j < kRP; ++j) {
+                    if (px.ok[j]) {
+                        const double rho = hyp_rho(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, depth_mode, plan);
+                        const double err = point_error(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, rho);
+                        if (err < tol) {
+                            cnt += 1.0;
+                            es += err;
+                        }
                     }
                 }
             }
@@ -461,8 +528,8 @@ __global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __rest
         __syncthreads();
     }
     __syncthreads();
-    double* out = partials + (int64_t)blockIdx.x * T * 2;
-    for (int i = tid; i < T * 2; i += kRB) out[i] = s_acc[i];
+    double* out = partials + (int64_t)tb * T * 2;
+    for (int i = t_begin * 2 + tid; i < t_end * 2; i += kRB) out[i] = s_acc[i];
 }
 
 // fixed-order reduction of one hypothesis batch's score partials into trial_count / trial_err (already offset):
@@ -799,9 +866,10 @@ int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* 
                         const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
                         double* partials, double* trial_count, double* trial_err) {
     const int grid = ransac_pixel_grid(c, n);
-    hipLaunchKernelGGL(ransac_score_kernel, dim3(grid), dim3(kRB), sizeof(double) * T * 2, c->stream,
+    const int groups = ransac_lm_groups(c, grid, T);
+    hipLaunchKernelGGL(ransac_score_kernel, dim3(((grid + 7) / 8) * 8 * groups), dim3(kRB), sizeof(double) * T * 2, c->stream,
                        reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states,
-                       depth_mode, tol, scored, partials);
+                       depth_mode, tol, scored, partials, grid, groups);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(ransac_reduce_scores_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, scored, trial_count,
                        trial_err);
@@ -834,9 +902,10 @@ int ransac_score_rows_launch(Ctx* c, const double* q, const double* u, const dou
                              const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
                              double* partials, double* rows) {
     const int grid = ransac_pixel_grid(c, n);
-    hipLaunchKernelGGL(ransac_score_kernel, dim3(grid), dim3(kRB), sizeof(double) * T * 2, c->stream,
+    const int groups = ransac_lm_groups(c, grid, T);
+    hipLaunchKernelGGL(ransac_score_kernel, dim3(((grid + 7) / 8) * 8 * groups), dim3(kRB), sizeof(double) * T * 2, c->stream,
                        reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states,
-                       depth_mode, tol, scored, partials);
+                       depth_mode, tol, scored, partials, grid, groups);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(ransac_score_rows_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, scored, rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());

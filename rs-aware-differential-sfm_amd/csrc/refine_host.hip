@@ -60,8 +60,12 @@ int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const
     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(B.state, hs, sizeof(RefineState) + sizeof(int), hipMemcpyHostToDevice, c->stream));
     rc = refine_init_launch(c, B, np);
     if (rc != RSDSFM_OK) return rc;
-    // LM iterations are enqueued in chunks; kernels of a finished solve return immediately
-    const int chunk = 5;
+    // LM iterations are enqueued in chunks; the kernels of a finished solve return immediately, but an empty iteration still costs
+    // four launches (~19 us) and a chunk that is too short a host round trip (~25 us).  Chunks are 5 iterations (DeepFlow-like data
+    // takes 3..6: following the previous solve's count more closely was measured 1 % slower, the counts vary from pair to pair),
+    // except behind a refinement that ended within 2 iterations -- noise-free data, e.g. ground-truth flow, ends after ONE -- where
+    // the first chunk is that count + 1.  The chunking changes when the host looks at the state, never what the kernels compute.
+    int chunk = (c->refine_iters_hint >= 0 && c->refine_iters_hint <= 2) ? c->refine_iters_hint + 1 : 5;
     for (int launched = 0;;) {
         for (int i = 0; i < chunk; ++i) {
             rc = refine_iter_launch(c, B, np);
@@ -77,7 +81,9 @@ int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const
         if (*h_bad) return fail(c, RSDSFM_ERR_INVALID, "flow index out of range (flow has fewer columns than inliers / bad inlier_idx)");
         if (hs->termination >= 0) break;
         if (launched > 4 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
+        chunk = 5;
     }
+    c->refine_iters_hint = hs->iteration;
     for (int i = 0; i < 3; ++i) {
         v_out[i] = hs->p[i];
         w_out[i] = hs->p[3 + i];

@@ -126,7 +126,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     int32_t* h_samples_pinned = reinterpret_cast<int32_t*>(h_states + Tn);
 
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
-    bool final_done = false;
+    bool final_done = false, spec_scored = false;
     const int k0 = c->ransac_k0;  // speculation depth of round 0 (see ransac_kernels.hip)
     int not_one_step = 0;
     if (T > 0) {
@@ -146,7 +146,17 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
                     if (round == 0 && B == T) {
                         // one batch, and on typical data every hypothesis is decided and scored by round 0: the final stage
                         // (best trial, its rho + mask, compaction) is enqueued BEFORE the host reads the flags, which saves a
-                        // host round trip with an idle GPU; if the flags say otherwise its output is simply recomputed below
+                        // host round trip with an idle GPU; if the flags say otherwise its output is simply recomputed below.
+                        // Where the context's previous solve needed the separate scoring pass (noise-free data: every hypothesis
+                        // ends after three accepted steps, which round 0 does not score), that pass is enqueued ahead of the final
+                        // stage as well: it only touches hypotheses round 0 left unscored (a no-op on other data) and saves the
+                        // round trip plus a discarded final stage (~57 us).  What is enqueued when never changes a result.
+                        if (c->ransac_score_hint) {
+                            rc = ransac_score_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp, T, d_states, depth_mode, tol, d_scored, d_partials,
+                                                     d_tcount, d_terr);
+                            if (rc != RSDSFM_OK) return rc;
+                            spec_scored = true;
+                        }
                         rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, h_best);
                         if (rc != RSDSFM_OK) return rc;
                         rc = ransac_final_launch(c, d_q, d_u, d_a, d_ak, n, d_best, d_states, depth_mode, tol, d_rho, d_mask, d_bcounts,
@@ -161,6 +171,8 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
                     final_done = false;  // more LM rounds: the speculated final stage saw incomplete trials
                 }
                 need_score = h_running[1] > 0;  // hypotheses whose final iterate is not the fused one-step state
+                if (B == T) c->ransac_score_hint = need_score ? 1 : 0;
+                if (need_score && final_done && spec_scored) need_score = false;  // round 0 decided everything and the pass already ran
                 if (need_score) final_done = false;
             }
             if (need_score) {

@@ -91,6 +91,7 @@ struct Ctx {
     LmState* h_lm = nullptr;       // pinned host copy
     int lm_issued_k = 0;           // depth_lm_kernel launches issued for the current solve
     int true_flow_exhaustive = 0;  // ground-truth flow search: 0 = interval-pruned from 96 scanlines on (default), 1 = every scanline for every pixel, 2 = pruned at any size
+    int ransac_score_hint = 0;     // 1: the previous solve needed the separate scoring pass behind round 0 (it is then enqueued ahead of the host's flag read)
     int refine_iters_hint = -1;    // LM iterations the context's previous refinement took (-1: none yet): length of the first chunk the host enqueues
     int lm_issued_d = 0;           // depth_lm_decide_kernel launches issued for the current solve
     // staging buffers for the host-pointer API (grown on demand)

@@ -105,6 +105,36 @@ def test_solve_frame_is_bit_reproducible(rsdsfm):
     assert all(o == outs[0] for o in outs[1:])
 
 
+def test_solve_does_not_depend_on_the_contexts_history(rsdsfm):
+    """a context remembers how its previous solve went -- whether the separate scoring pass was needed (noise-free data), how many
+    refinement iterations it took, which depth iterate was right -- only to decide what it enqueues AHEAD of the host's reads; a
+    frame solved behind frames of the other kind returns the bits of the same frame on a fresh context"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    frames = []
+    for cfg in (1, 5, 3):  # noise-free (three accepted steps, one refinement iteration), DeepFlow-like, noisy
+        d = rsdsfm.synth.make_config(cfg, rows=150, cols=260)
+        frames.append((d, torch.from_numpy(d["flow_img"]).to(dev)))
+
+    def solve(s, k):
+        d, img = frames[k]
+        dm = torch.zeros((d["cols"], d["rows"]), dtype=torch.float64, device=dev)
+        r = s.solve_frame_dev(img.data_ptr(), d["rows"], d["cols"], d["K"], d["gamma"], dm.data_ptr(), trials=20, tol=0.01, seed=5)
+        s.synchronize()
+        return (r["num_inliers"], r["best_trial"], r["v"].tobytes(), r["w"].tobytes(), r["k"], r["refine_summary"]["final_cost"],
+                r["refine_summary"]["num_iterations"], dm.cpu().numpy().tobytes())
+
+    fresh = []
+    for k in range(3):
+        with rsdsfm.Solver(0) as s:
+            fresh.append(solve(s, k))
+    assert fresh[0][6] <= 2 < fresh[1][6]  # the regimes differ the way the hints care about
+    with rsdsfm.Solver(0) as s:
+        for k in (0, 0, 1, 1, 0, 2, 0, 1, 2, 2, 0):
+            assert solve(s, k) == fresh[k], k
+
+
 def test_concurrent_contexts_do_not_interfere(oracle, rsdsfm):
     """the sequence-throughput mode of bench.py: several contexts on separate streams, (a) one host thread interleaving
     asynchronous depth solves of DIFFERENT problems, (b) one host thread per context running whole-frame solves -- every

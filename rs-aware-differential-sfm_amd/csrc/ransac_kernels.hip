@@ -464,6 +464,8 @@ __global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __rest
     extern __shared__ double s_acc[];  // [T][2]
     __shared__ LmPlanLds plan;
     __shared__ double s_red[2][kRB / 64][2];
+    __shared__ double s_T2[kRB / 64][2 * kTStride];
+    __shared__ double s_half2[kRB / 64][2][2];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int tb, grp;
     tile_group_of_block((int)blockIdx.x, ntile_blocks, ngroups, tb, grp);
@@ -513,10 +515,24 @@ __global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __rest
                 }
             }
             double(*red)[2] = s_red[t & 1];
-            double rc = wave_sum(cnt), re = wave_sum(es);
-            if (lane == 0) {
-                red[wv][0] = rc;
-                red[wv][1] = re;
+            // the wave's two sums in the order ransac_lm_kernel adds its fused scores (transposed through LDS: each half of the wave
+            // in lane order, then the halves) -- the inlier-error sum of a hypothesis has the same bits whichever kernel forms it
+            {
+                double* Tw = s_T2[wv];
+                Tw[lane] = cnt;
+                Tw[kTStride + lane] = es;
+                __builtin_amdgcn_wave_barrier();
+                const int sl = lane & 31, half = lane >> 5;
+                if (sl < 2) {
+                    const double* row = Tw + sl * kTStride + half * 32;
+                    double part = row[0];
+#pragma unroll
+                    for (int j = 1; j < 32; ++j) part += row[j];
+                    s_half2[wv][half][sl] = part;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane < 2) red[wv][lane] = s_half2[wv][0][lane] + s_half2[wv][1][lane];
+                __builtin_amdgcn_wave_barrier();
             }
             __syncthreads();
             if (tid < 2) {
@@ -532,6 +548,28 @@ __global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __rest
     for (int i = t_begin * 2 + tid; i < t_end * 2; i += kRB) out[i] = s_acc[i];
 }
 
+// the two score sums of hypothesis t over the tile blocks in the order reduce_hyp_sums (ransac_decide_kernel) adds a slot of the
+// fused rows: row group g adds the rows g, g + G, g + 2 G, ... in order, then the G group sums are added in order
+__device__ __forceinline__ void reduce_score_rows(const double* __restrict__ partials, int nblocks, int T, int t, double& c_out, double& e_out) {
+    constexpr int G = 256 / (NSR / 2);
+    __shared__ double s_grp[G][2];
+    const int tid = threadIdx.x;
+    if (tid < G) {
+        double c = 0.0, e = 0.0;
+        for (int b = tid; b < nblocks; b += G) {
+            c += partials[((int64_t)b * T + t) * 2 + 0];
+            e += partials[((int64_t)b * T + t) * 2 + 1];
+        }
+        s_grp[tid][0] = c;
+        s_grp[tid][1] = e;
+    }
+    __syncthreads();
+    double c = s_grp[0][0], e = s_grp[0][1];
+#pragma unroll
+    for (int g2 = 1; g2 < G; ++g2) c += s_grp[g2][0], e += s_grp[g2][1];
+    c_out = c, e_out = e;
+}
+
 // fixed-order reduction of one hypothesis batch's score partials into trial_count / trial_err (already offset):
 // one workgroup per hypothesis, threads stride over the pixel workgroups (independent loads in flight), then a
 // DPP wave reduction and the 4 waves in order
@@ -539,24 +577,13 @@ __global__ __launch_bounds__(256) void ransac_reduce_scores_kernel(const double*
                                                                   const int* __restrict__ scored,
                                                                   double* __restrict__ trial_count,
                                                                   double* __restrict__ trial_err) {
-    __shared__ double s_red[4][2];
-    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int t = blockIdx.x, tid = threadIdx.x;
     if (scored && scored[t]) return;
-    double c = 0.0, e = 0.0;
-    for (int b = tid; b < nblocks; b += 256) {
-        c += partials[((int64_t)b * T + t) * 2 + 0];
-        e += partials[((int64_t)b * T + t) * 2 + 1];
-    }
-    c = wave_sum(c);
-    e = wave_sum(e);
-    if (lane == 0) {
-        s_red[wv][0] = c;
-        s_red[wv][1] = e;
-    }
-    __syncthreads();
+    double c, e;
+    reduce_score_rows(partials, nblocks, T, t, c, e);
     if (tid == 0) {
-        trial_count[t] = ((s_red[0][0] + s_red[1][0]) + s_red[2][0]) + s_red[3][0];
-        trial_err[t] = ((s_red[0][1] + s_red[1][1]) + s_red[2][1]) + s_red[3][1];
+        trial_count[t] = c;
+        trial_err[t] = e;
     }
 }
 

@@ -206,7 +206,7 @@ def test_ransac_speculation_depth_does_not_change_results(oracle, rsdsfm, cfg, r
     """rsdsfm_set_ransac_speculation: round 0 of the hypothesis-batched LM solves speculates 3 iterations (+ fused scores of the one-
     and two-step iterates) or 2 (+ the one-step score).  Mixed step counts (DeepFlow-like data: mostly two accepted steps), noise-
     free data (2-3 steps) and outlier-dominated data (one step, decided by either depth in a single pass): every integer output is
-    identical for both depths and equal to the oracle's, floats agree to the summation order of the error sums"""
+    identical for both depths and equal to the oracle's, and so are the bits of every float -- the error sums included"""
     d = rsdsfm.synth.make_config(cfg, rows=rows, cols=cols)
     q, u, a, ak = d["q"], d["u"].copy(), d["alpha"], d["alpha_k"]
     if noise is not None:  # gross errors on a third of the points: the cost is dominated by them, every solve stops after one step
@@ -222,8 +222,10 @@ def test_ransac_speculation_depth_does_not_change_results(oracle, rsdsfm, cfg, r
             s.set_ransac_speculation(k0)
             r = s.ransac(q, u, a, ak, False, T, tol, samples=samples, depth_mode=1)
             _compare_ransac(r, ro)
+            # trial_err included: whichever kernel forms the inlier-error sum of a hypothesis (round 0's fused score or the separate
+            # scoring pass) adds the same numbers in the same order
             outs.append((r["trial_count"].tobytes(), r["trial_steps"].tobytes(), r["mask"].tobytes(), r["inv_depth"].tobytes(),
-                         r["inliers"].tobytes(), r["best_trial"]))
+                         r["inliers"].tobytes(), r["best_trial"], r["trial_err"].tobytes()))
         with pytest.raises(rsdsfm.RsdsfmError):
             s.set_ransac_speculation(1)
     assert all(o == outs[0] for o in outs[1:])

@@ -117,8 +117,9 @@ int rsdsfm_synchronize(rsdsfm_ctx* ctx);
 int rsdsfm_set_depth_variant(rsdsfm_ctx* ctx, int variant);
 /* LM iterations that round 0 of the hypothesis-batched depth solves inside rsdsfm_ransac* speculates per pixel: 3 (default, also
  * selected by 0) decides every hypothesis that ends with <= 2 accepted steps in one pass; 2 is cheaper when every hypothesis stops
- * after ONE accepted step (outlier-dominated data); hypotheses that need more take a continuation round.  Integer results (counts,
- * masks, LM steps, winner) are identical for both; the inlier-error sums of two-step hypotheses can differ in their last bits. */
+ * after ONE accepted step (outlier-dominated data); hypotheses that need more take a continuation round.  Every result is
+ * identical for both, bit for bit (round 0 also scores the iterate most hypotheses of the context's previous solve ended at; all
+ * other hypotheses are scored by a separate pass that adds the inlier errors in the same order). */
 int rsdsfm_set_ransac_speculation(rsdsfm_ctx* ctx, int k0);
 /* Opt-in profiling: while on, rsdsfm_ransac* / rsdsfm_solve_frame_dev bracket the dominant kernel of the whole solve -- round 0
  * of the hypothesis-batched LM depth solves, `ransac_lm_kernel<true, 3>` -- with two HIP events on the context's stream (in

@@ -91,7 +91,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     const int batch = std::min(Tn, kRansacBatch);
     size_t need = Arena::need(sizeof(double) * Tn * 8) +
                   Arena::need(sizeof(LmState) * Tn) + Arena::need(sizeof(double) * (size_t)ransac_lm_partials_doubles(c, n, batch)) +
-                  Arena::need(sizeof(int) * 4) + Arena::need(sizeof(int) * Tn) + 2 * Arena::need(sizeof(double) * Tn) + Arena::need(sizeof(RansacBest)) +
+                  Arena::need(sizeof(int) * 8) + Arena::need(sizeof(int) * Tn) + 2 * Arena::need(sizeof(double) * Tn) + Arena::need(sizeof(RansacBest)) +
                   2 * Arena::need(sizeof(int64_t) * 2048) + Arena::need(sizeof(double) * (size_t)n) + Arena::need((size_t)n) + 4096;
     int rc = ensure_ws(c, need);
     if (rc != RSDSFM_OK) return rc;
@@ -101,7 +101,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     char* zero_begin = ws.base + ws.off;
     LmState* d_states = ws.take<LmState>(Tn);
     int* d_scored = ws.take<int>(Tn);
-    int* d_flags = ws.take<int>(4);  // {running, unscored, not finished with <= 1 accepted step (predictor input), -}
+    int* d_flags = ws.take<int>(8);  // {running, unscored, not finished with <= 1 accepted step, -, ended after 0 / 1 / 2 / >= 3 accepted steps}
     const size_t zero_bytes = (size_t)((ws.base + ws.off) - zero_begin);
     double* d_partials = ws.take<double>((size_t)ransac_lm_partials_doubles(c, n, batch));
     double* d_tcount = ws.take<double>(Tn);
@@ -112,13 +112,13 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     double* d_rho = out->inv_depth ? out->inv_depth : ws.take<double>((size_t)n);
     uint8_t* d_mask = out->mask ? out->mask : ws.take<uint8_t>((size_t)n);
 
-    rc = ensure_pinned(c, sizeof(RansacBest) + 2 * sizeof(int) + sizeof(double) * 2 * Tn + sizeof(double) * 8 * Tn + sizeof(LmState) * Tn + 64 +
+    rc = ensure_pinned(c, sizeof(RansacBest) + 8 * sizeof(int) + sizeof(double) * 2 * Tn + sizeof(double) * 8 * Tn + sizeof(LmState) * Tn + 64 +
                               sizeof(int32_t) * (size_t)Tn * 9);
     if (rc != RSDSFM_OK) return rc;
     char* hp = static_cast<char*>(c->h_pinned);
     RansacBest* h_best = reinterpret_cast<RansacBest*>(hp);
     int* h_running = reinterpret_cast<int*>(hp + sizeof(RansacBest));
-    double* h_tcount = reinterpret_cast<double*>(hp + sizeof(RansacBest) + 16);
+    double* h_tcount = reinterpret_cast<double*>(hp + sizeof(RansacBest) + 32);
     double* h_terr = h_tcount + Tn;
     double* h_hyp = h_terr + Tn;
     LmState* h_states = reinterpret_cast<LmState*>(h_hyp + (size_t)8 * Tn);
@@ -128,6 +128,9 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
     bool final_done = false, spec_scored = false;
     const int k0 = c->ransac_k0;  // speculation depth of round 0 (see ransac_kernels.hip)
+    // the speculated iterate whose inlier score round 0 fuses: where most hypotheses of the context's previous solve ended (two
+    // iterations can only confirm an end after ONE accepted step).  A scheduling decision: the results do not depend on it.
+    const int fused_base = k0 == 2 ? 1 : std::min(std::max(c->ransac_fused_base, 1), (int)KMAX);
     int not_one_step = 0;
     if (T > 0) {
         memcpy(h_samples_pinned, samples.data(), sizeof(int32_t) * (size_t)T * 9);
@@ -137,11 +140,11 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
             const int B = std::min(batch, T - b0);
             bool need_score = true;
             if (depth_mode == RSDSFM_DEPTH_CERES_LM) {
-                if (b0 > 0) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_flags, 0, sizeof(int) * 4, c->stream));  // batch 0: cleared above
+                if (b0 > 0) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_flags, 0, sizeof(int) * 8, c->stream));  // batch 0: cleared above
                 for (int round = 0;; ++round) {
                     if (round > 4 * kMaxIter) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machines did not terminate");
                     rc = ransac_lm_round_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, d_partials, d_flags,
-                                                d_scored + b0, d_tcount + b0, d_terr + b0, round, tol, k0);
+                                                d_scored + b0, d_tcount + b0, d_terr + b0, round, tol, k0, fused_base);
                     if (rc != RSDSFM_OK) return rc;
                     if (round == 0 && B == T) {
                         // one batch, and on typical data every hypothesis is decided and scored by round 0: the final stage
@@ -164,9 +167,17 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
                         if (rc != RSDSFM_OK) return rc;
                         final_done = true;
                     }
-                    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_running, d_flags, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+                    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_running, d_flags, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
                     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-                    if (round == 0) not_one_step += h_running[2];
+                    if (round == 0) {
+                        not_one_step += h_running[2];
+                        if (b0 == 0) {  // where this solve's hypotheses ended: the state the context's next solve fuses the score of
+                            int best = 0;
+                            for (int a2 = 1; a2 <= 3; ++a2)
+                                if (h_running[4 + a2] > (best ? h_running[4 + best] : 0)) best = a2;
+                            if (best) c->ransac_fused_base = best;
+                        }
+                    }
                     if (h_running[0] == 0) break;
                     final_done = false;  // more LM rounds: the speculated final stage saw incomplete trials
                 }

@@ -31,15 +31,17 @@ constexpr int kRB = 256;  // workgroup size of the pixel kernels
 constexpr int kRP = RSDSFM_FUSED ? 5 : 6;  // (the fused build's point_error does not share terms with the pixel model: 6 would take 256 VGPRs and one wave per SIMD there)
                                         // pixels per thread per tile, register-resident across the hypothesis loop: every hypothesis pays one workgroup reduction of its 22 sums per tile, so more pixels per thread amortise it (round 1, fused model: 4 / 5: 451 / 419 us, 6 dropped to one wave per SIMD; round 2, reference arithmetic with the scores taken from the pixel model: 5 / 6: 0.476 / 0.471 ms at 246 VGPRs, 6.60 / 6.42 ms for the 4K tiled solve; 7 / 8 fit 256 VGPRs without scratch but run at 0.59 / 0.58 ms)
 // LM iterations speculated in round 0 (template parameter K0 of ransac_lm_kernel<true, K0>): KMAX = 3 (default) decides every
-// hypothesis that ends with <= 2 accepted steps in one pass and fuses the inlier scores {count, sum err} of the iterates after ONE
-// and after TWO accepted steps.  DeepFlow-like data (0.3 px noise + 10 % outliers) ends with TWO accepted steps for ~96 % of the
-// hypotheses (the third iteration's candidate fails the function tolerance), so that is the right default.  K0 = 2
-// (rsdsfm_set_ransac_speculation) speculates two iterations and fuses only the one-step score: cheaper when every hypothesis
-// stops after one accepted step (outlier-dominated costs); hypotheses that need more take the generic continuation round and the
-// separate score pass.  All integer results are identical for both depths; the inlier-error SUM of a two-step hypothesis is then
-// formed by ransac_score_kernel instead of this kernel (another summation order: last bits), which is why the depth is an explicit
-// setting and not a per-context predictor -- a solve's result never depends on the context's history.
-constexpr int kFused = 2;
+// hypothesis that ends with <= 2 accepted steps in one pass; K0 = 2 (rsdsfm_set_ransac_speculation) speculates two iterations,
+// cheaper when every hypothesis stops after one accepted step (outlier-dominated costs).  Round 0 also fuses the inlier score
+// {count, sum err} of ONE of the speculated iterates, the one after `fused_base` accepted steps: hypotheses that end there are
+// scored without another pass over the pixels, all others by ransac_score_kernel.  DeepFlow-like data (0.3 px noise + 10 %
+// outliers) ends after TWO accepted steps for ~96 % of the hypotheses, noise-free data (ground-truth flow) after THREE for all of
+// them, outlier-dominated data after ONE: the base follows the context's previous solve (Ctx::ransac_fused_base).  That is a
+// scheduling decision only: both kernels add a hypothesis' inlier errors in the same order (wave halves in lane order, waves,
+// tiles, row groups), so the error sum has the same bits whichever of them forms it -- a solve's result never depends on the
+// context's history (tests/test_gpu_frame.py::test_solve_does_not_depend_on_the_contexts_history).
+constexpr int kFused = 1;
+constexpr int kTiledFusedBase = 2;  // the column-tiled (multi-GPU) solve: a fixed base, every rank must take the same decisions
 constexpr int NSR = NS + 2 * kFused;
 constexpr int kNSum = NSR - (KMAX + 1);  // sum slots (the KMAX + 1 gradient-max slots are reduced with fmax)
 constexpr int kTStride = 65;             // row stride of the per-wave transpose buffer (bank-conflict-free)
@@ -48,18 +50,19 @@ constexpr int kTStride = 65;             // row stride of the per-wave transpose
 template <int K0>
 struct R0Shape {
     static constexpr int NSk = 3 + 5 * K0;
-    static constexpr int F = (K0 >= KMAX) ? kFused : 1;
+    static constexpr int F = kFused;
     static constexpr int nsum = NSk - (K0 + 1) + 2 * F;
 };
 static_assert(R0Shape<KMAX>::nsum == kNSum, "full shape uses every sum slot");
 
-template <int F>
+// BIDX: the speculated iterate that is scored (fused_base - 1), -1: none
+template <int BIDX>
 struct ScoreHook {
     double x, y, ux, uy, al, ak, two_over, tol;
     const Pose* pose;
-    double* sc;  // [2 * kFused] = {count, err} per fused state
+    double* sc;  // {count, err} of the fused state
     __device__ __forceinline__ void operator()(int j, double rho, const PixelModel& m) const {
-        if (j < F) {
+        if (j == BIDX) {
 #if RSDSFM_FUSED
             (void)m;
             const double e = point_error(x, y, ux, uy, al, ak, *pose, two_over, rho);
@@ -67,8 +70,8 @@ struct ScoreHook {
             const double e = point_error_from_model(m, rho);  // bit-identical to point_error(...): device_math.hpp
 #endif
             if (e < tol) {
-                sc[2 * j] += 1.0;
-                sc[2 * j + 1] += e;
+                sc[0] += 1.0;
+                sc[1] += e;
             }
         }
     }
@@ -114,7 +117,7 @@ __device__ __forceinline__ void load_tile(Tile& t, const double2* __restrict__ q
 // ---------------------------------------------------------------------------------------------------
 // round 0: every hypothesis starts from the built-in plan; round r > 0: only hypotheses whose state machine is
 // still running (status 0) and expects launch r take part.  partials: [T][gridDim.x][NSR] (hypothesis-major).
-template <bool R0, int K0>
+template <bool R0, int K0, int BASE>
 __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
                                                        const double* __restrict__ alpha,
                                                        const double* __restrict__ alpha_k, int64_t n,
@@ -214,14 +217,14 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
             if (R0 && full_tile) {  // round 0, no ragged lanes: one straight-line block, the kRP pixel chains interleave
 #pragma unroll
                 for (int j = 0; j < kRP; ++j) {
-                    const ScoreHook<F> hook{px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], two_over, tol, &pose, sc};
+                    const ScoreHook<(R0 ? BASE - 1 : -1)> hook{px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], two_over, tol, &pose, sc};
                     (void)lm_pixel(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, pf, acc, hook);
                 }
             } else {
 #pragma unroll
                 for (int j = 0; j < kRP; ++j)
                     if (px.ok[j]) {
-                        const ScoreHook<F> hook{px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], two_over, tol, &pose, sc};
+                        const ScoreHook<(R0 ? BASE - 1 : -1)> hook{px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], two_over, tol, &pose, sc};
                         (void)lm_pixel(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, plan, acc, hook);
                     }
             }
@@ -363,7 +366,7 @@ __global__ __launch_bounds__(256) void ransac_lm_rows_kernel(const double* __res
 __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __restrict__ partials, int nblocks, int T, int hyp_major,
                                                            LmState* states, int64_t n, int round, int k0, int* flags, int* pred_flag,
                                                            int* __restrict__ scored, double* __restrict__ trial_count,
-                                                           double* __restrict__ trial_err) {
+                                                           double* __restrict__ trial_err, int fused_base, int* steps_hist) {
     __shared__ double s_red[4][NSR];
     __shared__ double s_sums[NSR];
     const int t = blockIdx.x;
@@ -374,14 +377,15 @@ __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __rest
     if (tid == 0) {
         LmScal st = *static_cast<const LmScal*>(state);
         const int used_K = (round == 0) ? k0 : st.K;
-        const int fused = (k0 >= KMAX) ? kFused : 1;
         lm_advance(st, state->hist, s_sums, n, round == 0, used_K, 0, round);
         if (pred_flag && round == 0 && (st.status == 0 || st.n_hist >= 2)) atomicAdd(pred_flag, 1);
+        // where the hypotheses of this solve end (1, 2, >= 3 accepted steps or still running after round 0): the next solve's fused_base
+        if (steps_hist && round == 0) atomicAdd(&steps_hist[st.status == 0 ? 3 : (st.n_hist < 1 ? 0 : (st.n_hist > 3 ? 3 : st.n_hist))], 1);
         if (st.status == 0) {
             atomicAdd(&flags[0], 1);
-        } else if (round == 0 && st.n_hist >= 1 && st.n_hist <= fused) {  // a fused iterate is the final one
-            trial_count[t] = s_sums[NS + 2 * (st.n_hist - 1)];
-            trial_err[t] = s_sums[NS + 2 * (st.n_hist - 1) + 1];
+        } else if (round == 0 && st.n_hist == fused_base) {  // the fused iterate is the final one
+            trial_count[t] = s_sums[NS];
+            trial_err[t] = s_sums[NS + 1];
             scored[t] = 1;
         } else {
             atomicAdd(&flags[1], 1);
@@ -472,6 +476,11 @@ __global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __rest
     if (tb >= ntile_blocks) return;
     const int per_group = (T + ngroups - 1) / ngroups;
     const int t_begin = grp * per_group, t_end = min(T, t_begin + per_group);
+    if (scored) {  // nothing to score in this group (the usual case when round 0 fused the right state): leave before touching a tile
+        bool any = false;
+        for (int t = t_begin; t < t_end; ++t) any = any || !scored[t];
+        if (!any) return;
+    }
     for (int i = tid; i < T * 2; i += kRB) s_acc[i] = 0.0;
     __syncthreads();
     const int64_t tile_pixels = (int64_t)kRB * kRP;
@@ -849,41 +858,50 @@ static int ransac_lm_groups(const Ctx* c, int grid, int T) {
 int ransac_lm_partials_doubles(const Ctx* c, int64_t n, int batch) { return ransac_pixel_grid(c, n) * batch * NSR; }
 
 static int lm_launch(Ctx* c, const dim3& g2, int k0, const double* q, const double* u, const double* a, const double* ak, int64_t n,
-                     const double* hyp, int T, const LmState* states, double* partials, int round, double tol, int* flags) {
+                     const double* hyp, int T, const LmState* states, double* partials, int round, double tol, int* flags, int fused_base) {
     const double2* q2 = reinterpret_cast<const double2*>(q);
     const double2* u2 = reinterpret_cast<const double2*>(u);
     const size_t lds = sizeof(double) * T * NSR;
     // g2 = (tile blocks, hypothesis groups) is flattened into a 1-D grid of windows of 8 tile blocks x groups (see the kernel)
     const int tiles = (int)g2.x, groups = (int)g2.y;
     const dim3 g1((unsigned)(((tiles + 7) / 8) * 8 * groups));
+#define RSDSFM_LM_LAUNCH(R0, K0, BASE) \
+    hipLaunchKernelGGL((ransac_lm_kernel<R0, K0, BASE>), g1, dim3(kRB), lds, c->stream, q2, u2, a, ak, n, hyp, T, states, partials, round, tol, flags, tiles, groups)
     if (round != 0)
-        hipLaunchKernelGGL((ransac_lm_kernel<false, KMAX>), g1, dim3(kRB), lds, c->stream, q2, u2, a, ak, n, hyp, T, states, partials, round, tol, flags, tiles, groups);
+        RSDSFM_LM_LAUNCH(false, KMAX, 0);  // continuation rounds score nothing
     else if (k0 == 2)
-        hipLaunchKernelGGL((ransac_lm_kernel<true, 2>), g1, dim3(kRB), lds, c->stream, q2, u2, a, ak, n, hyp, T, states, partials, round, tol, flags, tiles, groups);
+        RSDSFM_LM_LAUNCH(true, 2, 1);
+    else if (fused_base == 1)
+        RSDSFM_LM_LAUNCH(true, KMAX, 1);
+    else if (fused_base == 3)
+        RSDSFM_LM_LAUNCH(true, KMAX, 3);
     else
-        hipLaunchKernelGGL((ransac_lm_kernel<true, KMAX>), g1, dim3(kRB), lds, c->stream, q2, u2, a, ak, n, hyp, T, states, partials, round, tol, flags, tiles, groups);
+        RSDSFM_LM_LAUNCH(true, KMAX, 2);
+#undef RSDSFM_LM_LAUNCH
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
 
-// flags: device int[4] = {running, unscored, not-done-with-one-step, -}; flags[0] is cleared here, the others by the caller once
-// per batch.  k0 (2 or KMAX): LM iterations speculated by round 0 (the same value must be passed for every round of a batch).
+// flags: device int[8] = {running, unscored, not-done-with-one-step, -, hypotheses that ended after 0 / 1 / 2 / >= 3 (or not yet)
+// accepted steps}; flags[0] is cleared here, the others by the caller once per batch.  k0 (2 or KMAX): LM iterations speculated by
+// round 0; fused_base (1 .. k0): the speculated iterate whose score round 0 fuses (the same values for every round of a batch).
 int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                            const double* hyp, int T, LmState* states, double* partials, int* flags, int* scored,
-                           double* trial_count, double* trial_err, int round, double tol, int k0) {
+                           double* trial_count, double* trial_err, int round, double tol, int k0, int fused_base) {
     const int grid = ransac_pixel_grid(c, n);
     const dim3 g2(grid, ransac_lm_groups(c, grid, T));
     if (k0 != 2) k0 = KMAX;
+    if (fused_base < 1 || fused_base > k0) fused_base = std::min(2, k0);
     const bool prof = c->profile && round == 0 && c->ev_prof[0] && c->ev_prof[1];
     if (prof) RSDSFM_HIP_CHECK(c, hipEventRecord(c->ev_prof[0], c->stream));
-    int rc = lm_launch(c, g2, k0, q, u, a, ak, n, hyp, T, states, partials, round, tol, flags);
+    int rc = lm_launch(c, g2, k0, q, u, a, ak, n, hyp, T, states, partials, round, tol, flags, fused_base);
     if (rc != RSDSFM_OK) return rc;
     if (prof) {
         RSDSFM_HIP_CHECK(c, hipEventRecord(c->ev_prof[1], c->stream));
         c->prof_pending = true;
     }
     hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, 1, states, n, round, k0, flags, flags + 2, scored,
-                       trial_count, trial_err);
+                       trial_count, trial_err, fused_base, flags + 4);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
@@ -909,7 +927,7 @@ int ransac_lm_rows_launch(Ctx* c, const double* q, const double* u, const double
                           const double* hyp, int T, const LmState* states, double* partials, int round, double tol, double* rows) {
     const int grid = ransac_pixel_grid(c, n);
     const dim3 g2(grid, ransac_lm_groups(c, grid, T));
-    int rc = lm_launch(c, g2, KMAX, q, u, a, ak, n, hyp, T, states, partials, round, tol, nullptr);
+    int rc = lm_launch(c, g2, KMAX, q, u, a, ak, n, hyp, T, states, partials, round, tol, nullptr, kTiledFusedBase);
     if (rc != RSDSFM_OK) return rc;
     hipLaunchKernelGGL(ransac_lm_rows_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, states, round, rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
@@ -920,7 +938,7 @@ int ransac_decide_rows_launch(Ctx* c, const double* rows_all, int nranks, int T,
                               int* flags, int* scored, double* trial_count, double* trial_err) {
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(flags, 0, sizeof(int), c->stream));
     hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, rows_all, nranks, T, 0, states, n_total, round, (int)KMAX, flags,
-                       static_cast<int*>(nullptr), scored, trial_count, trial_err);
+                       static_cast<int*>(nullptr), scored, trial_count, trial_err, kTiledFusedBase, static_cast<int*>(nullptr));
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -91,6 +91,7 @@ struct Ctx {
     LmState* h_lm = nullptr;       // pinned host copy
     int lm_issued_k = 0;           // depth_lm_kernel launches issued for the current solve
     int true_flow_exhaustive = 0;  // ground-truth flow search: 0 = interval-pruned from 96 scanlines on (default), 1 = every scanline for every pixel, 2 = pruned at any size
+    int ransac_fused_base = 2;     // accepted steps after which most hypotheses of the previous solve ended: the iterate round 0 scores
     int ransac_score_hint = 0;     // 1: the previous solve needed the separate scoring pass behind round 0 (it is then enqueued ahead of the host's flag read)
     int refine_iters_hint = -1;    // LM iterations the context's previous refinement took (-1: none yet): length of the first chunk the host enqueues
     int lm_issued_d = 0;           // depth_lm_decide_kernel launches issued for the current solve
@@ -228,7 +229,7 @@ int ransac_pixel_grid(const Ctx* c, int64_t n);
 int ransac_lm_partials_doubles(const Ctx* c, int64_t n, int batch);
 int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                            const double* hyp, int T, LmState* states, double* partials, int* flags, int* scored,
-                           double* trial_count, double* trial_err, int round, double tol, int k0);
+                           double* trial_count, double* trial_err, int round, double tol, int k0, int fused_base);
 int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
                         double* partials, double* trial_count, double* trial_err);

@@ -115,14 +115,15 @@ int rsdsfm_synchronize(rsdsfm_ctx* ctx);
  * the separate decide kernel; 2 = the decision fused into the tail of launch 0 (experimental, measured slower); 3 = launch
  * 0, separate decide kernel, follow-up launch (the fast path before the fusion).  Same arithmetic, same results. */
 int rsdsfm_set_depth_variant(rsdsfm_ctx* ctx, int variant);
-/* LM iterations that round 0 of the hypothesis-batched depth solves inside rsdsfm_ransac* speculates per pixel: 3 (default, also
- * selected by 0) decides every hypothesis that ends with <= 2 accepted steps in one pass; 2 is cheaper when every hypothesis stops
- * after ONE accepted step (outlier-dominated data); hypotheses that need more take a continuation round.  Every result is
- * identical for both, bit for bit (round 0 also scores the iterate most hypotheses of the context's previous solve ended at; all
- * other hypotheses are scored by a separate pass that adds the inlier errors in the same order). */
+/* LM iterations that round 0 of the hypothesis-batched depth solves inside rsdsfm_ransac* speculates per pixel: 3 decides every
+ * hypothesis that ends with <= 2 accepted steps in one pass; 2 is cheaper when every hypothesis stops after ONE accepted step
+ * (outlier-dominated data); hypotheses that need more take a continuation round; 0 (default) follows the context's previous solve
+ * (2 when none of its hypotheses went beyond one accepted step).  Every result is identical for all settings, bit for bit: round 0
+ * also scores the iterate most hypotheses of the context's previous solve ended at, all other hypotheses are scored by a separate
+ * pass that adds the inlier errors in the same order. */
 int rsdsfm_set_ransac_speculation(rsdsfm_ctx* ctx, int k0);
 /* Opt-in profiling: while on, rsdsfm_ransac* / rsdsfm_solve_frame_dev bracket the dominant kernel of the whole solve -- round 0
- * of the hypothesis-batched LM depth solves, `ransac_lm_kernel<true, 3>` -- with two HIP events on the context's stream (in
+ * of the hypothesis-batched LM depth solves, `ransac_lm_kernel<true, 3, BASE>` -- with two HIP events on the context's stream (in
  * situ: same launch, same neighbours, same clocks as any other solve).  rsdsfm_profile_last_ms(ctx, "ransac_lm_round0", &ms)
  * returns the duration of that launch in the most recent call.  bench.py's roofline record uses it. */
 int rsdsfm_set_profiling(rsdsfm_ctx* ctx, int on);

@@ -204,8 +204,8 @@ int rsdsfm_profile_last_ms(rsdsfm_ctx* ctx, const char* what, double* ms) {
 
 int rsdsfm_set_ransac_speculation(rsdsfm_ctx* ctx, int k0) {
     CTX_OR_FAIL(ctx);
-    if (k0 != 0 && k0 != 2 && k0 != KMAX) return fail(c, RSDSFM_ERR_INVALID, "ransac speculation depth must be 0 (default = 3), 2 or 3");
-    c->ransac_k0 = k0 == 2 ? 2 : KMAX;
+    if (k0 != 0 && k0 != 2 && k0 != KMAX) return fail(c, RSDSFM_ERR_INVALID, "ransac speculation depth must be 0 (automatic, default), 2 or 3");
+    c->ransac_k0 = k0;
     return RSDSFM_OK;
 }
 

@@ -127,7 +127,9 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
 
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
     bool final_done = false, spec_scored = false;
-    const int k0 = c->ransac_k0;  // speculation depth of round 0 (see ransac_kernels.hip)
+    // speculation depth of round 0 (see ransac_kernels.hip): explicit, or two iterations behind a solve none of whose hypotheses
+    // went beyond one accepted step (outlier-dominated costs), three otherwise.  Like fused_base below: scheduling only.
+    const int k0 = c->ransac_k0 != 0 ? c->ransac_k0 : (c->ransac_not_one_step == 0 ? 2 : (int)KMAX);
     // the speculated iterate whose inlier score round 0 fuses: where most hypotheses of the context's previous solve ended (two
     // iterations can only confirm an end after ONE accepted step).  A scheduling decision: the results do not depend on it.
     const int fused_base = k0 == 2 ? 1 : std::min(std::max(c->ransac_fused_base, 1), (int)KMAX);
@@ -194,7 +196,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
             }
         }
     }
-    c->ransac_not_one_step = not_one_step;
+    if (depth_mode == RSDSFM_DEPTH_CERES_LM && T > 0) c->ransac_not_one_step = not_one_step;
     // best trial, its dense rho + mask, order-preserving compaction
     if (!final_done) {
         rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, h_best);  // h_best: host-mapped, written by the kernels

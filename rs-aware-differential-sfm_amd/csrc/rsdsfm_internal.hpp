@@ -107,8 +107,8 @@ struct Ctx {
     hipEvent_t ev_ready = nullptr;  // "value ready" event for stages whose host read does not have to wait for the whole stream
     size_t pinned_bytes = 0;
     int num_cus = 256;
-    int ransac_k0 = KMAX;      // LM iterations round 0 of the hypothesis-batched depth solves speculates (rsdsfm_set_ransac_speculation: 2 or KMAX)
-    int ransac_not_one_step = 0;  // diagnostic of the last RANSAC: hypotheses that did not stop after exactly one accepted step
+    int ransac_k0 = 0;         // LM iterations round 0 of the hypothesis-batched depth solves speculates (rsdsfm_set_ransac_speculation): 2, KMAX, or 0 = follow the previous solve (2 when none of its hypotheses went beyond one accepted step)
+    int ransac_not_one_step = -1; // last RANSAC: hypotheses that did not stop after at most one accepted step (-1: no solve yet)
     // opt-in profiling (rsdsfm_set_profiling): HIP events on the context's stream around the dominant kernel of the last RANSAC
     bool profile = false;
     hipEvent_t ev_prof[2] = {nullptr, nullptr};

@@ -161,6 +161,24 @@ int rsdsfm_refine(rsdsfm_ctx* ctx, const double* flow2n, int64_t n_flow, int64_t
                   const double v_in[3], const double w_in[3], double k_in, int const_acceleration,
                   int flow_index_mode, double* inliers_out_3m, double v_out[3], double w_out[3], double* k_out,
                   rsdsfm_lm_summary* summary_or_null);
+/* Trace of the joint refinement's trust-region iterations (the counterpart of Ceres' per-iteration log,
+ * `Solver::Summary::iterations` behind nonlinearRefinement.cc:228-230 `FullReport()`; diagnostic, off by default).
+ * rsdsfm_set_refine_trace(ctx, rows): rows > 0 makes every following refinement on this context (rsdsfm_refine*, the frame
+ * solves) record its first `rows` LM iterations in a context-owned device buffer; 0 switches it off.  The record is written by
+ * the kernel that takes the iteration's accept / reject / converge decision; results are unaffected.
+ * rsdsfm_get_refine_trace(ctx, out, rows): copies rows x RSDSFM_REFINE_TRACE_COLS doubles of the LAST refinement to the host;
+ * row i (iteration i + 1): [0] iteration number, [1] cost before the step, [2] cost of the candidate, [3] model cost change,
+ * [4] relative decrease (cost change / model change), [5] trust-region radius the step was computed with, [6] step norm,
+ * [7] outcome (RSDSFM_TRACE_*); entries the iteration never computed are NaN, rows beyond the last iteration are NaN. */
+#define RSDSFM_REFINE_TRACE_COLS 8
+#define RSDSFM_TRACE_REJECTED 0.0              /* relative decrease <= 1e-3: radius shrinks */
+#define RSDSFM_TRACE_ACCEPTED 1.0
+#define RSDSFM_TRACE_INVALID 2.0               /* the reduced system failed to factor, or model change <= 0 */
+#define RSDSFM_TRACE_PARAMETER_TOL 3.0         /* terminated: step norm below the parameter tolerance */
+#define RSDSFM_TRACE_FUNCTION_TOL 4.0          /* terminated: |cost change| below the function tolerance (candidate not applied) */
+#define RSDSFM_TRACE_ACCEPTED_GRADIENT_TOL 5.0 /* accepted, then terminated on the gradient tolerance */
+int rsdsfm_set_refine_trace(rsdsfm_ctx* ctx, int32_t rows);
+int rsdsfm_get_refine_trace(rsdsfm_ctx* ctx, double* trace_rows_x_8, int32_t rows);
 /* caller glue main.cc:398-444 / errorMeasure.cpp:66-111: column-major scan of the row-major flow image,
  * threshold, normalisation, alpha / alpha_k.  Outputs have capacity rows*cols; *n_out = kept points. */
 int rsdsfm_flatten(rsdsfm_ctx* ctx, const double* flow_img_rows_cols_2, int32_t rows, int32_t cols, double fx,

@@ -1140,6 +1140,20 @@ static int chol_solve(double* A, int n, const double* b, double* x) {
     return 0;
 }
 
+/* Optional per-iteration trace of rso_refine (test diagnostics): rows of 8 doubles laid out like the product's
+ * rsdsfm_get_refine_trace (include/rsdsfm.h): iteration, cost, candidate cost, model cost change, relative decrease,
+ * radius, step norm, outcome (0 rejected, 1 accepted, 2 invalid, 3 parameter tol, 4 function tol, 5 accepted + gradient tol);
+ * what an iteration never computed is NaN.  The caller NaN-fills the buffer. */
+static double* g_refine_trace = 0;
+static int g_refine_trace_rows = 0;
+void rso_set_refine_trace(double* buf, int rows) {
+    g_refine_trace = buf;
+    g_refine_trace_rows = buf ? rows : 0;
+}
+static double* refine_trace_row(int iteration) {
+    return (g_refine_trace && iteration >= 1 && iteration <= g_refine_trace_rows) ? g_refine_trace + (size_t)(iteration - 1) * 8 : 0;
+}
+
 int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl, const double* alpha,
                const double* alpha_k, const int64_t* inlier_idx, const double v_in[3], const double w_in[3],
                double k_in, int const_acceleration, int flow_index_mode, double* inl_out, double v_out[3],
@@ -1288,7 +1302,15 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
             }
             ccost *= 0.5;
         }
+        double* tr = refine_trace_row(iteration);
+        if (tr) {
+            tr[0] = (double)iteration;
+            tr[1] = cost;
+            tr[3] = model_change;
+            tr[5] = radius;
+        }
         if (!solve_ok || !(model_change > 0.0)) {
+            if (tr) tr[7] = 2.0;
             ++sm.num_unsuccessful_steps;
             if (++invalid >= CERES_MAX_INVALID) {
                 sm.termination = RSO_TERM_FAILURE;
@@ -1299,16 +1321,23 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
         }
         invalid = 0;
         double step_norm = sqrt(stepsq);
+        if (tr) {
+            tr[2] = ccost;
+            tr[6] = step_norm;
+        }
         if (step_norm <= CERES_PARAMETER_TOL * (x_norm + CERES_PARAMETER_TOL)) {
+            if (tr) tr[7] = 3.0;
             sm.termination = RSO_TERM_PARAMETER;
             break;
         }
         double cost_change = cost - ccost;
         if (fabs(cost_change) <= CERES_FUNCTION_TOL * cost) {
+            if (tr) tr[7] = 4.0;
             sm.termination = RSO_TERM_FUNCTION;
             break;
         }
         double rel = cost_change / model_change;
+        if (tr) tr[4] = rel;
         if (getenv("RSO_TRACE")) fprintf(stderr, "oracle it %d cost %.17g ccost %.17g model %.17g rel %.17g radius %.17g step %.6g\n", iteration, cost, ccost, model_change, rel, radius, step_norm);
         if (rel > CERES_MIN_REL_DECREASE) {
             memcpy(p, pc, sizeof(pc));
@@ -1339,7 +1368,9 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
             decrease_factor = 2.0;
             ++sm.num_successful_steps;
             if (gmax <= CERES_GRADIENT_TOL) sm.termination = RSO_TERM_GRADIENT;
+            if (tr) tr[7] = gmax <= CERES_GRADIENT_TOL ? 5.0 : 1.0;
         } else {
+            if (tr) tr[7] = 0.0;
             ++sm.num_unsuccessful_steps;
             radius = radius / decrease_factor;
             decrease_factor *= 2.0;

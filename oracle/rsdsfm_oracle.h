@@ -103,6 +103,8 @@ int rso_ransac(const double* q2n, const double* u2n, const double* alpha_n, cons
 
 /* nonlinearRefinement.cc:183-252.  flow_index_mode 0 = compat (quirk Q2: flow(.,rank)), 1 = gathered
  * (flow(., inlier_idx[rank])).  inliers_out is 3xM. */
+/* test diagnostics: per-iteration trace of the next rso_refine calls (rows x 8 doubles, caller NaN-fills; NULL = off) */
+void rso_set_refine_trace(double* buf, int rows);
 int rso_refine(const double* flow2n, int64_t n_flow, int64_t m, const double* inliers_3m,
                const double* alpha_m, const double* alpha_k_m, const int64_t* inlier_idx_or_null,
                const double v_in[3], const double w_in[3], double k_in, int const_acceleration,

@@ -29,6 +29,8 @@ ERR_PENDING = -5
 DEPTH_CLOSED_FORM, DEPTH_CERES_LM = 0, 1
 K_COMPAT, K_FIXED = 0, 1
 FLOW_COMPAT_RANK, FLOW_GATHERED = 0, 1
+REFINE_TRACE_COLS = 8  # rsdsfm_get_refine_trace
+TRACE_REJECTED, TRACE_ACCEPTED, TRACE_INVALID, TRACE_PARAMETER_TOL, TRACE_FUNCTION_TOL, TRACE_ACCEPTED_GRADIENT_TOL = 0.0, 1.0, 2.0, 3.0, 4.0, 5.0
 TERMINATION = {0: "gradient", 1: "parameter", 2: "function", 3: "max_iter", 4: "failure", 5: "min_radius"}
 
 _libs = {}
@@ -313,6 +315,19 @@ class Solver:
         sm = LmSummary()
         self._check(self.lib.rsdsfm_refine(self._ctx, _p(flow), C.c_int64(flow.shape[0]), C.c_int64(m), _p(inliers), _p(alpha), _p(alpha_k), _p(idx), _v3(v), _v3(w), C.c_double(k), int(const_acceleration), int(flow_index_mode), _p(out), vo, wo, C.byref(ko), C.byref(sm)), "rsdsfm_refine")
         return dict(inliers=out, v=np.array(vo[:]), w=np.array(wo[:]), k=ko.value, summary=sm.as_dict())
+
+    def set_refine_trace(self, rows):
+        """rows > 0: record the first `rows` LM iterations of every following refinement (rsdsfm_set_refine_trace); 0 = off"""
+        self._check(self.lib.rsdsfm_set_refine_trace(self._ctx, C.c_int32(int(rows))), "rsdsfm_set_refine_trace")
+        self._refine_trace_rows = int(rows)
+
+    def get_refine_trace(self, rows=None):
+        """(rows, 8) array of the last refinement: iteration, cost, candidate cost, model cost change, relative decrease, radius,
+        step norm, outcome (TRACE_*); NaN = not computed / no such iteration"""
+        rows = getattr(self, "_refine_trace_rows", 0) if rows is None else int(rows)
+        out = np.empty((max(rows, 1), REFINE_TRACE_COLS))
+        self._check(self.lib.rsdsfm_get_refine_trace(self._ctx, _p(out), C.c_int32(rows)), "rsdsfm_get_refine_trace")
+        return out[:rows]
 
     # ---- caller glue ----
     def flatten(self, flow_img, K, gamma, thr=1e-10):

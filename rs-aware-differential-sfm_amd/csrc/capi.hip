@@ -152,6 +152,7 @@ void rsdsfm_destroy(rsdsfm_ctx* ctx) {
     if (c->d_ws) (void)hipFree(c->d_ws);
     if (c->d_frame) (void)hipFree(c->d_frame);
     if (c->d_tile) (void)hipFree(c->d_tile);
+    if (c->d_refine_trace) (void)hipFree(c->d_refine_trace);
     delete static_cast<RefineBuffers*>(c->tile_session);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     dist_release(c);
@@ -199,6 +200,34 @@ int rsdsfm_profile_last_ms(rsdsfm_ctx* ctx, const char* what, double* ms) {
     float f = 0.f;
     RSDSFM_HIP_CHECK(c, hipEventElapsedTime(&f, c->ev_prof[0], c->ev_prof[1]));
     *ms = (double)f;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_set_refine_trace(rsdsfm_ctx* ctx, int32_t rows) {
+    CTX_OR_FAIL(ctx);
+    if (rows < 0 || rows > 4096) return fail(c, RSDSFM_ERR_INVALID, "refine trace: 0 <= rows <= 4096");
+    if (rows != c->refine_trace_rows) {
+        RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        if (c->d_refine_trace) RSDSFM_HIP_CHECK(c, hipFree(c->d_refine_trace));
+        c->d_refine_trace = nullptr;
+        c->refine_trace_rows = 0;
+        if (rows > 0) {
+            RSDSFM_HIP_CHECK(c, hipMalloc((void**)&c->d_refine_trace, (size_t)rows * kRefineTraceCols * sizeof(double)));
+            c->refine_trace_rows = rows;
+        }
+    }
+    if (c->d_refine_trace)  // all-ones bytes = NaN: "no such iteration"
+        RSDSFM_HIP_CHECK(c, hipMemsetAsync(c->d_refine_trace, 0xFF, (size_t)rows * kRefineTraceCols * sizeof(double), c->stream));
+    return RSDSFM_OK;
+}
+
+int rsdsfm_get_refine_trace(rsdsfm_ctx* ctx, double* out, int32_t rows) {
+    CTX_OR_FAIL(ctx);
+    if (!out || rows < 1) return fail(c, RSDSFM_ERR_INVALID, "refine trace: null output or rows < 1");
+    if (!c->d_refine_trace) return fail(c, RSDSFM_ERR_INVALID, "no refine trace: call rsdsfm_set_refine_trace(ctx, rows) before the refinement");
+    if (rows > c->refine_trace_rows) return fail(c, RSDSFM_ERR_INVALID, "refine trace: more rows requested than rsdsfm_set_refine_trace reserved");
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(out, c->d_refine_trace, (size_t)rows * kRefineTraceCols * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     return RSDSFM_OK;
 }
 

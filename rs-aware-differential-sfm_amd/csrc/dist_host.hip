@@ -564,6 +564,8 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
         h_state->radius = kInitialRadius;
         *h_bad = 0;
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(B.state, h_state, sizeof(RefineState) + sizeof(int), hipMemcpyHostToDevice, c->stream));
+        rc = refine_trace_reset(c);
+        if (rc != RSDSFM_OK) return rc;
         auto staged = [&](int stage) -> int {
             int rc2 = refine_stage_rows_launch(c, B, np, stage, d_row);
             if (rc2 != RSDSFM_OK) return rc2;

@@ -58,6 +58,8 @@ int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const
     hs->radius = kInitialRadius;
     *h_bad = 0;
     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(B.state, hs, sizeof(RefineState) + sizeof(int), hipMemcpyHostToDevice, c->stream));
+    rc = refine_trace_reset(c);
+    if (rc != RSDSFM_OK) return rc;
     rc = refine_init_launch(c, B, np);
     if (rc != RSDSFM_OK) return rc;
     // LM iterations are enqueued in chunks; the kernels of a finished solve return immediately, but an empty iteration still costs

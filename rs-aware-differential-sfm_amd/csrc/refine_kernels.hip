@@ -535,7 +535,7 @@ __global__ __launch_bounds__(kFB) void refine_backsub_kernel(int64_t m, const do
 
 template <int NP>
 __global__ __launch_bounds__(kFB) void refine_decide_kernel(const double* __restrict__ partials, int nblocks,
-                                                           RefineState* st) {
+                                                           RefineState* st, double* __restrict__ trace, int trace_rows) {
     using CT = Counts<NP>;
     __shared__ double s_red[kFB / 64][CT::NBACK];
     __shared__ double s[CT::NBACK];
@@ -543,8 +543,18 @@ __global__ __launch_bounds__(kFB) void refine_decide_kernel(const double* __rest
     const int solve_ok = st->solve_ok;
     if (solve_ok) reduce_partials<CT::NBACK>(partials, nblocks, CT::BACK_MAX, s_red, s);
     if (threadIdx.x != 0) return;
+    // optional trace (rsdsfm_set_refine_trace): one row of kRefineTraceCols doubles per LM iteration, see include/rsdsfm.h
+    double* tr = (trace && st->iteration >= 1 && st->iteration <= trace_rows) ? trace + (int64_t)(st->iteration - 1) * kRefineTraceCols : nullptr;
     const double model_change = solve_ok ? s[0] : 0.0;
+    if (tr) {
+        tr[0] = (double)st->iteration;
+        tr[1] = st->cost;
+        tr[2] = tr[4] = tr[6] = __builtin_nan("");
+        tr[3] = model_change;
+        tr[5] = st->radius;
+    }
     if (!solve_ok || !(model_change > 0.0)) {  // HandleInvalidStep
+        if (tr) tr[7] = RSDSFM_TRACE_INVALID;
         st->num_unsuccessful += 1;
         st->invalid_run += 1;
         if (st->invalid_run >= kMaxInvalid) {
@@ -557,16 +567,23 @@ __global__ __launch_bounds__(kFB) void refine_decide_kernel(const double* __rest
     st->invalid_run = 0;
     const double step_norm = sqrt(st->stepsq_p + s[1]);
     const double ccost = 0.5 * s[2];
+    if (tr) {
+        tr[2] = ccost;
+        tr[6] = step_norm;
+    }
     if (step_norm <= kParameterTol * (st->x_norm + kParameterTol)) {
+        if (tr) tr[7] = RSDSFM_TRACE_PARAMETER_TOL;
         st->termination = RSDSFM_TERM_PARAMETER;
         return;
     }
     const double cost_change = st->cost - ccost;
     if (fabs(cost_change) <= kFunctionTol * st->cost) {
+        if (tr) tr[7] = RSDSFM_TRACE_FUNCTION_TOL;
         st->termination = RSDSFM_TERM_FUNCTION;
         return;
     }
     const double rel = cost_change / model_change;
+    if (tr) tr[4] = rel;
     if (rel > kMinRelDecrease) {  // HandleSuccessfulStep
         double gmax = s[CT::BACK_MAX], xsq = s[CT::BACK_MAX + 1];
         for (int c = 0; c < 7; ++c) st->p[c] = st->pc[c];
@@ -582,7 +599,9 @@ __global__ __launch_bounds__(kFB) void refine_decide_kernel(const double* __rest
         st->decrease_factor = 2.0;
         st->num_successful += 1;
         if (gmax <= kGradientTol) st->termination = RSDSFM_TERM_GRADIENT;
+        if (tr) tr[7] = gmax <= kGradientTol ? RSDSFM_TRACE_ACCEPTED_GRADIENT_TOL : RSDSFM_TRACE_ACCEPTED;
     } else {  // HandleUnsuccessfulStep
+        if (tr) tr[7] = RSDSFM_TRACE_REJECTED;
         st->num_unsuccessful += 1;
         st->radius = st->radius / st->decrease_factor;
         st->decrease_factor *= 2.0;
@@ -641,7 +660,7 @@ static int refine_iter_t(Ctx* c, const RefineBuffers& B) {
     hipLaunchKernelGGL(refine_backsub_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m, reinterpret_cast<const double4*>(B.uu), B.beta,
                        B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(refine_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, B.state);
+    hipLaunchKernelGGL(refine_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, B.state, c->d_refine_trace, c->refine_trace_rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
@@ -690,7 +709,7 @@ static int refine_stage_apply_t(Ctx* c, const RefineBuffers& B, int stage, const
     else if (stage == 1)
         hipLaunchKernelGGL(refine_solve_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state);
     else
-        hipLaunchKernelGGL(refine_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state);
+        hipLaunchKernelGGL(refine_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state, c->d_refine_trace, c->refine_trace_rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

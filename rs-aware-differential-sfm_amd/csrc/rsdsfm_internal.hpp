@@ -15,6 +15,7 @@ namespace rsdsfm {
 // only sets linear_solver_type = DENSE_SCHUR, nonlinearRefinement.cc:160-161, :225-226)
 // ---------------------------------------------------------------------------------------------------
 constexpr int kMaxIter = 50;
+constexpr int kRefineTraceCols = RSDSFM_REFINE_TRACE_COLS;
 constexpr double kInitialRadius = 1e4;
 constexpr double kMaxRadius = 1e16;
 constexpr double kMinRadius = 1e-32;
@@ -113,6 +114,9 @@ struct Ctx {
     bool profile = false;
     hipEvent_t ev_prof[2] = {nullptr, nullptr};
     bool prof_pending = false;
+    // opt-in trace of the joint refinement's LM iterations (rsdsfm_set_refine_trace): rows of kRefineTraceCols doubles, written by refine_decide_kernel
+    double* d_refine_trace = nullptr;
+    int refine_trace_rows = 0;
     int depth_variant = 0;  // 0 = register-staged depth_lm_kernel, 1 = LDS-DMA depth_lm_dma_kernel, 2 = launch 0 with the decision fused into its tail, 3 = separate decide kernel + follow-up launch (the pre-fusion fast path)
     // row-tiled refinement session (tiled_host.hip): buffers live in d_tile, not in the shared workspace
     void* d_tile = nullptr;
@@ -278,6 +282,11 @@ struct RefineBuffers {
     int* bad_index;
 };
 int refine_partials_doubles(const Ctx* c, int64_t m);
+// start of a refinement: NaN-fill the opt-in iteration trace (rsdsfm_set_refine_trace), enqueued on the context's stream
+inline int refine_trace_reset(Ctx* c) {
+    if (!c->d_refine_trace) return RSDSFM_OK;
+    return hipMemsetAsync(c->d_refine_trace, 0xFF, (size_t)c->refine_trace_rows * kRefineTraceCols * sizeof(double), c->stream) == hipSuccess ? RSDSFM_OK : RSDSFM_ERR_HIP;
+}
 int refine_init_launch(Ctx* c, const RefineBuffers& B, int np);
 int refine_iter_launch(Ctx* c, const RefineBuffers& B, int np);
 int refine_finish_launch(Ctx* c, const RefineBuffers& B, double* inl_out);

@@ -215,6 +215,8 @@ int rsdsfm_tile_refine_begin_dev(rsdsfm_ctx* ctx, const double* d_flow, int64_t 
     hs->radius = kInitialRadius;
     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(B.state, hs, sizeof(RefineState), hipMemcpyHostToDevice, c->stream));
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(B.bad_index, 0, sizeof(int), c->stream));
+    rc = refine_trace_reset(c);
+    if (rc != RSDSFM_OK) return rc;
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));  // the pinned block is reused by the polls
     return RSDSFM_OK;
 }

@@ -107,6 +107,34 @@ def _refine_deviation(x, ref):
                 depth_max=float(rel.max()) if len(rel) else 0.0, cost=abs(cx - cr) / max(abs(cr), 1e-18))
 
 
+def _first_divergence(s, O, u, r, ro, use_k):
+    """where a split trajectory leaves the oracle's: both sides re-run with their iteration traces (rsdsfm_set_refine_trace / the
+    oracle's own); returns the first iteration whose outcome differs, both outcomes, and how close the deciding quantity sat to its
+    threshold (relative decrease against 1e-3, |cost change| / cost against 1e-6) -- the margin a summation order has to flip"""
+    s.set_refine_trace(50)
+    try:
+        s.non_linear_refinement(u, r["inliers"], r["alpha"], r["alpha_k"], r["v"], r["w"], r["k"], use_k, flow_index_mode=1, inlier_idx=r["inlier_idx"])
+        tg = s.get_refine_trace()
+    finally:
+        s.set_refine_trace(0)
+    to = O.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], use_k, 1, ro["inlier_idx"], trace_rows=50)["trace"]
+    for i in range(50):
+        a, b = tg[i, 7], to[i, 7]
+        if np.isnan(a) and np.isnan(b):
+            break
+        if a != b and not (np.isnan(a) and np.isnan(b)):
+            out = dict(iteration=i + 1, gpu_outcome=float(a), oracle_outcome=float(b), radius=float(to[i, 5]))
+            for name, t in (("gpu", tg), ("oracle", to)):
+                cost, ccost, model = t[i, 1], t[i, 2], t[i, 3]
+                out[name + "_rel_decrease"] = float((cost - ccost) / model) if model > 0 else float("nan")
+                out[name + "_cost_change_over_cost"] = float(abs(cost - ccost) / cost) if cost > 0 else float("nan")
+            prev = slice(0, i)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                out["max_rel_diff_of_the_sums_before"] = float(np.nanmax(np.abs(tg[prev, 1:5] / to[prev, 1:5] - 1.0))) if i > 0 else 0.0
+            return out
+    return None
+
+
 def _oracle_reorderings(O, u, ro, use_k):
     """the oracle's refinement of the same problem with its inlier list re-ordered (reversed + 3 seeded random permutations): its
     own sums added in other orders.  What these runs disagree about is not defined by the reference's arithmetic."""
@@ -221,7 +249,10 @@ def main(cases=None, seed0=None):
                         assert not oracle_stable, ("refinement decisions differ although the oracle's trajectory is stable under re-ordering its sums", so, sr)
                         spread = max(abs(o2["summary"]["final_cost"] - sr["final_cost"]) for o2 in others)
                         # diagnostics of a failure: how far the results are apart (gauge-free), next to the oracle's own re-ordering spread
-                        diag = dict(gpu_vs_oracle=_refine_deviation(out, ref), oracle_reorderings=[_refine_deviation(o2, ref) for o2 in others])
+                        diag = dict(gpu_vs_oracle=_refine_deviation(out, ref), oracle_reorderings=[_refine_deviation(o2, ref) for o2 in others],
+                                    first_divergence=_first_divergence(s, O, u, r, ro, use_k))
+                        if os.environ.get("FUZZ_VERBOSE"):
+                            print("SPLIT", tag, diag["first_divergence"], flush=True)
                         assert so["termination"] in [sr["termination"]] + [o2["summary"]["termination"] for o2 in others], ("termination type of a split trajectory", so, sr, diag)
                         # (a trajectory cut off by the 50-iteration cap ends wherever its accept / reject pattern took it: one order
                         # of magnitude around the oracle's own spread is the bar, a lower cost than every oracle run is not a defect)

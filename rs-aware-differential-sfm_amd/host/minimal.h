@@ -6,11 +6,17 @@
 //  * RansacValues carries inlier_idx (the reference cannot express which points are inliers);
 //  * the sampler is the reference's partial Fisher-Yates driven by splitmix64(rsdsfm::ransac_seed()) instead of
 //    srand(time(NULL)) / rand()  (quirk Q1) -- set the seed with rsdsfm::set_ransac_seed();
-//  * failures throw std::runtime_error instead of producing garbage (the reference has no error path).
+//  * failures throw std::runtime_error instead of producing garbage (the reference has no error path);
+//  * show_messages prints what the reference prints (Ceres' BriefReport line, solve time, "Finished i RANSAC trials ...") to
+//    std::cout; the T trials of a RANSAC run as one batch on the GPU, so their lines appear after the batch and the
+//    per-trial depth-solve reports inside the RANSAC loop (minimal.cc:254) are not printed.
 #ifndef RSDSFM_HOST_MINIMAL_H
 #define RSDSFM_HOST_MINIMAL_H
 
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <iostream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -43,6 +49,18 @@ inline int& depth_mode() {
     static int mode = RSDSFM_DEPTH_CERES_LM;  // what the reference's Ceres solve produces
     return mode;
 }
+// the line ceres::Solver::Summary::BriefReport() returns (Ceres 1.14 solver.cc: iterations = successful + unsuccessful steps)
+inline std::string brief_report(const rsdsfm_lm_summary& s) {
+    const char* term = (s.termination == RSDSFM_TERM_MAX_ITER) ? "NO_CONVERGENCE" : (s.termination == RSDSFM_TERM_FAILURE) ? "FAILURE" : "CONVERGENCE";
+    char buf[256];
+    std::snprintf(buf, sizeof(buf), "Ceres Solver Report: Iterations: %d, Initial cost: %e, Final cost: %e, Termination: %s",
+                  (int)(s.num_successful_steps + s.num_unsuccessful_steps), s.initial_cost, s.final_cost, term);
+    return buf;
+}
+struct StopWatch {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    double seconds() const { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
 inline void check(int rc, const char* what) {
     if (rc != RSDSFM_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + rsdsfm_last_error(default_context()));
 }
@@ -113,7 +131,6 @@ inline ArrayXd getAlphaK(const Array2Xd& q, const Array2Xd& flow, double h, doub
 /** reference minimal.cc:209-306 */
 inline RansacValues ransac(const Array2Xd& q, const Array2Xd& u, const ArrayXd& alpha, const ArrayXd& alpha_k, bool use_alpha_k,
                            int iterations, double tolerance, bool show_messages) {
-    (void)show_messages;
     const long n = q.cols();
     Array3Xd inl(3, n);
     VectorXd a(n), ak(n);
@@ -123,9 +140,26 @@ inline RansacValues ransac(const Array2Xd& q, const Array2Xd& u, const ArrayXd& 
     out.alpha = a.data();
     out.alpha_k = ak.data();
     out.inlier_idx = idx.data();
+    std::vector<int64_t> trial_count(show_messages && iterations > 0 ? (size_t)iterations : 0);
+    std::vector<double> trial_err(trial_count.size());
+    if (!trial_count.empty()) {
+        out.trial_count = trial_count.data();
+        out.trial_err = trial_err.data();
+    }
     rsdsfm::check(rsdsfm_ransac(rsdsfm::default_context(), q.data(), u.data(), alpha.data(), alpha_k.data(), n, use_alpha_k ? 1 : 0,
                                 iterations, tolerance, nullptr, rsdsfm::ransac_seed(), rsdsfm::depth_mode(), RSDSFM_K_COMPAT, &out),
                   "rsdsfm_ransac");
+    if (show_messages) {  // minimal.cc:278-288: best = more inliers, ties by the smaller error sum
+        int64_t best = 0;
+        double best_err = 0.0;
+        for (size_t i = 0; i < trial_count.size(); ++i) {
+            if (trial_count[i] > best || (trial_count[i] == best && trial_err[i] < best_err)) {
+                best = trial_count[i];
+                best_err = trial_err[i];
+            }
+            std::cout << "Finished " << i + 1 << " RANSAC trials. The current maximum number of inliers is " << best << "." << std::endl;
+        }
+    }
     const long m = (long)out.num_inliers;
     inl.conservativeResize(3, m);
     a.conservativeResize(m);

@@ -46,13 +46,19 @@ private:
 inline ArrayXd estimateInverseDepths(const Array2Xd& normalized_coordinates, const Array2Xd& flow, const Vector3d& linear_velocity,
                                      const Vector3d& angular_velocity, const double& k, const ArrayXd& alpha, const ArrayXd& alphaK,
                                      bool show_messages) {
-    (void)show_messages;
     const long n = normalized_coordinates.cols();
     ArrayXd rho(n);
+    rsdsfm_lm_summary summary = {};
+    rsdsfm::StopWatch watch;
     rsdsfm::check(rsdsfm_estimate_inverse_depths(rsdsfm::default_context(), normalized_coordinates.data(), flow.data(), n,
                                                  linear_velocity.data(), angular_velocity.data(), k, alpha.data(), alphaK.data(),
-                                                 rsdsfm::depth_mode(), rho.data(), nullptr),
+                                                 rsdsfm::depth_mode(), rho.data(), &summary),
                   "rsdsfm_estimate_inverse_depths");
+    if (show_messages) {  // nonlinearRefinement.cc:165-169
+        std::cout << std::endl;
+        std::cout << rsdsfm::brief_report(summary) << std::endl;
+        std::cout << "Total time for solving optimization: " << watch.seconds() << " s" << std::endl;
+    }
     return rho;
 }
 
@@ -60,11 +66,15 @@ inline ArrayXd estimateInverseDepths(const Array2Xd& normalized_coordinates, con
 inline double estimateInverseDepth(const Vector2d& normalized_coordinates, const Vector3d& linear_velocity,
                                    const Vector3d& angular_velocity, const Vector2d& flow, const double& k, const double& alpha,
                                    const double& alphaK, bool show_messages) {
-    (void)show_messages;
     double rho = 1.0;
+    rsdsfm_lm_summary summary = {};
     rsdsfm::check(rsdsfm_estimate_inverse_depths(rsdsfm::default_context(), normalized_coordinates.data(), flow.data(), 1, linear_velocity.data(),
-                                                 angular_velocity.data(), k, &alpha, &alphaK, rsdsfm::depth_mode(), &rho, nullptr),
+                                                 angular_velocity.data(), k, &alpha, &alphaK, rsdsfm::depth_mode(), &rho, &summary),
                   "rsdsfm_estimate_inverse_depths");
+    if (show_messages) {  // nonlinearRefinement.cc:100-103
+        std::cout << rsdsfm::brief_report(summary) << std::endl;
+        std::cout << rho << std::endl;
+    }
     return rho;
 }
 
@@ -75,17 +85,23 @@ inline int& flow_index_mode() {
     return mode;
 }
 inline RansacValues nonLinearRefinement(const Array2Xd& flow, const RansacValues& inliers, bool const_acceleration, bool show_messages) {
-    (void)show_messages;
     const long m = inliers.num_inliers;
     Array3Xd out(3, m);
     Vector3d v, w;
     double k = 0;
+    rsdsfm_lm_summary summary = {};
+    rsdsfm::StopWatch watch;
     rsdsfm::check(rsdsfm_refine(rsdsfm::default_context(), flow.data(), flow.cols(), m, inliers.inliers.data(), inliers.alpha.data(),
                                 inliers.alpha_k.data(), inliers.inlier_idx.empty() ? nullptr : inliers.inlier_idx.data(),
                                 inliers.v.data(), inliers.w.data(), inliers.k, const_acceleration ? 1 : 0,
                                 inliers.inlier_idx.empty() ? RSDSFM_FLOW_COMPAT_RANK : flow_index_mode(), out.data(), v.data(), w.data(),
-                                &k, nullptr),
+                                &k, &summary),
                   "rsdsfm_refine");
+    if (show_messages) {  // nonlinearRefinement.cc:230-234
+        std::cout << rsdsfm::brief_report(summary) << std::endl;
+        std::cout << "Total time for solving optimization: " << watch.seconds() << " s" << std::endl;
+        std::cout << std::endl;
+    }
     RansacValues r(inliers.num_inliers, out, inliers.alpha, inliers.alpha_k, w, v, k);
     r.inlier_idx = inliers.inlier_idx;
     return r;

@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
         // run ransac (main.cc:447), then the nonlinear refinement (main.cc:457) on the gathered flow
         RansacValues ransac_results = minimal::ransac(coord, flow, alpha, alphaK, false, ransac_trials, ransac_tol, true);
         nonlinear_refinement::flow_index_mode() = RSDSFM_FLOW_GATHERED;
-        RansacValues results = nonlinear_refinement::nonLinearRefinement(flow, ransac_results, false, false);
+        RansacValues results = nonlinear_refinement::nonLinearRefinement(flow, ransac_results, false, /*show_messages=*/true);
 
         // single-pixel depth solve through the reference's signature (nonlinearRefinement.h:77-79: Vector2d / Vector3d references)
         const double rho0 = nonlinear_refinement::estimateInverseDepth(Vector2d(coord(0, 0), coord(1, 0)), ransac_results.v, ransac_results.w,

@@ -109,12 +109,24 @@ def test_single_run_matches_python_path(tmp_path, rsdsfm, oracle):
     out = subprocess.run([exe, raw, "120", "200"] + ["%.17g" % x for x in K] + ["%.17g" % gamma, str(T), "%.17g" % tol, str(seed)],
                          capture_output=True, text=True)
     assert out.returncode == 0, out.stderr
-    r = json.loads(out.stdout)
+    lines = out.stdout.splitlines()
+    r = json.loads(lines[-1])
+    # show_messages = true prints what the reference prints (minimal.cc:286-288, nonlinearRefinement.cc:230-234)
+    fin = [ln for ln in lines[:-1] if ln.startswith("Finished ")]
+    assert [ln.split()[1] for ln in fin] == [str(i + 1) for i in range(T)]
+    best_so_far = [int(ln.rstrip(".").split()[-1]) for ln in fin]
+    assert best_so_far == sorted(best_so_far) and best_so_far[-1] == r["ransac_inliers"]
+    rep = [ln for ln in lines[:-1] if ln.startswith("Ceres Solver Report: Iterations: ")]
+    assert len(rep) == 1 and rep[0].endswith("Termination: CONVERGENCE") and "Initial cost: " in rep[0] and "Final cost: " in rep[0]
+    assert any(ln.startswith("Total time for solving optimization: ") for ln in lines[:-1])
     with rsdsfm.Solver(0) as s:
         q, u, a, ak = s.flatten(img, K, gamma)
         rr = s.ransac(q, u, a, ak, False, T, tol, samples=None, seed=seed, depth_mode=1)
         ref = s.non_linear_refinement(u, rr["inliers"], rr["alpha"], rr["alpha_k"], rr["v"], rr["w"], rr["k"], False, flow_index_mode=1,
                                       inlier_idx=rr["inlier_idx"])
+        sm = ref["summary"]
+        assert rep[0].startswith("Ceres Solver Report: Iterations: %d, Initial cost: %e, Final cost: %e," % (
+            sm["num_successful_steps"] + sm["num_unsuccessful_steps"], sm["initial_cost"], sm["final_cost"]))
         dm = s.depth_map(ref["inliers"], ref["v"], K, 120, 200)
         R, t = s.pose_table(dm["v"], ref["w"], ref["k"], gamma, 120)
         rho0 = s.estimate_inverse_depth(q[0], rr["v"], rr["w"], u[0], rr["k"], a[0], ak[0])

@@ -124,3 +124,21 @@ def test_refine(golden, oracle, case, mode):
     assert np.isclose(out["k"], g("ref_%s_k" % mode), rtol=1e-7, atol=1e-10)
     assert np.allclose(out["inliers"][:, 2], g("ref_%s_z" % mode), rtol=1e-7)
     assert np.isclose(sm["final_cost"], ref_sm[5], rtol=1e-8)
+    # the oracle's iteration trace (the checker of the product's rsdsfm_get_refine_trace) is consistent with its own summary,
+    # follows Ceres' radius rule, and tracing does not change the result
+    tr = oracle.refine(u, inl, a[mask], ak[mask], v, w, k, use_k, flow_index_mode=0 if mode == "compat" else 1,
+                       inlier_idx=np.nonzero(mask)[0], trace_rows=50)
+    assert tr["summary"] == sm and np.array_equal(tr["inliers"], out["inliers"])
+    t = tr["trace"]
+    n_it = sm["num_iterations"]
+    assert np.array_equal(t[:n_it, 0], np.arange(1, n_it + 1)) and np.isnan(t[n_it:]).all()
+    assert int(np.isin(t[:n_it, 7], (1.0, 5.0)).sum()) == sm["num_successful_steps"]
+    assert int(np.isin(t[:n_it, 7], (0.0, 2.0)).sum()) == sm["num_unsuccessful_steps"]
+    assert t[0, 1] == sm["initial_cost"] and t[0, 5] == 1e4
+    for i in range(n_it - 1):
+        if t[i, 7] == 1.0:  # accepted: cost moves to the candidate's, radius /= max(1/3, 1 - (2 rel - 1)^3)
+            assert t[i + 1, 1] == t[i, 2]
+            assert np.isclose(t[i + 1, 5], min(t[i, 5] / max(1.0 / 3.0, 1.0 - (2.0 * t[i, 4] - 1.0) ** 3), 1e16), rtol=1e-14)
+            assert t[i, 4] > 1e-3
+        elif t[i, 7] == 0.0:
+            assert t[i + 1, 1] == t[i, 1] and t[i + 1, 5] < t[i, 5] and not t[i, 4] > 1e-3

@@ -144,7 +144,8 @@ int rsdsfm_calculate_velocities(rsdsfm_ctx* ctx, const double* q_18xT, const dou
                                 const double* alpha_9xT, const double* alpha_k_9xT, int32_t count,
                                 int use_alpha_k, int k_sign_mode, double* w_3xT, double* v_3xT, double* k_T);
 /* nonlinear_refinement::estimateInverseDepths  nonlinearRefinement.cc:109-180
- * (and estimateInverseDepth :55-106 with n = 1) */
+ * (and estimateInverseDepth :55-106 with n = 1).  summary: the LM emulation's counters, termination type, costs and final
+ * radius; RSDSFM_DEPTH_CLOSED_FORM reports one successful iteration and does not evaluate the costs (both 0). */
 int rsdsfm_estimate_inverse_depths(rsdsfm_ctx* ctx, const double* q2n, const double* u2n, int64_t n,
                                    const double v[3], const double w[3], double k, const double* alpha_n,
                                    const double* alpha_k_n, int depth_mode, double* inv_depth_n,

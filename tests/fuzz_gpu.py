@@ -158,7 +158,7 @@ def main(cases=None, seed0=None):
         cases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     if seed0 is None:
         seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    bad = ties = splits = 0
+    bad = ties = splits = floors = 0
     only = [int(x) for x in os.environ.get("FUZZ_ONLY", "").split(",") if x]  # re-run selected case numbers of a campaign
     with rsdsfm.Solver(0) as s:
         for c in (only or range(cases)):
@@ -185,7 +185,9 @@ def main(cases=None, seed0=None):
                 for mode in (0, 1):
                     rho, sm = s.estimate_inverse_depths(q, u, pv, pw, pk, a, ak, mode=mode)
                     rho_o, sm_o = O.estimate_inverse_depths(q, u, pv, pw, pk, a, ak, mode=mode)
-                    assert np.allclose(rho, rho_o, rtol=1e-9, atol=1e-13), "depth values mode %d" % mode
+                    # (equal_nan: a sliver-shaped frame's degenerate intrinsics can give finite flows of 1e260 whose squares overflow --
+                    # NaN depths on both sides)
+                    assert np.allclose(rho, rho_o, rtol=1e-9, atol=1e-13, equal_nan=True), "depth values mode %d" % mode
                     if mode == 1:
                         for key in ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination"):
                             assert sm[key] == sm_o[key], ("depth " + key, sm, sm_o)
@@ -246,7 +248,18 @@ def main(cases=None, seed0=None):
                         # the same termination type, inside the oracle's own spread of the final cost.  Counted, not failed.
                         others = _oracle_reorderings(O, u, ro, use_k)
                         oracle_stable = all(all(o2["summary"][key] == sr[key] for key in DECISION_KEYS) for o2 in others)
-                        assert not oracle_stable, ("refinement decisions differ although the oracle's trajectory is stable under re-ordering its sums", so, sr)
+                        if oracle_stable:
+                            # four re-orderings are a sample, not a proof.  One more class is benign by construction: noise-free data
+                            # refined down to the rounding floor (final cost <= 1e-12 x initial cost on both sides) -- there the gradient's
+                            # max norm IS rounding residue, and whether it lands below the 1e-10 gradient tolerance one iteration earlier or
+                            # later cannot matter: the results must then agree at the value bars; anything else stays a mismatch
+                            floor = max(so["final_cost"], sr["final_cost"]) <= 1e-12 * sr["initial_cost"]
+                            dev = _refine_deviation(out, ref)
+                            assert floor and dev["pose"] <= 1e-5 and dev["depth_q995"] <= 1e-5 and dev["depth_max"] <= 1e-2, (
+                                "refinement decisions differ although the oracle's trajectory is stable under re-ordering its sums", so, sr, dev,
+                                _first_divergence(s, O, u, r, ro, use_k))
+                            floors += 1
+                            continue
                         spread = max(abs(o2["summary"]["final_cost"] - sr["final_cost"]) for o2 in others)
                         # diagnostics of a failure: how far the results are apart (gauge-free), next to the oracle's own re-ordering spread
                         diag = dict(gpu_vs_oracle=_refine_deviation(out, ref), oracle_reorderings=[_refine_deviation(o2, ref) for o2 in others],
@@ -289,7 +302,8 @@ def main(cases=None, seed0=None):
                 print("ERROR", tag, e, flush=True)
     if not only:
         bad += fuzz_consumers(O, rsdsfm, max(cases // 2, 1), seed0)
-    print("fuzz: %d cases, %d mismatches; %d all-inlier ties decided by rounding noise, %d ill-conditioned / split refinement trajectories (outcome compared)" % (cases, bad, ties, splits))
+    print("fuzz: %d cases, %d mismatches; %d all-inlier ties decided by rounding noise, %d ill-conditioned / split refinement trajectories (outcome compared), "
+          "%d refinements to the rounding floor ending one iteration apart (values compared)" % (cases, bad, ties, splits, floors))
     return 1 if bad else 0
 
 

@@ -120,6 +120,43 @@ def test_tiled_3840x2160_in_8_slabs_matches_single_context_and_oracle(rsdsfm, or
     assert np.array_equal(got != 0, o["depth_map"] != 0) and np.allclose(got, o["depth_map"], rtol=1e-6)
 
 
+def test_tiled_frame_refinement_trace_is_replicated_and_matches_single_context(rsdsfm):
+    """the refinement's iteration log (rsdsfm_set_refine_trace) in the column-tiled solve: every slab's context takes the same
+    decisions on the same gathered sum rows, so all logs are bit-identical; against the single-context solve every outcome is equal
+    and the costs agree to 1e-10 (the sums are added per slab first)"""
+    import torch
+
+    d = rsdsfm.synth.make_config(3, rows=96, cols=250)
+    stream = torch.cuda.Stream(torch.device("cuda", 0))
+    dev = torch.device("cuda", 0)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    kw = dict(trials=12, tol=0.01, seed=5)
+    with torch.cuda.stream(stream):
+        img = torch.from_numpy(d["flow_img"]).to(dev)
+        dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+        with rsdsfm.Solver(0, stream=stream.cuda_stream) as s:
+            s.set_refine_trace(50)
+            r1 = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), 0, 0, flow_index_mode=rsdsfm.FLOW_GATHERED, **kw)
+            t1 = s.get_refine_trace()
+        bounds, per = rsdsfm.dist.slab_bounds(cols, 3)
+        solvers = [rsdsfm.Solver(0, stream=stream.cuda_stream) for _ in range(3)]
+        for sv in solvers:
+            sv.set_refine_trace(50)
+        shards = [rsdsfm.dist.HipFrameShard(sv, img[:, c0:c1, :].contiguous(), c0, K, gamma, torch) for sv, (c0, c1) in zip(solvers, bounds)]
+        r3 = rsdsfm.dist.TiledFrameSolve(shards, rows, cols, per, torch, None).solve(**kw)
+        traces = [sv.get_refine_trace() for sv in solvers]
+        for sv in solvers:
+            sv.close()
+    n_it = r1["refine_summary"]["num_iterations"]
+    assert n_it >= 2 and r3["refine_summary"]["num_iterations"] == n_it
+    for t in traces[1:]:
+        assert np.array_equal(t, traces[0], equal_nan=True)
+    t3 = traces[0]
+    assert np.array_equal(t3[:, 7], t1[:, 7], equal_nan=True) and np.array_equal(np.isnan(t3), np.isnan(t1))
+    assert np.allclose(t3[:n_it, 1:3], t1[:n_it, 1:3], rtol=1e-10, atol=0.0, equal_nan=True)
+    assert np.allclose(t3[:n_it, 5], t1[:n_it, 5], rtol=1e-9)
+
+
 def test_tiled_frame_closed_form_no_refinement_and_many_trials(rsdsfm):
     """closed-form depth mode (no LM rounds, score pass only), no refinement, and more trials than one hypothesis
     batch (> 128) so that the batched rows / decide calls are offset correctly"""

@@ -71,6 +71,17 @@ def evaluate_single_run(solver, task_dir, out_dir, trials=50, tol=0.05, seed=1, 
         formats.write_png(out_dir + "/rs_image.png", f1["rs_image"])
         formats.write_png(out_dir + "/backprojection.png", backprojection)
         formats.write_png(out_dir + "/error_image.png", error_image)
+        formats.write_png(out_dir + "/optical_flow.png", formats.flow_to_bgr(flow))  # main.cc:390-392
+        if f1.get("gs_image") is not None:  # main.cc:535-554: comparisons against the archive's global-shutter image
+            original_gs, original_rs = f1["gs_image"], f1["rs_image"]
+            difference = formats.abs_diff(backprojection, original_gs)
+            formats.write_png(out_dir + "/gs_image.png", original_gs)
+            formats.write_png(out_dir + "/difference.png", difference)
+            formats.write_png(out_dir + "/remainder.png", formats.abs_diff(original_gs, difference))
+            base = formats.shift_channel_bgr(original_gs, 1, 1, 1)
+            formats.write_png(out_dir + "/overlay_gs_rs.png", formats.create_overlay_image(
+                base, formats.shift_channel_bgr(formats.abs_diff(original_rs, original_gs), 2, 0.5, 0.5)))
+            formats.write_png(out_dir + "/overlay_gs_bp.png", formats.create_overlay_image(base, formats.shift_channel_bgr(difference, 2, 0.5, 0.5)))
         formats.write_ply(out_dir + "/point_cloud.ply", coords, f1["rs_image"])
         formats.write_sweep_results(out_dir, [os.path.basename(task_dir.rstrip("/"))], [[w_err]], [[v_err]], [[stats["mean_error"]]],
                                     w=[res["w"]], v=[dm["v"]], k=[[res["k"]]])

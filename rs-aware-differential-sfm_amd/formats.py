@@ -234,6 +234,56 @@ def load_flow(path_or_array):
 
 
 # ---- sweep outputs (main.cc:179-206, 262-300) -----------------------------------------------------
+# ---- the diagnostic images evaluateSingleRun writes next to its results (main.cc:386-394, :533-554) ----------------------------
+def abs_diff(a, b):
+    """`abs(a - b)` of two 8-bit cv::Mat as the reference evaluates it (OpenCV folds the expression into absdiff): |a - b| per byte"""
+    return np.abs(a.astype(np.int16) - b.astype(np.int16)).astype(np.uint8)
+
+
+def _saturate_u8(x):
+    """cv::saturate_cast<uchar>(double): round half to even (cvRound), then clamp"""
+    return np.clip(np.rint(x), 0, 255).astype(np.uint8)
+
+
+def shift_channel_bgr(img, shift_blue, shift_green, shift_red):
+    """Camera::shiftChannelBGR (camera.cc:777-815): per-channel gain, clamped to [0, 255], truncated"""
+    v = img.astype(np.float64) * np.array([shift_blue, shift_green, shift_red], dtype=np.float64)
+    return np.clip(v, 0.0, 255.0).astype(np.uint8)
+
+
+def create_overlay_image(original, shift, black_threshold=15):
+    """Camera::createOverlayImage (camera.cc:818-840): where `shift` is not black (pixel norm > 15) the two pixels are blended by
+    their norms in cv::Vec3b arithmetic -- each product rounded to 8 bits, the sum saturated --, elsewhere the original pixel"""
+    o, sft = original.astype(np.float64), shift.astype(np.float64)
+    no, ns = np.sqrt((o * o).sum(axis=2)), np.sqrt((sft * sft).sum(axis=2))
+    blend = ns > black_threshold
+    with np.errstate(invalid="ignore", divide="ignore"):
+        m = np.where(blend, no / (no + ns), 1.0)[:, :, None]
+    a = _saturate_u8(m * o).astype(np.int16)
+    b = _saturate_u8((1.0 - m) * sft).astype(np.int16)
+    out = np.minimum(a + b, 255).astype(np.uint8)
+    return np.where(blend[:, :, None], out, original)
+
+
+def flow_to_bgr(flow):
+    """Camera::getImageOpticalFlow (camera.cc:280-309) followed by main.cc:391's scaling to 8 bits: direction as hue, magnitude
+    (normalised by its maximum) as value, full saturation.  Visualisation only: OpenCV's cartToPolar / cvtColor work in float with a
+    polynomial atan2 (0.3 degrees), so this image is not claimed to be byte-identical to the reference's optical_flow.png."""
+    f = np.asarray(flow, dtype=np.float32)
+    mag = np.sqrt(f[:, :, 0] ** 2 + f[:, :, 1] ** 2)
+    ang = np.degrees(np.arctan2(f[:, :, 1], f[:, :, 0])) % 360.0
+    mmax = float(mag.max()) if mag.size else 0.0
+    val = mag / mmax if mmax > 0 else mag
+    h = ang / 60.0
+    i = np.floor(h).astype(np.int32) % 6
+    fr = h - np.floor(h)
+    p, q_, t = np.zeros_like(val), val * (1.0 - fr), val * fr  # saturation 1: p = 0
+    r = np.choose(i, [val, q_, p, p, t, val])
+    g = np.choose(i, [t, val, val, q_, p, p])
+    b = np.choose(i, [p, p, t, val, val, q_])
+    return _saturate_u8(np.stack([b, g, r], axis=2).astype(np.float64) * 255.0)
+
+
 def write_sweep_results(result_dir, tasks, w_errors, v_errors, reproject_errors, w=None, v=None, k=None):
     """errors.csv with the reference's header plus the per-quantity CSVs (one line per task)"""
     with open(result_dir + "/errors.csv", "w") as f:
@@ -250,7 +300,8 @@ def write_sweep_results(result_dir, tasks, w_errors, v_errors, reproject_errors,
 # ---- example archive in the reference's layout (matlab take_sequence.m:27-94, start_generating.m:38-42) -----------
 def write_example_archive(task_dir, K, gamma, v, w, k, frames):
     """frames: two dicts with rs_image (rows, cols, 3 BGR), R (rows, 3, 3), t (rows, 3), world (rows, cols, 3).  Writes
-    <task_dir>/{v,w,gamma,k}.csv and <task_dir>/images/{A.csv, N_rs.png, N_rs_t.csv, N_rs_r.csv, N_rs_unproject_{x,y,z}.csv}."""
+    <task_dir>/{v,w,gamma,k}.csv and <task_dir>/images/{A.csv, N_rs.png, N_rs_t.csv, N_rs_r.csv, N_rs_unproject_{x,y,z}.csv} and, when
+    a frame carries gs_image, N_initial_gs.png."""
     import os
 
     os.makedirs(task_dir + "/images", exist_ok=True)
@@ -264,6 +315,8 @@ def write_example_archive(task_dir, K, gamma, v, w, k, frames):
     for n, fr in enumerate(frames, start=1):
         rows = fr["rs_image"].shape[0]
         write_png(img + "%d_rs.png" % n, fr["rs_image"])
+        if fr.get("gs_image") is not None:  # main.cc:626 / :646 <n>_initial_gs.png
+            write_png(img + "%d_initial_gs.png" % n, fr["gs_image"])
         write_matrix_csv(img + "%d_rs_t.csv" % n, fr["t"])
         write_matrix_csv(img + "%d_rs_r.csv" % n, np.asarray(fr["R"]).reshape(rows, 9))
         for c, ax in enumerate("xyz"):
@@ -281,5 +334,8 @@ def load_example_archive(task_dir):
         rows, cols = rs.shape[:2]
         R, t = load_poses(img + "%d_rs_t.csv" % n, img + "%d_rs_r.csv" % n, rows)
         world = load_unprojection(*[img + "%d_rs_unproject_%s.csv" % (n, ax) for ax in "xyz"], rows, cols)
-        frames.append(dict(rs_image=rs, R=R, t=t, world=world))
+        import os
+
+        gs = read_png(img + "%d_initial_gs.png" % n) if os.path.exists(img + "%d_initial_gs.png" % n) else None
+        frames.append(dict(rs_image=rs, gs_image=gs, R=R, t=t, world=world))
     return dict(K=K, Kmat=Kmat, truth=truth, frames=frames)

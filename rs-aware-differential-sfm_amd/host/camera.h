@@ -6,6 +6,7 @@
 #define RSDSFM_HOST_CAMERA_H
 
 #include <cmath>
+#include <cstdlib>
 #include <iostream>
 #include <string>
 #include <vector>
@@ -40,6 +41,11 @@ public:
     void addFrame(int rows, int cols) {
         frames_.emplace_back(rows, cols);
         frames_.back().setIntrinsics(K_);
+    }
+    /** reference camera.cc:39-46: a frame of real data (RS image + intrinsics only) */
+    void addFrameReal(const rsdsfm::ImageBGR& rs_image) {
+        addFrame(rs_image.rows(), rs_image.cols());
+        frames_.back().setImage(rs_image);
     }
     RsFrame getFrame(const int frameNr) { return frames_[(size_t)frameNr - 1]; }
     RsFrame& frame(const int frameNr) { return frames_[(size_t)frameNr - 1]; }
@@ -99,6 +105,75 @@ public:
                       "rsdsfm_interpolate_cracky");
         return image_out;
     }
+    /** reference camera.cc:694-750: the per-pixel predicates of interpolateCrackyImage on the host (the GPU kernel behind
+     *  interpolateCrackyImage evaluates the same rules).  A pixel is "black" when the Euclidean norm of its BGR triple is <= threshold;
+     *  the four neighbours at distance `offset` must lie inside the image (the reference does not check either). */
+    static bool isBlackPixel(const unsigned char point[3], const unsigned threshold) {
+        const double n2 = (double)point[0] * point[0] + (double)point[1] * point[1] + (double)point[2] * point[2];
+        return std::sqrt(n2) <= (double)threshold;
+    }
+    static bool isColorfulArea(const rsdsfm::ImageBGR& image_in, const unsigned row, const unsigned col, const unsigned offset) {
+        const unsigned black_threshold = 15;
+        const int r = (int)row, c = (int)col, o = (int)offset;
+        return !isBlackPixel(px(image_in, r - o, c), black_threshold) || !isBlackPixel(px(image_in, r + o, c), black_threshold) ||
+               !isBlackPixel(px(image_in, r, c - o), black_threshold) || !isBlackPixel(px(image_in, r, c + o), black_threshold);
+    }
+    /** average colour of the non-black neighbours above / below / left / right (camera.cc:712-750); out = (0, 0, 0) if all are black */
+    static void interpolateAreaColor(const rsdsfm::ImageBGR& image_in, const unsigned row, const unsigned col, const unsigned offset, unsigned char out[3]) {
+        const unsigned black_threshold = 15;
+        const int r = (int)row, c = (int)col, o = (int)offset;
+        const unsigned char* nb[4] = {px(image_in, r - o, c), px(image_in, r + o, c), px(image_in, r, c - o), px(image_in, r, c + o)};
+        double sum[3] = {0, 0, 0};
+        unsigned count = 0;
+        for (int k = 0; k < 4; ++k)
+            if (!isBlackPixel(nb[k], black_threshold)) {
+                for (int ch = 0; ch < 3; ++ch) sum[ch] += (double)nb[k][ch];
+                count++;
+            }
+        for (int ch = 0; ch < 3; ++ch) out[ch] = count > 0 ? saturate_u8((1 / static_cast<double>(count)) * sum[ch]) : 0;
+    }
+    /** reference camera.cc:777-815: per-channel gain, clamped to [0, 255], truncated (static_cast<uint8_t>) */
+    static rsdsfm::ImageBGR shiftChannelBGR(const rsdsfm::ImageBGR& image_in, double shift_blue, double shift_green, double shift_red) {
+        rsdsfm::ImageBGR shifted(image_in.rows(), image_in.cols());
+        const double gain[3] = {shift_blue, shift_green, shift_red};
+        for (int row = 0; row < image_in.rows(); row++)
+            for (int col = 0; col < image_in.cols(); col++)
+                for (int ch = 0; ch < 3; ++ch) {
+                    double v = image_in.at(row, col, ch) * gain[ch];
+                    if (v > 255) v = 255; else if (v < 0) v = 0;
+                    shifted.at(row, col, ch) = static_cast<unsigned char>(v);
+                }
+        return shifted;
+    }
+    /** reference camera.cc:818-840: where shift_image is not black, blend the two pixels by their norms (cv::Vec3b arithmetic:
+     *  every product and the sum are rounded / saturated to 8 bits); elsewhere the original pixel */
+    static rsdsfm::ImageBGR createOverlayImage(const rsdsfm::ImageBGR& original_image, const rsdsfm::ImageBGR& shift_image) {
+        const unsigned black_threshold = 15;
+        rsdsfm::ImageBGR image_out(original_image.rows(), original_image.cols());
+        for (int row = 0; row < original_image.rows(); row++)
+            for (int col = 0; col < original_image.cols(); col++) {
+                const unsigned char* ps = px(shift_image, row, col);
+                const unsigned char* po = px(original_image, row, col);
+                const double ns = norm3(ps), no = norm3(po);
+                for (int ch = 0; ch < 3; ++ch) {
+                    if (ns > black_threshold) {
+                        const double multiplier = no / (no + ns);
+                        const int a = saturate_u8(multiplier * po[ch]), b = saturate_u8((1 - multiplier) * ps[ch]);
+                        image_out.at(row, col, ch) = (unsigned char)(a + b > 255 ? 255 : a + b);
+                    } else {
+                        image_out.at(row, col, ch) = po[ch];
+                    }
+                }
+            }
+        return image_out;
+    }
+    /** |a - b| per byte: what the reference's `abs(a - b)` on 8-bit cv::Mat evaluates to (OpenCV folds it into absdiff; main.cc:542-547) */
+    static rsdsfm::ImageBGR absDiff(const rsdsfm::ImageBGR& a, const rsdsfm::ImageBGR& b) {
+        rsdsfm::ImageBGR out(a.rows(), a.cols());
+        const size_t n = (size_t)a.rows() * (size_t)a.cols() * 3;
+        for (size_t i = 0; i < n; ++i) out.data()[i] = (unsigned char)std::abs((int)a.data()[i] - (int)b.data()[i]);
+        return out;
+    }
     /** reference camera.cc:209-249: ground-truth flow from frame frameNr1 to frame frameNr2 (unprojection maps of frame 1,
      *  relative scanline poses of frame 2) */
     rsdsfm::FlowImage calculateTrueFlow(const int frameNr1, const int frameNr2) {
@@ -117,6 +192,13 @@ public:
     }
 
 private:
+    static const unsigned char* px(const rsdsfm::ImageBGR& img, int row, int col) { return img.data() + ((size_t)row * (size_t)img.cols() + (size_t)col) * 3; }
+    static double norm3(const unsigned char p[3]) { return std::sqrt((double)p[0] * p[0] + (double)p[1] * p[1] + (double)p[2] * p[2]); }
+    /** cv::saturate_cast<uchar>(double): round half to even (cvRound), then clamp */
+    static unsigned char saturate_u8(double v) {
+        const long iv = std::lrint(v);
+        return (unsigned char)(iv < 0 ? 0 : iv > 255 ? 255 : iv);
+    }
     rsdsfm::lite::Matrix3d K_;
     std::vector<RsFrame> frames_;
 };

@@ -50,6 +50,41 @@ def test_rsframe_geometry_members_on_the_host(tmp_path, rsdsfm):
     assert abs(float(i2[0]) - px) < 1e-4  # (printed with 6 significant digits)
 
 
+def test_image_helpers_on_the_host(tmp_path, rsdsfm, oracle):
+    """tests/cpp/image_host.cpp: shiftChannelBGR / createOverlayImage / absDiff / isBlackPixel / isColorfulArea / interpolateAreaColor /
+    addFrameReal of the Camera mirror against the package's numpy versions (formats.py) and the oracle's crack interpolation -- two
+    independent statements of cv::Vec3b arithmetic (rounded products, saturated sums); host only, runs without a GPU"""
+    rsdsfm.load_library()
+    exe = os.path.join(str(tmp_path), "image_host")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-o", exe, os.path.join(ROOT, "tests", "cpp", "image_host.cpp"),
+                           "-L", PKG, "-lrsdsfm_hip", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
+    rng = np.random.default_rng(11)
+    rows, cols = 37, 53
+    a = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+    a[rng.random((rows, cols)) < 0.3] = rng.integers(0, 9, 3, dtype=np.uint8)   # black pixels (norm <= 15): cracks to interpolate
+    a[5:9, 7:12] = 0                                                              # and a black area with black neighbours
+    b = np.clip(a.astype(np.int16) + rng.integers(-40, 41, a.shape), 0, 255).astype(np.uint8)
+    b[rng.random((rows, cols)) < 0.5] = a[rng.random((rows, cols)) < 0.5][0]    # many equal / nearly equal pixels: black differences
+    pa, pb, out = [os.path.join(str(tmp_path), n) for n in ("a.raw", "b.raw", "out")]
+    a.tofile(pa), b.tofile(pb)
+    p = subprocess.run([exe, pa, pb, str(rows), str(cols), out], capture_output=True, text=True)
+    assert p.returncode == 0 and p.stdout.strip() == "ok", p.stderr
+    rd = lambda ext: np.fromfile(out + ext, dtype=np.uint8).reshape(rows, cols, 3)
+    F = rsdsfm.formats
+    assert np.array_equal(rd(".shift"), F.shift_channel_bgr(a, 2, 0.5, 0.5))
+    ov = F.create_overlay_image(F.shift_channel_bgr(a, 1, 1, 1), F.shift_channel_bgr(F.abs_diff(a, b), 2, 0.5, 0.5))
+    assert np.array_equal(rd(".overlay"), ov)
+    assert (ov != a).any() and (ov == a).all(axis=2).any()  # both branches taken
+    assert np.array_equal(rd(".cracky"), oracle.interpolate_cracky(a, 1))
+    # known answers of the 8-bit arithmetic: truncating gain, round-half-even blend, saturated sum
+    px = np.array([[[200, 101, 7]]], dtype=np.uint8)
+    assert F.shift_channel_bgr(px, 2, 0.5, 0.5).tolist() == [[[255, 50, 3]]]
+    o, sh = np.array([[[30, 40, 0]]], dtype=np.uint8), np.array([[[0, 30, 40]]], dtype=np.uint8)  # equal norms: multiplier 0.5
+    assert F.create_overlay_image(o, sh).tolist() == [[[15, 35, 20]]]
+    assert F.create_overlay_image(o, (sh // 10)).tolist() == o.tolist()  # shift pixel black (norm 5): original kept
+    assert F.abs_diff(np.array([3, 250], dtype=np.uint8), np.array([10, 5], dtype=np.uint8)).tolist() == [7, 245]
+
+
 def test_tiled_host_compiles_and_links(tmp_path, rsdsfm):
     rsdsfm.load_library()
     exe = _build_tiled(tmp_path)

@@ -137,6 +137,26 @@ def test_example_archive_roundtrip_python(F, rsdsfm, oracle, tmp_path):
         assert os.path.exists(os.path.join(task, "images", name))  # the reference's file names (main.cc:613-671)
 
 
+def test_archive_global_shutter_images_and_flow_visualisation(F, rsdsfm, oracle, tmp_path):
+    """N_initial_gs.png (main.cc:626, :646) is optional in the archive writer / reader; flow_to_bgr: hue from the direction
+    (0 deg = +x = red, 120 = green, 240 = blue in BGR order), value from the magnitude normalised by its maximum"""
+    task, K, gamma, t, frames = _archive(rsdsfm, oracle, tmp_path)
+    assert all(fr["gs_image"] is None for fr in F.load_example_archive(task)["frames"])
+    for fr in frames:
+        fr["gs_image"] = fr["rs_image"][::-1].copy()
+    F.write_example_archive(task, K, gamma, t["v"], t["w"], 0.0, frames)
+    for got, ref in zip(F.load_example_archive(task)["frames"], frames):
+        assert np.array_equal(got["gs_image"], ref["gs_image"])
+    c, s3 = np.cos(np.radians(120.0)), np.sin(np.radians(120.0))
+    flow = np.array([[[2.0, 0.0], [c, s3], [0.5 * c, -0.5 * s3], [0.0, 0.0]]])
+    img = F.flow_to_bgr(flow)
+    assert img.dtype == np.uint8 and img.shape == (1, 4, 3)
+    assert img[0, 0].tolist() == [0, 0, 255]            # +x, the largest magnitude: pure red at full value
+    assert img[0, 1].tolist() == [0, 128, 0]            # 120 degrees, half the magnitude: green at half value
+    assert img[0, 2].tolist() == [64, 0, 0]             # 240 degrees, a quarter: blue
+    assert img[0, 3].tolist() == [0, 0, 0]
+
+
 def test_cpp_mirror_reads_the_archive(F, rsdsfm, oracle, tmp_path):
     """host/formats.h (loadIntrinsicsFromFile, setPoses, setUnprojectionMapRs, imread / imwrite PNG) on the Python-written archive"""
     task, K, gamma, t, frames = _archive(rsdsfm, oracle, tmp_path)

@@ -30,7 +30,8 @@ def _write_archive(rsdsfm, oracle, task, rows=60, cols=96):
         pc = np.stack([(xx - cx) / fx, (yy - cy) / fy, np.ones((rows, cols))], axis=2) * Z[:, :, None]
         world = np.einsum("yji,yxj->yxi", R, pc - t[:, None, :])  # R^T (P_cam - t), per scanline
         img = rng.integers(16, 256, (rows, cols, 3), dtype=np.uint8)
-        frames.append(dict(rs_image=img, R=R, t=t, world=world))
+        gs = np.roll(img, n + 1, axis=1)  # stand-in for the archive's global-shutter rendering (N_initial_gs.png)
+        frames.append(dict(rs_image=img, gs_image=gs, R=R, t=t, world=world))
     rsdsfm.formats.write_example_archive(task, K, gamma, v, w, 0.0, frames)
     return K, gamma, v, w, frames
 
@@ -80,6 +81,18 @@ def test_archive_end_to_end(rsdsfm, oracle, tmp_path):
         assert os.path.exists(os.path.join(out_dir, name)), name
     assert np.array_equal(rsdsfm.formats.read_png(out_dir + "/backprojection.png"), r["backprojection"])
     assert np.array_equal(rsdsfm.formats.read_png(out_dir + "/MinimalDepth.png", grayscale=True), r["depth_est"])
+    # the diagnostic images of main.cc:386-394, :533-554 (comparisons against the archive's global-shutter image)
+    F = rsdsfm.formats
+    rd = lambda name: F.read_png(out_dir + "/" + name)
+    gs0, rs0 = f1["gs_image"], f1["rs_image"]
+    assert np.array_equal(rd("gs_image.png"), gs0)
+    diff = np.abs(r["backprojection"].astype(int) - gs0.astype(int)).astype(np.uint8)
+    assert np.array_equal(rd("difference.png"), diff)
+    assert np.array_equal(rd("remainder.png"), np.abs(gs0.astype(int) - diff.astype(int)).astype(np.uint8))
+    assert np.array_equal(rd("overlay_gs_bp.png"), F.create_overlay_image(gs0, F.shift_channel_bgr(diff, 2, 0.5, 0.5)))
+    assert np.array_equal(rd("overlay_gs_rs.png"), F.create_overlay_image(gs0, F.shift_channel_bgr(F.abs_diff(rs0, gs0), 2, 0.5, 0.5)))
+    of = rd("optical_flow.png")
+    assert of.shape == (rows, cols, 3) and of.max() == 255  # hue = direction, value = magnitude / max magnitude
     pc, col = rsdsfm.formats.read_ply(out_dir + "/point_cloud.ply")
     assert np.array_equal(pc, r["coords"].reshape(-1, 3)) and np.array_equal(col, f1["rs_image"].reshape(-1, 3))
     assert open(out_dir + "/errors.csv").read().startswith("task,error_w,error_v,reproject_error\ntask_1,")

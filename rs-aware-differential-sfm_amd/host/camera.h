@@ -93,6 +93,10 @@ public:
     void setPose(const int frameNr, const double k, const rsdsfm::lite::Vector3d& linear_velocity, const rsdsfm::lite::Vector3d& angular_velocity) {
         frames_[(size_t)frameNr - 1].setRelativePose(linear_velocity, angular_velocity, k);
     }
+    /** reference camera.cc:494-497 */
+    void smallMotionWrapping(const int frameNr, const rsdsfm::lite::Vector3d& linear_velocity, const rsdsfm::lite::Vector3d& angular_velocity, const double k) {
+        frames_[(size_t)frameNr - 1].smallMotionWrapping(linear_velocity, angular_velocity, k);
+    }
     void setImage(const int frameNr, const rsdsfm::ImageBGR& image) { frames_[(size_t)frameNr - 1].setImage(image); }
     /** reference camera.cc:353-361 */
     void backProject(const int frameNr) { frames_[(size_t)frameNr - 1].backProject(); }

@@ -187,6 +187,7 @@ public:
     float* data() { return d_.data(); }
     const float* data() const { return d_.data(); }
     float at(int row, int col, int ch) const { return d_[((size_t)row * (size_t)c_ + (size_t)col) * 3 + (size_t)ch]; }
+    float& at(int row, int col, int ch) { return d_[((size_t)row * (size_t)c_ + (size_t)col) * 3 + (size_t)ch]; }
 
 private:
     int r_, c_;

@@ -206,6 +206,40 @@ public:
         return mode;
     }
 
+    /** reference rsframe.cc:881-949 (not called by the reference's drivers): the small-motion alternative to backProject -- every
+     *  pixel (x, y >= 1) is moved against its model flow beta_1(y) * (A v / depth + B w), rounded to whole pixels, into gs_image_
+     *  (pixels whose rounded flow is zero are NOT copied, as in the reference), and the 3-D coordinates are those of planeToSpace +
+     *  cameraToWorldFrame.  Host loop (a diagnostic, not on the hot path).  Two guards the reference lacks: pixels without depth are
+     *  skipped (the reference divides by zero), and a write is dropped when its TARGET (y - dy, x - dx) lies outside the image (the
+     *  reference tests (y + dy, x + dx) and may write out of bounds). */
+    void smallMotionWrapping(const rsdsfm::lite::Vector3d& linear_velocity, const rsdsfm::lite::Vector3d& angular_velocity, const double k) {
+        const double f_x = K_(0, 0), f_y = K_(1, 1), c_x = K_(0, 2), c_y = K_(1, 2);
+        rsdsfm::ImageBGR gs_image(rows_, cols_);
+        rsdsfm::ImageXYZf coordinates_3d(rows_, cols_);
+        for (int y = 1; y < rows_; ++y) {
+            const double beta_1 = (gamma_ * y / rows_ + 0.5 * k * (gamma_ * gamma_ * y * y) / (rows_ * rows_)) * (2.0 / (2.0 + k));
+            for (int x = 1; x < cols_; ++x) {
+                const double depth = depth_map_(y, x);
+                if (depth == 0) continue;
+                const double u = (x - c_x) * 1.0 / f_x, v = (y - c_y) * 1.0 / f_y;
+                const double inv_depth = 1.0 / depth;
+                // A = -[-1 0 u; 0 -1 v], B = -[uv -(1+u^2) v; (1+v^2) -uv -u]
+                const double av0 = (linear_velocity(0) - u * linear_velocity(2)) * inv_depth, av1 = (linear_velocity(1) - v * linear_velocity(2)) * inv_depth;
+                const double bw0 = -(u * v * angular_velocity(0) - (1 + u * u) * angular_velocity(1) + v * angular_velocity(2));
+                const double bw1 = -((1 + v * v) * angular_velocity(0) - u * v * angular_velocity(1) - u * angular_velocity(2));
+                const double flow_x = beta_1 * (av0 + bw0) * (f_x * 1.0 / gamma_), flow_y = beta_1 * (av1 + bw1) * (f_y * 1.0 / gamma_);
+                const int dx = (int)std::floor(flow_x + 0.5), dy = (int)std::floor(flow_y + 0.5);
+                if ((dx != 0 || dy != 0) && y + dy < rows_ && y + dy >= 0 && x + dx < cols_ && x + dx >= 0 && y - dy < rows_ && y - dy >= 0 &&
+                    x - dx < cols_ && x - dx >= 0)
+                    for (int ch = 0; ch < 3; ++ch) gs_image.at(y - dy, x - dx, ch) = image_.at(y, x, ch);
+                const rsdsfm::lite::Vector3d Point_world = cameraToWorldFrame(planeToSpace(rsdsfm::lite::Vector2d(x, y)), y);
+                for (int ch = 0; ch < 3; ++ch) coordinates_3d.at(y, x, ch) = (float)Point_world(ch);
+            }
+        }
+        coordinates_3d_ = coordinates_3d;
+        gs_image_ = gs_image;
+    }
+
     /** reference rsframe.cc:771-800 */
     void setRelativePose(const rsdsfm::lite::Vector3d& linear_velocity, const rsdsfm::lite::Vector3d& angular_velocity, const double k) {
         std::vector<double> R((size_t)rows_ * 9), t((size_t)rows_ * 3);

@@ -85,6 +85,37 @@ int main() {
     CHECK(px.x() == 3 && px.y() == 0);
     const Vector2d pc = f.pixelToCoordinate(Vector2i(7, 3));
     CHECK(pc.x() == 7.0 && pc.y() == 3.0);
+    {  // smallMotionWrapping (rsframe.cc:881-949): a pure sideways translation moves every pixel by its rounded model flow
+        rsdsfm::ImageBGR img(rows, cols);
+        for (int y = 0; y < rows; ++y)
+            for (int x = 0; x < cols; ++x) img.at(y, x, 0) = (unsigned char)(10 + x), img.at(y, x, 1) = (unsigned char)(100 + y), img.at(y, x, 2) = 200;
+        f.setImage(img);
+        f.setGamma(0.9);
+        f.setSyntheticDepthMapRs();
+        const double vx = 0.02, gamma = 0.9, kk = 0.25;
+        camera.smallMotionWrapping(1, Vector3d(vx, 0.0, 0.0), Vector3d(0.0, 0.0, 0.0), kk);
+        const rsdsfm::ImageBGR gs = f.getGsImage();
+        const MatrixXd zz = f.getDepthMap();
+        int moved = 0;
+        rsdsfm::ImageBGR expect(rows, cols);
+        for (int y = 1; y < rows; ++y) {
+            const double beta = (gamma * y / rows + 0.5 * kk * (gamma * gamma * y * y) / (rows * rows)) * (2.0 / (2.0 + kk));
+            for (int x = 1; x < cols; ++x) {
+                if (zz(y, x) == 0) continue;
+                const int dx = (int)std::floor(beta * vx / zz(y, x) * K(0, 0) / gamma + 0.5);  // flow_y is exactly zero
+                if (dx != 0 && x + dx < cols && x - dx >= 0) {
+                    for (int ch = 0; ch < 3; ++ch) expect.at(y, x - dx, ch) = img.at(y, x, ch);
+                    ++moved;
+                }
+            }
+        }
+        CHECK(moved > 20);
+        for (int y = 0; y < rows; ++y)
+            for (int x = 0; x < cols; ++x)
+                for (int ch = 0; ch < 3; ++ch) CHECK(gs.at(y, x, ch) == expect.at(y, x, ch));
+        const Vector3d Wp = f.cameraToWorldFrame(f.planeToSpace(Vector2d(9, 4)), 4);
+        CHECK(f.get3dCoordinates().at(4, 9, 2) == (float)Wp.z() && f.get3dCoordinates().at(0, 0, 2) == 0.0f);
+    }
     if (std::getenv("RSDSFM_TEST_PROJECTION")) camera.testProjection();  // prints one block per pixel with ground truth
     std::printf("ok\n");
     return 0;

@@ -265,6 +265,21 @@ def create_overlay_image(original, shift, black_threshold=15):
     return np.where(blend[:, :, None], out, original)
 
 
+def reconstruct_image_from_flow(image, flow):
+    """Camera::reconstructImageFromFlow (camera.cc:842-865): the image pushed forward along the flow rounded to whole pixels;
+    columns outer / rows inner, the last writer wins, targets with x <= 0 or y <= 0 are dropped (the reference's strict test)"""
+    rows, cols = flow.shape[:2]
+    out = np.zeros_like(image)
+    dx = np.floor(flow[:, :, 0] + 0.5).astype(np.int64)
+    dy = np.floor(flow[:, :, 1] + 0.5).astype(np.int64)
+    vv, uu = np.mgrid[0:rows, 0:cols]
+    nx, ny = uu + dx, vv + dy
+    ok = (nx > 0) & (nx < cols) & (ny > 0) & (ny < rows)
+    order = np.argsort((uu * rows + vv)[ok], kind="stable")  # the reference's scan order: later sources overwrite earlier ones
+    out[ny[ok][order], nx[ok][order]] = image[vv[ok][order], uu[ok][order]]
+    return out
+
+
 def flow_to_bgr(flow):
     """Camera::getImageOpticalFlow (camera.cc:280-309) followed by main.cc:391's scaling to 8 bits: direction as hue, magnitude
     (normalised by its maximum) as value, full saturation.  Visualisation only: OpenCV's cartToPolar / cvtColor work in float with a

@@ -171,6 +171,19 @@ public:
             }
         return image_out;
     }
+    /** reference camera.cc:842-865: frame 1's RS image pushed forward along a flow field rounded to whole pixels; scan order
+     *  columns outer / rows inner, the last writer wins, targets with x <= 0 or y <= 0 are dropped (the reference's strict test) */
+    rsdsfm::ImageBGR reconstructImageFromFlow(const rsdsfm::FlowImage& flow_image) {
+        const rsdsfm::ImageBGR original_image = frames_[0].getRsImage();
+        rsdsfm::ImageBGR reconstructed_image(original_image.rows(), original_image.cols());
+        for (int u = 0; u < flow_image.cols(); ++u)
+            for (int v = 0; v < flow_image.rows(); ++v) {
+                const int new_x = u + (int)std::floor(flow_image.x(v, u) + 0.5), new_y = v + (int)std::floor(flow_image.y(v, u) + 0.5);
+                if (new_x > 0 && new_x < flow_image.cols() && new_y > 0 && new_y < flow_image.rows())
+                    for (int ch = 0; ch < 3; ++ch) reconstructed_image.at(new_y, new_x, ch) = original_image.at(v, u, ch);
+            }
+        return reconstructed_image;
+    }
     /** |a - b| per byte: what the reference's `abs(a - b)` on 8-bit cv::Mat evaluates to (OpenCV folds it into absdiff; main.cc:542-547) */
     static rsdsfm::ImageBGR absDiff(const rsdsfm::ImageBGR& a, const rsdsfm::ImageBGR& b) {
         rsdsfm::ImageBGR out(a.rows(), a.cols());

@@ -4,6 +4,7 @@
 //   <out>.overlay createOverlayImage(shiftChannelBGR(a, 1, 1, 1), shiftChannelBGR(absDiff(a, b), 2, 0.5, 0.5))   (main.cc:548-549)
 //   <out>.cracky  the crack interpolation of `a` written with isBlackPixel / isColorfulArea / interpolateAreaColor on the host
 //                 (camera.cc:753-774), offset 1
+//   <out>.warp    reconstructImageFromFlow of `a` along the flow ((7u + 3v) % 11 - 5) / 2, 3 ((5u + 2v) % 7 - 3) / 4
 // for the Python test to compare with the package's numpy versions and the oracle.
 #include <cstdio>
 #include <cstdlib>
@@ -55,6 +56,14 @@ int main(int argc, char** argv) {
     camera.setIntrinsics("galaxy_vga");
     camera.addFrameReal(a);  // camera.cc:39-46
     if (camera.getFrame(1).getRsImage().at(rows / 2, cols / 2, 1) != a.at(rows / 2, cols / 2, 1)) return 5;
+    // reconstructImageFromFlow (camera.cc:842-865) along a flow of exact quarter-pixel values (many collisions, half-pixel ties)
+    rsdsfm::FlowImage flow(rows, cols);
+    for (int v = 0; v < rows; ++v)
+        for (int u = 0; u < cols; ++u) {
+            flow.data()[((size_t)v * cols + u) * 2] = ((u * 7 + v * 3) % 11 - 5) * 0.5;
+            flow.data()[((size_t)v * cols + u) * 2 + 1] = ((u * 5 + v * 2) % 7 - 3) * 0.75;
+        }
+    if (!write_raw(out + ".warp", camera.reconstructImageFromFlow(flow))) return 4;
     std::printf("ok\n");
     return 0;
 }

@@ -52,7 +52,7 @@ def test_rsframe_geometry_members_on_the_host(tmp_path, rsdsfm):
 
 def test_image_helpers_on_the_host(tmp_path, rsdsfm, oracle):
     """tests/cpp/image_host.cpp: shiftChannelBGR / createOverlayImage / absDiff / isBlackPixel / isColorfulArea / interpolateAreaColor /
-    addFrameReal of the Camera mirror against the package's numpy versions (formats.py) and the oracle's crack interpolation -- two
+    addFrameReal / reconstructImageFromFlow of the Camera mirror against the package's numpy versions (formats.py) and the oracle's crack interpolation -- two
     independent statements of cv::Vec3b arithmetic (rounded products, saturated sums); host only, runs without a GPU"""
     rsdsfm.load_library()
     exe = os.path.join(str(tmp_path), "image_host")
@@ -76,6 +76,17 @@ def test_image_helpers_on_the_host(tmp_path, rsdsfm, oracle):
     assert np.array_equal(rd(".overlay"), ov)
     assert (ov != a).any() and (ov == a).all(axis=2).any()  # both branches taken
     assert np.array_equal(rd(".cracky"), oracle.interpolate_cracky(a, 1))
+    vv, uu = np.mgrid[0:rows, 0:cols]
+    flow = np.stack([((uu * 7 + vv * 3) % 11 - 5) * 0.5, ((uu * 5 + vv * 2) % 7 - 3) * 0.75], axis=2)
+    warp = F.reconstruct_image_from_flow(a, flow)
+    assert np.array_equal(rd(".warp"), warp) and (warp[0] == 0).all() and (warp[:, 0] == 0).all() and (warp != 0).any()
+    ref = np.zeros_like(a)  # the reference's loop, spelled out
+    for u in range(cols):
+        for v in range(rows):
+            nx, ny = u + int(np.floor(flow[v, u, 0] + 0.5)), v + int(np.floor(flow[v, u, 1] + 0.5))
+            if 0 < nx < cols and 0 < ny < rows:
+                ref[ny, nx] = a[v, u]
+    assert np.array_equal(warp, ref)
     # known answers of the 8-bit arithmetic: truncating gain, round-half-even blend, saturated sum
     px = np.array([[[200, 101, 7]]], dtype=np.uint8)
     assert F.shift_channel_bgr(px, 2, 0.5, 0.5).tolist() == [[[255, 50, 3]]]

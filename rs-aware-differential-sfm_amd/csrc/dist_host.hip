@@ -608,7 +608,6 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
     // ---- mean-z sign (global), depth-map slab, ONE all-gather of the slabs, pose table ----
     {
         Arena ws2(c->d_ws);
-        long long* d_owner = ws2.take<long long>(std::max<size_t>(cap, 1));
         double* d_zpart = ws2.take<double>(1024);
         rc = zsum_row_launch(c, d_final, m, d_zpart, d_zs);
         if (rc != RSDSFM_OK) return rc;
@@ -616,7 +615,7 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
         if (rc != RSDSFM_OK) return rc;
         double* d_slab = d_gather + (size_t)rank * cap;
         if (cap > Ns) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_slab + Ns, 0, sizeof(double) * (cap - Ns), c->stream));  // columns past the image: zeros
-        rc = depth_map_slab_launch(c, d_final, m, d_zs_all, R, m_total, v, fx, fy, cx, cy, rows, col0, sc, d_slab, nullptr, d_ys, d_header, d_owner, h_header);
+        rc = depth_map_slab_launch(c, d_final, m, d_zs_all, R, m_total, v, fx, fy, cx, cy, rows, col0, sc, d_slab, nullptr, d_ys, d_header, h_header);
         if (rc != RSDSFM_OK) return rc;
         rc = all_gather(c, D, d_slab, d_gather, sizeof(double) * cap);  // the one data-path collective
         if (rc != RSDSFM_OK) return rc;

@@ -110,17 +110,15 @@ int depth_map_device(Ctx* c, double* d_inl, int64_t m, double v_inout[3], double
     if (m < 0 || rows < 0 || cols < 0 || !v_inout) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     const size_t npix = (size_t)rows * (size_t)cols;
     if ((m > 0 && !d_inl) || (npix > 0 && !d_depth_map)) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
-    int rc = ensure_ws(c, Arena::need(64) + Arena::need(8 * npix) + Arena::need(8 * 1024) + 1024);
+    int rc = ensure_ws(c, Arena::need(64) + Arena::need(8 * 1024) + 1024);
     if (rc != RSDSFM_OK) return rc;
     rc = ensure_pinned(c, 64);
     if (rc != RSDSFM_OK) return rc;
     Arena ws(c->d_ws);
     double* d_header = ws.take<double>(4);
-    long long* d_owner = ws.take<long long>(npix);
     double* d_partials = ws.take<double>(1024);
     double* h_header = static_cast<double*>(c->h_pinned);  // written by zsum_decide_kernel itself (host-mapped)
-    rc = depth_map_launch(c, d_inl, m, v_inout, fx, fy, cx, cy, rows, cols, d_depth_map, d_xs, d_ys, d_header, d_owner, d_partials,
-                          h_header);
+    rc = depth_map_launch(c, d_inl, m, v_inout, fx, fy, cx, cy, rows, cols, d_depth_map, d_xs, d_ys, d_header, d_partials, h_header);
     if (rc != RSDSFM_OK) return rc;
     if (w_or_null && d_R_rows9 && d_t_rows3) {
         Pose pose;

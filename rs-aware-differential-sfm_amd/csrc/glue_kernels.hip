@@ -205,9 +205,11 @@ __global__ __launch_bounds__(256) void zsum_decide_kernel(const double* __restri
 
 // flips z in place if requested, computes pixel indices, claims pixels for the HIGHEST inlier index (the
 // reference's sequential loop lets the last writer win, main.cc:499-508)
+// owner: persistent claim words `tag | inlier index` (claim_map_acquire: words of earlier calls carry an older epoch and lose every
+// atomicMax, so the map needs no clearing pass per call -- round 1 filled 8 B/pixel with -1 before every depth map)
 __global__ __launch_bounds__(kGB) void depth_claim_kernel(double* __restrict__ inl, int64_t m, const double* __restrict__ header,
                                                          double fx, double fy, double cx, double cy, int rows, int col0,
-                                                         int ncols, long long* __restrict__ owner,
+                                                         int ncols, unsigned* __restrict__ owner, unsigned tag,
                                                          int32_t* __restrict__ xs, int32_t* __restrict__ ys) {
     const bool flip = header[0] != 0.0;
     const int64_t stride = (int64_t)gridDim.x * kGB;
@@ -217,16 +219,16 @@ __global__ __launch_bounds__(kGB) void depth_claim_kernel(double* __restrict__ i
         const int y = (int)(fy * inl[3 * i + 1] + cy + 0.5);
         if (xs) xs[i] = x;
         if (ys) ys[i] = y;
-        if (x >= col0 && x < col0 + ncols && y >= 0 && y < rows) atomicMax(&owner[(int64_t)(x - col0) * rows + y], (long long)i);
+        if (x >= col0 && x < col0 + ncols && y >= 0 && y < rows) atomicMax(&owner[(int64_t)(x - col0) * rows + y], tag | (unsigned)i);
     }
 }
 
-__global__ __launch_bounds__(kGB) void depth_write_kernel(const double* __restrict__ inl, const long long* __restrict__ owner,
-                                                         int64_t npix, double* __restrict__ depth_map) {
+__global__ __launch_bounds__(kGB) void depth_write_kernel(const double* __restrict__ inl, const unsigned* __restrict__ owner, unsigned tag,
+                                                         unsigned mask, int64_t npix, double* __restrict__ depth_map) {
     const int64_t stride = (int64_t)gridDim.x * kGB;
     for (int64_t p = (int64_t)blockIdx.x * kGB + threadIdx.x; p < npix; p += stride) {
-        const long long o = owner[p];
-        depth_map[p] = (o >= 0) ? inl[3 * o + 2] : 0.0;
+        const unsigned w = owner[p];
+        depth_map[p] = ((w & ~mask) == tag) ? inl[3 * (int64_t)(w & mask) + 2] : 0.0;
     }
 }
 
@@ -363,36 +365,40 @@ int zsum_row_launch(Ctx* c, const double* d_inl, int64_t m, double* d_partials, 
 }
 
 // sign decision from nz partial z sums over m_total points, then claim + write of the column slab [col0, col0 + ncols)
-// d_header: 4 doubles (flipped, v'); d_owner: rows*ncols int64
+// d_header: 4 doubles (flipped, v')
 int depth_map_slab_launch(Ctx* c, double* d_inl, int64_t m, const double* d_zsums, int nz, int64_t m_total, const double v[3],
                           double fx, double fy, double cx, double cy, int rows, int col0, int ncols, double* d_depth_map,
-                          int32_t* d_xs, int32_t* d_ys, double* d_header, long long* d_owner, double* h_header) {
+                          int32_t* d_xs, int32_t* d_ys, double* d_header, double* h_header) {
     const int64_t npix = (int64_t)rows * ncols;
+    if (m >= ((int64_t)1 << 31)) return fail(c, RSDSFM_ERR_INVALID, "depth map: more than 2^31 inliers");
     Pose pv;
     memset(&pv, 0, sizeof(pv));
     pv.v[0] = v[0], pv.v[1] = v[1], pv.v[2] = v[2];
     hipLaunchKernelGGL(zsum_decide_kernel, dim3(1), dim3(256), 0, c->stream, d_zsums, nz, m_total, pv, d_header, h_header);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_owner, 0xFF, sizeof(long long) * (size_t)npix, c->stream));  // -1
+    // the claim word holds the inlier index: the map's index field is sized by the larger of the two counts
+    unsigned *d_owner = nullptr, tag = 0, mask = 0;
+    int rc = claim_map_acquire(c, 2, (size_t)std::max<int64_t>(std::max<int64_t>(npix, m), 1), &d_owner, &tag, &mask);
+    if (rc != RSDSFM_OK) return rc;
     if (m > 0) {
         hipLaunchKernelGGL(depth_claim_kernel, dim3(stream_grid(m)), dim3(kGB), 0, c->stream, d_inl, m, d_header, fx, fy, cx, cy, rows,
-                           col0, ncols, d_owner, d_xs, d_ys);
+                           col0, ncols, d_owner, tag, d_xs, d_ys);
         RSDSFM_HIP_CHECK(c, hipGetLastError());
     }
-    hipLaunchKernelGGL(depth_write_kernel, dim3(stream_grid(npix)), dim3(kGB), 0, c->stream, d_inl, d_owner, npix, d_depth_map);
+    hipLaunchKernelGGL(depth_write_kernel, dim3(stream_grid(npix)), dim3(kGB), 0, c->stream, d_inl, d_owner, tag, mask, npix, d_depth_map);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
 
-// d_header: 4 doubles (flipped, v'); d_owner: rows*cols int64; d_partials: >= 1024 doubles
+// d_header: 4 doubles (flipped, v'); d_partials: >= 1024 doubles
 int depth_map_launch(Ctx* c, double* d_inl, int64_t m, const double v[3], double fx, double fy, double cx, double cy, int rows,
-                     int cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, double* d_header, long long* d_owner,
-                     double* d_partials, double* h_header) {
+                     int cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, double* d_header, double* d_partials,
+                     double* h_header) {
     const int zb = zsum_blocks(m);
     hipLaunchKernelGGL(zsum_partial_kernel, dim3(zb), dim3(kGB), 0, c->stream, d_inl, m, d_partials);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return depth_map_slab_launch(c, d_inl, m, d_partials, zb, m, v, fx, fy, cx, cy, rows, 0, cols, d_depth_map, d_xs, d_ys, d_header,
-                                 d_owner, h_header);
+                                 h_header);
 }
 
 }  // namespace rsdsfm

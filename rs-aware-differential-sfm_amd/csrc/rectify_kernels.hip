@@ -361,12 +361,12 @@ static inline int stream_grid(int64_t n, int per_thread = 1) {
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
-// Persistent claim map `which` (0: back projection, 1: depth image) of the context with room for npix words.  Words are
+// Persistent claim map `which` (0: back projection, 1: depth image, 2: the solve's depth map) of the context with room for npix words.  Words are
 // `tag | index`: tag = epoch << 24 with a per-call epoch 1..255 and index < 2^24 -- a word written by an earlier call carries an
 // older epoch, loses every atomicMax against the current one and is ignored by the read-back (valid iff word & ~mask == tag), so
 // the map is cleared only when it is (re)allocated and when the epoch wraps (every 255 calls).  Images beyond 2^24 pixels fall
 // back to a clear per call with a 1-bit tag.
-static int claim_map_acquire(Ctx* c, int which, size_t npix, unsigned** map, unsigned* tag, unsigned* mask) {
+int claim_map_acquire(Ctx* c, int which, size_t npix, unsigned** map, unsigned* tag, unsigned* mask) {
     bool clear = false;
     if (npix > c->claim_words[which]) {
         RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));

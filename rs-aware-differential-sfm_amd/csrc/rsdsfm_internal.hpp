@@ -124,9 +124,9 @@ struct Ctx {
     void* tile_session = nullptr;  // heap RefineBuffers of the open session
     int tile_np = 0;
     // persistent claim maps of the forward-splat kernels (rectify_kernels.hip: claim_map_acquire): 0 = back projection, 1 = depth image
-    unsigned* d_claim[2] = {nullptr, nullptr};
-    size_t claim_words[2] = {0, 0};
-    unsigned claim_epoch[2] = {0, 0};
+    unsigned* d_claim[3] = {nullptr, nullptr, nullptr};  // 2 = the depth map of the solve (glue_kernels.hip: depth_claim_kernel)
+    size_t claim_words[3] = {0, 0, 0};
+    unsigned claim_epoch[3] = {0, 0, 0};
     void* dist = nullptr;  // dist_host.hip: communicator / transport + exchange buffers of the native tiled solve
 };
 void dist_release(Ctx* c);
@@ -213,12 +213,14 @@ int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, int col0, do
                    double gamma, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* d_counts,
                    int64_t* d_offsets, int64_t* d_total, hipEvent_t total_ready = nullptr);
 int depth_map_launch(Ctx* c, double* d_inl, int64_t m, const double v[3], double fx, double fy, double cx, double cy, int rows,
-                     int cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, double* d_header, long long* d_owner,
-                     double* d_partials, double* h_header = nullptr);
-int zsum_row_launch(Ctx* c, const double* d_inl, int64_t m, double* d_partials, double* d_out);
+                     int cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, double* d_header, double* d_partials,
+                     double* h_header = nullptr);
 int depth_map_slab_launch(Ctx* c, double* d_inl, int64_t m, const double* d_zsums, int nz, int64_t m_total, const double v[3],
                           double fx, double fy, double cx, double cy, int rows, int col0, int ncols, double* d_depth_map,
-                          int32_t* d_xs, int32_t* d_ys, double* d_header, long long* d_owner, double* h_header = nullptr);
+                          int32_t* d_xs, int32_t* d_ys, double* d_header, double* h_header = nullptr);
+// persistent epoch-tagged claim map `which` of the context (rectify_kernels.hip)
+int claim_map_acquire(Ctx* c, int which, size_t npix, unsigned** map, unsigned* tag, unsigned* mask);
+int zsum_row_launch(Ctx* c, const double* d_inl, int64_t m, double* d_partials, double* d_out);
 }  // namespace rsdsfm
 
 namespace rsdsfm {

@@ -308,15 +308,14 @@ int rsdsfm_tile_depth_map_dev(rsdsfm_ctx* ctx, double* d_inl, int64_t m, const d
     if (m < 0 || rows < 0 || col0 < 0 || slab_cols < 0 || nranks < 1 || m_total < m || !v_inout || !d_zsums_all) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     const size_t npix = (size_t)rows * (size_t)slab_cols;
     if ((m > 0 && !d_inl) || (npix > 0 && !d_depth_slab)) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
-    int rc = ensure_ws(c, Arena::need(64) + Arena::need(8 * npix) + 1024);
+    int rc = ensure_ws(c, Arena::need(64) + 1024);
     if (rc != RSDSFM_OK) return rc;
     rc = ensure_pinned(c, 64);
     if (rc != RSDSFM_OK) return rc;
     Arena ws(c->d_ws);
     double* d_header = ws.take<double>(4);
-    long long* d_owner = ws.take<long long>(npix);
     rc = depth_map_slab_launch(c, d_inl, m, d_zsums_all, nranks, m_total, v_inout, fx, fy, cx, cy, rows, col0, slab_cols, d_depth_slab,
-                               d_xs, d_ys, d_header, d_owner);
+                               d_xs, d_ys, d_header);
     if (rc != RSDSFM_OK) return rc;
     double* h_header = static_cast<double*>(c->h_pinned);
     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_header, d_header, 4 * sizeof(double), hipMemcpyDeviceToHost, c->stream));

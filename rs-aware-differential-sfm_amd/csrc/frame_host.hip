@@ -1,6 +1,7 @@
 // frame_host.hip -- rsdsfm_solve_frame_dev: the solver part of the reference's evaluateSingleRun() (main.cc:398-522) as
 // ONE call on device-resident buffers: flatten + alpha -> RANSAC -> nonlinear refinement -> sign flip + depth map ->
 // per-scanline pose table.  Pure orchestration of the stage entry points (no extra kernels).
+#include <stdlib.h>
 #include <string.h>
 
 #include "rsdsfm_internal.hpp"
@@ -11,7 +12,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
 int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
                   const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
                   int const_acceleration, int flow_index_mode, double* d_inl_out, double v_out[3], double w_out[3], double* k_out,
-                  rsdsfm_lm_summary* summary);
+                  rsdsfm_lm_summary* summary, const RefineTail* tail);
 int alpha_ones_launch(Ctx* c, double* d_alpha, int64_t n);
 }  // namespace rsdsfm
 
@@ -30,7 +31,7 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
     const size_t N = (size_t)rows * (size_t)cols;
     // frame buffers live in the context's frame arena (separate from the per-stage workspace)
     const size_t need = 2 * Arena::need(16 * N) + 4 * Arena::need(8 * N) + 2 * Arena::need(24 * N) + Arena::need(8 * N) + Arena::need(N) +
-                        Arena::need(4 * N) + 4096;
+                        Arena::need(4 * N) + Arena::need(8 * 1024) + Arena::need(64) + 4096;
     if (need > c->frame_bytes) {
         RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
         if (c->d_frame) RSDSFM_HIP_CHECK(c, hipFree(c->d_frame));
@@ -51,6 +52,8 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
     int64_t* d_idx = fa.take<int64_t>(N);
     uint8_t* d_mask = fa.take<uint8_t>(N);
     int32_t* d_ys = fa.take<int32_t>(N);
+    double* d_zpartials = fa.take<double>(1024);  // scratch of the depth-map stage when it is enqueued behind the refinement
+    double* d_zheader = fa.take<double>(8);
 
     memset(res, 0, sizeof(*res));
     int64_t n = 0;
@@ -78,17 +81,39 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
     res->ransac_k = ro.k;
     double v[3] = {ro.v[0], ro.v[1], ro.v[2]}, w[3] = {ro.w[0], ro.w[1], ro.w[2]}, k = ro.k;
     double* d_final = d_inl;
+    int flipped = 0;
     if (prm->use_refinement) {
-        rc = refine_device(c, d_u, n, ro.num_inliers, d_inl, d_in_a, d_in_ak, d_idx, v, w, k, prm->use_acceleration_mode,
-                           prm->flow_index_mode, d_inl_ref, v, w, &k, &res->refine_summary);
+        // The depth map and the pose table only need the refinement's DEVICE-resident result (refined inliers, v / w / k in the state),
+        // so they are enqueued behind its output pass and the synchronisation that ends the refinement covers them: no second host
+        // round trip.  {flipped, v'} arrive through host-mapped memory (written by zsum_decide_kernel), past the refinement's own block.
+        constexpr size_t kHeaderOff = 2048;
+        rc = ensure_pinned(c, kHeaderOff + 64);
+        if (rc != RSDSFM_OK) return rc;
+        double* h_header = reinterpret_cast<double*>(static_cast<char*>(c->h_pinned) + kHeaderOff);
+        const int64_t m = ro.num_inliers;
+        const RefineTail tail = [&](const RefineState* st) -> int {
+            int rt = depth_map_launch(c, d_inl_ref, m, nullptr, fx, fy, cx, cy, rows, cols, d_depth_map, nullptr, d_ys, d_zheader, d_zpartials,
+                                      h_header, st->p);
+            if (rt != RSDSFM_OK) return rt;
+            if (d_R_rows9 && d_t_rows3) {
+                Pose pose;
+                memset(&pose, 0, sizeof(pose));
+                rt = pose_table_launch(c, pose, gamma, rows, d_R_rows9, d_t_rows3, d_zheader + 1, st->p + 3);
+            }
+            return rt;
+        };
+        rc = refine_device(c, d_u, n, m, d_inl, d_in_a, d_in_ak, d_idx, v, w, k, prm->use_acceleration_mode, prm->flow_index_mode, d_inl_ref,
+                           v, w, &k, &res->refine_summary, &tail);
         if (rc != RSDSFM_OK) return rc;
         d_final = d_inl_ref;
+        flipped = h_header[0] != 0.0;
+        v[0] = h_header[1], v[1] = h_header[2], v[2] = h_header[3];
+    } else {
+        // depth map and, behind it on the stream, the pose table of the (possibly sign-flipped) final motion: one synchronisation
+        rc = depth_map_device(c, d_final, ro.num_inliers, v, fx, fy, cx, cy, rows, cols, d_depth_map, nullptr, d_ys, &flipped, w, k, gamma,
+                              d_R_rows9, d_t_rows3);
+        if (rc != RSDSFM_OK) return rc;
     }
-    int flipped = 0;
-    // depth map and, behind it on the stream, the pose table of the (possibly sign-flipped) final motion: one synchronisation
-    rc = depth_map_device(c, d_final, ro.num_inliers, v, fx, fy, cx, cy, rows, cols, d_depth_map, nullptr, d_ys, &flipped, w, k, gamma,
-                          d_R_rows9, d_t_rows3);
-    if (rc != RSDSFM_OK) return rc;
     res->flipped = flipped;
     memcpy(res->v, v, sizeof(v));
     memcpy(res->w, w, sizeof(w));

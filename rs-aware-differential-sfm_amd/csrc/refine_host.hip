@@ -9,10 +9,15 @@
 namespace rsdsfm {
 
 // all pointers DEVICE (d_inlier_idx may be null in compat mode); v/w/k and summary on the host
+// tail (optional): work of the CALLER that only needs the refinement's device-resident result -- the refined inliers in d_inl_out and
+// (v, w, k) in RefineState::p -- and is enqueued behind the output pass, BEFORE the host waits for the state: the frame solve hands
+// in its depth-map + pose-table stage, so that the one synchronisation at the end of the refinement covers that stage as well
+// (one host round trip with an idle GPU less per frame).  If LM iterations remain after a chunk the tail simply runs again behind
+// the next output pass; what it computed on the unfinished state is overwritten.
 int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
                   const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
                   int const_acceleration, int flow_index_mode, double* d_inl_out, double v_out[3], double w_out[3], double* k_out,
-                  rsdsfm_lm_summary* summary) {
+                  rsdsfm_lm_summary* summary, const RefineTail* tail) {
     if (m < 0 || n_flow < 0 || !v_in || !w_in || !v_out || !w_out || !k_out) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     if (flow_index_mode != RSDSFM_FLOW_COMPAT_RANK && flow_index_mode != RSDSFM_FLOW_GATHERED) return fail(c, RSDSFM_ERR_INVALID, "unknown flow_index_mode");
     if (flow_index_mode == RSDSFM_FLOW_GATHERED && m > 0 && !d_inlier_idx) return fail(c, RSDSFM_ERR_INVALID, "gathered mode needs inlier_idx");
@@ -63,11 +68,12 @@ int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const
     rc = refine_init_launch(c, B, np);
     if (rc != RSDSFM_OK) return rc;
     // LM iterations are enqueued in chunks; the kernels of a finished solve return immediately, but an empty iteration still costs
-    // four launches (~19 us) and a chunk that is too short a host round trip (~25 us).  Chunks are 5 iterations (DeepFlow-like data
+    // four launches (~19 us) and a chunk that is too short a host round trip (~25 us).  The first chunk is 5 iterations (DeepFlow-like data
     // takes 3..6: following the previous solve's count more closely was measured 1 % slower, the counts vary from pair to pair),
     // except behind a refinement that ended within 2 iterations -- noise-free data, e.g. ground-truth flow, ends after ONE -- where
     // the first chunk is that count + 1.  The chunking changes when the host looks at the state, never what the kernels compute.
-    int chunk = (c->refine_iters_hint >= 0 && c->refine_iters_hint <= 2) ? c->refine_iters_hint + 1 : 5;
+    const int hint_prev = c->refine_iters_hint;
+    int chunk = (hint_prev >= 0 && hint_prev <= 2) ? hint_prev + 1 : 5;
     for (int launched = 0;;) {
         for (int i = 0; i < chunk; ++i) {
             rc = refine_iter_launch(c, B, np);
@@ -78,12 +84,18 @@ int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const
         // which saves a host round trip with an idle GPU; if iterations remain it simply runs again after the next chunk
         rc = refine_finish_launch(c, B, d_inl_out);
         if (rc != RSDSFM_OK) return rc;
+        if (tail) {
+            rc = (*tail)(B.state);
+            if (rc != RSDSFM_OK) return rc;
+        }
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(hs, B.state, sizeof(RefineState) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
         RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
         if (*h_bad) return fail(c, RSDSFM_ERR_INVALID, "flow index out of range (flow has fewer columns than inliers / bad inlier_idx)");
         if (hs->termination >= 0) break;
         if (launched > 4 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
-        chunk = 5;
+        // later chunks: what the previous solve still needed at this point, between 2 and 5 (DeepFlow-like data has 0..1 iterations
+        // left after the first chunk -- an empty iteration costs four launches --, acceleration mode runs ~13 in all)
+        chunk = std::min(5, std::max(2, hint_prev - launched));
     }
     c->refine_iters_hint = hs->iteration;
     for (int i = 0; i < 3; ++i) {
@@ -116,7 +128,7 @@ int rsdsfm_refine_dev(rsdsfm_ctx* ctx, const double* d_flow, int64_t n_flow, int
     if (!ctx) return RSDSFM_ERR_INVALID;
     DeviceGuard device_guard_(&ctx->c);
     return refine_device(&ctx->c, d_flow, n_flow, m, d_inl, d_alpha, d_alpha_k, d_inlier_idx, v_in, w_in, k_in, const_acceleration,
-                         flow_index_mode, d_inl_out, v_out, w_out, k_out, summary);
+                         flow_index_mode, d_inl_out, v_out, w_out, k_out, summary, nullptr);
 }
 
 int rsdsfm_refine(rsdsfm_ctx* ctx, const double* flow, int64_t n_flow, int64_t m, const double* inl, const double* alpha,
@@ -146,7 +158,7 @@ int rsdsfm_refine(rsdsfm_ctx* ctx, const double* flow, int64_t n_flow, int64_t m
         if (inlier_idx) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_idx, inlier_idx, 8 * M, hipMemcpyHostToDevice, c->stream));
     }
     rc = refine_device(c, d_flow, n_flow, m, d_inl, d_a, d_ak, inlier_idx ? d_idx : nullptr, v_in, w_in, k_in, const_acceleration,
-                       flow_index_mode, d_out, v_out, w_out, k_out, summary);
+                       flow_index_mode, d_out, v_out, w_out, k_out, summary, nullptr);
     if (rc != RSDSFM_OK) return rc;
     if (M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(inl_out, d_out, 24 * M, hipMemcpyDeviceToHost, c->stream));
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
 #include <string>
 
 #include "../../include/rsdsfm.h"
@@ -207,17 +208,18 @@ int alpha_k_launch(Ctx* c, const double* q_px, const double* flow_px, int64_t n,
 int depth_map_device(Ctx* c, double* d_inl, int64_t m, double v_inout[3], double fx, double fy, double cx, double cy, int32_t rows, int32_t cols,
                      double* d_depth_map, int32_t* d_xs, int32_t* d_ys, int* flipped, const double* w_or_null, double k, double gamma,
                      double* d_R_rows9, double* d_t_rows3);
-int pose_table_launch(Ctx* c, const Pose& pose, double gamma, int rows, double* R, double* t, const double* v_dev = nullptr);
+int pose_table_launch(Ctx* c, const Pose& pose, double gamma, int rows, double* R, double* t, const double* v_dev = nullptr,
+                      const double* wk_dev = nullptr);
 int64_t flatten_cells(int rows, int cols);
 int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, int col0, double fx, double fy, double cx, double cy,
                    double gamma, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* d_counts,
                    int64_t* d_offsets, int64_t* d_total, hipEvent_t total_ready = nullptr);
 int depth_map_launch(Ctx* c, double* d_inl, int64_t m, const double v[3], double fx, double fy, double cx, double cy, int rows,
                      int cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, double* d_header, double* d_partials,
-                     double* h_header = nullptr);
+                     double* h_header = nullptr, const double* v_dev = nullptr);
 int depth_map_slab_launch(Ctx* c, double* d_inl, int64_t m, const double* d_zsums, int nz, int64_t m_total, const double v[3],
                           double fx, double fy, double cx, double cy, int rows, int col0, int ncols, double* d_depth_map,
-                          int32_t* d_xs, int32_t* d_ys, double* d_header, double* h_header = nullptr);
+                          int32_t* d_xs, int32_t* d_ys, double* d_header, double* h_header = nullptr, const double* v_dev = nullptr);
 // persistent epoch-tagged claim map `which` of the context (rectify_kernels.hip)
 int claim_map_acquire(Ctx* c, int which, size_t npix, unsigned** map, unsigned* tag, unsigned* mask);
 int zsum_row_launch(Ctx* c, const double* d_inl, int64_t m, double* d_partials, double* d_out);
@@ -283,6 +285,8 @@ struct RefineBuffers {
     double* partials;
     int* bad_index;
 };
+// see refine_device (refine_host.hip): caller's work enqueued behind the refinement's output pass, given the device-resident state
+typedef std::function<int(const RefineState*)> RefineTail;
 int refine_partials_doubles(const Ctx* c, int64_t m);
 // start of a refinement: NaN-fill the opt-in iteration trace (rsdsfm_set_refine_trace), enqueued on the context's stream
 inline int refine_trace_reset(Ctx* c) {

@@ -168,8 +168,12 @@ __global__ __launch_bounds__(kGB) void flatten_tile_kernel(const double2* __rest
 
 // ---- depth map ----
 // fixed-order sum of z = inliers(2, i): per-block partials then one workgroup
-__global__ __launch_bounds__(kGB) void zsum_partial_kernel(const double* __restrict__ inl, int64_t m, double* __restrict__ partials) {
+// m_dev (optional, here and in the kernels below): the inlier count is read from device memory (RefineState::m) -- the frame solve
+// enqueues this stage before the host knows it; `m` is then only the upper bound the grid was sized for
+__global__ __launch_bounds__(kGB) void zsum_partial_kernel(const double* __restrict__ inl, int64_t m, double* __restrict__ partials,
+                                                          const int64_t* __restrict__ m_dev) {
     __shared__ double s_red[kGB / 64];
+    if (m_dev) m = *m_dev;
     double acc = 0.0;
     const int64_t stride = (int64_t)gridDim.x * kGB;
     for (int64_t i = (int64_t)blockIdx.x * kGB + threadIdx.x; i < m; i += stride) acc += inl[3 * i + 2];
@@ -187,8 +191,9 @@ __global__ __launch_bounds__(kGB) void zsum_partial_kernel(const double* __restr
 // v_dev (optional): v is read from device memory (RefineState::p) instead of `pose_v`
 __global__ __launch_bounds__(256) void zsum_decide_kernel(const double* __restrict__ partials, int nblocks, int64_t m, Pose pose_v,
                                                          double* __restrict__ header, double* __restrict__ header_host,
-                                                         const double* __restrict__ v_dev) {
+                                                         const double* __restrict__ v_dev, const int64_t* __restrict__ m_dev) {
     if (v_dev) pose_v.v[0] = v_dev[0], pose_v.v[1] = v_dev[1], pose_v.v[2] = v_dev[2];
+    if (m_dev) m = *m_dev;
     __shared__ double s_red[4];
     double acc = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256) acc += partials[b];
@@ -217,7 +222,9 @@ __global__ __launch_bounds__(256) void zsum_decide_kernel(const double* __restri
 __global__ __launch_bounds__(kGB) void depth_claim_kernel(double* __restrict__ inl, int64_t m, const double* __restrict__ header,
                                                          double fx, double fy, double cx, double cy, int rows, int col0,
                                                          int ncols, unsigned* __restrict__ owner, unsigned tag,
-                                                         int32_t* __restrict__ xs, int32_t* __restrict__ ys) {
+                                                         int32_t* __restrict__ xs, int32_t* __restrict__ ys,
+                                                         const int64_t* __restrict__ m_dev) {
+    if (m_dev) m = *m_dev;
     const bool flip = header[0] != 0.0;
     const int64_t stride = (int64_t)gridDim.x * kGB;
     for (int64_t i = (int64_t)blockIdx.x * kGB + threadIdx.x; i < m; i += stride) {
@@ -364,7 +371,7 @@ static inline int zsum_blocks(int64_t m) { return (int)std::min<int64_t>(1024, s
 
 int zsum_row_launch(Ctx* c, const double* d_inl, int64_t m, double* d_partials, double* d_out) {
     const int zb = zsum_blocks(m);
-    hipLaunchKernelGGL(zsum_partial_kernel, dim3(zb), dim3(kGB), 0, c->stream, d_inl, m, d_partials);
+    hipLaunchKernelGGL(zsum_partial_kernel, dim3(zb), dim3(kGB), 0, c->stream, d_inl, m, d_partials, (const int64_t*)nullptr);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(zsum_row_kernel, dim3(1), dim3(256), 0, c->stream, d_partials, zb, d_out);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
@@ -375,13 +382,13 @@ int zsum_row_launch(Ctx* c, const double* d_inl, int64_t m, double* d_partials, 
 // d_header: 4 doubles (flipped, v')
 int depth_map_slab_launch(Ctx* c, double* d_inl, int64_t m, const double* d_zsums, int nz, int64_t m_total, const double v[3],
                           double fx, double fy, double cx, double cy, int rows, int col0, int ncols, double* d_depth_map,
-                          int32_t* d_xs, int32_t* d_ys, double* d_header, double* h_header, const double* v_dev) {
+                          int32_t* d_xs, int32_t* d_ys, double* d_header, double* h_header, const double* v_dev, const int64_t* m_dev) {
     const int64_t npix = (int64_t)rows * ncols;
     if (m >= ((int64_t)1 << 31)) return fail(c, RSDSFM_ERR_INVALID, "depth map: more than 2^31 inliers");
     Pose pv;
     memset(&pv, 0, sizeof(pv));
     if (v) pv.v[0] = v[0], pv.v[1] = v[1], pv.v[2] = v[2];
-    hipLaunchKernelGGL(zsum_decide_kernel, dim3(1), dim3(256), 0, c->stream, d_zsums, nz, m_total, pv, d_header, h_header, v_dev);
+    hipLaunchKernelGGL(zsum_decide_kernel, dim3(1), dim3(256), 0, c->stream, d_zsums, nz, m_total, pv, d_header, h_header, v_dev, m_dev);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     // the claim word holds the inlier index: the map's index field is sized by the larger of the two counts
     unsigned *d_owner = nullptr, tag = 0, mask = 0;
@@ -389,7 +396,7 @@ int depth_map_slab_launch(Ctx* c, double* d_inl, int64_t m, const double* d_zsum
     if (rc != RSDSFM_OK) return rc;
     if (m > 0) {
         hipLaunchKernelGGL(depth_claim_kernel, dim3(stream_grid(m)), dim3(kGB), 0, c->stream, d_inl, m, d_header, fx, fy, cx, cy, rows,
-                           col0, ncols, d_owner, tag, d_xs, d_ys);
+                           col0, ncols, d_owner, tag, d_xs, d_ys, m_dev);
         RSDSFM_HIP_CHECK(c, hipGetLastError());
     }
     hipLaunchKernelGGL(depth_write_kernel, dim3(stream_grid(npix)), dim3(kGB), 0, c->stream, d_inl, d_owner, tag, mask, npix, d_depth_map);
@@ -400,12 +407,12 @@ int depth_map_slab_launch(Ctx* c, double* d_inl, int64_t m, const double* d_zsum
 // d_header: 4 doubles (flipped, v'); d_partials: >= 1024 doubles
 int depth_map_launch(Ctx* c, double* d_inl, int64_t m, const double v[3], double fx, double fy, double cx, double cy, int rows,
                      int cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, double* d_header, double* d_partials,
-                     double* h_header, const double* v_dev) {
+                     double* h_header, const double* v_dev, const int64_t* m_dev) {
     const int zb = zsum_blocks(m);
-    hipLaunchKernelGGL(zsum_partial_kernel, dim3(zb), dim3(kGB), 0, c->stream, d_inl, m, d_partials);
+    hipLaunchKernelGGL(zsum_partial_kernel, dim3(zb), dim3(kGB), 0, c->stream, d_inl, m, d_partials, m_dev);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return depth_map_slab_launch(c, d_inl, m, d_partials, zb, m, v, fx, fy, cx, cy, rows, 0, cols, d_depth_map, d_xs, d_ys, d_header,
-                                 h_header, v_dev);
+                                 h_header, v_dev, m_dev);
 }
 
 }  // namespace rsdsfm

@@ -14,26 +14,38 @@ namespace rsdsfm {
 // in its depth-map + pose-table stage, so that the one synchronisation at the end of the refinement covers that stage as well
 // (one host round trip with an idle GPU less per frame).  If LM iterations remain after a chunk the tail simply runs again behind
 // the next output pass; what it computed on the unfinished state is overwritten.
-int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
-                  const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
-                  int const_acceleration, int flow_index_mode, double* d_inl_out, double v_out[3], double w_out[3], double* k_out,
-                  rsdsfm_lm_summary* summary, const RefineTail* tail) {
-    if (m < 0 || n_flow < 0 || !v_in || !w_in || !v_out || !w_out || !k_out) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+//
+// The refinement runs in two phases.  refine_begin lays out the buffers and enqueues the start state, iteration zero, the first chunk of
+// LM iterations, the output pass and the tail; refine_poll waits for the state and enqueues further chunks until the solve has
+// terminated.  refine_device = both.  The frame solve calls refine_begin BEFORE it has read the RANSAC result (d_best != null: the
+// start pose and the inlier count come from the device-resident RansacBest, `m` is only an upper bound, the buffers live in
+// `ws_base` instead of the stage workspace the RANSAC still owns) and refine_poll once the RANSAC's own synchronisation has passed.
+int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
+                 const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
+                 int const_acceleration, int flow_index_mode, double* d_inl_out, const RefineTail* tail, const RansacBest* d_best,
+                 void* ws_base, RefineRun* run) {
+    if (m < 0 || n_flow < 0 || (!d_best && (!v_in || !w_in))) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     if (flow_index_mode != RSDSFM_FLOW_COMPAT_RANK && flow_index_mode != RSDSFM_FLOW_GATHERED) return fail(c, RSDSFM_ERR_INVALID, "unknown flow_index_mode");
     if (flow_index_mode == RSDSFM_FLOW_GATHERED && m > 0 && !d_inlier_idx) return fail(c, RSDSFM_ERR_INVALID, "gathered mode needs inlier_idx");
     if (m > 0 && (!d_flow || !d_inl || !d_alpha || !d_alpha_k || !d_inl_out)) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
     const int np = const_acceleration ? 7 : 6;
     const size_t M = (size_t)std::max<int64_t>(m, 1);
-    const size_t npart = (size_t)refine_partials_doubles(c, m);
-    int rc = ensure_ws(c, Arena::need(sizeof(RefineState) + 64) + Arena::need(32 * M) + 4 * Arena::need(8 * M) + Arena::need(8 * npart) + Arena::need(64) + 1024);
-    if (rc != RSDSFM_OK) return rc;
+    const size_t npart = (size_t)(d_best ? refine_partials_doubles_cap(c) : refine_partials_doubles(c, m));
+    int rc = RSDSFM_OK;
+    if (!ws_base) {
+        rc = ensure_ws(c, refine_workspace_bytes(c, m, d_best != nullptr));
+        if (rc != RSDSFM_OK) return rc;
+        ws_base = c->d_ws;
+    }
     rc = ensure_pinned(c, sizeof(RefineState) + 64);
     if (rc != RSDSFM_OK) return rc;
-    Arena ws(c->d_ws);
-    RefineBuffers B;
+    Arena ws(ws_base);
+    RefineBuffers& B = run->B;
+    B = RefineBuffers();
     B.flow = d_flow;
     B.n_flow = n_flow;
     B.m = m;
+    B.m_on_device = d_best != nullptr;
     B.inl = d_inl;
     B.alpha = d_alpha;
     B.alpha_k = d_alpha_k;
@@ -50,19 +62,29 @@ int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const
     B.srho = ws.take<double>(M);
     B.partials = ws.take<double>(npart);
     B.bad_index = reinterpret_cast<int*>(state_block + sizeof(RefineState));
-    RefineState* hs = static_cast<RefineState*>(c->h_pinned);
-    int* h_bad = reinterpret_cast<int*>(static_cast<char*>(c->h_pinned) + sizeof(RefineState));
-    memset(hs, 0, sizeof(RefineState));
-    hs->np = np;
-    for (int i = 0; i < 3; ++i) {
-        hs->p[i] = v_in[i];
-        hs->p[3 + i] = w_in[i];
+    run->np = np;
+    run->d_inl_out = d_inl_out;
+    run->tail = tail;
+    run->launched = 0;
+    run->hint_prev = c->refine_iters_hint;
+    if (d_best) {
+        rc = refine_state_from_best_launch(c, d_best, B, np);
+        if (rc != RSDSFM_OK) return rc;
+    } else {
+        RefineState* hs = static_cast<RefineState*>(c->h_pinned);
+        int* h_bad = reinterpret_cast<int*>(static_cast<char*>(c->h_pinned) + sizeof(RefineState));
+        memset(hs, 0, sizeof(RefineState));
+        hs->np = np;
+        for (int i = 0; i < 3; ++i) {
+            hs->p[i] = v_in[i];
+            hs->p[3 + i] = w_in[i];
+        }
+        hs->p[6] = k_in;
+        hs->termination = -1;
+        hs->radius = kInitialRadius;
+        *h_bad = 0;
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(B.state, hs, sizeof(RefineState) + sizeof(int), hipMemcpyHostToDevice, c->stream));
     }
-    hs->p[6] = k_in;
-    hs->termination = -1;
-    hs->radius = kInitialRadius;
-    *h_bad = 0;
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(B.state, hs, sizeof(RefineState) + sizeof(int), hipMemcpyHostToDevice, c->stream));
     rc = refine_trace_reset(c);
     if (rc != RSDSFM_OK) return rc;
     rc = refine_init_launch(c, B, np);
@@ -72,30 +94,40 @@ int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const
     // takes 3..6: following the previous solve's count more closely was measured 1 % slower, the counts vary from pair to pair),
     // except behind a refinement that ended within 2 iterations -- noise-free data, e.g. ground-truth flow, ends after ONE -- where
     // the first chunk is that count + 1.  The chunking changes when the host looks at the state, never what the kernels compute.
-    const int hint_prev = c->refine_iters_hint;
-    int chunk = (hint_prev >= 0 && hint_prev <= 2) ? hint_prev + 1 : 5;
-    for (int launched = 0;;) {
-        for (int i = 0; i < chunk; ++i) {
-            rc = refine_iter_launch(c, B, np);
-            if (rc != RSDSFM_OK) return rc;
-        }
-        launched += chunk;
-        // the output pass is enqueued before the host knows whether the solve has finished (the common case: <= 5 iterations),
-        // which saves a host round trip with an idle GPU; if iterations remain it simply runs again after the next chunk
-        rc = refine_finish_launch(c, B, d_inl_out);
+    run->chunk = (run->hint_prev >= 0 && run->hint_prev <= 2) ? run->hint_prev + 1 : 5;
+    return refine_enqueue_chunk(c, run);
+}
+
+// one chunk of LM iterations, the output pass and the caller's tail
+int refine_enqueue_chunk(Ctx* c, RefineRun* run) {
+    for (int i = 0; i < run->chunk; ++i) {
+        int rc = refine_iter_launch(c, run->B, run->np);
         if (rc != RSDSFM_OK) return rc;
-        if (tail) {
-            rc = (*tail)(B.state);
-            if (rc != RSDSFM_OK) return rc;
-        }
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(hs, B.state, sizeof(RefineState) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    }
+    run->launched += run->chunk;
+    // the output pass is enqueued before the host knows whether the solve has finished (the common case: <= 5 iterations),
+    // which saves a host round trip with an idle GPU; if iterations remain it simply runs again after the next chunk
+    int rc = refine_finish_launch(c, run->B, run->d_inl_out);
+    if (rc != RSDSFM_OK) return rc;
+    if (run->tail) rc = (*run->tail)(run->B.state);
+    return rc;
+}
+
+int refine_poll(Ctx* c, RefineRun* run, double v_out[3], double w_out[3], double* k_out, rsdsfm_lm_summary* summary) {
+    if (!v_out || !w_out || !k_out) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    RefineState* hs = static_cast<RefineState*>(c->h_pinned);
+    int* h_bad = reinterpret_cast<int*>(static_cast<char*>(c->h_pinned) + sizeof(RefineState));
+    for (;;) {
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(hs, run->B.state, sizeof(RefineState) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
         RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
         if (*h_bad) return fail(c, RSDSFM_ERR_INVALID, "flow index out of range (flow has fewer columns than inliers / bad inlier_idx)");
         if (hs->termination >= 0) break;
-        if (launched > 4 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
+        if (run->launched > 4 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
         // later chunks: what the previous solve still needed at this point, between 2 and 5 (DeepFlow-like data has 0..1 iterations
         // left after the first chunk -- an empty iteration costs four launches --, acceleration mode runs ~13 in all)
-        chunk = std::min(5, std::max(2, hint_prev - launched));
+        run->chunk = std::min(5, std::max(2, run->hint_prev - run->launched));
+        int rc = refine_enqueue_chunk(c, run);
+        if (rc != RSDSFM_OK) return rc;
     }
     c->refine_iters_hint = hs->iteration;
     for (int i = 0; i < 3; ++i) {
@@ -113,6 +145,24 @@ int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const
         summary->final_radius = hs->radius;
     }
     return RSDSFM_OK;
+}
+
+size_t refine_workspace_bytes(const Ctx* c, int64_t m, bool m_on_device) {
+    const size_t M = (size_t)std::max<int64_t>(m, 1);
+    const size_t npart = (size_t)(m_on_device ? refine_partials_doubles_cap(c) : refine_partials_doubles(c, m));
+    return Arena::need(sizeof(RefineState) + 64) + Arena::need(32 * M) + 4 * Arena::need(8 * M) + Arena::need(8 * npart) + Arena::need(64) + 1024;
+}
+
+int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
+                  const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
+                  int const_acceleration, int flow_index_mode, double* d_inl_out, double v_out[3], double w_out[3], double* k_out,
+                  rsdsfm_lm_summary* summary, const RefineTail* tail) {
+    if (!v_out || !w_out || !k_out) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    RefineRun run;
+    int rc = refine_begin(c, d_flow, n_flow, m, d_inl, d_alpha, d_alpha_k, d_inlier_idx, v_in, w_in, k_in, const_acceleration, flow_index_mode,
+                          d_inl_out, tail, nullptr, nullptr, &run);
+    if (rc != RSDSFM_OK) return rc;
+    return refine_poll(c, &run, v_out, w_out, k_out, summary);
 }
 
 }  // namespace rsdsfm

@@ -25,6 +25,24 @@ namespace {
 
 constexpr int kFB = 256;
 
+// Streaming passes: `m_arg >= 0` is the inlier count and the launch grid is the logical grid (host knows both); `m_arg < 0` means
+// both are device-resident (RefineState::m / ::grid) and the launch grid is an upper bound: workgroups beyond the logical grid leave,
+// the others stride by the LOGICAL grid, so every partial row holds exactly the sums it holds on the host-sized launch.
+struct PassShape {
+    int64_t m;
+    int grid;
+    bool live;
+};
+__device__ __forceinline__ PassShape pass_shape(const RefineState* __restrict__ st, int64_t m_arg) {
+    PassShape ps;
+    if (m_arg >= 0) {
+        ps.m = m_arg, ps.grid = (int)gridDim.x, ps.live = true;
+    } else {
+        ps.m = st->m, ps.grid = st->grid, ps.live = (int)blockIdx.x < ps.grid;
+    }
+    return ps;
+}
+
 template <int NP>
 struct RJ {
     double r[2];
@@ -218,13 +236,16 @@ __global__ __launch_bounds__(kFB) void refine_init_kernel(const double2* __restr
                                                          int* __restrict__ bad_index) {
     using CT = Counts<NP>;
     __shared__ double s_red[kFB / 64][CT::NINIT];
+    const PassShape ps = pass_shape(st, m);
+    if (!ps.live) return;
+    m = ps.m;
     double p[7];
 #pragma unroll
     for (int c = 0; c < 7; ++c) p[c] = st->p[c];
     double acc[CT::NINIT];
 #pragma unroll
     for (int s = 0; s < CT::NINIT; ++s) acc[s] = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * kFB;
+    const int64_t stride = (int64_t)ps.grid * kFB;
     for (int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x; i < m; i += stride) {
         int64_t fi = (flow_index_mode == RSDSFM_FLOW_GATHERED) ? inlier_idx[i] : i;
         if (fi < 0 || fi >= n_flow) {
@@ -260,6 +281,7 @@ __global__ __launch_bounds__(kFB) void refine_init_decide_kernel(const double* _
     using CT = Counts<NP>;
     __shared__ double s_red[kFB / 64][CT::NINIT];
     __shared__ double s[CT::NINIT];
+    if (nblocks < 0) nblocks = st->grid, m = st->m;  // device-resident shape (see pass_shape)
     reduce_partials<CT::NINIT>(partials, nblocks, CT::INIT_MAX, s_red, s);
     if (threadIdx.x == 0) {
         double gmax = s[CT::INIT_MAX], xsq = s[CT::INIT_MAX + 1];
@@ -297,6 +319,9 @@ __global__ __launch_bounds__(kFB) void refine_schur_kernel(int64_t m, const doub
     using CT = Counts<NP>;
     __shared__ double s_red[kFB / 64][CT::NSCHUR];
     if (st->termination >= 0 || st->iteration >= kMaxIter || st->radius < kMinRadius) return;
+    const PassShape ps = pass_shape(st, m);
+    if (!ps.live) return;
+    m = ps.m;
     double p[7], sp[NP];
 #pragma unroll
     for (int c = 0; c < 7; ++c) p[c] = st->p[c];
@@ -307,7 +332,7 @@ __global__ __launch_bounds__(kFB) void refine_schur_kernel(int64_t m, const doub
     double acc[CT::NSCHUR];
 #pragma unroll
     for (int s = 0; s < CT::NSCHUR; ++s) acc[s] = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * kFB;
+    const int64_t stride = (int64_t)ps.grid * kFB;
     for (int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x; i < m; i += stride) {
         const double4 c4 = xyuv[i];
         RJ<NP> o;
@@ -370,7 +395,7 @@ __global__ __launch_bounds__(kFB) void refine_solve_kernel(const double* __restr
 #pragma unroll
         for (int c = 0; c < NP; ++c) sp_cur[c] = st->sp[c];
     }
-    reduce_partials<CT::NSCHUR>(partials, nblocks, -1, s_red, s);
+    reduce_partials<CT::NSCHUR>(partials, nblocks >= 0 ? nblocks : st->grid, -1, s_red, s);
     if (threadIdx.x == 0) {
         st->iteration += 1;
         const double inv_radius = 1.0 / radius;
@@ -466,6 +491,9 @@ __global__ __launch_bounds__(kFB) void refine_backsub_kernel(int64_t m, const do
     using CT = Counts<NP>;
     __shared__ double s_red[kFB / 64][CT::NBACK];
     if (st->termination >= 0 || !st->solve_ok) return;
+    const PassShape ps = pass_shape(st, m);
+    if (!ps.live) return;
+    m = ps.m;
     double p[7], pc[7], sp[NP], yp[NP];
 #pragma unroll
     for (int c = 0; c < 7; ++c) {
@@ -483,7 +511,7 @@ __global__ __launch_bounds__(kFB) void refine_backsub_kernel(int64_t m, const do
     double acc[CT::NBACK];
 #pragma unroll
     for (int s = 0; s < CT::NBACK; ++s) acc[s] = 0.0;
-    const int64_t stride = (int64_t)gridDim.x * kFB;
+    const int64_t stride = (int64_t)ps.grid * kFB;
     for (int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x; i < m; i += stride) {
         const double4 c4 = xyuv[i];
         const double x = c4.x, y = c4.y;
@@ -541,7 +569,7 @@ __global__ __launch_bounds__(kFB) void refine_decide_kernel(const double* __rest
     __shared__ double s[CT::NBACK];
     if (st->termination >= 0) return;
     const int solve_ok = st->solve_ok;
-    if (solve_ok) reduce_partials<CT::NBACK>(partials, nblocks, CT::BACK_MAX, s_red, s);
+    if (solve_ok) reduce_partials<CT::NBACK>(partials, nblocks >= 0 ? nblocks : st->grid, CT::BACK_MAX, s_red, s);
     if (threadIdx.x != 0) return;
     // optional trace (rsdsfm_set_refine_trace): one row of kRefineTraceCols doubles per LM iteration, see include/rsdsfm.h
     double* tr = (trace && st->iteration >= 1 && st->iteration <= trace_rows) ? trace + (int64_t)(st->iteration - 1) * kRefineTraceCols : nullptr;
@@ -613,6 +641,7 @@ __global__ __launch_bounds__(kFB) void refine_finish_kernel(int64_t m, const dou
                                                            const double* __restrict__ rho_a, const double* __restrict__ rho_b,
                                                            const RefineState* __restrict__ st, double* __restrict__ inl_out) {
     const double* __restrict__ rho = st->cur ? rho_b : rho_a;
+    if (m < 0) m = st->m;  // device-resident count: a plain copy pass, any grid will do
     const int64_t stride = (int64_t)gridDim.x * kFB;
     for (int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x; i < m; i += stride) {
         inl_out[3 * i] = inl[3 * i];
@@ -621,9 +650,38 @@ __global__ __launch_bounds__(kFB) void refine_finish_kernel(int64_t m, const dou
     }
 }
 
+// Start state of a refinement that is enqueued before the host has read the RANSAC result (frame solve): pose of the best trial and
+// the inlier count from the device-resident RansacBest, logical grid by the launchers' rule (refine_grid below).
+__global__ void refine_state_from_best_kernel(const RansacBest* __restrict__ best, RefineState* __restrict__ st, int np, int cap,
+                                              int* __restrict__ bad_index) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    RefineState z;
+    memset(&z, 0, sizeof(z));
+    z.np = np;
+    for (int i = 0; i < 3; ++i) {
+        z.p[i] = best->hyp[3 + i];      // v
+        z.p[3 + i] = best->hyp[i];      // w
+    }
+    z.p[6] = best->hyp[6];
+    z.termination = -1;
+    z.radius = kInitialRadius;
+    const int64_t m = best->num_inliers_scan;
+    z.m = m;
+    int64_t b = (m + kFB - 1) / kFB;
+    if (b < 1) b = 1;
+    if (b > cap) {
+        const int64_t iters = (b + cap - 1) / cap;
+        b = (b + iters - 1) / iters;
+    }
+    z.grid = (int)b;
+    *st = z;
+    *bad_index = 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
+static inline int refine_grid_cap(const Ctx* c) { return c->num_cus * 2; }
 static inline int refine_grid(const Ctx* c, int64_t m) {
     int64_t b = (m + kFB - 1) / kFB;
     const int64_t cap = (int64_t)c->num_cus * 2;
@@ -636,31 +694,41 @@ static inline int refine_grid(const Ctx* c, int64_t m) {
 }
 
 int refine_partials_doubles(const Ctx* c, int64_t m) { return refine_grid(c, m) * Counts<7>::NSCHUR; }
+int refine_partials_doubles_cap(const Ctx* c) { return refine_grid_cap(c) * Counts<7>::NSCHUR; }
+
+int refine_state_from_best_launch(Ctx* c, const RansacBest* d_best, const RefineBuffers& B, int np) {
+    hipLaunchKernelGGL(refine_state_from_best_kernel, dim3(1), dim3(64), 0, c->stream, d_best, B.state, np, refine_grid_cap(c), B.bad_index);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
 
 template <int NP>
 static int refine_init_t(Ctx* c, const RefineBuffers& B) {
-    const int grid = refine_grid(c, B.m);
+    const int grid = B.m_on_device ? refine_grid_cap(c) : refine_grid(c, B.m);
+    const int64_t m_arg = B.m_on_device ? -1 : B.m;
     hipLaunchKernelGGL(refine_init_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, reinterpret_cast<const double2*>(B.flow), B.n_flow,
-                       B.m, B.inl, B.alpha, B.alpha_k, B.inlier_idx, B.flow_index_mode, B.state, reinterpret_cast<double4*>(B.uu),
+                       m_arg, B.inl, B.alpha, B.alpha_k, B.inlier_idx, B.flow_index_mode, B.state, reinterpret_cast<double4*>(B.uu),
                        B.beta, B.rho_a, B.srho, B.partials, B.bad_index);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(refine_init_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, B.state, B.m);
+    hipLaunchKernelGGL(refine_init_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, B.m_on_device ? -1 : grid, B.state, m_arg);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
 
 template <int NP>
 static int refine_iter_t(Ctx* c, const RefineBuffers& B) {
-    const int grid = refine_grid(c, B.m);
-    hipLaunchKernelGGL(refine_schur_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m, reinterpret_cast<const double4*>(B.uu), B.beta,
+    const int grid = B.m_on_device ? refine_grid_cap(c) : refine_grid(c, B.m);
+    const int64_t m_arg = B.m_on_device ? -1 : B.m;
+    const int nb_arg = B.m_on_device ? -1 : grid;
+    hipLaunchKernelGGL(refine_schur_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, m_arg, reinterpret_cast<const double4*>(B.uu), B.beta,
                        B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(refine_solve_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, B.state);
+    hipLaunchKernelGGL(refine_solve_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, nb_arg, B.state);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(refine_backsub_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m, reinterpret_cast<const double4*>(B.uu), B.beta,
+    hipLaunchKernelGGL(refine_backsub_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, m_arg, reinterpret_cast<const double4*>(B.uu), B.beta,
                        B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(refine_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, B.state, c->d_refine_trace, c->refine_trace_rows);
+    hipLaunchKernelGGL(refine_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, nb_arg, B.state, c->d_refine_trace, c->refine_trace_rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
@@ -730,9 +798,9 @@ int refine_init_launch(Ctx* c, const RefineBuffers& B, int np) { return np == 7 
 int refine_iter_launch(Ctx* c, const RefineBuffers& B, int np) { return np == 7 ? refine_iter_t<7>(c, B) : refine_iter_t<6>(c, B); }
 
 int refine_finish_launch(Ctx* c, const RefineBuffers& B, double* inl_out) {
-    if (B.m == 0) return RSDSFM_OK;
-    hipLaunchKernelGGL(refine_finish_kernel, dim3(refine_grid(c, B.m)), dim3(kFB), 0, c->stream, B.m, B.inl, B.rho_a, B.rho_b, B.state,
-                       inl_out);
+    if (!B.m_on_device && B.m == 0) return RSDSFM_OK;
+    hipLaunchKernelGGL(refine_finish_kernel, dim3(B.m_on_device ? refine_grid_cap(c) : refine_grid(c, B.m)), dim3(kFB), 0, c->stream,
+                       B.m_on_device ? (int64_t)-1 : B.m, B.inl, B.rho_a, B.rho_b, B.state, inl_out);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

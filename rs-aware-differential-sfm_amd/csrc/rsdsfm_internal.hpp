@@ -216,10 +216,11 @@ int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, int col0, do
                    int64_t* d_offsets, int64_t* d_total, hipEvent_t total_ready = nullptr);
 int depth_map_launch(Ctx* c, double* d_inl, int64_t m, const double v[3], double fx, double fy, double cx, double cy, int rows,
                      int cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, double* d_header, double* d_partials,
-                     double* h_header = nullptr, const double* v_dev = nullptr);
+                     double* h_header = nullptr, const double* v_dev = nullptr, const int64_t* m_dev = nullptr);
 int depth_map_slab_launch(Ctx* c, double* d_inl, int64_t m, const double* d_zsums, int nz, int64_t m_total, const double v[3],
                           double fx, double fy, double cx, double cy, int rows, int col0, int ncols, double* d_depth_map,
-                          int32_t* d_xs, int32_t* d_ys, double* d_header, double* h_header = nullptr, const double* v_dev = nullptr);
+                          int32_t* d_xs, int32_t* d_ys, double* d_header, double* h_header = nullptr, const double* v_dev = nullptr,
+                          const int64_t* m_dev = nullptr);
 // persistent epoch-tagged claim map `which` of the context (rectify_kernels.hip)
 int claim_map_acquire(Ctx* c, int which, size_t npix, unsigned** map, unsigned* tag, unsigned* mask);
 int zsum_row_launch(Ctx* c, const double* d_inl, int64_t m, double* d_partials, double* d_out);
@@ -267,10 +268,16 @@ struct RefineState {
     int32_t np, cur, iteration, invalid_run, num_successful, num_unsuccessful, termination, solve_ok;
     double p[7], pc[7], sp[7], yp[7];
     double radius, decrease_factor, cost, initial_cost, x_norm, gmax, stepsq_p;
+    // inlier count and logical grid of the streaming passes when the host does not know them at enqueue time (the frame solve
+    // enqueues the refinement before it has read the RANSAC result: refine_state_from_best_kernel); kernels launched with
+    // m < 0 / nblocks < 0 take these
+    int64_t m;
+    int32_t grid, _pad;
 };
 struct RefineBuffers {
     const double* flow;  // 2 x n_flow
     int64_t n_flow, m;
+    bool m_on_device = false;  // m and the logical grid live in RefineState (refine_state_from_best_kernel); `m` is then an upper bound
     const double* inl;  // 3 x m
     const double* alpha;
     const double* alpha_k;
@@ -287,7 +294,23 @@ struct RefineBuffers {
 };
 // see refine_device (refine_host.hip): caller's work enqueued behind the refinement's output pass, given the device-resident state
 typedef std::function<int(const RefineState*)> RefineTail;
+// one refinement in flight (refine_host.hip: refine_begin / refine_poll)
+struct RefineRun {
+    RefineBuffers B;
+    int np = 6, launched = 0, chunk = 5, hint_prev = -1;
+    double* d_inl_out = nullptr;
+    const RefineTail* tail = nullptr;
+};
+size_t refine_workspace_bytes(const Ctx* c, int64_t m, bool m_on_device);
+int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
+                 const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
+                 int const_acceleration, int flow_index_mode, double* d_inl_out, const RefineTail* tail, const RansacBest* d_best,
+                 void* ws_base, RefineRun* run);
+int refine_enqueue_chunk(Ctx* c, RefineRun* run);
+int refine_poll(Ctx* c, RefineRun* run, double v_out[3], double w_out[3], double* k_out, rsdsfm_lm_summary* summary);
 int refine_partials_doubles(const Ctx* c, int64_t m);
+int refine_partials_doubles_cap(const Ctx* c);
+int refine_state_from_best_launch(Ctx* c, const RansacBest* d_best, const RefineBuffers& B, int np);
 // start of a refinement: NaN-fill the opt-in iteration trace (rsdsfm_set_refine_trace), enqueued on the context's stream
 inline int refine_trace_reset(Ctx* c) {
     if (!c->d_refine_trace) return RSDSFM_OK;

@@ -43,7 +43,7 @@ int ensure_pinned(Ctx* c, size_t bytes) {
     if (c->h_pinned) RSDSFM_HIP_CHECK(c, hipHostFree(c->h_pinned));
     c->h_pinned = nullptr;
     c->pinned_bytes = 0;
-    size_t want = std::max(bytes, (size_t)1 << 16);
+    size_t want = (std::max(bytes, (size_t)1 << 16) + 63) & ~(size_t)63;  // (a multiple of 64: users address the END of the block too)
     RSDSFM_HIP_CHECK(c, hipHostMalloc(&c->h_pinned, want, hipHostMallocDefault));
     c->pinned_bytes = want;
     return RSDSFM_OK;

@@ -8,7 +8,8 @@
 
 namespace rsdsfm {
 int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n, int use_alpha_k, int T,
-                  double tol, const int32_t* h_samples, uint64_t seed, int depth_mode, int k_sign_mode, rsdsfm_ransac_out* out);
+                  double tol, const int32_t* h_samples, uint64_t seed, int depth_mode, int k_sign_mode, rsdsfm_ransac_out* out,
+                  const RansacSpecTail* spec_tail, bool* spec_tail_held);
 int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
                   const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
                   int const_acceleration, int flow_index_mode, double* d_inl_out, double v_out[3], double w_out[3], double* k_out,
@@ -31,7 +32,7 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
     const size_t N = (size_t)rows * (size_t)cols;
     // frame buffers live in the context's frame arena (separate from the per-stage workspace)
     const size_t need = 2 * Arena::need(16 * N) + 4 * Arena::need(8 * N) + 2 * Arena::need(24 * N) + Arena::need(8 * N) + Arena::need(N) +
-                        Arena::need(4 * N) + Arena::need(8 * 1024) + Arena::need(64) + 4096;
+                        Arena::need(4 * N) + Arena::need(8 * 1024) + Arena::need(64) + Arena::need(refine_workspace_bytes(c, (int64_t)N, true)) + 4096;
     if (need > c->frame_bytes) {
         RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
         if (c->d_frame) RSDSFM_HIP_CHECK(c, hipFree(c->d_frame));
@@ -54,6 +55,8 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
     int32_t* d_ys = fa.take<int32_t>(N);
     double* d_zpartials = fa.take<double>(1024);  // scratch of the depth-map stage when it is enqueued behind the refinement
     double* d_zheader = fa.take<double>(8);
+    // buffers of a refinement that is enqueued while the RANSAC still owns the stage workspace (see below)
+    char* d_refine_ws = fa.take<char>(refine_workspace_bytes(c, (int64_t)N, true));
 
     memset(res, 0, sizeof(*res));
     int64_t n = 0;
@@ -71,41 +74,63 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
     ro.alpha = d_in_a;
     ro.alpha_k = d_in_ak;
     ro.mask = d_mask;
+    // ---- RANSAC, refinement, depth map + pose table: three stages, ONE host wait in the common case ------------------------------
+    // Each later stage only needs the device-resident result of the one before it, so it is enqueued BEHIND that stage before the host
+    // has read anything:
+    //  * the depth map and the pose table behind the refinement's output pass (they read v / w / k from the refinement's state and
+    //    report {flipped, v'} through host-mapped memory, written by zsum_decide_kernel);
+    //  * the refinement's start (state from the device-resident RansacBest, iteration zero, the first chunk of LM iterations, output
+    //    pass, and that tail) behind the RANSAC's speculated final stage -- its buffers live in the frame arena, since the RANSAC
+    //    may still need the stage workspace for further rounds.
+    // If the RANSAC's speculation did not hold (more LM rounds / a scoring pass) the refinement starts over from the host-side result;
+    // if LM iterations remain after a chunk the tail runs again behind the next output pass.  None of this changes a result.
+    double v[3] = {0, 0, 0}, w[3] = {0, 0, 0}, k = 0;
+    double* d_final = d_inl;
+    int flipped = 0;
+    int64_t m_known = -1;  // the inlier count once the host has it; until then the kernels read it from the refinement's state
+    // (pointers into the pinned block are taken when they are used: the RANSAC may still grow the block)
+    auto header_host = [&]() { return reinterpret_cast<double*>(static_cast<char*>(c->h_pinned) + c->pinned_bytes - 64); };
+    auto state_host = [&]() { return reinterpret_cast<RefineState*>(static_cast<char*>(c->h_pinned) + c->pinned_bytes - kPinnedTail); };
+    static_assert(sizeof(RefineState) + sizeof(int) + 64 <= kPinnedTail, "state read-back + header fit the reserved tail");
+    const RefineTail tail = [&](const RefineState* st) -> int {
+        const int64_t m_arg = m_known >= 0 ? m_known : n;
+        const int64_t* m_dev = m_known >= 0 ? nullptr : &st->m;
+        int rt = depth_map_launch(c, d_inl_ref, m_arg, nullptr, fx, fy, cx, cy, rows, cols, d_depth_map, nullptr, d_ys, d_zheader, d_zpartials,
+                                  header_host(), st->p, m_dev);
+        if (rt != RSDSFM_OK) return rt;
+        if (d_R_rows9 && d_t_rows3) {
+            Pose pose;
+            memset(&pose, 0, sizeof(pose));
+            rt = pose_table_launch(c, pose, gamma, rows, d_R_rows9, d_t_rows3, d_zheader + 1, st->p + 3);
+        }
+        return rt;
+    };
+    RefineRun run;
+    const RansacSpecTail spec_tail = [&](const RansacBest* d_best) -> int {
+        return refine_begin(c, d_u, n, n, d_inl, d_in_a, d_in_ak, d_idx, nullptr, nullptr, 0.0, prm->use_acceleration_mode, prm->flow_index_mode,
+                            d_inl_ref, &tail, d_best, d_refine_ws, &run, state_host());
+    };
+    bool refinement_enqueued = false;
     rc = ransac_device(c, d_q, d_u, d_a, d_ak, n, prm->use_acceleration_mode, prm->ransac_trials, prm->ransac_tol, nullptr, prm->seed,
-                       prm->depth_mode, prm->k_sign_mode, &ro);
+                       prm->depth_mode, prm->k_sign_mode, &ro, prm->use_refinement ? &spec_tail : nullptr, &refinement_enqueued);
     if (rc != RSDSFM_OK) return rc;
     res->num_inliers = ro.num_inliers;
     res->best_trial = ro.best_trial;
     memcpy(res->ransac_w, ro.w, sizeof(ro.w));
     memcpy(res->ransac_v, ro.v, sizeof(ro.v));
     res->ransac_k = ro.k;
-    double v[3] = {ro.v[0], ro.v[1], ro.v[2]}, w[3] = {ro.w[0], ro.w[1], ro.w[2]}, k = ro.k;
-    double* d_final = d_inl;
-    int flipped = 0;
+    for (int i = 0; i < 3; ++i) v[i] = ro.v[i], w[i] = ro.w[i];
+    k = ro.k;
+    m_known = ro.num_inliers;
     if (prm->use_refinement) {
-        // The depth map and the pose table only need the refinement's DEVICE-resident result (refined inliers, v / w / k in the state),
-        // so they are enqueued behind its output pass and the synchronisation that ends the refinement covers them: no second host
-        // round trip.  {flipped, v'} arrive through host-mapped memory (written by zsum_decide_kernel), past the refinement's own block.
-        constexpr size_t kHeaderOff = 2048;
-        rc = ensure_pinned(c, kHeaderOff + 64);
-        if (rc != RSDSFM_OK) return rc;
-        double* h_header = reinterpret_cast<double*>(static_cast<char*>(c->h_pinned) + kHeaderOff);
-        const int64_t m = ro.num_inliers;
-        const RefineTail tail = [&](const RefineState* st) -> int {
-            int rt = depth_map_launch(c, d_inl_ref, m, nullptr, fx, fy, cx, cy, rows, cols, d_depth_map, nullptr, d_ys, d_zheader, d_zpartials,
-                                      h_header, st->p);
-            if (rt != RSDSFM_OK) return rt;
-            if (d_R_rows9 && d_t_rows3) {
-                Pose pose;
-                memset(&pose, 0, sizeof(pose));
-                rt = pose_table_launch(c, pose, gamma, rows, d_R_rows9, d_t_rows3, d_zheader + 1, st->p + 3);
-            }
-            return rt;
-        };
-        rc = refine_device(c, d_u, n, m, d_inl, d_in_a, d_in_ak, d_idx, v, w, k, prm->use_acceleration_mode, prm->flow_index_mode, d_inl_ref,
-                           v, w, &k, &res->refine_summary, &tail);
+        if (refinement_enqueued)
+            rc = refine_poll(c, &run, v, w, &k, &res->refine_summary);
+        else
+            rc = refine_device(c, d_u, n, ro.num_inliers, d_inl, d_in_a, d_in_ak, d_idx, v, w, k, prm->use_acceleration_mode, prm->flow_index_mode,
+                               d_inl_ref, v, w, &k, &res->refine_summary, &tail);
         if (rc != RSDSFM_OK) return rc;
         d_final = d_inl_ref;
+        const double* h_header = header_host();
         flipped = h_header[0] != 0.0;
         v[0] = h_header[1], v[1] = h_header[2], v[2] = h_header[3];
     } else {

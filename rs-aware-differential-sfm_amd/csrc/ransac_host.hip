@@ -69,9 +69,16 @@ void sample_indices(int64_t n, int T, uint64_t seed, int32_t* out) {
 
 // Device-resident RANSAC.  d_* inputs and the arrays of `out` are device pointers (any of the out arrays may be
 // NULL); scalars of `out` and its trial_* arrays (host) are filled after one final synchronisation.
+// spec_tail (optional): work of the CALLER that only needs the RANSAC's device-resident result (RansacBest + the compacted inlier
+// arrays).  It is enqueued behind the SPECULATED final stage -- i.e. before the host has read the round-0 flags -- and
+// *spec_tail_held tells the caller afterwards whether that final stage was the one that counts; if not (more LM rounds or a scoring
+// pass were needed) what the tail computed is garbage and the caller starts over from the host-side result.  The frame solve hands in
+// the start of its refinement (refine_begin), which removes the host round trip between the two stages.
 int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n,
                   int use_alpha_k, int T, double tol, const int32_t* h_samples, uint64_t seed, int depth_mode,
-                  int k_sign_mode, rsdsfm_ransac_out* out) {
+                  int k_sign_mode, rsdsfm_ransac_out* out, const RansacSpecTail* spec_tail, bool* spec_tail_held) {
+    bool tail_enqueued = false;
+    if (spec_tail_held) *spec_tail_held = false;
     if (!out) return fail(c, RSDSFM_ERR_INVALID, "null out");
     if (n < 9) return fail(c, RSDSFM_ERR_INVALID, "ransac needs at least 9 points (the reference would compute rand() % 0)");
     if (T < 0) return fail(c, RSDSFM_ERR_INVALID, "negative iterations");
@@ -113,7 +120,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     uint8_t* d_mask = out->mask ? out->mask : ws.take<uint8_t>((size_t)n);
 
     rc = ensure_pinned(c, sizeof(RansacBest) + 8 * sizeof(int) + sizeof(double) * 2 * Tn + sizeof(double) * 8 * Tn + sizeof(LmState) * Tn + 64 +
-                              sizeof(int32_t) * (size_t)Tn * 9);
+                              sizeof(int32_t) * (size_t)Tn * 9 + kPinnedTail);  // (the end of the block belongs to the frame solve)
     if (rc != RSDSFM_OK) return rc;
     char* hp = static_cast<char*>(c->h_pinned);
     RansacBest* h_best = reinterpret_cast<RansacBest*>(hp);
@@ -168,6 +175,11 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
                                                  d_boffs, out->inlier_idx, out->inliers, out->alpha, out->alpha_k, h_best);
                         if (rc != RSDSFM_OK) return rc;
                         final_done = true;
+                        if (spec_tail) {
+                            rc = (*spec_tail)(d_best);
+                            if (rc != RSDSFM_OK) return rc;
+                            tail_enqueued = true;
+                        }
                     }
                     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_running, d_flags, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
                     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
@@ -199,6 +211,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     if (depth_mode == RSDSFM_DEPTH_CERES_LM && T > 0) c->ransac_not_one_step = not_one_step;
     // best trial, its dense rho + mask, order-preserving compaction
     if (!final_done) {
+        tail_enqueued = false;  // the speculated final stage (and whatever was enqueued behind it) saw incomplete trials
         rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, h_best);  // h_best: host-mapped, written by the kernels
         if (rc != RSDSFM_OK) return rc;
         rc = ransac_final_launch(c, d_q, d_u, d_a, d_ak, n, d_best, d_states, depth_mode, tol, d_rho, d_mask, d_bcounts, d_boffs,
@@ -225,6 +238,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
         if (out->trial_vel) memcpy(out->trial_vel + (size_t)7 * t, h_hyp + (size_t)8 * t, 7 * sizeof(double));
         if (out->trial_steps) out->trial_steps[t] = depth_mode == RSDSFM_DEPTH_CERES_LM ? h_states[t].num_successful : 1;
     }
+    if (spec_tail_held) *spec_tail_held = tail_enqueued;
     return RSDSFM_OK;
 }
 
@@ -277,7 +291,8 @@ int rsdsfm_ransac_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_u, con
     Ctx* c = &ctx->c;
     DeviceGuard device_guard_(c);
     if (!d_q || !d_u || !d_alpha || !d_alpha_k) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
-    return ransac_device(c, d_q, d_u, d_alpha, d_alpha_k, n, use_alpha_k, iterations, tolerance, samples, seed, depth_mode, k_sign_mode, out);
+    return ransac_device(c, d_q, d_u, d_alpha, d_alpha_k, n, use_alpha_k, iterations, tolerance, samples, seed, depth_mode, k_sign_mode, out,
+                         nullptr, nullptr);
 }
 
 int rsdsfm_ransac(rsdsfm_ctx* ctx, const double* q, const double* u, const double* alpha, const double* alpha_k, int64_t n,
@@ -307,7 +322,7 @@ int rsdsfm_ransac(rsdsfm_ctx* ctx, const double* q, const double* u, const doubl
     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_u, u, 16 * N, hipMemcpyHostToDevice, c->stream));
     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_a, alpha, 8 * N, hipMemcpyHostToDevice, c->stream));
     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_ak, alpha_k, 8 * N, hipMemcpyHostToDevice, c->stream));
-    rc = ransac_device(c, d_q, d_u, d_a, d_ak, n, use_alpha_k, iterations, tolerance, samples, seed, depth_mode, k_sign_mode, &dev);
+    rc = ransac_device(c, d_q, d_u, d_a, d_ak, n, use_alpha_k, iterations, tolerance, samples, seed, depth_mode, k_sign_mode, &dev, nullptr, nullptr);
     if (rc != RSDSFM_OK) return rc;
     const size_t M = (size_t)dev.num_inliers;
     if (out->inlier_idx && M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(out->inlier_idx, dev.inlier_idx, 8 * M, hipMemcpyDeviceToHost, c->stream));

@@ -23,7 +23,7 @@ namespace rsdsfm {
 int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
                  const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
                  int const_acceleration, int flow_index_mode, double* d_inl_out, const RefineTail* tail, const RansacBest* d_best,
-                 void* ws_base, RefineRun* run) {
+                 void* ws_base, RefineRun* run, RefineState* hs_prefetch) {
     if (m < 0 || n_flow < 0 || (!d_best && (!v_in || !w_in))) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     if (flow_index_mode != RSDSFM_FLOW_COMPAT_RANK && flow_index_mode != RSDSFM_FLOW_GATHERED) return fail(c, RSDSFM_ERR_INVALID, "unknown flow_index_mode");
     if (flow_index_mode == RSDSFM_FLOW_GATHERED && m > 0 && !d_inlier_idx) return fail(c, RSDSFM_ERR_INVALID, "gathered mode needs inlier_idx");
@@ -67,6 +67,9 @@ int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const 
     run->tail = tail;
     run->launched = 0;
     run->hint_prev = c->refine_iters_hint;
+    run->hs = hs_prefetch ? hs_prefetch : static_cast<RefineState*>(c->h_pinned);
+    run->prefetch = hs_prefetch != nullptr;
+    run->prefetched = false;
     if (d_best) {
         rc = refine_state_from_best_launch(c, d_best, B, np);
         if (rc != RSDSFM_OK) return rc;
@@ -110,16 +113,23 @@ int refine_enqueue_chunk(Ctx* c, RefineRun* run) {
     int rc = refine_finish_launch(c, run->B, run->d_inl_out);
     if (rc != RSDSFM_OK) return rc;
     if (run->tail) rc = (*run->tail)(run->B.state);
+    if (rc != RSDSFM_OK) return rc;
+    if (run->prefetch) {
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(run->hs, run->B.state, sizeof(RefineState) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        run->prefetched = true;
+    }
     return rc;
 }
 
 int refine_poll(Ctx* c, RefineRun* run, double v_out[3], double w_out[3], double* k_out, rsdsfm_lm_summary* summary) {
     if (!v_out || !w_out || !k_out) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
-    RefineState* hs = static_cast<RefineState*>(c->h_pinned);
-    int* h_bad = reinterpret_cast<int*>(static_cast<char*>(c->h_pinned) + sizeof(RefineState));
-    for (;;) {
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(hs, run->B.state, sizeof(RefineState) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    RefineState* hs = run->hs;
+    int* h_bad = reinterpret_cast<int*>(reinterpret_cast<char*>(hs) + sizeof(RefineState));
+    for (bool first = true;; first = false) {
+        if (!(first && run->prefetch && run->prefetched)) {  // (otherwise the read-back was enqueued with the chunk and the caller has waited)
+            if (!run->prefetch) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(hs, run->B.state, sizeof(RefineState) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        }
         if (*h_bad) return fail(c, RSDSFM_ERR_INVALID, "flow index out of range (flow has fewer columns than inliers / bad inlier_idx)");
         if (hs->termination >= 0) break;
         if (run->launched > 4 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
@@ -160,7 +170,7 @@ int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const
     if (!v_out || !w_out || !k_out) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     RefineRun run;
     int rc = refine_begin(c, d_flow, n_flow, m, d_inl, d_alpha, d_alpha_k, d_inlier_idx, v_in, w_in, k_in, const_acceleration, flow_index_mode,
-                          d_inl_out, tail, nullptr, nullptr, &run);
+                          d_inl_out, tail, nullptr, nullptr, &run, nullptr);
     if (rc != RSDSFM_OK) return rc;
     return refine_poll(c, &run, v_out, w_out, k_out, summary);
 }

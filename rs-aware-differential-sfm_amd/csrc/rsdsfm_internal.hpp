@@ -292,6 +292,8 @@ struct RefineBuffers {
     double* partials;
     int* bad_index;
 };
+// see ransac_device (ransac_host.hip): caller's work enqueued behind the speculated final stage, given the device-resident result
+typedef std::function<int(const RansacBest*)> RansacSpecTail;
 // see refine_device (refine_host.hip): caller's work enqueued behind the refinement's output pass, given the device-resident state
 typedef std::function<int(const RefineState*)> RefineTail;
 // one refinement in flight (refine_host.hip: refine_begin / refine_poll)
@@ -300,12 +302,18 @@ struct RefineRun {
     int np = 6, launched = 0, chunk = 5, hint_prev = -1;
     double* d_inl_out = nullptr;
     const RefineTail* tail = nullptr;
+    // pinned host copy of the state (+ bad-index flag).  prefetch: every chunk also enqueues its read-back, and the first refine_poll
+    // trusts that the CALLER has synchronised the stream since (the frame solve: the RANSAC's own wait) instead of waiting again
+    RefineState* hs = nullptr;
+    bool prefetch = false, prefetched = false;
 };
+// the last kPinnedTail bytes of the context's pinned block are reserved for the frame solve (refinement state read-back, depth-map header)
+constexpr size_t kPinnedTail = 1024;
 size_t refine_workspace_bytes(const Ctx* c, int64_t m, bool m_on_device);
 int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
                  const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
                  int const_acceleration, int flow_index_mode, double* d_inl_out, const RefineTail* tail, const RansacBest* d_best,
-                 void* ws_base, RefineRun* run);
+                 void* ws_base, RefineRun* run, RefineState* hs_prefetch);
 int refine_enqueue_chunk(Ctx* c, RefineRun* run);
 int refine_poll(Ctx* c, RefineRun* run, double v_out[3], double w_out[3], double* k_out, rsdsfm_lm_summary* summary);
 int refine_partials_doubles(const Ctx* c, int64_t m);

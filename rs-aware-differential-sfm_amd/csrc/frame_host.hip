@@ -95,15 +95,10 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
     const RefineTail tail = [&](const RefineState* st) -> int {
         const int64_t m_arg = m_known >= 0 ? m_known : n;
         const int64_t* m_dev = m_known >= 0 ? nullptr : &st->m;
-        int rt = depth_map_launch(c, d_inl_ref, m_arg, nullptr, fx, fy, cx, cy, rows, cols, d_depth_map, nullptr, d_ys, d_zheader, d_zpartials,
-                                  header_host(), st->p, m_dev);
-        if (rt != RSDSFM_OK) return rt;
-        if (d_R_rows9 && d_t_rows3) {
-            Pose pose;
-            memset(&pose, 0, sizeof(pose));
-            rt = pose_table_launch(c, pose, gamma, rows, d_R_rows9, d_t_rows3, d_zheader + 1, st->p + 3);
-        }
-        return rt;
+        PoseTableOut pt;  // the pose table of (v', w, k) is written by the kernel that decides the sign of v
+        if (d_R_rows9 && d_t_rows3) pt.R = d_R_rows9, pt.t = d_t_rows3, pt.rows = rows, pt.gamma = gamma, pt.wk_dev = st->p + 3;
+        return depth_map_launch(c, d_inl_ref, m_arg, nullptr, fx, fy, cx, cy, rows, cols, d_depth_map, nullptr, d_ys, d_zheader, d_zpartials,
+                                header_host(), st->p, m_dev, &pt);
     };
     RefineRun run;
     const RansacSpecTail spec_tail = [&](const RansacBest* d_best) -> int {

@@ -33,13 +33,8 @@ __global__ __launch_bounds__(256) void alpha_k_kernel(const double2* __restrict_
 // instead of `pose.v`, so that the table can be enqueued behind that stage without a host round trip
 // wk_dev (optional): (w, k) likewise from device memory (RefineState::p + 3: the table is then enqueued before the host has read the
 // refinement's result)
-__global__ __launch_bounds__(256) void pose_table_kernel(Pose pose, double gamma, int rows, double* __restrict__ R,
-                                                         double* __restrict__ t, const double* __restrict__ v_dev,
-                                                         const double* __restrict__ wk_dev) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows) return;
-    if (v_dev) pose.v[0] = v_dev[0], pose.v[1] = v_dev[1], pose.v[2] = v_dev[2];
-    if (wk_dev) pose.w[0] = wk_dev[0], pose.w[1] = wk_dev[1], pose.w[2] = wk_dev[2], pose.k = wk_dev[3];
+// one scanline of the table (rsframe.cc:771-800)
+__device__ __forceinline__ void pose_table_row(const Pose& pose, double gamma, int rows, int i, double* __restrict__ R, double* __restrict__ t) {
     double beta_1 = 0.0;
     if (i > 0)
         beta_1 = (gamma * i / rows + 0.5 * pose.k * (gamma * gamma * i * i) / ((double)rows * rows)) * (2.0 / (2.0 + pose.k));
@@ -56,6 +51,16 @@ __global__ __launch_bounds__(256) void pose_table_kernel(Pose pose, double gamma
     t[(int64_t)i * 3 + 0] = 0.0 + beta_1 * pose.v[0];
     t[(int64_t)i * 3 + 1] = 0.0 + beta_1 * pose.v[1];
     t[(int64_t)i * 3 + 2] = 0.0 + beta_1 * pose.v[2];
+}
+
+__global__ __launch_bounds__(256) void pose_table_kernel(Pose pose, double gamma, int rows, double* __restrict__ R,
+                                                         double* __restrict__ t, const double* __restrict__ v_dev,
+                                                         const double* __restrict__ wk_dev) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    if (v_dev) pose.v[0] = v_dev[0], pose.v[1] = v_dev[1], pose.v[2] = v_dev[2];
+    if (wk_dev) pose.w[0] = wk_dev[0], pose.w[1] = wk_dev[1], pose.w[2] = wk_dev[2], pose.k = wk_dev[3];
+    pose_table_row(pose, gamma, rows, i, R, t);
 }
 
 static inline int stream_grid(int64_t n) {
@@ -191,10 +196,12 @@ __global__ __launch_bounds__(kGB) void zsum_partial_kernel(const double* __restr
 // v_dev (optional): v is read from device memory (RefineState::p) instead of `pose_v`
 __global__ __launch_bounds__(256) void zsum_decide_kernel(const double* __restrict__ partials, int nblocks, int64_t m, Pose pose_v,
                                                          double* __restrict__ header, double* __restrict__ header_host,
-                                                         const double* __restrict__ v_dev, const int64_t* __restrict__ m_dev) {
+                                                         const double* __restrict__ v_dev, const int64_t* __restrict__ m_dev,
+                                                         PoseTableOut pt) {
     if (v_dev) pose_v.v[0] = v_dev[0], pose_v.v[1] = v_dev[1], pose_v.v[2] = v_dev[2];
     if (m_dev) m = *m_dev;
     __shared__ double s_red[4];
+    __shared__ double s_v[3];
     double acc = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256) acc += partials[b];
     const double r = wave_sum(acc);
@@ -212,6 +219,14 @@ __global__ __launch_bounds__(256) void zsum_decide_kernel(const double* __restri
 #pragma unroll
             for (int i = 0; i < 4; ++i) header_host[i] = header[i];
         }
+        s_v[0] = header[1], s_v[1] = header[2], s_v[2] = header[3];
+    }
+    if (pt.R) {  // frame solve: RsFrame::setRelativePose's table for (v', w, k) right here instead of in a launch of its own
+        __syncthreads();
+        Pose pose;
+        pose.v[0] = s_v[0], pose.v[1] = s_v[1], pose.v[2] = s_v[2];
+        pose.w[0] = pt.wk_dev[0], pose.w[1] = pt.wk_dev[1], pose.w[2] = pt.wk_dev[2], pose.k = pt.wk_dev[3];
+        for (int i = threadIdx.x; i < pt.rows; i += 256) pose_table_row(pose, pt.gamma, pt.rows, i, pt.R, pt.t);
     }
 }
 
@@ -382,13 +397,15 @@ int zsum_row_launch(Ctx* c, const double* d_inl, int64_t m, double* d_partials, 
 // d_header: 4 doubles (flipped, v')
 int depth_map_slab_launch(Ctx* c, double* d_inl, int64_t m, const double* d_zsums, int nz, int64_t m_total, const double v[3],
                           double fx, double fy, double cx, double cy, int rows, int col0, int ncols, double* d_depth_map,
-                          int32_t* d_xs, int32_t* d_ys, double* d_header, double* h_header, const double* v_dev, const int64_t* m_dev) {
+                          int32_t* d_xs, int32_t* d_ys, double* d_header, double* h_header, const double* v_dev, const int64_t* m_dev,
+                          const PoseTableOut* pt) {
     const int64_t npix = (int64_t)rows * ncols;
     if (m >= ((int64_t)1 << 31)) return fail(c, RSDSFM_ERR_INVALID, "depth map: more than 2^31 inliers");
     Pose pv;
     memset(&pv, 0, sizeof(pv));
     if (v) pv.v[0] = v[0], pv.v[1] = v[1], pv.v[2] = v[2];
-    hipLaunchKernelGGL(zsum_decide_kernel, dim3(1), dim3(256), 0, c->stream, d_zsums, nz, m_total, pv, d_header, h_header, v_dev, m_dev);
+    hipLaunchKernelGGL(zsum_decide_kernel, dim3(1), dim3(256), 0, c->stream, d_zsums, nz, m_total, pv, d_header, h_header, v_dev, m_dev,
+                       pt ? *pt : PoseTableOut());
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     // the claim word holds the inlier index: the map's index field is sized by the larger of the two counts
     unsigned *d_owner = nullptr, tag = 0, mask = 0;
@@ -407,12 +424,12 @@ int depth_map_slab_launch(Ctx* c, double* d_inl, int64_t m, const double* d_zsum
 // d_header: 4 doubles (flipped, v'); d_partials: >= 1024 doubles
 int depth_map_launch(Ctx* c, double* d_inl, int64_t m, const double v[3], double fx, double fy, double cx, double cy, int rows,
                      int cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, double* d_header, double* d_partials,
-                     double* h_header, const double* v_dev, const int64_t* m_dev) {
+                     double* h_header, const double* v_dev, const int64_t* m_dev, const PoseTableOut* pt) {
     const int zb = zsum_blocks(m);
     hipLaunchKernelGGL(zsum_partial_kernel, dim3(zb), dim3(kGB), 0, c->stream, d_inl, m, d_partials, m_dev);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return depth_map_slab_launch(c, d_inl, m, d_partials, zb, m, v, fx, fy, cx, cy, rows, 0, cols, d_depth_map, d_xs, d_ys, d_header,
-                                 h_header, v_dev, m_dev);
+                                 h_header, v_dev, m_dev, pt);
 }
 
 }  // namespace rsdsfm

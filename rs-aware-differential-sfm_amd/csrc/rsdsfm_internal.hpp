@@ -208,6 +208,14 @@ int alpha_k_launch(Ctx* c, const double* q_px, const double* flow_px, int64_t n,
 int depth_map_device(Ctx* c, double* d_inl, int64_t m, double v_inout[3], double fx, double fy, double cx, double cy, int32_t rows, int32_t cols,
                      double* d_depth_map, int32_t* d_xs, int32_t* d_ys, int* flipped, const double* w_or_null, double k, double gamma,
                      double* d_R_rows9, double* d_t_rows3);
+// optional output of zsum_decide_kernel (frame solve): the per-scanline pose table of (v', w, k) with (w, k) read from wk_dev
+struct PoseTableOut {
+    double* R = nullptr;
+    double* t = nullptr;
+    int rows = 0;
+    double gamma = 0.0;
+    const double* wk_dev = nullptr;
+};
 int pose_table_launch(Ctx* c, const Pose& pose, double gamma, int rows, double* R, double* t, const double* v_dev = nullptr,
                       const double* wk_dev = nullptr);
 int64_t flatten_cells(int rows, int cols);
@@ -216,11 +224,12 @@ int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, int col0, do
                    int64_t* d_offsets, int64_t* d_total, hipEvent_t total_ready = nullptr);
 int depth_map_launch(Ctx* c, double* d_inl, int64_t m, const double v[3], double fx, double fy, double cx, double cy, int rows,
                      int cols, double* d_depth_map, int32_t* d_xs, int32_t* d_ys, double* d_header, double* d_partials,
-                     double* h_header = nullptr, const double* v_dev = nullptr, const int64_t* m_dev = nullptr);
+                     double* h_header = nullptr, const double* v_dev = nullptr, const int64_t* m_dev = nullptr,
+                     const PoseTableOut* pt = nullptr);
 int depth_map_slab_launch(Ctx* c, double* d_inl, int64_t m, const double* d_zsums, int nz, int64_t m_total, const double v[3],
                           double fx, double fy, double cx, double cy, int rows, int col0, int ncols, double* d_depth_map,
                           int32_t* d_xs, int32_t* d_ys, double* d_header, double* h_header = nullptr, const double* v_dev = nullptr,
-                          const int64_t* m_dev = nullptr);
+                          const int64_t* m_dev = nullptr, const PoseTableOut* pt = nullptr);
 // persistent epoch-tagged claim map `which` of the context (rectify_kernels.hip)
 int claim_map_acquire(Ctx* c, int which, size_t npix, unsigned** map, unsigned* tag, unsigned* mask);
 int zsum_row_launch(Ctx* c, const double* d_inl, int64_t m, double* d_partials, double* d_out);

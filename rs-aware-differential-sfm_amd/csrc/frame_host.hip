@@ -13,7 +13,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
 int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
                   const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
                   int const_acceleration, int flow_index_mode, double* d_inl_out, double v_out[3], double w_out[3], double* k_out,
-                  rsdsfm_lm_summary* summary, const RefineTail* tail);
+                  rsdsfm_lm_summary* summary, const RefineTail* tail, double* d_zpartials);
 int alpha_ones_launch(Ctx* c, double* d_alpha, int64_t n);
 }  // namespace rsdsfm
 
@@ -92,18 +92,20 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
     auto header_host = [&]() { return reinterpret_cast<double*>(static_cast<char*>(c->h_pinned) + c->pinned_bytes - 64); };
     auto state_host = [&]() { return reinterpret_cast<RefineState*>(static_cast<char*>(c->h_pinned) + c->pinned_bytes - kPinnedTail); };
     static_assert(sizeof(RefineState) + sizeof(int) + 64 <= kPinnedTail, "state read-back + header fit the reserved tail");
-    const RefineTail tail = [&](const RefineState* st) -> int {
+    const RefineTail tail = [&](const RefineBuffers& B) -> int {
+        const RefineState* st = B.state;
         const int64_t m_arg = m_known >= 0 ? m_known : n;
         const int64_t* m_dev = m_known >= 0 ? nullptr : &st->m;
         PoseTableOut pt;  // the pose table of (v', w, k) is written by the kernel that decides the sign of v
         if (d_R_rows9 && d_t_rows3) pt.R = d_R_rows9, pt.t = d_t_rows3, pt.rows = rows, pt.gamma = gamma, pt.wk_dev = st->p + 3;
-        return depth_map_launch(c, d_inl_ref, m_arg, nullptr, fx, fy, cx, cy, rows, cols, d_depth_map, nullptr, d_ys, d_zheader, d_zpartials,
-                                header_host(), st->p, m_dev, &pt);
+        // (the sums of z come from the refinement's output pass: one entry per workgroup of that launch)
+        return depth_map_slab_launch(c, d_inl_ref, m_arg, d_zpartials, refine_finish_grid(c, B), m_arg, nullptr, fx, fy, cx, cy, rows, 0, cols,
+                                     d_depth_map, nullptr, d_ys, d_zheader, header_host(), st->p, m_dev, &pt);
     };
     RefineRun run;
     const RansacSpecTail spec_tail = [&](const RansacBest* d_best) -> int {
         return refine_begin(c, d_u, n, n, d_inl, d_in_a, d_in_ak, d_idx, nullptr, nullptr, 0.0, prm->use_acceleration_mode, prm->flow_index_mode,
-                            d_inl_ref, &tail, d_best, d_refine_ws, &run, state_host());
+                            d_inl_ref, &tail, d_best, d_refine_ws, &run, state_host(), d_zpartials);
     };
     bool refinement_enqueued = false;
     rc = ransac_device(c, d_q, d_u, d_a, d_ak, n, prm->use_acceleration_mode, prm->ransac_trials, prm->ransac_tol, nullptr, prm->seed,
@@ -122,7 +124,7 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
             rc = refine_poll(c, &run, v, w, &k, &res->refine_summary);
         else
             rc = refine_device(c, d_u, n, ro.num_inliers, d_inl, d_in_a, d_in_ak, d_idx, v, w, k, prm->use_acceleration_mode, prm->flow_index_mode,
-                               d_inl_ref, v, w, &k, &res->refine_summary, &tail);
+                               d_inl_ref, v, w, &k, &res->refine_summary, &tail, d_zpartials);
         if (rc != RSDSFM_OK) return rc;
         d_final = d_inl_ref;
         const double* h_header = header_host();

@@ -23,7 +23,7 @@ namespace rsdsfm {
 int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
                  const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
                  int const_acceleration, int flow_index_mode, double* d_inl_out, const RefineTail* tail, const RansacBest* d_best,
-                 void* ws_base, RefineRun* run, RefineState* hs_prefetch) {
+                 void* ws_base, RefineRun* run, RefineState* hs_prefetch, double* d_zpartials) {
     if (m < 0 || n_flow < 0 || (!d_best && (!v_in || !w_in))) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     if (flow_index_mode != RSDSFM_FLOW_COMPAT_RANK && flow_index_mode != RSDSFM_FLOW_GATHERED) return fail(c, RSDSFM_ERR_INVALID, "unknown flow_index_mode");
     if (flow_index_mode == RSDSFM_FLOW_GATHERED && m > 0 && !d_inlier_idx) return fail(c, RSDSFM_ERR_INVALID, "gathered mode needs inlier_idx");
@@ -62,6 +62,7 @@ int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const 
     B.srho = ws.take<double>(M);
     B.partials = ws.take<double>(npart);
     B.bad_index = reinterpret_cast<int*>(state_block + sizeof(RefineState));
+    B.zpartials = d_zpartials;
     run->np = np;
     run->d_inl_out = d_inl_out;
     run->tail = tail;
@@ -112,7 +113,7 @@ int refine_enqueue_chunk(Ctx* c, RefineRun* run) {
     // which saves a host round trip with an idle GPU; if iterations remain it simply runs again after the next chunk
     int rc = refine_finish_launch(c, run->B, run->d_inl_out);
     if (rc != RSDSFM_OK) return rc;
-    if (run->tail) rc = (*run->tail)(run->B.state);
+    if (run->tail) rc = (*run->tail)(run->B);
     if (rc != RSDSFM_OK) return rc;
     if (run->prefetch) {
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(run->hs, run->B.state, sizeof(RefineState) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -166,11 +167,11 @@ size_t refine_workspace_bytes(const Ctx* c, int64_t m, bool m_on_device) {
 int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
                   const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
                   int const_acceleration, int flow_index_mode, double* d_inl_out, double v_out[3], double w_out[3], double* k_out,
-                  rsdsfm_lm_summary* summary, const RefineTail* tail) {
+                  rsdsfm_lm_summary* summary, const RefineTail* tail, double* d_zpartials) {
     if (!v_out || !w_out || !k_out) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     RefineRun run;
     int rc = refine_begin(c, d_flow, n_flow, m, d_inl, d_alpha, d_alpha_k, d_inlier_idx, v_in, w_in, k_in, const_acceleration, flow_index_mode,
-                          d_inl_out, tail, nullptr, nullptr, &run, nullptr);
+                          d_inl_out, tail, nullptr, nullptr, &run, nullptr, d_zpartials);
     if (rc != RSDSFM_OK) return rc;
     return refine_poll(c, &run, v_out, w_out, k_out, summary);
 }
@@ -188,7 +189,7 @@ int rsdsfm_refine_dev(rsdsfm_ctx* ctx, const double* d_flow, int64_t n_flow, int
     if (!ctx) return RSDSFM_ERR_INVALID;
     DeviceGuard device_guard_(&ctx->c);
     return refine_device(&ctx->c, d_flow, n_flow, m, d_inl, d_alpha, d_alpha_k, d_inlier_idx, v_in, w_in, k_in, const_acceleration,
-                         flow_index_mode, d_inl_out, v_out, w_out, k_out, summary, nullptr);
+                         flow_index_mode, d_inl_out, v_out, w_out, k_out, summary, nullptr, nullptr);
 }
 
 int rsdsfm_refine(rsdsfm_ctx* ctx, const double* flow, int64_t n_flow, int64_t m, const double* inl, const double* alpha,
@@ -218,7 +219,7 @@ int rsdsfm_refine(rsdsfm_ctx* ctx, const double* flow, int64_t n_flow, int64_t m
         if (inlier_idx) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_idx, inlier_idx, 8 * M, hipMemcpyHostToDevice, c->stream));
     }
     rc = refine_device(c, d_flow, n_flow, m, d_inl, d_a, d_ak, inlier_idx ? d_idx : nullptr, v_in, w_in, k_in, const_acceleration,
-                       flow_index_mode, d_out, v_out, w_out, k_out, summary, nullptr);
+                       flow_index_mode, d_out, v_out, w_out, k_out, summary, nullptr, nullptr);
     if (rc != RSDSFM_OK) return rc;
     if (M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(inl_out, d_out, 24 * M, hipMemcpyDeviceToHost, c->stream));
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));

@@ -639,14 +639,29 @@ __global__ __launch_bounds__(kFB) void refine_decide_kernel(const double* __rest
 // nonlinearRefinement.cc:244-248
 __global__ __launch_bounds__(kFB) void refine_finish_kernel(int64_t m, const double* __restrict__ inl,
                                                            const double* __restrict__ rho_a, const double* __restrict__ rho_b,
-                                                           const RefineState* __restrict__ st, double* __restrict__ inl_out) {
+                                                           const RefineState* __restrict__ st, double* __restrict__ inl_out,
+                                                           double* __restrict__ zpartials) {
+    __shared__ double s_red[kFB / 64];
     const double* __restrict__ rho = st->cur ? rho_b : rho_a;
     if (m < 0) m = st->m;  // device-resident count: a plain copy pass, any grid will do
     const int64_t stride = (int64_t)gridDim.x * kFB;
+    double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x; i < m; i += stride) {
         inl_out[3 * i] = inl[3 * i];
         inl_out[3 * i + 1] = inl[3 * i + 1];
-        inl_out[3 * i + 2] = 1.0 / rho[i];
+        const double z = 1.0 / rho[i];
+        inl_out[3 * i + 2] = z;
+        acc += z;
+    }
+    if (zpartials) {  // frame solve: the per-workgroup sums of z the mean-z sign test needs (main.cc:466-472), saving that stage's own pass
+        const double r = wave_sum(acc);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = r;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = s_red[0];
+            for (int w2 = 1; w2 < kFB / 64; ++w2) t += s_red[w2];
+            zpartials[blockIdx.x] = t;
+        }
     }
 }
 
@@ -797,10 +812,12 @@ int refine_stage_apply_launch(Ctx* c, const RefineBuffers& B, int np, int stage,
 int refine_init_launch(Ctx* c, const RefineBuffers& B, int np) { return np == 7 ? refine_init_t<7>(c, B) : refine_init_t<6>(c, B); }
 int refine_iter_launch(Ctx* c, const RefineBuffers& B, int np) { return np == 7 ? refine_iter_t<7>(c, B) : refine_iter_t<6>(c, B); }
 
+int refine_finish_grid(const Ctx* c, const RefineBuffers& B) { return B.m_on_device ? refine_grid_cap(c) : refine_grid(c, B.m); }
+
 int refine_finish_launch(Ctx* c, const RefineBuffers& B, double* inl_out) {
-    if (!B.m_on_device && B.m == 0) return RSDSFM_OK;
-    hipLaunchKernelGGL(refine_finish_kernel, dim3(B.m_on_device ? refine_grid_cap(c) : refine_grid(c, B.m)), dim3(kFB), 0, c->stream,
-                       B.m_on_device ? (int64_t)-1 : B.m, B.inl, B.rho_a, B.rho_b, B.state, inl_out);
+    if (!B.m_on_device && B.m == 0 && !B.zpartials) return RSDSFM_OK;
+    hipLaunchKernelGGL(refine_finish_kernel, dim3(refine_finish_grid(c, B)), dim3(kFB), 0, c->stream,
+                       B.m_on_device ? (int64_t)-1 : B.m, B.inl, B.rho_a, B.rho_b, B.state, inl_out, B.zpartials);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

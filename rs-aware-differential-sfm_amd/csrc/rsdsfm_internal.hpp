@@ -300,11 +300,13 @@ struct RefineBuffers {
     double* srho;
     double* partials;
     int* bad_index;
+    double* zpartials = nullptr;  // frame solve: refine_finish_kernel also leaves its per-workgroup sums of z here (refine_finish_grid entries)
 };
 // see ransac_device (ransac_host.hip): caller's work enqueued behind the speculated final stage, given the device-resident result
 typedef std::function<int(const RansacBest*)> RansacSpecTail;
 // see refine_device (refine_host.hip): caller's work enqueued behind the refinement's output pass, given the device-resident state
-typedef std::function<int(const RefineState*)> RefineTail;
+typedef std::function<int(const RefineBuffers&)> RefineTail;
+int refine_finish_grid(const Ctx* c, const RefineBuffers& B);
 // one refinement in flight (refine_host.hip: refine_begin / refine_poll)
 struct RefineRun {
     RefineBuffers B;
@@ -322,7 +324,7 @@ size_t refine_workspace_bytes(const Ctx* c, int64_t m, bool m_on_device);
 int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
                  const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
                  int const_acceleration, int flow_index_mode, double* d_inl_out, const RefineTail* tail, const RansacBest* d_best,
-                 void* ws_base, RefineRun* run, RefineState* hs_prefetch);
+                 void* ws_base, RefineRun* run, RefineState* hs_prefetch, double* d_zpartials);
 int refine_enqueue_chunk(Ctx* c, RefineRun* run);
 int refine_poll(Ctx* c, RefineRun* run, double v_out[3], double w_out[3], double* k_out, rsdsfm_lm_summary* summary);
 int refine_partials_doubles(const Ctx* c, int64_t m);

@@ -59,10 +59,17 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
     char* d_refine_ws = fa.take<char>(refine_workspace_bytes(c, (int64_t)N, true));
 
     memset(res, 0, sizeof(*res));
-    int64_t n = 0;
-    int rc = rsdsfm_flatten_dev(ctx, d_flow_img, rows, cols, fx, fy, cx, cy, gamma, prm->flow_threshold, d_q, d_u, d_a, d_ak, &n);
+    // The flatten is enqueued WITHOUT waiting for its point count: a dense optical flow gives every pixel a flow vector, so the RANSAC
+    // (sampler, grids) is set up for n = rows * cols right away and the stream runs on from the flatten into the minimal solver; the
+    // real count arrives in host-mapped memory and is checked at the RANSAC's own wait.  If pixels were dropped (zero flow below the
+    // threshold) the stages are simply run again with the real count -- the slower path every frame took before.
+    int rc = ensure_pinned(c, ransac_pinned_bytes(prm->ransac_trials));  // (sized up front: pointers into the block stay valid)
     if (rc != RSDSFM_OK) return rc;
-    res->n_points = n;
+    int64_t* h_n = reinterpret_cast<int64_t*>(static_cast<char*>(c->h_pinned) + c->pinned_bytes - kPinnedTail / 2);
+    *h_n = -1;
+    rc = flatten_enqueue(c, d_flow_img, rows, cols, fx, fy, cx, cy, gamma, prm->flow_threshold, d_q, d_u, d_a, d_ak, h_n);
+    if (rc != RSDSFM_OK) return rc;
+    int64_t n = (int64_t)N;
     if (prm->use_global_shutter_mode) {  // main.cc:441-444: alpha *= 0; alpha += 1
         rc = alpha_ones_launch(c, d_a, n);
         if (rc != RSDSFM_OK) return rc;
@@ -91,7 +98,7 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
     // (pointers into the pinned block are taken when they are used: the RANSAC may still grow the block)
     auto header_host = [&]() { return reinterpret_cast<double*>(static_cast<char*>(c->h_pinned) + c->pinned_bytes - 64); };
     auto state_host = [&]() { return reinterpret_cast<RefineState*>(static_cast<char*>(c->h_pinned) + c->pinned_bytes - kPinnedTail); };
-    static_assert(sizeof(RefineState) + sizeof(int) + 64 <= kPinnedTail, "state read-back + header fit the reserved tail");
+    static_assert(sizeof(RefineState) + sizeof(int) <= kPinnedTail / 2, "reserved tail: state read-back | point count ... depth-map header");
     const RefineTail tail = [&](const RefineBuffers& B) -> int {
         const RefineState* st = B.state;
         const int64_t m_arg = m_known >= 0 ? m_known : n;
@@ -110,7 +117,15 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
     bool refinement_enqueued = false;
     rc = ransac_device(c, d_q, d_u, d_a, d_ak, n, prm->use_acceleration_mode, prm->ransac_trials, prm->ransac_tol, nullptr, prm->seed,
                        prm->depth_mode, prm->k_sign_mode, &ro, prm->use_refinement ? &spec_tail : nullptr, &refinement_enqueued);
+    if (rc != RSDSFM_OK) RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));  // (an error of the speculated run may only mean n was wrong)
+    if (*h_n != n) {  // pixels without flow were dropped: everything behind the flatten ran on the wrong point count
+        n = *h_n;
+        refinement_enqueued = false;
+        rc = ransac_device(c, d_q, d_u, d_a, d_ak, n, prm->use_acceleration_mode, prm->ransac_trials, prm->ransac_tol, nullptr, prm->seed,
+                           prm->depth_mode, prm->k_sign_mode, &ro, prm->use_refinement ? &spec_tail : nullptr, &refinement_enqueued);
+    }
     if (rc != RSDSFM_OK) return rc;
+    res->n_points = n;
     res->num_inliers = ro.num_inliers;
     res->best_trial = ro.best_trial;
     memcpy(res->ransac_w, ro.w, sizeof(ro.w));

@@ -38,6 +38,24 @@ static int flatten_device(Ctx* c, const double* d_img, int32_t rows, int32_t col
     return RSDSFM_OK;
 }
 
+namespace rsdsfm {
+// The flatten of a whole image WITHOUT the host wait: the point count lands in *h_total (host-mapped pinned memory, written by the scan
+// kernel) once the stream gets there.  The frame solve uses it to enqueue the RANSAC behind the flatten on the assumption that every
+// pixel carries flow (a dense optical flow: n = rows * cols) and checks the count at its next wait.
+int flatten_enqueue(Ctx* c, const double* d_img, int32_t rows, int32_t cols, double fx, double fy, double cx, double cy, double gamma,
+                    double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* h_total) {
+    if (rows <= 0 || cols <= 0 || !h_total) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    if (!d_img || !d_q || !d_u || !d_alpha || !d_alpha_k) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
+    const size_t ncells = (size_t)flatten_cells(rows, cols);
+    int rc = ensure_ws(c, 2 * Arena::need(sizeof(int64_t) * ncells) + Arena::need(64) + 1024);
+    if (rc != RSDSFM_OK) return rc;
+    Arena ws(c->d_ws);
+    int64_t* d_counts = ws.take<int64_t>(ncells);
+    int64_t* d_offsets = ws.take<int64_t>(ncells);
+    return flatten_launch(c, d_img, rows, cols, 0, fx, fy, cx, cy, gamma, thr, d_q, d_u, d_alpha, d_alpha_k, d_counts, d_offsets, h_total, nullptr);
+}
+}  // namespace rsdsfm
+
 extern "C" {
 
 int rsdsfm_flatten_dev(rsdsfm_ctx* ctx, const double* d_img, int32_t rows, int32_t cols, double fx, double fy, double cx, double cy,

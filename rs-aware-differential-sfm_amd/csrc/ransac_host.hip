@@ -67,6 +67,13 @@ void sample_indices(int64_t n, int T, uint64_t seed, int32_t* out) {
     if (!v.empty()) memcpy(out, v.data(), sizeof(int32_t) * v.size());
 }
 
+// pinned host memory a RANSAC with T trials uses (the end of the block, kPinnedTail bytes, belongs to the frame solve)
+size_t ransac_pinned_bytes(int T) {
+    const size_t Tn = (size_t)std::max(T, 1);
+    return sizeof(RansacBest) + 8 * sizeof(int) + sizeof(double) * 2 * Tn + sizeof(double) * 8 * Tn + sizeof(LmState) * Tn + 64 +
+           sizeof(int32_t) * Tn * 9 + kPinnedTail;
+}
+
 // Device-resident RANSAC.  d_* inputs and the arrays of `out` are device pointers (any of the out arrays may be
 // NULL); scalars of `out` and its trial_* arrays (host) are filled after one final synchronisation.
 // spec_tail (optional): work of the CALLER that only needs the RANSAC's device-resident result (RansacBest + the compacted inlier
@@ -119,8 +126,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     double* d_rho = out->inv_depth ? out->inv_depth : ws.take<double>((size_t)n);
     uint8_t* d_mask = out->mask ? out->mask : ws.take<uint8_t>((size_t)n);
 
-    rc = ensure_pinned(c, sizeof(RansacBest) + 8 * sizeof(int) + sizeof(double) * 2 * Tn + sizeof(double) * 8 * Tn + sizeof(LmState) * Tn + 64 +
-                              sizeof(int32_t) * (size_t)Tn * 9 + kPinnedTail);  // (the end of the block belongs to the frame solve)
+    rc = ensure_pinned(c, ransac_pinned_bytes(T));
     if (rc != RSDSFM_OK) return rc;
     char* hp = static_cast<char*>(c->h_pinned);
     RansacBest* h_best = reinterpret_cast<RansacBest*>(hp);

@@ -302,6 +302,9 @@ struct RefineBuffers {
     int* bad_index;
     double* zpartials = nullptr;  // frame solve: refine_finish_kernel also leaves its per-workgroup sums of z here (refine_finish_grid entries)
 };
+size_t ransac_pinned_bytes(int T);
+int flatten_enqueue(Ctx* c, const double* d_img, int32_t rows, int32_t cols, double fx, double fy, double cx, double cy, double gamma,
+                    double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* h_total);
 // see ransac_device (ransac_host.hip): caller's work enqueued behind the speculated final stage, given the device-resident result
 typedef std::function<int(const RansacBest*)> RansacSpecTail;
 // see refine_device (refine_host.hip): caller's work enqueued behind the refinement's output pass, given the device-resident state

@@ -58,6 +58,45 @@ def test_solve_frame_dev_matches_stages_and_oracle(oracle, rsdsfm, flow_mode):
         assert np.allclose(1.0 / got[m], 1.0 / dm_o[m], rtol=1e-6, atol=1e-9)
 
 
+def test_solve_frame_with_pixels_without_flow_equals_stages(rsdsfm):
+    """The one-call solve enqueues the RANSAC behind the flatten on the assumption of a dense flow (n = rows * cols) and checks the real
+    point count at its first wait; a flow image with zero-flow pixels (dropped by the threshold, main.cc:410) takes the second path --
+    everything behind the flatten runs again with the real count -- and must give what the stage-by-stage path gives, bit for bit;
+    a following dense frame on the same context takes the fast path again"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(3, rows=96, cols=200)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    holes = np.array(d["flow_img"])
+    rng = np.random.default_rng(5)
+    holes[rng.random((rows, cols)) < 0.07] = 0.0       # scattered pixels without flow
+    holes[10:30, 50:90] = 0.0                           # and a block
+    T, tol, seed = 10, 0.003, 7
+    dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+    R = torch.empty((rows, 9), dtype=torch.float64, device=dev)
+    t = torch.empty((rows, 3), dtype=torch.float64, device=dev)
+    with rsdsfm.Solver(0) as s:
+        for flow in (holes, np.array(d["flow_img"]), holes):
+            img = torch.from_numpy(flow).to(dev)
+            r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), trials=T, tol=tol, seed=seed,
+                                  flow_index_mode=rsdsfm.FLOW_GATHERED)
+            s.synchronize()
+            q, u, a, ak = s.flatten(flow, K, gamma)
+            assert r["n"] == len(q) and (len(q) < rows * cols) == (flow is holes)
+            rr = s.ransac(q, u, a, ak, False, T, tol, samples=None, seed=seed, depth_mode=1)
+            ref = s.non_linear_refinement(u, rr["inliers"], rr["alpha"], rr["alpha_k"], rr["v"], rr["w"], rr["k"], False, flow_index_mode=1,
+                                          inlier_idx=rr["inlier_idx"])
+            dmap = s.depth_map(ref["inliers"], ref["v"], K, rows, cols)
+            Rr, tr = s.pose_table(dmap["v"], ref["w"], ref["k"], gamma, rows)
+            assert r["num_inliers"] == rr["num_inliers"] and r["best_trial"] == rr["best_trial"]
+            assert np.array_equal(r["ransac_w"], rr["w"]) and np.array_equal(r["ransac_v"], rr["v"])
+            assert np.array_equal(r["w"], ref["w"]) and np.array_equal(r["v"], dmap["v"]) and r["k"] == ref["k"] and r["flipped"] == dmap["flipped"]
+            assert r["refine_summary"] == ref["summary"]
+            assert np.array_equal(dm.cpu().numpy().T, dmap["depth_map"])
+            assert np.array_equal(R.cpu().numpy().reshape(rows, 3, 3), Rr) and np.array_equal(t.cpu().numpy(), tr)
+
+
 def test_full_solve_4k_frame(rsdsfm, big_config):
     """3840x2160 (BASELINE configs[3] size): the whole solve runs at the largest configured size -- workspace sizing,
     64-bit indexing, compaction over > 2048 workgroups -- and recovers the motion of the DeepFlow-like pair."""

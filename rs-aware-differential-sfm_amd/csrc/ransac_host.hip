@@ -157,6 +157,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
             if (depth_mode == RSDSFM_DEPTH_CERES_LM) {
                 if (b0 > 0) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_flags, 0, sizeof(int) * 8, c->stream));  // batch 0: cleared above
                 for (int round = 0;; ++round) {
+                    bool flags_via_pick = false;  // this round's flag words reach the host with the speculated pick kernel
                     if (round > 4 * kMaxIter) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machines did not terminate");
                     rc = ransac_lm_round_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, d_partials, d_flags,
                                                 d_scored + b0, d_tcount + b0, d_terr + b0, round, tol, k0, fused_base);
@@ -175,8 +176,9 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
                             if (rc != RSDSFM_OK) return rc;
                             spec_scored = true;
                         }
-                        rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, h_best);
+                        rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, h_best, d_flags, h_running);  // (+ the flag words)
                         if (rc != RSDSFM_OK) return rc;
+                        flags_via_pick = true;
                         rc = ransac_final_launch(c, d_q, d_u, d_a, d_ak, n, d_best, d_states, depth_mode, tol, d_rho, d_mask, d_bcounts,
                                                  d_boffs, out->inlier_idx, out->inliers, out->alpha, out->alpha_k, h_best);
                         if (rc != RSDSFM_OK) return rc;
@@ -187,7 +189,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
                             tail_enqueued = true;
                         }
                     }
-                    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_running, d_flags, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
+                    if (!flags_via_pick) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_running, d_flags, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
                     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
                     if (round == 0) {
                         not_one_step += h_running[2];

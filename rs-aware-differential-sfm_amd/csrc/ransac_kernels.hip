@@ -649,9 +649,12 @@ __device__ __forceinline__ void pick_best_trial(const double* __restrict__ trial
 
 // best_host (optional): host-mapped pinned copy of the result, written by the kernel itself (no copy kernel behind the stage)
 __global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restrict__ trial_count, const double* __restrict__ trial_err, int T,
-                                                        const double* __restrict__ hyp, RansacBest* best, RansacBest* best_host) {
+                                                        const double* __restrict__ hyp, RansacBest* best, RansacBest* best_host,
+                                                        const int* __restrict__ flags, int* __restrict__ flags_host) {
     if (blockIdx.x != 0) return;
     const int lane = threadIdx.x;
+    // the round's flag words (final since ransac_decide_kernel) travel to host-mapped memory with this launch: no copy behind the stage
+    if (flags_host && lane < 8) flags_host[lane] = flags[lane];
     double best_count, best_err;
     int bi;
     pick_best_trial(trial_count, trial_err, T, lane, bi, best_count, best_err);
@@ -968,8 +971,8 @@ int ransac_score_merge_launch(Ctx* c, const double* rows_all, int nranks, int T,
 int ransac_rows_doubles() { return NSR; }
 
 int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best,
-                       RansacBest* best_host) {
-    hipLaunchKernelGGL(ransac_pick_kernel, dim3(1), dim3(64), 0, c->stream, trial_count, trial_err, T, hyp, best, best_host);
+                       RansacBest* best_host, const int* d_flags, int* h_flags) {
+    hipLaunchKernelGGL(ransac_pick_kernel, dim3(1), dim3(64), 0, c->stream, trial_count, trial_err, T, hyp, best, best_host, d_flags, h_flags);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -71,6 +71,7 @@ int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const 
     run->hs = hs_prefetch ? hs_prefetch : static_cast<RefineState*>(c->h_pinned);
     run->prefetch = hs_prefetch != nullptr;
     run->prefetched = false;
+    B.state_host = hs_prefetch;  // prefetch: the output pass writes the state there itself
     if (d_best) {
         rc = refine_state_from_best_launch(c, d_best, B, np);
         if (rc != RSDSFM_OK) return rc;
@@ -115,10 +116,7 @@ int refine_enqueue_chunk(Ctx* c, RefineRun* run) {
     if (rc != RSDSFM_OK) return rc;
     if (run->tail) rc = (*run->tail)(run->B);
     if (rc != RSDSFM_OK) return rc;
-    if (run->prefetch) {
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(run->hs, run->B.state, sizeof(RefineState) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        run->prefetched = true;
-    }
+    if (run->prefetch) run->prefetched = true;  // (refine_finish_kernel has written the state to run->hs)
     return rc;
 }
 

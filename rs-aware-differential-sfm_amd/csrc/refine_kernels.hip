@@ -640,8 +640,15 @@ __global__ __launch_bounds__(kFB) void refine_decide_kernel(const double* __rest
 __global__ __launch_bounds__(kFB) void refine_finish_kernel(int64_t m, const double* __restrict__ inl,
                                                            const double* __restrict__ rho_a, const double* __restrict__ rho_b,
                                                            const RefineState* __restrict__ st, double* __restrict__ inl_out,
-                                                           double* __restrict__ zpartials) {
+                                                           double* __restrict__ zpartials, RefineState* __restrict__ state_host,
+                                                           const int* __restrict__ bad_index) {
     __shared__ double s_red[kFB / 64];
+    if (state_host && blockIdx.x == 0) {  // frame solve: the state (+ bad-index flag) travels to host-mapped memory with this launch
+        static_assert(sizeof(RefineState) % 8 == 0, "copied as 8-byte words");
+        for (int i = threadIdx.x; i < (int)(sizeof(RefineState) / 8); i += kFB)
+            reinterpret_cast<double*>(state_host)[i] = reinterpret_cast<const double*>(st)[i];
+        if (threadIdx.x == 0) *reinterpret_cast<int*>(reinterpret_cast<char*>(state_host) + sizeof(RefineState)) = *bad_index;
+    }
     const double* __restrict__ rho = st->cur ? rho_b : rho_a;
     if (m < 0) m = st->m;  // device-resident count: a plain copy pass, any grid will do
     const int64_t stride = (int64_t)gridDim.x * kFB;
@@ -815,9 +822,9 @@ int refine_iter_launch(Ctx* c, const RefineBuffers& B, int np) { return np == 7 
 int refine_finish_grid(const Ctx* c, const RefineBuffers& B) { return B.m_on_device ? refine_grid_cap(c) : refine_grid(c, B.m); }
 
 int refine_finish_launch(Ctx* c, const RefineBuffers& B, double* inl_out) {
-    if (!B.m_on_device && B.m == 0 && !B.zpartials) return RSDSFM_OK;
+    if (!B.m_on_device && B.m == 0 && !B.zpartials && !B.state_host) return RSDSFM_OK;
     hipLaunchKernelGGL(refine_finish_kernel, dim3(refine_finish_grid(c, B)), dim3(kFB), 0, c->stream,
-                       B.m_on_device ? (int64_t)-1 : B.m, B.inl, B.rho_a, B.rho_b, B.state, inl_out, B.zpartials);
+                       B.m_on_device ? (int64_t)-1 : B.m, B.inl, B.rho_a, B.rho_b, B.state, inl_out, B.zpartials, B.state_host, B.bad_index);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -252,7 +252,7 @@ int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* 
                         const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
                         double* partials, double* trial_count, double* trial_err);
 int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best,
-                       RansacBest* best_host = nullptr);
+                       RansacBest* best_host = nullptr, const int* d_flags = nullptr, int* h_flags = nullptr);
 int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         RansacBest* best, const LmState* states, int depth_mode, double tol, double* rho, uint8_t* mask,
                         int64_t* block_counts, int64_t* block_offsets, int64_t* inlier_idx, double* inliers,
@@ -300,6 +300,7 @@ struct RefineBuffers {
     double* srho;
     double* partials;
     int* bad_index;
+    RefineState* state_host = nullptr;  // frame solve: host-mapped copy of the state (+ flag) written by refine_finish_kernel
     double* zpartials = nullptr;  // frame solve: refine_finish_kernel also leaves its per-workgroup sums of z here (refine_finish_grid entries)
 };
 size_t ransac_pinned_bytes(int T);

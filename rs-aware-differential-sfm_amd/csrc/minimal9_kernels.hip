@@ -625,9 +625,14 @@ __global__ __launch_bounds__(64) void minimal9_kernel(const double* __restrict__
                                                      const double* __restrict__ alpha,
                                                      const double* __restrict__ alpha_k,
                                                      const int32_t* __restrict__ samples, int T, int use_alpha_k,
-                                                     int k_sign_mode, double* __restrict__ hyp_out) {
+                                                     int k_sign_mode, double* __restrict__ hyp_out, uint64_t* __restrict__ zero_words,
+                                                     int64_t n_zero_words) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
+    // RANSAC: the per-hypothesis LM states, score marks and flag words must be zero before the depth solves start; the workgroups of
+    // this launch clear them on the way (8-byte words, grid-strided) instead of a fill launch in front of it
+    if (zero_words)
+        for (int64_t i = (int64_t)blockIdx.x * 64 + lane; i < n_zero_words; i += (int64_t)gridDim.x * 64) zero_words[i] = 0ull;
     const int t = COOP ? (int)blockIdx.x : (int)blockIdx.x * 64 + lane;
     if (t >= T) return;  // per-lane independent work, no workgroup barriers below
     LVec base{lds + lane};
@@ -817,8 +822,10 @@ __global__ __launch_bounds__(64) void minimal9_kernel(const double* __restrict__
 }
 
 int minimal9_launch(Ctx* c, const double* q, const double* u, const double* alpha, const double* alpha_k,
-                    const int32_t* samples, int T, int use_alpha_k, int k_sign_mode, double* hyp_out) {
+                    const int32_t* samples, int T, int use_alpha_k, int k_sign_mode, double* hyp_out, void* zero_begin, size_t zero_bytes) {
     if (T <= 0) return RSDSFM_OK;
+    uint64_t* zero_words = reinterpret_cast<uint64_t*>(zero_begin);
+    const int64_t n_zero_words = (int64_t)(zero_bytes / 8);
     const size_t lds_bytes = (size_t)(use_alpha_k ? kSlotsK : kSlotsNoK) * 64 * sizeof(double);
     static bool attr_set = false;
     if (!attr_set) {
@@ -833,10 +840,10 @@ int minimal9_launch(Ctx* c, const double* q, const double* u, const double* alph
     // few hypotheses (RANSAC: T = 5 ... a few hundred): one wave per hypothesis, 9x9 SVD shared by the wave; many: one lane each
     if (T <= c->num_cus * 2)
         hipLaunchKernelGGL(minimal9_kernel<true>, dim3(T), dim3(64), lds_bytes, c->stream, q, u, alpha, alpha_k, samples, T, use_alpha_k,
-                           k_sign_mode, hyp_out);
+                           k_sign_mode, hyp_out, zero_words, n_zero_words);
     else
         hipLaunchKernelGGL(minimal9_kernel<false>, dim3((T + 63) / 64), dim3(64), lds_bytes, c->stream, q, u, alpha, alpha_k, samples, T,
-                           use_alpha_k, k_sign_mode, hyp_out);
+                           use_alpha_k, k_sign_mode, hyp_out, zero_words, n_zero_words);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -138,7 +138,9 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     // the sample table stays in host-mapped pinned memory: minimal9_kernel reads its 9 indices per hypothesis from there
     int32_t* h_samples_pinned = reinterpret_cast<int32_t*>(h_states + Tn);
 
-    RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
+    // (with T > 0 the region is cleared by the workgroups of minimal9_kernel: one launch less in front of the solver)
+    const bool zero_in_minimal9 = T > 0 && zero_bytes % 8 == 0 && (reinterpret_cast<uintptr_t>(zero_begin) & 7) == 0;
+    if (!zero_in_minimal9) RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
     bool final_done = false, spec_scored = false;
     // speculation depth of round 0 (see ransac_kernels.hip): explicit, or two iterations behind a solve none of whose hypotheses
     // went beyond one accepted step (outlier-dominated costs), three otherwise.  Like fused_base below: scheduling only.
@@ -149,7 +151,8 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     int not_one_step = 0;
     if (T > 0) {
         memcpy(h_samples_pinned, samples.data(), sizeof(int32_t) * (size_t)T * 9);
-        rc = minimal9_launch(c, d_q, d_u, d_a, d_ak, h_samples_pinned, T, use_alpha_k, k_sign_mode, d_hyp);
+        rc = minimal9_launch(c, d_q, d_u, d_a, d_ak, h_samples_pinned, T, use_alpha_k, k_sign_mode, d_hyp, zero_in_minimal9 ? zero_begin : nullptr,
+                             zero_in_minimal9 ? zero_bytes : 0);
         if (rc != RSDSFM_OK) return rc;
         for (int b0 = 0; b0 < T; b0 += batch) {
             const int B = std::min(batch, T - b0);

@@ -238,7 +238,8 @@ int zsum_row_launch(Ctx* c, const double* d_inl, int64_t m, double* d_partials, 
 namespace rsdsfm {
 // minimal9_kernels.hip : hyp_out [T][8] = w(3), v(3), k, status
 int minimal9_launch(Ctx* c, const double* q, const double* u, const double* alpha, const double* alpha_k,
-                    const int32_t* samples, int T, int use_alpha_k, int k_sign_mode, double* hyp_out);
+                    const int32_t* samples, int T, int use_alpha_k, int k_sign_mode, double* hyp_out, void* zero_begin = nullptr,
+                    size_t zero_bytes = 0);
 }  // namespace rsdsfm
 
 namespace rsdsfm {

@@ -137,10 +137,18 @@ __global__ __launch_bounds__(kGB) void flatten_tile_kernel(const double2* __rest
                                                           const int64_t* __restrict__ cell_offsets,
                                                           const int64_t* __restrict__ seg_bases, double2* __restrict__ q,
                                                           double2* __restrict__ u, double* __restrict__ alpha,
-                                                          double* __restrict__ alpha_k) {
+                                                          double* __restrict__ alpha_k, int nseg, int64_t* __restrict__ total_out) {
+    // SCATTER: 0 = count the cells, 1 = scatter with scanned segment bases, 2 = scatter with the raw segment TOTALS of
+    // cell_scan_local_kernel in `seg_bases` (nseg of them: a handful -- every wave adds up the ones in front of its cell itself, and
+    // the first workgroup stores the grand total; the frame solve's variant: no launch for the second scan level)
     __shared__ double2 s_tile[kFT_H][kFT_W + 1];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int c0 = blockIdx.x * kFT_W, r0 = blockIdx.y * kFT_H;
+    if (SCATTER == 2 && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) {
+        int64_t run = 0;
+        for (int sgi = 0; sgi < nseg; ++sgi) run += seg_bases[sgi];
+        *total_out = run;
+    }
 #pragma unroll
     for (int k = 0; k < kFT_H * kFT_W / kGB; ++k) {
         const int lr = tid / kFT_W + k * (kGB / kFT_W), lc = tid % kFT_W;
@@ -160,7 +168,15 @@ __global__ __launch_bounds__(kGB) void flatten_tile_kernel(const double2* __rest
         if (!SCATTER) {
             if (lane == 0) cell_counts[cell] = __popcll(bal);
         } else if (keep) {
-            const int64_t o = seg_bases[cell / kScanSegCells] + cell_offsets[cell] + __popcll(bal & ((1ull << lane) - 1ull));
+            int64_t seg_base;
+            if (SCATTER == 2) {
+                seg_base = 0;
+                const int sg = (int)(cell / kScanSegCells);  // wave-uniform
+                for (int sgi = 0; sgi < sg; ++sgi) seg_base += seg_bases[sgi];
+            } else {
+                seg_base = seg_bases[cell / kScanSegCells];
+            }
+            const int64_t o = seg_base + cell_offsets[cell] + __popcll(bal & ((1ull << lane) - 1ull));
             q[o] = make_double2(((i + col0) - cx) * 1.0 / fx, (j - cy) * 1.0 / fy);
             u[o] = make_double2(f.x * gamma / fx, f.y * gamma / fy);
             alpha[o] = 1 + gamma * f.y / h;  // minimal.cc:183 with pixel flow, h = rows (quirk Q6)
@@ -358,15 +374,25 @@ int flatten_launch(Ctx* c, const double* d_img, int rows, int cols, int col0, do
     const int nseg = (int)((ncells + kScanSeg - 1) / kScanSeg);
     int64_t* d_seg = d_offsets + ncells;  // segment totals -> bases
     hipLaunchKernelGGL(flatten_tile_kernel<0>, grid, dim3(kGB), 0, c->stream, img2, rows, cols, fx, fy, cx, cy, gamma, thr, col0, nchunks,
-                       d_counts, d_offsets, d_seg, reinterpret_cast<double2*>(d_q), reinterpret_cast<double2*>(d_u), d_alpha, d_alpha_k);
+                       d_counts, d_offsets, d_seg, reinterpret_cast<double2*>(d_q), reinterpret_cast<double2*>(d_u), d_alpha, d_alpha_k, 0,
+                       (int64_t*)nullptr);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(cell_scan_local_kernel, dim3(nseg), dim3(256), 0, c->stream, d_counts, ncells, d_offsets, d_seg);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
+    if (!total_ready && nseg <= 256) {
+        // nobody waits for the count in front of the scatter pass (the frame solve): that pass adds up the few segment totals itself
+        hipLaunchKernelGGL(flatten_tile_kernel<2>, grid, dim3(kGB), 0, c->stream, img2, rows, cols, fx, fy, cx, cy, gamma, thr, col0, nchunks,
+                           d_counts, d_offsets, d_seg, reinterpret_cast<double2*>(d_q), reinterpret_cast<double2*>(d_u), d_alpha, d_alpha_k, nseg,
+                           d_total);
+        RSDSFM_HIP_CHECK(c, hipGetLastError());
+        return RSDSFM_OK;
+    }
     hipLaunchKernelGGL(cell_scan_segments_kernel, dim3(1), dim3(256), 0, c->stream, d_seg, nseg, d_total);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     if (total_ready) RSDSFM_HIP_CHECK(c, hipEventRecord(total_ready, c->stream));  // the count is final here; the scatter pass follows
     hipLaunchKernelGGL(flatten_tile_kernel<1>, grid, dim3(kGB), 0, c->stream, img2, rows, cols, fx, fy, cx, cy, gamma, thr, col0, nchunks,
-                       d_counts, d_offsets, d_seg, reinterpret_cast<double2*>(d_q), reinterpret_cast<double2*>(d_u), d_alpha, d_alpha_k);
+                       d_counts, d_offsets, d_seg, reinterpret_cast<double2*>(d_q), reinterpret_cast<double2*>(d_u), d_alpha, d_alpha_k, 0,
+                       (int64_t*)nullptr);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -431,3 +431,53 @@ def test_stage_pipeline_on_device_buffers_equals_one_call_solve(rsdsfm, flow_mod
         assert np.array_equal(p["v"], r["v"]) and np.array_equal(p["w"], r["w"]) and p["k"] == r["k"] and p["flipped"] == r["flipped"]
         assert p["refine"]["summary"] == r["refine_summary"]
         assert torch.equal(pipe.depth_map, dm) and torch.equal(pipe.R, R) and torch.equal(pipe.t, t)
+
+
+def test_one_call_solve_equals_stage_pipeline_on_random_frames(rsdsfm):
+    """The one-call solve speculates at three places (a dense flow, the RANSAC's final stage, the refinement ending within its first
+    chunk) and enqueues each stage behind the one before it; the stage pipeline (pipeline.FramePipeline over the `_dev` entry points)
+    waits for the host in between.  36 random frames on ONE context pair -- sizes, noise-free / DeepFlow-like data, pixels without flow,
+    1...50 trials, tolerances that make the inlier set a strict subset, acceleration mode, closed-form depths, refinement on / off,
+    both flow index modes, each configuration behind a different one (history) -- must agree bit for bit in every output."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(20261002)
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream), rsdsfm.Solver(0, stream=stream.cuda_stream) as s_one, rsdsfm.Solver(0, stream=stream.cuda_stream) as s_stage:
+        for case in range(36):
+            rows, cols = int(rng.integers(40, 140)), int(rng.integers(60, 230))
+            cfg = int(rng.choice([1, 3, 5]))
+            d = rsdsfm.synth.make_config(cfg, seed=int(rng.integers(1 << 30)), rows=rows, cols=cols)
+            K, gamma = d["K"], d["gamma"]
+            flow = np.array(d["flow_img"])
+            if rng.random() < 0.4:
+                flow[rng.random((rows, cols)) < rng.uniform(0.01, 0.3)] = 0.0
+            if not np.all(np.isfinite(flow)):
+                continue
+            kw = dict(trials=int(rng.choice([1, 3, 5, 20, 50])), tol=float(rng.choice([0.05, 0.01, 0.003])), seed=int(rng.integers(1, 1000)),
+                      flow_index_mode=int(rng.integers(2)))
+            accel, closed, refine = bool(rng.random() < 0.25), bool(rng.random() < 0.2), bool(rng.random() < 0.85)
+            img = torch.from_numpy(flow).to(dev)
+            dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+            R = torch.empty((rows, 9), dtype=torch.float64, device=dev)
+            t = torch.empty((rows, 3), dtype=torch.float64, device=dev)
+            tag = "case %d: %dx%d cfg %d %s accel %s closed %s refine %s" % (case, rows, cols, cfg, kw, accel, closed, refine)
+            pipe = rsdsfm.pipeline.FramePipeline(s_stage, torch, dev, rows, cols, K, gamma)
+            try:
+                p = pipe.solve(img, use_alpha_k=accel, refine=refine, depth_mode=0 if closed else 1, **kw)
+            except rsdsfm.RsdsfmError as e:  # e.g. no real k for a hypothesis in acceleration mode, fewer than 9 points: the one-call solve must fail too
+                with pytest.raises(rsdsfm.RsdsfmError):
+                    s_one.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), use_acceleration_mode=accel,
+                                          use_refinement=refine, depth_mode=0 if closed else 1, **kw)
+                continue
+            r = s_one.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), use_acceleration_mode=accel,
+                                      use_refinement=refine, depth_mode=0 if closed else 1, **kw)
+            s_one.synchronize()
+            assert p["n"] == r["n"] and p["num_inliers"] == r["num_inliers"], tag
+            assert np.array_equal(p["v"], r["v"], equal_nan=True) and np.array_equal(p["w"], r["w"], equal_nan=True), tag
+            assert (p["k"] == r["k"] or (np.isnan(p["k"]) and np.isnan(r["k"]))) and p["flipped"] == r["flipped"], tag
+            if refine:
+                assert p["refine"]["summary"] == r["refine_summary"] or np.isnan(r["refine_summary"]["final_cost"]), tag
+            eq = lambda a, b: torch.equal(a, b) or torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+            assert eq(pipe.depth_map, dm) and eq(pipe.R, R) and eq(pipe.t, t), tag

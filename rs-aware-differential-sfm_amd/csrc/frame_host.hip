@@ -65,11 +65,21 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
     // threshold) the stages are simply run again with the real count -- the slower path every frame took before.
     int rc = ensure_pinned(c, ransac_pinned_bytes(prm->ransac_trials));  // (sized up front: pointers into the block stay valid)
     if (rc != RSDSFM_OK) return rc;
+    // (Only behind a frame that WAS dense: a sequence of frames with pixels without flow -- e.g. the ground-truth flow of a synthetic
+    // example with void pixels -- waits for the count as before instead of paying for a discarded RANSAC every time.  A hint like the
+    // others: it decides what is enqueued when, never a result.)
     int64_t* h_n = reinterpret_cast<int64_t*>(static_cast<char*>(c->h_pinned) + c->pinned_bytes - kPinnedTail / 2);
-    *h_n = -1;
-    rc = flatten_enqueue(c, d_flow_img, rows, cols, fx, fy, cx, cy, gamma, prm->flow_threshold, d_q, d_u, d_a, d_ak, h_n);
-    if (rc != RSDSFM_OK) return rc;
     int64_t n = (int64_t)N;
+    if (c->frame_dense_hint) {
+        *h_n = -1;
+        rc = flatten_enqueue(c, d_flow_img, rows, cols, fx, fy, cx, cy, gamma, prm->flow_threshold, d_q, d_u, d_a, d_ak, h_n);
+        if (rc != RSDSFM_OK) return rc;
+    } else {
+        rc = rsdsfm_flatten_dev(ctx, d_flow_img, rows, cols, fx, fy, cx, cy, gamma, prm->flow_threshold, d_q, d_u, d_a, d_ak, &n);
+        if (rc != RSDSFM_OK) return rc;
+        h_n = reinterpret_cast<int64_t*>(static_cast<char*>(c->h_pinned) + c->pinned_bytes - kPinnedTail / 2);
+        *h_n = n;
+    }
     if (prm->use_global_shutter_mode) {  // main.cc:441-444: alpha *= 0; alpha += 1
         rc = alpha_ones_launch(c, d_a, n);
         if (rc != RSDSFM_OK) return rc;
@@ -124,6 +134,7 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
         rc = ransac_device(c, d_q, d_u, d_a, d_ak, n, prm->use_acceleration_mode, prm->ransac_trials, prm->ransac_tol, nullptr, prm->seed,
                            prm->depth_mode, prm->k_sign_mode, &ro, prm->use_refinement ? &spec_tail : nullptr, &refinement_enqueued);
     }
+    c->frame_dense_hint = n == (int64_t)N ? 1 : 0;
     if (rc != RSDSFM_OK) return rc;
     res->n_points = n;
     res->num_inliers = ro.num_inliers;

@@ -125,14 +125,17 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
                             d_inl_ref, &tail, d_best, d_refine_ws, &run, state_host(), d_zpartials);
     };
     bool refinement_enqueued = false;
+    // (the refinement is only enqueued ahead where the previous RANSAC's speculated final stage held: data whose hypotheses need further
+    // LM rounds every time -- noise-free flow -- would pay for a discarded refinement chunk per frame)
+    const bool ahead = prm->use_refinement && c->ransac_spec_held_hint != 0;
     rc = ransac_device(c, d_q, d_u, d_a, d_ak, n, prm->use_acceleration_mode, prm->ransac_trials, prm->ransac_tol, nullptr, prm->seed,
-                       prm->depth_mode, prm->k_sign_mode, &ro, prm->use_refinement ? &spec_tail : nullptr, &refinement_enqueued);
+                       prm->depth_mode, prm->k_sign_mode, &ro, ahead ? &spec_tail : nullptr, &refinement_enqueued);
     if (rc != RSDSFM_OK) RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));  // (an error of the speculated run may only mean n was wrong)
     if (*h_n != n) {  // pixels without flow were dropped: everything behind the flatten ran on the wrong point count
         n = *h_n;
         refinement_enqueued = false;
         rc = ransac_device(c, d_q, d_u, d_a, d_ak, n, prm->use_acceleration_mode, prm->ransac_trials, prm->ransac_tol, nullptr, prm->seed,
-                           prm->depth_mode, prm->k_sign_mode, &ro, prm->use_refinement ? &spec_tail : nullptr, &refinement_enqueued);
+                           prm->depth_mode, prm->k_sign_mode, &ro, ahead ? &spec_tail : nullptr, &refinement_enqueued);
     }
     c->frame_dense_hint = n == (int64_t)N ? 1 : 0;
     if (rc != RSDSFM_OK) return rc;

@@ -84,7 +84,7 @@ size_t ransac_pinned_bytes(int T) {
 int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n,
                   int use_alpha_k, int T, double tol, const int32_t* h_samples, uint64_t seed, int depth_mode,
                   int k_sign_mode, rsdsfm_ransac_out* out, const RansacSpecTail* spec_tail, bool* spec_tail_held) {
-    bool tail_enqueued = false;
+    bool tail_enqueued = false, spec_final = false;
     if (spec_tail_held) *spec_tail_held = false;
     if (!out) return fail(c, RSDSFM_ERR_INVALID, "null out");
     if (n < 9) return fail(c, RSDSFM_ERR_INVALID, "ransac needs at least 9 points (the reference would compute rand() % 0)");
@@ -186,6 +186,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
                                                  d_boffs, out->inlier_idx, out->inliers, out->alpha, out->alpha_k, h_best);
                         if (rc != RSDSFM_OK) return rc;
                         final_done = true;
+                        spec_final = true;
                         if (spec_tail) {
                             rc = (*spec_tail)(d_best);
                             if (rc != RSDSFM_OK) return rc;
@@ -223,6 +224,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     // best trial, its dense rho + mask, order-preserving compaction
     if (!final_done) {
         tail_enqueued = false;  // the speculated final stage (and whatever was enqueued behind it) saw incomplete trials
+        spec_final = false;
         rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, h_best);  // h_best: host-mapped, written by the kernels
         if (rc != RSDSFM_OK) return rc;
         rc = ransac_final_launch(c, d_q, d_u, d_a, d_ak, n, d_best, d_states, depth_mode, tol, d_rho, d_mask, d_bcounts, d_boffs,
@@ -250,6 +252,7 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
         if (out->trial_steps) out->trial_steps[t] = depth_mode == RSDSFM_DEPTH_CERES_LM ? h_states[t].num_successful : 1;
     }
     if (spec_tail_held) *spec_tail_held = tail_enqueued;
+    if (depth_mode == RSDSFM_DEPTH_CERES_LM && T > 0) c->ransac_spec_held_hint = spec_final ? 1 : 0;
     return RSDSFM_OK;
 }
 

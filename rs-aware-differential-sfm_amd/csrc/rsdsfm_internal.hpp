@@ -96,6 +96,7 @@ struct Ctx {
     int ransac_fused_base = 2;     // accepted steps after which most hypotheses of the previous solve ended: the iterate round 0 scores
     int ransac_score_hint = 0;     // 1: the previous solve needed the separate scoring pass behind round 0 (it is then enqueued ahead of the host's flag read)
     int refine_iters_hint = -1;    // LM iterations the context's previous refinement took (-1: none yet): length of the first chunk the host enqueues
+    int ransac_spec_held_hint = 0;  // the previous RANSAC's speculated final stage was the one that counted -> the frame solve may enqueue the refinement behind it
     int frame_dense_hint = 1;  // frame solve: the previous frame kept every pixel (dense flow) -> set the RANSAC up for n = rows * cols without waiting for the count
     int lm_issued_d = 0;           // depth_lm_decide_kernel launches issued for the current solve
     // staging buffers for the host-pointer API (grown on demand)

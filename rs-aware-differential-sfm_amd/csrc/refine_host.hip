@@ -114,7 +114,13 @@ int refine_enqueue_chunk(Ctx* c, RefineRun* run) {
     // which saves a host round trip with an idle GPU; if iterations remain it simply runs again after the next chunk
     int rc = refine_finish_launch(c, run->B, run->d_inl_out);
     if (rc != RSDSFM_OK) return rc;
-    if (run->tail) rc = (*run->tail)(run->B);
+    // the tail only pays behind a chunk that can be the last one: where the previous solve needed more iterations than are enqueued so
+    // far (acceleration mode: ~10-13) it is left out, and refine_poll enqueues it should the solve end early after all
+    run->tail_done = false;
+    if (run->tail && !(run->hint_prev > run->launched)) {
+        rc = (*run->tail)(run->B);
+        run->tail_done = true;
+    }
     if (rc != RSDSFM_OK) return rc;
     if (run->prefetch) run->prefetched = true;  // (refine_finish_kernel has written the state to run->hs)
     return rc;
@@ -130,7 +136,15 @@ int refine_poll(Ctx* c, RefineRun* run, double v_out[3], double w_out[3], double
             RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
         }
         if (*h_bad) return fail(c, RSDSFM_ERR_INVALID, "flow index out of range (flow has fewer columns than inliers / bad inlier_idx)");
-        if (hs->termination >= 0) break;
+        if (hs->termination >= 0) {
+            if (run->tail && !run->tail_done) {  // ended earlier than the previous solve: the tail was not behind this chunk
+                int rc = (*run->tail)(run->B);
+                if (rc != RSDSFM_OK) return rc;
+                run->tail_done = true;
+                RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+            }
+            break;
+        }
         if (run->launched > 4 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
         // later chunks: what the previous solve still needed at this point, between 2 and 5 (DeepFlow-like data has 0..1 iterations
         // left after the first chunk -- an empty iteration costs four launches --, acceleration mode runs ~13 in all)

@@ -324,6 +324,7 @@ struct RefineRun {
     // trusts that the CALLER has synchronised the stream since (the frame solve: the RANSAC's own wait) instead of waiting again
     RefineState* hs = nullptr;
     bool prefetch = false, prefetched = false;
+    bool tail_done = false;  // the caller's tail was enqueued behind the last output pass (skipped for chunks that cannot be the last)
 };
 // the last kPinnedTail bytes of the context's pinned block are reserved for the frame solve (refinement state read-back, depth-map header)
 constexpr size_t kPinnedTail = 1024;

@@ -5,7 +5,11 @@ Each case draws a frame size, motion, shutter parameter, noise / outlier level, 
 compares through the C ABI against the CPU oracle: the dense depth solve for a random pose (closed form + LM: depths,
 iteration counts, termination), RANSAC (per-trial counts and accepted LM steps, best trial, mask, index list: bit-exact)
 and the refinement started from the RANSAC result (iteration counts and termination exact, values 1e-6).  Prints one
-line per failing case and a summary; exit code 1 if anything differed."""
+line per failing case and a summary; exit code 1 if anything differed.
+
+Environment: FUZZ_ONLY=4200,7707 re-runs selected case numbers of a campaign (same cases / seed arguments); FUZZ_VERBOSE=1 prints, for
+every refinement whose decisions split from the oracle's, the first LM iteration where the two iteration traces differ and how close
+the deciding quantity sat to its threshold (rsdsfm_set_refine_trace / the oracle's rso_set_refine_trace)."""
 import os
 import sys
 

@@ -39,6 +39,11 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 METRIC = "Mpixels/sec RS depth+pose solve, 1280x720 pair"
 METRIC_DEPTH = "Mpixels/sec RS per-pixel depth solve (pose fixed), 1280x720 pair"
 FP64_VALU_PEAK = 39.3e12        # fp64 lane-instructions / s: 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 4 cycles per wave-instruction
+# DESIGN section 8 scaling model of the column-tiled 3840x2160 whole solve (ms; N = 1 measured in profiles/r02_trace_tiled_full.txt):
+# kernels whose work is per pixel of the slab / replicated stages (minimal9 + single-workgroup decides + pick) / per-collective latency
+# over xGMI for the small rows / the depth-map all-gather: (N - 1) / N x 66 MB at ~45 GB/s per link direction, 7 links in parallel
+TILED_MODEL = {"per_pixel_ms": 5.55, "replicated_ms": 0.55, "collective_latency_ms": 0.02, "collectives": 17,
+               "depth_gather_ms": lambda n: (66.4e6 * (n - 1) / n / min(n - 1, 7)) / 45e9 * 1e3}
 KIND_PORT = "closed-loop port (oracle C restatement; not reference-structured: no per-pixel residual objects / Ceres problem build)"
 
 
@@ -179,12 +184,48 @@ def cpu_baseline_full_all_cores(rsdsfm, np, rank, trials, tol, single, budget_s=
     return best
 
 
-def main():
+def cpu_baseline_reference_structured(rsdsfm, np, rank, trials, tol, budget_s=25.0):
+    """BASELINE.md section 3.1's `cpu_ref`: the oracle's arithmetic in the reference's STRUCTURE -- per estimateInverseDepths call (one per
+    RANSAC trial, nonlinearRefinement.cc:130-163) a problem is built from scratch: one heap-allocated residual object and one parameter
+    block per pixel, an ordering pass over the N blocks, and every residual is evaluated through Jet<double, 8>-style dual numbers (value +
+    8 derivatives) at each LM iteration, as Ceres' AutoDiffCostFunction<RsResidual, 2, 3, 3, 1, 1> does; one thread (Ceres num_threads = 1).
+    Same 1280x720 DeepFlow-like pair; as many of the `trials` trials as fit the budget (stated in the record), scaled to the whole solve."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle_py as O
+
+    if not hasattr(O, "ransac_reference_structured"):
+        return None
+    O.lib()
+    d = rsdsfm.synth.make_config(5, seed=0x5EED0005 + rank)
+    rows, cols = d["rows"], d["cols"]
+    q, u, qpx, fpx = O.flatten(d["flow_img"], *d["K"], d["gamma"])
+    a, ak = O.get_alpha(fpx, rows, d["gamma"]), O.get_alpha_k(qpx, fpx, rows, d["gamma"])
+    samples = O.sample_indices(len(q), trials, 1)
+    # one trial first: it prices the rest
+    t0 = time.perf_counter()
+    O.ransac_reference_structured(q, u, a, ak, False, 1, tol, samples[:1])
+    t1 = time.perf_counter() - t0
+    T = int(max(1, min(trials, (budget_s - t1) // max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    r = O.ransac_reference_structured(q, u, a, ak, False, T, tol, samples[:T])
+    t_ransac = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    O.refine_reference_structured(u, r["inliers"], r["alpha"], r["alpha_k"], r["v"], r["w"], r["k"], False, 0, None)
+    t_refine = time.perf_counter() - t0
+    sec = t_ransac / T * trials + t_refine
+    return {"value": rows * cols / sec / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "port, reference-structured",
+            "seconds_per_solve_extrapolated": sec, "seconds_per_trial": t_ransac / T, "seconds_refinement": t_refine, "trials_timed": T, "trials": trials,
+            "sample": "%d of the %d RANSAC trials (per trial: problem build with one heap residual object + parameter block per pixel, ordering pass, "
+                      "Jet<double,8>-style evaluation of all %d residuals per LM iteration) + the joint refinement built the same way, 1 thread; "
+                      "whole solve = trials x per-trial time + refinement" % (T, trials, len(q))}
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default per workload: 100 whole solves; 160 chunks of 64 pairs for the depth workloads)")
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", default="full", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify", "true_flow", "metrics"])
+    ap.add_argument("--workload", default="full", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify", "true_flow", "metrics", "launch_check"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side-records", action="store_true", help="full workload: skip depth_only / full_solve_batched / full_solve_fused (profiling runs)")
     ap.add_argument("--tiled-driver", default="native", choices=["native", "python"], help="tiled / tiled_full: the C++ driver inside the library (default) or the Python driver")
@@ -196,13 +237,106 @@ def main():
     ap.add_argument("--depth-variant", type=int, default=None, help="rsdsfm_set_depth_variant: 0 register-staged, 1 LDS-DMA, 2 decision fused into launch 0")
     ap.add_argument("--trials", type=int, default=50, help="RANSAC trials of the full solve (report section 5.4 used 50)")
     ap.add_argument("--tol", type=float, default=0.05, help="RANSAC tolerance (reference main.cc:310)")
-    args = ap.parse_args()
-    dsteps = {"depth": 160, "depth_closed_form": 160, "full": 100, "tiled": 2000, "tiled_full": 100, "rectify": 2000, "true_flow": 500, "metrics": 2000}
+    ap.add_argument("--dry-launch", action="store_true", help="print the rank environments / command lines the launcher would start (JSON) and exit; starts nothing, touches no GPU")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="launcher: seconds after which the ranks are ended")
+    ap.add_argument("--launch-grace", type=float, default=10.0, help="launcher: seconds the other ranks get after one rank failed")
+    ap.add_argument("--tiled-timeout", type=float, default=240.0, help="full workload: watchdog of the tiled_full (strong scaling) sub-record; on expiry the line is printed without it")
+    args = ap.parse_args(argv)
+    dsteps = {"depth": 160, "depth_closed_form": 160, "full": 100, "tiled": 2000, "tiled_full": 100, "rectify": 2000, "true_flow": 500, "metrics": 2000, "launch_check": 3}
     if args.steps is None:
         args.steps = dsteps[args.workload]
     if args.warmup is None:
         args.warmup = max(3, args.steps // 25)
+    return args
 
+
+def rank_environments(gpus, port=None, base_env=None):
+    """the environments of the N rank processes the launcher starts (what `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1` would set, minus its agent): rank i on GPU i, rendezvous on 127.0.0.1"""
+    if port is None:
+        import socket
+
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    envs = []
+    for r in range(gpus):
+        e = dict(os.environ if base_env is None else base_env)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(gpus), "LOCAL_WORLD_SIZE": str(gpus), "MASTER_ADDR": "127.0.0.1",
+                  "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": e.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), "RSDSFM_BENCH_CHILD": "1"})
+        envs.append(e)
+    return envs
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` (N > 1) WITHOUT a launcher: this process -- which has not imported torch and never touches a GPU --
+    starts the N ranks as child processes (never an exec), relays rank 0's single JSON line and exits with the worst child exit code.
+    --dry-launch prints what would be started instead."""
+    import subprocess
+
+    envs = rank_environments(args.gpus)
+    child_argv = [a for a in argv if a != "--dry-launch"]
+    cmd = [sys.executable, os.path.abspath(__file__)] + child_argv
+    if args.dry_launch:
+        keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")
+        print(json.dumps({"dry_launch": True, "n_ranks": args.gpus, "cmd": cmd, "ranks": [{k2: e[k2] for k2 in keys} for e in envs],
+                          "backend": os.environ.get("RSDSFM_DIST_BACKEND", "nccl"),
+                          "equivalent": "python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 --master-port %s bench.py %s"
+                                        % (args.gpus, envs[0]["MASTER_PORT"], " ".join(child_argv))}), flush=True)
+        return 0
+    procs = []
+    for r, e in enumerate(envs):  # rank 0's stdout carries the line; the other ranks' output goes to this process' stderr
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    import threading
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.extend(procs[0].stdout.read().decode(errors="replace").splitlines()), daemon=True)
+    reader.start()
+    deadline = time.time() + args.launch_timeout
+    codes = [None] * len(procs)
+    failed_at = None
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+                if codes[i] not in (None, 0) and failed_at is None:
+                    failed_at = time.time()
+        now = time.time()
+        # one rank died (the others would wait in a collective for ever) or the time is up: end exactly the processes started here
+        if (failed_at is not None and now - failed_at > args.launch_grace) or now > deadline:
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.kill()
+                    codes[i] = p.wait()
+                    codes[i] = codes[i] if codes[i] != 0 else 1
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10.0)
+    line = None
+    for ln in out0:
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    worst = max((abs(c) for c in codes), default=0)
+    if line is not None:
+        print(line, flush=True)
+    elif worst == 0:
+        worst = 1
+    return worst
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    # a launched rank has WORLD_SIZE == --gpus in its environment (torch.distributed.run or launch_ranks above); anything else with
+    # --gpus N > 1 is the bare command line, which must become N ranks itself -- before torch is imported or a GPU is touched
+    if args.dry_launch or (args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1):
+        raise SystemExit(launch_ranks(args, argv))
+    run(args)
+
+
+def run(args):
     import numpy as np
     import torch  # first: one HIP runtime per process (torch's), shared with librsdsfm_hip.so
     import torch.distributed as dist
@@ -210,8 +344,34 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.workload == "launch_check":
+        # the launcher and the timing protocol without a GPU (tests/test_bench_launch.py, world_size 2 over gloo): rendezvous,
+        # barrier-bracketed timed region, MAX over ranks, one JSON line from rank 0; RSDSFM_LAUNCH_CHECK_FAIL_RANK makes one rank die
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ.get("RSDSFM_LAUNCH_CHECK_FAIL_RANK") == str(rank):
+            raise SystemExit(3)
+        seen = [rank]
+        el = 0.0
+        if world > 1:
+            dist.init_process_group(os.environ.get("RSDSFM_DIST_BACKEND", "gloo"), rank=rank, world_size=world)
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                time.sleep(0.01 * (rank + 1))
+            dist.barrier()
+            tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+            got = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(got, torch.tensor([rank], dtype=torch.int64))
+            seen = [int(g.item()) for g in got]
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "launch_check", "value": el, "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ranks_seen": seen, "local_rank_of_rank0": local_rank, "master": "%s:%s" % (os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"))}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
     if os.environ.get("RSDSFM_SHARE_GPU"):  # smoke test only: several ranks on one device
@@ -460,25 +620,46 @@ def main():
         full = _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps=args.steps, warmup=args.warmup, timed=timed)
         roof = _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full) if rank == 0 else None
         side = not args.no_side_records
-        batched = _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, 8, per_thread=25) if side else None
-        fused = None
-        if side and args.arith == "reference" and rank == 0:
-            with rsdsfm.Solver(local_rank, stream=stream.cuda_stream, arith="fused") as sf:
-                fr = _full_solve(rsdsfm, sf, torch, dev, np, rank, args, steps=max(20, args.steps // 2), warmup=3, timed=lambda st, k2, w2: _plain_timed(torch, st, k2, w2))
-            fused = {k2: fr[k2] for k2 in ("value", "unit", "ms_per_solve", "median_ms_per_solve", "num_inliers")}
-            fused["note"] = "same workload on the opt-in librsdsfm_hip_fused.so (explicit fmas in the per-pixel model); not the headline"
-        depth_only = run_depth("depth", 40, 3, side_records=False) if side else None
+        # sequence-throughput mode (BASELINE configs[4]): 32 pairs with 32 data seeds through ONE context of each GPU
+        batched = _full_solve_sequence(rsdsfm, solver, torch, dev, np, rank, args) if side else None
+        fused = depth_only = regimes = None
+        if side and world == 1:  # single-GPU side records (a multi-rank run keeps to what scales: replicas + the tiled frame)
+            if args.arith == "reference":
+                with rsdsfm.Solver(local_rank, stream=stream.cuda_stream, arith="fused") as sf:
+                    fr = _full_solve(rsdsfm, sf, torch, dev, np, rank, args, steps=max(20, args.steps // 2), warmup=3, timed=lambda st, k2, w2: _plain_timed(torch, st, k2, w2))
+                fused = {k2: fr[k2] for k2 in ("value", "unit", "ms_per_solve", "median_ms_per_solve", "num_inliers")}
+                fused["note"] = "same workload on the opt-in librsdsfm_hip_fused.so (explicit fmas in the per-pixel model); not the headline"
+            regimes = _full_solve_regimes(rsdsfm, solver, torch, dev, np, rank, args)
+            depth_only = run_depth("depth", 40, 3, side_records=False)
         if rank == 0:
             line.update({"value": full["value"] * world, "ms_per_step": full["ms_per_solve"], "median_ms_per_solve": full["median_ms_per_solve"], "scaling": "weak",
                          "config": {"workload": "BASELINE metric: WHOLE depth+pose solve of a synthetic 1280x720 DeepFlow-like pair (BASELINE configs[4] data: 0.3 px noise, "
                                                 "10 %% outliers): flatten + alpha, RANSAC(%d trials, tol %g) = 9-point minimal solver + Ceres-LM depth solve of all pixels per "
                                                 "trial + scoring, joint nonlinear refinement, sign fix + depth map, pose table; ONE C-ABI call per pair, one pair at a time, "
-                                                "one pair per GPU" % (args.trials, args.tol),
+                                                "one pair per GPU (N ranks = N independent replicas, no data-path collective)" % (args.trials, args.tol),
                                     **{k2: full[k2] for k2 in ("rows", "cols", "trials", "tol", "n", "num_inliers", "refine_summary", "w_err", "v_angle_deg")}},
-                         "roofline": roof, "full_solve_batched": batched, "full_solve_fused": fused, "depth_only": depth_only,
+                         "roofline": roof, "full_solve_batched": batched, "full_solve_fused": fused, "regimes": regimes, "depth_only": depth_only,
                          "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_full(rsdsfm, np, rank, args.trials, args.tol)})
             if line["cpu_baseline"] and side:  # the single-thread figure "plus an all-cores variant"
                 line["cpu_baseline"]["all_cores"] = cpu_baseline_full_all_cores(rsdsfm, np, rank, args.trials, args.tol, line["cpu_baseline"])
+            if line["cpu_baseline"] and side:  # the reference-STRUCTURED single-thread variant
+                line["cpu_baseline"]["reference_structured"] = cpu_baseline_reference_structured(rsdsfm, np, rank, args.trials, args.tol)
+        # LAST: the strong-scaling sub-record (north_star: one 3840x2160 frame in N column slabs over the native RCCL driver).  Multi-rank
+        # RCCL inside the library cannot be exercised on the 1-GPU development boxes, so the section runs under a watchdog: if it
+        # does not come back, rank 0 prints the line it has (tiled_full = the error) and every rank leaves.
+        if side:
+            line["tiled_full"] = None
+            emitted = _watchdog(args.tiled_timeout, rank, line, "tiled_full")
+            try:
+                barrier()
+                rec = _tiled_full_record(rsdsfm, solver, torch, dist, dev, np, world, rank, args, max(20, args.steps // 2), 3, timed)
+                if rank == 0:
+                    rec.update(_tiled_scaling_model(rec, world))
+                    line["tiled_full"] = rec
+            except Exception as e:  # a failure here must not take the headline with it
+                line["tiled_full"] = {"error": repr(e)[:300]}
+            finally:
+                emitted.cancel()
 
     # =================================================================================================
     elif args.workload == "rectify":
@@ -649,45 +830,10 @@ def main():
 
     # =================================================================================================
     elif args.workload == "tiled_full":
-        # one 3840x2160 DeepFlow-like frame split into column slabs over the ranks: the WHOLE solve (flatten, RANSAC, refinement,
-        # sign fix + depth map) by ONE C-ABI call per rank (rsdsfm_solve_frame_tiled_dev: the C++ driver issues the stage kernels and
-        # the RCCL collectives on the context's stream); every rank holds only its slab.  --tiled-driver python = the round-1
-        # Python driver over the rsdsfm_tile_* stage entry points (dist.TiledFrameSolve), for comparison.
-        data = rsdsfm.synth.make_config(4, seed=0x5EED0004)
-        rows, cols = data["rows"], data["cols"]
-        c0, sc, per = rsdsfm.tiled_slab_bounds(cols, world, rank)
-        slab = torch.from_numpy(np.ascontiguousarray(data["flow_img"][:, c0:c0 + sc, :])).to(dev)
-        depth_map = torch.empty(rows * cols, dtype=torch.float64, device=dev)
-        res = {}
-        native = args.tiled_driver == "native"
-        transport = "python driver + torch.distributed"
-        if native:
-            transport = _dist_setup(solver, rsdsfm, torch, dist, world, rank, dev)
-
-            def step(i):
-                res["r"] = solver.solve_frame_tiled_dev(slab.data_ptr(), rows, cols, data["K"], data["gamma"], depth_map.data_ptr(),
-                                                        trials=args.trials, tol=args.tol, seed=1 + i)
-        else:
-            def step(i):
-                shard = rsdsfm.dist.HipFrameShard(solver, slab, c0, data["K"], data["gamma"], torch)  # flatten is part of the solve
-                drv = rsdsfm.dist.TiledFrameSolve([shard], rows, cols, per, torch, dist if world > 1 else None)
-                res["r"] = drv.solve(trials=args.trials, tol=args.tol, seed=1 + i)
-
-        el = timed(step, args.steps, args.warmup)
+        rec = _tiled_full_record(rsdsfm, solver, torch, dist, dev, np, world, rank, args, args.steps, args.warmup, timed)
         if rank == 0:
-            r = res["r"]
-            t = data["truth"]
-            line.update({"value": rows * cols * args.steps / el / 1e6, "ms_per_step": el / args.steps * 1e3, "scaling": "strong",
-                         "metric": "Mpixels/sec RS whole solve, 3840x2160 frame column-tiled over the ranks",
-                         "config": {"workload": "BASELINE configs[3]: synthetic 3840x2160 DeepFlow-like frame, column slabs over %d rank(s): flatten + RANSAC(%d, tol %g) "
-                                                "+ refinement + depth map; all-gathers of the stage sum rows + ONE all-gather of the depth slabs"
-                                                % (world, args.trials, args.tol),
-                                    "driver": "native C++ (rsdsfm_solve_frame_tiled_dev)" if native else "python (dist.TiledFrameSolve)", "transport": transport,
-                                    "rows": rows, "cols": cols, "n": r["n"], "num_inliers": r["num_inliers"], "info": r.get("info"),
-                                    "refine_summary": r["refine_summary"], "w_err": float(np.linalg.norm(r["w"] - t["w"]))},
-                         "roofline": None, "cpu_baseline": None})
-        if native:
-            solver.dist_finalize()
+            line.update({"value": rec["value"], "ms_per_step": rec["ms_per_solve"], "scaling": "strong", "metric": rec.pop("metric"),
+                         "config": rec.pop("config"), "roofline": None, "cpu_baseline": None, "tiled_full": rec})
 
     # =================================================================================================
     else:  # tiled
@@ -744,6 +890,98 @@ def main():
     solver.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def _watchdog(seconds, rank, line, key):
+    """threading.Timer that ends the process if a section hangs: rank 0 first prints the JSON line it has, with line[key] = the error"""
+    import threading
+
+    def fire():
+        if rank == 0:
+            line[key] = {"error": "no result within %.0f s (watchdog)" % seconds}
+            print(json.dumps(line), flush=True)
+        os._exit(0 if rank == 0 else 3)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def _tiled_scaling_model(rec, world):
+    """DESIGN section 8's model of the column-tiled 3840x2160 solve on N ranks, printed next to the measurement so that a SCALE
+    run can be judged against it: per-slab kernels shrink with 1/N, the minimal solver and the single-workgroup decide stages are
+    replicated, every collective costs a latency (small rows) or bytes / link bandwidth (the depth-map all-gather)"""
+    n1 = None
+    try:
+        n1 = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_full.json")))["tiled_full"]["ms_per_solve"]
+    except Exception:
+        pass
+    m = TILED_MODEL
+    coll = rec.get("collectives") or m["collectives"]
+    pred = m["per_pixel_ms"] / world + m["replicated_ms"] + (0.0 if world == 1 else coll * m["collective_latency_ms"] + m["depth_gather_ms"](world))
+    out = {"model": {"predicted_ms_per_solve": pred, "per_pixel_ms_at_n1": m["per_pixel_ms"], "replicated_ms": m["replicated_ms"],
+                     "collective_latency_ms": m["collective_latency_ms"], "collectives": coll, "depth_gather_ms": 0.0 if world == 1 else m["depth_gather_ms"](world),
+                     "formula": "per_pixel / N + replicated + collectives x latency + depth all-gather (DESIGN section 8)"},
+           "n1_reference_ms_per_solve": n1}
+    if n1:
+        out["speedup_vs_committed_n1"] = n1 / rec["ms_per_solve"]
+    return out
+
+
+def _tiled_full_record(rsdsfm, solver, torch, dist, dev, np, world, rank, args, steps, warmup, timed):
+    """BASELINE configs[3] / north_star "large frames tile across the GPUs": ONE 3840x2160 DeepFlow-like frame split into column slabs
+    over the ranks, the WHOLE solve (flatten, RANSAC, refinement, sign fix + depth map) by ONE C-ABI call per rank
+    (rsdsfm_solve_frame_tiled_dev: the C++ driver issues the stage kernels and the RCCL collectives on the context's stream); every
+    rank holds only its slab.  Strong scaling: the frame is fixed, the slabs shrink with N.  --tiled-driver python = the Python driver
+    over the rsdsfm_tile_* stage entry points (dist.TiledFrameSolve), for comparison."""
+    data = rsdsfm.synth.make_config(4, seed=0x5EED0004)  # every rank generates the same frame and keeps its slab
+    rows, cols = data["rows"], data["cols"]
+    c0, sc, per = rsdsfm.tiled_slab_bounds(cols, world, rank)
+    slab = torch.from_numpy(np.ascontiguousarray(data["flow_img"][:, c0:c0 + sc, :])).to(dev)
+    depth_map = torch.empty(rows * cols, dtype=torch.float64, device=dev)
+    res = {}
+    native = args.tiled_driver == "native"
+    transport = "python driver + torch.distributed"
+    if native:
+        transport = _dist_setup(solver, rsdsfm, torch, dist, world, rank, dev)
+
+        def step(i):
+            res["r"] = solver.solve_frame_tiled_dev(slab.data_ptr(), rows, cols, data["K"], data["gamma"], depth_map.data_ptr(),
+                                                    trials=args.trials, tol=args.tol, seed=1 + i)
+    else:
+        def step(i):
+            shard = rsdsfm.dist.HipFrameShard(solver, slab, c0, data["K"], data["gamma"], torch)  # flatten is part of the solve
+            drv = rsdsfm.dist.TiledFrameSolve([shard], rows, cols, per, torch, dist if world > 1 else None)
+            res["r"] = drv.solve(trials=args.trials, tol=args.tol, seed=1 + i)
+
+    per_step = []
+
+    def tstep(i):
+        t0 = time.perf_counter()
+        step(i)
+        per_step.append(time.perf_counter() - t0)
+
+    el = timed(tstep, steps, warmup)
+    rec = None
+    if rank == 0:
+        r = res["r"]
+        t = data["truth"]
+        ts = sorted(per_step[-steps:])
+        info = r.get("info") or {}
+        rec = {"metric": "Mpixels/sec RS whole solve, 3840x2160 frame column-tiled over the ranks", "scaling": "strong", "n_ranks": world,
+               "value": rows * cols * steps / el / 1e6, "unit": "Mpixels/s", "ms_per_solve": el / steps * 1e3, "median_ms_per_solve": ts[len(ts) // 2] * 1e3,
+               "steps": steps, "rccl_ranks": info.get("nranks"), "collectives": info.get("collectives"), "host_syncs": info.get("host_syncs"),
+               "config": {"workload": "BASELINE configs[3]: synthetic 3840x2160 DeepFlow-like frame, column slabs over %d rank(s): flatten + RANSAC(%d, tol %g) "
+                                      "+ refinement + depth map; all-gathers of the stage sum rows + ONE all-gather of the depth slabs"
+                                      % (world, args.trials, args.tol),
+                          "driver": "native C++ (rsdsfm_solve_frame_tiled_dev)" if native else "python (dist.TiledFrameSolve)", "transport": transport,
+                          "rows": rows, "cols": cols, "n": r["n"], "num_inliers": r["num_inliers"], "info": r.get("info"),
+                          "flow_index_mode": r.get("flow_index_mode"),
+                          "refine_summary": r["refine_summary"], "w_err": float(np.linalg.norm(r["w"] - t["w"]))}}
+    if native:
+        solver.dist_finalize()
+    return rec
 
 
 def _dist_setup(solver, rsdsfm, torch, dist, world, rank, dev):
@@ -854,6 +1092,39 @@ def _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps, warmup, timed
             "stages": "flatten+alpha, minimal9 x %d, RANSAC LM sums/decide/score/pick/compaction, refinement, depth map, pose table" % args.trials}
 
 
+def _full_solve_regimes(rsdsfm, solver, torch, dev, np, rank, args, solves=24):
+    """The headline exercises ONE regime (tol 0.05 keeps every pixel an inlier).  The same one-call solve, driver-timed, on the other
+    regimes the reference's own constants and modes give: each = `solves` whole solves after 3 warm-ups on the bench's context, one at
+    a time, sampler seed changing per solve; median of the per-solve host times (the call returns after its last result reached the host)."""
+    out = {}
+    d5 = rsdsfm.synth.make_config(5, seed=0x5EED0005 + rank)
+    d2 = rsdsfm.synth.make_config(2, seed=0x5EED0002 + rank)
+    d3 = rsdsfm.synth.make_config(3, seed=0x5EED0003 + rank)
+    cases = [("trials_5", d5, dict(trials=5, tol=args.tol), "main.cc:304's default trial count, T = 5"),
+             ("selective_tol_0.002", d5, dict(trials=args.trials, tol=0.002), "selective tolerance 0.002: the +-30 px outliers are rejected (M < N), compaction and the rank-indexed flow of main.cc:457 are not the identity"),
+             ("noise_free", d2, dict(trials=args.trials, tol=args.tol), "noise-free model flow (ground-truth flow of a synthetic example): every hypothesis takes three accepted LM steps"),
+             ("acceleration_mode", d5, dict(trials=args.trials, tol=args.tol, use_acceleration_mode=True), "use_acceleration_mode (main.cc:306): k estimated by the minimal solver (6x6 eigenvalues) and refined (7x7 Schur complement)"),
+             ("configs2_1920x1080", d3, dict(trials=args.trials, tol=args.tol), "BASELINE configs[2]: 1920x1080 DeepFlow-like pair, full RANSAC + depth + refinement")]
+    for name, d, kw, note in cases:
+        rows, cols = d["rows"], d["cols"]
+        img = torch.from_numpy(d["flow_img"]).to(dev)
+        dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+        R, tt = torch.empty((rows, 9), dtype=torch.float64, device=dev), torch.empty((rows, 3), dtype=torch.float64, device=dev)
+        call = solver.prepared_frame_solve(img.data_ptr(), rows, cols, d["K"], d["gamma"], dm.data_ptr(), R.data_ptr(), tt.data_ptr(), **kw)
+        ts = []
+        for i in range(3 + solves):
+            t0 = time.perf_counter()
+            r = call(1 + i)
+            ts.append(time.perf_counter() - t0)
+        ts = sorted(ts[3:])
+        med = ts[len(ts) // 2]
+        out[name] = {"median_ms_per_solve": med * 1e3, "min_ms_per_solve": ts[0] * 1e3, "value": rows * cols / med / 1e6, "unit": "Mpixels/s", "solves": solves,
+                     "rows": rows, "cols": cols, "trials": kw["trials"], "tol": kw["tol"], "n": int(r.n_points), "num_inliers": int(r.num_inliers),
+                     "refine_iterations": int(r.refine_summary.num_iterations), "note": note}
+        del img, dm
+    return out
+
+
 def _counters(kernel):
     """per-launch PMC counter means of `kernel` from profiles/counters.json (rocprofv3 --pmc passes of `bench.py`, see
     profiles/collect.sh); None when absent"""
@@ -908,6 +1179,16 @@ def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):
                     "alg_bytes_per_solve": hbm_bytes, "formula": "57 N + 64 M iterations (SURVEY 8 d), N = %d, M = %d, iterations = %d, over the median solve time" % (full["n"], full["num_inliers"], iters)},
             "note": "the whole solve is bound by fp64 VALU issue and by serial latency chains (9x9 Jacobi SVD), not by HBM: its HBM fraction is reported "
                     "because the metric asks for it; counters: profiles/counters.json (rocprofv3 --pmc of this command)"}
+
+
+def _full_solve_sequence(rsdsfm, solver, torch, dev, np, rank, args):
+    return _full_solve_batched(rsdsfm, torch, dev, solver_device(solver), rank, args, 8, per_thread=25)
+
+
+def solver_device(solver):
+    import torch
+
+    return torch.cuda.current_device()
 
 
 def _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, S, per_thread):

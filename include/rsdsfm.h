@@ -359,7 +359,10 @@ int rsdsfm_tile_ransac_final_dev(rsdsfm_ctx* ctx, const double* d_q2n, const dou
                                  double* d_inliers3m, double* d_out_alpha, double* d_out_alpha_k, rsdsfm_ransac_out* out);
 int64_t rsdsfm_tile_ransac_global_inliers(rsdsfm_ctx* ctx, const void* d_best); /* synchronises; -1 on error */
 /* joint refinement on the shard's inliers.  begin opens a session on the context (flow = the shard's flattened u,
- * inlier_idx shard-local: RSDSFM_FLOW_GATHERED only); stage 0 = iteration-zero sums, then per LM iteration stage 1
+ * inlier_idx shard-local with RSDSFM_FLOW_GATHERED; with RSDSFM_FLOW_COMPAT_RANK -- the reference's rank-indexed flow,
+ * main.cc:457 -> nonlinearRefinement.cc:209-212 -- d_flow holds the columns of the GLOBAL flow list at this shard's global
+ * inlier ranks, one per inlier, fetched by the caller from the shards in front of it; d_inlier_idx may then be NULL);
+ * stage 0 = iteration-zero sums, then per LM iteration stage 1
  * (Schur sums -> reduced solve) and stage 2 (back-substitution sums -> accept / reject / converge):
  *   rows_dev(stage) -> all-gather -> apply_dev(stage) on every rank;  poll (synchronises) reads the state machine
  * (summary->termination == -1 while running); finish writes (x, y, 1/rho) and closes the session. */
@@ -414,7 +417,10 @@ typedef struct rsdsfm_tiled_info {
 } rsdsfm_tiled_info;
 
 /* d_img_slab: row-major [rows][slab_cols][2] slab of this rank (DEVICE); cols = width of the WHOLE image.  params->
- * flow_index_mode must be RSDSFM_FLOW_GATHERED.  d_depth_map: rows x cols column-major (DEVICE), the full map on every rank.
+ * flow_index_mode as in rsdsfm_solve_frame_dev: 0 = RSDSFM_FLOW_COMPAT_RANK, the reference's default (the i-th inlier of the GLOBAL
+ * inlier list reads column i of the GLOBAL flow list, main.cc:457 -> nonlinearRefinement.cc:209-212: the columns a rank needs sit on
+ * the slabs in front of it and are exchanged inside the call -- one all-gather of the heads of the slabs' flow lists, skipped when
+ * every needed column is local), 1 = RSDSFM_FLOW_GATHERED.  d_depth_map: rows x cols column-major (DEVICE), the full map on every rank.
  * result: n_points / num_inliers are GLOBAL counts; d_inliers / d_inlier_idx / d_scanline describe this rank's slab (info->
  * shard_inliers entries, indices local to the slab's point list).  Without a communicator (no rsdsfm_dist_* call) the context
  * is a single rank.  info may be NULL. */

@@ -240,7 +240,8 @@ class Solver:
         return ms.value
 
     def set_ransac_speculation(self, k0):
-        """LM iterations speculated by round 0 of RANSAC's batched depth solves: 3 (default; 0 selects it) or 2"""
+        """LM iterations speculated by round 0 of RANSAC's batched depth solves: 0 (default) = automatic, follows the context's previous
+        solve (2 when none of its hypotheses went beyond one accepted step, else 3); 2 or 3 = fixed.  Scheduling only: never a result."""
         self._check(self.lib.rsdsfm_set_ransac_speculation(self._ctx, int(k0)), "rsdsfm_set_ransac_speculation")
 
     def synchronize(self):
@@ -449,11 +450,13 @@ class Solver:
 
     def solve_frame_tiled_dev(self, d_img_slab, rows, cols, K, gamma, d_depth_map, d_R=None, d_t=None, trials=50, tol=0.05, seed=1,
                               use_acceleration_mode=False, use_refinement=True, depth_mode=DEPTH_CERES_LM, k_sign_mode=K_COMPAT,
-                              flow_threshold=1e-10, use_global_shutter_mode=False):
+                              flow_threshold=1e-10, use_global_shutter_mode=False, flow_index_mode=FLOW_COMPAT_RANK):
         """this rank's part of the column-tiled whole solve (rsdsfm_solve_frame_tiled_dev): d_img_slab = this rank's [rows][slab_cols][2]
-        slab, cols = width of the whole image; returns the dict of solve_frame_dev (global counts) plus the slab's info"""
+        slab, cols = width of the whole image; returns the dict of solve_frame_dev (global counts) plus the slab's info.  Defaults as
+        solve_frame_dev: the refinement reads the flow by GLOBAL inlier rank (quirk Q2, main.cc:457) -- the columns a rank needs from
+        the slabs in front of it are exchanged inside the call; FLOW_GATHERED = the flow of each inlier's own pixel."""
         prm = FrameParams(int(trials), int(use_acceleration_mode), int(use_refinement), int(depth_mode), int(k_sign_mode),
-                          FLOW_GATHERED, int(use_global_shutter_mode), 0, float(tol), float(flow_threshold), int(seed))
+                          int(flow_index_mode), int(use_global_shutter_mode), 0, float(tol), float(flow_threshold), int(seed))
         res, info = FrameResult(), TiledInfo()
         d = C.c_double
         self._check(self.lib.rsdsfm_solve_frame_tiled_dev(self._ctx, _dp(d_img_slab) if d_img_slab else None, C.c_int32(rows), C.c_int32(cols), d(K[0]), d(K[1]),
@@ -462,7 +465,7 @@ class Solver:
         return dict(n=int(res.n_points), num_inliers=int(res.num_inliers), best_trial=int(res.best_trial), flipped=bool(res.flipped),
                     ransac_w=np.array(res.ransac_w[:]), ransac_v=np.array(res.ransac_v[:]), ransac_k=float(res.ransac_k),
                     w=np.array(res.w[:]), v=np.array(res.v[:]), k=float(res.k), refine_summary=res.refine_summary.as_dict(),
-                    d_inliers=res.d_inliers, d_inlier_idx=res.d_inlier_idx, d_scanline=res.d_scanline,
+                    d_inliers=res.d_inliers, d_inlier_idx=res.d_inlier_idx, d_scanline=res.d_scanline, flow_index_mode=int(flow_index_mode),
                     info={k2: int(getattr(info, k2)) for k2, _ in TiledInfo._fields_ if k2 != "_pad"})
 
     def estimate_inverse_depths_tiled_dev(self, d_q_shard, d_u_shard, n_total, v, w, k, d_alpha_shard, d_alpha_k_shard, d_inv_depth,

@@ -108,6 +108,8 @@ struct Dist {
     size_t bytes = 0;
     void* d_session = nullptr;  // refinement session buffers
     size_t session_bytes = 0;
+    void* d_flow = nullptr;  // rank-indexed flow (quirk Q2): the gathered heads of the slabs' flow lists + this rank's columns
+    size_t flow_bytes = 0;
     int host_syncs = 0, collectives = 0, ransac_rounds = 0;  // diagnostics of the last solve
 };
 
@@ -202,6 +204,25 @@ __global__ __launch_bounds__(256) void pack_samples_kernel(const double2* __rest
     ak9[j] = ak;
 }
 
+// Rank-indexed flow (quirk Q2, main.cc:457 -> nonlinearRefinement.cc:209-212): the i-th inlier of the GLOBAL inlier list reads column
+// i of the GLOBAL, un-compacted flow list.  This rank's inliers hold the global ranks [prefix, prefix + m); column g of the global
+// list is column g - offset_r of the slab r with offset_r <= g < offset_r + cnt_r.  `heads` holds the first `lmax` columns of every
+// slab's flow list in rank order (only columns below the global inlier count are ever addressed: the ranks stop there).
+__global__ __launch_bounds__(256) void rank_flow_gather_kernel(const double2* __restrict__ heads, int64_t lmax, const int64_t* __restrict__ cnt_all,
+                                                              int nranks, int64_t prefix, int64_t m, double2* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const int64_t g = prefix + i;
+    int64_t off = 0;
+    int r = 0;
+    for (; r < nranks - 1; ++r) {
+        const int64_t cnt = cnt_all[r];
+        if (g < off + cnt) break;
+        off += cnt;
+    }
+    out[i] = heads[(int64_t)r * lmax + (g - off)];
+}
+
 }  // namespace
 
 namespace rsdsfm {
@@ -211,6 +232,7 @@ void dist_release(Ctx* c) {
     if (D->comm && D->own_comm && rccl()->CommDestroy) (void)rccl()->CommDestroy(D->comm);
     if (D->d_buf) (void)hipFree(D->d_buf);
     if (D->d_session) (void)hipFree(D->d_session);
+    if (D->d_flow) (void)hipFree(D->d_flow);
     delete D;
     c->dist = nullptr;
 }
@@ -316,8 +338,7 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
     Ctx* c = &ctx->c;
     DeviceGuard device_guard_(c);
     if (!prm || !res || rows <= 0 || cols <= 0 || !d_depth_map) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
-    if (prm->flow_index_mode != RSDSFM_FLOW_GATHERED)
-        return fail(c, RSDSFM_ERR_INVALID, "the tiled solve needs flow_index_mode = RSDSFM_FLOW_GATHERED (a rank-indexed flow, quirk Q2, would live on another rank's slab)");
+    if (prm->flow_index_mode != RSDSFM_FLOW_COMPAT_RANK && prm->flow_index_mode != RSDSFM_FLOW_GATHERED) return fail(c, RSDSFM_ERR_INVALID, "unknown flow_index_mode");
     const int depth_mode = prm->depth_mode;
     if (depth_mode != RSDSFM_DEPTH_CLOSED_FORM && depth_mode != RSDSFM_DEPTH_CERES_LM) return fail(c, RSDSFM_ERR_INVALID, "unknown depth_mode");
     const int T = prm->ransac_trials;
@@ -547,6 +568,47 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
         B.alpha_k = d_in_ak;
         B.inlier_idx = d_idx;
         B.flow_index_mode = RSDSFM_FLOW_GATHERED;
+        if (prm->flow_index_mode == RSDSFM_FLOW_COMPAT_RANK) {
+            // The reference's default (quirk Q2): inlier i of the global list reads flow column i of the global list.  This rank's
+            // inliers are the global ranks [prefix, prefix + m), and since a slab never holds more inliers than points those
+            // columns live on slabs <= rank.  Every rank knows every count, so all ranks agree on what is exchanged: the heads of
+            // the slabs' flow lists up to the global inlier count (nothing at all when every needed column is local -- e.g. every
+            // pixel an inlier), all-gathered in rank order; then each rank picks its m columns.
+            int64_t prefix = 0, lmax = 0;
+            bool remote = false;
+            int64_t pm = 0, po = 0;  // inliers / points in front of slab r
+            for (int r = 0; r < R; ++r) {
+                if (h_m[r] > 0 && pm != po) remote = true;
+                lmax = std::max(lmax, std::min<int64_t>(h_cnt[r], std::max<int64_t>(m_total - po, 0)));
+                if (r == rank) prefix = pm;
+                pm += h_m[r];
+                po += h_cnt[r];
+            }
+            if (remote) {
+                const size_t L = (size_t)std::max<int64_t>(lmax, 1);
+                rc = ensure_dev(c, &D->d_flow, &D->flow_bytes, Arena::need(16 * L * R) + Arena::need(16 * M) + 1024);
+                if (rc != RSDSFM_OK) return rc;
+                Arena fl(D->d_flow);
+                double* d_heads = fl.take<double>(2 * L * R);
+                double* d_flow_rank = fl.take<double>(2 * M);
+                const int64_t mine = std::min<int64_t>(n, std::max<int64_t>(m_total - offset, 0));  // columns of this slab the ranks can reach
+                if (mine > 0)
+                    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_heads + 2 * L * (size_t)rank, d_u, 16 * (size_t)mine, hipMemcpyDeviceToDevice, c->stream));
+                rc = all_gather(c, D, d_heads + 2 * L * (size_t)rank, d_heads, 16 * L);
+                if (rc != RSDSFM_OK) return rc;
+                if (m > 0) {
+                    hipLaunchKernelGGL(rank_flow_gather_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
+                                       reinterpret_cast<const double2*>(d_heads), (int64_t)L, d_cnt_all, R, prefix, m,
+                                       reinterpret_cast<double2*>(d_flow_rank));
+                    RSDSFM_HIP_CHECK(c, hipGetLastError());
+                }
+                B.flow = d_flow_rank;
+                B.n_flow = m;
+            }
+            // (no remote column: prefix == offset for every slab with inliers, so the global column of local inlier i is local column i)
+            B.flow_index_mode = RSDSFM_FLOW_COMPAT_RANK;
+            B.inlier_idx = nullptr;
+        }
         char* state_block = sa.take<char>(sizeof(RefineState) + 64);
         B.state = reinterpret_cast<RefineState*>(state_block);
         B.bad_index = reinterpret_cast<int*>(state_block + sizeof(RefineState));

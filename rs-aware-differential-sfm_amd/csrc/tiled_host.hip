@@ -173,8 +173,13 @@ int rsdsfm_tile_refine_begin_dev(rsdsfm_ctx* ctx, const double* d_flow, int64_t 
     Ctx* c = &ctx->c;
     DeviceGuard device_guard_(c);
     if (m < 0 || n_flow < 0 || !v_in || !w_in) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
-    if (flow_index_mode != RSDSFM_FLOW_GATHERED) return fail(c, RSDSFM_ERR_INVALID, "the row-tiled refinement needs RSDSFM_FLOW_GATHERED (shard-local inlier indices)");
-    if (m > 0 && (!d_flow || !d_inl || !d_alpha || !d_alpha_k || !d_inlier_idx)) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
+    // RSDSFM_FLOW_GATHERED: d_flow = the shard's flow list, column d_inlier_idx[i] (shard-local) belongs to inlier i.
+    // RSDSFM_FLOW_COMPAT_RANK (the reference's rank-indexed flow, quirk Q2): the CALLER has fetched the columns of the GLOBAL flow list
+    // at this shard's global inlier ranks [prefix, prefix + m) -- they live on the shards in front of it -- and d_flow holds them:
+    // column i belongs to inlier i, n_flow >= m (dist.TiledFrameSolve does that exchange; the native driver does it itself).
+    if (flow_index_mode != RSDSFM_FLOW_GATHERED && flow_index_mode != RSDSFM_FLOW_COMPAT_RANK) return fail(c, RSDSFM_ERR_INVALID, "unknown flow_index_mode");
+    if (flow_index_mode == RSDSFM_FLOW_COMPAT_RANK && n_flow < m) return fail(c, RSDSFM_ERR_INVALID, "rank-indexed flow: d_flow must hold one column per inlier of the shard");
+    if (m > 0 && (!d_flow || !d_inl || !d_alpha || !d_alpha_k || (flow_index_mode == RSDSFM_FLOW_GATHERED && !d_inlier_idx))) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
     const int np = const_acceleration ? 7 : 6;
     const size_t M = (size_t)std::max<int64_t>(m, 1);
     const size_t npart = (size_t)refine_partials_doubles(c, m);

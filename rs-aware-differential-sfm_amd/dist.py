@@ -212,6 +212,7 @@ class TiledFrameSolve:
         offs_all = np.concatenate([[0], np.cumsum(counts)])
         self.offsets = [int(offs_all[first + i]) for i in range(L)]
         self.n_total = n_total
+        self.counts_all, self.first_shard = counts.astype(np.int64), first
         if n_total < 9:
             raise ValueError("ransac needs at least 9 points (the reference would compute rand() % 0)")
         if samples is None:
@@ -292,11 +293,47 @@ class TiledFrameSolve:
             sh.s.tile_refine_apply_dev(stage, rows_all.data_ptr(), int(rows_all.shape[0]), self.m_total)
         return rows_all
 
-    def _refine(self, v, w, k, const_acceleration):
+    def rank_indexed_flow(self):
+        """The reference's default flow indexing (quirk Q2: main.cc:457 passes the UN-compacted flow, nonlinearRefinement.cc:209-212 reads
+        column i for the i-th inlier): per local shard the columns of the GLOBAL flow list at the shard's global inlier ranks
+        [prefix, prefix + m) as an [m, 2] tensor.  A shard never holds more inliers than points, so those columns sit on the shards in
+        front of it: every shard contributes the head of its flow list up to the global inlier count (ONE all-gather; all counts are
+        known everywhere, so all ranks agree on its size -- and on skipping it when every needed column is local, in which case
+        None is returned and column i of the shard's own list is the one)."""
+        torch = self.torch
+        cnt, ms = self.counts_all, np.asarray(self.m_all, dtype=np.int64)
+        po = np.concatenate([[0], np.cumsum(cnt)])[:-1]
+        pm = np.concatenate([[0], np.cumsum(ms)])[:-1]
+        if not np.any((ms > 0) & (pm != po)):
+            return None
+        heads_len = np.minimum(cnt, np.maximum(self.m_total - po, 0))
+        lmax = max(int(heads_len.max()), 1)
+        heads = torch.zeros(len(self.shards), lmax, 2, dtype=torch.float64, device=self.dev)
+        for i, sh in enumerate(self.shards):
+            h = int(heads_len[self.first_shard + i])
+            if h:
+                heads[i, :h] = sh.u.view(-1, 2)[:h]
+        heads_all = self._all_gather(heads)  # [shards, lmax, 2] in global shard order
+        ends = torch.from_numpy(np.cumsum(cnt)).to(self.dev)
+        starts = torch.from_numpy(po.astype(np.int64)).to(self.dev)
+        out = []
+        for i, sh in enumerate(self.shards):
+            g = int(pm[self.first_shard + i]) + torch.arange(sh.m, dtype=torch.int64, device=self.dev)
+            r = torch.searchsorted(ends, g, right=True)
+            out.append(heads_all[r, g - starts[r]].contiguous())
+        return out
+
+    def _refine(self, v, w, k, const_acceleration, flow_index_mode=1):
         torch = self.torch
         sizes = [self.s0.tile_refine_row_size(const_acceleration, st) for st in range(3)]
-        for sh in self.shards:
+        by_rank = self.rank_indexed_flow() if flow_index_mode == 0 else None
+        self._flow_keep = by_rank
+        for i, sh in enumerate(self.shards):
             sh.inl_ref = torch.empty(3 * max(sh.m, 1), dtype=torch.float64, device=self.dev)
+            if flow_index_mode == 0:  # column i of d_flow belongs to inlier i (the shard's own list when nothing had to be fetched)
+                fl, nf = (by_rank[i], sh.m) if by_rank is not None else (sh.u, sh.n)
+                sh.s.tile_refine_begin_dev(fl.data_ptr(), nf, sh.m, sh.inl.data_ptr(), sh.in_a.data_ptr(), sh.in_ak.data_ptr(), 0, v, w, k, const_acceleration, 0)
+                continue
             sh.s.tile_refine_begin_dev(sh.u.data_ptr(), sh.n, sh.m, sh.inl.data_ptr(), sh.in_a.data_ptr(), sh.in_ak.data_ptr(), sh.idx.data_ptr(), v, w, k, const_acceleration)
         keep = [self._staged(0, sizes[0])]
         st = self.s0.tile_refine_poll()
@@ -313,14 +350,15 @@ class TiledFrameSolve:
         return st
 
     def solve(self, trials=50, tol=0.05, seed=1, use_acceleration_mode=False, use_refinement=True, depth_mode=DEPTH_CERES_LM,
-              k_sign_mode=0, samples=None, pose_table=False):
+              k_sign_mode=0, samples=None, pose_table=False, flow_index_mode=0):
         """returns the dict of Solver.solve_frame_dev (same keys) plus depth_map (torch, column-major [cols * rows]);
-        the shards keep their refined inliers (sh.final, 3 x sh.m) and scanline indices (sh.ys)."""
+        the shards keep their refined inliers (sh.final, 3 x sh.m) and scanline indices (sh.ys).  flow_index_mode as in
+        Solver.solve_frame_dev: 0 (default) = the reference's rank-indexed flow (see rank_indexed_flow), 1 = gathered."""
         torch = self.torch
         res = self._ransac(int(trials), float(tol), int(seed), int(bool(use_acceleration_mode)), depth_mode, k_sign_mode, samples)
         v, w, k = res["ransac_v"], res["ransac_w"], res["ransac_k"]
         if use_refinement:
-            st = self._refine(v, w, k, bool(use_acceleration_mode))
+            st = self._refine(v, w, k, bool(use_acceleration_mode), int(flow_index_mode))
             v, w, k = st["v"], st["w"], st["k"]
             res["refine_summary"] = st["summary"]
             for sh in self.shards:

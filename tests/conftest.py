@@ -60,16 +60,22 @@ def oracle_chain(oracle, big_config):
     against it"""
     cache = {}
 
-    def get(cfg, T, tol, seed, accel=False, data_seed=None, arith="reference"):
-        key = (cfg, T, tol, seed, accel, data_seed, arith)
+    def get(cfg, T, tol, seed, accel=False, data_seed=None, arith="reference", flow_mode=1):
+        """flow_mode 1 = the gathered flow, 0 = the reference's rank-indexed flow (main.cc:457, quirk Q2); the RANSAC part is shared"""
+        key = (cfg, T, tol, seed, accel, data_seed, arith, flow_mode)
         if key not in cache:
             d = big_config(cfg, data_seed)
             rows, K, gamma = d["rows"], d["K"], d["gamma"]
+            other = cache.get(key[:-1] + (1 - flow_mode,))
             with oracle.arithmetic(arith):
-                q, u, qpx, fpx = oracle.flatten(d["flow_img"], *K, gamma)
-                a, ak = oracle.get_alpha(fpx, rows, gamma), oracle.get_alpha_k(qpx, fpx, rows, gamma)
-                ro = oracle.ransac(q, u, a, ak, accel, T, tol, oracle.sample_indices(len(q), T, seed), depth_mode=1)
-                refo = oracle.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], accel, 1, ro["inlier_idx"])
+                if other is not None:
+                    q, u, a, ak, ro = other["q"], other["u"], other["a"], other["ak"], other["ransac"]
+                else:
+                    q, u, qpx, fpx = oracle.flatten(d["flow_img"], *K, gamma)
+                    a, ak = oracle.get_alpha(fpx, rows, gamma), oracle.get_alpha_k(qpx, fpx, rows, gamma)
+                    ro = oracle.ransac(q, u, a, ak, accel, T, tol, oracle.sample_indices(len(q), T, seed), depth_mode=1)
+                refo = oracle.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], accel, flow_mode,
+                                     ro["inlier_idx"] if flow_mode else None)
                 inl, v, flipped = oracle.canonicalize_sign(refo["inliers"], refo["v"])
                 dm, xs, ys = oracle.scatter_depth(inl, *K, d["rows"], d["cols"])
             cache[key] = dict(q=q, u=u, a=a, ak=ak, ransac=ro, refine=refo, inliers=inl, v=v, flipped=flipped, depth_map=dm, ys=ys)

@@ -85,7 +85,7 @@ int main(int argc, char** argv) {
     prm.flow_threshold = 1e-10;                     // main.cc:311
     prm.use_refinement = 1;                         // main.cc:307
     prm.depth_mode = RSDSFM_DEPTH_CERES_LM;
-    prm.flow_index_mode = RSDSFM_FLOW_GATHERED;     // the tiled solve gathers each inlier's own flow
+    // flow_index_mode stays 0 = RSDSFM_FLOW_COMPAT_RANK: the zero-initialised struct reproduces evaluateSingleRun (main.cc:457)
     rsdsfm_frame_result res;
     rsdsfm_tiled_info info;
     CHECK_RS(ctx, rsdsfm_solve_frame_tiled_dev(ctx, d_slab, rows, cols, fx, fy, cx, cy, gamma, &prm, d_map, d_R, d_t, &res, &info));

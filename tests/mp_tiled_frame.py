@@ -28,7 +28,7 @@ def main():
         slab = torch.from_numpy(np.ascontiguousarray(d["flow_img"][:, c0:c1, :])).to(dev)  # each rank only holds its slab
         shard = rsdsfm.dist.HipFrameShard(solver, slab, c0, K, gamma, torch)
         drv = rsdsfm.dist.TiledFrameSolve([shard], rows, cols, per, torch, dist)
-        r = drv.solve(trials=14, tol=0.002, seed=7)
+        r = drv.solve(trials=14, tol=0.002, seed=7, flow_index_mode=int(os.environ.get("RSDSFM_TEST_FLOW_MODE", "1")))
         torch.cuda.synchronize()
         dm = r["depth_map"].cpu().numpy()
         mine = np.concatenate([r["v"], r["w"], [r["k"], r["num_inliers"], r["best_trial"], float((dm != 0).sum()), dm.sum()]])

@@ -29,7 +29,7 @@ def main():
     solver.dist_set_transport(world, rank, *GlooTransport(dist, torch).callbacks())
     slab = torch.from_numpy(np.ascontiguousarray(d["flow_img"][:, c0:c0 + sc, :])).to(dev)  # each rank only holds its slab
     dm = torch.zeros(cols * rows, dtype=torch.float64, device=dev)
-    r = solver.solve_frame_tiled_dev(slab.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=14, tol=0.002, seed=7)
+    r = solver.solve_frame_tiled_dev(slab.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=14, tol=0.002, seed=7, flow_index_mode=int(os.environ.get("RSDSFM_TEST_FLOW_MODE", "1")))
     torch.cuda.synchronize()
     dmh = dm.cpu().numpy()
     mine = np.concatenate([r["v"], r["w"], [r["k"], r["num_inliers"], r["best_trial"], float((dmh != 0).sum()), dmh.sum()]])

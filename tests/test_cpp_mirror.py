@@ -124,9 +124,8 @@ def test_tiled_host_in_cpp_over_rccl_matches_python_solve(tmp_path, rsdsfm):
     R = torch.empty((rows, 9), dtype=torch.float64, device=dev)
     t = torch.empty((rows, 3), dtype=torch.float64, device=dev)
     with rsdsfm.Solver(0) as s:
-        one = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), trials=T, tol=tol, seed=seed,
-                                flow_index_mode=rsdsfm.FLOW_GATHERED)
-        s.synchronize()
+        one = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), trials=T, tol=tol, seed=seed)
+        s.synchronize()  # (both sides with the zero-initialised default: the reference's rank-indexed flow)
     assert r["world"] == 1 and r["n"] == one["n"] and r["num_inliers"] == one["num_inliers"] and r["best_trial"] == one["best_trial"]
     assert np.array_equal(r["v"], one["v"]) and np.array_equal(r["w"], one["w"]) and r["k"] == one["k"]
     assert r["iterations"] == one["refine_summary"]["num_iterations"] and r["flipped"] == int(one["flipped"])

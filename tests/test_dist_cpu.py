@@ -159,6 +159,10 @@ def _frame_worker(rank, world, port, out_dir, nlocal):
         shards.append(rsdsfm.dist.HipFrameShard(OracleTileSolver(oracle_py), slab, c0, K, gamma, torch))
     drv = rsdsfm.dist.TiledFrameSolve(shards, rows, cols, per, torch, dist)
     r = drv.solve(trials=9, tol=0.004, seed=11, use_refinement=False, depth_mode=0)
+    # the reference's rank-indexed flow (quirk Q2): what each shard would hand to the refinement, fetched across the gloo group
+    by_rank = drv.rank_indexed_flow()
+    assert by_rank is not None  # selective tolerance: ranks != indices
+    np.save(os.path.join(out_dir, "flowrank%d.npy" % rank), np.concatenate([f.numpy().reshape(-1, 2) for f in by_rank]))
     np.savez(os.path.join(out_dir, "frame%d.npz" % rank), depth=r["depth_map"].numpy(), v=r["v"], w=r["w"], k=r["k"], n=r["n"],
              m=r["num_inliers"], best=r["best_trial"], tc=r["trial_count"], te=r["trial_err"], flipped=r["flipped"],
              inl=np.concatenate([sh.final[: 3 * sh.m].numpy() for sh in shards]))
@@ -187,3 +191,6 @@ def test_tiled_frame_driver_gloo_world2(tmp_path, oracle, rsdsfm, nlocal):
         assert np.array_equal(r[i]["depth"].reshape(cols, rows).T, dm_o)
     # the ranks' inliers concatenate (rank order) to the oracle's inlier list
     assert np.array_equal(np.concatenate([r[0]["inl"], r[1]["inl"]]).reshape(-1, 3), inl_o)
+    # rank-indexed flow: shard by shard the columns [prefix, prefix + m) of the GLOBAL flow list = its first num_inliers columns
+    fr = np.concatenate([np.load(os.path.join(str(tmp_path), "flowrank%d.npy" % i)) for i in range(2)])
+    assert ro["num_inliers"] < len(q) and np.array_equal(fr, u[: ro["num_inliers"]])

@@ -32,6 +32,8 @@ def _native_threads(rsdsfm, torch, d, nranks, **kw):
     img = torch.from_numpy(d["flow_img"]).to(dev)
     tr = ThreadTransport(nranks)
     outs, errs = [None] * nranks, [None] * nranks
+    kw = dict(kw)
+    kw.setdefault("flow_index_mode", rsdsfm.FLOW_GATHERED)  # (tests of the reference's rank-indexed flow pass FLOW_COMPAT_RANK)
 
     def work(rank):
         try:
@@ -153,7 +155,7 @@ def test_native_tiled_over_rccl_one_rank(rsdsfm):
         with rsdsfm.Solver(0, stream=stream.cuda_stream) as s:
             s.dist_init(1, 0, rsdsfm.dist_unique_id())
             for _ in range(2):  # the communicator is reused across solves
-                r = s.solve_frame_tiled_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), **kw)
+                r = s.solve_frame_tiled_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), flow_index_mode=rsdsfm.FLOW_GATHERED, **kw)
             s.synchronize()
             assert r["info"]["collectives"] >= 8 and r["info"]["nranks"] == 1
             s.dist_finalize()
@@ -190,14 +192,108 @@ def test_native_tiled_3840x2160_in_8_ranks(rsdsfm, oracle_chain, big_config):
     assert np.array_equal(got != 0, o["depth_map"] != 0) and np.allclose(got, o["depth_map"], rtol=1e-6)
 
 
-def test_native_tiled_two_processes_share_the_gpu(rsdsfm, tmp_path):
+# ---------------------------------------------------------------------------------------------------
+# the reference's DEFAULT flow indexing across slabs (quirk Q2: main.cc:457 passes the un-compacted flow, nonlinearRefinement.cc:
+# 209-212 reads column i for the i-th inlier): a zero-initialised rsdsfm_frame_params must work tiled, also when M < N
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,accel", [(3, False), (5, True)])
+def test_native_tiled_rank_indexed_flow_matches_single_context(rsdsfm, oracle, cfg, accel):
+    """selective tolerance (M < N): inlier ranks and point indices differ, a slab's inliers read flow columns that live on the
+    slabs in front of it.  1 / 2 / 3 / 5 logical ranks = the single-context default solve (integers exact, floats to the summation
+    order), and the single-context solve = the oracle chain in mode 0"""
+    import torch
+
+    stream = torch.cuda.Stream(torch.device("cuda", 0))
+    d = rsdsfm.synth.make_config(cfg, rows=96, cols=250)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    kw = dict(trials=14, tol=0.002 if cfg == 3 else 0.004, seed=7, use_acceleration_mode=accel, flow_index_mode=rsdsfm.FLOW_COMPAT_RANK)
+    with torch.cuda.stream(stream):
+        one = _single(rsdsfm, torch, d, stream, **kw)
+        gathered = _single(rsdsfm, torch, d, stream, **dict(kw, flow_index_mode=rsdsfm.FLOW_GATHERED))
+    assert 0.1 * rows * cols < one["num_inliers"] < 0.97 * rows * cols  # selective: the two indexings are different problems
+    assert not np.allclose(one["v"], gathered["v"], rtol=1e-7)
+    # oracle chain, rank-indexed
+    q, u, qpx, fpx = oracle.flatten(d["flow_img"], *K, gamma)
+    a, ak = oracle.get_alpha(fpx, rows, gamma), oracle.get_alpha_k(qpx, fpx, rows, gamma)
+    ro = oracle.ransac(q, u, a, ak, accel, kw["trials"], kw["tol"], oracle.sample_indices(len(q), kw["trials"], kw["seed"]), depth_mode=1)
+    refo = oracle.refine(u, ro["inliers"], ro["alpha"], ro["alpha_k"], ro["v"], ro["w"], ro["k"], accel, 0, None)
+    _, v_o, _ = oracle.canonicalize_sign(refo["inliers"], refo["v"])
+    assert one["num_inliers"] == ro["num_inliers"] and one["refine_summary"]["num_iterations"] == refo["summary"]["num_iterations"]
+    assert np.allclose(one["v"], v_o, rtol=1e-6, atol=1e-10) and np.allclose(one["w"], refo["w"], rtol=1e-6, atol=1e-10)
+    for nranks in (1, 2, 3, 5):
+        til = _native_threads(rsdsfm, torch, d, nranks, **kw)
+        _compare(til, one, rows, cols, depth_rtol=1e-6 if accel else 1e-9)
+        base = _native_threads(rsdsfm, torch, d, nranks, **dict(kw, flow_index_mode=rsdsfm.FLOW_GATHERED))
+        # one more exchange than the gathered solve (the heads of the slabs' flow lists) -- none with a single rank
+        extra = [a_["collectives"] - b_["collectives"] for a_, b_ in zip(til["infos"], base["infos"])]
+        assert extra == [0 if nranks == 1 else 1] * nranks, extra
+
+
+def test_native_tiled_rank_indexed_flow_without_remote_columns(rsdsfm):
+    """every pixel an inlier (main.cc:310's tolerance 0.05 on DeepFlow-like data): rank == index, every column is local and the
+    exchange is skipped; the zero-initialised parameter struct (flow_index_mode 0) is accepted"""
+    import torch
+
+    stream = torch.cuda.Stream(torch.device("cuda", 0))
+    d = rsdsfm.synth.make_config(5, rows=96, cols=250)
+    rows, cols = d["rows"], d["cols"]
+    kw = dict(trials=10, tol=0.05, seed=3, flow_index_mode=rsdsfm.FLOW_COMPAT_RANK)
+    with torch.cuda.stream(stream):
+        one = _single(rsdsfm, torch, d, stream, **kw)
+    assert one["num_inliers"] == one["n"] == rows * cols
+    til = _native_threads(rsdsfm, torch, d, 3, **kw)
+    base = _native_threads(rsdsfm, torch, d, 3, **dict(kw, flow_index_mode=rsdsfm.FLOW_GATHERED))
+    _compare(til, one, rows, cols)
+    assert [i["collectives"] for i in til["infos"]] == [i["collectives"] for i in base["infos"]]
+    # holes in the LAST slab only: the slabs in front of it are all-inlier, still no remote column; holes in the FIRST: all shift
+    for c_lo, expect_extra in ((200, 0), (10, 1)):
+        d2 = dict(d)
+        img = d["flow_img"].copy()
+        img[20:50, c_lo:c_lo + 30] = 0.0  # pixels without flow are dropped by the flatten
+        d2["flow_img"] = img
+        with torch.cuda.stream(stream):
+            one2 = _single(rsdsfm, torch, d2, stream, **kw)
+        assert one2["num_inliers"] == one2["n"] == rows * cols - 30 * 30
+        til2 = _native_threads(rsdsfm, torch, d2, 3, **kw)
+        _compare(til2, one2, rows, cols)
+
+
+def test_native_tiled_rank_indexed_flow_3840x2160_in_8_ranks(rsdsfm, oracle_chain, big_config):
+    """BASELINE configs[3] at full size with the reference's default flow indexing and a selective tolerance: 8 logical ranks = the
+    single-context default solve = the oracle chain in mode 0 (integers exact incl. every inlier's scanline index)"""
+    import torch
+
+    stream = torch.cuda.Stream(torch.device("cuda", 0))
+    T, tol, seed = 5, 0.002, 5
+    d = big_config(4)
+    rows, cols = d["rows"], d["cols"]
+    kw = dict(trials=T, tol=tol, seed=seed, flow_index_mode=rsdsfm.FLOW_COMPAT_RANK)
+    with torch.cuda.stream(stream):
+        one = _single(rsdsfm, torch, d, stream, **kw)
+    assert one["num_inliers"] < 0.97 * one["n"]
+    til = _native_threads(rsdsfm, torch, d, 8, **kw)
+    _compare(til, one, rows, cols)
+    o = oracle_chain(4, T, tol, seed, flow_mode=0)
+    ro, refo = o["ransac"], o["refine"]
+    assert til["num_inliers"] == ro["num_inliers"] and til["best_trial"] == ro["best_trial"]
+    for key in ("num_iterations", "num_successful_steps", "termination"):
+        assert til["refine_summary"][key] == refo["summary"][key], key
+    assert til["flipped"] == o["flipped"] and np.allclose(til["v"], o["v"], rtol=1e-6, atol=1e-10) and np.allclose(til["w"], refo["w"], rtol=1e-6, atol=1e-10)
+    assert np.array_equal(til["ys"], o["ys"])
+    got = til["depth_map"].reshape(cols, rows).T
+    assert np.array_equal(got != 0, o["depth_map"] != 0) and np.allclose(got, o["depth_map"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("flow_mode", [1, 0])
+def test_native_tiled_two_processes_share_the_gpu(rsdsfm, tmp_path, flow_mode):
     """two ranks = two processes (gloo rendezvous on 127.0.0.1, both on cuda:0, collectives through GlooTransport) run
-    tests/mp_tiled_native.py; rank 0's result equals the single-context solve and both ranks agree bit for bit"""
+    tests/mp_tiled_native.py; rank 0's result equals the single-context solve and both ranks agree bit for bit.  flow_mode 0 = the
+    reference's rank-indexed flow (rank 1 fetches flow columns of rank 0's slab)"""
     import torch
 
     out = tmp_path / "res.json"
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RSDSFM_TILED_OUT=str(out))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29641",
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RSDSFM_TILED_OUT=str(out), RSDSFM_TEST_FLOW_MODE=str(flow_mode))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(29641 + flow_mode),
            os.path.join(ROOT, "tests", "mp_tiled_native.py")]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
@@ -205,7 +301,7 @@ def test_native_tiled_two_processes_share_the_gpu(rsdsfm, tmp_path):
     stream = torch.cuda.Stream(torch.device("cuda", 0))
     with torch.cuda.stream(stream):
         d = rsdsfm.synth.make_config(3, rows=96, cols=250)
-        one = _single(rsdsfm, torch, d, stream, trials=14, tol=0.002, seed=7)
+        one = _single(rsdsfm, torch, d, stream, trials=14, tol=0.002, seed=7, flow_index_mode=flow_mode)
     assert got["world"] == 2 and got["ranks_agree"] and got["info"]["nranks"] == 2
     assert got["n"] == one["n"] and got["num_inliers"] == one["num_inliers"] and got["best_trial"] == one["best_trial"]
     assert np.allclose(got["v"], one["v"], rtol=1e-9) and np.allclose(got["w"], one["w"], rtol=1e-9)

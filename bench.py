@@ -622,8 +622,10 @@ def run(args):
         side = not args.no_side_records
         # sequence-throughput mode (BASELINE configs[4]): 32 pairs with 32 data seeds through ONE context of each GPU
         batched = _full_solve_sequence(rsdsfm, solver, torch, dev, np, rank, args) if side else None
-        fused = depth_only = regimes = None
-        if side and world == 1:  # single-GPU side records (a multi-rank run keeps to what scales: replicas + the tiled frame)
+        fused = depth_only = regimes = threads8 = None
+        if side and world == 1:
+            threads8 = _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, 8, per_thread=12)  # round 2's way, for comparison
+            threads8["note"] = "comparison: 8 host threads x 8 contexts, each calling the single solve (what round 2 reported as full_solve_batched)"  # single-GPU side records (a multi-rank run keeps to what scales: replicas + the tiled frame)
             if args.arith == "reference":
                 with rsdsfm.Solver(local_rank, stream=stream.cuda_stream, arith="fused") as sf:
                     fr = _full_solve(rsdsfm, sf, torch, dev, np, rank, args, steps=max(20, args.steps // 2), warmup=3, timed=lambda st, k2, w2: _plain_timed(torch, st, k2, w2))
@@ -638,7 +640,7 @@ def run(args):
                                                 "trial + scoring, joint nonlinear refinement, sign fix + depth map, pose table; ONE C-ABI call per pair, one pair at a time, "
                                                 "one pair per GPU (N ranks = N independent replicas, no data-path collective)" % (args.trials, args.tol),
                                     **{k2: full[k2] for k2 in ("rows", "cols", "trials", "tol", "n", "num_inliers", "refine_summary", "w_err", "v_angle_deg")}},
-                         "roofline": roof, "full_solve_batched": batched, "full_solve_fused": fused, "regimes": regimes, "depth_only": depth_only,
+                         "roofline": roof, "full_solve_batched": batched, "full_solve_8_threads": threads8, "full_solve_fused": fused, "regimes": regimes, "depth_only": depth_only,
                          "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_full(rsdsfm, np, rank, args.trials, args.tol)})
             if line["cpu_baseline"] and side:  # the single-thread figure "plus an all-cores variant"
                 line["cpu_baseline"]["all_cores"] = cpu_baseline_full_all_cores(rsdsfm, np, rank, args.trials, args.tol, line["cpu_baseline"])
@@ -1181,14 +1183,41 @@ def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):
                     "because the metric asks for it; counters: profiles/counters.json (rocprofv3 --pmc of this command)"}
 
 
-def _full_solve_sequence(rsdsfm, solver, torch, dev, np, rank, args):
-    return _full_solve_batched(rsdsfm, torch, dev, solver_device(solver), rank, args, 8, per_thread=25)
+def _full_solve_sequence(rsdsfm, solver, torch, dev, np, rank, args, pairs=32, passes=6):
+    """BASELINE configs[4] / SURVEY 8(d) row 5: a sequence of 32 frame pairs @1280x720 with 32 DIFFERENT data seeds (one noise / outlier
+    realisation each) through ONE context and ONE host thread: rsdsfm_solve_frames_dev pipelines them inside the library (lanes on
+    streams of their own; the minimal solver and the single-workgroup stages of one pair run beside the streaming kernels of another).
+    One call = the whole sequence; `passes` timed calls after one warm-up call, sampler seeds changing per call."""
+    from concurrent.futures import ThreadPoolExecutor
 
-
-def solver_device(solver):
-    import torch
-
-    return torch.cuda.current_device()
+    seeds_data = [0x5EED0005 + 64 * rank + 1000 * i for i in range(pairs)]
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:  # (numpy releases the GIL: ~0.6 s per frame otherwise)
+        chunks = list(ex.map(lambda sd: rsdsfm.synth.make_flow_sequence(5, [sd]), seeds_data))
+    meta = chunks[0][1]
+    rows, cols = meta["rows"], meta["cols"]
+    imgs = [torch.from_numpy(ch[0][0]).to(dev) for ch in chunks]
+    dms = [torch.empty((cols, rows), dtype=torch.float64, device=dev) for _ in range(pairs)]
+    Rs = [torch.empty((rows, 9), dtype=torch.float64, device=dev) for _ in range(pairs)]
+    ts = [torch.empty((rows, 3), dtype=torch.float64, device=dev) for _ in range(pairs)]
+    jobs = [dict(d_flow_img=im.data_ptr(), rows=rows, cols=cols, K=meta["K"], gamma=meta["gamma"], d_depth_map=dm.data_ptr(), d_R=R_.data_ptr(), d_t=t_.data_ptr())
+            for im, dm, R_, t_ in zip(imgs, dms, Rs, ts)]
+    call = solver.prepared_frames_solve(jobs, trials=args.trials, tol=args.tol)
+    torch.cuda.synchronize()
+    call([1 + i for i in range(pairs)])
+    times = []
+    for p_ in range(passes):
+        t0 = time.perf_counter()
+        res = call([1 + pairs * (p_ + 1) + i for i in range(pairs)])
+        times.append(time.perf_counter() - t0)
+    el = sum(times)
+    inl = [int(r.num_inliers) for r in res]
+    # one pair of the last pass once more through the single solve: the sequence returns the single solve's results
+    chk = solver.solve_frame_dev(imgs[3].data_ptr(), rows, cols, meta["K"], meta["gamma"], dms[3].data_ptr(), trials=args.trials, tol=args.tol, seed=1 + pairs * passes + 3)
+    same = bool(chk["num_inliers"] == inl[3] and np.array_equal(chk["v"], np.array(res[3].v[:])) and np.array_equal(chk["w"], np.array(res[3].w[:])))
+    return {"value": rows * cols * pairs * passes / el / 1e6, "unit": "Mpixels/s", "pairs": pairs, "data_seeds": pairs, "passes": passes, "solves": pairs * passes,
+            "ms_per_solve_amortised": el / (pairs * passes) * 1e3, "best_pass_ms_per_solve": min(times) / pairs * 1e3, "host_threads": 1, "contexts": 1,
+            "api": "rsdsfm_solve_frames_dev (pairs pipelined inside the library)", "num_inliers_min_max": [min(inl), max(inl)],
+            "pair_equals_single_solve": same}
 
 
 def _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, S, per_thread):

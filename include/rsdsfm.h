@@ -226,11 +226,17 @@ typedef struct rsdsfm_frame_params {
                                      nonlinearRefinement.cc:209-212 reads column i for the i-th inlier, quirk Q2);
                                      1 = GATHERED (column inlier_idx[i])                                  */
     int32_t use_global_shutter_mode; /* main.cc:305, :441-444: alpha = 1 for every point (overrides the RS model) */
-    int32_t _pad;
+    int32_t struct_bytes;         /* 0 (zero-initialised struct) or sizeof(rsdsfm_frame_params), as rsdsfm_frame_params_init
+                                     sets it; anything else is refused: the caller was built against another layout of this
+                                     struct (round 1's was 8 bytes shorter and its ransac_tol sits where this field is)   */
     double ransac_tol;            /* main.cc:310 (0.05)                                                 */
     double flow_threshold;        /* main.cc:311 (1e-10)                                                */
     uint64_t seed;                /* sampler seed (reference: srand(time))                              */
 } rsdsfm_frame_params;
+
+/* the reference's constants (main.cc:304-311: 5 trials, tolerance 0.05, flow threshold 1e-10, refinement on, rolling shutter,
+ * rank-indexed flow), Ceres-LM depth mode, seed 1, struct_bytes = sizeof */
+void rsdsfm_frame_params_init(rsdsfm_frame_params* params);
 
 typedef struct rsdsfm_frame_result {
     int64_t n_points, num_inliers;
@@ -252,6 +258,28 @@ int rsdsfm_solve_frame_dev(rsdsfm_ctx* ctx, const double* d_flow_img, int32_t ro
                            double cx, double cy, double gamma, const rsdsfm_frame_params* params,
                            double* d_depth_map_colmajor, double* d_R_rows9_or_null, double* d_t_rows3_or_null,
                            rsdsfm_frame_result* result);
+/* ---- a SEQUENCE of frame pairs (BASELINE configs[4]: "batched frame pairs, sequence throughput mode") ---------------------
+ * evaluateSingleRun (main.cc:302-559) solves one pair per process run; a host that has a whole sequence resident hands the pairs
+ * over in ONE call.  The library pipelines them: up to `lanes` pairs are in flight on streams of their own, so the latency-bound
+ * kernels of one pair (the 9-point minimal solver, the single-workgroup decide / solve stages) run beside the streaming kernels
+ * of another.  One host thread, one context; results[i] is exactly what rsdsfm_solve_frame_dev returns for jobs[i] with
+ * params->seed = jobs[i].seed (the device pointers inside results[i] stay valid for the last `lanes` pairs only). */
+typedef struct rsdsfm_frame_job {
+    const double* d_flow_img;      /* DEVICE, row-major rows x cols x 2 (as rsdsfm_solve_frame_dev)            */
+    int32_t rows, cols;
+    double fx, fy, cx, cy, gamma;
+    double* d_depth_map_colmajor;  /* DEVICE, rows x cols                                                     */
+    double* d_R_rows9_or_null;     /* DEVICE pose table, may be NULL                                          */
+    double* d_t_rows3_or_null;
+    uint64_t seed;                 /* sampler seed of this pair (params->seed is ignored)                     */
+} rsdsfm_frame_job;
+int rsdsfm_solve_frames_dev(rsdsfm_ctx* ctx, const rsdsfm_frame_job* jobs, int32_t count, const rsdsfm_frame_params* params,
+                            rsdsfm_frame_result* results);
+/* pairs in flight of rsdsfm_solve_frames_dev: 1 .. 16, 0 = default (4).  Scheduling only. */
+int rsdsfm_set_sequence_lanes(rsdsfm_ctx* ctx, int32_t lanes);
+/* 1 (default): a frame whose predecessor on the context was dense forms the minimal solver's sampled points straight from the flow
+ * image and runs the flatten beside the solver on a second stream; 0: flatten first, on the context's stream.  Scheduling only. */
+int rsdsfm_set_frame_side_flatten(rsdsfm_ctx* ctx, int on);
 /* minimal::ransac on device-resident inputs.  The arrays of `out` (inlier_idx, inliers, alpha, alpha_k, mask,
  * inv_depth) are DEVICE pointers with capacity n (each may be NULL); its trial_* arrays are HOST pointers.
  * samples_9xT_or_null is a HOST pointer.  Synchronises once at the end to return the scalars of `out`. */

@@ -58,8 +58,13 @@ class LmSummary(C.Structure):
 class FrameParams(C.Structure):
     _fields_ = [("ransac_trials", C.c_int32), ("use_acceleration_mode", C.c_int32), ("use_refinement", C.c_int32),
                 ("depth_mode", C.c_int32), ("k_sign_mode", C.c_int32), ("flow_index_mode", C.c_int32), ("use_global_shutter_mode", C.c_int32),
-                ("_pad", C.c_int32), ("ransac_tol", C.c_double),
+                ("struct_bytes", C.c_int32), ("ransac_tol", C.c_double),
                 ("flow_threshold", C.c_double), ("seed", C.c_uint64)]
+
+
+class FrameJob(C.Structure):
+    _fields_ = [("d_flow_img", C.c_void_p), ("rows", C.c_int32), ("cols", C.c_int32), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double),
+                ("cy", C.c_double), ("gamma", C.c_double), ("d_depth_map", C.c_void_p), ("d_R", C.c_void_p), ("d_t", C.c_void_p), ("seed", C.c_uint64)]
 
 
 class FrameResult(C.Structure):
@@ -504,6 +509,50 @@ class Solver:
             return res
 
         return call
+
+    def set_sequence_lanes(self, lanes):
+        """pairs in flight of solve_frames_dev (rsdsfm_set_sequence_lanes): 1..16, 0 = default (4); scheduling only"""
+        self._check(self.lib.rsdsfm_set_sequence_lanes(self._ctx, C.c_int32(int(lanes))), "rsdsfm_set_sequence_lanes")
+
+    def set_frame_side_flatten(self, on):
+        """True (default): dense frames form the minimal solver's points straight from the flow image and run the flatten beside it on
+        a second stream (rsdsfm_set_frame_side_flatten); scheduling only"""
+        self._check(self.lib.rsdsfm_set_frame_side_flatten(self._ctx, int(bool(on))), "rsdsfm_set_frame_side_flatten")
+
+    def prepared_frames_solve(self, jobs, trials=50, tol=0.05, use_acceleration_mode=False, use_refinement=True, depth_mode=DEPTH_CERES_LM,
+                              k_sign_mode=K_COMPAT, flow_threshold=1e-10, flow_index_mode=FLOW_COMPAT_RANK, use_global_shutter_mode=False):
+        """A SEQUENCE of frame pairs in ONE C-ABI call (rsdsfm_solve_frames_dev), pipelined inside the library.  jobs: list of dicts with
+        d_flow_img, rows, cols, K, gamma, d_depth_map and optionally d_R, d_t (device pointers).  Returns call(seeds) -> list of
+        FrameResult (the ctypes array is reused by the next call); seeds: one sampler seed per pair."""
+        n = len(jobs)
+        arr = (FrameJob * n)()
+        for a, j in zip(arr, jobs):
+            K = j["K"]
+            a.d_flow_img, a.rows, a.cols = int(j["d_flow_img"]), int(j["rows"]), int(j["cols"])
+            a.fx, a.fy, a.cx, a.cy, a.gamma = float(K[0]), float(K[1]), float(K[2]), float(K[3]), float(j["gamma"])
+            a.d_depth_map, a.d_R, a.d_t = int(j["d_depth_map"]), int(j.get("d_R") or 0) or None, int(j.get("d_t") or 0) or None
+        prm = FrameParams(int(trials), int(use_acceleration_mode), int(use_refinement), int(depth_mode), int(k_sign_mode),
+                          int(flow_index_mode), int(use_global_shutter_mode), 0, float(tol), float(flow_threshold), 0)
+        res = (FrameResult * n)()
+        fn, ctx, check = self.lib.rsdsfm_solve_frames_dev, self._ctx, self._check
+
+        def call(seeds):
+            for a, sd in zip(arr, seeds):
+                a.seed = int(sd)
+            rc = fn(ctx, arr, C.c_int32(n), C.byref(prm), res)
+            if rc != OK:
+                check(rc, "rsdsfm_solve_frames_dev")
+            return res
+
+        return call
+
+    def solve_frames_dev(self, jobs, seeds, **kw):
+        """rsdsfm_solve_frames_dev once; returns one dict per pair (as solve_frame_dev)"""
+        res = self.prepared_frames_solve(jobs, **kw)(seeds)
+        return [dict(n=int(r.n_points), num_inliers=int(r.num_inliers), best_trial=int(r.best_trial), flipped=bool(r.flipped),
+                     ransac_w=np.array(r.ransac_w[:]), ransac_v=np.array(r.ransac_v[:]), ransac_k=float(r.ransac_k),
+                     w=np.array(r.w[:]), v=np.array(r.v[:]), k=float(r.k), refine_summary=r.refine_summary.as_dict(),
+                     d_inliers=r.d_inliers, d_inlier_idx=r.d_inlier_idx, d_scanline=r.d_scanline) for r in res]
 
     def depth_lm_reduce_dev(self, n_shard, d_row):
         self._check(self.lib.rsdsfm_depth_lm_reduce_dev(self._ctx, C.c_int64(n_shard), _dp(d_row)), "rsdsfm_depth_lm_reduce_dev")

@@ -83,8 +83,8 @@ extern "C" {
 #define RSDSFM_FUSED 0
 #endif
 const char* rsdsfm_version(void) {
-    return RSDSFM_FUSED ? "rsdsfm-mi355x 0.2.0 (gfx950, fp64, -ffp-contract=off, FUSED per-pixel model: explicit fmas)"
-                        : "rsdsfm-mi355x 0.2.0 (gfx950, fp64, -ffp-contract=off, reference arithmetic: no fused multiply-add)";
+    return RSDSFM_FUSED ? "rsdsfm-mi355x 0.3.0 (gfx950, fp64, -ffp-contract=off, FUSED per-pixel model: explicit fmas)"
+                        : "rsdsfm-mi355x 0.3.0 (gfx950, fp64, -ffp-contract=off, reference arithmetic: no fused multiply-add)";
 }
 int rsdsfm_fused_arithmetic(void) { return RSDSFM_FUSED; }
 
@@ -144,6 +144,7 @@ void rsdsfm_destroy(rsdsfm_ctx* ctx) {
     DeviceGuard device_guard_(c);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    frame_release(c);  // (the sequence lanes, the second stream and its events)
     if (c->d_partials) (void)hipFree(c->d_partials);
     if (c->d_tickets) (void)hipFree(c->d_tickets);
     if (c->d_lm) (void)hipFree(c->d_lm);

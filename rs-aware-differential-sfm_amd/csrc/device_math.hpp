@@ -27,6 +27,25 @@ namespace rsdsfm {
 
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+// One point of the caller glue main.cc:398-444 + getAlpha / getAlphaK (minimal.cc:179-197): pixel (column i, row j) with flow f in
+// pixels -> normalised position q, normalised flow u, alpha, alpha_k (pixel units, h = rows: quirk Q6).  The ONE statement of these
+// expressions: flatten_tile_kernel writes them to the point arrays, minimal9_kernel's direct mode forms its sampled points with them.
+struct FlatPoint {
+    double qx, qy, ux, uy, alpha, alpha_k;
+};
+__device__ __forceinline__ FlatPoint flatten_point(double2 f, int i, int j, double fx, double fy, double cx, double cy, double gamma, double h) {
+    FlatPoint p;
+    p.qx = (i - cx) * 1.0 / fx;
+    p.qy = (j - cy) * 1.0 / fy;
+    p.ux = f.x * gamma / fx;
+    p.uy = f.y * gamma / fy;
+    p.alpha = 1 + gamma * f.y / h;  // minimal.cc:183 with pixel flow, h = rows (quirk Q6)
+    const double part1 = gamma * (double)j / h;
+    const double part2 = 1.0 + gamma * ((double)j + f.y) / h;
+    p.alpha_k = 0.5 * (part2 * part2 - part1 * part1);
+    return p;
+}
+
 // LevenbergMarquardtStrategy::StepAccepted (Ceres 1.14 levenberg_marquardt_strategy.cc)
 __host__ __device__ __forceinline__ double radius_accept(double radius, double q) {
     double t = 2.0 * q - 1.0;

@@ -7,7 +7,8 @@
 using namespace rsdsfm;
 
 // flatten of a column slab: d_img is the row-major [rows][cols] slab whose first column is image column col0
-static int flatten_device(Ctx* c, const double* d_img, int32_t rows, int32_t cols, int32_t col0, double fx, double fy, double cx,
+namespace rsdsfm {
+int flatten_device(Ctx* c, const double* d_img, int32_t rows, int32_t cols, int32_t col0, double fx, double fy, double cx,
                           double cy, double gamma, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k,
                           int64_t* n_out) {
     if (rows < 0 || cols < 0 || col0 < 0 || !n_out) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
@@ -37,6 +38,7 @@ static int flatten_device(Ctx* c, const double* d_img, int32_t rows, int32_t col
     *n_out = *h_total;
     return RSDSFM_OK;
 }
+}  // namespace rsdsfm
 
 namespace rsdsfm {
 // The flatten of a whole image WITHOUT the host wait: the point count lands in *h_total (host-mapped pinned memory, written by the scan

@@ -177,12 +177,11 @@ __global__ __launch_bounds__(kGB) void flatten_tile_kernel(const double2* __rest
                 seg_base = seg_bases[cell / kScanSegCells];
             }
             const int64_t o = seg_base + cell_offsets[cell] + __popcll(bal & ((1ull << lane) - 1ull));
-            q[o] = make_double2(((i + col0) - cx) * 1.0 / fx, (j - cy) * 1.0 / fy);
-            u[o] = make_double2(f.x * gamma / fx, f.y * gamma / fy);
-            alpha[o] = 1 + gamma * f.y / h;  // minimal.cc:183 with pixel flow, h = rows (quirk Q6)
-            const double part1 = gamma * (double)j / h;
-            const double part2 = 1.0 + gamma * ((double)j + f.y) / h;
-            alpha_k[o] = 0.5 * (part2 * part2 - part1 * part1);
+            const FlatPoint fp = flatten_point(f, i + col0, j, fx, fy, cx, cy, gamma, h);
+            q[o] = make_double2(fp.qx, fp.qy);
+            u[o] = make_double2(fp.ux, fp.uy);
+            alpha[o] = fp.alpha;
+            alpha_k[o] = fp.alpha_k;
         }
     }
 }

@@ -626,7 +626,7 @@ __global__ __launch_bounds__(64) void minimal9_kernel(const double* __restrict__
                                                      const double* __restrict__ alpha_k,
                                                      const int32_t* __restrict__ samples, int T, int use_alpha_k,
                                                      int k_sign_mode, double* __restrict__ hyp_out, uint64_t* __restrict__ zero_words,
-                                                     int64_t n_zero_words) {
+                                                     int64_t n_zero_words, Minimal9Direct direct) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     // RANSAC: the per-hypothesis LM states, score marks and flag words must be zero before the depth solves start; the workgroups of
@@ -643,9 +643,20 @@ __global__ __launch_bounds__(64) void minimal9_kernel(const double* __restrict__
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const int64_t idx = samples ? (int64_t)samples[t * 9 + i] : (int64_t)t * 9 + i;
-        const double x = q[2 * idx], y = q[2 * idx + 1], ux = u[2 * idx], uy = u[2 * idx + 1];
-        al[i] = alpha[idx];
-        alk[i] = alpha_k[idx];
+        double x, y, ux, uy;
+        if (direct.img) {
+            // dense flow: point idx of the column-major scan IS pixel (column idx / rows, row idx % rows); same expressions, same bits
+            const int pi = (int)(idx / direct.rows), pj = (int)(idx % direct.rows);
+            const double2 f = reinterpret_cast<const double2*>(direct.img)[(int64_t)pj * direct.cols + pi];
+            const FlatPoint fp = flatten_point(f, pi, pj, direct.fx, direct.fy, direct.cx, direct.cy, direct.gamma, (double)direct.rows);
+            x = fp.qx, y = fp.qy, ux = fp.ux, uy = fp.uy;
+            al[i] = direct.alpha_ones ? fp.alpha * 0.0 + 1.0 : fp.alpha;
+            alk[i] = fp.alpha_k;
+        } else {
+            x = q[2 * idx], y = q[2 * idx + 1], ux = u[2 * idx], uy = u[2 * idx + 1];
+            al[i] = alpha[idx];
+            alk[i] = alpha_k[idx];
+        }
         Z[i * 9 + 0] = -uy;
         Z[i * 9 + 1] = ux;
         Z[i * 9 + 2] = uy * x - ux * y;
@@ -822,12 +833,15 @@ __global__ __launch_bounds__(64) void minimal9_kernel(const double* __restrict__
 }
 
 int minimal9_launch(Ctx* c, const double* q, const double* u, const double* alpha, const double* alpha_k,
-                    const int32_t* samples, int T, int use_alpha_k, int k_sign_mode, double* hyp_out, void* zero_begin, size_t zero_bytes) {
+                    const int32_t* samples, int T, int use_alpha_k, int k_sign_mode, double* hyp_out, void* zero_begin, size_t zero_bytes,
+                    const Minimal9Direct* direct_or_null) {
     if (T <= 0) return RSDSFM_OK;
+    const Minimal9Direct direct = direct_or_null ? *direct_or_null : Minimal9Direct();
     uint64_t* zero_words = reinterpret_cast<uint64_t*>(zero_begin);
     const int64_t n_zero_words = (int64_t)(zero_bytes / 8);
     const size_t lds_bytes = (size_t)(use_alpha_k ? kSlotsK : kSlotsNoK) * 64 * sizeof(double);
-    static bool attr_set = false;
+    static bool attr_set_dev[64] = {false};  // (per device: a function attribute belongs to the device that is current)
+    bool& attr_set = attr_set_dev[c->device & 63];
     if (!attr_set) {
         RSDSFM_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(minimal9_kernel<false>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -840,10 +854,10 @@ int minimal9_launch(Ctx* c, const double* q, const double* u, const double* alph
     // few hypotheses (RANSAC: T = 5 ... a few hundred): one wave per hypothesis, 9x9 SVD shared by the wave; many: one lane each
     if (T <= c->num_cus * 2)
         hipLaunchKernelGGL(minimal9_kernel<true>, dim3(T), dim3(64), lds_bytes, c->stream, q, u, alpha, alpha_k, samples, T, use_alpha_k,
-                           k_sign_mode, hyp_out, zero_words, n_zero_words);
+                           k_sign_mode, hyp_out, zero_words, n_zero_words, direct);
     else
         hipLaunchKernelGGL(minimal9_kernel<false>, dim3((T + 63) / 64), dim3(64), lds_bytes, c->stream, q, u, alpha, alpha_k, samples, T,
-                           use_alpha_k, k_sign_mode, hyp_out, zero_words, n_zero_words);
+                           use_alpha_k, k_sign_mode, hyp_out, zero_words, n_zero_words, direct);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -81,24 +81,219 @@ size_t ransac_pinned_bytes(int T) {
 // *spec_tail_held tells the caller afterwards whether that final stage was the one that counts; if not (more LM rounds or a scoring
 // pass were needed) what the tail computed is garbage and the caller starts over from the host-side result.  The frame solve hands in
 // the start of its refinement (refine_begin), which removes the host round trip between the two stages.
-int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n,
-                  int use_alpha_k, int T, double tol, const int32_t* h_samples, uint64_t seed, int depth_mode,
-                  int k_sign_mode, rsdsfm_ransac_out* out, const RansacSpecTail* spec_tail, bool* spec_tail_held) {
-    bool tail_enqueued = false, spec_final = false;
+//
+// The run is a small resumable state machine (RansacRun, rsdsfm_internal.hpp): ransac_begin enqueues everything up to the FIRST point
+// where the host has to wait (round 0 of the first hypothesis batch with its speculated final stage and the caller's tail; the whole
+// run in closed-form mode) and returns without waiting; ransac_finish waits and drives the rest.  ransac_device = both.  The sequence
+// solve (frame_host.hip) begins the next frame pair on another stream between the two halves.
+namespace {
+
+enum RansacPc { kPcStart = 0, kPcBatchBegin, kPcRoundEnqueue, kPcRoundWait, kPcAfterRounds, kPcScore, kPcFinal, kPcFinalWait, kPcDone };
+
+// runs the state machine; with yield_at_wait it returns (RSDSFM_OK, R.pc != kPcDone) in front of the first host wait
+int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
+    rsdsfm_ransac_out* out = R.out;
+    const int T = R.T, Tn = R.Tn, batch = R.batch, depth_mode = R.depth_mode;
+    const int64_t n = R.n;
+    const double tol = R.tol;
+    int rc = RSDSFM_OK;
+    for (;;) {
+        switch (R.pc) {
+            case kPcStart: {
+                // (with T > 0 the region is cleared by the workgroups of minimal9_kernel: one launch less in front of the solver)
+                const bool zero_in_minimal9 = T > 0 && R.zero_bytes % 8 == 0 && (reinterpret_cast<uintptr_t>(R.zero_begin) & 7) == 0;
+                if (!zero_in_minimal9) RSDSFM_HIP_CHECK(c, hipMemsetAsync(R.zero_begin, 0, R.zero_bytes, c->stream));
+                if (T > 0) {
+                    memcpy(R.h_samples_pinned, R.samples.data(), sizeof(int32_t) * (size_t)T * 9);
+                    rc = minimal9_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, R.h_samples_pinned, T, R.use_alpha_k, R.k_sign_mode, R.d_hyp,
+                                         zero_in_minimal9 ? R.zero_begin : nullptr, zero_in_minimal9 ? R.zero_bytes : 0, R.direct);
+                    if (rc != RSDSFM_OK) return rc;
+                    if (R.after_minimal9) {  // (the frame solve: join the stream that ran the flatten beside the minimal solver)
+                        rc = (*R.after_minimal9)();
+                        if (rc != RSDSFM_OK) return rc;
+                    }
+                }
+                R.b0 = 0;
+                R.pc = kPcBatchBegin;
+                break;
+            }
+            case kPcBatchBegin: {
+                if (R.b0 >= T) {
+                    R.pc = kPcFinal;
+                    break;
+                }
+                R.B = std::min(batch, T - R.b0);
+                R.need_score = true;
+                if (depth_mode == RSDSFM_DEPTH_CERES_LM) {
+                    if (R.b0 > 0) RSDSFM_HIP_CHECK(c, hipMemsetAsync(R.d_flags, 0, sizeof(int) * 8, c->stream));  // batch 0: cleared above
+                    R.round = 0;
+                    R.pc = kPcRoundEnqueue;
+                } else {
+                    R.pc = kPcScore;
+                }
+                break;
+            }
+            case kPcRoundEnqueue: {
+                const int b0 = R.b0, B = R.B, round = R.round;
+                bool flags_via_pick = false;  // this round's flag words reach the host with the speculated pick kernel
+                if (round > 4 * kMaxIter) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machines did not terminate");
+                rc = ransac_lm_round_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_hyp + (size_t)b0 * 8, B, R.d_states + b0, R.d_partials, R.d_flags,
+                                            R.d_scored + b0, R.d_tcount + b0, R.d_terr + b0, round, tol, R.k0, R.fused_base);
+                if (rc != RSDSFM_OK) return rc;
+                if (round == 0 && B == T) {
+                    // one batch, and on typical data every hypothesis is decided and scored by round 0: the final stage
+                    // (best trial, its rho + mask, compaction) is enqueued BEFORE the host reads the flags, which saves a
+                    // host round trip with an idle GPU; if the flags say otherwise its output is simply recomputed below.
+                    // Where the context's previous solve needed the separate scoring pass (noise-free data: every hypothesis
+                    // ends after three accepted steps, which round 0 does not score), that pass is enqueued ahead of the final
+                    // stage as well: it only touches hypotheses round 0 left unscored (a no-op on other data) and saves the
+                    // round trip plus a discarded final stage (~57 us).  What is enqueued when never changes a result.
+                    if (c->ransac_score_hint) {
+                        rc = ransac_score_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_hyp, T, R.d_states, depth_mode, tol, R.d_scored, R.d_partials,
+                                                 R.d_tcount, R.d_terr);
+                        if (rc != RSDSFM_OK) return rc;
+                        R.spec_scored = true;
+                    }
+                    rc = ransac_pick_launch(c, R.d_tcount, R.d_terr, T, R.d_hyp, R.d_best, R.h_best, R.d_flags, R.h_running);  // (+ the flag words)
+                    if (rc != RSDSFM_OK) return rc;
+                    flags_via_pick = true;
+                    rc = ransac_final_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_best, R.d_states, depth_mode, tol, R.d_rho, R.d_mask, R.d_bcounts,
+                                             R.d_boffs, out->inlier_idx, out->inliers, out->alpha, out->alpha_k, R.h_best);
+                    if (rc != RSDSFM_OK) return rc;
+                    R.final_done = true;
+                    R.spec_final = true;
+                    if (R.spec_tail) {
+                        rc = (*R.spec_tail)(R.d_best);
+                        if (rc != RSDSFM_OK) return rc;
+                        R.tail_enqueued = true;
+                    }
+                }
+                if (!flags_via_pick) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(R.h_running, R.d_flags, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
+                R.pc = kPcRoundWait;
+                if (yield_at_wait) return RSDSFM_OK;
+                break;
+            }
+            case kPcRoundWait: {
+                yield_at_wait = false;  // (a run yields once: after its first wait the caller is blocked in it anyway)
+                RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+                const int* h_running = R.h_running;
+                if (R.round == 0) {
+                    R.not_one_step += h_running[2];
+                    if (R.b0 == 0) {  // where this solve's hypotheses ended: the state the context's next solve fuses the score of
+                        int best = 0;
+                        for (int a2 = 1; a2 <= 3; ++a2)
+                            if (h_running[4 + a2] > (best ? h_running[4 + best] : 0)) best = a2;
+                        if (best) R.fused_base_next = best;
+                    }
+                }
+                if (h_running[0] == 0) {
+                    R.pc = kPcAfterRounds;
+                } else {
+                    R.final_done = false;  // more LM rounds: the speculated final stage saw incomplete trials
+                    R.round += 1;
+                    R.pc = kPcRoundEnqueue;
+                }
+                break;
+            }
+            case kPcAfterRounds: {
+                R.need_score = R.h_running[1] > 0;  // hypotheses whose final iterate is not the fused one-step state
+                if (R.B == T) R.score_hint_next = R.need_score ? 1 : 0;
+                if (R.need_score && R.final_done && R.spec_scored) R.need_score = false;  // round 0 decided everything and the pass already ran
+                if (R.need_score) R.final_done = false;
+                R.pc = kPcScore;
+                break;
+            }
+            case kPcScore: {
+                if (R.need_score) {
+                    rc = ransac_score_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_hyp + (size_t)R.b0 * 8, R.B, R.d_states + R.b0, depth_mode, tol,
+                                             depth_mode == RSDSFM_DEPTH_CERES_LM ? R.d_scored + R.b0 : nullptr, R.d_partials, R.d_tcount + R.b0,
+                                             R.d_terr + R.b0);
+                    if (rc != RSDSFM_OK) return rc;
+                }
+                R.b0 += batch;
+                R.pc = kPcBatchBegin;
+                break;
+            }
+            case kPcFinal: {
+                // best trial, its dense rho + mask, order-preserving compaction
+                if (!R.final_done) {
+                    R.tail_enqueued = false;  // the speculated final stage (and whatever was enqueued behind it) saw incomplete trials
+                    R.spec_final = false;
+                    rc = ransac_pick_launch(c, R.d_tcount, R.d_terr, T, R.d_hyp, R.d_best, R.h_best);  // h_best: host-mapped, written by the kernels
+                    if (rc != RSDSFM_OK) return rc;
+                    rc = ransac_final_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_best, R.d_states, depth_mode, tol, R.d_rho, R.d_mask, R.d_bcounts,
+                                             R.d_boffs, out->inlier_idx, out->inliers, out->alpha, out->alpha_k, R.h_best);
+                    if (rc != RSDSFM_OK) return rc;
+                }
+                // per-trial diagnostics are copied back only when the caller asked for them (the frame solve does not)
+                if (T > 0 && out->trial_count) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(R.h_tcount, R.d_tcount, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
+                if (T > 0 && out->trial_err) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(R.h_terr, R.d_terr, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
+                if (T > 0 && out->trial_vel) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(R.h_hyp, R.d_hyp, sizeof(double) * 8 * T, hipMemcpyDeviceToHost, c->stream));
+                if (T > 0 && out->trial_steps && depth_mode == RSDSFM_DEPTH_CERES_LM)
+                    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(R.h_states, R.d_states, sizeof(LmState) * T, hipMemcpyDeviceToHost, c->stream));
+                R.pc = kPcFinalWait;
+                if (yield_at_wait) return RSDSFM_OK;
+                break;
+            }
+            case kPcFinalWait: {
+                RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+                const RansacBest* h_best = R.h_best;
+                if (h_best->num_inliers != h_best->num_inliers_scan) return fail(c, RSDSFM_ERR_NUMERIC, "inlier count mismatch between scoring and compaction");
+                out->num_inliers = h_best->num_inliers;
+                out->best_trial = h_best->best_trial;
+                memcpy(out->w, &h_best->hyp[0], 3 * sizeof(double));
+                memcpy(out->v, &h_best->hyp[3], 3 * sizeof(double));
+                out->k = h_best->hyp[6];
+                out->inlier_error = h_best->inlier_error;
+                for (int t = 0; t < T; ++t) {
+                    if (out->trial_count) out->trial_count[t] = (int64_t)R.h_tcount[t];
+                    if (out->trial_err) out->trial_err[t] = R.h_terr[t];
+                    if (out->trial_vel) memcpy(out->trial_vel + (size_t)7 * t, R.h_hyp + (size_t)8 * t, 7 * sizeof(double));
+                    if (out->trial_steps) out->trial_steps[t] = depth_mode == RSDSFM_DEPTH_CERES_LM ? R.h_states[t].num_successful : 1;
+                }
+                if (R.spec_tail_held) *R.spec_tail_held = R.tail_enqueued;
+                // the scheduling hints of the context's NEXT solve (never a result).  A run the caller discards -- the frame solve's
+                // speculation on a dense flow that turned out to have dropped pixels ran on garbage -- leaves them alone.
+                R.hints_ready = true;
+                R.pc = kPcDone;
+                (void)Tn;
+                return RSDSFM_OK;
+            }
+            default:
+                return RSDSFM_OK;
+        }
+    }
+}
+
+}  // namespace
+
+void ransac_commit_hints(Ctx* c, const RansacRun& R) {
+    if (!R.hints_ready || R.depth_mode != RSDSFM_DEPTH_CERES_LM || R.T <= 0) return;
+    if (R.fused_base_next) c->ransac_fused_base = R.fused_base_next;
+    if (R.score_hint_next >= 0) c->ransac_score_hint = R.score_hint_next;
+    c->ransac_not_one_step = R.not_one_step;
+    c->ransac_spec_held_hint = R.spec_final ? 1 : 0;
+}
+
+int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n, int use_alpha_k, int T,
+                 double tol, const int32_t* h_samples, uint64_t seed, int depth_mode, int k_sign_mode, rsdsfm_ransac_out* out,
+                 const RansacSpecTail* spec_tail, bool* spec_tail_held, RansacRun* run, const Minimal9Direct* direct,
+                 const std::function<int()>* after_minimal9) {
+    RansacRun& R = *run;
+    R = RansacRun();
     if (spec_tail_held) *spec_tail_held = false;
     if (!out) return fail(c, RSDSFM_ERR_INVALID, "null out");
     if (n < 9) return fail(c, RSDSFM_ERR_INVALID, "ransac needs at least 9 points (the reference would compute rand() % 0)");
     if (T < 0) return fail(c, RSDSFM_ERR_INVALID, "negative iterations");
     if (depth_mode != RSDSFM_DEPTH_CLOSED_FORM && depth_mode != RSDSFM_DEPTH_CERES_LM) return fail(c, RSDSFM_ERR_INVALID, "unknown depth_mode");
     if (n > (int64_t)INT32_MAX) return fail(c, RSDSFM_ERR_INVALID, "n exceeds the int32 sample index range");
-    std::vector<int32_t> samples;
     if (T > 0) {
         if (h_samples) {
-            samples.assign(h_samples, h_samples + (size_t)T * 9);
-            for (int32_t s : samples)
+            R.samples.assign(h_samples, h_samples + (size_t)T * 9);
+            for (int32_t s : R.samples)
                 if (s < 0 || s >= n) return fail(c, RSDSFM_ERR_INVALID, "sample index out of range");
         } else {
-            sample_indices(n, T, seed, samples);
+            sample_indices(n, T, seed, R.samples);
         }
     }
     const int Tn = std::max(T, 1);
@@ -110,150 +305,59 @@ int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_
     int rc = ensure_ws(c, need);
     if (rc != RSDSFM_OK) return rc;
     Arena ws(c->d_ws);
-    double* d_hyp = ws.take<double>((size_t)Tn * 8);
+    R.d_hyp = ws.take<double>((size_t)Tn * 8);
     // states, scored and flags are adjacent so that ONE memset clears them
-    char* zero_begin = ws.base + ws.off;
-    LmState* d_states = ws.take<LmState>(Tn);
-    int* d_scored = ws.take<int>(Tn);
-    int* d_flags = ws.take<int>(8);  // {running, unscored, not finished with <= 1 accepted step, -, ended after 0 / 1 / 2 / >= 3 accepted steps}
-    const size_t zero_bytes = (size_t)((ws.base + ws.off) - zero_begin);
-    double* d_partials = ws.take<double>((size_t)ransac_lm_partials_doubles(c, n, batch));
-    double* d_tcount = ws.take<double>(Tn);
-    double* d_terr = ws.take<double>(Tn);
-    RansacBest* d_best = ws.take<RansacBest>(1);
-    int64_t* d_bcounts = ws.take<int64_t>(2048);
-    int64_t* d_boffs = ws.take<int64_t>(2048);
-    double* d_rho = out->inv_depth ? out->inv_depth : ws.take<double>((size_t)n);
-    uint8_t* d_mask = out->mask ? out->mask : ws.take<uint8_t>((size_t)n);
+    R.zero_begin = ws.base + ws.off;
+    R.d_states = ws.take<LmState>(Tn);
+    R.d_scored = ws.take<int>(Tn);
+    R.d_flags = ws.take<int>(8);  // {running, unscored, not finished with <= 1 accepted step, -, ended after 0 / 1 / 2 / >= 3 accepted steps}
+    R.zero_bytes = (size_t)((ws.base + ws.off) - R.zero_begin);
+    R.d_partials = ws.take<double>((size_t)ransac_lm_partials_doubles(c, n, batch));
+    R.d_tcount = ws.take<double>(Tn);
+    R.d_terr = ws.take<double>(Tn);
+    R.d_best = ws.take<RansacBest>(1);
+    R.d_bcounts = ws.take<int64_t>(2048);
+    R.d_boffs = ws.take<int64_t>(2048);
+    R.d_rho = out->inv_depth ? out->inv_depth : ws.take<double>((size_t)n);
+    R.d_mask = out->mask ? out->mask : ws.take<uint8_t>((size_t)n);
 
     rc = ensure_pinned(c, ransac_pinned_bytes(T));
     if (rc != RSDSFM_OK) return rc;
     char* hp = static_cast<char*>(c->h_pinned);
-    RansacBest* h_best = reinterpret_cast<RansacBest*>(hp);
-    int* h_running = reinterpret_cast<int*>(hp + sizeof(RansacBest));
-    double* h_tcount = reinterpret_cast<double*>(hp + sizeof(RansacBest) + 32);
-    double* h_terr = h_tcount + Tn;
-    double* h_hyp = h_terr + Tn;
-    LmState* h_states = reinterpret_cast<LmState*>(h_hyp + (size_t)8 * Tn);
+    R.h_best = reinterpret_cast<RansacBest*>(hp);
+    R.h_running = reinterpret_cast<int*>(hp + sizeof(RansacBest));
+    R.h_tcount = reinterpret_cast<double*>(hp + sizeof(RansacBest) + 32);
+    R.h_terr = R.h_tcount + Tn;
+    R.h_hyp = R.h_terr + Tn;
+    R.h_states = reinterpret_cast<LmState*>(R.h_hyp + (size_t)8 * Tn);
     // the sample table stays in host-mapped pinned memory: minimal9_kernel reads its 9 indices per hypothesis from there
-    int32_t* h_samples_pinned = reinterpret_cast<int32_t*>(h_states + Tn);
+    R.h_samples_pinned = reinterpret_cast<int32_t*>(R.h_states + Tn);
 
-    // (with T > 0 the region is cleared by the workgroups of minimal9_kernel: one launch less in front of the solver)
-    const bool zero_in_minimal9 = T > 0 && zero_bytes % 8 == 0 && (reinterpret_cast<uintptr_t>(zero_begin) & 7) == 0;
-    if (!zero_in_minimal9) RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
-    bool final_done = false, spec_scored = false;
+    R.d_q = d_q, R.d_u = d_u, R.d_a = d_a, R.d_ak = d_ak;
+    R.n = n, R.T = T, R.Tn = Tn, R.batch = batch, R.tol = tol, R.depth_mode = depth_mode, R.use_alpha_k = use_alpha_k, R.k_sign_mode = k_sign_mode;
+    R.out = out, R.spec_tail = spec_tail, R.spec_tail_held = spec_tail_held;
+    R.direct = direct, R.after_minimal9 = after_minimal9;
     // speculation depth of round 0 (see ransac_kernels.hip): explicit, or two iterations behind a solve none of whose hypotheses
     // went beyond one accepted step (outlier-dominated costs), three otherwise.  Like fused_base below: scheduling only.
-    const int k0 = c->ransac_k0 != 0 ? c->ransac_k0 : (c->ransac_not_one_step == 0 ? 2 : (int)KMAX);
+    R.k0 = c->ransac_k0 != 0 ? c->ransac_k0 : (c->ransac_not_one_step == 0 ? 2 : (int)KMAX);
     // the speculated iterate whose inlier score round 0 fuses: where most hypotheses of the context's previous solve ended (two
     // iterations can only confirm an end after ONE accepted step).  A scheduling decision: the results do not depend on it.
-    const int fused_base = k0 == 2 ? 1 : std::min(std::max(c->ransac_fused_base, 1), (int)KMAX);
-    int not_one_step = 0;
-    if (T > 0) {
-        memcpy(h_samples_pinned, samples.data(), sizeof(int32_t) * (size_t)T * 9);
-        rc = minimal9_launch(c, d_q, d_u, d_a, d_ak, h_samples_pinned, T, use_alpha_k, k_sign_mode, d_hyp, zero_in_minimal9 ? zero_begin : nullptr,
-                             zero_in_minimal9 ? zero_bytes : 0);
-        if (rc != RSDSFM_OK) return rc;
-        for (int b0 = 0; b0 < T; b0 += batch) {
-            const int B = std::min(batch, T - b0);
-            bool need_score = true;
-            if (depth_mode == RSDSFM_DEPTH_CERES_LM) {
-                if (b0 > 0) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_flags, 0, sizeof(int) * 8, c->stream));  // batch 0: cleared above
-                for (int round = 0;; ++round) {
-                    bool flags_via_pick = false;  // this round's flag words reach the host with the speculated pick kernel
-                    if (round > 4 * kMaxIter) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machines did not terminate");
-                    rc = ransac_lm_round_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, d_partials, d_flags,
-                                                d_scored + b0, d_tcount + b0, d_terr + b0, round, tol, k0, fused_base);
-                    if (rc != RSDSFM_OK) return rc;
-                    if (round == 0 && B == T) {
-                        // one batch, and on typical data every hypothesis is decided and scored by round 0: the final stage
-                        // (best trial, its rho + mask, compaction) is enqueued BEFORE the host reads the flags, which saves a
-                        // host round trip with an idle GPU; if the flags say otherwise its output is simply recomputed below.
-                        // Where the context's previous solve needed the separate scoring pass (noise-free data: every hypothesis
-                        // ends after three accepted steps, which round 0 does not score), that pass is enqueued ahead of the final
-                        // stage as well: it only touches hypotheses round 0 left unscored (a no-op on other data) and saves the
-                        // round trip plus a discarded final stage (~57 us).  What is enqueued when never changes a result.
-                        if (c->ransac_score_hint) {
-                            rc = ransac_score_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp, T, d_states, depth_mode, tol, d_scored, d_partials,
-                                                     d_tcount, d_terr);
-                            if (rc != RSDSFM_OK) return rc;
-                            spec_scored = true;
-                        }
-                        rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, h_best, d_flags, h_running);  // (+ the flag words)
-                        if (rc != RSDSFM_OK) return rc;
-                        flags_via_pick = true;
-                        rc = ransac_final_launch(c, d_q, d_u, d_a, d_ak, n, d_best, d_states, depth_mode, tol, d_rho, d_mask, d_bcounts,
-                                                 d_boffs, out->inlier_idx, out->inliers, out->alpha, out->alpha_k, h_best);
-                        if (rc != RSDSFM_OK) return rc;
-                        final_done = true;
-                        spec_final = true;
-                        if (spec_tail) {
-                            rc = (*spec_tail)(d_best);
-                            if (rc != RSDSFM_OK) return rc;
-                            tail_enqueued = true;
-                        }
-                    }
-                    if (!flags_via_pick) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_running, d_flags, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
-                    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-                    if (round == 0) {
-                        not_one_step += h_running[2];
-                        if (b0 == 0) {  // where this solve's hypotheses ended: the state the context's next solve fuses the score of
-                            int best = 0;
-                            for (int a2 = 1; a2 <= 3; ++a2)
-                                if (h_running[4 + a2] > (best ? h_running[4 + best] : 0)) best = a2;
-                            if (best) c->ransac_fused_base = best;
-                        }
-                    }
-                    if (h_running[0] == 0) break;
-                    final_done = false;  // more LM rounds: the speculated final stage saw incomplete trials
-                }
-                need_score = h_running[1] > 0;  // hypotheses whose final iterate is not the fused one-step state
-                if (B == T) c->ransac_score_hint = need_score ? 1 : 0;
-                if (need_score && final_done && spec_scored) need_score = false;  // round 0 decided everything and the pass already ran
-                if (need_score) final_done = false;
-            }
-            if (need_score) {
-                rc = ransac_score_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, depth_mode, tol,
-                                         depth_mode == RSDSFM_DEPTH_CERES_LM ? d_scored + b0 : nullptr, d_partials, d_tcount + b0,
-                                         d_terr + b0);
-                if (rc != RSDSFM_OK) return rc;
-            }
-        }
-    }
-    if (depth_mode == RSDSFM_DEPTH_CERES_LM && T > 0) c->ransac_not_one_step = not_one_step;
-    // best trial, its dense rho + mask, order-preserving compaction
-    if (!final_done) {
-        tail_enqueued = false;  // the speculated final stage (and whatever was enqueued behind it) saw incomplete trials
-        spec_final = false;
-        rc = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, h_best);  // h_best: host-mapped, written by the kernels
-        if (rc != RSDSFM_OK) return rc;
-        rc = ransac_final_launch(c, d_q, d_u, d_a, d_ak, n, d_best, d_states, depth_mode, tol, d_rho, d_mask, d_bcounts, d_boffs,
-                                 out->inlier_idx, out->inliers, out->alpha, out->alpha_k, h_best);
-        if (rc != RSDSFM_OK) return rc;
-    }
-    // per-trial diagnostics are copied back only when the caller asked for them (the frame solve does not)
-    if (T > 0 && out->trial_count) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_tcount, d_tcount, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
-    if (T > 0 && out->trial_err) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_terr, d_terr, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
-    if (T > 0 && out->trial_vel) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_hyp, d_hyp, sizeof(double) * 8 * T, hipMemcpyDeviceToHost, c->stream));
-    if (T > 0 && out->trial_steps && depth_mode == RSDSFM_DEPTH_CERES_LM)
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_states, d_states, sizeof(LmState) * T, hipMemcpyDeviceToHost, c->stream));
-    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    if (h_best->num_inliers != h_best->num_inliers_scan) return fail(c, RSDSFM_ERR_NUMERIC, "inlier count mismatch between scoring and compaction");
-    out->num_inliers = h_best->num_inliers;
-    out->best_trial = h_best->best_trial;
-    memcpy(out->w, &h_best->hyp[0], 3 * sizeof(double));
-    memcpy(out->v, &h_best->hyp[3], 3 * sizeof(double));
-    out->k = h_best->hyp[6];
-    out->inlier_error = h_best->inlier_error;
-    for (int t = 0; t < T; ++t) {
-        if (out->trial_count) out->trial_count[t] = (int64_t)h_tcount[t];
-        if (out->trial_err) out->trial_err[t] = h_terr[t];
-        if (out->trial_vel) memcpy(out->trial_vel + (size_t)7 * t, h_hyp + (size_t)8 * t, 7 * sizeof(double));
-        if (out->trial_steps) out->trial_steps[t] = depth_mode == RSDSFM_DEPTH_CERES_LM ? h_states[t].num_successful : 1;
-    }
-    if (spec_tail_held) *spec_tail_held = tail_enqueued;
-    if (depth_mode == RSDSFM_DEPTH_CERES_LM && T > 0) c->ransac_spec_held_hint = spec_final ? 1 : 0;
-    return RSDSFM_OK;
+    R.fused_base = R.k0 == 2 ? 1 : std::min(std::max(c->ransac_fused_base, 1), (int)KMAX);
+    R.pc = kPcStart;
+    return ransac_advance(c, R, true);
+}
+
+int ransac_finish(Ctx* c, RansacRun* run) { return ransac_advance(c, *run, false); }
+
+int ransac_device(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n,
+                  int use_alpha_k, int T, double tol, const int32_t* h_samples, uint64_t seed, int depth_mode,
+                  int k_sign_mode, rsdsfm_ransac_out* out, const RansacSpecTail* spec_tail, bool* spec_tail_held) {
+    RansacRun run;
+    int rc = ransac_begin(c, d_q, d_u, d_a, d_ak, n, use_alpha_k, T, tol, h_samples, seed, depth_mode, k_sign_mode, out, spec_tail, spec_tail_held,
+                          &run, nullptr, nullptr);
+    if (rc == RSDSFM_OK) rc = ransac_finish(c, &run);
+    if (rc == RSDSFM_OK) ransac_commit_hints(c, run);
+    return rc;
 }
 
 }  // namespace rsdsfm

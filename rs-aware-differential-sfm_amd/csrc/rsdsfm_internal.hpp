@@ -6,6 +6,7 @@
 
 #include <functional>
 #include <string>
+#include <vector>
 
 #include "../../include/rsdsfm.h"
 
@@ -131,8 +132,18 @@ struct Ctx {
     size_t claim_words[3] = {0, 0, 0};
     unsigned claim_epoch[3] = {0, 0, 0};
     void* dist = nullptr;  // dist_host.hip: communicator / transport + exchange buffers of the native tiled solve
+    // frame_host.hip: the frame solve in flight (FrameRun), the second stream that runs the flatten beside the minimal solver, and the
+    // lanes (contexts of their own, owned by this one) of the sequence solve
+    void* frame_run = nullptr;
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_seq = nullptr;
+    bool frame_side_flatten = true;  // rsdsfm_set_frame_side_flatten: dense frames run the flatten on aux_stream beside the minimal solver
+    int seq_lanes = 0;               // rsdsfm_set_sequence_lanes (0 = kSequenceLanesDefault)
+    std::vector<rsdsfm_ctx*> lanes;
 };
+constexpr int kSequenceLanesDefault = 4;
 void dist_release(Ctx* c);
+void frame_release(Ctx* c);
 
 constexpr int kDepthBlock = 256;
 constexpr int kDepthMaxBlocks = 512;
@@ -239,9 +250,18 @@ int zsum_row_launch(Ctx* c, const double* d_inl, int64_t m, double* d_partials, 
 
 namespace rsdsfm {
 // minimal9_kernels.hip : hyp_out [T][8] = w(3), v(3), k, status
+// Minimal9Direct: the sampled points are formed straight from the flow IMAGE instead of the flattened arrays -- valid when the
+// flatten keeps every pixel (dense flow), so that point index i is pixel (column i / rows, row i % rows) of the column-major scan
+// (main.cc:398-444); the expressions are the flatten's own (device_math.hpp: flatten_point), so the hypotheses have the same bits.
+// The frame solve uses it to run the minimal solver BESIDE the flatten instead of behind it.
+struct Minimal9Direct {
+    const double* img = nullptr;  // row-major [rows][cols][2] flow image (DEVICE)
+    int rows = 0, cols = 0, alpha_ones = 0;  // alpha_ones: the global-shutter override alpha = alpha * 0 + 1 (main.cc:441-444)
+    double fx = 0, fy = 0, cx = 0, cy = 0, gamma = 0;
+};
 int minimal9_launch(Ctx* c, const double* q, const double* u, const double* alpha, const double* alpha_k,
                     const int32_t* samples, int T, int use_alpha_k, int k_sign_mode, double* hyp_out, void* zero_begin = nullptr,
-                    size_t zero_bytes = 0);
+                    size_t zero_bytes = 0, const Minimal9Direct* direct = nullptr);
 }  // namespace rsdsfm
 
 namespace rsdsfm {
@@ -307,10 +327,51 @@ struct RefineBuffers {
     double* zpartials = nullptr;  // frame solve: refine_finish_kernel also leaves its per-workgroup sums of z here (refine_finish_grid entries)
 };
 size_t ransac_pinned_bytes(int T);
-int flatten_enqueue(Ctx* c, const double* d_img, int32_t rows, int32_t cols, double fx, double fy, double cx, double cy, double gamma,
-                    double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* h_total);
 // see ransac_device (ransac_host.hip): caller's work enqueued behind the speculated final stage, given the device-resident result
 typedef std::function<int(const RansacBest*)> RansacSpecTail;
+// one RANSAC in flight (ransac_host.hip: ransac_begin / ransac_finish): everything the resumable state machine keeps between its steps
+struct RansacRun {
+    int pc = 0;
+    // problem
+    const double *d_q = nullptr, *d_u = nullptr, *d_a = nullptr, *d_ak = nullptr;
+    int64_t n = 0;
+    int T = 0, Tn = 1, batch = 1, depth_mode = 0, use_alpha_k = 0, k_sign_mode = 0, k0 = 0, fused_base = 0;
+    double tol = 0.0;
+    rsdsfm_ransac_out* out = nullptr;
+    const RansacSpecTail* spec_tail = nullptr;
+    bool* spec_tail_held = nullptr;
+    const Minimal9Direct* direct = nullptr;
+    const std::function<int()>* after_minimal9 = nullptr;
+    std::vector<int32_t> samples;
+    // workspace (device) and pinned host views
+    double *d_hyp = nullptr, *d_partials = nullptr, *d_tcount = nullptr, *d_terr = nullptr, *d_rho = nullptr;
+    char* zero_begin = nullptr;
+    size_t zero_bytes = 0;
+    LmState* d_states = nullptr;
+    int *d_scored = nullptr, *d_flags = nullptr;
+    RansacBest* d_best = nullptr;
+    int64_t *d_bcounts = nullptr, *d_boffs = nullptr;
+    uint8_t* d_mask = nullptr;
+    RansacBest* h_best = nullptr;
+    int* h_running = nullptr;
+    double *h_tcount = nullptr, *h_terr = nullptr, *h_hyp = nullptr;
+    LmState* h_states = nullptr;
+    int32_t* h_samples_pinned = nullptr;
+    // progress
+    int b0 = 0, B = 0, round = 0;
+    bool need_score = true, final_done = false, spec_scored = false, tail_enqueued = false, spec_final = false;
+    // scheduling hints this run leaves for the context's next solve (ransac_commit_hints)
+    int not_one_step = 0, fused_base_next = 0, score_hint_next = -1;
+    bool hints_ready = false;
+};
+int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n, int use_alpha_k, int T,
+                 double tol, const int32_t* h_samples, uint64_t seed, int depth_mode, int k_sign_mode, rsdsfm_ransac_out* out,
+                 const RansacSpecTail* spec_tail, bool* spec_tail_held, RansacRun* run, const Minimal9Direct* direct,
+                 const std::function<int()>* after_minimal9);
+int ransac_finish(Ctx* c, RansacRun* run);
+void ransac_commit_hints(Ctx* c, const RansacRun& run);
+int flatten_enqueue(Ctx* c, const double* d_img, int32_t rows, int32_t cols, double fx, double fy, double cx, double cy, double gamma,
+                    double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* h_total);
 // see refine_device (refine_host.hip): caller's work enqueued behind the refinement's output pass, given the device-resident state
 typedef std::function<int(const RefineBuffers&)> RefineTail;
 int refine_finish_grid(const Ctx* c, const RefineBuffers& B);

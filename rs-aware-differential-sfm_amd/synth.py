@@ -54,7 +54,7 @@ def scene_depth(rows, cols):
     return 1.0 + 0.35 * np.sin(2 * np.pi * 1.3 * x / cols) * np.cos(2 * np.pi * 0.9 * y / rows) + 0.25 * (x / cols)
 
 
-def make_flow(rows, cols, K, v, w, k=0.0, gamma=0.8, noise_px=0.0, outliers=0.0, seed=0x5EED0000, depth=None):
+def make_flow(rows, cols, K, v, w, k=0.0, gamma=0.8, noise_px=0.0, outliers=0.0, seed=0x5EED0000, depth=None, _model_only=False):
     """Dense model-consistent RS flow image (rows, cols, 2) in pixels, row-major, plus ground truth.
 
     Model (minimal.cc:257-266):  u = beta (A v rho + B w),  u = flow_px * gamma / f,
@@ -92,6 +92,19 @@ def make_flow(rows, cols, K, v, w, k=0.0, gamma=0.8, noise_px=0.0, outliers=0.0,
     beta = 2.0 * (alpha + k * alpha_k) / (2.0 + k)
     fxx = beta * m0 * fx / gamma
     flow = np.stack([fxx, fyy], axis=-1)
+    truth = dict(v=v, w=w, k=float(k), gamma=float(gamma), Z=Z, K=K)
+    if _model_only:
+        return np.ascontiguousarray(flow), truth
+    flow, outlier_mask = add_noise(flow, noise_px, outliers, seed)
+    truth["outlier_mask"] = outlier_mask
+    return np.ascontiguousarray(flow), truth
+
+
+def add_noise(flow, noise_px, outliers, seed):
+    """DeepFlow-like degradation of a model flow field: Gaussian noise (pixels) and a fraction of uniform +-30 px outliers, both from
+    splitmix64(seed) -- the second half of make_flow, callable on its own so that a SEQUENCE of pairs (one noise seed each) shares
+    the model field.  Returns (flow, outlier mask)."""
+    rows, cols = flow.shape[:2]
     n = rows * cols
     if noise_px > 0.0:
         flow = flow + noise_px * normal(seed + 1, 2 * n).reshape(rows, cols, 2)
@@ -100,8 +113,18 @@ def make_flow(rows, cols, K, v, w, k=0.0, gamma=0.8, noise_px=0.0, outliers=0.0,
         outlier_mask = uniform01(seed + 2, n).reshape(rows, cols) < outliers
         rnd = (uniform01(seed + 3, 2 * n).reshape(rows, cols, 2) * 2.0 - 1.0) * 30.0
         flow = np.where(outlier_mask[..., None], rnd, flow)
-    truth = dict(v=v, w=w, k=float(k), gamma=float(gamma), Z=Z, outlier_mask=outlier_mask, K=K)
-    return np.ascontiguousarray(flow), truth
+    return flow, outlier_mask
+
+
+def make_flow_sequence(cfg, seeds):
+    """flow images (rows, cols, 2) of BASELINE config `cfg` for several data seeds: the same scene and motion, one noise / outlier
+    realisation per seed (each identical to make_config(cfg, seed=s)["flow_img"]); the model field is computed once"""
+    c = CONFIGS[cfg]
+    v, w, k = default_motion()
+    K = INTRINSICS[c["K"]]
+    base, truth = make_flow(c["rows"], c["cols"], K, v, w, k, c["gamma"], _model_only=True)
+    imgs = [np.ascontiguousarray(add_noise(base, c["noise_px"], c["outliers"], s_)[0]) for s_ in seeds]
+    return imgs, dict(rows=c["rows"], cols=c["cols"], K=K, gamma=c["gamma"], truth=truth)
 
 
 def flatten_numpy(flow_img, K, gamma, thr=1e-10):

@@ -174,6 +174,127 @@ def test_solve_does_not_depend_on_the_contexts_history(rsdsfm):
             assert solve(s, k) == fresh[k], k
 
 
+def test_side_flatten_and_direct_minimal_solver_do_not_change_results(rsdsfm):
+    """a dense frame forms the minimal solver's sampled points straight from the flow image (the flatten's own expressions) and runs
+    the flatten beside the solver on a second stream; switching that off (flatten first, on the context's stream) returns the same
+    bits -- rolling and global shutter, k estimated or not, and a frame with dropped pixels (which takes the fallback either way)"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(11)
+    for cfg, kw in ((5, {}), (3, dict(use_global_shutter_mode=True)), (5, dict(use_acceleration_mode=True)), (1, dict(trials=0)), (3, dict(hole=True))):
+        kw = dict(kw)
+        d = rsdsfm.synth.make_config(cfg, rows=130, cols=210)
+        img_h = d["flow_img"].copy()
+        if kw.pop("hole", False):
+            img_h[40:70, 100:140] = 0.0
+        img = torch.from_numpy(img_h).to(dev)
+        rows, cols = d["rows"], d["cols"]
+        outs = []
+        for side in (True, False):
+            with rsdsfm.Solver(0) as s:
+                s.set_frame_side_flatten(side)
+                got = []
+                for rep in range(3):  # (the first solve of a context already assumes a dense frame)
+                    dm = torch.zeros((cols, rows), dtype=torch.float64, device=dev)
+                    R = torch.zeros((rows, 9), dtype=torch.float64, device=dev)
+                    r = s.solve_frame_dev(img.data_ptr(), rows, cols, d["K"], d["gamma"], dm.data_ptr(), R.data_ptr(), 0,
+                                          **dict(dict(trials=12, tol=0.01, seed=3 + rep), **kw))
+                    s.synchronize()
+                    got.append((r["n"], r["num_inliers"], r["best_trial"], r["ransac_v"].tobytes(), r["ransac_w"].tobytes(), r["ransac_k"], r["v"].tobytes(),
+                                r["w"].tobytes(), r["k"], r["refine_summary"]["final_cost"], dm.cpu().numpy().tobytes(), R.cpu().numpy().tobytes()))
+                outs.append(got)
+        assert outs[0] == outs[1], (cfg, kw)
+
+
+def test_sequence_solve_equals_single_solves(rsdsfm):
+    """rsdsfm_solve_frames_dev: pairs of different sizes, data kinds and data seeds (dense, with dropped pixels, noise-free, DeepFlow-like)
+    pipelined over 1 / 2 / 3 / 4 lanes return, pair by pair, the bits of rsdsfm_solve_frame_dev on a fresh context -- which lane a pair
+    runs on, what ran before it there and what runs beside it decides when its kernels run, never what they compute"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    frames = []
+    shapes = [(150, 260), (96, 250), (150, 260), (200, 120)]
+    for i in range(11):
+        cfg = (5, 1, 3)[i % 3]
+        rows, cols = shapes[i % 4]
+        d = rsdsfm.synth.make_config(cfg, rows=rows, cols=cols, seed=0x5EED0100 + i)
+        img_h = d["flow_img"].copy()
+        if i in (4, 5, 9):
+            img_h[10:30, 20 + i:50 + i] = 0.0  # pixels without flow: the flatten drops them, the speculation on a dense frame fails
+        frames.append((d, img_h))
+    kw = dict(trials=16, tol=0.01)
+    seeds = [7 + 3 * i for i in range(len(frames))]
+
+    def record(r, dm, R):
+        return (int(r["n"]), int(r["num_inliers"]), int(r["best_trial"]), bool(r["flipped"]), r["v"].tobytes(), r["w"].tobytes(), float(r["k"]),
+                r["refine_summary"]["num_iterations"], r["refine_summary"]["final_cost"], dm.cpu().numpy().tobytes(), R.cpu().numpy().tobytes())
+
+    with torch.cuda.stream(stream):
+        bufs = []
+        for d, img_h in frames:
+            rows, cols = d["rows"], d["cols"]
+            bufs.append(dict(img=torch.from_numpy(img_h).to(dev), dm=torch.zeros((cols, rows), dtype=torch.float64, device=dev),
+                             R=torch.zeros((rows, 9), dtype=torch.float64, device=dev), t=torch.zeros((rows, 3), dtype=torch.float64, device=dev)))
+        fresh = []
+        for (d, _), b, sd in zip(frames, bufs, seeds):
+            with rsdsfm.Solver(0, stream=stream.cuda_stream) as s:
+                r = s.solve_frame_dev(b["img"].data_ptr(), d["rows"], d["cols"], d["K"], d["gamma"], b["dm"].data_ptr(), b["R"].data_ptr(), b["t"].data_ptr(), seed=sd, **kw)
+                s.synchronize()
+                fresh.append(record(r, b["dm"], b["R"]))
+        assert len({f[0] for f in fresh}) > 3 and any(f[0] != d["rows"] * d["cols"] for f, (d, _) in zip(fresh, frames))
+        jobs = [dict(d_flow_img=b["img"].data_ptr(), rows=d["rows"], cols=d["cols"], K=d["K"], gamma=d["gamma"], d_depth_map=b["dm"].data_ptr(),
+                     d_R=b["R"].data_ptr(), d_t=b["t"].data_ptr()) for (d, _), b in zip(frames, bufs)]
+        for lanes in (1, 2, 3, 4):
+            with rsdsfm.Solver(0, stream=stream.cuda_stream) as s:
+                s.set_sequence_lanes(lanes)
+                for rep in range(2):  # the second pass meets warm lanes (hints of other pairs)
+                    for b in bufs:
+                        b["dm"].zero_(), b["R"].zero_()
+                    res = s.solve_frames_dev(jobs, seeds, **kw)
+                    s.synchronize()
+                    got = [record(r, b["dm"], b["R"]) for r, b in zip(res, bufs)]
+                    assert got == fresh, (lanes, rep, [i for i in range(len(got)) if got[i] != fresh[i]])
+        # errors surface: a pair with fewer than 9 points fails the call like the single solve does
+        tiny = torch.zeros((3, 3, 2), dtype=torch.float64, device=dev)
+        bad = dict(jobs[0], d_flow_img=tiny.data_ptr(), rows=3, cols=3)
+        with rsdsfm.Solver(0, stream=stream.cuda_stream) as s:
+            with pytest.raises(rsdsfm.RsdsfmError):
+                s.solve_frames_dev([jobs[1], bad, jobs[2]], [1, 2, 3], **kw)
+            r = s.solve_frames_dev([jobs[1]], [seeds[1]], **kw)  # the context stays usable
+            s.synchronize()
+            assert record(r[0], bufs[1]["dm"], bufs[1]["R"]) == fresh[1]
+
+
+def test_frame_params_struct_bytes_is_checked(rsdsfm):
+    """rsdsfm_frame_params_init fills the reference's constants and stamps the struct size; a struct from another header layout
+    (round 1's: ransac_tol where struct_bytes now sits) is refused instead of being misread"""
+    import ctypes as C
+
+    import torch
+
+    lib = rsdsfm.load_library()
+    p = rsdsfm.FrameParams()
+    lib.rsdsfm_frame_params_init.restype = None
+    lib.rsdsfm_frame_params_init(C.byref(p))
+    assert (p.ransac_trials, p.use_refinement, p.flow_index_mode, p.use_global_shutter_mode) == (5, 1, rsdsfm.FLOW_COMPAT_RANK, 0)
+    assert p.struct_bytes == C.sizeof(rsdsfm.FrameParams) and p.ransac_tol == 0.05 and p.flow_threshold == 1e-10
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(5, rows=64, cols=80)
+    img = torch.from_numpy(d["flow_img"]).to(dev)
+    dm = torch.zeros((80, 64), dtype=torch.float64, device=dev)
+    res = rsdsfm.FrameResult()
+    dd = C.c_double
+    with rsdsfm.Solver(0) as s:
+        args = (s._ctx, C.c_void_p(img.data_ptr()), C.c_int32(64), C.c_int32(80), dd(d["K"][0]), dd(d["K"][1]), dd(d["K"][2]), dd(d["K"][3]), dd(d["gamma"]))
+        assert lib.rsdsfm_solve_frame_dev(*args, C.byref(p), C.c_void_p(dm.data_ptr()), None, None, C.byref(res)) == 0
+        p.struct_bytes = C.sizeof(rsdsfm.FrameParams) - 8
+        assert lib.rsdsfm_solve_frame_dev(*args, C.byref(p), C.c_void_p(dm.data_ptr()), None, None, C.byref(res)) != 0
+        assert b"struct_bytes" in lib.rsdsfm_last_error(s._ctx)
+
+
 def test_concurrent_contexts_do_not_interfere(oracle, rsdsfm):
     """the sequence-throughput mode of bench.py: several contexts on separate streams, (a) one host thread interleaving
     asynchronous depth solves of DIFFERENT problems, (b) one host thread per context running whole-frame solves -- every

@@ -34,6 +34,7 @@ extern "C" {
 #define RSDSFM_ERR_NO_DEVICE (-3)   /* no usable gfx950 device */
 #define RSDSFM_ERR_NUMERIC (-4)     /* solver failure (singular system, no real k, LM failure) */
 #define RSDSFM_ERR_PENDING (-5)     /* device LM state machine needs more launches (see rsdsfm_depth_finish_dev) */
+#define RSDSFM_ERR_PEER (-6)        /* tiled solve: ANOTHER rank failed while setting up its part; every rank returns together */
 
 /* depth_mode */
 #define RSDSFM_DEPTH_CLOSED_FORM 0  /* exact per-pixel least-squares optimum (one undamped GN step from rho=1) */
@@ -275,11 +276,14 @@ typedef struct rsdsfm_frame_job {
 } rsdsfm_frame_job;
 int rsdsfm_solve_frames_dev(rsdsfm_ctx* ctx, const rsdsfm_frame_job* jobs, int32_t count, const rsdsfm_frame_params* params,
                             rsdsfm_frame_result* results);
-/* pairs in flight of rsdsfm_solve_frames_dev: 1 .. 16, 0 = default (4).  Scheduling only. */
+/* pairs in flight of rsdsfm_solve_frames_dev: 1 .. 16, 0 = default (3).  Scheduling only. */
 int rsdsfm_set_sequence_lanes(rsdsfm_ctx* ctx, int32_t lanes);
-/* 1 (default): a frame whose predecessor on the context was dense forms the minimal solver's sampled points straight from the flow
- * image and runs the flatten beside the solver on a second stream; 0: flatten first, on the context's stream.  Scheduling only. */
-int rsdsfm_set_frame_side_flatten(rsdsfm_ctx* ctx, int on);
+/* Where the flatten of a frame runs whose predecessor on the context was dense (every pixel kept, so that point i IS pixel
+ * (i / rows, i % rows) and the minimal solver can form its sampled points straight from the flow image): 0 (default) = in front
+ * of the minimal solver (which reads the flattened arrays), 1 = beside it on a second stream, 2 = behind it on the context's stream.
+ * Measured on MI355X (1280x720, T = 50, median of 60 solves): 0.977 / 0.995 / 0.986 ms -- the cross-stream join costs more than the
+ * 21 us of flatten kernels it hides, and with the solver first the host's sampler is exposed in front of it.  Scheduling only. */
+int rsdsfm_set_frame_side_flatten(rsdsfm_ctx* ctx, int mode);
 /* minimal::ransac on device-resident inputs.  The arrays of `out` (inlier_idx, inliers, alpha, alpha_k, mask,
  * inv_depth) are DEVICE pointers with capacity n (each may be NULL); its trial_* arrays are HOST pointers.
  * samples_9xT_or_null is a HOST pointer.  Synchronises once at the end to return the scalars of `out`. */

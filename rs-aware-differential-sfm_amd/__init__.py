@@ -511,13 +511,13 @@ class Solver:
         return call
 
     def set_sequence_lanes(self, lanes):
-        """pairs in flight of solve_frames_dev (rsdsfm_set_sequence_lanes): 1..16, 0 = default (4); scheduling only"""
+        """pairs in flight of solve_frames_dev (rsdsfm_set_sequence_lanes): 1..16, 0 = default (3); scheduling only"""
         self._check(self.lib.rsdsfm_set_sequence_lanes(self._ctx, C.c_int32(int(lanes))), "rsdsfm_set_sequence_lanes")
 
     def set_frame_side_flatten(self, on):
-        """True (default): dense frames form the minimal solver's points straight from the flow image and run the flatten beside it on
-        a second stream (rsdsfm_set_frame_side_flatten); scheduling only"""
-        self._check(self.lib.rsdsfm_set_frame_side_flatten(self._ctx, int(bool(on))), "rsdsfm_set_frame_side_flatten")
+        """where a dense frame's flatten runs (rsdsfm_set_frame_side_flatten): 0 (default) in front of the minimal solver, 1 beside it on
+        a second stream, 2 behind it (1, 2: the solver forms its sampled points straight from the flow image); scheduling only"""
+        self._check(self.lib.rsdsfm_set_frame_side_flatten(self._ctx, int(on)), "rsdsfm_set_frame_side_flatten")
 
     def prepared_frames_solve(self, jobs, trials=50, tol=0.05, use_acceleration_mode=False, use_refinement=True, depth_mode=DEPTH_CERES_LM,
                               k_sign_mode=K_COMPAT, flow_threshold=1e-10, flow_index_mode=FLOW_COMPAT_RANK, use_global_shutter_mode=False):

@@ -23,13 +23,13 @@
 // owns an ncclComm_t).  rsdsfm_dist_set_transport installs caller-provided collectives instead (used by the tests to run several
 // logical ranks on one GPU, and by hosts with another communication library).
 #include <dlfcn.h>
-#include <rccl/rccl.h>
 #include <string.h>
 
 #include <algorithm>
 #include <mutex>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "rsdsfm_internal.hpp"
 
@@ -44,11 +44,26 @@ namespace {
 // ---------------------------------------------------------------------------------------------------
 // RCCL, resolved at run time
 // ---------------------------------------------------------------------------------------------------
+// The handful of RCCL / NCCL 2.x ABI types the driver uses, declared here so that the library BUILDS without the RCCL headers as
+// well (it already loads without the library): values as in rccl.h / nccl.h (ncclSuccess 0; ncclInt8 = ncclChar 0, ncclFloat64 =
+// ncclDouble 8; ncclSum 0; NCCL_UNIQUE_ID_BYTES 128; the communicator is an opaque pointer).
+typedef struct ncclComm* ncclComm_t;
+typedef struct {
+    char internal[128];
+} ncclUniqueId;
+typedef int ncclResult_t;
+typedef int ncclDataType_t;
+typedef int ncclRedOp_t;
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclChar = 0, ncclDouble = 8;
+constexpr ncclRedOp_t ncclSum = 0;
+
 struct Rccl {
     void* handle = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -83,6 +98,7 @@ Rccl* rccl() {
         R.GetUniqueId = reinterpret_cast<decltype(R.GetUniqueId)>(sym("ncclGetUniqueId"));
         R.CommInitRank = reinterpret_cast<decltype(R.CommInitRank)>(sym("ncclCommInitRank"));
         R.CommDestroy = reinterpret_cast<decltype(R.CommDestroy)>(sym("ncclCommDestroy"));
+        R.CommAbort = reinterpret_cast<decltype(R.CommAbort)>(sym("ncclCommAbort"));
         R.AllGather = reinterpret_cast<decltype(R.AllGather)>(sym("ncclAllGather"));
         R.AllReduce = reinterpret_cast<decltype(R.AllReduce)>(sym("ncclAllReduce"));
         R.GetErrorString = reinterpret_cast<decltype(R.GetErrorString)>(sym("ncclGetErrorString"));
@@ -110,6 +126,8 @@ struct Dist {
     size_t session_bytes = 0;
     void* d_flow = nullptr;  // rank-indexed flow (quirk Q2): the gathered heads of the slabs' flow lists + this rank's columns
     size_t flow_bytes = 0;
+    void* d_xchg = nullptr;  // {point count, setup status} of every rank: allocated apart from (and before) everything that can fail
+    size_t xchg_bytes = 0;
     int host_syncs = 0, collectives = 0, ransac_rounds = 0;  // diagnostics of the last solve
 };
 
@@ -233,6 +251,7 @@ void dist_release(Ctx* c) {
     if (D->d_buf) (void)hipFree(D->d_buf);
     if (D->d_session) (void)hipFree(D->d_session);
     if (D->d_flow) (void)hipFree(D->d_flow);
+    if (D->d_xchg) (void)hipFree(D->d_xchg);
     delete D;
     c->dist = nullptr;
 }
@@ -264,8 +283,14 @@ int rsdsfm_dist_init(rsdsfm_ctx* ctx, int32_t nranks, int32_t rank, const void* 
     D->comm = nullptr;
     ncclUniqueId id;
     memcpy(&id, id_128_bytes, sizeof(id));
+    D->nranks = 1, D->rank = 0, D->own_comm = false;  // (what a failed init leaves behind: a single rank without communicator)
+    D->ag = nullptr;
+    D->ar = nullptr;
     ncclResult_t r = R->CommInitRank(&D->comm, nranks, id, rank);  // on the context's device (made current by the guard)
-    if (r != ncclSuccess) return nccl_fail(c, r, "ncclCommInitRank");
+    if (r != ncclSuccess) {
+        D->comm = nullptr;
+        return nccl_fail(c, r, "ncclCommInitRank");
+    }
     D->own_comm = true;
     D->nranks = nranks;
     D->rank = rank;
@@ -351,7 +376,6 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
     rsdsfm_tiled_slab_bounds(cols, R, rank, &col0, &sc, &per);
     const size_t Ns = (size_t)rows * (size_t)sc;      // pixels of this slab
     const size_t cap = (size_t)rows * (size_t)per;     // pixels of a full-width slab (all-gather stride)
-    if (Ns > 0 && !d_img_slab) return fail(c, RSDSFM_ERR_INVALID, "null slab pointer");
     const size_t N1 = std::max<size_t>(Ns, 1);
     const int Tn = std::max(T, 1);
     const int batch = std::min(Tn, kRansacBatch);
@@ -362,8 +386,15 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
     // ---- frame buffers of the slab (context arena shared with rsdsfm_solve_frame_dev) ----
     const size_t need_frame = 2 * Arena::need(16 * N1) + 5 * Arena::need(8 * N1) + 2 * Arena::need(24 * N1) + Arena::need(8 * N1) + Arena::need(N1) +
                               Arena::need(4 * N1) + 4096;
-    int rc = ensure_dev(c, &c->d_frame, &c->frame_bytes, need_frame);
+    // A failure that only THIS rank sees (an allocation, a null slab pointer) must not leave the other ranks waiting in the next
+    // collective for ever: everything that can fail locally happens in this setup part, its outcome travels with the point counts in
+    // the first exchange, and every rank leaves together (RSDSFM_ERR_PEER on the ranks that were fine).  The exchange buffer itself
+    // is allocated first and apart; buffers whose size depends on later results are sized by their upper bounds here.
+    int rc = ensure_dev(c, &D->d_xchg, &D->xchg_bytes, Arena::need(16 * (size_t)R + 64));
     if (rc != RSDSFM_OK) return rc;
+    int64_t* d_xchg = static_cast<int64_t*>(D->d_xchg);  // [R][2] = {point count, setup status}
+    if (Ns > 0 && !d_img_slab) rc = fail(c, RSDSFM_ERR_INVALID, "null slab pointer");
+    if (rc == RSDSFM_OK) rc = ensure_dev(c, &c->d_frame, &c->frame_bytes, need_frame);
     Arena fa(c->d_frame);
     double* d_q = fa.take<double>(2 * N1);
     double* d_u = fa.take<double>(2 * N1);
@@ -384,8 +415,7 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
                     Arena::need(sizeof(LmState) * Tn) + Arena::need(4 * (size_t)Tn) + Arena::need(64) + 2 * Arena::need(8 * (size_t)Tn) +
                     2 * Arena::need(sizeof(RansacBest)) + Arena::need(8 * (size_t)row_max) + Arena::need(8 * (size_t)row_max * R) + Arena::need(64) +
                     Arena::need(8 * (size_t)R + 64) + Arena::need(64) + (padded ? Arena::need(8 * cap * R) : 0) + 4096;
-    rc = ensure_dev(c, &D->d_buf, &D->bytes, need_d);
-    if (rc != RSDSFM_OK) return rc;
+    if (rc == RSDSFM_OK) rc = ensure_dev(c, &D->d_buf, &D->bytes, need_d);
     Arena da(D->d_buf);
     int64_t* d_cnt_all = da.take<int64_t>((size_t)R + 8);
     int64_t* d_m_all = da.take<int64_t>((size_t)R + 8);
@@ -413,10 +443,18 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
     const size_t ws_need = std::max({2 * Arena::need(sizeof(int64_t) * ncells),
                                      Arena::need(sizeof(double) * (size_t)ransac_lm_partials_doubles(c, (int64_t)N1, batch)) + 2 * Arena::need(sizeof(int64_t) * 2048),
                                      Arena::need(8 * cap) + Arena::need(8 * 1024)}) + 4096;
-    rc = ensure_ws(c, ws_need);
-    if (rc != RSDSFM_OK) return rc;
-    rc = ensure_pinned(c, sizeof(RansacBest) + 64 + 8 * (size_t)R * 2 + 64 + sizeof(RefineState) + 64 + sizeof(int32_t) * 9 * (size_t)Tn + 64);
-    if (rc != RSDSFM_OK) return rc;
+    if (rc == RSDSFM_OK) rc = ensure_ws(c, ws_need);
+    if (rc == RSDSFM_OK)
+        rc = ensure_pinned(c, sizeof(RansacBest) + 64 + 8 * (size_t)R * 2 + 64 + sizeof(RefineState) + 64 + sizeof(int32_t) * 9 * (size_t)Tn + 64 + 16 * (size_t)R + 64);
+    // the refinement's session (sized for every point of the slab an inlier), the rank-indexed flow exchange (quirk Q2: at most the
+    // whole flow list of every slab + this slab's columns) and the depth map's claim words
+    const size_t npart_cap = (size_t)refine_partials_doubles(c, (int64_t)N1);
+    if (rc == RSDSFM_OK && prm->use_refinement)
+        rc = ensure_dev(c, &D->d_session, &D->session_bytes, Arena::need(sizeof(RefineState) + 64) + Arena::need(32 * N1) + 4 * Arena::need(8 * N1) + Arena::need(8 * npart_cap) + 1024);
+    if (rc == RSDSFM_OK && prm->use_refinement && prm->flow_index_mode == RSDSFM_FLOW_COMPAT_RANK && R > 1)
+        rc = ensure_dev(c, &D->d_flow, &D->flow_bytes, Arena::need(16 * std::max<size_t>(cap, 1) * R) + Arena::need(16 * N1) + 1024);
+    if (rc == RSDSFM_OK) rc = claim_map_reserve(c, 2, N1);
+    const int setup_rc = rc;
     char* hp = static_cast<char*>(c->h_pinned);
     RansacBest* h_best = reinterpret_cast<RansacBest*>(hp);
     int* h_flags = reinterpret_cast<int*>(hp + sizeof(RansacBest));
@@ -428,23 +466,31 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
     int32_t* h_samples = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(h_state) + sizeof(RefineState) + 64);
 
     memset(res, 0, sizeof(*res));
-    // ---- flatten of the slab; point counts of all slabs ----
-    if (Ns > 0) {
+    // ---- flatten of the slab; point counts + setup status of all slabs ----
+    std::vector<int64_t> h_xchg(2 * (size_t)R + 2, 0);  // (pageable on purpose: it must exist even when the pinned block could not grow)
+    h_xchg[1] = setup_rc;
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_xchg + 2 * rank, h_xchg.data(), 2 * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));  // {0, status}
+    if (setup_rc == RSDSFM_OK && Ns > 0) {
         Arena ws(c->d_ws);
         int64_t* d_counts = ws.take<int64_t>(ncells);
         int64_t* d_offsets = ws.take<int64_t>(ncells);
         rc = flatten_launch(c, d_img_slab, rows, sc, col0, fx, fy, cx, cy, gamma, prm->flow_threshold, d_q, d_u, d_a, d_ak, d_counts, d_offsets,
-                            d_cnt_all + rank, nullptr);
+                            d_xchg + 2 * rank, nullptr);
         if (rc != RSDSFM_OK) return rc;
-    } else {
-        RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_cnt_all + rank, 0, sizeof(int64_t), c->stream));
     }
-    rc = all_gather(c, D, d_cnt_all + rank, d_cnt_all, sizeof(int64_t));
+    rc = all_gather(c, D, d_xchg + 2 * rank, d_xchg, 2 * sizeof(int64_t));
     if (rc != RSDSFM_OK) return rc;
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_cnt, d_cnt_all, sizeof(int64_t) * R, hipMemcpyDeviceToHost, c->stream));
-    RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_xchg.data(), d_xchg, 2 * sizeof(int64_t) * R, hipMemcpyDeviceToHost, c->stream));
+    if (setup_rc == RSDSFM_OK) RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
     rc = sync(c, D);
     if (rc != RSDSFM_OK) return rc;
+    for (int r = 0; r < R; ++r)
+        if (h_xchg[2 * (size_t)r + 1] != 0) {
+            if (setup_rc != RSDSFM_OK) return setup_rc;  // (this rank's own message is in place)
+            return fail(c, RSDSFM_ERR_PEER, ("rank " + std::to_string(r) + " failed while setting up its slab (code " + std::to_string(h_xchg[2 * (size_t)r + 1]) + ")").c_str());
+        }
+    for (int r = 0; r < R; ++r) h_cnt[r] = h_xchg[2 * (size_t)r];
+    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_cnt_all, h_cnt, sizeof(int64_t) * R, hipMemcpyHostToDevice, c->stream));  // (the rank-indexed flow gather reads them)
     int64_t n_total = 0, offset = 0;
     for (int r = 0; r < R; ++r) {
         if (r == rank) offset = n_total;
@@ -555,10 +601,7 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
     if (prm->use_refinement) {
         const size_t M = (size_t)std::max<int64_t>(m, 1);
         const size_t npart = (size_t)refine_partials_doubles(c, m);
-        rc = ensure_dev(c, &D->d_session, &D->session_bytes,
-                        Arena::need(sizeof(RefineState) + 64) + Arena::need(32 * M) + 4 * Arena::need(8 * M) + Arena::need(8 * npart) + 1024);
-        if (rc != RSDSFM_OK) return rc;
-        Arena sa(D->d_session);
+        Arena sa(D->d_session);  // (allocated in the setup part for the slab's upper bound)
         RefineBuffers B;
         B.flow = d_u;
         B.n_flow = n;
@@ -586,9 +629,7 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
             }
             if (remote) {
                 const size_t L = (size_t)std::max<int64_t>(lmax, 1);
-                rc = ensure_dev(c, &D->d_flow, &D->flow_bytes, Arena::need(16 * L * R) + Arena::need(16 * M) + 1024);
-                if (rc != RSDSFM_OK) return rc;
-                Arena fl(D->d_flow);
+                Arena fl(D->d_flow);  // (allocated in the setup part: L <= the slab stride, M <= the slab's points)
                 double* d_heads = fl.take<double>(2 * L * R);
                 double* d_flow_rank = fl.take<double>(2 * M);
                 const int64_t mine = std::min<int64_t>(n, std::max<int64_t>(m_total - offset, 0));  // columns of this slab the ranks can reach

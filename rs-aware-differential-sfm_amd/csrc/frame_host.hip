@@ -138,8 +138,26 @@ int frame_begin(Ctx* c, FrameRun* F) {
     F->side_flatten = false;
     if (c->frame_dense_hint) {
         *count_host(c) = -1;
-        const bool side = prm->ransac_trials > 0 && c->frame_side_flatten;
+        const int side = prm->ransac_trials > 0 ? c->frame_side_flatten : 0;
         if (side) {
+            F->side_flatten = true;
+            F->direct = Minimal9Direct();
+            F->direct.img = J.d_flow_img, F->direct.rows = rows, F->direct.cols = cols, F->direct.alpha_ones = prm->use_global_shutter_mode ? 1 : 0;
+            F->direct.fx = fx, F->direct.fy = fy, F->direct.cx = cx, F->direct.cy = cy, F->direct.gamma = gamma;
+        }
+        if (side == 2) {
+            // the flatten BEHIND the minimal solver on the context's stream: the solver (one wave per hypothesis, ~186 us) is the first
+            // kernel of the solve, and while it runs the host enqueues everything else -- the short flatten kernels then start back to
+            // back instead of as fast as the host can enqueue them
+            F->join = [c, F, d_flat_counts, d_flat_offsets]() -> int {
+                const rsdsfm_frame_job& J2 = F->job;
+                int rc2 = flatten_launch(c, J2.d_flow_img, J2.rows, J2.cols, 0, J2.fx, J2.fy, J2.cx, J2.cy, J2.gamma, F->prm.flow_threshold, F->d_q, F->d_u, F->d_a,
+                                         F->d_ak, d_flat_counts, d_flat_offsets, count_host(c), nullptr);
+                if (rc2 == RSDSFM_OK && F->prm.use_global_shutter_mode) rc2 = alpha_ones_launch(c, F->d_a, (int64_t)F->N);
+                return rc2;
+            };
+        } else if (side == 1) {
+            // the flatten BESIDE the minimal solver on the context's second stream, joined in front of the first pass over all points
             rc = ensure_side_stream(c);
             if (rc != RSDSFM_OK) return rc;
             RSDSFM_HIP_CHECK(c, hipEventRecord(c->ev_fork, c->stream));  // (the caller's uploads on the context's stream come first)
@@ -152,10 +170,6 @@ int frame_begin(Ctx* c, FrameRun* F) {
             }
             if (rc != RSDSFM_OK) return rc;
             RSDSFM_HIP_CHECK(c, hipEventRecord(c->ev_join, c->aux_stream));
-            F->side_flatten = true;
-            F->direct = Minimal9Direct();
-            F->direct.img = J.d_flow_img, F->direct.rows = rows, F->direct.cols = cols, F->direct.alpha_ones = prm->use_global_shutter_mode ? 1 : 0;
-            F->direct.fx = fx, F->direct.fy = fy, F->direct.cx = cx, F->direct.cy = cy, F->direct.gamma = gamma;
             F->join = [c]() -> int {
                 RSDSFM_HIP_CHECK(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
                 return RSDSFM_OK;
@@ -227,8 +241,12 @@ int frame_finish(Ctx* c, FrameRun* F, rsdsfm_frame_result* res) {
     int rc = F->rc_begin;
     if (rc == RSDSFM_OK) rc = ransac_finish(c, &F->ransac);
     if (rc != RSDSFM_OK) RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));  // (an error of the speculated run may only mean n was wrong)
-    if (F->side_flatten) RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->aux_stream));  // (joined long ago, unless the run failed in front of the join)
+    if (F->side_flatten && c->aux_stream) RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->aux_stream));  // (joined long ago, unless the run failed in front of the join)
     int64_t n = F->n;
+    if (*count_host(c) < 0) {  // the flatten behind the minimal solver was never enqueued: the run failed in front of it
+        c->frame_dense_hint = 1;
+        return rc != RSDSFM_OK ? rc : fail(c, RSDSFM_ERR_NUMERIC, "frame solve: the point count did not arrive");
+    }
     bool counted = true;  // the run above is the one that counts (its scheduling hints are kept)
     if (*count_host(c) != n) {  // pixels without flow were dropped: everything behind the flatten ran on the wrong point count
         n = *count_host(c);
@@ -349,9 +367,10 @@ int rsdsfm_set_sequence_lanes(rsdsfm_ctx* ctx, int32_t lanes) {
     return RSDSFM_OK;
 }
 
-int rsdsfm_set_frame_side_flatten(rsdsfm_ctx* ctx, int on) {
+int rsdsfm_set_frame_side_flatten(rsdsfm_ctx* ctx, int mode) {
     if (!ctx) return RSDSFM_ERR_INVALID;
-    ctx->c.frame_side_flatten = on != 0;
+    if (mode < 0 || mode > 2) return fail(&ctx->c, RSDSFM_ERR_INVALID, "mode must be 0 (flatten first), 1 (flatten on a second stream) or 2 (flatten behind the minimal solver)");
+    ctx->c.frame_side_flatten = mode;
     return RSDSFM_OK;
 }
 

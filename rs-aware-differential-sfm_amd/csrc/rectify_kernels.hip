@@ -366,6 +366,19 @@ static inline int stream_grid(int64_t n, int per_thread = 1) {
 // older epoch, loses every atomicMax against the current one and is ignored by the read-back (valid iff word & ~mask == tag), so
 // the map is cleared only when it is (re)allocated and when the epoch wraps (every 255 calls).  Images beyond 2^24 pixels fall
 // back to a clear per call with a 1-bit tag.
+// room for `words` claim words in map `which`, without starting a new epoch (the tiled solve allocates in its setup part)
+int claim_map_reserve(Ctx* c, int which, size_t words) {
+    if (words <= c->claim_words[which]) return RSDSFM_OK;
+    RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    if (c->d_claim[which]) RSDSFM_HIP_CHECK(c, hipFree(c->d_claim[which]));
+    c->d_claim[which] = nullptr;
+    c->claim_words[which] = 0;
+    RSDSFM_HIP_CHECK(c, hipMalloc(reinterpret_cast<void**>(&c->d_claim[which]), sizeof(unsigned) * words));
+    c->claim_words[which] = words;
+    c->claim_epoch[which] = 255u;  // the next acquire starts from a cleared map
+    return RSDSFM_OK;
+}
+
 int claim_map_acquire(Ctx* c, int which, size_t npix, unsigned** map, unsigned* tag, unsigned* mask) {
     bool clear = false;
     if (npix > c->claim_words[which]) {
@@ -383,6 +396,9 @@ int claim_map_acquire(Ctx* c, int which, size_t npix, unsigned** map, unsigned* 
         clear = true;
         *tag = 0x80000000u;
         *mask = 0x7FFFFFFFu;
+        // a wide call leaves words tagged 0x80000000 | index behind, which would beat every epoch tag 0x01.. - 0x7F.. of a later
+        // narrow call on the same map: the next narrow call must start from a cleared map (the epoch wrap below does that)
+        c->claim_epoch[which] = 255u;
     } else {
         if (c->claim_epoch[which] >= 255u) {
             c->claim_epoch[which] = 0;
@@ -425,7 +441,9 @@ int depth_preview_launch(Ctx* c, const double* d_inl, int64_t m, double fx, doub
     const int64_t npix = (int64_t)rows * cols;
     const int zb = (int)std::min<int64_t>(1024, std::max<int64_t>(1, (m + kBP - 1) / kBP));
     unsigned *d_owner = nullptr, tag = 0, mask = 0;
-    int rc = claim_map_acquire(c, 1, (size_t)npix, &d_owner, &tag, &mask);
+    if (m >= ((int64_t)1 << 31)) return fail(c, RSDSFM_ERR_INVALID, "depth image: more than 2^31 inliers");
+    // the claim word holds the INLIER index: the map's index field is sized by the larger of the two counts (as depth_map_slab_launch)
+    int rc = claim_map_acquire(c, 1, (size_t)std::max<int64_t>(std::max<int64_t>(npix, m), 1), &d_owner, &tag, &mask);
     if (rc != RSDSFM_OK) return rc;
     hipLaunchKernelGGL(preview_claim_minmax_kernel, dim3(zb), dim3(kBP), 0, c->stream, d_inl, m, fx, fy, cx, cy, rows, cols, d_owner, tag,
                        d_partials);

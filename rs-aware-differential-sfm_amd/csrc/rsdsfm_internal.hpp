@@ -137,11 +137,11 @@ struct Ctx {
     void* frame_run = nullptr;
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_seq = nullptr;
-    bool frame_side_flatten = true;  // rsdsfm_set_frame_side_flatten: dense frames run the flatten on aux_stream beside the minimal solver
+    int frame_side_flatten = 0;  // rsdsfm_set_frame_side_flatten: where a dense frame's flatten runs -- 0 first, 1 on aux_stream beside the minimal solver, 2 behind it
     int seq_lanes = 0;               // rsdsfm_set_sequence_lanes (0 = kSequenceLanesDefault)
     std::vector<rsdsfm_ctx*> lanes;
 };
-constexpr int kSequenceLanesDefault = 4;
+constexpr int kSequenceLanesDefault = 3;  // measured: 1 / 2 / 3 / 4 / 6 / 8 lanes = 0.91 / 1.19 / 1.31 / 1.21 / 1.31 / 1.27 Gpix/s at 1280x720, T = 50
 void dist_release(Ctx* c);
 void frame_release(Ctx* c);
 
@@ -245,6 +245,7 @@ int depth_map_slab_launch(Ctx* c, double* d_inl, int64_t m, const double* d_zsum
                           const int64_t* m_dev = nullptr, const PoseTableOut* pt = nullptr);
 // persistent epoch-tagged claim map `which` of the context (rectify_kernels.hip)
 int claim_map_acquire(Ctx* c, int which, size_t npix, unsigned** map, unsigned* tag, unsigned* mask);
+int claim_map_reserve(Ctx* c, int which, size_t words);
 int zsum_row_launch(Ctx* c, const double* d_inl, int64_t m, double* d_partials, double* d_out);
 }  // namespace rsdsfm
 

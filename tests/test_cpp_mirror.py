@@ -133,7 +133,8 @@ def test_tiled_host_in_cpp_over_rccl_matches_python_solve(tmp_path, rsdsfm):
     assert r["depth_nonzero"] == int((dmh != 0).sum()) and np.isclose(r["depth_sum"], dmh.sum(), rtol=1e-12)
     assert np.array_equal(r["last_t"], t.cpu().numpy()[-1])
     # counts, RANSAC, one refinement poll per 5 LM iterations, the final header -- never per RANSAC round or LM iteration
-    assert r["host_syncs"] <= 4 + -(-r["iterations"] // 5) and r["collectives"] >= 8
+    # (+ at most two more when the RANSAC needs a second LM round / the separate scoring pass)
+    assert r["host_syncs"] <= 6 + -(-r["iterations"] // 5) and r["collectives"] >= 8
 
 
 def test_mirror_compiles_and_links(tmp_path, rsdsfm):

@@ -93,6 +93,49 @@ def test_claim_maps_survive_epoch_wrap_and_resizing(oracle, rsdsfm):
                 assert np.array_equal(s.depth_preview(inl, K, rows, cols), pv), i
 
 
+def test_claim_map_after_a_frame_beyond_2_pow_24_pixels(oracle, rsdsfm):
+    """frames of more than 2^24 pixels use a 1-bit tag and a clear per call; the words they leave behind (0x80000000 | index) would
+    beat every epoch tag of a later, smaller frame on the same context -- the next narrow call must start from a cleared map.  And
+    the depth image's claim word holds the INLIER index: more inliers than 2^24 on a small image must not spill into the epoch bits."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    rows, cols = 4100, 4100  # 16.81 M pixels > 2^24
+    assert rows * cols > 1 << 24
+    d, img, depth, R, t = _scene(rsdsfm, oracle, 60, 90, seed=5)
+    K = d["K"]
+    depth = np.abs(depth) + 1.0
+    exp_small = oracle.back_project(img, depth, R, t, *K, want_coords=False)[0]
+    inl_small = np.column_stack([np.linspace(-0.15, 0.15, 3000), np.linspace(-0.1, 0.1, 3000), np.linspace(1.0, 3.0, 3000)])
+    pv_small = oracle.depth_preview(inl_small, *K, 60, 90)
+    big_img = torch.full((rows, cols, 3), 7, dtype=torch.uint8, device=dev)
+    big_depth = torch.full((cols, rows), 2.0, dtype=torch.float64, device=dev)
+    Rb = torch.eye(3, dtype=torch.float64, device=dev).reshape(1, 9).repeat(rows, 1).contiguous()
+    tb = torch.zeros((rows, 3), dtype=torch.float64, device=dev)
+    gs = torch.zeros((rows, cols, 3), dtype=torch.uint8, device=dev)
+    Kb = (3000.0, 3000.0, cols / 2.0, rows / 2.0)
+    with rsdsfm.Solver(0) as s:
+        assert np.array_equal(s.back_project(img, depth, R, t, K, want_coords=False)[0], exp_small)
+        s.back_project_dev(big_img.data_ptr(), big_depth.data_ptr(), Rb.data_ptr(), tb.data_ptr(), Kb, rows, cols, gs.data_ptr())
+        s.synchronize()
+        assert float((gs.view(-1, 3).sum(dim=1) != 0).double().mean().item()) > 0.9  # identity motion: (almost) every pixel lands on itself
+        for _ in range(3):
+            assert np.array_equal(s.back_project(img, depth, R, t, K, want_coords=False)[0], exp_small)
+        # depth image: 2^24 + 5 inliers on a 60 x 90 image (all but the last 3000 outside the image), then the small list again
+        m = (1 << 24) + 5
+        far = torch.empty((m, 3), dtype=torch.float64, device=dev)
+        far[:, 0], far[:, 1], far[:, 2] = 50.0, 50.0, 1.5
+        far[m - 3000:] = torch.from_numpy(inl_small).to(dev)
+        out = torch.zeros((60, 90), dtype=torch.uint8, device=dev)
+        s.depth_preview_dev(far.data_ptr(), m, K, 60, 90, out.data_ptr())
+        s.synchronize()
+        far_h = np.empty((3005, 3))  # the oracle on the tail only (+ 5 outside points): same image, the others never touch a pixel
+        far_h[:5] = (50.0, 50.0, 1.5)
+        far_h[5:] = inl_small
+        assert np.array_equal(out.cpu().numpy(), oracle.depth_preview(far_h, *K, 60, 90))
+        assert np.array_equal(s.depth_preview(inl_small, K, 60, 90), pv_small)
+
+
 @pytest.mark.parametrize("rows,cols,off", [(3, 3, 1), (40, 61, 1), (40, 61, 3), (5, 4, 2), (720, 1280, 1)])
 def test_interpolate_equals_oracle(oracle, rsdsfm, rows, cols, off):
     rng = np.random.default_rng(rows + cols + off)

@@ -146,7 +146,7 @@ def test_tiled_frame_refinement_trace_is_replicated_and_matches_single_context(r
         for sv in solvers:
             sv.set_refine_trace(50)
         shards = [rsdsfm.dist.HipFrameShard(sv, img[:, c0:c1, :].contiguous(), c0, K, gamma, torch) for sv, (c0, c1) in zip(solvers, bounds)]
-        r3 = rsdsfm.dist.TiledFrameSolve(shards, rows, cols, per, torch, None).solve(**kw)
+        r3 = rsdsfm.dist.TiledFrameSolve(shards, rows, cols, per, torch, None).solve(flow_index_mode=rsdsfm.FLOW_GATHERED, **kw)
         traces = [sv.get_refine_trace() for sv in solvers]
         for sv in solvers:
             sv.close()

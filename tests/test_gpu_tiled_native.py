@@ -284,6 +284,49 @@ def test_native_tiled_rank_indexed_flow_3840x2160_in_8_ranks(rsdsfm, oracle_chai
     assert np.array_equal(got != 0, o["depth_map"] != 0) and np.allclose(got, o["depth_map"], rtol=1e-6)
 
 
+def test_native_tiled_setup_failure_on_one_rank_ends_every_rank(rsdsfm):
+    """a failure only one rank sees (here: a null slab pointer) travels with the point counts in the first exchange: that rank
+    reports its own error, the others return RSDSFM_ERR_PEER instead of waiting in the next collective for ever; the contexts stay
+    usable"""
+    import torch
+    from transports import ThreadTransport
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(3, rows=64, cols=90)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    img = torch.from_numpy(d["flow_img"]).to(dev)
+    nranks = 3
+    tr = ThreadTransport(nranks, timeout=60.0)
+    errs, oks = [None] * nranks, [None] * nranks
+
+    def work(rank):
+        torch.cuda.set_device(0)
+        c0, sc, per = rsdsfm.tiled_slab_bounds(cols, nranks, rank)
+        slab = img[:, c0:c0 + sc, :].contiguous()
+        dm = torch.zeros(cols * rows, dtype=torch.float64, device=dev)
+        torch.cuda.synchronize()
+        with rsdsfm.Solver(0) as s:
+            s.dist_set_transport(nranks, rank, *tr.callbacks(rank))
+            try:
+                s.solve_frame_tiled_dev(0 if rank == 1 else slab.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=6, tol=0.01, seed=2)
+            except rsdsfm.RsdsfmError as e:
+                errs[rank] = str(e)
+            r = s.solve_frame_tiled_dev(slab.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=6, tol=0.01, seed=2)  # all ranks fine now
+            s.synchronize()
+            oks[rank] = (r["num_inliers"], r["v"].tobytes())
+
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join(timeout=120)
+    assert not any(th.is_alive() for th in ths), "a rank is still waiting in a collective"
+    assert errs[1] is not None and "(-1)" in errs[1] and "null slab pointer" in errs[1]
+    for r in (0, 2):
+        assert errs[r] is not None and "(-6)" in errs[r] and "rank 1 failed" in errs[r], errs[r]
+    assert oks[0] is not None and oks[0] == oks[1] == oks[2]
+
+
 @pytest.mark.parametrize("flow_mode", [1, 0])
 def test_native_tiled_two_processes_share_the_gpu(rsdsfm, tmp_path, flow_mode):
     """two ranks = two processes (gloo rendezvous on 127.0.0.1, both on cuda:0, collectives through GlooTransport) run

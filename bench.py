@@ -227,6 +227,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", default="full", choices=["depth", "depth_closed_form", "full", "tiled", "tiled_full", "rectify", "true_flow", "metrics", "launch_check"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sequence-only", action="store_true", help="full workload: only the sequence solve (rsdsfm_solve_frames_dev), --steps passes of 32 pairs (profiling runs)")
     ap.add_argument("--no-side-records", action="store_true", help="full workload: skip depth_only / full_solve_batched / full_solve_fused (profiling runs)")
     ap.add_argument("--tiled-driver", default="native", choices=["native", "python"], help="tiled / tiled_full: the C++ driver inside the library (default) or the Python driver")
     ap.add_argument("--arith", default="reference", choices=["reference", "fused"], help="library: reference arithmetic (default) or the opt-in fused-fma build")
@@ -616,6 +617,13 @@ def run(args):
             line.update(rec)
 
     # =================================================================================================
+    elif args.workload == "full" and args.sequence_only:
+        rec = _full_solve_sequence(rsdsfm, solver, torch, dev, np, rank, args, passes=args.steps)
+        if rank == 0:
+            line.update({"value": rec["value"] * world, "ms_per_step": rec["ms_per_solve_amortised"] * rec["pairs"], "scaling": "weak",
+                         "config": {"workload": "BASELINE configs[4]: 32 frame pairs @1280x720 (32 data seeds) per step through rsdsfm_solve_frames_dev, one context, one host thread"},
+                         "full_solve_batched": rec, "roofline": None, "cpu_baseline": None})
+
     elif args.workload == "full":
         full = _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps=args.steps, warmup=args.warmup, timed=timed)
         roof = _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full) if rank == 0 else None
@@ -1034,6 +1042,8 @@ def _traffic(workload):
                "depth_batch4": ["depth_lm_batch_kernel"], "depth_closed_form": ["depth_closed_form_kernel"]}.get(workload)
     if kernels:
         ctr = [_counters(k2) for k2 in kernels]
+        if any(c2 and c2.get("stale") for c2 in ctr):
+            return None  # the kernel sources changed since the counters were collected
         if all(c2 and "FETCH_SIZE" in c2 and "WRITE_SIZE" in c2 for c2 in ctr):
             return sum((2.0 * c2["FETCH_SIZE"] + c2["WRITE_SIZE"]) * 1024.0 for c2 in ctr)
     tf = os.path.join(ROOT, "profiles", "traffic.json")
@@ -1129,12 +1139,22 @@ def _full_solve_regimes(rsdsfm, solver, torch, dev, np, rank, args, solves=24):
 
 def _counters(kernel):
     """per-launch PMC counter means of `kernel` from profiles/counters.json (rocprofv3 --pmc passes of `bench.py`, see
-    profiles/collect.sh); None when absent"""
+    profiles/collect_r03.sh); None when absent.  The file is stamped with the hashes of the kernel sources it was collected from
+    (profiles/source_hash.py): when the files this kernel is built from have changed since, {"stale": [files]} is returned instead of
+    counts that may no longer describe the kernel."""
     f = os.path.join(ROOT, "profiles", "counters.json")
     try:
-        return json.load(open(f)).get(kernel)
+        data = json.load(open(f))
     except Exception:
         return None
+    ctr = data.get(kernel)
+    if ctr is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    import source_hash
+
+    stale = source_hash.stale_files(kernel.split(":")[0], (data.get("_meta") or {}).get("sources"))
+    return {"stale": stale} if stale else ctr
 
 
 def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):
@@ -1161,7 +1181,8 @@ def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):
     kname = "ransac_lm_kernel<true, 3, 2>"  # round 0: three speculated iterations, the score of the two-step iterate fused (DeepFlow-like data)
     ctr = _counters(kname + (":fused" if args.arith == "fused" else ""))
     insts = achieved = frac = traffic = frac_all = None
-    if ctr:
+    stale = ctr.get("stale") if ctr else None
+    if ctr and not stale:
         insts = 64.0 * sum(ctr.get(k2, 0.0) for k2 in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
         achieved = insts / (kern_ms * 1e-3)
         frac = achieved / FP64_VALU_PEAK
@@ -1176,7 +1197,7 @@ def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):
             "unit": "T fp64 lane-instructions/s", "frac": frac, "frac_all_valu_instructions": frac_all, "traffic": traffic,
             "fp64_lane_instructions_per_launch": insts, "avg_launch_ms": kern_ms, "median_launch_ms": float(ts[len(ts) // 2]),
             "pixel_hypotheses_per_launch": int(n) * T, "alg_bytes_per_launch": 48 * int(n),
-            "share_of_solve": kern_ms / full["median_ms_per_solve"],
+            "share_of_solve": kern_ms / full["median_ms_per_solve"], "counters_stale": bool(stale), "counters_stale_files": stale or None,
             "hbm": {"bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                     "alg_bytes_per_solve": hbm_bytes, "formula": "57 N + 64 M iterations (SURVEY 8 d), N = %d, M = %d, iterations = %d, over the median solve time" % (full["n"], full["num_inliers"], iters)},
             "note": "the whole solve is bound by fp64 VALU issue and by serial latency chains (9x9 Jacobi SVD), not by HBM: its HBM fraction is reported "

@@ -51,6 +51,11 @@ def main():
         for cn, v in d.items():
             e[cn] = sum(v) / len(v)
         e["launches_sampled"] = max(len(v) for v in d.values())
+    # stamp: the sources these counts belong to (bench.py refuses to price a kernel whose sources have changed since)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import source_hash
+
+    res["_meta"] = {"sources": source_hash.source_hashes(), "note": "sha256[:16] of the sources at collection time; see profiles/source_hash.py"}
     json.dump(res, open(out_path, "w"), indent=1, sort_keys=True)
     print("wrote %s: %d kernels" % (out_path, len(res)))
 

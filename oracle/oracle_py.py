@@ -154,6 +154,26 @@ class all_cores:
 _FORCE = None
 
 
+VARIANTS = {"ftol": 0, "jacobi": 1, "mindiag": 2, "dsq": 3, "radius": 4, "ftol_lt": 5}
+
+
+class variant:
+    """sensitivity study only: `with oracle.variant(ftol=1): ...` replaces ONE recalled detail of the Ceres 1.14 loop by an alternative
+    reading (rso_set_variant, oracle/rsdsfm_oracle.c) for the calls inside; everything is reset on exit"""
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    def __enter__(self):
+        for k, v in self.kw.items():
+            assert lib().rso_set_variant(C.c_int(VARIANTS[k]), C.c_int(int(v))) == 0
+        return self
+
+    def __exit__(self, *a):
+        for k in self.kw:
+            lib().rso_set_variant(C.c_int(VARIANTS[k]), C.c_int(0))
+
+
 def lib():
     if _FORCE is not None:
         return _FORCE

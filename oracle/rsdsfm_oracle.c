@@ -740,8 +740,47 @@ static inline void jac_rho(double x, double y, double alpha, double alpha_k, con
 
 static inline double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+/* SENSITIVITY SWITCHES (tests/test_oracle_sensitivity.py, tools/oracle_sensitivity.py).  The trust-region loop below restates
+ * Ceres 1.14 from recollection -- Ceres is not on disk (PARITY UNPINNED).  Each switch replaces ONE recalled detail by a plausible
+ * alternative reading, so that the effect of a wrong recollection on the integer outputs (inlier masks, winners, LM step counts)
+ * and on the digits of rho / v / w can be measured instead of guessed.  All zero = the oracle as pinned by the parity tests;
+ * nothing outside the sensitivity study ever sets them.
+ *   RSO_VAR_FTOL     0: function tolerance tested on the candidate BEFORE acceptance, candidate not applied on convergence
+ *                    1: same test, but a candidate that would have been accepted IS applied before terminating
+ *                    2: tested only after an accepted step (an unsuccessful step cannot converge by function tolerance)
+ *   RSO_VAR_JACOBI   0: Jacobi column scaling 1 / (1 + ||J_col||) from the iteration-0 Jacobian   1: no scaling
+ *   RSO_VAR_MINDIAG  0: LM diagonal clamp(||J_col||^2, 1e-6, 1e32)                                 1: no clamp
+ *   RSO_VAR_DSQ      0: D^2 = clamp(diag) * (1 / radius)   1: D = sqrt(clamp(diag) / radius), D^2 = D * D (Ceres' literal form)
+ *   RSO_VAR_RADIUS   0: accepted step: radius /= max(1/3, 1 - (2 rho_q - 1)^3)
+ *                    1: textbook rule: radius *= 3 if rho_q > 0.75, unchanged above 0.25, / 2 below
+ *   RSO_VAR_FTOL_LT  0: |cost change| <= tol * cost   1: strict < (Ceres <= 1.12 wrote <)                                     */
+enum { RSO_VAR_FTOL = 0, RSO_VAR_JACOBI, RSO_VAR_MINDIAG, RSO_VAR_DSQ, RSO_VAR_RADIUS, RSO_VAR_FTOL_LT, RSO_VAR_COUNT };
+static int g_var[RSO_VAR_COUNT] = {0};
+int rso_set_variant(int which, int value) {
+    if (which < 0 || which >= RSO_VAR_COUNT) return -1;
+    g_var[which] = value;
+    return 0;
+}
+static inline double lm_diag(double ht) { return g_var[RSO_VAR_MINDIAG] ? ht : clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG); }
+static inline double lm_dsq(double diag, double radius, double inv_radius) {
+    if (g_var[RSO_VAR_DSQ]) {
+        double d = sqrt(diag / radius);
+        return d * d;
+    }
+    return diag * inv_radius;
+}
+static inline int ftol_hit(double cost_change, double cost) {
+    return g_var[RSO_VAR_FTOL_LT] ? fabs(cost_change) < CERES_FUNCTION_TOL * cost : fabs(cost_change) <= CERES_FUNCTION_TOL * cost;
+}
+
 /* LevenbergMarquardtStrategy::StepAccepted */
 static inline double radius_accept(double radius, double q) {
+    if (g_var[RSO_VAR_RADIUS]) {
+        if (q > 0.75) radius *= 3.0;
+        else if (q < 0.25) radius *= 0.5;
+        if (radius > CERES_MAX_RADIUS) radius = CERES_MAX_RADIUS;
+        return radius;
+    }
     double t = 2.0 * q - 1.0;
     double f = 1.0 - t * t * t;
     if (f < 1.0 / 3.0) f = 1.0 / 3.0;
@@ -799,7 +838,7 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
     for (int64_t i = 0; i < n; ++i) {
         rho[i] = 1.0; /* nonlinearRefinement.cc:140 */
         jac_rho(q[2 * i], q[2 * i + 1], alpha[i], alpha_k[i], v, k, &J[2 * i]);
-        s[i] = 1.0 / (1.0 + sqrt(RSO_DOT2(J[2 * i], J[2 * i], J[2 * i + 1], J[2 * i + 1]))); /* jacobi scaling */
+        s[i] = g_var[RSO_VAR_JACOBI] ? 1.0 : 1.0 / (1.0 + sqrt(RSO_DOT2(J[2 * i], J[2 * i], J[2 * i + 1], J[2 * i + 1]))); /* jacobi scaling */
         rso_residual(q[2 * i], q[2 * i + 1], u[2 * i], u[2 * i + 1], alpha[i], alpha_k[i], v, w, k, rho[i],
                      &res[2 * i]);
         cost = RSO_ACC_SQ2(cost, res[2 * i], res[2 * i + 1]);
@@ -836,7 +875,7 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
         for (int64_t i = 0; i < n; ++i) {
             double jt0 = J[2 * i] * s[i], jt1 = J[2 * i + 1] * s[i];
             double ht = RSO_DOT2(jt0, jt0, jt1, jt1);
-            double diag = clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG);
+            double diag = lm_diag(ht);
             double gt = RSO_DOT2(jt0, res[2 * i], jt1, res[2 * i + 1]);
             double m0, m1, step;
 #if RSO_FUSED
@@ -845,7 +884,7 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
             /* model_change -= m0 (r0 + m0 / 2) + m1 (r1 + m1 / 2) */
             model_change = fma(-m0, fma(m0, 0.5, res[2 * i]), fma(-m1, fma(m1, 0.5, res[2 * i + 1]), model_change));
 #else
-            double lam = diag * inv_radius;
+            double lam = lm_dsq(diag, radius, inv_radius);
             step = -(gt / (ht + lam));
             m0 = jt0 * step, m1 = jt1 * step;
             model_change -= m0 * (res[2 * i] + m0 / 2.0) + m1 * (res[2 * i + 1] + m1 / 2.0);
@@ -874,11 +913,16 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
             break;
         }
         double cost_change = cost - ccost;
-        if (fabs(cost_change) <= CERES_FUNCTION_TOL * cost) {
+        const int hit = ftol_hit(cost_change, cost);
+        if (hit && g_var[RSO_VAR_FTOL] == 0) {
             sm.termination = RSO_TERM_FUNCTION;
             break;
         }
         double rel = cost_change / model_change;
+        if (hit && g_var[RSO_VAR_FTOL] == 1 && !(rel > CERES_MIN_REL_DECREASE)) { /* nothing to apply */
+            sm.termination = RSO_TERM_FUNCTION;
+            break;
+        }
         if (rel > CERES_MIN_REL_DECREASE) { /* HandleSuccessfulStep */
             xsq = 0.0;
             cost = 0.0;
@@ -901,6 +945,7 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
             decrease_factor = 2.0;
             ++sm.num_successful_steps;
             if (gmax <= CERES_GRADIENT_TOL) sm.termination = RSO_TERM_GRADIENT;
+            if (hit && g_var[RSO_VAR_FTOL] != 0) sm.termination = RSO_TERM_FUNCTION; /* variants 1, 2: converged WITH the candidate applied */
         } else { /* HandleUnsuccessfulStep */
             ++sm.num_unsuccessful_steps;
             radius = radius / decrease_factor;
@@ -1191,14 +1236,14 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
             colsq[c] += Jp[0][c] * Jp[0][c] + Jp[1][c] * Jp[1][c];
             gp[c] += Jp[0][c] * r[0] + Jp[1][c] * r[1];
         }
-        srho[i] = 1.0 / (1.0 + sqrt(Jr[0] * Jr[0] + Jr[1] * Jr[1]));
+        srho[i] = g_var[RSO_VAR_JACOBI] ? 1.0 : 1.0 / (1.0 + sqrt(Jr[0] * Jr[0] + Jr[1] * Jr[1]));
         double g = fabs(Jr[0] * r[0] + Jr[1] * r[1]);
         if (g > gmax) gmax = g;
         xsq += rho[i] * rho[i];
     }
     cost *= 0.5;
     for (int c = 0; c < np; ++c) {
-        sp[c] = 1.0 / (1.0 + sqrt(colsq[c]));
+        sp[c] = g_var[RSO_VAR_JACOBI] ? 1.0 : 1.0 / (1.0 + sqrt(colsq[c]));
         if (fabs(gp[c]) > gmax) gmax = fabs(gp[c]);
         xsq += p[c] * p[c];
     }
@@ -1230,7 +1275,7 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
             resid_jac(inl[3 * i], inl[3 * i + 1], uu[2 * i], uu[2 * i + 1], alpha[i], alpha_k[i], p, rho[i], r, Jp, Jr);
             double E0 = Jr[0] * srho[i], E1 = Jr[1] * srho[i];
             double ht = E0 * E0 + E1 * E1;
-            double lam = clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG) * inv_radius;
+            double lam = lm_dsq(lm_diag(ht), radius, inv_radius);
             double ete_inv = 1.0 / (ht + lam);
             double Etb = E0 * r[0] + E1 * r[1];
             double F[2][7], EtF[7];
@@ -1250,7 +1295,7 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
         }
         double S[49], rhs[7], yp[7], Dp[7];
         for (int a = 0; a < np; ++a) {
-            Dp[a] = clampd(FtF[a * 7 + a], CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG) * inv_radius; /* = D_f^2 */
+            Dp[a] = lm_dsq(lm_diag(FtF[a * 7 + a]), radius, inv_radius); /* = D_f^2 */
             rhs[a] = Ftb[a] - cvec[a];
             for (int b = a; b < np; ++b) {
                 double sab = FtF[a * 7 + b] - C[a * 7 + b];
@@ -1280,7 +1325,7 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
                 resid_jac(inl[3 * i], inl[3 * i + 1], uu[2 * i], uu[2 * i + 1], alpha[i], alpha_k[i], p, rho[i], r, Jp, Jr);
                 double E0 = Jr[0] * srho[i], E1 = Jr[1] * srho[i];
                 double ht = E0 * E0 + E1 * E1;
-                double lam = clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG) * inv_radius;
+                double lam = lm_dsq(lm_diag(ht), radius, inv_radius);
                 double ete_inv = 1.0 / (ht + lam);
                 double Etb = E0 * r[0] + E1 * r[1];
                 double Fy0 = 0.0, Fy1 = 0.0;
@@ -1331,12 +1376,18 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
             break;
         }
         double cost_change = cost - ccost;
-        if (fabs(cost_change) <= CERES_FUNCTION_TOL * cost) {
+        const int hit = ftol_hit(cost_change, cost);
+        if (hit && g_var[RSO_VAR_FTOL] == 0) {
             if (tr) tr[7] = 4.0;
             sm.termination = RSO_TERM_FUNCTION;
             break;
         }
         double rel = cost_change / model_change;
+        if (hit && g_var[RSO_VAR_FTOL] == 1 && !(rel > CERES_MIN_REL_DECREASE)) {
+            if (tr) tr[7] = 4.0;
+            sm.termination = RSO_TERM_FUNCTION;
+            break;
+        }
         if (tr) tr[4] = rel;
         if (getenv("RSO_TRACE")) fprintf(stderr, "oracle it %d cost %.17g ccost %.17g model %.17g rel %.17g radius %.17g step %.6g\n", iteration, cost, ccost, model_change, rel, radius, step_norm);
         if (rel > CERES_MIN_REL_DECREASE) {
@@ -1369,6 +1420,7 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
             ++sm.num_successful_steps;
             if (gmax <= CERES_GRADIENT_TOL) sm.termination = RSO_TERM_GRADIENT;
             if (tr) tr[7] = gmax <= CERES_GRADIENT_TOL ? 5.0 : 1.0;
+            if (hit && g_var[RSO_VAR_FTOL] != 0) sm.termination = RSO_TERM_FUNCTION; /* variants 1, 2: converged WITH the candidate applied */
         } else {
             if (tr) tr[7] = 0.0;
             ++sm.num_unsuccessful_steps;

@@ -154,6 +154,70 @@ class all_cores:
 _FORCE = None
 
 
+_REF = None
+
+
+def lib_ref():
+    """librsdsfm_cpu_ref.so: the reference-STRUCTURED single-thread CPU baseline (oracle/rsdsfm_cpu_ref.cpp)"""
+    global _REF
+    if _REF is None:
+        build()  # it links against the oracle library
+        so = os.path.join(_HERE, "librsdsfm_cpu_ref.so")
+        src = os.path.join(_HERE, "rsdsfm_cpu_ref.cpp")
+        deps = [src, os.path.join(_HERE, "rsdsfm_oracle.h")]
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+            tmp = so + ".tmp%d" % os.getpid()
+            subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-Wall", "-Wextra", "-std=c++14", "-shared", "-o", tmp, src,
+                                   "-L" + _HERE, "-lrsdsfm_oracle", "-Wl,-rpath," + _HERE, "-lm"])
+            os.replace(tmp, so)
+        _REF = C.CDLL(so)
+    return _REF
+
+
+def estimate_inverse_depths_reference_structured(q, u, v, w, k, alpha, alpha_k):
+    q, u, alpha, alpha_k = _f64(q), _f64(u), _f64(alpha), _f64(alpha_k)
+    n = q.shape[0]
+    rho = np.empty(n)
+    sm = LmSummary()
+    rc = lib_ref().rsr_estimate_inverse_depths(_p(q), _p(u), C.c_int64(n), _v3(v), _v3(w), C.c_double(k), _p(alpha), _p(alpha_k), _p(rho), C.byref(sm))
+    if rc != 0:
+        raise RuntimeError("rsr_estimate_inverse_depths failed rc=%d" % rc)
+    return rho, sm.as_dict()
+
+
+def ransac_reference_structured(q, u, alpha, alpha_k, use_alpha_k, iterations, tolerance, samples, k_sign_mode=0):
+    """minimal::ransac with one reference-structured depth solve (problem build + solve + teardown) per trial"""
+    q, u, alpha, alpha_k = _f64(q), _f64(u), _f64(alpha), _f64(alpha_k)
+    n, T = q.shape[0], int(iterations)
+    smp = np.ascontiguousarray(samples, dtype=np.int32).reshape(-1)
+    bufs = dict(inlier_idx=np.zeros(n, dtype=np.int64), inliers=np.zeros((n, 3)), alpha=np.zeros(n), alpha_k=np.zeros(n), mask=np.zeros(n, dtype=np.uint8),
+                inv_depth=np.zeros(n), trial_count=np.zeros(max(T, 1), dtype=np.int64), trial_err=np.zeros(max(T, 1)), trial_steps=np.zeros(max(T, 1), dtype=np.int32))
+    out = RansacOut()
+    for name, arr in bufs.items():
+        setattr(out, name, arr.ctypes.data)
+    rc = lib_ref().rsr_ransac(_p(q), _p(u), _p(alpha), _p(alpha_k), C.c_int64(n), int(use_alpha_k), C.c_int32(T), C.c_double(tolerance), _p(smp), int(k_sign_mode), C.byref(out))
+    if rc != 0:
+        raise RuntimeError("rsr_ransac failed rc=%d" % rc)
+    m = int(out.num_inliers)
+    return dict(num_inliers=m, best_trial=int(out.best_trial), w=np.array(out.w[:]), v=np.array(out.v[:]), k=float(out.k), inlier_error=float(out.inlier_error),
+                inlier_idx=bufs["inlier_idx"][:m].copy(), inliers=bufs["inliers"][:m].copy(), alpha=bufs["alpha"][:m].copy(), alpha_k=bufs["alpha_k"][:m].copy(),
+                mask=bufs["mask"], inv_depth=bufs["inv_depth"], trial_count=bufs["trial_count"][:T], trial_err=bufs["trial_err"][:T], trial_steps=bufs["trial_steps"][:T])
+
+
+def refine_reference_structured(flow, inliers, alpha, alpha_k, v, w, k, const_acceleration=False, flow_index_mode=0, inlier_idx=None):
+    flow, inliers, alpha, alpha_k = _f64(flow), _f64(inliers), _f64(alpha), _f64(alpha_k)
+    m = inliers.shape[0]
+    idx = None if inlier_idx is None else np.ascontiguousarray(inlier_idx, dtype=np.int64)
+    out = np.empty((m, 3))
+    vo, wo, ko = (C.c_double * 3)(), (C.c_double * 3)(), C.c_double()
+    sm = LmSummary()
+    rc = lib_ref().rsr_refine(_p(flow), C.c_int64(flow.shape[0]), C.c_int64(m), _p(inliers), _p(alpha), _p(alpha_k), None if idx is None else _p(idx), _v3(v), _v3(w),
+                              C.c_double(k), int(const_acceleration), int(flow_index_mode), _p(out), vo, wo, C.byref(ko), C.byref(sm))
+    if rc != 0:
+        raise RuntimeError("rsr_refine failed rc=%d" % rc)
+    return dict(inliers=out, v=np.array(vo[:]), w=np.array(wo[:]), k=ko.value, summary=sm.as_dict())
+
+
 VARIANTS = {"ftol": 0, "jacobi": 1, "mindiag": 2, "dsq": 3, "radius": 4, "ftol_lt": 5}
 
 

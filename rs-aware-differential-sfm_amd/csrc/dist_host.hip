@@ -129,6 +129,10 @@ struct Dist {
     void* d_xchg = nullptr;  // {point count, setup status} of every rank: allocated apart from (and before) everything that can fail
     size_t xchg_bytes = 0;
     int host_syncs = 0, collectives = 0, ransac_rounds = 0;  // diagnostics of the last solve
+    // what the previous solve on this communicator needed -- decides what the next one enqueues ahead of its host reads, never a
+    // result (every rank derives them from the same replicated decisions, so all ranks enqueue the same collectives)
+    int score_hint = 0;          // the separate scoring pass was needed behind round 0
+    int refine_iters_hint = -1;  // LM iterations of the refinement (-1: none yet)
 };
 
 Dist* dist_of(Ctx* c, bool create) {
@@ -540,7 +544,7 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_m, d_m_all, sizeof(int64_t) * R, hipMemcpyDeviceToHost, c->stream));
         return RSDSFM_OK;
     };
-    bool final_done = false;
+    bool final_done = false, spec_scored = false;
     for (int b0 = 0; b0 < T; b0 += batch) {
         const int B = std::min(batch, T - b0);
         bool need_score = true;
@@ -556,6 +560,18 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
                 if (rc != RSDSFM_OK) return rc;
                 D->ransac_rounds += 1;
                 if (round == 0 && B == T) {  // the common case is decided and scored by round 0: enqueue the final stage before reading the flags
+                    if (D->score_hint) {
+                        // the previous solve needed the separate scoring pass (hypotheses that end at an iterate round 0 does not score):
+                        // enqueue it ahead of the flags too -- it only touches hypotheses round 0 left unscored -- which saves a host
+                        // round trip, a discarded final stage and its all-gather
+                        rc = ransac_score_rows_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp, T, d_states, depth_mode, prm->ransac_tol, d_scored, d_partials, d_row);
+                        if (rc != RSDSFM_OK) return rc;
+                        rc = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)T * 2);
+                        if (rc != RSDSFM_OK) return rc;
+                        rc = ransac_score_merge_launch(c, d_rows_all, R, T, d_scored, d_tcount, d_terr);
+                        if (rc != RSDSFM_OK) return rc;
+                        spec_scored = true;
+                    }
                     rc = final_stage();
                     if (rc != RSDSFM_OK) return rc;
                     final_done = true;
@@ -567,6 +583,8 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
                 final_done = false;
             }
             need_score = h_flags[1] > 0;
+            if (B == T) D->score_hint = need_score ? 1 : 0;
+            if (need_score && final_done && spec_scored) need_score = false;  // round 0 decided everything and the pass already ran
             if (need_score) final_done = false;
         }
         if (need_score) {
@@ -678,8 +696,13 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
         };
         rc = staged(0);
         if (rc != RSDSFM_OK) return rc;
-        const int chunk = 5;  // LM iterations per host poll; the kernels of a finished solve return immediately
-        for (int launched = 0;;) {
+        // LM iterations per host poll.  The kernels of a finished solve return immediately, but an empty iteration still costs two
+        // all-gathers here: the first chunk is what the previous solve on this communicator needed (5 before there is one), later
+        // chunks what it still needed at that point (2 .. 5).  Every rank holds the same hint (it comes from the replicated state), so all ranks issue the same
+        // collectives; the chunking changes when the host looks at the state, never what the kernels compute.
+        const int hint = D->refine_iters_hint;
+        int chunk = hint >= 1 ? std::min(hint, 10) : 5;
+        for (int launched = 0;; chunk = hint >= 1 ? std::min(5, std::max(2, hint - launched)) : 5) {
             for (int i = 0; i < chunk; ++i) {
                 rc = staged(1);
                 if (rc != RSDSFM_OK) return rc;
@@ -696,6 +719,7 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
             if (h_state->termination >= 0) break;
             if (launched > 4 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
         }
+        D->refine_iters_hint = h_state->iteration;
         for (int i = 0; i < 3; ++i) v[i] = h_state->p[i], w[i] = h_state->p[3 + i];
         k = h_state->p[6];
         res->refine_summary.num_iterations = h_state->iteration;

@@ -39,11 +39,13 @@ HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 METRIC = "Mpixels/sec RS depth+pose solve, 1280x720 pair"
 METRIC_DEPTH = "Mpixels/sec RS per-pixel depth solve (pose fixed), 1280x720 pair"
 FP64_VALU_PEAK = 39.3e12        # fp64 lane-instructions / s: 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 4 cycles per wave-instruction
-# DESIGN section 8 scaling model of the column-tiled 3840x2160 whole solve (ms; N = 1 measured in profiles/r02_trace_tiled_full.txt):
-# kernels whose work is per pixel of the slab / replicated stages (minimal9 + single-workgroup decides + pick) / per-collective latency
-# over xGMI for the small rows / the depth-map all-gather: (N - 1) / N x 66 MB at ~45 GB/s per link direction, 7 links in parallel
-TILED_MODEL = {"per_pixel_ms": 5.55, "replicated_ms": 0.55, "collective_latency_ms": 0.02, "collectives": 17,
-               "depth_gather_ms": lambda n: (66.4e6 * (n - 1) / n / min(n - 1, 7)) / 45e9 * 1e3}
+# DESIGN section 8 scaling model of the column-tiled 3840x2160 whole solve (ms; calibrated on the N = 1 kernel trace
+# profiles/r03_trace_tiled_full.txt): kernels whose work is per pixel of the slab (ransac_lm 4.03, refinement passes ~1.0, flatten,
+# final stage, depth map ...) / replicated or latency-bound stages (minimal9 0.19 + ~60 launches of ~5 us) / an ASSUMED 25 us per
+# small collective over xGMI / the depth-map all-gather: every rank receives (N - 1) slabs of 66.4 MB / N over min(N - 1, 7) links
+# in parallel at an ASSUMED 48 GB/s per link and direction
+TILED_MODEL = {"per_pixel_ms": 5.70, "replicated_ms": 0.50, "collective_latency_ms": 0.025, "collectives": 17,
+               "depth_gather_ms": lambda n: (66.4e6 / n * (n - 1) / min(n - 1, 7)) / 48e9 * 1e3}
 KIND_PORT = "closed-loop port (oracle C restatement; not reference-structured: no per-pixel residual objects / Ceres problem build)"
 
 

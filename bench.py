@@ -370,6 +370,15 @@ def run(args):
             got = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
             dist.all_gather(got, torch.tensor([rank], dtype=torch.int64))
             seen = [int(g.item()) for g in got]
+            if os.environ.get("RSDSFM_LAUNCH_CHECK_HANG_RANK") is not None:
+                # the watchdog of the bench's last section (tiled_full): one rank never comes back, the others wait for it in a
+                # collective -- rank 0 must still print the line it has, and every rank must leave
+                line = {"metric": "launch_check", "value": el, "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ranks_seen": seen, "guarded": None}
+                _watchdog(args.tiled_timeout, rank, line, "guarded")
+                if os.environ["RSDSFM_LAUNCH_CHECK_HANG_RANK"] == str(rank):
+                    time.sleep(3600)
+                dist.barrier()
+                time.sleep(3600)  # (not reached in time: the barrier needs the hanging rank)
             dist.destroy_process_group()
         if rank == 0:
             print(json.dumps({"metric": "launch_check", "value": el, "unit": "s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -912,7 +921,7 @@ def _watchdog(seconds, rank, line, key):
         if rank == 0:
             line[key] = {"error": "no result within %.0f s (watchdog)" % seconds}
             print(json.dumps(line), flush=True)
-        os._exit(0 if rank == 0 else 3)
+        os._exit(0)  # (every rank: the line carries the error; a non-zero code would make a launcher discard the headline with it)
 
     t = threading.Timer(seconds, fire)
     t.daemon = True

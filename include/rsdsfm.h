@@ -279,10 +279,13 @@ int rsdsfm_solve_frames_dev(rsdsfm_ctx* ctx, const rsdsfm_frame_job* jobs, int32
 /* pairs in flight of rsdsfm_solve_frames_dev: 1 .. 16, 0 = default (3).  Scheduling only. */
 int rsdsfm_set_sequence_lanes(rsdsfm_ctx* ctx, int32_t lanes);
 /* Where the flatten of a frame runs whose predecessor on the context was dense (every pixel kept, so that point i IS pixel
- * (i / rows, i % rows) and the minimal solver can form its sampled points straight from the flow image): 0 (default) = in front
- * of the minimal solver (which reads the flattened arrays), 1 = beside it on a second stream, 2 = behind it on the context's stream.
- * Measured on MI355X (1280x720, T = 50, median of 60 solves): 0.977 / 0.995 / 0.986 ms -- the cross-stream join costs more than the
- * 21 us of flatten kernels it hides, and with the solver first the host's sampler is exposed in front of it.  Scheduling only. */
+ * (i / rows, i % rows) and the minimal solver can form its sampled points straight from the flow image):
+ *   3 (default) = INSIDE the minimal solver's launch: the first T workgroups solve (one wave per hypothesis, ~186 us of a serial
+ *       division / square-root chain with the rest of the GPU idle), the other workgroups flatten the dense frame to its known
+ *       positions -- no scan -- and count dropped pixels; a frame that turns out not to be dense runs the general flatten again;
+ *   2 = behind the solver on the context's stream, 1 = beside it on a second stream, 0 = in front of it (count, scan, scatter).
+ * Measured on MI355X (1280x720, T = 50, medians of 60 solves): 0.963 / 0.986 / 0.995 / 0.977 ms for 3 / 2 / 1 / 0 -- the
+ * cross-stream join of mode 1 costs more than the 21 us of flatten kernels it hides.  Scheduling only: identical results. */
 int rsdsfm_set_frame_side_flatten(rsdsfm_ctx* ctx, int mode);
 /* minimal::ransac on device-resident inputs.  The arrays of `out` (inlier_idx, inliers, alpha, alpha_k, mask,
  * inv_depth) are DEVICE pointers with capacity n (each may be NULL); its trial_* arrays are HOST pointers.

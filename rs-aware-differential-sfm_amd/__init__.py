@@ -515,8 +515,8 @@ class Solver:
         self._check(self.lib.rsdsfm_set_sequence_lanes(self._ctx, C.c_int32(int(lanes))), "rsdsfm_set_sequence_lanes")
 
     def set_frame_side_flatten(self, on):
-        """where a dense frame's flatten runs (rsdsfm_set_frame_side_flatten): 0 (default) in front of the minimal solver, 1 beside it on
-        a second stream, 2 behind it (1, 2: the solver forms its sampled points straight from the flow image); scheduling only"""
+        """where a dense frame's flatten runs (rsdsfm_set_frame_side_flatten): 3 (default) inside the minimal solver's launch (spare
+        workgroups flatten while T waves solve), 2 behind the solver, 1 beside it on a second stream, 0 in front of it; scheduling only"""
         self._check(self.lib.rsdsfm_set_frame_side_flatten(self._ctx, int(on)), "rsdsfm_set_frame_side_flatten")
 
     def prepared_frames_solve(self, jobs, trials=50, tol=0.05, use_acceleration_mode=False, use_refinement=True, depth_mode=DEPTH_CERES_LM,

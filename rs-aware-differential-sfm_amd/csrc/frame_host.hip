@@ -44,7 +44,8 @@ struct FrameRun {
     RansacRun ransac;
     RefineRun refine;
     Minimal9Direct direct;
-    bool refinement_enqueued = false, ahead = false, side_flatten = false, open = false;
+    DenseFlatten dense;
+    bool refinement_enqueued = false, ahead = false, side_flatten = false, dense_in_launch = false, open = false;
     int rc_begin = RSDSFM_OK;
     int64_t m_known = -1;  // the inlier count once the host has it; until then the kernels read it from the refinement's state
     RefineTail tail;
@@ -138,14 +139,29 @@ int frame_begin(Ctx* c, FrameRun* F) {
     F->side_flatten = false;
     if (c->frame_dense_hint) {
         *count_host(c) = -1;
-        const int side = prm->ransac_trials > 0 ? c->frame_side_flatten : 0;
+        int side = prm->ransac_trials > 0 ? c->frame_side_flatten : 0;
+        if (side == 3 && prm->ransac_trials > c->num_cus * 2) side = 0;  // (the solver then runs one hypothesis per LANE: no spare workgroups to speak of)
+        F->dense_in_launch = false;
         if (side) {
             F->side_flatten = true;
             F->direct = Minimal9Direct();
             F->direct.img = J.d_flow_img, F->direct.rows = rows, F->direct.cols = cols, F->direct.alpha_ones = prm->use_global_shutter_mode ? 1 : 0;
             F->direct.fx = fx, F->direct.fy = fy, F->direct.cx = cx, F->direct.cy = cy, F->direct.gamma = gamma;
         }
-        if (side == 2) {
+        if (side == 3) {
+            // the flatten INSIDE the minimal solver's launch: the first T workgroups solve, the others flatten the dense frame to its
+            // known positions and count the pixels they had to drop (minimal9_flatten_kernel); no scan, no second stream, no join
+            if (!c->d_flat_counters) {
+                RSDSFM_HIP_CHECK(c, hipMalloc(reinterpret_cast<void**>(&c->d_flat_counters), 2 * sizeof(unsigned long long)));
+                RSDSFM_HIP_CHECK(c, hipMemsetAsync(c->d_flat_counters, 0, 2 * sizeof(unsigned long long), c->stream));
+            }
+            F->dense = DenseFlatten();
+            F->dense.thr = prm->flow_threshold;
+            F->dense.d_q = F->d_q, F->dense.d_u = F->d_u, F->dense.d_alpha = F->d_a, F->dense.d_alpha_k = F->d_ak;
+            F->dense.d_counters = c->d_flat_counters;
+            F->dense.total_out = count_host(c);
+            F->dense_in_launch = true;
+        } else if (side == 2) {
             // the flatten BEHIND the minimal solver on the context's stream: the solver (one wave per hypothesis, ~186 us) is the first
             // kernel of the solve, and while it runs the host enqueues everything else -- the short flatten kernels then start back to
             // back instead of as fast as the host can enqueue them
@@ -228,7 +244,8 @@ int frame_begin(Ctx* c, FrameRun* F) {
     F->open = true;
     F->rc_begin = ransac_begin(c, F->d_q, F->d_u, F->d_a, F->d_ak, n, prm->use_acceleration_mode, prm->ransac_trials, prm->ransac_tol, nullptr, J.seed,
                                prm->depth_mode, prm->k_sign_mode, &F->ro, F->ahead ? &F->spec_tail : nullptr, &F->refinement_enqueued, &F->ransac,
-                               F->side_flatten ? &F->direct : nullptr, F->side_flatten ? &F->join : nullptr);
+                               F->side_flatten ? &F->direct : nullptr, F->side_flatten && !F->dense_in_launch ? &F->join : nullptr,
+                               F->dense_in_launch ? &F->dense : nullptr);
     return RSDSFM_OK;  // (an error of the speculated run may only mean that n was wrong: frame_finish sorts that out)
 }
 
@@ -249,6 +266,15 @@ int frame_finish(Ctx* c, FrameRun* F, rsdsfm_frame_result* res) {
     }
     bool counted = true;  // the run above is the one that counts (its scheduling hints are kept)
     if (*count_host(c) != n) {  // pixels without flow were dropped: everything behind the flatten ran on the wrong point count
+        if (F->dense_in_launch) {
+            // ... and the dense flatten wrote every kept pixel to the position it would have in a frame without holes: the general
+            // flatten (count, scan, scatter) has to run after all
+            int64_t n_real = 0;
+            rc = flatten_device(c, J.d_flow_img, J.rows, J.cols, 0, J.fx, J.fy, J.cx, J.cy, J.gamma, prm->flow_threshold, F->d_q, F->d_u, F->d_a, F->d_ak, &n_real);
+            if (rc == RSDSFM_OK && prm->use_global_shutter_mode) rc = alpha_ones_launch(c, F->d_a, n_real);
+            if (rc != RSDSFM_OK) return rc;
+            *count_host(c) = n_real;
+        }
         n = *count_host(c);
         F->n = n;
         F->refinement_enqueued = false;
@@ -316,6 +342,8 @@ void frame_release(Ctx* c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_seq) (void)hipEventDestroy(c->ev_seq);
     if (c->aux_stream) (void)hipStreamDestroy(c->aux_stream);
+    if (c->d_flat_counters) (void)hipFree(c->d_flat_counters);
+    c->d_flat_counters = nullptr;
     c->ev_fork = c->ev_join = c->ev_seq = nullptr;
     c->aux_stream = nullptr;
 }
@@ -369,7 +397,7 @@ int rsdsfm_set_sequence_lanes(rsdsfm_ctx* ctx, int32_t lanes) {
 
 int rsdsfm_set_frame_side_flatten(rsdsfm_ctx* ctx, int mode) {
     if (!ctx) return RSDSFM_ERR_INVALID;
-    if (mode < 0 || mode > 2) return fail(&ctx->c, RSDSFM_ERR_INVALID, "mode must be 0 (flatten first), 1 (flatten on a second stream) or 2 (flatten behind the minimal solver)");
+    if (mode < 0 || mode > 3) return fail(&ctx->c, RSDSFM_ERR_INVALID, "mode must be 0 (flatten first), 1 (flatten on a second stream), 2 (flatten behind the minimal solver) or 3 (flatten inside the solver's launch)");
     ctx->c.frame_side_flatten = mode;
     return RSDSFM_OK;
 }

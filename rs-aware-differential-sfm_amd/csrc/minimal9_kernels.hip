@@ -620,20 +620,19 @@ constexpr int kSlotsK = 294;                      // + k-estimation temporaries 
 // hyp_out: [T][8] = w(3), v(3), k, status (0 ok, -1 no real k, -2 singular system)
 // COOP = false: one hypothesis per LANE (throughput mode, many hypotheses); COOP = true: one hypothesis per WAVE -- every lane
 // evaluates the (cheap, register / per-lane-LDS) scalar parts redundantly and the 9x9 SVD is shared (latency mode)
+// the solver proper: the body of minimal9_kernel and of the solver workgroups of minimal9_flatten_kernel (one wave; `nblocks` = number
+// of workgroups that run this body, for the grid-strided clearing loop)
 template <bool COOP>
-__global__ __launch_bounds__(64) void minimal9_kernel(const double* __restrict__ q, const double* __restrict__ u,
-                                                     const double* __restrict__ alpha,
-                                                     const double* __restrict__ alpha_k,
-                                                     const int32_t* __restrict__ samples, int T, int use_alpha_k,
-                                                     int k_sign_mode, double* __restrict__ hyp_out, uint64_t* __restrict__ zero_words,
-                                                     int64_t n_zero_words, Minimal9Direct direct) {
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
+__device__ __forceinline__ void minimal9_body(double* lds, int block, int nblocks, int lane, const double* __restrict__ q,
+                                              const double* __restrict__ u, const double* __restrict__ alpha,
+                                              const double* __restrict__ alpha_k, const int32_t* __restrict__ samples, int T,
+                                              int use_alpha_k, int k_sign_mode, double* __restrict__ hyp_out,
+                                              uint64_t* __restrict__ zero_words, int64_t n_zero_words, const Minimal9Direct& direct) {
     // RANSAC: the per-hypothesis LM states, score marks and flag words must be zero before the depth solves start; the workgroups of
     // this launch clear them on the way (8-byte words, grid-strided) instead of a fill launch in front of it
     if (zero_words)
-        for (int64_t i = (int64_t)blockIdx.x * 64 + lane; i < n_zero_words; i += (int64_t)gridDim.x * 64) zero_words[i] = 0ull;
-    const int t = COOP ? (int)blockIdx.x : (int)blockIdx.x * 64 + lane;
+        for (int64_t i = (int64_t)block * 64 + lane; i < n_zero_words; i += (int64_t)nblocks * 64) zero_words[i] = 0ull;
+    const int t = COOP ? block : block * 64 + lane;
     if (t >= T) return;  // per-lane independent work, no workgroup barriers below
     LVec base{lds + lane};
     LVec Z = base.at(0), V = base.at(81), sv = base.at(162), col = base.at(171);
@@ -830,6 +829,120 @@ __global__ __launch_bounds__(64) void minimal9_kernel(const double* __restrict__
     o[5] = e[2];
     o[6] = k;
     o[7] = (double)rc;
+}
+
+template <bool COOP>
+__global__ __launch_bounds__(64) void minimal9_kernel(const double* __restrict__ q, const double* __restrict__ u,
+                                                     const double* __restrict__ alpha,
+                                                     const double* __restrict__ alpha_k,
+                                                     const int32_t* __restrict__ samples, int T, int use_alpha_k,
+                                                     int k_sign_mode, double* __restrict__ hyp_out, uint64_t* __restrict__ zero_words,
+                                                     int64_t n_zero_words, Minimal9Direct direct) {
+    extern __shared__ double lds[];
+    minimal9_body<COOP>(lds, (int)blockIdx.x, (int)gridDim.x, (int)threadIdx.x, q, u, alpha, alpha_k, samples, T, use_alpha_k, k_sign_mode, hyp_out,
+                        zero_words, n_zero_words, direct);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The minimal solver and the flatten of a DENSE frame in ONE launch.  The solver is latency-bound on T waves (one hypothesis per
+// wave, ~186 us of a serial division / square-root chain) while 950+ SIMDs idle; the flatten (main.cc:398-444: 16 B read + 48 B
+// written per pixel) needs ~10 us of the whole GPU.  Two streams could overlap them, but the cross-stream join costs more than the
+// flatten (measured).  So the workgroups of one launch take two roles: the first T run the solver on wave 0 (the
+// other three waves leave at once), forming their sampled points straight from the flow image (Minimal9Direct); the rest flatten.
+// A dense frame needs no scan: when every pixel carries flow, point index = column * rows + row, so every tile knows where it
+// writes.  Pixels that ARE dropped are counted (integer atomics); the workgroup that finishes last publishes rows * cols - dropped
+// to host-mapped memory and resets the counters, and the host -- which set the RANSAC up for n = rows * cols -- runs the general
+// flatten and everything behind it again if the count says the frame was not dense (frame_host.hip).  Same expressions
+// (flatten_point), same output order: the arrays of a dense frame are bit-identical to flatten_tile_kernel's.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kDF_W = 8, kDF_H = 64;  // tile columns (one 128-byte line per image row) x tile rows (one wave per column)
+
+__global__ __launch_bounds__(256) void minimal9_flatten_kernel(const int32_t* __restrict__ samples, int T, int use_alpha_k, int k_sign_mode,
+                                                              double* __restrict__ hyp_out, uint64_t* __restrict__ zero_words,
+                                                              int64_t n_zero_words, Minimal9Direct direct, double thr,
+                                                              double2* __restrict__ q, double2* __restrict__ u,
+                                                              double* __restrict__ alpha, double* __restrict__ alpha_k,
+                                                              unsigned long long* __restrict__ counters, int64_t* __restrict__ total_out,
+                                                              int tiles_x, int nflat) {
+    extern __shared__ double lds[];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x < T) {
+        if (tid >= 64) return;
+        minimal9_body<true>(lds, (int)blockIdx.x, T, tid, nullptr, nullptr, nullptr, nullptr, samples, T, use_alpha_k, k_sign_mode, hyp_out, zero_words,
+                            n_zero_words, direct);
+        return;
+    }
+    // ---- dense flatten of one 8 x 64 tile (the tile lives at the start of the dynamic LDS block) ----
+    double2(*s_tile)[kDF_W + 1] = reinterpret_cast<double2(*)[kDF_W + 1]>(lds);
+    const int b = (int)blockIdx.x - T;
+    const int rows = direct.rows, cols = direct.cols;
+    const int c0 = (b % tiles_x) * kDF_W, r0 = (b / tiles_x) * kDF_H;
+    const double2* img = reinterpret_cast<const double2*>(direct.img);
+#pragma unroll
+    for (int k = 0; k < kDF_H * kDF_W / 256; ++k) {
+        const int lr = tid / kDF_W + k * (256 / kDF_W), lc = tid % kDF_W;
+        const int r = r0 + lr, c = c0 + lc;
+        s_tile[lr][lc] = (r < rows && c < cols) ? img[(int64_t)r * cols + c] : make_double2(0.0, 0.0);
+    }
+    __syncthreads();
+    const int lane = tid & 63, wv = tid >> 6;
+    const double h = (double)rows;
+    unsigned dropped = 0;
+    for (int lc = wv; lc < kDF_W; lc += 4) {
+        const int i = c0 + lc, j = r0 + lane;  // column i, row j
+        if (i >= cols) break;
+        const double2 f = s_tile[lane][lc];
+        const bool inside = j < rows;
+        const bool keep = inside && f.x * f.x + f.y * f.y > thr;
+        dropped += (unsigned)__popcll(__ballot(inside && !keep));
+        if (keep) {
+            const int64_t o = (int64_t)i * rows + j;  // every pixel in front of this one is kept: a dense frame
+            const FlatPoint fp = flatten_point(f, i, j, direct.fx, direct.fy, direct.cx, direct.cy, direct.gamma, h);
+            q[o] = make_double2(fp.qx, fp.qy);
+            u[o] = make_double2(fp.ux, fp.uy);
+            alpha[o] = direct.alpha_ones ? fp.alpha * 0.0 + 1.0 : fp.alpha;
+            alpha_k[o] = fp.alpha_k;
+        }
+    }
+    // counters[0] = dropped pixels, counters[1] = flatten workgroups done; the last one publishes the count and resets both.
+    // No fence (a device-scope fence writes back the XCD's whole L2: measured ruinous in round 2): the only data another workgroup
+    // reads are the two counters, which are device-scope atomics performed at the memory side.  What has to be ordered is "this
+    // workgroup's dropped-count is added BEFORE its ticket is drawn": the add RETURNS its old value, the value travels through LDS
+    // into the operand of the ticket atomic (>> 63: always 0, but a real data dependency), so the ticket cannot issue earlier.
+    __shared__ unsigned long long s_prev[4];
+    if (lane == 0) s_prev[wv] = dropped ? atomicAdd(&counters[0], (unsigned long long)dropped) : 0ull;
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned long long seen = s_prev[0] | s_prev[1] | s_prev[2] | s_prev[3];
+        const unsigned long long ticket = atomicAdd(&counters[1], 1ull + (seen >> 63));
+        if (ticket == (unsigned long long)(nflat - 1)) {
+            const unsigned long long d = atomicAdd(&counters[0], ticket >> 63);  // (reads the sum; ordered behind the ticket the same way)
+            *total_out = (int64_t)rows * cols - (int64_t)d;
+            counters[0] = 0ull;
+            counters[1] = 0ull;
+        }
+    }
+}
+
+int minimal9_flatten_launch(Ctx* c, const int32_t* samples, int T, int use_alpha_k, int k_sign_mode, double* hyp_out, void* zero_begin, size_t zero_bytes,
+                            const Minimal9Direct& direct, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k,
+                            unsigned long long* d_counters, int64_t* total_out) {
+    const size_t lds_bytes = (size_t)(use_alpha_k ? kSlotsK : kSlotsNoK) * 64 * sizeof(double);
+    static_assert(sizeof(double2) * kDF_H * (kDF_W + 1) <= (size_t)kSlotsNoK * 64 * sizeof(double), "the flatten tile fits the solver's LDS block");
+    static bool attr_set_dev[64] = {false};
+    bool& attr_set = attr_set_dev[c->device & 63];
+    if (!attr_set) {
+        RSDSFM_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(minimal9_flatten_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)((size_t)kSlotsK * 64 * sizeof(double))));
+        attr_set = true;
+    }
+    const int tiles_x = (direct.cols + kDF_W - 1) / kDF_W, tiles_y = (direct.rows + kDF_H - 1) / kDF_H;
+    const int nflat = tiles_x * tiles_y;
+    hipLaunchKernelGGL(minimal9_flatten_kernel, dim3(T + nflat), dim3(256), lds_bytes, c->stream, samples, T, use_alpha_k, k_sign_mode, hyp_out,
+                       reinterpret_cast<uint64_t*>(zero_begin), (int64_t)(zero_bytes / 8), direct, thr, reinterpret_cast<double2*>(d_q),
+                       reinterpret_cast<double2*>(d_u), d_alpha, d_alpha_k, d_counters, total_out, tiles_x, nflat);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
 }
 
 int minimal9_launch(Ctx* c, const double* q, const double* u, const double* alpha, const double* alpha_k,

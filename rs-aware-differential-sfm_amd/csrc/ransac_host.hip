@@ -105,8 +105,13 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                 if (!zero_in_minimal9) RSDSFM_HIP_CHECK(c, hipMemsetAsync(R.zero_begin, 0, R.zero_bytes, c->stream));
                 if (T > 0) {
                     memcpy(R.h_samples_pinned, R.samples.data(), sizeof(int32_t) * (size_t)T * 9);
-                    rc = minimal9_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, R.h_samples_pinned, T, R.use_alpha_k, R.k_sign_mode, R.d_hyp,
-                                         zero_in_minimal9 ? R.zero_begin : nullptr, zero_in_minimal9 ? R.zero_bytes : 0, R.direct);
+                    if (R.direct && R.dense && T <= c->num_cus * 2)  // one launch: T solver workgroups + the dense flatten's
+                        rc = minimal9_flatten_launch(c, R.h_samples_pinned, T, R.use_alpha_k, R.k_sign_mode, R.d_hyp, zero_in_minimal9 ? R.zero_begin : nullptr,
+                                                     zero_in_minimal9 ? R.zero_bytes : 0, *R.direct, R.dense->thr, R.dense->d_q, R.dense->d_u, R.dense->d_alpha,
+                                                     R.dense->d_alpha_k, R.dense->d_counters, R.dense->total_out);
+                    else
+                        rc = minimal9_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, R.h_samples_pinned, T, R.use_alpha_k, R.k_sign_mode, R.d_hyp,
+                                             zero_in_minimal9 ? R.zero_begin : nullptr, zero_in_minimal9 ? R.zero_bytes : 0, R.direct);
                     if (rc != RSDSFM_OK) return rc;
                     if (R.after_minimal9) {  // (the frame solve: join the stream that ran the flatten beside the minimal solver)
                         rc = (*R.after_minimal9)();
@@ -278,7 +283,7 @@ void ransac_commit_hints(Ctx* c, const RansacRun& R) {
 int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n, int use_alpha_k, int T,
                  double tol, const int32_t* h_samples, uint64_t seed, int depth_mode, int k_sign_mode, rsdsfm_ransac_out* out,
                  const RansacSpecTail* spec_tail, bool* spec_tail_held, RansacRun* run, const Minimal9Direct* direct,
-                 const std::function<int()>* after_minimal9) {
+                 const std::function<int()>* after_minimal9, const DenseFlatten* dense) {
     RansacRun& R = *run;
     R = RansacRun();
     if (spec_tail_held) *spec_tail_held = false;
@@ -336,7 +341,7 @@ int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a
     R.d_q = d_q, R.d_u = d_u, R.d_a = d_a, R.d_ak = d_ak;
     R.n = n, R.T = T, R.Tn = Tn, R.batch = batch, R.tol = tol, R.depth_mode = depth_mode, R.use_alpha_k = use_alpha_k, R.k_sign_mode = k_sign_mode;
     R.out = out, R.spec_tail = spec_tail, R.spec_tail_held = spec_tail_held;
-    R.direct = direct, R.after_minimal9 = after_minimal9;
+    R.direct = direct, R.after_minimal9 = after_minimal9, R.dense = dense;
     // speculation depth of round 0 (see ransac_kernels.hip): explicit, or two iterations behind a solve none of whose hypotheses
     // went beyond one accepted step (outlier-dominated costs), three otherwise.  Like fused_base below: scheduling only.
     R.k0 = c->ransac_k0 != 0 ? c->ransac_k0 : (c->ransac_not_one_step == 0 ? 2 : (int)KMAX);

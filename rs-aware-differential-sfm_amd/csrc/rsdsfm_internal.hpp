@@ -137,7 +137,8 @@ struct Ctx {
     void* frame_run = nullptr;
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_seq = nullptr;
-    int frame_side_flatten = 0;  // rsdsfm_set_frame_side_flatten: where a dense frame's flatten runs -- 0 first, 1 on aux_stream beside the minimal solver, 2 behind it
+    int frame_side_flatten = 3;  // rsdsfm_set_frame_side_flatten: where a dense frame's flatten runs -- 0 first, 1 on aux_stream beside the minimal solver, 2 behind it, 3 INSIDE the solver's launch
+    unsigned long long* d_flat_counters = nullptr;  // the two counters of minimal9_flatten_kernel (zero between launches)
     int seq_lanes = 0;               // rsdsfm_set_sequence_lanes (0 = kSequenceLanesDefault)
     std::vector<rsdsfm_ctx*> lanes;
 };
@@ -263,6 +264,17 @@ struct Minimal9Direct {
 int minimal9_launch(Ctx* c, const double* q, const double* u, const double* alpha, const double* alpha_k,
                     const int32_t* samples, int T, int use_alpha_k, int k_sign_mode, double* hyp_out, void* zero_begin = nullptr,
                     size_t zero_bytes = 0, const Minimal9Direct* direct = nullptr);
+// the solver (direct mode, one wave per hypothesis) and the flatten of a DENSE frame as two roles of ONE launch (minimal9_kernels.hip);
+// d_counters: two zero-initialised device words the launch leaves zero again; *total_out (host-mapped) = kept pixels
+struct DenseFlatten {
+    double thr = 0.0;
+    double *d_q = nullptr, *d_u = nullptr, *d_alpha = nullptr, *d_alpha_k = nullptr;
+    unsigned long long* d_counters = nullptr;
+    int64_t* total_out = nullptr;
+};
+int minimal9_flatten_launch(Ctx* c, const int32_t* samples, int T, int use_alpha_k, int k_sign_mode, double* hyp_out, void* zero_begin, size_t zero_bytes,
+                            const Minimal9Direct& direct, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k,
+                            unsigned long long* d_counters, int64_t* total_out);
 }  // namespace rsdsfm
 
 namespace rsdsfm {
@@ -342,6 +354,7 @@ struct RansacRun {
     const RansacSpecTail* spec_tail = nullptr;
     bool* spec_tail_held = nullptr;
     const Minimal9Direct* direct = nullptr;
+    const DenseFlatten* dense = nullptr;  // with `direct`: the flatten of the dense frame rides in the solver's launch
     const std::function<int()>* after_minimal9 = nullptr;
     std::vector<int32_t> samples;
     // workspace (device) and pinned host views
@@ -368,7 +381,7 @@ struct RansacRun {
 int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n, int use_alpha_k, int T,
                  double tol, const int32_t* h_samples, uint64_t seed, int depth_mode, int k_sign_mode, rsdsfm_ransac_out* out,
                  const RansacSpecTail* spec_tail, bool* spec_tail_held, RansacRun* run, const Minimal9Direct* direct,
-                 const std::function<int()>* after_minimal9);
+                 const std::function<int()>* after_minimal9, const DenseFlatten* dense = nullptr);
 int ransac_finish(Ctx* c, RansacRun* run);
 void ransac_commit_hints(Ctx* c, const RansacRun& run);
 int flatten_enqueue(Ctx* c, const double* d_img, int32_t rows, int32_t cols, double fx, double fy, double cx, double cy, double gamma,

@@ -191,7 +191,7 @@ def test_side_flatten_and_direct_minimal_solver_do_not_change_results(rsdsfm):
         img = torch.from_numpy(img_h).to(dev)
         rows, cols = d["rows"], d["cols"]
         outs = []
-        for side in (2, 1, 0):  # flatten behind the minimal solver (default) / beside it on a second stream / in front of it
+        for side in (3, 2, 1, 0):  # flatten inside the minimal solver's launch (default) / behind it / beside it on a second stream / in front of it
             with rsdsfm.Solver(0) as s:
                 s.set_frame_side_flatten(side)
                 got = []
@@ -204,7 +204,7 @@ def test_side_flatten_and_direct_minimal_solver_do_not_change_results(rsdsfm):
                     got.append((r["n"], r["num_inliers"], r["best_trial"], r["ransac_v"].tobytes(), r["ransac_w"].tobytes(), r["ransac_k"], r["v"].tobytes(),
                                 r["w"].tobytes(), r["k"], r["refine_summary"]["final_cost"], dm.cpu().numpy().tobytes(), R.cpu().numpy().tobytes()))
                 outs.append(got)
-        assert outs[0] == outs[1] == outs[2], (cfg, kw)
+        assert outs[0] == outs[1] == outs[2] == outs[3], (cfg, kw)
 
 
 def test_sequence_solve_equals_single_solves(rsdsfm):

@@ -96,6 +96,58 @@ def test_image_helpers_on_the_host(tmp_path, rsdsfm, oracle):
     assert F.abs_diff(np.array([3, 250], dtype=np.uint8), np.array([10, 5], dtype=np.uint8)).tolist() == [7, 245]
 
 
+def _build_sequence(tmp_path):
+    """tests/cpp/sequence_run.cpp: a C++ host of the sequence solve (rsdsfm_solve_frames_dev) against the C ABI + the HIP runtime only"""
+    exe = os.path.join(str(tmp_path), "sequence_run")
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-o", exe,
+           os.path.join(ROOT, "tests", "cpp", "sequence_run.cpp"), "-L", PKG, "-lrsdsfm_hip", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_sequence_host_compiles_and_links(tmp_path, rsdsfm):
+    rsdsfm.load_library()
+    exe = _build_sequence(tmp_path)
+    assert subprocess.run([exe], capture_output=True).returncode == 2  # usage, no GPU work
+
+
+@pytest.mark.gpu
+def test_sequence_host_in_cpp_equals_single_solves(tmp_path, rsdsfm):
+    """BASELINE configs[4] from a C++ host (the reference is C++): 7 pairs with different data seeds, one of them with dropped pixels,
+    through ONE rsdsfm_solve_frames_dev call over 3 lanes; every pair equals rsdsfm_solve_frame_dev on another context bit for bit
+    (pose, counts, iteration count, depth map), and the Python binding's single solve agrees"""
+    import torch
+
+    exe = _build_sequence(tmp_path)
+    B, rows, cols = 7, 120, 200
+    imgs = []
+    for i in range(B):
+        d = rsdsfm.synth.make_config(5 if i % 2 == 0 else 3, rows=rows, cols=cols, seed=0x5EED0200 + i)
+        im = d["flow_img"].copy()
+        if i == 3:
+            im[30:50, 60:90] = 0.0
+        imgs.append(im)
+    K, gamma = d["K"], d["gamma"]
+    raw = os.path.join(str(tmp_path), "flows.bin")
+    np.stack(imgs).astype(np.float64).tofile(raw)
+    T, tol = 10, 0.01
+    out = subprocess.run([exe, raw, str(B), str(rows), str(cols)] + ["%.17g" % x for x in K] + ["%.17g" % gamma, str(T), "%.17g" % tol, "3"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    recs = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(recs) == B and all(r["equals_single_solve"] for r in recs), recs
+    assert recs[3]["n"] == rows * cols - 20 * 30 and recs[0]["n"] == rows * cols
+    dev = torch.device("cuda", 0)
+    with rsdsfm.Solver(0) as s:
+        for i in (0, 3, 6):
+            img = torch.from_numpy(imgs[i]).to(dev)
+            dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+            one = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=T, tol=tol, seed=100 + 7 * i)
+            assert one["num_inliers"] == recs[i]["num_inliers"] and one["best_trial"] == recs[i]["best_trial"]
+            assert np.array_equal(one["v"], recs[i]["v"]) and np.array_equal(one["w"], recs[i]["w"])
+
+
 def test_tiled_host_compiles_and_links(tmp_path, rsdsfm):
     rsdsfm.load_library()
     exe = _build_tiled(tmp_path)

@@ -8,7 +8,10 @@ f = glob.glob(sys.argv[1] + "/**/*_results.db", recursive=True)[0]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 cur = sqlite3.connect(f).cursor()
 rows = list(cur.execute("select name, start, end from kernels order by start"))
-starts = [i for i, r in enumerate(rows) if "flatten_tile_kernel<0>" in r[0] or "flatten_tile_kernel<false>" in r[0]]
+# a solve starts with the minimal solver's launch (which carries the flatten of a dense frame) or, on the older path, with the flatten
+starts = [i for i, r in enumerate(rows) if "minimal9_flatten_kernel" in r[0]]
+if len(starts) < k + 2:
+    starts = [i for i, r in enumerate(rows) if "flatten_tile_kernel<0>" in r[0] or "flatten_tile_kernel<false>" in r[0]]
 if len(starts) < k + 2:
     starts = [i for i, r in enumerate(rows) if "flatten_tile_kernel" in r[0]][::2]
 a, b = starts[k], starts[k + 1]

@@ -386,8 +386,15 @@ def run(args):
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists)")
-    if os.environ.get("RSDSFM_SHARE_GPU"):  # smoke test only: several ranks on one device
+    if os.environ.get("RSDSFM_SHARE_GPU"):
+        # development boxes have ONE GPU: several ranks share device 0.  RCCL refuses two ranks of one HOST on one device, but it
+        # identifies the host by NCCL_HOSTID when that is set -- with one id per rank it treats the ranks as single-GPU nodes and
+        # connects them through its socket transport over the loopback interface.  Not xGMI (the rates mean nothing), but the
+        # multi-rank RCCL path for real: torch's process group and the library's own communicator with N ranks.
         local_rank = 0
+        os.environ.setdefault("NCCL_HOSTID", "rsdsfm-shared-gpu-rank-%d" % rank)
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

@@ -1,0 +1,80 @@
+"""Helper of tests/test_gpu_tiled_native.py (not a test): one rank of a 2-process run of the NATIVE column-tiled solve over a REAL
+2-rank RCCL communicator on ONE GPU.  RCCL refuses two ranks of one host on one device ("Duplicate GPU detected"), but it identifies a
+host by NCCL_HOSTID when that is set: giving every rank its own makes RCCL treat the ranks as two single-GPU nodes and connect them
+through its socket transport over the loopback interface.  That is not xGMI -- it proves nothing about bandwidth -- but it runs the
+multi-rank code path for real: ncclCommInitRank with 2 ranks from the broadcast unique id, in-place ncclAllGather (ncclChar) and
+ncclAllReduce on the context's stream, a second communicator next to torch's, and the driver's rank-ordered protocol on top.
+The unique id travels over a gloo group.  Environment per rank (set by the test): NCCL_HOSTID, NCCL_SOCKET_IFNAME=lo, NCCL_IB_DISABLE=1."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ["NCCL_HOSTID"] = "rsdsfm-test-host-%d" % rank  # before RCCL is loaded
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
+    import torch
+    import torch.distributed as dist
+
+    import rsdsfm
+
+    dist.init_process_group("gloo")
+    dev = torch.device("cuda", 0)
+    flow_mode = int(os.environ.get("RSDSFM_TEST_FLOW_MODE", "0"))
+    d = rsdsfm.synth.make_config(3, rows=96, cols=250)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    c0, sc, per = rsdsfm.tiled_slab_bounds(cols, world, rank)
+    solver = rsdsfm.Solver(0)
+    ident = torch.zeros(rsdsfm.DIST_ID_BYTES, dtype=torch.uint8)
+    if rank == 0:
+        ident = torch.frombuffer(bytearray(rsdsfm.dist_unique_id()), dtype=torch.uint8).clone()
+    dist.broadcast(ident, 0)
+    out = {"world": world, "init": None}
+    try:
+        solver.dist_init(world, rank, bytes(ident.numpy().tobytes()))
+        out["init"] = "ok"
+    except rsdsfm.RsdsfmError as e:  # e.g. a box whose RCCL cannot open the loopback interface: reported, the test skips
+        out["init"] = str(e)
+    if out["init"] == "ok":
+        slab = torch.from_numpy(np.ascontiguousarray(d["flow_img"][:, c0:c0 + sc, :])).to(dev)  # each rank only holds its slab
+        dm = torch.zeros(cols * rows, dtype=torch.float64, device=dev)
+        for rep in range(2):  # the communicator is reused across solves
+            r = solver.solve_frame_tiled_dev(slab.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=14, tol=0.002, seed=7, flow_index_mode=flow_mode)
+        torch.cuda.synchronize()
+        dmh = dm.cpu().numpy()
+        mine = np.concatenate([r["v"], r["w"], [r["k"], r["num_inliers"], r["best_trial"], float((dmh != 0).sum()), dmh.sum()]])
+        t = torch.from_numpy(mine).clone()
+        outs = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(outs, t)
+        out.update(n=r["n"], num_inliers=r["num_inliers"], best_trial=r["best_trial"], v=list(r["v"]), w=list(r["w"]), k=r["k"],
+                   depth_nonzero=int((dmh != 0).sum()), depth_sum=float(dmh.sum()), ranks_agree=bool(all(torch.equal(o, outs[0]) for o in outs)), info=r["info"],
+                   iterations=r["refine_summary"]["num_iterations"])
+        # the row-tiled dense depth solve over the same communicator
+        t_ = d["truth"]
+        v = t_["v"] / np.linalg.norm(t_["v"])
+        n = len(d["alpha"])
+        i0, cnt, _ = rsdsfm.tiled_shard_bounds(n, world, rank)
+        tt = lambda a: torch.from_numpy(np.ascontiguousarray(a[i0:i0 + cnt])).to(dev)
+        q, u, a, ak = tt(d["q"]), tt(d["u"]), tt(d["alpha"]), tt(d["alpha_k"])
+        full = torch.zeros(max(n, 2), dtype=torch.float64, device=dev)
+        sm, info = solver.estimate_inverse_depths_tiled_dev(q.data_ptr(), u.data_ptr(), n, v, t_["w"], 0.0, a.data_ptr(), ak.data_ptr(), full.data_ptr())
+        torch.cuda.synchronize()
+        out.update(depth_sum_tiled=float(full[:n].sum().item()), depth_lm=sm, depth_info=info)
+        solver.dist_finalize()
+    if rank == 0:
+        with open(os.environ["RSDSFM_TILED_OUT"], "w") as f:
+            json.dump(out, f)
+    solver.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -349,6 +349,41 @@ def test_native_tiled_two_processes_share_the_gpu(rsdsfm, tmp_path, flow_mode):
     assert got["depth_nonzero"] == int((one["depth_map"] != 0).sum()) and np.isclose(got["depth_sum"], one["depth_map"].sum(), rtol=1e-9)
 
 
+@pytest.mark.parametrize("flow_mode", [0, 1])
+def test_native_tiled_over_a_real_two_rank_rccl_communicator(rsdsfm, tmp_path, flow_mode):
+    """TWO ranks over RCCL itself on the one GPU of the box (tests/mp_tiled_rccl.py): RCCL identifies a host by NCCL_HOSTID, so one id
+    per rank makes it treat the ranks as two single-GPU nodes joined by its socket transport over the loopback interface -- not
+    xGMI, but the multi-rank code path for real: ncclCommInitRank(2 ranks) from the broadcast unique id, in-place ncclAllGather
+    (ncclChar) / ncclAllReduce on the context's stream, the rank-ordered protocol of the driver (incl. the rank-indexed flow exchange in
+    flow_mode 0 and the row-tiled depth solve).  Rank 0's result equals the single-context solve; both ranks agree bit for bit."""
+    import torch
+
+    out = tmp_path / "res.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RSDSFM_TILED_OUT=str(out), RSDSFM_TEST_FLOW_MODE=str(flow_mode), NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1")
+    env.pop("NCCL_HOSTID", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(29651 + flow_mode),
+           os.path.join(ROOT, "tests", "mp_tiled_rccl.py")]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    got = json.loads(out.read_text())
+    if got["init"] != "ok":
+        pytest.skip("this box's RCCL cannot connect two ranks over the loopback interface: " + got["init"][:300])
+    stream = torch.cuda.Stream(torch.device("cuda", 0))
+    d = rsdsfm.synth.make_config(3, rows=96, cols=250)
+    with torch.cuda.stream(stream):
+        one = _single(rsdsfm, torch, d, stream, trials=14, tol=0.002, seed=7, flow_index_mode=flow_mode)
+    assert got["world"] == 2 and got["ranks_agree"] and got["info"]["nranks"] == 2
+    assert got["n"] == one["n"] and got["num_inliers"] == one["num_inliers"] and got["best_trial"] == one["best_trial"]
+    assert got["iterations"] == one["refine_summary"]["num_iterations"]
+    assert np.allclose(got["v"], one["v"], rtol=1e-9) and np.allclose(got["w"], one["w"], rtol=1e-9)
+    assert got["depth_nonzero"] == int((one["depth_map"] != 0).sum()) and np.isclose(got["depth_sum"], one["depth_map"].sum(), rtol=1e-9)
+    # the row-tiled dense depth solve over the same communicator = the single-context solve
+    t = d["truth"]
+    rho, sm = _depth_single(rsdsfm, torch, d, t["v"] / np.linalg.norm(t["v"]), t["w"], 0.0, 1)
+    assert got["depth_lm"]["num_iterations"] == sm["num_iterations"] and got["depth_lm"]["termination"] == sm["termination"]
+    assert np.isclose(got["depth_sum_tiled"], rho.sum(), rtol=1e-12) and got["depth_info"]["nranks"] == 2
+
+
 # ---------------------------------------------------------------------------------------------------
 # the row-tiled DENSE DEPTH solve driven from C++ (rsdsfm_estimate_inverse_depths_tiled_dev)
 # ---------------------------------------------------------------------------------------------------

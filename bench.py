@@ -8,19 +8,24 @@ Contract: python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on
               Ceres-LM depth solves of ALL pixels, scoring, best trial, compaction), joint nonlinear refinement, sign fix + depth
               map, per-scanline pose table (reference main.cc:398-522), ONE C-ABI call per pair (rsdsfm_solve_frame_dev), one
               pair at a time.  `value` = pixels of the K timed pairs / the time of the K steps; `median_ms_per_solve` beside it.
-              `roofline`: the dominant kernel ransac_lm_kernel<true> (fp64 VALU bound: counted fp64 lane-instructions / its
-              launch duration, measured here with HIP events, / 39.3e12) and, under "hbm", SURVEY 8(d)'s whole-solve figure
-              (57 N + 64 M iters bytes / solve time / 8 TB/s).  `cpu_baseline`: the oracle's whole solve on the SAME pair, same
-              trial count.  `depth_only`: BASELINE configs[1] (dense depth solve alone, pose fixed, batched sequence mode).
-              depth             : BASELINE configs[1] as the timed workload: 1280x720, per-pixel depth solve (Ceres-LM emulation),
-                                  pose fixed; --batch / --streams / --pairs-per-step apply.
-              depth_closed_form : same with the exact closed-form per-pixel solve.
-              tiled             : BASELINE configs[3]-style row tiling of the DEPTH solve: a 3840x2160 frame sharded over the N
-                                  ranks, LM sum rows + ONE all-gather of the depth map over RCCL (scaling "strong").
-              tiled_full        : the WHOLE solve of a 3840x2160 frame split into column slabs over the N ranks (scaling "strong").
-              rectify / true_flow / metrics : SURVEY 8(f-1) / (f-2) / (f-4) consumers on a 1280x720 frame.
-  N > 1     = one process per GPU (torch.distributed / RCCL).  full / depth: each rank solves its own frame pairs
-              (BASELINE configs[4], sequence throughput), no data-path collective -> scaling "weak".
+              Sub-records of the line:
+                roofline            the dominant kernel ransac_lm_kernel<true> (fp64 VALU bound: counted fp64 lane-instructions / its
+                                    launch duration, measured here with HIP events, / 39.3e12; counts from profiles/counters.json, which
+                                    is stamped with the kernel source hashes -- `counters_stale` when they do not match) and, under
+                                    "hbm", SURVEY 8(d)'s whole-solve figure (57 N + 64 M iters bytes / solve time / 8 TB/s)
+                regimes             the same solve, driver-timed, with T = 5, a selective tolerance, noise-free flow, acceleration mode, 1920x1080
+                full_solve_batched  BASELINE configs[4]: 32 pairs with 32 data seeds through rsdsfm_solve_frames_dev (one context, one host thread)
+                tiled_full          north_star's multi-GPU claim: ONE 3840x2160 frame in N column slabs through the native RCCL driver
+                                    (scaling "strong"), with the DESIGN section 8 model beside the measurement; runs last, under a watchdog
+                cpu_baseline        the oracle's whole solve of the SAME pair, 1 thread (+ all_cores, + reference_structured: per-call
+                                    problem build with per-pixel heap objects and dual-number Jacobians)
+                depth_only          BASELINE configs[1] (dense depth solve alone, pose fixed, batched sequence mode; HBM roofline)
+              depth / depth_closed_form / tiled / tiled_full / rectify / true_flow / metrics : those workloads as the timed one.
+  N > 1     = one process per GPU.  `python bench.py --gpus N` starts its N ranks itself (the parent never touches a GPU; --dry-launch
+              prints the rank environments); under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the ranks
+              run as launched.  `value` = N independent replicas of the whole solve (BASELINE configs[4], no data-path collective ->
+              scaling "weak"); `tiled_full` = the strong-scaling record.  RSDSFM_SHARE_GPU=1 puts all ranks on device 0 with one
+              NCCL_HOSTID each (RCCL then connects them over its socket transport: the N-rank path on a one-GPU box).
   --arith fused = the opt-in librsdsfm_hip_fused.so (explicit fmas in the per-pixel model) instead of the reference-arithmetic
               default; the default line carries its whole-solve time as `full_solve_fused`.
 Frame pairs rotate through distinct HBM buffers, so the timed loops stream from HBM, not from the 256 MiB Infinity Cache.

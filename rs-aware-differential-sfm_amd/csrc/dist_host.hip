@@ -368,6 +368,8 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
     DeviceGuard device_guard_(c);
     if (!prm || !res || rows <= 0 || cols <= 0 || !d_depth_map) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     if (prm->flow_index_mode != RSDSFM_FLOW_COMPAT_RANK && prm->flow_index_mode != RSDSFM_FLOW_GATHERED) return fail(c, RSDSFM_ERR_INVALID, "unknown flow_index_mode");
+    if (prm->struct_bytes != 0 && prm->struct_bytes != (int32_t)sizeof(rsdsfm_frame_params))
+        return fail(c, RSDSFM_ERR_INVALID, "rsdsfm_frame_params: struct_bytes is neither 0 nor sizeof(rsdsfm_frame_params) -- caller built against another header (use rsdsfm_frame_params_init)");
     const int depth_mode = prm->depth_mode;
     if (depth_mode != RSDSFM_DEPTH_CLOSED_FORM && depth_mode != RSDSFM_DEPTH_CERES_LM) return fail(c, RSDSFM_ERR_INVALID, "unknown depth_mode");
     const int T = prm->ransac_trials;

@@ -218,7 +218,7 @@ def refine_reference_structured(flow, inliers, alpha, alpha_k, v, w, k, const_ac
     return dict(inliers=out, v=np.array(vo[:]), w=np.array(wo[:]), k=ko.value, summary=sm.as_dict())
 
 
-VARIANTS = {"ftol": 0, "jacobi": 1, "mindiag": 2, "dsq": 3, "radius": 4, "ftol_lt": 5}
+VARIANTS = {"ftol": 0, "jacobi": 1, "mindiag": 2, "dsq": 3, "radius": 4, "ftol_lt": 5, "svd_sign": 6}
 
 
 class variant:

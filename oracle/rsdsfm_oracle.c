@@ -34,6 +34,31 @@
 #define M_PI 3.14159265358979323846
 #endif
 
+/* SENSITIVITY SWITCHES (tests/test_oracle_sensitivity.py, tools/oracle_sensitivity.py).  The trust-region loops further down restate
+ * Ceres 1.14 from recollection -- Ceres is not on disk (PARITY UNPINNED).  Each switch replaces ONE recalled detail by a plausible
+ * alternative reading, so that the effect of a wrong recollection on the integer outputs (inlier masks, winners, LM step counts)
+ * and on the digits of rho / v / w can be measured instead of guessed.  All zero = the oracle as pinned by the parity tests;
+ * nothing outside the sensitivity study ever sets them.
+ *   RSO_VAR_FTOL     0: function tolerance tested on the candidate BEFORE acceptance, candidate not applied on convergence
+ *                    1: same test, but a candidate that would have been accepted IS applied before terminating
+ *                    2: tested only after an accepted step (an unsuccessful step cannot converge by function tolerance)
+ *   RSO_VAR_JACOBI   0: Jacobi column scaling 1 / (1 + ||J_col||) from the iteration-0 Jacobian   1: no scaling
+ *   RSO_VAR_MINDIAG  0: LM diagonal clamp(||J_col||^2, 1e-6, 1e32)                                 1: no clamp
+ *   RSO_VAR_DSQ      0: D^2 = clamp(diag) * (1 / radius)   1: D = sqrt(clamp(diag) / radius), D^2 = D * D (Ceres' literal form)
+ *   RSO_VAR_RADIUS   0: accepted step: radius /= max(1/3, 1 - (2 rho_q - 1)^3)
+ *                    1: textbook rule: radius *= 3 if rho_q > 0.75, unchanged above 0.25, / 2 below
+ *   RSO_VAR_FTOL_LT  0: |cost change| <= tol * cost   1: strict < (Ceres <= 1.12 wrote <)
+ * and one recalled detail of Eigen 3.3.4 (JacobiSVD):
+ *   RSO_VAR_SVD_SIGN 0: the sign of the null vector V.col(8) as the restated two-sided Jacobi sweep leaves it   1: the opposite sign
+ *                    (implementation-defined in Eigen; it flips v and every inverse depth, and the LM trajectories that start at
+ *                    rho = 1 are not symmetric under it)                                                                        */
+enum { RSO_VAR_FTOL = 0, RSO_VAR_JACOBI, RSO_VAR_MINDIAG, RSO_VAR_DSQ, RSO_VAR_RADIUS, RSO_VAR_FTOL_LT, RSO_VAR_SVD_SIGN, RSO_VAR_COUNT };
+static int g_var[RSO_VAR_COUNT] = {0};
+int rso_set_variant(int which, int value) {
+    if (which < 0 || which >= RSO_VAR_COUNT) return -1;
+    g_var[which] = value;
+    return 0;
+}
 /* ------------------------------------------------------------------------------------------------ */
 /* RS scale factors                                                                                  */
 /* ------------------------------------------------------------------------------------------------ */
@@ -603,7 +628,7 @@ int rso_calculate_velocities(const double q[18], const double u[18], const doubl
     double sv[9], V[81];
     jacobi_svd_square(Z, 9, sv, V);
     double e[9];
-    for (int i = 0; i < 9; ++i) e[i] = V[i * 9 + 8];
+    for (int i = 0; i < 9; ++i) e[i] = g_var[RSO_VAR_SVD_SIGN] ? -V[i * 9 + 8] : V[i * 9 + 8];
     double norm_v0 = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
     for (int i = 0; i < 9; ++i) e[i] = e[i] / norm_v0;
     double v0[3] = {e[0], e[1], e[2]};
@@ -740,27 +765,6 @@ static inline void jac_rho(double x, double y, double alpha, double alpha_k, con
 
 static inline double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
-/* SENSITIVITY SWITCHES (tests/test_oracle_sensitivity.py, tools/oracle_sensitivity.py).  The trust-region loop below restates
- * Ceres 1.14 from recollection -- Ceres is not on disk (PARITY UNPINNED).  Each switch replaces ONE recalled detail by a plausible
- * alternative reading, so that the effect of a wrong recollection on the integer outputs (inlier masks, winners, LM step counts)
- * and on the digits of rho / v / w can be measured instead of guessed.  All zero = the oracle as pinned by the parity tests;
- * nothing outside the sensitivity study ever sets them.
- *   RSO_VAR_FTOL     0: function tolerance tested on the candidate BEFORE acceptance, candidate not applied on convergence
- *                    1: same test, but a candidate that would have been accepted IS applied before terminating
- *                    2: tested only after an accepted step (an unsuccessful step cannot converge by function tolerance)
- *   RSO_VAR_JACOBI   0: Jacobi column scaling 1 / (1 + ||J_col||) from the iteration-0 Jacobian   1: no scaling
- *   RSO_VAR_MINDIAG  0: LM diagonal clamp(||J_col||^2, 1e-6, 1e32)                                 1: no clamp
- *   RSO_VAR_DSQ      0: D^2 = clamp(diag) * (1 / radius)   1: D = sqrt(clamp(diag) / radius), D^2 = D * D (Ceres' literal form)
- *   RSO_VAR_RADIUS   0: accepted step: radius /= max(1/3, 1 - (2 rho_q - 1)^3)
- *                    1: textbook rule: radius *= 3 if rho_q > 0.75, unchanged above 0.25, / 2 below
- *   RSO_VAR_FTOL_LT  0: |cost change| <= tol * cost   1: strict < (Ceres <= 1.12 wrote <)                                     */
-enum { RSO_VAR_FTOL = 0, RSO_VAR_JACOBI, RSO_VAR_MINDIAG, RSO_VAR_DSQ, RSO_VAR_RADIUS, RSO_VAR_FTOL_LT, RSO_VAR_COUNT };
-static int g_var[RSO_VAR_COUNT] = {0};
-int rso_set_variant(int which, int value) {
-    if (which < 0 || which >= RSO_VAR_COUNT) return -1;
-    g_var[which] = value;
-    return 0;
-}
 static inline double lm_diag(double ht) { return g_var[RSO_VAR_MINDIAG] ? ht : clampd(ht, CERES_MIN_LM_DIAG, CERES_MAX_LM_DIAG); }
 static inline double lm_dsq(double diag, double radius, double inv_radius) {
     if (g_var[RSO_VAR_DSQ]) {

@@ -104,7 +104,8 @@ int rso_ransac(const double* q2n, const double* u2n, const double* alpha_n, cons
 /* nonlinearRefinement.cc:183-252.  flow_index_mode 0 = compat (quirk Q2: flow(.,rank)), 1 = gathered
  * (flow(., inlier_idx[rank])).  inliers_out is 3xM. */
 /* sensitivity study only (tests/test_oracle_sensitivity.py): replaces one recalled detail of the Ceres 1.14 loop by an alternative
- * reading (which: 0 function-tolerance placement, 1 Jacobi scaling, 2 diagonal clamp, 3 literal D^2, 4 radius rule, 5 strict <);
+ * reading (which: 0 function-tolerance placement, 1 Jacobi scaling, 2 diagonal clamp, 3 literal D^2, 4 radius rule, 5 strict <,
+ * 6 the sign of Eigen's SVD null vector);
  * value 0 = the pinned oracle.  Returns 0, or -1 for an unknown switch. */
 int rso_set_variant(int which, int value);
 /* test diagnostics: per-iteration trace of the next rso_refine calls (rows x 8 doubles, caller NaN-fills; NULL = off) */

@@ -24,7 +24,8 @@ SWITCHES = [("ftol", 1, "function tolerance: a candidate that would be accepted 
             ("jacobi", 1, "no Jacobi column scaling"),
             ("mindiag", 1, "LM diagonal not clamped to [1e-6, 1e32]"),
             ("dsq", 1, "D^2 formed as sqrt(diag / radius)^2 (Ceres' literal form) instead of diag * (1 / radius)"),
-            ("radius", 1, "textbook radius rule (x3 above 0.75, / 2 below 0.25) instead of 1 / max(1/3, 1 - (2 rho - 1)^3)")]
+            ("radius", 1, "textbook radius rule (x3 above 0.75, / 2 below 0.25) instead of 1 / max(1/3, 1 - (2 rho - 1)^3)"),
+            ("svd_sign", 1, "Eigen's JacobiSVD leaves the null vector V.col(8) with the opposite sign (implementation-defined)")]
 
 
 def chain(O, d, T, tol, seed, accel=False):
@@ -61,6 +62,10 @@ def rel_quantiles(a, b):
 
 def compare(base, var):
     rb, rv = base["ransac"], var["ransac"]
+    # a flipped null vector flips the RANSAC's v and every inverse depth (main.cc:466-478 undoes it after the refinement): compare the
+    # winner's dense 1/depth and the RANSAC pose up to that global sign
+    sgn = 1.0 if float(np.dot(rb["v"], rv["v"])) >= 0 else -1.0
+    rv = dict(rv, inv_depth=sgn * rv["inv_depth"], v=sgn * rv["v"])
     out = {"winner_same": bool(rb["best_trial"] == rv["best_trial"]),
            "inlier_count": [int(rb["num_inliers"]), int(rv["num_inliers"])],
            "mask_bits_flipped": int(np.count_nonzero(rb["mask"] != rv["mask"])),
@@ -74,6 +79,7 @@ def compare(base, var):
            "ransac_v_rel": rel_norm(rv["v"], rb["v"]), "ransac_w_rel": rel_norm(rv["w"], rb["w"])}
     if rb["num_inliers"] == rv["num_inliers"] and out["mask_bits_flipped"] == 0:
         out["depth_refined_max_rel"] = rel(var["inliers"][:, 2], base["inliers"][:, 2])
+        out["depth_refined_rel_quantiles"] = rel_quantiles(var["inliers"][:, 2], base["inliers"][:, 2])  # median / 99.9 % / max (pixels with rho ~ 0 dominate the max)
     return out
 
 
@@ -100,13 +106,15 @@ def markdown(report):
     lines = []
     for name, rec in report.items():
         lines.append("**%s** (n = %d, inliers = %d, accepted LM steps per trial: %s)\n" % (name, rec["n"], rec["num_inliers"], rec["lm_steps_per_trial"]))
-        lines.append("| if recollection X is wrong | winner | mask bits | trials whose count / LM steps change | rho of the winner: median / 99.9 % / max rel. change | refinement iterations | v (refined) | w (refined) |")
-        lines.append("|---|---|---|---|---|---|---|---|")
+        lines.append("| if recollection X is wrong | winner | mask bits | trials whose count / LM steps change | rho of the winner: median / 99.9 % / max rel. change | refinement iterations | v (refined) | w (refined) | refined depth: median / 99.9 % |")
+        lines.append("|---|---|---|---|---|---|---|---|---|")
         for key, r in rec["switches"].items():
             qs = r["rho_winner_rel_quantiles"]
-            lines.append("| %s (%s) | %s | %d | %d (max %d) / %d | %.1e / %.1e / %.1e | %d -> %d | %.1e | %.1e |" % (
+            dq = r.get("depth_refined_rel_quantiles")
+            lines.append("| %s (%s) | %s | %d | %d (max %d) / %d | %.1e / %.1e / %.1e | %d -> %d | %.1e | %.1e | %s |" % (
                 r["note"], key, "same" if r["winner_same"] else "CHANGES", r["mask_bits_flipped"], r["trial_counts_differ"], r["max_trial_count_change"],
-                r["trial_lm_steps_differ"], qs[0], qs[1], qs[2], r["refine_iterations"][0], r["refine_iterations"][1], r["v_max_rel"], r["w_max_rel"]))
+                r["trial_lm_steps_differ"], qs[0], qs[1], qs[2], r["refine_iterations"][0], r["refine_iterations"][1], r["v_max_rel"], r["w_max_rel"],
+                ("%.1e / %.1e" % (dq[0], dq[1])) if dq else "-"))
         lines.append("")
     return "\n".join(lines)
 

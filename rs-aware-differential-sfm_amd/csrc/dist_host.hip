@@ -131,7 +131,7 @@ struct Dist {
     int host_syncs = 0, collectives = 0, ransac_rounds = 0;  // diagnostics of the last solve
     // what the previous solve on this communicator needed -- decides what the next one enqueues ahead of its host reads, never a
     // result (every rank derives them from the same replicated decisions, so all ranks enqueue the same collectives)
-    int score_hint = 0;          // the separate scoring pass was needed behind round 0
+    int score_idle = kScoreIdleLimit;  // consecutive solves (saturating) that did not need the separate scoring pass behind round 0 (rsdsfm_internal.hpp)
     int refine_iters_hint = -1;  // LM iterations of the refinement (-1: none yet)
 };
 
@@ -562,8 +562,8 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
                 if (rc != RSDSFM_OK) return rc;
                 D->ransac_rounds += 1;
                 if (round == 0 && B == T) {  // the common case is decided and scored by round 0: enqueue the final stage before reading the flags
-                    if (D->score_hint) {
-                        // the previous solve needed the separate scoring pass (hypotheses that end at an iterate round 0 does not score):
+                    if (D->score_idle < kScoreIdleLimit) {
+                        // a recent solve needed the separate scoring pass (hypotheses that end at an iterate round 0 does not score):
                         // enqueue it ahead of the flags too -- it only touches hypotheses round 0 left unscored -- which saves a host
                         // round trip, a discarded final stage and its all-gather
                         rc = ransac_score_rows_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp, T, d_states, depth_mode, prm->ransac_tol, d_scored, d_partials, d_row);
@@ -585,7 +585,7 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
                 final_done = false;
             }
             need_score = h_flags[1] > 0;
-            if (B == T) D->score_hint = need_score ? 1 : 0;
+            if (B == T) D->score_idle = need_score ? 0 : std::min(D->score_idle + 1, kScoreIdleLimit);
             if (need_score && final_done && spec_scored) need_score = false;  // round 0 decided everything and the pass already ran
             if (need_score) final_done = false;
         }

@@ -238,14 +238,16 @@ int frame_begin(Ctx* c, FrameRun* F) {
                             F->prm.flow_index_mode, F->d_inl_ref, &F->tail, d_best, F->d_refine_ws, &F->refine, state_host(c), F->d_zpartials);
     };
     F->refinement_enqueued = false;
-    // (the refinement is only enqueued ahead where the previous RANSAC's speculated final stage held: data whose hypotheses need further
-    // LM rounds every time -- noise-free flow -- would pay for a discarded refinement chunk per frame)
-    F->ahead = prm->use_refinement && c->ransac_spec_held_hint != 0;
+    // (the refinement goes behind the SPECULATED final stage unless that stage did not count in the last two RANSACs: data whose
+    // hypotheses need further LM rounds every time -- noise-free flow -- would pay ~26 launches that leave at once per frame; an isolated
+    // miss -- one DeepFlow-like pair in ten has a hypothesis with three accepted steps -- does not switch it off.  Either way the
+    // refinement is enqueued behind the definitive final stage from the device-resident result, without a host round trip.)
+    F->ahead = prm->use_refinement && c->ransac_spec_miss < 2;
     F->open = true;
     F->rc_begin = ransac_begin(c, F->d_q, F->d_u, F->d_a, F->d_ak, n, prm->use_acceleration_mode, prm->ransac_trials, prm->ransac_tol, nullptr, J.seed,
-                               prm->depth_mode, prm->k_sign_mode, &F->ro, F->ahead ? &F->spec_tail : nullptr, &F->refinement_enqueued, &F->ransac,
+                               prm->depth_mode, prm->k_sign_mode, &F->ro, prm->use_refinement ? &F->spec_tail : nullptr, &F->refinement_enqueued, &F->ransac,
                                F->side_flatten ? &F->direct : nullptr, F->side_flatten && !F->dense_in_launch ? &F->join : nullptr,
-                               F->dense_in_launch ? &F->dense : nullptr);
+                               F->dense_in_launch ? &F->dense : nullptr, F->ahead);
     return RSDSFM_OK;  // (an error of the speculated run may only mean that n was wrong: frame_finish sorts that out)
 }
 
@@ -280,7 +282,8 @@ int frame_finish(Ctx* c, FrameRun* F, rsdsfm_frame_result* res) {
         F->refinement_enqueued = false;
         counted = false;
         rc = ransac_begin(c, F->d_q, F->d_u, F->d_a, F->d_ak, n, prm->use_acceleration_mode, prm->ransac_trials, prm->ransac_tol, nullptr, J.seed,
-                          prm->depth_mode, prm->k_sign_mode, &F->ro, F->ahead ? &F->spec_tail : nullptr, &F->refinement_enqueued, &F->ransac, nullptr, nullptr);
+                          prm->depth_mode, prm->k_sign_mode, &F->ro, prm->use_refinement ? &F->spec_tail : nullptr, &F->refinement_enqueued, &F->ransac, nullptr, nullptr,
+                          nullptr, F->ahead);
         if (rc == RSDSFM_OK) rc = ransac_finish(c, &F->ransac);
         counted = rc == RSDSFM_OK;
     }

@@ -153,13 +153,13 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                     // ends after three accepted steps, which round 0 does not score), that pass is enqueued ahead of the final
                     // stage as well: it only touches hypotheses round 0 left unscored (a no-op on other data) and saves the
                     // round trip plus a discarded final stage (~57 us).  What is enqueued when never changes a result.
-                    if (c->ransac_score_hint) {
+                    if (c->ransac_score_idle < kScoreIdleLimit) {
                         rc = ransac_score_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_hyp, T, R.d_states, depth_mode, tol, R.d_scored, R.d_partials,
                                                  R.d_tcount, R.d_terr);
                         if (rc != RSDSFM_OK) return rc;
                         R.spec_scored = true;
                     }
-                    rc = ransac_pick_launch(c, R.d_tcount, R.d_terr, T, R.d_hyp, R.d_best, R.h_best, R.d_flags, R.h_running);  // (+ the flag words)
+                    rc = ransac_pick_launch(c, R.d_tcount, R.d_terr, T, R.d_hyp, R.d_best, R.h_best, R.d_flags, R.h_running, R.spec_scored ? 1 : 0);  // (+ the flag words)
                     if (rc != RSDSFM_OK) return rc;
                     flags_via_pick = true;
                     rc = ransac_final_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_best, R.d_states, depth_mode, tol, R.d_rho, R.d_mask, R.d_bcounts,
@@ -167,7 +167,7 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                     if (rc != RSDSFM_OK) return rc;
                     R.final_done = true;
                     R.spec_final = true;
-                    if (R.spec_tail) {
+                    if (R.spec_tail && R.tail_ahead) {
                         rc = (*R.spec_tail)(R.d_best);
                         if (rc != RSDSFM_OK) return rc;
                         R.tail_enqueued = true;
@@ -230,6 +230,13 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                                              R.d_boffs, out->inlier_idx, out->inliers, out->alpha, out->alpha_k, R.h_best);
                     if (rc != RSDSFM_OK) return rc;
                 }
+                // the caller's tail behind the DEFINITIVE final stage, where it is not already behind a speculated one that held: it
+                // starts from the device-resident result without a host round trip in between
+                if (R.spec_tail && !R.tail_enqueued) {
+                    rc = (*R.spec_tail)(R.d_best);
+                    if (rc != RSDSFM_OK) return rc;
+                    R.tail_enqueued = true;
+                }
                 // per-trial diagnostics are copied back only when the caller asked for them (the frame solve does not)
                 if (T > 0 && out->trial_count) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(R.h_tcount, R.d_tcount, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
                 if (T > 0 && out->trial_err) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(R.h_terr, R.d_terr, sizeof(double) * T, hipMemcpyDeviceToHost, c->stream));
@@ -275,17 +282,18 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
 void ransac_commit_hints(Ctx* c, const RansacRun& R) {
     if (!R.hints_ready || R.depth_mode != RSDSFM_DEPTH_CERES_LM || R.T <= 0) return;
     if (R.fused_base_next) c->ransac_fused_base = R.fused_base_next;
-    if (R.score_hint_next >= 0) c->ransac_score_hint = R.score_hint_next;
+    if (R.score_hint_next >= 0) c->ransac_score_idle = R.score_hint_next ? 0 : std::min(c->ransac_score_idle + 1, kScoreIdleLimit);
     c->ransac_not_one_step = R.not_one_step;
-    c->ransac_spec_held_hint = R.spec_final ? 1 : 0;
+    c->ransac_spec_miss = R.spec_final ? 0 : std::min(c->ransac_spec_miss + 1, 2);
 }
 
 int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n, int use_alpha_k, int T,
                  double tol, const int32_t* h_samples, uint64_t seed, int depth_mode, int k_sign_mode, rsdsfm_ransac_out* out,
                  const RansacSpecTail* spec_tail, bool* spec_tail_held, RansacRun* run, const Minimal9Direct* direct,
-                 const std::function<int()>* after_minimal9, const DenseFlatten* dense) {
+                 const std::function<int()>* after_minimal9, const DenseFlatten* dense, bool tail_ahead) {
     RansacRun& R = *run;
     R = RansacRun();
+    R.tail_ahead = tail_ahead;
     if (spec_tail_held) *spec_tail_held = false;
     if (!out) return fail(c, RSDSFM_ERR_INVALID, "null out");
     if (n < 9) return fail(c, RSDSFM_ERR_INVALID, "ransac needs at least 9 points (the reference would compute rand() % 0)");

@@ -650,11 +650,16 @@ __device__ __forceinline__ void pick_best_trial(const double* __restrict__ trial
 // best_host (optional): host-mapped pinned copy of the result, written by the kernel itself (no copy kernel behind the stage)
 __global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restrict__ trial_count, const double* __restrict__ trial_err, int T,
                                                         const double* __restrict__ hyp, RansacBest* best, RansacBest* best_host,
-                                                        const int* __restrict__ flags, int* __restrict__ flags_host) {
+                                                        const int* __restrict__ flags, int* __restrict__ flags_host, int scored_ahead) {
     if (blockIdx.x != 0) return;
     const int lane = threadIdx.x;
     // the round's flag words (final since ransac_decide_kernel) travel to host-mapped memory with this launch: no copy behind the stage
     if (flags_host && lane < 8) flags_host[lane] = flags[lane];
+    // With flags this pick runs on speculation (behind round 0, before the host has seen them).  If hypotheses are still running, or
+    // ended where round 0 did not score them and no scoring pass was enqueued ahead, the trial scores are incomplete -- the host's own
+    // test in ransac_advance -- and the final stage and the caller's work behind it (the refinement) leave at once instead of running
+    // on a winner that does not count: ~250 us of kernels the host would otherwise wait for before it can enqueue the next LM round.
+    const int undecided = (flags && (flags[0] != 0 || (flags[1] > 0 && !scored_ahead))) ? 1 : 0;
     double best_count, best_err;
     int bi;
     pick_best_trial(trial_count, trial_err, T, lane, bi, best_count, best_err);
@@ -663,10 +668,12 @@ __global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restric
     if (lane < 8 && best_host) best_host->hyp[lane] = h;
     if (lane == 0) {
         best->best_trial = bi;
+        best->undecided = undecided;
         best->num_inliers = bi >= 0 ? (int64_t)best_count : 0;
         best->inlier_error = best_err;
         if (best_host) {
             best_host->best_trial = bi;
+            best_host->undecided = undecided;
             best_host->num_inliers = bi >= 0 ? (int64_t)best_count : 0;
             best_host->inlier_error = best_err;
         }
@@ -687,6 +694,7 @@ __global__ __launch_bounds__(kRB) void ransac_final_kernel(const double2* __rest
     __shared__ LmPlanLds plan;
     __shared__ int s_cnt[kRB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (best->undecided) return;  // (see ransac_pick_kernel)
     const int bt = best->best_trial;
     Pose pose;
     pose.w[0] = best->hyp[0], pose.w[1] = best->hyp[1], pose.w[2] = best->hyp[2];
@@ -773,6 +781,10 @@ __global__ __launch_bounds__(kRB) void ransac_scatter_kernel(const double2* __re
     __shared__ int64_t s_base;
     __shared__ int64_t s_pre[kRB / 64], s_all[kRB / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // behind a final stage that left at once (RansacBest::undecided, see ransac_pick_kernel) the counts and the mask are stale, possibly
+    // of a solve of another size: nothing may be written.  (The word is loaded here and tested behind the scan of the counts, whose loads
+    // it travels with: a test up here would put a dependent load in front of every workgroup.)
+    const int undecided = best->undecided;
     const int64_t i0 = (int64_t)blockIdx.x * chunk;
     const int64_t i1 = (i0 + chunk < n) ? i0 + chunk : n;
     // exclusive scan of the per-workgroup inlier counts, done by every workgroup for itself (<= 2048 integers: exact in any
@@ -795,12 +807,13 @@ __global__ __launch_bounds__(kRB) void ransac_scatter_kernel(const double2* __re
             int64_t p2 = 0, a2 = 0;
             for (int w2 = 0; w2 < kRB / 64; ++w2) p2 += s_pre[w2], a2 += s_all[w2];
             s_base = p2;
-            if (blockIdx.x == 0) {
+            if (blockIdx.x == 0 && !undecided) {
                 best->num_inliers_scan = a2;
                 if (best_host) best_host->num_inliers_scan = a2;
             }
         }
     }
+    if (undecided) return;  // (uniform)
     __syncthreads();
     for (int64_t start = i0; start < i1; start += kRB) {
         const int64_t i = start + tid;
@@ -971,8 +984,8 @@ int ransac_score_merge_launch(Ctx* c, const double* rows_all, int nranks, int T,
 int ransac_rows_doubles() { return NSR; }
 
 int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best,
-                       RansacBest* best_host, const int* d_flags, int* h_flags) {
-    hipLaunchKernelGGL(ransac_pick_kernel, dim3(1), dim3(64), 0, c->stream, trial_count, trial_err, T, hyp, best, best_host, d_flags, h_flags);
+                       RansacBest* best_host, const int* d_flags, int* h_flags, int scored_ahead) {
+    hipLaunchKernelGGL(ransac_pick_kernel, dim3(1), dim3(64), 0, c->stream, trial_count, trial_err, T, hyp, best, best_host, d_flags, h_flags, scored_ahead);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

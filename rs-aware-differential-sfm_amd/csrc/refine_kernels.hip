@@ -687,7 +687,8 @@ __global__ void refine_state_from_best_kernel(const RansacBest* __restrict__ bes
     z.p[6] = best->hyp[6];
     z.termination = -1;
     z.radius = kInitialRadius;
-    const int64_t m = best->num_inliers_scan;
+    // (a RANSAC that is not over -- ransac_pick_kernel -- : no inliers, and every kernel of this refinement leaves at once)
+    const int64_t m = best->undecided ? 0 : best->num_inliers_scan;
     z.m = m;
     int64_t b = (m + kFB - 1) / kFB;
     if (b < 1) b = 1;

@@ -73,13 +73,18 @@ struct LmState : LmScal {
 // device-resident result header of a RANSAC run
 struct RansacBest {
     int32_t best_trial;
-    int32_t _pad;
+    int32_t undecided;         // 1: written by a pick that ran BEHIND round 0 on flags that say the RANSAC is not over (hypotheses still running or unscored): everything enqueued behind it on speculation leaves at once
     int64_t num_inliers;       // from the score of the best trial
     int64_t num_inliers_scan;  // total of the compaction scan (must agree)
     double inlier_error;
     double hyp[8];  // w(3), v(3), k, status of the best trial
 };
 
+// The scoring pass behind round 0 is enqueued ahead of the host's flag read while one of the context's last kScoreIdleLimit solves needed
+// it.  (Following only the previous solve flip-flopped on DeepFlow-like data: one pair in ~25 has every hypothesis end where round 0
+// scores it, and the pair after it then paid for a discarded final stage and refinement, ~280 us, against ~12 us for a pass that finds
+// nothing to do.)
+constexpr int kScoreIdleLimit = 4;
 constexpr int kRansacBatch = 128;  // hypotheses per pixel pass (LDS accumulators: 128 x NS x 8 B = 18 KB)
 
 struct Ctx {
@@ -95,9 +100,9 @@ struct Ctx {
     int lm_issued_k = 0;           // depth_lm_kernel launches issued for the current solve
     int true_flow_exhaustive = 0;  // ground-truth flow search: 0 = interval-pruned from 96 scanlines on (default), 1 = every scanline for every pixel, 2 = pruned at any size
     int ransac_fused_base = 2;     // accepted steps after which most hypotheses of the previous solve ended: the iterate round 0 scores
-    int ransac_score_hint = 0;     // 1: the previous solve needed the separate scoring pass behind round 0 (it is then enqueued ahead of the host's flag read)
+    int ransac_score_idle = kScoreIdleLimit;  // consecutive solves (saturating) that did NOT need the separate scoring pass behind round 0; below the limit the pass is enqueued ahead of the host's flag read
     int refine_iters_hint = -1;    // LM iterations the context's previous refinement took (-1: none yet): length of the first chunk the host enqueues
-    int ransac_spec_held_hint = 0;  // the previous RANSAC's speculated final stage was the one that counted -> the frame solve may enqueue the refinement behind it
+    int ransac_spec_miss = 0;  // consecutive RANSACs (saturating at 2) whose speculated final stage did not count; below 2 the frame solve enqueues the refinement behind the speculated stage
     int frame_dense_hint = 1;  // frame solve: the previous frame kept every pixel (dense flow) -> set the RANSAC up for n = rows * cols without waiting for the count
     int lm_issued_d = 0;           // depth_lm_decide_kernel launches issued for the current solve
     // staging buffers for the host-pointer API (grown on demand)
@@ -288,7 +293,7 @@ int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* 
                         const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
                         double* partials, double* trial_count, double* trial_err);
 int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best,
-                       RansacBest* best_host = nullptr, const int* d_flags = nullptr, int* h_flags = nullptr);
+                       RansacBest* best_host = nullptr, const int* d_flags = nullptr, int* h_flags = nullptr, int scored_ahead = 0);
 int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         RansacBest* best, const LmState* states, int depth_mode, double tol, double* rho, uint8_t* mask,
                         int64_t* block_counts, int64_t* block_offsets, int64_t* inlier_idx, double* inliers,
@@ -353,6 +358,7 @@ struct RansacRun {
     rsdsfm_ransac_out* out = nullptr;
     const RansacSpecTail* spec_tail = nullptr;
     bool* spec_tail_held = nullptr;
+    bool tail_ahead = true;  // enqueue the caller's tail behind the SPECULATED final stage (otherwise only behind the definitive one)
     const Minimal9Direct* direct = nullptr;
     const DenseFlatten* dense = nullptr;  // with `direct`: the flatten of the dense frame rides in the solver's launch
     const std::function<int()>* after_minimal9 = nullptr;
@@ -381,7 +387,7 @@ struct RansacRun {
 int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n, int use_alpha_k, int T,
                  double tol, const int32_t* h_samples, uint64_t seed, int depth_mode, int k_sign_mode, rsdsfm_ransac_out* out,
                  const RansacSpecTail* spec_tail, bool* spec_tail_held, RansacRun* run, const Minimal9Direct* direct,
-                 const std::function<int()>* after_minimal9, const DenseFlatten* dense = nullptr);
+                 const std::function<int()>* after_minimal9, const DenseFlatten* dense = nullptr, bool tail_ahead = true);
 int ransac_finish(Ctx* c, RansacRun* run);
 void ransac_commit_hints(Ctx* c, const RansacRun& run);
 int flatten_enqueue(Ctx* c, const double* d_img, int32_t rows, int32_t cols, double fx, double fy, double cx, double cy, double gamma,

@@ -1,5 +1,6 @@
 """Same-box A/B of two builds of the library on the whole frame solve (1280x720, 50 trials, DeepFlow-like pair): the two packages are
-imported side by side, blocks of solves alternate between them, and the median ms per solve of every block is printed.
+imported side by side, blocks of solves alternate between them, and the median and the mean ms per solve of every block are printed
+(the mean carries the solves whose speculation did not hold: one DeepFlow-like pair in ten).
 usage (GPU box): python tools/ab_lib.py <package dir A> <package dir B> [blocks] [solves per block]
 (package dir = a directory holding __init__.py and a built librsdsfm_hip.so, e.g. rs-aware-differential-sfm_amd and a copy of an older
 checkout built with its own build.py under ab_old/)"""
@@ -36,6 +37,7 @@ def main():
             for i in range(20):
                 c(1 + i)
         med = ([], [])
+        mean = ([], [])
         for blk in range(blocks):
             for w, c in enumerate(calls):
                 ts = []
@@ -44,8 +46,10 @@ def main():
                     c(1 + i)
                     ts.append((time.perf_counter() - t0) * 1e3)
                 med[w].append(statistics.median(ts))
+                mean[w].append(statistics.fmean(ts))
         for w, nm in enumerate(("A", "B")):
-            print(nm, sys.argv[1 + w], " ".join("%.4f" % x for x in med[w]), "| median of medians %.4f ms" % statistics.median(med[w]))
+            print(nm, sys.argv[1 + w], "medians", " ".join("%.4f" % x for x in med[w]), "| median of medians %.4f ms" % statistics.median(med[w]))
+            print(nm, sys.argv[1 + w], "means  ", " ".join("%.4f" % x for x in mean[w]), "| mean of means %.4f ms" % statistics.fmean(mean[w]))
 
 
 if __name__ == "__main__":

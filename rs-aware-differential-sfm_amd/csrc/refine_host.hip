@@ -146,9 +146,10 @@ int refine_poll(Ctx* c, RefineRun* run, double v_out[3], double w_out[3], double
             break;
         }
         if (run->launched > 4 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
-        // later chunks: what the previous solve still needed at this point, between 2 and 5 (DeepFlow-like data has 0..1 iterations
-        // left after the first chunk -- an empty iteration costs four launches --, acceleration mode runs ~13 in all)
-        run->chunk = std::min(5, std::max(2, run->hint_prev - run->launched));
+        // later chunks: what the previous solve still needed at this point, between 1 and 5 (DeepFlow-like data: 3 / 4 / 5 / 6 / 7
+        // iterations in 5 / 37 / 49 / 8.5 / 0.25 % of the pairs, so ONE more is what a solve that outlives the first chunk almost always
+        // needs, and an empty iteration costs four launches; acceleration mode runs ~13 in all)
+        run->chunk = std::min(5, std::max(1, run->hint_prev - run->launched));
         int rc = refine_enqueue_chunk(c, run);
         if (rc != RSDSFM_OK) return rc;
     }

@@ -1,0 +1,37 @@
+"""Distribution of the host time of the whole frame solve (1280x720, 50 trials, the bench's pair and seeds): percentiles, and for the
+slowest solves the refinement's iteration count -- what separates the mean from the median.
+usage (GPU box): python tools/solve_times.py [solves]"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("rs-aware-differential-sfm_amd")
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
+d = pkg.synth.make_config(5, seed=0x5EED0005)
+rows, cols = d["rows"], d["cols"]
+imgs = [torch.from_numpy(d["flow_img"]).cuda() for _ in range(3)]
+dm = torch.empty((cols, rows), dtype=torch.float64, device="cuda")
+R = torch.empty((rows, 9), dtype=torch.float64, device="cuda")
+t = torch.empty((rows, 3), dtype=torch.float64, device="cuda")
+with pkg.Solver(0) as s:
+    calls = [s.prepared_frame_solve(im.data_ptr(), rows, cols, d["K"], d["gamma"], dm.data_ptr(), R.data_ptr(), t.data_ptr(), trials=50, tol=0.05) for im in imgs]
+    rec = []
+    for i in range(n + 10):
+        t0 = time.perf_counter()
+        r = calls[i % 3](1 + i)
+        dt = (time.perf_counter() - t0) * 1e3
+        if i >= 10:
+            rec.append((dt, 1 + i, int(r.refine_summary.num_iterations), int(r.best_trial)))
+ts = np.array([x[0] for x in rec])
+print("solves %d: mean %.4f median %.4f p90 %.4f p99 %.4f max %.4f ms" % (n, ts.mean(), np.median(ts), np.percentile(ts, 90), np.percentile(ts, 99), ts.max()))
+its = np.array([x[2] for x in rec])
+for k in sorted(set(its.tolist())):
+    sel = ts[its == k]
+    print("  refinement iterations %d: %4d solves, mean %.4f median %.4f max %.4f ms" % (k, len(sel), sel.mean(), np.median(sel), sel.max()))
+print("slowest:", ", ".join("%.3f ms (seed %d, %d iterations)" % x[:3] for x in sorted(rec, reverse=True)[:12]))

@@ -95,11 +95,14 @@ int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const 
     rc = refine_init_launch(c, B, np);
     if (rc != RSDSFM_OK) return rc;
     // LM iterations are enqueued in chunks; the kernels of a finished solve return immediately, but an empty iteration still costs
-    // four launches (~19 us) and a chunk that is too short a host round trip (~25 us).  The first chunk is 5 iterations (DeepFlow-like data
+    // four launches and a chunk that is too short a host round trip.  The first chunk is 5 iterations (DeepFlow-like data
     // takes 3..6: following the previous solve's count more closely was measured 1 % slower, the counts vary from pair to pair),
     // except behind a refinement that ended within 2 iterations -- noise-free data, e.g. ground-truth flow, ends after ONE -- where
     // the first chunk is that count + 1.  The chunking changes when the host looks at the state, never what the kernels compute.
-    run->chunk = (run->hint_prev >= 0 && run->hint_prev <= 2) ? run->hint_prev + 1 : 5;
+    // Behind a refinement that took more than 6 (acceleration mode: ~13) the first chunk is that count + 1: an empty iteration is four
+    // launches that leave at once (~7 us), a chunk that is too short a host round trip plus a second output pass and tail (~33 us).
+    const int hp = run->hint_prev;
+    run->chunk = (hp >= 0 && hp <= 2) ? hp + 1 : (hp > 6 ? std::min(hp + 1, 16) : 5);
     return refine_enqueue_chunk(c, run);
 }
 

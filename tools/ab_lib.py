@@ -3,7 +3,7 @@ imported side by side, blocks of solves alternate between them, and the median a
 (the mean carries the solves whose speculation did not hold: one DeepFlow-like pair in ten).
 usage (GPU box): python tools/ab_lib.py <package dir A> <package dir B> [blocks] [solves per block]
 (package dir = a directory holding __init__.py and a built librsdsfm_hip.so, e.g. rs-aware-differential-sfm_amd and a copy of an older
-checkout built with its own build.py under ab_old/)"""
+checkout built with its own build.py under ab_old/); AB_ACCEL=1 in the environment: acceleration mode (k estimated and refined)"""
 import importlib.util
 import os
 import statistics
@@ -32,7 +32,7 @@ def main():
     R = torch.empty((rows, 9), dtype=torch.float64, device="cuda")
     t = torch.empty((rows, 3), dtype=torch.float64, device="cuda")
     with a.Solver(0) as sa, b.Solver(0) as sb:
-        calls = [s.prepared_frame_solve(img.data_ptr(), rows, cols, d["K"], d["gamma"], dm.data_ptr(), R.data_ptr(), t.data_ptr(), trials=50, tol=0.05) for s in (sa, sb)]
+        calls = [s.prepared_frame_solve(img.data_ptr(), rows, cols, d["K"], d["gamma"], dm.data_ptr(), R.data_ptr(), t.data_ptr(), trials=50, tol=0.05, use_acceleration_mode=bool(int(os.environ.get("AB_ACCEL", "0")))) for s in (sa, sb)]
         for c in calls:
             for i in range(20):
                 c(1 + i)

@@ -123,6 +123,15 @@ int rsdsfm_set_depth_variant(rsdsfm_ctx* ctx, int variant);
  * also scores the iterate most hypotheses of the context's previous solve ended at, all other hypotheses are scored by a separate
  * pass that adds the inlier errors in the same order. */
 int rsdsfm_set_ransac_speculation(rsdsfm_ctx* ctx, int k0);
+/* How round 0 of those depth solves evaluates its two square roots and its reciprocal per pixel-hypothesis (reference-arithmetic
+ * library only).  0 (default): through the in-range cores of the compiler's own correctly rounded expansions -- the same instructions
+ * without the argument rescaling and special-case patching that do nothing for a normal, positive, finite argument (16 of the kernel's 307
+ * instructions; bit-identical in range, tools/fastmath_check.hip) -- and a RANSAC that meets an argument outside the range (a zero
+ * Jacobian, a zero or non-finite error: not on real data) starts over with the standard functions, as do the context's next 16.
+ * 1: always the standard functions.  Every result is identical for both settings, bit for bit.
+ * rsdsfm_ransac_restarts: how many RANSAC runs of this context (and its sequence lanes) started over. */
+int rsdsfm_set_ransac_math(rsdsfm_ctx* ctx, int mode);
+int rsdsfm_ransac_restarts(rsdsfm_ctx* ctx, int64_t* count);
 /* Opt-in profiling: while on, rsdsfm_ransac* / rsdsfm_solve_frame_dev bracket the dominant kernel of the whole solve -- round 0
  * of the hypothesis-batched LM depth solves, `ransac_lm_kernel<true, 3, BASE>` -- with two HIP events on the context's stream (in
  * situ: same launch, same neighbours, same clocks as any other solve).  rsdsfm_profile_last_ms(ctx, "ransac_lm_round0", &ms)

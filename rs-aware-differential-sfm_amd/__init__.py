@@ -249,6 +249,17 @@ class Solver:
         solve (2 when none of its hypotheses went beyond one accepted step, else 3); 2 or 3 = fixed.  Scheduling only: never a result."""
         self._check(self.lib.rsdsfm_set_ransac_speculation(self._ctx, int(k0)), "rsdsfm_set_ransac_speculation")
 
+    def set_ransac_math(self, mode):
+        """round 0 of RANSAC's batched depth solves: 0 (default) = in-range cores of sqrt / reciprocal with a restart on an argument out
+        of range, 1 = always the standard functions (rsdsfm_set_ransac_math); never a result"""
+        self._check(self.lib.rsdsfm_set_ransac_math(self._ctx, int(mode)), "rsdsfm_set_ransac_math")
+
+    def ransac_restarts(self):
+        """RANSAC runs of this context that started over with the standard functions (rsdsfm_ransac_restarts)"""
+        n = C.c_int64()
+        self._check(self.lib.rsdsfm_ransac_restarts(self._ctx, C.byref(n)), "rsdsfm_ransac_restarts")
+        return n.value
+
     def synchronize(self):
         self._check(self.lib.rsdsfm_synchronize(self._ctx), "rsdsfm_synchronize")
 

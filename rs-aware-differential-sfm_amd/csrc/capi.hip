@@ -154,6 +154,7 @@ void rsdsfm_destroy(rsdsfm_ctx* ctx) {
     if (c->d_frame) (void)hipFree(c->d_frame);
     if (c->d_tile) (void)hipFree(c->d_tile);
     if (c->d_refine_trace) (void)hipFree(c->d_refine_trace);
+    if (c->d_core_flag) (void)hipFree(c->d_core_flag);
     delete static_cast<RefineBuffers*>(c->tile_session);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     dist_release(c);
@@ -236,6 +237,22 @@ int rsdsfm_set_ransac_speculation(rsdsfm_ctx* ctx, int k0) {
     CTX_OR_FAIL(ctx);
     if (k0 != 0 && k0 != 2 && k0 != KMAX) return fail(c, RSDSFM_ERR_INVALID, "ransac speculation depth must be 0 (automatic, default), 2 or 3");
     c->ransac_k0 = k0;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_set_ransac_math(rsdsfm_ctx* ctx, int mode) {
+    CTX_OR_FAIL(ctx);
+    if (mode < 0 || mode > 1) return fail(c, RSDSFM_ERR_INVALID, "ransac math: 0 = in-range function cores with restart (default), 1 = standard functions");
+    c->ransac_math_mode = mode;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_ransac_restarts(rsdsfm_ctx* ctx, int64_t* count) {
+    CTX_OR_FAIL(ctx);
+    if (!count) return fail(c, RSDSFM_ERR_INVALID, "ransac restarts: null output");
+    int64_t total = c->ransac_restarts;
+    for (rsdsfm_ctx* lane : c->lanes) total += lane->c.ransac_restarts;
+    *count = total;
     return RSDSFM_OK;
 }
 

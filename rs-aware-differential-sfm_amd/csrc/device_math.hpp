@@ -27,6 +27,67 @@ namespace rsdsfm {
 
 __device__ __forceinline__ double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
+// ---- in-range cores of the correctly rounded fp64 square root and reciprocal ---------------------------------------------------------
+// The compiler expands sqrt(x) into  [x < 2^-767 ? scale x by 2^256]  v_rsq_f64 + two Newton steps on (g, h) + two residual corrections
+// [scale back by 2^-128]  [x is +-0 or +inf ? x]  -- 18 instructions of which 8 are the bracketed wrapper -- and 1.0 / d into
+// v_div_scale x 2, v_rcp_f64, two Newton steps, q = n r, one residual correction (v_div_fmas) and v_div_fixup: 11 instructions of which 4
+// do nothing for a normal d with a normal reciprocal and n = 1 (tools/fastmath_check.hip lists the ISA's conditions).  For an argument inside
+// the range the wrapper is the identity, so the cores below -- the SAME instructions in the same order -- return the same bits:
+// tools/fastmath_check.hip compares them with the compiler's expansions over 1e10 random in-range bit patterns and the range bounds.
+// ransac_lm_kernel runs them on every pixel of round 0 and ORs the range tests into one flag word of the launch; a RANSAC whose flag is
+// raised (a zero Jacobian, a zero or non-finite error: never on real data) is run again with the standard functions (ransac_host.hip):
+// 16 of the kernel's 307 instructions per pixel-hypothesis for the price of two 32-bit instructions per test and a branch per hypothesis.
+// (An in-kernel fallback -- the wave recomputes the hypothesis -- was built first: whatever its shape, the second pixel loop behind the
+// first one took the kernel from 240 to 300+ registers, one wave per SIMD; so did carrying the tests as a bool through the pixel loop.
+// The tests are carried as the maximum of an integer key instead: sqrt_range_track.)
+//
+// x in [2^-767, DBL_MAX]: positive, finite, and not small enough for sqrt()'s expansion to rescale it (a test on the high word: the
+// exponent field in [0x100, 0x7FE], sign clear -- NaNs, infinities, zeros, denormals and negative numbers all fail it)
+__device__ __forceinline__ uint32_t sqrt_range_key(double x) { return (uint32_t)__double2hiint(x) - 0x10000000u; }  // in range iff < kSqrtRangeKeys
+constexpr uint32_t kSqrtRangeKeys = 0x6FF00000u;
+__device__ __forceinline__ bool sqrt_in_range(double x) { return sqrt_range_key(x) < kSqrtRangeKeys; }
+// the range tests of many arguments as ONE comparison: `worst` = the maximum of their keys (two 32-bit instructions per argument)
+__device__ __forceinline__ void sqrt_range_track(uint32_t& worst, double x) { worst = max(worst, sqrt_range_key(x)); }
+__device__ __forceinline__ double sqrt_core(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y;
+    double h = y * 0.5;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+// n / d for operands inside the window where v_div_scale does not rescale and v_div_fixup passes the quotient through: both
+// magnitudes in [2^-383, 2^385) (then the exponents differ by less than 768, no operand and no quotient is zero, denormal or infinite).
+// The core is the compiler's expansion without the two v_div_scale, with v_div_fmas as the plain fma it is when nothing was scaled,
+// and without v_div_fixup.
+__device__ __forceinline__ uint32_t div_range_key(double x) { return ((uint32_t)__double2hiint(x) & 0x7FFFFFFFu) - 0x28000000u; }  // in range iff < kDivRangeKeys
+constexpr uint32_t kDivRangeKeys = 0x30000000u;
+__device__ __forceinline__ void div_range_track(uint32_t& worst, double x) { worst = max(worst, div_range_key(x)); }
+__device__ __forceinline__ double div_core(double n, double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    const double q = n * r;
+    e = __builtin_fma(-d, q, n);
+    return __builtin_fma(e, r, q);
+}
+// 1.0 / d for a normal d whose reciprocal is normal (2^-1021 <= |d| <= 2^1021 is more than the callers need: d = 1 + sqrt(x) lies in [1, 2^513))
+__device__ __forceinline__ double rcp_core(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-d, r, 1.0);  // (q = 1.0 * r is r)
+    return __builtin_fma(e, r, r);
+}
+
 // One point of the caller glue main.cc:398-444 + getAlpha / getAlphaK (minimal.cc:179-197): pixel (column i, row j) with flow f in
 // pixels -> normalised position q, normalised flow u, alpha, alpha_k (pixel units, h = rows: quirk Q6).  The ONE statement of these
 // expressions: flatten_tile_kernel writes them to the point arrays, minimal9_kernel's direct mode forms its sampled points with them.
@@ -154,6 +215,17 @@ __device__ __forceinline__ double point_error_from_model(const PixelModel& m, do
     const double e1 = beta * (bw1 - m.a1 * rho) - m.uy;
     return sqrt(e0 * e0 + e1 * e1);
 #endif
+}
+// the same with the in-range core of the square root; `worst` tracks the range test of the argument (sqrt_range_track)
+__device__ __forceinline__ double point_error_from_model_core(const PixelModel& m, double rho, uint32_t& worst) {
+    const double beta = -m.nbeta;
+    const double bw0 = (m.t02 - m.t01) - m.t03;
+    const double bw1 = (m.t12 - m.t11) + m.t13;
+    const double e0 = beta * (bw0 - m.a0 * rho) - m.ux;
+    const double e1 = beta * (bw1 - m.a1 * rho) - m.uy;
+    const double ss = e0 * e0 + e1 * e1;
+    sqrt_range_track(worst, ss);
+    return sqrt_core(ss);
 }
 
 // minimal.cc:255-270: residual norm of the flow predicted from (v, w, k, rho)

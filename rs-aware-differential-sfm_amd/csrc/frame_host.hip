@@ -433,6 +433,7 @@ int rsdsfm_solve_frames_dev(rsdsfm_ctx* ctx, const rsdsfm_frame_job* jobs, int32
         Ctx* lc = lane_ctx(l);
         RSDSFM_HIP_CHECK(c, hipStreamWaitEvent(lc->stream, c->ev_seq, 0));
         lc->ransac_k0 = c->ransac_k0;
+        lc->ransac_math_mode = c->ransac_math_mode;
         lc->frame_side_flatten = c->frame_side_flatten;
     }
     int first_error = RSDSFM_OK;

@@ -211,14 +211,23 @@ struct NoHook {
 };
 
 // `hook(j, rho_j, model)` is called with every speculated iterate (j = 0 .. K-1: the state after j+1 accepted steps)
-template <class Plan, class Hook = NoHook>
-__device__ __forceinline__ double lm_pixel(double x, double y, double ux, double uy, double al, double ak,
-                                           const Pose& pose, double two_over, const Plan& plan,
-                                           double (&acc)[NS], const Hook& hook = Hook(), PixelModel* model_out = nullptr) {
+// CORE: the Jacobi scaling through the in-range cores of sqrt and the reciprocal (device_math.hpp: the same bits for an argument in
+// range); *worst tracks the range tests (sqrt_range_track) and the caller has the solve run again with CORE = false when one failed
+template <bool CORE, class Plan, class Hook = NoHook>
+__device__ __forceinline__ double lm_pixel_t(double x, double y, double ux, double uy, double al, double ak,
+                                             const Pose& pose, double two_over, const Plan& plan,
+                                             double (&acc)[NS], const Hook& hook = Hook(), PixelModel* model_out = nullptr, uint32_t* worst = nullptr) {
     PixelModel m;
     m.init(x, y, ux, uy, al, ak, pose, two_over);
     if (model_out) *model_out = m;
-    const double s = 1.0 / (1.0 + sqrt(dot2(m.J0, m.J0, m.J1, m.J1)));  // Jacobi scaling (iteration 0 Jacobian)
+    double s;  // Jacobi scaling (iteration 0 Jacobian)
+    if (CORE) {
+        const double jj = dot2(m.J0, m.J0, m.J1, m.J1);
+        sqrt_range_track(*worst, jj);
+        s = rcp_core(1.0 + sqrt_core(jj));
+    } else {
+        s = 1.0 / (1.0 + sqrt(dot2(m.J0, m.J0, m.J1, m.J1)));
+    }
     const double jt0 = m.J0 * s, jt1 = m.J1 * s;
     const double ht = dot2(jt0, jt0, jt1, jt1);
     const double diag = clampd(ht, kMinLmDiag, kMaxLmDiag);
@@ -261,6 +270,13 @@ __device__ __forceinline__ double lm_pixel(double x, double y, double ux, double
         }
     }
     return out;
+}
+
+template <class Plan, class Hook = NoHook>
+__device__ __forceinline__ double lm_pixel(double x, double y, double ux, double uy, double al, double ak,
+                                           const Pose& pose, double two_over, const Plan& plan,
+                                           double (&acc)[NS], const Hook& hook = Hook(), PixelModel* model_out = nullptr) {
+    return lm_pixel_t<false>(x, y, ux, uy, al, ak, pose, two_over, plan, acc, hook, model_out);
 }
 
 __device__ __forceinline__ bool is_max_slot(int s) { return s == 2 || (s >= 3 && ((s - 3) % 5) == 4); }

@@ -157,6 +157,32 @@ __device__ void jacobi_svd9_nullvec(LVec W, LVec V, LVec sv, LVec col, double e_
     for (int i = 0; i < 9; ++i) e_out[i] = V[i * 9 + c8];
 }
 
+// makeJacobi through the in-range cores of division, reciprocal and square root (device_math.hpp): the same bits for operands in
+// range; wd / ws track the range tests of the operands that are not in range by construction
+__device__ __forceinline__ Rot make_jacobi_core(double x, double y, double z, uint32_t& wd, uint32_t& ws) {
+    Rot j;
+    double deno = 2.0 * fabs(y);
+    if (deno < DBL_MIN) {
+        j.c = 1.0;
+        j.s = 0.0;
+    } else {
+        const double xz = x - z;
+        div_range_track(wd, xz);
+        div_range_track(wd, deno);
+        double tau = div_core(xz, deno);
+        const double ww = tau * tau + 1.0;
+        sqrt_range_track(ws, ww);  // (>= 1: only an overflow of tau * tau takes it out of range)
+        double w = sqrt_core(ww);
+        const double den = (tau > 0.0) ? tau + w : tau - w;  // |den| >= 1, < 2^513 while ww is in range
+        double t = rcp_core(den);
+        double sign_t = t > 0.0 ? 1.0 : -1.0;
+        double n = rcp_core(sqrt_core(t * t + 1.0));  // |t| <= 1: the argument lies in [1, 2], its root in [1, 1.42]
+        j.s = -sign_t * copysign(1.0, y) * fabs(t) * n;
+        j.c = n;
+    }
+    return j;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // wave-cooperative variant of jacobi_svd9_nullvec: ONE hypothesis per wave (used when there are few hypotheses, the
 // RANSAC case: T = 5 ... a few hundred, where the one-lane-per-hypothesis kernel leaves the machine idle and serialises
@@ -168,7 +194,11 @@ __device__ void jacobi_svd9_nullvec(LVec W, LVec V, LVec sv, LVec col, double e_
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double& sh(double* M, int e) { return M[e * 64]; }
 
-__device__ void jacobi_svd9_nullvec_coop(double* W, double* V, int lane, LVec sv, LVec col, double e_out[9]) {
+// CORE: the rotations through the in-range function cores; *outside is set when an operand was out of range (the caller has the
+// hypotheses computed again with CORE = false)
+template <bool CORE>
+__device__ void jacobi_svd9_nullvec_coop(double* W, double* V, int lane, LVec sv, LVec col, double e_out[9], bool* outside) {
+    uint32_t wd = 0, ws = 0;
     const double precision = 2.0 * DBL_EPSILON;
     // scale = max |W| (exact in any order)
     double m = fabs(sh(W, lane));
@@ -208,17 +238,30 @@ __device__ void jacobi_svd9_nullvec_coop(double* W, double* V, int lane, LVec sv
                         rot1.s = 0.0;
                         rot1.c = 1.0;
                     } else {
-                        const double uu = t / d;
-                        const double tmp = sqrt(1.0 + uu * uu);
-                        rot1.s = 1.0 / tmp;
-                        rot1.c = uu / tmp;
+                        if (CORE) {
+                            div_range_track(wd, t);
+                            div_range_track(wd, d);
+                            const double uu = div_core(t, d);
+                            const double a1p = 1.0 + uu * uu;
+                            sqrt_range_track(ws, a1p);
+                            const double tmp = sqrt_core(a1p);  // in [1, 2^512) while a1p is in range
+                            rot1.s = rcp_core(tmp);
+                            div_range_track(wd, uu);
+                            div_range_track(wd, tmp);
+                            rot1.c = div_core(uu, tmp);
+                        } else {
+                            const double uu = t / d;
+                            const double tmp = sqrt(1.0 + uu * uu);
+                            rot1.s = 1.0 / tmp;
+                            rot1.c = uu / tmp;
+                        }
                     }
                     if (!(rot1.c == 1.0 && rot1.s == 0.0)) {
                         const double a0 = rot1.c * m0 + rot1.s * m2, a2 = -rot1.s * m0 + rot1.c * m2;
                         const double a1 = rot1.c * m1 + rot1.s * m3, a3 = -rot1.s * m1 + rot1.c * m3;
                         m0 = a0, m1 = a1, m2 = a2, m3 = a3;
                     }
-                    jr = make_jacobi(m0, m1, m3);
+                    jr = CORE ? make_jacobi_core(m0, m1, m3, wd, ws) : make_jacobi(m0, m1, m3);
                     const Rot jt = {jr.c, -jr.s};
                     jl.c = rot1.c * jt.c - rot1.s * jt.s;
                     jl.s = rot1.c * jt.s + rot1.s * jt.c;
@@ -240,6 +283,7 @@ __device__ void jacobi_svd9_nullvec_coop(double* W, double* V, int lane, LVec sv
             }
         }
     }
+    if (CORE) *outside = wd >= kDivRangeKeys || ws >= kSqrtRangeKeys;
     for (int i = 0; i < 9; ++i) {
         sv[i] = fabs(sh(W, i * 9 + i)) * scale;
         col[i] = (double)i;
@@ -743,10 +787,18 @@ __device__ __forceinline__ void minimal9_body(double* lds, int block, int nblock
 
     // ---- null vector (minimal.cc:98-103) ----
     double e[9];
-    if (COOP)
-        jacobi_svd9_nullvec_coop(lds, lds + 81 * 64, lane, sv, col, e);  // the lane-0 copies of Z and V
-    else
+    if (COOP) {
+        // the lane-0 copies of Z and V
+        if (direct.core_flag) {
+            bool outside = false;
+            jacobi_svd9_nullvec_coop<true>(lds, lds + 81 * 64, lane, sv, col, e, &outside);
+            if (outside && lane == 0) *direct.core_flag = direct.core_epoch;  // (every writer of this launch stores the same value)
+        } else {
+            jacobi_svd9_nullvec_coop<false>(lds, lds + 81 * 64, lane, sv, col, e, nullptr);
+        }
+    } else {
         jacobi_svd9_nullvec(Z, V, sv, col, e);
+    }
     const double norm_v0 = sqrt(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
 #pragma unroll
     for (int i = 0; i < 9; ++i) e[i] = e[i] / norm_v0;

@@ -105,13 +105,22 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                 if (!zero_in_minimal9) RSDSFM_HIP_CHECK(c, hipMemsetAsync(R.zero_begin, 0, R.zero_bytes, c->stream));
                 if (T > 0) {
                     memcpy(R.h_samples_pinned, R.samples.data(), sizeof(int32_t) * (size_t)T * 9);
+                    // the wave-per-hypothesis SVD through the in-range function cores (minimal9_kernels.hip), where round 0 of the LM depth
+                    // solves is there to pass its flag on
+                    Minimal9Direct dir = R.direct ? *R.direct : Minimal9Direct();
+                    R.core_epoch = 0;
+                    if (R.core_math && depth_mode == RSDSFM_DEPTH_CERES_LM && T <= c->num_cus * 2 && c->d_core_flag) {
+                        c->core_epoch = c->core_epoch >= 0x3fffffff ? 1 : c->core_epoch + 1;
+                        dir.core_flag = c->d_core_flag;
+                        dir.core_epoch = R.core_epoch = c->core_epoch;
+                    }
                     if (R.direct && R.dense && T <= c->num_cus * 2)  // one launch: T solver workgroups + the dense flatten's
                         rc = minimal9_flatten_launch(c, R.h_samples_pinned, T, R.use_alpha_k, R.k_sign_mode, R.d_hyp, zero_in_minimal9 ? R.zero_begin : nullptr,
-                                                     zero_in_minimal9 ? R.zero_bytes : 0, *R.direct, R.dense->thr, R.dense->d_q, R.dense->d_u, R.dense->d_alpha,
+                                                     zero_in_minimal9 ? R.zero_bytes : 0, dir, R.dense->thr, R.dense->d_q, R.dense->d_u, R.dense->d_alpha,
                                                      R.dense->d_alpha_k, R.dense->d_counters, R.dense->total_out);
                     else
                         rc = minimal9_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, R.h_samples_pinned, T, R.use_alpha_k, R.k_sign_mode, R.d_hyp,
-                                             zero_in_minimal9 ? R.zero_begin : nullptr, zero_in_minimal9 ? R.zero_bytes : 0, R.direct);
+                                             zero_in_minimal9 ? R.zero_begin : nullptr, zero_in_minimal9 ? R.zero_bytes : 0, &dir);
                     if (rc != RSDSFM_OK) return rc;
                     if (R.after_minimal9) {  // (the frame solve: join the stream that ran the flatten beside the minimal solver)
                         rc = (*R.after_minimal9)();
@@ -143,7 +152,8 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                 bool flags_via_pick = false;  // this round's flag words reach the host with the speculated pick kernel
                 if (round > 4 * kMaxIter) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machines did not terminate");
                 rc = ransac_lm_round_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_hyp + (size_t)b0 * 8, B, R.d_states + b0, R.d_partials, R.d_flags,
-                                            R.d_scored + b0, R.d_tcount + b0, R.d_terr + b0, round, tol, R.k0, R.fused_base);
+                                            R.d_scored + b0, R.d_tcount + b0, R.d_terr + b0, round, tol, R.k0, R.fused_base, R.core_math,
+                                            R.core_epoch ? c->d_core_flag : nullptr, R.core_epoch);
                 if (rc != RSDSFM_OK) return rc;
                 if (round == 0 && B == T) {
                     // one batch, and on typical data every hypothesis is decided and scored by round 0: the final stage
@@ -182,6 +192,19 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                 yield_at_wait = false;  // (a run yields once: after its first wait the caller is blocked in it anyway)
                 RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
                 const int* h_running = R.h_running;
+                if (R.round == 0 && R.core_math && h_running[3] != 0) {
+                    // round 0 met an argument outside the range of its in-range function cores (ransac_lm_kernel CORE: a zero Jacobian,
+                    // a zero or non-finite error -- not on real data): its sums may differ from the standard functions', so the LM rounds
+                    // start over from the hypotheses with the standard functions.  What was enqueued behind on speculation has left at
+                    // once (the pick kernel marks such a run undecided).
+                    R.core_math = false;
+                    R.restarted = true;
+                    R.not_one_step = 0;
+                    R.final_done = R.spec_scored = R.tail_enqueued = R.spec_final = false;
+                    R.dense = nullptr;  // (the flatten that rode in the minimal solver's launch has run)
+                    R.pc = kPcStart;    // the hypotheses too: the minimal solver's SVD may have been the one (it clears the states again)
+                    break;
+                }
                 if (R.round == 0) {
                     R.not_one_step += h_running[2];
                     if (R.b0 == 0) {  // where this solve's hypotheses ended: the state the context's next solve fuses the score of
@@ -285,6 +308,12 @@ void ransac_commit_hints(Ctx* c, const RansacRun& R) {
     if (R.score_hint_next >= 0) c->ransac_score_idle = R.score_hint_next ? 0 : std::min(c->ransac_score_idle + 1, kScoreIdleLimit);
     c->ransac_not_one_step = R.not_one_step;
     c->ransac_spec_miss = R.spec_final ? 0 : std::min(c->ransac_spec_miss + 1, 2);
+    if (R.restarted) {
+        c->ransac_standard_math = 16;
+        c->ransac_restarts += 1;
+    } else if (c->ransac_standard_math > 0) {
+        c->ransac_standard_math -= 1;
+    }
 }
 
 int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n, int use_alpha_k, int T,
@@ -294,6 +323,7 @@ int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a
     RansacRun& R = *run;
     R = RansacRun();
     R.tail_ahead = tail_ahead;
+    R.core_math = c->ransac_math_mode == 0 && c->ransac_standard_math == 0;
     if (spec_tail_held) *spec_tail_held = false;
     if (!out) return fail(c, RSDSFM_ERR_INVALID, "null out");
     if (n < 9) return fail(c, RSDSFM_ERR_INVALID, "ransac needs at least 9 points (the reference would compute rand() % 0)");
@@ -336,6 +366,10 @@ int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a
 
     rc = ensure_pinned(c, ransac_pinned_bytes(T));
     if (rc != RSDSFM_OK) return rc;
+    if (!c->d_core_flag) {
+        RSDSFM_HIP_CHECK(c, hipMalloc(reinterpret_cast<void**>(&c->d_core_flag), 64));
+        RSDSFM_HIP_CHECK(c, hipMemsetAsync(c->d_core_flag, 0, 64, c->stream));
+    }
     char* hp = static_cast<char*>(c->h_pinned);
     R.h_best = reinterpret_cast<RansacBest*>(hp);
     R.h_running = reinterpret_cast<int*>(hp + sizeof(RansacBest));

@@ -55,19 +55,21 @@ struct R0Shape {
 };
 static_assert(R0Shape<KMAX>::nsum == kNSum, "full shape uses every sum slot");
 
-// BIDX: the speculated iterate that is scored (fused_base - 1), -1: none
-template <int BIDX>
+// BIDX: the speculated iterate that is scored (fused_base - 1), -1: none.  CORE (reference arithmetic only): the error's square root
+// through its in-range core, *worst tracking the range test of its argument (see lm_pixel_t)
+template <int BIDX, bool CORE = false>
 struct ScoreHook {
     double x, y, ux, uy, al, ak, two_over, tol;
     const Pose* pose;
     double* sc;  // {count, err} of the fused state
+    uint32_t* worst = nullptr;
     __device__ __forceinline__ void operator()(int j, double rho, const PixelModel& m) const {
         if (j == BIDX) {
 #if RSDSFM_FUSED
             (void)m;
             const double e = point_error(x, y, ux, uy, al, ak, *pose, two_over, rho);
 #else
-            const double e = point_error_from_model(m, rho);  // bit-identical to point_error(...): device_math.hpp
+            const double e = CORE ? point_error_from_model_core(m, rho, *worst) : point_error_from_model(m, rho);  // bit-identical to point_error(...): device_math.hpp
 #endif
             if (e < tol) {
                 sc[0] += 1.0;
@@ -100,6 +102,15 @@ __device__ __forceinline__ void load_tile(Tile& t, const double2* __restrict__ q
     }
 }
 
+__device__ __forceinline__ bool is_nan_bits(double x) {  // (integer test: the pose is wave-uniform, this stays on the scalar unit)
+    const uint32_t h = (uint32_t)__double2hiint(x) & 0x7FFFFFFFu;
+    return h > 0x7FF00000u || (h == 0x7FF00000u && __double2loint(x) != 0);
+}
+__device__ __forceinline__ bool pose_has_nan(const Pose& p) {
+    return ((int)is_nan_bits(p.w[0]) | (int)is_nan_bits(p.w[1]) | (int)is_nan_bits(p.w[2]) | (int)is_nan_bits(p.v[0]) | (int)is_nan_bits(p.v[1]) |
+            (int)is_nan_bits(p.v[2]) | (int)is_nan_bits(p.k)) != 0;
+}
+
 // hypothesis pose from the (wave-uniform) hypothesis table; written field by field so that it stays in registers
 #define RSDSFM_LOAD_POSE(pose, hyp, t)                       \
     Pose pose;                                               \
@@ -117,18 +128,27 @@ __device__ __forceinline__ void load_tile(Tile& t, const double2* __restrict__ q
 // ---------------------------------------------------------------------------------------------------
 // round 0: every hypothesis starts from the built-in plan; round r > 0: only hypotheses whose state machine is
 // still running (status 0) and expects launch r take part.  partials: [T][gridDim.x][NSR] (hypothesis-major).
-template <bool R0, int K0, int BASE>
+// CORE (round 0 of the reference-arithmetic build, with flag words): the two square roots and the reciprocal of a pixel-hypothesis go
+// through their in-range cores (device_math.hpp: 16 instructions less, the same bits for arguments in range); flags[3] is raised when
+// an argument was outside -- a zero Jacobian, a zero or non-finite error -- and the host runs the RANSAC again with CORE = false.
+template <bool R0, int K0, int BASE, bool CORE>
 __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
                                                        const double* __restrict__ alpha,
                                                        const double* __restrict__ alpha_k, int64_t n,
                                                        const double* __restrict__ hyp, int T,
                                                        const LmState* __restrict__ states,
                                                        double* __restrict__ partials, int round, double tol,
-                                                       int* __restrict__ running_flag, int ntile_blocks, int ngroups) {
+                                                       int* __restrict__ running_flag, int ntile_blocks, int ngroups,
+                                                       const int* __restrict__ m9_core_flag, int m9_core_epoch) {
     extern __shared__ double s_acc[];  // [T][NSR]
     // the decide kernel of this round counts the still-running hypotheses into *running_flag; it runs after this kernel
     // (stream order), so the counter is cleared here instead of by a separate memset
-    if (running_flag && blockIdx.x == 0 && threadIdx.x == 0) *running_flag = 0;
+    if (running_flag && blockIdx.x == 0 && threadIdx.x == 0) {
+        *running_flag = 0;
+        // the minimal solver of this run met an SVD operand outside the range of its function cores (minimal9_kernels.hip): reported
+        // through the same flag word as this kernel's own cores -- the host starts the run over with the standard functions
+        if (m9_core_flag && *m9_core_flag == m9_core_epoch) running_flag[3] = 1;
+    }
     // XCD-aware block -> (tile block, hypothesis group) mapping.  The hypotheses are split over `ngroups` workgroups per tile
     // block (short workgroups: a full last round of the chip), and all of them read the same pixels.  Workgroups are dispatched
     // round-robin over the 8 XCDs, each with its own L2: the FULL groups (0 .. ngroups - 2, ceil(T / ngroups) hypotheses each) of
@@ -183,6 +203,7 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
 
     const int64_t tile_pixels = (int64_t)kRB * kRP;
     const int64_t ntiles = (n + tile_pixels - 1) / tile_pixels;
+    uint32_t worst_key = 0;  // CORE: the range tests of this thread's function-core arguments (sqrt_range_track)
     for (int64_t tile = tb; tile < ntiles; tile += ntile_blocks) {
         Tile px;
         load_tile(px, q, u, alpha, alpha_k, tile * tile_pixels, n);
@@ -214,12 +235,18 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
             double sc[2 * kFused];
 #pragma unroll
             for (int s = 0; s < 2 * kFused; ++s) sc[s] = 0.0;
+            static_assert(!CORE || (R0 && !RSDSFM_FUSED), "the cores stand for the reference arithmetic's functions in round 0");
             if (R0 && full_tile) {  // round 0, no ragged lanes: one straight-line block, the kRP pixel chains interleave
+                uint32_t wk = 0;
 #pragma unroll
                 for (int j = 0; j < kRP; ++j) {
-                    const ScoreHook<(R0 ? BASE - 1 : -1)> hook{px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], two_over, tol, &pose, sc};
-                    (void)lm_pixel(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, pf, acc, hook);
+                    const ScoreHook<(R0 ? BASE - 1 : -1), CORE> hook{px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], two_over, tol, &pose, sc, &wk};
+                    (void)lm_pixel_t<CORE>(px.x[j], px.y[j], px.ux[j], px.uy[j], px.al[j], px.ak[j], pose, two_over, pf, acc, hook, nullptr, &wk);
                 }
+                // A hypothesis with a NaN in its pose (a degenerate sample: one trial in a few hundred) does not count: a NaN argument
+                // goes through the same instructions in the cores and in the standard functions, and with a NaN pose component every
+                // sum that depends on the Jacobi scaling is NaN either way (the residual is) -- such a hypothesis must not cost a restart.
+                if (CORE && !pose_has_nan(pose)) worst_key = max(worst_key, wk);
             } else {
 #pragma unroll
                 for (int j = 0; j < kRP; ++j)
@@ -288,6 +315,7 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
         __syncthreads();
     }
     __syncthreads();
+    if (CORE && worst_key >= kSqrtRangeKeys) running_flag[3] = 1;  // (benign race: every writer stores the same word)
     // hypothesis-major rows [T][gridDim.x][NSR]: the per-hypothesis reduction that follows reads one contiguous block
     for (int i = t_begin * NSR + tid; i < t_end * NSR; i += kRB) {
         const int t = i / NSR, sl = i - t * NSR;
@@ -659,7 +687,9 @@ __global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restric
     // ended where round 0 did not score them and no scoring pass was enqueued ahead, the trial scores are incomplete -- the host's own
     // test in ransac_advance -- and the final stage and the caller's work behind it (the refinement) leave at once instead of running
     // on a winner that does not count: ~250 us of kernels the host would otherwise wait for before it can enqueue the next LM round.
-    const int undecided = (flags && (flags[0] != 0 || (flags[1] > 0 && !scored_ahead))) ? 1 : 0;
+    // (flags[3]: round 0 met an argument outside the range of its in-range function cores -- ransac_lm_kernel's CORE --: the host runs the
+    // whole RANSAC again)
+    const int undecided = (flags && (flags[0] != 0 || (flags[1] > 0 && !scored_ahead) || flags[3] != 0)) ? 1 : 0;
     double best_count, best_err;
     int bi;
     pick_best_trial(trial_count, trial_err, T, lane, bi, best_count, best_err);
@@ -874,25 +904,39 @@ static int ransac_lm_groups(const Ctx* c, int grid, int T) {
 int ransac_lm_partials_doubles(const Ctx* c, int64_t n, int batch) { return ransac_pixel_grid(c, n) * batch * NSR; }
 
 static int lm_launch(Ctx* c, const dim3& g2, int k0, const double* q, const double* u, const double* a, const double* ak, int64_t n,
-                     const double* hyp, int T, const LmState* states, double* partials, int round, double tol, int* flags, int fused_base) {
+                     const double* hyp, int T, const LmState* states, double* partials, int round, double tol, int* flags, int fused_base,
+                     bool core_math, const int* m9_flag, int m9_epoch) {
     const double2* q2 = reinterpret_cast<const double2*>(q);
     const double2* u2 = reinterpret_cast<const double2*>(u);
     const size_t lds = sizeof(double) * T * NSR;
     // g2 = (tile blocks, hypothesis groups) is flattened into a 1-D grid of windows of 8 tile blocks x groups (see the kernel)
     const int tiles = (int)g2.x, groups = (int)g2.y;
     const dim3 g1((unsigned)(((tiles + 7) / 8) * 8 * groups));
-#define RSDSFM_LM_LAUNCH(R0, K0, BASE) \
-    hipLaunchKernelGGL((ransac_lm_kernel<R0, K0, BASE>), g1, dim3(kRB), lds, c->stream, q2, u2, a, ak, n, hyp, T, states, partials, round, tol, flags, tiles, groups)
+#define RSDSFM_LM_LAUNCH(R0, K0, BASE, CORE) \
+    hipLaunchKernelGGL((ransac_lm_kernel<R0, K0, BASE, CORE>), g1, dim3(kRB), lds, c->stream, q2, u2, a, ak, n, hyp, T, states, partials, round, tol, flags, tiles, groups, m9_flag, m9_epoch)
+    // (core: see the kernel's CORE -- needs the flag words, and stands for the reference arithmetic's functions only)
+    const bool core = core_math && flags != nullptr && !RSDSFM_FUSED;
+    (void)core;
+#if RSDSFM_FUSED
+#define RSDSFM_LM_LAUNCH2(R0, K0, BASE) RSDSFM_LM_LAUNCH(R0, K0, BASE, false)
+#else
+#define RSDSFM_LM_LAUNCH2(R0, K0, BASE)                 \
+    do {                                                \
+        if (core) RSDSFM_LM_LAUNCH(R0, K0, BASE, true); \
+        else RSDSFM_LM_LAUNCH(R0, K0, BASE, false);     \
+    } while (0)
+#endif
     if (round != 0)
-        RSDSFM_LM_LAUNCH(false, KMAX, 0);  // continuation rounds score nothing
+        RSDSFM_LM_LAUNCH(false, KMAX, 0, false);  // continuation rounds score nothing
     else if (k0 == 2)
-        RSDSFM_LM_LAUNCH(true, 2, 1);
+        RSDSFM_LM_LAUNCH2(true, 2, 1);
     else if (fused_base == 1)
-        RSDSFM_LM_LAUNCH(true, KMAX, 1);
+        RSDSFM_LM_LAUNCH2(true, KMAX, 1);
     else if (fused_base == 3)
-        RSDSFM_LM_LAUNCH(true, KMAX, 3);
+        RSDSFM_LM_LAUNCH2(true, KMAX, 3);
     else
-        RSDSFM_LM_LAUNCH(true, KMAX, 2);
+        RSDSFM_LM_LAUNCH2(true, KMAX, 2);
+#undef RSDSFM_LM_LAUNCH2
 #undef RSDSFM_LM_LAUNCH
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
@@ -903,14 +947,15 @@ static int lm_launch(Ctx* c, const dim3& g2, int k0, const double* q, const doub
 // round 0; fused_base (1 .. k0): the speculated iterate whose score round 0 fuses (the same values for every round of a batch).
 int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                            const double* hyp, int T, LmState* states, double* partials, int* flags, int* scored,
-                           double* trial_count, double* trial_err, int round, double tol, int k0, int fused_base) {
+                           double* trial_count, double* trial_err, int round, double tol, int k0, int fused_base, bool core_math,
+                           const int* m9_core_flag, int m9_core_epoch) {
     const int grid = ransac_pixel_grid(c, n);
     const dim3 g2(grid, ransac_lm_groups(c, grid, T));
     if (k0 != 2) k0 = KMAX;
     if (fused_base < 1 || fused_base > k0) fused_base = std::min(2, k0);
     const bool prof = c->profile && round == 0 && c->ev_prof[0] && c->ev_prof[1];
     if (prof) RSDSFM_HIP_CHECK(c, hipEventRecord(c->ev_prof[0], c->stream));
-    int rc = lm_launch(c, g2, k0, q, u, a, ak, n, hyp, T, states, partials, round, tol, flags, fused_base);
+    int rc = lm_launch(c, g2, k0, q, u, a, ak, n, hyp, T, states, partials, round, tol, flags, fused_base, core_math, round == 0 ? m9_core_flag : nullptr, m9_core_epoch);
     if (rc != RSDSFM_OK) return rc;
     if (prof) {
         RSDSFM_HIP_CHECK(c, hipEventRecord(c->ev_prof[1], c->stream));
@@ -943,7 +988,7 @@ int ransac_lm_rows_launch(Ctx* c, const double* q, const double* u, const double
                           const double* hyp, int T, const LmState* states, double* partials, int round, double tol, double* rows) {
     const int grid = ransac_pixel_grid(c, n);
     const dim3 g2(grid, ransac_lm_groups(c, grid, T));
-    int rc = lm_launch(c, g2, KMAX, q, u, a, ak, n, hyp, T, states, partials, round, tol, nullptr, kTiledFusedBase);
+    int rc = lm_launch(c, g2, KMAX, q, u, a, ak, n, hyp, T, states, partials, round, tol, nullptr, kTiledFusedBase, false, nullptr, 0);
     if (rc != RSDSFM_OK) return rc;
     hipLaunchKernelGGL(ransac_lm_rows_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, states, round, rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());

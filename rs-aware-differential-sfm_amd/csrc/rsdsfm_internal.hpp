@@ -102,6 +102,11 @@ struct Ctx {
     int ransac_fused_base = 2;     // accepted steps after which most hypotheses of the previous solve ended: the iterate round 0 scores
     int ransac_score_idle = kScoreIdleLimit;  // consecutive solves (saturating) that did NOT need the separate scoring pass behind round 0; below the limit the pass is enqueued ahead of the host's flag read
     int refine_iters_hint = -1;    // LM iterations the context's previous refinement took (-1: none yet): length of the first chunk the host enqueues
+    int ransac_standard_math = 0;  // > 0: that many of the context's next RANSACs run round 0 with the standard sqrt / reciprocal (set to 16 by a run that met an argument outside the range of the in-range cores and had to start over; ransac_lm_kernel CORE)
+    int* d_core_flag = nullptr;    // device word the minimal solver stores its launch epoch in when an SVD operand left the range of the function cores (persistent: never a stale value)
+    int core_epoch = 0;
+    int ransac_math_mode = 0;      // rsdsfm_set_ransac_math: 0 = in-range cores with restart (default), 1 = always the standard functions
+    int64_t ransac_restarts = 0;   // RANSAC runs of this context that started over for that reason (rsdsfm_ransac_restarts)
     int ransac_spec_miss = 0;  // consecutive RANSACs (saturating at 2) whose speculated final stage did not count; below 2 the frame solve enqueues the refinement behind the speculated stage
     int frame_dense_hint = 1;  // frame solve: the previous frame kept every pixel (dense flow) -> set the RANSAC up for n = rows * cols without waiting for the count
     int lm_issued_d = 0;           // depth_lm_decide_kernel launches issued for the current solve
@@ -265,6 +270,11 @@ struct Minimal9Direct {
     const double* img = nullptr;  // row-major [rows][cols][2] flow image (DEVICE)
     int rows = 0, cols = 0, alpha_ones = 0;  // alpha_ones: the global-shutter override alpha = alpha * 0 + 1 (main.cc:441-444)
     double fx = 0, fy = 0, cx = 0, cy = 0, gamma = 0;
+    // (independent of img) non-null: the wave-per-hypothesis SVD runs its rotations through the in-range cores of division, reciprocal
+    // and square root (device_math.hpp) and stores core_epoch here when an operand was out of range (the caller then has the
+    // hypotheses computed again without it)
+    int* core_flag = nullptr;
+    int core_epoch = 0;
 };
 int minimal9_launch(Ctx* c, const double* q, const double* u, const double* alpha, const double* alpha_k,
                     const int32_t* samples, int T, int use_alpha_k, int k_sign_mode, double* hyp_out, void* zero_begin = nullptr,
@@ -288,7 +298,8 @@ int ransac_pixel_grid(const Ctx* c, int64_t n);
 int ransac_lm_partials_doubles(const Ctx* c, int64_t n, int batch);
 int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                            const double* hyp, int T, LmState* states, double* partials, int* flags, int* scored,
-                           double* trial_count, double* trial_err, int round, double tol, int k0, int fused_base);
+                           double* trial_count, double* trial_err, int round, double tol, int k0, int fused_base, bool core_math,
+                           const int* m9_core_flag = nullptr, int m9_core_epoch = 0);
 int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
                         double* partials, double* trial_count, double* trial_err);
@@ -358,6 +369,9 @@ struct RansacRun {
     rsdsfm_ransac_out* out = nullptr;
     const RansacSpecTail* spec_tail = nullptr;
     bool* spec_tail_held = nullptr;
+    int core_epoch = 0;      // the minimal solver's launch epoch of this run (0: it ran without the cores)
+    bool core_math = true;   // round 0 through the in-range function cores (ransac_lm_kernel CORE); false after a restart
+    bool restarted = false;
     bool tail_ahead = true;  // enqueue the caller's tail behind the SPECULATED final stage (otherwise only behind the definitive one)
     const Minimal9Direct* direct = nullptr;
     const DenseFlatten* dense = nullptr;  // with `direct`: the flatten of the dense frame rides in the solver's launch

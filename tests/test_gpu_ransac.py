@@ -75,7 +75,7 @@ def _compare_ransac(r, ro, rho_rtol=1e-9):
     assert np.array_equal(r["trial_count"], ro["trial_count"])
     assert np.array_equal(r["trial_steps"], ro["trial_steps"])
     assert np.allclose(r["trial_err"], ro["trial_err"], rtol=1e-9, atol=1e-12)
-    assert np.allclose(r["trial_vel"], ro["trial_vel"], rtol=1e-8, atol=1e-10)
+    assert np.allclose(r["trial_vel"], ro["trial_vel"], rtol=1e-8, atol=1e-10, equal_nan=True)  # (a degenerate sample gives a NaN hypothesis on both sides)
     assert r["best_trial"] == ro["best_trial"]
     assert r["num_inliers"] == ro["num_inliers"]
     assert np.array_equal(r["mask"], ro["mask"])
@@ -231,3 +231,94 @@ def test_ransac_speculation_depth_does_not_change_results(oracle, rsdsfm, cfg, r
     assert all(o == outs[0] for o in outs[1:])
     if noise is not None:
         assert ro["trial_steps"].max() == 1
+
+
+def _ransac_bytes(r):
+    return (r["trial_count"].tobytes(), r["trial_steps"].tobytes(), r["mask"].tobytes(), r["inv_depth"].tobytes(), r["inliers"].tobytes(),
+            r["best_trial"], r["trial_err"].tobytes(), r["trial_vel"].tobytes(), r["inlier_idx"].tobytes())
+
+
+@pytest.mark.parametrize("cfg,rows,cols,tol", [(3, 135, 240, 0.002), (1, 96, 128, 0.05), (5, 144, 256, 0.05), (5, 360, 640, 0.05)])
+def test_ransac_function_cores_do_not_change_results(oracle, rsdsfm, cfg, rows, cols, tol):
+    """rsdsfm_set_ransac_math: round 0 of the batched depth solves takes sqrt and the reciprocal through the in-range cores of the
+    compiler's expansions (default) or through the standard functions.  Every output is identical bit for bit, equal to the oracle's,
+    and on real-valued data no run has to start over."""
+    d = rsdsfm.synth.make_config(cfg, rows=rows, cols=cols)
+    q, u, a, ak = d["q"], d["u"], d["alpha"], d["alpha_k"]
+    T = 24
+    samples = oracle.sample_indices(len(q), T, 31337)
+    ro = oracle.ransac(q, u, a, ak, False, T, tol, samples, depth_mode=1)
+    outs = []
+    with rsdsfm.Solver(0) as s:
+        for mode in (0, 1, 0):
+            s.set_ransac_math(mode)
+            r = s.ransac(q, u, a, ak, False, T, tol, samples=samples, depth_mode=1)
+            _compare_ransac(r, ro)
+            outs.append(_ransac_bytes(r))
+        assert s.ransac_restarts() == 0
+        with pytest.raises(rsdsfm.RsdsfmError):
+            s.set_ransac_math(2)
+    assert outs[0] == outs[1] == outs[2]
+    if (cfg, rows) == (5, 144):  # this draw holds a degenerate sample: a NaN hypothesis must not cost a restart (asserted above)
+        assert np.isnan(ro["trial_vel"]).any()
+
+
+@pytest.mark.parametrize("poison", ["zero_jacobian", "nan_flow", "zero_error"])
+def test_ransac_function_cores_restart_on_arguments_out_of_range(oracle, rsdsfm, poison):
+    """an argument outside the range of the in-range cores -- a pixel whose Jacobian vanishes (alpha = alpha_k = 0: beta = 0), a
+    non-finite flow, an error of exactly zero -- makes the run start over with the standard functions: results equal the oracle's and
+    the standard-function setting's bit for bit, the restart is counted, and the context keeps the standard functions for its next runs"""
+    d = rsdsfm.synth.make_config(5, rows=240, cols=320)  # 76800 points: 50 full tiles of 1536, the path the cores run on
+    q, u, a, ak = d["q"].copy(), d["u"].copy(), d["alpha"].copy(), d["alpha_k"].copy()
+    n = len(q)
+    T = 16
+    samples = oracle.sample_indices(n, T, 99)
+    victim = 1536 * 7 + 100
+    assert victim not in samples
+    if poison == "zero_jacobian":
+        a[victim] = 0.0
+        ak[victim] = 0.0
+    elif poison == "nan_flow":
+        u[victim] = np.nan
+    else:
+        # an error of exactly zero under every hypothesis: beta = 0 and u = 0 give e = beta (...) - u = 0 (and a zero Jacobian with it)
+        a[victim] = 0.0
+        ak[victim] = 0.0
+        u[victim] = 0.0
+    ro = oracle.ransac(q, u, a, ak, False, T, 0.05, samples, depth_mode=1)
+    with rsdsfm.Solver(0) as s:
+        r0 = s.ransac(q, u, a, ak, False, T, 0.05, samples=samples, depth_mode=1)
+        assert s.ransac_restarts() == 1
+        _compare_ransac(r0, ro)
+        r1 = s.ransac(q, u, a, ak, False, T, 0.05, samples=samples, depth_mode=1)  # standard functions from the start: no second restart
+        assert s.ransac_restarts() == 1
+        s.set_ransac_math(1)
+        r2 = s.ransac(q, u, a, ak, False, T, 0.05, samples=samples, depth_mode=1)
+    assert _ransac_bytes(r0) == _ransac_bytes(r1) == _ransac_bytes(r2)
+
+
+def test_minimal_solver_function_cores_restart_on_operands_out_of_range(oracle, rsdsfm):
+    """the wave-per-hypothesis SVD of the minimal solver runs its rotations through the in-range cores of division, reciprocal and
+    square root; an operand outside their window makes the RANSAC start over with the standard functions.  Forced here with the first
+    rotation's t = W(1,1) + W(0,0) = (u_x of the second sampled point - u_y of the first) / scale = 0 exactly; results equal the oracle's
+    and the standard-function setting's bit for bit, one restart is counted."""
+    d = rsdsfm.synth.make_config(5, rows=240, cols=320)
+    q, u, a, ak = d["q"].copy(), d["u"].copy(), d["alpha"].copy(), d["alpha_k"].copy()
+    T = 12
+    samples = oracle.sample_indices(len(q), T, 4711)
+    i0, i1 = int(samples[5][0]), int(samples[5][1])
+    u[i1, 0] = u[i0, 1]
+    ro = oracle.ransac(q, u, a, ak, False, T, 0.05, samples, depth_mode=1)
+    with rsdsfm.Solver(0) as s:
+        r0 = s.ransac(q, u, a, ak, False, T, 0.05, samples=samples, depth_mode=1)
+        assert s.ransac_restarts() == 1
+        _compare_ransac(r0, ro)
+        s.set_ransac_math(1)
+        r1 = s.ransac(q, u, a, ak, False, T, 0.05, samples=samples, depth_mode=1)
+        assert s.ransac_restarts() == 1
+    assert _ransac_bytes(r0) == _ransac_bytes(r1)
+    # and the same draw without the planted zero does not restart
+    with rsdsfm.Solver(0) as s:
+        r2 = s.ransac(d["q"], d["u"], a, ak, False, T, 0.05, samples=samples, depth_mode=1)
+        assert s.ransac_restarts() == 0
+        _compare_ransac(r2, oracle.ransac(d["q"], d["u"], a, ak, False, T, 0.05, samples, depth_mode=1))

@@ -28,7 +28,9 @@ with pkg.Solver(0) as s:
         dt = (time.perf_counter() - t0) * 1e3
         if i >= 10:
             rec.append((dt, 1 + i, int(r.refine_summary.num_iterations), int(r.best_trial)))
+    restarts = s.ransac_restarts()
 ts = np.array([x[0] for x in rec])
+print("RANSAC runs that started over with the standard functions (an operand outside the range of a function core): %d of %d" % (restarts, n + 10))
 print("solves %d: mean %.4f median %.4f p90 %.4f p99 %.4f max %.4f ms" % (n, ts.mean(), np.median(ts), np.percentile(ts, 90), np.percentile(ts, 99), ts.max()))
 its = np.array([x[2] for x in rec])
 for k in sorted(set(its.tolist())):

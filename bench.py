@@ -1181,7 +1181,7 @@ def _counters(kernel):
 
 
 def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):
-    """Roofline record of the whole solve's dominant kernel, ransac_lm_kernel<true, 3, 2> (round 0 of the hypothesis-batched LM depth
+    """Roofline record of the whole solve's dominant kernel, ransac_lm_kernel<true, 3, 2, true> (round 0 of the hypothesis-batched LM depth
     solves: ~45 % of the solve), measured LIVE and in situ: the library brackets that launch with HIP events on the stream it runs
     on (rsdsfm_set_profiling) inside 27 ordinary whole solves after 3 warm-ups.  Its bound is
     fp64 VALU issue, not HBM: `achieved` = fp64 lane-instructions of one launch (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes,
@@ -1201,7 +1201,9 @@ def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):
     solver.set_profiling(False)
     ts = sorted(ts[3:])
     kern_ms = float(np.mean(ts))
-    kname = "ransac_lm_kernel<true, 3, 2>"  # round 0: three speculated iterations, the score of the two-step iterate fused (DeepFlow-like data)
+    # round 0: three speculated iterations, the score of the two-step iterate fused (DeepFlow-like data); last template argument: sqrt and
+    # the reciprocal through their in-range cores (reference-arithmetic library only)
+    kname = "ransac_lm_kernel<true, 3, 2, %s>" % ("false" if args.arith == "fused" else "true")
     ctr = _counters(kname + (":fused" if args.arith == "fused" else ""))
     insts = achieved = frac = traffic = frac_all = None
     stale = ctr.get("stale") if ctr else None

@@ -21,7 +21,7 @@ def test_stale_sources_are_detected(tmp_path, monkeypatch):
 
     now = source_hash.source_hashes()
     assert {"ransac_kernels.hip", "device_math.hpp", "lm_common.hpp", "rsdsfm_internal.hpp", "build.py", "rsdsfm.h"} <= set(now)
-    k = "ransac_lm_kernel<true, 3, 2>"
+    k = "ransac_lm_kernel<true, 3, 2, true>"
     assert source_hash.stale_files(k, now) == []
     assert "ransac_kernels.hip" in source_hash.files_of(k) and "depth_kernels.hip" not in source_hash.files_of(k)
     old = dict(now, **{"ransac_kernels.hip": "0" * 16})
@@ -51,7 +51,7 @@ def test_committed_counters_carry_a_stamp_or_are_reported_stale():
 
     data = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))
     stamp = (data.get("_meta") or {}).get("sources")
-    stale = source_hash.stale_files("ransac_lm_kernel<true, 3, 2>", stamp)
+    stale = source_hash.stale_files("ransac_lm_kernel<true, 3, 2, true>", stamp)
     b = _bench()
-    got = b._counters("ransac_lm_kernel<true, 3, 2>")
+    got = b._counters("ransac_lm_kernel<true, 3, 2, true>")
     assert (got == {"stale": stale}) if stale else ("SQ_INSTS_VALU_ADD_F64" in got)

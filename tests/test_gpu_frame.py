@@ -554,6 +554,52 @@ def test_stage_pipeline_on_device_buffers_equals_one_call_solve(rsdsfm, flow_mod
         assert torch.equal(pipe.depth_map, dm) and torch.equal(pipe.R, R) and torch.equal(pipe.t, t)
 
 
+def test_frame_solve_starts_over_with_the_standard_functions(rsdsfm):
+    """round 0 of the depth solves and the minimal solver run sqrt / reciprocal / division through their in-range cores; a frame with a
+    pixel whose Jacobian vanishes -- alpha = 1 + gamma f_y / h = 0 exactly: h = 64 rows, gamma = 0.5, f_y = -128 px -- makes the one-call
+    solve start its RANSAC over with the standard functions behind the speculated chain (which leaves at once).  Same results as with the
+    standard functions from the start, bit for bit, in the single solve and in the sequence solve; the dense frames around it in the
+    sequence are not affected."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(5, rows=64, cols=480)  # 30720 points: 20 full tiles of 1536
+    rows, cols, K = d["rows"], d["cols"], d["K"]
+    gamma = 0.5
+    clean = np.array(d["flow_img"])
+    bad = clean.copy()
+    bad[17, 301] = (3.0, -128.0)
+    imgs = {"clean": torch.from_numpy(clean).to(dev), "bad": torch.from_numpy(bad).to(dev)}
+    outs = {}
+    for math in (0, 1):
+        with rsdsfm.Solver(0) as s:
+            s.set_ransac_math(math)
+            res = []
+            for name in ("clean", "bad", "clean"):
+                dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+                R = torch.empty((rows, 9), dtype=torch.float64, device=dev)
+                t = torch.empty((rows, 3), dtype=torch.float64, device=dev)
+                r = s.solve_frame_dev(imgs[name].data_ptr(), rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), trials=20, tol=0.05, seed=11)
+                s.synchronize()
+                res.append((r["n"], r["num_inliers"], r["best_trial"], r["v"].tobytes(), r["w"].tobytes(), r["k"], r["flipped"], str(r["refine_summary"]),
+                            dm.cpu().numpy().tobytes(), R.cpu().numpy().tobytes(), t.cpu().numpy().tobytes()))
+            restarts_single = s.ransac_restarts()
+            # the same three pairs through the sequence solve (lanes of their own)
+            dms = [torch.empty((cols, rows), dtype=torch.float64, device=dev) for _ in range(3)]
+            jobs = [dict(d_flow_img=imgs[name].data_ptr(), rows=rows, cols=cols, K=K, gamma=gamma, d_depth_map=dm.data_ptr()) for name, dm in zip(("clean", "bad", "clean"), dms)]
+            call = s.prepared_frames_solve(jobs, trials=20, tol=0.05)
+            rs = call([11, 11, 11])
+            seq = [(int(x.n_points), int(x.num_inliers), int(x.best_trial), bytes(bytearray(np.array(x.v[:]).tobytes())), dm.cpu().numpy().tobytes()) for x, dm in zip(rs, dms)]
+            restarts_all = s.ransac_restarts()
+        outs[math] = (res, seq)
+        assert restarts_single == (1 if math == 0 else 0)
+        assert restarts_all == (2 if math == 0 else 0)  # (the sequence's lane met the pixel with the cores again)
+        for (a, b) in zip(res, seq):
+            assert (a[0], a[1], a[2], a[3], a[8]) == b
+    assert outs[0] == outs[1]
+    assert outs[0][0][0] == outs[0][0][2] and outs[0][0][0] != outs[0][0][1]
+
+
 def test_one_call_solve_equals_stage_pipeline_on_random_frames(rsdsfm):
     """The one-call solve speculates at three places (a dense flow, the RANSAC's final stage, the refinement ending within its first
     chunk) and enqueues each stage behind the one before it; the stage pipeline (pipeline.FramePipeline over the `_dev` entry points)

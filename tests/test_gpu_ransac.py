@@ -263,15 +263,15 @@ def test_ransac_function_cores_do_not_change_results(oracle, rsdsfm, cfg, rows, 
         assert np.isnan(ro["trial_vel"]).any()
 
 
+@pytest.mark.parametrize("T", [16, 150])  # 150: two hypothesis batches (the flag words reach the host by a copy, not with the pick kernel)
 @pytest.mark.parametrize("poison", ["zero_jacobian", "nan_flow", "zero_error"])
-def test_ransac_function_cores_restart_on_arguments_out_of_range(oracle, rsdsfm, poison):
+def test_ransac_function_cores_restart_on_arguments_out_of_range(oracle, rsdsfm, poison, T):
     """an argument outside the range of the in-range cores -- a pixel whose Jacobian vanishes (alpha = alpha_k = 0: beta = 0), a
     non-finite flow, an error of exactly zero -- makes the run start over with the standard functions: results equal the oracle's and
     the standard-function setting's bit for bit, the restart is counted, and the context keeps the standard functions for its next runs"""
     d = rsdsfm.synth.make_config(5, rows=240, cols=320)  # 76800 points: 50 full tiles of 1536, the path the cores run on
     q, u, a, ak = d["q"].copy(), d["u"].copy(), d["alpha"].copy(), d["alpha_k"].copy()
     n = len(q)
-    T = 16
     samples = oracle.sample_indices(n, T, 99)
     victim = 1536 * 7 + 100
     assert victim not in samples

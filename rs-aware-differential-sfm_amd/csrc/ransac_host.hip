@@ -26,23 +26,38 @@ inline uint64_t splitmix64(uint64_t& state) {
 // stored, in a flat open-addressing table (at most 18 T entries; a node-based map cost ~40 us per solve on the host, in the
 // middle of the frame pipeline with the GPU idle).
 void sample_indices(int64_t n, int T, uint64_t seed, std::vector<int32_t>& out) {
+    // (the table outlives the call -- one per host thread -- and its slots carry the number of the call that wrote them: no clearing
+    // pass; allocating and filling 48 KB per solve was a fifth of this function's 4.7 us, which the GPU spends idle)
+    struct Slot {
+        int64_t key;
+        int32_t val;
+        uint32_t gen;
+    };
+    thread_local std::vector<Slot> table;
+    thread_local uint32_t gen = 0;
     size_t cap = 64;
     while (cap < (size_t)T * 18 * 4) cap <<= 1;
-    std::vector<int64_t> keys(cap, -1);
-    std::vector<int32_t> vals(cap);
+    if (table.size() != cap || gen == 0xFFFFFFFFu) {
+        table.assign(cap, Slot{-1, 0, 0});
+        gen = 0;
+    }
+    gen += 1;
+    Slot* tb = table.data();
+    const uint32_t g = gen;
     auto slot = [&](int64_t i) -> size_t {
         size_t h = (size_t)(((uint64_t)i * 0x9E3779B97F4A7C15ull) >> 20) & (cap - 1);
-        while (keys[h] != -1 && keys[h] != i) h = (h + 1) & (cap - 1);
+        while (tb[h].gen == g && tb[h].key != i) h = (h + 1) & (cap - 1);
         return h;
     };
     auto get = [&](int64_t i) -> int32_t {
         const size_t h = slot(i);
-        return keys[h] == i ? vals[h] : (int32_t)i;
+        return tb[h].gen == g ? tb[h].val : (int32_t)i;
     };
     auto put = [&](int64_t i, int32_t v) {
         const size_t h = slot(i);
-        keys[h] = i;
-        vals[h] = v;
+        tb[h].key = i;
+        tb[h].val = v;
+        tb[h].gen = g;
     };
     out.resize((size_t)T * 9);
     uint64_t st = seed;

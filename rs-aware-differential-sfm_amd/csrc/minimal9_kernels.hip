@@ -192,7 +192,11 @@ __device__ __forceinline__ Rot make_jacobi_core(double x, double y, double z, ui
 // no barriers are needed.  Every element goes through exactly the operations of the scalar version: results are
 // bit-identical.
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double& sh(double* M, int e) { return M[e * 64]; }
+// COMPACT copies (element e at M[e]): with the per-lane layout's stride of 64 doubles every element of one lane's copy sits in the same
+// LDS bank pair, and the 9 (W) + 9 (V) lanes of a rotation serialised on it (SQ_LDS_BANK_CONFLICT: 0.97 M cycles per launch)
+__device__ __forceinline__ double& sh(double* M, int e) { return M[e]; }
+constexpr int kCoopV = 98;      // V behind W, two doubles off a multiple of 32: the row accesses of the two halves (stride 9) then use disjoint banks
+constexpr int kCoopSlots = 3;   // LDS slots (of 64 doubles) behind the per-lane block that hold the compact W and V
 
 // CORE: the rotations through the in-range function cores; *outside is set when an operand was out of range (the caller has the
 // hypotheses computed again with CORE = false)
@@ -788,13 +792,18 @@ __device__ __forceinline__ void minimal9_body(double* lds, int block, int nblock
     // ---- null vector (minimal.cc:98-103) ----
     double e[9];
     if (COOP) {
-        // the lane-0 copies of Z and V
+        // ONE copy of Z (lane 0's: every lane built the same), compact, behind the per-lane block; V beside it
+        double* Wc = lds + (size_t)(use_alpha_k ? kSlotsK : kSlotsNoK) * 64;
+        __builtin_amdgcn_wave_barrier();
+        Wc[lane] = lds[lane * 64];
+        if (lane < 17) Wc[64 + lane] = lds[(64 + lane) * 64];
+        __builtin_amdgcn_wave_barrier();
         if (direct.core_flag) {
             bool outside = false;
-            jacobi_svd9_nullvec_coop<true>(lds, lds + 81 * 64, lane, sv, col, e, &outside);
+            jacobi_svd9_nullvec_coop<true>(Wc, Wc + kCoopV, lane, sv, col, e, &outside);
             if (outside && lane == 0) *direct.core_flag = direct.core_epoch;  // (every writer of this launch stores the same value)
         } else {
-            jacobi_svd9_nullvec_coop<false>(lds, lds + 81 * 64, lane, sv, col, e, nullptr);
+            jacobi_svd9_nullvec_coop<false>(Wc, Wc + kCoopV, lane, sv, col, e, nullptr);
         }
     } else {
         jacobi_svd9_nullvec(Z, V, sv, col, e);
@@ -979,13 +988,13 @@ __global__ __launch_bounds__(256) void minimal9_flatten_kernel(const int32_t* __
 int minimal9_flatten_launch(Ctx* c, const int32_t* samples, int T, int use_alpha_k, int k_sign_mode, double* hyp_out, void* zero_begin, size_t zero_bytes,
                             const Minimal9Direct& direct, double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k,
                             unsigned long long* d_counters, int64_t* total_out) {
-    const size_t lds_bytes = (size_t)(use_alpha_k ? kSlotsK : kSlotsNoK) * 64 * sizeof(double);
+    const size_t lds_bytes = (size_t)((use_alpha_k ? kSlotsK : kSlotsNoK) + kCoopSlots) * 64 * sizeof(double);
     static_assert(sizeof(double2) * kDF_H * (kDF_W + 1) <= (size_t)kSlotsNoK * 64 * sizeof(double), "the flatten tile fits the solver's LDS block");
     static bool attr_set_dev[64] = {false};
     bool& attr_set = attr_set_dev[c->device & 63];
     if (!attr_set) {
         RSDSFM_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(minimal9_flatten_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                (int)((size_t)kSlotsK * 64 * sizeof(double))));
+                                                (int)((size_t)(kSlotsK + kCoopSlots) * 64 * sizeof(double))));
         attr_set = true;
     }
     const int tiles_x = (direct.cols + kDF_W - 1) / kDF_W, tiles_y = (direct.rows + kDF_H - 1) / kDF_H;
@@ -1004,16 +1013,16 @@ int minimal9_launch(Ctx* c, const double* q, const double* u, const double* alph
     const Minimal9Direct direct = direct_or_null ? *direct_or_null : Minimal9Direct();
     uint64_t* zero_words = reinterpret_cast<uint64_t*>(zero_begin);
     const int64_t n_zero_words = (int64_t)(zero_bytes / 8);
-    const size_t lds_bytes = (size_t)(use_alpha_k ? kSlotsK : kSlotsNoK) * 64 * sizeof(double);
+    const size_t lds_bytes = (size_t)((use_alpha_k ? kSlotsK : kSlotsNoK) + kCoopSlots) * 64 * sizeof(double);
     static bool attr_set_dev[64] = {false};  // (per device: a function attribute belongs to the device that is current)
     bool& attr_set = attr_set_dev[c->device & 63];
     if (!attr_set) {
         RSDSFM_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(minimal9_kernel<false>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                (int)((size_t)kSlotsK * 64 * sizeof(double))));
+                                                (int)((size_t)(kSlotsK + kCoopSlots) * 64 * sizeof(double))));
         RSDSFM_HIP_CHECK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(minimal9_kernel<true>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                (int)((size_t)kSlotsK * 64 * sizeof(double))));
+                                                (int)((size_t)(kSlotsK + kCoopSlots) * 64 * sizeof(double))));
         attr_set = true;
     }
     // few hypotheses (RANSAC: T = 5 ... a few hundred): one wave per hypothesis, 9x9 SVD shared by the wave; many: one lane each

@@ -133,7 +133,7 @@ int rsdsfm_set_ransac_speculation(rsdsfm_ctx* ctx, int k0);
 int rsdsfm_set_ransac_math(rsdsfm_ctx* ctx, int mode);
 int rsdsfm_ransac_restarts(rsdsfm_ctx* ctx, int64_t* count);
 /* Opt-in profiling: while on, rsdsfm_ransac* / rsdsfm_solve_frame_dev bracket the dominant kernel of the whole solve -- round 0
- * of the hypothesis-batched LM depth solves, `ransac_lm_kernel<true, 3, BASE>` -- with two HIP events on the context's stream (in
+ * of the hypothesis-batched LM depth solves, `ransac_lm_kernel<true, 3, BASE, CORE>` -- with two HIP events on the context's stream (in
  * situ: same launch, same neighbours, same clocks as any other solve).  rsdsfm_profile_last_ms(ctx, "ransac_lm_round0", &ms)
  * returns the duration of that launch in the most recent call.  bench.py's roofline record uses it. */
 int rsdsfm_set_profiling(rsdsfm_ctx* ctx, int on);

@@ -28,9 +28,12 @@ def test_bench_line_has_the_contracts_fields():
     assert abs(d["value"] - 1280 * 720 / (d["ms_per_step"] * 1e-3) / 1e6) <= 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] in ("fp64-valu", "hbm", "mfma") and r["peak"] > 0 and r["unit"]
-    assert r["counters_stale"] is False, r["counters_stale_files"]
-    assert 0.3 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["traffic"] is None or r["traffic"] > 0.5 * r["alg_bytes_per_launch"]
+    if r["counters_stale"]:  # the kernel sources changed since profiles/counters.json was collected: the line must say so and price nothing
+        assert r["counters_stale_files"] and r["frac"] is None and r["achieved"] is None
+    else:
+        assert 0.3 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        assert r["traffic"] is None or r["traffic"] > 0.5 * r["alg_bytes_per_launch"]
+    assert r["avg_launch_ms"] > 0
     assert 0.0 < r["hbm"]["frac"] < 1.0
     c = d["cpu_baseline"]
     assert c["value"] > 0 and c["unit"] == "Mpixels/s" and c["cores"] >= 1 and c["kind"] in ("port", "reference") and c["sample"]

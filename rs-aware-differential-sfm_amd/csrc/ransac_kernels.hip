@@ -262,11 +262,16 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
             // values of its half in lane order and the two halves are added -- a fixed order, 18 stores + 32 loads + 32
             // adds per lane instead of ~320 DPP/VALU instructions per hypothesis.  A wave's LDS operations execute in
             // order, so no barrier is needed inside the wave.
+            // The max slots: max |J r| is only ever compared with the gradient tolerance (lm_advance: `<= kGradientTol`), and "the maximum
+            // is at most tol" is "no value is above tol" -- so what travels from here on is 1.0 if a pixel of this wave is above the
+            // tolerance and 0.0 otherwise (one compare and a ballot per slot instead of a six-step DPP butterfly of 64-bit maxima:
+            // ~68 instructions per hypothesis and thread); every later stage combines the slots with fmax as before and the test decides
+            // exactly as it did on the maxima (NaNs never entered them: fmax drops a NaN operand, and so does the comparison).
 #pragma unroll
             for (int s = 0; s < NSk; ++s)
                 if (is_max_slot(s)) {
-                    const double r = wave_max(acc[s]);
-                    if (lane == 0) red[wv][s] = r;
+                    const bool above = __builtin_amdgcn_ballot_w64(acc[s] > kGradientTol) != 0;  // (wave-uniform)
+                    if (lane == 0) red[wv][s] = above ? 1.0 : 0.0;
                 }
             double* Tw = s_T[wv];
             {

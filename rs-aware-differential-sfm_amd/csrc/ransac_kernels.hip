@@ -597,10 +597,23 @@ __device__ __forceinline__ void reduce_score_rows(const double* __restrict__ par
     __shared__ double s_grp[G][2];
     const int tid = threadIdx.x;
     if (tid < G) {
+        // (16 independent 16-byte loads in flight, then the ordered additions: the loop is bound by load latency, like reduce_hyp_sums)
+        constexpr int U = 16;
+        const double2* __restrict__ p2 = reinterpret_cast<const double2*>(partials);
         double c = 0.0, e = 0.0;
-        for (int b = tid; b < nblocks; b += G) {
-            c += partials[((int64_t)b * T + t) * 2 + 0];
-            e += partials[((int64_t)b * T + t) * 2 + 1];
+        for (int b = tid; b < nblocks; b += U * G) {
+            double2 v[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int bj = b + j * G;
+                const double2 x = p2[(int64_t)(bj < nblocks ? bj : tid) * T + t];
+                v[j] = bj < nblocks ? x : make_double2(0.0, 0.0);  // (rows past the end add +0.0 to a non-negative sum: the identity)
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                c += v[j].x;
+                e += v[j].y;
+            }
         }
         s_grp[tid][0] = c;
         s_grp[tid][1] = e;

@@ -36,6 +36,10 @@ class ThreadTransport:
                     dst = recv + r * nbytes
                     if dst != self.slots[r]:
                         assert hip.hipMemcpy(dst, self.slots[r], nbytes, _D2D) == 0
+                # a device-to-device hipMemcpy may return before the copy has finished, and the contexts' streams do not wait for the null
+                # stream: without this the kernels a rank enqueues next could read `recv` too early (seen once as one rank's refinement
+                # summary differing from the others')
+                assert hip.hipDeviceSynchronize() == 0
                 self.barrier.wait()  # nobody reuses its send buffer before all have read it
                 return 0
             except Exception:  # a broken barrier / failed copy must surface as an error code, not as a hang

@@ -159,12 +159,12 @@ __device__ __forceinline__ void block_reduce_store(const double (&v)[NV], int ma
 // g, g + G, g + 2G, ... of its two slots in order (adjacent lanes read adjacent 16-byte pieces of a row: coalesced, 16 loads in
 // flight), then thread s adds the G group sums of slot s in order.  (The first version gave every thread whole rows and reduced the NV per-thread sums with NV / 8 rounds of
 // LDS transposes: 7 us of the 10 us refine_solve_kernel, measured by returning right after the reduction.)
-template <int NV, int THREADS = kFB>
+template <int NV>
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int nblocks, int max_slot,
                                                 double (*s_red)[NV], double* s_out) {
     constexpr int W = (NV % 2 == 0) ? 2 : 1;  // slots per lane: pairs as double2 when the rows are 16-byte aligned (NV even)
     constexpr int NH = NV / W;                // lanes per row
-    constexpr int G = THREADS / NH;           // row groups (9 for the 54 Schur sums of NP = 6 with 256 threads, 37 with 1024)
+    constexpr int G = kFB / NH;               // row groups (9 for the 54 Schur sums of NP = 6)
     constexpr int U = 16;                     // independent loads in flight per thread: the reduction is bound by load latency
     __shared__ double s_grp[G][NV];
     const int tid = threadIdx.x;
@@ -369,12 +369,9 @@ __global__ __launch_bounds__(kFB) void refine_schur_kernel(int64_t m, const doub
     block_reduce_store<CT::NSCHUR>(acc, -1, s_red, partials + (int64_t)blockIdx.x * CT::NSCHUR);
 }
 
-// reduced system + Cholesky (one workgroup; the solve itself runs on one lane: NP <= 7).  1024 threads: the 512 rows of 54 / 70 Schur sums
-// are then ONE batch of 16 loads per thread instead of four (the reduction is bound by load latency).
-// (512 with k among the parameters: the 7 x 7 system's registers do not fit the 128 a thread of a 1024-thread workgroup may have)
-constexpr int solve_threads(int np) { return np == 6 ? 1024 : 512; }
+// reduced system + Cholesky (one workgroup; the solve itself runs on one lane: NP <= 7)
 template <int NP>
-__global__ __launch_bounds__(solve_threads(NP)) void refine_solve_kernel(const double* __restrict__ partials, int nblocks,
+__global__ __launch_bounds__(kFB) void refine_solve_kernel(const double* __restrict__ partials, int nblocks,
                                                           RefineState* st) {
     using CT = Counts<NP>;
     __shared__ double s_red[kFB / 64][CT::NSCHUR];
@@ -398,7 +395,7 @@ __global__ __launch_bounds__(solve_threads(NP)) void refine_solve_kernel(const d
 #pragma unroll
         for (int c = 0; c < NP; ++c) sp_cur[c] = st->sp[c];
     }
-    reduce_partials<CT::NSCHUR, solve_threads(NP)>(partials, nblocks >= 0 ? nblocks : st->grid, -1, s_red, s);
+    reduce_partials<CT::NSCHUR>(partials, nblocks >= 0 ? nblocks : st->grid, -1, s_red, s);
     if (threadIdx.x == 0) {
         st->iteration += 1;
         const double inv_radius = 1.0 / radius;
@@ -749,7 +746,7 @@ static int refine_iter_t(Ctx* c, const RefineBuffers& B) {
     hipLaunchKernelGGL(refine_schur_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, m_arg, reinterpret_cast<const double4*>(B.uu), B.beta,
                        B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(refine_solve_kernel<NP>, dim3(1), dim3(solve_threads(NP)), 0, c->stream, B.partials, nb_arg, B.state);
+    hipLaunchKernelGGL(refine_solve_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, nb_arg, B.state);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(refine_backsub_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, m_arg, reinterpret_cast<const double4*>(B.uu), B.beta,
                        B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
@@ -801,7 +798,7 @@ static int refine_stage_apply_t(Ctx* c, const RefineBuffers& B, int stage, const
     if (stage == 0)
         hipLaunchKernelGGL(refine_init_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state, m_total);
     else if (stage == 1)
-        hipLaunchKernelGGL(refine_solve_kernel<NP>, dim3(1), dim3(solve_threads(NP)), 0, c->stream, rows_all, nranks, B.state);
+        hipLaunchKernelGGL(refine_solve_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state);
     else
         hipLaunchKernelGGL(refine_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state, c->d_refine_trace, c->refine_trace_rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());

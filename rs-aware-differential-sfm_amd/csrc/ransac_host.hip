@@ -168,7 +168,7 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                 if (round > 4 * kMaxIter) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machines did not terminate");
                 rc = ransac_lm_round_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_hyp + (size_t)b0 * 8, B, R.d_states + b0, R.d_partials, R.d_flags,
                                             R.d_scored + b0, R.d_tcount + b0, R.d_terr + b0, round, tol, R.k0, R.fused_base, R.core_math,
-                                            R.core_epoch ? c->d_core_flag : nullptr, R.core_epoch);
+                                            R.core_epoch ? c->d_core_flag : nullptr, R.core_epoch, R.d_unscored);
                 if (rc != RSDSFM_OK) return rc;
                 if (round == 0 && B == T) {
                     // one batch, and on typical data every hypothesis is decided and scored by round 0: the final stage
@@ -180,7 +180,7 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                     // round trip plus a discarded final stage (~57 us).  What is enqueued when never changes a result.
                     if (c->ransac_score_idle < kScoreIdleLimit) {
                         rc = ransac_score_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_hyp, T, R.d_states, depth_mode, tol, R.d_scored, R.d_partials,
-                                                 R.d_tcount, R.d_terr);
+                                                 R.d_tcount, R.d_terr, R.d_unscored, R.d_flags + 1);
                         if (rc != RSDSFM_OK) return rc;
                         R.spec_scored = true;
                     }
@@ -250,7 +250,7 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                 if (R.need_score) {
                     rc = ransac_score_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_hyp + (size_t)R.b0 * 8, R.B, R.d_states + R.b0, depth_mode, tol,
                                              depth_mode == RSDSFM_DEPTH_CERES_LM ? R.d_scored + R.b0 : nullptr, R.d_partials, R.d_tcount + R.b0,
-                                             R.d_terr + R.b0);
+                                             R.d_terr + R.b0, depth_mode == RSDSFM_DEPTH_CERES_LM ? R.d_unscored : nullptr, R.d_flags + 1);
                     if (rc != RSDSFM_OK) return rc;
                 }
                 R.b0 += batch;
@@ -358,7 +358,7 @@ int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a
     const int batch = std::min(Tn, kRansacBatch);
     size_t need = Arena::need(sizeof(double) * Tn * 8) +
                   Arena::need(sizeof(LmState) * Tn) + Arena::need(sizeof(double) * (size_t)ransac_lm_partials_doubles(c, n, batch)) +
-                  Arena::need(sizeof(int) * 8) + Arena::need(sizeof(int) * Tn) + 2 * Arena::need(sizeof(double) * Tn) + Arena::need(sizeof(RansacBest)) +
+                  Arena::need(sizeof(int) * 8) + 2 * Arena::need(sizeof(int) * Tn) + 2 * Arena::need(sizeof(double) * Tn) + Arena::need(sizeof(RansacBest)) +
                   2 * Arena::need(sizeof(int64_t) * 2048) + Arena::need(sizeof(double) * (size_t)n) + Arena::need((size_t)n) + 4096;
     int rc = ensure_ws(c, need);
     if (rc != RSDSFM_OK) return rc;
@@ -370,6 +370,7 @@ int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a
     R.d_scored = ws.take<int>(Tn);
     R.d_flags = ws.take<int>(8);  // {running, unscored, not finished with <= 1 accepted step, -, ended after 0 / 1 / 2 / >= 3 accepted steps}
     R.zero_bytes = (size_t)((ws.base + ws.off) - R.zero_begin);
+    R.d_unscored = ws.take<int>(batch);
     R.d_partials = ws.take<double>((size_t)ransac_lm_partials_doubles(c, n, batch));
     R.d_tcount = ws.take<double>(Tn);
     R.d_terr = ws.take<double>(Tn);

@@ -399,7 +399,8 @@ __global__ __launch_bounds__(256) void ransac_lm_rows_kernel(const double* __res
 __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __restrict__ partials, int nblocks, int T, int hyp_major,
                                                            LmState* states, int64_t n, int round, int k0, int* flags, int* pred_flag,
                                                            int* __restrict__ scored, double* __restrict__ trial_count,
-                                                           double* __restrict__ trial_err, int fused_base, int* steps_hist) {
+                                                           double* __restrict__ trial_err, int fused_base, int* steps_hist,
+                                                           int* __restrict__ unscored_list) {
     __shared__ double s_red[4][NSR];
     __shared__ double s_sums[NSR];
     const int t = blockIdx.x;
@@ -421,7 +422,11 @@ __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __rest
             trial_err[t] = s_sums[NS + 1];
             scored[t] = 1;
         } else {
-            atomicAdd(&flags[1], 1);
+            // finished where round 0 did not fuse the score: counted, and (where the caller keeps a list) appended for the scoring pass,
+            // which then only looks at these (the order of the entries is the order of arrival: it decides which workgroup scores which
+            // hypothesis, not what the sums are)
+            const int pos = atomicAdd(&flags[1], 1);
+            if (unscored_list) unscored_list[pos] = t;
         }
         *static_cast<LmScal*>(state) = st;
     }
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __rest
                                                           const double* __restrict__ hyp, int T,
                                                           const LmState* __restrict__ states, int depth_mode, double tol,
                                                           const int* __restrict__ scored, double* __restrict__ partials, int ntile_blocks,
-                                                          int ngroups) {
+                                                          int ngroups, const int* __restrict__ list, const int* __restrict__ list_count) {
     extern __shared__ double s_acc[];  // [T][2]
     __shared__ LmPlanLds plan;
     __shared__ double s_red[2][kRB / 64][2];
@@ -507,12 +512,25 @@ __global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __rest
     int tb, grp;
     tile_group_of_block((int)blockIdx.x, ntile_blocks, ngroups, tb, grp);
     if (tb >= ntile_blocks) return;
-    const int per_group = (T + ngroups - 1) / ngroups;
-    const int t_begin = grp * per_group, t_end = min(T, t_begin + per_group);
-    if (scored) {  // nothing to score in this group (the usual case when round 0 fused the right state): leave before touching a tile
-        bool any = false;
-        for (int t = t_begin; t < t_end; ++t) any = any || !scored[t];
-        if (!any) return;
+    // The hypotheses of this workgroup: a slice of the hypothesis range (and of those the ones not scored yet), or -- with `list`, the
+    // indices ransac_decide_kernel appended for the hypotheses that finished without a fused score, *list_count of them -- a slice of
+    // that list: the few hypotheses left over by round 0 (~2 of 50 on DeepFlow-like data) then share their tiles in ONE group of
+    // workgroups instead of one group each, and the other groups leave before touching a tile.  Which workgroup scores a hypothesis
+    // never changes its sums (per hypothesis: lanes, waves, tile blocks in order).
+    int t_begin, t_end;
+    if (list) {
+        const int U = min(*list_count, T);
+        const int per = max(2, (U + ngroups - 1) / ngroups);
+        t_begin = grp * per, t_end = min(U, t_begin + per);  // (positions in the list)
+        if (t_begin >= t_end) return;
+    } else {
+        const int per_group = (T + ngroups - 1) / ngroups;
+        t_begin = grp * per_group, t_end = min(T, t_begin + per_group);
+        if (scored) {  // nothing to score in this group (the usual case when round 0 fused the right state): leave before touching a tile
+            bool any = false;
+            for (int t = t_begin; t < t_end; ++t) any = any || !scored[t];
+            if (!any) return;
+        }
     }
     for (int i = tid; i < T * 2; i += kRB) s_acc[i] = 0.0;
     __syncthreads();
@@ -522,8 +540,10 @@ __global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __rest
         Tile px;
         load_tile(px, q, u, alpha, alpha_k, tile * tile_pixels, n);
         const bool full_tile = (tile + 1) * tile_pixels <= n;
-        for (int t = t_begin; t < t_end; ++t) {
-            if (scored && scored[t]) continue;  // already scored by the fused LM pass (uniform branch)
+        int done = 0;  // hypotheses this workgroup has scored on this tile (selects the reduction's double buffer)
+        for (int ti = t_begin; ti < t_end; ++ti) {
+            const int t = list ? list[ti] : ti;
+            if (!list && scored && scored[t]) continue;  // already scored by the fused LM pass (uniform branch)
             RSDSFM_LOAD_POSE(pose, hyp, t)
             const double two_over = 2.0 / (2.0 + pose.k);
             double cnt = 0.0, es = 0.0;
@@ -556,7 +576,8 @@ __global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __rest
                     }
                 }
             }
-            double(*red)[2] = s_red[t & 1];
+            double(*red)[2] = s_red[done & 1];
+            ++done;
             // the wave's two sums in the order ransac_lm_kernel adds its fused scores (transposed through LDS: each half of the wave
             // in lane order, then the halves) -- the inlier-error sum of a hypothesis has the same bits whichever kernel forms it
             {
@@ -587,7 +608,14 @@ __global__ __launch_bounds__(kRB) void ransac_score_kernel(const double2* __rest
     }
     __syncthreads();
     double* out = partials + (int64_t)tb * T * 2;
-    for (int i = t_begin * 2 + tid; i < t_end * 2; i += kRB) out[i] = s_acc[i];
+    if (list) {
+        for (int i = t_begin * 2 + tid; i < t_end * 2; i += kRB) {
+            const int t = list[i >> 1];
+            out[t * 2 + (i & 1)] = s_acc[t * 2 + (i & 1)];
+        }
+    } else {
+        for (int i = t_begin * 2 + tid; i < t_end * 2; i += kRB) out[i] = s_acc[i];
+    }
 }
 
 // the two score sums of hypothesis t over the tile blocks in the order reduce_hyp_sums (ransac_decide_kernel) adds a slot of the
@@ -966,7 +994,7 @@ static int lm_launch(Ctx* c, const dim3& g2, int k0, const double* q, const doub
 int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                            const double* hyp, int T, LmState* states, double* partials, int* flags, int* scored,
                            double* trial_count, double* trial_err, int round, double tol, int k0, int fused_base, bool core_math,
-                           const int* m9_core_flag, int m9_core_epoch) {
+                           const int* m9_core_flag, int m9_core_epoch, int* unscored_list) {
     const int grid = ransac_pixel_grid(c, n);
     const dim3 g2(grid, ransac_lm_groups(c, grid, T));
     if (k0 != 2) k0 = KMAX;
@@ -980,7 +1008,7 @@ int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const doubl
         c->prof_pending = true;
     }
     hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, 1, states, n, round, k0, flags, flags + 2, scored,
-                       trial_count, trial_err, fused_base, flags + 4);
+                       trial_count, trial_err, fused_base, flags + 4, unscored_list);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
@@ -988,12 +1016,12 @@ int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const doubl
 // scores the hypotheses of the batch [0, T) that are not yet scored; trial_count / trial_err point at the batch's slots
 int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
-                        double* partials, double* trial_count, double* trial_err) {
+                        double* partials, double* trial_count, double* trial_err, const int* unscored_list, const int* unscored_count) {
     const int grid = ransac_pixel_grid(c, n);
     const int groups = ransac_lm_groups(c, grid, T);
     hipLaunchKernelGGL(ransac_score_kernel, dim3(((grid + 7) / 8) * 8 * groups), dim3(kRB), sizeof(double) * T * 2, c->stream,
                        reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states,
-                       depth_mode, tol, scored, partials, grid, groups);
+                       depth_mode, tol, scored, partials, grid, groups, unscored_list, unscored_list ? unscored_count : nullptr);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(ransac_reduce_scores_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, scored, trial_count,
                        trial_err);
@@ -1017,7 +1045,8 @@ int ransac_decide_rows_launch(Ctx* c, const double* rows_all, int nranks, int T,
                               int* flags, int* scored, double* trial_count, double* trial_err) {
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(flags, 0, sizeof(int), c->stream));
     hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, rows_all, nranks, T, 0, states, n_total, round, (int)KMAX, flags,
-                       static_cast<int*>(nullptr), scored, trial_count, trial_err, kTiledFusedBase, static_cast<int*>(nullptr));
+                       static_cast<int*>(nullptr), scored, trial_count, trial_err, kTiledFusedBase, static_cast<int*>(nullptr),
+                       static_cast<int*>(nullptr));
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
@@ -1029,7 +1058,7 @@ int ransac_score_rows_launch(Ctx* c, const double* q, const double* u, const dou
     const int groups = ransac_lm_groups(c, grid, T);
     hipLaunchKernelGGL(ransac_score_kernel, dim3(((grid + 7) / 8) * 8 * groups), dim3(kRB), sizeof(double) * T * 2, c->stream,
                        reinterpret_cast<const double2*>(q), reinterpret_cast<const double2*>(u), a, ak, n, hyp, T, states,
-                       depth_mode, tol, scored, partials, grid, groups);
+                       depth_mode, tol, scored, partials, grid, groups, static_cast<const int*>(nullptr), static_cast<const int*>(nullptr));
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(ransac_score_rows_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, scored, rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());

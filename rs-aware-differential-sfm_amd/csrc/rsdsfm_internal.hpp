@@ -299,10 +299,10 @@ int ransac_lm_partials_doubles(const Ctx* c, int64_t n, int batch);
 int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                            const double* hyp, int T, LmState* states, double* partials, int* flags, int* scored,
                            double* trial_count, double* trial_err, int round, double tol, int k0, int fused_base, bool core_math,
-                           const int* m9_core_flag = nullptr, int m9_core_epoch = 0);
+                           const int* m9_core_flag = nullptr, int m9_core_epoch = 0, int* unscored_list = nullptr);
 int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
-                        double* partials, double* trial_count, double* trial_err);
+                        double* partials, double* trial_count, double* trial_err, const int* unscored_list = nullptr, const int* unscored_count = nullptr);
 int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best,
                        RansacBest* best_host = nullptr, const int* d_flags = nullptr, int* h_flags = nullptr, int scored_ahead = 0);
 int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
@@ -370,6 +370,7 @@ struct RansacRun {
     const RansacSpecTail* spec_tail = nullptr;
     bool* spec_tail_held = nullptr;
     int core_epoch = 0;      // the minimal solver's launch epoch of this run (0: it ran without the cores)
+    int* d_unscored = nullptr;  // [batch] indices (within the batch) of the hypotheses that finished without a fused score, in order of arrival; their number is d_flags[1]
     bool core_math = true;   // round 0 through the in-range function cores (ransac_lm_kernel CORE); false after a restart
     bool restarted = false;
     bool tail_ahead = true;  // enqueue the caller's tail behind the SPECULATED final stage (otherwise only behind the definitive one)

@@ -263,6 +263,11 @@ __device__ __forceinline__ double dpp_move(double v) {
     hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
     return __hiloint2double(hi, lo);
 }
+// the value lane `l` (wave-uniform) holds in v
+__device__ __forceinline__ double lane_value(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double lane63(double v) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);

@@ -711,7 +711,7 @@ __device__ __forceinline__ void pick_best_trial(const double* __restrict__ trial
         const double cl = t < T ? trial_count[t] : 0.0, el = t < T ? trial_err[t] : 0.0;
         const int nt = T - t0 < 64 ? T - t0 : 64;
         for (int j = 0; j < nt; ++j) {
-            const double c = __shfl(cl, j, 64), e = __shfl(el, j, 64);
+            const double c = lane_value(cl, j), e = lane_value(el, j);  // (v_readlane: j is uniform; __shfl went through four ds_bpermute per trial)
             if (c > best_count || (c == best_count && e < best_err)) {
                 best_count = c;
                 best_err = e;

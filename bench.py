@@ -34,6 +34,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -919,21 +920,42 @@ def run(args):
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(line), flush=True)
+        _emit_line(line)
     solver.close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def _watchdog(seconds, rank, line, key):
-    """threading.Timer that ends the process if a section hangs: rank 0 first prints the JSON line it has, with line[key] = the error"""
-    import threading
+_EMIT_LOCK = threading.Lock()
+_EMITTED = [False]
+WATCHDOG_EXIT_CODE = 3
 
+
+def _emit_line(line):
+    """prints THE JSON line of this process exactly once (the main thread at the end of run(), or a watchdog that fired first)"""
+    with _EMIT_LOCK:
+        if _EMITTED[0]:
+            return False
+        _EMITTED[0] = True
+        print(json.dumps(line), flush=True)
+        return True
+
+
+def _watchdog(seconds, rank, line, key):
+    """threading.Timer that ends the process if a section hangs: rank 0 first prints the JSON line it has, with line[key] = the error,
+    then EVERY rank exits with WATCHDOG_EXIT_CODE -- a hung section is a failed run for the launcher and the harness, while the line
+    (whose headline was measured before the guarded section) is still relayed: launch_ranks prints rank 0's line whatever the exit
+    codes.  The timer thread works on a COPY of the line taken under the emit lock, so it never prints a dict the main thread is
+    updating, and exactly one line leaves the process."""
     def fire():
         if rank == 0:
-            line[key] = {"error": "no result within %.0f s (watchdog)" % seconds}
-            print(json.dumps(line), flush=True)
-        os._exit(0)  # (every rank: the line carries the error; a non-zero code would make a launcher discard the headline with it)
+            with _EMIT_LOCK:
+                if not _EMITTED[0]:
+                    _EMITTED[0] = True
+                    snap = dict(line)
+                    snap[key] = {"error": "no result within %.0f s (watchdog); the process exits with code %d" % (seconds, WATCHDOG_EXIT_CODE)}
+                    print(json.dumps(snap, default=repr), flush=True)
+        os._exit(WATCHDOG_EXIT_CODE)
 
     t = threading.Timer(seconds, fire)
     t.daemon = True

@@ -4,7 +4,12 @@ host by NCCL_HOSTID when that is set: giving every rank its own makes RCCL treat
 through its socket transport over the loopback interface.  That is not xGMI -- it proves nothing about bandwidth -- but it runs the
 multi-rank code path for real: ncclCommInitRank with 2 ranks from the broadcast unique id, in-place ncclAllGather (ncclChar) and
 ncclAllReduce on the context's stream, a second communicator next to torch's, and the driver's rank-ordered protocol on top.
-The unique id travels over a gloo group.  Environment per rank (set by the test): NCCL_HOSTID, NCCL_SOCKET_IFNAME=lo, NCCL_IB_DISABLE=1."""
+The unique id travels over a gloo group.  Environment per rank (set by the test): NCCL_HOSTID, NCCL_SOCKET_IFNAME=lo, NCCL_IB_DISABLE=1.
+
+RSDSFM_TEST_FRAME_NPY = a (rows, cols, 2) flow image saved by the test (BASELINE configs[3], 3840x2160): the ranks solve THAT frame
+(RSDSFM_TEST_FRAME_META: json with K, gamma, trials, tol, seed) instead of the small one, every rank loading only its column slab,
+and write what the test compares with the oracle chain: pose, counts, refinement summary, the gathered depth map (rank 0) and every
+inlier's scanline index (one file per rank, concatenated in rank order by the test)."""
 import json
 import os
 import sys
@@ -28,7 +33,15 @@ def main():
     dist.init_process_group("gloo")
     dev = torch.device("cuda", 0)
     flow_mode = int(os.environ.get("RSDSFM_TEST_FLOW_MODE", "0"))
-    d = rsdsfm.synth.make_config(3, rows=96, cols=250)
+    big = os.environ.get("RSDSFM_TEST_FRAME_NPY")
+    if big:
+        meta = json.loads(os.environ["RSDSFM_TEST_FRAME_META"])
+        flow_img = np.load(big, mmap_mode="r")
+        d = dict(flow_img=flow_img, rows=flow_img.shape[0], cols=flow_img.shape[1], K=tuple(meta["K"]), gamma=meta["gamma"])
+        skw = dict(trials=meta["trials"], tol=meta["tol"], seed=meta["seed"])
+    else:
+        d = rsdsfm.synth.make_config(3, rows=96, cols=250)
+        skw = dict(trials=14, tol=0.002, seed=7)
     rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
     c0, sc, per = rsdsfm.tiled_slab_bounds(cols, world, rank)
     solver = rsdsfm.Solver(0)
@@ -46,16 +59,29 @@ def main():
         slab = torch.from_numpy(np.ascontiguousarray(d["flow_img"][:, c0:c0 + sc, :])).to(dev)  # each rank only holds its slab
         dm = torch.zeros(cols * rows, dtype=torch.float64, device=dev)
         for rep in range(2):  # the communicator is reused across solves
-            r = solver.solve_frame_tiled_dev(slab.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=14, tol=0.002, seed=7, flow_index_mode=flow_mode)
+            r = solver.solve_frame_tiled_dev(slab.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), flow_index_mode=flow_mode, **skw)
         torch.cuda.synchronize()
         dmh = dm.cpu().numpy()
+        if big:  # what the full-size test compares with the oracle chain
+            import ctypes
+
+            hip = ctypes.CDLL("libamdhip64.so")
+            m = r["info"]["shard_inliers"]
+            ys = torch.empty(max(m, 1), dtype=torch.int32, device=dev)
+            if m:
+                assert hip.hipMemcpy(ctypes.c_void_p(ys.data_ptr()), ctypes.c_void_p(r["d_scanline"]), ctypes.c_size_t(4 * m), 3) == 0
+            base = os.environ["RSDSFM_TILED_OUT"]
+            np.save(base + ".ys%d.npy" % rank, ys.cpu().numpy()[:m])
+            if rank == 0:
+                np.save(base + ".depth.npy", dmh)
         mine = np.concatenate([r["v"], r["w"], [r["k"], r["num_inliers"], r["best_trial"], float((dmh != 0).sum()), dmh.sum()]])
         t = torch.from_numpy(mine).clone()
         outs = [torch.empty_like(t) for _ in range(world)]
         dist.all_gather(outs, t)
         out.update(n=r["n"], num_inliers=r["num_inliers"], best_trial=r["best_trial"], v=list(r["v"]), w=list(r["w"]), k=r["k"],
                    depth_nonzero=int((dmh != 0).sum()), depth_sum=float(dmh.sum()), ranks_agree=bool(all(torch.equal(o, outs[0]) for o in outs)), info=r["info"],
-                   iterations=r["refine_summary"]["num_iterations"])
+                   iterations=r["refine_summary"]["num_iterations"], refine_summary=r["refine_summary"], flipped=bool(r["flipped"]))
+    if out["init"] == "ok" and not big:
         # the row-tiled dense depth solve over the same communicator
         t_ = d["truth"]
         v = t_["v"] / np.linalg.norm(t_["v"])
@@ -67,6 +93,7 @@ def main():
         sm, info = solver.estimate_inverse_depths_tiled_dev(q.data_ptr(), u.data_ptr(), n, v, t_["w"], 0.0, a.data_ptr(), ak.data_ptr(), full.data_ptr())
         torch.cuda.synchronize()
         out.update(depth_sum_tiled=float(full[:n].sum().item()), depth_lm=sm, depth_info=info)
+    if out["init"] == "ok":
         solver.dist_finalize()
     if rank == 0:
         with open(os.environ["RSDSFM_TILED_OUT"], "w") as f:

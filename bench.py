@@ -671,9 +671,17 @@ def run(args):
                                                 "10 %% outliers): flatten + alpha, RANSAC(%d trials, tol %g) = 9-point minimal solver + Ceres-LM depth solve of all pixels per "
                                                 "trial + scoring, joint nonlinear refinement, sign fix + depth map, pose table; ONE C-ABI call per pair, one pair at a time, "
                                                 "one pair per GPU (N ranks = N independent replicas, no data-path collective)" % (args.trials, args.tol),
-                                    **{k2: full[k2] for k2 in ("rows", "cols", "trials", "tol", "n", "num_inliers", "refine_summary", "w_err", "v_angle_deg")}},
+                                    "pairs": "the timed steps rotate over %d different pairs (data seeds) and a new sampler seed per step" % full["data_seeds"],
+                                    **{k2: full[k2] for k2 in ("rows", "cols", "trials", "tol", "n", "num_inliers", "data_seeds", "num_inliers_min_max",
+                                                               "refine_iterations_min_max", "distinct_winners", "refine_summary", "w_err", "v_angle_deg")}},
                          "roofline": roof, "full_solve_batched": batched, "full_solve_8_threads": threads8, "full_solve_fused": fused, "regimes": regimes, "depth_only": depth_only,
                          "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_full(rsdsfm, np, rank, args.trials, args.tol)})
+            # the regimes the headline does not exercise, lifted to the top level of the line: `value_selective` = the same one-call solve
+            # at the selective tolerance 0.002 (M < N: compaction and the rank-indexed flow are NOT the identity), `value_sequence` =
+            # BASELINE configs[4] (32 pairs / 32 data seeds through rsdsfm_solve_frames_dev), both in the line's unit
+            line["ransac_restarts"] = solver.ransac_restarts()  # solves of this context that started over with the standard functions (0 on real-valued data)
+            line["value_selective"] = regimes["selective_tol_0.002"]["value"] if regimes else None
+            line["value_sequence"] = batched["value"] * world if batched else None
             if line["cpu_baseline"] and side:  # the single-thread figure "plus an all-cores variant"
                 line["cpu_baseline"]["all_cores"] = cpu_baseline_full_all_cores(rsdsfm, np, rank, args.trials, args.tol, line["cpu_baseline"])
             if line["cpu_baseline"] and side:  # the reference-STRUCTURED single-thread variant
@@ -1111,40 +1119,46 @@ def _plain_timed(torch, step, steps, warmup):
     return time.perf_counter() - t0
 
 
-def _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps, warmup, timed):
-    """whole solve on a 1280x720 DeepFlow-like pair (0.3 px noise, 10 % outliers), flow image resident in HBM; the sampler seed
-    changes every step (different hypotheses, different winner)"""
-    d = rsdsfm.synth.make_config(5, seed=0x5EED0005 + rank)
-    rows, cols = d["rows"], d["cols"]
-    imgs = [torch.from_numpy(d["flow_img"]).to(dev) for _ in range(3)]
+def _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps, warmup, timed, data_seeds=4):
+    """whole solve on 1280x720 DeepFlow-like pairs (0.3 px noise, 10 % outliers), flow images resident in HBM.  The timed steps rotate
+    over `data_seeds` DIFFERENT pairs (one noise / outlier realisation each: other hypotheses, another winner, another refinement
+    length per step) and the sampler seed changes every step as well; the per-pair results of the timed steps are kept for the record."""
+    seeds = [0x5EED0005 + rank + 7919 * j for j in range(data_seeds)]
+    flows, meta = rsdsfm.synth.make_flow_sequence(5, seeds)
+    rows, cols, K, gamma = meta["rows"], meta["cols"], meta["K"], meta["gamma"]
+    imgs = [torch.from_numpy(f).to(dev) for f in flows]
     depth_map = torch.empty((cols, rows), dtype=torch.float64, device=dev)  # column-major rows x cols
     R, tt = torch.empty((rows, 9), dtype=torch.float64, device=dev), torch.empty((rows, 3), dtype=torch.float64, device=dev)
-    out = {}
-    per_step = []
+    per_step, seen = [], []
 
     # ONE C-ABI call per frame pair (rsdsfm_solve_frame_dev) with pre-marshalled arguments; it returns after its last result has
     # reached the host
-    calls = [solver.prepared_frame_solve(im.data_ptr(), rows, cols, d["K"], d["gamma"], depth_map.data_ptr(), R.data_ptr(), tt.data_ptr(),
+    calls = [solver.prepared_frame_solve(im.data_ptr(), rows, cols, K, gamma, depth_map.data_ptr(), R.data_ptr(), tt.data_ptr(),
                                          trials=args.trials, tol=args.tol) for im in imgs]
     clock = time.perf_counter
+    nd = len(calls)
 
     def step(i):
         t0 = clock()
-        calls[i % 3](1 + i)
+        r_ = calls[i % nd](1 + i)
         per_step.append(clock() - t0)
+        seen.append((int(r_.num_inliers), int(r_.refine_summary.num_iterations), int(r_.best_trial)))  # (after the clock: not in the step's own time)
 
     el = timed(step, steps, warmup)
     # the last timed solve once more through the dict-building wrapper (same seed: same result), for the record
-    r = solver.solve_frame_dev(imgs[(steps - 1) % 3].data_ptr(), rows, cols, d["K"], d["gamma"], depth_map.data_ptr(), R.data_ptr(),
+    r = solver.solve_frame_dev(imgs[(steps - 1) % nd].data_ptr(), rows, cols, K, gamma, depth_map.data_ptr(), R.data_ptr(),
                                tt.data_ptr(), trials=args.trials, tol=args.tol, seed=steps)
-    t = d["truth"]
+    t = meta["truth"]
     vt = t["v"] / np.linalg.norm(t["v"])
     vv = r["v"] / np.linalg.norm(r["v"])
     ts = sorted(per_step[-steps:])
-    return {"value": d["rows"] * d["cols"] * steps / el / 1e6, "unit": "Mpixels/s", "ms_per_solve": el / steps * 1e3,
+    seen = seen[-steps:]
+    return {"value": rows * cols * steps / el / 1e6, "unit": "Mpixels/s", "ms_per_solve": el / steps * 1e3,
             "median_ms_per_solve": ts[len(ts) // 2] * 1e3, "min_ms_per_solve": ts[0] * 1e3,
-            "rows": d["rows"], "cols": d["cols"], "trials": args.trials, "tol": args.tol, "n": r["n"], "num_inliers": r["num_inliers"],
-            "refine_summary": r["refine_summary"], "K": d["K"], "gamma": d["gamma"], "_img": imgs[0],
+            "rows": rows, "cols": cols, "trials": args.trials, "tol": args.tol, "n": r["n"], "num_inliers": r["num_inliers"],
+            "data_seeds": nd, "num_inliers_min_max": [min(x[0] for x in seen), max(x[0] for x in seen)],
+            "refine_iterations_min_max": [min(x[1] for x in seen), max(x[1] for x in seen)], "distinct_winners": len({x[2] for x in seen}),
+            "refine_summary": r["refine_summary"], "K": K, "gamma": gamma, "_img": imgs[0],
             "w_err": float(np.linalg.norm(r["w"] - t["w"])), "v_angle_deg": float(np.degrees(np.arccos(min(1.0, abs(float(vv @ vt)))))),
             "stages": "flatten+alpha, minimal9 x %d, RANSAC LM sums/decide/score/pick/compaction, refinement, depth map, pose table" % args.trials}
 

@@ -375,7 +375,11 @@ size_t rsdsfm_tile_lm_state_bytes(void);   /* bytes of one per-hypothesis LM sta
 size_t rsdsfm_tile_best_bytes(void);       /* bytes of the device-resident winner record                             */
 int32_t rsdsfm_tile_ransac_row_size(void); /* doubles per hypothesis in an LM sums row                               */
 int32_t rsdsfm_tile_ransac_batch(void);    /* max hypotheses per *_rows_dev call (128)                               */
-/* round r of the speculative LM depth solves of hypotheses [0, count): shard sums -> d_rows[count][row_size] */
+/* round r of the speculative LM depth solves of hypotheses [0, count): shard sums -> d_rows[count][row_size].
+ * The rows are opaque to the caller except for how they combine across shards: the decide stage adds the SUM slots in rank order
+ * and takes the maximum of the four max|J r| slots.  Those four slots do not carry gradient norms: they hold 1.0 when some pixel
+ * of the shard is above Ceres' gradient tolerance (1e-10) and 0.0 otherwise -- the only thing the trust-region loop ever asks of
+ * them -- so a custom transport must all-gather (or max-reduce) them as they are and must not rescale them. */
 int rsdsfm_tile_ransac_lm_rows_dev(rsdsfm_ctx* ctx, const double* d_q2n, const double* d_u2n, const double* d_alpha_n,
                                    const double* d_alpha_k_n, int64_t n_shard, const double* d_hyp, int32_t count,
                                    const void* d_states, int32_t round, double tolerance, double* d_rows);

@@ -192,6 +192,17 @@ int ensure_dev(Ctx* c, void** p, size_t* have, size_t bytes) {
     return RSDSFM_OK;
 }
 
+// the first exchange's buffer ({point count, setup status} of every rank) exists before any solve: allocated where the communicator or
+// the transport is installed, so that no solve can fail on one rank before it has told the others
+int reserve_xchg(Ctx* c, Dist* D, int nranks) { return ensure_dev(c, &D->d_xchg, &D->xchg_bytes, Arena::need(16 * (size_t)nranks + 64)); }
+
+// the scheduling hints back to their defaults (what a solve that returned an error leaves behind: the ranks may have left at different
+// points, and a hint that differs between ranks would make the next solve enqueue different collectives on different ranks)
+void reset_hints(Dist* D) {
+    D->score_idle = kScoreIdleLimit;
+    D->refine_iters_hint = -1;
+}
+
 int sync(Ctx* c, Dist* D) {
     D->host_syncs += 1;
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
@@ -300,7 +311,8 @@ int rsdsfm_dist_init(rsdsfm_ctx* ctx, int32_t nranks, int32_t rank, const void* 
     D->rank = rank;
     D->ag = nullptr;
     D->ar = nullptr;
-    return RSDSFM_OK;
+    reset_hints(D);
+    return reserve_xchg(c, D, nranks);
 }
 
 int rsdsfm_dist_adopt(rsdsfm_ctx* ctx, void* nccl_comm, int32_t nranks, int32_t rank) {
@@ -319,7 +331,8 @@ int rsdsfm_dist_adopt(rsdsfm_ctx* ctx, void* nccl_comm, int32_t nranks, int32_t 
     D->rank = rank;
     D->ag = nullptr;
     D->ar = nullptr;
-    return RSDSFM_OK;
+    reset_hints(D);
+    return reserve_xchg(c, D, nranks);
 }
 
 int rsdsfm_dist_set_transport(rsdsfm_ctx* ctx, int32_t nranks, int32_t rank, rsdsfm_all_gather_fn all_gather_fn,
@@ -338,7 +351,8 @@ int rsdsfm_dist_set_transport(rsdsfm_ctx* ctx, int32_t nranks, int32_t rank, rsd
     D->ag = all_gather_fn;
     D->ar = all_reduce_fn;
     D->user = user;
-    return RSDSFM_OK;
+    reset_hints(D);
+    return reserve_xchg(c, D, nranks);
 }
 
 int rsdsfm_dist_finalize(rsdsfm_ctx* ctx) {
@@ -360,9 +374,24 @@ int rsdsfm_tiled_slab_bounds(int32_t cols, int32_t nranks, int32_t rank, int32_t
     return RSDSFM_OK;
 }
 
+static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int32_t rows, int32_t cols, double fx, double fy, double cx,
+                                  double cy, double gamma, const rsdsfm_frame_params* prm, double* d_depth_map, double* d_R_rows9,
+                                  double* d_t_rows3, rsdsfm_frame_result* res, rsdsfm_tiled_info* info);
+
 int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int32_t rows, int32_t cols, double fx, double fy, double cx,
                                  double cy, double gamma, const rsdsfm_frame_params* prm, double* d_depth_map, double* d_R_rows9,
                                  double* d_t_rows3, rsdsfm_frame_result* res, rsdsfm_tiled_info* info) {
+    const int rc = solve_frame_tiled_impl(ctx, d_img_slab, rows, cols, fx, fy, cx, cy, gamma, prm, d_depth_map, d_R_rows9, d_t_rows3, res, info);
+    if (rc != RSDSFM_OK && ctx) {  // an error return: the ranks may have left at different points -- no hint survives it
+        Dist* D = static_cast<Dist*>(ctx->c.dist);
+        if (D) reset_hints(D);
+    }
+    return rc;
+}
+
+static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int32_t rows, int32_t cols, double fx, double fy, double cx,
+                                  double cy, double gamma, const rsdsfm_frame_params* prm, double* d_depth_map, double* d_R_rows9,
+                                  double* d_t_rows3, rsdsfm_frame_result* res, rsdsfm_tiled_info* info) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
     DeviceGuard device_guard_(c);
@@ -395,8 +424,9 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
     // A failure that only THIS rank sees (an allocation, a null slab pointer) must not leave the other ranks waiting in the next
     // collective for ever: everything that can fail locally happens in this setup part, its outcome travels with the point counts in
     // the first exchange, and every rank leaves together (RSDSFM_ERR_PEER on the ranks that were fine).  The exchange buffer itself
-    // is allocated first and apart; buffers whose size depends on later results are sized by their upper bounds here.
-    int rc = ensure_dev(c, &D->d_xchg, &D->xchg_bytes, Arena::need(16 * (size_t)R + 64));
+    // exists since the communicator / transport was installed (reserve_xchg; a context that never had one is a single rank: nobody to
+    // strand); buffers whose size depends on later results are sized by their upper bounds here.
+    int rc = reserve_xchg(c, D, R);
     if (rc != RSDSFM_OK) return rc;
     int64_t* d_xchg = static_cast<int64_t*>(D->d_xchg);  // [R][2] = {point count, setup status}
     if (Ns > 0 && !d_img_slab) rc = fail(c, RSDSFM_ERR_INVALID, "null slab pointer");

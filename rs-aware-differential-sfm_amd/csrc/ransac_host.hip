@@ -217,6 +217,7 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                     R.not_one_step = 0;
                     R.final_done = R.spec_scored = R.tail_enqueued = R.spec_final = false;
                     R.dense = nullptr;  // (the flatten that rode in the minimal solver's launch has run)
+                    R.after_minimal9 = nullptr;  // (and so has a flatten the caller enqueued behind / beside the solver: q, u, alpha are valid)
                     R.pc = kPcStart;    // the hypotheses too: the minimal solver's SVD may have been the one (it clears the states again)
                     break;
                 }

@@ -26,6 +26,9 @@ constexpr double kMinLmDiag = 1e-6;
 constexpr double kMaxLmDiag = 1e32;
 constexpr double kFunctionTol = 1e-6;
 constexpr double kGradientTol = 1e-10;
+// (the max|J r| slots of the RANSAC's LM rows travel as the indicator "some pixel is above kGradientTol" -- 1.0 / 0.0, combined with
+// fmax and compared with `<= kGradientTol` downstream: ransac_kernels.hip; that encoding needs the tolerance below 1)
+static_assert(kGradientTol < 1.0, "the indicator encoding of the gradient-maximum slots needs kGradientTol < 1");
 constexpr double kParameterTol = 1e-8;
 constexpr int kMaxInvalid = 5;
 

@@ -1,0 +1,41 @@
+"""The pinning kit (tools/pin_reference) cannot meet the reference in this image; what CAN be checked here is its plumbing: the
+exporter, the .pin container, the importer's layout and every comparison of tests/test_reference_golden.py, run against a stand-in
+fixture built from the oracle (tools/pin_reference/selfcheck.py) -- on the CPU for the oracle's half, on the GPU for the HIP half."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SELFCHECK = os.path.join(ROOT, "tools", "pin_reference", "selfcheck.py")
+
+
+def _run(marker):
+    p = subprocess.run([sys.executable, SELFCHECK, "-m", marker], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0 and "plumbing ok" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "25 passed" in p.stdout, p.stdout[-1500:]  # 5 cases x (minimal solver, depth solve, RANSAC, 2 refinements): none skipped
+
+
+def test_pin_kit_plumbing_oracle_half():
+    _run("not gpu")
+
+
+@pytest.mark.gpu
+def test_pin_kit_plumbing_hip_half():
+    """the HIP path against the ORACLE's outputs in the reference fixture's layout: the parity the GPU suite asserts everywhere, through
+    the code that will meet the real fixture"""
+    _run("gpu")
+
+
+def test_pin_kit_inputs_export(tmp_path):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pin_reference", "export_inputs.py"), str(tmp_path)], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    sys.path.insert(0, os.path.join(ROOT, "tools", "pin_reference"))
+    import numpy as np
+    import pinio
+
+    g = np.load(os.path.join(ROOT, "tests", "golden", "golden_v1.npz"))
+    a = pinio.read(str(tmp_path / "deepflow_k0.pin"))
+    assert np.array_equal(a["q"], g["deepflow_k0/q"]) and np.array_equal(a["samples"], g["deepflow_k0/samples"]) and a["samples"].dtype == np.int32
+    assert a["tolerance"][0] == 0.05 and a["use_k"][0] == 0

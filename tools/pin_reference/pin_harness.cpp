@@ -145,12 +145,16 @@ struct Writer {
 };
 
 // ---- what is kept of a ceres::Solver::Summary ---------------------------------------------------------------------------------------
-// summary row: {iterations (without iteration 0), successful steps, unsuccessful steps, termination in the repository's coding
-// (include/rsdsfm.h RSDSFM_TERM_*: 0 gradient, 1 parameter, 2 function tolerance, 3 max iterations, 4 failure, 5 min radius), initial
-// cost, final cost, ceres termination_type, trust-region radius after the last iteration}
+// summary row: {entries of summary.iterations behind iteration 0, successful among them, unsuccessful among them (invalid steps
+// included), termination in the repository's coding (include/rsdsfm.h RSDSFM_TERM_*: 0 gradient, 1 parameter, 2 function tolerance,
+// 3 max iterations, 4 failure, 5 min radius), initial cost, final cost, ceres termination_type, trust-region radius of the last entry,
+// summary.num_successful_steps, summary.num_unsuccessful_steps (Ceres' own counters, whatever they do with iteration 0)}.
+// The counts come from the iterations vector itself, so they do not depend on how Ceres counts iteration 0.  NOTE for the reader of
+// the fixture: TrustRegionMinimizer returns from INSIDE the loop on the parameter / function tolerance, so the iteration that met that
+// tolerance is not in the vector -- an implementation that counts it reports one iteration more (tests/test_reference_golden.py).
 // trace rows (one per entry of summary.iterations, iteration 0 included): {iteration, cost, cost_change, gradient_max_norm, step_norm,
 // relative_decrease, trust_region_radius, step_is_successful, step_is_valid}
-const int kSummaryCols = 8, kTraceCols = 9, kTraceRows = 64;
+const int kSummaryCols = 10, kTraceCols = 9, kTraceRows = 64;
 
 int term_code(const ceres::Solver::Summary& s) {
     const std::string& m = s.message;
@@ -163,14 +167,18 @@ int term_code(const ceres::Solver::Summary& s) {
 }
 
 void keep_summary(const ceres::Solver::Summary& s, double* row, double* trace) {
+    int succ = 0, unsucc = 0;
+    for (size_t i = 1; i < s.iterations.size(); ++i) (s.iterations[i].step_is_successful ? succ : unsucc) += 1;
     row[0] = s.iterations.empty() ? 0.0 : (double)(s.iterations.size() - 1);
-    row[1] = (double)s.num_successful_steps;
-    row[2] = (double)s.num_unsuccessful_steps;
+    row[1] = (double)succ;
+    row[2] = (double)unsucc;
     row[3] = (double)term_code(s);
     row[4] = s.initial_cost;
     row[5] = s.final_cost;
     row[6] = (double)s.termination_type;
     row[7] = s.iterations.empty() ? 0.0 : s.iterations.back().trust_region_radius;
+    row[8] = (double)s.num_successful_steps;
+    row[9] = (double)s.num_unsuccessful_steps;
     for (int i = 0; i < kTraceRows * kTraceCols; ++i) trace[i] = std::numeric_limits<double>::quiet_NaN();
     for (size_t i = 0; i < s.iterations.size() && (int)i < kTraceRows; ++i) {
         const ceres::IterationSummary& it = s.iterations[i];

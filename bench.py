@@ -574,27 +574,44 @@ def run(args):
         n1 = max(20, npairs // 8)
         el1 = timed(lambda i: single_calls[i % len(single_calls)](), n1, 5)
 
-        # dominant-kernel duration: HIP events on stream 0 around bursts of BURST back-to-back launches of the streaming
-        # kernel alone (launch 0 of the batched LM solve = `depth_lm_batch_kernel`, B pairs per launch; the other streams
-        # are idle); the quotient includes the ~1 us inter-kernel gap, i.e. it is a slightly conservative launch duration
+        # dominant-kernel duration.  LM mode: the streaming kernel (launch 0 of the batched solve = `depth_lm_batch_kernel`, B pairs per launch)
+        # carries its DISPATCH's own start / stop timestamps when profiling is on for the batch's first context (rsdsfm_set_profiling:
+        # hipExtLaunchKernel events -- what rocprofv3 --kernel-trace reports for the kernel, no inter-launch gap in it).  Bursts of BURST
+        # ordinary batched calls (streaming launch + decide / apply launch) back to back on stream 0, the other streams idle; the record
+        # read is the LAST call's, i.e. a launch under the sustained load the clocks settle on.  Closed-form mode (no batched entry point):
+        # HIP events around the burst, divided by BURST (includes the ~1 us gaps: slightly conservative).
         kern_ms = kern_med = None
         if rank == 0:
+            BURST, reps = 10, 30
             if mode == rsdsfm.DEPTH_CERES_LM:
-                burst_calls = [rsdsfm.prepared_depth_batch(grp[1], [problem(x) for x in grp[2]], launch0_only=True) for grp in groups[:G]]
+                own_g = groups[:G]
+                for grp in own_g:
+                    grp[1][0].set_profiling(True)
+                ts = []
+                for i in range(reps):
+                    for b_ in range(BURST):
+                        last = own_g[(i * BURST + b_) % len(own_g)]
+                        last[0]()
+                    torch.cuda.synchronize()
+                    ts.append(last[1][0].profile_last_ms("depth_lm_batch"))
+                for grp in own_g:
+                    grp[1][0].set_profiling(False)
+                ts = sorted(ts[3:])
             else:
                 burst_calls = single_calls
-            BURST, reps = 10, 30
-            e0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-            e1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
-            for i in range(reps):
-                e0[i].record(stream)
-                for b_ in range(BURST):
-                    burst_calls[(i * BURST + b_) % len(burst_calls)]()
-                e1[i].record(stream)
-            torch.cuda.synchronize()
-            ts = sorted(a_.elapsed_time(b_) / BURST for a_, b_ in zip(e0, e1))
+                e0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+                e1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+                for i in range(reps):
+                    e0[i].record(stream)
+                    for b_ in range(BURST):
+                        burst_calls[(i * BURST + b_) % len(burst_calls)]()
+                    e1[i].record(stream)
+                torch.cuda.synchronize()
+                ts = sorted(a_.elapsed_time(b_) / BURST for a_, b_ in zip(e0, e1))
             kern_ms, kern_med = float(np.mean(ts)), float(ts[len(ts) // 2])
 
+        # (its template argument: launch 0 takes the Jacobi scaling through the in-range function cores -- reference-arithmetic library only)
+        batch_kernel = "depth_lm_batch_kernel<%s>" % ("false" if args.arith == "fused" else "true")
         if rank == 0:
             alg_bytes = ALG_BYTES_PER_PIXEL_DEPTH * n * B
             achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -615,12 +632,12 @@ def run(args):
                            "max_rel_err_vs_truth": max_rel,
                            # every context of the last batches: LM finished inside the timed launch sequence and the depths match the truth
                            "verified": bool(max_rel < 1e-8 and (mode != 1 or (extra == 0 and summary is not None and summary["termination"] >= 0)))},
-                "roofline": {"bound": "hbm", "kernel": ("depth_lm_batch_kernel (%d pairs per launch)" % B) if mode == 1 else "depth_closed_form_kernel",
+                "roofline": {"bound": "hbm", "kernel": ("%s (%d pairs per launch)" % (batch_kernel, B)) if mode == 1 else "depth_closed_form_kernel",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                             "traffic": _traffic("depth_batch%d" % B if mode == 1 else workload), "alg_bytes_per_launch": alg_bytes,
+                             "traffic": _traffic("depth_batch%d" % B if mode == 1 else workload, [batch_kernel] if (mode == 1 and B == 4) else None), "alg_bytes_per_launch": alg_bytes,
                              "avg_launch_ms": kern_ms, "median_launch_ms": kern_med,
-                             "note": "launch duration measured with the other streams idle (bursts on one stream); profiles/: rocprofv3 "
-                                     "of `bench.py --streams 1`"},
+                             "note": "launch duration = the dispatch's own start / stop timestamps (hipExtLaunchKernel events on the library's launch), last "
+                                     "call of bursts of 10 batched solves on one stream, the other streams idle; profiles/: rocprofv3 of `bench.py --streams 1`"},
                 # the same algorithmic bytes over the JOB's time per pair: what the HBM system delivers to the whole loop
                 "roofline_job": {"bound": "hbm", "achieved": job, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": job / HBM_PEAK_GBS,
                                  "pairs_per_launch": B, "streams": S},
@@ -1087,12 +1104,12 @@ def cpu_baseline_rectify(img, depth, R, t, K, inl, budget_s=8.0):
             "sample": "%d whole 1280x720 frames (depth image + back projection + interpolation) in %.1f s" % (reps, el)}
 
 
-def _traffic(workload):
+def _traffic(workload, kernels=None):
     """HBM bytes per launch of the workload's dominant kernel(s) from the rocprofv3 PMC passes committed under profiles/:
     counters.json (round 2: per-kernel FETCH_SIZE / WRITE_SIZE means in KB, FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md) when it
     has the kernels, else the round-1 record in traffic.json; None if absent."""
     kernels = {"rectify": ["back_project_claim_kernel", "back_project_write_kernel"], "true_flow": ["true_flow_pruned_kernel"],
-               "depth_batch4": ["depth_lm_batch_kernel"], "depth_closed_form": ["depth_closed_form_kernel"]}.get(workload)
+               "depth_batch4": ["depth_lm_batch_kernel<true>"], "depth_closed_form": ["depth_closed_form_kernel"]}.get(workload) if kernels is None else kernels
     if kernels:
         ctr = [_counters(k2) for k2 in kernels]
         if any(c2 and c2.get("stale") for c2 in ctr):

@@ -132,10 +132,18 @@ int rsdsfm_set_ransac_speculation(rsdsfm_ctx* ctx, int k0);
  * rsdsfm_ransac_restarts: how many RANSAC runs of this context (and its sequence lanes) started over. */
 int rsdsfm_set_ransac_math(rsdsfm_ctx* ctx, int mode);
 int rsdsfm_ransac_restarts(rsdsfm_ctx* ctx, int64_t* count);
+/* The dense depth solve (rsdsfm_estimate_inverse_depths*, LM mode) takes the same in-range cores in launch 0 (Jacobi scaling) under the same
+ * switch (rsdsfm_set_ransac_math); a solve whose launch 0 met an argument out of their range is left unfinished by its follow-up
+ * launch and rsdsfm_depth_finish_dev -- which every LM-mode caller runs to obtain the summary -- starts it over with the standard
+ * functions: identical results, counted here.  (nonlinearRefinement.cc:109-180: the reference has one code path) */
+int rsdsfm_depth_restarts(rsdsfm_ctx* ctx, int64_t* count);
 /* Opt-in profiling: while on, rsdsfm_ransac* / rsdsfm_solve_frame_dev bracket the dominant kernel of the whole solve -- round 0
  * of the hypothesis-batched LM depth solves, `ransac_lm_kernel<true, 3, BASE, CORE>` -- with two HIP events on the context's stream (in
  * situ: same launch, same neighbours, same clocks as any other solve).  rsdsfm_profile_last_ms(ctx, "ransac_lm_round0", &ms)
- * returns the duration of that launch in the most recent call.  bench.py's roofline record uses it. */
+ * returns the duration of that launch in the most recent call.  bench.py's roofline record uses it.
+ * With profiling on for the FIRST context of a batched dense depth solve (rsdsfm_estimate_inverse_depths_batch_dev), its streaming
+ * launch (`depth_lm_batch_kernel`) carries the dispatch's own start / stop timestamps (hipExtLaunchKernel events: what rocprofv3
+ * --kernel-trace reports for the kernel, without the gap between launches): rsdsfm_profile_last_ms(ctx, "depth_lm_batch", &ms). */
 int rsdsfm_set_profiling(rsdsfm_ctx* ctx, int on);
 int rsdsfm_profile_last_ms(rsdsfm_ctx* ctx, const char* what, double* ms);
 /* name of the HIP kernel that dominates the given entry point (for profiling / roofline reports) */

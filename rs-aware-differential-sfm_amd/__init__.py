@@ -260,6 +260,12 @@ class Solver:
         self._check(self.lib.rsdsfm_ransac_restarts(self._ctx, C.byref(n)), "rsdsfm_ransac_restarts")
         return n.value
 
+    def depth_restarts(self):
+        """dense depth solves of this context that started over with the standard functions (rsdsfm_depth_restarts)"""
+        n = C.c_int64()
+        self._check(self.lib.rsdsfm_depth_restarts(self._ctx, C.byref(n)), "rsdsfm_depth_restarts")
+        return int(n.value)
+
     def synchronize(self):
         self._check(self.lib.rsdsfm_synchronize(self._ctx), "rsdsfm_synchronize")
 

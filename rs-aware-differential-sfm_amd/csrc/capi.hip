@@ -196,8 +196,10 @@ int rsdsfm_set_profiling(rsdsfm_ctx* ctx, int on) {
 
 int rsdsfm_profile_last_ms(rsdsfm_ctx* ctx, const char* what, double* ms) {
     CTX_OR_FAIL(ctx);
-    if (!what || !ms || strcmp(what, "ransac_lm_round0") != 0) return fail(c, RSDSFM_ERR_INVALID, "unknown profile record (known: \"ransac_lm_round0\")");
-    if (!c->prof_pending) return fail(c, RSDSFM_ERR_INVALID, "no profile record: enable rsdsfm_set_profiling and run a RANSAC (LM mode) first");
+    const int which = !what ? -1 : !strcmp(what, "ransac_lm_round0") ? 0 : !strcmp(what, "depth_lm_batch") ? 1 : -1;
+    if (which < 0 || !ms) return fail(c, RSDSFM_ERR_INVALID, "unknown profile record (known: \"ransac_lm_round0\", \"depth_lm_batch\")");
+    if (!c->prof_pending || c->prof_what != which)
+        return fail(c, RSDSFM_ERR_INVALID, "no such profile record: enable rsdsfm_set_profiling and run a RANSAC (LM mode) / a batched dense depth solve first");
     RSDSFM_HIP_CHECK(c, hipEventSynchronize(c->ev_prof[1]));
     float f = 0.f;
     RSDSFM_HIP_CHECK(c, hipEventElapsedTime(&f, c->ev_prof[0], c->ev_prof[1]));
@@ -256,6 +258,13 @@ int rsdsfm_ransac_restarts(rsdsfm_ctx* ctx, int64_t* count) {
     return RSDSFM_OK;
 }
 
+int rsdsfm_depth_restarts(rsdsfm_ctx* ctx, int64_t* count) {
+    CTX_OR_FAIL(ctx);
+    if (!count) return fail(c, RSDSFM_ERR_INVALID, "depth restarts: null output");
+    *count = c->depth_restarts;
+    return RSDSFM_OK;
+}
+
 int rsdsfm_set_true_flow_search(rsdsfm_ctx* ctx, int mode) {
     CTX_OR_FAIL(ctx);
     if (mode < 0 || mode > 2) return fail(c, RSDSFM_ERR_INVALID, "true-flow search mode: 0 = automatic, 1 = exhaustive, 2 = interval-pruned");
@@ -265,7 +274,7 @@ int rsdsfm_set_true_flow_search(rsdsfm_ctx* ctx, int mode) {
 
 const char* rsdsfm_kernel_name(const char* entry_point) {
     if (!entry_point) return "";
-    if (!strcmp(entry_point, "estimate_inverse_depths_lm")) return "depth_lm_kernel<1>";
+    if (!strcmp(entry_point, "estimate_inverse_depths_lm")) return RSDSFM_FUSED ? "depth_lm_kernel<1, false>" : "depth_lm_kernel<1, true>";
     if (!strcmp(entry_point, "estimate_inverse_depths_closed_form")) return "depth_closed_form_kernel";
     return "";
 }
@@ -295,7 +304,7 @@ int rsdsfm_estimate_inverse_depths_dev(rsdsfm_ctx* ctx, const double* d_q, const
         return rcf;
     }
     if (c->depth_variant == 0) {  // launch 0, then ONE launch that decides and (if needed) applies
-        int rc0 = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 0);
+        int rc0 = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 0, /*core=*/true);  // (the follow-up launch checks the cores' range flag)
         if (rc0 != RSDSFM_OK) return rc0;
         rc0 = depth_lm_decide_apply_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho);
         c->lm_issued_k = 1;  // a continuation (status 0) starts with launch 1 in rsdsfm_depth_finish_dev
@@ -404,6 +413,22 @@ int rsdsfm_depth_finish_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_
     int extra = 0;
     int rc = read_lm_state(c);
     if (rc != RSDSFM_OK) return rc;
+    if (c->h_lm->status == 0 && c->h_lm->restart) {
+        // launch 0 ran its Jacobi scaling through the in-range function cores and met an argument out of range (a vanishing Jacobian, a
+        // non-finite flow: depth_kernels.hip CORE): the solve starts over with the standard functions -- launch 0, its decision, and
+        // from there the ordinary continuation below; the context keeps the standard functions for its next 16 solves
+        c->depth_standard_math = 16;
+        c->depth_restarts += 1;
+        rc = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 0, /*core=*/false);
+        if (rc != RSDSFM_OK) return rc;
+        rc = depth_lm_decide_launch(c, n, 0);
+        if (rc != RSDSFM_OK) return rc;
+        c->lm_issued_k = 1;
+        c->lm_issued_d = 1;
+        extra += 2;
+        rc = read_lm_state(c);
+        if (rc != RSDSFM_OK) return rc;
+    }
     for (;;) {
         const LmState& st = *c->h_lm;
         if (st.status == 1) break;

@@ -15,6 +15,7 @@
 //
 // HBM-bound streaming, one lane per pixel PAIR so that every global access is a 16-byte vector
 // (q: 2 x dwordx4, u: 2 x dwordx4, alpha / alpha_k / rho: dwordx4).  No LDS tiling (no reuse), no MFMA.
+#include <hip/hip_ext.h>
 #include <string.h>
 
 #include <algorithm>
@@ -123,7 +124,11 @@ __device__ __forceinline__ void nt_store(double2* p, double2 o) {
 // state machine designated exactly this launch (next_launch) to continue (status 0) or to apply (status 2).
 // FIRST = 1: launch 0 of a solve (always a full speculative pass); FIRST = 0: follow-up launches (apply / continue /
 // no-op).  Same code; the template only gives the two roles distinct kernel names in profiles.
-template <int FIRST>
+// CORE (launch 0 only): the Jacobi scaling 1 / (1 + sqrt(J.J)) through the in-range cores of sqrt and the reciprocal (device_math.hpp:
+// the same bits for an argument in range, 12 instructions per pixel less).  A thread that met an argument out of range (a vanishing
+// Jacobian, a non-finite flow) stores the launch's epoch into the context's flag word; the follow-up launch then leaves the solve
+// unfinished with LmScal::restart set and rsdsfm_depth_finish_dev runs it again with the standard functions (capi.hip).
+template <int FIRST, bool CORE = false>
 __global__ __launch_bounds__(kDepthBlock) void depth_lm_kernel(const double2* __restrict__ q,
                                                                const double2* __restrict__ u,
                                                                const double2* __restrict__ alpha2,
@@ -131,7 +136,8 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lm_kernel(const double2* __
                                                                Pose pose, double2* __restrict__ rho2,
                                                                const LmState* __restrict__ state,
                                                                double* __restrict__ partials, int launch_id,
-                                                               int* __restrict__ predict_used) {
+                                                               int* __restrict__ predict_used, int core_epoch) {
+    static_assert(!CORE || FIRST, "the function cores run in launch 0 only");
     __shared__ LmPlanLds plan;
     __shared__ double s_red[kDepthBlock / 64][NS];
     __shared__ double s_T[kDepthBlock / 64][kTRows * kTStride];
@@ -174,15 +180,17 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lm_kernel(const double2* __
     if constexpr (FIRST) {  // launch 0: compile-time plan shape, operands streamed once
         LmPlanFirst pf;
         pf.load(plan);
+        uint32_t worst = 0;  // CORE: the range tests of this thread's function-core arguments (sqrt_range_track)
         for (int64_t p = (int64_t)blockIdx.x * blockDim.x + tid; p < npairs; p += stride) {
             const double2 qa = nt_load(q + 2 * p), qb = nt_load(q + 2 * p + 1);
             const double2 ua = nt_load(u + 2 * p), ub = nt_load(u + 2 * p + 1);
             const double2 al = nt_load(alpha2 + p), ak = nt_load(alpha_k2 + p);
             double2 out;
-            out.x = lm_pixel(qa.x, qa.y, ua.x, ua.y, al.x, ak.x, pose, two_over, pf, acc);
-            out.y = lm_pixel(qb.x, qb.y, ub.x, ub.y, al.y, ak.y, pose, two_over, pf, acc);
+            out.x = lm_pixel_t<CORE>(qa.x, qa.y, ua.x, ua.y, al.x, ak.x, pose, two_over, pf, acc, NoHook(), nullptr, &worst);
+            out.y = lm_pixel_t<CORE>(qb.x, qb.y, ub.x, ub.y, al.y, ak.y, pose, two_over, pf, acc, NoHook(), nullptr, &worst);
             nt_store(rho2 + p, out);
         }
+        if (CORE && worst >= kSqrtRangeKeys) predict_used[1] = core_epoch;  // (benign race: every writer stores the same word)
     } else {
         for (int64_t p = (int64_t)blockIdx.x * blockDim.x + tid; p < npairs; p += stride) {
             double2 qa = q[2 * p], qb = q[2 * p + 1];
@@ -228,7 +236,7 @@ __device__ __forceinline__ void decide_apply_body(const double2* __restrict__ q,
                                                   const double2* __restrict__ alpha2, const double2* __restrict__ alpha_k2, int64_t n,
                                                   const Pose& pose, double2* __restrict__ rho2, LmState* state,
                                                   const double* __restrict__ partials, int nrows,
-                                                  const int* __restrict__ predict_used) {
+                                                  const int* __restrict__ predict_used, int core_epoch) {
     __shared__ LmPlanLds plan;
     __shared__ double s_red[kDepthBlock / 64][NS];
     __shared__ double s_T[kDepthBlock / 64][kTRows * kTStride];
@@ -238,6 +246,8 @@ __device__ __forceinline__ void decide_apply_body(const double2* __restrict__ q,
     __shared__ int s_status;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int pr = *predict_used;
+    // launch 0 ran its Jacobi scaling through the in-range function cores and met an argument out of range: its sums do not count
+    const bool core_miss = core_epoch != 0 && predict_used[1] == core_epoch;
     double fin[NS];
 #pragma unroll
     for (int s = 0; s < NS; ++s) fin[s] = 0.0;
@@ -261,6 +271,12 @@ __device__ __forceinline__ void decide_apply_body(const double2* __restrict__ q,
         st.predict = pr;
         const int used_write = (pr >= 0 && pr <= KMAX) ? pr : 1;
         lm_advance(st, s_hist, s_sums, n, 1, KMAX, used_write, 0);
+        if (core_miss) {  // unfinished, whatever the sums said: rsdsfm_depth_finish_dev starts the solve over with the standard functions
+            st.status = 0;
+            st.restart = 1;
+            st.termination = -1;
+            st.next_launch = 1;
+        }
         s_status = st.status;
         plan.n_hist = st.n_hist;
         plan.K = 0;
@@ -310,8 +326,8 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lm_decide_apply_kernel(cons
                                                                             const double2* __restrict__ alpha_k2, int64_t n, Pose pose,
                                                                             double2* __restrict__ rho2, LmState* state,
                                                                             const double* __restrict__ partials, int nrows,
-                                                                            const int* __restrict__ predict_used) {
-    decide_apply_body(q, u, alpha2, alpha_k2, n, pose, rho2, state, partials, nrows, predict_used);
+                                                                            const int* __restrict__ predict_used, int core_epoch) {
+    decide_apply_body(q, u, alpha2, alpha_k2, n, pose, rho2, state, partials, nrows, predict_used, core_epoch);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -328,13 +344,15 @@ struct DepthBatchItem {
     Pose pose;
     LmState* state;
     double* partials;
-    int* predict_used;
+    int* predict_used;  // [0] the predictor value launch 0 used, [1] the range-flag word of the function cores
+    int core_epoch;     // != 0: this solve's launch 0 runs the function cores; the value a thread stores into predict_used[1] on a miss
 };
 struct DepthBatchArgs {
     int count;
     DepthBatchItem item[kDepthBatchMax];
 };
 
+template <bool CORE>
 __global__ __launch_bounds__(kDepthBlock) void depth_lm_batch_kernel(DepthBatchArgs args) {
     __shared__ LmPlanLds plan;
     __shared__ double s_red[kDepthBlock / 64][NS];
@@ -367,15 +385,18 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lm_batch_kernel(DepthBatchA
     for (int s = 0; s < NS; ++s) acc[s] = 0.0;
     const int64_t npairs = n >> 1;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint32_t worst = 0;  // CORE: the range tests of this thread's function-core arguments (sqrt_range_track)
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + tid; p < npairs; p += stride) {
         const double2 qa = nt_load(q + 2 * p), qb = nt_load(q + 2 * p + 1);
         const double2 ua = nt_load(u + 2 * p), ub = nt_load(u + 2 * p + 1);
         const double2 al = nt_load(alpha2 + p), ak = nt_load(alpha_k2 + p);
         double2 out;
-        out.x = lm_pixel(qa.x, qa.y, ua.x, ua.y, al.x, ak.x, pose, two_over, pf, acc);
-        out.y = lm_pixel(qb.x, qb.y, ub.x, ub.y, al.y, ak.y, pose, two_over, pf, acc);
+        out.x = lm_pixel_t<CORE>(qa.x, qa.y, ua.x, ua.y, al.x, ak.x, pose, two_over, pf, acc, NoHook(), nullptr, &worst);
+        out.y = lm_pixel_t<CORE>(qb.x, qb.y, ub.x, ub.y, al.y, ak.y, pose, two_over, pf, acc, NoHook(), nullptr, &worst);
         nt_store(rho2 + p, out);
     }
+    // (a batch runs the cores only when every solve of it does: core_epoch != 0 for all items)
+    if (CORE && worst >= kSqrtRangeKeys) it.predict_used[1] = it.core_epoch;  // (benign race: every writer stores the same word)
     if ((n & 1) && blockIdx.x == 0 && tid == 0) {
         const int64_t i = n - 1;
         double2 qa = q[i], ua = u[i];
@@ -395,7 +416,7 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lm_batch_kernel(DepthBatchA
 
 __global__ __launch_bounds__(kDepthBlock) void depth_lm_decide_apply_batch_kernel(DepthBatchArgs args, int nrows) {
     const DepthBatchItem& it = args.item[blockIdx.y];
-    decide_apply_body(it.q, it.u, it.a2, it.ak2, it.n, it.pose, it.rho2, it.state, it.partials, nrows, it.predict_used);
+    decide_apply_body(it.q, it.u, it.a2, it.ak2, it.n, it.pose, it.rho2, it.state, it.partials, nrows, it.predict_used, it.core_epoch);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -758,8 +779,12 @@ static inline int depth_dma_grid(const Ctx* c, int64_t n) {
 
 int depth_lm_grid(const Ctx* c, int64_t n) { return c->depth_variant == 1 ? depth_dma_grid(c, n) : depth_grid(n, kDepthMaxBlocks); }
 
+// launch 0 of a solve takes the in-range function cores when the caller allows it (`core`: the fast path of variant 0, whose follow-up
+// launch checks the flag) and the context has not just had to start a solve over; the epoch a miss is reported with is c->depth_epoch
+static inline bool depth_use_cores(const Ctx* c) { return !RSDSFM_FUSED && c->ransac_math_mode == 0 && c->depth_standard_math == 0; }
+
 int depth_lm_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
-                    const Pose& pose, double* rho, int launch_id) {
+                    const Pose& pose, double* rho, int launch_id, bool core) {
     if (!aligned16(q) || !aligned16(u) || !aligned16(a) || !aligned16(ak) || !aligned16(rho))
         return fail(c, RSDSFM_ERR_INVALID, "device pointers must be 16-byte aligned");
     const int grid = depth_lm_grid(c, n);
@@ -782,12 +807,27 @@ int depth_lm_launch(Ctx* c, const double* q, const double* u, const double* a, c
             hipLaunchKernelGGL(depth_lm_dma_kernel<0>, dim3(grid), dim3(kDepthBlock), kDmaLdsBytes, c->stream, q2, u2, a2, ak2, n, pose,
                                rho2, c->d_lm, c->d_partials, launch_id);
     } else {
-        if (launch_id == 0)
-            hipLaunchKernelGGL(depth_lm_kernel<1>, dim3(grid), dim3(kDepthBlock), 0, c->stream, q2, u2, a2, ak2, n, pose, rho2, c->d_lm,
-                               c->d_partials, launch_id, reinterpret_cast<int*>(c->d_tickets + 40));
-        else
-            hipLaunchKernelGGL(depth_lm_kernel<0>, dim3(grid), dim3(kDepthBlock), 0, c->stream, q2, u2, a2, ak2, n, pose, rho2, c->d_lm,
-                               c->d_partials, launch_id, static_cast<int*>(nullptr));
+        int* predict_used = reinterpret_cast<int*>(c->d_tickets + 40);
+        if (launch_id == 0) {
+            bool use = false;
+            if (core) {
+                if (c->depth_standard_math > 0) c->depth_standard_math -= 1;  // (one more solve on the standard functions behind a restart)
+                else use = depth_use_cores(c);
+            }
+            if (use) {
+                c->depth_epoch = c->depth_epoch >= 0x3fffffff ? 1 : c->depth_epoch + 1;
+                hipLaunchKernelGGL((depth_lm_kernel<1, true>), dim3(grid), dim3(kDepthBlock), 0, c->stream, q2, u2, a2, ak2, n, pose, rho2, c->d_lm,
+                                   c->d_partials, launch_id, predict_used, c->depth_epoch);
+                c->depth_core_launch = c->depth_epoch;
+            } else {
+                hipLaunchKernelGGL((depth_lm_kernel<1, false>), dim3(grid), dim3(kDepthBlock), 0, c->stream, q2, u2, a2, ak2, n, pose, rho2, c->d_lm,
+                                   c->d_partials, launch_id, predict_used, 0);
+                c->depth_core_launch = 0;
+            }
+        } else {
+            hipLaunchKernelGGL((depth_lm_kernel<0, false>), dim3(grid), dim3(kDepthBlock), 0, c->stream, q2, u2, a2, ak2, n, pose, rho2, c->d_lm,
+                               c->d_partials, launch_id, static_cast<int*>(nullptr), 0);
+        }
     }
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
@@ -805,7 +845,8 @@ int depth_lm_decide_apply_launch(Ctx* c, const double* q, const double* u, const
     const int grid = depth_lm_grid(c, n);
     hipLaunchKernelGGL(depth_lm_decide_apply_kernel, dim3(std::min(grid, kApplyGrid)), dim3(kDepthBlock), 0, c->stream, reinterpret_cast<const double2*>(q),
                        reinterpret_cast<const double2*>(u), reinterpret_cast<const double2*>(a), reinterpret_cast<const double2*>(ak), n, pose,
-                       reinterpret_cast<double2*>(rho), c->d_lm, c->d_partials, grid, reinterpret_cast<const int*>(c->d_tickets + 40));
+                       reinterpret_cast<double2*>(rho), c->d_lm, c->d_partials, grid, reinterpret_cast<const int*>(c->d_tickets + 40),
+                       c->depth_core_launch);  // (the epoch of the launch 0 in front of it when that ran the function cores, else 0)
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
@@ -822,6 +863,13 @@ int depth_lm_batch_launch(Ctx* const* cs, int count, const double* const* q, con
     memset(&args, 0, sizeof(args));
     args.count = count;
     int grid = 1;
+    // the function cores in launch 0 when EVERY solve of the batch may take them (one kernel variant per launch) and a follow-up
+    // launch is there to check the flags (a launch0_only caller has none)
+    bool core = !launch0_only;
+    for (int i = 0; i < count; ++i) core = core && depth_use_cores(cs[i]) && cs[i]->depth_variant == 0;
+    if (!launch0_only)
+        for (int i = 0; i < count; ++i)
+            if (cs[i]->depth_standard_math > 0) cs[i]->depth_standard_math -= 1;  // (one more solve on the standard functions behind a restart)
     for (int i = 0; i < count; ++i) {
         if (!aligned16(q[i]) || !aligned16(u[i]) || !aligned16(a[i]) || !aligned16(ak[i]) || !aligned16(rho[i]))
             return fail(c0, RSDSFM_ERR_INVALID, "device pointers must be 16-byte aligned");
@@ -836,10 +884,23 @@ int depth_lm_batch_launch(Ctx* const* cs, int count, const double* const* q, con
         it.state = cs[i]->d_lm;
         it.partials = cs[i]->d_partials;
         it.predict_used = reinterpret_cast<int*>(cs[i]->d_tickets + 40);
+        if (core) {
+            cs[i]->depth_epoch = cs[i]->depth_epoch >= 0x3fffffff ? 1 : cs[i]->depth_epoch + 1;
+            it.core_epoch = cs[i]->depth_epoch;
+        }
+        cs[i]->depth_core_launch = it.core_epoch;
         grid = std::max(grid, depth_grid(n[i], kDepthBatchBlocks));
     }
-    hipLaunchKernelGGL(depth_lm_batch_kernel, dim3(grid, count), dim3(kDepthBlock), 0, c0->stream, args);
+    // rsdsfm_set_profiling on the batch's first context: the launch is bracketed by the DISPATCH's own start / stop timestamps
+    // (hipExtLaunchKernelGGL events = what rocprofv3 --kernel-trace reports; events recorded around the launch would add the gap)
+    const bool prof = c0->profile && c0->ev_prof[0] && c0->ev_prof[1];
+    hipEvent_t ev0 = prof ? c0->ev_prof[0] : nullptr, ev1 = prof ? c0->ev_prof[1] : nullptr;
+    if (core)
+        hipExtLaunchKernelGGL(depth_lm_batch_kernel<true>, dim3(grid, count), dim3(kDepthBlock), 0, c0->stream, ev0, ev1, 0, args);
+    else
+        hipExtLaunchKernelGGL(depth_lm_batch_kernel<false>, dim3(grid, count), dim3(kDepthBlock), 0, c0->stream, ev0, ev1, 0, args);
     RSDSFM_HIP_CHECK(c0, hipGetLastError());
+    if (prof) c0->prof_pending = true, c0->prof_what = 1;
     if (launch0_only) return RSDSFM_OK;
     hipLaunchKernelGGL(depth_lm_decide_apply_batch_kernel, dim3(std::min(grid, kApplyGrid), count), dim3(kDepthBlock), 0, c0->stream, args, grid);
     RSDSFM_HIP_CHECK(c0, hipGetLastError());

@@ -32,6 +32,7 @@ __device__ __forceinline__ void lm_advance(LmScal& st, double* hist, const doubl
                                            int used_write, int launch_id) {
     if (first) {
         st.status = 0;
+        st.restart = 0;
         st.n_hist = 0;
         st.iteration = 0;
         st.num_successful = 0;

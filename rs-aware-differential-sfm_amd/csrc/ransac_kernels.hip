@@ -1006,6 +1006,7 @@ int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const doubl
     if (prof) {
         RSDSFM_HIP_CHECK(c, hipEventRecord(c->ev_prof[1], c->stream));
         c->prof_pending = true;
+        c->prof_what = 0;
     }
     hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, 1, states, n, round, k0, flags, flags + 2, scored,
                        trial_count, trial_err, fused_base, flags + 4, unscored_list);

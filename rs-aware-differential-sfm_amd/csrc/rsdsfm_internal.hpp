@@ -62,7 +62,9 @@ struct LmScal {
     int32_t next_launch;  // status 0: id of the launch that must speculate next; status 2: id of the launch that applies
     int32_t predict;      // accepted-step count of the previous solve on this context: the iterate launch 0 of the
                           // NEXT solve writes speculatively (a branch predictor; results never depend on it)
-    int32_t _pad;
+    int32_t restart;      // 1: launch 0 met an argument outside the range of its in-range function cores (depth_kernels.hip CORE): its sums
+                          // may differ from the standard functions', the solve is unfinished (status 0) and rsdsfm_depth_finish_dev runs it
+                          // again from launch 0 with the standard functions
     double radius;
     double decrease_factor;
     double cost;  // cost of the current state
@@ -113,6 +115,11 @@ struct Ctx {
     int ransac_spec_miss = 0;  // consecutive RANSACs (saturating at 2) whose speculated final stage did not count; below 2 the frame solve enqueues the refinement behind the speculated stage
     int frame_dense_hint = 1;  // frame solve: the previous frame kept every pixel (dense flow) -> set the RANSAC up for n = rows * cols without waiting for the count
     int lm_issued_d = 0;           // depth_lm_decide_kernel launches issued for the current solve
+    int depth_epoch = 0;           // launch-0 counter of the dense depth solve: the value a thread of launch 0 stores into the context's range-flag word (d_tickets[41]) when an argument left the range of the function cores -- never a stale flag, no clearing pass
+    int depth_standard_math = 0;   // > 0: that many of the context's next dense depth solves run launch 0 with the standard sqrt / reciprocal (set to 16 by a solve that had to start over)
+    int64_t depth_restarts = 0;    // dense depth solves of this context that started over for that reason
+    int depth_core_launch = 0;     // epoch of the current solve's launch 0 when it ran the function cores, else 0 (what its follow-up launch compares the flag word with)
+    int prof_what = 0;             // rsdsfm_set_profiling: what the pending record brackets (0 = round 0 of the RANSAC's LM solves, 1 = launch 0 of a batched dense depth solve)
     // staging buffers for the host-pointer API (grown on demand)
     void* d_stage = nullptr;
     size_t stage_bytes = 0;
@@ -213,7 +220,7 @@ struct Arena {
 int depth_closed_form_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak,
                              int64_t n, const Pose& pose, double* rho);
 int depth_lm_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
-                    const Pose& pose, double* rho, int launch_id);
+                    const Pose& pose, double* rho, int launch_id, bool core = false);
 int depth_lm_decide_launch(Ctx* c, int64_t n, int launch_id);
 int depth_lm_decide_apply_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                                  const Pose& pose, double* rho);

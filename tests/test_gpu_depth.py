@@ -212,3 +212,77 @@ def test_nan_input_is_reported_not_hidden(oracle, solver, rsdsfm):
     rho, sm = solver.estimate_inverse_depths(q, d["u"], v, t["w"], 0.0, a, ak, mode=1)
     rho_o, sm_o2 = oracle.estimate_inverse_depths(q, d["u"], v, t["w"], 0.0, a, ak, mode=1)
     assert sm["termination"] == sm_o2["termination"] and np.allclose(rho, rho_o, rtol=1e-9, atol=1e-13)
+
+
+# ---------------------------------------------------------------------------------------------------
+# launch 0 of the dense depth solve through the in-range function cores (depth_kernels.hip CORE)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg,rows,cols", [(1, 96, 128), (3, 135, 240), (5, 360, 640)])
+def test_depth_function_cores_do_not_change_results(oracle, rsdsfm, cfg, rows, cols):
+    """rsdsfm_set_ransac_math also governs launch 0 of the dense depth solve: in-range cores of sqrt / reciprocal in the Jacobi scaling
+    (default) or the standard functions -- every inverse depth and every LM decision identical bit for bit, equal to the oracle's, and
+    on real-valued data no solve has to start over"""
+    d = rsdsfm.synth.make_config(cfg, rows=rows, cols=cols)
+    q, u, a, ak, t = d["q"], d["u"], d["alpha"], d["alpha_k"], d["truth"]
+    v = t["v"] / np.linalg.norm(t["v"])
+    rho_o, sm_o = oracle.estimate_inverse_depths(q, u, v, t["w"], 0.0, a, ak, mode=1)
+    outs = []
+    with rsdsfm.Solver(0) as s:
+        for mode in (0, 1, 0):
+            s.set_ransac_math(mode)
+            rho, sm = s.estimate_inverse_depths(q, u, v, t["w"], 0.0, a, ak, mode=1)
+            _check_summary(sm, sm_o)
+            assert np.allclose(rho, rho_o, rtol=1e-9, atol=1e-13)
+            outs.append((rho.tobytes(), sm["num_iterations"], sm["num_successful_steps"], sm["termination"], sm["final_cost"], sm["final_radius"]))
+        assert s.depth_restarts() == 0
+    assert outs[0] == outs[1] == outs[2]
+
+
+@pytest.mark.parametrize("poison", ["zero_jacobian", "zero_jacobian_zero_flow"])
+def test_depth_function_cores_restart_on_arguments_out_of_range(oracle, rsdsfm, poison):
+    """an argument outside the cores' range -- a pixel whose Jacobian vanishes (alpha = alpha_k = 0: beta = 0; sqrt's argument is +0),
+    with and without a residual -- leaves the fast path unfinished and rsdsfm_depth_finish_dev runs the solve again with the standard functions: results equal
+    the oracle's and the standard-function setting's bit for bit, the restart is counted, the context keeps the standard functions
+    for its next solves; also through the batched entry point"""
+    import torch
+
+    d = rsdsfm.synth.make_config(5, rows=240, cols=320)
+    q, u, a, ak, t = d["q"].copy(), d["u"].copy(), d["alpha"].copy(), d["alpha_k"].copy(), d["truth"]
+    v = t["v"] / np.linalg.norm(t["v"])
+    victim = 1536 * 7 + 100
+    a[victim] = 0.0
+    ak[victim] = 0.0
+    if poison == "zero_jacobian_zero_flow":
+        u[victim] = 0.0
+    rho_o, sm_o = oracle.estimate_inverse_depths(q, u, v, t["w"], 0.0, a, ak, mode=1)
+    with rsdsfm.Solver(0) as s:
+        rho0, sm0 = s.estimate_inverse_depths(q, u, v, t["w"], 0.0, a, ak, mode=1)
+        assert s.depth_restarts() == 1
+        _check_summary(sm0, sm_o)
+        assert np.allclose(rho0, rho_o, rtol=1e-9, atol=1e-13, equal_nan=True)
+        rho1, sm1 = s.estimate_inverse_depths(q, u, v, t["w"], 0.0, a, ak, mode=1)  # standard functions from the start: no second restart
+        assert s.depth_restarts() == 1
+        s.set_ransac_math(1)
+        rho2, sm2 = s.estimate_inverse_depths(q, u, v, t["w"], 0.0, a, ak, mode=1)
+    assert rho0.tobytes() == rho1.tobytes() == rho2.tobytes() and sm0 == sm1 == sm2
+    # the batched entry point: one poisoned and one clean problem in the same launch
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        solvers = [rsdsfm.Solver(0, stream=stream.cuda_stream) for _ in range(2)]
+        data = [(q, u, a, ak), (d["q"], d["u"], d["alpha"], d["alpha_k"])]
+        dev_t = [[torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in c] for c in data]
+        rhos = [torch.zeros(len(a), dtype=torch.float64, device=dev) for _ in data]
+        probs = [dict(d_q=t_[0].data_ptr(), d_u=t_[1].data_ptr(), d_alpha=t_[2].data_ptr(), d_alpha_k=t_[3].data_ptr(), d_rho=r.data_ptr(), n=len(a), v=v, w=t["w"], k=0.0)
+                 for t_, r in zip(dev_t, rhos)]
+        call = rsdsfm.prepared_depth_batch(solvers, probs)
+        for rep in range(2):
+            call()
+            for i, p in enumerate(probs):
+                sm, _ = solvers[i].depth_finish_dev(p["d_q"], p["d_u"], p["n"], v, t["w"], 0.0, p["d_alpha"], p["d_alpha_k"], p["d_rho"])
+                ro, so = oracle.estimate_inverse_depths(*data[i][:2], v, t["w"], 0.0, *data[i][2:], mode=1)
+                _check_summary(sm, so)
+                assert np.allclose(rhos[i].cpu().numpy(), ro, rtol=1e-9, atol=1e-13, equal_nan=True), (rep, i)
+        assert solvers[0].depth_restarts() == 1 and solvers[1].depth_restarts() == 0
+        for s in solvers:
+            s.close()

@@ -16,8 +16,6 @@
 // (RefineState); the host only polls the termination flag every few iterations.
 // Arithmetic mirrors oracle/rsdsfm_oracle.c rso_refine operation for operation (per-inlier terms bit-identical;
 // the global sums differ only in summation order).
-#include <stdlib.h>
-
 #include "device_math.hpp"
 #include "rsdsfm_internal.hpp"
 
@@ -157,42 +155,11 @@ __device__ __forceinline__ void block_reduce_store(const double (&v)[NV], int ma
     }
 }
 
-// AGENT: the rows were published by other workgroups of the SAME launch (sc1 write-through stores behind an arrival ticket): read them
-// with agent-scope loads (global_load ... sc1: past this CU's L1, never a line another CU has since rewritten)
-__device__ __forceinline__ double agent_load(const double* p) {
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void agent_store(double* p, double v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// EXPERIMENT (RSDSFM_REFINE_FOLD): the row is published write-through (sc1: no release fence), wave 0 drains its stores, ONE lane takes a
-// returning agent-scope ticket; the workgroup that draws the last ticket goes on to the single-workgroup stage (guide G16, recipe R1)
-template <int NV>
-__device__ __forceinline__ bool block_reduce_publish(const double (&v)[NV], int max_slot, double (*s_red)[NV], double* out_row, unsigned* ticket, int grid) {
-    __shared__ int s_last;
-    const int tid = threadIdx.x, wv = tid >> 6;
-    wave_reduce_to_row<NV>(v, max_slot, s_red[wv]);
-    __syncthreads();
-    if (tid < NV) {
-        double r = s_red[0][tid];
-        for (int w2 = 1; w2 < kFB / 64; ++w2) r = (tid == max_slot) ? fmax(r, s_red[w2][tid]) : r + s_red[w2][tid];
-        agent_store(out_row + tid, r);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
-    if (NV > 64) __syncthreads();                      // (two storing waves: both have drained before the ticket)
-    if (tid == 0) s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(grid - 1);
-    __syncthreads();
-    const bool last = s_last != 0;
-    if (last && tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-    return last;
-}
-
 // single-workgroup fixed-order reduction of partials[nblocks][NV] into s_out[NV].  Thread (group g, slot pair sp) adds the rows
 // g, g + G, g + 2G, ... of its two slots in order (adjacent lanes read adjacent 16-byte pieces of a row: coalesced, 16 loads in
 // flight), then thread s adds the G group sums of slot s in order.  (The first version gave every thread whole rows and reduced the NV per-thread sums with NV / 8 rounds of
 // LDS transposes: 7 us of the 10 us refine_solve_kernel, measured by returning right after the reduction.)
-template <int NV, bool AGENT = false>
+template <int NV>
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int nblocks, int max_slot,
                                                 double (*s_red)[NV], double* s_out) {
     constexpr int W = (NV % 2 == 0) ? 2 : 1;  // slots per lane: pairs as double2 when the rows are 16-byte aligned (NV even)
@@ -212,15 +179,11 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
                 const int bj = b + j * G;
                 const int64_t row = bj < nblocks ? bj : g;
                 if (W == 2) {
-                    double2 x;
-                    if (AGENT)
-                        x = make_double2(agent_load(partials + (row * NH + sp) * 2), agent_load(partials + (row * NH + sp) * 2 + 1));
-                    else
-                        x = reinterpret_cast<const double2*>(partials)[row * NH + sp];
+                    const double2 x = reinterpret_cast<const double2*>(partials)[row * NH + sp];
                     v0[j] = bj < nblocks ? x.x : 0.0;
                     v1[j] = bj < nblocks ? x.y : 0.0;
                 } else {
-                    const double x = AGENT ? agent_load(partials + row * NV + sp) : partials[row * NV + sp];
+                    const double x = partials[row * NV + sp];
                     v0[j] = bj < nblocks ? x : 0.0;
                     v1[j] = 0.0;
                 }
@@ -343,32 +306,18 @@ __global__ __launch_bounds__(kFB) void refine_init_decide_kernel(const double* _
     }
 }
 
-template <int NP, bool AGENT>
-__device__ __forceinline__ void refine_solve_body(const double* __restrict__ partials, int nblocks, RefineState* st);
-template <int NP, bool AGENT>
-__device__ __forceinline__ void refine_decide_body(const double* __restrict__ partials, int nblocks, RefineState* st, double* __restrict__ trace,
-                                                   int trace_rows);
-
 // ---------------------------------------------------------------------------------------------------
 // pass 1: Schur complement sums
 // ---------------------------------------------------------------------------------------------------
-// FOLD (experiment): the workgroup that arrives last runs the reduced solve in this launch (no refine_solve_kernel behind it)
-template <int NP, bool FOLD = false>
+template <int NP>
 __global__ __launch_bounds__(kFB) void refine_schur_kernel(int64_t m, const double4* __restrict__ xyuv,
                                                           const double* __restrict__ beta_in, const double* __restrict__ alpha,
                                                           const double* __restrict__ alpha_k,
                                                           const double* __restrict__ rho_a, const double* __restrict__ rho_b,
-                                                          const double* __restrict__ srho, RefineState* st,
-                                                          double* partials, unsigned* ticket) {
+                                                          const double* __restrict__ srho, const RefineState* __restrict__ st,
+                                                          double* __restrict__ partials) {
     using CT = Counts<NP>;
     __shared__ double s_red[kFB / 64][CT::NSCHUR];
-    if (FOLD) {  // the top-of-loop checks of the solve stage: every workgroup leaves, workgroup 0 records the termination
-        if (st->termination >= 0) return;
-        if (st->iteration >= kMaxIter || st->radius < kMinRadius) {
-            if (blockIdx.x == 0 && threadIdx.x == 0) st->termination = st->iteration >= kMaxIter ? RSDSFM_TERM_MAX_ITER : RSDSFM_TERM_MIN_RADIUS;
-            return;
-        }
-    }
     if (st->termination >= 0 || st->iteration >= kMaxIter || st->radius < kMinRadius) return;
     const PassShape ps = pass_shape(st, m);
     if (!ps.live) return;
@@ -417,17 +366,13 @@ __global__ __launch_bounds__(kFB) void refine_schur_kernel(int64_t m, const doub
             }
         }
     }
-    if (FOLD) {
-        if (block_reduce_publish<CT::NSCHUR>(acc, -1, s_red, partials + (int64_t)blockIdx.x * CT::NSCHUR, ticket, ps.grid))
-            refine_solve_body<NP, true>(partials, ps.grid, st);
-    } else {
-        block_reduce_store<CT::NSCHUR>(acc, -1, s_red, partials + (int64_t)blockIdx.x * CT::NSCHUR);
-    }
+    block_reduce_store<CT::NSCHUR>(acc, -1, s_red, partials + (int64_t)blockIdx.x * CT::NSCHUR);
 }
 
 // reduced system + Cholesky (one workgroup; the solve itself runs on one lane: NP <= 7)
-template <int NP, bool AGENT>
-__device__ __forceinline__ void refine_solve_body(const double* __restrict__ partials, int nblocks, RefineState* st) {
+template <int NP>
+__global__ __launch_bounds__(kFB) void refine_solve_kernel(const double* __restrict__ partials, int nblocks,
+                                                          RefineState* st) {
     using CT = Counts<NP>;
     __shared__ double s_red[kFB / 64][CT::NSCHUR];
     __shared__ double s[CT::NSCHUR];
@@ -450,7 +395,7 @@ __device__ __forceinline__ void refine_solve_body(const double* __restrict__ par
 #pragma unroll
         for (int c = 0; c < NP; ++c) sp_cur[c] = st->sp[c];
     }
-    reduce_partials<CT::NSCHUR, AGENT>(partials, nblocks >= 0 ? nblocks : st->grid, -1, s_red, s);
+    reduce_partials<CT::NSCHUR>(partials, nblocks >= 0 ? nblocks : st->grid, -1, s_red, s);
     if (threadIdx.x == 0) {
         st->iteration += 1;
         const double inv_radius = 1.0 / radius;
@@ -534,26 +479,17 @@ __device__ __forceinline__ void refine_solve_body(const double* __restrict__ par
     }
 }
 
-template <int NP>
-__global__ __launch_bounds__(kFB) void refine_solve_kernel(const double* __restrict__ partials, int nblocks, RefineState* st) {
-    refine_solve_body<NP, false>(partials, nblocks, st);
-}
-
 // ---------------------------------------------------------------------------------------------------
 // pass 2: back-substitution + candidate evaluation
 // ---------------------------------------------------------------------------------------------------
-template <int NP, bool FOLD = false>
+template <int NP>
 __global__ __launch_bounds__(kFB) void refine_backsub_kernel(int64_t m, const double4* __restrict__ xyuv,
                                                             const double* __restrict__ beta_in, const double* __restrict__ alpha,
                                                             const double* __restrict__ alpha_k, double* __restrict__ rho_a,
                                                             double* __restrict__ rho_b, const double* __restrict__ srho,
-                                                            RefineState* st, double* partials, unsigned* ticket, double* trace, int trace_rows) {
+                                                            const RefineState* __restrict__ st, double* __restrict__ partials) {
     using CT = Counts<NP>;
     __shared__ double s_red[kFB / 64][CT::NBACK];
-    if (FOLD && st->termination < 0 && !st->solve_ok) {  // the reduced system failed to factor: no pass, the decision alone (one workgroup)
-        if (blockIdx.x == 0) refine_decide_body<NP, false>(partials, 0, st, trace, trace_rows);
-        return;
-    }
     if (st->termination >= 0 || !st->solve_ok) return;
     const PassShape ps = pass_shape(st, m);
     if (!ps.live) return;
@@ -622,23 +558,18 @@ __global__ __launch_bounds__(kFB) void refine_backsub_kernel(int64_t m, const do
         acc[CT::BACK_MAX] = fmax(acc[CT::BACK_MAX], fabs(oc.Jr[0] * oc.r[0] + oc.Jr[1] * oc.r[1]));
         acc[CT::BACK_MAX + 1] += cd * cd;
     }
-    if (FOLD) {
-        if (block_reduce_publish<CT::NBACK>(acc, CT::BACK_MAX, s_red, partials + (int64_t)blockIdx.x * CT::NBACK, ticket, ps.grid))
-            refine_decide_body<NP, true>(partials, ps.grid, st, trace, trace_rows);
-    } else {
-        block_reduce_store<CT::NBACK>(acc, CT::BACK_MAX, s_red, partials + (int64_t)blockIdx.x * CT::NBACK);
-    }
+    block_reduce_store<CT::NBACK>(acc, CT::BACK_MAX, s_red, partials + (int64_t)blockIdx.x * CT::NBACK);
 }
 
-template <int NP, bool AGENT>
-__device__ __forceinline__ void refine_decide_body(const double* __restrict__ partials, int nblocks, RefineState* st, double* __restrict__ trace,
-                                                   int trace_rows) {
+template <int NP>
+__global__ __launch_bounds__(kFB) void refine_decide_kernel(const double* __restrict__ partials, int nblocks,
+                                                           RefineState* st, double* __restrict__ trace, int trace_rows) {
     using CT = Counts<NP>;
     __shared__ double s_red[kFB / 64][CT::NBACK];
     __shared__ double s[CT::NBACK];
     if (st->termination >= 0) return;
     const int solve_ok = st->solve_ok;
-    if (solve_ok) reduce_partials<CT::NBACK, AGENT>(partials, nblocks >= 0 ? nblocks : st->grid, CT::BACK_MAX, s_red, s);
+    if (solve_ok) reduce_partials<CT::NBACK>(partials, nblocks >= 0 ? nblocks : st->grid, CT::BACK_MAX, s_red, s);
     if (threadIdx.x != 0) return;
     // optional trace (rsdsfm_set_refine_trace): one row of kRefineTraceCols doubles per LM iteration, see include/rsdsfm.h
     double* tr = (trace && st->iteration >= 1 && st->iteration <= trace_rows) ? trace + (int64_t)(st->iteration - 1) * kRefineTraceCols : nullptr;
@@ -703,12 +634,6 @@ __device__ __forceinline__ void refine_decide_body(const double* __restrict__ pa
         st->radius = st->radius / st->decrease_factor;
         st->decrease_factor *= 2.0;
     }
-}
-
-template <int NP>
-__global__ __launch_bounds__(kFB) void refine_decide_kernel(const double* __restrict__ partials, int nblocks, RefineState* st,
-                                                           double* __restrict__ trace, int trace_rows) {
-    refine_decide_body<NP, false>(partials, nblocks, st, trace, trace_rows);
 }
 
 // nonlinearRefinement.cc:244-248
@@ -818,32 +743,16 @@ static int refine_iter_t(Ctx* c, const RefineBuffers& B) {
     const int grid = B.m_on_device ? refine_grid_cap(c) : refine_grid(c, B.m);
     const int64_t m_arg = B.m_on_device ? -1 : B.m;
     const int nb_arg = B.m_on_device ? -1 : grid;
-    // EXPERIMENT RSDSFM_REFINE_FOLD (bit 0: the decision in the tail of the back-substitution pass, bit 1: the reduced solve in the tail of
-    // the Schur pass): the workgroup that arrives last runs the single-workgroup stage inside the streaming launch
-    static const int fold = getenv("RSDSFM_REFINE_FOLD") ? atoi(getenv("RSDSFM_REFINE_FOLD")) : 0;
-    unsigned* tk = c->d_tickets + 48;
-    if (fold & 2)
-        hipLaunchKernelGGL((refine_schur_kernel<NP, true>), dim3(grid), dim3(kFB), 0, c->stream, m_arg, reinterpret_cast<const double4*>(B.uu), B.beta,
-                           B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials, tk);
-    else
-        hipLaunchKernelGGL((refine_schur_kernel<NP, false>), dim3(grid), dim3(kFB), 0, c->stream, m_arg, reinterpret_cast<const double4*>(B.uu), B.beta,
-                           B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials, tk);
+    hipLaunchKernelGGL(refine_schur_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, m_arg, reinterpret_cast<const double4*>(B.uu), B.beta,
+                       B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    if (!(fold & 2)) {
-        hipLaunchKernelGGL(refine_solve_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, nb_arg, B.state);
-        RSDSFM_HIP_CHECK(c, hipGetLastError());
-    }
-    if (fold & 1)
-        hipLaunchKernelGGL((refine_backsub_kernel<NP, true>), dim3(grid), dim3(kFB), 0, c->stream, m_arg, reinterpret_cast<const double4*>(B.uu), B.beta,
-                           B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials, tk + 1, c->d_refine_trace, c->refine_trace_rows);
-    else
-        hipLaunchKernelGGL((refine_backsub_kernel<NP, false>), dim3(grid), dim3(kFB), 0, c->stream, m_arg, reinterpret_cast<const double4*>(B.uu), B.beta,
-                           B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials, tk + 1, c->d_refine_trace, c->refine_trace_rows);
+    hipLaunchKernelGGL(refine_solve_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, nb_arg, B.state);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    if (!(fold & 1)) {
-        hipLaunchKernelGGL(refine_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, nb_arg, B.state, c->d_refine_trace, c->refine_trace_rows);
-        RSDSFM_HIP_CHECK(c, hipGetLastError());
-    }
+    hipLaunchKernelGGL(refine_backsub_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, m_arg, reinterpret_cast<const double4*>(B.uu), B.beta,
+                       B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(refine_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, nb_arg, B.state, c->d_refine_trace, c->refine_trace_rows);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
 
@@ -870,15 +779,13 @@ static int refine_stage_rows_t(Ctx* c, const RefineBuffers& B, int stage, double
         RSDSFM_HIP_CHECK(c, hipGetLastError());
         hipLaunchKernelGGL(refine_row_kernel<CT::NINIT>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, CT::INIT_MAX, row);
     } else if (stage == 1) {
-        hipLaunchKernelGGL((refine_schur_kernel<NP, false>), dim3(grid), dim3(kFB), 0, c->stream, B.m,
-                           reinterpret_cast<const double4*>(B.uu), B.beta, B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials,
-                           static_cast<unsigned*>(nullptr));
+        hipLaunchKernelGGL(refine_schur_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m,
+                           reinterpret_cast<const double4*>(B.uu), B.beta, B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
         RSDSFM_HIP_CHECK(c, hipGetLastError());
         hipLaunchKernelGGL(refine_row_kernel<CT::NSCHUR>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, -1, row);
     } else {
-        hipLaunchKernelGGL((refine_backsub_kernel<NP, false>), dim3(grid), dim3(kFB), 0, c->stream, B.m,
-                           reinterpret_cast<const double4*>(B.uu), B.beta, B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials,
-                           static_cast<unsigned*>(nullptr), static_cast<double*>(nullptr), 0);
+        hipLaunchKernelGGL(refine_backsub_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m,
+                           reinterpret_cast<const double4*>(B.uu), B.beta, B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
         RSDSFM_HIP_CHECK(c, hipGetLastError());
         hipLaunchKernelGGL(refine_row_kernel<CT::NBACK>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, CT::BACK_MAX, row);
     }

@@ -734,6 +734,14 @@ class _RectifyMixin:
         d = C.c_double
         self._check(self.lib.rsdsfm_depth_preview_dev(self._ctx, _np0(d_inl), C.c_int64(m), d(K[0]), d(K[1]), d(K[2]), d(K[3]), C.c_int32(rows), C.c_int32(cols), _dp(d_out)), "rsdsfm_depth_preview_dev")
 
+    def rectify_frame_dev(self, d_inl, m, d_img, d_depth_map, d_R, d_t, K, rows, cols, d_preview, d_gs, d_fixed, d_coords=None, mode=BACKPROJECT_RS,
+                          q5_mode=Q5_COMPAT, offset=1):
+        """main.cc:480-523 in one call (rsdsfm_rectify_frame_dev): depth image + back projection + crack interpolation, three launches"""
+        d = C.c_double
+        self._check(self.lib.rsdsfm_rectify_frame_dev(self._ctx, _np0(d_inl), C.c_int64(m), _dp(d_img), _dp(d_depth_map), _dp(d_R), _dp(d_t), d(K[0]), d(K[1]),
+                                                      d(K[2]), d(K[3]), C.c_int32(rows), C.c_int32(cols), int(mode), int(q5_mode), C.c_int32(offset),
+                                                      _dp(d_preview), _dp(d_gs), _np0(d_coords), _dp(d_fixed)), "rsdsfm_rectify_frame_dev")
+
 
 for _name, _fn in list(vars(_RectifyMixin).items()):
     if not _name.startswith("__"):

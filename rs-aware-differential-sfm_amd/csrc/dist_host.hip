@@ -646,6 +646,7 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
     res->ransac_k = h_best->hyp[6];
     double v[3] = {h_best->hyp[3], h_best->hyp[4], h_best->hyp[5]}, w[3] = {h_best->hyp[0], h_best->hyp[1], h_best->hyp[2]}, k = h_best->hyp[6];
     double* d_final = d_inl;
+    const double* d_zsum_global = nullptr;
 
     // ---- joint refinement: per LM iteration two staged passes (Schur sums -> reduced solve; back-substitution sums -> decision) ----
     if (prm->use_refinement) {
@@ -661,6 +662,7 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
         B.alpha_k = d_in_ak;
         B.inlier_idx = d_idx;
         B.flow_index_mode = RSDSFM_FLOW_GATHERED;
+        B.want_zsum = true;  // the rows of the refinement carry the sum of z: the sign test below needs no exchange of its own
         if (prm->flow_index_mode == RSDSFM_FLOW_COMPAT_RANK) {
             // The reference's default (quirk Q2): inlier i of the global list reads flow column i of the global list.  This rank's
             // inliers are the global ranks [prefix, prefix + m), and since a slab never holds more inliers than points those
@@ -752,6 +754,7 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
             if (launched > 4 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
         }
         D->refine_iters_hint = h_state->iteration;
+        d_zsum_global = &B.state->zsum;  // every rank holds the same GLOBAL sum of z of the final state (replicated decide stages)
         for (int i = 0; i < 3; ++i) v[i] = h_state->p[i], w[i] = h_state->p[3 + i];
         k = h_state->p[6];
         res->refine_summary.num_iterations = h_state->iteration;
@@ -768,13 +771,19 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
     {
         Arena ws2(c->d_ws);
         double* d_zpart = ws2.take<double>(1024);
-        rc = zsum_row_launch(c, d_final, m, d_zpart, d_zs);
-        if (rc != RSDSFM_OK) return rc;
-        rc = all_gather(c, D, d_zs, d_zs_all, sizeof(double));
-        if (rc != RSDSFM_OK) return rc;
+        const double* d_zsums = d_zsum_global;
+        int nz = 1;
+        if (!d_zsums) {  // no refinement ran: the slabs' sums of z travel in an exchange of their own
+            rc = zsum_row_launch(c, d_final, m, d_zpart, d_zs);
+            if (rc != RSDSFM_OK) return rc;
+            rc = all_gather(c, D, d_zs, d_zs_all, sizeof(double));
+            if (rc != RSDSFM_OK) return rc;
+            d_zsums = d_zs_all;
+            nz = R;
+        }
         double* d_slab = d_gather + (size_t)rank * cap;
         if (cap > Ns) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_slab + Ns, 0, sizeof(double) * (cap - Ns), c->stream));  // columns past the image: zeros
-        rc = depth_map_slab_launch(c, d_final, m, d_zs_all, R, m_total, v, fx, fy, cx, cy, rows, col0, sc, d_slab, nullptr, d_ys, d_header, h_header);
+        rc = depth_map_slab_launch(c, d_final, m, d_zsums, nz, m_total, v, fx, fy, cx, cy, rows, col0, sc, d_slab, nullptr, d_ys, d_header, h_header);
         if (rc != RSDSFM_OK) return rc;
         rc = all_gather(c, D, d_slab, d_gather, sizeof(double) * cap);  // the one data-path collective
         if (rc != RSDSFM_OK) return rc;

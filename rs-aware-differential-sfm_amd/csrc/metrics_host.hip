@@ -8,9 +8,10 @@
 #include "rsdsfm_internal.hpp"
 
 namespace rsdsfm {
+int metrics_blocks_max();
 int reprojection_error_launch(Ctx* c, const float* d_est, const double* d_gt_depth, const double* d_est_depth, const double* d_R,
                               const double* d_t, double fx, double fy, double cx, double cy, int rows, int cols, double max_norm,
-                              unsigned char* d_error_image, double* d_partials, double* d_header);
+                              unsigned char* d_error_image, double* d_scale_partials, double* d_header, double* d_error_partials, int* error_rows);
 }
 
 using namespace rsdsfm;
@@ -49,24 +50,33 @@ int rsdsfm_reprojection_error_dev(rsdsfm_ctx* ctx, const float* d_est_coords, co
         return RSDSFM_OK;
     }
     if (!d_est_coords || !d_gt_depth || !d_est_depth || !d_R_abs_rows9 || !d_t_abs_rows3) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
-    int rc = ensure_ws(c, Arena::need(8 * 3 * 2048) + Arena::need(64) + 1024);
+    const size_t G = (size_t)metrics_blocks_max();
+    int rc = ensure_ws(c, Arena::need(8 * 3 * G) + 1024);
     if (rc != RSDSFM_OK) return rc;
-    rc = ensure_pinned(c, 64);
+    rc = ensure_pinned(c, 8 * (8 + 3 * G));
     if (rc != RSDSFM_OK) return rc;
     Arena ws(c->d_ws);
-    double* d_partials = ws.take<double>(3 * 2048);
-    double* d_header = ws.take<double>(5);
-    rc = reprojection_error_launch(c, d_est_coords, d_gt_depth, d_est_depth, d_R_abs_rows9, d_t_abs_rows3, fx, fy, cx, cy, rows, cols, max_norm,
-                                   d_error_image_or_null, d_partials, d_header);
-    if (rc != RSDSFM_OK) return rc;
+    double* d_scale_partials = ws.take<double>(3 * G);
+    // the header (8 doubles) and the error partials behind it are written by the second pass straight into host-mapped pinned memory
+    // (3 doubles per workgroup over the host link): no copy command behind the launches, the host only synchronises
     double* h = static_cast<double*>(c->h_pinned);
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h, d_header, 5 * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    int erows = 0;
+    rc = reprojection_error_launch(c, d_est_coords, d_gt_depth, d_est_depth, d_R_abs_rows9, d_t_abs_rows3, fx, fy, cx, cy, rows, cols, max_norm,
+                                   d_error_image_or_null, d_scale_partials, h, h + 8, &erows);
+    if (rc != RSDSFM_OK) return rc;
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    // the error sums: the workgroups' partials in workgroup order (a fixed order: the result does not depend on the dispatch); counts are exact
+    double sum_error = 0.0, error_inliers = 0.0;
+    for (int b = 0; b < erows; ++b) {
+        sum_error += h[8 + 3 * b];
+        error_inliers += h[8 + 3 * b + 1];
+    }
     stats->scale = h[0];
     stats->scale_inliers = (int64_t)h[1];
     stats->number_outliers = (int64_t)h[2];
-    stats->sum_error = h[3];
-    stats->error_inliers = (int64_t)h[4];
+    stats->sum_error = sum_error;
+    stats->error_inliers = (int64_t)error_inliers;
+    h[3] = sum_error, h[4] = error_inliers;
     stats->mean_error = h[3] * 1.0 / h[4];
     return RSDSFM_OK;
 }

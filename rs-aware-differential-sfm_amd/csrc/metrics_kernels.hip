@@ -5,9 +5,11 @@
 //   reproj_scale_kernel   per pixel: ground-truth world point (planeToSpace + cameraToWorldFrame with the absolute
 //                         pose of the pixel's scanline, rounded to float like the reference's cv::Vec3f), the three
 //                         float ratios estimate / truth, outlier rule |ratio| > 10 -> partials {sum, inliers, outliers}
-//   reproj_scale_decide   fixed-order reduction -> scale = sum / inliers (device-resident header)
-//   reproj_error_kernel   per pixel: || estimate / scale - truth ||, summed where finite and < 50, optional 8-bit image
-//   reproj_error_decide   fixed-order reduction -> {sum_error, error_inliers}
+//   reproj_error_kernel   every workgroup first reduces those partials itself (fixed order: all obtain the same scale = sum / inliers,
+//                         no single-workgroup launch in between); per pixel: || estimate / scale - truth ||, summed where finite
+//                         and < 50, optional 8-bit image -> partials {sum_error, error_inliers}
+//   the host adds the (<= 512) error partials in workgroup order after ONE device-to-host copy (round 3 ran four launches -- two
+//   streaming passes over 2048 workgroups, each followed by a single-workgroup reduction -- and then copied a 40-byte header)
 // Pixels are walked in 16 x 16 tiles with the lanes along y (depth maps are column-major); the estimated points are
 // row-major float3.  HBM-bound streaming passes: 28 B/pixel read per pass (12 B point + 2 x 8 B depth), 1 B written.
 // Per-pixel arithmetic mirrors oracle/rsdsfm_oracle.c (rso_reprojection_error) exactly; the two global sums differ
@@ -23,6 +25,7 @@ namespace rsdsfm {
 
 namespace {
 constexpr int kMB = 256;
+constexpr int kMetricsMaxBlocks = 1024;  // four workgroups per CU (latency-bound passes: 16 waves per CU); every workgroup of the second pass reads all partial rows of the first (24 KB)
 
 __device__ __forceinline__ int trunc_int_m(double x) {
     if (!(x > -2147483649.0 && x < 2147483648.0)) return INT32_MIN;
@@ -115,9 +118,8 @@ __global__ __launch_bounds__(kMB) void reproj_scale_kernel(const float* __restri
     block_reduce3(sum, inl, outl, partials);
 }
 
-// header: [0] scale, [1] scale inliers, [2] outliers, [3] sum_error, [4] error inliers
-__global__ __launch_bounds__(kMB) void reproj_decide_kernel(const double* __restrict__ partials, int nblocks, int stage,
-                                                           double* __restrict__ header) {
+// fixed-order reduction of partials[nblocks][3] by one workgroup: thread i adds rows i, i + 256, ...; waves by DPP; the four waves in order
+__device__ __forceinline__ void reduce3(const double* __restrict__ partials, int nblocks, double (&r)[3]) {
     __shared__ double s_red[3][kMB / 64];
     double a = 0.0, b = 0.0, c2 = 0.0;
     for (int i = threadIdx.x; i < nblocks; i += kMB) {
@@ -132,26 +134,21 @@ __global__ __launch_bounds__(kMB) void reproj_decide_kernel(const double* __rest
         s_red[2][threadIdx.x >> 6] = c2;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double r[3];
-        for (int k = 0; k < 3; ++k) r[k] = ((s_red[k][0] + s_red[k][1]) + s_red[k][2]) + s_red[k][3];
-        if (stage == 0) {
-            header[0] = r[0] / r[1];  // sum / double(inliers)
-            header[1] = r[1];
-            header[2] = r[2];
-        } else {
-            header[3] = r[0];
-            header[4] = r[1];
-        }
-    }
+    for (int k = 0; k < 3; ++k) r[k] = ((s_red[k][0] + s_red[k][1]) + s_red[k][2]) + s_red[k][3];
+    __syncthreads();
 }
 
+// header (written by workgroup 0): [0] scale, [1] scale inliers, [2] outliers
 __global__ __launch_bounds__(kMB) void reproj_error_kernel(const float* __restrict__ est, const double* __restrict__ gt_depth,
                                                           const double* __restrict__ est_depth, const double* __restrict__ R,
                                                           const double* __restrict__ t, double fx, double fy, double cx, double cy,
-                                                          int rows, int cols, const double* __restrict__ header, double max_norm,
-                                                          double* __restrict__ partials, unsigned char* __restrict__ error_image) {
-    const double scale = header[0];
+                                                          int rows, int cols, const double* __restrict__ scale_partials, int nscale,
+                                                          double* __restrict__ header, double max_norm, double* __restrict__ partials,
+                                                          unsigned char* __restrict__ error_image) {
+    double sc3[3];
+    reduce3(scale_partials, nscale, sc3);
+    const double scale = sc3[0] / sc3[1];  // sum / double(inliers) (camera.cc:640)
+    if (blockIdx.x == 0 && threadIdx.x == 0) header[0] = scale, header[1] = sc3[1], header[2] = sc3[2];
     const int tiles_x = (cols + 15) / 16;
     const int64_t ntiles = (int64_t)tiles_x * ((rows + 15) / 16);
     double sum = 0.0;
@@ -185,24 +182,24 @@ __global__ __launch_bounds__(kMB) void reproj_error_kernel(const float* __restri
 
 static inline int metrics_grid(int rows, int cols) {
     const int64_t tiles = (int64_t)((cols + 15) / 16) * ((rows + 15) / 16);
-    return (int)std::min<int64_t>(2048, std::max<int64_t>(1, tiles));
+    return (int)std::min<int64_t>(kMetricsMaxBlocks, std::max<int64_t>(1, tiles));
 }
 
-// d_partials: >= 3 * 2048 doubles; d_header: 5 doubles
+int metrics_blocks_max() { return kMetricsMaxBlocks; }
+
+// d_scale_partials, d_error_partials: >= 3 * metrics_blocks_max() doubles each; d_header: 8 doubles.  *error_rows = rows of d_error_partials
+// the caller adds up (in row order)
 int reprojection_error_launch(Ctx* c, const float* d_est, const double* d_gt_depth, const double* d_est_depth, const double* d_R,
                               const double* d_t, double fx, double fy, double cx, double cy, int rows, int cols, double max_norm,
-                              unsigned char* d_error_image, double* d_partials, double* d_header) {
+                              unsigned char* d_error_image, double* d_scale_partials, double* d_header, double* d_error_partials, int* error_rows) {
     const int grid = metrics_grid(rows, cols);
     hipLaunchKernelGGL(reproj_scale_kernel, dim3(grid), dim3(kMB), 0, c->stream, d_est, d_gt_depth, d_est_depth, d_R, d_t, fx, fy, cx, cy,
-                       rows, cols, d_partials);
-    RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(reproj_decide_kernel, dim3(1), dim3(kMB), 0, c->stream, d_partials, grid, 0, d_header);
+                       rows, cols, d_scale_partials);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(reproj_error_kernel, dim3(grid), dim3(kMB), 0, c->stream, d_est, d_gt_depth, d_est_depth, d_R, d_t, fx, fy, cx, cy,
-                       rows, cols, d_header, max_norm, d_partials, d_error_image);
+                       rows, cols, d_scale_partials, grid, d_header, max_norm, d_error_partials, d_error_image);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(reproj_decide_kernel, dim3(1), dim3(kMB), 0, c->stream, d_partials, grid, 1, d_header);
-    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    *error_rows = grid;
     return RSDSFM_OK;
 }
 

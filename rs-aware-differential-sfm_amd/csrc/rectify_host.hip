@@ -104,6 +104,26 @@ int rsdsfm_depth_preview_dev(rsdsfm_ctx* ctx, const double* d_inl, int64_t m, do
     return depth_preview_launch(c, d_inl, m, fx, fy, cx, cy, rows, cols, d_depth_est, static_cast<double*>(c->d_ws));
 }
 
+int rsdsfm_rectify_frame_dev(rsdsfm_ctx* ctx, const double* d_inl, int64_t m, const uint8_t* d_image_bgr, const double* d_depth_map,
+                             const double* d_R_rows9, const double* d_t_rows3, double fx, double fy, double cx, double cy, int32_t rows, int32_t cols,
+                             int mode, int q5_mode, int32_t offset, uint8_t* d_depth_est, uint8_t* d_gs_image_bgr, float* d_coords3d_or_null,
+                             uint8_t* d_fixed_image_bgr) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
+    if (m < 0 || m > (int64_t)INT32_MAX || rows < 0 || cols < 0 || offset < 0 || (int64_t)rows * cols > (int64_t)INT32_MAX) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
+    if (mode != RSDSFM_BACKPROJECT_RS && mode != RSDSFM_BACKPROJECT_GS) return fail(c, RSDSFM_ERR_INVALID, "unknown back-projection mode");
+    if (q5_mode != RSDSFM_Q5_COMPAT && q5_mode != RSDSFM_Q5_FIXED) return fail(c, RSDSFM_ERR_INVALID, "unknown q5_mode");
+    if ((int64_t)rows * cols == 0) return RSDSFM_OK;
+    if ((m > 0 && !d_inl) || !d_image_bgr || !d_depth_map || !d_R_rows9 || !d_t_rows3 || !d_depth_est || !d_gs_image_bgr || !d_fixed_image_bgr ||
+        d_gs_image_bgr == d_fixed_image_bgr)
+        return fail(c, RSDSFM_ERR_INVALID, "null or aliased device pointer");
+    int rc = ensure_ws(c, Arena::need(8 * 2048) + 1024);
+    if (rc != RSDSFM_OK) return rc;
+    return rectify_frame_launch(c, d_inl, m, d_image_bgr, d_depth_map, d_R_rows9, d_t_rows3, fx, fy, cx, cy, rows, cols, mode, q5_mode, offset,
+                                d_depth_est, d_gs_image_bgr, d_coords3d_or_null, d_fixed_image_bgr, static_cast<double*>(c->d_ws));
+}
+
 int rsdsfm_depth_preview(rsdsfm_ctx* ctx, const double* inl, int64_t m, double fx, double fy, double cx, double cy, int32_t rows,
                          int32_t cols, uint8_t* depth_est) {
     if (!ctx) return RSDSFM_ERR_INVALID;

@@ -211,10 +211,10 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
 template <int NP>
 struct Counts {
     static constexpr int TRI = NP * (NP + 1) / 2;
-    static constexpr int NINIT = 1 + NP + NP + 1 + 1;       // cost2, colsq[NP], gp[NP], gmax_rho (max), xsq_rho
+    static constexpr int NINIT = 1 + NP + NP + 1 + 1 + 1;   // cost2, colsq[NP], gp[NP], gmax_rho (max), xsq_rho, sum of 1 / rho (want_zsum)
     static constexpr int INIT_MAX = 1 + 2 * NP;
     static constexpr int NSCHUR = 2 * TRI + 2 * NP;         // FtF tri, C tri, Ftb, cvec
-    static constexpr int NBACK = 3 + 1 + NP + 1 + 1;        // model, stepsq_rho, ccost2 | cost2@cand (= ccost2), gp[NP], gmax_rho, xsq_rho
+    static constexpr int NBACK = 3 + 1 + NP + 1 + 1 + 1 + 1;  // model, stepsq_rho, ccost2 | cost2@cand (= ccost2), gp[NP], gmax_rho, xsq_rho, sum of 1 / rho@cand (want_zsum), one unused slot (keeps the rows of NP = 6 an even number of doubles: 16-byte loads in reduce_partials)
     static constexpr int BACK_MAX = 3 + 1 + NP;
 };
 
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kFB) void refine_init_kernel(const double2* __restr
                                                          const RefineState* __restrict__ st, double4* __restrict__ xyuv,
                                                          double* __restrict__ beta_out, double* __restrict__ rho0,
                                                          double* __restrict__ srho, double* __restrict__ partials,
-                                                         int* __restrict__ bad_index) {
+                                                         int* __restrict__ bad_index, int want_zsum) {
     using CT = Counts<NP>;
     __shared__ double s_red[kFB / 64][CT::NINIT];
     const PassShape ps = pass_shape(st, m);
@@ -271,6 +271,7 @@ __global__ __launch_bounds__(kFB) void refine_init_kernel(const double2* __restr
         srho[i] = 1.0 / (1.0 + sqrt(o.Jr[0] * o.Jr[0] + o.Jr[1] * o.Jr[1]));
         acc[CT::INIT_MAX] = fmax(acc[CT::INIT_MAX], fabs(o.Jr[0] * o.r[0] + o.Jr[1] * o.r[1]));
         acc[CT::INIT_MAX + 1] += rho * rho;
+        if (want_zsum) acc[CT::INIT_MAX + 2] += 1.0 / rho;  // z as refine_finish_kernel forms it
     }
     block_reduce_store<CT::NINIT>(acc, CT::INIT_MAX, s_red, partials + (int64_t)blockIdx.x * CT::NINIT);
 }
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(kFB) void refine_init_decide_kernel(const double* _
             xsq += st->p[c] * st->p[c];
         }
         st->cost = 0.5 * s[0];
+        st->zsum = s[CT::INIT_MAX + 2];
         st->initial_cost = st->cost;
         st->gmax = gmax;
         st->x_norm = sqrt(xsq);
@@ -487,7 +489,7 @@ __global__ __launch_bounds__(kFB) void refine_backsub_kernel(int64_t m, const do
                                                             const double* __restrict__ beta_in, const double* __restrict__ alpha,
                                                             const double* __restrict__ alpha_k, double* __restrict__ rho_a,
                                                             double* __restrict__ rho_b, const double* __restrict__ srho,
-                                                            const RefineState* __restrict__ st, double* __restrict__ partials) {
+                                                            const RefineState* __restrict__ st, double* __restrict__ partials, int want_zsum) {
     using CT = Counts<NP>;
     __shared__ double s_red[kFB / 64][CT::NBACK];
     if (st->termination >= 0 || !st->solve_ok) return;
@@ -557,6 +559,7 @@ __global__ __launch_bounds__(kFB) void refine_backsub_kernel(int64_t m, const do
         for (int c = 0; c < NP; ++c) acc[4 + c] += oc.Jp[0][c] * oc.r[0] + oc.Jp[1][c] * oc.r[1];
         acc[CT::BACK_MAX] = fmax(acc[CT::BACK_MAX], fabs(oc.Jr[0] * oc.r[0] + oc.Jr[1] * oc.r[1]));
         acc[CT::BACK_MAX + 1] += cd * cd;
+        if (want_zsum) acc[CT::BACK_MAX + 2] += 1.0 / cd;
     }
     block_reduce_store<CT::NBACK>(acc, CT::BACK_MAX, s_red, partials + (int64_t)blockIdx.x * CT::NBACK);
 }
@@ -620,6 +623,7 @@ __global__ __launch_bounds__(kFB) void refine_decide_kernel(const double* __rest
             if (fabs(s[4 + c]) > gmax) gmax = fabs(s[4 + c]);
         }
         st->cur ^= 1;
+        st->zsum = s[CT::BACK_MAX + 2];
         st->cost = 0.5 * s[3];
         st->gmax = gmax;
         st->x_norm = sqrt(xsq);
@@ -731,7 +735,7 @@ static int refine_init_t(Ctx* c, const RefineBuffers& B) {
     const int64_t m_arg = B.m_on_device ? -1 : B.m;
     hipLaunchKernelGGL(refine_init_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, reinterpret_cast<const double2*>(B.flow), B.n_flow,
                        m_arg, B.inl, B.alpha, B.alpha_k, B.inlier_idx, B.flow_index_mode, B.state, reinterpret_cast<double4*>(B.uu),
-                       B.beta, B.rho_a, B.srho, B.partials, B.bad_index);
+                       B.beta, B.rho_a, B.srho, B.partials, B.bad_index, B.want_zsum ? 1 : 0);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(refine_init_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, B.m_on_device ? -1 : grid, B.state, m_arg);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
@@ -749,7 +753,7 @@ static int refine_iter_t(Ctx* c, const RefineBuffers& B) {
     hipLaunchKernelGGL(refine_solve_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, nb_arg, B.state);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(refine_backsub_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, m_arg, reinterpret_cast<const double4*>(B.uu), B.beta,
-                       B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
+                       B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials, B.want_zsum ? 1 : 0);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(refine_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, nb_arg, B.state, c->d_refine_trace, c->refine_trace_rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
@@ -775,7 +779,7 @@ static int refine_stage_rows_t(Ctx* c, const RefineBuffers& B, int stage, double
     if (stage == 0) {
         hipLaunchKernelGGL(refine_init_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, reinterpret_cast<const double2*>(B.flow),
                            B.n_flow, B.m, B.inl, B.alpha, B.alpha_k, B.inlier_idx, B.flow_index_mode, B.state,
-                           reinterpret_cast<double4*>(B.uu), B.beta, B.rho_a, B.srho, B.partials, B.bad_index);
+                           reinterpret_cast<double4*>(B.uu), B.beta, B.rho_a, B.srho, B.partials, B.bad_index, B.want_zsum ? 1 : 0);
         RSDSFM_HIP_CHECK(c, hipGetLastError());
         hipLaunchKernelGGL(refine_row_kernel<CT::NINIT>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, CT::INIT_MAX, row);
     } else if (stage == 1) {
@@ -785,7 +789,7 @@ static int refine_stage_rows_t(Ctx* c, const RefineBuffers& B, int stage, double
         hipLaunchKernelGGL(refine_row_kernel<CT::NSCHUR>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, -1, row);
     } else {
         hipLaunchKernelGGL(refine_backsub_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m,
-                           reinterpret_cast<const double4*>(B.uu), B.beta, B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
+                           reinterpret_cast<const double4*>(B.uu), B.beta, B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials, B.want_zsum ? 1 : 0);
         RSDSFM_HIP_CHECK(c, hipGetLastError());
         hipLaunchKernelGGL(refine_row_kernel<CT::NBACK>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, CT::BACK_MAX, row);
     }

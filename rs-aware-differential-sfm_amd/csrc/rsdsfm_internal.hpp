@@ -344,6 +344,9 @@ struct RefineState {
     // m < 0 / nblocks < 0 take these
     int64_t m;
     int32_t grid, _pad;
+    // sum of z = 1 / rho over the inliers at the CURRENT state (what refine_finish_kernel writes), kept by the decide stages when the passes
+    // are asked for it (RefineBuffers::want_zsum: the column-tiled solve, whose mean-z sign test main.cc:466-472 then needs no exchange of its own)
+    double zsum;
 };
 struct RefineBuffers {
     const double* flow;  // 2 x n_flow
@@ -364,6 +367,7 @@ struct RefineBuffers {
     int* bad_index;
     RefineState* state_host = nullptr;  // frame solve: host-mapped copy of the state (+ flag) written by refine_finish_kernel
     double* zpartials = nullptr;  // frame solve: refine_finish_kernel also leaves its per-workgroup sums of z here (refine_finish_grid entries)
+    bool want_zsum = false;       // the streaming passes also sum 1 / rho (one division per inlier and pass) into the last slot of their rows -> RefineState::zsum
 };
 size_t ransac_pinned_bytes(int T);
 // see ransac_device (ransac_host.hip): caller's work enqueued behind the speculated final stage, given the device-resident result
@@ -463,6 +467,9 @@ namespace rsdsfm {
 int back_project_launch(Ctx* c, const unsigned char* d_img, const double* d_depth_cm, const double* d_R, const double* d_t, double fx,
                         double fy, double cx, double cy, int rows, int cols, int mode, int q5_mode, unsigned char* d_gs, float* d_c3d);
 int interpolate_cracky_launch(Ctx* c, const unsigned char* d_in, int rows, int cols, int offset, unsigned char* d_out);
+int rectify_frame_launch(Ctx* c, const double* d_inl, int64_t m, const unsigned char* d_img, const double* d_depth_cm, const double* d_R,
+                         const double* d_t, double fx, double fy, double cx, double cy, int rows, int cols, int mode, int q5_mode, int offset,
+                         unsigned char* d_preview, unsigned char* d_gs, float* d_c3d, unsigned char* d_fixed, double* d_partials);
 int depth_preview_launch(Ctx* c, const double* d_inl, int64_t m, double fx, double fy, double cx, double cy, int rows, int cols,
                          unsigned char* d_out, double* d_partials);
 }  // namespace rsdsfm

@@ -179,6 +179,16 @@ def test_preview_equals_oracle_and_device_chain(oracle, rsdsfm):
             s.back_project_dev(t_img.data_ptr(), dm.data_ptr(), R.data_ptr(), t.data_ptr(), K, rows, cols, gs.data_ptr(), c3.data_ptr())
             s.interpolate_cracky_dev(gs.data_ptr(), rows, cols, fixed.data_ptr(), offset=1)
             s.synchronize()
+            # the same three stages in ONE call (rsdsfm_rectify_frame_dev: claims in one launch, writes in one launch): the same bytes
+            gs2, fixed2, c32, prev2 = torch.zeros_like(gs), torch.zeros_like(fixed), torch.zeros_like(c3), torch.zeros_like(prev)
+            for rep in range(2):  # (twice: the claim maps' epochs advance)
+                s.rectify_frame_dev(r["d_inliers"], r["num_inliers"], t_img.data_ptr(), dm.data_ptr(), R.data_ptr(), t.data_ptr(), K, rows, cols,
+                                    prev2.data_ptr(), gs2.data_ptr(), fixed2.data_ptr(), c32.data_ptr(), offset=1)
+            s.synchronize()
+            assert torch.equal(gs2, gs) and torch.equal(fixed2, fixed) and torch.equal(prev2, prev) and torch.equal(c32.view(torch.int32), c3.view(torch.int32))
+            with pytest.raises(rsdsfm.RsdsfmError):
+                s.rectify_frame_dev(r["d_inliers"], r["num_inliers"], t_img.data_ptr(), dm.data_ptr(), R.data_ptr(), t.data_ptr(), K, rows, cols,
+                                    prev2.data_ptr(), gs2.data_ptr(), gs2.data_ptr(), offset=1)  # gs and fixed alias
             m = r["num_inliers"]
             inl_t = torch.empty(3 * m, dtype=torch.float64, device=dev)
             import ctypes
@@ -192,6 +202,37 @@ def test_preview_equals_oracle_and_device_chain(oracle, rsdsfm):
         assert np.array_equal(fixed.cpu().numpy(), oracle.interpolate_cracky(gs_o, 1))
         assert np.array_equal(prev.cpu().numpy(), oracle.depth_preview(inl_h, *K, rows, cols))
         assert (prev.cpu().numpy() != 0).sum() == (dm_h != 0).sum()
+
+
+@pytest.mark.parametrize("rows,cols,m", [(33, 70, 5000), (16, 64, 0), (150, 200, 40000), (720, 1280, 921600)])
+def test_rectify_frame_one_call_equals_the_oracle(oracle, rsdsfm, rows, cols, m):
+    """rsdsfm_rectify_frame_dev on ragged sizes, no inliers, colliding inliers and the full 1280x720 frame: every output equals the oracle's
+    (depth image, global-shutter image, float3 world points, interpolated image: bytes / bits)"""
+    import torch
+
+    rng = np.random.default_rng(rows * 7 + cols)
+    dev = torch.device("cuda", 0)
+    K = (0.8 * cols, 0.8 * cols, cols / 2.0 - 0.3, rows / 2.0 + 0.2)
+    img = rng.integers(16, 256, size=(rows, cols, 3), dtype=np.uint8)
+    img[rng.random((rows, cols)) < 0.02] = 1  # marker pixels (rsframe.cc:816)
+    depth = rng.uniform(0.6, 2.5, size=(rows, cols))
+    inl = np.column_stack([rng.uniform(-0.7, 0.7, m), rng.uniform(-0.45, 0.45, m), rng.normal(2.0, 1.0, m)]) if m else np.zeros((0, 3))
+    with rsdsfm.Solver(0) as s:
+        R, t = s.pose_table(np.array([0.3, -0.2, 0.1]), np.array([0.02, 0.03, -0.04]), 0.1, 0.9, rows)
+        R = R.reshape(rows, 9)
+        tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        d_img, d_dm, d_R, d_t, d_inl = tt(img), tt(depth.T), tt(R), tt(t), tt(inl if m else np.zeros((1, 3)))
+        prev = torch.zeros((rows, cols), dtype=torch.uint8, device=dev)
+        gs, fixed = torch.zeros((rows, cols, 3), dtype=torch.uint8, device=dev), torch.zeros((rows, cols, 3), dtype=torch.uint8, device=dev)
+        c3 = torch.zeros((rows, cols, 3), dtype=torch.float32, device=dev)
+        for off in (1, 2):
+            s.rectify_frame_dev(d_inl.data_ptr(), m, d_img.data_ptr(), d_dm.data_ptr(), d_R.data_ptr(), d_t.data_ptr(), K, rows, cols, prev.data_ptr(),
+                                gs.data_ptr(), fixed.data_ptr(), c3.data_ptr(), offset=off)
+            s.synchronize()
+            gs_o, c3_o = oracle.back_project(img, depth, R, t, *K)
+            assert np.array_equal(gs.cpu().numpy(), gs_o) and np.array_equal(c3.cpu().numpy().view(np.uint32), c3_o.view(np.uint32))
+            assert np.array_equal(fixed.cpu().numpy(), oracle.interpolate_cracky(gs_o, off))
+            assert np.array_equal(prev.cpu().numpy(), oracle.depth_preview(inl, *K, rows, cols))
 
 
 def test_rectify_argument_errors(rsdsfm):

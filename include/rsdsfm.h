@@ -469,7 +469,10 @@ int rsdsfm_tiled_slab_bounds(int32_t cols, int32_t nranks, int32_t rank, int32_t
 typedef struct rsdsfm_tiled_info {
     int32_t nranks, rank, col0, slab_cols;
     int64_t shard_points, shard_inliers;          /* of this rank's slab                                              */
-    int32_t host_syncs, collectives, ransac_rounds, _pad; /* diagnostics of the call                                   */
+    int32_t host_syncs, collectives, ransac_rounds;       /* diagnostics of the call                                   */
+    int32_t path_flags; /* bit 0: the ranks went ahead on the point counts of a dense frame instead of waiting for the counts exchange
+                         * (the previous solve of this shape on the communicator succeeded everywhere, all its slabs dense); bit 1: that
+                         * assumption did not hold for this frame and the solve started over through the counts / status exchange */
 } rsdsfm_tiled_info;
 
 /* d_img_slab: row-major [rows][slab_cols][2] slab of this rank (DEVICE); cols = width of the WHOLE image.  params->

@@ -76,7 +76,7 @@ class FrameResult(C.Structure):
 
 class TiledInfo(C.Structure):
     _fields_ = [("nranks", C.c_int32), ("rank", C.c_int32), ("col0", C.c_int32), ("slab_cols", C.c_int32), ("shard_points", C.c_int64),
-                ("shard_inliers", C.c_int64), ("host_syncs", C.c_int32), ("collectives", C.c_int32), ("ransac_rounds", C.c_int32), ("_pad", C.c_int32)]
+                ("shard_inliers", C.c_int64), ("host_syncs", C.c_int32), ("collectives", C.c_int32), ("ransac_rounds", C.c_int32), ("path_flags", C.c_int32)]
 
 
 ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)

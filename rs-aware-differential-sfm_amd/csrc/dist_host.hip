@@ -133,6 +133,11 @@ struct Dist {
     // result (every rank derives them from the same replicated decisions, so all ranks enqueue the same collectives)
     int score_idle = kScoreIdleLimit;  // consecutive solves (saturating) that did not need the separate scoring pass behind round 0 (rsdsfm_internal.hpp)
     int refine_iters_hint = -1;  // LM iterations of the refinement (-1: none yet)
+    // "warm": the previous solve on this communicator succeeded on EVERY rank with exactly this shape, so this one needs no allocation on any
+    // rank and its setup cannot fail for lack of memory; with dense_hint (every slab of that solve kept all its pixels) the ranks then
+    // go on with the counts a dense frame has instead of waiting for the counts exchange (checked with the RANSAC's first host read)
+    bool warm = false, dense_hint = false;
+    int warm_rows = 0, warm_cols = 0, warm_T = 0, warm_flags = 0;
 };
 
 Dist* dist_of(Ctx* c, bool create) {
@@ -201,6 +206,7 @@ int reserve_xchg(Ctx* c, Dist* D, int nranks) { return ensure_dev(c, &D->d_xchg,
 void reset_hints(Dist* D) {
     D->score_idle = kScoreIdleLimit;
     D->refine_iters_hint = -1;
+    D->warm = D->dense_hint = false;
 }
 
 int sync(Ctx* c, Dist* D) {
@@ -211,11 +217,15 @@ int sync(Ctx* c, Dist* D) {
 
 // the 9 T sampled points as the minimal solver wants them (q9, u9: [9T][2]; a9, ak9: [9T]), one contiguous block of 54 T doubles:
 // a rank writes the points it owns and zeros elsewhere, so the sum over ranks has exactly one non-zero term per entry
+// tail (optional): out[6 * count + r] = this rank's point count for r == rank (as a double: exact), 0 for the other ranks -- the counts
+// exchange rides in the same all-reduce when the ranks went ahead on the counts of a dense frame (my_count: the flatten's device word)
 __global__ __launch_bounds__(256) void pack_samples_kernel(const double2* __restrict__ q, const double2* __restrict__ u,
                                                           const double* __restrict__ alpha, const double* __restrict__ alpha_k,
                                                           int64_t n_local, int64_t offset, const int32_t* __restrict__ samples,
-                                                          int count, double* __restrict__ out) {
+                                                          int count, double* __restrict__ out, const int64_t* __restrict__ my_count, int rank,
+                                                          int nranks) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (my_count && j < nranks) out[6 * (size_t)count + j] = j == rank ? (double)*my_count : 0.0;
     if (j >= count) return;
     const int64_t loc = (int64_t)samples[j] - offset;
     const bool mine = loc >= 0 && loc < n_local;
@@ -447,7 +457,7 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
 
     // ---- small exchange buffers ----
     const int row_max = std::max({nsr * batch, refine_stage_row_doubles(np, 0), refine_stage_row_doubles(np, 1), refine_stage_row_doubles(np, 2), 2 * batch});
-    size_t need_d = 2 * Arena::need(8 * (size_t)R + 64) + Arena::need(4 * 9 * (size_t)Tn) + Arena::need(8 * 54 * (size_t)Tn) + Arena::need(8 * 8 * (size_t)Tn) +
+    size_t need_d = 2 * Arena::need(8 * (size_t)R + 64) + Arena::need(4 * 9 * (size_t)Tn) + Arena::need(8 * (54 * (size_t)Tn + (size_t)R + 8)) + Arena::need(8 * 8 * (size_t)Tn) +
                     Arena::need(sizeof(LmState) * Tn) + Arena::need(4 * (size_t)Tn) + Arena::need(64) + 2 * Arena::need(8 * (size_t)Tn) +
                     2 * Arena::need(sizeof(RansacBest)) + Arena::need(8 * (size_t)row_max) + Arena::need(8 * (size_t)row_max * R) + Arena::need(64) +
                     Arena::need(8 * (size_t)R + 64) + Arena::need(64) + (padded ? Arena::need(8 * cap * R) : 0) + 4096;
@@ -456,7 +466,7 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
     int64_t* d_cnt_all = da.take<int64_t>((size_t)R + 8);
     int64_t* d_m_all = da.take<int64_t>((size_t)R + 8);
     int32_t* d_samples = da.take<int32_t>(9 * (size_t)Tn);
-    double* d_pts = da.take<double>(54 * (size_t)Tn);
+    double* d_pts = da.take<double>(54 * (size_t)Tn + (size_t)R + 8);  // the sampled points + (warm path) the ranks' point counts behind them
     double* d_hyp = da.take<double>(8 * (size_t)Tn);
     char* zero_begin = da.base + da.off;  // states, scored, flags: one memset
     LmState* d_states = da.take<LmState>(Tn);
@@ -481,7 +491,7 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
                                      Arena::need(8 * cap) + Arena::need(8 * 1024)}) + 4096;
     if (rc == RSDSFM_OK) rc = ensure_ws(c, ws_need);
     if (rc == RSDSFM_OK)
-        rc = ensure_pinned(c, sizeof(RansacBest) + 64 + 8 * (size_t)R * 2 + 64 + sizeof(RefineState) + 64 + sizeof(int32_t) * 9 * (size_t)Tn + 64 + 16 * (size_t)R + 64);
+        rc = ensure_pinned(c, sizeof(RansacBest) + 64 + 8 * (size_t)R * 2 + 64 + sizeof(RefineState) + 64 + sizeof(int32_t) * 9 * (size_t)Tn + 64 + 16 * (size_t)R + 64 + 8 * (size_t)R + 64);
     // the refinement's session (sized for every point of the slab an inlier), the rank-indexed flow exchange (quirk Q2: at most the
     // whole flow list of every slab + this slab's columns) and the depth map's claim words
     const size_t npart_cap = (size_t)refine_partials_doubles(c, (int64_t)N1);
@@ -503,36 +513,71 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
 
     memset(res, 0, sizeof(*res));
     // ---- flatten of the slab; point counts + setup status of all slabs ----
+    // WARM path (the previous solve on this communicator succeeded on every rank with this very shape, and all its slabs were dense):
+    // no rank can need an allocation, so the ranks do not wait for each other's setup status; they go on with the point counts of a
+    // dense frame, the real counts ride in the sampled points' all-reduce and are checked with the RANSAC's first host read.  A rank
+    // that does fail here (only an argument error is left: a null slab pointer) reports a count of -1 and works on whatever its
+    // buffers hold: the check fails on every rank, all start over on the COLD path below, and its status exchange ends the call.
+    const int shape_flags = (prm->use_acceleration_mode ? 1 : 0) | (prm->use_refinement ? 2 : 0) | (prm->flow_index_mode << 2) | (depth_mode << 4) |
+                            (prm->use_global_shutter_mode ? 64 : 0);
+    const bool warm = D->warm && D->warm_rows == rows && D->warm_cols == cols && D->warm_T == T && D->warm_flags == shape_flags && T > 0 &&
+                      depth_mode == RSDSFM_DEPTH_CERES_LM && T <= kRansacBatch;
+    bool spec_dense = warm && D->dense_hint;
+    int path_flags = spec_dense ? 1 : 0;
+    D->warm = false;  // (set again by a solve that ends well)
     std::vector<int64_t> h_xchg(2 * (size_t)R + 2, 0);  // (pageable on purpose: it must exist even when the pinned block could not grow)
-    h_xchg[1] = setup_rc;
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_xchg + 2 * rank, h_xchg.data(), 2 * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));  // {0, status}
-    if (setup_rc == RSDSFM_OK && Ns > 0) {
-        Arena ws(c->d_ws);
-        int64_t* d_counts = ws.take<int64_t>(ncells);
-        int64_t* d_offsets = ws.take<int64_t>(ncells);
-        rc = flatten_launch(c, d_img_slab, rows, sc, col0, fx, fy, cx, cy, gamma, prm->flow_threshold, d_q, d_u, d_a, d_ak, d_counts, d_offsets,
-                            d_xchg + 2 * rank, nullptr);
-        if (rc != RSDSFM_OK) return rc;
-    }
-    rc = all_gather(c, D, d_xchg + 2 * rank, d_xchg, 2 * sizeof(int64_t));
-    if (rc != RSDSFM_OK) return rc;
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_xchg.data(), d_xchg, 2 * sizeof(int64_t) * R, hipMemcpyDeviceToHost, c->stream));
-    if (setup_rc == RSDSFM_OK) RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
-    rc = sync(c, D);
-    if (rc != RSDSFM_OK) return rc;
-    for (int r = 0; r < R; ++r)
-        if (h_xchg[2 * (size_t)r + 1] != 0) {
-            if (setup_rc != RSDSFM_OK) return setup_rc;  // (this rank's own message is in place)
-            return fail(c, RSDSFM_ERR_PEER, ("rank " + std::to_string(r) + " failed while setting up its slab (code " + std::to_string(h_xchg[2 * (size_t)r + 1]) + ")").c_str());
+    double* h_counts_tail = reinterpret_cast<double*>(reinterpret_cast<char*>(h_samples) + sizeof(int32_t) * 9 * (size_t)Tn + 64 + 16 * (size_t)R + 64);
+    int64_t n_total = 0, offset = 0, n = 0;
+restart_cold:
+    if (!spec_dense) {
+        h_xchg[1] = setup_rc;
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_xchg + 2 * rank, h_xchg.data(), 2 * sizeof(int64_t), hipMemcpyHostToDevice, c->stream));  // {0, status}
+        if (setup_rc == RSDSFM_OK && Ns > 0) {
+            Arena ws(c->d_ws);
+            int64_t* d_counts = ws.take<int64_t>(ncells);
+            int64_t* d_offsets = ws.take<int64_t>(ncells);
+            rc = flatten_launch(c, d_img_slab, rows, sc, col0, fx, fy, cx, cy, gamma, prm->flow_threshold, d_q, d_u, d_a, d_ak, d_counts, d_offsets,
+                                d_xchg + 2 * rank, nullptr);
+            if (rc != RSDSFM_OK) return rc;
         }
-    for (int r = 0; r < R; ++r) h_cnt[r] = h_xchg[2 * (size_t)r];
+        rc = all_gather(c, D, d_xchg + 2 * rank, d_xchg, 2 * sizeof(int64_t));
+        if (rc != RSDSFM_OK) return rc;
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_xchg.data(), d_xchg, 2 * sizeof(int64_t) * R, hipMemcpyDeviceToHost, c->stream));
+        if (setup_rc == RSDSFM_OK) RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
+        rc = sync(c, D);
+        if (rc != RSDSFM_OK) return rc;
+        for (int r = 0; r < R; ++r)
+            if (h_xchg[2 * (size_t)r + 1] != 0) {
+                if (setup_rc != RSDSFM_OK) return setup_rc;  // (this rank's own message is in place)
+                return fail(c, RSDSFM_ERR_PEER, ("rank " + std::to_string(r) + " failed while setting up its slab (code " + std::to_string(h_xchg[2 * (size_t)r + 1]) + ")").c_str());
+            }
+        for (int r = 0; r < R; ++r) h_cnt[r] = h_xchg[2 * (size_t)r];
+    } else {
+        // the counts of a dense frame; this rank's real count lands in its exchange word (device) and travels with the sampled points
+        for (int r = 0; r < R; ++r) {
+            int32_t c0r = 0, scr = 0;
+            rsdsfm_tiled_slab_bounds(cols, R, r, &c0r, &scr, nullptr);
+            h_cnt[r] = (int64_t)rows * scr;
+        }
+        h_xchg[0] = setup_rc == RSDSFM_OK ? 0 : -1;  // (a failing rank: a count no dense slab has)
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_xchg + 2 * rank, h_xchg.data(), sizeof(int64_t), hipMemcpyHostToDevice, c->stream));
+        if (setup_rc == RSDSFM_OK && Ns > 0) {
+            Arena ws(c->d_ws);
+            int64_t* d_counts = ws.take<int64_t>(ncells);
+            int64_t* d_offsets = ws.take<int64_t>(ncells);
+            rc = flatten_launch(c, d_img_slab, rows, sc, col0, fx, fy, cx, cy, gamma, prm->flow_threshold, d_q, d_u, d_a, d_ak, d_counts, d_offsets,
+                                d_xchg + 2 * rank, nullptr);
+            if (rc != RSDSFM_OK) return rc;
+        }
+        RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
+    }
     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_cnt_all, h_cnt, sizeof(int64_t) * R, hipMemcpyHostToDevice, c->stream));  // (the rank-indexed flow gather reads them)
-    int64_t n_total = 0, offset = 0;
+    n_total = 0, offset = 0;
     for (int r = 0; r < R; ++r) {
         if (r == rank) offset = n_total;
         n_total += h_cnt[r];
     }
-    const int64_t n = h_cnt[rank];
+    n = h_cnt[rank];
     res->n_points = n_total;
     if (n_total < 9) return fail(c, RSDSFM_ERR_INVALID, "ransac needs at least 9 points (the reference would compute rand() % 0)");
     if (n_total > (int64_t)INT32_MAX) return fail(c, RSDSFM_ERR_INVALID, "n exceeds the int32 sample index range");
@@ -546,9 +591,10 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
         sample_indices(n_total, T, prm->seed, h_samples);
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_samples, h_samples, sizeof(int32_t) * 9 * (size_t)T, hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(pack_samples_kernel, dim3((9 * T + 255) / 256), dim3(256), 0, c->stream, reinterpret_cast<const double2*>(d_q),
-                           reinterpret_cast<const double2*>(d_u), d_a, d_ak, n, offset, d_samples, 9 * T, d_pts);
+                           reinterpret_cast<const double2*>(d_u), d_a, d_ak, n, offset, d_samples, 9 * T, d_pts,
+                           spec_dense ? static_cast<const int64_t*>(d_xchg + 2 * rank) : nullptr, rank, R);
         RSDSFM_HIP_CHECK(c, hipGetLastError());
-        rc = all_reduce_sum(c, D, d_pts, 54 * (size_t)T);
+        rc = all_reduce_sum(c, D, d_pts, 54 * (size_t)T + (spec_dense ? (size_t)R : 0));
         if (rc != RSDSFM_OK) return rc;
         rc = minimal9_launch(c, d_pts, d_pts + 18 * (size_t)T, d_pts + 36 * (size_t)T, d_pts + 45 * (size_t)T, nullptr, T, prm->use_acceleration_mode,
                              prm->k_sign_mode, d_hyp);
@@ -609,8 +655,21 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
                     final_done = true;
                 }
                 RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
+                const bool check_counts = spec_dense && round == 0 && b0 == 0;  // the warm path's first host read: were the slabs dense?
+                if (check_counts)
+                    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_counts_tail, d_pts + 54 * (size_t)T, sizeof(double) * R, hipMemcpyDeviceToHost, c->stream));
                 rc = sync(c, D);
                 if (rc != RSDSFM_OK) return rc;
+                if (check_counts) {
+                    bool held = true;
+                    for (int r = 0; r < R; ++r) held = held && h_counts_tail[r] == (double)h_cnt[r];
+                    if (!held) {  // a slab dropped pixels (or a rank failed): everything so far ran on wrong counts -- all ranks see the same
+                        spec_dense = false;  // gathered counts and start over together, through the counts / status exchange
+                        D->dense_hint = false;
+                        path_flags |= 2;
+                        goto restart_cold;
+                    }
+                }
                 if (h_flags[0] == 0) break;
                 final_done = false;
             }
@@ -799,6 +858,17 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
         rc = sync(c, D);
         if (rc != RSDSFM_OK) return rc;
     }
+    {  // what the next solve on this communicator may take for granted (identical on every rank: all of it is replicated knowledge)
+        bool dense_now = true;
+        for (int r = 0; r < R; ++r) {
+            int32_t c0r = 0, scr = 0;
+            rsdsfm_tiled_slab_bounds(cols, R, r, &c0r, &scr, nullptr);
+            dense_now = dense_now && h_cnt[r] == (int64_t)rows * scr;
+        }
+        D->dense_hint = dense_now;
+        D->warm = true;
+        D->warm_rows = rows, D->warm_cols = cols, D->warm_T = T, D->warm_flags = shape_flags;
+    }
     res->flipped = h_header[0] != 0.0;
     res->v[0] = h_header[1], res->v[1] = h_header[2], res->v[2] = h_header[3];
     memcpy(res->w, w, sizeof(w));
@@ -816,6 +886,7 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
         info->host_syncs = D->host_syncs;
         info->collectives = D->collectives;
         info->ransac_rounds = D->ransac_rounds;
+        info->path_flags = path_flags;
     }
     return RSDSFM_OK;
 }

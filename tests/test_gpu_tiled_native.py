@@ -83,6 +83,76 @@ def _native_threads(rsdsfm, torch, d, nranks, **kw):
     return res
 
 
+def test_native_tiled_warm_path_and_a_frame_that_is_not_dense_after_all(rsdsfm):
+    """A sequence on ONE set of contexts: the second solve of a shape goes ahead on the point counts of a dense frame (no wait for the counts
+    exchange: one host synchronisation and one collective less), a frame with dropped pixels then breaks that assumption -- every rank
+    notices with its first host read, all start over through the counts exchange -- and the frame after it waits again.  Every solve
+    equals the single-context solve of its frame."""
+    import torch
+    from transports import ThreadTransport
+
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    d = rsdsfm.synth.make_config(3, rows=96, cols=250)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    holed = d["flow_img"].copy()
+    holed[20:40, 100:130] = 0.0
+    frames = [d["flow_img"], d["flow_img"], d["flow_img"], holed, d["flow_img"], d["flow_img"], d["flow_img"]]
+    kw = dict(trials=14, tol=0.002, flow_index_mode=rsdsfm.FLOW_GATHERED)
+    singles = []
+    with torch.cuda.stream(stream):
+        for i, f in enumerate(frames):
+            singles.append(_single(rsdsfm, torch, dict(d, flow_img=f), stream, seed=3, **kw))
+    nranks = 3
+    tr = ThreadTransport(nranks)
+    outs, errs = [[] for _ in range(nranks)], [None] * nranks
+    imgs = [torch.from_numpy(f).to(dev) for f in frames]
+
+    def work(rank):
+        try:
+            torch.cuda.set_device(0)
+            c0, sc, per = rsdsfm.tiled_slab_bounds(cols, nranks, rank)
+            with rsdsfm.Solver(0) as s:
+                s.dist_set_transport(nranks, rank, *tr.callbacks(rank))
+                for i, img in enumerate(imgs):
+                    slab = img[:, c0:c0 + sc, :].contiguous()
+                    dm = torch.zeros(cols * rows, dtype=torch.float64, device=dev)
+                    torch.cuda.synchronize()
+                    r = s.solve_frame_tiled_dev(slab.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), seed=3, **kw)
+                    s.synchronize()
+                    r["depth_map"] = dm.cpu().numpy()
+                    outs[rank].append(r)
+        except Exception as e:  # noqa: BLE001
+            errs[rank] = e
+            tr.barrier.abort()
+
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    for e in errs:
+        if e is not None:
+            raise e
+    syncs = [outs[0][i]["info"]["host_syncs"] for i in range(len(frames))]
+    colls = [outs[0][i]["info"]["collectives"] for i in range(len(frames))]
+    for i, one in enumerate(singles):
+        for rank in range(nranks):
+            r = outs[rank][i]
+            assert r["n"] == one["n"] and r["num_inliers"] == one["num_inliers"] and r["best_trial"] == one["best_trial"], (i, rank)
+            assert np.array_equal(r["ransac_v"], one["ransac_v"]) and r["refine_summary"]["num_iterations"] == one["refine_summary"]["num_iterations"], (i, rank)
+            assert np.allclose(r["v"], one["v"], rtol=1e-9, atol=1e-14) and np.allclose(r["w"], one["w"], rtol=1e-9, atol=1e-14)
+            assert np.array_equal(r["depth_map"] != 0, one["depth_map"] != 0) and np.allclose(r["depth_map"], one["depth_map"], rtol=1e-9)
+    assert singles[3]["n"] < rows * cols == singles[0]["n"]
+    # the path every solve took (identical on all ranks): cold / ahead on dense counts / ahead / ahead but the frame has a hole: started over /
+    # the previous frame was not dense: cold / ahead / ahead
+    for rank in range(nranks):
+        assert [o["info"]["path_flags"] for o in outs[rank]] == [0, 1, 1, 3, 0, 1, 1], rank
+    # same frame, same seed, hints settled: going ahead saves exactly one host synchronisation and one collective
+    assert syncs[6] == syncs[5] == syncs[2] and colls[6] == colls[5] == colls[2], (syncs, colls)
+    assert syncs[3] > syncs[2] and colls[3] > colls[2], (syncs, colls)
+
+
 @pytest.mark.parametrize("cfg,accel", [(3, False), (5, True)])
 def test_native_tiled_solve_matches_single_context(rsdsfm, cfg, accel):
     import torch

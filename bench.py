@@ -1019,6 +1019,11 @@ def _tiled_scaling_model(rec, world):
     return out
 
 
+def _mmm(xs):
+    xs = sorted(x for x in xs if x is not None)
+    return [xs[0], xs[len(xs) // 2], xs[-1]] if xs else None
+
+
 def _tiled_full_record(rsdsfm, solver, torch, dist, dev, np, world, rank, args, steps, warmup, timed):
     """BASELINE configs[3] / north_star "large frames tile across the GPUs": ONE 3840x2160 DeepFlow-like frame split into column slabs
     over the ranks, the WHOLE solve (flatten, RANSAC, refinement, sign fix + depth map) by ONE C-ABI call per rank
@@ -1047,10 +1052,14 @@ def _tiled_full_record(rsdsfm, solver, torch, dist, dev, np, world, rank, args, 
 
     per_step = []
 
+    per_info = []
+
     def tstep(i):
         t0 = time.perf_counter()
         step(i)
         per_step.append(time.perf_counter() - t0)
+        inf = (res["r"].get("info") or {})
+        per_info.append((inf.get("collectives"), inf.get("host_syncs"), inf.get("path_flags"), res["r"]["refine_summary"]["num_iterations"]))
 
     el = timed(tstep, steps, warmup)
     rec = None
@@ -1062,6 +1071,11 @@ def _tiled_full_record(rsdsfm, solver, torch, dist, dev, np, world, rank, args, 
         rec = {"metric": "Mpixels/sec RS whole solve, 3840x2160 frame column-tiled over the ranks", "scaling": "strong", "n_ranks": world,
                "value": rows * cols * steps / el / 1e6, "unit": "Mpixels/s", "ms_per_solve": el / steps * 1e3, "median_ms_per_solve": ts[len(ts) // 2] * 1e3,
                "steps": steps, "rccl_ranks": info.get("nranks"), "collectives": info.get("collectives"), "host_syncs": info.get("host_syncs"),
+               # over the timed solves (the sampler seed changes per solve: the refinement's length does too, and a chunk that follows the
+               # previous solve's length then costs a poll and two collectives per extra iteration): [min, median, max]
+               "collectives_min_med_max": _mmm([x[0] for x in per_info[-steps:]]), "host_syncs_min_med_max": _mmm([x[1] for x in per_info[-steps:]]),
+               "refine_iterations_min_med_max": _mmm([x[3] for x in per_info[-steps:]]),
+               "solves_ahead_on_dense_counts": sum(1 for x in per_info[-steps:] if x[2] is not None and (x[2] & 1) and not (x[2] & 2)),
                "config": {"workload": "BASELINE configs[3]: synthetic 3840x2160 DeepFlow-like frame, column slabs over %d rank(s): flatten + RANSAC(%d, tol %g) "
                                       "+ refinement + depth map; all-gathers of the stage sum rows + ONE all-gather of the depth slabs"
                                       % (world, args.trials, args.tol),

@@ -472,7 +472,9 @@ typedef struct rsdsfm_tiled_info {
     int32_t host_syncs, collectives, ransac_rounds;       /* diagnostics of the call                                   */
     int32_t path_flags; /* bit 0: the ranks went ahead on the point counts of a dense frame instead of waiting for the counts exchange
                          * (the previous solve of this shape on the communicator succeeded everywhere, all its slabs dense); bit 1: that
-                         * assumption did not hold for this frame and the solve started over through the counts / status exchange */
+                         * assumption did not hold for this frame and the solve started over through the counts / status exchange; bit 2:
+                         * the RANSAC started over with the standard functions (an argument outside the range of the in-range function cores
+                         * on some rank; counted by rsdsfm_ransac_restarts as well) */
 } rsdsfm_tiled_info;
 
 /* d_img_slab: row-major [rows][slab_cols][2] slab of this rank (DEVICE); cols = width of the WHOLE image.  params->

@@ -138,6 +138,11 @@ struct Dist {
     // go on with the counts a dense frame has instead of waiting for the counts exchange (checked with the RANSAC's first host read)
     bool warm = false, dense_hint = false;
     int warm_rows = 0, warm_cols = 0, warm_T = 0, warm_flags = 0;
+    // round 0 of the RANSAC's LM solves and the minimal solver's SVD through the in-range function cores (as in the single-context solve):
+    // a shard that met an argument out of range says so in the trailer of its rows, every rank sees it and all start the RANSAC over with
+    // the standard functions, which the communicator then keeps for its next 16 solves
+    int standard_math = 0;
+    int64_t restarts = 0;
 };
 
 Dist* dist_of(Ctx* c, bool create) {
@@ -207,6 +212,7 @@ void reset_hints(Dist* D) {
     D->score_idle = kScoreIdleLimit;
     D->refine_iters_hint = -1;
     D->warm = D->dense_hint = false;
+    D->standard_math = 0;
 }
 
 int sync(Ctx* c, Dist* D) {
@@ -456,7 +462,7 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
     int32_t* d_ys = fa.take<int32_t>(N1);
 
     // ---- small exchange buffers ----
-    const int row_max = std::max({nsr * batch, refine_stage_row_doubles(np, 0), refine_stage_row_doubles(np, 1), refine_stage_row_doubles(np, 2), 2 * batch});
+    const int row_max = std::max({nsr * batch + 2, refine_stage_row_doubles(np, 0), refine_stage_row_doubles(np, 1), refine_stage_row_doubles(np, 2), 2 * batch});
     size_t need_d = 2 * Arena::need(8 * (size_t)R + 64) + Arena::need(4 * 9 * (size_t)Tn) + Arena::need(8 * (54 * (size_t)Tn + (size_t)R + 8)) + Arena::need(8 * 8 * (size_t)Tn) +
                     Arena::need(sizeof(LmState) * Tn) + Arena::need(4 * (size_t)Tn) + Arena::need(64) + 2 * Arena::need(8 * (size_t)Tn) +
                     2 * Arena::need(sizeof(RansacBest)) + Arena::need(8 * (size_t)row_max) + Arena::need(8 * (size_t)row_max * R) + Arena::need(64) +
@@ -500,6 +506,12 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
     if (rc == RSDSFM_OK && prm->use_refinement && prm->flow_index_mode == RSDSFM_FLOW_COMPAT_RANK && R > 1)
         rc = ensure_dev(c, &D->d_flow, &D->flow_bytes, Arena::need(16 * std::max<size_t>(cap, 1) * R) + Arena::need(16 * N1) + 1024);
     if (rc == RSDSFM_OK) rc = claim_map_reserve(c, 2, N1);
+    if (rc == RSDSFM_OK && !c->d_core_flag) {  // the minimal solver's persistent range-flag word (as ransac_begin allocates it)
+        if (hipMalloc(reinterpret_cast<void**>(&c->d_core_flag), 64) != hipSuccess || hipMemsetAsync(c->d_core_flag, 0, 64, c->stream) != hipSuccess) {
+            c->d_core_flag = nullptr;
+            rc = fail(c, RSDSFM_ERR_HIP, "out of device memory (range-flag word)");
+        }
+    }
     const int setup_rc = rc;
     char* hp = static_cast<char*>(c->h_pinned);
     RansacBest* h_best = reinterpret_cast<RansacBest*>(hp);
@@ -587,6 +599,12 @@ restart_cold:
     }
 
     // ---- hypotheses: deterministic sampler on every rank, sampled points by one exact all-reduce, minimal solver replicated ----
+    // the in-range function cores (device_math.hpp) in the minimal solver's SVD and in round 0 of the LM solves, as the single-context solve
+    // runs them: one hypothesis batch, LM mode, the user's switch (rsdsfm_set_ransac_math: the same on every rank), no recent restart
+    bool core = T > 0 && T <= kRansacBatch && depth_mode == RSDSFM_DEPTH_CERES_LM && c->ransac_math_mode == 0 && D->standard_math == 0 && setup_rc == RSDSFM_OK;
+    if (!core && D->standard_math > 0) D->standard_math -= 1;
+    int* d_core_flags = d_flags + 8;  // (inside the zeroed block)
+    int m9_epoch = 0;
     if (T > 0) {
         sample_indices(n_total, T, prm->seed, h_samples);
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_samples, h_samples, sizeof(int32_t) * 9 * (size_t)T, hipMemcpyHostToDevice, c->stream));
@@ -596,8 +614,17 @@ restart_cold:
         RSDSFM_HIP_CHECK(c, hipGetLastError());
         rc = all_reduce_sum(c, D, d_pts, 54 * (size_t)T + (spec_dense ? (size_t)R : 0));
         if (rc != RSDSFM_OK) return rc;
+    }
+restart_ransac:
+    if (T > 0) {
+        Minimal9Direct dir;
+        if (core && T <= c->num_cus * 2) {  // (the wave-per-hypothesis solver: the one with the cores)
+            c->core_epoch = c->core_epoch >= 0x3fffffff ? 1 : c->core_epoch + 1;
+            dir.core_flag = c->d_core_flag;
+            dir.core_epoch = m9_epoch = c->core_epoch;
+        }
         rc = minimal9_launch(c, d_pts, d_pts + 18 * (size_t)T, d_pts + 36 * (size_t)T, d_pts + 45 * (size_t)T, nullptr, T, prm->use_acceleration_mode,
-                             prm->k_sign_mode, d_hyp);
+                             prm->k_sign_mode, d_hyp, nullptr, 0, m9_epoch ? &dir : nullptr);
         if (rc != RSDSFM_OK) return rc;
     }
 
@@ -630,11 +657,13 @@ restart_cold:
             if (b0 > 0) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_flags, 0, sizeof(int) * 4, c->stream));
             for (int round = 0;; ++round) {
                 if (round > 4 * kMaxIter) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machines did not terminate");
-                rc = ransac_lm_rows_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, d_partials, round, prm->ransac_tol, d_row);
+                const bool core_round = core && round == 0;  // (core implies one batch: B == T)
+                rc = ransac_lm_rows_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, d_partials, round, prm->ransac_tol, d_row,
+                                           core_round ? d_core_flags : nullptr, m9_epoch ? c->d_core_flag : nullptr, m9_epoch);
                 if (rc != RSDSFM_OK) return rc;
-                rc = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)B * nsr);
+                rc = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)ransac_rows_payload_doubles(B, core_round));
                 if (rc != RSDSFM_OK) return rc;
-                rc = ransac_decide_rows_launch(c, d_rows_all, R, B, d_states + b0, n_total, round, d_flags, d_scored + b0, d_tcount + b0, d_terr + b0);
+                rc = ransac_decide_rows_launch(c, d_rows_all, R, B, d_states + b0, n_total, round, d_flags, d_scored + b0, d_tcount + b0, d_terr + b0, core_round);
                 if (rc != RSDSFM_OK) return rc;
                 D->ransac_rounds += 1;
                 if (round == 0 && B == T) {  // the common case is decided and scored by round 0: enqueue the final stage before reading the flags
@@ -654,7 +683,7 @@ restart_cold:
                     if (rc != RSDSFM_OK) return rc;
                     final_done = true;
                 }
-                RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 2, hipMemcpyDeviceToHost, c->stream));
+                RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
                 const bool check_counts = spec_dense && round == 0 && b0 == 0;  // the warm path's first host read: were the slabs dense?
                 if (check_counts)
                     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_counts_tail, d_pts + 54 * (size_t)T, sizeof(double) * R, hipMemcpyDeviceToHost, c->stream));
@@ -669,6 +698,18 @@ restart_cold:
                         path_flags |= 2;
                         goto restart_cold;
                     }
+                }
+                if (core_round && h_flags[3] != 0) {
+                    // some shard's round 0 (or the minimal solver) met an argument outside the range of the function cores: every rank read
+                    // the same flag, all run the RANSAC again from the minimal solver on with the standard functions (identical results)
+                    core = false;
+                    m9_epoch = 0;
+                    D->standard_math = 16;
+                    D->restarts += 1;
+                    c->ransac_restarts += 1;
+                    path_flags |= 4;
+                    RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
+                    goto restart_ransac;
                 }
                 if (h_flags[0] == 0) break;
                 final_done = false;

@@ -334,8 +334,10 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
 // ... of its two slots in order with 16 independent 16-byte loads in flight (the reduction is bound by load latency), then thread
 // s adds the G group sums of slot s in order -- no wave butterflies (the first version reduced 22 per-thread sums with 22 DPP
 // butterflies: 12.1 -> 9.6 (hypothesis-major rows) -> see DESIGN for this version).
+// rank_stride2 (rows of the column-tiled solve only): distance between two ranks' rows in 16-byte units; T * NSR / 2 when 0 (the rows follow
+// each other), one more when every rank's rows are followed by a trailer (ransac_lm_rows_kernel)
 __device__ __forceinline__ void reduce_hyp_sums(const double* __restrict__ partials, int nblocks, int T, int t, bool hyp_major,
-                                                double (*s_red)[NSR], double* s_sums) {
+                                                double (*s_red)[NSR], double* s_sums, int rank_stride2 = 0) {
     static_assert(NSR % 2 == 0, "slot pairs are read as double2");
     constexpr int NH = NSR / 2, G = 256 / NH, U = 16;
     __shared__ double s_grp[G][NSR];
@@ -351,7 +353,7 @@ __device__ __forceinline__ void reduce_hyp_sums(const double* __restrict__ parti
             for (int j = 0; j < U; ++j) {  // rows past the end contribute the identity (sums: + 0.0; max slots hold absolute values)
                 const int bj = b + j * G;
                 const int64_t br = bj < nblocks ? bj : g;
-                const double2 x = p2[(hyp_major ? ((int64_t)t * nblocks + br) : (br * T + t)) * NH + sp];
+                const double2 x = p2[hyp_major ? ((int64_t)t * nblocks + br) * NH + sp : br * (int64_t)(rank_stride2 ? rank_stride2 : T * NH) + (int64_t)t * NH + sp];
                 v[j] = bj < nblocks ? x : make_double2(0.0, 0.0);
             }
 #pragma unroll
@@ -376,12 +378,16 @@ __device__ __forceinline__ void reduce_hyp_sums(const double* __restrict__ parti
 
 // row-tiled solve: the shard's partials of every hypothesis reduced to one row [T][NSR] (the all-gather payload;
 // the gathered [ranks][T][NSR] array is then what ransac_decide_kernel reduces, ranks in place of workgroups)
+// core_flags (may be null): the flag words of a launch that ran the in-range function cores (ransac_lm_kernel CORE); the rows are then
+// followed by a 16-byte trailer whose first double is 1.0 when this shard's launch met an argument out of range -- the flag travels
+// with the rows, the decide stage raises it on every rank and all ranks start over together
 __global__ __launch_bounds__(256) void ransac_lm_rows_kernel(const double* __restrict__ partials, int nblocks, int T,
                                                             const LmState* __restrict__ states, int round,
-                                                            double* __restrict__ rows) {
+                                                            double* __restrict__ rows, const int* __restrict__ core_flags) {
     __shared__ double s_red[4][NSR];
     __shared__ double s_sums[NSR];
     const int t = blockIdx.x;
+    if (core_flags && t == 0 && threadIdx.x < 2) rows[(int64_t)T * NSR + threadIdx.x] = (threadIdx.x == 0 && core_flags[3] != 0) ? 1.0 : 0.0;
     const LmState* state = states + t;
     if (round > 0 && (state->status != 0 || state->next_launch != round)) {
         if (threadIdx.x < NSR) rows[(int64_t)t * NSR + threadIdx.x] = 0.0;
@@ -400,14 +406,17 @@ __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __rest
                                                            LmState* states, int64_t n, int round, int k0, int* flags, int* pred_flag,
                                                            int* __restrict__ scored, double* __restrict__ trial_count,
                                                            double* __restrict__ trial_err, int fused_base, int* steps_hist,
-                                                           int* __restrict__ unscored_list) {
+                                                           int* __restrict__ unscored_list, int rank_stride2 = 0) {
     __shared__ double s_red[4][NSR];
     __shared__ double s_sums[NSR];
     const int t = blockIdx.x;
     const int tid = threadIdx.x;
     LmState* state = states + t;
+    if (rank_stride2 && t == 0 && tid < nblocks) {  // the ranks' trailers (ransac_lm_rows_kernel): some shard left the range of the function cores
+        if (partials[(int64_t)tid * rank_stride2 * 2 + (int64_t)T * NSR] != 0.0) flags[3] = 1;  // (benign race: every writer stores the same word)
+    }
     if (round > 0 && (state->status != 0 || state->next_launch != round)) return;
-    reduce_hyp_sums(partials, nblocks, T, t, hyp_major != 0, s_red, s_sums);
+    reduce_hyp_sums(partials, nblocks, T, t, hyp_major != 0, s_red, s_sums, rank_stride2);
     if (tid == 0) {
         LmScal st = *static_cast<const LmScal*>(state);
         const int used_K = (round == 0) ? k0 : st.K;
@@ -1031,23 +1040,32 @@ int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* 
 }
 
 // ---- row-tiled stages (one shard of the points per rank; see dist.py TiledFrameSolve) ----
+// core_flags (round 0 of the native tiled driver, may be null): 8 zeroed device words; round 0 then runs the in-range function cores, folds
+// the minimal solver's flag (m9_flag / m9_epoch, may be null / 0) in, and the rows carry a 16-byte trailer (ransac_lm_rows_kernel): the
+// all-gather payload is ransac_rows_payload_doubles(T, true) doubles per rank
 int ransac_lm_rows_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
-                          const double* hyp, int T, const LmState* states, double* partials, int round, double tol, double* rows) {
+                          const double* hyp, int T, const LmState* states, double* partials, int round, double tol, double* rows,
+                          int* core_flags, const int* m9_flag, int m9_epoch) {
     const int grid = ransac_pixel_grid(c, n);
     const dim3 g2(grid, ransac_lm_groups(c, grid, T));
-    int rc = lm_launch(c, g2, KMAX, q, u, a, ak, n, hyp, T, states, partials, round, tol, nullptr, kTiledFusedBase, false, nullptr, 0);
+    const bool core = core_flags != nullptr && round == 0;
+    int rc = lm_launch(c, g2, KMAX, q, u, a, ak, n, hyp, T, states, partials, round, tol, core ? core_flags : nullptr, kTiledFusedBase, core,
+                       core ? m9_flag : nullptr, m9_epoch);
     if (rc != RSDSFM_OK) return rc;
-    hipLaunchKernelGGL(ransac_lm_rows_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, states, round, rows);
+    hipLaunchKernelGGL(ransac_lm_rows_kernel, dim3(T), dim3(256), 0, c->stream, partials, grid, T, states, round, rows,
+                       static_cast<const int*>(core ? core_flags : nullptr));
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
 
+int ransac_rows_payload_doubles(int T, bool core_trailer) { return T * NSR + (core_trailer ? 2 : 0); }
+
 int ransac_decide_rows_launch(Ctx* c, const double* rows_all, int nranks, int T, LmState* states, int64_t n_total, int round,
-                              int* flags, int* scored, double* trial_count, double* trial_err) {
+                              int* flags, int* scored, double* trial_count, double* trial_err, bool core_trailer) {
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(flags, 0, sizeof(int), c->stream));
     hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, rows_all, nranks, T, 0, states, n_total, round, (int)KMAX, flags,
                        static_cast<int*>(nullptr), scored, trial_count, trial_err, kTiledFusedBase, static_cast<int*>(nullptr),
-                       static_cast<int*>(nullptr));
+                       static_cast<int*>(nullptr), core_trailer ? T * NSR / 2 + 1 : 0);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -322,9 +322,11 @@ int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* 
 // row-tiled stages
 int ransac_rows_doubles();
 int ransac_lm_rows_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
-                          const double* hyp, int T, const LmState* states, double* partials, int round, double tol, double* rows);
+                          const double* hyp, int T, const LmState* states, double* partials, int round, double tol, double* rows,
+                          int* core_flags = nullptr, const int* m9_flag = nullptr, int m9_epoch = 0);
+int ransac_rows_payload_doubles(int T, bool core_trailer);
 int ransac_decide_rows_launch(Ctx* c, const double* rows_all, int nranks, int T, LmState* states, int64_t n_total, int round,
-                              int* flags, int* scored, double* trial_count, double* trial_err);
+                              int* flags, int* scored, double* trial_count, double* trial_err, bool core_trailer = false);
 int ransac_score_rows_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                              const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
                              double* partials, double* rows);

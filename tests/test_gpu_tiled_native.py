@@ -153,6 +153,71 @@ def test_native_tiled_warm_path_and_a_frame_that_is_not_dense_after_all(rsdsfm):
     assert syncs[3] > syncs[2] and colls[3] > colls[2], (syncs, colls)
 
 
+def test_native_tiled_function_cores_and_a_restart_on_one_rank(rsdsfm):
+    """The tiled RANSAC runs the minimal solver's SVD and round 0 of the LM solves through the in-range function cores like the single-context
+    solve.  A pixel whose Jacobian vanishes (alpha = 1 + gamma f_y / h = 0 exactly: h = 64 rows, gamma = 0.5, f_y = -128 px) lies in ONE
+    rank's slab: that rank's rows carry the flag, every rank sees it, all start the RANSAC over with the standard functions (path_flags bit
+    2) -- and the results equal the single-context solve's and those of a communicator set to the standard functions from the start."""
+    import torch
+    from transports import ThreadTransport
+
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    d = rsdsfm.synth.make_config(5, rows=64, cols=480)
+    rows, cols, K = d["rows"], d["cols"], d["K"]
+    gamma = 0.5
+    clean = np.array(d["flow_img"])
+    bad = clean.copy()
+    bad[17, 301] = (3.0, -128.0)  # column 301: the second of three slabs
+    kw = dict(trials=20, tol=0.05, seed=11, flow_index_mode=rsdsfm.FLOW_GATHERED)
+    nranks = 3
+    results = {}
+    for math in (0, 1):
+        tr = ThreadTransport(nranks)
+        outs, errs = [[] for _ in range(nranks)], [None] * nranks
+        imgs = [torch.from_numpy(f).to(dev) for f in (clean, bad, clean)]
+
+        def work(rank):
+            try:
+                torch.cuda.set_device(0)
+                c0, sc, per = rsdsfm.tiled_slab_bounds(cols, nranks, rank)
+                with rsdsfm.Solver(0) as s:
+                    s.set_ransac_math(math)
+                    s.dist_set_transport(nranks, rank, *tr.callbacks(rank))
+                    for img in imgs:
+                        slab = img[:, c0:c0 + sc, :].contiguous()
+                        dm = torch.zeros(cols * rows, dtype=torch.float64, device=dev)
+                        torch.cuda.synchronize()
+                        r = s.solve_frame_tiled_dev(slab.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), **kw)
+                        s.synchronize()
+                        outs[rank].append((r["n"], r["num_inliers"], r["best_trial"], r["ransac_v"].tobytes(), r["v"].tobytes(), r["w"].tobytes(),
+                                           str(r["refine_summary"]), dm.cpu().numpy().tobytes(), r["info"]["path_flags"] & 4))
+                    outs[rank].append(s.ransac_restarts())
+            except Exception as e:  # noqa: BLE001
+                errs[rank] = e
+                tr.barrier.abort()
+
+        ths = [threading.Thread(target=work, args=(r,)) for r in range(nranks)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        for e in errs:
+            if e is not None:
+                raise e
+        for rank in range(1, nranks):
+            assert outs[rank] == outs[0], (math, rank)
+        assert [o[8] for o in outs[0][:3]] == ([0, 4, 0] if math == 0 else [0, 0, 0]) and outs[0][3] == (1 if math == 0 else 0)
+        results[math] = [o[:8] for o in outs[0][:3]]
+    assert results[0] == results[1]
+    assert results[0][0] == results[0][2] and results[0][0] != results[0][1]
+    with torch.cuda.stream(stream):
+        for f, got in zip((clean, bad), results[0][:2]):
+            one = _single(rsdsfm, torch, dict(d, flow_img=f, gamma=gamma), stream, **kw)
+            assert (one["n"], one["num_inliers"], one["best_trial"], one["ransac_v"].tobytes()) == got[:4]
+            assert np.allclose(np.frombuffer(got[4]), one["v"], rtol=1e-9, atol=1e-14) and np.allclose(np.frombuffer(got[5]), one["w"], rtol=1e-9, atol=1e-14)
+
+
 @pytest.mark.parametrize("cfg,accel", [(3, False), (5, True)])
 def test_native_tiled_solve_matches_single_context(rsdsfm, cfg, accel):
     import torch

@@ -379,6 +379,12 @@ int rsdsfm_sample_indices(int64_t n, int32_t iterations, uint64_t seed, int32_t*
  * d_q9 / d_u9 = count x 9 x 2, d_alpha9 / d_alpha_k9 = count x 9; d_hyp = count x 8: w(3), v(3), k, status */
 int rsdsfm_minimal9_dev(rsdsfm_ctx* ctx, const double* d_q9, const double* d_u9, const double* d_alpha9,
                         const double* d_alpha_k9, int32_t count, int use_alpha_k, int k_sign_mode, double* d_hyp);
+/* diagnostics: the same solver (one wavefront per hypothesis: count <= 2 x the device's CUs; use_cores: its SVD through the in-range
+ * function cores, as inside a RANSAC) which also leaves, per hypothesis, d_probe4[4 t ..] = {sweeps of the 9x9 two-sided Jacobi SVD
+ * (minimal.cc:98), rotations it performed, shader clocks of the SVD, shader clocks of the whole hypothesis} -- the launch lasts as
+ * long as its slowest hypothesis (tools/svd_spread.py) */
+int rsdsfm_minimal9_probe_dev(rsdsfm_ctx* ctx, const double* d_q9, const double* d_u9, const double* d_alpha9, const double* d_alpha_k9,
+                              int32_t count, int use_alpha_k, int k_sign_mode, int use_cores, double* d_hyp, double* d_probe4);
 size_t rsdsfm_tile_lm_state_bytes(void);   /* bytes of one per-hypothesis LM state (caller zero-fills count of them) */
 size_t rsdsfm_tile_best_bytes(void);       /* bytes of the device-resident winner record                             */
 int32_t rsdsfm_tile_ransac_row_size(void); /* doubles per hypothesis in an LM sums row                               */

@@ -622,6 +622,11 @@ class _TileMixin:
         self._check(self.lib.rsdsfm_flatten_slab_dev(self._ctx, _np0(d_img_slab), C.c_int32(rows), C.c_int32(slab_cols), C.c_int32(col0), d(K[0]), d(K[1]), d(K[2]), d(K[3]), d(gamma), d(thr), _np0(d_q), _np0(d_u), _np0(d_alpha), _np0(d_alpha_k), C.byref(cnt)), "rsdsfm_flatten_slab_dev")
         return cnt.value
 
+    def minimal9_probe_dev(self, d_q9, d_u9, d_a9, d_ak9, count, use_alpha_k, k_sign_mode, use_cores, d_hyp, d_probe4):
+        """the wave-per-hypothesis minimal solver with per-hypothesis {SVD sweeps, rotations, SVD clocks, total clocks} (rsdsfm_minimal9_probe_dev)"""
+        self._check(self.lib.rsdsfm_minimal9_probe_dev(self._ctx, _dp(d_q9), _dp(d_u9), _dp(d_a9), _dp(d_ak9), C.c_int32(count), int(use_alpha_k), int(k_sign_mode),
+                                                       int(use_cores), _dp(d_hyp), _dp(d_probe4)), "rsdsfm_minimal9_probe_dev")
+
     def minimal9_dev(self, d_q9, d_u9, d_a9, d_ak9, count, use_alpha_k, k_sign_mode, d_hyp):
         self._check(self.lib.rsdsfm_minimal9_dev(self._ctx, _np0(d_q9), _np0(d_u9), _np0(d_a9), _np0(d_ak9), C.c_int32(count), int(use_alpha_k), int(k_sign_mode), _np0(d_hyp)), "rsdsfm_minimal9_dev")
 

@@ -201,8 +201,9 @@ constexpr int kCoopSlots = 3;   // LDS slots (of 64 doubles) behind the per-lane
 // CORE: the rotations through the in-range function cores; *outside is set when an operand was out of range (the caller has the
 // hypotheses computed again with CORE = false)
 template <bool CORE>
-__device__ void jacobi_svd9_nullvec_coop(double* W, double* V, int lane, LVec sv, LVec col, double e_out[9], bool* outside) {
+__device__ void jacobi_svd9_nullvec_coop(double* W, double* V, int lane, LVec sv, LVec col, double e_out[9], bool* outside, int* counts = nullptr) {
     uint32_t wd = 0, ws = 0;
+    int rotations = 0;
     const double precision = 2.0 * DBL_EPSILON;
     // scale = max |W| (exact in any order)
     double m = fabs(sh(W, lane));
@@ -234,6 +235,7 @@ __device__ void jacobi_svd9_nullvec_coop(double* W, double* V, int lane, LVec sv
                 double m0 = sh(W, p * 9 + p), m1 = sh(W, p * 9 + q), m2 = sh(W, q * 9 + p), m3 = sh(W, q * 9 + q);
                 if (fabs(m1) > threshold || fabs(m2) > threshold) {
                     finished = false;
+                    ++rotations;
                     // real_2x2_jacobi_svd (JacobiSVD.h), identical to the scalar version
                     Rot rot1, jl, jr;
                     const double t = m0 + m3;
@@ -288,6 +290,7 @@ __device__ void jacobi_svd9_nullvec_coop(double* W, double* V, int lane, LVec sv
         }
     }
     if (CORE) *outside = wd >= kDivRangeKeys || ws >= kSqrtRangeKeys;
+    if (counts) counts[0] = sweeps, counts[1] = rotations;
     for (int i = 0; i < 9; ++i) {
         sv[i] = fabs(sh(W, i * 9 + i)) * scale;
         col[i] = (double)i;
@@ -682,6 +685,7 @@ __device__ __forceinline__ void minimal9_body(double* lds, int block, int nblock
         for (int64_t i = (int64_t)block * 64 + lane; i < n_zero_words; i += (int64_t)nblocks * 64) zero_words[i] = 0ull;
     const int t = COOP ? block : block * 64 + lane;
     if (t >= T) return;  // per-lane independent work, no workgroup barriers below
+    const unsigned long long body_clk0 = (COOP && direct.probe) ? __builtin_amdgcn_s_memtime() : 0ull;
     LVec base{lds + lane};
     LVec Z = base.at(0), V = base.at(81), sv = base.at(162), col = base.at(171);
 
@@ -798,12 +802,19 @@ __device__ __forceinline__ void minimal9_body(double* lds, int block, int nblock
         Wc[lane] = lds[lane * 64];
         if (lane < 17) Wc[64 + lane] = lds[(64 + lane) * 64];
         __builtin_amdgcn_wave_barrier();
+        int counts[2] = {0, 0};
+        const unsigned long long svd_clk0 = direct.probe ? __builtin_amdgcn_s_memtime() : 0ull;
         if (direct.core_flag) {
             bool outside = false;
-            jacobi_svd9_nullvec_coop<true>(Wc, Wc + kCoopV, lane, sv, col, e, &outside);
+            jacobi_svd9_nullvec_coop<true>(Wc, Wc + kCoopV, lane, sv, col, e, &outside, direct.probe ? counts : nullptr);
             if (outside && lane == 0) *direct.core_flag = direct.core_epoch;  // (every writer of this launch stores the same value)
         } else {
-            jacobi_svd9_nullvec_coop<false>(Wc, Wc + kCoopV, lane, sv, col, e, nullptr);
+            jacobi_svd9_nullvec_coop<false>(Wc, Wc + kCoopV, lane, sv, col, e, nullptr, direct.probe ? counts : nullptr);
+        }
+        if (direct.probe && lane == 0) {
+            direct.probe[4 * t] = (double)counts[0];
+            direct.probe[4 * t + 1] = (double)counts[1];
+            direct.probe[4 * t + 2] = (double)(__builtin_amdgcn_s_memtime() - svd_clk0);
         }
     } else {
         jacobi_svd9_nullvec(Z, V, sv, col, e);
@@ -881,6 +892,7 @@ __device__ __forceinline__ void minimal9_body(double* lds, int block, int nblock
     tr3(wb, bt);
     mm3(t2, bt, w_hat);
     if (COOP && lane != 0) return;
+    if (COOP && direct.probe) direct.probe[4 * t + 3] = (double)(__builtin_amdgcn_s_memtime() - body_clk0);
     double* o = hyp_out + (int64_t)t * 8;
     o[0] = w_hat[7];
     o[1] = w_hat[2];

@@ -285,6 +285,9 @@ struct Minimal9Direct {
     // hypotheses computed again without it)
     int* core_flag = nullptr;
     int core_epoch = 0;
+    // diagnostics (rsdsfm_minimal9_probe_dev; wave-per-hypothesis solver only): per hypothesis {sweeps of the 9x9 Jacobi SVD, rotations it
+    // performed, shader clocks the SVD took, shader clocks of the whole hypothesis}
+    double* probe = nullptr;
 };
 int minimal9_launch(Ctx* c, const double* q, const double* u, const double* alpha, const double* alpha_k,
                     const int32_t* samples, int T, int use_alpha_k, int k_sign_mode, double* hyp_out, void* zero_begin = nullptr,

@@ -56,6 +56,27 @@ int rsdsfm_minimal9_dev(rsdsfm_ctx* ctx, const double* d_q9, const double* d_u9,
     return minimal9_launch(c, d_q9, d_u9, d_alpha9, d_alpha_k9, nullptr, count, use_alpha_k, k_sign_mode, d_hyp);
 }
 
+int rsdsfm_minimal9_probe_dev(rsdsfm_ctx* ctx, const double* d_q9, const double* d_u9, const double* d_alpha9, const double* d_alpha_k9,
+                              int32_t count, int use_alpha_k, int k_sign_mode, int use_cores, double* d_hyp, double* d_probe4) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    DeviceGuard device_guard_(c);
+    if (count < 1 || count > c->num_cus * 2) return fail(c, RSDSFM_ERR_INVALID, "probe: 1 <= count <= 2 x CUs (the wave-per-hypothesis solver)");
+    if (!d_q9 || !d_u9 || !d_alpha9 || !d_alpha_k9 || !d_hyp || !d_probe4) return fail(c, RSDSFM_ERR_INVALID, "null device pointer");
+    Minimal9Direct dir;
+    dir.probe = d_probe4;
+    if (use_cores) {
+        if (!c->d_core_flag) {
+            RSDSFM_HIP_CHECK(c, hipMalloc(reinterpret_cast<void**>(&c->d_core_flag), 64));
+            RSDSFM_HIP_CHECK(c, hipMemsetAsync(c->d_core_flag, 0, 64, c->stream));
+        }
+        c->core_epoch = c->core_epoch >= 0x3fffffff ? 1 : c->core_epoch + 1;
+        dir.core_flag = c->d_core_flag;
+        dir.core_epoch = c->core_epoch;
+    }
+    return minimal9_launch(c, d_q9, d_u9, d_alpha9, d_alpha_k9, nullptr, count, use_alpha_k, k_sign_mode, d_hyp, nullptr, 0, &dir);
+}
+
 size_t rsdsfm_tile_lm_state_bytes(void) { return sizeof(LmState); }
 size_t rsdsfm_tile_best_bytes(void) { return sizeof(RansacBest); }
 int32_t rsdsfm_tile_ransac_row_size(void) { return ransac_rows_doubles(); }

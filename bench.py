@@ -749,7 +749,7 @@ def run(args):
             bp(s)
             solver.interpolate_cracky_dev(s["gs"].data_ptr(), rows, cols, s["fixed"].data_ptr(), offset=1)
 
-        def step(i):  # main.cc:480-523 in one call: three launches (rsdsfm_rectify_frame_dev)
+        def step(i):  # main.cc:480-523 in one call: two launches (rsdsfm_rectify_frame_dev)
             s = sets[i % nbuf]
             solver.rectify_frame_dev(s["inl"].data_ptr(), npix, s["img"].data_ptr(), s["depth"].data_ptr(), R.data_ptr(), tt.data_ptr(), K, rows, cols,
                                      s["prev"].data_ptr(), s["gs"].data_ptr(), s["fixed"].data_ptr(), s["c3"].data_ptr(), offset=1)
@@ -780,7 +780,7 @@ def run(args):
                          "dtype": "u8/f64",
                          "config": {"workload": "SURVEY 8(f-1): 8-bit depth image + backProject (with float3 world points) + interpolateCrackyImage of "
                                                 "a synthetic 1280x720 BGR frame, depth map and pose table resident in HBM; one frame per GPU",
-                                    "api": "rsdsfm_rectify_frame_dev (one call, three launches)", "rows": rows, "cols": cols, "gs_coverage": covered,
+                                    "api": "rsdsfm_rectify_frame_dev (one call, two launches)", "rows": rows, "cols": cols, "gs_coverage": covered,
                                     "three_entry_points_five_launches": {"value": npix * world * args.steps / el_sep / 1e6, "ms_per_step": el_sep / args.steps * 1e3},
                                     "same_bytes_as_the_separate_calls": bool(same_bytes)},
                          "roofline": {"bound": "hbm", "kernel": "back projection alone (rsdsfm_back_project_dev) = back_project_claim_kernel + back_project_write_kernel",

@@ -539,8 +539,9 @@ int rsdsfm_depth_preview_dev(rsdsfm_ctx* ctx, const double* d_inliers3m, int64_t
                              int32_t rows, int32_t cols, uint8_t* d_depth_est);
 /* main.cc:480-523 in ONE call on device buffers: the 8-bit depth image (rsdsfm_depth_preview_dev), the back projection
  * (rsdsfm_back_project_dev) and the crack interpolation of its result (rsdsfm_interpolate_cracky_dev) -- the same kernels' code and
- * the same bytes, in three launches instead of five: the two claim passes share a launch and so do the two write passes (each of the
- * five is short enough for the launch floor to show).  d_gs_image_bgr and d_fixed_image_bgr must not alias. */
+ * the same bytes, in two launches instead of five: the two claim passes share a launch, and the write pass of the back projection forms
+ * the interpolated image from its own tile + halo next to the depth image's write pass (offset <= 2 and cols % 4 == 0; three launches
+ * otherwise) -- each of the five is short enough for the launch floor to show.  d_gs_image_bgr and d_fixed_image_bgr must not alias. */
 int rsdsfm_rectify_frame_dev(rsdsfm_ctx* ctx, const double* d_inliers3m, int64_t m, const uint8_t* d_image_bgr,
                              const double* d_depth_map_colmajor, const double* d_R_rows9, const double* d_t_rows3, double fx, double fy,
                              double cx, double cy, int32_t rows, int32_t cols, int mode, int q5_mode, int32_t offset, uint8_t* d_depth_est,

@@ -380,6 +380,98 @@ __global__ __launch_bounds__(kBP) void preview_write_kernel(const double* __rest
     preview_write_body(blockIdx.x, blockIdx.y, inl, owner, tag, mask, partials, nblocks, rows, cols, out);
 }
 
+// ---- back-projection write pass + crack interpolation on one tile (rsdsfm_rectify_frame_dev with offset <= kMaxHalo) ------------------
+// The interpolation (camera.cc:694-774) only reads the global-shutter image at the pixel and its four neighbours `offset` away, so a
+// workgroup that forms a kWT x kHT tile of that image plus a halo of `offset` pixels from the claim map (LDS: one packed BGR word per pixel)
+// can write the tile of BOTH images: no launch of its own for the interpolation, and the global-shutter image is not read back.
+constexpr int kWT = 64, kHT = 16, kMaxHalo = 2;
+__device__ __forceinline__ void write_interpolate_body(int bx, int by, const unsigned char* __restrict__ img, const unsigned* __restrict__ owner,
+                                                       unsigned tag, unsigned mask, int rows, int cols, int offset, unsigned char* __restrict__ gs,
+                                                       unsigned char* __restrict__ fixed) {
+    __shared__ unsigned s_px[(kHT + 2 * kMaxHalo) * (kWT + 2 * kMaxHalo)];
+    const int tid = threadIdx.x;
+    const int h = offset;
+    const int x0 = bx * kWT - h, y0 = by * kHT - h, W = kWT + 2 * h, H = kHT + 2 * h;
+    for (int i = tid; i < W * H; i += kBP) {  // the tile and its halo: the winner's colour, 0 where nobody landed or outside the image
+        const int ly = i / W, lx = i - ly * W;
+        const int x = x0 + lx, y = y0 + ly;
+        unsigned v = 0u;
+        if (x >= 0 && x < cols && y >= 0 && y < rows) {
+            const unsigned w = owner[(int64_t)y * cols + x];
+            if ((w & ~mask) == tag) {
+                const int64_t src = 3 * (int64_t)(w & mask);
+                v = (unsigned)img[src] | ((unsigned)img[src + 1] << 8) | ((unsigned)img[src + 2] << 16);
+            }
+        }
+        s_px[i] = v;
+    }
+    __syncthreads();
+    // 4 consecutive pixels of a tile row per thread (kWT / 4 threads per row, kHT rows): 12 bytes = 3 dwords of each image
+    const int ly = tid / (kWT / 4), lx4 = (tid - ly * (kWT / 4)) * 4;
+    const int y = by * kHT + ly, xb = bx * kWT + lx4;
+    if (y >= rows || xb >= cols) return;
+    unsigned g[12], f[12];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = xb + j;
+        const unsigned c0 = s_px[(ly + h) * W + (lx4 + j + h)];
+        unsigned b = c0 & 0xffu, gg = (c0 >> 8) & 0xffu, r = c0 >> 16;
+        g[3 * j] = b, g[3 * j + 1] = gg, g[3 * j + 2] = r;
+        if (x < cols && y >= offset && y < rows - offset && x >= offset && x < cols - offset && is_black(b, gg, r)) {  // interpolate_pixel on the tile
+            const unsigned nb[4] = {s_px[(ly + h - offset) * W + (lx4 + j + h)], s_px[(ly + h + offset) * W + (lx4 + j + h)],
+                                    s_px[(ly + h) * W + (lx4 + j + h - offset)], s_px[(ly + h) * W + (lx4 + j + h + offset)]};
+            double s0 = 0, s1 = 0, s2 = 0;
+            unsigned count = 0;
+#pragma unroll
+            for (int k2 = 0; k2 < 4; ++k2) {
+                const unsigned n0 = nb[k2] & 0xffu, n1 = (nb[k2] >> 8) & 0xffu, n2 = nb[k2] >> 16;
+                if (!is_black(n0, n1, n2)) {
+                    s0 += (double)n0;
+                    s1 += (double)n1;
+                    s2 += (double)n2;
+                    count++;
+                }
+            }
+            if (count > 0) {
+                const double inv = 1 / (double)count;
+                b = saturate_u8(inv * s0);
+                gg = saturate_u8(inv * s1);
+                r = saturate_u8(inv * s2);
+            }
+        }
+        f[3 * j] = b, f[3 * j + 1] = gg, f[3 * j + 2] = r;
+    }
+    const int64_t p0 = (int64_t)y * cols + xb;
+    if (xb + 4 <= cols && ((3 * p0) & 3) == 0) {
+        unsigned* dg = reinterpret_cast<unsigned*>(gs + 3 * p0);
+        unsigned* df = reinterpret_cast<unsigned*>(fixed + 3 * p0);
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            dg[d] = g[4 * d] | (g[4 * d + 1] << 8) | (g[4 * d + 2] << 16) | (g[4 * d + 3] << 24);
+            df[d] = f[4 * d] | (f[4 * d + 1] << 8) | (f[4 * d + 2] << 16) | (f[4 * d + 3] << 24);
+        }
+    } else {
+        for (int j = 0; j < 4 && xb + j < cols; ++j)
+            for (int c2 = 0; c2 < 3; ++c2) {
+                gs[3 * (p0 + j) + c2] = (unsigned char)g[3 * j + c2];
+                fixed[3 * (p0 + j) + c2] = (unsigned char)f[3 * j + c2];
+            }
+    }
+}
+
+__global__ __launch_bounds__(kBP) void rectify_write_interpolate_kernel(const unsigned char* __restrict__ img, const unsigned* __restrict__ owner_bp,
+                                                                       unsigned tag_bp, unsigned mask_bp, int rows, int cols, int offset,
+                                                                       unsigned char* __restrict__ gs, unsigned char* __restrict__ fixed, int tiles_x,
+                                                                       int nb_t, const double* __restrict__ inl, const unsigned* __restrict__ owner_pv,
+                                                                       unsigned tag_pv, unsigned mask_pv, const double* __restrict__ partials,
+                                                                       int nrows_pv, int tiles_x_pv, unsigned char* __restrict__ preview) {
+    const int b = blockIdx.x;
+    if (b < nb_t)
+        write_interpolate_body(b % tiles_x, b / tiles_x, img, owner_bp, tag_bp, mask_bp, rows, cols, offset, gs, fixed);
+    else
+        preview_write_body((b - nb_t) % tiles_x_pv, (b - nb_t) / tiles_x_pv, inl, owner_pv, tag_pv, mask_pv, partials, nrows_pv, rows, cols, preview);
+}
+
 // ---- main.cc:480-523 in three launches instead of five (rsdsfm_rectify_frame_dev) ----------------------------------------------------
 // The depth image and the back projection are independent chains (inliers -> claim map 1 -> 8-bit image; image + depth map -> claim map 0
 // -> global-shutter image) of two launches each, every one of them short enough for the launch floor to show: the two claim passes share
@@ -528,8 +620,15 @@ int rectify_frame_launch(Ctx* c, const double* d_inl, int64_t m, const unsigned 
     hipLaunchKernelGGL(rectify_claim_kernel, dim3(nb_bp + zb), dim3(kCB), 0, c->stream, d_img, d_depth_cm, d_R, d_t, fx, fy, cx, cy,
                        q5_mode == 0 ? fx : fy, rows, cols, mode, d_owner_bp, tag_bp, d_c3d, tiles_x, nb_bp, d_inl, m, d_owner_pv, tag_pv, d_partials);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    const int nb_w = stream_grid(npix, 4);
     const int ptx = (cols + 31) / 32, pty = (rows + 31) / 32;
+    if (offset <= kMaxHalo && (cols % 4) == 0) {  // two launches: the write pass forms the interpolated image from its own tile (+ halo)
+        const int ttx = (cols + kWT - 1) / kWT, tty = (rows + kHT - 1) / kHT;
+        hipLaunchKernelGGL(rectify_write_interpolate_kernel, dim3(ttx * tty + ptx * pty), dim3(kBP), 0, c->stream, d_img, d_owner_bp, tag_bp, mask_bp, rows,
+                           cols, offset, d_gs, d_fixed, ttx, ttx * tty, d_inl, d_owner_pv, tag_pv, mask_pv, d_partials, zb, ptx, d_preview);
+        RSDSFM_HIP_CHECK(c, hipGetLastError());
+        return RSDSFM_OK;
+    }
+    const int nb_w = stream_grid(npix, 4);
     hipLaunchKernelGGL(rectify_write_kernel, dim3(nb_w + ptx * pty), dim3(kBP), 0, c->stream, d_img, d_owner_bp, tag_bp, mask_bp, npix, d_gs, nb_w,
                        d_inl, d_owner_pv, tag_pv, mask_pv, d_partials, zb, rows, cols, ptx, d_preview);
     RSDSFM_HIP_CHECK(c, hipGetLastError());

@@ -132,7 +132,7 @@ struct Dist {
     // what the previous solve on this communicator needed -- decides what the next one enqueues ahead of its host reads, never a
     // result (every rank derives them from the same replicated decisions, so all ranks enqueue the same collectives)
     int score_idle = kScoreIdleLimit;  // consecutive solves (saturating) that did not need the separate scoring pass behind round 0 (rsdsfm_internal.hpp)
-    int refine_iters_hint = -1;  // LM iterations of the refinement (-1: none yet)
+    int refine_iters_hint = -1;  // refinement SLOTS the previous solve consumed (one exchange each; -1: none yet)
     // "warm": the previous solve on this communicator succeeded on EVERY rank with exactly this shape, so this one needs no allocation on any
     // rank and its setup cannot fail for lack of memory; with dense_hint (every slab of that solve kept all its pixels) the ranks then
     // go on with the counts a dense frame has instead of waiting for the counts exchange (checked with the RANSAC's first host read)
@@ -462,7 +462,7 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
     int32_t* d_ys = fa.take<int32_t>(N1);
 
     // ---- small exchange buffers ----
-    const int row_max = std::max({nsr * batch + 2, refine_stage_row_doubles(np, 0), refine_stage_row_doubles(np, 1), refine_stage_row_doubles(np, 2), 2 * batch});
+    const int row_max = std::max({nsr * batch + 2, refine_slot_row_doubles(np), refine_stage_row_doubles(np, 0), refine_stage_row_doubles(np, 1), refine_stage_row_doubles(np, 2), 2 * batch});
     size_t need_d = 2 * Arena::need(8 * (size_t)R + 64) + Arena::need(4 * 9 * (size_t)Tn) + Arena::need(8 * (54 * (size_t)Tn + (size_t)R + 8)) + Arena::need(8 * 8 * (size_t)Tn) +
                     Arena::need(sizeof(LmState) * Tn) + Arena::need(4 * (size_t)Tn) + Arena::need(64) + 2 * Arena::need(8 * (size_t)Tn) +
                     2 * Arena::need(sizeof(RansacBest)) + Arena::need(8 * (size_t)row_max) + Arena::need(8 * (size_t)row_max * R) + Arena::need(64) +
@@ -500,7 +500,7 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
         rc = ensure_pinned(c, sizeof(RansacBest) + 64 + 8 * (size_t)R * 2 + 64 + sizeof(RefineState) + 64 + sizeof(int32_t) * 9 * (size_t)Tn + 64 + 16 * (size_t)R + 64 + 8 * (size_t)R + 64);
     // the refinement's session (sized for every point of the slab an inlier), the rank-indexed flow exchange (quirk Q2: at most the
     // whole flow list of every slab + this slab's columns) and the depth map's claim words
-    const size_t npart_cap = (size_t)refine_partials_doubles(c, (int64_t)N1);
+    const size_t npart_cap = (size_t)std::max(refine_partials_doubles(c, (int64_t)N1), refine_slot_partials_doubles(c, (int64_t)N1));
     if (rc == RSDSFM_OK && prm->use_refinement)
         rc = ensure_dev(c, &D->d_session, &D->session_bytes, Arena::need(sizeof(RefineState) + 64) + Arena::need(32 * N1) + 4 * Arena::need(8 * N1) + Arena::need(8 * npart_cap) + 1024);
     if (rc == RSDSFM_OK && prm->use_refinement && prm->flow_index_mode == RSDSFM_FLOW_COMPAT_RANK && R > 1)
@@ -751,7 +751,7 @@ restart_ransac:
     // ---- joint refinement: per LM iteration two staged passes (Schur sums -> reduced solve; back-substitution sums -> decision) ----
     if (prm->use_refinement) {
         const size_t M = (size_t)std::max<int64_t>(m, 1);
-        const size_t npart = (size_t)refine_partials_doubles(c, m);
+        const size_t npart = (size_t)std::max(refine_partials_doubles(c, m), refine_slot_partials_doubles(c, m));
         Arena sa(D->d_session);  // (allocated in the setup part for the slab's upper bound)
         RefineBuffers B;
         B.flow = d_u;
@@ -817,6 +817,7 @@ restart_ransac:
         h_state->p[6] = k;
         h_state->termination = -1;
         h_state->radius = kInitialRadius;
+        h_state->need_schur = 1;  // the first slot is the Schur pass of iteration 1
         *h_bad = 0;
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(B.state, h_state, sizeof(RefineState) + sizeof(int), hipMemcpyHostToDevice, c->stream));
         rc = refine_trace_reset(c);
@@ -830,17 +831,24 @@ restart_ransac:
         };
         rc = staged(0);
         if (rc != RSDSFM_OK) return rc;
-        // LM iterations per host poll.  The kernels of a finished solve return immediately, but an empty iteration still costs two
-        // all-gathers here: the first chunk is what the previous solve on this communicator needed (5 before there is one), later
-        // chunks what it still needed at that point (2 .. 5).  Every rank holds the same hint (it comes from the replicated state), so all ranks issue the same
+        // ONE exchange per LM iteration (refine_kernels.hip, slot kernels): a slot's pass carries the back-substitution of iteration i and the
+        // Schur sums of iteration i + 1 speculated at the candidate for the radius an accepted step of quality >= 0.937 gets; a slot whose
+        // speculation did not apply is followed by a plain Schur slot (the kernels read which kind from the replicated state).  Slots per
+        // host poll: what the previous solve on this communicator consumed (6 before there is one: the first Schur slot + 5 iterations),
+        // later chunks what it still needed at that point (2 .. 5).  Every rank holds the same hint, so all ranks issue the same
         // collectives; the chunking changes when the host looks at the state, never what the kernels compute.
+        auto slot = [&]() -> int {
+            int rc2 = refine_slot_rows_launch(c, B, np, d_row);
+            if (rc2 != RSDSFM_OK) return rc2;
+            rc2 = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)refine_slot_row_doubles(np));
+            if (rc2 != RSDSFM_OK) return rc2;
+            return refine_slot_apply_launch(c, B, np, d_rows_all, R);
+        };
         const int hint = D->refine_iters_hint;
-        int chunk = hint >= 1 ? std::min(hint, 10) : 5;
+        int chunk = hint >= 1 ? std::min(hint, 12) : 6;
         for (int launched = 0;; chunk = hint >= 1 ? std::min(5, std::max(2, hint - launched)) : 5) {
             for (int i = 0; i < chunk; ++i) {
-                rc = staged(1);
-                if (rc != RSDSFM_OK) return rc;
-                rc = staged(2);
+                rc = slot();
                 if (rc != RSDSFM_OK) return rc;
             }
             launched += chunk;
@@ -851,9 +859,10 @@ restart_ransac:
             if (rc != RSDSFM_OK) return rc;
             if (*h_bad) return fail(c, RSDSFM_ERR_INVALID, "flow index out of range (bad inlier_idx)");
             if (h_state->termination >= 0) break;
-            if (launched > 4 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
+            if (launched > 8 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
         }
-        D->refine_iters_hint = h_state->iteration;
+        D->refine_iters_hint = h_state->slots;
+        path_flags |= (std::min(h_state->slots, 0xFFFF) << 8);
         d_zsum_global = &B.state->zsum;  // every rank holds the same GLOBAL sum of z of the final state (replicated decide stages)
         for (int i = 0; i < 3; ++i) v[i] = h_state->p[i], w[i] = h_state->p[3 + i];
         k = h_state->p[6];

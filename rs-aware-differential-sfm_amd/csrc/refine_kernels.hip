@@ -159,9 +159,10 @@ __device__ __forceinline__ void block_reduce_store(const double (&v)[NV], int ma
 // g, g + G, g + 2G, ... of its two slots in order (adjacent lanes read adjacent 16-byte pieces of a row: coalesced, 16 loads in
 // flight), then thread s adds the G group sums of slot s in order.  (The first version gave every thread whole rows and reduced the NV per-thread sums with NV / 8 rounds of
 // LDS transposes: 7 us of the 10 us refine_solve_kernel, measured by returning right after the reduction.)
+// stride / offset (in doubles; both even when NV is): the NV slots are a column range of wider rows (the slot rows of the column-tiled solve)
 template <int NV>
 __device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int nblocks, int max_slot,
-                                                double (*s_red)[NV], double* s_out) {
+                                                double (*s_red)[NV], double* s_out, int stride = NV, int offset = 0) {
     constexpr int W = (NV % 2 == 0) ? 2 : 1;  // slots per lane: pairs as double2 when the rows are 16-byte aligned (NV even)
     constexpr int NH = NV / W;                // lanes per row
     constexpr int G = kFB / NH;               // row groups (9 for the 54 Schur sums of NP = 6)
@@ -179,11 +180,11 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
                 const int bj = b + j * G;
                 const int64_t row = bj < nblocks ? bj : g;
                 if (W == 2) {
-                    const double2 x = reinterpret_cast<const double2*>(partials)[row * NH + sp];
+                    const double2 x = reinterpret_cast<const double2*>(partials + row * stride + offset)[sp];
                     v0[j] = bj < nblocks ? x.x : 0.0;
                     v1[j] = bj < nblocks ? x.y : 0.0;
                 } else {
-                    const double x = partials[row * NV + sp];
+                    const double x = partials[row * stride + offset + sp];
                     v0[j] = bj < nblocks ? x : 0.0;
                     v1[j] = 0.0;
                 }
@@ -311,6 +312,38 @@ __global__ __launch_bounds__(kFB) void refine_init_decide_kernel(const double* _
 // ---------------------------------------------------------------------------------------------------
 // pass 1: Schur complement sums
 // ---------------------------------------------------------------------------------------------------
+// one inlier's contribution to the 2 TRI + 2 NP sums, from its residual / Jacobian `o` at the point the sums are taken at, its Jacobi
+// scale `sr`, the parameter columns' scales `sp` and 1 / radius
+template <int NP>
+__device__ __forceinline__ void schur_accumulate(const RJ<NP>& o, double sr, const double (&sp)[NP], double inv_radius,
+                                                 double (&acc)[NP * (NP + 1) + 2 * NP]) {
+    constexpr int TRI = NP * (NP + 1) / 2;
+    const double E0 = o.Jr[0] * sr, E1 = o.Jr[1] * sr;
+    const double ht = E0 * E0 + E1 * E1;
+    const double lam = clampd(ht, kMinLmDiag, kMaxLmDiag) * inv_radius;
+    const double ete_inv = 1.0 / (ht + lam);
+    const double Etb = E0 * o.r[0] + E1 * o.r[1];
+    double F0[NP], F1[NP], EtF[NP];
+#pragma unroll
+    for (int c = 0; c < NP; ++c) {
+        F0[c] = o.Jp[0][c] * sp[c];
+        F1[c] = o.Jp[1][c] * sp[c];
+        EtF[c] = E0 * F0[c] + E1 * F1[c];
+    }
+    int tri = 0;
+#pragma unroll
+    for (int a = 0; a < NP; ++a) {
+        acc[2 * TRI + a] += F0[a] * o.r[0] + F1[a] * o.r[1];
+        acc[2 * TRI + NP + a] += EtF[a] * (ete_inv * Etb);
+#pragma unroll
+        for (int b = a; b < NP; ++b) {
+            acc[tri] += F0[a] * F0[b] + F1[a] * F1[b];
+            acc[TRI + tri] += EtF[a] * (ete_inv * EtF[b]);
+            ++tri;
+        }
+    }
+}
+
 template <int NP>
 __global__ __launch_bounds__(kFB) void refine_schur_kernel(int64_t m, const double4* __restrict__ xyuv,
                                                           const double* __restrict__ beta_in, const double* __restrict__ alpha,
@@ -342,33 +375,94 @@ __global__ __launch_bounds__(kFB) void refine_schur_kernel(int64_t m, const doub
             resid_jac_beta<NP>(c4.x, c4.y, c4.z, c4.w, beta_in[i], 0.0, p, rho[i], o);
         else
             resid_jac<NP>(c4.x, c4.y, c4.z, c4.w, alpha[i], alpha_k[i], p, rho[i], o);
-        const double sr = srho[i];
-        const double E0 = o.Jr[0] * sr, E1 = o.Jr[1] * sr;
-        const double ht = E0 * E0 + E1 * E1;
-        const double lam = clampd(ht, kMinLmDiag, kMaxLmDiag) * inv_radius;
-        const double ete_inv = 1.0 / (ht + lam);
-        const double Etb = E0 * o.r[0] + E1 * o.r[1];
-        double F0[NP], F1[NP], EtF[NP];
+        schur_accumulate<NP>(o, srho[i], sp, inv_radius, acc);
+    }
+    block_reduce_store<CT::NSCHUR>(acc, -1, s_red, partials + (int64_t)blockIdx.x * CT::NSCHUR);
+}
+
+// the serial tail of the reduced solve (one lane): damped Schur complement from the NSCHUR sums `s`, Cholesky, candidate parameters
+template <int NP>
+__device__ __forceinline__ void solve_serial(RefineState* st, const double* s, const double (&p_cur)[7], const double (&sp_cur)[NP], double radius) {
+    using CT = Counts<NP>;
+    st->iteration += 1;
+    const double inv_radius = 1.0 / radius;
+    // reduced system in registers (all loops fully unrolled: static indices, no LDS round trips in the serial chain)
+    double sv[CT::NSCHUR];
 #pragma unroll
-        for (int c = 0; c < NP; ++c) {
-            F0[c] = o.Jp[0][c] * sp[c];
-            F1[c] = o.Jp[1][c] * sp[c];
-            EtF[c] = E0 * F0[c] + E1 * F1[c];
-        }
+    for (int i = 0; i < CT::NSCHUR; ++i) sv[i] = s[i];
+    double S[NP][NP], rhs[NP], yv[NP], yp[NP];
+    {
         int tri = 0;
 #pragma unroll
         for (int a = 0; a < NP; ++a) {
-            acc[2 * CT::TRI + a] += F0[a] * o.r[0] + F1[a] * o.r[1];
-            acc[2 * CT::TRI + NP + a] += EtF[a] * (ete_inv * Etb);
+            rhs[a] = sv[2 * CT::TRI + a] - sv[2 * CT::TRI + NP + a];
 #pragma unroll
             for (int b = a; b < NP; ++b) {
-                acc[tri] += F0[a] * F0[b] + F1[a] * F1[b];
-                acc[CT::TRI + tri] += EtF[a] * (ete_inv * EtF[b]);
+                double sab = sv[tri] - sv[CT::TRI + tri];
+                if (a == b) sab += clampd(sv[tri], kMinLmDiag, kMaxLmDiag) * inv_radius;  // D_f^2
+                S[a][b] = sab;
+                S[b][a] = sab;
                 ++tri;
             }
         }
     }
-    block_reduce_store<CT::NSCHUR>(acc, -1, s_red, partials + (int64_t)blockIdx.x * CT::NSCHUR);
+    // dense Cholesky solve (mirrors the oracle's chol_solve operation for operation)
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        if (ok) {
+            double d = S[j][j];
+#pragma unroll
+            for (int t = 0; t < j; ++t) d -= S[j][t] * S[j][t];
+            if (!(d > 0.0)) {
+                ok = false;
+            } else {
+                d = sqrt(d);
+                S[j][j] = d;
+#pragma unroll
+                for (int i = j + 1; i < NP; ++i) {
+                    double sacc = S[i][j];
+#pragma unroll
+                    for (int t = 0; t < j; ++t) sacc -= S[i][t] * S[j][t];
+                    S[i][j] = sacc / d;
+                }
+            }
+        }
+    }
+    if (ok) {
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            double sacc = rhs[i];
+#pragma unroll
+            for (int t = 0; t < i; ++t) sacc -= S[i][t] * yv[t];
+            yv[i] = sacc / S[i][i];
+        }
+#pragma unroll
+        for (int i = NP - 1; i >= 0; --i) {
+            double sacc = yv[i];
+#pragma unroll
+            for (int t = i + 1; t < NP; ++t) sacc -= S[t][i] * yp[t];
+            yp[i] = sacc / S[i][i];
+        }
+        double stepsq = 0.0;
+        double pc_new[7];
+#pragma unroll
+        for (int c = 0; c < 7; ++c) pc_new[c] = p_cur[c];
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            const double step = -yp[c];
+            const double pc = p_cur[c] + step * sp_cur[c];
+            pc_new[c] = pc;
+            const double dx = p_cur[c] - pc;
+            stepsq += dx * dx;
+        }
+#pragma unroll
+        for (int c = 0; c < 7; ++c) st->pc[c] = pc_new[c];
+#pragma unroll
+        for (int c = 0; c < NP; ++c) st->yp[c] = yp[c];
+        st->stepsq_p = stepsq;
+    }
+    st->solve_ok = ok ? 1 : 0;
 }
 
 // reduced system + Cholesky (one workgroup; the solve itself runs on one lane: NP <= 7)
@@ -398,87 +492,7 @@ __global__ __launch_bounds__(kFB) void refine_solve_kernel(const double* __restr
         for (int c = 0; c < NP; ++c) sp_cur[c] = st->sp[c];
     }
     reduce_partials<CT::NSCHUR>(partials, nblocks >= 0 ? nblocks : st->grid, -1, s_red, s);
-    if (threadIdx.x == 0) {
-        st->iteration += 1;
-        const double inv_radius = 1.0 / radius;
-        // reduced system in registers (all loops fully unrolled: static indices, no LDS round trips in the serial chain)
-        double sv[CT::NSCHUR];
-#pragma unroll
-        for (int i = 0; i < CT::NSCHUR; ++i) sv[i] = s[i];
-        double S[NP][NP], rhs[NP], yv[NP], yp[NP];
-        {
-            int tri = 0;
-#pragma unroll
-            for (int a = 0; a < NP; ++a) {
-                rhs[a] = sv[2 * CT::TRI + a] - sv[2 * CT::TRI + NP + a];
-#pragma unroll
-                for (int b = a; b < NP; ++b) {
-                    double sab = sv[tri] - sv[CT::TRI + tri];
-                    if (a == b) sab += clampd(sv[tri], kMinLmDiag, kMaxLmDiag) * inv_radius;  // D_f^2
-                    S[a][b] = sab;
-                    S[b][a] = sab;
-                    ++tri;
-                }
-            }
-        }
-        // dense Cholesky solve (mirrors the oracle's chol_solve operation for operation)
-        bool ok = true;
-#pragma unroll
-        for (int j = 0; j < NP; ++j) {
-            if (ok) {
-                double d = S[j][j];
-#pragma unroll
-                for (int t = 0; t < j; ++t) d -= S[j][t] * S[j][t];
-                if (!(d > 0.0)) {
-                    ok = false;
-                } else {
-                    d = sqrt(d);
-                    S[j][j] = d;
-#pragma unroll
-                    for (int i = j + 1; i < NP; ++i) {
-                        double sacc = S[i][j];
-#pragma unroll
-                        for (int t = 0; t < j; ++t) sacc -= S[i][t] * S[j][t];
-                        S[i][j] = sacc / d;
-                    }
-                }
-            }
-        }
-        if (ok) {
-#pragma unroll
-            for (int i = 0; i < NP; ++i) {
-                double sacc = rhs[i];
-#pragma unroll
-                for (int t = 0; t < i; ++t) sacc -= S[i][t] * yv[t];
-                yv[i] = sacc / S[i][i];
-            }
-#pragma unroll
-            for (int i = NP - 1; i >= 0; --i) {
-                double sacc = yv[i];
-#pragma unroll
-                for (int t = i + 1; t < NP; ++t) sacc -= S[t][i] * yp[t];
-                yp[i] = sacc / S[i][i];
-            }
-            double stepsq = 0.0;
-            double pc_new[7];
-#pragma unroll
-            for (int c = 0; c < 7; ++c) pc_new[c] = p_cur[c];
-#pragma unroll
-            for (int c = 0; c < NP; ++c) {
-                const double step = -yp[c];
-                const double pc = p_cur[c] + step * sp_cur[c];
-                pc_new[c] = pc;
-                const double dx = p_cur[c] - pc;
-                stepsq += dx * dx;
-            }
-#pragma unroll
-            for (int c = 0; c < 7; ++c) st->pc[c] = pc_new[c];
-#pragma unroll
-            for (int c = 0; c < NP; ++c) st->yp[c] = yp[c];
-            st->stepsq_p = stepsq;
-        }
-        st->solve_ok = ok ? 1 : 0;
-    }
+    if (threadIdx.x == 0) solve_serial<NP>(st, s, p_cur, sp_cur, radius);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -564,16 +578,12 @@ __global__ __launch_bounds__(kFB) void refine_backsub_kernel(int64_t m, const do
     block_reduce_store<CT::NBACK>(acc, CT::BACK_MAX, s_red, partials + (int64_t)blockIdx.x * CT::NBACK);
 }
 
+// the serial part of the trust-region decision (one lane): `s` = the NBACK sums (read only when the reduced system had factored);
+// returns 1 when the step was ACCEPTED and the solve goes on (the state then sits at the candidate, with the radius Ceres' rule gives it)
 template <int NP>
-__global__ __launch_bounds__(kFB) void refine_decide_kernel(const double* __restrict__ partials, int nblocks,
-                                                           RefineState* st, double* __restrict__ trace, int trace_rows) {
+__device__ __forceinline__ int decide_serial(RefineState* st, const double* s, int solve_ok, double* __restrict__ trace, int trace_rows) {
     using CT = Counts<NP>;
-    __shared__ double s_red[kFB / 64][CT::NBACK];
-    __shared__ double s[CT::NBACK];
-    if (st->termination >= 0) return;
-    const int solve_ok = st->solve_ok;
-    if (solve_ok) reduce_partials<CT::NBACK>(partials, nblocks >= 0 ? nblocks : st->grid, CT::BACK_MAX, s_red, s);
-    if (threadIdx.x != 0) return;
+    const int successful_before = st->num_successful;
     // optional trace (rsdsfm_set_refine_trace): one row of kRefineTraceCols doubles per LM iteration, see include/rsdsfm.h
     double* tr = (trace && st->iteration >= 1 && st->iteration <= trace_rows) ? trace + (int64_t)(st->iteration - 1) * kRefineTraceCols : nullptr;
     const double model_change = solve_ok ? s[0] : 0.0;
@@ -590,10 +600,10 @@ __global__ __launch_bounds__(kFB) void refine_decide_kernel(const double* __rest
         st->invalid_run += 1;
         if (st->invalid_run >= kMaxInvalid) {
             st->termination = RSDSFM_TERM_FAILURE;
-            return;
+            return 0;
         }
         st->radius *= 0.5;
-        return;
+        return 0;
     }
     st->invalid_run = 0;
     const double step_norm = sqrt(st->stepsq_p + s[1]);
@@ -605,13 +615,13 @@ __global__ __launch_bounds__(kFB) void refine_decide_kernel(const double* __rest
     if (step_norm <= kParameterTol * (st->x_norm + kParameterTol)) {
         if (tr) tr[7] = RSDSFM_TRACE_PARAMETER_TOL;
         st->termination = RSDSFM_TERM_PARAMETER;
-        return;
+        return 0;
     }
     const double cost_change = st->cost - ccost;
     if (fabs(cost_change) <= kFunctionTol * st->cost) {
         if (tr) tr[7] = RSDSFM_TRACE_FUNCTION_TOL;
         st->termination = RSDSFM_TERM_FUNCTION;
-        return;
+        return 0;
     }
     const double rel = cost_change / model_change;
     if (tr) tr[4] = rel;
@@ -638,6 +648,20 @@ __global__ __launch_bounds__(kFB) void refine_decide_kernel(const double* __rest
         st->radius = st->radius / st->decrease_factor;
         st->decrease_factor *= 2.0;
     }
+    return st->termination < 0 && st->num_successful > successful_before ? 1 : 0;
+}
+
+template <int NP>
+__global__ __launch_bounds__(kFB) void refine_decide_kernel(const double* __restrict__ partials, int nblocks,
+                                                           RefineState* st, double* __restrict__ trace, int trace_rows) {
+    using CT = Counts<NP>;
+    __shared__ double s_red[kFB / 64][CT::NBACK];
+    __shared__ double s[CT::NBACK];
+    if (st->termination >= 0) return;
+    const int solve_ok = st->solve_ok;
+    if (solve_ok) reduce_partials<CT::NBACK>(partials, nblocks >= 0 ? nblocks : st->grid, CT::BACK_MAX, s_red, s);
+    if (threadIdx.x != 0) return;
+    (void)decide_serial<NP>(st, s, solve_ok, trace, trace_rows);
 }
 
 // nonlinearRefinement.cc:244-248
@@ -805,6 +829,217 @@ static int refine_stage_apply_t(Ctx* c, const RefineBuffers& B, int stage, const
         hipLaunchKernelGGL(refine_solve_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state);
     else
         hipLaunchKernelGGL(refine_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state, c->d_refine_trace, c->refine_trace_rows);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// column-tiled solve: ONE exchange per LM iteration
+// ---------------------------------------------------------------------------------------------------
+// The two-stage protocol above exchanges twice per iteration (Schur rows -> solve; back-substitution rows -> decision) because the next
+// Schur sums depend on the decision: on the point (candidate or not) and on the radius Ceres' rule derives from the step quality.  A
+// SLOT merges them: its pass runs the back-substitution of iteration i AND, at the candidate it has just formed, the Schur sums of
+// iteration i + 1 for the radius an accepted step of quality >= 0.937 gets (radius_accept(radius, 1): x 3, the common case); one row
+// [NSCHUR | NBACK] per rank travels; the apply stage decides iteration i and -- when the step was accepted with exactly that radius --
+// solves iteration i + 1 from the speculated sums, which are the very numbers the Schur pass would produce (same per-inlier code, same
+// thread mapping, same reductions).  Otherwise (rejected, invalid, or another radius) it sets RefineState::need_schur and the NEXT slot is a
+// plain Schur pass.  The host enqueues slots without knowing which kind each will be: the kernels read it from the state.
+template <int NP>
+struct SlotRow {
+    using CT = Counts<NP>;
+    static constexpr int OFF_BACK = CT::NSCHUR;                                   // (even: NBACK rows of NP = 6 stay 16-byte aligned)
+    static constexpr int NW = CT::NSCHUR + CT::NBACK + ((CT::NBACK & 1) ? 1 : 0);  // row width (even)
+};
+
+template <int NP>
+__global__ __launch_bounds__(kFB) void refine_slot_pass_kernel(int64_t m, const double4* __restrict__ xyuv, const double* __restrict__ beta_in,
+                                                              const double* __restrict__ alpha, const double* __restrict__ alpha_k,
+                                                              double* __restrict__ rho_a, double* __restrict__ rho_b, const double* __restrict__ srho,
+                                                              const RefineState* __restrict__ st, double* __restrict__ partials, int want_zsum) {
+    using CT = Counts<NP>;
+    using SR = SlotRow<NP>;
+    __shared__ double s_redS[kFB / 64][CT::NSCHUR];
+    __shared__ double s_redB[kFB / 64][CT::NBACK];
+    if (st->termination >= 0) return;
+    double* row = partials + (int64_t)blockIdx.x * SR::NW;
+    double p[7], sp[NP];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) p[c] = st->p[c];
+#pragma unroll
+    for (int c = 0; c < NP; ++c) sp[c] = st->sp[c];
+    const double* __restrict__ rho = st->cur ? rho_b : rho_a;
+    const int64_t stride = (int64_t)gridDim.x * kFB;
+    double accS[CT::NSCHUR];
+#pragma unroll
+    for (int s = 0; s < CT::NSCHUR; ++s) accS[s] = 0.0;
+    if (st->need_schur) {  // a plain Schur pass at the current state (refine_schur_kernel's loop)
+        if (st->iteration >= kMaxIter || st->radius < kMinRadius) return;  // (the apply stage records the termination)
+        const double inv_radius = 1.0 / st->radius;
+        for (int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x; i < m; i += stride) {
+            const double4 c4 = xyuv[i];
+            RJ<NP> o;
+            if (NP == 6)
+                resid_jac_beta<NP>(c4.x, c4.y, c4.z, c4.w, beta_in[i], 0.0, p, rho[i], o);
+            else
+                resid_jac<NP>(c4.x, c4.y, c4.z, c4.w, alpha[i], alpha_k[i], p, rho[i], o);
+            schur_accumulate<NP>(o, srho[i], sp, inv_radius, accS);
+        }
+        block_reduce_store<CT::NSCHUR>(accS, -1, s_redS, row);
+        return;
+    }
+    if (!st->solve_ok) return;
+    // the back-substitution of this iteration (refine_backsub_kernel's loop) + the Schur sums of the next one at the candidate
+    double pc[7], yp[NP];
+#pragma unroll
+    for (int c = 0; c < 7; ++c) pc[c] = st->pc[c];
+#pragma unroll
+    for (int c = 0; c < NP; ++c) yp[c] = st->yp[c];
+    const double inv_radius = 1.0 / st->radius;
+    const double inv_radius_spec = 1.0 / radius_accept(st->radius, 1.0);
+    double* __restrict__ cand = st->cur ? rho_a : rho_b;
+    double acc[CT::NBACK];
+#pragma unroll
+    for (int s = 0; s < CT::NBACK; ++s) acc[s] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x; i < m; i += stride) {
+        const double4 c4 = xyuv[i];
+        const double x = c4.x, y = c4.y;
+        const double rh = rho[i];
+        double be, dbe = 0.0, bec, dbec = 0.0;
+        if (NP == 6) {
+            be = bec = beta_in[i];
+        } else {
+            const double al = alpha[i], ak = alpha_k[i];
+            be = beta_of(al, ak, p[6]), dbe = dbeta_of(al, ak, p[6]);
+            bec = beta_of(al, ak, pc[6]), dbec = dbeta_of(al, ak, pc[6]);
+        }
+        RJ<NP> o;
+        resid_jac_beta<NP>(x, y, c4.z, c4.w, be, dbe, p, rh, o);
+        const double sr = srho[i];
+        const double E0 = o.Jr[0] * sr, E1 = o.Jr[1] * sr;
+        const double ht = E0 * E0 + E1 * E1;
+        const double lam = clampd(ht, kMinLmDiag, kMaxLmDiag) * inv_radius;
+        const double ete_inv = 1.0 / (ht + lam);
+        const double Etb = E0 * o.r[0] + E1 * o.r[1];
+        double Fy0 = 0.0, Fy1 = 0.0;
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            Fy0 += o.Jp[0][c] * sp[c] * yp[c];
+            Fy1 += o.Jp[1][c] * sp[c] * yp[c];
+        }
+        const double ye = ete_inv * (Etb - (E0 * Fy0 + E1 * Fy1));
+        const double step_e = -ye;
+        const double m0 = -Fy0 + E0 * step_e, m1 = -Fy1 + E1 * step_e;
+        acc[0] -= m0 * (o.r[0] + m0 / 2.0) + m1 * (o.r[1] + m1 / 2.0);
+        const double cd = rh + step_e * sr;
+        cand[i] = cd;
+        const double dx = rh - cd;
+        acc[1] += dx * dx;
+        RJ<NP> oc;
+        resid_jac_beta<NP>(x, y, c4.z, c4.w, bec, dbec, pc, cd, oc);
+        const double c2 = oc.r[0] * oc.r[0] + oc.r[1] * oc.r[1];
+        acc[2] += c2;
+        acc[3] += c2;
+#pragma unroll
+        for (int c = 0; c < NP; ++c) acc[4 + c] += oc.Jp[0][c] * oc.r[0] + oc.Jp[1][c] * oc.r[1];
+        acc[CT::BACK_MAX] = fmax(acc[CT::BACK_MAX], fabs(oc.Jr[0] * oc.r[0] + oc.Jr[1] * oc.r[1]));
+        acc[CT::BACK_MAX + 1] += cd * cd;
+        if (want_zsum) acc[CT::BACK_MAX + 2] += 1.0 / cd;
+        schur_accumulate<NP>(oc, sr, sp, inv_radius_spec, accS);  // (oc: exactly what the next Schur pass would evaluate at the accepted candidate)
+    }
+    block_reduce_store<CT::NSCHUR>(accS, -1, s_redS, row);
+    __syncthreads();
+    block_reduce_store<CT::NBACK>(acc, CT::BACK_MAX, s_redB, row + SR::OFF_BACK);
+}
+
+// the shard's slot partials [workgroups][NW] reduced to one row [NW]: the two column ranges with the reductions of their own stages
+template <int NP>
+__global__ __launch_bounds__(kFB) void refine_slot_row_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ row) {
+    using CT = Counts<NP>;
+    using SR = SlotRow<NP>;
+    __shared__ double s_redS[kFB / 64][CT::NSCHUR];
+    __shared__ double s_redB[kFB / 64][CT::NBACK];
+    __shared__ double sS[CT::NSCHUR];
+    __shared__ double sB[CT::NBACK];
+    reduce_partials<CT::NSCHUR>(partials, nblocks, -1, s_redS, sS, SR::NW, 0);
+    reduce_partials<CT::NBACK>(partials, nblocks, CT::BACK_MAX, s_redB, sB, SR::NW, SR::OFF_BACK);
+    if (threadIdx.x < CT::NSCHUR) row[threadIdx.x] = sS[threadIdx.x];
+    if (threadIdx.x < CT::NBACK) row[SR::OFF_BACK + threadIdx.x] = sB[threadIdx.x];
+    if (threadIdx.x == 0 && (CT::NBACK & 1)) row[SR::NW - 1] = 0.0;
+}
+
+// the apply stage of a slot, replicated on every rank: rows_all = the gathered [nranks][NW] rows
+template <int NP>
+__global__ __launch_bounds__(kFB) void refine_slot_apply_kernel(const double* __restrict__ rows_all, int nranks, RefineState* st,
+                                                               double* __restrict__ trace, int trace_rows) {
+    using CT = Counts<NP>;
+    using SR = SlotRow<NP>;
+    __shared__ double s_redS[kFB / 64][CT::NSCHUR];
+    __shared__ double s_redB[kFB / 64][CT::NBACK];
+    __shared__ double sS[CT::NSCHUR];
+    __shared__ double sB[CT::NBACK];
+    __shared__ int s_do_solve;
+    if (st->termination >= 0) return;
+    const int tid = threadIdx.x;
+    const int was_schur = st->need_schur;
+    if (tid == 0) s_do_solve = was_schur;
+    if (!was_schur) {  // the decision of the iteration whose back-substitution this slot carried
+        const int solve_ok = st->solve_ok;
+        if (solve_ok) reduce_partials<CT::NBACK>(rows_all, nranks, CT::BACK_MAX, s_redB, sB, SR::NW, SR::OFF_BACK);
+        if (tid == 0) {
+            const double r_spec = radius_accept(st->radius, 1.0);  // (what the pass speculated with: the radius BEFORE the decision)
+            const int accepted = decide_serial<NP>(st, sB, solve_ok, trace, trace_rows);
+            // the speculated Schur sums are the next iteration's iff the state moved to the candidate with exactly that radius
+            s_do_solve = (accepted && st->radius == r_spec) ? 1 : 0;
+            st->need_schur = (st->termination < 0 && !s_do_solve) ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) st->slots += 1;
+    if (!s_do_solve || st->termination >= 0) return;
+    if (st->iteration >= kMaxIter) {  // top-of-loop checks of TrustRegionMinimizer (refine_solve_kernel)
+        if (tid == 0) st->termination = RSDSFM_TERM_MAX_ITER;
+        return;
+    }
+    if (st->radius < kMinRadius) {
+        if (tid == 0) st->termination = RSDSFM_TERM_MIN_RADIUS;
+        return;
+    }
+    double p_cur[7], sp_cur[NP];
+    double radius = 0.0;
+    if (tid == 0) {
+        radius = st->radius;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) p_cur[c] = st->p[c];
+#pragma unroll
+        for (int c = 0; c < NP; ++c) sp_cur[c] = st->sp[c];
+    }
+    reduce_partials<CT::NSCHUR>(rows_all, nranks, -1, s_redS, sS, SR::NW, 0);
+    if (tid == 0) {
+        solve_serial<NP>(st, sS, p_cur, sp_cur, radius);
+        st->need_schur = 0;
+    }
+}
+
+template <int NP>
+static int refine_slot_rows_t(Ctx* c, const RefineBuffers& B, double* row) {
+    const int grid = refine_grid(c, B.m);
+    hipLaunchKernelGGL(refine_slot_pass_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m, reinterpret_cast<const double4*>(B.uu), B.beta, B.alpha,
+                       B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials, B.want_zsum ? 1 : 0);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(refine_slot_row_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, row);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+int refine_slot_row_doubles(int np) { return np == 7 ? SlotRow<7>::NW : SlotRow<6>::NW; }
+int refine_slot_partials_doubles(const Ctx* c, int64_t m) { return refine_grid(c, m) * SlotRow<7>::NW; }
+int refine_slot_rows_launch(Ctx* c, const RefineBuffers& B, int np, double* row) {
+    return np == 7 ? refine_slot_rows_t<7>(c, B, row) : refine_slot_rows_t<6>(c, B, row);
+}
+int refine_slot_apply_launch(Ctx* c, const RefineBuffers& B, int np, const double* rows_all, int nranks) {
+    if (np == 7)
+        hipLaunchKernelGGL(refine_slot_apply_kernel<7>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state, c->d_refine_trace, c->refine_trace_rows);
+    else
+        hipLaunchKernelGGL(refine_slot_apply_kernel<6>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state, c->d_refine_trace, c->refine_trace_rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

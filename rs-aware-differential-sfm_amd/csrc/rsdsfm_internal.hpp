@@ -348,10 +348,14 @@ struct RefineState {
     // enqueues the refinement before it has read the RANSAC result: refine_state_from_best_kernel); kernels launched with
     // m < 0 / nblocks < 0 take these
     int64_t m;
-    int32_t grid, _pad;
+    int32_t grid;
+    // column-tiled solve, one exchange per LM iteration (refine slot kernels): 1 = the next slot is a plain Schur pass at the current state
+    // (the first iteration, or the sums speculated with the previous back-substitution do not apply); slots = slots consumed so far
+    int32_t need_schur;
     // sum of z = 1 / rho over the inliers at the CURRENT state (what refine_finish_kernel writes), kept by the decide stages when the passes
     // are asked for it (RefineBuffers::want_zsum: the column-tiled solve, whose mean-z sign test main.cc:466-472 then needs no exchange of its own)
     double zsum;
+    int32_t slots, _pad2;
 };
 struct RefineBuffers {
     const double* flow;  // 2 x n_flow
@@ -463,6 +467,12 @@ int refine_iter_launch(Ctx* c, const RefineBuffers& B, int np);
 int refine_finish_launch(Ctx* c, const RefineBuffers& B, double* inl_out);
 // row-tiled stages: stage 0 = iteration-zero sums, 1 = Schur sums, 2 = back-substitution sums
 int refine_stage_row_doubles(int np, int stage);
+// one exchange per LM iteration (dist_host.hip): a slot = one streaming pass -> one row of refine_slot_row_doubles(np) doubles per rank
+// -> (all-gather) -> refine_slot_apply_launch on every rank
+int refine_slot_row_doubles(int np);
+int refine_slot_partials_doubles(const Ctx* c, int64_t m);
+int refine_slot_rows_launch(Ctx* c, const RefineBuffers& B, int np, double* row);
+int refine_slot_apply_launch(Ctx* c, const RefineBuffers& B, int np, const double* rows_all, int nranks);
 int refine_stage_rows_launch(Ctx* c, const RefineBuffers& B, int np, int stage, double* row);
 int refine_stage_apply_launch(Ctx* c, const RefineBuffers& B, int np, int stage, const double* rows_all, int nranks, int64_t m_total);
 }  // namespace rsdsfm

@@ -141,6 +141,9 @@ int rsdsfm_depth_restarts(rsdsfm_ctx* ctx, int64_t* count);
  * of the hypothesis-batched LM depth solves, `ransac_lm_kernel<true, 3, BASE, CORE>` -- with two HIP events on the context's stream (in
  * situ: same launch, same neighbours, same clocks as any other solve).  rsdsfm_profile_last_ms(ctx, "ransac_lm_round0", &ms)
  * returns the duration of that launch in the most recent call.  bench.py's roofline record uses it.
+ * rsdsfm_profile_last_ms(ctx, "ransac_lm_round0_clock_mhz", &mhz) returns -- in MHz, through the same out-parameter -- the shader clock
+ * one workgroup in the middle of that launch ran at (shader clocks of its life / 100 MHz ticks of its life): the chip lowers its clock
+ * under sustained fp64 load, and a roofline priced at the nominal clock overstates the ceiling by that ratio.
  * With profiling on for the FIRST context of a batched dense depth solve (rsdsfm_estimate_inverse_depths_batch_dev), its streaming
  * launch (`depth_lm_batch_kernel`) carries the dispatch's own start / stop timestamps (hipExtLaunchKernel events: what rocprofv3
  * --kernel-trace reports for the kernel, without the gap between launches): rsdsfm_profile_last_ms(ctx, "depth_lm_batch", &ms). */

@@ -163,6 +163,7 @@ void rsdsfm_destroy(rsdsfm_ctx* ctx) {
     if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
     for (hipEvent_t e : c->ev_prof)
         if (e) (void)hipEventDestroy(e);
+    if (c->d_clk_probe) (void)hipFree(c->d_clk_probe);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete ctx;
 }
@@ -188,6 +189,8 @@ int rsdsfm_set_profiling(rsdsfm_ctx* ctx, int on) {
     if (on && !c->ev_prof[0]) {
         RSDSFM_HIP_CHECK(c, hipEventCreate(&c->ev_prof[0]));
         RSDSFM_HIP_CHECK(c, hipEventCreate(&c->ev_prof[1]));
+        RSDSFM_HIP_CHECK(c, hipMalloc((void**)&c->d_clk_probe, 4 * sizeof(unsigned long long)));
+        RSDSFM_HIP_CHECK(c, hipMemset(c->d_clk_probe, 0, 4 * sizeof(unsigned long long)));
     }
     c->profile = on != 0;
     c->prof_pending = false;
@@ -196,11 +199,21 @@ int rsdsfm_set_profiling(rsdsfm_ctx* ctx, int on) {
 
 int rsdsfm_profile_last_ms(rsdsfm_ctx* ctx, const char* what, double* ms) {
     CTX_OR_FAIL(ctx);
-    const int which = !what ? -1 : !strcmp(what, "ransac_lm_round0") ? 0 : !strcmp(what, "depth_lm_batch") ? 1 : -1;
-    if (which < 0 || !ms) return fail(c, RSDSFM_ERR_INVALID, "unknown profile record (known: \"ransac_lm_round0\", \"depth_lm_batch\")");
+    const bool clock = what && !strcmp(what, "ransac_lm_round0_clock_mhz");
+    const int which = !what ? -1 : clock || !strcmp(what, "ransac_lm_round0") ? 0 : !strcmp(what, "depth_lm_batch") ? 1 : -1;
+    if (which < 0 || !ms)
+        return fail(c, RSDSFM_ERR_INVALID, "unknown profile record (known: \"ransac_lm_round0\", \"ransac_lm_round0_clock_mhz\", \"depth_lm_batch\")");
     if (!c->prof_pending || c->prof_what != which)
         return fail(c, RSDSFM_ERR_INVALID, "no such profile record: enable rsdsfm_set_profiling and run a RANSAC (LM mode) / a batched dense depth solve first");
     RSDSFM_HIP_CHECK(c, hipEventSynchronize(c->ev_prof[1]));
+    if (clock) {
+        // the shader clock one workgroup of that launch ran at: clocks of its life / 100 MHz ticks of its life (ransac_lm_kernel clk_probe)
+        unsigned long long h[4];
+        RSDSFM_HIP_CHECK(c, hipMemcpy(h, c->d_clk_probe, sizeof(h), hipMemcpyDeviceToHost));
+        if (h[3] <= h[1] || h[2] <= h[0]) return fail(c, RSDSFM_ERR_INVALID, "the bracketed launch left no clock stamps");
+        *ms = (double)(h[2] - h[0]) * 100.0 / (double)(h[3] - h[1]);
+        return RSDSFM_OK;
+    }
     float f = 0.f;
     RSDSFM_HIP_CHECK(c, hipEventElapsedTime(&f, c->ev_prof[0], c->ev_prof[1]));
     *ms = (double)f;

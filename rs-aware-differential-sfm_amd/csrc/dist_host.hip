@@ -738,6 +738,7 @@ restart_ransac:
     int64_t m_total = 0;
     for (int r = 0; r < R; ++r) m_total += h_m[r];
     const int64_t m = h_m[rank];
+    auto m_total_of = [&]() -> int64_t { return m_total; };
     if (m_total != h_best->num_inliers) return fail(c, RSDSFM_ERR_NUMERIC, "inlier count mismatch between scoring and compaction");
     res->num_inliers = m_total;
     res->best_trial = h_best->best_trial;
@@ -747,6 +748,34 @@ restart_ransac:
     double v[3] = {h_best->hyp[3], h_best->hyp[4], h_best->hyp[5]}, w[3] = {h_best->hyp[0], h_best->hyp[1], h_best->hyp[2]}, k = h_best->hyp[6];
     double* d_final = d_inl;
     const double* d_zsum_global = nullptr;
+
+    // mean-z sign (global), depth-map slab, ONE all-gather of the slabs, pose table.  The motion comes from the host (v_host; pose table by a
+    // launch of its own) or -- enqueued behind the refinement's output pass BEFORE the host has read the state, so that the wait for the state
+    // covers this stage too -- from the device-resident state (v_dev = RefineState::p; the sign kernel writes the pose table).
+    auto depth_stage = [&](double* d_points, const double* d_zsums, int nz, const double* v_host, const double* w_host, double k_host,
+                           const double* state_p_dev) -> int {
+        double* d_slab = d_gather + (size_t)rank * cap;
+        if (cap > Ns) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_slab + Ns, 0, sizeof(double) * (cap - Ns), c->stream));  // columns past the image: zeros
+        PoseTableOut pt;
+        const bool table = d_R_rows9 && d_t_rows3;
+        if (state_p_dev && table) pt.R = d_R_rows9, pt.t = d_t_rows3, pt.rows = rows, pt.gamma = gamma, pt.wk_dev = state_p_dev + 3;
+        int rc2 = depth_map_slab_launch(c, d_points, h_m[rank], d_zsums, nz, m_total_of(), v_host, fx, fy, cx, cy, rows, col0, sc, d_slab, nullptr, d_ys,
+                                        d_header, h_header, state_p_dev, nullptr, state_p_dev && table ? &pt : nullptr);
+        if (rc2 != RSDSFM_OK) return rc2;
+        rc2 = all_gather(c, D, d_slab, d_gather, sizeof(double) * cap);  // the one data-path collective
+        if (rc2 != RSDSFM_OK) return rc2;
+        if (padded)
+            RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_depth_map, d_gather, sizeof(double) * (size_t)rows * (size_t)cols, hipMemcpyDeviceToDevice, c->stream));
+        if (!state_p_dev && table) {
+            Pose pose;
+            for (int i = 0; i < 3; ++i) pose.v[i] = v_host[i], pose.w[i] = w_host[i];
+            pose.k = k_host;
+            rc2 = pose_table_launch(c, pose, gamma, rows, d_R_rows9, d_t_rows3, d_header + 1);  // v' (possibly flipped) from the device header
+            if (rc2 != RSDSFM_OK) return rc2;
+        }
+        return RSDSFM_OK;
+    };
+    bool depth_done = false;
 
     // ---- joint refinement: per LM iteration two staged passes (Schur sums -> reduced solve; back-substitution sums -> decision) ----
     if (prm->use_refinement) {
@@ -854,6 +883,13 @@ restart_ransac:
             launched += chunk;
             rc = refine_finish_launch(c, B, d_inl_ref);  // enqueued before the poll: the common case ends within one chunk
             if (rc != RSDSFM_OK) return rc;
+            // ... and so is the depth-map stage, from the device-resident state, behind a chunk that can be the last one (every rank holds
+            // the same hint): the poll's wait then covers it.  Behind a chunk the solve outlives it runs again; what it wrote is overwritten.
+            depth_done = hint < 1 || launched + 1 >= hint;
+            if (depth_done) {
+                rc = depth_stage(d_inl_ref, &B.state->zsum, 1, nullptr, nullptr, 0.0, B.state->p);
+                if (rc != RSDSFM_OK) return rc;
+            }
             RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_state, B.state, sizeof(RefineState) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
             rc = sync(c, D);
             if (rc != RSDSFM_OK) return rc;
@@ -876,8 +912,8 @@ restart_ransac:
         d_final = d_inl_ref;
     }
 
-    // ---- mean-z sign (global), depth-map slab, ONE all-gather of the slabs, pose table ----
-    {
+    // ---- mean-z sign (global), depth-map slab, ONE all-gather of the slabs, pose table (unless it rode behind the refinement's last chunk) ----
+    if (!depth_done) {
         Arena ws2(c->d_ws);
         double* d_zpart = ws2.take<double>(1024);
         const double* d_zsums = d_zsum_global;
@@ -890,21 +926,8 @@ restart_ransac:
             d_zsums = d_zs_all;
             nz = R;
         }
-        double* d_slab = d_gather + (size_t)rank * cap;
-        if (cap > Ns) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_slab + Ns, 0, sizeof(double) * (cap - Ns), c->stream));  // columns past the image: zeros
-        rc = depth_map_slab_launch(c, d_final, m, d_zsums, nz, m_total, v, fx, fy, cx, cy, rows, col0, sc, d_slab, nullptr, d_ys, d_header, h_header);
+        rc = depth_stage(d_final, d_zsums, nz, v, w, k, nullptr);
         if (rc != RSDSFM_OK) return rc;
-        rc = all_gather(c, D, d_slab, d_gather, sizeof(double) * cap);  // the one data-path collective
-        if (rc != RSDSFM_OK) return rc;
-        if (padded)
-            RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_depth_map, d_gather, sizeof(double) * (size_t)rows * (size_t)cols, hipMemcpyDeviceToDevice, c->stream));
-        if (d_R_rows9 && d_t_rows3) {
-            Pose pose;
-            for (int i = 0; i < 3; ++i) pose.v[i] = v[i], pose.w[i] = w[i];
-            pose.k = k;
-            rc = pose_table_launch(c, pose, gamma, rows, d_R_rows9, d_t_rows3, d_header + 1);  // v' (possibly flipped) from the device header
-            if (rc != RSDSFM_OK) return rc;
-        }
         rc = sync(c, D);
         if (rc != RSDSFM_OK) return rc;
     }

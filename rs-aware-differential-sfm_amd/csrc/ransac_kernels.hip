@@ -139,7 +139,8 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
                                                        const LmState* __restrict__ states,
                                                        double* __restrict__ partials, int round, double tol,
                                                        int* __restrict__ running_flag, int ntile_blocks, int ngroups,
-                                                       const int* __restrict__ m9_core_flag, int m9_core_epoch) {
+                                                       const int* __restrict__ m9_core_flag, int m9_core_epoch,
+                                                       unsigned long long* __restrict__ clk_probe, int clk_bid) {
     extern __shared__ double s_acc[];  // [T][NSR]
     // the decide kernel of this round counts the still-running hypotheses into *running_flag; it runs after this kernel
     // (stream order), so the counter is cleared here instead of by a separate memset
@@ -171,6 +172,12 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
         grp = nfull;
     }
     if (tb >= ntile_blocks) return;
+    // rsdsfm_set_profiling: one lane of one workgroup in the middle of the launch (clk_bid; -1 = off) stamps the shader clock counter
+    // and the 100 MHz counter at both ends of its life -- the clock this kernel actually runs at (the chip lowers it under fp64 load)
+    if (bid == clk_bid && threadIdx.x == 0) {
+        clk_probe[0] = __builtin_amdgcn_s_memtime();
+        clk_probe[1] = __builtin_amdgcn_s_memrealtime();
+    }
     __shared__ LmPlanLds plan;
     __shared__ double s_red[2][kRB / 64][NSR];
     __shared__ double s_T[kRB / 64][kNSum * kTStride];  // per-wave transpose buffer of the sum slots
@@ -325,6 +332,10 @@ __global__ __launch_bounds__(kRB) void ransac_lm_kernel(const double2* __restric
     for (int i = t_begin * NSR + tid; i < t_end * NSR; i += kRB) {
         const int t = i / NSR, sl = i - t * NSR;
         partials[((int64_t)t * ntile_blocks + tb) * NSR + sl] = s_acc[i];
+    }
+    if (bid == clk_bid && tid == 0) {
+        clk_probe[2] = __builtin_amdgcn_s_memtime();
+        clk_probe[3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -960,15 +971,17 @@ int ransac_lm_partials_doubles(const Ctx* c, int64_t n, int batch) { return rans
 
 static int lm_launch(Ctx* c, const dim3& g2, int k0, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                      const double* hyp, int T, const LmState* states, double* partials, int round, double tol, int* flags, int fused_base,
-                     bool core_math, const int* m9_flag, int m9_epoch) {
+                     bool core_math, const int* m9_flag, int m9_epoch, unsigned long long* clk = nullptr) {
     const double2* q2 = reinterpret_cast<const double2*>(q);
     const double2* u2 = reinterpret_cast<const double2*>(u);
     const size_t lds = sizeof(double) * T * NSR;
     // g2 = (tile blocks, hypothesis groups) is flattened into a 1-D grid of windows of 8 tile blocks x groups (see the kernel)
     const int tiles = (int)g2.x, groups = (int)g2.y;
     const dim3 g1((unsigned)(((tiles + 7) / 8) * 8 * groups));
+    // the workgroup that stamps the clocks (see the kernel): group 0 of the middle window's first tile
+    const int clk_bid = !clk ? -1 : groups > 1 ? (((tiles + 7) / 8) / 2) * 8 * (groups - 1) : tiles / 2;
 #define RSDSFM_LM_LAUNCH(R0, K0, BASE, CORE) \
-    hipLaunchKernelGGL((ransac_lm_kernel<R0, K0, BASE, CORE>), g1, dim3(kRB), lds, c->stream, q2, u2, a, ak, n, hyp, T, states, partials, round, tol, flags, tiles, groups, m9_flag, m9_epoch)
+    hipLaunchKernelGGL((ransac_lm_kernel<R0, K0, BASE, CORE>), g1, dim3(kRB), lds, c->stream, q2, u2, a, ak, n, hyp, T, states, partials, round, tol, flags, tiles, groups, m9_flag, m9_epoch, clk, clk_bid)
     // (core: see the kernel's CORE -- needs the flag words, and stands for the reference arithmetic's functions only)
     const bool core = core_math && flags != nullptr && !RSDSFM_FUSED;
     (void)core;
@@ -1010,7 +1023,8 @@ int ransac_lm_round_launch(Ctx* c, const double* q, const double* u, const doubl
     if (fused_base < 1 || fused_base > k0) fused_base = std::min(2, k0);
     const bool prof = c->profile && round == 0 && c->ev_prof[0] && c->ev_prof[1];
     if (prof) RSDSFM_HIP_CHECK(c, hipEventRecord(c->ev_prof[0], c->stream));
-    int rc = lm_launch(c, g2, k0, q, u, a, ak, n, hyp, T, states, partials, round, tol, flags, fused_base, core_math, round == 0 ? m9_core_flag : nullptr, m9_core_epoch);
+    int rc = lm_launch(c, g2, k0, q, u, a, ak, n, hyp, T, states, partials, round, tol, flags, fused_base, core_math, round == 0 ? m9_core_flag : nullptr, m9_core_epoch,
+                       prof ? c->d_clk_probe : nullptr);
     if (rc != RSDSFM_OK) return rc;
     if (prof) {
         RSDSFM_HIP_CHECK(c, hipEventRecord(c->ev_prof[1], c->stream));

@@ -87,6 +87,7 @@ int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const 
         hs->p[6] = k_in;
         hs->termination = -1;
         hs->radius = kInitialRadius;
+        hs->need_schur = 1;  // the first slot of the iteration loop is the Schur pass of iteration 1
         *h_bad = 0;
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(B.state, hs, sizeof(RefineState) + sizeof(int), hipMemcpyHostToDevice, c->stream));
     }
@@ -94,19 +95,22 @@ int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const 
     if (rc != RSDSFM_OK) return rc;
     rc = refine_init_launch(c, B, np);
     if (rc != RSDSFM_OK) return rc;
-    // LM iterations are enqueued in chunks; the kernels of a finished solve return immediately, but an empty iteration still costs
-    // four launches and a chunk that is too short a host round trip.  The first chunk is 5 iterations (DeepFlow-like data
-    // takes 3..6: following the previous solve's count more closely was measured 1 % slower, the counts vary from pair to pair),
-    // except behind a refinement that ended within 2 iterations -- noise-free data, e.g. ground-truth flow, ends after ONE -- where
-    // the first chunk is that count + 1.  The chunking changes when the host looks at the state, never what the kernels compute.
-    // Behind a refinement that took more than 6 (acceleration mode: ~13) the first chunk is that count + 1: an empty iteration is four
-    // launches that leave at once (~7 us), a chunk that is too short a host round trip plus a second output pass and tail (~33 us).
+    // The iteration loop is enqueued in chunks of SLOTS (refine_kernels.hip: a streaming pass + the single-workgroup stage behind it; a solve
+    // of `it` LM iterations consumes it + 1 of them, one more for every step that was rejected or got another radius than the speculated
+    // one).  The kernels of a finished solve return immediately, but an empty slot still costs two launches (~9 us at 1280x720) and a chunk
+    // that is too short a host round trip plus a second output pass and tail (~40 us).  The first chunk is 7 slots: DeepFlow-like pairs
+    // take 3 / 4 / 5 / 6 iterations in 4 / 33 / 46 / 17 % of the solves and one in five has a step whose speculation does not apply
+    // (tools/refine_slots.py: 4 .. 8 slots, 7 cover 96 %; 6 cover 73 % and cost 2 us more per solve on average; following the previous solve's
+    // count more closely was measured 1 % slower, the counts vary from pair to pair) -- except behind a refinement that ended within 3
+    // slots (noise-free data, e.g. ground-truth flow, ends after ONE iteration), where the first chunk is that count + 1, and behind one
+    // that took more than 8 (acceleration mode: ~14), where it is that count + 1 as well.  The chunking changes when the host looks at the
+    // state, never what the kernels compute.
     const int hp = run->hint_prev;
-    run->chunk = (hp >= 0 && hp <= 2) ? hp + 1 : (hp > 6 ? std::min(hp + 1, 16) : 5);
+    run->chunk = (hp >= 0 && hp <= 3) ? hp + 1 : (hp > 8 ? std::min(hp + 1, 17) : 7);
     return refine_enqueue_chunk(c, run);
 }
 
-// one chunk of LM iterations, the output pass and the caller's tail
+// one chunk of slots of the iteration loop, the output pass and the caller's tail
 int refine_enqueue_chunk(Ctx* c, RefineRun* run) {
     for (int i = 0; i < run->chunk; ++i) {
         int rc = refine_iter_launch(c, run->B, run->np);
@@ -117,10 +121,12 @@ int refine_enqueue_chunk(Ctx* c, RefineRun* run) {
     // which saves a host round trip with an idle GPU; if iterations remain it simply runs again after the next chunk
     int rc = refine_finish_launch(c, run->B, run->d_inl_out);
     if (rc != RSDSFM_OK) return rc;
-    // the tail only pays behind a chunk that can be the last one: where the previous solve needed more iterations than are enqueued so
-    // far (acceleration mode: ~10-13) it is left out, and refine_poll enqueues it should the solve end early after all
+    // the tail only pays behind a chunk that can be the last one: where the previous solve needed clearly more slots than are enqueued so
+    // far (acceleration mode: ~14) it is left out, and refine_poll enqueues it should the solve end early after all.  (One more than
+    // enqueued is not "clearly": DeepFlow-like pairs vary by one or two from pair to pair, and a tail that was enqueued in vain is ~20 us
+    // of kernels where a missing one is a ~35 us host round trip with an idle GPU.)
     run->tail_done = false;
-    if (run->tail && !(run->hint_prev > run->launched)) {
+    if (run->tail && !(run->hint_prev > run->launched + 1)) {
         rc = (*run->tail)(run->B);
         run->tail_done = true;
     }
@@ -148,15 +154,15 @@ int refine_poll(Ctx* c, RefineRun* run, double v_out[3], double w_out[3], double
             }
             break;
         }
-        if (run->launched > 4 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
+        if (run->launched > 8 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
         // later chunks: what the previous solve still needed at this point, between 1 and 5 (DeepFlow-like data: 3 / 4 / 5 / 6 / 7
         // iterations in 5 / 37 / 49 / 8.5 / 0.25 % of the pairs, so ONE more is what a solve that outlives the first chunk almost always
-        // needs, and an empty iteration costs four launches; acceleration mode runs ~13 in all)
+        // needs; acceleration mode runs ~13 iterations in all)
         run->chunk = std::min(5, std::max(1, run->hint_prev - run->launched));
         int rc = refine_enqueue_chunk(c, run);
         if (rc != RSDSFM_OK) return rc;
     }
-    c->refine_iters_hint = hs->iteration;
+    c->refine_iters_hint = hs->slots;
     for (int i = 0; i < 3; ++i) {
         v_out[i] = hs->p[i];
         w_out[i] = hs->p[3 + i];

@@ -161,14 +161,17 @@ __device__ __forceinline__ void block_reduce_store(const double (&v)[NV], int ma
 // LDS transposes: 7 us of the 10 us refine_solve_kernel, measured by returning right after the reduction.)
 // stride / offset (in doubles; both even when NV is): the NV slots are a column range of wider rows (the slot rows of the column-tiled solve)
 template <int NV>
-__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int nblocks, int max_slot,
-                                                double (*s_red)[NV], double* s_out, int stride = NV, int offset = 0) {
-    constexpr int W = (NV % 2 == 0) ? 2 : 1;  // slots per lane: pairs as double2 when the rows are 16-byte aligned (NV even)
-    constexpr int NH = NV / W;                // lanes per row
-    constexpr int G = kFB / NH;               // row groups (9 for the 54 Schur sums of NP = 6)
-    constexpr int U = 16;                     // independent loads in flight per thread: the reduction is bound by load latency
-    __shared__ double s_grp[G][NV];
-    const int tid = threadIdx.x;
+struct ReduceShape {
+    static constexpr int W = (NV % 2 == 0) ? 2 : 1;  // slots per lane: pairs as double2 when the rows are 16-byte aligned (NV even)
+    static constexpr int NH = NV / W;                // lanes per row
+    static constexpr int G = kFB / NH;               // row groups (9 for the 54 Schur sums of NP = 6)
+};
+// part 1 (thread `tid` of kFB): the group sums into s_grp[G][NV]; part 2, behind a workgroup barrier: thread s < NV adds the G group sums of slot s
+template <int NV>
+__device__ __forceinline__ void reduce_partials_groups(const double* __restrict__ partials, int nblocks, int max_slot, double (*s_grp)[NV], int tid,
+                                                       int stride, int offset) {
+    constexpr int W = ReduceShape<NV>::W, NH = ReduceShape<NV>::NH, G = ReduceShape<NV>::G;
+    constexpr int U = 16;  // independent loads in flight per thread: the reduction is bound by load latency
     const int g = tid / NH, sp = tid - g * NH;
     if (g < G) {
         const bool mx0 = (W * sp == max_slot), mx1 = (W * sp + 1 == max_slot);
@@ -198,13 +201,24 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
         s_grp[g][W * sp] = a0;
         if (W == 2) s_grp[g][W * sp + 1] = a1;
     }
-    __syncthreads();
+}
+template <int NV>
+__device__ __forceinline__ void reduce_partials_slots(const double (*s_grp)[NV], int max_slot, double* s_out, int tid) {
+    constexpr int G = ReduceShape<NV>::G;
     if (tid < NV) {
         double r = s_grp[0][tid];
 #pragma unroll
         for (int g2 = 1; g2 < G; ++g2) r = (tid == max_slot) ? fmax(r, s_grp[g2][tid]) : r + s_grp[g2][tid];
         s_out[tid] = r;
     }
+}
+template <int NV>
+__device__ __forceinline__ void reduce_partials(const double* __restrict__ partials, int nblocks, int max_slot,
+                                                double (*s_red)[NV], double* s_out, int stride = NV, int offset = 0) {
+    __shared__ double s_grp[ReduceShape<NV>::G][NV];
+    reduce_partials_groups<NV>(partials, nblocks, max_slot, s_grp, threadIdx.x, stride, offset);
+    __syncthreads();
+    reduce_partials_slots<NV>(s_grp, max_slot, s_out, threadIdx.x);
     __syncthreads();
     (void)s_red;
 }
@@ -217,6 +231,14 @@ struct Counts {
     static constexpr int NSCHUR = 2 * TRI + 2 * NP;         // FtF tri, C tri, Ftb, cvec
     static constexpr int NBACK = 3 + 1 + NP + 1 + 1 + 1 + 1;  // model, stepsq_rho, ccost2 | cost2@cand (= ccost2), gp[NP], gmax_rho, xsq_rho, sum of 1 / rho@cand (want_zsum), one unused slot (keeps the rows of NP = 6 an even number of doubles: 16-byte loads in reduce_partials)
     static constexpr int BACK_MAX = 3 + 1 + NP;
+};
+
+// one row of a SLOT (see the slot kernels below): the Schur sums and the back-substitution sums side by side
+template <int NP>
+struct SlotRow {
+    using CT = Counts<NP>;
+    static constexpr int OFF_BACK = CT::NSCHUR;                                   // (even: NBACK rows of NP = 6 stay 16-byte aligned)
+    static constexpr int NW = CT::NSCHUR + CT::NBACK + ((CT::NBACK & 1) ? 1 : 0);  // row width (even)
 };
 
 }  // namespace
@@ -715,6 +737,7 @@ __global__ void refine_state_from_best_kernel(const RansacBest* __restrict__ bes
     z.p[6] = best->hyp[6];
     z.termination = -1;
     z.radius = kInitialRadius;
+    z.need_schur = 1;  // the first slot of the iteration loop is the Schur pass of iteration 1
     // (a RANSAC that is not over -- ransac_pick_kernel -- : no inliers, and every kernel of this refinement leaves at once)
     const int64_t m = best->undecided ? 0 : best->num_inliers_scan;
     z.m = m;
@@ -744,8 +767,9 @@ static inline int refine_grid(const Ctx* c, int64_t m) {
     return (int)b;
 }
 
-int refine_partials_doubles(const Ctx* c, int64_t m) { return refine_grid(c, m) * Counts<7>::NSCHUR; }
-int refine_partials_doubles_cap(const Ctx* c) { return refine_grid_cap(c) * Counts<7>::NSCHUR; }
+// (a workgroup's row: the init sums, the Schur sums, the back-substitution sums, or a slot's Schur | back-substitution sums -- the widest)
+int refine_partials_doubles(const Ctx* c, int64_t m) { return refine_grid(c, m) * SlotRow<7>::NW; }
+int refine_partials_doubles_cap(const Ctx* c) { return refine_grid_cap(c) * SlotRow<7>::NW; }
 
 int refine_state_from_best_launch(Ctx* c, const RansacBest* d_best, const RefineBuffers& B, int np) {
     hipLaunchKernelGGL(refine_state_from_best_kernel, dim3(1), dim3(64), 0, c->stream, d_best, B.state, np, refine_grid_cap(c), B.bad_index);
@@ -762,24 +786,6 @@ static int refine_init_t(Ctx* c, const RefineBuffers& B) {
                        B.beta, B.rho_a, B.srho, B.partials, B.bad_index, B.want_zsum ? 1 : 0);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(refine_init_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, B.m_on_device ? -1 : grid, B.state, m_arg);
-    RSDSFM_HIP_CHECK(c, hipGetLastError());
-    return RSDSFM_OK;
-}
-
-template <int NP>
-static int refine_iter_t(Ctx* c, const RefineBuffers& B) {
-    const int grid = B.m_on_device ? refine_grid_cap(c) : refine_grid(c, B.m);
-    const int64_t m_arg = B.m_on_device ? -1 : B.m;
-    const int nb_arg = B.m_on_device ? -1 : grid;
-    hipLaunchKernelGGL(refine_schur_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, m_arg, reinterpret_cast<const double4*>(B.uu), B.beta,
-                       B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
-    RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(refine_solve_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, nb_arg, B.state);
-    RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(refine_backsub_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, m_arg, reinterpret_cast<const double4*>(B.uu), B.beta,
-                       B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials, B.want_zsum ? 1 : 0);
-    RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(refine_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, nb_arg, B.state, c->d_refine_trace, c->refine_trace_rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
@@ -845,13 +851,6 @@ static int refine_stage_apply_t(Ctx* c, const RefineBuffers& B, int stage, const
 // thread mapping, same reductions).  Otherwise (rejected, invalid, or another radius) it sets RefineState::need_schur and the NEXT slot is a
 // plain Schur pass.  The host enqueues slots without knowing which kind each will be: the kernels read it from the state.
 template <int NP>
-struct SlotRow {
-    using CT = Counts<NP>;
-    static constexpr int OFF_BACK = CT::NSCHUR;                                   // (even: NBACK rows of NP = 6 stay 16-byte aligned)
-    static constexpr int NW = CT::NSCHUR + CT::NBACK + ((CT::NBACK & 1) ? 1 : 0);  // row width (even)
-};
-
-template <int NP>
 __global__ __launch_bounds__(kFB) void refine_slot_pass_kernel(int64_t m, const double4* __restrict__ xyuv, const double* __restrict__ beta_in,
                                                               const double* __restrict__ alpha, const double* __restrict__ alpha_k,
                                                               double* __restrict__ rho_a, double* __restrict__ rho_b, const double* __restrict__ srho,
@@ -861,6 +860,9 @@ __global__ __launch_bounds__(kFB) void refine_slot_pass_kernel(int64_t m, const 
     __shared__ double s_redS[kFB / 64][CT::NSCHUR];
     __shared__ double s_redB[kFB / 64][CT::NBACK];
     if (st->termination >= 0) return;
+    const PassShape ps = pass_shape(st, m);
+    if (!ps.live) return;
+    m = ps.m;
     double* row = partials + (int64_t)blockIdx.x * SR::NW;
     double p[7], sp[NP];
 #pragma unroll
@@ -868,7 +870,7 @@ __global__ __launch_bounds__(kFB) void refine_slot_pass_kernel(int64_t m, const 
 #pragma unroll
     for (int c = 0; c < NP; ++c) sp[c] = st->sp[c];
     const double* __restrict__ rho = st->cur ? rho_b : rho_a;
-    const int64_t stride = (int64_t)gridDim.x * kFB;
+    const int64_t stride = (int64_t)ps.grid * kFB;
     double accS[CT::NSCHUR];
 #pragma unroll
     for (int s = 0; s < CT::NSCHUR; ++s) accS[s] = 0.0;
@@ -967,7 +969,9 @@ __global__ __launch_bounds__(kFB) void refine_slot_row_kernel(const double* __re
     if (threadIdx.x == 0 && (CT::NBACK & 1)) row[SR::NW - 1] = 0.0;
 }
 
-// the apply stage of a slot, replicated on every rank: rows_all = the gathered [nranks][NW] rows
+// the apply stage of a slot (replicated on every rank of the column-tiled solve): rows_all = the gathered [nranks][NW] rows, or the
+// workgroups' partials of a single context.  (Reducing the Schur columns beside the back-substitution columns on a second half of the
+// workgroup, ahead of the decision, was measured: no gain -- the stage is the serial decision + Cholesky chain of one lane, not its loads.)
 template <int NP>
 __global__ __launch_bounds__(kFB) void refine_slot_apply_kernel(const double* __restrict__ rows_all, int nranks, RefineState* st,
                                                                double* __restrict__ trace, int trace_rows) {
@@ -979,6 +983,7 @@ __global__ __launch_bounds__(kFB) void refine_slot_apply_kernel(const double* __
     __shared__ double sB[CT::NBACK];
     __shared__ int s_do_solve;
     if (st->termination >= 0) return;
+    if (nranks < 0) nranks = st->grid;  // single-context solve enqueued ahead of the RANSAC result: the rows are the workgroups' partials
     const int tid = threadIdx.x;
     const int was_schur = st->need_schur;
     if (tid == 0) s_do_solve = was_schur;
@@ -1020,6 +1025,25 @@ __global__ __launch_bounds__(kFB) void refine_slot_apply_kernel(const double* __
     }
 }
 
+// One SLOT of the iteration loop (the slot kernels below): a streaming pass and the single-workgroup stage behind it.  The first slot of a
+// solve is the Schur pass of iteration 1 + its reduced solve; every later one carries the back-substitution of iteration i together with the
+// Schur sums of iteration i + 1 speculated at the candidate, then the decision of iteration i and -- when the speculation applies, the
+// common case -- the reduced solve of iteration i + 1: two launches and ONE read of the inliers per LM iteration where the four-kernel
+// sequence (refine_schur / solve / backsub / decide, still the stage protocol of rsdsfm_tile_refine_*) takes four and two.  A slot whose
+// speculation did not apply is followed by a plain Schur slot; the kernels read which kind from the state.
+template <int NP>
+static int refine_iter_t(Ctx* c, const RefineBuffers& B) {
+    const int grid = B.m_on_device ? refine_grid_cap(c) : refine_grid(c, B.m);
+    const int64_t m_arg = B.m_on_device ? -1 : B.m;
+    const int nb_arg = B.m_on_device ? -1 : grid;
+    hipLaunchKernelGGL(refine_slot_pass_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, m_arg, reinterpret_cast<const double4*>(B.uu), B.beta,
+                       B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials, B.want_zsum ? 1 : 0);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    hipLaunchKernelGGL(refine_slot_apply_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, nb_arg, B.state, c->d_refine_trace, c->refine_trace_rows);
+    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    return RSDSFM_OK;
+}
+
 template <int NP>
 static int refine_slot_rows_t(Ctx* c, const RefineBuffers& B, double* row) {
     const int grid = refine_grid(c, B.m);
@@ -1031,7 +1055,7 @@ static int refine_slot_rows_t(Ctx* c, const RefineBuffers& B, double* row) {
     return RSDSFM_OK;
 }
 int refine_slot_row_doubles(int np) { return np == 7 ? SlotRow<7>::NW : SlotRow<6>::NW; }
-int refine_slot_partials_doubles(const Ctx* c, int64_t m) { return refine_grid(c, m) * SlotRow<7>::NW; }
+int refine_slot_partials_doubles(const Ctx* c, int64_t m) { return refine_partials_doubles(c, m); }
 int refine_slot_rows_launch(Ctx* c, const RefineBuffers& B, int np, double* row) {
     return np == 7 ? refine_slot_rows_t<7>(c, B, row) : refine_slot_rows_t<6>(c, B, row);
 }

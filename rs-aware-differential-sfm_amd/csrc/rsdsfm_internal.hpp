@@ -106,7 +106,7 @@ struct Ctx {
     int true_flow_exhaustive = 0;  // ground-truth flow search: 0 = interval-pruned from 96 scanlines on (default), 1 = every scanline for every pixel, 2 = pruned at any size
     int ransac_fused_base = 2;     // accepted steps after which most hypotheses of the previous solve ended: the iterate round 0 scores
     int ransac_score_idle = kScoreIdleLimit;  // consecutive solves (saturating) that did NOT need the separate scoring pass behind round 0; below the limit the pass is enqueued ahead of the host's flag read
-    int refine_iters_hint = -1;    // LM iterations the context's previous refinement took (-1: none yet): length of the first chunk the host enqueues
+    int refine_iters_hint = -1;    // slots (refine_kernels.hip; LM iterations + 1 as a rule) the context's previous refinement consumed (-1: none yet): length of the first chunk the host enqueues
     int ransac_standard_math = 0;  // > 0: that many of the context's next RANSACs run round 0 with the standard sqrt / reciprocal (set to 16 by a run that met an argument outside the range of the in-range cores and had to start over; ransac_lm_kernel CORE)
     int* d_core_flag = nullptr;    // device word the minimal solver stores its launch epoch in when an SVD operand left the range of the function cores (persistent: never a stale value)
     int core_epoch = 0;
@@ -137,6 +137,7 @@ struct Ctx {
     // opt-in profiling (rsdsfm_set_profiling): HIP events on the context's stream around the dominant kernel of the last RANSAC
     bool profile = false;
     hipEvent_t ev_prof[2] = {nullptr, nullptr};
+    unsigned long long* d_clk_probe = nullptr;  // [4] {shader clocks, 100 MHz ticks} at the start and the end of one workgroup of the bracketed ransac_lm_kernel
     bool prof_pending = false;
     // opt-in trace of the joint refinement's LM iterations (rsdsfm_set_refine_trace): rows of kRefineTraceCols doubles, written by refine_decide_kernel
     double* d_refine_trace = nullptr;

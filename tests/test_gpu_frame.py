@@ -144,6 +144,42 @@ def test_solve_frame_is_bit_reproducible(rsdsfm):
     assert all(o == outs[0] for o in outs[1:])
 
 
+def test_profiling_records_do_not_change_results(rsdsfm):
+    """rsdsfm_set_profiling brackets round 0 of the RANSAC's LM solves with two events and lets one workgroup of that launch stamp the
+    shader clock: a duration and a plausible clock come back, the solve's bits stay the same, and asking without a record is an error"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(5, rows=180, cols=320)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    img = torch.from_numpy(d["flow_img"]).to(dev)
+
+    def solve(s):
+        dm = torch.zeros((cols, rows), dtype=torch.float64, device=dev)
+        r = s.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=30, tol=0.01, seed=11)
+        s.synchronize()
+        return (r["num_inliers"], r["best_trial"], r["v"].tobytes(), r["w"].tobytes(), r["k"], r["refine_summary"]["final_cost"],
+                dm.cpu().numpy().tobytes())
+
+    with rsdsfm.Solver(0) as s:
+        plain = solve(s)
+        with pytest.raises(rsdsfm.RsdsfmError):
+            s.profile_last_ms("ransac_lm_round0")
+        s.set_profiling(True)
+        for _ in range(3):
+            assert solve(s) == plain
+            ms = s.profile_last_ms("ransac_lm_round0")
+            mhz = s.profile_last_ms("ransac_lm_round0_clock_mhz")
+            assert 0.0 < ms < 50.0
+            assert 500.0 < mhz < 2600.0, mhz  # MI355X: 2.4 GHz nominal, lower under fp64 load
+        with pytest.raises(rsdsfm.RsdsfmError):
+            s.profile_last_ms("depth_lm_batch")  # the pending record is the RANSAC's
+        with pytest.raises(rsdsfm.RsdsfmError):
+            s.profile_last_ms("no_such_record")
+        s.set_profiling(False)
+        assert solve(s) == plain
+
+
 def test_solve_does_not_depend_on_the_contexts_history(rsdsfm):
     """a context remembers how its previous solve went -- whether the separate scoring pass was needed (noise-free data), how many
     refinement iterations it took, which depth iterate was right -- only to decide what it enqueues AHEAD of the host's reads; a

@@ -52,4 +52,5 @@ if [ "${1:-}" != "quick" ]; then
   for n in 2 4 8; do RSDSFM_SHARE_GPU=1 python3 bench.py --gpus $n --steps 10 --warmup 3 --no-cpu-baseline 2>$OUT/bench_shared_gpu_rccl$n.err | tail -1 > $OUT/bench_shared_gpu_rccl$n.json; echo "shared $n: $(cut -c1-160 $OUT/bench_shared_gpu_rccl$n.json)"; done
   ./tools/depth_clock_probe 60 > $OUT/depth_clock_probe.txt 2>&1
   python3 tools/svd_spread.py 1000 > $OUT/svd_spread.txt 2>/dev/null
+  python3 tools/refine_slots.py > $OUT/refine_slots.txt 2>/dev/null
 fi

@@ -13,7 +13,7 @@ for f in glob.glob(F + "/trace_*.txt"):
     head = "# rocprofv3 --kernel-trace --stats -- python3 bench.py (workload / flags: %s, see profiles/collect_r04.sh); per-kernel durations, round 4\n" % name
     open(P + "/r04_" + os.path.basename(f), "w").write(head + "".join(body))
 shutil.copy(F + "/counters.json", P + "/counters.json")
-for name in ("timeline_full.txt", "depth_clock_probe.txt", "svd_spread.txt"):
+for name in ("timeline_full.txt", "depth_clock_probe.txt", "svd_spread.txt", "refine_slots.txt"):
     if os.path.exists(F + "/" + name):
         shutil.copy(F + "/" + name, P + "/r04_" + name)
 print("installed %d bench lines, %d traces" % (len(glob.glob(F + "/bench_*.json")), len(glob.glob(F + "/trace_*.txt"))))

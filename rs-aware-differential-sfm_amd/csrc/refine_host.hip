@@ -103,10 +103,10 @@ int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const 
     // (tools/refine_slots.py: 4 .. 8 slots, 7 cover 96 %; 6 cover 73 % and cost 2 us more per solve on average; following the previous solve's
     // count more closely was measured 1 % slower, the counts vary from pair to pair) -- except behind a refinement that ended within 3
     // slots (noise-free data, e.g. ground-truth flow, ends after ONE iteration), where the first chunk is that count + 1, and behind one
-    // that took more than 8 (acceleration mode: ~14), where it is that count + 1 as well.  The chunking changes when the host looks at the
-    // state, never what the kernels compute.
+    // that took more than 8 (acceleration mode: 7 .. 38, two per iteration that did not speculate or whose speculation did not apply), where it
+    // is that count + 1 as well, at most 28.  The chunking changes when the host looks at the state, never what the kernels compute.
     const int hp = run->hint_prev;
-    run->chunk = (hp >= 0 && hp <= 3) ? hp + 1 : (hp > 8 ? std::min(hp + 1, 17) : 7);
+    run->chunk = (hp >= 0 && hp <= 3) ? hp + 1 : (hp > 8 ? std::min(hp + 1, 28) : 7);
     return refine_enqueue_chunk(c, run);
 }
 
@@ -155,10 +155,9 @@ int refine_poll(Ctx* c, RefineRun* run, double v_out[3], double w_out[3], double
             break;
         }
         if (run->launched > 8 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
-        // later chunks: what the previous solve still needed at this point, between 1 and 5 (DeepFlow-like data: 3 / 4 / 5 / 6 / 7
-        // iterations in 5 / 37 / 49 / 8.5 / 0.25 % of the pairs, so ONE more is what a solve that outlives the first chunk almost always
-        // needs; acceleration mode runs ~13 iterations in all)
-        run->chunk = std::min(5, std::max(1, run->hint_prev - run->launched));
+        // later chunks: what the previous solve still needed at this point, between 2 and 8 slots (a DeepFlow-like solve that outlives its 7
+        // slots needs one or two more; acceleration mode varies by tens from pair to pair)
+        run->chunk = std::min(8, std::max(2, run->hint_prev - run->launched));
         int rc = refine_enqueue_chunk(c, run);
         if (rc != RSDSFM_OK) return rc;
     }

@@ -239,6 +239,10 @@ struct SlotRow {
     using CT = Counts<NP>;
     static constexpr int OFF_BACK = CT::NSCHUR;                                   // (even: NBACK rows of NP = 6 stay 16-byte aligned)
     static constexpr int NW = CT::NSCHUR + CT::NBACK + ((CT::NBACK & 1) ? 1 : 0);  // row width (even)
+    // Whether the back-substitution pass speculates at all.  With k refined (NP = 7) it does not: the steps of that problem are rejected or
+    // accepted with qualities of 0.65 .. 0.93 most of the time (tools/refine_slots.py with SLOTS_ACCEL=1: 15 of 21 at worst), and a pass
+    // that carries both evaluations needs more than 256 registers there (one wave per SIMD).  Its slots alternate Schur / back-substitution.
+    static constexpr bool SPECULATES = NP == 6;
 };
 
 }  // namespace
@@ -898,6 +902,7 @@ __global__ __launch_bounds__(kFB) void refine_slot_pass_kernel(int64_t m, const 
     for (int c = 0; c < NP; ++c) yp[c] = st->yp[c];
     const double inv_radius = 1.0 / st->radius;
     const double inv_radius_spec = 1.0 / radius_accept(st->radius, 1.0);
+    const bool spec = SR::SPECULATES && st->spec_miss_run < 2;  // (the apply stage reads the same word before it updates it)
     double* __restrict__ cand = st->cur ? rho_a : rho_b;
     double acc[CT::NBACK];
 #pragma unroll
@@ -946,10 +951,14 @@ __global__ __launch_bounds__(kFB) void refine_slot_pass_kernel(int64_t m, const 
         acc[CT::BACK_MAX] = fmax(acc[CT::BACK_MAX], fabs(oc.Jr[0] * oc.r[0] + oc.Jr[1] * oc.r[1]));
         acc[CT::BACK_MAX + 1] += cd * cd;
         if (want_zsum) acc[CT::BACK_MAX + 2] += 1.0 / cd;
-        schur_accumulate<NP>(oc, sr, sp, inv_radius_spec, accS);  // (oc: exactly what the next Schur pass would evaluate at the accepted candidate)
+        if (SR::SPECULATES) {  // (compile-time: the NP = 7 pass carries one evaluation or the other, never both)
+            if (spec) schur_accumulate<NP>(oc, sr, sp, inv_radius_spec, accS);  // (oc: exactly what the next Schur pass would evaluate at the accepted candidate)
+        }
     }
-    block_reduce_store<CT::NSCHUR>(accS, -1, s_redS, row);
-    __syncthreads();
+    if (spec) {
+        block_reduce_store<CT::NSCHUR>(accS, -1, s_redS, row);
+        __syncthreads();
+    }
     block_reduce_store<CT::NBACK>(acc, CT::BACK_MAX, s_redB, row + SR::OFF_BACK);
 }
 
@@ -992,9 +1001,12 @@ __global__ __launch_bounds__(kFB) void refine_slot_apply_kernel(const double* __
         if (solve_ok) reduce_partials<CT::NBACK>(rows_all, nranks, CT::BACK_MAX, s_redB, sB, SR::NW, SR::OFF_BACK);
         if (tid == 0) {
             const double r_spec = radius_accept(st->radius, 1.0);  // (what the pass speculated with: the radius BEFORE the decision)
+            const int spec_on = SR::SPECULATES && st->spec_miss_run < 2;  // (whether it speculated at all)
             const int accepted = decide_serial<NP>(st, sB, solve_ok, trace, trace_rows);
             // the speculated Schur sums are the next iteration's iff the state moved to the candidate with exactly that radius
-            s_do_solve = (accepted && st->radius == r_spec) ? 1 : 0;
+            const int applies = (accepted && st->radius == r_spec) ? 1 : 0;
+            st->spec_miss_run = applies ? 0 : min(st->spec_miss_run + 1, 2);
+            s_do_solve = applies && spec_on;
             st->need_schur = (st->termination < 0 && !s_do_solve) ? 1 : 0;
         }
     }

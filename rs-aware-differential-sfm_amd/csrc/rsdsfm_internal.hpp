@@ -356,7 +356,11 @@ struct RefineState {
     // sum of z = 1 / rho over the inliers at the CURRENT state (what refine_finish_kernel writes), kept by the decide stages when the passes
     // are asked for it (RefineBuffers::want_zsum: the column-tiled solve, whose mean-z sign test main.cc:466-472 then needs no exchange of its own)
     double zsum;
-    int32_t slots, _pad2;
+    int32_t slots;
+    // consecutive decisions (capped at 2) whose step was not "accepted with the radius the slot's pass speculated on": the back-substitution pass
+    // speculates while this is < 2 (DeepFlow-like data: four steps in five apply, misses are isolated; acceleration mode: runs of rejected
+    // steps and of qualities 0.65 .. 0.93, where speculating would add a wasted Schur evaluation to every pass)
+    int32_t spec_miss_run;
 };
 struct RefineBuffers {
     const double* flow;  // 2 x n_flow

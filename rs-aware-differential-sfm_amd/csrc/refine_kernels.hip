@@ -23,7 +23,12 @@ namespace rsdsfm {
 
 namespace {
 
-constexpr int kFB = 256;
+// Workgroups of 8 waves, at most one per CU: the streaming passes run at two waves per SIMD either way (254 registers), and half as many
+// partial rows leave half as much for the single-workgroup stages to reduce -- those stages pull their rows through ONE CU (measured with
+// s_memtime stamps at 1280x720, 512 rows of 4 waves each: 3.4 us for the 14 back-substitution columns, 4.8 us for the 54 Schur columns,
+// against 1.2 us for the decision and 2.4 us for the Cholesky solve).
+constexpr int kFB = 512;
+constexpr int kWorkgroupsPerCu = 1;
 
 // Streaming passes: `m_arg >= 0` is the inlier count and the launch grid is the logical grid (host knows both); `m_arg < 0` means
 // both are device-resident (RefineState::m / ::grid) and the launch grid is an upper bound: workgroups beyond the logical grid leave,
@@ -759,10 +764,10 @@ __global__ void refine_state_from_best_kernel(const RansacBest* __restrict__ bes
 // ---------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------
-static inline int refine_grid_cap(const Ctx* c) { return c->num_cus * 2; }
+static inline int refine_grid_cap(const Ctx* c) { return c->num_cus * kWorkgroupsPerCu; }
 static inline int refine_grid(const Ctx* c, int64_t m) {
     int64_t b = (m + kFB - 1) / kFB;
-    const int64_t cap = (int64_t)c->num_cus * 2;
+    const int64_t cap = (int64_t)c->num_cus * kWorkgroupsPerCu;
     if (b < 1) b = 1;
     if (b > cap) {
         const int64_t iters = (b + cap - 1) / cap;
@@ -979,8 +984,9 @@ __global__ __launch_bounds__(kFB) void refine_slot_row_kernel(const double* __re
 }
 
 // the apply stage of a slot (replicated on every rank of the column-tiled solve): rows_all = the gathered [nranks][NW] rows, or the
-// workgroups' partials of a single context.  (Measured without gain at 1280x720, 11.8 us per stage either way: reducing the Schur columns
-// beside the back-substitution columns on a second half of the workgroup ahead of the decision; working on a copy of the state in LDS.)
+// workgroups' partials of a single context.  (Measured without gain at 1280x720: reducing the Schur columns beside the back-substitution
+// columns on a second half of the workgroup ahead of the decision -- slower, with 512 and with 256 rows --; working on a copy of the
+// state in LDS.  What did help is fewer rows: see kFB.)
 template <int NP>
 __global__ __launch_bounds__(kFB) void refine_slot_apply_kernel(const double* __restrict__ rows_all, int nranks, RefineState* st,
                                                                double* __restrict__ trace, int trace_rows) {

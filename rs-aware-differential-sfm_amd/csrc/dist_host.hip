@@ -863,8 +863,8 @@ restart_ransac:
         // ONE exchange per LM iteration (refine_kernels.hip, slot kernels): a slot's pass carries the back-substitution of iteration i and the
         // Schur sums of iteration i + 1 speculated at the candidate for the radius an accepted step of quality >= 0.937 gets; a slot whose
         // speculation did not apply is followed by a plain Schur slot (the kernels read which kind from the replicated state).  Slots per
-        // host poll: what the previous solve on this communicator consumed (6 before there is one: the first Schur slot + 5 iterations),
-        // later chunks what it still needed at that point (2 .. 5).  Every rank holds the same hint, so all ranks issue the same
+        // host poll: what the previous solve on this communicator consumed (6 before there is one: the first Schur slot + 5 iterations; at most
+        // 28), later chunks what it still needed at that point (2 .. 8).  Every rank holds the same hint, so all ranks issue the same
         // collectives; the chunking changes when the host looks at the state, never what the kernels compute.
         auto slot = [&]() -> int {
             int rc2 = refine_slot_rows_launch(c, B, np, d_row);
@@ -874,8 +874,8 @@ restart_ransac:
             return refine_slot_apply_launch(c, B, np, d_rows_all, R);
         };
         const int hint = D->refine_iters_hint;
-        int chunk = hint >= 1 ? std::min(hint, 12) : 6;
-        for (int launched = 0;; chunk = hint >= 1 ? std::min(5, std::max(2, hint - launched)) : 5) {
+        int chunk = hint >= 1 ? std::min(hint, 28) : 6;  // (k refined: two slots per LM iteration, ~27 in all)
+        for (int launched = 0;; chunk = hint >= 1 ? std::min(8, std::max(2, hint - launched)) : 5) {
             for (int i = 0; i < chunk; ++i) {
                 rc = slot();
                 if (rc != RSDSFM_OK) return rc;

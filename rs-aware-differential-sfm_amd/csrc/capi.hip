@@ -190,7 +190,7 @@ int rsdsfm_set_profiling(rsdsfm_ctx* ctx, int on) {
         RSDSFM_HIP_CHECK(c, hipEventCreate(&c->ev_prof[0]));
         RSDSFM_HIP_CHECK(c, hipEventCreate(&c->ev_prof[1]));
         RSDSFM_HIP_CHECK(c, hipMalloc((void**)&c->d_clk_probe, 4 * sizeof(unsigned long long)));
-        RSDSFM_HIP_CHECK(c, hipMemset(c->d_clk_probe, 0, 4 * sizeof(unsigned long long)));
+        RSDSFM_HIP_CHECK(c, hipMemsetAsync(c->d_clk_probe, 0, 4 * sizeof(unsigned long long), c->stream));
     }
     c->profile = on != 0;
     c->prof_pending = false;
@@ -209,7 +209,8 @@ int rsdsfm_profile_last_ms(rsdsfm_ctx* ctx, const char* what, double* ms) {
     if (clock) {
         // the shader clock one workgroup of that launch ran at: clocks of its life / 100 MHz ticks of its life (ransac_lm_kernel clk_probe)
         unsigned long long h[4];
-        RSDSFM_HIP_CHECK(c, hipMemcpy(h, c->d_clk_probe, sizeof(h), hipMemcpyDeviceToHost));
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h, c->d_clk_probe, sizeof(h), hipMemcpyDeviceToHost, c->stream));  // (on the context's stream: no null-stream semantics)
+        RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
         if (h[3] <= h[1] || h[2] <= h[0]) return fail(c, RSDSFM_ERR_INVALID, "the bracketed launch left no clock stamps");
         *ms = (double)(h[2] - h[0]) * 100.0 / (double)(h[3] - h[1]);
         return RSDSFM_OK;

@@ -311,7 +311,7 @@ int solve(Problem& pb, rso_lm_summary* summary) {
             sm.termination = RSO_TERM_MAX_ITER;
             break;
         }
-        if (radius < 1e-32) {
+        if (radius <= 1e-32) {
             sm.termination = RSO_TERM_MIN_RADIUS;
             break;
         }

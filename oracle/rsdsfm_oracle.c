@@ -862,7 +862,7 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
             sm.termination = RSO_TERM_MAX_ITER;
             break;
         }
-        if (radius < CERES_MIN_RADIUS) {
+        if (radius <= CERES_MIN_RADIUS) {  /* MinTrustRegionRadiusReached(): "radius > min_trust_region_radius" goes on, i.e. <= terminates */
             sm.termination = RSO_TERM_MIN_RADIUS;
             break;
         }
@@ -1262,7 +1262,7 @@ int rso_refine(const double* flow, int64_t n_flow, int64_t m, const double* inl,
             sm.termination = RSO_TERM_MAX_ITER;
             break;
         }
-        if (radius < CERES_MIN_RADIUS) {
+        if (radius <= CERES_MIN_RADIUS) {
             sm.termination = RSO_TERM_MIN_RADIUS;
             break;
         }

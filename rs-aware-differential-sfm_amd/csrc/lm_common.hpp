@@ -64,7 +64,7 @@ __device__ __forceinline__ void lm_advance(LmScal& st, double* hist, const doubl
             st.termination = RSDSFM_TERM_MAX_ITER;
             break;
         }
-        if (st.radius < kMinRadius) {
+        if (st.radius <= kMinRadius) {
             st.termination = RSDSFM_TERM_MIN_RADIUS;
             break;
         }
@@ -120,7 +120,7 @@ __device__ __forceinline__ void lm_advance(LmScal& st, double* hist, const doubl
     if (used_write <= accepted_in_batch) st.rho_holds = base_hist + used_write;
     else st.rho_holds = -1;
     if (st.termination < 0 && st.iteration >= kMaxIter) st.termination = RSDSFM_TERM_MAX_ITER;
-    if (st.termination < 0 && st.radius < kMinRadius) st.termination = RSDSFM_TERM_MIN_RADIUS;
+    if (st.termination < 0 && st.radius <= kMinRadius) st.termination = RSDSFM_TERM_MIN_RADIUS;
     st.next_launch = launch_id + 1;
     if (st.termination >= 0) {
         st.predict = st.n_hist < KMAX ? st.n_hist : KMAX;

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(kFB) void refine_schur_kernel(int64_t m, const doub
                                                           double* __restrict__ partials) {
     using CT = Counts<NP>;
     __shared__ double s_red[kFB / 64][CT::NSCHUR];
-    if (st->termination >= 0 || st->iteration >= kMaxIter || st->radius < kMinRadius) return;
+    if (st->termination >= 0 || st->iteration >= kMaxIter || st->radius <= kMinRadius) return;
     const PassShape ps = pass_shape(st, m);
     if (!ps.live) return;
     m = ps.m;
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(kFB) void refine_solve_kernel(const double* __restr
         if (threadIdx.x == 0) st->termination = RSDSFM_TERM_MAX_ITER;
         return;
     }
-    if (st->radius < kMinRadius) {
+    if (st->radius <= kMinRadius) {
         if (threadIdx.x == 0) st->termination = RSDSFM_TERM_MIN_RADIUS;
         return;
     }
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(kFB) void refine_slot_pass_kernel(int64_t m, const 
 #pragma unroll
     for (int s = 0; s < CT::NSCHUR; ++s) accS[s] = 0.0;
     if (st->need_schur) {  // a plain Schur pass at the current state (refine_schur_kernel's loop)
-        if (st->iteration >= kMaxIter || st->radius < kMinRadius) return;  // (the apply stage records the termination)
+        if (st->iteration >= kMaxIter || st->radius <= kMinRadius) return;  // (the apply stage records the termination)
         const double inv_radius = 1.0 / st->radius;
         for (int64_t i = (int64_t)blockIdx.x * kFB + threadIdx.x; i < m; i += stride) {
             const double4 c4 = xyuv[i];
@@ -1023,7 +1023,7 @@ __global__ __launch_bounds__(kFB) void refine_slot_apply_kernel(const double* __
         if (tid == 0) st->termination = RSDSFM_TERM_MAX_ITER;
         return;
     }
-    if (st->radius < kMinRadius) {
+    if (st->radius <= kMinRadius) {
         if (tid == 0) st->termination = RSDSFM_TERM_MIN_RADIUS;
         return;
     }

@@ -149,7 +149,7 @@ def ceres_lm_dense(fun, jac, x0, max_iter=50, trace=None):
         if it >= max_iter:
             term = 3
             break
-        if radius < 1e-32:
+        if radius <= 1e-32:
             term = 5
             break
         it += 1
@@ -231,7 +231,7 @@ def lm_depth_np(q, u, alpha, alpha_k, v, w, k):
         if it >= 50:
             term = 3
             break
-        if radius < 1e-32:
+        if radius <= 1e-32:
             term = 5
             break
         it += 1

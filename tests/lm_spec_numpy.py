@@ -62,7 +62,7 @@ def lm_advance(st, sums, n, first, used_K, used_write, launch_id):
         if st.iteration >= MAX_ITER:
             st.termination = 3
             break
-        if st.radius < RMIN:
+        if st.radius <= RMIN:
             st.termination = 5
             break
         if st.cand[j] != st.radius:
@@ -108,7 +108,7 @@ def lm_advance(st, sums, n, first, used_K, used_write, launch_id):
     st.rho_holds = base_hist + used_write if used_write <= accepted else -1
     if st.termination < 0 and st.iteration >= MAX_ITER:
         st.termination = 3
-    if st.termination < 0 and st.radius < RMIN:
+    if st.termination < 0 and st.radius <= RMIN:
         st.termination = 5
     st.next_launch = launch_id + 1
     if st.termination >= 0:

@@ -243,6 +243,59 @@ def test_native_tiled_solve_matches_single_context(rsdsfm, cfg, accel):
         assert len(set(slots)) == 1 and iters <= slots[0] <= 2 * iters, (slots, iters)
 
 
+rsdsfm_trace_accepted = 1.0  # RSDSFM_TRACE_ACCEPTED
+
+
+def _predicted_slots(trace, np_params):
+    """Slots the refinement consumes by the documented rule (refine_kernels.hip): one in front (the Schur pass of
+    iteration 1), one per LM iteration (its back-substitution + decision), and one plain Schur slot behind every iteration the solve
+    outlives unless that iteration's step was accepted with exactly the radius the pass speculated on (radius_accept(radius, 1): x 3,
+    capped) WHILE the pass was speculating -- it is while fewer than two decisions in a row failed that test, and never with k refined."""
+    rows = trace[~np.isnan(trace[:, 0])]
+    slots, miss_run = 1, 0
+    for i, row in enumerate(rows):
+        slots += 1
+        if i == len(rows) - 1:
+            break  # (the callers only pass solves that ended inside a decision)
+        r_spec = min(row[5] / (1.0 / 3.0), 1e16)
+        applies = row[7] == rsdsfm_trace_accepted and rows[i + 1][5] == r_spec  # accepted, and the next iteration starts from the speculated radius
+        spec_on = np_params == 6 and miss_run < 2
+        miss_run = 0 if applies else min(miss_run + 1, 2)
+        if not (applies and spec_on):
+            slots += 1
+    return slots
+
+
+@pytest.mark.parametrize("cfg,accel,tol", [(5, False, 0.05), (3, False, 0.002), (3, False, 0.01), (5, True, 0.01)])
+def test_native_tiled_refinement_consumes_the_documented_number_of_slots(rsdsfm, cfg, accel, tol):
+    """the exchanges of the tiled refinement (rsdsfm_tiled_info::path_flags bits 8-23) against the rule applied to the iteration trace of the
+    single-context solve of the same frame: one exchange per LM iteration where the speculation applies, two where it does not"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(cfg, rows=120, cols=208)
+    rows, cols = d["rows"], d["cols"]
+    img = torch.from_numpy(d["flow_img"]).to(dev)
+    dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
+    checked = 0
+    for seed in (3, 11, 29):
+        kw = dict(trials=12, tol=tol, seed=seed, use_acceleration_mode=accel)
+        with rsdsfm.Solver(0) as s:
+            s.set_refine_trace(60)
+            one = s.solve_frame_dev(img.data_ptr(), rows, cols, d["K"], d["gamma"], dm.data_ptr(), flow_index_mode=rsdsfm.FLOW_GATHERED, **kw)
+            trace = s.get_refine_trace()
+        if rsdsfm.TERMINATION[one["refine_summary"]["termination"]] not in ("gradient", "parameter", "function"):
+            continue  # (max iterations / minimum radius are found at the top of the loop, in a slot of their own)
+        want = _predicted_slots(trace, 7 if accel else 6)
+        for nranks in (1, 3):
+            til = _native_threads(rsdsfm, torch, d, nranks, **kw)
+            assert til["refine_summary"]["num_iterations"] == one["refine_summary"]["num_iterations"]
+            slots = {(i["path_flags"] >> 8) & 0xFFFF for i in til["infos"]}
+            assert slots == {want}, (seed, nranks, slots, want, trace[~np.isnan(trace[:, 0])][:, [4, 5, 7]])
+        checked += 1
+    assert checked >= 2
+
+
 def test_native_tiled_modes(rsdsfm):
     """closed-form depth mode, no refinement, more trials than one hypothesis batch (> 128), empty trailing slabs, global
     shutter mode, too few points"""

@@ -49,10 +49,10 @@ NOMINAL_CLOCK_MHZ = 2400.0      # the clock that peak is priced at (MI355X_MICRO
 # DESIGN section 8 scaling model of the column-tiled 3840x2160 whole solve (ms; calibrated on the N = 1 kernel trace
 # profiles/r04_trace_tiled_full.txt): kernels whose work is per pixel of the slab (ransac_lm 3.62, the refinement's slot passes 0.64,
 # iteration zero, compaction, scoring pass, flatten, final stage, output pass, depth map ...) / replicated or latency-bound stages
-# (minimal9 0.16 + ~65 launches and small copies of 2-8 us) / an ASSUMED 25 us per small collective over xGMI (11 per solve of 4 LM
+# (minimal9 0.16 + ~65 launches and small copies of 2-8 us) / an ASSUMED 25 us per small collective over xGMI (10 per solve of 4 LM
 # iterations) / the depth-map all-gather: every rank receives (N - 1) slabs of 66.4 MB / N over min(N - 1, 7) links in parallel at an
 # ASSUMED 48 GB/s per link and direction
-TILED_MODEL = {"per_pixel_ms": 5.10, "replicated_ms": 0.48, "collective_latency_ms": 0.025, "collectives": 11,
+TILED_MODEL = {"per_pixel_ms": 5.10, "replicated_ms": 0.48, "collective_latency_ms": 0.025, "collectives": 10,
                "depth_gather_ms": lambda n: (66.4e6 / n * (n - 1) / min(n - 1, 7)) / 48e9 * 1e3}
 KIND_PORT = "closed-loop port (oracle C restatement; not reference-structured: no per-pixel residual objects / Ceres problem build)"
 

@@ -463,7 +463,7 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
 
     // ---- small exchange buffers ----
     const int row_max = std::max({nsr * batch + 2, refine_slot_row_doubles(np), refine_stage_row_doubles(np, 0), refine_stage_row_doubles(np, 1), refine_stage_row_doubles(np, 2), 2 * batch});
-    size_t need_d = 2 * Arena::need(8 * (size_t)R + 64) + Arena::need(4 * 9 * (size_t)Tn) + Arena::need(8 * (54 * (size_t)Tn + (size_t)R + 8)) + Arena::need(8 * 8 * (size_t)Tn) +
+    size_t need_d = 2 * Arena::need(8 * (size_t)R + 64) + Arena::need(8 * (size_t)R * Tn) + Arena::need(4 * 9 * (size_t)Tn) + Arena::need(8 * (54 * (size_t)Tn + (size_t)R + 8)) + Arena::need(8 * 8 * (size_t)Tn) +
                     Arena::need(sizeof(LmState) * Tn) + Arena::need(4 * (size_t)Tn) + Arena::need(64) + 2 * Arena::need(8 * (size_t)Tn) +
                     2 * Arena::need(sizeof(RansacBest)) + Arena::need(8 * (size_t)row_max) + Arena::need(8 * (size_t)row_max * R) + Arena::need(64) +
                     Arena::need(8 * (size_t)R + 64) + Arena::need(64) + (padded ? Arena::need(8 * cap * R) : 0) + 4096;
@@ -471,6 +471,7 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
     Arena da(D->d_buf);
     int64_t* d_cnt_all = da.take<int64_t>((size_t)R + 8);
     int64_t* d_m_all = da.take<int64_t>((size_t)R + 8);
+    double* d_cnt_rt = da.take<double>((size_t)R * Tn);  // [rank][hypothesis]: the slabs' shares of every hypothesis' inlier count
     int32_t* d_samples = da.take<int32_t>(9 * (size_t)Tn);
     double* d_pts = da.take<double>(54 * (size_t)Tn + (size_t)R + 8);  // the sampled points + (warm path) the ranks' point counts behind them
     double* d_hyp = da.take<double>(8 * (size_t)Tn);
@@ -516,6 +517,8 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
     char* hp = static_cast<char*>(c->h_pinned);
     RansacBest* h_best = reinterpret_cast<RansacBest*>(hp);
     int* h_flags = reinterpret_cast<int*>(hp + sizeof(RansacBest));
+    static_assert(sizeof(RansacBest) % 8 == 0, "the words behind the record are 8-byte aligned");
+    int64_t* h_scan = reinterpret_cast<int64_t*>(hp + sizeof(RansacBest) + 32);  // (second half of the 64 bytes of flag words: the slab's compaction total)
     int64_t* h_cnt = reinterpret_cast<int64_t*>(hp + sizeof(RansacBest) + 64);
     int64_t* h_m = h_cnt + R;
     double* h_header = reinterpret_cast<double*>(h_m + R);
@@ -634,7 +637,9 @@ restart_ransac:
     int64_t* d_bcounts = ws.take<int64_t>(2048);
     int64_t* d_boffs = ws.take<int64_t>(2048);
     auto final_stage = [&]() -> int {  // winner (replicated), its dense 1/depth + mask + compaction on the slab, inlier counts of all slabs
-        int rc2 = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, nullptr);
+        // the winner (replicated) -- and with it the inlier counts of ALL slabs: the ranks' shares of the winner's count were in the rows the
+        // scores came from (ransac_decide_kernel / ransac_reduce_scores_kernel keep them), so the counts need no exchange of their own
+        int rc2 = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, nullptr, nullptr, nullptr, 0, d_cnt_rt, T, R, d_m_all);
         if (rc2 != RSDSFM_OK) return rc2;
         // the compaction stores the SLAB's scan total into its record: every rank works on a copy of the (identical) winner record
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_best_shard, d_best, sizeof(RansacBest), hipMemcpyDeviceToDevice, c->stream));
@@ -642,9 +647,8 @@ restart_ransac:
                                   d_idx, d_inl, d_in_a, d_in_ak, nullptr);
         if (rc2 != RSDSFM_OK) return rc2;
         static_assert(sizeof(d_best_shard->num_inliers_scan) == sizeof(int64_t), "count type");
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_m_all + rank, &d_best_shard->num_inliers_scan, sizeof(int64_t), hipMemcpyDeviceToDevice, c->stream));
-        rc2 = all_gather(c, D, d_m_all + rank, d_m_all, sizeof(int64_t));
-        if (rc2 != RSDSFM_OK) return rc2;
+        // (what the compaction found on THIS slab travels to the host beside the counts from the rows: they must agree)
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_scan, &d_best_shard->num_inliers_scan, sizeof(int64_t), hipMemcpyDeviceToHost, c->stream));
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_best, d_best, sizeof(RansacBest), hipMemcpyDeviceToHost, c->stream));
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_m, d_m_all, sizeof(int64_t) * R, hipMemcpyDeviceToHost, c->stream));
         return RSDSFM_OK;
@@ -663,7 +667,8 @@ restart_ransac:
                 if (rc != RSDSFM_OK) return rc;
                 rc = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)ransac_rows_payload_doubles(B, core_round));
                 if (rc != RSDSFM_OK) return rc;
-                rc = ransac_decide_rows_launch(c, d_rows_all, R, B, d_states + b0, n_total, round, d_flags, d_scored + b0, d_tcount + b0, d_terr + b0, core_round);
+                rc = ransac_decide_rows_launch(c, d_rows_all, R, B, d_states + b0, n_total, round, d_flags, d_scored + b0, d_tcount + b0, d_terr + b0, core_round,
+                                               d_cnt_rt + b0, T);
                 if (rc != RSDSFM_OK) return rc;
                 D->ransac_rounds += 1;
                 if (round == 0 && B == T) {  // the common case is decided and scored by round 0: enqueue the final stage before reading the flags
@@ -675,7 +680,7 @@ restart_ransac:
                         if (rc != RSDSFM_OK) return rc;
                         rc = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)T * 2);
                         if (rc != RSDSFM_OK) return rc;
-                        rc = ransac_score_merge_launch(c, d_rows_all, R, T, d_scored, d_tcount, d_terr);
+                        rc = ransac_score_merge_launch(c, d_rows_all, R, T, d_scored, d_tcount, d_terr, d_cnt_rt, T);
                         if (rc != RSDSFM_OK) return rc;
                         spec_scored = true;
                     }
@@ -725,7 +730,7 @@ restart_ransac:
             if (rc != RSDSFM_OK) return rc;
             rc = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)B * 2);
             if (rc != RSDSFM_OK) return rc;
-            rc = ransac_score_merge_launch(c, d_rows_all, R, B, sc_ptr, d_tcount + b0, d_terr + b0);
+            rc = ransac_score_merge_launch(c, d_rows_all, R, B, sc_ptr, d_tcount + b0, d_terr + b0, d_cnt_rt + b0, T);
             if (rc != RSDSFM_OK) return rc;
         }
     }
@@ -739,7 +744,7 @@ restart_ransac:
     for (int r = 0; r < R; ++r) m_total += h_m[r];
     const int64_t m = h_m[rank];
     auto m_total_of = [&]() -> int64_t { return m_total; };
-    if (m_total != h_best->num_inliers) return fail(c, RSDSFM_ERR_NUMERIC, "inlier count mismatch between scoring and compaction");
+    if (m_total != h_best->num_inliers || *h_scan != m) return fail(c, RSDSFM_ERR_NUMERIC, "inlier count mismatch between scoring and compaction");
     res->num_inliers = m_total;
     res->best_trial = h_best->best_trial;
     memcpy(res->ransac_w, &h_best->hyp[0], 3 * sizeof(double));

@@ -417,12 +417,15 @@ __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __rest
                                                            LmState* states, int64_t n, int round, int k0, int* flags, int* pred_flag,
                                                            int* __restrict__ scored, double* __restrict__ trial_count,
                                                            double* __restrict__ trial_err, int fused_base, int* steps_hist,
-                                                           int* __restrict__ unscored_list, int rank_stride2 = 0) {
+                                                           int* __restrict__ unscored_list, int rank_stride2 = 0,
+                                                           double* __restrict__ cnt_rt = nullptr, int cnt_stride = 0) {
     __shared__ double s_red[4][NSR];
     __shared__ double s_sums[NSR];
+    __shared__ int s_fused_score;
     const int t = blockIdx.x;
     const int tid = threadIdx.x;
     LmState* state = states + t;
+    if (tid == 0) s_fused_score = 0;
     if (rank_stride2 && t == 0 && tid < nblocks) {  // the ranks' trailers (ransac_lm_rows_kernel): some shard left the range of the function cores
         if (partials[(int64_t)tid * rank_stride2 * 2 + (int64_t)T * NSR] != 0.0) flags[3] = 1;  // (benign race: every writer stores the same word)
     }
@@ -441,6 +444,7 @@ __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __rest
             trial_count[t] = s_sums[NS];
             trial_err[t] = s_sums[NS + 1];
             scored[t] = 1;
+            s_fused_score = 1;
         } else {
             // finished where round 0 did not fuse the score: counted, and (where the caller keeps a list) appended for the scoring pass,
             // which then only looks at these (the order of the entries is the order of arrival: it decides which workgroup scores which
@@ -449,6 +453,13 @@ __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __rest
             if (unscored_list) unscored_list[pos] = t;
         }
         *static_cast<LmScal*>(state) = st;
+    }
+    // column-tiled solve: the ranks' shares of this hypothesis' inlier count (cnt_rt[rank][hypothesis]: exact integers in doubles).  The winner's
+    // shares ARE the slabs' inlier counts -- what the compaction will find -- so the counts need no exchange of their own (ransac_pick_kernel).
+    if (cnt_rt) {
+        __syncthreads();
+        if (s_fused_score && tid < nblocks)
+            cnt_rt[(int64_t)tid * cnt_stride + t] = partials[((int64_t)tid * (rank_stride2 ? rank_stride2 : T * (NSR / 2)) + (int64_t)t * (NSR / 2)) * 2 + NS];
     }
 }
 
@@ -679,7 +690,8 @@ __device__ __forceinline__ void reduce_score_rows(const double* __restrict__ par
 __global__ __launch_bounds__(256) void ransac_reduce_scores_kernel(const double* __restrict__ partials, int nblocks, int T,
                                                                   const int* __restrict__ scored,
                                                                   double* __restrict__ trial_count,
-                                                                  double* __restrict__ trial_err) {
+                                                                  double* __restrict__ trial_err, double* __restrict__ cnt_rt = nullptr,
+                                                                  int cnt_stride = 0) {
     const int t = blockIdx.x, tid = threadIdx.x;
     if (scored && scored[t]) return;
     double c, e;
@@ -688,6 +700,7 @@ __global__ __launch_bounds__(256) void ransac_reduce_scores_kernel(const double*
         trial_count[t] = c;
         trial_err[t] = e;
     }
+    if (cnt_rt && tid < nblocks) cnt_rt[(int64_t)tid * cnt_stride + t] = partials[((int64_t)tid * T + t) * 2];  // (the ranks' shares: see ransac_decide_kernel)
 }
 
 // row-tiled solve: the shard's score partials reduced to rows[T][2] (zeros for hypotheses already scored)
@@ -744,7 +757,9 @@ __device__ __forceinline__ void pick_best_trial(const double* __restrict__ trial
 // best_host (optional): host-mapped pinned copy of the result, written by the kernel itself (no copy kernel behind the stage)
 __global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restrict__ trial_count, const double* __restrict__ trial_err, int T,
                                                         const double* __restrict__ hyp, RansacBest* best, RansacBest* best_host,
-                                                        const int* __restrict__ flags, int* __restrict__ flags_host, int scored_ahead) {
+                                                        const int* __restrict__ flags, int* __restrict__ flags_host, int scored_ahead,
+                                                        const double* __restrict__ cnt_rt = nullptr, int cnt_stride = 0, int nranks = 0,
+                                                        int64_t* __restrict__ m_all = nullptr) {
     if (blockIdx.x != 0) return;
     const int lane = threadIdx.x;
     // the round's flag words (final since ransac_decide_kernel) travel to host-mapped memory with this launch: no copy behind the stage
@@ -759,6 +774,9 @@ __global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restric
     double best_count, best_err;
     int bi;
     pick_best_trial(trial_count, trial_err, T, lane, bi, best_count, best_err);
+    // column-tiled solve: the inlier counts of ALL slabs for the winner, from the shares the decide / merge stages kept
+    if (m_all)
+        for (int r = lane; r < nranks; r += 64) m_all[r] = bi >= 0 ? (int64_t)cnt_rt[(int64_t)r * cnt_stride + bi] : 0;
     const double h = (lane < 8 && bi >= 0) ? hyp[(int64_t)bi * 8 + lane] : 0.0;
     if (lane < 8) best->hyp[lane] = h;
     if (lane < 8 && best_host) best_host->hyp[lane] = h;
@@ -1075,11 +1093,12 @@ int ransac_lm_rows_launch(Ctx* c, const double* q, const double* u, const double
 int ransac_rows_payload_doubles(int T, bool core_trailer) { return T * NSR + (core_trailer ? 2 : 0); }
 
 int ransac_decide_rows_launch(Ctx* c, const double* rows_all, int nranks, int T, LmState* states, int64_t n_total, int round,
-                              int* flags, int* scored, double* trial_count, double* trial_err, bool core_trailer) {
+                              int* flags, int* scored, double* trial_count, double* trial_err, bool core_trailer, double* cnt_rt, int cnt_stride) {
+    if (cnt_rt && nranks > 256) return fail(c, RSDSFM_ERR_INVALID, "more than 256 ranks");
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(flags, 0, sizeof(int), c->stream));
     hipLaunchKernelGGL(ransac_decide_kernel, dim3(T), dim3(256), 0, c->stream, rows_all, nranks, T, 0, states, n_total, round, (int)KMAX, flags,
                        static_cast<int*>(nullptr), scored, trial_count, trial_err, kTiledFusedBase, static_cast<int*>(nullptr),
-                       static_cast<int*>(nullptr), core_trailer ? T * NSR / 2 + 1 : 0);
+                       static_cast<int*>(nullptr), core_trailer ? T * NSR / 2 + 1 : 0, cnt_rt, cnt_stride);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
@@ -1099,9 +1118,10 @@ int ransac_score_rows_launch(Ctx* c, const double* q, const double* u, const dou
 }
 
 int ransac_score_merge_launch(Ctx* c, const double* rows_all, int nranks, int T, const int* scored, double* trial_count,
-                              double* trial_err) {
+                              double* trial_err, double* cnt_rt, int cnt_stride) {
+    if (cnt_rt && nranks > 256) return fail(c, RSDSFM_ERR_INVALID, "more than 256 ranks");
     hipLaunchKernelGGL(ransac_reduce_scores_kernel, dim3(T), dim3(256), 0, c->stream, rows_all, nranks, T, scored, trial_count,
-                       trial_err);
+                       trial_err, cnt_rt, cnt_stride);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
@@ -1109,8 +1129,10 @@ int ransac_score_merge_launch(Ctx* c, const double* rows_all, int nranks, int T,
 int ransac_rows_doubles() { return NSR; }
 
 int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best,
-                       RansacBest* best_host, const int* d_flags, int* h_flags, int scored_ahead) {
-    hipLaunchKernelGGL(ransac_pick_kernel, dim3(1), dim3(64), 0, c->stream, trial_count, trial_err, T, hyp, best, best_host, d_flags, h_flags, scored_ahead);
+                       RansacBest* best_host, const int* d_flags, int* h_flags, int scored_ahead, const double* cnt_rt, int cnt_stride,
+                       int nranks, int64_t* m_all) {
+    hipLaunchKernelGGL(ransac_pick_kernel, dim3(1), dim3(64), 0, c->stream, trial_count, trial_err, T, hyp, best, best_host, d_flags, h_flags, scored_ahead,
+                       cnt_rt, cnt_stride, nranks, m_all);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -318,7 +318,8 @@ int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* 
                         const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
                         double* partials, double* trial_count, double* trial_err, const int* unscored_list = nullptr, const int* unscored_count = nullptr);
 int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best,
-                       RansacBest* best_host = nullptr, const int* d_flags = nullptr, int* h_flags = nullptr, int scored_ahead = 0);
+                       RansacBest* best_host = nullptr, const int* d_flags = nullptr, int* h_flags = nullptr, int scored_ahead = 0,
+                       const double* cnt_rt = nullptr, int cnt_stride = 0, int nranks = 0, int64_t* m_all = nullptr);
 int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         RansacBest* best, const LmState* states, int depth_mode, double tol, double* rho, uint8_t* mask,
                         int64_t* block_counts, int64_t* block_offsets, int64_t* inlier_idx, double* inliers,
@@ -330,12 +331,13 @@ int ransac_lm_rows_launch(Ctx* c, const double* q, const double* u, const double
                           int* core_flags = nullptr, const int* m9_flag = nullptr, int m9_epoch = 0);
 int ransac_rows_payload_doubles(int T, bool core_trailer);
 int ransac_decide_rows_launch(Ctx* c, const double* rows_all, int nranks, int T, LmState* states, int64_t n_total, int round,
-                              int* flags, int* scored, double* trial_count, double* trial_err, bool core_trailer = false);
+                              int* flags, int* scored, double* trial_count, double* trial_err, bool core_trailer = false,
+                              double* cnt_rt = nullptr, int cnt_stride = 0);  // cnt_rt[rank][hypothesis]: the ranks' shares of the fused inlier counts
 int ransac_score_rows_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                              const double* hyp, int T, const LmState* states, int depth_mode, double tol, const int* scored,
                              double* partials, double* rows);
 int ransac_score_merge_launch(Ctx* c, const double* rows_all, int nranks, int T, const int* scored, double* trial_count,
-                              double* trial_err);
+                              double* trial_err, double* cnt_rt = nullptr, int cnt_stride = 0);
 void sample_indices(int64_t n, int T, uint64_t seed, int32_t* out);
 }  // namespace rsdsfm
 

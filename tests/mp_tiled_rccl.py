@@ -9,7 +9,12 @@ The unique id travels over a gloo group.  Environment per rank (set by the test)
 RSDSFM_TEST_FRAME_NPY = a (rows, cols, 2) flow image saved by the test (BASELINE configs[3], 3840x2160): the ranks solve THAT frame
 (RSDSFM_TEST_FRAME_META: json with K, gamma, trials, tol, seed) instead of the small one, every rank loading only its column slab,
 and write what the test compares with the oracle chain: pose, counts, refinement summary, the gathered depth map (rank 0) and every
-inlier's scanline index (one file per rank, concatenated in rank order by the test)."""
+inlier's scanline index (one file per rank, concatenated in rank order by the test).
+
+RSDSFM_TEST_SEQUENCE=1: instead, a SEQUENCE of frames on the one communicator that walks the driver's paths -- cold, ahead on the dense
+counts, a frame with a hole in rank 1's slab (every rank starts over through the counts exchange), cold again, ahead, a frame with a pixel
+outside the range of the function cores in rank 1's slab (every rank starts the RANSAC over), ahead -- and records, per solve and per
+rank, the results and rsdsfm_tiled_info: every collective of every path has to pair up between the two processes, or the run hangs."""
 import json
 import os
 import sys
@@ -55,6 +60,37 @@ def main():
         out["init"] = "ok"
     except rsdsfm.RsdsfmError as e:  # e.g. a box whose RCCL cannot open the loopback interface: reported, the test skips
         out["init"] = str(e)
+    if out["init"] == "ok" and os.environ.get("RSDSFM_TEST_SEQUENCE"):
+        d = rsdsfm.synth.make_config(5, rows=64, cols=480)  # (alpha = 1 + gamma f_y / h vanishes for f_y = -128 px: h = 64, gamma = 0.5)
+        rows, cols, K, gamma = d["rows"], d["cols"], d["K"], 0.5
+        c0, sc, per = rsdsfm.tiled_slab_bounds(cols, world, rank)
+        clean = np.array(d["flow_img"])
+        holed = clean.copy()
+        holed[10:30, 300:340] = 0.0          # columns of rank 1's slab
+        bad = clean.copy()
+        bad[17, 301] = (3.0, -128.0)         # rank 1's slab
+        frames = [clean, clean, holed, clean, clean, bad, clean]
+        dm = torch.zeros(cols * rows, dtype=torch.float64, device=dev)
+        seq = []
+        for f in frames:
+            slab = torch.from_numpy(np.ascontiguousarray(f[:, c0:c0 + sc, :])).to(dev)
+            r = solver.solve_frame_tiled_dev(slab.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), flow_index_mode=flow_mode, trials=20, tol=0.05, seed=11)
+            torch.cuda.synchronize()
+            dmh = dm.cpu().numpy()
+            seq.append(dict(n=r["n"], num_inliers=r["num_inliers"], best_trial=r["best_trial"], v=list(r["v"]), w=list(r["w"]),
+                            iterations=r["refine_summary"]["num_iterations"], depth_nonzero=int((dmh != 0).sum()), depth_sum=float(dmh.sum()),
+                            path_flags=r["info"]["path_flags"], collectives=r["info"]["collectives"], host_syncs=r["info"]["host_syncs"]))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, seq)
+        out.update(sequence=gathered, restarts=solver.ransac_restarts())
+        solver.dist_finalize()
+        if rank == 0:
+            with open(os.environ["RSDSFM_TILED_OUT"], "w") as f:
+                json.dump(out, f)
+        solver.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if out["init"] == "ok":
         slab = torch.from_numpy(np.ascontiguousarray(d["flow_img"][:, c0:c0 + sc, :])).to(dev)  # each rank only holds its slab
         dm = torch.zeros(cols * rows, dtype=torch.float64, device=dev)

@@ -580,6 +580,52 @@ def test_native_tiled_over_a_real_two_rank_rccl_communicator(rsdsfm, tmp_path, f
     assert np.isclose(got["depth_sum_tiled"], rho.sum(), rtol=1e-12) and got["depth_info"]["nranks"] == 2
 
 
+def test_native_tiled_paths_over_a_real_two_rank_rccl_communicator(rsdsfm, tmp_path):
+    """The driver's speculative paths over RCCL itself (two processes, tests/mp_tiled_rccl.py with RSDSFM_TEST_SEQUENCE): cold, ahead on the
+    dense counts, a frame that is not dense after all (restart through the counts exchange), a function-core miss in ONE rank's slab (every
+    rank restarts the RANSAC).  Each path issues another sequence of collectives; the two processes only finish if they pair up.  Every
+    solve equals the single-context solve of its frame, both ranks report the same path."""
+    import torch
+
+    out = tmp_path / "seq.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RSDSFM_TILED_OUT=str(out), RSDSFM_TEST_FLOW_MODE="1", RSDSFM_TEST_SEQUENCE="1", NCCL_SOCKET_IFNAME="lo",
+               NCCL_IB_DISABLE="1")
+    env.pop("NCCL_HOSTID", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29657",
+           os.path.join(ROOT, "tests", "mp_tiled_rccl.py")]
+    try:
+        p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    except subprocess.TimeoutExpired:  # (the trick depends on the box's loopback networking: an environment limit, not a product failure)
+        pytest.skip("two RCCL ranks over the loopback interface did not connect within 300 s on this box")
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    got = json.loads(out.read_text())
+    if got["init"] != "ok":
+        pytest.skip("this box's RCCL cannot connect two ranks over the loopback interface: " + got["init"][:300])
+    seq = got["sequence"]
+    assert len(seq) == 2 and len(seq[0]) == 7 and seq[0] == seq[1]  # both ranks: same results, same paths, same numbers of collectives
+    # cold / ahead / ahead but the frame has a hole: started over / cold (the previous frame was not dense) / ahead / ahead, and the RANSAC
+    # started over with the standard functions / ahead (standard functions: no restart)
+    assert [s["path_flags"] & 0xFF for s in seq[0]] == [0, 1, 3, 0, 1, 5, 1]
+    assert got["restarts"] == 1
+    stream = torch.cuda.Stream(torch.device("cuda", 0))
+    d = rsdsfm.synth.make_config(5, rows=64, cols=480)
+    clean = np.array(d["flow_img"])
+    holed = clean.copy()
+    holed[10:30, 300:340] = 0.0
+    bad = clean.copy()
+    bad[17, 301] = (3.0, -128.0)
+    ones = {}
+    with torch.cuda.stream(stream):
+        for name, f in (("clean", clean), ("holed", holed), ("bad", bad)):
+            ones[name] = _single(rsdsfm, torch, dict(d, flow_img=f, gamma=0.5), stream, trials=20, tol=0.05, seed=11, flow_index_mode=1)
+    assert ones["holed"]["n"] < ones["clean"]["n"]
+    for s, name in zip(seq[0], ["clean", "clean", "holed", "clean", "clean", "bad", "clean"]):
+        one = ones[name]
+        assert (s["n"], s["num_inliers"], s["best_trial"], s["iterations"]) == (one["n"], one["num_inliers"], one["best_trial"], one["refine_summary"]["num_iterations"]), name
+        assert np.allclose(s["v"], one["v"], rtol=1e-9, atol=1e-14) and np.allclose(s["w"], one["w"], rtol=1e-9, atol=1e-14), name
+        assert s["depth_nonzero"] == int((one["depth_map"] != 0).sum()) and np.isclose(s["depth_sum"], one["depth_map"].sum(), rtol=1e-9), name
+
+
 # ---------------------------------------------------------------------------------------------------
 # the row-tiled DENSE DEPTH solve driven from C++ (rsdsfm_estimate_inverse_depths_tiled_dev)
 # ---------------------------------------------------------------------------------------------------

@@ -104,6 +104,37 @@ def compare(a, b, rtol):
     return None
 
 
+def draw_case(rsdsfm, seed0, c):
+    """case number c of campaign seed0: (rows, cols, K, gamma, frames, kinds, solver keywords, tag, logical ranks, acceleration mode)"""
+    rng = np.random.default_rng(seed0 * 104729 + c)
+    rows, cols = int(rng.integers(24, 100)), int(rng.integers(40, 260))
+    cfg = int(rng.choice([1, 3, 5]))
+    accel = bool(rng.random() < 0.25)
+    nranks = int(rng.integers(1, 7))
+    kw = dict(trials=int(rng.integers(1, 40)), tol=float(rng.choice([0.05, 0.01, 0.003, 0.001])), seed=int(rng.integers(1, 1 << 20)),
+              flow_index_mode=int(rng.integers(0, 2)), use_acceleration_mode=accel)
+    if kw["flow_index_mode"] == 0 and accel:
+        kw["flow_index_mode"] = 1  # (rank-indexed flow + selective tolerance + free k: a problem that wanders, DESIGN section 6)
+    d = rsdsfm.synth.make_config(cfg, seed=int(rng.integers(1 << 30)), rows=rows, cols=cols)
+    rows, cols, K = d["rows"], d["cols"], d["K"]
+    gamma = 0.5 if rng.random() < 0.3 else d["gamma"]
+    clean = np.array(d["flow_img"])
+    frames, kinds = [clean], ["first"]
+    for _ in range(int(rng.integers(1, 4))):
+        kind = str(rng.choice(["same", "holed", "poisoned"]))
+        f = clean.copy()
+        if kind == "holed":
+            y0, x0 = int(rng.integers(0, rows - 4)), int(rng.integers(0, cols - 6))
+            f[y0:y0 + int(rng.integers(1, 12)), x0:x0 + int(rng.integers(1, 30))] = 0.0
+        elif kind == "poisoned":  # alpha = 1 + gamma f_y / rows = 0 exactly needs gamma f_y = -rows
+            f[int(rng.integers(0, rows)), int(rng.integers(0, cols))] = (3.0, -rows / gamma)
+        frames.append(f)
+        kinds.append(kind)
+    tag = "case %d (%dx%d cfg %d accel %d ranks %d trials %d tol %g flow %d seq %s)" % (c, rows, cols, cfg, accel, nranks, kw["trials"], kw["tol"],
+                                                                                        kw["flow_index_mode"], ",".join(kinds))
+    return rows, cols, K, gamma, frames, kinds, kw, tag, nranks, accel
+
+
 def main():
     import torch
 
@@ -115,32 +146,7 @@ def main():
     paths = {}
     only = [int(x) for x in os.environ.get("FUZZ_ONLY", "").split(",") if x]
     for c in (only or range(cases)):
-        rng = np.random.default_rng(seed0 * 104729 + c)
-        rows, cols = int(rng.integers(24, 100)), int(rng.integers(40, 260))
-        cfg = int(rng.choice([1, 3, 5]))
-        accel = bool(rng.random() < 0.25)
-        nranks = int(rng.integers(1, 7))
-        kw = dict(trials=int(rng.integers(1, 40)), tol=float(rng.choice([0.05, 0.01, 0.003, 0.001])), seed=int(rng.integers(1, 1 << 20)),
-                  flow_index_mode=int(rng.integers(0, 2)), use_acceleration_mode=accel)
-        if kw["flow_index_mode"] == 0 and accel:
-            kw["flow_index_mode"] = 1  # (rank-indexed flow + selective tolerance + free k: a problem that wanders)
-        d = rsdsfm.synth.make_config(cfg, seed=int(rng.integers(1 << 30)), rows=rows, cols=cols)
-        rows, cols, K = d["rows"], d["cols"], d["K"]
-        gamma = 0.5 if rng.random() < 0.3 else d["gamma"]
-        clean = np.array(d["flow_img"])
-        frames, kinds = [clean], ["first"]
-        for _ in range(int(rng.integers(1, 4))):
-            kind = str(rng.choice(["same", "holed", "poisoned"]))
-            f = clean.copy()
-            if kind == "holed":
-                y0, x0 = int(rng.integers(0, rows - 4)), int(rng.integers(0, cols - 6))
-                f[y0:y0 + int(rng.integers(1, 12)), x0:x0 + int(rng.integers(1, 30))] = 0.0
-            elif kind == "poisoned":  # alpha = 1 + gamma f_y / rows = 0 exactly needs gamma f_y = -rows
-                f[int(rng.integers(0, rows)), int(rng.integers(0, cols))] = (3.0, -rows / gamma)
-            frames.append(f)
-            kinds.append(kind)
-        tag = "case %d (%dx%d cfg %d accel %d ranks %d trials %d tol %g flow %d seq %s)" % (c, rows, cols, cfg, accel, nranks, kw["trials"], kw["tol"],
-                                                                                            kw["flow_index_mode"], ",".join(kinds))
+        rows, cols, K, gamma, frames, kinds, kw, tag, nranks, accel = draw_case(rsdsfm, seed0, c)
         try:
             ones = []
             for f in frames:

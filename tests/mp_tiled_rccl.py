@@ -14,7 +14,11 @@ inlier's scanline index (one file per rank, concatenated in rank order by the te
 RSDSFM_TEST_SEQUENCE=1: instead, a SEQUENCE of frames on the one communicator that walks the driver's paths -- cold, ahead on the dense
 counts, a frame with a hole in rank 1's slab (every rank starts over through the counts exchange), cold again, ahead, a frame with a pixel
 outside the range of the function cores in rank 1's slab (every rank starts the RANSAC over), ahead -- and records, per solve and per
-rank, the results and rsdsfm_tiled_info: every collective of every path has to pair up between the two processes, or the run hangs."""
+rank, the results and rsdsfm_tiled_info: every collective of every path has to pair up between the two processes, or the run hangs.
+
+RSDSFM_TEST_FUZZ=N: N random cases of tests/fuzz_tiled.py (same generator, same seed on both ranks: frame size, data kind, tolerance, trials,
+flow mode, acceleration mode, a sequence of clean / holed / poisoned frames) over the one RCCL communicator; rank 0 also solves every frame
+on a single context and compares (fuzz_tiled.compare); the ranks' results are compared with each other bit for bit."""
 import json
 import os
 import sys
@@ -60,6 +64,54 @@ def main():
         out["init"] = "ok"
     except rsdsfm.RsdsfmError as e:  # e.g. a box whose RCCL cannot open the loopback interface: reported, the test skips
         out["init"] = str(e)
+    if out["init"] == "ok" and os.environ.get("RSDSFM_TEST_FUZZ"):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import fuzz_tiled
+
+        bad, solves, paths = [], 0, {}
+        for c in range(int(os.environ["RSDSFM_TEST_FUZZ"])):
+            rows, cols, K, gamma, frames, kinds, kw, tag, _, _ = fuzz_tiled.draw_case(rsdsfm, 20261003, c)
+            c0, sc, per = rsdsfm.tiled_slab_bounds(cols, world, rank)
+            dm = torch.zeros(cols * rows, dtype=torch.float64, device=dev)
+            R = torch.empty(rows * 9, dtype=torch.float64, device=dev)
+            t = torch.empty(rows * 3, dtype=torch.float64, device=dev)
+            for i, f in enumerate(frames):
+                slab = torch.from_numpy(np.ascontiguousarray(f[:, c0:c0 + sc, :])).to(dev)
+                try:
+                    r = solver.solve_frame_tiled_dev(slab.data_ptr() if sc else 0, rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), **kw)
+                    torch.cuda.synchronize()
+                    r["depth_map"] = dm.cpu().numpy()
+                    r["R"], r["t"] = R.cpu().numpy().reshape(rows, 9), t.cpu().numpy().reshape(rows, 3)
+                    err = None
+                except rsdsfm.RsdsfmError as e:  # (both ranks fail together: e.g. no real k for a hypothesis in acceleration mode)
+                    r, err = None, str(e)[:80]
+                mine = None if r is None else (r["n"], r["num_inliers"], r["best_trial"], r["v"].tobytes(), r["w"].tobytes(), r["k"], str(r["refine_summary"]),
+                                               r["depth_map"].tobytes(), r["info"]["path_flags"] & 0xFF, r["info"]["collectives"])
+                gathered = [None] * world
+                dist.all_gather_object(gathered, (mine, err is None))
+                solves += 1
+                if any(g != gathered[0] for g in gathered):
+                    bad.append("%s frame %d %s: the ranks disagree" % (tag, i, kinds[i]))
+                if rank == 0 and r is not None:
+                    paths[str(r["info"]["path_flags"] & 0xFF)] = paths.get(str(r["info"]["path_flags"] & 0xFF), 0) + 1
+                    try:
+                        one = fuzz_tiled.single(rsdsfm, torch, f, rows, cols, K, gamma, kw)
+                    except rsdsfm.RsdsfmError as e:
+                        bad.append("%s frame %d %s: the single-context solve fails (%s), the tiled one did not" % (tag, i, kinds[i], str(e)[:80]))
+                        continue
+                    rtol = 1e-5 if one["refine_summary"]["num_iterations"] >= 12 else (1e-6 if kw["use_acceleration_mode"] else 1e-9)
+                    what = fuzz_tiled.compare(r, one, rtol)
+                    if what and not (one["refine_summary"]["num_iterations"] >= 20 and what.startswith(("refinement", "pose", "depth", "flipped"))):
+                        bad.append("%s frame %d %s: %s" % (tag, i, kinds[i], what))
+        out.update(fuzz=dict(solves=solves, bad=bad, paths=paths))
+        solver.dist_finalize()
+        if rank == 0:
+            with open(os.environ["RSDSFM_TILED_OUT"], "w") as f:
+                json.dump(out, f)
+        solver.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if out["init"] == "ok" and os.environ.get("RSDSFM_TEST_SEQUENCE"):
         d = rsdsfm.synth.make_config(5, rows=64, cols=480)  # (alpha = 1 + gamma f_y / h vanishes for f_y = -128 px: h = 64, gamma = 0.5)
         rows, cols, K, gamma = d["rows"], d["cols"], d["K"], 0.5

@@ -626,6 +626,27 @@ def test_native_tiled_paths_over_a_real_two_rank_rccl_communicator(rsdsfm, tmp_p
         assert s["depth_nonzero"] == int((one["depth_map"] != 0).sum()) and np.isclose(s["depth_sum"], one["depth_map"].sum(), rtol=1e-9), name
 
 
+def test_native_tiled_random_sequences_over_a_real_two_rank_rccl_communicator(rsdsfm, tmp_path):
+    """40 random cases of tests/fuzz_tiled.py (frame size, data kind, tolerance, trials, flow mode, acceleration mode, sequences of clean /
+    holed / poisoned frames) over ONE real two-rank RCCL communicator (two processes): the ranks agree bit for bit on every solve and rank 0's
+    results equal the single-context solves"""
+    out = tmp_path / "fuzz.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RSDSFM_TILED_OUT=str(out), RSDSFM_TEST_FUZZ="40", NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1")
+    env.pop("NCCL_HOSTID", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29659",
+           os.path.join(ROOT, "tests", "mp_tiled_rccl.py")]
+    try:
+        p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=420)
+    except subprocess.TimeoutExpired:  # (the trick depends on the box's loopback networking: an environment limit, not a product failure)
+        pytest.skip("two RCCL ranks over the loopback interface did not finish within 420 s on this box")
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    got = json.loads(out.read_text())
+    if got["init"] != "ok":
+        pytest.skip("this box's RCCL cannot connect two ranks over the loopback interface: " + got["init"][:300])
+    assert got["fuzz"]["solves"] >= 80 and got["fuzz"]["bad"] == [], got["fuzz"]
+    assert len(got["fuzz"]["paths"]) >= 3, got["fuzz"]["paths"]  # cold, ahead, started over ...
+
+
 # ---------------------------------------------------------------------------------------------------
 # the row-tiled DENSE DEPTH solve driven from C++ (rsdsfm_estimate_inverse_depths_tiled_dev)
 # ---------------------------------------------------------------------------------------------------

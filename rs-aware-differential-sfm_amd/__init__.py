@@ -741,7 +741,8 @@ class _RectifyMixin:
 
     def rectify_frame_dev(self, d_inl, m, d_img, d_depth_map, d_R, d_t, K, rows, cols, d_preview, d_gs, d_fixed, d_coords=None, mode=BACKPROJECT_RS,
                           q5_mode=Q5_COMPAT, offset=1):
-        """main.cc:480-523 in one call (rsdsfm_rectify_frame_dev): depth image + back projection + crack interpolation, three launches"""
+        """main.cc:480-523 in one call (rsdsfm_rectify_frame_dev): depth image + back projection + crack interpolation, two launches (three when
+        the interpolation offset exceeds 2 or cols is not a multiple of 4)"""
         d = C.c_double
         self._check(self.lib.rsdsfm_rectify_frame_dev(self._ctx, _np0(d_inl), C.c_int64(m), _dp(d_img), _dp(d_depth_map), _dp(d_R), _dp(d_t), d(K[0]), d(K[1]),
                                                       d(K[2]), d(K[3]), C.c_int32(rows), C.c_int32(cols), int(mode), int(q5_mode), C.c_int32(offset),

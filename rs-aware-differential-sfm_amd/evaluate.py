@@ -122,9 +122,9 @@ def evaluate_real_run(solver, data_prefix, flow, camera="galaxy", gamma=0.95, ou
                                    seed=seed, use_acceleration_mode=use_acceleration_mode, use_refinement=use_refinement,
                                    flow_threshold=flow_threshold, flow_index_mode=flow_index_mode, use_global_shutter_mode=use_global_shutter_mode)
         m = r["num_inliers"]
-        solver.depth_preview_dev(r["d_inliers"], m, K, rows, cols, d_depth_est.data_ptr())  # main.cc:484-509
-        solver.back_project_dev(d_img.data_ptr(), d_map.data_ptr(), d_R.data_ptr(), d_t.data_ptr(), K, rows, cols, d_gs.data_ptr(), d_coords.data_ptr(), mode=mode)
-        solver.interpolate_cracky_dev(d_gs.data_ptr(), rows, cols, d_back.data_ptr(), 1)  # main.cc:523
+        # main.cc:480-523 -- 8-bit depth image, back projection, crack interpolation -- in ONE call of two launches
+        solver.rectify_frame_dev(r["d_inliers"], m, d_img.data_ptr(), d_map.data_ptr(), d_R.data_ptr(), d_t.data_ptr(), K, rows, cols, d_depth_est.data_ptr(),
+                                 d_gs.data_ptr(), d_back.data_ptr(), d_coords=d_coords.data_ptr(), mode=mode, offset=1)
         solver.synchronize()
         depth_map = d_map.cpu().numpy().reshape(cols, rows).T.copy()  # the device map is column-major (Eigen MatrixXd)
         R_rel, t_rel = d_R.cpu().numpy().reshape(rows, 3, 3), d_t.cpu().numpy().reshape(rows, 3)

@@ -871,20 +871,21 @@ restart_ransac:
         // host poll: what the previous solve on this communicator consumed (6 before there is one: the first Schur slot + 5 iterations; at most
         // 28), later chunks what it still needed at that point (2 .. 8).  Every rank holds the same hint, so all ranks issue the same
         // collectives; the chunking changes when the host looks at the state, never what the kernels compute.
-        auto slot = [&]() -> int {
-            int rc2 = refine_slot_rows_launch(c, B, np, d_row);
+        // (slot j of a chunk: the pass, whose prologue is the replicated stage of slot j - 1 on the rows gathered then; the shard's row; the exchange)
+        auto slot = [&](int j) -> int {
+            int rc2 = refine_slot_rows_launch(c, B, np, d_row, j, d_rows_all, R);
             if (rc2 != RSDSFM_OK) return rc2;
-            rc2 = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)refine_slot_row_doubles(np));
-            if (rc2 != RSDSFM_OK) return rc2;
-            return refine_slot_apply_launch(c, B, np, d_rows_all, R);
+            return all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)refine_slot_row_doubles(np));
         };
         const int hint = D->refine_iters_hint;
         int chunk = hint >= 1 ? std::min(hint, 28) : 6;  // (k refined: two slots per LM iteration, ~27 in all)
         for (int launched = 0;; chunk = hint >= 1 ? std::min(8, std::max(2, hint - launched)) : 5) {
             for (int i = 0; i < chunk; ++i) {
-                rc = slot();
+                rc = slot(i);
                 if (rc != RSDSFM_OK) return rc;
             }
+            rc = refine_slot_apply_launch(c, B, np, d_rows_all, R, chunk);  // the stage behind the chunk's last exchange -> B.state
+            if (rc != RSDSFM_OK) return rc;
             launched += chunk;
             rc = refine_finish_launch(c, B, d_inl_ref);  // enqueued before the poll: the common case ends within one chunk
             if (rc != RSDSFM_OK) return rc;

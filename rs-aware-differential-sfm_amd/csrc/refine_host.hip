@@ -113,7 +113,7 @@ int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const 
 // one chunk of slots of the iteration loop, the output pass and the caller's tail
 int refine_enqueue_chunk(Ctx* c, RefineRun* run) {
     for (int i = 0; i < run->chunk; ++i) {
-        int rc = refine_iter_launch(c, run->B, run->np);
+        int rc = refine_iter_launch(c, run->B, run->np, i, run->chunk);
         if (rc != RSDSFM_OK) return rc;
     }
     run->launched += run->chunk;

@@ -777,8 +777,18 @@ static inline int refine_grid(const Ctx* c, int64_t m) {
 }
 
 // (a workgroup's row: the init sums, the Schur sums, the back-substitution sums, or a slot's Schur | back-substitution sums -- the widest)
-int refine_partials_doubles(const Ctx* c, int64_t m) { return refine_grid(c, m) * SlotRow<7>::NW; }
-int refine_partials_doubles_cap(const Ctx* c) { return refine_grid_cap(c) * SlotRow<7>::NW; }
+// (the buffer also holds a second set of rows -- the prologue of a slot's pass reads the previous pass's rows while the workgroups write
+// their own -- and the two states the slot kernels of a chunk alternate between: sized by the cap, whatever m)
+static inline int refine_partials_half(const Ctx* c) { return refine_grid_cap(c) * SlotRow<7>::NW; }
+constexpr int kStateDoubles = (int)((sizeof(RefineState) + 63) / 64 * 8);  // one state, padded to 64 bytes, in doubles
+int refine_partials_doubles_cap(const Ctx* c) { return 2 * refine_partials_half(c) + 2 * kStateDoubles + 8; }
+int refine_partials_doubles(const Ctx* c, int64_t m) { (void)m; return refine_partials_doubles_cap(c); }
+static inline double* rows_buffer(const Ctx* c, const RefineBuffers& B, int which) { return B.partials + (size_t)(which & 1) * refine_partials_half(c); }
+static inline RefineState* chunk_state(const Ctx* c, const RefineBuffers& B, int which) {
+    return reinterpret_cast<RefineState*>(B.partials + 2 * (size_t)refine_partials_half(c) + (size_t)(which & 1) * kStateDoubles);
+}
+// slot j of a chunk starts from the published state (j = 0) or from what slot j - 1 left, and leaves its own in the other buffer
+static inline const RefineState* slot_state_in(const Ctx* c, const RefineBuffers& B, int j) { return j == 0 ? B.state : chunk_state(c, B, j - 1); }
 
 int refine_state_from_best_launch(Ctx* c, const RansacBest* d_best, const RefineBuffers& B, int np) {
     hipLaunchKernelGGL(refine_state_from_best_kernel, dim3(1), dim3(64), 0, c->stream, d_best, B.state, np, refine_grid_cap(c), B.bad_index);
@@ -859,15 +869,52 @@ static int refine_stage_apply_t(Ctx* c, const RefineBuffers& B, int stage, const
 // solves iteration i + 1 from the speculated sums, which are the very numbers the Schur pass would produce (same per-inlier code, same
 // thread mapping, same reductions).  Otherwise (rejected, invalid, or another radius) it sets RefineState::need_schur and the NEXT slot is a
 // plain Schur pass.  The host enqueues slots without knowing which kind each will be: the kernels read it from the state.
+// a wave-uniform double read from LDS, moved to scalar registers (the slot pass used to read its state through the scalar data path: 26 doubles
+// of pose, scales and step that would otherwise occupy 52 vector registers of a kernel that has none to spare)
+__device__ __forceinline__ double uniform_d(double x) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
+// the state of a slot kernel: copied to LDS, one 8-byte word per thread
+__device__ __forceinline__ void state_to_lds(RefineState* s_st, const RefineState* __restrict__ st_in) {
+    static_assert(sizeof(RefineState) % 8 == 0 && sizeof(RefineState) / 8 <= kFB, "copied as 8-byte words, one per thread");
+    if (threadIdx.x < sizeof(RefineState) / 8) reinterpret_cast<double*>(s_st)[threadIdx.x] = reinterpret_cast<const double*>(st_in)[threadIdx.x];
+    __syncthreads();
+}
+__device__ __forceinline__ void state_from_lds(RefineState* __restrict__ st_out, const RefineState* s_st) {
+    if (threadIdx.x < sizeof(RefineState) / 8) reinterpret_cast<double*>(st_out)[threadIdx.x] = reinterpret_cast<const double*>(s_st)[threadIdx.x];
+}
+
+template <int NP>
+__device__ __forceinline__ void slot_apply_body(RefineState* st, const double* __restrict__ rows_all, int nranks, double* __restrict__ trace, int trace_rows);
+
+// The streaming pass of a slot, with the single-workgroup stage of the PREVIOUS slot in its prologue: every workgroup copies the state it
+// starts from (st_in) to LDS, reduces the previous slot's rows and runs the decision / reduced solve on that copy -- the same code on the
+// same numbers in every workgroup, no hand-off between workgroups -- and goes on with the result; workgroup 0 also leaves it in st_out for
+// the next kernel (another buffer than st_in: a slower workgroup may still be reading that).  A launch and a pass over an idle chip less
+// per LM iteration than a stage kernel of its own between the passes, which is what VERDICT r3's item 3 was after; the hand-off variants
+// (fences in round 2, write-through stores + ticket in round 4) lost because of the hand-off, which this form does not have.
 template <int NP>
 __global__ __launch_bounds__(kFB) void refine_slot_pass_kernel(int64_t m, const double4* __restrict__ xyuv, const double* __restrict__ beta_in,
                                                               const double* __restrict__ alpha, const double* __restrict__ alpha_k,
                                                               double* __restrict__ rho_a, double* __restrict__ rho_b, const double* __restrict__ srho,
-                                                              const RefineState* __restrict__ st, double* __restrict__ partials, int want_zsum) {
+                                                              const RefineState* __restrict__ st_in, RefineState* __restrict__ st_out,
+                                                              const double* __restrict__ rows_prev, int nrows_prev, double* __restrict__ partials,
+                                                              int want_zsum, double* __restrict__ trace, int trace_rows) {
     using CT = Counts<NP>;
     using SR = SlotRow<NP>;
     __shared__ double s_redS[kFB / 64][CT::NSCHUR];
     __shared__ double s_redB[kFB / 64][CT::NBACK];
+    __shared__ RefineState s_state;
+    state_to_lds(&s_state, st_in);
+    RefineState* st = &s_state;
+    if (st->termination < 0 && st->pending_apply)
+        slot_apply_body<NP>(st, rows_prev, nrows_prev >= 0 ? nrows_prev : st->grid, blockIdx.x == 0 ? trace : nullptr, trace_rows);
+    __syncthreads();
+    if (threadIdx.x == 0) st->pending_apply = st->termination < 0 ? 1 : 0;  // (this pass runs: its rows -- or its top-of-loop exit -- wait for an apply)
+    __syncthreads();
+    if (blockIdx.x == 0) state_from_lds(st_out, st);
     if (st->termination >= 0) return;
     const PassShape ps = pass_shape(st, m);
     if (!ps.live) return;
@@ -875,9 +922,9 @@ __global__ __launch_bounds__(kFB) void refine_slot_pass_kernel(int64_t m, const 
     double* row = partials + (int64_t)blockIdx.x * SR::NW;
     double p[7], sp[NP];
 #pragma unroll
-    for (int c = 0; c < 7; ++c) p[c] = st->p[c];
+    for (int c = 0; c < 7; ++c) p[c] = uniform_d(st->p[c]);
 #pragma unroll
-    for (int c = 0; c < NP; ++c) sp[c] = st->sp[c];
+    for (int c = 0; c < NP; ++c) sp[c] = uniform_d(st->sp[c]);
     const double* __restrict__ rho = st->cur ? rho_b : rho_a;
     const int64_t stride = (int64_t)ps.grid * kFB;
     double accS[CT::NSCHUR];
@@ -902,9 +949,9 @@ __global__ __launch_bounds__(kFB) void refine_slot_pass_kernel(int64_t m, const 
     // the back-substitution of this iteration (refine_backsub_kernel's loop) + the Schur sums of the next one at the candidate
     double pc[7], yp[NP];
 #pragma unroll
-    for (int c = 0; c < 7; ++c) pc[c] = st->pc[c];
+    for (int c = 0; c < 7; ++c) pc[c] = uniform_d(st->pc[c]);
 #pragma unroll
-    for (int c = 0; c < NP; ++c) yp[c] = st->yp[c];
+    for (int c = 0; c < NP; ++c) yp[c] = uniform_d(st->yp[c]);
     const double inv_radius = 1.0 / st->radius;
     const double inv_radius_spec = 1.0 / radius_accept(st->radius, 1.0);
     const bool spec = SR::SPECULATES && st->spec_miss_run < 2;  // (the apply stage reads the same word before it updates it)
@@ -988,23 +1035,20 @@ __global__ __launch_bounds__(kFB) void refine_slot_row_kernel(const double* __re
 // columns on a second half of the workgroup ahead of the decision -- slower, with 512 and with 256 rows --; working on a copy of the
 // state in LDS.  What did help is fewer rows: see kFB.)
 template <int NP>
-__global__ __launch_bounds__(kFB) void refine_slot_apply_kernel(const double* __restrict__ rows_all, int nranks, RefineState* st,
-                                                               double* __restrict__ trace, int trace_rows) {
+__device__ __forceinline__ void slot_apply_body(RefineState* st, const double* __restrict__ rows_all, int nranks, double* __restrict__ trace, int trace_rows) {
     using CT = Counts<NP>;
     using SR = SlotRow<NP>;
-    __shared__ double s_redS[kFB / 64][CT::NSCHUR];
-    __shared__ double s_redB[kFB / 64][CT::NBACK];
+    __shared__ double s_aS[kFB / 64][CT::NSCHUR];
+    __shared__ double s_aB[kFB / 64][CT::NBACK];
     __shared__ double sS[CT::NSCHUR];
     __shared__ double sB[CT::NBACK];
     __shared__ int s_do_solve;
-    if (st->termination >= 0) return;
-    if (nranks < 0) nranks = st->grid;  // single-context solve enqueued ahead of the RANSAC result: the rows are the workgroups' partials
     const int tid = threadIdx.x;
     const int was_schur = st->need_schur;
+    const int solve_ok = st->solve_ok;
     if (tid == 0) s_do_solve = was_schur;
     if (!was_schur) {  // the decision of the iteration whose back-substitution this slot carried
-        const int solve_ok = st->solve_ok;
-        if (solve_ok) reduce_partials<CT::NBACK>(rows_all, nranks, CT::BACK_MAX, s_redB, sB, SR::NW, SR::OFF_BACK);
+        if (solve_ok) reduce_partials<CT::NBACK>(rows_all, nranks, CT::BACK_MAX, s_aB, sB, SR::NW, SR::OFF_BACK);
         if (tid == 0) {
             const double r_spec = radius_accept(st->radius, 1.0);  // (what the pass speculated with: the radius BEFORE the decision)
             const int spec_on = SR::SPECULATES && st->spec_miss_run < 2;  // (whether it speculated at all)
@@ -1018,29 +1062,43 @@ __global__ __launch_bounds__(kFB) void refine_slot_apply_kernel(const double* __
     }
     __syncthreads();
     if (tid == 0) st->slots += 1;
-    if (!s_do_solve || st->termination >= 0) return;
-    if (st->iteration >= kMaxIter) {  // top-of-loop checks of TrustRegionMinimizer (refine_solve_kernel)
+    const int do_solve = s_do_solve, termination = st->termination, iteration = st->iteration;
+    const double radius = st->radius;
+    __syncthreads();  // (every thread holds the decision's outcome before lane 0 goes on writing the state)
+    if (!do_solve || termination >= 0) return;
+    if (iteration >= kMaxIter) {  // top-of-loop checks of TrustRegionMinimizer (refine_solve_kernel)
         if (tid == 0) st->termination = RSDSFM_TERM_MAX_ITER;
         return;
     }
-    if (st->radius <= kMinRadius) {
+    if (radius <= kMinRadius) {
         if (tid == 0) st->termination = RSDSFM_TERM_MIN_RADIUS;
         return;
     }
-    double p_cur[7], sp_cur[NP];
-    double radius = 0.0;
+    reduce_partials<CT::NSCHUR>(rows_all, nranks, -1, s_aS, sS, SR::NW, 0);
     if (tid == 0) {
-        radius = st->radius;
+        double p_cur[7], sp_cur[NP];
 #pragma unroll
         for (int c = 0; c < 7; ++c) p_cur[c] = st->p[c];
 #pragma unroll
         for (int c = 0; c < NP; ++c) sp_cur[c] = st->sp[c];
-    }
-    reduce_partials<CT::NSCHUR>(rows_all, nranks, -1, s_redS, sS, SR::NW, 0);
-    if (tid == 0) {
         solve_serial<NP>(st, sS, p_cur, sp_cur, radius);
         st->need_schur = 0;
     }
+}
+
+// the single-workgroup stage on its own: behind the LAST pass of a chunk (st_in -> st_out = the published state the output pass, the caller's
+// tail and the host read), and behind every exchange of a custom transport that drives the slots stage by stage
+template <int NP>
+__global__ __launch_bounds__(kFB) void refine_slot_apply_kernel(const double* __restrict__ rows_all, int nranks, const RefineState* __restrict__ st_in,
+                                                               RefineState* __restrict__ st_out, double* __restrict__ trace, int trace_rows) {
+    __shared__ RefineState s_state;
+    state_to_lds(&s_state, st_in);
+    RefineState* st = &s_state;
+    if (st->termination < 0 && st->pending_apply) slot_apply_body<NP>(st, rows_all, nranks >= 0 ? nranks : st->grid, trace, trace_rows);
+    __syncthreads();
+    if (threadIdx.x == 0) st->pending_apply = 0;
+    __syncthreads();
+    state_from_lds(st_out, st);
 }
 
 // One SLOT of the iteration loop (the slot kernels below): a streaming pass and the single-workgroup stage behind it.  The first slot of a
@@ -1050,38 +1108,45 @@ __global__ __launch_bounds__(kFB) void refine_slot_apply_kernel(const double* __
 // sequence (refine_schur / solve / backsub / decide, still the stage protocol of rsdsfm_tile_refine_*) takes four and two.  A slot whose
 // speculation did not apply is followed by a plain Schur slot; the kernels read which kind from the state.
 template <int NP>
-static int refine_iter_t(Ctx* c, const RefineBuffers& B) {
+static int refine_iter_t(Ctx* c, const RefineBuffers& B, int j, int chunk) {
     const int grid = B.m_on_device ? refine_grid_cap(c) : refine_grid(c, B.m);
     const int64_t m_arg = B.m_on_device ? -1 : B.m;
     const int nb_arg = B.m_on_device ? -1 : grid;
     hipLaunchKernelGGL(refine_slot_pass_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, m_arg, reinterpret_cast<const double4*>(B.uu), B.beta,
-                       B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials, B.want_zsum ? 1 : 0);
+                       B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, slot_state_in(c, B, j), chunk_state(c, B, j), rows_buffer(c, B, j - 1), nb_arg,
+                       rows_buffer(c, B, j), B.want_zsum ? 1 : 0, c->d_refine_trace, c->refine_trace_rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(refine_slot_apply_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, nb_arg, B.state, c->d_refine_trace, c->refine_trace_rows);
-    RSDSFM_HIP_CHECK(c, hipGetLastError());
+    if (j == chunk - 1) {  // behind the last pass of a chunk: its stage on its own, into the published state
+        hipLaunchKernelGGL(refine_slot_apply_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_buffer(c, B, j), nb_arg, chunk_state(c, B, j), B.state,
+                           c->d_refine_trace, c->refine_trace_rows);
+        RSDSFM_HIP_CHECK(c, hipGetLastError());
+    }
     return RSDSFM_OK;
 }
 
 template <int NP>
-static int refine_slot_rows_t(Ctx* c, const RefineBuffers& B, double* row) {
+static int refine_slot_rows_t(Ctx* c, const RefineBuffers& B, double* row, int j, const double* rows_all_prev, int nranks) {
     const int grid = refine_grid(c, B.m);
     hipLaunchKernelGGL(refine_slot_pass_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m, reinterpret_cast<const double4*>(B.uu), B.beta, B.alpha,
-                       B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials, B.want_zsum ? 1 : 0);
+                       B.alpha_k, B.rho_a, B.rho_b, B.srho, slot_state_in(c, B, j), chunk_state(c, B, j), rows_all_prev, nranks, rows_buffer(c, B, 0),
+                       B.want_zsum ? 1 : 0, c->d_refine_trace, c->refine_trace_rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(refine_slot_row_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, row);
+    hipLaunchKernelGGL(refine_slot_row_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_buffer(c, B, 0), grid, row);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
 int refine_slot_row_doubles(int np) { return np == 7 ? SlotRow<7>::NW : SlotRow<6>::NW; }
 int refine_slot_partials_doubles(const Ctx* c, int64_t m) { return refine_partials_doubles(c, m); }
-int refine_slot_rows_launch(Ctx* c, const RefineBuffers& B, int np, double* row) {
-    return np == 7 ? refine_slot_rows_t<7>(c, B, row) : refine_slot_rows_t<6>(c, B, row);
+int refine_slot_rows_launch(Ctx* c, const RefineBuffers& B, int np, double* row, int j, const double* rows_all_prev, int nranks) {
+    return np == 7 ? refine_slot_rows_t<7>(c, B, row, j, rows_all_prev, nranks) : refine_slot_rows_t<6>(c, B, row, j, rows_all_prev, nranks);
 }
-int refine_slot_apply_launch(Ctx* c, const RefineBuffers& B, int np, const double* rows_all, int nranks) {
+int refine_slot_apply_launch(Ctx* c, const RefineBuffers& B, int np, const double* rows_all, int nranks, int chunk) {
     if (np == 7)
-        hipLaunchKernelGGL(refine_slot_apply_kernel<7>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state, c->d_refine_trace, c->refine_trace_rows);
+        hipLaunchKernelGGL(refine_slot_apply_kernel<7>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, chunk_state(c, B, chunk - 1), B.state,
+                           c->d_refine_trace, c->refine_trace_rows);
     else
-        hipLaunchKernelGGL(refine_slot_apply_kernel<6>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state, c->d_refine_trace, c->refine_trace_rows);
+        hipLaunchKernelGGL(refine_slot_apply_kernel<6>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, chunk_state(c, B, chunk - 1), B.state,
+                           c->d_refine_trace, c->refine_trace_rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
@@ -1099,7 +1164,7 @@ int refine_stage_apply_launch(Ctx* c, const RefineBuffers& B, int np, int stage,
 }
 
 int refine_init_launch(Ctx* c, const RefineBuffers& B, int np) { return np == 7 ? refine_init_t<7>(c, B) : refine_init_t<6>(c, B); }
-int refine_iter_launch(Ctx* c, const RefineBuffers& B, int np) { return np == 7 ? refine_iter_t<7>(c, B) : refine_iter_t<6>(c, B); }
+int refine_iter_launch(Ctx* c, const RefineBuffers& B, int np, int j, int chunk) { return np == 7 ? refine_iter_t<7>(c, B, j, chunk) : refine_iter_t<6>(c, B, j, chunk); }
 
 int refine_finish_grid(const Ctx* c, const RefineBuffers& B) { return B.m_on_device ? refine_grid_cap(c) : refine_grid(c, B.m); }
 

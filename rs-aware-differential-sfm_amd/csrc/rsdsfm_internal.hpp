@@ -363,6 +363,9 @@ struct RefineState {
     // speculates while this is < 2 (DeepFlow-like data: four steps in five apply, misses are isolated; acceleration mode: runs of rejected
     // steps and of qualities 0.65 .. 0.93, where speculating would add a wasted Schur evaluation to every pass)
     int32_t spec_miss_run;
+    // a slot's pass has run and its single-workgroup stage has not: the next slot kernel's prologue (or the stage kernel behind the last
+    // pass of a chunk) reduces that pass's rows and runs the decision / reduced solve before anything else
+    int32_t pending_apply, _pad3;
 };
 struct RefineBuffers {
     const double* flow;  // 2 x n_flow
@@ -470,7 +473,9 @@ inline int refine_trace_reset(Ctx* c) {
     return hipMemsetAsync(c->d_refine_trace, 0xFF, (size_t)c->refine_trace_rows * kRefineTraceCols * sizeof(double), c->stream) == hipSuccess ? RSDSFM_OK : RSDSFM_ERR_HIP;
 }
 int refine_init_launch(Ctx* c, const RefineBuffers& B, int np);
-int refine_iter_launch(Ctx* c, const RefineBuffers& B, int np);
+// slot `j` of a chunk of `chunk` slots (refine_kernels.hip): its pass carries the single-workgroup stage of slot j - 1 in its prologue; the
+// last one is followed by that stage on its own, which leaves the state in B.state for the output pass, the caller's tail and the host
+int refine_iter_launch(Ctx* c, const RefineBuffers& B, int np, int j, int chunk);
 int refine_finish_launch(Ctx* c, const RefineBuffers& B, double* inl_out);
 // row-tiled stages: stage 0 = iteration-zero sums, 1 = Schur sums, 2 = back-substitution sums
 int refine_stage_row_doubles(int np, int stage);
@@ -478,8 +483,10 @@ int refine_stage_row_doubles(int np, int stage);
 // -> (all-gather) -> refine_slot_apply_launch on every rank
 int refine_slot_row_doubles(int np);
 int refine_slot_partials_doubles(const Ctx* c, int64_t m);
-int refine_slot_rows_launch(Ctx* c, const RefineBuffers& B, int np, double* row);
-int refine_slot_apply_launch(Ctx* c, const RefineBuffers& B, int np, const double* rows_all, int nranks);
+// column-tiled solve, slot j of a chunk: the pass (prologue: the stage of slot j - 1 on the gathered rows `rows_all_prev`) + the shard's row;
+// refine_slot_apply_launch: the stage behind the last exchange of a chunk (-> B.state)
+int refine_slot_rows_launch(Ctx* c, const RefineBuffers& B, int np, double* row, int j, const double* rows_all_prev, int nranks);
+int refine_slot_apply_launch(Ctx* c, const RefineBuffers& B, int np, const double* rows_all, int nranks, int chunk);
 int refine_stage_rows_launch(Ctx* c, const RefineBuffers& B, int np, int stage, double* row);
 int refine_stage_apply_launch(Ctx* c, const RefineBuffers& B, int np, int stage, const double* rows_all, int nranks, int64_t m_total);
 }  // namespace rsdsfm

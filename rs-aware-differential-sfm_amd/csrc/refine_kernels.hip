@@ -228,6 +228,55 @@ __device__ __forceinline__ void reduce_partials(const double* __restrict__ parti
     (void)s_red;
 }
 
+// The group sums of TWO column ranges of the same rows with every load of both issued before the first addition (one round trip to the rows
+// instead of two): thread tid is lane (gA, spA) of range A and lane (gB, spB) of range B, each adds its rows in reduce_partials_groups' order.
+// Only for row counts one batch covers (nblocks <= 16 G of both ranges: 288 rows for the 54 Schur sums); returns false otherwise.
+template <int NA, int NB>
+__device__ __forceinline__ bool reduce_two_ranges_groups(const double* __restrict__ rows, int nblocks, int stride, int offA, int maxA, bool doA,
+                                                         double (*s_grpA)[NA], int offB, int maxB, bool doB, double (*s_grpB)[NB], int tid) {
+    using SA = ReduceShape<NA>;
+    using SB = ReduceShape<NB>;
+    static_assert(SA::W == 2 && SB::W == 2, "slot pairs");
+    constexpr int U = 16;
+    if (nblocks > U * SA::G || nblocks > U * SB::G) return false;
+    const int gA = tid / SA::NH, spA = tid - gA * SA::NH, gB = tid / SB::NH, spB = tid - gB * SB::NH;
+    const bool onA = doA && gA < SA::G, onB = doB && gB < SB::G;
+    double2 vA[U], vB[U];
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const int bj = gA + j * SA::G;
+        vA[j] = (onA && bj < nblocks) ? reinterpret_cast<const double2*>(rows + (int64_t)bj * stride + offA)[spA] : make_double2(0.0, 0.0);
+    }
+#pragma unroll
+    for (int j = 0; j < U; ++j) {
+        const int bj = gB + j * SB::G;
+        vB[j] = (onB && bj < nblocks) ? reinterpret_cast<const double2*>(rows + (int64_t)bj * stride + offB)[spB] : make_double2(0.0, 0.0);
+    }
+    if (onA) {
+        const bool mx0 = (2 * spA == maxA), mx1 = (2 * spA + 1 == maxA);
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            a0 = mx0 ? fmax(a0, vA[j].x) : a0 + vA[j].x;
+            a1 = mx1 ? fmax(a1, vA[j].y) : a1 + vA[j].y;
+        }
+        s_grpA[gA][2 * spA] = a0;
+        s_grpA[gA][2 * spA + 1] = a1;
+    }
+    if (onB) {
+        const bool mx0 = (2 * spB == maxB), mx1 = (2 * spB + 1 == maxB);
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            a0 = mx0 ? fmax(a0, vB[j].x) : a0 + vB[j].x;
+            a1 = mx1 ? fmax(a1, vB[j].y) : a1 + vB[j].y;
+        }
+        s_grpB[gB][2 * spB] = a0;
+        s_grpB[gB][2 * spB + 1] = a1;
+    }
+    return true;
+}
+
 template <int NP>
 struct Counts {
     static constexpr int TRI = NP * (NP + 1) / 2;
@@ -1038,6 +1087,8 @@ template <int NP>
 __device__ __forceinline__ void slot_apply_body(RefineState* st, const double* __restrict__ rows_all, int nranks, double* __restrict__ trace, int trace_rows) {
     using CT = Counts<NP>;
     using SR = SlotRow<NP>;
+    __shared__ double s_gS[ReduceShape<CT::NSCHUR>::G][CT::NSCHUR];
+    __shared__ double s_gB[ReduceShape<CT::NBACK>::G][CT::NBACK];
     __shared__ double s_aS[kFB / 64][CT::NSCHUR];
     __shared__ double s_aB[kFB / 64][CT::NBACK];
     __shared__ double sS[CT::NSCHUR];
@@ -1046,19 +1097,31 @@ __device__ __forceinline__ void slot_apply_body(RefineState* st, const double* _
     const int tid = threadIdx.x;
     const int was_schur = st->need_schur;
     const int solve_ok = st->solve_ok;
+    const int spec_on = SR::SPECULATES && st->spec_miss_run < 2;  // (whether the pass speculated at all)
     if (tid == 0) s_do_solve = was_schur;
-    if (!was_schur) {  // the decision of the iteration whose back-substitution this slot carried
-        if (solve_ok) reduce_partials<CT::NBACK>(rows_all, nranks, CT::BACK_MAX, s_aB, sB, SR::NW, SR::OFF_BACK);
-        if (tid == 0) {
-            const double r_spec = radius_accept(st->radius, 1.0);  // (what the pass speculated with: the radius BEFORE the decision)
-            const int spec_on = SR::SPECULATES && st->spec_miss_run < 2;  // (whether it speculated at all)
-            const int accepted = decide_serial<NP>(st, sB, solve_ok, trace, trace_rows);
-            // the speculated Schur sums are the next iteration's iff the state moved to the candidate with exactly that radius
-            const int applies = (accepted && st->radius == r_spec) ? 1 : 0;
-            st->spec_miss_run = applies ? 0 : min(st->spec_miss_run + 1, 2);
-            s_do_solve = applies && spec_on;
-            st->need_schur = (st->termination < 0 && !s_do_solve) ? 1 : 0;
+    // the sums: the back-substitution columns the decision needs and -- ahead of the decision -- the Schur columns the reduced solve needs
+    // when the slot was a Schur pass or its speculation applies; one round trip to the rows for both (each in reduce_partials' order)
+    const bool needB = !was_schur && solve_ok, wantS = was_schur || (spec_on && solve_ok);
+    bool haveS = false, fused = false;
+    if constexpr (SR::SPECULATES) {  // (with k refined a slot carries one range or the other, never both)
+        fused = reduce_two_ranges_groups<CT::NBACK, CT::NSCHUR>(rows_all, nranks, SR::NW, SR::OFF_BACK, CT::BACK_MAX, needB, s_gB, 0, -1, wantS, s_gS, tid);
+        if (fused) {
+            __syncthreads();
+            if (needB) reduce_partials_slots<CT::NBACK>(s_gB, CT::BACK_MAX, sB, tid);
+            if (wantS) reduce_partials_slots<CT::NSCHUR>(s_gS, -1, sS, tid);
+            __syncthreads();
+            haveS = wantS;
         }
+    }
+    if (!fused && needB) reduce_partials<CT::NBACK>(rows_all, nranks, CT::BACK_MAX, s_aB, sB, SR::NW, SR::OFF_BACK);
+    if (!was_schur && tid == 0) {  // the decision of the iteration whose back-substitution this slot carried
+        const double r_spec = radius_accept(st->radius, 1.0);  // (what the pass speculated with: the radius BEFORE the decision)
+        const int accepted = decide_serial<NP>(st, sB, solve_ok, trace, trace_rows);
+        // the speculated Schur sums are the next iteration's iff the state moved to the candidate with exactly that radius
+        const int applies = (accepted && st->radius == r_spec) ? 1 : 0;
+        st->spec_miss_run = applies ? 0 : min(st->spec_miss_run + 1, 2);
+        s_do_solve = applies && spec_on;
+        st->need_schur = (st->termination < 0 && !s_do_solve) ? 1 : 0;
     }
     __syncthreads();
     if (tid == 0) st->slots += 1;
@@ -1074,7 +1137,7 @@ __device__ __forceinline__ void slot_apply_body(RefineState* st, const double* _
         if (tid == 0) st->termination = RSDSFM_TERM_MIN_RADIUS;
         return;
     }
-    reduce_partials<CT::NSCHUR>(rows_all, nranks, -1, s_aS, sS, SR::NW, 0);
+    if (!haveS) reduce_partials<CT::NSCHUR>(rows_all, nranks, -1, s_aS, sS, SR::NW, 0);
     if (tid == 0) {
         double p_cur[7], sp_cur[NP];
 #pragma unroll

@@ -244,6 +244,11 @@ class Solver:
         self._check(self.lib.rsdsfm_profile_last_ms(self._ctx, what.encode(), C.byref(ms)), "rsdsfm_profile_last_ms")
         return ms.value
 
+    def set_refine_stage(self, mode):
+        """where the refinement's single-workgroup stage runs: 0 (default) = automatic, 1 = in the next pass's prologue, 2 = a launch of its own
+        (rsdsfm_set_refine_stage); never a result"""
+        self._check(self.lib.rsdsfm_set_refine_stage(self._ctx, int(mode)), "rsdsfm_set_refine_stage")
+
     def set_ransac_speculation(self, k0):
         """LM iterations speculated by round 0 of RANSAC's batched depth solves: 0 (default) = automatic, follows the context's previous
         solve (2 when none of its hypotheses went beyond one accepted step, else 3); 2 or 3 = fixed.  Scheduling only: never a result."""

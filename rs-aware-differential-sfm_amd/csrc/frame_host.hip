@@ -435,7 +435,10 @@ int rsdsfm_solve_frames_dev(rsdsfm_ctx* ctx, const rsdsfm_frame_job* jobs, int32
         lc->ransac_k0 = c->ransac_k0;
         lc->ransac_math_mode = c->ransac_math_mode;
         lc->frame_side_flatten = c->frame_side_flatten;
+        lc->refine_stage_mode = c->refine_stage_mode;
     }
+    // several pairs in flight share the GPU: the refinement's single-workgroup stage gets launches of its own (Ctx::refine_stage_mode)
+    for (int l = 0; l < L; ++l) lane_ctx(l)->refine_stage_separate = L > 1;
     int first_error = RSDSFM_OK;
     int in_flight[16];  // pair index each lane is working on, -1 = none
     for (int l = 0; l < 16; ++l) in_flight[l] = -1;
@@ -478,7 +481,16 @@ int rsdsfm_solve_frames_dev(rsdsfm_ctx* ctx, const rsdsfm_frame_job* jobs, int32
         if (best < 0) break;
         finish_lane(best);
     }
+    for (int l = 0; l < L; ++l) lane_ctx(l)->refine_stage_separate = false;  // (single solves on this context: the stage back in the prologue)
     return first_error;
+}
+
+int rsdsfm_set_refine_stage(rsdsfm_ctx* ctx, int mode) {
+    if (!ctx) return RSDSFM_ERR_INVALID;
+    Ctx* c = &ctx->c;
+    if (mode < 0 || mode > 2) return fail(c, RSDSFM_ERR_INVALID, "refine stage: 0 (automatic), 1 (in the next pass's prologue) or 2 (a launch of its own)");
+    c->refine_stage_mode = mode;
+    return RSDSFM_OK;
 }
 
 }  // extern "C"

@@ -1179,9 +1179,12 @@ static int refine_iter_t(Ctx* c, const RefineBuffers& B, int j, int chunk) {
                        B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, slot_state_in(c, B, j), chunk_state(c, B, j), rows_buffer(c, B, j - 1), nb_arg,
                        rows_buffer(c, B, j), B.want_zsum ? 1 : 0, c->d_refine_trace, c->refine_trace_rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    if (j == chunk - 1) {  // behind the last pass of a chunk: its stage on its own, into the published state
-        hipLaunchKernelGGL(refine_slot_apply_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_buffer(c, B, j), nb_arg, chunk_state(c, B, j), B.state,
-                           c->d_refine_trace, c->refine_trace_rows);
+    // the stage on its own: behind the last pass of a chunk (into the published state), and -- while several pairs of a sequence share the
+    // GPU, or on request -- behind every pass (in place: the next pass then finds nothing pending and its prologue only copies the state)
+    const bool separate = c->refine_stage_mode == 2 || (c->refine_stage_mode == 0 && c->refine_stage_separate);
+    if (j == chunk - 1 || separate) {
+        hipLaunchKernelGGL(refine_slot_apply_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_buffer(c, B, j), nb_arg, chunk_state(c, B, j),
+                           j == chunk - 1 ? B.state : chunk_state(c, B, j), c->d_refine_trace, c->refine_trace_rows);
         RSDSFM_HIP_CHECK(c, hipGetLastError());
     }
     return RSDSFM_OK;

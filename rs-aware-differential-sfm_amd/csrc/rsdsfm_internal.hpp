@@ -161,6 +161,12 @@ struct Ctx {
     int frame_side_flatten = 3;  // rsdsfm_set_frame_side_flatten: where a dense frame's flatten runs -- 0 first, 1 on aux_stream beside the minimal solver, 2 behind it, 3 INSIDE the solver's launch
     unsigned long long* d_flat_counters = nullptr;  // the two counters of minimal9_flatten_kernel (zero between launches)
     int seq_lanes = 0;               // rsdsfm_set_sequence_lanes (0 = kSequenceLanesDefault)
+    // where the refinement's single-workgroup stage runs (rsdsfm_set_refine_stage): 0 = automatic -- in the prologue of the next slot's pass
+    // (one launch per slot: the shortest single solve), except while several pairs of a sequence are in flight, where the stage gets a
+    // launch of its own behind every pass (the prologue occupies the WHOLE chip for its ~8 us, a single workgroup leaves it to the other
+    // lanes' kernels); 1 = always in the prologue; 2 = always a launch of its own.  Never a result.
+    int refine_stage_mode = 0;
+    bool refine_stage_separate = false;  // (what the automatic mode resolves to for the solve in flight)
     std::vector<rsdsfm_ctx*> lanes;
 };
 constexpr int kSequenceLanesDefault = 3;  // measured: 1 / 2 / 3 / 4 / 6 / 8 lanes = 0.91 / 1.19 / 1.31 / 1.21 / 1.31 / 1.27 Gpix/s at 1280x720, T = 50

@@ -180,6 +180,42 @@ def test_profiling_records_do_not_change_results(rsdsfm):
         assert solve(s) == plain
 
 
+def test_refine_stage_placement_does_not_change_results(rsdsfm):
+    """rsdsfm_set_refine_stage: the single-workgroup stage of the refinement in the next pass's prologue (1), as a launch of its own (2), or
+    chosen automatically (0: prologue for single solves, own launches while a sequence has several pairs in flight) -- the same bits from
+    the single solve and from the sequence solve in every mode, with k fixed and with k refined"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    frames = [rsdsfm.synth.make_config(cfg, rows=120, cols=200, seed=77 + cfg) for cfg in (5, 3, 5, 1, 3)]
+    rows, cols = frames[0]["rows"], frames[0]["cols"]
+    imgs = [torch.from_numpy(d["flow_img"]).to(dev) for d in frames]
+    dms = [torch.zeros((cols, rows), dtype=torch.float64, device=dev) for _ in frames]
+    jobs = [dict(d_flow_img=im.data_ptr(), rows=rows, cols=cols, K=d["K"], gamma=d["gamma"], d_depth_map=dm.data_ptr()) for im, dm, d in zip(imgs, dms, frames)]
+    for accel in (False, True):
+        kw = dict(trials=16, tol=0.01, use_acceleration_mode=accel, flow_index_mode=rsdsfm.FLOW_GATHERED)
+        want = None
+        for mode in (0, 1, 2):
+            with rsdsfm.Solver(0) as s:
+                s.set_refine_stage(mode)
+                seq = s.solve_frames_dev(jobs, [3 + i for i in range(len(jobs))], **kw)
+                s.synchronize()
+                got = [(r["num_inliers"], r["best_trial"], r["v"].tobytes(), r["w"].tobytes(), r["k"], str(r["refine_summary"]), dm.cpu().numpy().tobytes())
+                       for r, dm in zip(seq, dms)]
+                singles = []
+                for i, (im, d) in enumerate(zip(imgs, frames)):
+                    r = s.solve_frame_dev(im.data_ptr(), rows, cols, d["K"], d["gamma"], dms[i].data_ptr(), seed=3 + i, **kw)
+                    s.synchronize()
+                    singles.append((r["num_inliers"], r["best_trial"], r["v"].tobytes(), r["w"].tobytes(), r["k"], str(r["refine_summary"]),
+                                    dms[i].cpu().numpy().tobytes()))
+            assert got == singles, (accel, mode)
+            want = want or got
+            assert got == want, (accel, mode)
+    with rsdsfm.Solver(0) as s:
+        with pytest.raises(rsdsfm.RsdsfmError):
+            s.set_refine_stage(3)
+
+
 def test_solve_does_not_depend_on_the_contexts_history(rsdsfm):
     """a context remembers how its previous solve went -- whether the separate scoring pass was needed (noise-free data), how many
     refinement iterations it took, which depth iterate was right -- only to decide what it enqueues AHEAD of the host's reads; a

@@ -149,9 +149,10 @@ int rsdsfm_depth_restarts(rsdsfm_ctx* ctx, int64_t* count);
  * --kernel-trace reports for the kernel, without the gap between launches): rsdsfm_profile_last_ms(ctx, "depth_lm_batch", &ms). */
 /* Where the single-workgroup stage of the joint refinement's iteration loop runs (nonlinearRefinement.cc:183-252 has no such notion: Ceres runs
  * the loop on the host).  0 (default) = automatic: in the prologue of the next slot's streaming pass, computed redundantly by every workgroup
- * -- one launch per LM iteration, the shortest single solve -- except inside rsdsfm_solve_frames_dev with more than one lane, where it gets a
- * launch of its own behind every pass (the prologue keeps the whole chip busy for its ~8 us; a single workgroup leaves it to the other pairs'
- * kernels: +5 % sequence throughput); 1 = always in the prologue; 2 = always a launch of its own.  Identical results in every mode. */
+ * -- one launch per LM iteration, the shortest single solve -- except when the solve is not alone on its GPU (several lanes of
+ * rsdsfm_solve_frames_dev in flight, or frame solves of other contexts of the process on the same device), where it gets a launch of its
+ * own behind every pass (the prologue keeps the whole chip busy for its ~8 us; a single workgroup leaves it to the other solves' kernels:
+ * +4 % sequence throughput); 1 = always in the prologue; 2 = always a launch of its own.  Identical results in every mode. */
 int rsdsfm_set_refine_stage(rsdsfm_ctx* ctx, int mode);
 int rsdsfm_set_profiling(rsdsfm_ctx* ctx, int on);
 int rsdsfm_profile_last_ms(rsdsfm_ctx* ctx, const char* what, double* ms);

@@ -14,12 +14,21 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+
 #include <algorithm>
 #include <new>
 
 #include "rsdsfm_internal.hpp"
 
 namespace rsdsfm {
+
+// Frame solves between their begin and the end of their finish, per device and over ALL contexts of the process: a solve that is not alone on
+// its GPU (several host threads with a context each; the lanes of a sequence) gives the refinement's single-workgroup stage launches of its own
+// instead of the redundant prologue (Ctx::refine_stage_mode, refine_kernels.hip) -- a scheduling choice, never a result.
+static std::atomic<int> g_frames_in_flight[64];
+int frames_in_flight(const Ctx* c) { return g_frames_in_flight[c->device & 63].load(std::memory_order_relaxed); }
+
 int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
                   const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
                   int const_acceleration, int flow_index_mode, double* d_inl_out, double v_out[3], double w_out[3], double* k_out,
@@ -77,6 +86,11 @@ int ensure_side_stream(Ctx* c) {
     RSDSFM_HIP_CHECK(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     return RSDSFM_OK;
 }
+
+struct FrameInFlightEnd {
+    const Ctx* c;
+    ~FrameInFlightEnd() { g_frames_in_flight[c->device & 63].fetch_sub(1, std::memory_order_relaxed); }
+};
 
 int frame_begin(Ctx* c, FrameRun* F) {
     const rsdsfm_frame_job& J = F->job;
@@ -244,6 +258,7 @@ int frame_begin(Ctx* c, FrameRun* F) {
     // refinement is enqueued behind the definitive final stage from the device-resident result, without a host round trip.)
     F->ahead = prm->use_refinement && c->ransac_spec_miss < 2;
     F->open = true;
+    g_frames_in_flight[c->device & 63].fetch_add(1, std::memory_order_relaxed);
     F->rc_begin = ransac_begin(c, F->d_q, F->d_u, F->d_a, F->d_ak, n, prm->use_acceleration_mode, prm->ransac_trials, prm->ransac_tol, nullptr, J.seed,
                                prm->depth_mode, prm->k_sign_mode, &F->ro, prm->use_refinement ? &F->spec_tail : nullptr, &F->refinement_enqueued, &F->ransac,
                                F->side_flatten ? &F->direct : nullptr, F->side_flatten && !F->dense_in_launch ? &F->join : nullptr,
@@ -254,6 +269,7 @@ int frame_begin(Ctx* c, FrameRun* F) {
 int frame_finish(Ctx* c, FrameRun* F, rsdsfm_frame_result* res) {
     if (!F->open) return fail(c, RSDSFM_ERR_INVALID, "no frame solve in flight");
     F->open = false;
+    FrameInFlightEnd in_flight_end_{c};  // (until this function returns: the solve's kernels occupy the GPU while the host waits)
     const rsdsfm_frame_job& J = F->job;
     const rsdsfm_frame_params* prm = &F->prm;
     memset(res, 0, sizeof(*res));

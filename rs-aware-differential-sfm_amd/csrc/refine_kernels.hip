@@ -1181,7 +1181,7 @@ static int refine_iter_t(Ctx* c, const RefineBuffers& B, int j, int chunk) {
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     // the stage on its own: behind the last pass of a chunk (into the published state), and -- while several pairs of a sequence share the
     // GPU, or on request -- behind every pass (in place: the next pass then finds nothing pending and its prologue only copies the state)
-    const bool separate = c->refine_stage_mode == 2 || (c->refine_stage_mode == 0 && c->refine_stage_separate);
+    const bool separate = c->refine_stage_mode == 2 || (c->refine_stage_mode == 0 && (c->refine_stage_separate || frames_in_flight(c) > 1));
     if (j == chunk - 1 || separate) {
         hipLaunchKernelGGL(refine_slot_apply_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_buffer(c, B, j), nb_arg, chunk_state(c, B, j),
                            j == chunk - 1 ? B.state : chunk_state(c, B, j), c->d_refine_trace, c->refine_trace_rows);

@@ -162,9 +162,10 @@ struct Ctx {
     unsigned long long* d_flat_counters = nullptr;  // the two counters of minimal9_flatten_kernel (zero between launches)
     int seq_lanes = 0;               // rsdsfm_set_sequence_lanes (0 = kSequenceLanesDefault)
     // where the refinement's single-workgroup stage runs (rsdsfm_set_refine_stage): 0 = automatic -- in the prologue of the next slot's pass
-    // (one launch per slot: the shortest single solve), except while several pairs of a sequence are in flight, where the stage gets a
-    // launch of its own behind every pass (the prologue occupies the WHOLE chip for its ~8 us, a single workgroup leaves it to the other
-    // lanes' kernels); 1 = always in the prologue; 2 = always a launch of its own.  Never a result.
+    // (one launch per slot: the shortest single solve), except while the solve is not alone on its GPU -- several pairs of a sequence in
+    // flight, or frame solves of other contexts (frames_in_flight) --, where the stage gets a launch of its own behind every pass (the
+    // prologue occupies the WHOLE chip for its ~8 us, a single workgroup leaves it to the other solves' kernels); 1 = always in the
+    // prologue; 2 = always a launch of its own.  Never a result.
     int refine_stage_mode = 0;
     bool refine_stage_separate = false;  // (what the automatic mode resolves to for the solve in flight)
     std::vector<rsdsfm_ctx*> lanes;
@@ -469,6 +470,7 @@ int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const 
                  int const_acceleration, int flow_index_mode, double* d_inl_out, const RefineTail* tail, const RansacBest* d_best,
                  void* ws_base, RefineRun* run, RefineState* hs_prefetch, double* d_zpartials);
 int refine_enqueue_chunk(Ctx* c, RefineRun* run);
+int frames_in_flight(const Ctx* c);  // frame solves between begin and the end of finish on the context's device, all contexts of the process (frame_host.hip)
 int refine_poll(Ctx* c, RefineRun* run, double v_out[3], double w_out[3], double* k_out, rsdsfm_lm_summary* summary);
 int refine_partials_doubles(const Ctx* c, int64_t m);
 int refine_partials_doubles_cap(const Ctx* c);

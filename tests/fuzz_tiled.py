@@ -85,7 +85,9 @@ def compare(a, b, rtol):
     for key in ("n", "num_inliers", "best_trial", "flipped"):
         if a[key] != b[key]:
             return key
-    if not (np.array_equal(a["ransac_w"], b["ransac_w"]) and np.array_equal(a["ransac_v"], b["ransac_v"]) and a["ransac_k"] == b["ransac_k"]):
+    same_k = a["ransac_k"] == b["ransac_k"] or (np.isnan(a["ransac_k"]) and np.isnan(b["ransac_k"]))
+    # (a degenerate sample gives a NaN hypothesis on both sides: with ONE trial that is the winner)
+    if not (np.array_equal(a["ransac_w"], b["ransac_w"], equal_nan=True) and np.array_equal(a["ransac_v"], b["ransac_v"], equal_nan=True) and same_k):
         return "winner's hypothesis"
     for key in ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination"):
         if a["refine_summary"][key] != b["refine_summary"][key]:

@@ -132,6 +132,22 @@ int rsdsfm_set_ransac_speculation(rsdsfm_ctx* ctx, int k0);
  * rsdsfm_ransac_restarts: how many RANSAC runs of this context (and its sequence lanes) started over. */
 int rsdsfm_set_ransac_math(rsdsfm_ctx* ctx, int mode);
 int rsdsfm_ransac_restarts(rsdsfm_ctx* ctx, int64_t* count);
+/* The arithmetic of the T dense depth solves inside a RANSAC (minimal.cc:246: estimateInverseDepths per trial, nonlinearRefinement.cc:109-180
+ * under Ceres 1.14's trust-region loop), RSDSFM_DEPTH_CERES_LM mode.
+ * 0 (default): the ANALYTIC LM TRAJECTORY.  For a fixed pose every residual is linear in its own inverse depth, so the iterates Ceres
+ *   walks, and every global quantity its accept / converge tests look at, are closed forms of five sums and a maximum per hypothesis
+ *   (csrc/lma_common.hpp): one pass over the pixels, ~70 operations per pixel-hypothesis instead of ~55 per pixel, hypothesis AND
+ *   iteration.  Guards keep every integer output (accepted steps, terminations, per-trial inlier counts, winner, inlier mask / index list)
+ *   equal to the iterate-by-iterate arithmetic's: pixels whose LM diagonal is clamped, and pixels whose error comes within a margin of the
+ *   tolerance, walk the reference's exact recurrence; a global decision within 1e-6 (relative) of its threshold, or a tie in the inlier
+ *   count that only rounding noise could break (noise-free data), makes the run start over iterate by iterate, as do the context's next
+ *   16 runs.  The winner's dense inverse depths and mask always come from the exact replay of its accepted steps.
+ * 1: always iterate by iterate (the reference's arithmetic, operation for operation).
+ * rsdsfm_lma_restarts: how many RANSAC runs of this context (and its sequence lanes) started over because a guard tripped, and (optional)
+ * which guards tripped last, as a bit set (1 << r: r = 1 infinite sum, 2 gradient / 3 model-change / 4 parameter / 5 function tolerance within
+ * the band, 6 step quality, 7 tie, 8 list overflow, 9 listed pixels off the tabulated trajectory, 10 count check of the winner's replay). */
+int rsdsfm_set_lm_arithmetic(rsdsfm_ctx* ctx, int mode);
+int rsdsfm_lma_restarts(rsdsfm_ctx* ctx, int64_t* count, int32_t* last_guards_or_null);
 /* The dense depth solve (rsdsfm_estimate_inverse_depths*, LM mode) takes the same in-range cores in launch 0 (Jacobi scaling) under the same
  * switch (rsdsfm_set_ransac_math); a solve whose launch 0 met an argument out of their range is left unfinished by its follow-up
  * launch and rsdsfm_depth_finish_dev -- which every LM-mode caller runs to obtain the summary -- starts it over with the standard

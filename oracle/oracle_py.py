@@ -314,6 +314,43 @@ def score(q, u, alpha, alpha_k, v, w, k, rho, tol):
     return int(cnt), err.value, mask
 
 
+class LmaStats(C.Structure):
+    _fields_ = [
+        ("listed_clamped", C.c_int64),
+        ("listed_near", C.c_int64),
+        ("fallback", C.c_int32),
+        ("fallback_reason", C.c_int32),
+        ("margin_use_max", C.c_double),
+        ("rho_diff_max", C.c_double),
+        ("flips_unguarded", C.c_int64),
+        ("flips_listed", C.c_int64),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def lma_trial(q, u, alpha, alpha_k, v, w, k, tol=-1.0, study=False):
+    """one depth solve on the analytic LM trajectory (mode 2) and, with tol >= 0, its inlier score; study: also the distance to mode 1"""
+    q, u, alpha, alpha_k = _f64(q), _f64(u), _f64(alpha), _f64(alpha_k)
+    n = q.shape[0]
+    rho = np.empty(n)
+    mask = np.zeros(n, dtype=np.uint8)
+    cnt, err = C.c_int64(), C.c_double()
+    sm, st = LmSummary(), LmaStats()
+    rc = lib().rso_lma_trial(_p(q), _p(u), _p(alpha), _p(alpha_k), C.c_int64(n), _v3(v), _v3(w), C.c_double(k), C.c_double(tol), _p(rho), _p(mask),
+                             C.byref(cnt), C.byref(err), C.byref(sm), C.byref(st), int(bool(study)))
+    assert rc == 0
+    return dict(rho=rho, mask=mask, count=int(cnt.value), err=err.value, summary=sm.as_dict(), stats=st.as_dict())
+
+
+def lma_last_stats():
+    """totals over the trials of the last ransac(depth_mode=2)"""
+    st = LmaStats()
+    lib().rso_lma_last_stats(C.byref(st))
+    return st.as_dict()
+
+
 def sample_indices(n, trials, seed):
     out = np.empty(trials * 9, dtype=np.int32)
     lib().rso_sample_indices(C.c_int64(n), C.c_int32(trials), C.c_uint64(seed), _p(out))

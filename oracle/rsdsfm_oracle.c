@@ -802,6 +802,7 @@ int rso_estimate_inverse_depths(const double* q, const double* u, int64_t n, con
     rso_lm_summary sm;
     memset(&sm, 0, sizeof(sm));
     if (n < 0) return -1;
+    if (mode == 2) return rso_lma_trial(q, u, alpha, alpha_k, n, v, w, k, -1.0, rho, NULL, NULL, NULL, summary, NULL, 0);
     if (mode == 0) {
         /* exact optimum of the linear 1-D problem: one undamped Gauss-Newton step from rho = 1 */
         double c0 = 0.0, c1 = 0.0;
@@ -1017,6 +1018,352 @@ int64_t rso_score(const double* q, const double* u, const double* alpha, const d
 }
 
 /* ------------------------------------------------------------------------------------------------ */
+/* ANALYTIC LM TRAJECTORY (mode 2) -- checker of the HIP library's default arithmetic for the dense    */
+/* depth solves (csrc/lma_common.hpp, ransac_lma_kernel, depth_lma_kernel)                              */
+/* ------------------------------------------------------------------------------------------------ */
+/* For a fixed pose the residual of a pixel is linear in its own rho (nonlinearRefinement.cc:36-49):  r(rho) = c + rho J.  With
+ *   h = J.J,  g = J.r(1),  e0 = g / h,  rho* = 1 - e0  (the pixel's optimum),
+ * an LM step at trust-region radius R (Ceres 1.14: diagonal clamp(s^2 h, 1e-6, 1e32) / R, Jacobi scaling s -- which cancels)
+ * multiplies rho - rho* by 1 / (1 + R) for every pixel whose clamp is inactive, so after accepted steps with radii R_1..R_K
+ *   rho_K = rho* + e0 phi_K,   phi_K = prod 1 / (1 + R_i),      |r(rho_K)|^2 = |r(rho*)|^2 + g e0 phi_K^2
+ * and every global quantity the trust-region loop looks at is a closed form of FIVE sums and a maximum:
+ *   A = sum |r(rho*)|^2   B = sum g e0   C = sum e0^2   D = sum rho*^2   E = sum rho* e0   G = max |g|
+ *   cost(phi) = (A + B phi^2) / 2;  a step from phi at radius R (psi = R / (1 + R)):  model change = B phi^2 psi (1 - psi / 2),
+ *   |step|^2 = C phi^2 psi^2,  |x|^2 = D + 2 E phi + C phi^2,  max |gradient| = G phi.
+ * That is the trajectory Ceres walks, iterate for iterate, in ~70 operations per pixel instead of 55 per pixel AND iteration.
+ * It is another arithmetic than the reference's, so three guards keep every INTEGER output (accepted steps, terminations,
+ * inlier masks / counts, winners) equal to mode 1's:
+ *  (a) a pixel whose clamp may be active (h < LMA_H_IRR: s^2 h < 1e-6 -- the pixels within ~1 px of the focus of expansion)
+ *      is left out of the closed form (it enters the sums frozen at rho = 1) and walks mode 1's exact recurrence beside it;
+ *  (b) a pixel whose squared error can come within m = eta tol (2 + |r(1)|^2 + h) / 2 of tol^2 at any iterate is scored from
+ *      mode 1's exact iterate instead (m is > 100 x the largest difference between the two arithmetics ever observed:
+ *      rso_lma_stats::margin_use_max, tests/test_oracle_lma.py);
+ *  (c) a global decision within a relative 1e-6 of its threshold (or a non-finite, non-NaN sum) makes the whole solve fall
+ *      back to mode 1 (rso_lma_stats::fallback; the HIP library runs the RANSAC again on its iterate-by-iterate kernels).
+ * fma() is used where the HIP kernels use it (this arithmetic is the library's own, not the reference's): gcc calls libm's
+ * correctly rounded fma, which is the hardware instruction where the CPU has one. */
+#define LMA_H_IRR 1.01e-6 /* h below which the LM diagonal's lower clamp may bind: s^2 h = h / (1 + sqrt h)^2 = 1e-6 at h = 1.002003e-6 */
+#define LMA_ETA 1e-11     /* guard (b): see above */
+#define LMA_TIE 1e-11     /* guard (d): two trials with the same inlier count whose error sums differ by at most LMA_TIE x count are a tie this arithmetic cannot break the way mode 1 does */
+#define LMA_BAND 1e-6     /* guard (c): relative width of the undecided band around a threshold */
+#define LMA_SQRT_MIN 0x1p-767 /* squared errors below this (incl. 0) count as error 0 in the inlier error SUM (the kernels' in-range sqrt core) */
+
+typedef struct lma_px {
+    double a, ge, e0, rhos, h, g; /* |r(rho*)|^2, g e0, e0, rho*, J.J, J.r(1) (g, e0 = 0 for a clamped pixel) */
+    int clamped;
+} lma_px;
+
+/* csrc/lma_common.hpp lma_pixel(): the SAME operations in the same order */
+static inline void lma_pixel(double x, double y, double ux, double uy, double al, double ak, const double v[3], const double w[3],
+                             double k, double two_over, lma_px* o) {
+    const double beta = two_over * fma(k, ak, al);
+    const double a0 = fma(x, v[2], -v[0]), a1 = fma(y, v[2], -v[1]);
+    const double J0 = beta * a0, J1 = beta * a1;
+    const double xy = x * y, xx1 = fma(x, x, 1.0), yy1 = fma(y, y, 1.0);
+    const double bw0 = fma(xx1, w[1], fma(-xy, w[0], -(y * w[2]))); /* (B w)_0 = -xy w0 + (1 + x^2) w1 - y w2 */
+    const double bw1 = fma(xy, w[1], fma(-yy1, w[0], x * w[2]));    /* (B w)_1 = -(1 + y^2) w0 + xy w1 + x w2 */
+    const double c0 = fma(-beta, bw0, ux), c1 = fma(-beta, bw1, uy); /* r(rho) = c + rho J */
+    const double r0 = c0 + J0, r1 = c1 + J1;
+    const double h = fma(J0, J0, J1 * J1);
+    double g = fma(J0, r0, J1 * r1);
+    const int clamped = h < LMA_H_IRR;
+    double e0 = g / (clamped ? 1.0 : h);
+    if (clamped) g = 0.0, e0 = 0.0;
+    const double rhos = 1.0 - e0;
+    const double s0 = fma(rhos, J0, c0), s1 = fma(rhos, J1, c1);
+    o->a = fma(s0, s0, s1 * s1);
+    o->ge = g * e0;
+    o->e0 = e0;
+    o->rhos = rhos;
+    o->h = h;
+    o->g = g;
+    o->clamped = clamped;
+}
+
+/* guard (b): is the squared error of this pixel at the iterate phi^2 within the margin of tol^2?  (the HIP kernels test every iterate
+ * whose score they fuse, i.e. a superset) */
+static inline double lma_margin(const lma_px* p, double c1) {
+    const double t = (p->a + p->ge) + p->h;
+    return fma(t, c1, 2.0 * c1);
+}
+static inline int lma_near(const lma_px* p, double tol2, double c1, double phi2) {
+    const double d = fma(p->ge, phi2, p->a) - tol2;
+    return fabs(d) <= lma_margin(p, c1);
+}
+
+/* one pixel on mode 1's exact recurrence (the listed pixels of guards (a) and (b)) */
+typedef struct lmx_px {
+    int64_t i;
+    double J[2], s, rho, res[2];
+    double cand, rc[2]; /* candidate of the step in flight */
+} lmx_px;
+
+static void lmx_init(lmx_px* p, int64_t i, const double* q, const double* u, const double* alpha, const double* alpha_k, const double v[3],
+                     const double w[3], double k) {
+    p->i = i;
+    jac_rho(q[2 * i], q[2 * i + 1], alpha[i], alpha_k[i], v, k, p->J);
+    p->s = g_var[RSO_VAR_JACOBI] ? 1.0 : 1.0 / (1.0 + sqrt(RSO_DOT2(p->J[0], p->J[0], p->J[1], p->J[1])));
+    p->rho = 1.0;
+    rso_residual(q[2 * i], q[2 * i + 1], u[2 * i], u[2 * i + 1], alpha[i], alpha_k[i], v, w, k, 1.0, p->res);
+}
+/* the body of mode 1's step loop for one pixel: candidate, its residual, and the pixel's terms of the three sums */
+static void lmx_step(lmx_px* p, const double* q, const double* u, const double* alpha, const double* alpha_k, const double v[3],
+                     const double w[3], double k, double radius, double inv_radius, double* model, double* stepsq, double* ccost2) {
+    const int64_t i = p->i;
+    double jt0 = p->J[0] * p->s, jt1 = p->J[1] * p->s;
+    double ht = RSO_DOT2(jt0, jt0, jt1, jt1);
+    double diag = lm_diag(ht);
+    double gt = RSO_DOT2(jt0, p->res[0], jt1, p->res[1]);
+    double m0, m1, step;
+#if RSO_FUSED
+    step = -(gt / fma(diag, inv_radius, ht));
+    m0 = jt0 * step, m1 = jt1 * step;
+    *model = fma(-m0, fma(m0, 0.5, p->res[0]), fma(-m1, fma(m1, 0.5, p->res[1]), *model));
+    (void)radius;
+#else
+    double lam = lm_dsq(diag, radius, inv_radius);
+    step = -(gt / (ht + lam));
+    m0 = jt0 * step, m1 = jt1 * step;
+    *model -= m0 * (p->res[0] + m0 / 2.0) + m1 * (p->res[1] + m1 / 2.0);
+#endif
+    p->cand = RSO_MAD(step, p->s, p->rho);
+    double dx = p->rho - p->cand;
+    *stepsq = RSO_ACC_SQ(*stepsq, dx);
+    rso_residual(q[2 * i], q[2 * i + 1], u[2 * i], u[2 * i + 1], alpha[i], alpha_k[i], v, w, k, p->cand, p->rc);
+    *ccost2 = RSO_ACC_SQ2(*ccost2, p->rc[0], p->rc[1]);
+}
+static inline double lmx_gabs(const lmx_px* p, const double r[2]) { return fabs(RSO_DOT2(p->J[0], r[0], p->J[1], r[1])); }
+
+/* rho of pixel i after the accepted steps hist[0 .. nh) on mode 1's recurrence (what ransac_final_kernel replays) */
+static double lmx_replay(int64_t i, const double* q, const double* u, const double* alpha, const double* alpha_k, const double v[3],
+                         const double w[3], double k, const double* hist, int nh) {
+    lmx_px p;
+    lmx_init(&p, i, q, u, alpha, alpha_k, v, w, k);
+    for (int hI = 0; hI < nh; ++hI) {
+        double m = 0.0, s2 = 0.0, c2 = 0.0;
+        lmx_step(&p, q, u, alpha, alpha_k, v, w, k, hist[hI], 1.0 / hist[hI], &m, &s2, &c2);
+        p.rho = p.cand;
+        p.res[0] = p.rc[0], p.res[1] = p.rc[1];
+    }
+    return p.rho;
+}
+
+static inline int lma_band(double x, double thr) { return fabs(x - thr) <= LMA_BAND * fabs(thr); } /* (false for NaN) */
+
+int rso_lma_trial(const double* q, const double* u, const double* alpha, const double* alpha_k, int64_t n, const double v[3],
+                  const double w[3], double k, double tol, double* rho_out, uint8_t* mask_out, int64_t* count_out, double* err_out,
+                  rso_lm_summary* summary, rso_lma_stats* stats, int study) {
+    rso_lm_summary sm;
+    rso_lma_stats stt;
+    memset(&sm, 0, sizeof(sm));
+    memset(&stt, 0, sizeof(stt));
+    if (n < 0) return -1;
+    const int scoring = tol >= 0.0; /* (a dense depth solve has nothing to score: guard (b) is off) */
+    const double tol2 = tol * tol, c1 = 0.5 * LMA_ETA * tol;
+    const double two_over = 2.0 / (2.0 + k);
+    lma_px* px = (lma_px*)malloc(sizeof(lma_px) * (n > 0 ? n : 1));
+    lmx_px* cl = NULL; /* the clamped pixels, on the exact recurrence */
+    int64_t ncl = 0, cap = 0;
+    double A = 0.0, B = 0.0, Cs = 0.0, D = 0.0, E = 0.0, G = 0.0;
+    double A_cl = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        lma_px* p = &px[i];
+        lma_pixel(q[2 * i], q[2 * i + 1], u[2 * i], u[2 * i + 1], alpha[i], alpha_k[i], v, w, k, two_over, p);
+        A += p->a;
+        B += p->ge;
+        Cs = fma(p->e0, p->e0, Cs);
+        D = fma(p->rhos, p->rhos, D);
+        E = fma(p->rhos, p->e0, E);
+        const double ga = fabs(p->g);
+        if (ga > G) G = ga;
+        if (p->clamped) {
+            if (ncl == cap) {
+                cap = cap ? 2 * cap : 64;
+                cl = (lmx_px*)realloc(cl, sizeof(lmx_px) * cap);
+            }
+            lmx_init(&cl[ncl++], i, q, u, alpha, alpha_k, v, w, k);
+            A_cl += p->a;
+        }
+    }
+    stt.listed_clamped = ncl;
+    /* the clamped pixels leave the closed form: they entered it frozen at rho = 1 (a = |r(1)|^2, rho* = 1, everything else 0) */
+    const double Ap = A - A_cl, Dp = D - (double)ncl;
+    double XC = 0.0, Xg = 0.0; /* their exact terms at the current state */
+    for (int64_t j = 0; j < ncl; ++j) {
+        XC = RSO_ACC_SQ2(XC, cl[j].res[0], cl[j].res[1]);
+        const double ga = lmx_gabs(&cl[j], cl[j].res);
+        if (ga > Xg) Xg = ga;
+    }
+    double hist[CERES_MAX_ITER];
+    int nh = 0, fallback = 0;
+    double phi = 1.0;
+    double cost = 0.5 * ((Ap + B) + XC), x_norm = sqrt((double)n);
+    double gmax = G > Xg ? G : Xg;
+    double radius = CERES_INITIAL_RADIUS, decrease_factor = 2.0;
+    int iteration = 0, invalid = 0;
+    sm.initial_cost = cost;
+    sm.termination = -1;
+    /* a sum that is infinite (not NaN: a NaN pose / pixel poisons both arithmetics the same way) is not worth reasoning about */
+    if (isinf(A) || isinf(B) || isinf(Cs) || isinf(D) || isinf(E) || isinf(G)) fallback = 1;
+    if (lma_band(gmax, CERES_GRADIENT_TOL)) fallback = 2;
+    if (n == 0 || gmax <= CERES_GRADIENT_TOL) sm.termination = RSO_TERM_GRADIENT;
+    while (sm.termination < 0 && !fallback) {
+        if (iteration >= CERES_MAX_ITER) {
+            sm.termination = RSO_TERM_MAX_ITER;
+            break;
+        }
+        if (radius <= CERES_MIN_RADIUS) {
+            sm.termination = RSO_TERM_MIN_RADIUS;
+            break;
+        }
+        ++iteration;
+        const double ir = 1.0 / radius, psi = 1.0 / (1.0 + ir), phic = phi * (ir * psi);
+        const double p2 = phi * phi, pc2 = phic * phic;
+        double XM = 0.0, XS = 0.0, XCc = 0.0;
+        for (int64_t j = 0; j < ncl; ++j) lmx_step(&cl[j], q, u, alpha, alpha_k, v, w, k, radius, ir, &XM, &XS, &XCc);
+        const double model_change = fma(B * p2, psi * (1.0 - 0.5 * psi), XM);
+        const double stepsq = fma(Cs * p2, psi * psi, XS);
+        if (!(model_change > 0.0)) { /* HandleInvalidStep */
+            if (model_change == model_change) { /* (not NaN) a non-positive model change out of non-negative sums: rounding territory */
+                fallback = 3;
+                break;
+            }
+            ++sm.num_unsuccessful_steps;
+            if (++invalid >= CERES_MAX_INVALID) {
+                sm.termination = RSO_TERM_FAILURE;
+                break;
+            }
+            radius *= 0.5;
+            continue;
+        }
+        if (model_change < 1e-25 * cost) {
+            fallback = 3;
+            break;
+        }
+        invalid = 0;
+        const double step_norm = sqrt(stepsq);
+        const double ptol = CERES_PARAMETER_TOL * (x_norm + CERES_PARAMETER_TOL);
+        if (lma_band(step_norm, ptol)) {
+            fallback = 4;
+            break;
+        }
+        if (step_norm <= ptol) {
+            sm.termination = RSO_TERM_PARAMETER;
+            break;
+        }
+        const double cost_change = 0.5 * fma(B, p2 - pc2, XC - XCc);
+        if (lma_band(fabs(cost_change), CERES_FUNCTION_TOL * cost)) {
+            fallback = 5;
+            break;
+        }
+        if (fabs(cost_change) <= CERES_FUNCTION_TOL * cost) {
+            sm.termination = RSO_TERM_FUNCTION;
+            break;
+        }
+        const double rel = cost_change / model_change;
+        if (!(rel > 0.95)) { /* the model of a quadratic cost is the cost: anything else is not this algorithm's business */
+            fallback = 6;
+            break;
+        }
+        /* HandleSuccessfulStep */
+        hist[nh++] = radius;
+        phi = phic;
+        XC = XCc;
+        Xg = 0.0;
+        for (int64_t j = 0; j < ncl; ++j) {
+            cl[j].rho = cl[j].cand;
+            cl[j].res[0] = cl[j].rc[0], cl[j].res[1] = cl[j].rc[1];
+            const double ga = lmx_gabs(&cl[j], cl[j].res);
+            if (ga > Xg) Xg = ga;
+        }
+        double XX = 0.0;
+        for (int64_t j = 0; j < ncl; ++j) XX = RSO_ACC_SQ(XX, cl[j].rho);
+        cost = 0.5 * (fma(B, pc2, Ap) + XC);
+        x_norm = sqrt(fma(Cs, pc2, fma(2.0 * E, phi, Dp)) + XX);
+        const double gphi = G * phi;
+        gmax = gphi > Xg ? gphi : Xg;
+        radius = radius_accept(radius, rel);
+        decrease_factor = 2.0;
+        ++sm.num_successful_steps;
+        if (lma_band(gmax, CERES_GRADIENT_TOL)) {
+            fallback = 2;
+            break;
+        }
+        if (gmax <= CERES_GRADIENT_TOL) sm.termination = RSO_TERM_GRADIENT;
+    }
+    (void)decrease_factor;
+    if (fallback) {
+        stt.fallback = 1;
+        stt.fallback_reason = fallback;
+        free(px);
+        free(cl);
+        int rc = rso_estimate_inverse_depths(q, u, n, v, w, k, alpha, alpha_k, 1, rho_out, summary);
+        if (rc == 0 && scoring) {
+            double es = 0.0;
+            int64_t cnt = rso_score(q, u, alpha, alpha_k, n, v, w, k, rho_out, tol, mask_out, &es);
+            if (count_out) *count_out = cnt;
+            if (err_out) *err_out = es;
+        }
+        if (stats) *stats = stt;
+        return rc;
+    }
+    sm.num_iterations = iteration;
+    sm.final_cost = cost;
+    sm.final_radius = radius;
+    if (summary) *summary = sm;
+    /* the final iterate, and its score */
+    const double phi2 = phi * phi;
+    int64_t count = 0;
+    double es = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        const lma_px* p = &px[i];
+        const int near = scoring && !p->clamped && lma_near(p, tol2, c1, phi2);
+        double rho = fma(p->e0, phi, p->rhos);
+        int in = 0;
+        double err = 0.0;
+        if (p->clamped || near || study) {
+            const double rx = lmx_replay(i, q, u, alpha, alpha_k, v, w, k, hist, nh);
+            const double ex = point_error(q[2 * i], q[2 * i + 1], u[2 * i], u[2 * i + 1], alpha[i], alpha_k[i], v, w, k, rx);
+            if (p->clamped || near) {
+                rho = rx;
+                err = ex;
+                in = scoring && ex < tol;
+                if (near) ++stt.listed_near;
+                if (study && scoring && !p->clamped && in != (fma(p->ge, phi2, p->a) < tol2)) ++stt.flips_listed;
+            } else { /* study: how far apart are the two arithmetics, in units of the guard's margin? */
+                const double e2 = fma(p->ge, phi2, p->a);
+                const double dr = fabs(rx - rho) / (1.0 + fabs(rx));
+                if (dr > stt.rho_diff_max) stt.rho_diff_max = dr;
+                if (scoring) {
+                    /* the difference of the two errors in units of the margin's scale: the margin is eta tol x that scale, a pixel at
+                     * the threshold differs by 2 tol |e_x - e_a| in the square -> the guard holds while kappa < eta / 2 */
+                    const double kappa = fabs(ex - sqrt(e2)) / (lma_margin(p, c1) / (LMA_ETA * tol));
+                    if (kappa > stt.margin_use_max) stt.margin_use_max = kappa;
+                    if ((ex < tol) != (e2 < tol2)) ++stt.flips_unguarded;
+                }
+            }
+        }
+        if (!(p->clamped || near) && scoring) {
+            const double e2 = fma(p->ge, phi2, p->a);
+            in = e2 < tol2;
+            err = e2 < LMA_SQRT_MIN ? 0.0 : sqrt(e2);
+        }
+        if (rho_out) rho_out[i] = rho;
+        if (mask_out) mask_out[i] = (uint8_t)in;
+        if (in) {
+            ++count;
+            es += err;
+        }
+    }
+    if (count_out) *count_out = count;
+    if (err_out) *err_out = es;
+    if (stats) *stats = stt;
+    free(px);
+    free(cl);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
 /* sampler (minimal.cc:226-244 with rand() -> splitmix64)                                            */
 /* ------------------------------------------------------------------------------------------------ */
 static inline uint64_t splitmix64(uint64_t* state) {
@@ -1044,6 +1391,9 @@ void rso_sample_indices(int64_t n, int32_t trials, uint64_t seed, int32_t* sampl
     free(indices);
 }
 
+static rso_lma_stats g_lma_last; /* totals over the trials of the last rso_ransac in mode 2 */
+void rso_lma_last_stats(rso_lma_stats* out) { *out = g_lma_last; }
+
 /* ------------------------------------------------------------------------------------------------ */
 /* minimal::ransac (minimal.cc:209-306), samples injected                                            */
 /* ------------------------------------------------------------------------------------------------ */
@@ -1051,6 +1401,9 @@ int rso_ransac(const double* q, const double* u, const double* alpha, const doub
                int use_alpha_k, int32_t iterations, double tol, const int32_t* samples, int depth_mode,
                int k_sign_mode, rso_ransac_out* out) {
     if (n < 9 || !samples || !out) return -1;
+    if (depth_mode == 2) memset(&g_lma_last, 0, sizeof(g_lma_last));
+    int64_t* tcnt = (int64_t*)malloc(sizeof(int64_t) * (iterations > 0 ? iterations : 1)); /* (mode 2's tie guard looks at all trials) */
+    double* terr = (double*)malloc(sizeof(double) * (iterations > 0 ? iterations : 1));
     double* inv_depth = (double*)malloc(sizeof(double) * n);
     uint8_t* mask = (uint8_t*)malloc(n);
     int64_t best_count = -1;
@@ -1066,6 +1419,8 @@ int rso_ransac(const double* q, const double* u, const double* alpha, const doub
             if (idx < 0 || idx >= n) {
                 free(inv_depth);
                 free(mask);
+                free(tcnt);
+                free(terr);
                 return -2;
             }
             cq[2 * j] = q[2 * idx];
@@ -1078,9 +1433,20 @@ int rso_ransac(const double* q, const double* u, const double* alpha, const doub
         double w[3], v[3], k;
         rso_calculate_velocities(cq, cu, ca, cak, use_alpha_k, k_sign_mode, w, v, &k);
         rso_lm_summary sm;
-        rso_estimate_inverse_depths(q, u, n, v, w, k, alpha, alpha_k, depth_mode, inv_depth, &sm);
         double err = 0.0;
-        int64_t count = rso_score(q, u, alpha, alpha_k, n, v, w, k, inv_depth, tol, mask, &err);
+        int64_t count = 0;
+        if (depth_mode == 2) { /* analytic trajectory: depth solve and score in one (rso_lma_trial) */
+            rso_lma_stats st;
+            rso_lma_trial(q, u, alpha, alpha_k, n, v, w, k, tol, inv_depth, mask, &count, &err, &sm, &st, 0);
+            g_lma_last.listed_clamped += st.listed_clamped;
+            g_lma_last.listed_near += st.listed_near;
+            g_lma_last.fallback += st.fallback;
+            if (st.fallback) g_lma_last.fallback_reason = st.fallback_reason;
+        } else {
+            rso_estimate_inverse_depths(q, u, n, v, w, k, alpha, alpha_k, depth_mode, inv_depth, &sm);
+            count = rso_score(q, u, alpha, alpha_k, n, v, w, k, inv_depth, tol, mask, &err);
+        }
+        tcnt[t] = count, terr[t] = err;
         if (out->trial_count) out->trial_count[t] = count;
         if (out->trial_err) out->trial_err[t] = err;
         if (out->trial_vel) {
@@ -1105,6 +1471,37 @@ int rso_ransac(const double* q, const double* u, const double* alpha, const doub
         memset(out->mask, 0, n);
         memset(out->inv_depth, 0, sizeof(double) * n);
     }
+    if (depth_mode == 2 && out->best_trial >= 0 && best_count > 0) {
+        /* guard (d): minimal.cc:278-285 breaks a tie in the inlier count by the sum of the inlier errors.  On noise-free data (ground-truth
+         * flow) every good hypothesis has every pixel as an inlier and an error sum that IS rounding noise: which trial wins is decided by the
+         * last bits of the reference's arithmetic, which no other arithmetic can reproduce -- such a RANSAC is run in mode 1 */
+        for (int32_t t = 0; t < iterations; ++t)
+            if (t != out->best_trial && tcnt[t] == best_count && fabs(terr[t] - best_err) <= LMA_TIE * (double)best_count) {
+                free(inv_depth);
+                free(mask);
+                free(tcnt);
+                free(terr);
+                int rc = rso_ransac(q, u, alpha, alpha_k, n, use_alpha_k, iterations, tol, samples, 1, k_sign_mode, out);
+                g_lma_last.fallback += 1;
+                g_lma_last.fallback_reason = 7;
+                return rc;
+            }
+    }
+    if (depth_mode == 2 && out->best_trial >= 0) {
+        /* the HIP library's final stage replays the winner on the reference's recurrence (ransac_final_kernel): its dense rho is
+         * mode 1's, and its mask must be the one the analytic score counted -- the guards' claim, checked on every run */
+        rso_lm_summary sm;
+        rso_estimate_inverse_depths(q, u, n, out->v, out->w, out->k, alpha, alpha_k, 1, out->inv_depth, &sm);
+        double e1 = 0.0;
+        int64_t c1 = rso_score(q, u, alpha, alpha_k, n, out->v, out->w, out->k, out->inv_depth, tol, mask, &e1);
+        if (c1 != best_count || memcmp(mask, out->mask, n) != 0) {
+            free(inv_depth);
+            free(mask);
+            free(tcnt);
+            free(terr);
+            return -3;
+        }
+    }
     int64_t j = 0;
     for (int64_t i = 0; i < n; ++i) {
         if (out->mask[i]) {
@@ -1121,6 +1518,8 @@ int rso_ransac(const double* q, const double* u, const double* alpha, const doub
     out->inlier_error = best_err;
     free(inv_depth);
     free(mask);
+    free(tcnt);
+    free(terr);
     return 0;
 }
 

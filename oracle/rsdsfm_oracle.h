@@ -63,11 +63,34 @@ void rso_residual(double x, double y, double ux, double uy, double alpha, double
                   const double v[3], const double w[3], double k, double rho, double r[2]);
 
 /* nonlinearRefinement.cc:109-180.  mode 0: exact per-pixel least-squares optimum (one undamped
- * Gauss-Newton step from rho=1); mode 1: emulation of the Ceres 1.14 trust-region LM the reference runs. */
+ * Gauss-Newton step from rho=1); mode 1: emulation of the Ceres 1.14 trust-region LM the reference runs;
+ * mode 2: the same trust-region loop on the closed-form trajectory (rso_lma_trial below). */
 int rso_estimate_inverse_depths(const double* q2n, const double* u2n, int64_t n, const double v[3],
                                 const double w[3], double k, const double* alpha_n,
                                 const double* alpha_k_n, int mode, double* inv_depth_n,
                                 rso_lm_summary* summary);
+
+/* ---- mode 2: the ANALYTIC LM TRAJECTORY, checker of the HIP library's default arithmetic for the dense depth solves --------------
+ * (see the comment block in rsdsfm_oracle.c).  rso_estimate_inverse_depths(mode 2) and rso_ransac(depth_mode 2) go through
+ * rso_lma_trial: one depth solve on the closed-form trajectory and, with tol >= 0, its inlier score {count, sum of inlier errors,
+ * mask}; tol < 0: no scoring.  A solve whose guards trip is computed by mode 1 (stats->fallback).  study != 0 also runs mode 1's
+ * exact recurrence for EVERY pixel and reports how far the two arithmetics are apart (test infrastructure of the guards). */
+typedef struct rso_lma_stats {
+    int64_t listed_clamped;   /* pixels on the exact recurrence because the LM diagonal's clamp may bind (guard a)            */
+    int64_t listed_near;      /* pixels scored from the exact iterate because their error is within the margin of tol (guard b) */
+    int32_t fallback;         /* (count of) solves a global guard sent to mode 1 (guard c)                                   */
+    int32_t fallback_reason;  /* 1 infinite sum, 2 gradient, 3 model change, 4 parameter, 5 function tolerance, 6 step quality, 7 (rso_ransac) a tie in count and error sum */
+    double margin_use_max;    /* study: kappa = max |e_exact - e_analytic| / ((2 + |r(1)|^2 + h) / 2) over the unlisted pixels; guard (b) holds while kappa < eta / 2 */
+    double rho_diff_max;      /* study: max |rho_exact - rho_analytic| / (1 + |rho|)                                          */
+    int64_t flips_unguarded;  /* study: unlisted pixels whose inlier decision differs between the arithmetics (must be 0)    */
+    int64_t flips_listed;     /* study: listed pixels whose analytic decision would have differed (what the guard caught)    */
+} rso_lma_stats;
+int rso_lma_trial(const double* q2n, const double* u2n, const double* alpha_n, const double* alpha_k_n, int64_t n,
+                  const double v[3], const double w[3], double k, double tol, double* inv_depth_n_or_null,
+                  uint8_t* mask_n_or_null, int64_t* count_or_null, double* err_sum_or_null, rso_lm_summary* summary_or_null,
+                  rso_lma_stats* stats_or_null, int study);
+/* totals over the trials of the last rso_ransac(depth_mode 2) */
+void rso_lma_last_stats(rso_lma_stats* out);
 
 /* minimal.cc:255-275: per-point residual norm, inlier flag; returns count, *err_sum = sum over inliers. */
 int64_t rso_score(const double* q2n, const double* u2n, const double* alpha_n, const double* alpha_k_n,

@@ -259,6 +259,17 @@ class Solver:
         of range, 1 = always the standard functions (rsdsfm_set_ransac_math); never a result"""
         self._check(self.lib.rsdsfm_set_ransac_math(self._ctx, int(mode)), "rsdsfm_set_ransac_math")
 
+    def set_lm_arithmetic(self, mode):
+        """arithmetic of the depth solves inside a RANSAC: 0 = analytic LM trajectory with guards (default), 1 = iterate by iterate
+        (rsdsfm_set_lm_arithmetic); integer outputs never depend on it"""
+        self._check(self.lib.rsdsfm_set_lm_arithmetic(self._ctx, int(mode)), "rsdsfm_set_lm_arithmetic")
+
+    def lma_restarts(self):
+        """(RANSAC runs of this context that started over because a guard of the analytic trajectory tripped, bit set of the last guards)"""
+        n, g = C.c_int64(0), C.c_int32(0)
+        self._check(self.lib.rsdsfm_lma_restarts(self._ctx, C.byref(n), C.byref(g)), "rsdsfm_lma_restarts")
+        return int(n.value), int(g.value)
+
     def ransac_restarts(self):
         """RANSAC runs of this context that started over with the standard functions (rsdsfm_ransac_restarts)"""
         n = C.c_int64()

@@ -272,6 +272,26 @@ int rsdsfm_ransac_restarts(rsdsfm_ctx* ctx, int64_t* count) {
     return RSDSFM_OK;
 }
 
+int rsdsfm_set_lm_arithmetic(rsdsfm_ctx* ctx, int mode) {
+    CTX_OR_FAIL(ctx);
+    if (mode < 0 || mode > 1) return fail(c, RSDSFM_ERR_INVALID, "LM arithmetic: 0 = analytic trajectory with guards (default), 1 = iterate by iterate");
+    c->lm_arithmetic = mode;
+    c->lma_hold = 0;
+    for (rsdsfm_ctx* lane : c->lanes) lane->c.lm_arithmetic = mode, lane->c.lma_hold = 0;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_lma_restarts(rsdsfm_ctx* ctx, int64_t* count, int32_t* last_guards) {
+    CTX_OR_FAIL(ctx);
+    if (!count) return fail(c, RSDSFM_ERR_INVALID, "lma restarts: null output");
+    int64_t total = c->lma_restarts;
+    int guards = c->lma_last_guard;
+    for (rsdsfm_ctx* lane : c->lanes) total += lane->c.lma_restarts, guards |= lane->c.lma_last_guard;
+    *count = total;
+    if (last_guards) *last_guards = guards;
+    return RSDSFM_OK;
+}
+
 int rsdsfm_depth_restarts(rsdsfm_ctx* ctx, int64_t* count) {
     CTX_OR_FAIL(ctx);
     if (!count) return fail(c, RSDSFM_ERR_INVALID, "depth restarts: null output");

@@ -11,6 +11,8 @@ namespace rsdsfm {
 
 namespace {
 
+constexpr double kLmaTieMargin = 1e-11;  // = kLmaTie (lma_common.hpp, guard d)
+
 inline uint64_t splitmix64(uint64_t& state) {
     uint64_t z = (state += 0x9E3779B97F4A7C15ULL);
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
@@ -105,6 +107,20 @@ namespace {
 
 enum RansacPc { kPcStart = 0, kPcBatchBegin, kPcRoundEnqueue, kPcRoundWait, kPcAfterRounds, kPcScore, kPcFinal, kPcFinalWait, kPcDone };
 
+// a guard of the analytic pass tripped: the depth solves of the run start over on the iterate-by-iterate kernels, from the hypotheses
+int lma_start_over(Ctx* c, RansacRun& R, int guards) {
+    R.analytic = false;
+    R.lma_restarted = true;
+    R.lma_guard |= guards;
+    R.tie_margin = -kLmaTieMargin;  // (from here on a tie is only reported)
+    R.not_one_step = 0;
+    R.final_done = R.spec_scored = R.tail_enqueued = R.spec_final = false;
+    RSDSFM_HIP_CHECK(c, hipMemsetAsync(R.zero_begin, 0, R.zero_bytes, c->stream));  // states, scored, flags, list counters
+    R.b0 = 0;
+    R.pc = kPcBatchBegin;
+    return RSDSFM_OK;
+}
+
 // runs the state machine; with yield_at_wait it returns (RSDSFM_OK, R.pc != kPcDone) in front of the first host wait
 int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
     rsdsfm_ransac_out* out = R.out;
@@ -154,7 +170,8 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                 R.B = std::min(batch, T - R.b0);
                 R.need_score = true;
                 if (depth_mode == RSDSFM_DEPTH_CERES_LM) {
-                    if (R.b0 > 0) RSDSFM_HIP_CHECK(c, hipMemsetAsync(R.d_flags, 0, sizeof(int) * 8, c->stream));  // batch 0: cleared above
+                    if (R.b0 > 0)  // batch 0: cleared above (the flag words and the analytic pass's list counters are adjacent)
+                        RSDSFM_HIP_CHECK(c, hipMemsetAsync(R.d_flags, 0, (size_t)(reinterpret_cast<char*>(R.d_irr_count + R.batch) - reinterpret_cast<char*>(R.d_flags)), c->stream));
                     R.round = 0;
                     R.pc = kPcRoundEnqueue;
                 } else {
@@ -166,9 +183,18 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                 const int b0 = R.b0, B = R.B, round = R.round;
                 bool flags_via_pick = false;  // this round's flag words reach the host with the speculated pick kernel
                 if (round > 4 * kMaxIter) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machines did not terminate");
-                rc = ransac_lm_round_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_hyp + (size_t)b0 * 8, B, R.d_states + b0, R.d_partials, R.d_flags,
-                                            R.d_scored + b0, R.d_tcount + b0, R.d_terr + b0, round, tol, R.k0, R.fused_base, R.core_math,
-                                            R.core_epoch ? c->d_core_flag : nullptr, R.core_epoch, R.d_unscored);
+                if (R.analytic) {
+                    // the B depth solves on the analytic LM trajectory (ransac_lma_kernels.hip): one pixel pass + one decide launch, never a
+                    // second round; hypotheses that end where no score was fused go to the scoring pass like round 0's
+                    if (round != 0) return fail(c, RSDSFM_ERR_NUMERIC, "analytic LM pass asked for a second round");
+                    rc = ransac_lma_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_hyp + (size_t)b0 * 8, B, R.d_states + b0, R.d_partials, R.d_flags,
+                                           R.d_scored + b0, R.d_tcount + b0, R.d_terr + b0, tol, R.lma_cand, 2, R.d_irr_count, R.d_irr_list, R.d_unscored,
+                                           nullptr, R.core_epoch ? c->d_core_flag : nullptr, R.core_epoch);
+                } else {
+                    rc = ransac_lm_round_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_hyp + (size_t)b0 * 8, B, R.d_states + b0, R.d_partials, R.d_flags,
+                                                R.d_scored + b0, R.d_tcount + b0, R.d_terr + b0, round, tol, R.k0, R.fused_base, R.core_math,
+                                                R.core_epoch ? c->d_core_flag : nullptr, R.core_epoch, R.d_unscored);
+                }
                 if (rc != RSDSFM_OK) return rc;
                 if (round == 0 && B == T) {
                     // one batch, and on typical data every hypothesis is decided and scored by round 0: the final stage
@@ -184,7 +210,8 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                         if (rc != RSDSFM_OK) return rc;
                         R.spec_scored = true;
                     }
-                    rc = ransac_pick_launch(c, R.d_tcount, R.d_terr, T, R.d_hyp, R.d_best, R.h_best, R.d_flags, R.h_running, R.spec_scored ? 1 : 0);  // (+ the flag words)
+                    rc = ransac_pick_launch(c, R.d_tcount, R.d_terr, T, R.d_hyp, R.d_best, R.h_best, R.d_flags, R.h_running, R.spec_scored ? 1 : 0,  // (+ the flag words)
+                                            nullptr, 0, 0, nullptr, R.tie_margin);
                     if (rc != RSDSFM_OK) return rc;
                     flags_via_pick = true;
                     rc = ransac_final_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_best, R.d_states, depth_mode, tol, R.d_rho, R.d_mask, R.d_bcounts,
@@ -207,7 +234,15 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                 yield_at_wait = false;  // (a run yields once: after its first wait the caller is blocked in it anyway)
                 RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
                 const int* h_running = R.h_running;
-                if (R.round == 0 && R.core_math && h_running[3] != 0) {
+                if (R.round == 0 && R.analytic && (h_running[3] & 6) != 0 && !((h_running[3] & 1) && R.core_math)) {
+                    // the analytic pass: a guard tripped (bit 1; which: bits 8..) or the speculated pick met a tie it must not break (bit 2):
+                    // the depth solves start over on the iterate-by-iterate kernels, from the hypotheses (which are fine).  What was
+                    // enqueued behind on speculation has left at once (the pick marks such a run undecided).
+                    rc = lma_start_over(c, R, (h_running[3] >> 8) | ((h_running[3] & 4) ? (1 << 7) : 0));
+                    if (rc != RSDSFM_OK) return rc;
+                    break;
+                }
+                if (R.round == 0 && R.core_math && (h_running[3] & 1) != 0) {
                     // round 0 met an argument outside the range of its in-range function cores (ransac_lm_kernel CORE: a zero Jacobian,
                     // a zero or non-finite error -- not on real data): its sums may differ from the standard functions', so the LM rounds
                     // start over from the hypotheses with the standard functions.  What was enqueued behind on speculation has left at
@@ -228,6 +263,14 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                         for (int a2 = 1; a2 <= 3; ++a2)
                             if (h_running[4 + a2] > (best ? h_running[4 + best] : 0)) best = a2;
                         if (best) R.fused_base_next = best;
+                        // (analytic pass: the two iterates where most hypotheses ended; the second defaults to the neighbour below / above)
+                        int second = 0;
+                        for (int a2 = 1; a2 <= 3; ++a2)
+                            if (a2 != best && h_running[4 + a2] > (second ? h_running[4 + second] : 0)) second = a2;
+                        if (best) {
+                            R.lma_cand_next[0] = best;
+                            R.lma_cand_next[1] = second ? second : (best > 1 ? best - 1 : 2);
+                        }
                     }
                 }
                 if (h_running[0] == 0) {
@@ -263,7 +306,7 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                 if (!R.final_done) {
                     R.tail_enqueued = false;  // the speculated final stage (and whatever was enqueued behind it) saw incomplete trials
                     R.spec_final = false;
-                    rc = ransac_pick_launch(c, R.d_tcount, R.d_terr, T, R.d_hyp, R.d_best, R.h_best);  // h_best: host-mapped, written by the kernels
+                    rc = ransac_pick_launch(c, R.d_tcount, R.d_terr, T, R.d_hyp, R.d_best, R.h_best, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, R.tie_margin);  // h_best: host-mapped, written by the kernels
                     if (rc != RSDSFM_OK) return rc;
                     rc = ransac_final_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_best, R.d_states, depth_mode, tol, R.d_rho, R.d_mask, R.d_bcounts,
                                              R.d_boffs, out->inlier_idx, out->inliers, out->alpha, out->alpha_k, R.h_best);
@@ -289,7 +332,22 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
             case kPcFinalWait: {
                 RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
                 const RansacBest* h_best = R.h_best;
-                if (h_best->num_inliers != h_best->num_inliers_scan) return fail(c, RSDSFM_ERR_NUMERIC, "inlier count mismatch between scoring and compaction");
+                if (R.analytic && h_best->lma_tie) {  // guard (d) at the definitive pick (everything behind it has left at once)
+                    rc = lma_start_over(c, R, 1 << 7);
+                    if (rc != RSDSFM_OK) return rc;
+                    break;
+                }
+                R.lma_tie_seen = h_best->lma_tie != 0;
+                if (h_best->num_inliers != h_best->num_inliers_scan) {
+                    // analytic pass: the winner's mask comes from the reference's exact replay (ransac_final_kernel) and must count what the
+                    // closed form counted -- the guards' claim, checked on every run.  A difference is not an error of the data: start over.
+                    if (R.analytic) {
+                        rc = lma_start_over(c, R, 1 << 10);
+                        if (rc != RSDSFM_OK) return rc;
+                        break;
+                    }
+                    return fail(c, RSDSFM_ERR_NUMERIC, "inlier count mismatch between scoring and compaction");
+                }
                 out->num_inliers = h_best->num_inliers;
                 out->best_trial = h_best->best_trial;
                 memcpy(out->w, &h_best->hyp[0], 3 * sizeof(double));
@@ -324,6 +382,15 @@ void ransac_commit_hints(Ctx* c, const RansacRun& R) {
     if (R.score_hint_next >= 0) c->ransac_score_idle = R.score_hint_next ? 0 : std::min(c->ransac_score_idle + 1, kScoreIdleLimit);
     c->ransac_not_one_step = R.not_one_step;
     c->ransac_spec_miss = R.spec_final ? 0 : std::min(c->ransac_spec_miss + 1, 2);
+    if (R.lma_cand_next[0]) c->lma_cand[0] = R.lma_cand_next[0], c->lma_cand[1] = R.lma_cand_next[1];
+    if (R.lma_restarted) {  // a guard tripped: this kind of data stays on the iterate-by-iterate kernels for a while
+        c->lma_hold = 16;
+        c->lma_restarts += 1;
+        c->lma_last_guard = R.lma_guard;
+    } else if (c->lma_hold > 0 && !R.analytic) {
+        // an iterate-by-iterate run inside a hold: it goes on while the data keeps showing ties the analytic arithmetic cannot break
+        c->lma_hold = R.lma_tie_seen ? 16 : c->lma_hold - 1;
+    }
     if (R.restarted) {
         c->ransac_standard_math = 16;
         c->ransac_restarts += 1;
@@ -340,6 +407,11 @@ int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a
     R = RansacRun();
     R.tail_ahead = tail_ahead;
     R.core_math = c->ransac_math_mode == 0 && c->ransac_standard_math == 0;
+    R.analytic = depth_mode == RSDSFM_DEPTH_CERES_LM && T > 0 && c->lm_arithmetic == 0 && c->lma_hold == 0;
+    // guard (d): the analytic pass must not break a tie (+); an iterate-by-iterate run of a context that may go back to the analytic pass
+    // reports such ties (-: they renew the hold)
+    R.tie_margin = depth_mode != RSDSFM_DEPTH_CERES_LM || c->lm_arithmetic != 0 ? 0.0 : (R.analytic ? kLmaTieMargin : -kLmaTieMargin);
+    R.lma_cand[0] = c->lma_cand[0], R.lma_cand[1] = c->lma_cand[1];
     if (spec_tail_held) *spec_tail_held = false;
     if (!out) return fail(c, RSDSFM_ERR_INVALID, "null out");
     if (n < 9) return fail(c, RSDSFM_ERR_INVALID, "ransac needs at least 9 points (the reference would compute rand() % 0)");
@@ -357,8 +429,9 @@ int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a
     }
     const int Tn = std::max(T, 1);
     const int batch = std::min(Tn, kRansacBatch);
-    size_t need = Arena::need(sizeof(double) * Tn * 8) +
-                  Arena::need(sizeof(LmState) * Tn) + Arena::need(sizeof(double) * (size_t)ransac_lm_partials_doubles(c, n, batch)) +
+    const size_t partials_doubles = std::max<size_t>((size_t)ransac_lm_partials_doubles(c, n, batch), (size_t)ransac_lma_partials_doubles(c, n, batch));
+    size_t need = Arena::need(sizeof(double) * Tn * 8) + Arena::need(sizeof(int) * batch) + Arena::need(sizeof(int) * ransac_lma_list_ints(batch)) +
+                  Arena::need(sizeof(LmState) * Tn) + Arena::need(sizeof(double) * partials_doubles) +
                   Arena::need(sizeof(int) * 8) + 2 * Arena::need(sizeof(int) * Tn) + 2 * Arena::need(sizeof(double) * Tn) + Arena::need(sizeof(RansacBest)) +
                   2 * Arena::need(sizeof(int64_t) * 2048) + Arena::need(sizeof(double) * (size_t)n) + Arena::need((size_t)n) + 4096;
     int rc = ensure_ws(c, need);
@@ -369,10 +442,12 @@ int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a
     R.zero_begin = ws.base + ws.off;
     R.d_states = ws.take<LmState>(Tn);
     R.d_scored = ws.take<int>(Tn);
-    R.d_flags = ws.take<int>(8);  // {running, unscored, not finished with <= 1 accepted step, -, ended after 0 / 1 / 2 / >= 3 accepted steps}
+    R.d_flags = ws.take<int>(8);  // {running, unscored, not finished with <= 1 accepted step, restart bits, ended after 0 / 1 / 2 / >= 3 accepted steps}
+    R.d_irr_count = ws.take<int>(batch);  // analytic pass: listed pixels per hypothesis of the batch
     R.zero_bytes = (size_t)((ws.base + ws.off) - R.zero_begin);
+    R.d_irr_list = ws.take<int>(ransac_lma_list_ints(batch));
     R.d_unscored = ws.take<int>(batch);
-    R.d_partials = ws.take<double>((size_t)ransac_lm_partials_doubles(c, n, batch));
+    R.d_partials = ws.take<double>(partials_doubles);
     R.d_tcount = ws.take<double>(Tn);
     R.d_terr = ws.take<double>(Tn);
     R.d_best = ws.take<RansacBest>(1);

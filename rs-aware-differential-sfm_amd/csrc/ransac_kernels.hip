@@ -759,21 +759,37 @@ __global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restric
                                                         const double* __restrict__ hyp, RansacBest* best, RansacBest* best_host,
                                                         const int* __restrict__ flags, int* __restrict__ flags_host, int scored_ahead,
                                                         const double* __restrict__ cnt_rt = nullptr, int cnt_stride = 0, int nranks = 0,
-                                                        int64_t* __restrict__ m_all = nullptr) {
+                                                        int64_t* __restrict__ m_all = nullptr, double tie_margin = 0.0) {
     if (blockIdx.x != 0) return;
     const int lane = threadIdx.x;
-    // the round's flag words (final since ransac_decide_kernel) travel to host-mapped memory with this launch: no copy behind the stage
-    if (flags_host && lane < 8) flags_host[lane] = flags[lane];
     // With flags this pick runs on speculation (behind round 0, before the host has seen them).  If hypotheses are still running, or
     // ended where round 0 did not score them and no scoring pass was enqueued ahead, the trial scores are incomplete -- the host's own
     // test in ransac_advance -- and the final stage and the caller's work behind it (the refinement) leave at once instead of running
     // on a winner that does not count: ~250 us of kernels the host would otherwise wait for before it can enqueue the next LM round.
     // (flags[3]: round 0 met an argument outside the range of its in-range function cores -- ransac_lm_kernel's CORE --: the host runs the
     // whole RANSAC again)
-    const int undecided = (flags && (flags[0] != 0 || (flags[1] > 0 && !scored_ahead) || flags[3] != 0)) ? 1 : 0;
+    int undecided = (flags && (flags[0] != 0 || (flags[1] > 0 && !scored_ahead) || flags[3] != 0)) ? 1 : 0;
     double best_count, best_err;
     int bi;
     pick_best_trial(trial_count, trial_err, T, lane, bi, best_count, best_err);
+    // analytic LM trajectory, guard (d) (lma_common.hpp): minimal.cc:278-285 breaks a tie in the inlier count by the SUM of the inlier errors.
+    // Where another trial has the winner's count and an error sum within tie_margin x count of the winner's (noise-free data: every good
+    // hypothesis explains every pixel and the sums are rounding noise) the reference's winner is decided by the last bits of ITS arithmetic:
+    // the result does not count and the host runs the RANSAC again on the iterate-by-iterate kernels.
+    // (tie_margin < 0: only reported in RansacBest::lma_tie -- an iterate-by-iterate run telling the context what kind of data it is on)
+    int tie = 0;
+    if (tie_margin != 0.0 && bi >= 0 && best_count > 0.0) {
+        const double tm = fabs(tie_margin);
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + lane;
+            const bool hit = t < T && t != bi && trial_count[t] == best_count && fabs(trial_err[t] - best_err) <= tm * best_count;
+            if (__builtin_amdgcn_ballot_w64(hit) != 0) tie = 1;
+        }
+    }
+    if (tie_margin > 0.0) undecided |= tie;
+    // the round's flag words (final since ransac_decide_kernel) travel to host-mapped memory with this launch: no copy behind the stage
+    // ([3] bit 2: the tie)
+    if (flags_host && lane < 8) flags_host[lane] = flags[lane] | ((lane == 3 && tie && tie_margin > 0.0) ? 4 : 0);
     // column-tiled solve: the inlier counts of ALL slabs for the winner, from the shares the decide / merge stages kept
     if (m_all)
         for (int r = lane; r < nranks; r += 64) m_all[r] = bi >= 0 ? (int64_t)cnt_rt[(int64_t)r * cnt_stride + bi] : 0;
@@ -783,11 +799,13 @@ __global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restric
     if (lane == 0) {
         best->best_trial = bi;
         best->undecided = undecided;
+        best->lma_tie = tie;
         best->num_inliers = bi >= 0 ? (int64_t)best_count : 0;
         best->inlier_error = best_err;
         if (best_host) {
             best_host->best_trial = bi;
             best_host->undecided = undecided;
+            best_host->lma_tie = tie;
             best_host->num_inliers = bi >= 0 ? (int64_t)best_count : 0;
             best_host->inlier_error = best_err;
         }
@@ -1130,9 +1148,9 @@ int ransac_rows_doubles() { return NSR; }
 
 int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best,
                        RansacBest* best_host, const int* d_flags, int* h_flags, int scored_ahead, const double* cnt_rt, int cnt_stride,
-                       int nranks, int64_t* m_all) {
+                       int nranks, int64_t* m_all, double tie_margin) {
     hipLaunchKernelGGL(ransac_pick_kernel, dim3(1), dim3(64), 0, c->stream, trial_count, trial_err, T, hyp, best, best_host, d_flags, h_flags, scored_ahead,
-                       cnt_rt, cnt_stride, nranks, m_all);
+                       cnt_rt, cnt_stride, nranks, m_all, tie_margin);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -83,6 +83,8 @@ struct RansacBest {
     int64_t num_inliers_scan;  // total of the compaction scan (must agree)
     double inlier_error;
     double hyp[8];  // w(3), v(3), k, status of the best trial
+    int32_t lma_tie;  // analytic LM trajectory, guard (d): another trial has the winner's inlier count and an error sum within kLmaTie x count of the winner's (set by a pick launched with a tie margin; such a result is also `undecided`)
+    int32_t _pad_tie;
 };
 
 // The scoring pass behind round 0 is enqueued ahead of the host's flag read while one of the context's last kScoreIdleLimit solves needed
@@ -112,6 +114,13 @@ struct Ctx {
     int core_epoch = 0;
     int ransac_math_mode = 0;      // rsdsfm_set_ransac_math: 0 = in-range cores with restart (default), 1 = always the standard functions
     int64_t ransac_restarts = 0;   // RANSAC runs of this context that started over for that reason (rsdsfm_ransac_restarts)
+    // the T depth solves of a RANSAC on the analytic LM trajectory (lma_common.hpp, ransac_lma_kernels.hip): the default; a run whose guards
+    // trip starts over on the iterate-by-iterate kernels (ransac_kernels.hip), and the context then stays on those for its next lma_hold solves
+    int lm_arithmetic = 0;         // rsdsfm_set_lm_arithmetic: 0 = analytic trajectory with guards (default), 1 = always iterate by iterate
+    int lma_hold = 0;              // > 0: that many of the context's next RANSACs run iterate by iterate (set to 16 by a run whose guards tripped; renewed by an iterate-by-iterate run that ends in a tie the analytic arithmetic could not break: noise-free data)
+    int64_t lma_restarts = 0;      // RANSAC runs of this context that started over because a guard tripped (rsdsfm_lma_restarts)
+    int lma_last_guard = 0;        // bit set of the guards that tripped last (1 << reason: lma_common.hpp; 1 << 7: tie)
+    int lma_cand[2] = {2, 1};      // the two iterates (accepted steps) whose scores the next pixel pass fuses: where most hypotheses of the previous solve ended
     int ransac_spec_miss = 0;  // consecutive RANSACs (saturating at 2) whose speculated final stage did not count; below 2 the frame solve enqueues the refinement behind the speculated stage
     int frame_dense_hint = 1;  // frame solve: the previous frame kept every pixel (dense flow) -> set the RANSAC up for n = rows * cols without waiting for the count
     int lm_issued_d = 0;           // depth_lm_decide_kernel launches issued for the current solve
@@ -326,7 +335,7 @@ int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* 
                         double* partials, double* trial_count, double* trial_err, const int* unscored_list = nullptr, const int* unscored_count = nullptr);
 int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best,
                        RansacBest* best_host = nullptr, const int* d_flags = nullptr, int* h_flags = nullptr, int scored_ahead = 0,
-                       const double* cnt_rt = nullptr, int cnt_stride = 0, int nranks = 0, int64_t* m_all = nullptr);
+                       const double* cnt_rt = nullptr, int cnt_stride = 0, int nranks = 0, int64_t* m_all = nullptr, double tie_margin = 0.0);
 int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         RansacBest* best, const LmState* states, int depth_mode, double tol, double* rho, uint8_t* mask,
                         int64_t* block_counts, int64_t* block_offsets, int64_t* inlier_idx, double* inliers,
@@ -346,6 +355,19 @@ int ransac_score_rows_launch(Ctx* c, const double* q, const double* u, const dou
 int ransac_score_merge_launch(Ctx* c, const double* rows_all, int nranks, int T, const int* scored, double* trial_count,
                               double* trial_err, double* cnt_rt = nullptr, int cnt_stride = 0);
 void sample_indices(int64_t n, int T, uint64_t seed, int32_t* out);
+// ransac_lma_kernels.hip: the depth solves of a hypothesis batch on the analytic LM trajectory
+int64_t ransac_lma_partials_doubles(const Ctx* c, int64_t n, int batch);
+size_t ransac_lma_list_ints(int batch);
+int ransac_lma_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n, const double* hyp, int T,
+                      LmState* states, double* partials, int* flags, int* scored, double* trial_count, double* trial_err, double tol,
+                      const int* cand_steps, int ncand, int* irr_count, int* irr_list, int* unscored_list, int* guard_word,
+                      const int* m9_core_flag = nullptr, int m9_core_epoch = 0);
+int ransac_lma_rows_doubles();
+int ransac_lma_rows_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n, const double* hyp, int T,
+                           double* partials, double tol, const int* cand_steps, int ncand, int* irr_count, int* irr_list, double* rows);
+int ransac_lma_decide_rows_launch(Ctx* c, const double* rows_all, int nranks, int64_t rank_stride, int T, int64_t n_total, const double* hyp,
+                                  LmState* states, int* flags, int* scored, double* trial_count, double* trial_err, double tol, const int* cand_steps,
+                                  int ncand, int* unscored_list, int* guard_word, double* cnt_rt, int cnt_stride);
 }  // namespace rsdsfm
 
 namespace rsdsfm {
@@ -412,6 +434,13 @@ struct RansacRun {
     int core_epoch = 0;      // the minimal solver's launch epoch of this run (0: it ran without the cores)
     int* d_unscored = nullptr;  // [batch] indices (within the batch) of the hypotheses that finished without a fused score, in order of arrival; their number is d_flags[1]
     bool core_math = true;   // round 0 through the in-range function cores (ransac_lm_kernel CORE); false after a restart
+    bool analytic = false;   // the depth solves on the analytic LM trajectory (ransac_lma_kernels.hip); false after a guard tripped
+    bool lma_restarted = false;
+    double tie_margin = 0.0;  // what the picks are launched with (ransac_pick_kernel)
+    int lma_guard = 0;       // guards that tripped (bit set)
+    bool lma_tie_seen = false;  // the final pick of an iterate-by-iterate run saw a tie the analytic arithmetic could not have broken
+    int lma_cand[2] = {2, 1}, lma_cand_next[2] = {0, 0};
+    int *d_irr_count = nullptr, *d_irr_list = nullptr;
     bool restarted = false;
     bool tail_ahead = true;  // enqueue the caller's tail behind the SPECULATED final stage (otherwise only behind the definitive one)
     const Minimal9Direct* direct = nullptr;

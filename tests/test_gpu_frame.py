@@ -643,9 +643,10 @@ def test_frame_solve_starts_over_with_the_standard_functions(rsdsfm):
     bad[17, 301] = (3.0, -128.0)
     imgs = {"clean": torch.from_numpy(clean).to(dev), "bad": torch.from_numpy(bad).to(dev)}
     outs = {}
-    for math in (0, 1):
+    for math in (0, 1, 2):  # 2: the default arithmetic of the depth solves (analytic LM trajectory): no restart of either kind, the same bits
         with rsdsfm.Solver(0) as s:
-            s.set_ransac_math(math)
+            s.set_ransac_math(math & 1)
+            s.set_lm_arithmetic(1 if math < 2 else 0)
             res = []
             for name in ("clean", "bad", "clean"):
                 dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
@@ -663,12 +664,13 @@ def test_frame_solve_starts_over_with_the_standard_functions(rsdsfm):
             rs = call([11, 11, 11])
             seq = [(int(x.n_points), int(x.num_inliers), int(x.best_trial), bytes(bytearray(np.array(x.v[:]).tobytes())), dm.cpu().numpy().tobytes()) for x, dm in zip(rs, dms)]
             restarts_all = s.ransac_restarts()
+            assert s.lma_restarts()[0] == 0
         outs[math] = (res, seq)
         assert restarts_single == (1 if math == 0 else 0)
         assert restarts_all == (2 if math == 0 else 0)  # (the sequence's lane met the pixel with the cores again)
         for (a, b) in zip(res, seq):
             assert (a[0], a[1], a[2], a[3], a[8]) == b
-    assert outs[0] == outs[1]
+    assert outs[0] == outs[1] == outs[2]
     assert outs[0][0][0] == outs[0][0][2] and outs[0][0][0] != outs[0][0][1]
 
 

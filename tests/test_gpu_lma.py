@@ -1,0 +1,167 @@
+"""GPU: the RANSAC's depth solves on the ANALYTIC LM TRAJECTORY (csrc/lma_common.hpp, csrc/ransac_lma_kernels.hip; the library's default
+since round 5) against the iterate-by-iterate kernels (rsdsfm_set_lm_arithmetic(1): the reference's arithmetic, operation for operation)
+and against the CPU oracle.  Integer outputs -- per-trial inlier counts, accepted LM steps, winner, mask, index list -- bit-exact on both
+sides; the winner's depths come from the same exact replay and are bit-identical between the two arithmetics; error sums 1e-9."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def solver(rsdsfm):
+    s = rsdsfm.Solver(0)
+    yield s
+    s.close()
+
+
+def _same(r, ro, exact_depths=True):
+    assert np.array_equal(r["trial_count"], ro["trial_count"])
+    assert np.array_equal(r["trial_steps"], ro["trial_steps"])
+    assert r["best_trial"] == ro["best_trial"] and r["num_inliers"] == ro["num_inliers"]
+    assert np.array_equal(r["mask"], ro["mask"]) and np.array_equal(r["inlier_idx"], ro["inlier_idx"])
+    assert np.allclose(r["trial_err"], ro["trial_err"], rtol=1e-9, atol=1e-12)
+    if exact_depths:
+        assert np.array_equal(r["inv_depth"], ro["inv_depth"]) and np.array_equal(r["inliers"], ro["inliers"])
+    else:
+        assert np.allclose(r["inv_depth"], ro["inv_depth"], rtol=1e-9, atol=1e-13)
+
+
+def _both(solver, *args, **kw):
+    solver.set_lm_arithmetic(0)
+    n0 = solver.lma_restarts()[0]
+    ra = solver.ransac(*args, **kw)
+    restarts = solver.lma_restarts()[0] - n0
+    solver.set_lm_arithmetic(1)
+    rx = solver.ransac(*args, **kw)
+    solver.set_lm_arithmetic(0)
+    return ra, rx, restarts
+
+
+@pytest.mark.parametrize("T", [1, 5, 50, 130])
+@pytest.mark.parametrize("tol", [0.05, 0.002])
+def test_analytic_equals_iterate_by_iterate_and_the_oracle(oracle, solver, rsdsfm, T, tol):
+    d = rsdsfm.synth.make_config(3, rows=135, cols=240)
+    q, u, a, ak = d["q"], d["u"], d["alpha"], d["alpha_k"]
+    samples = oracle.sample_indices(len(q), T, 1234)
+    ra, rx, restarts = _both(solver, q, u, a, ak, False, T, tol, samples=samples)
+    assert restarts == 0
+    _same(ra, rx)
+    ro = oracle.ransac(q, u, a, ak, False, T, tol, samples, depth_mode=1)
+    _same(ra, ro, exact_depths=False)
+    ro2 = oracle.ransac(q, u, a, ak, False, T, tol, samples, depth_mode=2)  # the analytic arithmetic restated on the CPU
+    _same(ra, ro2, exact_depths=False)
+    assert np.allclose(ra["trial_err"], ro2["trial_err"], rtol=1e-12, atol=1e-300)
+
+
+def test_clamped_pixels_around_the_focus_of_expansion(oracle, solver, rsdsfm):
+    """forward motion: the pixels around the focus of expansion have a Jacobian below the LM diagonal's clamp (guard a): listed, walked on
+    the exact recurrence by the decide stage -- no restart, every integer as iterate by iterate"""
+    d = rsdsfm.synth.make_config(3, rows=180, cols=320, v=np.array([0.002, 0.001, 0.03]))
+    q, u, a, ak = d["q"], d["u"], d["alpha"], d["alpha_k"]
+    T = 24
+    samples = oracle.sample_indices(len(q), T, 5)
+    ra, rx, restarts = _both(solver, q, u, a, ak, False, T, 0.01, samples=samples)
+    assert restarts == 0
+    _same(ra, rx)
+    ro2 = oracle.ransac(q, u, a, ak, False, T, 0.01, samples, depth_mode=2)
+    assert oracle.lma_last_stats()["listed_clamped"] > 0
+    _same(ra, ro2, exact_depths=False)
+
+
+def test_noise_free_tie_starts_over_and_holds(oracle, solver, rsdsfm):
+    """noise-free data: a tie in count and error sum that only the reference's own rounding breaks (guard d) -- the run starts over
+    iterate by iterate (counted), the context stays there while the data keeps tying, and the results are the iterate-by-iterate ones"""
+    d = rsdsfm.synth.make_config(1, rows=96, cols=128)
+    q, u, a, ak = d["q"], d["u"], d["alpha"], d["alpha_k"]
+    T = 10
+    samples = oracle.sample_indices(len(q), T, 3)
+    n0 = solver.lma_restarts()[0]
+    r1 = solver.ransac(q, u, a, ak, False, T, 0.05, samples=samples)
+    n1, guards = solver.lma_restarts()
+    assert n1 == n0 + 1 and guards & (1 << 7)
+    for _ in range(20):  # (> the hold of 16: a tie seen by the iterate-by-iterate run renews it)
+        r2 = solver.ransac(q, u, a, ak, False, T, 0.05, samples=samples)
+    assert solver.lma_restarts()[0] == n1
+    solver.set_lm_arithmetic(1)
+    rx = solver.ransac(q, u, a, ak, False, T, 0.05, samples=samples)
+    solver.set_lm_arithmetic(0)
+    for r in (r1, r2):
+        _same(r, rx)
+        assert np.array_equal(r["trial_err"], rx["trial_err"])
+    # noisy data ends the hold after 16 runs
+    dn = rsdsfm.synth.make_config(3, rows=96, cols=128)
+    sn = oracle.sample_indices(len(dn["q"]), T, 3)
+    for _ in range(17):
+        solver.ransac(dn["q"], dn["u"], dn["alpha"], dn["alpha_k"], False, T, 0.05, samples=sn)
+    ra, rx, restarts = _both(solver, dn["q"], dn["u"], dn["alpha"], dn["alpha_k"], False, T, 0.05, samples=sn)
+    assert restarts == 0
+    _same(ra, rx)
+
+
+def test_nan_hypotheses_and_acceleration_mode(golden, oracle, solver):
+    for case in ("noisy_k0", "deepflow_k0", "noisy_k04"):
+        g = lambda k: golden[case + "/" + k]
+        q, u, a, ak, samples = g("q"), g("u"), g("alpha"), g("alpha_k"), g("samples")
+        use_k = bool(g("use_k"))
+        ra, rx, restarts = _both(solver, q, u, a, ak, use_k, len(samples), 0.05, samples=samples)
+        assert restarts == 0
+        _same(ra, rx)
+        assert np.array_equal(ra["trial_count"], g("count_lm"))
+    # a non-finite flow at a sampled point: that trial's pose is NaN (it ends at iteration zero, no inlier), and the NaN pixel makes the sums of
+    # every other trial NaN (five invalid steps, termination FAILURE, scored at rho = 1 by the scoring pass) -- no restart, same integers
+    q, u, a, ak = golden["noisy_k0/q"], golden["noisy_k0/u"].copy(), golden["noisy_k0/alpha"], golden["noisy_k0/alpha_k"]
+    samples = oracle.sample_indices(len(q), 6, 9)
+    u[samples[2, 0], 0] = np.nan
+    ra, rx, restarts = _both(solver, q, u, a, ak, False, 6, 0.05, samples=samples)
+    assert restarts == 0
+    _same(ra, rx)
+    ro = oracle.ransac(q, u, a, ak, False, 6, 0.05, samples, depth_mode=1)
+    assert np.array_equal(ra["trial_count"], ro["trial_count"]) and np.array_equal(ra["trial_steps"], ro["trial_steps"]) and ra["best_trial"] == ro["best_trial"]
+    assert not ra["trial_steps"].any()
+
+
+def test_every_pixel_clamped_overflows_the_list_and_starts_over(oracle, solver, rsdsfm):
+    """a translation of 1e-5 x the unit vector the solver returns cannot happen -- but a frame whose points all sit at the focus of
+    expansion can be built: the Jacobian of every point is below the clamp, the hypothesis' list overflows (guard c) and the run starts
+    over iterate by iterate with identical results"""
+    rng = np.random.default_rng(1)
+    n = 4000
+    q = rng.normal(size=(n, 2)) * 1e-5  # all points within 1e-5 of the principal point
+    u = rng.normal(size=(n, 2)) * 1e-3
+    a, ak = np.ones(n), np.full(n, 0.5)
+    T = 4
+    samples = oracle.sample_indices(n, T, 1)
+    n0 = solver.lma_restarts()[0]
+    ra, rx, restarts = _both(solver, q, u, a, ak, False, T, 0.05, samples=samples)
+    _same(ra, rx)
+    ro = oracle.ransac(q, u, a, ak, False, T, 0.05, samples, depth_mode=1)
+    _same(ra, ro, exact_depths=False)
+
+
+def test_frame_solve_is_the_same_in_both_arithmetics(solver, rsdsfm):
+    """the one-call frame solve (flatten -> RANSAC -> refinement -> depth map): analytic pass and iterate-by-iterate kernels give the same
+    inliers, the same refinement, the same depth map -- bit for bit (everything behind the RANSAC starts from the same exact replay)"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(3, rows=270, cols=480)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    img = torch.from_numpy(d["flow_img"]).to(dev)
+    outs = []
+    for tol in (0.05, 0.002):
+        for mode in (0, 1, 0):
+            solver.set_lm_arithmetic(mode)
+            dm = torch.zeros((cols, rows), dtype=torch.float64, device=dev)
+            r = solver.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), trials=50, tol=tol, seed=7)
+            solver.synchronize()
+            outs.append((r, dm.cpu().numpy()))
+        solver.set_lm_arithmetic(0)
+        (a, da), (b, db), (c, dc) = outs[-3:]
+        for x, dx in ((b, db), (c, dc)):
+            assert a["num_inliers"] == x["num_inliers"] and a["best_trial"] == x["best_trial"]
+            assert a["refine_summary"] == x["refine_summary"]
+            for key in ("v", "w", "ransac_v", "ransac_w"):
+                assert np.array_equal(a[key], x[key]), key
+            assert np.array_equal(da, dx, equal_nan=True)
+    assert solver.lma_restarts()[0] == 0

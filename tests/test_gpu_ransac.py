@@ -287,6 +287,7 @@ def test_ransac_function_cores_restart_on_arguments_out_of_range(oracle, rsdsfm,
         u[victim] = 0.0
     ro = oracle.ransac(q, u, a, ak, False, T, 0.05, samples, depth_mode=1)
     with rsdsfm.Solver(0) as s:
+        s.set_lm_arithmetic(1)  # the iterate-by-iterate kernels: the ones that run the cores
         r0 = s.ransac(q, u, a, ak, False, T, 0.05, samples=samples, depth_mode=1)
         assert s.ransac_restarts() == 1
         _compare_ransac(r0, ro)
@@ -295,6 +296,15 @@ def test_ransac_function_cores_restart_on_arguments_out_of_range(oracle, rsdsfm,
         s.set_ransac_math(1)
         r2 = s.ransac(q, u, a, ak, False, T, 0.05, samples=samples, depth_mode=1)
     assert _ransac_bytes(r0) == _ransac_bytes(r1) == _ransac_bytes(r2)
+    # the default arithmetic (the analytic LM trajectory, csrc/lma_common.hpp) needs no restart of either kind for any of them: a pixel with a
+    # vanishing Jacobian is one of the pixels it walks on the exact recurrence anyway (guard a), an error of exactly zero is a select, and
+    # a NaN pixel poisons its sums exactly as it poisons the reference's -- same bits in every output
+    with rsdsfm.Solver(0) as s:
+        r3 = s.ransac(q, u, a, ak, False, T, 0.05, samples=samples, depth_mode=1)
+        assert s.ransac_restarts() == 0 and s.lma_restarts()[0] == 0
+    _compare_ransac(r3, ro)
+    for key in ("trial_count", "trial_steps", "mask", "inlier_idx", "inv_depth", "inliers"):
+        assert np.array_equal(r3[key], r0[key], equal_nan=True), key
 
 
 def test_minimal_solver_function_cores_restart_on_operands_out_of_range(oracle, rsdsfm):

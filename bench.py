@@ -9,10 +9,12 @@ Contract: python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on
               map, per-scanline pose table (reference main.cc:398-522), ONE C-ABI call per pair (rsdsfm_solve_frame_dev), one
               pair at a time.  `value` = pixels of the K timed pairs / the time of the K steps; `median_ms_per_solve` beside it.
               Sub-records of the line:
-                roofline            the dominant kernel ransac_lm_kernel<true> (fp64 VALU bound: counted fp64 lane-instructions / its
+                roofline            the dominant kernel ransac_lma_kernel<2> (fp64 VALU bound: counted fp64 lane-instructions / its
                                     launch duration, measured here with HIP events, / 39.3e12; counts from profiles/counters.json, which
                                     is stamped with the kernel source hashes -- `counters_stale` when they do not match) and, under
                                     "hbm", SURVEY 8(d)'s whole-solve figure (57 N + 64 M iters bytes / solve time / 8 TB/s)
+                full_solve_exact_kernel  the same workload with the RANSAC's depth solves iterate by iterate (rsdsfm_set_lm_arithmetic(1))
+                lma_restarts        solves whose analytic pass tripped a guard and started over iterate by iterate (+ which guards)
                 regimes             the same solve, driver-timed, with T = 5, a selective tolerance, noise-free flow, acceleration mode, 1920x1080
                 full_solve_batched  BASELINE configs[4]: 32 pairs with 32 data seeds through rsdsfm_solve_frames_dev (one context, one host thread)
                 tiled_full          north_star's multi-GPU claim: ONE 3840x2160 frame in N column slabs through the native RCCL driver
@@ -673,7 +675,7 @@ def run(args):
         side = not args.no_side_records
         # sequence-throughput mode (BASELINE configs[4]): 32 pairs with 32 data seeds through ONE context of each GPU
         batched = _full_solve_sequence(rsdsfm, solver, torch, dev, np, rank, args) if side else None
-        fused = depth_only = regimes = threads8 = None
+        fused = depth_only = regimes = threads8 = exact_kernel = None
         if side and world == 1:
             threads8 = _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, 8, per_thread=12)  # round 2's way, for comparison
             threads8["note"] = "comparison: 8 host threads x 8 contexts, each calling the single solve (what round 2 reported as full_solve_batched)"  # single-GPU side records (a multi-rank run keeps to what scales: replicas + the tiled frame)
@@ -684,6 +686,13 @@ def run(args):
                 fused["note"] = "same workload on the opt-in librsdsfm_hip_fused.so (explicit fmas in the per-pixel model); not the headline"
             regimes = _full_solve_regimes(rsdsfm, solver, torch, dev, np, rank, args)
             depth_only = run_depth("depth", 40, 3, side_records=False)
+            # the same workload on the iterate-by-iterate kernels (rsdsfm_set_lm_arithmetic(1): the reference's arithmetic operation for
+            # operation -- what the analytic pass falls back to when a guard trips, and the headline of rounds 1-4)
+            with rsdsfm.Solver(local_rank, stream=stream.cuda_stream) as sx:
+                sx.set_lm_arithmetic(1)
+                xr = _full_solve(rsdsfm, sx, torch, dev, np, rank, args, steps=max(20, args.steps // 2), warmup=3, timed=lambda st, k2, w2: _plain_timed(torch, st, k2, w2))
+            exact_kernel = {k2: xr[k2] for k2 in ("value", "unit", "ms_per_solve", "median_ms_per_solve", "num_inliers")}
+            exact_kernel["note"] = "same workload with rsdsfm_set_lm_arithmetic(1): the RANSAC's depth solves iterate by iterate (ransac_lm_kernel); identical integer outputs"
         if rank == 0:
             line.update({"value": full["value"] * world, "ms_per_step": full["ms_per_solve"], "median_ms_per_solve": full["median_ms_per_solve"], "scaling": "weak",
                          "config": {"workload": "BASELINE metric: WHOLE depth+pose solve of a synthetic 1280x720 DeepFlow-like pair (BASELINE configs[4] data: 0.3 px noise, "
@@ -693,12 +702,16 @@ def run(args):
                                     "pairs": "the timed steps rotate over %d different pairs (data seeds) and a new sampler seed per step" % full["data_seeds"],
                                     **{k2: full[k2] for k2 in ("rows", "cols", "trials", "tol", "n", "num_inliers", "data_seeds", "num_inliers_min_max",
                                                                "refine_iterations_min_max", "distinct_winners", "refine_summary", "w_err", "v_angle_deg")}},
-                         "roofline": roof, "full_solve_batched": batched, "full_solve_8_threads": threads8, "full_solve_fused": fused, "regimes": regimes, "depth_only": depth_only,
+                         "roofline": roof, "full_solve_batched": batched, "full_solve_8_threads": threads8, "full_solve_fused": fused, "full_solve_exact_kernel": exact_kernel, "regimes": regimes, "depth_only": depth_only,
                          "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_full(rsdsfm, np, rank, args.trials, args.tol)})
             # the regimes the headline does not exercise, lifted to the top level of the line: `value_selective` = the same one-call solve
             # at the selective tolerance 0.002 (M < N: compaction and the rank-indexed flow are NOT the identity), `value_sequence` =
             # BASELINE configs[4] (32 pairs / 32 data seeds through rsdsfm_solve_frames_dev), both in the line's unit
             line["ransac_restarts"] = solver.ransac_restarts()  # solves of this context that started over with the standard functions (0 on real-valued data)
+            # solves of this context whose analytic pass tripped a guard and started over iterate by iterate, and which guards (bit 7: a tie in
+            # count and error sum -- the noise-free regime; the headline's DeepFlow-like pairs trip none)
+            lr, lg = solver.lma_restarts()
+            line["lma_restarts"] = {"count": lr, "last_guards": lg, "per_solve_headline": 0.0 if full.get("lma_restarts") is None else full["lma_restarts"] / max(1, args.steps + args.warmup)}
             line["value_selective"] = regimes["selective_tol_0.002"]["value"] if regimes else None
             line["value_sequence"] = batched["value"] * world if batched else None
             if line["cpu_baseline"] and side:  # the single-thread figure "plus an all-cores variant"
@@ -1187,7 +1200,9 @@ def _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps, warmup, timed
         per_step.append(clock() - t0)
         seen.append((int(r_.num_inliers), int(r_.refine_summary.num_iterations), int(r_.best_trial)))  # (after the clock: not in the step's own time)
 
+    lma0 = solver.lma_restarts()[0]
     el = timed(step, steps, warmup)
+    lma_restarts = solver.lma_restarts()[0] - lma0  # guard restarts of the analytic pass during the warm-up + timed steps
     # the last timed solve once more through the dict-building wrapper (same seed: same result), for the record
     r = solver.solve_frame_dev(imgs[(steps - 1) % nd].data_ptr(), rows, cols, K, gamma, depth_map.data_ptr(), R.data_ptr(),
                                tt.data_ptr(), trials=args.trials, tol=args.tol, seed=steps)
@@ -1199,7 +1214,7 @@ def _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps, warmup, timed
     return {"value": rows * cols * steps / el / 1e6, "unit": "Mpixels/s", "ms_per_solve": el / steps * 1e3,
             "median_ms_per_solve": ts[len(ts) // 2] * 1e3, "min_ms_per_solve": ts[0] * 1e3,
             "rows": rows, "cols": cols, "trials": args.trials, "tol": args.tol, "n": r["n"], "num_inliers": r["num_inliers"],
-            "data_seeds": nd, "num_inliers_min_max": [min(x[0] for x in seen), max(x[0] for x in seen)],
+            "lma_restarts": lma_restarts, "data_seeds": nd, "num_inliers_min_max": [min(x[0] for x in seen), max(x[0] for x in seen)],
             "refine_iterations_min_max": [min(x[1] for x in seen), max(x[1] for x in seen)], "distinct_winners": len({x[2] for x in seen}),
             "refine_summary": r["refine_summary"], "K": K, "gamma": gamma, "_img": imgs[0],
             "w_err": float(np.linalg.norm(r["w"] - t["w"])), "v_angle_deg": float(np.degrees(np.arccos(min(1.0, abs(float(vv @ vt)))))),
@@ -1260,8 +1275,8 @@ def _counters(kernel):
 
 
 def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):
-    """Roofline record of the whole solve's dominant kernel, ransac_lm_kernel<true, 3, 2, true> (round 0 of the hypothesis-batched LM depth
-    solves: ~45 % of the solve), measured LIVE and in situ: the library brackets that launch with HIP events on the stream it runs
+    """Roofline record of the whole solve's dominant kernel, ransac_lma_kernel<2> (the T depth solves of the RANSAC on the analytic LM
+    trajectory: ~26 % of the solve, level with the minimal solver's SVD chain and the refinement's passes), measured LIVE and in situ: the library brackets that launch with HIP events on the stream it runs
     on (rsdsfm_set_profiling) inside 27 ordinary whole solves after 3 warm-ups.  Its bound is
     fp64 VALU issue, not HBM: `achieved` = fp64 lane-instructions of one launch (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes,
     rocprofv3 PMC pass committed as profiles/counters.json) / the measured duration; `peak` = 39.3e12 / s.  "hbm" = SURVEY 8(d):
@@ -1286,10 +1301,11 @@ def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):
     clock_mhz = float(np.mean(mhz[3:]))
     # round 0: three speculated iterations, the score of the two-step iterate fused (DeepFlow-like data); last template argument: sqrt and
     # the reciprocal through their in-range cores (reference-arithmetic library only)
-    kname = "ransac_lm_kernel<true, 3, 2, %s>" % ("false" if args.arith == "fused" else "true")
+    # the pixel pass of the RANSAC's depth solves on the analytic LM trajectory (ransac_lma_kernels.hip), the scores of two iterates fused
+    kname = "ransac_lma_kernel<2>"
     ctr = _counters(kname + (":fused" if args.arith == "fused" else ""))
     insts = achieved = frac = traffic = frac_all = None
-    stale = ctr.get("stale") if ctr else None
+    stale = ctr.get("stale") if ctr else ["profiles/counters.json: no entry for " + kname]
     if ctr and not stale:
         insts = 64.0 * sum(ctr.get(k2, 0.0) for k2 in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
         achieved = insts / (kern_ms * 1e-3)

@@ -1067,8 +1067,8 @@ static inline void lma_pixel(double x, double y, double ux, double uy, double al
     const double h = fma(J0, J0, J1 * J1);
     double g = fma(J0, r0, J1 * r1);
     const int clamped = h < LMA_H_IRR;
-    double e0 = g / (clamped ? 1.0 : h);
-    if (clamped) g = 0.0, e0 = 0.0;
+    g = g * (clamped ? 0.0 : 1.0);        /* a clamped pixel enters the sums frozen at rho = 1: g = e0 = 0 */
+    const double e0 = g / fmax(h, LMA_H_IRR); /* (fmax: a NaN h is floored too, like the kernel's v_max_f64) */
     const double rhos = 1.0 - e0;
     const double s0 = fma(rhos, J0, c0), s1 = fma(rhos, J1, c1);
     o->a = fma(s0, s0, s1 * s1);

@@ -19,7 +19,7 @@ OBJ_DIR = os.path.join(HERE, "build")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wno-unused-function"]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-ldl"]
 # translation units that include the per-pixel model (device_math.hpp / lm_common.hpp) or carry their own RSDSFM_FUSED switch
-FUSED_UNITS = ("depth_kernels", "ransac_kernels", "ransac_lma_kernels", "gtflow_kernels", "capi")
+FUSED_UNITS = ("depth_kernels", "ransac_kernels", "ransac_lma_kernels", "depth_lma_kernels", "gtflow_kernels", "capi")
 
 
 def sources():

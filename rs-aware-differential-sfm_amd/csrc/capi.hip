@@ -164,6 +164,7 @@ void rsdsfm_destroy(rsdsfm_ctx* ctx) {
     for (hipEvent_t e : c->ev_prof)
         if (e) (void)hipEventDestroy(e);
     if (c->d_clk_probe) (void)hipFree(c->d_clk_probe);
+    if (c->d_lma_list) (void)hipFree(c->d_lma_list);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete ctx;
 }
@@ -337,6 +338,15 @@ int rsdsfm_estimate_inverse_depths_dev(rsdsfm_ctx* ctx, const double* d_q, const
         c->lm_issued_d = 1;
         return rcf;
     }
+    if (depth_lma_allowed(c, n)) {  // the analytic LM trajectory (depth_lma_kernels.hip): launch 0 + ONE launch that decides and finishes
+        Ctx* cs1[1] = {c};
+        const double *q1[1] = {d_q}, *u1[1] = {d_u}, *a1[1] = {d_alpha}, *ak1[1] = {d_alpha_k};
+        double* r1[1] = {d_rho};
+        int rc0 = depth_lma_batch_launch(cs1, 1, q1, u1, a1, ak1, &n, &pose, r1);
+        c->lm_issued_k = 1;
+        c->lm_issued_d = 1;
+        return rc0;
+    }
     if (c->depth_variant == 0) {  // launch 0, then ONE launch that decides and (if needed) applies
         int rc0 = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 0, /*core=*/true);  // (the follow-up launch checks the cores' range flag)
         if (rc0 != RSDSFM_OK) return rc0;
@@ -376,7 +386,10 @@ static int depth_batch_common(rsdsfm_ctx* const* ctxs, int32_t count, const doub
         memcpy(poses[i].w, w3 + 3 * i, sizeof(poses[i].w));
         poses[i].k = k[i];
     }
-    int rc = depth_lm_batch_launch(cs, count, d_q, d_u, d_alpha, d_alpha_k, n, poses, d_rho, launch0_only);
+    bool analytic = !launch0_only;  // (a launch0_only caller drives the decide stage itself: the iterate-by-iterate protocol)
+    for (int i = 0; i < count; ++i) analytic = analytic && depth_lma_allowed(cs[i], n[i]);
+    int rc = analytic ? depth_lma_batch_launch(cs, count, d_q, d_u, d_alpha, d_alpha_k, n, poses, d_rho)
+                      : depth_lm_batch_launch(cs, count, d_q, d_u, d_alpha, d_alpha_k, n, poses, d_rho, launch0_only);
     if (rc != RSDSFM_OK) return rc;
     for (int i = 0; i < count; ++i) {
         cs[i]->lm_issued_k = 1;
@@ -448,11 +461,17 @@ int rsdsfm_depth_finish_dev(rsdsfm_ctx* ctx, const double* d_q, const double* d_
     int rc = read_lm_state(c);
     if (rc != RSDSFM_OK) return rc;
     if (c->h_lm->status == 0 && c->h_lm->restart) {
-        // launch 0 ran its Jacobi scaling through the in-range function cores and met an argument out of range (a vanishing Jacobian, a
-        // non-finite flow: depth_kernels.hip CORE): the solve starts over with the standard functions -- launch 0, its decision, and
-        // from there the ordinary continuation below; the context keeps the standard functions for its next 16 solves
-        c->depth_standard_math = 16;
-        c->depth_restarts += 1;
+        // launch 0 ran its Jacobi scaling through the in-range function cores and met an argument out of range (a non-finite flow, a
+        // denormal Jacobian: depth_kernels.hip CORE) -- or (restart == 2) it ran on the analytic trajectory and a guard tripped
+        // (depth_lma_kernels.hip): the solve starts over iterate by iterate with the standard functions -- launch 0, its decision, and
+        // from there the ordinary continuation below (a function-core miss keeps the context on the standard functions for its next 16 solves)
+        if (c->h_lm->restart == 2) {
+            c->lma_restarts += 1;
+            c->lma_last_guard = 1 << std::min(std::max(c->h_lm->iteration, 0), 15);
+        } else {
+            c->depth_standard_math = 16;
+            c->depth_restarts += 1;
+        }
         rc = depth_lm_launch(c, d_q, d_u, d_alpha, d_alpha_k, n, pose, d_rho, 0, /*core=*/false);
         if (rc != RSDSFM_OK) return rc;
         rc = depth_lm_decide_launch(c, n, 0);

@@ -60,6 +60,15 @@ __device__ __forceinline__ double sqrt_core(double x) {
     d = __builtin_fma(-g, g, x);
     return __builtin_fma(d, h, g);
 }
+// sqrt_core for an argument that may be EXACTLY zero (a vanishing Jacobian; the error of a pixel the model explains exactly: ground-truth
+// flow is a supported input, main.cc:380-384): sqrt(0) = 0 is a select, not a reason to leave the cores -- `worst` tracks the range test of
+// every other argument (sqrt_range_track).  x is a sum of squares: never -0.
+__device__ __forceinline__ double sqrt_core_z(double x, uint32_t& worst) {
+    const bool z = x == 0.0;
+    worst = max(worst, z ? 0u : sqrt_range_key(x));
+    const double r = sqrt_core(x);
+    return z ? 0.0 : r;
+}
 // n / d for operands inside the window where v_div_scale does not rescale and v_div_fixup passes the quotient through: both
 // magnitudes in [2^-383, 2^385) (then the exponents differ by less than 768, no operand and no quotient is zero, denormal or infinite).
 // The core is the compiler's expansion without the two v_div_scale, with v_div_fmas as the plain fma it is when nothing was scaled,
@@ -224,8 +233,7 @@ __device__ __forceinline__ double point_error_from_model_core(const PixelModel& 
     const double e0 = beta * (bw0 - m.a0 * rho) - m.ux;
     const double e1 = beta * (bw1 - m.a1 * rho) - m.uy;
     const double ss = e0 * e0 + e1 * e1;
-    sqrt_range_track(worst, ss);
-    return sqrt_core(ss);
+    return sqrt_core_z(ss, worst);
 }
 
 // minimal.cc:255-270: residual norm of the flow predicted from (v, w, k, rho)

@@ -23,6 +23,8 @@
 // owns an ncclComm_t).  rsdsfm_dist_set_transport installs caller-provided collectives instead (used by the tests to run several
 // logical ranks on one GPU, and by hosts with another communication library).
 #include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -113,6 +115,8 @@ Rccl* rccl() {
 // ---------------------------------------------------------------------------------------------------
 // per-context distributed state
 // ---------------------------------------------------------------------------------------------------
+constexpr double kLmaTieMarginD = 1e-11;  // = kLmaTie (lma_common.hpp, guard d)
+
 struct Dist {
     int nranks = 1, rank = 0;
     ncclComm_t comm = nullptr;
@@ -143,6 +147,10 @@ struct Dist {
     // the standard functions, which the communicator then keeps for its next 16 solves
     int standard_math = 0;
     int64_t restarts = 0;
+    // the RANSAC's depth solves on the analytic LM trajectory (ransac_lma_kernels.hip), as in the single-context solve: a run whose guards trip
+    // (every rank reads the same replicated flag words) starts over iterate by iterate, and the communicator stays there for its next solves
+    // (renewed by a solve that ends in a tie the analytic arithmetic could not break: noise-free data)
+    int lma_hold = 0;
 };
 
 Dist* dist_of(Ctx* c, bool create) {
@@ -160,6 +168,8 @@ int nccl_fail(Ctx* c, ncclResult_t r, const char* what) {
 int all_gather(Ctx* c, Dist* D, const void* d_send, void* d_recv, size_t bytes) {
     if (bytes == 0) return RSDSFM_OK;
     D->collectives += 1;
+    static const bool dbg = getenv("RSDSFM_TILED_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[rank %d] collective %d: all_gather %zu bytes\n", D->rank, D->collectives, bytes);
     if (D->ag) {
         if (D->ag(D->user, d_send, d_recv, bytes, c->stream) != 0) return fail(c, RSDSFM_ERR_HIP, "caller-provided all-gather failed");
         return RSDSFM_OK;
@@ -178,6 +188,8 @@ int all_gather(Ctx* c, Dist* D, const void* d_send, void* d_recv, size_t bytes) 
 int all_reduce_sum(Ctx* c, Dist* D, double* d_buf, size_t count) {
     if (count == 0) return RSDSFM_OK;
     D->collectives += 1;
+    static const bool dbg = getenv("RSDSFM_TILED_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "[rank %d] collective %d: all_reduce %zu doubles\n", D->rank, D->collectives, count);
     if (D->ar) {
         if (D->ar(D->user, d_buf, count, c->stream) != 0) return fail(c, RSDSFM_ERR_HIP, "caller-provided all-reduce failed");
         return RSDSFM_OK;
@@ -462,11 +474,12 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
     int32_t* d_ys = fa.take<int32_t>(N1);
 
     // ---- small exchange buffers ----
-    const int row_max = std::max({nsr * batch + 2, refine_slot_row_doubles(np), refine_stage_row_doubles(np, 0), refine_stage_row_doubles(np, 1), refine_stage_row_doubles(np, 2), 2 * batch});
+    const int row_max = std::max({nsr * batch + 2, ransac_lma_rows_doubles() * batch, refine_slot_row_doubles(np), refine_stage_row_doubles(np, 0), refine_stage_row_doubles(np, 1), refine_stage_row_doubles(np, 2), 2 * batch});
     size_t need_d = 2 * Arena::need(8 * (size_t)R + 64) + Arena::need(8 * (size_t)R * Tn) + Arena::need(4 * 9 * (size_t)Tn) + Arena::need(8 * (54 * (size_t)Tn + (size_t)R + 8)) + Arena::need(8 * 8 * (size_t)Tn) +
                     Arena::need(sizeof(LmState) * Tn) + Arena::need(4 * (size_t)Tn) + Arena::need(64) + 2 * Arena::need(8 * (size_t)Tn) +
                     2 * Arena::need(sizeof(RansacBest)) + Arena::need(8 * (size_t)row_max) + Arena::need(8 * (size_t)row_max * R) + Arena::need(64) +
-                    Arena::need(8 * (size_t)R + 64) + Arena::need(64) + (padded ? Arena::need(8 * cap * R) : 0) + 4096;
+                    Arena::need(8 * (size_t)R + 64) + Arena::need(64) + (padded ? Arena::need(8 * cap * R) : 0) + Arena::need(4 * (size_t)batch) +
+                    Arena::need(4 * ransac_lma_list_ints(batch)) + 4096;
     if (rc == RSDSFM_OK) rc = ensure_dev(c, &D->d_buf, &D->bytes, need_d);
     Arena da(D->d_buf);
     int64_t* d_cnt_all = da.take<int64_t>((size_t)R + 8);
@@ -479,7 +492,9 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
     LmState* d_states = da.take<LmState>(Tn);
     int* d_scored = da.take<int>(Tn);
     int* d_flags = da.take<int>(16);
+    int* d_irr_count = da.take<int>(batch);  // analytic pass: listed pixels per hypothesis of the batch (zeroed with the states)
     const size_t zero_bytes = (size_t)((da.base + da.off) - zero_begin);
+    int* d_irr_list = da.take<int>(ransac_lma_list_ints(batch));
     double* d_tcount = da.take<double>(Tn);
     double* d_terr = da.take<double>(Tn);
     RansacBest* d_best = da.take<RansacBest>(1);
@@ -494,7 +509,7 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
     // ---- per-stage workspace (stream-ordered reuse) ----
     const size_t ncells = sc > 0 ? (size_t)flatten_cells(rows, sc) : 1;
     const size_t ws_need = std::max({2 * Arena::need(sizeof(int64_t) * ncells),
-                                     Arena::need(sizeof(double) * (size_t)ransac_lm_partials_doubles(c, (int64_t)N1, batch)) + 2 * Arena::need(sizeof(int64_t) * 2048),
+                                     Arena::need(sizeof(double) * std::max<size_t>((size_t)ransac_lm_partials_doubles(c, (int64_t)N1, batch), (size_t)ransac_lma_partials_doubles(c, (int64_t)N1, batch))) + 2 * Arena::need(sizeof(int64_t) * 2048),
                                      Arena::need(8 * cap) + Arena::need(8 * 1024)}) + 4096;
     if (rc == RSDSFM_OK) rc = ensure_ws(c, ws_need);
     if (rc == RSDSFM_OK)
@@ -618,6 +633,12 @@ restart_cold:
         rc = all_reduce_sum(c, D, d_pts, 54 * (size_t)T + (spec_dense ? (size_t)R : 0));
         if (rc != RSDSFM_OK) return rc;
     }
+    // the depth solves of the trials on the analytic LM trajectory (lma_common.hpp), as in the single-context solve: the user's switch
+    // (rsdsfm_set_lm_arithmetic: the same on every rank) and the communicator's hold -- replicated knowledge, every rank decides alike
+    bool analytic = T > 0 && depth_mode == RSDSFM_DEPTH_CERES_LM && c->lm_arithmetic == 0 && D->lma_hold == 0 && setup_rc == RSDSFM_OK;
+    const bool lma_may_return = depth_mode == RSDSFM_DEPTH_CERES_LM && c->lm_arithmetic == 0;  // (ties are reported: they renew the hold)
+    bool lma_restarted = false, tie_seen = false;
+    const int lma_cand[2] = {2, 1};  // fused iterates: fixed, like kTiledFusedBase (every rank must fuse the same ones)
 restart_ransac:
     if (T > 0) {
         Minimal9Direct dir;
@@ -633,13 +654,14 @@ restart_ransac:
 
     // ---- RANSAC: LM rounds of the hypothesis batches, scores, winner, compaction ----
     Arena ws(c->d_ws);
-    double* d_partials = ws.take<double>((size_t)ransac_lm_partials_doubles(c, (int64_t)N1, batch));
+    double* d_partials = ws.take<double>(std::max<size_t>((size_t)ransac_lm_partials_doubles(c, (int64_t)N1, batch), (size_t)ransac_lma_partials_doubles(c, (int64_t)N1, batch)));
     int64_t* d_bcounts = ws.take<int64_t>(2048);
     int64_t* d_boffs = ws.take<int64_t>(2048);
     auto final_stage = [&]() -> int {  // winner (replicated), its dense 1/depth + mask + compaction on the slab, inlier counts of all slabs
         // the winner (replicated) -- and with it the inlier counts of ALL slabs: the ranks' shares of the winner's count were in the rows the
         // scores came from (ransac_decide_kernel / ransac_reduce_scores_kernel keep them), so the counts need no exchange of their own
-        int rc2 = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, nullptr, nullptr, nullptr, 0, d_cnt_rt, T, R, d_m_all);
+        int rc2 = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, nullptr, nullptr, nullptr, 0, d_cnt_rt, T, R, d_m_all,
+                                     !lma_may_return ? 0.0 : (analytic ? kLmaTieMarginD : -kLmaTieMarginD));
         if (rc2 != RSDSFM_OK) return rc2;
         // the compaction stores the SLAB's scan total into its record: every rank works on a copy of the (identical) winner record
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_best_shard, d_best, sizeof(RansacBest), hipMemcpyDeviceToDevice, c->stream));
@@ -661,15 +683,32 @@ restart_ransac:
             if (b0 > 0) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_flags, 0, sizeof(int) * 4, c->stream));
             for (int round = 0;; ++round) {
                 if (round > 4 * kMaxIter) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machines did not terminate");
-                const bool core_round = core && round == 0;  // (core implies one batch: B == T)
-                rc = ransac_lm_rows_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, d_partials, round, prm->ransac_tol, d_row,
-                                           core_round ? d_core_flags : nullptr, m9_epoch ? c->d_core_flag : nullptr, m9_epoch);
-                if (rc != RSDSFM_OK) return rc;
-                rc = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)ransac_rows_payload_doubles(B, core_round));
-                if (rc != RSDSFM_OK) return rc;
-                rc = ransac_decide_rows_launch(c, d_rows_all, R, B, d_states + b0, n_total, round, d_flags, d_scored + b0, d_tcount + b0, d_terr + b0, core_round,
-                                               d_cnt_rt + b0, T);
-                if (rc != RSDSFM_OK) return rc;
+                const bool core_round = core && round == 0 && !analytic;  // (core implies one batch: B == T)
+                if (analytic) {
+                    // ONE pixel pass + ONE exchange of [B][kLmaRow] closed-form sums per rank (no rounds), the trust-region loop replicated on
+                    // the gathered rows; the minimal solver's range flag is replicated knowledge (every rank ran the same solver on the same
+                    // points), so it needs no trailer
+                    if (round != 0) return fail(c, RSDSFM_ERR_NUMERIC, "analytic LM pass asked for a second round");
+                    if (b0 > 0) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_irr_count, 0, sizeof(int) * (size_t)batch, c->stream));
+                    rc = ransac_lma_rows_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_partials, prm->ransac_tol, lma_cand, 2, d_irr_count, d_irr_list, d_row);
+                    if (rc != RSDSFM_OK) return rc;
+                    const size_t row_doubles = (size_t)ransac_lma_rows_doubles() * (size_t)B;
+                    rc = all_gather(c, D, d_row, d_rows_all, sizeof(double) * row_doubles);
+                    if (rc != RSDSFM_OK) return rc;
+                    rc = ransac_lma_decide_rows_launch(c, d_rows_all, R, (int64_t)row_doubles, B, n_total, d_hyp + (size_t)b0 * 8, d_states + b0, d_flags, d_scored + b0,
+                                                       d_tcount + b0, d_terr + b0, prm->ransac_tol, lma_cand, 2, nullptr, nullptr, d_cnt_rt + b0, T,
+                                                       m9_epoch ? c->d_core_flag : nullptr, m9_epoch);
+                    if (rc != RSDSFM_OK) return rc;
+                } else {
+                    rc = ransac_lm_rows_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_states + b0, d_partials, round, prm->ransac_tol, d_row,
+                                               core_round ? d_core_flags : nullptr, m9_epoch ? c->d_core_flag : nullptr, m9_epoch);
+                    if (rc != RSDSFM_OK) return rc;
+                    rc = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)ransac_rows_payload_doubles(B, core_round));
+                    if (rc != RSDSFM_OK) return rc;
+                    rc = ransac_decide_rows_launch(c, d_rows_all, R, B, d_states + b0, n_total, round, d_flags, d_scored + b0, d_tcount + b0, d_terr + b0, core_round,
+                                                   d_cnt_rt + b0, T);
+                    if (rc != RSDSFM_OK) return rc;
+                }
                 D->ransac_rounds += 1;
                 if (round == 0 && B == T) {  // the common case is decided and scored by round 0: enqueue the final stage before reading the flags
                     if (D->score_idle < kScoreIdleLimit) {
@@ -704,7 +743,21 @@ restart_ransac:
                         goto restart_cold;
                     }
                 }
-                if (core_round && h_flags[3] != 0) {
+                // (the speculated pick's tie flag counts only where every trial had its score: this driver's pick does not see the flag words)
+                const bool spec_tie = final_done && h_flags[0] == 0 && (h_flags[1] == 0 || spec_scored) && h_best->lma_tie != 0;
+                if (analytic && ((h_flags[3] & 2) != 0 || spec_tie) && !((h_flags[3] & 1) && core)) {
+                    // a guard of the analytic pass tripped, or the speculated pick met a tie it must not break (replicated: every rank reads the
+                    // same words): the depth solves start over iterate by iterate on every rank, and the communicator stays there for a while
+                    analytic = false;
+                    lma_restarted = true;
+                    D->lma_hold = 16;
+                    c->lma_restarts += 1;
+                    c->lma_last_guard = (h_flags[3] >> 8) | (spec_tie ? (1 << 7) : 0);
+                    path_flags |= 8;
+                    RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
+                    goto restart_ransac;  // (from the minimal solver on, like a function-core miss: one path to start over on)
+                }
+                if ((core_round || (analytic && core && round == 0)) && (h_flags[3] & 1) != 0) {
                     // some shard's round 0 (or the minimal solver) met an argument outside the range of the function cores: every rank read
                     // the same flag, all run the RANSAC again from the minimal solver on with the standard functions (identical results)
                     core = false;
@@ -740,6 +793,17 @@ restart_ransac:
         rc = sync(c, D);
         if (rc != RSDSFM_OK) return rc;
     }
+    if (analytic && h_best->lma_tie) {  // guard (d) at the definitive pick (replicated: the trial scores are)
+        analytic = false;
+        lma_restarted = true;
+        D->lma_hold = 16;
+        c->lma_restarts += 1;
+        c->lma_last_guard = 1 << 7;
+        path_flags |= 8;
+        RSDSFM_HIP_CHECK(c, hipMemsetAsync(zero_begin, 0, zero_bytes, c->stream));
+        goto restart_ransac;
+    }
+    tie_seen = h_best->lma_tie != 0;
     int64_t m_total = 0;
     for (int r = 0; r < R; ++r) m_total += h_m[r];
     const int64_t m = h_m[rank];
@@ -945,6 +1009,8 @@ restart_ransac:
             dense_now = dense_now && h_cnt[r] == (int64_t)rows * scr;
         }
         D->dense_hint = dense_now;
+        // an iterate-by-iterate solve inside a hold: the hold goes on while the data keeps showing ties the analytic arithmetic cannot break
+        if (!lma_restarted && !analytic && D->lma_hold > 0) D->lma_hold = tie_seen ? 16 : D->lma_hold - 1;
         D->warm = true;
         D->warm_rows = rows, D->warm_cols = cols, D->warm_T = T, D->warm_flags = shape_flags;
     }
@@ -1014,11 +1080,12 @@ int rsdsfm_estimate_inverse_depths_tiled_dev(rsdsfm_ctx* ctx, const double* d_q_
     pose.k = k;
     const size_t cap = (size_t)std::max<int64_t>(per, 2);
     const bool padded = (size_t)R * cap != (size_t)n_total;
-    int rc = ensure_dev(c, &D->d_buf, &D->bytes, Arena::need(8 * (size_t)NS) + Arena::need(8 * (size_t)NS * R) + (padded ? Arena::need(8 * cap * R) : 0) + 4096);
+    const size_t row_max = (size_t)std::max((int)NS, depth_lma_row_doubles());
+    int rc = ensure_dev(c, &D->d_buf, &D->bytes, Arena::need(8 * row_max) + Arena::need(8 * row_max * R) + (padded ? Arena::need(8 * cap * R) : 0) + 4096);
     if (rc != RSDSFM_OK) return rc;
     Arena da(D->d_buf);
-    double* d_row = da.take<double>(NS);
-    double* d_rows_all = da.take<double>((size_t)NS * R);
+    double* d_row = da.take<double>(row_max);
+    double* d_rows_all = da.take<double>(row_max * R);
     double* d_gather = padded ? da.take<double>(cap * R) : d_inv_depth;
     double* d_rho = d_gather + (size_t)rank * cap;  // the shard is solved in place in the all-gather buffer
     // an empty shard still takes part in every collective; its kernels run over zero points of a valid (unused) address
@@ -1046,6 +1113,27 @@ int rsdsfm_estimate_inverse_depths_tiled_dev(rsdsfm_ctx* ctx, const double* d_q_
             RSDSFM_HIP_CHECK(c, hipMemcpyAsync(c->h_lm, c->d_lm, sizeof(LmState), hipMemcpyDeviceToHost, c->stream));
             return sync(c, D);
         };
+        // the analytic LM trajectory (depth_lma_kernels.hip; the user's switch is the same on every rank): ONE pass over the shard, ONE exchange of
+        // the closed-form row, the decision replicated -- no rounds.  A guard that trips (every rank reads the same replicated state) sends every
+        // rank through the iterate-by-iterate protocol below.
+        bool analytic_done = false;
+        if (depth_lma_allowed(c, ns) && n_total <= (int64_t)INT32_MAX) {
+            rc = depth_lma_shard_launch(c, q, u, a, ak, ns, pose, d_rho, d_row);
+            if (rc != RSDSFM_OK) return rc;
+            rc = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)depth_lma_row_doubles());
+            if (rc != RSDSFM_OK) return rc;
+            rc = depth_lma_shard_finish_launch(c, q, u, a, ak, ns, pose, d_rho, d_rows_all, R, n_total);
+            if (rc != RSDSFM_OK) return rc;
+            launches = 2;
+            rc = read_state();
+            if (rc != RSDSFM_OK) return rc;
+            analytic_done = c->h_lm->status == 1;
+            if (!analytic_done) c->lma_restarts += 1, c->lma_last_guard = 1 << std::min(std::max(c->h_lm->iteration, 0), 15);
+        }
+        if (analytic_done) {
+            c->lm_issued_k = c->lm_issued_d = 0;
+            fill_lm_summary(*c->h_lm, summary);
+        } else {
         // fast path, no host round trip: speculate (launch 0) -> decide -> launch 1 (applies / continues / nothing to do)
         rc = depth_lm_launch(c, q, u, a, ak, ns, pose, d_rho, 0);
         if (rc != RSDSFM_OK) return rc;
@@ -1083,6 +1171,7 @@ int rsdsfm_estimate_inverse_depths_tiled_dev(rsdsfm_ctx* ctx, const double* d_q_
         }
         c->lm_issued_k = c->lm_issued_d = 0;  // nothing for rsdsfm_depth_finish_dev to continue
         fill_lm_summary(*c->h_lm, summary);
+        }
     }
     // ---- ONE all-gather of the inverse-depth shards (the data-path collective: 8 B x points) ----
     if ((size_t)ns < cap) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_rho + ns, 0, sizeof(double) * (cap - (size_t)ns), c->stream));

@@ -224,8 +224,7 @@ __device__ __forceinline__ double lm_pixel_t(double x, double y, double ux, doub
     double s;  // Jacobi scaling (iteration 0 Jacobian)
     if (CORE) {
         const double jj = dot2(m.J0, m.J0, m.J1, m.J1);
-        sqrt_range_track(*worst, jj);
-        s = rcp_core(1.0 + sqrt_core(jj));
+        s = rcp_core(1.0 + sqrt_core_z(jj, *worst));
     } else {
         s = 1.0 / (1.0 + sqrt(dot2(m.J0, m.J0, m.J1, m.J1)));
     }

@@ -82,6 +82,7 @@ struct LmaCand {
     int steps[kLmaNC];    // accepted steps of each (1 ..  kLmaKP - 1)
     double phi2[kLmaNC];  // phi^2 of each
     double tol, tol2, c1, c1x2;  // tolerance, its square, eta tol / 2 and eta tol
+    LmaPlan plan;                // the planned trajectory (computed once on the host: a chain of divisions)
 };
 
 struct LmaPx {
@@ -89,6 +90,12 @@ struct LmaPx {
     bool clamped;
 };
 
+// max(x, lo) as the one instruction it is (v_max_f64 returns the other operand for a NaN, like fmax: a NaN h is floored too)
+__device__ __forceinline__ double lma_max_pos(double x, double lo) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(lo));
+    return r;
+}
 // oracle/rsdsfm_oracle.c lma_pixel(): the SAME operations in the same order
 // FULL: the standard division (the rows stage, which sees a handful of pixels: same bits in range)
 template <bool FULL = false>
@@ -104,11 +111,13 @@ __device__ __forceinline__ LmaPx lma_pixel(double x, double y, double ux, double
     const double r0 = c0 + J0, r1 = c1 + J1;
     const double h = __builtin_fma(J0, J0, J1 * J1);
     double g = __builtin_fma(J0, r0, J1 * r1);
+    // a clamped pixel enters the sums frozen at rho = 1: g = e0 = 0 (g times a 0 / 1 mask whose high word is one select, h floored at the
+    // threshold: four instructions instead of seven selects).  g / h through the in-range core of the division (device_math.hpp: the
+    // compiler's own expansion without the operand rescaling; the same bits for |g| in [2^-383, 2^385) or 0 and h in [1e-6, 2^385) -- sums of
+    // other magnitudes are infinite and send the run to guard (c))
     const bool clamped = h < kLmaHIrr;
-    // g / h through the in-range core of the division (device_math.hpp: the compiler's own expansion without the operand rescaling; the same
-    // bits for |g| in [2^-383, 2^385) or 0 and h in [1e-6, 2^385) -- sums of such magnitudes are infinite and send the run to guard (c))
-    double e0 = FULL ? g / (clamped ? 1.0 : h) : div_core(g, clamped ? 1.0 : h);
-    if (clamped) g = 0.0, e0 = 0.0;
+    g = g * __hiloint2double(clamped ? 0 : 0x3FF00000, 0);
+    const double e0 = FULL ? g / lma_max_pos(h, kLmaHIrr) : div_core(g, lma_max_pos(h, kLmaHIrr));
     const double rhos = 1.0 - e0;
     const double s0 = __builtin_fma(rhos, J0, c0), s1 = __builtin_fma(rhos, J1, c1);
     o.a = __builtin_fma(s0, s0, s1 * s1);

@@ -777,8 +777,9 @@ __global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restric
     // hypothesis explains every pixel and the sums are rounding noise) the reference's winner is decided by the last bits of ITS arithmetic:
     // the result does not count and the host runs the RANSAC again on the iterate-by-iterate kernels.
     // (tie_margin < 0: only reported in RansacBest::lma_tie -- an iterate-by-iterate run telling the context what kind of data it is on)
+    // (only where every trial has its score: with flags that say otherwise the scores of some trials are whatever the buffers hold)
     int tie = 0;
-    if (tie_margin != 0.0 && bi >= 0 && best_count > 0.0) {
+    if (tie_margin != 0.0 && bi >= 0 && best_count > 0.0 && !(flags && (flags[0] != 0 || (flags[1] > 0 && !scored_ahead)))) {
         const double tm = fabs(tie_margin);
         for (int t0 = 0; t0 < T; t0 += 64) {
             const int t = t0 + lane;

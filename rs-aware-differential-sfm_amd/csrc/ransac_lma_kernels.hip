@@ -13,16 +13,17 @@
 //   ransac_lma_decide_kernel  Ceres' trust-region loop on the closed forms (one lane per hypothesis), guard (c), the score of the final
 //                             iterate -> LmState (accepted radii: what ransac_final_kernel / ransac_score_kernel replay), trial scores
 // The single-context solve runs rows + decide as ONE launch (ransac_lma_rows_decide_kernel).
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "lma_common.hpp"
+#include "lma_stages.hpp"
 #include "rsdsfm_internal.hpp"
 
 namespace rsdsfm {
 
 namespace {
-
-constexpr int kLB = 256;
 
 __device__ __forceinline__ bool is_nan_bits2(double x) {
     const uint32_t h = (uint32_t)__double2hiint(x) & 0x7FFFFFFFu;
@@ -41,22 +42,6 @@ __device__ __forceinline__ bool pose_nan(const Pose& p) {
            is_nan_bits2(p.k);
 }
 
-struct PixIn {
-    double x, y, ux, uy, al, ak;
-};
-// (32-bit BYTE offsets from uniform bases: the loads take the scalar base + 32-bit vector offset form -- no 64-bit address arithmetic per load)
-__device__ __forceinline__ PixIn load_pix(const double2* __restrict__ q, const double2* __restrict__ u, const double* __restrict__ alpha,
-                                          const double* __restrict__ alpha_k, unsigned i) {
-    const unsigned o16 = i << 4, o8 = i << 3;
-    const double2 qq = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(q) + o16);
-    const double2 uu = *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(u) + o16);
-    PixIn p;
-    p.x = qq.x, p.y = qq.y, p.ux = uu.x, p.uy = uu.y;
-    p.al = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(alpha) + o8);
-    p.ak = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(alpha_k) + o8);
-    return p;
-}
-
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------
@@ -66,7 +51,7 @@ __device__ __forceinline__ PixIn load_pix(const double2* __restrict__ q, const d
 // the pixels b chunk + slot, + P, + 2 P, ...  partials: [T][gridDim.x][kLmaSlots] (hypothesis-major, like ransac_lm_kernel's).
 // lists: irr_count[T] (zeroed per solve), irr_list[T][kLmaListCap] pixel indices in order of arrival (the rows stage sorts them).
 template <int NC>
-__global__ __launch_bounds__(kLB) void ransac_lma_kernel(const double2* __restrict__ q, const double2* __restrict__ u, const double* __restrict__ alpha,
+__global__ __launch_bounds__(kLB) __attribute__((amdgpu_waves_per_eu(5, 5))) void ransac_lma_kernel(const double2* __restrict__ q, const double2* __restrict__ u, const double* __restrict__ alpha,
                                                         const double* __restrict__ alpha_k, int64_t n, const double* __restrict__ hyp, int T,
                                                         const LmaCand cd, double* __restrict__ partials, int* __restrict__ irr_count,
                                                         int* __restrict__ irr_list, int64_t chunk, unsigned long long* __restrict__ clk_probe, int clk_bid) {
@@ -160,275 +145,6 @@ __global__ __launch_bounds__(kLB) void ransac_lma_kernel(const double2* __restri
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// rows: reduction of the partial rows + the listed pixels
-// ---------------------------------------------------------------------------------------------------
-// (256 threads, hypothesis t) -> row[kLmaRow] in LDS `s_row`
-__device__ __forceinline__ void lma_rows_stage(const double* __restrict__ partials, int nblocks, int T, int t, const double2* __restrict__ q,
-                                               const double2* __restrict__ u, const double* __restrict__ alpha, const double* __restrict__ alpha_k,
-                                               const double* __restrict__ hyp, const LmaCand& cd, const int* __restrict__ irr_count,
-                                               const int* __restrict__ irr_list, double* s_row) {
-    constexpr int SP = 16;           // slots, padded
-    constexpr int GR = kLB / SP;     // row groups
-    __shared__ double s_grp[GR][SP];
-    __shared__ int s_list[kLmaListCap], s_sorted[kLmaListCap];
-    constexpr int LBATCH = 64;       // listed pixels per round (one wave walks them; lists are short)
-    __shared__ double s_x[LBATCH][2 + 5 * kLmaKP + 2 * kLmaNC + 2 + 1];  // per listed pixel of the current batch: its terms of the row (+ 1: bank padding)
-    static_assert(kLmaSlots <= SP, "slots fit a padded row");
-    const int tid = threadIdx.x;
-    // ---- the workgroups' partial rows of hypothesis t: group gq adds the rows gq, gq + GR, ... in order, then the groups in order
-    {
-        const int gq = tid / SP, sl = tid - gq * SP;
-        double acc = 0.0;
-        if (sl < kLmaSlots) {
-            constexpr int U = 8;
-            for (int b = gq; b < nblocks; b += U * GR) {
-                double vv[U];
-#pragma unroll
-                for (int j = 0; j < U; ++j) {
-                    const int bj = b + j * GR;
-                    const double x = partials[((int64_t)t * nblocks + (bj < nblocks ? bj : gq)) * kLmaSlots + sl];
-                    vv[j] = bj < nblocks ? x : 0.0;
-                }
-#pragma unroll
-                for (int j = 0; j < U; ++j) acc = sl == kLmaG ? fmax(acc, vv[j]) : acc + vv[j];
-            }
-        }
-        s_grp[gq][sl] = acc;
-        __syncthreads();
-        if (tid < kLmaSlots) {
-            double r = s_grp[0][tid];
-#pragma unroll
-            for (int g2 = 1; g2 < GR; ++g2) r = tid == kLmaG ? fmax(r, s_grp[g2][tid]) : r + s_grp[g2][tid];
-            // A B C D E G -> row[0..5]; the fused scores -> row[kLmaRowScore ..]
-            if (tid < 6) s_row[tid] = r;
-            else s_row[kLmaRowScore + (tid - 6)] = r;
-        }
-        if (tid >= 6 && tid < kLmaRowScore) s_row[tid] = 0.0;
-    }
-    // ---- the listed pixels, sorted by pixel index (rank sort: the indices of a hypothesis are distinct)
-    const int raw = irr_count[t];
-    const int nl = min(raw, kLmaListCap);
-    for (int i = tid; i < nl; i += kLB) s_list[i] = irr_list[(int64_t)t * kLmaListCap + i];
-    __syncthreads();
-    for (int i = tid; i < nl; i += kLB) {
-        const int mine = s_list[i];
-        int rank = 0;
-        for (int j = 0; j < nl; ++j) rank += s_list[j] < mine ? 1 : 0;
-        s_sorted[rank] = mine;
-    }
-    __syncthreads();
-    if (tid == 0 && raw > kLmaListCap) s_row[7] = 1.0;  // overflow: guard (c)
-    if (nl == 0) return;  // (uniform)
-    const Pose pose = load_pose(hyp, t);
-    const double two_over = 2.0 / (2.0 + pose.k);
-    const LmaPlan plan = lma_plan();
-    constexpr int XW = 2 + 5 * kLmaKP + 2 * kLmaNC + 2;
-    for (int base = 0; base < nl; base += LBATCH) {
-        const int e = base + tid;
-        double* xr = s_x[tid < LBATCH ? tid : 0];
-        if (tid >= LBATCH) {
-        } else if (e < nl) {
-            const int i = s_sorted[e];
-            const PixIn px = load_pix(q, u, alpha, alpha_k, i);
-            const LmaPx v = lma_pixel(px.x, px.y, px.ux, px.uy, px.al, px.ak, pose, two_over);  // the bits the pixel pass saw
-            LmxWalk wk;
-            lmx_walk(px.x, px.y, px.ux, px.uy, px.al, px.ak, pose, two_over, plan, kLmaKP, wk);
-            // clamped: its exact terms enter the row, its frozen closed-form terms (a = |r(1)|^2, rho* = 1) leave it
-            xr[0] = v.clamped ? wk.c0 : 0.0;
-            xr[1] = v.clamped ? wk.g0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < kLmaKP; ++k) {
-                xr[2 + 5 * k + 0] = v.clamped ? wk.m[k] : 0.0;
-                xr[2 + 5 * k + 1] = v.clamped ? wk.s2[k] : 0.0;
-                xr[2 + 5 * k + 2] = v.clamped ? wk.c[k] : 0.0;
-                xr[2 + 5 * k + 3] = v.clamped ? wk.x2[k] : 0.0;
-                xr[2 + 5 * k + 4] = v.clamped ? wk.g[k] : 0.0;
-            }
-            // scores: the exact iterate's in place of the closed form's, at every fused iterate
-#pragma unroll
-            for (int c = 0; c < kLmaNC; ++c) {
-                double dc = 0.0, de = 0.0;
-                if (c < cd.nc) {
-                    bool in_a;
-                    double err_a;
-                    lma_score(v, cd.phi2[c], cd.tol2, in_a, err_a);
-                    const double ex = point_error(px.x, px.y, px.ux, px.uy, px.al, px.ak, pose, two_over, wk.rho[cd.steps[c]]);
-                    const bool in_x = ex < cd.tol;
-                    dc = (in_x ? 1.0 : 0.0) - (in_a ? 1.0 : 0.0);
-                    de = (in_x ? ex : 0.0) - err_a;
-                }
-                xr[2 + 5 * kLmaKP + 2 * c] = dc;
-                xr[2 + 5 * kLmaKP + 2 * c + 1] = de;
-            }
-            xr[XW - 2] = v.clamped ? v.a : 0.0;
-            xr[XW - 1] = v.clamped ? 1.0 : 0.0;
-        } else {
-            for (int j = 0; j < XW; ++j) xr[j] = 0.0;
-        }
-        __syncthreads();
-        // column j of the batch, in pixel order (one thread per column: the batch is short)
-        if (tid < XW) {
-            const int cntb = min(LBATCH, nl - base);
-            const bool is_max = tid == 1 || (tid >= 2 && tid < 2 + 5 * kLmaKP && ((tid - 2) % 5) == 4);
-            double r = 0.0;
-            for (int j = 0; j < cntb; ++j) r = is_max ? fmax(r, s_x[j][tid]) : r + s_x[j][tid];
-            if (tid < 2) s_row[kLmaRowX0 + tid] = is_max ? fmax(s_row[kLmaRowX0 + tid], r) : s_row[kLmaRowX0 + tid] + r;
-            else if (tid < 2 + 5 * kLmaKP) s_row[kLmaRowXk + (tid - 2)] = is_max ? fmax(s_row[kLmaRowXk + (tid - 2)], r) : s_row[kLmaRowXk + (tid - 2)] + r;
-            else if (tid < XW - 2) s_row[kLmaRowScore + (tid - 2 - 5 * kLmaKP)] += r;
-            else if (tid == XW - 2) s_row[0] -= r;  // A' = A - sum of the clamped pixels' frozen terms
-            else {
-                s_row[3] -= r;  // D' = D - clamped pixels
-                s_row[6] += r;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// decide: the trust-region loop on the closed forms
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ bool lma_band(double x, double thr) { return fabs(x - thr) <= kLmaBand * fabs(thr); }  // (false for NaN)
-
-// row: the hypothesis' row summed over the ranks.  Returns the guard that tripped (0: none) and fills st / hist / score.
-__device__ __forceinline__ int lma_decide(const double* row, int64_t n, const LmaCand& cd, bool nan_pose, LmScal& st, double* hist, bool& scored,
-                                          double& count, double& err) {
-    const double A = row[0], B = row[1], C = row[2], D = row[3], E = row[4], G = row[5];
-    const bool listed_walk = row[6] != 0.0;  // clamped pixels walk the planned radii beside the closed form
-    const LmaPlan plan = lma_plan();
-    int fallback = 0;
-    if (row[7] != 0.0) fallback = 8;
-    if (__builtin_isinf(A) || __builtin_isinf(B) || __builtin_isinf(C) || __builtin_isinf(D) || __builtin_isinf(E) || __builtin_isinf(G)) fallback = 1;
-    st.status = 1;
-    st.restart = 0;
-    st.n_hist = 0;
-    st.K = 0;
-    st.write_which = 0;
-    st.iteration = 0;
-    st.num_successful = 0;
-    st.num_unsuccessful = 0;
-    st.invalid_run = 0;
-    st.termination = -1;
-    st.rho_holds = -1;
-    st.launches = 1;
-    st.next_launch = 1;
-    st.predict = 0;
-    st.radius = kInitialRadius;
-    st.decrease_factor = 2.0;
-    double phi = 1.0;
-    double XC = row[kLmaRowX0], Xg = row[kLmaRowX0 + 1];
-    double cost = 0.5 * ((A + B) + XC), x_norm = sqrt((double)n);
-    double gmax = fmax(G, Xg);
-    st.initial_cost = cost;
-    bool on_plan = true;  // the state is the planned iterate st.n_hist and the radius is the planned one
-    if (lma_band(gmax, kGradientTol)) fallback = 2;
-    if (n == 0 || gmax <= kGradientTol) st.termination = RSDSFM_TERM_GRADIENT;
-    while (st.termination < 0 && !fallback) {
-        if (st.iteration >= kMaxIter) {
-            st.termination = RSDSFM_TERM_MAX_ITER;
-            break;
-        }
-        if (st.radius <= kMinRadius) {
-            st.termination = RSDSFM_TERM_MIN_RADIUS;
-            break;
-        }
-        st.iteration += 1;
-        const int kk = st.n_hist;
-        on_plan = on_plan && kk < kLmaKP && st.radius == plan.radius[kk];
-        if (listed_walk && !on_plan && B == B) {  // (NaN sums -- a NaN pixel -- make every step invalid whatever the listed pixels add)
-            fallback = 9;
-            break;
-        }
-        double psi, phic;
-        lma_phi_step(st.radius, phi, psi, phic);
-        const double p2 = phi * phi, pc2 = phic * phic;
-        const double* xk = row + kLmaRowXk + 5 * (kk < kLmaKP ? kk : 0);
-        const double XM = listed_walk ? xk[0] : 0.0, XS = listed_walk ? xk[1] : 0.0, XCc = listed_walk ? xk[2] : 0.0;
-        const double XX = listed_walk ? xk[3] : 0.0, Xgc = listed_walk ? xk[4] : 0.0;
-        const double model_change = __builtin_fma(B * p2, psi * (1.0 - 0.5 * psi), XM);
-        const double stepsq = __builtin_fma(C * p2, psi * psi, XS);
-        if (!(model_change > 0.0)) {  // HandleInvalidStep
-            if (model_change == model_change) {
-                fallback = 3;
-                break;
-            }
-            st.num_unsuccessful += 1;
-            st.invalid_run += 1;
-            if (st.invalid_run >= kMaxInvalid) {
-                st.termination = RSDSFM_TERM_FAILURE;
-                break;
-            }
-            st.radius *= 0.5;
-            continue;
-        }
-        if (model_change < 1e-25 * cost) {
-            fallback = 3;
-            break;
-        }
-        st.invalid_run = 0;
-        const double step_norm = sqrt(stepsq);
-        const double ptol = kParameterTol * (x_norm + kParameterTol);
-        if (lma_band(step_norm, ptol)) {
-            fallback = 4;
-            break;
-        }
-        if (step_norm <= ptol) {
-            st.termination = RSDSFM_TERM_PARAMETER;
-            break;
-        }
-        const double cost_change = 0.5 * __builtin_fma(B, p2 - pc2, XC - XCc);
-        if (lma_band(fabs(cost_change), kFunctionTol * cost)) {
-            fallback = 5;
-            break;
-        }
-        if (fabs(cost_change) <= kFunctionTol * cost) {
-            st.termination = RSDSFM_TERM_FUNCTION;
-            break;
-        }
-        const double rel = cost_change / model_change;
-        if (!(rel > 0.95)) {
-            fallback = 6;
-            break;
-        }
-        // HandleSuccessfulStep
-        hist[st.n_hist] = st.radius;
-        st.n_hist += 1;
-        phi = phic;
-        XC = XCc;
-        Xg = Xgc;
-        cost = 0.5 * (__builtin_fma(B, pc2, A) + XC);
-        x_norm = sqrt(__builtin_fma(C, pc2, __builtin_fma(2.0 * E, phi, D)) + XX);
-        gmax = fmax(G * phi, Xg);
-        st.radius = radius_accept(st.radius, rel);
-        st.decrease_factor = 2.0;
-        st.num_successful += 1;
-        if (lma_band(gmax, kGradientTol)) {
-            fallback = 2;
-            break;
-        }
-        if (gmax <= kGradientTol) st.termination = RSDSFM_TERM_GRADIENT;
-    }
-    st.cost = cost;
-    st.rho_holds = -1;
-    scored = false;
-    count = err = 0.0;
-    if (fallback) return fallback;
-    // the score of the final iterate, where the pixel pass fused it (the iterate after n_hist steps ON THE PLAN)
-    if (nan_pose) {  // every error is NaN: no inlier at any iterate
-        scored = true;
-        return 0;
-    }
-    const double phi2 = phi * phi;
-    for (int c = 0; c < cd.nc; ++c)
-        if (cd.steps[c] == st.n_hist && cd.phi2[c] == phi2) {
-            count = row[kLmaRowScore + 2 * c];
-            err = row[kLmaRowScore + 2 * c + 1];
-            scored = true;
-        }
-    return 0;
-}
-
 // flags: the RANSAC's flag words (ransac_host.hip): [1] += hypotheses that ended where no score was fused (+ their list), [3] |= 2 a guard
 // tripped (the run starts over on the iterate-by-iterate kernels), [4 + min(steps, 3)] histogram of the accepted steps
 __device__ __forceinline__ void lma_publish(int t, const LmScal& st, const double* hist_l, int fallback, bool scored, double count, double err,
@@ -466,7 +182,7 @@ __global__ __launch_bounds__(kLB) void ransac_lma_rows_decide_kernel(const doubl
     // the minimal solver of this run met an SVD operand outside the range of its function cores (minimal9_kernels.hip): reported through the
     // run's flag word like ransac_lm_kernel does -- the host starts the run over with the standard functions
     if (t == 0 && threadIdx.x == 0 && m9_core_flag && *m9_core_flag == m9_core_epoch) atomicOr(&flags[3], 1);
-    lma_rows_stage(partials, nblocks, T, t, q, u, alpha, alpha_k, hyp, cd, irr_count, irr_list, s_row);
+    lma_rows_stage(partials, nblocks, T, t, q, u, alpha, alpha_k, load_pose(hyp, t), cd, irr_count, irr_list, s_row);
     __syncthreads();
     if (threadIdx.x == 0) {
         LmScal st;
@@ -474,7 +190,7 @@ __global__ __launch_bounds__(kLB) void ransac_lma_rows_decide_kernel(const doubl
         bool scored;
         double count, err;
         const Pose pose = load_pose(hyp, t);
-        const int fb = lma_decide(s_row, n, cd, pose_nan(pose), st, hist_l, scored, count, err);
+        const int fb = lma_decide(s_row, n, cd, cd.plan, pose_nan(pose), st, hist_l, scored, count, err);
         lma_publish(t, st, hist_l, fb, scored, count, err, states, flags, scored_out, trial_count, trial_err, flags + 4, unscored_list, guard_word);
     }
 }
@@ -486,7 +202,7 @@ __global__ __launch_bounds__(kLB) void ransac_lma_rows_kernel(const double* __re
                                                              const int* __restrict__ irr_count, const int* __restrict__ irr_list, double* __restrict__ rows) {
     __shared__ double s_row[kLmaRow];
     const int t = blockIdx.x;
-    lma_rows_stage(partials, nblocks, T, t, q, u, alpha, alpha_k, hyp, cd, irr_count, irr_list, s_row);
+    lma_rows_stage(partials, nblocks, T, t, q, u, alpha, alpha_k, load_pose(hyp, t), cd, irr_count, irr_list, s_row);
     __syncthreads();
     if (threadIdx.x < kLmaRow) rows[(int64_t)t * kLmaRow + threadIdx.x] = s_row[threadIdx.x];
 }
@@ -497,8 +213,10 @@ __global__ __launch_bounds__(64) void ransac_lma_decide_kernel(const double* __r
                                                               const double* __restrict__ hyp, const LmaCand cd, LmState* states, int* flags,
                                                               int* __restrict__ scored_out, double* __restrict__ trial_count,
                                                               double* __restrict__ trial_err, int* __restrict__ unscored_list, int* guard_word,
-                                                              double* __restrict__ cnt_rt, int cnt_stride) {
+                                                              double* __restrict__ cnt_rt, int cnt_stride, const int* __restrict__ m9_core_flag, int m9_core_epoch) {
     const int t = blockIdx.x * 64 + threadIdx.x;
+    // (the minimal solver's range flag: replicated -- every rank ran the same solver on the same points -- and read locally)
+    if (t == 0 && m9_core_flag && *m9_core_flag == m9_core_epoch) atomicOr(&flags[3], 1);
     if (t >= T) return;
     double row[kLmaRow];
     for (int j = 0; j < kLmaRow; ++j) {
@@ -515,7 +233,7 @@ __global__ __launch_bounds__(64) void ransac_lma_decide_kernel(const double* __r
     bool scored;
     double count, err;
     const Pose pose = load_pose(hyp, t);
-    const int fb = lma_decide(row, n_total, cd, pose_nan(pose), st, hist_l, scored, count, err);
+    const int fb = lma_decide(row, n_total, cd, cd.plan, pose_nan(pose), st, hist_l, scored, count, err);
     lma_publish(t, st, hist_l, fb, scored, count, err, states, flags, scored_out, trial_count, trial_err, nullptr, unscored_list, guard_word);
     if (cnt_rt && scored && !fb) {
         int cc = -1;
@@ -532,6 +250,7 @@ __global__ __launch_bounds__(64) void ransac_lma_decide_kernel(const double* __r
 LmaCand lma_candidates(const int* steps, int nc, double tol) {
     LmaCand cd;
     const LmaPlan plan = lma_plan();
+    cd.plan = plan;
     cd.nc = std::min(std::max(nc, 1), (int)kLmaNC);
     for (int c = 0; c < kLmaNC; ++c) {
         const int s = c < cd.nc ? std::min(std::max(steps[c], 1), kLmaKP - 1) : 1;
@@ -545,12 +264,17 @@ LmaCand lma_candidates(const int* steps, int nc, double tol) {
     return cd;
 }
 
-// workgroups of the pixel pass and the pixels each owns
-int ransac_lma_grid(const Ctx* c, int64_t n, int T, int64_t* chunk_out) {
+// workgroups of the pixel pass and the pixels each owns: ONE round of the chip's resident workgroups (every workgroup does the same work: they
+// start and end together; 2048 workgroups on 1280 resident slots ran 1.6 rounds, the second one 60 % empty), fewer for small inputs
+// (>= 8 pixels per slot and workgroup)
+int ransac_lma_grid(const Ctx* c, int64_t n, int T, int64_t* chunk_out, int blocks_per_cu) {
     const int P = std::max(1, kLB / std::max(T, 1));
-    // >= 8 pixels per slot and workgroup, at most 8 workgroups per CU
+    if (n <= 0) {  // (an empty slab of the column-tiled solve: one workgroup that finds nothing to do)
+        *chunk_out = P;
+        return 1;
+    }
     int64_t g = (n + (int64_t)P * 8 - 1) / ((int64_t)P * 8);
-    g = std::max<int64_t>(1, std::min<int64_t>(g, (int64_t)c->num_cus * 8));
+    g = std::max<int64_t>(1, std::min<int64_t>(g, (int64_t)c->num_cus * std::max(1, std::min(blocks_per_cu, 8))));
     int64_t chunk = (n + g - 1) / g;
     chunk = ((chunk + P - 1) / P) * P;  // whole rounds of the P slots
     g = std::max<int64_t>(1, (n + chunk - 1) / chunk);
@@ -566,8 +290,18 @@ size_t ransac_lma_list_ints(int batch) { return (size_t)batch * kLmaListCap; }
 
 static int lma_pass_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n, const double* hyp, int T,
                            const LmaCand& cd, double* partials, int* irr_count, int* irr_list, int* grid_out, unsigned long long* clk = nullptr) {
+    // resident workgroups per CU of the kernel that is about to run (registers set it: 5 at 94 VGPRs)
+    static int occ[kLmaNC + 1] = {0, 0, 0, 0};
+    const int nc = std::min(std::max(cd.nc, 1), (int)kLmaNC);
+    if (occ[nc] == 0) {
+        int nb = 0;
+        const void* fn = nc == 1 ? reinterpret_cast<const void*>(&ransac_lma_kernel<1>) : nc == 2 ? reinterpret_cast<const void*>(&ransac_lma_kernel<2>) : reinterpret_cast<const void*>(&ransac_lma_kernel<3>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, kLB, 0) != hipSuccess || nb < 1) nb = 4;
+        occ[nc] = nb;
+    }
     int64_t chunk;
-    const int grid = ransac_lma_grid(c, n, T, &chunk);
+    static const int grid_override = getenv("RSDSFM_LMA_BLOCKS_PER_CU") ? atoi(getenv("RSDSFM_LMA_BLOCKS_PER_CU")) : 0;  // (experiments)
+    const int grid = ransac_lma_grid(c, n, T, &chunk, grid_override > 0 ? grid_override : occ[nc]);
     *grid_out = grid;
     const double2* q2 = reinterpret_cast<const double2*>(q);
     const double2* u2 = reinterpret_cast<const double2*>(u);
@@ -623,10 +357,10 @@ int ransac_lma_rows_launch(Ctx* c, const double* q, const double* u, const doubl
 // ... and the decide stage on the gathered rows
 int ransac_lma_decide_rows_launch(Ctx* c, const double* rows_all, int nranks, int64_t rank_stride, int T, int64_t n_total, const double* hyp,
                                   LmState* states, int* flags, int* scored, double* trial_count, double* trial_err, double tol, const int* cand_steps,
-                                  int ncand, int* unscored_list, int* guard_word, double* cnt_rt, int cnt_stride) {
+                                  int ncand, int* unscored_list, int* guard_word, double* cnt_rt, int cnt_stride, const int* m9_core_flag, int m9_core_epoch) {
     const LmaCand cd = lma_candidates(cand_steps, ncand, tol);
     hipLaunchKernelGGL(ransac_lma_decide_kernel, dim3((T + 63) / 64), dim3(64), 0, c->stream, rows_all, nranks, rank_stride, T, n_total, hyp, cd, states,
-                       flags, scored, trial_count, trial_err, unscored_list, guard_word, cnt_rt, cnt_stride);
+                       flags, scored, trial_count, trial_err, unscored_list, guard_word, cnt_rt, cnt_stride, m9_core_flag, m9_core_epoch);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

@@ -120,6 +120,10 @@ struct Ctx {
     int lma_hold = 0;              // > 0: that many of the context's next RANSACs run iterate by iterate (set to 16 by a run whose guards tripped; renewed by an iterate-by-iterate run that ends in a tie the analytic arithmetic could not break: noise-free data)
     int64_t lma_restarts = 0;      // RANSAC runs of this context that started over because a guard tripped (rsdsfm_lma_restarts)
     int lma_last_guard = 0;        // bit set of the guards that tripped last (1 << reason: lma_common.hpp; 1 << 7: tie)
+    // the dense depth solve's fast path on the analytic trajectory (depth_lma_kernels.hip): the solve's list of clamped pixels (two halves used
+    // alternately: the follow-up launch of one solve zeroes the counter the next one starts from)
+    int* d_lma_list = nullptr;
+    int depth_lma_parity = 0;
     int lma_cand[2] = {2, 1};      // the two iterates (accepted steps) whose scores the next pixel pass fuses: where most hypotheses of the previous solve ended
     int ransac_spec_miss = 0;  // consecutive RANSACs (saturating at 2) whose speculated final stage did not count; below 2 the frame solve enqueues the refinement behind the speculated stage
     int frame_dense_hint = 1;  // frame solve: the previous frame kept every pixel (dense flow) -> set the RANSAC up for n = rows * cols without waiting for the count
@@ -248,6 +252,14 @@ int depth_lm_fused_launch(Ctx* c, const double* q, const double* u, const double
 int depth_lm_reduce_launch(Ctx* c, int64_t n, double* d_row);
 void fill_lm_summary(const LmState& st, rsdsfm_lm_summary* s);  // capi.hip
 int depth_lm_decide_rows_launch(Ctx* c, const double* d_rows, int nrows, int64_t n_total, int launch_id);
+// depth_lma_kernels.hip: the fast path on the analytic LM trajectory (launch 0 + the follow-up launch)
+bool depth_lma_allowed(const Ctx* c, int64_t n);
+int depth_lma_batch_launch(Ctx* const* cs, int count, const double* const* q, const double* const* u, const double* const* a,
+                           const double* const* ak, const int64_t* n, const Pose* poses, double* const* rho);
+int depth_lma_row_doubles();
+int depth_lma_shard_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n, const Pose& pose, double* rho, double* d_row);
+int depth_lma_shard_finish_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n, const Pose& pose, double* rho,
+                                  const double* d_rows_all, int nranks, int64_t n_total);
 
 }  // namespace rsdsfm
 
@@ -367,7 +379,8 @@ int ransac_lma_rows_launch(Ctx* c, const double* q, const double* u, const doubl
                            double* partials, double tol, const int* cand_steps, int ncand, int* irr_count, int* irr_list, double* rows);
 int ransac_lma_decide_rows_launch(Ctx* c, const double* rows_all, int nranks, int64_t rank_stride, int T, int64_t n_total, const double* hyp,
                                   LmState* states, int* flags, int* scored, double* trial_count, double* trial_err, double tol, const int* cand_steps,
-                                  int ncand, int* unscored_list, int* guard_word, double* cnt_rt, int cnt_stride);
+                                  int ncand, int* unscored_list, int* guard_word, double* cnt_rt, int cnt_stride, const int* m9_core_flag = nullptr,
+                                  int m9_core_epoch = 0);
 }  // namespace rsdsfm
 
 namespace rsdsfm {

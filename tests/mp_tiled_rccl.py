@@ -120,8 +120,10 @@ def main():
         holed = clean.copy()
         holed[10:30, 300:340] = 0.0          # columns of rank 1's slab
         bad = clean.copy()
-        bad[17, 301] = (3.0, -128.0)         # rank 1's slab
+        bad[17, 301] = (3.0, 1e160)         # rank 1's slab
         frames = [clean, clean, holed, clean, clean, bad, clean]
+        # 1: the iterate-by-iterate kernels (the ones whose function cores a NaN pixel leaves); 0 (default): the analytic LM trajectory
+        solver.set_lm_arithmetic(int(os.environ.get("RSDSFM_TEST_LM_ARITHMETIC", "0")))
         dm = torch.zeros(cols * rows, dtype=torch.float64, device=dev)
         seq = []
         for f in frames:
@@ -134,7 +136,7 @@ def main():
                             path_flags=r["info"]["path_flags"], collectives=r["info"]["collectives"], host_syncs=r["info"]["host_syncs"]))
         gathered = [None] * world
         dist.all_gather_object(gathered, seq)
-        out.update(sequence=gathered, restarts=solver.ransac_restarts())
+        out.update(sequence=gathered, restarts=solver.ransac_restarts(), lma_restarts=solver.lma_restarts()[0])
         solver.dist_finalize()
         if rank == 0:
             with open(os.environ["RSDSFM_TILED_OUT"], "w") as f:

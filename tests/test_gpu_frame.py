@@ -628,7 +628,7 @@ def test_stage_pipeline_on_device_buffers_equals_one_call_solve(rsdsfm, flow_mod
 
 def test_frame_solve_starts_over_with_the_standard_functions(rsdsfm):
     """round 0 of the depth solves and the minimal solver run sqrt / reciprocal / division through their in-range cores; a frame with a
-    pixel whose Jacobian vanishes -- alpha = 1 + gamma f_y / h = 0 exactly: h = 64 rows, gamma = 0.5, f_y = -128 px -- makes the one-call
+    pixel whose flow is 1e160 px -- alpha_k overflows, beta = alpha + 0 x inf = NaN: a NaN pixel -- makes the one-call
     solve start its RANSAC over with the standard functions behind the speculated chain (which leaves at once).  Same results as with the
     standard functions from the start, bit for bit, in the single solve and in the sequence solve; the dense frames around it in the
     sequence are not affected."""
@@ -640,7 +640,7 @@ def test_frame_solve_starts_over_with_the_standard_functions(rsdsfm):
     gamma = 0.5
     clean = np.array(d["flow_img"])
     bad = clean.copy()
-    bad[17, 301] = (3.0, -128.0)
+    bad[17, 301] = (3.0, 1e160)
     imgs = {"clean": torch.from_numpy(clean).to(dev), "bad": torch.from_numpy(bad).to(dev)}
     outs = {}
     for math in (0, 1, 2):  # 2: the default arithmetic of the depth solves (analytic LM trajectory): no restart of either kind, the same bits
@@ -664,6 +664,7 @@ def test_frame_solve_starts_over_with_the_standard_functions(rsdsfm):
             rs = call([11, 11, 11])
             seq = [(int(x.n_points), int(x.num_inliers), int(x.best_trial), bytes(bytearray(np.array(x.v[:]).tobytes())), dm.cpu().numpy().tobytes()) for x, dm in zip(rs, dms)]
             restarts_all = s.ransac_restarts()
+            # (the analytic pass takes a NaN pixel like the reference takes it: five invalid steps per trial, no guard, no cores, no restart)
             assert s.lma_restarts()[0] == 0
         outs[math] = (res, seq)
         assert restarts_single == (1 if math == 0 else 0)

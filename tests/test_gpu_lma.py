@@ -165,3 +165,91 @@ def test_frame_solve_is_the_same_in_both_arithmetics(solver, rsdsfm):
                 assert np.array_equal(a[key], x[key]), key
             assert np.array_equal(da, dx, equal_nan=True)
     assert solver.lma_restarts()[0] == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+# the dense depth solve on the analytic trajectory (depth_lma_kernels.hip)
+# ---------------------------------------------------------------------------------------------------
+INT_KEYS = ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination")
+
+
+def _depth_both(solver, *args):
+    solver.set_lm_arithmetic(0)
+    ra, sa = solver.estimate_inverse_depths(*args, mode=1)
+    solver.set_lm_arithmetic(1)
+    rx, sx = solver.estimate_inverse_depths(*args, mode=1)
+    solver.set_lm_arithmetic(0)
+    return ra, sa, rx, sx
+
+
+@pytest.mark.parametrize("cfg,rows,cols,kw", [(3, 135, 240, {}), (1, 96, 128, {}), (5, 360, 640, {}), (3, 180, 320, dict(v=np.array([0.002, 0.001, 0.03]))),
+                                              (2, 720, 1280, {})])
+def test_dense_depth_analytic_equals_oracle_mode2_and_iterate_by_iterate(oracle, rsdsfm, cfg, rows, cols, kw):
+    """rho of the analytic fast path = the oracle's mode 2 BIT FOR BIT (the same closed form per pixel, the same planned phi; clamped pixels
+    -- the forward-motion case has some -- from the same exact recurrence), the LM decisions those of the iterate-by-iterate kernels and of
+    the oracle's mode 1, rho within 1e-9 of theirs; repeated solves (predictor warm) give the same bits as the first (predictor cold)"""
+    d = rsdsfm.synth.make_config(cfg, rows=rows, cols=cols, **kw)
+    q, u, a, ak, t = d["q"], d["u"], d["alpha"], d["alpha_k"], d["truth"]
+    v = t["v"] / np.linalg.norm(t["v"]) + np.array([0.01, -0.02, 0.005])  # (not the true pose: a residual is left)
+    v /= np.linalg.norm(v)
+    w = t["w"] * 1.1
+    with rsdsfm.Solver(0) as s:
+        n0 = s.lma_restarts()[0]
+        ra, sa, rx, sx = _depth_both(s, q, u, v, w, 0.0, a, ak)
+        ra2, sa2 = s.estimate_inverse_depths(q, u, v, w, 0.0, a, ak, mode=1)
+        assert s.lma_restarts()[0] == n0
+    r2, s2 = oracle.estimate_inverse_depths(q, u, v, w, 0.0, a, ak, mode=2)
+    r1, s1 = oracle.estimate_inverse_depths(q, u, v, w, 0.0, a, ak, mode=1)
+    assert np.array_equal(ra, r2) and np.array_equal(ra, ra2)
+    for key in INT_KEYS:
+        assert sa[key] == sx[key] == s1[key] == s2[key] == sa2[key], (key, sa, sx, s1)
+    assert np.allclose(ra, rx, rtol=1e-9, atol=1e-13) and np.allclose(ra, r1, rtol=1e-9, atol=1e-13)
+    assert abs(sa["final_cost"] - s1["final_cost"]) <= 1e-10 * abs(s1["final_cost"]) + 1e-20 * s1["initial_cost"]
+    assert abs(sa["initial_cost"] - s1["initial_cost"]) <= 1e-11 * s1["initial_cost"] and sa["final_radius"] == s1["final_radius"]
+
+
+def test_dense_depth_analytic_batched_entry_point_and_a_guard(oracle, rsdsfm):
+    """the batched entry point (two problems per launch: DeepFlow-like and noise-free, i.e. other iterates are final) on the analytic path; and a
+    problem whose points all sit at the focus of expansion: the list of clamped pixels overflows (guard c), the solve is left unfinished and
+    rsdsfm_depth_finish_dev runs it again iterate by iterate -- same results as rsdsfm_set_lm_arithmetic(1), counted"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(dev)
+    da, db = rsdsfm.synth.make_config(5, rows=240, cols=320), rsdsfm.synth.make_config(2, rows=240, cols=320)
+    t = da["truth"]
+    v = t["v"] / np.linalg.norm(t["v"])
+    with torch.cuda.stream(stream):
+        solvers = [rsdsfm.Solver(0, stream=stream.cuda_stream) for _ in range(2)]
+        data = [(da["q"], da["u"], da["alpha"], da["alpha_k"]), (db["q"], db["u"], db["alpha"], db["alpha_k"])]
+        dev_t = [[torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in c] for c in data]
+        rhos = [torch.zeros(len(c[2]), dtype=torch.float64, device=dev) for c in data]
+        probs = [dict(d_q=t_[0].data_ptr(), d_u=t_[1].data_ptr(), d_alpha=t_[2].data_ptr(), d_alpha_k=t_[3].data_ptr(), d_rho=r.data_ptr(), n=len(c[2]), v=v, w=t["w"], k=0.0)
+                 for t_, r, c in zip(dev_t, rhos, data)]
+        call = rsdsfm.prepared_depth_batch(solvers, probs)
+        for rep in range(3):
+            call()
+            for i, p in enumerate(probs):
+                sm, _ = solvers[i].depth_finish_dev(p["d_q"], p["d_u"], p["n"], v, t["w"], 0.0, p["d_alpha"], p["d_alpha_k"], p["d_rho"])
+                r2, s2 = oracle.estimate_inverse_depths(*data[i][:2], v, t["w"], 0.0, *data[i][2:], mode=2)
+                for key in INT_KEYS:
+                    assert sm[key] == s2[key], (rep, i, key, sm, s2)
+                assert np.array_equal(rhos[i].cpu().numpy(), r2), (rep, i)
+        assert all(s.lma_restarts()[0] == 0 for s in solvers)
+        for s in solvers:
+            s.close()
+    # a guard: every pixel clamped
+    rng = np.random.default_rng(1)
+    n = 6000
+    q = rng.normal(size=(n, 2)) * 1e-5
+    u = rng.normal(size=(n, 2)) * 1e-3
+    a, ak = np.ones(n), np.full(n, 0.5)
+    vv, ww = np.array([0.0, 0.0, 1.0]), np.array([0.001, -0.002, 0.0005])
+    with rsdsfm.Solver(0) as s:
+        ra, sa, rx, sx = _depth_both(s, q, u, vv, ww, 0.0, a, ak)
+        assert s.lma_restarts()[0] == 1
+        assert np.array_equal(ra, rx) and all(sa[k] == sx[k] for k in INT_KEYS)
+        rb, sb = s.estimate_inverse_depths(q, u, vv, ww, 0.0, a, ak, mode=1)  # no hold for the dense solve: a result is a function of its inputs alone
+        assert s.lma_restarts()[0] == 2 and np.array_equal(rb, rx)
+    r1, s1 = oracle.estimate_inverse_depths(q, u, vv, ww, 0.0, a, ak, mode=1)
+    assert np.allclose(ra, r1, rtol=1e-9, atol=1e-13) and all(sa[k] == s1[k] for k in INT_KEYS)

@@ -30,7 +30,7 @@ def _native_threads(rsdsfm, torch, d, nranks, **kw):
     dev = torch.device("cuda", 0)
     rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
     img = torch.from_numpy(d["flow_img"]).to(dev)
-    tr = ThreadTransport(nranks)
+    tr = ThreadTransport(nranks, timeout=float(__import__("os").environ.get("RSDSFM_TEST_BARRIER_TIMEOUT", "120")))
     outs, errs = [None] * nranks, [None] * nranks
     kw = dict(kw)
     kw.setdefault("flow_index_mode", rsdsfm.FLOW_GATHERED)  # (tests of the reference's rank-indexed flow pass FLOW_COMPAT_RANK)
@@ -67,9 +67,10 @@ def _native_threads(rsdsfm, torch, d, nranks, **kw):
         th.start()
     for th in ths:
         th.join()
-    for e in errs:
-        if e is not None:
-            raise e
+    # (the error that matters is the one that is not "a peer left": a rank that fails breaks the barrier for the others)
+    real = [e for e in errs if e is not None and "all-gather failed" not in str(e) and "all-reduce failed" not in str(e)]
+    for e in real + [e for e in errs if e is not None]:
+        raise e
     r0 = outs[0]
     for r in outs[1:]:  # every rank returns the same pose, counts and the same full depth map
         assert r["n"] == r0["n"] and r["num_inliers"] == r0["num_inliers"] and r["best_trial"] == r0["best_trial"]
@@ -104,7 +105,7 @@ def test_native_tiled_warm_path_and_a_frame_that_is_not_dense_after_all(rsdsfm):
         for i, f in enumerate(frames):
             singles.append(_single(rsdsfm, torch, dict(d, flow_img=f), stream, seed=3, **kw))
     nranks = 3
-    tr = ThreadTransport(nranks)
+    tr = ThreadTransport(nranks, timeout=float(__import__("os").environ.get("RSDSFM_TEST_BARRIER_TIMEOUT", "120")))
     outs, errs = [[] for _ in range(nranks)], [None] * nranks
     imgs = [torch.from_numpy(f).to(dev) for f in frames]
 
@@ -155,7 +156,7 @@ def test_native_tiled_warm_path_and_a_frame_that_is_not_dense_after_all(rsdsfm):
 
 def test_native_tiled_function_cores_and_a_restart_on_one_rank(rsdsfm):
     """The tiled RANSAC runs the minimal solver's SVD and round 0 of the LM solves through the in-range function cores like the single-context
-    solve.  A pixel whose Jacobian vanishes (alpha = 1 + gamma f_y / h = 0 exactly: h = 64 rows, gamma = 0.5, f_y = -128 px) lies in ONE
+    solve.  A pixel with a flow of 1e160 px (alpha_k overflows, beta = alpha + 0 x inf = NaN: a NaN pixel) lies in ONE
     rank's slab: that rank's rows carry the flag, every rank sees it, all start the RANSAC over with the standard functions (path_flags bit
     2) -- and the results equal the single-context solve's and those of a communicator set to the standard functions from the start."""
     import torch
@@ -168,12 +169,12 @@ def test_native_tiled_function_cores_and_a_restart_on_one_rank(rsdsfm):
     gamma = 0.5
     clean = np.array(d["flow_img"])
     bad = clean.copy()
-    bad[17, 301] = (3.0, -128.0)  # column 301: the second of three slabs
+    bad[17, 301] = (3.0, 1e160)  # column 301: the second of three slabs
     kw = dict(trials=20, tol=0.05, seed=11, flow_index_mode=rsdsfm.FLOW_GATHERED)
     nranks = 3
     results = {}
-    for math in (0, 1):
-        tr = ThreadTransport(nranks)
+    for math in (0, 1, 2):  # 2: the default arithmetic of the depth solves (analytic LM trajectory): no cores to leave, same bits
+        tr = ThreadTransport(nranks, timeout=float(__import__("os").environ.get("RSDSFM_TEST_BARRIER_TIMEOUT", "120")))
         outs, errs = [[] for _ in range(nranks)], [None] * nranks
         imgs = [torch.from_numpy(f).to(dev) for f in (clean, bad, clean)]
 
@@ -182,7 +183,8 @@ def test_native_tiled_function_cores_and_a_restart_on_one_rank(rsdsfm):
                 torch.cuda.set_device(0)
                 c0, sc, per = rsdsfm.tiled_slab_bounds(cols, nranks, rank)
                 with rsdsfm.Solver(0) as s:
-                    s.set_ransac_math(math)
+                    s.set_ransac_math(math & 1)
+                    s.set_lm_arithmetic(1 if math < 2 else 0)
                     s.dist_set_transport(nranks, rank, *tr.callbacks(rank))
                     for img in imgs:
                         slab = img[:, c0:c0 + sc, :].contiguous()
@@ -209,7 +211,7 @@ def test_native_tiled_function_cores_and_a_restart_on_one_rank(rsdsfm):
             assert outs[rank] == outs[0], (math, rank)
         assert [o[8] for o in outs[0][:3]] == ([0, 4, 0] if math == 0 else [0, 0, 0]) and outs[0][3] == (1 if math == 0 else 0)
         results[math] = [o[:8] for o in outs[0][:3]]
-    assert results[0] == results[1]
+    assert results[0] == results[1] == results[2]
     assert results[0][0] == results[0][2] and results[0][0] != results[0][1]
     with torch.cuda.stream(stream):
         for f, got in zip((clean, bad), results[0][:2]):
@@ -580,7 +582,8 @@ def test_native_tiled_over_a_real_two_rank_rccl_communicator(rsdsfm, tmp_path, f
     assert np.isclose(got["depth_sum_tiled"], rho.sum(), rtol=1e-12) and got["depth_info"]["nranks"] == 2
 
 
-def test_native_tiled_paths_over_a_real_two_rank_rccl_communicator(rsdsfm, tmp_path):
+@pytest.mark.parametrize("lm_arithmetic", [1, 0])
+def test_native_tiled_paths_over_a_real_two_rank_rccl_communicator(rsdsfm, tmp_path, lm_arithmetic):
     """The driver's speculative paths over RCCL itself (two processes, tests/mp_tiled_rccl.py with RSDSFM_TEST_SEQUENCE): cold, ahead on the
     dense counts, a frame that is not dense after all (restart through the counts exchange), a function-core miss in ONE rank's slab (every
     rank restarts the RANSAC).  Each path issues another sequence of collectives; the two processes only finish if they pair up.  Every
@@ -589,7 +592,7 @@ def test_native_tiled_paths_over_a_real_two_rank_rccl_communicator(rsdsfm, tmp_p
 
     out = tmp_path / "seq.json"
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", RSDSFM_TILED_OUT=str(out), RSDSFM_TEST_FLOW_MODE="1", RSDSFM_TEST_SEQUENCE="1", NCCL_SOCKET_IFNAME="lo",
-               NCCL_IB_DISABLE="1")
+               NCCL_IB_DISABLE="1", RSDSFM_TEST_LM_ARITHMETIC=str(lm_arithmetic))
     env.pop("NCCL_HOSTID", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", "29657",
            os.path.join(ROOT, "tests", "mp_tiled_rccl.py")]
@@ -605,15 +608,16 @@ def test_native_tiled_paths_over_a_real_two_rank_rccl_communicator(rsdsfm, tmp_p
     assert len(seq) == 2 and len(seq[0]) == 7 and seq[0] == seq[1]  # both ranks: same results, same paths, same numbers of collectives
     # cold / ahead / ahead but the frame has a hole: started over / cold (the previous frame was not dense) / ahead / ahead, and the RANSAC
     # started over with the standard functions / ahead (standard functions: no restart)
-    assert [s["path_flags"] & 0xFF for s in seq[0]] == [0, 1, 3, 0, 1, 5, 1]
-    assert got["restarts"] == 1
+    # (lm_arithmetic 0, the default: the analytic pass takes the NaN pixel as the reference takes it -- no cores to leave, no restart)
+    assert [s["path_flags"] & 0xFF for s in seq[0]] == ([0, 1, 3, 0, 1, 5, 1] if lm_arithmetic == 1 else [0, 1, 3, 0, 1, 1, 1])
+    assert got["restarts"] == (1 if lm_arithmetic == 1 else 0) and got["lma_restarts"] == 0
     stream = torch.cuda.Stream(torch.device("cuda", 0))
     d = rsdsfm.synth.make_config(5, rows=64, cols=480)
     clean = np.array(d["flow_img"])
     holed = clean.copy()
     holed[10:30, 300:340] = 0.0
     bad = clean.copy()
-    bad[17, 301] = (3.0, -128.0)
+    bad[17, 301] = (3.0, 1e160)
     ones = {}
     with torch.cuda.stream(stream):
         for name, f in (("clean", clean), ("holed", holed), ("bad", bad)):
@@ -669,7 +673,7 @@ def _depth_threads(rsdsfm, torch, d, v, w, k, nranks, mode, repeat=1):
 
     dev = torch.device("cuda", 0)
     n = len(d["alpha"])
-    tr = ThreadTransport(nranks)
+    tr = ThreadTransport(nranks, timeout=float(__import__("os").environ.get("RSDSFM_TEST_BARRIER_TIMEOUT", "120")))
     outs, errs = [None] * nranks, [None] * nranks
 
     def work(rank):

@@ -246,7 +246,7 @@ def parse_args(argv=None):
     ap.add_argument("--nbuf", type=int, default=7, help="rotating HBM buffer sets (7 x 59 MB > 256 MiB L3)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU feeding independent batches (sequence-throughput mode, BASELINE configs[4])")
     ap.add_argument("--pairs-per-step", type=int, default=64, help="depth workloads: one step = one chunk of this many consecutive frame pairs of the sequence (default 64)")
-    ap.add_argument("--batch", type=int, default=4, help="independent frame pairs per launch of the batched depth fast path (1..8, one solver context each)")
+    ap.add_argument("--batch", type=int, default=8, help="independent frame pairs per launch of the batched depth fast path (1..8, one solver context each)")
     ap.add_argument("--depth-variant", type=int, default=None, help="rsdsfm_set_depth_variant: 0 register-staged, 1 LDS-DMA, 2 decision fused into launch 0")
     ap.add_argument("--trials", type=int, default=50, help="RANSAC trials of the full solve (report section 5.4 used 50)")
     ap.add_argument("--tol", type=float, default=0.05, help="RANSAC tolerance (reference main.cc:310)")
@@ -578,7 +578,7 @@ def run(args):
         n1 = max(20, npairs // 8)
         el1 = timed(lambda i: single_calls[i % len(single_calls)](), n1, 5)
 
-        # dominant-kernel duration.  LM mode: the streaming kernel (launch 0 of the batched solve = `depth_lm_batch_kernel`, B pairs per launch)
+        # dominant-kernel duration.  LM mode: the streaming kernel (launch 0 of the batched solve = `depth_lma_batch_kernel`, B pairs per launch)
         # carries its DISPATCH's own start / stop timestamps when profiling is on for the batch's first context (rsdsfm_set_profiling:
         # hipExtLaunchKernel events -- what rocprofv3 --kernel-trace reports for the kernel, no inter-launch gap in it).  Bursts of BURST
         # ordinary batched calls (streaming launch + decide / apply launch) back to back on stream 0, the other streams idle; the record
@@ -614,8 +614,9 @@ def run(args):
                 ts = sorted(a_.elapsed_time(b_) / BURST for a_, b_ in zip(e0, e1))
             kern_ms, kern_med = float(np.mean(ts)), float(ts[len(ts) // 2])
 
-        # (its template argument: launch 0 takes the Jacobi scaling through the in-range function cores -- reference-arithmetic library only)
-        batch_kernel = "depth_lm_batch_kernel<%s>" % ("false" if args.arith == "fused" else "true")
+        # the streaming kernel of the batched fast path: the analytic LM trajectory's (depth_lma_kernels.hip; its template argument: pixel
+        # pairs per thread and iteration)
+        batch_kernel = "depth_lma_batch_kernel<2>"
         if rank == 0:
             alg_bytes = ALG_BYTES_PER_PIXEL_DEPTH * n * B
             achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
@@ -638,7 +639,7 @@ def run(args):
                            "verified": bool(max_rel < 1e-8 and (mode != 1 or (extra == 0 and summary is not None and summary["termination"] >= 0)))},
                 "roofline": {"bound": "hbm", "kernel": ("%s (%d pairs per launch)" % (batch_kernel, B)) if mode == 1 else "depth_closed_form_kernel",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                             "traffic": _traffic("depth_batch%d" % B if mode == 1 else workload, [batch_kernel] if (mode == 1 and B == 4) else None), "alg_bytes_per_launch": alg_bytes,
+                             "traffic": _traffic("depth_batch%d" % B if mode == 1 else workload, [batch_kernel] if mode == 1 else None), "alg_bytes_per_launch": alg_bytes,
                              "avg_launch_ms": kern_ms, "median_launch_ms": kern_med,
                              "note": "launch duration = the dispatch's own start / stop timestamps (hipExtLaunchKernel events on the library's launch), last "
                                      "call of bursts of 10 batched solves on one stream, the other streams idle; profiles/: rocprofv3 of `bench.py --streams 1`"},
@@ -1148,7 +1149,7 @@ def _traffic(workload, kernels=None):
     counters.json (round 2: per-kernel FETCH_SIZE / WRITE_SIZE means in KB, FETCH_SIZE x2 on gfx950 per MI355X_MICROARCH.md) when it
     has the kernels, else the round-1 record in traffic.json; None if absent."""
     kernels = {"rectify": ["back_project_claim_kernel", "back_project_write_kernel"], "true_flow": ["true_flow_pruned_kernel"],
-               "depth_batch4": ["depth_lm_batch_kernel<true>"], "depth_closed_form": ["depth_closed_form_kernel"]}.get(workload) if kernels is None else kernels
+               "depth_batch8": ["depth_lma_batch_kernel<2>"], "depth_closed_form": ["depth_closed_form_kernel"]}.get(workload) if kernels is None else kernels
     if kernels:
         ctr = [_counters(k2) for k2 in kernels]
         if any(c2 and c2.get("stale") for c2 in ctr):

@@ -373,7 +373,11 @@ int rsdsfm_depth_lm_launch_dev(rsdsfm_ctx* ctx, const double* d_q2n, const doubl
 int rsdsfm_depth_lm_sums_row_size(void);
 int rsdsfm_depth_lm_reduce_dev(rsdsfm_ctx* ctx, int64_t n_shard, double* d_row_out);
 int rsdsfm_depth_lm_decide_rows_dev(rsdsfm_ctx* ctx, const double* d_rows, int32_t nrows, int64_t n_total, int launch_id);
-/* status: 0 = launch *next_launch must speculate, 1 = done (result written), 2 = done, launch *next_launch writes it */
+/* status: 0 = launch *next_launch must speculate, 1 = done (result written), 2 = done, launch *next_launch writes it,
+ * 3 = the solve must START OVER from launch 0 (*next_launch = 0): its launch 0 ran a fast path whose result does not count -- the
+ * in-range function cores met an argument out of their range, or a guard of the analytic LM trajectory tripped -- and only
+ * rsdsfm_depth_finish_dev knows how to run it again (it does so by itself); a caller that drives the launches on its own must not go on
+ * from the sums of that launch. */
 int rsdsfm_depth_lm_state(rsdsfm_ctx* ctx, int32_t* status, int32_t* next_launch, rsdsfm_lm_summary* summary_or_null);
 /* Synchronises, drives the device LM state machine to completion if the fast path did not finish it
  * (rare: more than 3 LM iterations or a rejected step) and returns the summary.  Returns the number of

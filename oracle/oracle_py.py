@@ -344,6 +344,14 @@ def lma_trial(q, u, alpha, alpha_k, v, w, k, tol=-1.0, study=False):
     return dict(rho=rho, mask=mask, count=int(cnt.value), err=err.value, summary=sm.as_dict(), stats=st.as_dict())
 
 
+def one_lm_step(q1, u1, alpha, alpha_k, v, w, k, radius=1e4):
+    """rho of one pixel after the first LM step from rho = 1 (mode 1's arithmetic)"""
+    L = lib()
+    L.rso_one_lm_step.restype = C.c_double
+    d = C.c_double
+    return float(L.rso_one_lm_step(d(q1[0]), d(q1[1]), d(u1[0]), d(u1[1]), d(alpha), d(alpha_k), _v3(v), _v3(w), d(k), d(radius)))
+
+
 def lma_last_stats():
     """totals over the trials of the last ransac(depth_mode=2)"""
     st = LmaStats()

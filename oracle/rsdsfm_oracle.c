@@ -1148,6 +1148,19 @@ static double lmx_replay(int64_t i, const double* q, const double* u, const doub
     return p.rho;
 }
 
+/* rho of ONE pixel after the first LM step at `radius` from rho = 1 (the body of mode 1's first iteration for that pixel alone): what
+ * tests/test_reference_golden.py puts beside real Ceres' one-step result (tools/pin_reference: "one_step_rho") to answer, in ulps, whether
+ * dividing by the damped 1x1 e-block (here) and Ceres' multiply-by-the-inverse agree */
+double rso_one_lm_step(double x, double y, double ux, double uy, double alpha, double alpha_k, const double v[3], const double w[3], double k,
+                       double radius) {
+    const double q[2] = {x, y}, u[2] = {ux, uy};
+    lmx_px p;
+    lmx_init(&p, 0, q, u, &alpha, &alpha_k, v, w, k);
+    double m = 0.0, s2 = 0.0, c2 = 0.0;
+    lmx_step(&p, q, u, &alpha, &alpha_k, v, w, k, radius, 1.0 / radius, &m, &s2, &c2);
+    return p.cand;
+}
+
 static inline int lma_band(double x, double thr) { return fabs(x - thr) <= LMA_BAND * fabs(thr); } /* (false for NaN) */
 
 int rso_lma_trial(const double* q, const double* u, const double* alpha, const double* alpha_k, int64_t n, const double v[3],

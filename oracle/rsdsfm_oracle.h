@@ -89,6 +89,9 @@ int rso_lma_trial(const double* q2n, const double* u2n, const double* alpha_n, c
                   const double v[3], const double w[3], double k, double tol, double* inv_depth_n_or_null,
                   uint8_t* mask_n_or_null, int64_t* count_or_null, double* err_sum_or_null, rso_lm_summary* summary_or_null,
                   rso_lma_stats* stats_or_null, int study);
+/* rho of one pixel after the FIRST LM step (radius: Ceres starts at 1e4) from rho = 1 under mode 1's arithmetic */
+double rso_one_lm_step(double x, double y, double ux, double uy, double alpha, double alpha_k, const double v[3], const double w[3], double k,
+                       double radius);
 /* totals over the trials of the last rso_ransac(depth_mode 2) */
 void rso_lma_last_stats(rso_lma_stats* out);
 

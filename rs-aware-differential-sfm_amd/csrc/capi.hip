@@ -442,8 +442,11 @@ int rsdsfm_depth_lm_state(rsdsfm_ctx* ctx, int32_t* status, int32_t* next_launch
     CTX_OR_FAIL(ctx);
     int rc = read_lm_state(c);
     if (rc != RSDSFM_OK) return rc;
-    if (status) *status = c->h_lm->status;
-    if (next_launch) *next_launch = c->h_lm->next_launch;
+    // (a launch 0 whose result does not count -- LmScal::restart: a function-core miss, a guard of the analytic trajectory -- is reported as
+    // "start over": rsdsfm_depth_finish_dev does that by itself, a caller driving the launches on its own must not continue from its sums)
+    const bool start_over = c->h_lm->status == 0 && c->h_lm->restart != 0;
+    if (status) *status = start_over ? 3 : c->h_lm->status;
+    if (next_launch) *next_launch = start_over ? 0 : c->h_lm->next_launch;
     fill_lm_summary(*c->h_lm, summary);
     return RSDSFM_OK;
 }

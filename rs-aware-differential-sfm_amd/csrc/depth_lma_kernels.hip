@@ -14,6 +14,7 @@
 //                                        rsdsfm_depth_finish_dev runs it again iterate by iterate.
 // HBM-bound: 56 B/pixel, ~5 us of arithmetic per 4 x 1280x720 under ~37 us of memory traffic.
 #include <hip/hip_ext.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -72,6 +73,7 @@ __device__ __forceinline__ double depth_lma_rho(double x, double y, double ux, d
 
 }  // namespace
 
+template <int U>
 __global__ __launch_bounds__(kDepthBlock) void depth_lma_batch_kernel(DepthLmaArgs args) {
     __shared__ double s_red[kDepthBlock / 64][6];
     const DepthLmaItem& it = args.item[blockIdx.y];
@@ -101,7 +103,27 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lma_batch_kernel(DepthLmaAr
     };
     const int64_t npairs = n >> 1;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + tid; p < npairs; p += stride) {
+    // U pixel pairs per thread and iteration, all their loads issued before the first result is needed
+    int64_t p = (int64_t)blockIdx.x * blockDim.x + tid;
+    for (; p + (U - 1) * stride < npairs; p += U * stride) {
+        double2 qa[U], qb[U], ua[U], ub[U], al[U], ak[U];
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int64_t pj = p + j * stride;
+            qa[j] = nt_load2(q + 2 * pj), qb[j] = nt_load2(q + 2 * pj + 1);
+            ua[j] = nt_load2(u + 2 * pj), ub[j] = nt_load2(u + 2 * pj + 1);
+            al[j] = nt_load2(alpha2 + pj), ak[j] = nt_load2(alpha_k2 + pj);
+        }
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            const int64_t pj = p + j * stride;
+            double2 out;
+            out.x = pixel(qa[j].x, qa[j].y, ua[j].x, ua[j].y, al[j].x, ak[j].x, 2 * pj);
+            out.y = pixel(qb[j].x, qb[j].y, ub[j].x, ub[j].y, al[j].y, ak[j].y, 2 * pj + 1);
+            nt_store2(rho2 + pj, out);
+        }
+    }
+    for (; p < npairs; p += stride) {
         const double2 qa = nt_load2(q + 2 * p), qb = nt_load2(q + 2 * p + 1);
         const double2 ua = nt_load2(u + 2 * p), ub = nt_load2(u + 2 * p + 1);
         const double2 al = nt_load2(alpha2 + p), ak = nt_load2(alpha_k2 + p);
@@ -233,7 +255,11 @@ __global__ __launch_bounds__(kDepthBlock) void depth_lma_decide_apply_rows_kerne
 // ---------------------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------------------
-constexpr int kDepthLmaBlocks = 300;  // workgroups per solve (as depth_lm_batch_launch: measured there)
+// workgroups per solve and pixel pairs per thread and iteration, measured on the memory-bound kernel (us per launch / HBM fraction; 1280x720 pairs):
+// 4 pairs per launch: 300 x 1: 41.9 / 0.616, 512 x 1: 40.9 / 0.631, 512 x 2: 41.0 / 0.630, 256 x 2: 42.9 / 0.601, 200 x 2: 46.6 / 0.553;
+// 8 pairs per launch: 300 x 1: 80.6 / 0.640, 512 x 1: 78.0 / 0.662, 512 x 2: 76.5 / 0.675
+constexpr int kDepthLmaBlocks = 512;
+constexpr int kDepthLmaUnroll = 2;
 constexpr int kDepthLmaApplyGrid = 32;
 static_assert(kDepthLmaBlocks <= kDepthMaxBlocks && kLmaSlots <= NS, "partial rows fit the context's partial buffer");
 
@@ -297,7 +323,7 @@ int depth_lma_batch_launch(Ctx* const* cs, int count, const double* const* q, co
     // rsdsfm_set_profiling on the batch's first context: the launch is bracketed by the DISPATCH's own start / stop timestamps
     const bool prof = c0->profile && c0->ev_prof[0] && c0->ev_prof[1];
     hipEvent_t ev0 = prof ? c0->ev_prof[0] : nullptr, ev1 = prof ? c0->ev_prof[1] : nullptr;
-    hipExtLaunchKernelGGL(depth_lma_batch_kernel, dim3(grid, count), dim3(kDepthBlock), 0, c0->stream, ev0, ev1, 0, args);
+    hipExtLaunchKernelGGL(depth_lma_batch_kernel<kDepthLmaUnroll>, dim3(grid, count), dim3(kDepthBlock), 0, c0->stream, ev0, ev1, 0, args);
     RSDSFM_HIP_CHECK(c0, hipGetLastError());
     if (prof) c0->prof_pending = true, c0->prof_what = 1;
     hipLaunchKernelGGL(depth_lma_decide_apply_batch_kernel, dim3(std::min(grid, kDepthLmaApplyGrid), count), dim3(kDepthBlock), 0, c0->stream, args, grid);
@@ -313,7 +339,7 @@ int depth_lma_shard_launch(Ctx* c, const double* q, const double* u, const doubl
     const int rc = depth_lma_item(c, c, q, u, a, ak, n, pose, rho, true, args.item[0]);
     if (rc != RSDSFM_OK) return rc;
     const int grid = depth_lma_blocks(n);
-    hipLaunchKernelGGL(depth_lma_batch_kernel, dim3(grid, 1), dim3(kDepthBlock), 0, c->stream, args);
+    hipLaunchKernelGGL(depth_lma_batch_kernel<kDepthLmaUnroll>, dim3(grid, 1), dim3(kDepthBlock), 0, c->stream, args);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     hipLaunchKernelGGL(depth_lma_rows_kernel, dim3(1), dim3(kDepthBlock), 0, c->stream, args, grid, d_row);
     RSDSFM_HIP_CHECK(c, hipGetLastError());

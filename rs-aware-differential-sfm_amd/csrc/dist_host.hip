@@ -151,6 +151,7 @@ struct Dist {
     // (every rank reads the same replicated flag words) starts over iterate by iterate, and the communicator stays there for its next solves
     // (renewed by a solve that ends in a tie the analytic arithmetic could not break: noise-free data)
     int lma_hold = 0;
+    bool lockstep_error = false;  // the last solve's error return came after the whole solve ran in lockstep with the peers (hints kept)
 };
 
 Dist* dist_of(Ctx* c, bool create) {
@@ -225,6 +226,7 @@ void reset_hints(Dist* D) {
     D->refine_iters_hint = -1;
     D->warm = D->dense_hint = false;
     D->standard_math = 0;
+    D->lma_hold = 0;
 }
 
 int sync(Ctx* c, Dist* D) {
@@ -412,7 +414,10 @@ int rsdsfm_solve_frame_tiled_dev(rsdsfm_ctx* ctx, const double* d_img_slab, int3
     const int rc = solve_frame_tiled_impl(ctx, d_img_slab, rows, cols, fx, fy, cx, cy, gamma, prm, d_depth_map, d_R_rows9, d_t_rows3, res, info);
     if (rc != RSDSFM_OK && ctx) {  // an error return: the ranks may have left at different points -- no hint survives it
         Dist* D = static_cast<Dist*>(ctx->c.dist);
-        if (D) reset_hints(D);
+        // (except an error this rank reported AFTER completing the solve in lockstep with its peers: they know nothing of it and keep their
+        // hints, so this rank must keep the same ones)
+        if (D && !D->lockstep_error) reset_hints(D);
+        if (D) D->lockstep_error = false;
     }
     return rc;
 }
@@ -513,7 +518,7 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
                                      Arena::need(8 * cap) + Arena::need(8 * 1024)}) + 4096;
     if (rc == RSDSFM_OK) rc = ensure_ws(c, ws_need);
     if (rc == RSDSFM_OK)
-        rc = ensure_pinned(c, sizeof(RansacBest) + 64 + 8 * (size_t)R * 2 + 64 + sizeof(RefineState) + 64 + sizeof(int32_t) * 9 * (size_t)Tn + 64 + 16 * (size_t)R + 64 + 8 * (size_t)R + 64);
+        rc = ensure_pinned(c, sizeof(RansacBest) + 64 + 8 * (size_t)R * 2 + 64 + sizeof(RefineState) + 64 + sizeof(int32_t) * 9 * (size_t)Tn + 8 + 64 + 16 * (size_t)R + 64 + 8 * (size_t)R + 64);
     // the refinement's session (sized for every point of the slab an inlier), the rank-indexed flow exchange (quirk Q2: at most the
     // whole flow list of every slab + this slab's columns) and the depth map's claim words
     const size_t npart_cap = (size_t)std::max(refine_partials_doubles(c, (int64_t)N1), refine_slot_partials_doubles(c, (int64_t)N1));
@@ -556,7 +561,8 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
     int path_flags = spec_dense ? 1 : 0;
     D->warm = false;  // (set again by a solve that ends well)
     std::vector<int64_t> h_xchg(2 * (size_t)R + 2, 0);  // (pageable on purpose: it must exist even when the pinned block could not grow)
-    double* h_counts_tail = reinterpret_cast<double*>(reinterpret_cast<char*>(h_samples) + sizeof(int32_t) * 9 * (size_t)Tn + 64 + 16 * (size_t)R + 64);
+    // (the samples block rounded up to 8 bytes: 36 Tn bytes is only 4-byte aligned for odd T, and this is read as doubles)
+    double* h_counts_tail = reinterpret_cast<double*>(reinterpret_cast<char*>(h_samples) + ((sizeof(int32_t) * 9 * (size_t)Tn + 7) & ~(size_t)7) + 64 + 16 * (size_t)R + 64);
     int64_t n_total = 0, offset = 0, n = 0;
 restart_cold:
     if (!spec_dense) {
@@ -684,11 +690,11 @@ restart_ransac:
             for (int round = 0;; ++round) {
                 if (round > 4 * kMaxIter) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machines did not terminate");
                 const bool core_round = core && round == 0 && !analytic;  // (core implies one batch: B == T)
-                if (analytic) {
-                    // ONE pixel pass + ONE exchange of [B][kLmaRow] closed-form sums per rank (no rounds), the trust-region loop replicated on
-                    // the gathered rows; the minimal solver's range flag is replicated knowledge (every rank ran the same solver on the same
-                    // points), so it needs no trailer
-                    if (round != 0) return fail(c, RSDSFM_ERR_NUMERIC, "analytic LM pass asked for a second round");
+                if (analytic && round == 0) {
+                    // ONE pixel pass + ONE exchange of [B][kLmaRow] closed-form sums per rank, the trust-region loop replicated on the gathered
+                    // rows; the minimal solver's range flag is replicated knowledge (every rank ran the same solver on the same points), so it
+                    // needs no trailer.  A hypothesis whose own guards tripped comes back as still running: rounds 1, 2, ... are the
+                    // iterate-by-iterate kernels', where only such hypotheses take part (replicated: every rank sees the same states)
                     if (b0 > 0) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_irr_count, 0, sizeof(int) * (size_t)batch, c->stream));
                     rc = ransac_lma_rows_launch(c, d_q, d_u, d_a, d_ak, n, d_hyp + (size_t)b0 * 8, B, d_partials, prm->ransac_tol, lma_cand, 2, d_irr_count, d_irr_list, d_row);
                     if (rc != RSDSFM_OK) return rc;
@@ -808,7 +814,13 @@ restart_ransac:
     for (int r = 0; r < R; ++r) m_total += h_m[r];
     const int64_t m = h_m[rank];
     auto m_total_of = [&]() -> int64_t { return m_total; };
-    if (m_total != h_best->num_inliers || *h_scan != m) return fail(c, RSDSFM_ERR_NUMERIC, "inlier count mismatch between scoring and compaction");
+    // the winner's count against the ranks' shares is replicated knowledge: every rank returns alike.  This slab's compaction total against its
+    // share is NOT (only this rank knows it): a rank that left here would strand the others in the refinement's exchanges and come back to
+    // the next solve with other hints than theirs -- so it stays in lockstep to the end of the solve (its slab's part of the result is not to
+    // be trusted: the buffers are sized for any count), keeps its hints, and reports the error then
+    if (m_total != h_best->num_inliers) return fail(c, RSDSFM_ERR_NUMERIC, "inlier count mismatch between scoring and compaction");
+    const bool local_scan_bad = *h_scan != m;
+    bool local_index_bad = false;
     res->num_inliers = m_total;
     res->best_trial = h_best->best_trial;
     memcpy(res->ransac_w, &h_best->hyp[0], 3 * sizeof(double));
@@ -963,7 +975,7 @@ restart_ransac:
             RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_state, B.state, sizeof(RefineState) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
             rc = sync(c, D);
             if (rc != RSDSFM_OK) return rc;
-            if (*h_bad) return fail(c, RSDSFM_ERR_INVALID, "flow index out of range (bad inlier_idx)");
+            if (*h_bad) local_index_bad = true;  // (rank-local like the count check above: reported at the end, in lockstep)
             if (h_state->termination >= 0) break;
             if (launched > 8 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
         }
@@ -1032,6 +1044,11 @@ restart_ransac:
         info->collectives = D->collectives;
         info->ransac_rounds = D->ransac_rounds;
         info->path_flags = path_flags;
+    }
+    if (local_scan_bad || local_index_bad) {
+        D->lockstep_error = true;  // (the hints stay: this rank issued every collective its peers issued)
+        return local_scan_bad ? fail(c, RSDSFM_ERR_NUMERIC, "inlier count mismatch between scoring and compaction on this rank's slab")
+                              : fail(c, RSDSFM_ERR_INVALID, "flow index out of range (bad inlier_idx)");
     }
     return RSDSFM_OK;
 }

@@ -55,6 +55,7 @@ struct FrameRun {
     Minimal9Direct direct;
     DenseFlatten dense;
     bool refinement_enqueued = false, ahead = false, side_flatten = false, dense_in_launch = false, open = false;
+    bool counted = false;  // this run is in g_frames_in_flight (begin counted it, nothing has taken it out yet)
     int rc_begin = RSDSFM_OK;
     int64_t m_known = -1;  // the inlier count once the host has it; until then the kernels read it from the refinement's state
     RefineTail tail;
@@ -87,14 +88,24 @@ int ensure_side_stream(Ctx* c) {
     return RSDSFM_OK;
 }
 
+// takes a run out of the count exactly once: at the end of its finish, when it is begun again without having been finished (a caller that
+// abandoned it on an error), or when its context goes away with the run still open
+static void frame_uncount(const Ctx* c, FrameRun* F) {
+    if (F && F->counted) {
+        F->counted = false;
+        g_frames_in_flight[c->device & 63].fetch_sub(1, std::memory_order_relaxed);
+    }
+}
 struct FrameInFlightEnd {
     const Ctx* c;
-    ~FrameInFlightEnd() { g_frames_in_flight[c->device & 63].fetch_sub(1, std::memory_order_relaxed); }
+    FrameRun* F;
+    ~FrameInFlightEnd() { frame_uncount(c, F); }
 };
 
 int frame_begin(Ctx* c, FrameRun* F) {
     const rsdsfm_frame_job& J = F->job;
     const rsdsfm_frame_params* prm = &F->prm;
+    frame_uncount(c, F);  // (a run that was begun and never finished)
     F->open = false;
     F->rc_begin = RSDSFM_OK;
     if (J.rows <= 0 || J.cols <= 0 || !J.d_flow_img || !J.d_depth_map_colmajor) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
@@ -259,6 +270,7 @@ int frame_begin(Ctx* c, FrameRun* F) {
     F->ahead = prm->use_refinement && c->ransac_spec_miss < 2;
     F->open = true;
     g_frames_in_flight[c->device & 63].fetch_add(1, std::memory_order_relaxed);
+    F->counted = true;
     F->rc_begin = ransac_begin(c, F->d_q, F->d_u, F->d_a, F->d_ak, n, prm->use_acceleration_mode, prm->ransac_trials, prm->ransac_tol, nullptr, J.seed,
                                prm->depth_mode, prm->k_sign_mode, &F->ro, prm->use_refinement ? &F->spec_tail : nullptr, &F->refinement_enqueued, &F->ransac,
                                F->side_flatten ? &F->direct : nullptr, F->side_flatten && !F->dense_in_launch ? &F->join : nullptr,
@@ -269,7 +281,7 @@ int frame_begin(Ctx* c, FrameRun* F) {
 int frame_finish(Ctx* c, FrameRun* F, rsdsfm_frame_result* res) {
     if (!F->open) return fail(c, RSDSFM_ERR_INVALID, "no frame solve in flight");
     F->open = false;
-    FrameInFlightEnd in_flight_end_{c};  // (until this function returns: the solve's kernels occupy the GPU while the host waits)
+    FrameInFlightEnd in_flight_end_{c, F};  // (until this function returns: the solve's kernels occupy the GPU while the host waits)
     const rsdsfm_frame_job& J = F->job;
     const rsdsfm_frame_params* prm = &F->prm;
     memset(res, 0, sizeof(*res));
@@ -353,6 +365,7 @@ FrameRun* frame_run_of(Ctx* c) {
 }  // namespace
 
 void frame_release(Ctx* c) {
+    frame_uncount(c, static_cast<FrameRun*>(c->frame_run));  // (a context destroyed with a run open)
     delete static_cast<FrameRun*>(c->frame_run);
     c->frame_run = nullptr;
     for (rsdsfm_ctx* lane : c->lanes) rsdsfm_destroy(lane);

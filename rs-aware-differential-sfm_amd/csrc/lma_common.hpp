@@ -54,6 +54,7 @@ constexpr int kLmaRow = kLmaRowScore + 2 * kLmaNC;
 // the planned trajectory: radius of step k, and phi after it (every step accepted with quality ~1: radius / (1 / 3))
 struct LmaPlan {
     double radius[kLmaKP + 1];
+    double psi[kLmaKP + 1];  // psi of step k (radius[k])
     double phi[kLmaKP + 2];  // phi[0] = 1
 };
 __host__ __device__ inline void lma_phi_step(double radius, double phi, double& psi, double& phic) {
@@ -69,6 +70,7 @@ __host__ __device__ inline LmaPlan lma_plan() {
         p.radius[k] = r;
         double psi, phic;
         lma_phi_step(r, phi, psi, phic);
+        p.psi[k] = psi;
         p.phi[k + 1] = phic;
         phi = phic;
         r = radius_accept(r, 1.0);

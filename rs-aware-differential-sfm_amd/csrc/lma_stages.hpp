@@ -213,7 +213,8 @@ __device__ __forceinline__ int lma_decide(const double* row, int64_t n, const Lm
             break;
         }
         double psi, phic;
-        lma_phi_step(st.radius, phi, psi, phic);
+        if (on_plan) psi = plan.psi[kk], phic = plan.phi[kk + 1];  // (the same bits: the plan was computed with lma_phi_step -- no divisions on the serial path)
+        else lma_phi_step(st.radius, phi, psi, phic);
         const double p2 = phi * phi, pc2 = phic * phic;
         const double* xk = row + kLmaRowXk + 5 * (kk < kLmaKP ? kk : 0);
         const double XM = listed_walk ? xk[0] : 0.0, XS = listed_walk ? xk[1] : 0.0, XCc = listed_walk ? xk[2] : 0.0;

@@ -183,10 +183,10 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                 const int b0 = R.b0, B = R.B, round = R.round;
                 bool flags_via_pick = false;  // this round's flag words reach the host with the speculated pick kernel
                 if (round > 4 * kMaxIter) return fail(c, RSDSFM_ERR_NUMERIC, "LM state machines did not terminate");
-                if (R.analytic) {
-                    // the B depth solves on the analytic LM trajectory (ransac_lma_kernels.hip): one pixel pass + one decide launch, never a
-                    // second round; hypotheses that end where no score was fused go to the scoring pass like round 0's
-                    if (round != 0) return fail(c, RSDSFM_ERR_NUMERIC, "analytic LM pass asked for a second round");
+                if (R.analytic && round == 0) {
+                    // the B depth solves on the analytic LM trajectory (ransac_lma_kernels.hip): one pixel pass + one decide launch; hypotheses
+                    // that end where no score was fused go to the scoring pass like round 0's, and a hypothesis whose own guards tripped comes
+                    // back as "still running": rounds 1, 2, ... below are the iterate-by-iterate kernels', where only such hypotheses take part
                     rc = ransac_lma_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_hyp + (size_t)b0 * 8, B, R.d_states + b0, R.d_partials, R.d_flags,
                                            R.d_scored + b0, R.d_tcount + b0, R.d_terr + b0, tol, R.lma_cand, 2, R.d_irr_count, R.d_irr_list, R.d_unscored,
                                            nullptr, R.core_epoch ? c->d_core_flag : nullptr, R.core_epoch);
@@ -234,6 +234,7 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                 yield_at_wait = false;  // (a run yields once: after its first wait the caller is blocked in it anyway)
                 RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
                 const int* h_running = R.h_running;
+                if (R.round == 0 && R.analytic && (h_running[3] & 16) != 0) R.lma_guard |= h_running[3] >> 8;  // (hypotheses handed over: diagnostics)
                 if (R.round == 0 && R.analytic && (h_running[3] & 6) != 0 && !((h_running[3] & 1) && R.core_math)) {
                     // the analytic pass: a guard tripped (bit 1; which: bits 8..) or the speculated pick met a tie it must not break (bit 2):
                     // the depth solves start over on the iterate-by-iterate kernels, from the hypotheses (which are fine).  What was
@@ -383,7 +384,8 @@ void ransac_commit_hints(Ctx* c, const RansacRun& R) {
     c->ransac_not_one_step = R.not_one_step;
     c->ransac_spec_miss = R.spec_final ? 0 : std::min(c->ransac_spec_miss + 1, 2);
     if (R.lma_cand_next[0]) c->lma_cand[0] = R.lma_cand_next[0], c->lma_cand[1] = R.lma_cand_next[1];
-    if (R.lma_restarted) {  // a guard tripped: this kind of data stays on the iterate-by-iterate kernels for a while
+    if (R.lma_guard) c->lma_last_guard = R.lma_guard, c->lma_handed_over += 1;
+    if (R.lma_restarted) {  // a global guard tripped (a tie, the count check): this kind of data stays on the iterate-by-iterate kernels for a while
         c->lma_hold = 16;
         c->lma_restarts += 1;
         c->lma_last_guard = R.lma_guard;

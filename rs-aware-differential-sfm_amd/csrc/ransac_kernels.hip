@@ -433,8 +433,11 @@ __global__ __launch_bounds__(256) void ransac_decide_kernel(const double* __rest
     reduce_hyp_sums(partials, nblocks, T, t, hyp_major != 0, s_red, s_sums, rank_stride2);
     if (tid == 0) {
         LmScal st = *static_cast<const LmScal*>(state);
+        // (a state without launches in a later round: a hypothesis the analytic pass handed over -- ransac_lma_kernels.hip lma_publish --, whose
+        // first iterate-by-iterate launch this is)
+        const bool first = round == 0 || st.launches == 0;
         const int used_K = (round == 0) ? k0 : st.K;
-        lm_advance(st, state->hist, s_sums, n, round == 0, used_K, 0, round);
+        lm_advance(st, state->hist, s_sums, n, first, used_K, 0, round);
         if (pred_flag && round == 0 && (st.status == 0 || st.n_hist >= 2)) atomicAdd(pred_flag, 1);
         // where the hypotheses of this solve end (1, 2, >= 3 accepted steps or still running after round 0): the next solve's fused_base
         if (steps_hist && round == 0) atomicAdd(&steps_hist[st.status == 0 ? 3 : (st.n_hist < 1 ? 0 : (st.n_hist > 3 ? 3 : st.n_hist))], 1);

@@ -151,13 +151,34 @@ __device__ __forceinline__ void lma_publish(int t, const LmScal& st, const doubl
                                             LmState* states, int* flags, int* __restrict__ scored_out, double* __restrict__ trial_count,
                                             double* __restrict__ trial_err, int* steps_hist, int* __restrict__ unscored_list, int* guard_word) {
     LmState* state = states + t;
-    *static_cast<LmScal*>(state) = st;
-    for (int j = 0; j < st.n_hist && j < kMaxIter; ++j) state->hist[j] = hist_l[j];
-    if (fallback) {  // bit 1: a guard tripped; bits 8..: which (1 << reason)
-        atomicOr(&flags[3], 2 | (1 << (8 + fallback)));
+    if (fallback) {
+        // a guard of THIS hypothesis tripped (a decision inside the undecided band, a list that overflows -- e.g. a hypothesis whose k puts beta
+        // near zero: every pixel clamped --, listed pixels off the tabulated plan): the hypothesis goes on ITERATE BY ITERATE, alone -- its state
+        // is the one ransac_lm_kernel's continuation rounds start a solve from (nothing accepted, KMAX planned iterations, launch 1), the run
+        // counts it as still running, and the host enqueues round 1 on the iterate-by-iterate kernels, where only such hypotheses take part.
+        // flags[3] bit 4 + bits 8..: diagnostics (which guards)
+        LmScal f = {};
+        f.status = 0;
+        f.K = KMAX;
+        f.termination = -1;
+        f.rho_holds = -1;
+        f.launches = 0;  // (ransac_decide_kernel: a state without launches takes the sums of its first launch as iteration zero)
+        f.next_launch = 1;
+        f.radius = kInitialRadius;
+        f.decrease_factor = 2.0;
+        double r = kInitialRadius;
+        for (int j = 0; j < KMAX; ++j) {
+            f.cand[j] = r;
+            r = radius_accept(r, 1.0);
+        }
+        *static_cast<LmScal*>(state) = f;
+        atomicAdd(&flags[0], 1);
+        atomicOr(&flags[3], 16 | (1 << (8 + fallback)));
         (void)guard_word;
         return;
     }
+    *static_cast<LmScal*>(state) = st;
+    for (int j = 0; j < st.n_hist && j < kMaxIter; ++j) state->hist[j] = hist_l[j];
     if (steps_hist) atomicAdd(&steps_hist[st.n_hist < 1 ? 0 : (st.n_hist > 3 ? 3 : st.n_hist)], 1);
     if (scored) {
         trial_count[t] = count;

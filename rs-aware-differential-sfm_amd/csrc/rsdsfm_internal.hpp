@@ -118,7 +118,8 @@ struct Ctx {
     // trip starts over on the iterate-by-iterate kernels (ransac_kernels.hip), and the context then stays on those for its next lma_hold solves
     int lm_arithmetic = 0;         // rsdsfm_set_lm_arithmetic: 0 = analytic trajectory with guards (default), 1 = always iterate by iterate
     int lma_hold = 0;              // > 0: that many of the context's next RANSACs run iterate by iterate (set to 16 by a run whose guards tripped; renewed by an iterate-by-iterate run that ends in a tie the analytic arithmetic could not break: noise-free data)
-    int64_t lma_restarts = 0;      // RANSAC runs of this context that started over because a guard tripped (rsdsfm_lma_restarts)
+    int64_t lma_restarts = 0;      // RANSAC runs of this context that started over because a GLOBAL guard tripped: a tie, the count check (rsdsfm_lma_restarts)
+    int64_t lma_handed_over = 0;   // RANSAC runs in which some hypothesis' own guard tripped and that hypothesis went on iterate by iterate
     int lma_last_guard = 0;        // bit set of the guards that tripped last (1 << reason: lma_common.hpp; 1 << 7: tie)
     // the dense depth solve's fast path on the analytic trajectory (depth_lma_kernels.hip): the solve's list of clamped pixels (two halves used
     // alternately: the follow-up launch of one solve zeroes the counter the next one starts from)

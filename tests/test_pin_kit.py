@@ -11,21 +11,21 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SELFCHECK = os.path.join(ROOT, "tools", "pin_reference", "selfcheck.py")
 
 
-def _run(marker):
+def _run(marker, expect):
     p = subprocess.run([sys.executable, SELFCHECK, "-m", marker], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "plumbing ok" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
-    assert "25 passed" in p.stdout, p.stdout[-1500:]  # 5 cases x (minimal solver, depth solve, RANSAC, 2 refinements): none skipped
+    assert "%d passed" % expect in p.stdout, p.stdout[-1500:]  # none skipped
 
 
 def test_pin_kit_plumbing_oracle_half():
-    _run("not gpu")
+    _run("not gpu", 30)  # 5 cases x (minimal solver, depth solve, RANSAC, 2 refinements, the first LM step in ulps)
 
 
 @pytest.mark.gpu
 def test_pin_kit_plumbing_hip_half():
     """the HIP path against the ORACLE's outputs in the reference fixture's layout: the parity the GPU suite asserts everywhere, through
     the code that will meet the real fixture"""
-    _run("gpu")
+    _run("gpu", 25)  # 5 cases x (minimal solver, depth solve, RANSAC, 2 refinements)
 
 
 def test_pin_kit_inputs_export(tmp_path):

@@ -179,6 +179,29 @@ def test_oracle_refinement_vs_reference(oracle, golden, ref, case, mode):
     _check_refine(_OracleImpl(oracle), golden, ref, case, mode)
 
 
+@pytest.mark.parametrize("case", GOLDEN_CASES)
+def test_oracle_first_lm_step_vs_ceres_in_ulps(oracle, golden, ref, case):
+    """The last-bit question of the 1x1 e-blocks (Weak #1): Ceres' Schur eliminator inverts each e-block through InvertPSDMatrix
+    (an LLT solve, then a MULTIPLY by the inverse), the oracle divides.  The harness lets real Ceres take ONE LM step for up to 100 pixels,
+    each as a problem of its own; the oracle's one-step rho stands beside it.  Asserted: 1e-12 relative (far inside the 1e-5 bar); REPORTED
+    (pytest -rA / -s): how many of the pixels agree bit for bit and the largest distance in ulps -- the number DESIGN.md section 5 quotes
+    once the fixture exists."""
+    key = case + "/one_step_rho"
+    if key not in ref:
+        pytest.skip("this fixture was produced by a harness without the one-step dump")
+    q, u, a, ak, samples, use_k = _inputs(golden, case)
+    t0 = int(ref[case + "/one_step_hypothesis"][0])
+    if t0 < 0:
+        pytest.skip("no finite hypothesis in this case")
+    W, V, K = ref[case + "/hyp_w"], ref[case + "/hyp_v"], ref[case + "/hyp_k"]
+    got = ref[key]
+    n, m = len(q), len(got)
+    mine = np.array([oracle.one_lm_step(q[i * n // m], u[i * n // m], a[i * n // m], ak[i * n // m], V[t0], W[t0], float(K[t0])) for i in range(m)])
+    assert np.allclose(mine, got, rtol=1e-12, atol=1e-15), (case, np.abs(mine - got).max())
+    ulps = np.abs(mine.view(np.int64) - got.view(np.int64))
+    print("%s: first LM step, oracle vs Ceres: %d of %d pixels bit-identical, max distance %d ulp" % (case, int((ulps == 0).sum()), m, int(ulps.max())))
+
+
 # ---------------------------------------------------------------------------------------------------
 # GPU: the HIP path through the C ABI
 # ---------------------------------------------------------------------------------------------------

@@ -43,10 +43,19 @@
 namespace pin {
 ceres::Solver::Summary last_summary;  // the Summary of the most recent ceres::Solve the reference issued
 int solves = 0;
+int max_iterations_override = 0;  // > 0: the next solves stop after that many iterations (the one-step dump below)
 }  // namespace pin
 
 namespace ceres {
 inline void PinnedSolve(const Solver::Options& options, Problem* problem, Solver::Summary* summary) {
+    if (pin::max_iterations_override > 0) {  // (everything else as the reference set it)
+        Solver::Options o2 = options;
+        o2.max_num_iterations = pin::max_iterations_override;
+        Solve(o2, problem, summary);
+        pin::last_summary = *summary;
+        pin::solves += 1;
+        return;
+    }
     Solve(options, problem, summary);  // the real one, same arguments
     pin::last_summary = *summary;
     pin::solves += 1;
@@ -240,6 +249,36 @@ static void run_case(const std::string& in_dir, const std::string& out_dir, cons
         if (solves != before + 1) throw std::runtime_error("estimateInverseDepths did not go through the pinned Solve");
         for (int i = 0; i < n; ++i) rho[(size_t)t * n + i] = r(i);
         keep_summary(last_summary, &dsum[(size_t)t * kSummaryCols], &dtrace[(size_t)t * kTraceRows * kTraceCols]);
+    }
+    // ---- the LAST-BIT question of the 1x1 e-blocks: Ceres' Schur eliminator inverts each e-block through InvertPSDMatrix (an LLT solve, then
+    // a MULTIPLY by the inverse), the oracle divides (rsdsfm_oracle.c: step = -(gt / (ht + lam))).  The first LM step of real Ceres for up to
+    // 100 pixels, each as a problem of its own (one pixel: the global tests are the pixel's) stopped after ONE iteration through the
+    // reference's own estimateInverseDepths, with the first finite hypothesis: rho_1 per pixel.  tests/test_reference_golden.py puts the
+    // oracle's one-step rho beside it and reports the difference in ulps.
+    {
+        int t0 = -1;
+        for (int t = 0; t < T && t0 < 0; ++t) {
+            bool ok = std::isfinite(hyp_k[t]);
+            for (int i = 0; i < 3; ++i) ok = ok && std::isfinite(hyp_v[3 * t + i]) && std::isfinite(hyp_w[3 * t + i]);
+            if (ok) t0 = t;
+        }
+        const int m = std::min(n, 100);
+        std::vector<double> one(m, 0.0);
+        if (t0 >= 0) {
+            const Eigen::Vector3d v(hyp_v[3 * t0], hyp_v[3 * t0 + 1], hyp_v[3 * t0 + 2]), w(hyp_w[3 * t0], hyp_w[3 * t0 + 1], hyp_w[3 * t0 + 2]);
+            max_iterations_override = 1;
+            for (int i = 0; i < m; ++i) {
+                const int idx = (int)((int64_t)i * n / m);
+                const Eigen::Array2Xd q1 = q.col(idx), u1 = u.col(idx);
+                Eigen::ArrayXd a1(1), ak1(1);
+                a1(0) = alpha(idx), ak1(0) = alpha_k(idx);
+                one[i] = nonlinear_refinement::estimateInverseDepths(q1, u1, v, w, hyp_k[t0], a1, ak1, false)(0);
+            }
+            max_iterations_override = 0;
+        }
+        const double which = (double)t0;
+        W.f64("one_step_rho", {(uint64_t)m}, one.data());
+        W.f64("one_step_hypothesis", {1}, &which);
     }
     W.f64("depth_rho", {(uint64_t)T, (uint64_t)n}, rho.data());
     W.f64("depth_summary", {(uint64_t)T, (uint64_t)kSummaryCols}, dsum.data());

@@ -75,6 +75,12 @@ def main():
             sums.append(summary_row(sm))
         out["depth_rho"], out["depth_summary"] = np.array(rho), np.array(sums)
         out["depth_trace"] = np.full((T, TRACE_ROWS, TRACE_COLS), np.nan)
+        # (the harness' one-step dump: the first finite hypothesis, up to 100 pixels at i * n / m)
+        t0 = next((t for t in range(T) if np.all(np.isfinite(np.r_[out["hyp_v"][t], out["hyp_w"][t], out["hyp_k"][t]]))), -1)
+        m = min(n, 100)
+        out["one_step_rho"] = np.array([O.one_lm_step(q[i * n // m], u[i * n // m], a[i * n // m], ak[i * n // m], out["hyp_v"][t0], out["hyp_w"][t0],
+                                                      out["hyp_k"][t0]) if t0 >= 0 else 0.0 for i in range(m)])
+        out["one_step_hypothesis"] = np.array([float(t0)])
         rr = O.ransac(q, u, a, ak, use_k, T, RANSAC_TOL, samples, depth_mode=1)
         out["ransac_num_inliers"] = np.array([float(rr["num_inliers"])])
         out["ransac_inliers"], out["ransac_alpha"], out["ransac_alpha_k"] = rr["inliers"], rr["alpha"], rr["alpha_k"]

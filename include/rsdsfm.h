@@ -510,7 +510,8 @@ typedef struct rsdsfm_tiled_info {
                          * (the previous solve of this shape on the communicator succeeded everywhere, all its slabs dense); bit 1: that
                          * assumption did not hold for this frame and the solve started over through the counts / status exchange; bit 2:
                          * the RANSAC started over with the standard functions (an argument outside the range of the in-range function cores
-                         * on some rank; counted by rsdsfm_ransac_restarts as well); bits 8-23: exchanges the refinement's LM iterations took
+                         * on some rank; counted by rsdsfm_ransac_restarts as well); bit 3: the RANSAC started over iterate by iterate because a
+                         * global guard of the analytic LM trajectory tripped (a tie; counted by rsdsfm_lma_restarts); bits 8-23: exchanges the refinement's LM iterations took
                          * (one per iteration + one in front of the first + one behind every iteration whose speculated Schur sums did
                          * not apply: a rejected step, or an accepted one of quality < 0.937) */
 } rsdsfm_tiled_info;

@@ -40,6 +40,7 @@ __device__ __forceinline__ void lma_rows_stage(const double* __restrict__ partia
     constexpr int LBATCH = 64;       // listed pixels per round (one wave walks them; lists are short)
     __shared__ double s_x[LBATCH][2 + 5 * kLmaKP + 2 * kLmaNC + 2 + 1];  // per listed pixel of the current batch: its terms of the row (+ 1: bank padding)
     const int tid = threadIdx.x;
+    const int raw = irr_count[t];  // (requested here: its round trip overlaps the rows')
     // ---- the workgroups' partial rows of hypothesis t: [nblocks][kLmaSlots] doubles, contiguous.  Thread `tid` walks the flat array with the
     // stride 768 = 64 rows (a multiple of kLmaSlots and of the workgroup): its three elements per stride keep their slots, every load is
     // coalesced, 12 are in flight; then slot sl adds its 64 (thread, m) partial sums in a fixed order.
@@ -51,7 +52,7 @@ __device__ __forceinline__ void lma_rows_stage(const double* __restrict__ partia
         bool mx[3];
 #pragma unroll
         for (int m = 0; m < 3; ++m) mx[m] = ((tid + kLB * m) % kLmaSlots) == kLmaG;
-        constexpr int UB = 8;  // strides per batch: 24 loads in flight per thread (the stage is bound by their latency)
+        constexpr int UB = 20;  // strides per batch: 60 loads in flight per thread -- 1280 rows in ONE round trip (the stage is bound by their latency)
         for (int f0 = 0; f0 < total; f0 += UB * 768) {
             double vv[UB][3];
 #pragma unroll
@@ -79,7 +80,6 @@ __device__ __forceinline__ void lma_rows_stage(const double* __restrict__ partia
         if (tid >= 6 && tid < kLmaRowScore) s_row[tid] = 0.0;
     }
     // ---- the listed pixels, sorted by pixel index (rank sort: the indices of a hypothesis are distinct)
-    const int raw = irr_count[t];
     const int nl = min(raw, kLmaListCap);
     for (int i = tid; i < nl; i += kLB) s_list[i] = irr_list[(int64_t)t * kLmaListCap + i];
     __syncthreads();

@@ -201,6 +201,10 @@ def main(cases=None, seed0=None):
                 use_k = bool(rng.integers(2)) and k != 0.0
                 samples = O.sample_indices(n, T, int(rng.integers(1 << 30)))
                 dm = int(rng.integers(2))
+                # (FUZZ_LM_ARITHMETIC=1: the iterate-by-iterate kernels.  Default 0 = the analytic LM trajectory -- set before EVERY case, which
+                # also ends a hold: otherwise the noise-free cases, whose ties send a run back to the iterate-by-iterate kernels for the
+                # context's next 16 runs, would keep most of the campaign off the analytic path)
+                s.set_lm_arithmetic(int(os.environ.get("FUZZ_LM_ARITHMETIC", "0")))
                 r = s.ransac(q, u, a, ak, use_k, T, tol, samples=samples, depth_mode=dm)
                 ro = O.ransac(q, u, a, ak, use_k, T, tol, samples, depth_mode=dm)
                 assert np.array_equal(r["trial_count"], ro["trial_count"]), "trial_count"
@@ -304,6 +308,11 @@ def main(cases=None, seed0=None):
             except rsdsfm.RsdsfmError as e:
                 bad += 1
                 print("ERROR", tag, e, flush=True)
+            lma = s.lma_restarts() if c == (only or range(cases))[-1] else None
+            if lma is not None:
+                # the RANSACs ran on the analytic LM trajectory (the library's default): how often a global guard sent a run back to the
+                # iterate-by-iterate kernels (ties on noise-free data, mostly), and which guards tripped last
+                print("analytic LM trajectory: %d of the RANSAC runs started over iterate by iterate (last guards: bit set %d)" % lma, flush=True)
     if not only:
         bad += fuzz_consumers(O, rsdsfm, max(cases // 2, 1), seed0)
     print("fuzz: %d cases, %d mismatches; %d all-inlier ties decided by rounding noise, %d ill-conditioned / split refinement trajectories (outcome compared), "

@@ -708,7 +708,10 @@ def run(args):
             # the regimes the headline does not exercise, lifted to the top level of the line: `value_selective` = the same one-call solve
             # at the selective tolerance 0.002 (M < N: compaction and the rank-indexed flow are NOT the identity), `value_sequence` =
             # BASELINE configs[4] (32 pairs / 32 data seeds through rsdsfm_solve_frames_dev), both in the line's unit
-            line["ransac_restarts"] = solver.ransac_restarts()  # solves of this context that started over with the standard functions (0 on real-valued data)
+            # solves of this context that started over with the standard functions: none on the headline's pairs nor (since round 5: an exact
+            # zero is a select inside the cores) on noise-free flow; the acceleration-mode regime's minimal solver (6x6 eigenvalues) meets an
+            # operand outside the cores' range once or twice
+            line["ransac_restarts"] = solver.ransac_restarts()
             # solves of this context whose analytic pass tripped a guard and started over iterate by iterate, and which guards (bit 7: a tie in
             # count and error sum -- the noise-free regime; the headline's DeepFlow-like pairs trip none)
             lr, lg = solver.lma_restarts()

@@ -51,7 +51,7 @@ __device__ __forceinline__ bool pose_nan(const Pose& p) {
 // the pixels b chunk + slot, + P, + 2 P, ...  partials: [T][gridDim.x][kLmaSlots] (hypothesis-major, like ransac_lm_kernel's).
 // lists: irr_count[T] (zeroed per solve), irr_list[T][kLmaListCap] pixel indices in order of arrival (the rows stage sorts them).
 template <int NC>
-__global__ __launch_bounds__(kLB) __attribute__((amdgpu_waves_per_eu(5, 5))) void ransac_lma_kernel(const double2* __restrict__ q, const double2* __restrict__ u, const double* __restrict__ alpha,
+__global__ __launch_bounds__(kLB) __attribute__((amdgpu_waves_per_eu(4, 5))) void ransac_lma_kernel(const double2* __restrict__ q, const double2* __restrict__ u, const double* __restrict__ alpha,
                                                         const double* __restrict__ alpha_k, int64_t n, const double* __restrict__ hyp, int T,
                                                         const LmaCand cd, double* __restrict__ partials, int* __restrict__ irr_count,
                                                         int* __restrict__ irr_list, int64_t chunk, unsigned long long* __restrict__ clk_probe, int clk_bid) {
@@ -80,8 +80,11 @@ __global__ __launch_bounds__(kLB) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
     if (active) {
         const Pose pose = load_pose(hyp, t);
         const double two_over = 2.0 / (2.0 + pose.k);
-        // one pixel under this lane's hypothesis
-        auto pixel = [&](const PixIn& px, unsigned i) {
+        // one pixel under this lane's hypothesis; returns whether it goes to the list.  Straight-line on purpose (no branch around the square
+        // roots: the error of a pixel that is not an inlier is multiplied by a 0.0 mask instead of being skipped -- the argument is floored into
+        // the core's range first, so the product is exact and the sum has the same bits), so that the two pixels of an iteration form ONE basic
+        // block and their chains interleave
+        auto pixel = [&](const PixIn& px) -> bool {
             const LmaPx v = lma_pixel(px.x, px.y, px.ux, px.uy, px.al, px.ak, pose, two_over);
             A += v.a;
             B += v.ge;
@@ -97,12 +100,14 @@ __global__ __launch_bounds__(kLB) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                 const bool in = e2 < cd.tol2;
                 listed = listed || (fabs(e2 - cd.tol2) <= m);
                 cnt[c] += in ? 1 : 0;
-                es[c] += (in && e2 >= kLmaSqrtMin) ? sqrt_core(e2) : 0.0;
+                const double err = sqrt_core(lma_max_pos(e2, kLmaSqrtMin));  // (finite for every e2, NaN included: v_max_f64 drops it)
+                es[c] = __builtin_fma(err, __hiloint2double((in && e2 >= kLmaSqrtMin) ? 0x3FF00000 : 0, 0), es[c]);
             }
-            if (listed) {  // guards (a) / (b): rare (a handful of pixels per hypothesis)
-                const int pos = atomicAdd(&irr_count[t], 1);
-                if (pos < kLmaListCap) irr_list[(int64_t)t * kLmaListCap + pos] = (int)(p0 + (int64_t)i);
-            }
+            return listed;
+        };
+        auto push = [&](unsigned i) {  // guards (a) / (b): rare (a handful of pixels per hypothesis)
+            const int pos = atomicAdd(&irr_count[t], 1);
+            if (pos < kLmaListCap) irr_list[(int64_t)t * kLmaListCap + pos] = (int)(p0 + (int64_t)i);
         };
         // whole rounds of the P slots: a uniform trip count (every workgroup but the last owns a multiple of P pixels), the next pixel's
         // loads in flight under this pixel's arithmetic; then the ragged round of the last workgroup
@@ -115,15 +120,19 @@ __global__ __launch_bounds__(kLB) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
         if (rounds > 0) pa = load_pix(qb, ub, ab, akb, i);
         for (; r + 1 < rounds; r += 2, i += 2 * uP) {
             pb = load_pix(qb, ub, ab, akb, i + uP);
-            pixel(pa, i);
-            if (r + 2 < rounds) pa = load_pix(qb, ub, ab, akb, i + 2 * uP);
-            pixel(pb, i + uP);
+            const bool la = pixel(pa);
+            pa = load_pix(qb, ub, ab, akb, r + 2 < rounds ? i + 2 * uP : i);  // (no branch between the two pixels: past the end, a pixel that is not used)
+            const bool lb = pixel(pb);
+            if (la || lb) {
+                if (la) push(i);
+                if (lb) push(i + uP);
+            }
         }
         if (r < rounds) {
-            pixel(pa, i);
+            if (pixel(pa)) push(i);
             i += uP;
         }
-        if (i < (unsigned)len) pixel(load_pix(qb, ub, ab, akb, i), i);
+        if (i < (unsigned)len && pixel(load_pix(qb, ub, ab, akb, i))) push(i);
     }
     // the P slots of a hypothesis, in slot order
     s_part[g][0] = A, s_part[g][1] = B, s_part[g][2] = C, s_part[g][3] = D, s_part[g][4] = E, s_part[g][kLmaG] = G;

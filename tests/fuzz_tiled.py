@@ -92,7 +92,9 @@ def compare(a, b, rtol):
     for key in ("num_iterations", "num_successful_steps", "num_unsuccessful_steps", "termination"):
         if a["refine_summary"][key] != b["refine_summary"][key]:
             return "refinement " + key
-    if not (np.allclose(a["v"], b["v"], rtol=rtol, atol=1e-13) and np.allclose(a["w"], b["w"], rtol=rtol, atol=1e-13) and np.isclose(a["k"], b["k"], rtol=rtol, atol=1e-13)):
+    # (equal_nan: ONE trial whose sample is degenerate gives a NaN hypothesis, no inlier, no refinement iteration: the pose stays NaN on both sides)
+    if not (np.allclose(a["v"], b["v"], rtol=rtol, atol=1e-13, equal_nan=True) and np.allclose(a["w"], b["w"], rtol=rtol, atol=1e-13, equal_nan=True) and
+            np.isclose(a["k"], b["k"], rtol=rtol, atol=1e-13, equal_nan=True)):
         pa, pb = np.concatenate([a["v"], a["w"], [a["k"]]]), np.concatenate([b["v"], b["w"], [b["k"]]])
         return "pose (max |difference| / max |component| = %.2e, %d refinement iterations)" % (np.abs(pa - pb).max() / np.abs(pb).max(), b["refine_summary"]["num_iterations"])
     da, db = a["depth_map"], b["depth_map"]

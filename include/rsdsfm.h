@@ -143,11 +143,20 @@ int rsdsfm_ransac_restarts(rsdsfm_ctx* ctx, int64_t* count);
  *   count that only rounding noise could break (noise-free data), makes the run start over iterate by iterate, as do the context's next
  *   16 runs.  The winner's dense inverse depths and mask always come from the exact replay of its accepted steps.
  * 1: always iterate by iterate (the reference's arithmetic, operation for operation).
+ * Inside rsdsfm_solve_frame*_dev, which does not report the trials' error sums, mode 0 has a second form of the pass: COUNT-ONLY.
+ *   minimal.cc:278-285 reads a trial's error sum only to break a tie in the inlier count, so behind two solves of the context whose best
+ *   count no other trial shared (a selective tolerance) the pass leaves the two square roots per pixel-hypothesis out (~30 % of its
+ *   instructions); should trials share the best count after all, exactly those are scored by the iterate-by-iterate scoring pass (the
+ *   reference's arithmetic: the tie is broken as the reference breaks it) and the context goes back to fused error sums.  With a
+ *   permissive tolerance (BASELINE's 0.05 admits every pixel under any good hypothesis) the sums decide every solve and stay fused.
+ * 2: mode 0 with the count-only form forced (tests and measurements).
  * rsdsfm_lma_restarts: how many RANSAC runs of this context (and its sequence lanes) started over because a guard tripped, and (optional)
  * which guards tripped last, as a bit set (1 << r: r = 1 infinite sum, 2 gradient / 3 model-change / 4 parameter / 5 function tolerance within
  * the band, 6 step quality, 7 tie, 8 list overflow, 9 listed pixels off the tabulated trajectory, 10 count check of the winner's replay). */
 int rsdsfm_set_lm_arithmetic(rsdsfm_ctx* ctx, int mode);
 int rsdsfm_lma_restarts(rsdsfm_ctx* ctx, int64_t* count, int32_t* last_guards_or_null);
+/* how many RANSACs of this context (and its sequence lanes) ran the count-only form of the pass, and how many of those had to fetch error sums */
+int rsdsfm_lma_count_only(rsdsfm_ctx* ctx, int64_t* runs, int64_t* lazy_runs_or_null);
 /* The dense depth solve (rsdsfm_estimate_inverse_depths*, LM mode) takes the same in-range cores in launch 0 (Jacobi scaling) under the same
  * switch (rsdsfm_set_ransac_math); a solve whose launch 0 met an argument out of their range is left unfinished by its follow-up
  * launch and rsdsfm_depth_finish_dev -- which every LM-mode caller runs to obtain the summary -- starts it over with the standard

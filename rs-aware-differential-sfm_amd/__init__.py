@@ -270,6 +270,12 @@ class Solver:
         self._check(self.lib.rsdsfm_lma_restarts(self._ctx, C.byref(n), C.byref(g)), "rsdsfm_lma_restarts")
         return int(n.value), int(g.value)
 
+    def lma_count_only(self):
+        """(RANSACs of frame solves that ran the count-only form of the analytic pass, those of them that had to fetch error sums)"""
+        a, b = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.rsdsfm_lma_count_only(self._ctx, C.byref(a), C.byref(b)), "rsdsfm_lma_count_only")
+        return int(a.value), int(b.value)
+
     def ransac_restarts(self):
         """RANSAC runs of this context that started over with the standard functions (rsdsfm_ransac_restarts)"""
         n = C.c_int64()

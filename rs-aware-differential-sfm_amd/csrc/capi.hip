@@ -275,10 +275,23 @@ int rsdsfm_ransac_restarts(rsdsfm_ctx* ctx, int64_t* count) {
 
 int rsdsfm_set_lm_arithmetic(rsdsfm_ctx* ctx, int mode) {
     CTX_OR_FAIL(ctx);
-    if (mode < 0 || mode > 1) return fail(c, RSDSFM_ERR_INVALID, "LM arithmetic: 0 = analytic trajectory with guards (default), 1 = iterate by iterate");
-    c->lm_arithmetic = mode;
-    c->lma_hold = 0;
-    for (rsdsfm_ctx* lane : c->lanes) lane->c.lm_arithmetic = mode, lane->c.lma_hold = 0;
+    if (mode < 0 || mode > 2)
+        return fail(c, RSDSFM_ERR_INVALID, "LM arithmetic: 0 = analytic trajectory with guards (default), 1 = iterate by iterate, 2 = 0 with the frame solve's count-only pass forced");
+    c->lm_arithmetic = mode == 1 ? 1 : 0;
+    c->lma_count_only_force = mode == 2;
+    c->lma_hold = c->lma_unique_run = 0;
+    for (rsdsfm_ctx* lane : c->lanes)
+        lane->c.lm_arithmetic = c->lm_arithmetic, lane->c.lma_count_only_force = c->lma_count_only_force, lane->c.lma_hold = lane->c.lma_unique_run = 0;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_lma_count_only(rsdsfm_ctx* ctx, int64_t* runs, int64_t* lazy_runs) {
+    CTX_OR_FAIL(ctx);
+    if (!runs) return fail(c, RSDSFM_ERR_INVALID, "lma count only: null output");
+    int64_t a = c->lma_count_only_runs, b = c->lma_lazy_runs;
+    for (rsdsfm_ctx* lane : c->lanes) a += lane->c.lma_count_only_runs, b += lane->c.lma_lazy_runs;
+    *runs = a;
+    if (lazy_runs) *lazy_runs = b;
     return RSDSFM_OK;
 }
 

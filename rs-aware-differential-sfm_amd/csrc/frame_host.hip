@@ -274,7 +274,7 @@ int frame_begin(Ctx* c, FrameRun* F) {
     F->rc_begin = ransac_begin(c, F->d_q, F->d_u, F->d_a, F->d_ak, n, prm->use_acceleration_mode, prm->ransac_trials, prm->ransac_tol, nullptr, J.seed,
                                prm->depth_mode, prm->k_sign_mode, &F->ro, prm->use_refinement ? &F->spec_tail : nullptr, &F->refinement_enqueued, &F->ransac,
                                F->side_flatten ? &F->direct : nullptr, F->side_flatten && !F->dense_in_launch ? &F->join : nullptr,
-                               F->dense_in_launch ? &F->dense : nullptr, F->ahead);
+                               F->dense_in_launch ? &F->dense : nullptr, F->ahead, true);
     return RSDSFM_OK;  // (an error of the speculated run may only mean that n was wrong: frame_finish sorts that out)
 }
 
@@ -311,7 +311,7 @@ int frame_finish(Ctx* c, FrameRun* F, rsdsfm_frame_result* res) {
         counted = false;
         rc = ransac_begin(c, F->d_q, F->d_u, F->d_a, F->d_ak, n, prm->use_acceleration_mode, prm->ransac_trials, prm->ransac_tol, nullptr, J.seed,
                           prm->depth_mode, prm->k_sign_mode, &F->ro, prm->use_refinement ? &F->spec_tail : nullptr, &F->refinement_enqueued, &F->ransac, nullptr, nullptr,
-                          nullptr, F->ahead);
+                          nullptr, F->ahead, true);
         if (rc == RSDSFM_OK) rc = ransac_finish(c, &F->ransac);
         counted = rc == RSDSFM_OK;
     }
@@ -464,6 +464,7 @@ int rsdsfm_solve_frames_dev(rsdsfm_ctx* ctx, const rsdsfm_frame_job* jobs, int32
         lc->ransac_k0 = c->ransac_k0;
         lc->ransac_math_mode = c->ransac_math_mode;
         lc->lm_arithmetic = c->lm_arithmetic;
+        lc->lma_count_only_force = c->lma_count_only_force;
         lc->frame_side_flatten = c->frame_side_flatten;
         lc->refine_stage_mode = c->refine_stage_mode;
     }

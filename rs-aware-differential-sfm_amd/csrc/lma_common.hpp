@@ -84,6 +84,7 @@ struct LmaCand {
     int steps[kLmaNC];    // accepted steps of each (1 ..  kLmaKP - 1)
     double phi2[kLmaNC];  // phi^2 of each
     double tol, tol2, c1, c1x2;  // tolerance, its square, eta tol / 2 and eta tol
+    int count_only;              // the pass fuses the inlier COUNTS of its iterates only (ransac_lma_kernel ERR = false): the error sums in the rows stay 0
     LmaPlan plan;                // the planned trajectory (computed once on the host: a chain of divisions)
 };
 

@@ -129,7 +129,7 @@ __device__ __forceinline__ void lma_rows_stage(const double* __restrict__ partia
                     const double ex = point_error(px.x, px.y, px.ux, px.uy, px.al, px.ak, pose, two_over, wk.rho[cd.steps[c]]);
                     const bool in_x = ex < cd.tol;
                     dc = (in_x ? 1.0 : 0.0) - (in_a ? 1.0 : 0.0);
-                    de = (in_x ? ex : 0.0) - err_a;
+                    de = cd.count_only ? 0.0 : (in_x ? ex : 0.0) - err_a;
                 }
                 xr[2 + 5 * kLmaKP + 2 * c] = dc;
                 xr[2 + 5 * kLmaKP + 2 * c + 1] = de;

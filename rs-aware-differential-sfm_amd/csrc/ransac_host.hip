@@ -1,5 +1,7 @@
 // ransac_host.hip -- host orchestration of minimal::calculateVelocities / minimal::ransac over the HIP kernels
 // (reference minimal.cc:36-177, :209-306) and their C-ABI entry points.
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -189,7 +191,7 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                     // back as "still running": rounds 1, 2, ... below are the iterate-by-iterate kernels', where only such hypotheses take part
                     rc = ransac_lma_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_hyp + (size_t)b0 * 8, B, R.d_states + b0, R.d_partials, R.d_flags,
                                            R.d_scored + b0, R.d_tcount + b0, R.d_terr + b0, tol, R.lma_cand, 2, R.d_irr_count, R.d_irr_list, R.d_unscored,
-                                           nullptr, R.core_epoch ? c->d_core_flag : nullptr, R.core_epoch);
+                                           nullptr, R.core_epoch ? c->d_core_flag : nullptr, R.core_epoch, R.count_only);
                 } else {
                     rc = ransac_lm_round_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_hyp + (size_t)b0 * 8, B, R.d_states + b0, R.d_partials, R.d_flags,
                                                 R.d_scored + b0, R.d_tcount + b0, R.d_terr + b0, round, tol, R.k0, R.fused_base, R.core_math,
@@ -204,14 +206,22 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                     // ends after three accepted steps, which round 0 does not score), that pass is enqueued ahead of the final
                     // stage as well: it only touches hypotheses round 0 left unscored (a no-op on other data) and saves the
                     // round trip plus a discarded final stage (~57 us).  What is enqueued when never changes a result.
+                    // Count-only analytic pass (the frame solve): the trials that SHARE the best count get their error sums from that same
+                    // pass, but which they are is the pick kernel's to say -- so a pick goes ahead of it too (it leaves the list alone where
+                    // the decide stage has put hypotheses on it, and writes it where the counts are complete and tie).
+                    const PickLazy lazy = R.count_only ? PickLazy{R.d_scored, R.d_unscored, R.d_flags + 1} : PickLazy();
                     if (c->ransac_score_idle < kScoreIdleLimit) {
+                        if (R.count_only) {
+                            rc = ransac_pick_launch(c, R.d_tcount, R.d_terr, T, R.d_hyp, R.d_best, nullptr, R.d_flags, nullptr, 0, nullptr, 0, 0, nullptr, 0.0, lazy);
+                            if (rc != RSDSFM_OK) return rc;
+                        }
                         rc = ransac_score_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_hyp, T, R.d_states, depth_mode, tol, R.d_scored, R.d_partials,
                                                  R.d_tcount, R.d_terr, R.d_unscored, R.d_flags + 1);
                         if (rc != RSDSFM_OK) return rc;
                         R.spec_scored = true;
                     }
                     rc = ransac_pick_launch(c, R.d_tcount, R.d_terr, T, R.d_hyp, R.d_best, R.h_best, R.d_flags, R.h_running, R.spec_scored ? 1 : 0,  // (+ the flag words)
-                                            nullptr, 0, 0, nullptr, R.tie_margin);
+                                            nullptr, 0, 0, nullptr, R.tie_margin, lazy);
                     if (rc != RSDSFM_OK) return rc;
                     flags_via_pick = true;
                     rc = ransac_final_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_best, R.d_states, depth_mode, tol, R.d_rho, R.d_mask, R.d_bcounts,
@@ -286,7 +296,8 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
             case kPcAfterRounds: {
                 R.need_score = R.h_running[1] > 0;  // hypotheses whose final iterate is not the fused one-step state
                 if (R.B == T) R.score_hint_next = R.need_score ? 1 : 0;
-                if (R.need_score && R.final_done && R.spec_scored) R.need_score = false;  // round 0 decided everything and the pass already ran
+                // round 0 decided everything and the pass already ran (unless the pick behind it found trials sharing the best count without their error sums)
+                if (R.need_score && R.final_done && R.spec_scored && !R.h_best->lazy_pending) R.need_score = false;
                 if (R.need_score) R.final_done = false;
                 R.pc = kPcScore;
                 break;
@@ -307,7 +318,8 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                 if (!R.final_done) {
                     R.tail_enqueued = false;  // the speculated final stage (and whatever was enqueued behind it) saw incomplete trials
                     R.spec_final = false;
-                    rc = ransac_pick_launch(c, R.d_tcount, R.d_terr, T, R.d_hyp, R.d_best, R.h_best, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, R.tie_margin);  // h_best: host-mapped, written by the kernels
+                    rc = ransac_pick_launch(c, R.d_tcount, R.d_terr, T, R.d_hyp, R.d_best, R.h_best, nullptr, nullptr, 0, nullptr, 0, 0, nullptr, R.tie_margin,  // h_best: host-mapped, written by the kernels
+                                            R.count_only ? PickLazy{R.d_scored, R.d_unscored, R.d_flags + 1} : PickLazy());
                     if (rc != RSDSFM_OK) return rc;
                     rc = ransac_final_launch(c, R.d_q, R.d_u, R.d_a, R.d_ak, n, R.d_best, R.d_states, depth_mode, tol, R.d_rho, R.d_mask, R.d_bcounts,
                                              R.d_boffs, out->inlier_idx, out->inliers, out->alpha, out->alpha_k, R.h_best);
@@ -333,12 +345,27 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
             case kPcFinalWait: {
                 RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
                 const RansacBest* h_best = R.h_best;
+                static const bool dbg = getenv("RSDSFM_RANSAC_DEBUG") != nullptr;
+                if (dbg) fprintf(stderr, "[ransac] final wait: lazy_pending %d undecided %d flags %d %d %d %d hist %d %d %d %d spec_scored %d spec_final %d tail %d idle %d\n", h_best->lazy_pending, h_best->undecided, R.h_running[0], R.h_running[1], R.h_running[2], R.h_running[3], R.h_running[4], R.h_running[5], R.h_running[6], R.h_running[7], (int)R.spec_scored, (int)R.spec_final, (int)R.tail_enqueued, c->ransac_score_idle);
+                if (R.count_only && h_best->lazy_pending) {
+                    // the definitive pick found several trials sharing the best count, some without their error sum (everything behind it has
+                    // left at once): the scoring pass on the list the pick wrote, then the final stage again
+                    if (++R.lazy_rounds > T + 2) return fail(c, RSDSFM_ERR_NUMERIC, "lazy error sums did not settle");
+                    R.final_done = R.tail_enqueued = R.spec_final = false;
+                    R.need_score = true;
+                    R.score_hint_next = 1;
+                    R.b0 = 0;
+                    R.B = T;
+                    R.pc = kPcScore;
+                    break;
+                }
                 if (R.analytic && h_best->lma_tie) {  // guard (d) at the definitive pick (everything behind it has left at once)
                     rc = lma_start_over(c, R, 1 << 7);
                     if (rc != RSDSFM_OK) return rc;
                     break;
                 }
                 R.lma_tie_seen = h_best->lma_tie != 0;
+                R.shared_best = h_best->shared_best;
                 if (h_best->num_inliers != h_best->num_inliers_scan) {
                     // analytic pass: the winner's mask comes from the reference's exact replay (ransac_final_kernel) and must count what the
                     // closed form counted -- the guards' claim, checked on every run.  A difference is not an error of the data: start over.
@@ -384,6 +411,9 @@ void ransac_commit_hints(Ctx* c, const RansacRun& R) {
     c->ransac_not_one_step = R.not_one_step;
     c->ransac_spec_miss = R.spec_final ? 0 : std::min(c->ransac_spec_miss + 1, 2);
     if (R.lma_cand_next[0]) c->lma_cand[0] = R.lma_cand_next[0], c->lma_cand[1] = R.lma_cand_next[1];
+    if (R.count_only) c->lma_count_only_runs += 1, c->lma_lazy_runs += (R.lazy_rounds > 0 || R.shared_best > 1) ? 1 : 0;
+    if (R.lazy_rounds > 0 || R.shared_best > 1) c->lma_unique_run = 0;
+    else if (R.shared_best == 1) c->lma_unique_run = std::min(c->lma_unique_run + 1, 2);
     if (R.lma_guard) c->lma_last_guard = R.lma_guard, c->lma_handed_over += 1;
     if (R.lma_restarted) {  // a global guard tripped (a tie, the count check): this kind of data stays on the iterate-by-iterate kernels for a while
         c->lma_hold = 16;
@@ -404,7 +434,7 @@ void ransac_commit_hints(Ctx* c, const RansacRun& R) {
 int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n, int use_alpha_k, int T,
                  double tol, const int32_t* h_samples, uint64_t seed, int depth_mode, int k_sign_mode, rsdsfm_ransac_out* out,
                  const RansacSpecTail* spec_tail, bool* spec_tail_held, RansacRun* run, const Minimal9Direct* direct,
-                 const std::function<int()>* after_minimal9, const DenseFlatten* dense, bool tail_ahead) {
+                 const std::function<int()>* after_minimal9, const DenseFlatten* dense, bool tail_ahead, bool count_only) {
     RansacRun& R = *run;
     R = RansacRun();
     R.tail_ahead = tail_ahead;
@@ -414,6 +444,12 @@ int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a
     // reports such ties (-: they renew the hold)
     R.tie_margin = depth_mode != RSDSFM_DEPTH_CERES_LM || c->lm_arithmetic != 0 ? 0.0 : (R.analytic ? kLmaTieMargin : -kLmaTieMargin);
     R.lma_cand[0] = c->lma_cand[0], R.lma_cand[1] = c->lma_cand[1];
+    // count-only analytic pass + lazy error sums (ransac_lma_kernel ERR = false, ransac_pick_kernel): for callers that do not read the trials' error
+    // sums (the frame solve); one hypothesis batch.  No tie guard there: where a tie has to be broken the sums are the reference arithmetic's.
+    // Only behind two solves whose best count was unique (a selective tolerance): with a permissive one -- BASELINE's 0.05 admits every
+    // pixel under any good hypothesis -- the error sums decide every solve and the fused ones are far cheaper than the scoring pass.
+    R.count_only = count_only && R.analytic && T <= kRansacBatch && (c->lma_unique_run >= 2 || c->lma_count_only_force);
+    if (R.count_only) R.tie_margin = 0.0;
     if (spec_tail_held) *spec_tail_held = false;
     if (!out) return fail(c, RSDSFM_ERR_INVALID, "null out");
     if (n < 9) return fail(c, RSDSFM_ERR_INVALID, "ransac needs at least 9 points (the reference would compute rand() % 0)");

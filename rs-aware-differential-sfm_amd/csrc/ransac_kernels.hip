@@ -762,7 +762,7 @@ __global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restric
                                                         const double* __restrict__ hyp, RansacBest* best, RansacBest* best_host,
                                                         const int* __restrict__ flags, int* __restrict__ flags_host, int scored_ahead,
                                                         const double* __restrict__ cnt_rt = nullptr, int cnt_stride = 0, int nranks = 0,
-                                                        int64_t* __restrict__ m_all = nullptr, double tie_margin = 0.0) {
+                                                        int64_t* __restrict__ m_all = nullptr, double tie_margin = 0.0, PickLazy lazy = PickLazy()) {
     if (blockIdx.x != 0) return;
     const int lane = threadIdx.x;
     // With flags this pick runs on speculation (behind round 0, before the host has seen them).  If hypotheses are still running, or
@@ -791,9 +791,41 @@ __global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restric
         }
     }
     if (tie_margin > 0.0) undecided |= tie;
+    // Lazy error sums (the analytic pixel pass in its count-only form, ransac_lma_kernel ERR = false): minimal.cc:278-285 reads a trial's error
+    // sum only to break a tie in the inlier count, so the winner is the earliest trial with the smallest error sum among the trials S that share
+    // the best count -- whatever the sums of the others.  One member: it has won.  More: every member needs its error sum in the REFERENCE's
+    // arithmetic (the tie is broken as the reference breaks it, down to the last bit); the members that only have a count (scored == 2) go to the
+    // scoring pass's list, the result is undecided, and the host runs ransac_score_kernel on the list and this kernel again.
+    int pending = 0, list_n = 0, ns = 0;
+    if (bi >= 0 && best_count > 0.0 && !(flags && (flags[0] != 0 || (flags[1] > 0 && !scored_ahead) || flags[3] != 0))) {
+        int nco = 0;
+        for (int t0 = 0; t0 < T; t0 += 64) {
+            const int t = t0 + lane;
+            const bool hit = t < T && trial_count[t] == best_count;
+            ns += __builtin_popcountll(__builtin_amdgcn_ballot_w64(hit));
+            nco += __builtin_popcountll(__builtin_amdgcn_ballot_w64(hit && lazy.scored && lazy.scored[t] == 2));
+        }
+        if (ns > 1 && nco > 0) {
+            int base = 0;
+            for (int t0 = 0; t0 < T; t0 += 64) {
+                const int t = t0 + lane;
+                const bool co = t < T && trial_count[t] == best_count && lazy.scored[t] == 2;
+                const unsigned long long mk = __builtin_amdgcn_ballot_w64(co);
+                if (co) {
+                    lazy.list[base + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] = t;
+                    lazy.scored[t] = 0;  // (ransac_score_kernel / ransac_reduce_scores_kernel: not scored yet)
+                }
+                base += __builtin_popcountll(mk);
+            }
+            if (lane == 0) *lazy.list_count = nco;
+            pending = 1;
+            list_n = nco;
+            undecided = 1;
+        }
+    }
     // the round's flag words (final since ransac_decide_kernel) travel to host-mapped memory with this launch: no copy behind the stage
-    // ([3] bit 2: the tie)
-    if (flags_host && lane < 8) flags_host[lane] = flags[lane] | ((lane == 3 && tie && tie_margin > 0.0) ? 4 : 0);
+    // ([3] bit 2: the tie; [1]: the scoring pass's list, which the lazy error sums above may have written)
+    if (flags_host && lane < 8) flags_host[lane] = (lane == 1 && pending) ? list_n : (flags[lane] | ((lane == 3 && tie && tie_margin > 0.0) ? 4 : 0));
     // column-tiled solve: the inlier counts of ALL slabs for the winner, from the shares the decide / merge stages kept
     if (m_all)
         for (int r = lane; r < nranks; r += 64) m_all[r] = bi >= 0 ? (int64_t)cnt_rt[(int64_t)r * cnt_stride + bi] : 0;
@@ -804,12 +836,16 @@ __global__ __launch_bounds__(64) void ransac_pick_kernel(const double* __restric
         best->best_trial = bi;
         best->undecided = undecided;
         best->lma_tie = tie;
+        best->lazy_pending = pending;
+        best->shared_best = ns;
         best->num_inliers = bi >= 0 ? (int64_t)best_count : 0;
         best->inlier_error = best_err;
         if (best_host) {
             best_host->best_trial = bi;
             best_host->undecided = undecided;
             best_host->lma_tie = tie;
+            best_host->lazy_pending = pending;
+            best_host->shared_best = ns;
             best_host->num_inliers = bi >= 0 ? (int64_t)best_count : 0;
             best_host->inlier_error = best_err;
         }
@@ -1152,9 +1188,9 @@ int ransac_rows_doubles() { return NSR; }
 
 int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best,
                        RansacBest* best_host, const int* d_flags, int* h_flags, int scored_ahead, const double* cnt_rt, int cnt_stride,
-                       int nranks, int64_t* m_all, double tie_margin) {
+                       int nranks, int64_t* m_all, double tie_margin, PickLazy lazy) {
     hipLaunchKernelGGL(ransac_pick_kernel, dim3(1), dim3(64), 0, c->stream, trial_count, trial_err, T, hyp, best, best_host, d_flags, h_flags, scored_ahead,
-                       cnt_rt, cnt_stride, nranks, m_all, tie_margin);
+                       cnt_rt, cnt_stride, nranks, m_all, tie_margin, lazy);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }

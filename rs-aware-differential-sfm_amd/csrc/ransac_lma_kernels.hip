@@ -50,7 +50,10 @@ __device__ __forceinline__ bool pose_nan(const Pose& p) {
 // Workgroup b owns the pixels [b chunk, (b + 1) chunk).  Thread g = slot T + t owns hypothesis t and pixel slot `slot` < P = 256 / T: it walks
 // the pixels b chunk + slot, + P, + 2 P, ...  partials: [T][gridDim.x][kLmaSlots] (hypothesis-major, like ransac_lm_kernel's).
 // lists: irr_count[T] (zeroed per solve), irr_list[T][kLmaListCap] pixel indices in order of arrival (the rows stage sorts them).
-template <int NC>
+// ERR = false (the frame solve's RANSAC: `LmaCand::count_only`): inlier COUNTS only.  minimal.cc:278-285 looks at a trial's error sum only to
+// break a tie in the count, so the pass leaves the two square roots per pixel-hypothesis out and ransac_pick_kernel asks for the exact error
+// sums (ransac_score_kernel: the reference's arithmetic) of the trials that share the best count, when there is more than one.
+template <int NC, bool ERR>
 __global__ __launch_bounds__(kLB) __attribute__((amdgpu_waves_per_eu(4, 5))) void ransac_lma_kernel(const double2* __restrict__ q, const double2* __restrict__ u, const double* __restrict__ alpha,
                                                         const double* __restrict__ alpha_k, int64_t n, const double* __restrict__ hyp, int T,
                                                         const LmaCand cd, double* __restrict__ partials, int* __restrict__ irr_count,
@@ -100,8 +103,10 @@ __global__ __launch_bounds__(kLB) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
                 const bool in = e2 < cd.tol2;
                 listed = listed || (fabs(e2 - cd.tol2) <= m);
                 cnt[c] += in ? 1 : 0;
-                const double err = sqrt_core(lma_max_pos(e2, kLmaSqrtMin));  // (finite for every e2, NaN included: v_max_f64 drops it)
-                es[c] = __builtin_fma(err, __hiloint2double((in && e2 >= kLmaSqrtMin) ? 0x3FF00000 : 0, 0), es[c]);
+                if (ERR) {
+                    const double err = sqrt_core(lma_max_pos(e2, kLmaSqrtMin));  // (finite for every e2, NaN included: v_max_f64 drops it)
+                    es[c] = __builtin_fma(err, __hiloint2double((in && e2 >= kLmaSqrtMin) ? 0x3FF00000 : 0, 0), es[c]);
+                }
             }
             return listed;
         };
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(kLB) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
 // tripped (the run starts over on the iterate-by-iterate kernels), [4 + min(steps, 3)] histogram of the accepted steps
 __device__ __forceinline__ void lma_publish(int t, const LmScal& st, const double* hist_l, int fallback, bool scored, double count, double err,
                                             LmState* states, int* flags, int* __restrict__ scored_out, double* __restrict__ trial_count,
-                                            double* __restrict__ trial_err, int* steps_hist, int* __restrict__ unscored_list, int* guard_word) {
+                                            double* __restrict__ trial_err, int* steps_hist, int* __restrict__ unscored_list, int* guard_word, bool count_only) {
     LmState* state = states + t;
     if (fallback) {
         // a guard of THIS hypothesis tripped (a decision inside the undecided band, a list that overflows -- e.g. a hypothesis whose k puts beta
@@ -192,7 +197,7 @@ __device__ __forceinline__ void lma_publish(int t, const LmScal& st, const doubl
     if (scored) {
         trial_count[t] = count;
         trial_err[t] = err;
-        scored_out[t] = 1;
+        scored_out[t] = count_only ? 2 : 1;  // (2: the count alone -- ransac_pick_kernel asks for the error sum where the tie rule needs it)
     } else {
         const int pos = atomicAdd(&flags[1], 1);
         if (unscored_list) unscored_list[pos] = t;
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(kLB) void ransac_lma_rows_decide_kernel(const doubl
         double count, err;
         const Pose pose = load_pose(hyp, t);
         const int fb = lma_decide(s_row, n, cd, cd.plan, pose_nan(pose), st, hist_l, scored, count, err);
-        lma_publish(t, st, hist_l, fb, scored, count, err, states, flags, scored_out, trial_count, trial_err, flags + 4, unscored_list, guard_word);
+        lma_publish(t, st, hist_l, fb, scored, count, err, states, flags, scored_out, trial_count, trial_err, flags + 4, unscored_list, guard_word, cd.count_only != 0);
     }
 }
 
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(64) void ransac_lma_decide_kernel(const double* __r
     double count, err;
     const Pose pose = load_pose(hyp, t);
     const int fb = lma_decide(row, n_total, cd, cd.plan, pose_nan(pose), st, hist_l, scored, count, err);
-    lma_publish(t, st, hist_l, fb, scored, count, err, states, flags, scored_out, trial_count, trial_err, nullptr, unscored_list, guard_word);
+    lma_publish(t, st, hist_l, fb, scored, count, err, states, flags, scored_out, trial_count, trial_err, nullptr, unscored_list, guard_word, cd.count_only != 0);
     if (cnt_rt && scored && !fb) {
         int cc = -1;
         for (int c = 0; c < cd.nc; ++c)
@@ -277,7 +282,7 @@ __global__ __launch_bounds__(64) void ransac_lma_decide_kernel(const double* __r
 // launchers
 // ---------------------------------------------------------------------------------------------------
 // fused iterates of a pixel pass: the accepted-step counts in `steps` (each 1 .. kLmaKP - 1, distinct), at most kLmaNC
-LmaCand lma_candidates(const int* steps, int nc, double tol) {
+LmaCand lma_candidates(const int* steps, int nc, double tol, bool count_only = false) {
     LmaCand cd;
     const LmaPlan plan = lma_plan();
     cd.plan = plan;
@@ -291,6 +296,7 @@ LmaCand lma_candidates(const int* steps, int nc, double tol) {
     cd.tol2 = tol * tol;
     cd.c1 = 0.5 * kLmaEta * tol;
     cd.c1x2 = 2.0 * cd.c1;
+    cd.count_only = count_only ? 1 : 0;
     return cd;
 }
 
@@ -321,11 +327,13 @@ size_t ransac_lma_list_ints(int batch) { return (size_t)batch * kLmaListCap; }
 static int lma_pass_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n, const double* hyp, int T,
                            const LmaCand& cd, double* partials, int* irr_count, int* irr_list, int* grid_out, unsigned long long* clk = nullptr) {
     // resident workgroups per CU of the kernel that is about to run (registers set it: 5 at 94 VGPRs)
-    static int occ[kLmaNC + 1] = {0, 0, 0, 0};
+    static int occ_tab[2][kLmaNC + 1] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     const int nc = std::min(std::max(cd.nc, 1), (int)kLmaNC);
+    int* occ = occ_tab[cd.count_only ? 1 : 0];
     if (occ[nc] == 0) {
         int nb = 0;
-        const void* fn = nc == 1 ? reinterpret_cast<const void*>(&ransac_lma_kernel<1>) : nc == 2 ? reinterpret_cast<const void*>(&ransac_lma_kernel<2>) : reinterpret_cast<const void*>(&ransac_lma_kernel<3>);
+        const void* fn = cd.count_only ? (nc == 1 ? reinterpret_cast<const void*>(&ransac_lma_kernel<1, false>) : nc == 2 ? reinterpret_cast<const void*>(&ransac_lma_kernel<2, false>) : reinterpret_cast<const void*>(&ransac_lma_kernel<3, false>))
+                                       : (nc == 1 ? reinterpret_cast<const void*>(&ransac_lma_kernel<1, true>) : nc == 2 ? reinterpret_cast<const void*>(&ransac_lma_kernel<2, true>) : reinterpret_cast<const void*>(&ransac_lma_kernel<3, true>));
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, kLB, 0) != hipSuccess || nb < 1) nb = 4;
         occ[nc] = nb;
     }
@@ -336,11 +344,15 @@ static int lma_pass_launch(Ctx* c, const double* q, const double* u, const doubl
     const double2* q2 = reinterpret_cast<const double2*>(q);
     const double2* u2 = reinterpret_cast<const double2*>(u);
     const int clk_bid = clk ? grid / 2 : -1;
-#define RSDSFM_LMA_LAUNCH(NC) \
-    hipLaunchKernelGGL((ransac_lma_kernel<NC>), dim3(grid), dim3(kLB), 0, c->stream, q2, u2, a, ak, n, hyp, T, cd, partials, irr_count, irr_list, chunk, clk, clk_bid)
-    if (cd.nc == 1) RSDSFM_LMA_LAUNCH(1);
-    else if (cd.nc == 2) RSDSFM_LMA_LAUNCH(2);
-    else RSDSFM_LMA_LAUNCH(3);
+#define RSDSFM_LMA_LAUNCH(NC, ERR) \
+    hipLaunchKernelGGL((ransac_lma_kernel<NC, ERR>), dim3(grid), dim3(kLB), 0, c->stream, q2, u2, a, ak, n, hyp, T, cd, partials, irr_count, irr_list, chunk, clk, clk_bid)
+    if (cd.count_only) {
+        if (cd.nc == 1) RSDSFM_LMA_LAUNCH(1, false);
+        else if (cd.nc == 2) RSDSFM_LMA_LAUNCH(2, false);
+        else RSDSFM_LMA_LAUNCH(3, false);
+    } else if (cd.nc == 1) RSDSFM_LMA_LAUNCH(1, true);
+    else if (cd.nc == 2) RSDSFM_LMA_LAUNCH(2, true);
+    else RSDSFM_LMA_LAUNCH(3, true);
 #undef RSDSFM_LMA_LAUNCH
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
@@ -350,9 +362,9 @@ static int lma_pass_launch(Ctx* c, const double* q, const double* u, const doubl
 int ransac_lma_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n, const double* hyp, int T,
                       LmState* states, double* partials, int* flags, int* scored, double* trial_count, double* trial_err, double tol,
                       const int* cand_steps, int ncand, int* irr_count, int* irr_list, int* unscored_list, int* guard_word, const int* m9_core_flag,
-                      int m9_core_epoch) {
+                      int m9_core_epoch, bool count_only) {
     if (T < 1 || T > kLB) return fail(c, RSDSFM_ERR_INVALID, "hypothesis batch of the analytic pass exceeds 256");
-    const LmaCand cd = lma_candidates(cand_steps, ncand, tol);
+    const LmaCand cd = lma_candidates(cand_steps, ncand, tol, count_only);
     int grid = 0;
     const bool prof = c->profile && c->ev_prof[0] && c->ev_prof[1];
     if (prof) RSDSFM_HIP_CHECK(c, hipEventRecord(c->ev_prof[0], c->stream));

@@ -84,7 +84,15 @@ struct RansacBest {
     double inlier_error;
     double hyp[8];  // w(3), v(3), k, status of the best trial
     int32_t lma_tie;  // analytic LM trajectory, guard (d): another trial has the winner's inlier count and an error sum within kLmaTie x count of the winner's (set by a pick launched with a tie margin; such a result is also `undecided`)
-    int32_t _pad_tie;
+    int32_t shared_best;   // trials that have the winner's inlier count, the winner included (0: not evaluated -- incomplete scores, no inliers)
+    int32_t _pad_shared;
+    int32_t lazy_pending;  // count-only analytic pass: several trials share the best inlier count and some of them have no error sum yet (ransac_pick_kernel put them on the scoring pass's list; such a result is also `undecided`)
+};
+// ransac_pick_kernel, lazy error sums: scored[T] (2 = the trial has a count only), the scoring pass's list and its counter; scored == null: off
+struct PickLazy {
+    int* scored = nullptr;
+    int* list = nullptr;
+    int* list_count = nullptr;
 };
 
 // The scoring pass behind round 0 is enqueued ahead of the host's flag read while one of the context's last kScoreIdleLimit solves needed
@@ -118,6 +126,9 @@ struct Ctx {
     // trip starts over on the iterate-by-iterate kernels (ransac_kernels.hip), and the context then stays on those for its next lma_hold solves
     int lm_arithmetic = 0;         // rsdsfm_set_lm_arithmetic: 0 = analytic trajectory with guards (default), 1 = always iterate by iterate
     int lma_hold = 0;              // > 0: that many of the context's next RANSACs run iterate by iterate (set to 16 by a run whose guards tripped; renewed by an iterate-by-iterate run that ends in a tie the analytic arithmetic could not break: noise-free data)
+    bool lma_count_only_force = false;  // rsdsfm_set_lm_arithmetic(2): the frame solve's pass is count-only whatever the previous solves saw (tests)
+    int64_t lma_count_only_runs = 0, lma_lazy_runs = 0;  // RANSACs whose pass was count-only, and those of them that had to fetch error sums (rsdsfm_lma_count_only)
+    int lma_unique_run = 0;        // consecutive RANSACs of this context whose best inlier count no other trial shared (capped at 2): from 2 on the frame solve's pixel pass leaves the error sums out (count-only; a tie there is broken by the scoring pass and resets the run)
     int64_t lma_restarts = 0;      // RANSAC runs of this context that started over because a GLOBAL guard tripped: a tie, the count check (rsdsfm_lma_restarts)
     int64_t lma_handed_over = 0;   // RANSAC runs in which some hypothesis' own guard tripped and that hypothesis went on iterate by iterate
     int lma_last_guard = 0;        // bit set of the guards that tripped last (1 << reason: lma_common.hpp; 1 << 7: tie)
@@ -348,7 +359,8 @@ int ransac_score_launch(Ctx* c, const double* q, const double* u, const double* 
                         double* partials, double* trial_count, double* trial_err, const int* unscored_list = nullptr, const int* unscored_count = nullptr);
 int ransac_pick_launch(Ctx* c, const double* trial_count, const double* trial_err, int T, const double* hyp, RansacBest* best,
                        RansacBest* best_host = nullptr, const int* d_flags = nullptr, int* h_flags = nullptr, int scored_ahead = 0,
-                       const double* cnt_rt = nullptr, int cnt_stride = 0, int nranks = 0, int64_t* m_all = nullptr, double tie_margin = 0.0);
+                       const double* cnt_rt = nullptr, int cnt_stride = 0, int nranks = 0, int64_t* m_all = nullptr, double tie_margin = 0.0,
+                       PickLazy lazy = PickLazy());
 int ransac_final_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n,
                         RansacBest* best, const LmState* states, int depth_mode, double tol, double* rho, uint8_t* mask,
                         int64_t* block_counts, int64_t* block_offsets, int64_t* inlier_idx, double* inliers,
@@ -374,7 +386,7 @@ size_t ransac_lma_list_ints(int batch);
 int ransac_lma_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n, const double* hyp, int T,
                       LmState* states, double* partials, int* flags, int* scored, double* trial_count, double* trial_err, double tol,
                       const int* cand_steps, int ncand, int* irr_count, int* irr_list, int* unscored_list, int* guard_word,
-                      const int* m9_core_flag = nullptr, int m9_core_epoch = 0);
+                      const int* m9_core_flag = nullptr, int m9_core_epoch = 0, bool count_only = false);
 int ransac_lma_rows_doubles();
 int ransac_lma_rows_launch(Ctx* c, const double* q, const double* u, const double* a, const double* ak, int64_t n, const double* hyp, int T,
                            double* partials, double tol, const int* cand_steps, int ncand, int* irr_count, int* irr_list, double* rows);
@@ -450,6 +462,9 @@ struct RansacRun {
     bool core_math = true;   // round 0 through the in-range function cores (ransac_lm_kernel CORE); false after a restart
     bool analytic = false;   // the depth solves on the analytic LM trajectory (ransac_lma_kernels.hip); false after a guard tripped
     bool lma_restarted = false;
+    bool count_only = false;  // analytic pass without error sums; ransac_pick_kernel asks for the exact sums of the trials that share the best count
+    int lazy_rounds = 0;
+    int shared_best = 0;      // RansacBest::shared_best of the definitive pick
     double tie_margin = 0.0;  // what the picks are launched with (ransac_pick_kernel)
     int lma_guard = 0;       // guards that tripped (bit set)
     bool lma_tie_seen = false;  // the final pick of an iterate-by-iterate run saw a tie the analytic arithmetic could not have broken
@@ -485,7 +500,7 @@ struct RansacRun {
 int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a, const double* d_ak, int64_t n, int use_alpha_k, int T,
                  double tol, const int32_t* h_samples, uint64_t seed, int depth_mode, int k_sign_mode, rsdsfm_ransac_out* out,
                  const RansacSpecTail* spec_tail, bool* spec_tail_held, RansacRun* run, const Minimal9Direct* direct,
-                 const std::function<int()>* after_minimal9, const DenseFlatten* dense = nullptr, bool tail_ahead = true);
+                 const std::function<int()>* after_minimal9, const DenseFlatten* dense = nullptr, bool tail_ahead = true, bool count_only = false);
 int ransac_finish(Ctx* c, RansacRun* run);
 void ransac_commit_hints(Ctx* c, const RansacRun& run);
 int flatten_enqueue(Ctx* c, const double* d_img, int32_t rows, int32_t cols, double fx, double fy, double cx, double cy, double gamma,

@@ -167,6 +167,82 @@ def test_frame_solve_is_the_same_in_both_arithmetics(solver, rsdsfm):
     assert solver.lma_restarts()[0] == 0
 
 
+def _frame(solver, torch, dev, img, rows, cols, K, gamma, **kw):
+    dm = torch.zeros((cols, rows), dtype=torch.float64, device=dev)
+    r = solver.solve_frame_dev(img.data_ptr(), rows, cols, K, gamma, dm.data_ptr(), **kw)
+    solver.synchronize()
+    return r, dm.cpu().numpy()
+
+
+def _same_frame(a, da, x, dx):
+    assert a["num_inliers"] == x["num_inliers"] and a["best_trial"] == x["best_trial"]
+    assert a["refine_summary"] == x["refine_summary"]
+    for key in ("v", "w", "ransac_v", "ransac_w"):
+        assert np.array_equal(a[key], x[key], equal_nan=True), key
+    assert np.array_equal(da, dx, equal_nan=True)
+
+
+@pytest.mark.parametrize("cfg", [3, 5, 2])  # (2: noise-free flow -- every good hypothesis explains every pixel)
+def test_count_only_pass_and_lazy_error_sums(solver, rsdsfm, cfg):
+    """The frame solve's count-only form of the analytic pass (rsdsfm_set_lm_arithmetic(2) forces it): no error sums in the pixel pass; where
+    trials share the best inlier count (BASELINE's tolerance 0.05 admits every pixel under any good hypothesis; noise-free flow) exactly those
+    are scored by the iterate-by-iterate scoring pass and minimal.cc:278-285's tie rule runs on the reference arithmetic's sums.  Winner,
+    inliers, refinement and depth map: bit for bit what the iterate-by-iterate library returns."""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(cfg, rows=270, cols=480)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    img = torch.from_numpy(d["flow_img"]).to(dev)
+    lazy_total = 0
+    for tol in (0.5, 0.05, 0.002):  # (0.5: every pixel of this small frame an inlier under any good hypothesis, as 0.05 is at 1280x720)
+        for T in (50, 5):
+            for seed in (7, 8, 9):
+                solver.set_lm_arithmetic(1)
+                x, dx = _frame(solver, torch, dev, img, rows, cols, K, gamma, trials=T, tol=tol, seed=seed)
+                solver.set_lm_arithmetic(2)
+                runs0, lazy0 = solver.lma_count_only()
+                a, da = _frame(solver, torch, dev, img, rows, cols, K, gamma, trials=T, tol=tol, seed=seed)
+                b, db = _frame(solver, torch, dev, img, rows, cols, K, gamma, trials=T, tol=tol, seed=seed)  # (warm: the speculated stages follow the first)
+                runs1, lazy1 = solver.lma_count_only()
+                assert runs1 - runs0 == 2
+                lazy_total += lazy1 - lazy0
+                _same_frame(a, da, x, dx)
+                _same_frame(b, db, x, dx)
+    solver.set_lm_arithmetic(0)
+    assert solver.lma_restarts()[0] == 0
+    if cfg == 3:
+        assert lazy_total > 0  # (tolerance 0.5: good hypotheses share the count N)
+
+
+def test_count_only_follows_the_data(solver, rsdsfm):
+    """mode 0: the pass turns count-only behind two solves whose best count was unique (selective tolerance) and goes back to fused error sums
+    when trials share the best count again (permissive tolerance); results never depend on it"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(5, rows=270, cols=480)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    img = torch.from_numpy(d["flow_img"]).to(dev)
+    solver.set_lm_arithmetic(0)
+    seq = [(0.002, s) for s in range(1, 6)] + [(0.5, s) for s in range(1, 5)] + [(0.002, s) for s in range(6, 10)]
+    got = []
+    for tol, seed in seq:
+        r0 = solver.lma_count_only()
+        a, da = _frame(solver, torch, dev, img, rows, cols, K, gamma, trials=50, tol=tol, seed=seed)
+        r1 = solver.lma_count_only()
+        got.append((r1[0] - r0[0], r1[1] - r0[1]))
+        ref = rsdsfm.Solver(0)
+        ref.set_lm_arithmetic(1)
+        x, dx = _frame(ref, torch, dev, img, rows, cols, K, gamma, trials=50, tol=tol, seed=seed)
+        ref.close()
+        _same_frame(a, da, x, dx)
+    # two unique solves, then count-only; the first permissive solve meets the tie (lazy), the following ones fuse the sums again
+    assert [g[0] for g in got[:5]] == [0, 0, 1, 1, 1]
+    assert got[5] == (1, 1) and [g[0] for g in got[6:9]] == [0, 0, 0]
+    assert [g[0] for g in got[9:]] == [0, 0, 1, 1]
+
+
 # ---------------------------------------------------------------------------------------------------
 # the dense depth solve on the analytic trajectory (depth_lma_kernels.hip)
 # ---------------------------------------------------------------------------------------------------

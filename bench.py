@@ -48,13 +48,13 @@ METRIC = "Mpixels/sec RS depth+pose solve, 1280x720 pair"
 METRIC_DEPTH = "Mpixels/sec RS per-pixel depth solve (pose fixed), 1280x720 pair"
 FP64_VALU_PEAK = 39.3e12        # fp64 lane-instructions / s: 256 CUs x 4 SIMDs x 64 lanes x 2.4 GHz / 4 cycles per wave-instruction
 NOMINAL_CLOCK_MHZ = 2400.0      # the clock that peak is priced at (MI355X_MICROARCH.md); the kernels' running clock is measured (shader_clock_mhz)
-# DESIGN section 8 scaling model of the column-tiled 3840x2160 whole solve (ms; calibrated on the N = 1 kernel trace
-# profiles/r04_trace_tiled_full.txt): kernels whose work is per pixel of the slab (ransac_lm 3.62, the refinement's slot passes 0.64,
-# iteration zero, compaction, scoring pass, flatten, final stage, output pass, depth map ...) / replicated or latency-bound stages
-# (minimal9 0.16 + ~65 launches and small copies of 2-8 us) / an ASSUMED 25 us per small collective over xGMI (10 per solve of 4 LM
-# iterations) / the depth-map all-gather: every rank receives (N - 1) slabs of 66.4 MB / N over min(N - 1, 7) links in parallel at an
-# ASSUMED 48 GB/s per link and direction
-TILED_MODEL = {"per_pixel_ms": 5.10, "replicated_ms": 0.48, "collective_latency_ms": 0.025, "collectives": 10,
+# DESIGN section 7 scaling model of the column-tiled 3840x2160 whole solve (ms; calibrated on the N = 1 kernel trace
+# profiles/r05_trace_tiled_full.txt and the measured 3.26 ms per solve): kernels whose work is per pixel of the slab (the analytic pixel
+# pass 1.49, the refinement's slot passes 0.69, iteration zero 0.18, compaction 0.13, flatten 0.13, final stage 0.10, output pass 0.10,
+# depth map 0.13) / replicated or latency-bound stages (minimal9 0.16 + ~55 launches and small copies of 2-8 us) / an ASSUMED 25 us per
+# small collective over xGMI (9 per solve of 4 LM iterations) / the depth-map all-gather: every rank receives (N - 1) slabs of 66.4 MB / N
+# over min(N - 1, 7) links in parallel at an ASSUMED 48 GB/s per link and direction
+TILED_MODEL = {"per_pixel_ms": 2.83, "replicated_ms": 0.43, "collective_latency_ms": 0.025, "collectives": 9,
                "depth_gather_ms": lambda n: (66.4e6 / n * (n - 1) / min(n - 1, 7)) / 48e9 * 1e3}
 KIND_PORT = "closed-loop port (oracle C restatement; not reference-structured: no per-pixel residual objects / Ceres problem build)"
 

@@ -520,7 +520,9 @@ typedef struct rsdsfm_tiled_info {
                          * assumption did not hold for this frame and the solve started over through the counts / status exchange; bit 2:
                          * the RANSAC started over with the standard functions (an argument outside the range of the in-range function cores
                          * on some rank; counted by rsdsfm_ransac_restarts as well); bit 3: the RANSAC started over iterate by iterate because a
-                         * global guard of the analytic LM trajectory tripped (a tie; counted by rsdsfm_lma_restarts); bits 8-23: exchanges the refinement's LM iterations took
+                         * global guard of the analytic LM trajectory tripped (a tie; counted by rsdsfm_lma_restarts); bit 4: the refinement's start, its
+                         * first chunk and the depth-map stage went behind the RANSAC's speculated final stage, from the device-resident winner,
+                         * and counted (on typical data the call then waits for the GPU once); bits 8-23: exchanges the refinement's LM iterations took
                          * (one per iteration + one in front of the first + one behind every iteration whose speculated Schur sums did
                          * not apply: a rejected step, or an accepted one of quality < 0.937) */
 } rsdsfm_tiled_info;

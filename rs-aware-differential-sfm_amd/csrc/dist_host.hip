@@ -151,6 +151,11 @@ struct Dist {
     // (every rank reads the same replicated flag words) starts over iterate by iterate, and the communicator stays there for its next solves
     // (renewed by a solve that ends in a tie the analytic arithmetic could not break: noise-free data)
     int lma_hold = 0;
+    // the refinement (+ depth-map stage) goes behind the SPECULATED final stage of the RANSAC, from the device-resident winner, while that
+    // stage was the one that counted in one of the communicator's last two solves and -- reference flow indexing (quirk Q2) over several ranks --
+    // the previous solve needed no remote flow column
+    int spec_miss = 2;
+    bool q2_local = false;
     bool lockstep_error = false;  // the last solve's error return came after the whole solve ran in lockstep with the peers (hints kept)
 };
 
@@ -227,6 +232,8 @@ void reset_hints(Dist* D) {
     D->warm = D->dense_hint = false;
     D->standard_math = 0;
     D->lma_hold = 0;
+    D->spec_miss = 2;
+    D->q2_local = false;
 }
 
 int sync(Ctx* c, Dist* D) {
@@ -643,7 +650,7 @@ restart_cold:
     // (rsdsfm_set_lm_arithmetic: the same on every rank) and the communicator's hold -- replicated knowledge, every rank decides alike
     bool analytic = T > 0 && depth_mode == RSDSFM_DEPTH_CERES_LM && c->lm_arithmetic == 0 && D->lma_hold == 0 && setup_rc == RSDSFM_OK;
     const bool lma_may_return = depth_mode == RSDSFM_DEPTH_CERES_LM && c->lm_arithmetic == 0;  // (ties are reported: they renew the hold)
-    bool lma_restarted = false, tie_seen = false;
+    bool lma_restarted = false, tie_seen = false, spec_refine_tried = false;
     const int lma_cand[2] = {2, 1};  // fused iterates: fixed, like kTiledFusedBase (every rank must fuse the same ones)
 restart_ransac:
     if (T > 0) {
@@ -663,10 +670,13 @@ restart_ransac:
     double* d_partials = ws.take<double>(std::max<size_t>((size_t)ransac_lm_partials_doubles(c, (int64_t)N1, batch), (size_t)ransac_lma_partials_doubles(c, (int64_t)N1, batch)));
     int64_t* d_bcounts = ws.take<int64_t>(2048);
     int64_t* d_boffs = ws.take<int64_t>(2048);
-    auto final_stage = [&]() -> int {  // winner (replicated), its dense 1/depth + mask + compaction on the slab, inlier counts of all slabs
+    bool spec_scored = false;
+    auto final_stage = [&](bool spec) -> int {  // winner (replicated), its dense 1/depth + mask + compaction on the slab, inlier counts of all slabs
         // the winner (replicated) -- and with it the inlier counts of ALL slabs: the ranks' shares of the winner's count were in the rows the
         // scores came from (ransac_decide_kernel / ransac_reduce_scores_kernel keep them), so the counts need no exchange of their own
-        int rc2 = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, nullptr, nullptr, nullptr, 0, d_cnt_rt, T, R, d_m_all,
+        // (spec: behind round 0, ahead of the host's read of the flag words -- the pick reads them itself and marks a RANSAC that is not over
+        // `undecided`, so that the final stage and everything enqueued behind it on speculation leave at once)
+        int rc2 = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, nullptr, spec ? d_flags : nullptr, nullptr, spec && spec_scored ? 1 : 0, d_cnt_rt, T, R, d_m_all,
                                      !lma_may_return ? 0.0 : (analytic ? kLmaTieMarginD : -kLmaTieMarginD));
         if (rc2 != RSDSFM_OK) return rc2;
         // the compaction stores the SLAB's scan total into its record: every rank works on a copy of the (identical) winner record
@@ -681,7 +691,166 @@ restart_ransac:
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_m, d_m_all, sizeof(int64_t) * R, hipMemcpyDeviceToHost, c->stream));
         return RSDSFM_OK;
     };
-    bool final_done = false, spec_scored = false;
+    // ---- the refinement and the depth-map stage as closures: they go behind the DEFINITIVE final stage, from the host-side result, or
+    // -- one host wait less -- behind the SPECULATED one, from the device-resident winner (inlier count and start pose in the slab's RansacBest
+    // record: RefineBuffers::m_on_device, as in the single-context frame solve), before the host has read anything of the RANSAC ----
+    int64_t m_total = 0, m = 0;
+    double v[3] = {0.0, 0.0, 0.0}, w[3] = {0.0, 0.0, 0.0}, k = 0.0;
+    bool local_index_bad = false;
+    // mean-z sign (global), depth-map slab, ONE all-gather of the slabs, pose table.  The motion comes from the host (v_host; pose table by a
+    // launch of its own) or -- enqueued behind the refinement's output pass BEFORE the host has read the state, so that the wait for the state
+    // covers this stage too -- from the device-resident state (v_dev = RefineState::p; the sign kernel writes the pose table).
+    // m_dev: the slab's inlier count, device-resident (the host's is an upper bound then)
+    auto depth_stage = [&](double* d_points, const double* d_zsums, int nz, const double* v_host, const double* w_host, double k_host,
+                           const double* state_p_dev, const int64_t* m_dev) -> int {
+        double* d_slab = d_gather + (size_t)rank * cap;
+        if (cap > Ns) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_slab + Ns, 0, sizeof(double) * (cap - Ns), c->stream));  // columns past the image: zeros
+        PoseTableOut pt;
+        const bool table = d_R_rows9 && d_t_rows3;
+        if (state_p_dev && table) pt.R = d_R_rows9, pt.t = d_t_rows3, pt.rows = rows, pt.gamma = gamma, pt.wk_dev = state_p_dev + 3;
+        int rc2 = depth_map_slab_launch(c, d_points, m_dev ? n : m, d_zsums, nz, m_dev ? n_total : m_total, v_host, fx, fy, cx, cy, rows, col0, sc, d_slab, nullptr, d_ys,
+                                        d_header, h_header, state_p_dev, m_dev, state_p_dev && table ? &pt : nullptr);
+        if (rc2 != RSDSFM_OK) return rc2;
+        rc2 = all_gather(c, D, d_slab, d_gather, sizeof(double) * cap);  // the one data-path collective
+        if (rc2 != RSDSFM_OK) return rc2;
+        if (padded)
+            RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_depth_map, d_gather, sizeof(double) * (size_t)rows * (size_t)cols, hipMemcpyDeviceToDevice, c->stream));
+        if (!state_p_dev && table) {
+            Pose pose;
+            for (int i = 0; i < 3; ++i) pose.v[i] = v_host[i], pose.w[i] = w_host[i];
+            pose.k = k_host;
+            rc2 = pose_table_launch(c, pose, gamma, rows, d_R_rows9, d_t_rows3, d_header + 1);  // v' (possibly flipped) from the device header
+            if (rc2 != RSDSFM_OK) return rc2;
+        }
+        return RSDSFM_OK;
+    };
+    RefineBuffers RB;
+    int launched = 0;
+    bool depth_done = false, spec_refine = false, final_spec = false, q2_remote = false;
+    const int refine_hint = D->refine_iters_hint;
+    // buffers of the refinement's session; dev: the slab's inlier count is device-resident (upper bound n), no remote flow column
+    auto refine_layout = [&](bool dev) -> int {
+        const int64_t mm = dev ? n : m;
+        const size_t M = (size_t)std::max<int64_t>(mm, 1);
+        const size_t npart = (size_t)std::max(refine_partials_doubles(c, mm), refine_slot_partials_doubles(c, mm));
+        Arena sa(D->d_session);  // (allocated in the setup part for the slab's upper bound)
+        RB = RefineBuffers();
+        RB.flow = d_u;
+        RB.n_flow = n;
+        RB.m = mm;
+        RB.m_on_device = dev;
+        RB.inl = d_inl;
+        RB.alpha = d_in_a;
+        RB.alpha_k = d_in_ak;
+        RB.inlier_idx = d_idx;
+        RB.flow_index_mode = RSDSFM_FLOW_GATHERED;
+        RB.want_zsum = true;  // the rows of the refinement carry the sum of z: the sign test below needs no exchange of its own
+        if (prm->flow_index_mode == RSDSFM_FLOW_COMPAT_RANK) {
+            // The reference's default (quirk Q2): inlier i of the global list reads flow column i of the global list.  This rank's
+            // inliers are the global ranks [prefix, prefix + m), and since a slab never holds more inliers than points those
+            // columns live on slabs <= rank.  Every rank knows every count, so all ranks agree on what is exchanged: the heads of
+            // the slabs' flow lists up to the global inlier count (nothing at all when every needed column is local -- e.g. every
+            // pixel an inlier), all-gathered in rank order; then each rank picks its m columns.
+            // (dev: enqueued on the assumption that no column is remote -- the previous solve's case --, checked once the counts are known)
+            if (!dev && q2_remote) {
+                int64_t prefix = 0, lmax = 0;
+                int64_t pm = 0, po = 0;  // inliers / points in front of slab r
+                for (int r = 0; r < R; ++r) {
+                    lmax = std::max(lmax, std::min<int64_t>(h_cnt[r], std::max<int64_t>(m_total - po, 0)));
+                    if (r == rank) prefix = pm;
+                    pm += h_m[r];
+                    po += h_cnt[r];
+                }
+                const size_t L = (size_t)std::max<int64_t>(lmax, 1);
+                Arena fl(D->d_flow);  // (allocated in the setup part: L <= the slab stride, M <= the slab's points)
+                double* d_heads = fl.take<double>(2 * L * R);
+                double* d_flow_rank = fl.take<double>(2 * M);
+                const int64_t mine = std::min<int64_t>(n, std::max<int64_t>(m_total - offset, 0));  // columns of this slab the ranks can reach
+                if (mine > 0)
+                    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_heads + 2 * L * (size_t)rank, d_u, 16 * (size_t)mine, hipMemcpyDeviceToDevice, c->stream));
+                int rc2 = all_gather(c, D, d_heads + 2 * L * (size_t)rank, d_heads, 16 * L);
+                if (rc2 != RSDSFM_OK) return rc2;
+                if (m > 0) {
+                    hipLaunchKernelGGL(rank_flow_gather_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
+                                       reinterpret_cast<const double2*>(d_heads), (int64_t)L, d_cnt_all, R, prefix, m,
+                                       reinterpret_cast<double2*>(d_flow_rank));
+                    RSDSFM_HIP_CHECK(c, hipGetLastError());
+                }
+                RB.flow = d_flow_rank;
+                RB.n_flow = m;
+            }
+            // (no remote column: prefix == offset for every slab with inliers, so the global column of local inlier i is local column i)
+            RB.flow_index_mode = RSDSFM_FLOW_COMPAT_RANK;
+            RB.inlier_idx = nullptr;
+        }
+        char* state_block = sa.take<char>(sizeof(RefineState) + 64);
+        RB.state = reinterpret_cast<RefineState*>(state_block);
+        RB.bad_index = reinterpret_cast<int*>(state_block + sizeof(RefineState));
+        RB.uu = sa.take<double>(4 * M);
+        RB.beta = sa.take<double>(M);
+        RB.rho_a = sa.take<double>(M);
+        RB.rho_b = sa.take<double>(M);
+        RB.srho = sa.take<double>(M);
+        RB.partials = sa.take<double>(npart);
+        return RSDSFM_OK;
+    };
+    // ONE exchange per LM iteration (refine_kernels.hip, slot kernels): a slot's pass carries the back-substitution of iteration i and the
+    // Schur sums of iteration i + 1 speculated at the candidate for the radius an accepted step of quality >= 0.937 gets; a slot whose
+    // speculation did not apply is followed by a plain Schur slot (the kernels read which kind from the replicated state).  Slots per
+    // host poll: what the previous solve on this communicator consumed (6 before there is one: the first Schur slot + 5 iterations; at most
+    // 28), later chunks what it still needed at that point (2 .. 8).  Every rank holds the same hint, so all ranks issue the same
+    // collectives; the chunking changes when the host looks at the state, never what the kernels compute.
+    // (slot j of a chunk: the pass, whose prologue is the replicated stage of slot j - 1 on the rows gathered then; the shard's row; the exchange)
+    auto refine_chunk = [&](int chunk) -> int {
+        for (int j = 0; j < chunk; ++j) {
+            int rc2 = refine_slot_rows_launch(c, RB, np, d_row, j, d_rows_all, R);
+            if (rc2 != RSDSFM_OK) return rc2;
+            rc2 = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)refine_slot_row_doubles(np));
+            if (rc2 != RSDSFM_OK) return rc2;
+        }
+        int rc2 = refine_slot_apply_launch(c, RB, np, d_rows_all, R, chunk);  // the stage behind the chunk's last exchange -> RB.state
+        if (rc2 != RSDSFM_OK) return rc2;
+        launched += chunk;
+        rc2 = refine_finish_launch(c, RB, d_inl_ref);  // enqueued before the poll: the common case ends within one chunk
+        if (rc2 != RSDSFM_OK) return rc2;
+        // ... and so is the depth-map stage, from the device-resident state, behind a chunk that can be the last one (every rank holds
+        // the same hint): the poll's wait then covers it.  Behind a chunk the solve outlives it runs again; what it wrote is overwritten.
+        depth_done = refine_hint < 1 || launched + 1 >= refine_hint;
+        if (depth_done) {
+            rc2 = depth_stage(d_inl_ref, &RB.state->zsum, 1, nullptr, nullptr, 0.0, RB.state->p, RB.m_on_device ? &RB.state->m : nullptr);
+            if (rc2 != RSDSFM_OK) return rc2;
+        }
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_state, RB.state, sizeof(RefineState) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        return RSDSFM_OK;
+    };
+    // start state, iteration zero (its rows all-gathered, the decision replicated), the first chunk of slots
+    auto refine_start = [&]() -> int {
+        int rc2 = RSDSFM_OK;
+        if (RB.m_on_device) {
+            rc2 = refine_state_from_best_launch(c, d_best_shard, RB, np);  // (count = the slab's compaction total, pose = the winner's; an undecided RANSAC: no inliers)
+            if (rc2 != RSDSFM_OK) return rc2;
+        } else {
+            memset(h_state, 0, sizeof(RefineState));
+            h_state->np = np;
+            for (int i = 0; i < 3; ++i) h_state->p[i] = v[i], h_state->p[3 + i] = w[i];
+            h_state->p[6] = k;
+            h_state->termination = -1;
+            h_state->radius = kInitialRadius;
+            h_state->need_schur = 1;  // the first slot is the Schur pass of iteration 1
+            *h_bad = 0;
+            RSDSFM_HIP_CHECK(c, hipMemcpyAsync(RB.state, h_state, sizeof(RefineState) + sizeof(int), hipMemcpyHostToDevice, c->stream));
+        }
+        rc2 = refine_trace_reset(c);
+        if (rc2 != RSDSFM_OK) return rc2;
+        rc2 = refine_stage_rows_launch(c, RB, np, 0, d_row);
+        if (rc2 != RSDSFM_OK) return rc2;
+        rc2 = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)refine_stage_row_doubles(np, 0));
+        if (rc2 != RSDSFM_OK) return rc2;
+        rc2 = refine_stage_apply_launch(c, RB, np, 0, d_rows_all, R, m_total, RB.m_on_device ? &d_best_shard->num_inliers : nullptr);
+        if (rc2 != RSDSFM_OK) return rc2;
+        return refine_chunk(refine_hint >= 1 ? std::min(refine_hint, 28) : 6);  // (k refined: two slots per LM iteration, ~27 in all)
+    };
+    bool final_done = false;
     for (int b0 = 0; b0 < T; b0 += batch) {
         const int B = std::min(batch, T - b0);
         bool need_score = true;
@@ -729,9 +898,19 @@ restart_ransac:
                         if (rc != RSDSFM_OK) return rc;
                         spec_scored = true;
                     }
-                    rc = final_stage();
+                    rc = final_stage(true);
                     if (rc != RSDSFM_OK) return rc;
-                    final_done = true;
+                    final_done = final_spec = true;
+                    if (prm->use_refinement && !spec_refine_tried && D->spec_miss < 2 &&
+                        (R == 1 || prm->flow_index_mode != RSDSFM_FLOW_COMPAT_RANK || D->q2_local)) {
+                        // the refinement's start, its first chunk of slots and the depth-map stage behind this final stage, from the device-resident
+                        // winner: on typical data the host's ONE wait below then covers the whole solve (every rank holds the same hints)
+                        spec_refine_tried = true;
+                        rc = refine_layout(true);
+                        if (rc == RSDSFM_OK) rc = refine_start();
+                        if (rc != RSDSFM_OK) return rc;
+                        spec_refine = true;
+                    }
                 }
                 RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_flags, d_flags, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
                 const bool check_counts = spec_dense && round == 0 && b0 == 0;  // the warm path's first host read: were the slabs dense?
@@ -794,10 +973,11 @@ restart_ransac:
         }
     }
     if (!final_done) {
-        rc = final_stage();
+        rc = final_stage(false);
         if (rc != RSDSFM_OK) return rc;
         rc = sync(c, D);
         if (rc != RSDSFM_OK) return rc;
+        final_spec = spec_refine = false;  // (the speculated final stage, and whatever went behind it, saw incomplete trials)
     }
     if (analytic && h_best->lma_tie) {  // guard (d) at the definitive pick (replicated: the trial scores are)
         analytic = false;
@@ -810,178 +990,64 @@ restart_ransac:
         goto restart_ransac;
     }
     tie_seen = h_best->lma_tie != 0;
-    int64_t m_total = 0;
+    m_total = 0;
     for (int r = 0; r < R; ++r) m_total += h_m[r];
-    const int64_t m = h_m[rank];
-    auto m_total_of = [&]() -> int64_t { return m_total; };
+    m = h_m[rank];
     // the winner's count against the ranks' shares is replicated knowledge: every rank returns alike.  This slab's compaction total against its
     // share is NOT (only this rank knows it): a rank that left here would strand the others in the refinement's exchanges and come back to
     // the next solve with other hints than theirs -- so it stays in lockstep to the end of the solve (its slab's part of the result is not to
     // be trusted: the buffers are sized for any count), keeps its hints, and reports the error then
     if (m_total != h_best->num_inliers) return fail(c, RSDSFM_ERR_NUMERIC, "inlier count mismatch between scoring and compaction");
     const bool local_scan_bad = *h_scan != m;
-    bool local_index_bad = false;
     res->num_inliers = m_total;
     res->best_trial = h_best->best_trial;
     memcpy(res->ransac_w, &h_best->hyp[0], 3 * sizeof(double));
     memcpy(res->ransac_v, &h_best->hyp[3], 3 * sizeof(double));
     res->ransac_k = h_best->hyp[6];
-    double v[3] = {h_best->hyp[3], h_best->hyp[4], h_best->hyp[5]}, w[3] = {h_best->hyp[0], h_best->hyp[1], h_best->hyp[2]}, k = h_best->hyp[6];
+    for (int i = 0; i < 3; ++i) v[i] = h_best->hyp[3 + i], w[i] = h_best->hyp[i];
+    k = h_best->hyp[6];
     double* d_final = d_inl;
     const double* d_zsum_global = nullptr;
-
-    // mean-z sign (global), depth-map slab, ONE all-gather of the slabs, pose table.  The motion comes from the host (v_host; pose table by a
-    // launch of its own) or -- enqueued behind the refinement's output pass BEFORE the host has read the state, so that the wait for the state
-    // covers this stage too -- from the device-resident state (v_dev = RefineState::p; the sign kernel writes the pose table).
-    auto depth_stage = [&](double* d_points, const double* d_zsums, int nz, const double* v_host, const double* w_host, double k_host,
-                           const double* state_p_dev) -> int {
-        double* d_slab = d_gather + (size_t)rank * cap;
-        if (cap > Ns) RSDSFM_HIP_CHECK(c, hipMemsetAsync(d_slab + Ns, 0, sizeof(double) * (cap - Ns), c->stream));  // columns past the image: zeros
-        PoseTableOut pt;
-        const bool table = d_R_rows9 && d_t_rows3;
-        if (state_p_dev && table) pt.R = d_R_rows9, pt.t = d_t_rows3, pt.rows = rows, pt.gamma = gamma, pt.wk_dev = state_p_dev + 3;
-        int rc2 = depth_map_slab_launch(c, d_points, h_m[rank], d_zsums, nz, m_total_of(), v_host, fx, fy, cx, cy, rows, col0, sc, d_slab, nullptr, d_ys,
-                                        d_header, h_header, state_p_dev, nullptr, state_p_dev && table ? &pt : nullptr);
-        if (rc2 != RSDSFM_OK) return rc2;
-        rc2 = all_gather(c, D, d_slab, d_gather, sizeof(double) * cap);  // the one data-path collective
-        if (rc2 != RSDSFM_OK) return rc2;
-        if (padded)
-            RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_depth_map, d_gather, sizeof(double) * (size_t)rows * (size_t)cols, hipMemcpyDeviceToDevice, c->stream));
-        if (!state_p_dev && table) {
-            Pose pose;
-            for (int i = 0; i < 3; ++i) pose.v[i] = v_host[i], pose.w[i] = w_host[i];
-            pose.k = k_host;
-            rc2 = pose_table_launch(c, pose, gamma, rows, d_R_rows9, d_t_rows3, d_header + 1);  // v' (possibly flipped) from the device header
-            if (rc2 != RSDSFM_OK) return rc2;
+    {
+        // reference flow indexing (quirk Q2) over several ranks: does any slab need a flow column of another one?  (replicated: the counts are)
+        q2_remote = false;
+        int64_t pm = 0, po = 0;  // inliers / points in front of slab r
+        for (int r = 0; r < R; ++r) {
+            if (h_m[r] > 0 && pm != po) q2_remote = true;
+            pm += h_m[r];
+            po += h_cnt[r];
         }
-        return RSDSFM_OK;
-    };
-    bool depth_done = false;
+        q2_remote = q2_remote && prm->flow_index_mode == RSDSFM_FLOW_COMPAT_RANK;
+        // what went behind the speculated final stage counts if that stage did and it assumed the right flow columns; the hints of the next solve
+        if (spec_refine && (h_best->undecided || q2_remote)) spec_refine = false;
+        D->spec_miss = (final_spec && !h_best->undecided) ? 0 : std::min(D->spec_miss + 1, 2);
+        D->q2_local = !q2_remote;
+        if (spec_refine) path_flags |= 16;
+    }
 
-    // ---- joint refinement: per LM iteration two staged passes (Schur sums -> reduced solve; back-substitution sums -> decision) ----
+    // ---- joint refinement: iteration zero, then ONE slot (pass + exchange) per LM iteration, polled in chunks ----
     if (prm->use_refinement) {
-        const size_t M = (size_t)std::max<int64_t>(m, 1);
-        const size_t npart = (size_t)std::max(refine_partials_doubles(c, m), refine_slot_partials_doubles(c, m));
-        Arena sa(D->d_session);  // (allocated in the setup part for the slab's upper bound)
-        RefineBuffers B;
-        B.flow = d_u;
-        B.n_flow = n;
-        B.m = m;
-        B.inl = d_inl;
-        B.alpha = d_in_a;
-        B.alpha_k = d_in_ak;
-        B.inlier_idx = d_idx;
-        B.flow_index_mode = RSDSFM_FLOW_GATHERED;
-        B.want_zsum = true;  // the rows of the refinement carry the sum of z: the sign test below needs no exchange of its own
-        if (prm->flow_index_mode == RSDSFM_FLOW_COMPAT_RANK) {
-            // The reference's default (quirk Q2): inlier i of the global list reads flow column i of the global list.  This rank's
-            // inliers are the global ranks [prefix, prefix + m), and since a slab never holds more inliers than points those
-            // columns live on slabs <= rank.  Every rank knows every count, so all ranks agree on what is exchanged: the heads of
-            // the slabs' flow lists up to the global inlier count (nothing at all when every needed column is local -- e.g. every
-            // pixel an inlier), all-gathered in rank order; then each rank picks its m columns.
-            int64_t prefix = 0, lmax = 0;
-            bool remote = false;
-            int64_t pm = 0, po = 0;  // inliers / points in front of slab r
-            for (int r = 0; r < R; ++r) {
-                if (h_m[r] > 0 && pm != po) remote = true;
-                lmax = std::max(lmax, std::min<int64_t>(h_cnt[r], std::max<int64_t>(m_total - po, 0)));
-                if (r == rank) prefix = pm;
-                pm += h_m[r];
-                po += h_cnt[r];
-            }
-            if (remote) {
-                const size_t L = (size_t)std::max<int64_t>(lmax, 1);
-                Arena fl(D->d_flow);  // (allocated in the setup part: L <= the slab stride, M <= the slab's points)
-                double* d_heads = fl.take<double>(2 * L * R);
-                double* d_flow_rank = fl.take<double>(2 * M);
-                const int64_t mine = std::min<int64_t>(n, std::max<int64_t>(m_total - offset, 0));  // columns of this slab the ranks can reach
-                if (mine > 0)
-                    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_heads + 2 * L * (size_t)rank, d_u, 16 * (size_t)mine, hipMemcpyDeviceToDevice, c->stream));
-                rc = all_gather(c, D, d_heads + 2 * L * (size_t)rank, d_heads, 16 * L);
-                if (rc != RSDSFM_OK) return rc;
-                if (m > 0) {
-                    hipLaunchKernelGGL(rank_flow_gather_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, c->stream,
-                                       reinterpret_cast<const double2*>(d_heads), (int64_t)L, d_cnt_all, R, prefix, m,
-                                       reinterpret_cast<double2*>(d_flow_rank));
-                    RSDSFM_HIP_CHECK(c, hipGetLastError());
-                }
-                B.flow = d_flow_rank;
-                B.n_flow = m;
-            }
-            // (no remote column: prefix == offset for every slab with inliers, so the global column of local inlier i is local column i)
-            B.flow_index_mode = RSDSFM_FLOW_COMPAT_RANK;
-            B.inlier_idx = nullptr;
-        }
-        char* state_block = sa.take<char>(sizeof(RefineState) + 64);
-        B.state = reinterpret_cast<RefineState*>(state_block);
-        B.bad_index = reinterpret_cast<int*>(state_block + sizeof(RefineState));
-        B.uu = sa.take<double>(4 * M);
-        B.beta = sa.take<double>(M);
-        B.rho_a = sa.take<double>(M);
-        B.rho_b = sa.take<double>(M);
-        B.srho = sa.take<double>(M);
-        B.partials = sa.take<double>(npart);
-        memset(h_state, 0, sizeof(RefineState));
-        h_state->np = np;
-        for (int i = 0; i < 3; ++i) h_state->p[i] = v[i], h_state->p[3 + i] = w[i];
-        h_state->p[6] = k;
-        h_state->termination = -1;
-        h_state->radius = kInitialRadius;
-        h_state->need_schur = 1;  // the first slot is the Schur pass of iteration 1
-        *h_bad = 0;
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(B.state, h_state, sizeof(RefineState) + sizeof(int), hipMemcpyHostToDevice, c->stream));
-        rc = refine_trace_reset(c);
-        if (rc != RSDSFM_OK) return rc;
-        auto staged = [&](int stage) -> int {
-            int rc2 = refine_stage_rows_launch(c, B, np, stage, d_row);
-            if (rc2 != RSDSFM_OK) return rc2;
-            rc2 = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)refine_stage_row_doubles(np, stage));
-            if (rc2 != RSDSFM_OK) return rc2;
-            return refine_stage_apply_launch(c, B, np, stage, d_rows_all, R, m_total);
-        };
-        rc = staged(0);
-        if (rc != RSDSFM_OK) return rc;
-        // ONE exchange per LM iteration (refine_kernels.hip, slot kernels): a slot's pass carries the back-substitution of iteration i and the
-        // Schur sums of iteration i + 1 speculated at the candidate for the radius an accepted step of quality >= 0.937 gets; a slot whose
-        // speculation did not apply is followed by a plain Schur slot (the kernels read which kind from the replicated state).  Slots per
-        // host poll: what the previous solve on this communicator consumed (6 before there is one: the first Schur slot + 5 iterations; at most
-        // 28), later chunks what it still needed at that point (2 .. 8).  Every rank holds the same hint, so all ranks issue the same
-        // collectives; the chunking changes when the host looks at the state, never what the kernels compute.
-        // (slot j of a chunk: the pass, whose prologue is the replicated stage of slot j - 1 on the rows gathered then; the shard's row; the exchange)
-        auto slot = [&](int j) -> int {
-            int rc2 = refine_slot_rows_launch(c, B, np, d_row, j, d_rows_all, R);
-            if (rc2 != RSDSFM_OK) return rc2;
-            return all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)refine_slot_row_doubles(np));
-        };
-        const int hint = D->refine_iters_hint;
-        int chunk = hint >= 1 ? std::min(hint, 28) : 6;  // (k refined: two slots per LM iteration, ~27 in all)
-        for (int launched = 0;; chunk = hint >= 1 ? std::min(8, std::max(2, hint - launched)) : 5) {
-            for (int i = 0; i < chunk; ++i) {
-                rc = slot(i);
-                if (rc != RSDSFM_OK) return rc;
-            }
-            rc = refine_slot_apply_launch(c, B, np, d_rows_all, R, chunk);  // the stage behind the chunk's last exchange -> B.state
+        if (!spec_refine) {
+            launched = 0;
+            depth_done = false;
+            rc = refine_layout(false);
+            if (rc == RSDSFM_OK) rc = refine_start();
             if (rc != RSDSFM_OK) return rc;
-            launched += chunk;
-            rc = refine_finish_launch(c, B, d_inl_ref);  // enqueued before the poll: the common case ends within one chunk
-            if (rc != RSDSFM_OK) return rc;
-            // ... and so is the depth-map stage, from the device-resident state, behind a chunk that can be the last one (every rank holds
-            // the same hint): the poll's wait then covers it.  Behind a chunk the solve outlives it runs again; what it wrote is overwritten.
-            depth_done = hint < 1 || launched + 1 >= hint;
-            if (depth_done) {
-                rc = depth_stage(d_inl_ref, &B.state->zsum, 1, nullptr, nullptr, 0.0, B.state->p);
-                if (rc != RSDSFM_OK) return rc;
-            }
-            RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_state, B.state, sizeof(RefineState) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
             rc = sync(c, D);
             if (rc != RSDSFM_OK) return rc;
+        }
+        for (;;) {  // (here: a chunk is behind us and the host has its state)
             if (*h_bad) local_index_bad = true;  // (rank-local like the count check above: reported at the end, in lockstep)
             if (h_state->termination >= 0) break;
             if (launched > 8 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
+            rc = refine_chunk(refine_hint >= 1 ? std::min(8, std::max(2, refine_hint - launched)) : 5);
+            if (rc != RSDSFM_OK) return rc;
+            rc = sync(c, D);
+            if (rc != RSDSFM_OK) return rc;
         }
         D->refine_iters_hint = h_state->slots;
         path_flags |= (std::min(h_state->slots, 0xFFFF) << 8);
-        d_zsum_global = &B.state->zsum;  // every rank holds the same GLOBAL sum of z of the final state (replicated decide stages)
+        d_zsum_global = &RB.state->zsum;  // every rank holds the same GLOBAL sum of z of the final state (replicated decide stages)
         for (int i = 0; i < 3; ++i) v[i] = h_state->p[i], w[i] = h_state->p[3 + i];
         k = h_state->p[6];
         res->refine_summary.num_iterations = h_state->iteration;
@@ -992,6 +1058,8 @@ restart_ransac:
         res->refine_summary.final_cost = h_state->cost;
         res->refine_summary.final_radius = h_state->radius;
         d_final = d_inl_ref;
+    } else {
+        depth_done = false;
     }
 
     // ---- mean-z sign (global), depth-map slab, ONE all-gather of the slabs, pose table (unless it rode behind the refinement's last chunk) ----
@@ -1008,7 +1076,7 @@ restart_ransac:
             d_zsums = d_zs_all;
             nz = R;
         }
-        rc = depth_stage(d_final, d_zsums, nz, v, w, k, nullptr);
+        rc = depth_stage(d_final, d_zsums, nz, v, w, k, nullptr, nullptr);
         if (rc != RSDSFM_OK) return rc;
         rc = sync(c, D);
         if (rc != RSDSFM_OK) return rc;

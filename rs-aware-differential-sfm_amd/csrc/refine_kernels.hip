@@ -359,11 +359,12 @@ __global__ __launch_bounds__(kFB) void refine_init_kernel(const double2* __restr
 
 template <int NP>
 __global__ __launch_bounds__(kFB) void refine_init_decide_kernel(const double* __restrict__ partials, int nblocks,
-                                                                RefineState* st, int64_t m) {
+                                                                RefineState* st, int64_t m, const int64_t* __restrict__ m_dev = nullptr) {
     using CT = Counts<NP>;
     __shared__ double s_red[kFB / 64][CT::NINIT];
     __shared__ double s[CT::NINIT];
     if (nblocks < 0) nblocks = st->grid, m = st->m;  // device-resident shape (see pass_shape)
+    if (m_dev) m = *m_dev;  // (column-tiled solve ahead of the host's read of the RANSAC result: the GLOBAL inlier count, device-resident)
     reduce_partials<CT::NINIT>(partials, nblocks, CT::INIT_MAX, s_red, s);
     if (threadIdx.x == 0) {
         double gmax = s[CT::INIT_MAX], xsq = s[CT::INIT_MAX + 1];
@@ -863,9 +864,10 @@ static int refine_init_t(Ctx* c, const RefineBuffers& B) {
 // [ranks][NV] array exactly as they reduce per-workgroup partials
 template <int NV>
 __global__ __launch_bounds__(kFB) void refine_row_kernel(const double* __restrict__ partials, int nblocks, int max_slot,
-                                                        double* __restrict__ row) {
+                                                        double* __restrict__ row, const RefineState* __restrict__ st = nullptr) {
     __shared__ double s_red[kFB / 64][NV];
     __shared__ double s[NV];
+    if (nblocks < 0) nblocks = st->grid;  // device-resident shape (see pass_shape)
     reduce_partials<NV>(partials, nblocks, max_slot, s_red, s);
     if (threadIdx.x < NV) row[threadIdx.x] = s[threadIdx.x];
 }
@@ -873,13 +875,16 @@ __global__ __launch_bounds__(kFB) void refine_row_kernel(const double* __restric
 template <int NP>
 static int refine_stage_rows_t(Ctx* c, const RefineBuffers& B, int stage, double* row) {
     using CT = Counts<NP>;
-    const int grid = refine_grid(c, B.m);
+    const int grid = B.m_on_device ? refine_grid_cap(c) : refine_grid(c, B.m);
     if (stage == 0) {
         hipLaunchKernelGGL(refine_init_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, reinterpret_cast<const double2*>(B.flow),
-                           B.n_flow, B.m, B.inl, B.alpha, B.alpha_k, B.inlier_idx, B.flow_index_mode, B.state,
+                           B.n_flow, B.m_on_device ? (int64_t)-1 : B.m, B.inl, B.alpha, B.alpha_k, B.inlier_idx, B.flow_index_mode, B.state,
                            reinterpret_cast<double4*>(B.uu), B.beta, B.rho_a, B.srho, B.partials, B.bad_index, B.want_zsum ? 1 : 0);
         RSDSFM_HIP_CHECK(c, hipGetLastError());
-        hipLaunchKernelGGL(refine_row_kernel<CT::NINIT>, dim3(1), dim3(kFB), 0, c->stream, B.partials, grid, CT::INIT_MAX, row);
+        hipLaunchKernelGGL(refine_row_kernel<CT::NINIT>, dim3(1), dim3(kFB), 0, c->stream, B.partials, B.m_on_device ? -1 : grid, CT::INIT_MAX, row,
+                           static_cast<const RefineState*>(B.state));
+    } else if (B.m_on_device) {
+        return fail(c, RSDSFM_ERR_INVALID, "two-stage refinement protocol: the inlier count must be known on the host");
     } else if (stage == 1) {
         hipLaunchKernelGGL(refine_schur_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m,
                            reinterpret_cast<const double4*>(B.uu), B.beta, B.alpha, B.alpha_k, B.rho_a, B.rho_b, B.srho, B.state, B.partials);
@@ -896,9 +901,9 @@ static int refine_stage_rows_t(Ctx* c, const RefineBuffers& B, int stage, double
 }
 
 template <int NP>
-static int refine_stage_apply_t(Ctx* c, const RefineBuffers& B, int stage, const double* rows_all, int nranks, int64_t m_total) {
+static int refine_stage_apply_t(Ctx* c, const RefineBuffers& B, int stage, const double* rows_all, int nranks, int64_t m_total, const int64_t* m_total_dev) {
     if (stage == 0)
-        hipLaunchKernelGGL(refine_init_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state, m_total);
+        hipLaunchKernelGGL(refine_init_decide_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state, m_total, m_total_dev);
     else if (stage == 1)
         hipLaunchKernelGGL(refine_solve_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_all, nranks, B.state);
     else
@@ -1065,13 +1070,15 @@ __global__ __launch_bounds__(kFB) void refine_slot_pass_kernel(int64_t m, const 
 
 // the shard's slot partials [workgroups][NW] reduced to one row [NW]: the two column ranges with the reductions of their own stages
 template <int NP>
-__global__ __launch_bounds__(kFB) void refine_slot_row_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ row) {
+__global__ __launch_bounds__(kFB) void refine_slot_row_kernel(const double* __restrict__ partials, int nblocks, double* __restrict__ row,
+                                                             const RefineState* __restrict__ st = nullptr) {
     using CT = Counts<NP>;
     using SR = SlotRow<NP>;
     __shared__ double s_redS[kFB / 64][CT::NSCHUR];
     __shared__ double s_redB[kFB / 64][CT::NBACK];
     __shared__ double sS[CT::NSCHUR];
     __shared__ double sB[CT::NBACK];
+    if (nblocks < 0) nblocks = st->grid;  // device-resident shape (see pass_shape)
     reduce_partials<CT::NSCHUR>(partials, nblocks, -1, s_redS, sS, SR::NW, 0);
     reduce_partials<CT::NBACK>(partials, nblocks, CT::BACK_MAX, s_redB, sB, SR::NW, SR::OFF_BACK);
     if (threadIdx.x < CT::NSCHUR) row[threadIdx.x] = sS[threadIdx.x];
@@ -1192,12 +1199,15 @@ static int refine_iter_t(Ctx* c, const RefineBuffers& B, int j, int chunk) {
 
 template <int NP>
 static int refine_slot_rows_t(Ctx* c, const RefineBuffers& B, double* row, int j, const double* rows_all_prev, int nranks) {
-    const int grid = refine_grid(c, B.m);
-    hipLaunchKernelGGL(refine_slot_pass_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m, reinterpret_cast<const double4*>(B.uu), B.beta, B.alpha,
+    // (device-resident inlier count -- the column-tiled solve ahead of the host's read of the RANSAC result --: the launch grid is the cap, the
+    // logical grid and the count are RefineState's, as in the single-context frame solve)
+    const int grid = B.m_on_device ? refine_grid_cap(c) : refine_grid(c, B.m);
+    hipLaunchKernelGGL(refine_slot_pass_kernel<NP>, dim3(grid), dim3(kFB), 0, c->stream, B.m_on_device ? (int64_t)-1 : B.m, reinterpret_cast<const double4*>(B.uu), B.beta, B.alpha,
                        B.alpha_k, B.rho_a, B.rho_b, B.srho, slot_state_in(c, B, j), chunk_state(c, B, j), rows_all_prev, nranks, rows_buffer(c, B, 0),
                        B.want_zsum ? 1 : 0, c->d_refine_trace, c->refine_trace_rows);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
-    hipLaunchKernelGGL(refine_slot_row_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_buffer(c, B, 0), grid, row);
+    hipLaunchKernelGGL(refine_slot_row_kernel<NP>, dim3(1), dim3(kFB), 0, c->stream, rows_buffer(c, B, 0), B.m_on_device ? -1 : grid, row,
+                       static_cast<const RefineState*>(B.state));
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
@@ -1224,9 +1234,9 @@ int refine_stage_row_doubles(int np, int stage) {
 int refine_stage_rows_launch(Ctx* c, const RefineBuffers& B, int np, int stage, double* row) {
     return np == 7 ? refine_stage_rows_t<7>(c, B, stage, row) : refine_stage_rows_t<6>(c, B, stage, row);
 }
-int refine_stage_apply_launch(Ctx* c, const RefineBuffers& B, int np, int stage, const double* rows_all, int nranks, int64_t m_total) {
-    return np == 7 ? refine_stage_apply_t<7>(c, B, stage, rows_all, nranks, m_total)
-                   : refine_stage_apply_t<6>(c, B, stage, rows_all, nranks, m_total);
+int refine_stage_apply_launch(Ctx* c, const RefineBuffers& B, int np, int stage, const double* rows_all, int nranks, int64_t m_total, const int64_t* m_total_dev) {
+    return np == 7 ? refine_stage_apply_t<7>(c, B, stage, rows_all, nranks, m_total, m_total_dev)
+                   : refine_stage_apply_t<6>(c, B, stage, rows_all, nranks, m_total, m_total_dev);
 }
 
 int refine_init_launch(Ctx* c, const RefineBuffers& B, int np) { return np == 7 ? refine_init_t<7>(c, B) : refine_init_t<6>(c, B); }

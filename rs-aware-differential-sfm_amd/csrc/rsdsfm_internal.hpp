@@ -554,7 +554,8 @@ int refine_slot_partials_doubles(const Ctx* c, int64_t m);
 int refine_slot_rows_launch(Ctx* c, const RefineBuffers& B, int np, double* row, int j, const double* rows_all_prev, int nranks);
 int refine_slot_apply_launch(Ctx* c, const RefineBuffers& B, int np, const double* rows_all, int nranks, int chunk);
 int refine_stage_rows_launch(Ctx* c, const RefineBuffers& B, int np, int stage, double* row);
-int refine_stage_apply_launch(Ctx* c, const RefineBuffers& B, int np, int stage, const double* rows_all, int nranks, int64_t m_total);
+int refine_stage_apply_launch(Ctx* c, const RefineBuffers& B, int np, int stage, const double* rows_all, int nranks, int64_t m_total,
+                              const int64_t* m_total_dev = nullptr);
 }  // namespace rsdsfm
 
 namespace rsdsfm {

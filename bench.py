@@ -9,7 +9,7 @@ Contract: python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on
               map, per-scanline pose table (reference main.cc:398-522), ONE C-ABI call per pair (rsdsfm_solve_frame_dev), one
               pair at a time.  `value` = pixels of the K timed pairs / the time of the K steps; `median_ms_per_solve` beside it.
               Sub-records of the line:
-                roofline            the dominant kernel ransac_lma_kernel<2> (fp64 VALU bound: counted fp64 lane-instructions / its
+                roofline            the dominant kernel ransac_lma_kernel<2, true> (fp64 VALU bound: counted fp64 lane-instructions / its
                                     launch duration, measured here with HIP events, / 39.3e12; counts from profiles/counters.json, which
                                     is stamped with the kernel source hashes -- `counters_stale` when they do not match) and, under
                                     "hbm", SURVEY 8(d)'s whole-solve figure (57 N + 64 M iters bytes / solve time / 8 TB/s)
@@ -676,8 +676,9 @@ def run(args):
         side = not args.no_side_records
         # sequence-throughput mode (BASELINE configs[4]): 32 pairs with 32 data seeds through ONE context of each GPU
         batched = _full_solve_sequence(rsdsfm, solver, torch, dev, np, rank, args) if side else None
-        fused = depth_only = regimes = threads8 = exact_kernel = None
+        fused = depth_only = regimes = threads8 = exact_kernel = host_boundary = None
         if side and world == 1:
+            host_boundary = _host_boundary(rsdsfm, solver, np, rank, args)
             threads8 = _full_solve_batched(rsdsfm, torch, dev, local_rank, rank, args, 8, per_thread=12)  # round 2's way, for comparison
             threads8["note"] = "comparison: 8 host threads x 8 contexts, each calling the single solve (what round 2 reported as full_solve_batched)"  # single-GPU side records (a multi-rank run keeps to what scales: replicas + the tiled frame)
             if args.arith == "reference":
@@ -703,7 +704,7 @@ def run(args):
                                     "pairs": "the timed steps rotate over %d different pairs (data seeds) and a new sampler seed per step" % full["data_seeds"],
                                     **{k2: full[k2] for k2 in ("rows", "cols", "trials", "tol", "n", "num_inliers", "data_seeds", "num_inliers_min_max",
                                                                "refine_iterations_min_max", "distinct_winners", "refine_summary", "w_err", "v_angle_deg")}},
-                         "roofline": roof, "full_solve_batched": batched, "full_solve_8_threads": threads8, "full_solve_fused": fused, "full_solve_exact_kernel": exact_kernel, "regimes": regimes, "depth_only": depth_only,
+                         "roofline": roof, "full_solve_batched": batched, "full_solve_8_threads": threads8, "full_solve_fused": fused, "full_solve_exact_kernel": exact_kernel, "host_boundary": host_boundary, "regimes": regimes, "depth_only": depth_only,
                          "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_full(rsdsfm, np, rank, args.trials, args.tol)})
             # the regimes the headline does not exercise, lifted to the top level of the line: `value_selective` = the same one-call solve
             # at the selective tolerance 0.002 (M < N: compaction and the rank-indexed flow are NOT the identity), `value_sequence` =
@@ -1225,6 +1226,27 @@ def _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps, warmup, timed
             "stages": "flatten+alpha, minimal9 x %d, RANSAC LM sums/decide/score/pick/compaction, refinement, depth map, pose table" % args.trials}
 
 
+def _host_boundary(rsdsfm, solver, np, rank, args, reps=3):
+    """The reference-shaped HOST-pointer boundary (rsdsfm_ransac + rsdsfm_refine: caller-owned host arrays in, host arrays out, synchronous --
+    what minimal::ransac / nonLinearRefinement's own signatures give a caller, main.cc:447-457) on one 1280x720 DeepFlow-like pair: the 44 MB
+    of inputs and the outputs cross PCIe inside the timed region (pageable numpy arrays) and the ctypes wrapper's marshalling is in it too.
+    Reported beside `value`, never as it: the metric's inputs are resident in HBM."""
+    d = rsdsfm.synth.make_config(5, seed=0x5EED0005 + rank)
+    q, u, a, ak = d["q"], d["u"], d["alpha"], d["alpha_k"]
+    ts = []
+    for i in range(reps + 1):
+        t0 = time.perf_counter()
+        r = solver.ransac(q, u, a, ak, False, args.trials, args.tol, seed=11 + i)
+        out = solver.non_linear_refinement(u, r["inliers"], r["alpha"], r["alpha_k"], r["v"], r["w"], r["k"], False)
+        ts.append(time.perf_counter() - t0)
+    ts = sorted(ts[1:])
+    med = ts[len(ts) // 2]
+    return {"value": d["rows"] * d["cols"] / med / 1e6, "unit": "Mpixels/s", "ms_per_pair": med * 1e3, "pairs": reps, "num_inliers": int(r["num_inliers"]),
+            "refine_iterations": int(out["summary"]["num_iterations"]),
+            "note": "PCIe-inclusive: rsdsfm_ransac + rsdsfm_refine on host arrays (inputs, per-trial diagnostics, inlier arrays, dense inverse depths and mask "
+                    "copied both ways, Python marshalling included); not the metric"}
+
+
 def _full_solve_regimes(rsdsfm, solver, torch, dev, np, rank, args, solves=24):
     """The headline exercises ONE regime (tol 0.05 keeps every pixel an inlier).  The same one-call solve, driver-timed, on the other
     regimes the reference's own constants and modes give: each = `solves` whole solves after 3 warm-ups on the bench's context, one at
@@ -1279,7 +1301,7 @@ def _counters(kernel):
 
 
 def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):
-    """Roofline record of the whole solve's dominant kernel, ransac_lma_kernel<2> (the T depth solves of the RANSAC on the analytic LM
+    """Roofline record of the whole solve's dominant kernel, ransac_lma_kernel<2, true> (the T depth solves of the RANSAC on the analytic LM
     trajectory: ~26 % of the solve, level with the minimal solver's SVD chain and the refinement's passes), measured LIVE and in situ: the library brackets that launch with HIP events on the stream it runs
     on (rsdsfm_set_profiling) inside 27 ordinary whole solves after 3 warm-ups.  Its bound is
     fp64 VALU issue, not HBM: `achieved` = fp64 lane-instructions of one launch (SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 x 64 lanes,
@@ -1306,9 +1328,9 @@ def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):
     # round 0: three speculated iterations, the score of the two-step iterate fused (DeepFlow-like data); last template argument: sqrt and
     # the reciprocal through their in-range cores (reference-arithmetic library only)
     # the pixel pass of the RANSAC's depth solves on the analytic LM trajectory (ransac_lma_kernels.hip), the scores of two iterates fused
-    kname = "ransac_lma_kernel<2>"
+    kname = "ransac_lma_kernel<2, true>"
     ctr = _counters(kname + (":fused" if args.arith == "fused" else ""))
-    insts = achieved = frac = traffic = frac_all = None
+    insts = achieved = frac = traffic = frac_all = issue_floor_ms = None
     stale = ctr.get("stale") if ctr else ["profiles/counters.json: no entry for " + kname]
     if ctr and not stale:
         insts = 64.0 * sum(ctr.get(k2, 0.0) for k2 in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"))
@@ -1316,6 +1338,13 @@ def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):
         frac = achieved / FP64_VALU_PEAK
         if ctr.get("SQ_INSTS_VALU"):  # every VALU instruction (incl. v_div_scale / fmas / fixup, compares, selects) at the fp64 issue rate
             frac_all = 64.0 * ctr["SQ_INSTS_VALU"] / (kern_ms * 1e-3) / FP64_VALU_PEAK
+            # the kernel's own issue floor at the clock it ran at: measured issue costs per wave-instruction and SIMD (tools/valu_rates.hip,
+            # profiles/r05_valu_rates.txt): fp64 add / mul / fma 4 cycles, v_rcp_f64 / v_rsq_f64 16, everything else (compares, selects, integer) priced
+            # at the 2 cycles of a 32-bit instruction -- a lower bound of the floor; 1024 SIMDs
+            f64 = sum(ctr.get(k2, 0.0) for k2 in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64"))
+            tr = ctr.get("SQ_INSTS_VALU_TRANS_F64", 0.0)
+            cyc = 4.0 * f64 + 16.0 * tr + 2.0 * max(ctr["SQ_INSTS_VALU"] - f64 - tr, 0.0)
+            issue_floor_ms = cyc / 1024.0 / (clock_mhz * 1e3)
         if "FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr:  # KB; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section)
             traffic = (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0
     iters = full["refine_summary"]["num_iterations"]
@@ -1326,6 +1355,7 @@ def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):
             "shader_clock_mhz": clock_mhz, "nominal_clock_mhz": NOMINAL_CLOCK_MHZ,
             "frac_at_running_clock": None if frac is None else frac * NOMINAL_CLOCK_MHZ / clock_mhz,
             "frac_all_valu_instructions_at_running_clock": None if frac_all is None else frac_all * NOMINAL_CLOCK_MHZ / clock_mhz,
+            "issue_floor_ms_at_running_clock": issue_floor_ms, "frac_of_issue_floor": None if issue_floor_ms is None else issue_floor_ms / kern_ms,
             "fp64_lane_instructions_per_launch": insts, "avg_launch_ms": kern_ms, "median_launch_ms": float(ts[len(ts) // 2]),
             "pixel_hypotheses_per_launch": int(n) * T, "alg_bytes_per_launch": 48 * int(n),
             "share_of_solve": kern_ms / full["median_ms_per_solve"], "counters_stale": bool(stale), "counters_stale_files": stale or None,

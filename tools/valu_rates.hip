@@ -32,6 +32,8 @@ __global__ __launch_bounds__(256) void rate_kernel(double* out, double b, double
             if (OP == 5) x[i] = sqrt(x[i]);
             if (OP == 6) x[i] = fmax(x[i], c) ;
             if (OP == 7) x[i] = x[i] * b + c;  // mul + add (contract off)
+            if (OP == 8) x[i] = __builtin_amdgcn_rsq(x[i]);
+            if (OP == 9) x[i] = x[i] < c ? b : x[i] + c;  // v_cmp_f64 + v_add_f64 + 2 x v_cndmask_b32
         }
     }
     double s = 0;
@@ -77,12 +79,12 @@ int main() {
     double* d;
     CHECK(hipMalloc(&d, 64));
     const int wg_per_cu[] = {4, 8};  // 256-thread workgroups per CU: 4 -> 4 waves / SIMD, 8 -> 8 waves / SIMD
-    const char* names[] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rcp_f64", "IEEE div f64", "sqrt f64", "v_max_f64", "mul+add f64"};
-    const int per_op[] = {1, 1, 1, 1, 1, 1, 1, 2};
+    const char* names[] = {"v_fma_f64", "v_mul_f64", "v_add_f64", "v_rcp_f64", "IEEE div f64", "sqrt f64", "v_max_f64", "mul+add f64", "v_rsq_f64", "cmp+add+2cndmask"};
+    const int per_op[] = {1, 1, 1, 1, 1, 1, 1, 2, 1, 4};
     for (int w = 0; w < 2; ++w) {
         const int grid = cus * wg_per_cu[w];
         printf("-- %d waves per SIMD\n", wg_per_cu[w]);
-        for (int op = 0; op < 8; ++op) {
+        for (int op = 0; op < 10; ++op) {
             double ms = 0;
             switch (op) {
                 case 0: ms = time_ms([&] { rate_kernel<0><<<grid, 256>>>(d, 0.999, 1e-3); }); break;
@@ -93,6 +95,8 @@ int main() {
                 case 5: ms = time_ms([&] { rate_kernel<5><<<grid, 256>>>(d, 0.999, 1e-3); }); break;
                 case 6: ms = time_ms([&] { rate_kernel<6><<<grid, 256>>>(d, 0.999, 1e-3); }); break;
                 case 7: ms = time_ms([&] { rate_kernel<7><<<grid, 256>>>(d, 0.999, 1e-3); }); break;
+                case 8: ms = time_ms([&] { rate_kernel<8><<<grid, 256>>>(d, 0.999, 1e-3); }); break;
+                case 9: ms = time_ms([&] { rate_kernel<9><<<grid, 256>>>(d, 0.999, 1e-3); }); break;
             }
             const double waves_per_simd = wg_per_cu[w];  // 4 waves per workgroup over 4 SIMDs
             const double ops_per_simd = waves_per_simd * (double)kIter * kChains * per_op[op];

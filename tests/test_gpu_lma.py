@@ -243,6 +243,46 @@ def test_count_only_follows_the_data(solver, rsdsfm):
     assert [g[0] for g in got[9:]] == [0, 0, 1, 1]
 
 
+def test_count_only_edge_cases(solver, rsdsfm):
+    """count-only form, forced: more trials than one hypothesis batch (the form does not apply: fused error sums, same results), a frame with a
+    NaN flow vector (NaN hypotheses count no inlier; a NaN pixel is no inlier of any hypothesis), acceleration mode (hypotheses handed over to
+    the iterate-by-iterate rounds have exact sums already), a sequence through the lanes of one context"""
+    import torch
+
+    dev = torch.device("cuda", 0)
+    d = rsdsfm.synth.make_config(5, rows=135, cols=240)
+    rows, cols, K, gamma = d["rows"], d["cols"], d["K"], d["gamma"]
+    clean = np.array(d["flow_img"])
+    bad = clean.copy()
+    bad[40, 100] = np.nan
+    for flow, kw, expect_runs in ((clean, dict(trials=130, tol=0.5), 0), (bad, dict(trials=50, tol=0.5), 1), (bad, dict(trials=20, tol=0.003), 1),
+                                  (clean, dict(trials=50, tol=0.5, use_acceleration_mode=True), 1), (clean, dict(trials=8, tol=0.01, use_refinement=False), 1)):
+        img = torch.from_numpy(flow).to(dev)
+        solver.set_lm_arithmetic(1)
+        x, dx = _frame(solver, torch, dev, img, rows, cols, K, gamma, seed=5, **kw)
+        solver.set_lm_arithmetic(2)
+        r0 = solver.lma_count_only()[0]
+        a, da = _frame(solver, torch, dev, img, rows, cols, K, gamma, seed=5, **kw)
+        assert solver.lma_count_only()[0] - r0 == expect_runs, kw
+        _same_frame(a, da, x, dx)
+    # a sequence of pairs through the context's lanes (rsdsfm_solve_frames_dev): every lane inherits the form
+    imgs = [torch.from_numpy(rsdsfm.synth.make_config(5, rows=rows, cols=cols, seed=100 + i)["flow_img"]).to(dev) for i in range(6)]
+    dms = [torch.zeros((cols, rows), dtype=torch.float64, device=dev) for _ in imgs]
+    jobs = [dict(d_flow_img=im.data_ptr(), rows=rows, cols=cols, K=K, gamma=gamma, d_depth_map=dm.data_ptr(), d_R=None, d_t=None) for im, dm in zip(imgs, dms)]
+    outs = {}
+    for mode in (1, 2):
+        solver.set_lm_arithmetic(mode)
+        for tol in (0.5, 0.003):
+            res = solver.solve_frames_dev(jobs, [3 + i for i in range(len(jobs))], trials=50, tol=tol)
+            solver.synchronize()
+            outs[(mode, tol)] = ([(r["num_inliers"], r["best_trial"], tuple(r["v"]), tuple(r["w"]), str(r["refine_summary"])) for r in res], [dm.cpu().numpy().copy() for dm in dms])
+    for tol in (0.5, 0.003):
+        assert outs[(1, tol)][0] == outs[(2, tol)][0]
+        for a_, b_ in zip(outs[(1, tol)][1], outs[(2, tol)][1]):
+            assert np.array_equal(a_, b_, equal_nan=True)
+    solver.set_lm_arithmetic(0)
+
+
 # ---------------------------------------------------------------------------------------------------
 # the dense depth solve on the analytic trajectory (depth_lma_kernels.hip)
 # ---------------------------------------------------------------------------------------------------

@@ -51,7 +51,7 @@ def test_committed_counters_carry_a_stamp_or_are_reported_stale():
 
     data = json.load(open(os.path.join(ROOT, "profiles", "counters.json")))
     stamp = (data.get("_meta") or {}).get("sources")
-    stale = source_hash.stale_files("ransac_lm_kernel<true, 3, 2, true>", stamp)
+    stale = source_hash.stale_files("ransac_lma_kernel<2, true>", stamp)
     b = _bench()
-    got = b._counters("ransac_lm_kernel<true, 3, 2, true>")
+    got = b._counters("ransac_lma_kernel<2, true>")
     assert (got == {"stale": stale}) if stale else ("SQ_INSTS_VALU_ADD_F64" in got)

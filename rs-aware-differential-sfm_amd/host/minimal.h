@@ -88,6 +88,11 @@ struct RansacValues {
     double k;
     std::vector<int64_t> inlier_idx;  // index of each inlier in the arrays handed to ransac()
 
+    /** the reference's 5-argument form (minimal.h:67-70): beta, alpha and alpha_k all start as beta_init, k = 0 */
+    RansacValues(int num_inliers_init, rsdsfm::lite::Array3Xd inliers_init, rsdsfm::lite::VectorXd beta_init, rsdsfm::lite::Vector3d w_init,
+                 rsdsfm::lite::Vector3d v_init)
+        : num_inliers(num_inliers_init), inliers(inliers_init), beta(beta_init), alpha(beta_init), alpha_k(beta_init), w(w_init), v(v_init), k(0) {}
+
     RansacValues(int num_inliers_init, rsdsfm::lite::Array3Xd inliers_init, rsdsfm::lite::VectorXd alpha_init,
                  rsdsfm::lite::VectorXd alpha_k_init, rsdsfm::lite::Vector3d w_init, rsdsfm::lite::Vector3d v_init, double k_init)
         : num_inliers(num_inliers_init), inliers(inliers_init), beta(alpha_init), alpha(alpha_init), alpha_k(alpha_k_init),

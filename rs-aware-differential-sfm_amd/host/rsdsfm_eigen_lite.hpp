@@ -10,6 +10,7 @@ namespace lite = Eigen;
 }
 #else
 #include <cstddef>
+#include <ostream>
 #include <vector>
 
 namespace rsdsfm {
@@ -22,6 +23,11 @@ public:
     ArrayRX() : cols_(0) {}
     ArrayRX(long rows, long cols) : cols_(cols), d_((size_t)(Rows * cols), 0.0) { (void)rows; }
     static ArrayRX Zero(long rows, long cols) { return ArrayRX(rows, cols); }
+    static ArrayRX Ones(long rows, long cols) {
+        ArrayRX a(rows, cols);
+        for (double& x : a.d_) x = 1.0;
+        return a;
+    }
     long rows() const { return Rows; }
     long cols() const { return cols_; }
     double& operator()(long r, long c) { return d_[(size_t)(c * Rows + r)]; }
@@ -47,6 +53,20 @@ public:
     ArrayXd() {}
     explicit ArrayXd(long n) : d_((size_t)n, 0.0) {}
     static ArrayXd Zero(long n) { return ArrayXd(n); }
+    static ArrayXd Ones(long n) {
+        ArrayXd a(n);
+        for (double& x : a.d_) x = 1.0;
+        return a;
+    }
+    // coefficient-wise scalar updates (the reference's global-shutter switch: `alpha *= 0; alpha += 1;`, main.cc:441-444)
+    ArrayXd& operator*=(double s) {
+        for (double& x : d_) x *= s;
+        return *this;
+    }
+    ArrayXd& operator+=(double s) {
+        for (double& x : d_) x += s;
+        return *this;
+    }
     long size() const { return (long)d_.size(); }
     long rows() const { return (long)d_.size(); }
     double& operator()(long i) { return d_[(size_t)i]; }
@@ -80,10 +100,17 @@ public:
         d_[0] *= s, d_[1] *= s, d_[2] *= s;
         return *this;
     }
+    // what `std::cout << w.transpose()` needs (main.cc:449-451): a row view that streams as "x y z"
+    struct RowView {
+        double x, y, z;
+    };
+    RowView transpose() const { return RowView{d_[0], d_[1], d_[2]}; }
 
 private:
     double d_[3];
 };
+
+inline std::ostream& operator<<(std::ostream& os, const Vector3d::RowView& r) { return os << r.x << " " << r.y << " " << r.z; }
 
 class Vector2d {
 public:

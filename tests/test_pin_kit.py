@@ -39,3 +39,25 @@ def test_pin_kit_inputs_export(tmp_path):
     a = pinio.read(str(tmp_path / "deepflow_k0.pin"))
     assert np.array_equal(a["q"], g["deepflow_k0/q"]) and np.array_equal(a["samples"], g["deepflow_k0/samples"]) and a["samples"].dtype == np.int32
     assert a["tolerance"][0] == 0.05 and a["use_k"][0] == 0
+
+
+def test_mirror_check_compiles(tmp_path):
+    """tools/pin_reference/mirror_check.cpp -- the reference's six call sites (main.cc:437-457, errorMeasure.cpp:104-152) written with the
+    reference's own argument expressions -- must at least be WELL-FORMED against the mirror's headers.  The image has no Eigen, so the
+    mirror's stand-in types answer to the name `Eigen` here (tests/cpp/eigen_shim): a compile check of host/*.h, not a pin."""
+    src = os.path.join(ROOT, "tools", "pin_reference", "mirror_check.cpp")
+    shim = os.path.join(ROOT, "tests", "cpp", "eigen_shim")
+    p = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-I", shim, src], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-4000:]
+    # both of the reference's RansacValues constructors (minimal.h:67-75) and its two Velocities constructors (minimal.h:45-50) exist
+    probe = tmp_path / "ctors.cpp"
+    probe.write_text(
+        '#include <Eigen/Dense>\n#include "%s/rs-aware-differential-sfm_amd/host/minimal.h"\n'
+        "int main() {\n"
+        "  Eigen::Array3Xd inl(3, 4); Eigen::VectorXd b(4); Eigen::Vector3d w, v;\n"
+        "  RansacValues r5(4, inl, b, w, v); RansacValues r7(4, inl, b, b, w, v, 0.5);\n"
+        "  Velocities v2(w, v); Velocities v3(w, v, 0.25);\n"
+        "  return (r5.k == 0 && r5.alpha_k.size() == 4 && r7.k == 0.5 && v2.k == 0 && v3.k == 0.25) ? 0 : 1;\n}\n" % ROOT
+    )
+    p = subprocess.run(["g++", "-std=c++14", "-fsyntax-only", "-Wall", "-I", shim, str(probe)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-4000:]

@@ -6,6 +6,7 @@
 //   main.cc:437-438, :447, :457 (evaluateSingleRun)  and  errorMeasure.cpp:104-105, :140, :152 (evaluateVelocities).
 #include <iostream>
 #include <type_traits>
+#include <utility>
 
 #include <Eigen/Dense>
 
@@ -14,8 +15,8 @@
 
 static_assert(std::is_same<rsdsfm::lite::ArrayXd, Eigen::ArrayXd>::value, "with Eigen present rsdsfm::lite IS Eigen");
 static_assert(std::is_same<rsdsfm::lite::Matrix2Xd, Eigen::Matrix2Xd>::value, "with Eigen present rsdsfm::lite IS Eigen");
-static_assert(std::is_same<decltype(RansacValues().w), Eigen::Vector3d>::value, "RansacValues::w is the reference's Vector3d");
-static_assert(std::is_same<decltype(RansacValues().inliers), Eigen::Array3Xd>::value, "RansacValues::inliers is the reference's Array3Xd");
+static_assert(std::is_same<std::decay<decltype(std::declval<RansacValues&>().w)>::type, Eigen::Vector3d>::value, "RansacValues::w is the reference's Vector3d");
+static_assert(std::is_same<std::decay<decltype(std::declval<RansacValues&>().inliers)>::type, Eigen::Array3Xd>::value, "RansacValues::inliers is the reference's Array3Xd");
 
 using namespace std;
 using namespace Eigen;

@@ -155,6 +155,16 @@ int rsdsfm_ransac_restarts(rsdsfm_ctx* ctx, int64_t* count);
  * the band, 6 step quality, 7 tie, 8 list overflow, 9 listed pixels off the tabulated trajectory, 10 count check of the winner's replay). */
 int rsdsfm_set_lm_arithmetic(rsdsfm_ctx* ctx, int mode);
 int rsdsfm_lma_restarts(rsdsfm_ctx* ctx, int64_t* count, int32_t* last_guards_or_null);
+/* The joint refinement (nonlinearRefinement.cc:183-252; rsdsfm_refine*, the refinement inside rsdsfm_solve_frame*_dev and the tiled solve) in
+ * mode 0 runs on RADIUS-FACTORISED Schur sums (csrc/refine_rf_kernels.hip): the sums a pass takes at a point serve any trust-region radius,
+ * so every LM iteration is ONE pass over the inliers and a rejected / invalid step costs none; its arithmetic is the library's own (fused
+ * multiply-adds), and every decision of Ceres' loop that lands within a relative band of its threshold (invalid step, parameter / function /
+ * gradient tolerance, step quality, Cholesky pivot, a non-finite sum, more than 64 inliers with an active LM-diagonal clamp) sends THAT solve
+ * back to the iterate-by-iterate kernels (the reference's arithmetic), which mode 1 selects outright.
+ * rsdsfm_refine_restarts: refinements of this context (and its sequence lanes) that ran on the radius-factorised path, how many of them were
+ * sent back, (optional) the reduced systems solved again from stored sums, and the guard that tripped last (1 non-finite sum, 2 gradient /
+ * 3 model change / 4 parameter / 5 function tolerance inside its band, 6 step quality, 7 pivot, 8 list overflow, 9 minimum radius). */
+int rsdsfm_refine_restarts(rsdsfm_ctx* ctx, int64_t* runs, int64_t* restarts, int64_t* resolves_or_null, int32_t* last_guard_or_null);
 /* how many RANSACs of this context (and its sequence lanes) ran the count-only form of the pass, and how many of those had to fetch error sums */
 int rsdsfm_lma_count_only(rsdsfm_ctx* ctx, int64_t* runs, int64_t* lazy_runs_or_null);
 /* The dense depth solve (rsdsfm_estimate_inverse_depths*, LM mode) takes the same in-range cores in launch 0 (Jacobi scaling) under the same

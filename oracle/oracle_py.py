@@ -409,8 +409,11 @@ def ransac(q, u, alpha, alpha_k, use_alpha_k, iterations, tol, samples, depth_mo
     )
 
 
-def refine(flow, inliers, alpha, alpha_k, v, w, k, const_acceleration=False, flow_index_mode=0, inlier_idx=None, trace_rows=0):
-    """trace_rows > 0: also return `trace`, the per-iteration record laid out like the product's rsdsfm_get_refine_trace"""
+def refine(flow, inliers, alpha, alpha_k, v, w, k, const_acceleration=False, flow_index_mode=0, inlier_idx=None, trace_rows=0, mode=1):
+    """trace_rows > 0: also return `trace`, the per-iteration record laid out like the product's rsdsfm_get_refine_trace.
+    mode 1 = the reference's arithmetic (rso_refine, the pinned target); mode 2 = the product's default arithmetic restated (rso_refine_rf:
+    radius-factorised Schur sums; also returns `guard` -- 0 or the guard at which the product would run the solve again iterate by iterate --
+    and `resolves`)"""
     flow, inliers, alpha, alpha_k = _f64(flow), _f64(inliers), _f64(alpha), _f64(alpha_k)
     m = inliers.shape[0]
     idx = None if inlier_idx is None else np.ascontiguousarray(inlier_idx, dtype=np.int64)
@@ -422,14 +425,20 @@ def refine(flow, inliers, alpha, alpha_k, v, w, k, const_acceleration=False, flo
     if trace is not None:
         L.rso_set_refine_trace.restype = None
         L.rso_set_refine_trace(_p(trace), C.c_int(trace_rows))
+    guard, resolves = C.c_int32(0), C.c_int32(0)
     try:
-        rc = L.rso_refine(_p(flow), C.c_int64(flow.shape[0]), C.c_int64(m), _p(inliers), _p(alpha), _p(alpha_k), None if idx is None else _p(idx), _v3(v), _v3(w), C.c_double(k), int(const_acceleration), int(flow_index_mode), _p(out), vo, wo, C.byref(ko), C.byref(sm))
+        if mode == 2:
+            rc = L.rso_refine_rf(_p(flow), C.c_int64(flow.shape[0]), C.c_int64(m), _p(inliers), _p(alpha), _p(alpha_k), None if idx is None else _p(idx), _v3(v), _v3(w), C.c_double(k), int(const_acceleration), int(flow_index_mode), _p(out), vo, wo, C.byref(ko), C.byref(sm), C.byref(guard), C.byref(resolves))
+        else:
+            rc = L.rso_refine(_p(flow), C.c_int64(flow.shape[0]), C.c_int64(m), _p(inliers), _p(alpha), _p(alpha_k), None if idx is None else _p(idx), _v3(v), _v3(w), C.c_double(k), int(const_acceleration), int(flow_index_mode), _p(out), vo, wo, C.byref(ko), C.byref(sm))
     finally:
         if trace is not None:
             L.rso_set_refine_trace(None, C.c_int(0))
     if rc != 0:
         raise RuntimeError("rso_refine failed rc=%d" % rc)
     res = dict(inliers=out, v=np.array(vo[:]), w=np.array(wo[:]), k=ko.value, summary=sm.as_dict())
+    if mode == 2:
+        res["guard"], res["resolves"] = guard.value, resolves.value
     if trace is not None:
         res["trace"] = trace
     return res

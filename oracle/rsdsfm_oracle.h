@@ -142,6 +142,13 @@ int rso_refine(const double* flow2n, int64_t n_flow, int64_t m, const double* in
                int flow_index_mode, double* inliers_out_3m, double v_out[3], double w_out[3],
                double* k_out, rso_lm_summary* summary);
 
+/* the same solve in the product's default arithmetic (radius-factorised Schur sums, refine_rf_kernels.hip), restated; *guard_out = 0 or the
+ * guard at which the product would leave that arithmetic; *resolves_out = reduced systems solved again from stored sums */
+int rso_refine_rf(const double* flow2n, int64_t n_flow, int64_t m, const double* inliers_3m, const double* alpha_m, const double* alpha_k_m,
+                  const int64_t* inlier_idx_or_null, const double v_in[3], const double w_in[3], double k_in, int const_acceleration,
+                  int flow_index_mode, double* inliers_out_3m, double v_out[3], double w_out[3], double* k_out, rso_lm_summary* summary,
+                  int32_t* guard_out, int32_t* resolves_out);
+
 /* main.cc:398-444 / errorMeasure.cpp:66-111 (shrinking variant).  flow image row-major rows x cols x 2.
  * returns the number of kept points. */
 int64_t rso_flatten(const double* flow_img, int32_t rows, int32_t cols, double fx, double fy, double cx,

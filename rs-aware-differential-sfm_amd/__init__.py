@@ -264,6 +264,13 @@ class Solver:
         (rsdsfm_set_lm_arithmetic); integer outputs never depend on it"""
         self._check(self.lib.rsdsfm_set_lm_arithmetic(self._ctx, int(mode)), "rsdsfm_set_lm_arithmetic")
 
+    def refine_restarts(self):
+        """(refinements on the radius-factorised path, those a guard sent back to the iterate-by-iterate kernels, reduced systems solved
+        again from stored sums, the guard that tripped last) -- rsdsfm_refine_restarts"""
+        n, r, sv, g = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int32(0)
+        self._check(self.lib.rsdsfm_refine_restarts(self._ctx, C.byref(n), C.byref(r), C.byref(sv), C.byref(g)), "rsdsfm_refine_restarts")
+        return dict(runs=n.value, restarts=r.value, resolves=sv.value, last_guard=g.value)
+
     def lma_restarts(self):
         """(RANSAC runs of this context that started over because a guard of the analytic trajectory tripped, bit set of the last guards)"""
         n, g = C.c_int64(0), C.c_int32(0)

@@ -84,4 +84,6 @@ def build(force=False, verbose=False, jobs=None):
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+
+    print(build(force="--stale" not in sys.argv, verbose="--stale" not in sys.argv))

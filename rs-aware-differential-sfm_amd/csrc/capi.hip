@@ -200,6 +200,19 @@ int rsdsfm_set_profiling(rsdsfm_ctx* ctx, int on) {
 
 int rsdsfm_profile_last_ms(rsdsfm_ctx* ctx, const char* what, double* ms) {
     CTX_OR_FAIL(ctx);
+    if (what && ms && !strncmp(what, "refine_rf_phase", 15) && what[15] >= '0' && what[15] <= '7' && !what[16]) {
+        // opt-in phase stamps of the radius-factorised refinement's pass (environment RSDSFM_RF_STAMPS=1): microseconds workgroup 0 spent in
+        // 0 the state load, 1 the stage in its prologue, 2 the loop over its inliers, 3 the row reduction, summed over the passes since the
+        // last read of record 4 = the number of passes (reading it zeroes all five)
+        static unsigned long long h[8];
+        if (what[15] == '0') {  // (record 0 reads -- and zeroes -- all of them; 1 .. 7 return what that read found; 5 .. 7 split the stage: rows reduced, decided, solved)
+            int rc = refine_rf_read_stamps(c, h);
+            if (rc != RSDSFM_OK) return fail(c, RSDSFM_ERR_INVALID, "no phase stamps: set RSDSFM_RF_STAMPS=1 before the first refinement");
+        }
+        const int k = what[15] - '0';
+        *ms = k == 4 ? (double)h[4] : (double)h[k] * 0.01;
+        return RSDSFM_OK;
+    }
     const bool clock = what && !strcmp(what, "ransac_lm_round0_clock_mhz");
     const int which = !what ? -1 : clock || !strcmp(what, "ransac_lm_round0") ? 0 : !strcmp(what, "depth_lm_batch") ? 1 : -1;
     if (which < 0 || !ms)
@@ -303,6 +316,21 @@ int rsdsfm_lma_restarts(rsdsfm_ctx* ctx, int64_t* count, int32_t* last_guards) {
     for (rsdsfm_ctx* lane : c->lanes) total += lane->c.lma_restarts, guards |= lane->c.lma_last_guard;
     *count = total;
     if (last_guards) *last_guards = guards;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_refine_restarts(rsdsfm_ctx* ctx, int64_t* runs, int64_t* restarts, int64_t* resolves_or_null, int32_t* last_guard_or_null) {
+    CTX_OR_FAIL(ctx);
+    if (!runs || !restarts) return fail(c, RSDSFM_ERR_INVALID, "refine restarts: null output");
+    int64_t n = c->refine_rf_runs, r = c->refine_rf_restarts, s = c->refine_rf_resolves;
+    int guard = c->refine_rf_last_guard;
+    for (rsdsfm_ctx* lane : c->lanes) {
+        n += lane->c.refine_rf_runs, r += lane->c.refine_rf_restarts, s += lane->c.refine_rf_resolves;
+        if (lane->c.refine_rf_last_guard) guard = lane->c.refine_rf_last_guard;
+    }
+    *runs = n, *restarts = r;
+    if (resolves_or_null) *resolves_or_null = s;
+    if (last_guard_or_null) *last_guard_or_null = guard;
     return RSDSFM_OK;
 }
 

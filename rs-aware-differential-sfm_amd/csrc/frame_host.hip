@@ -29,10 +29,6 @@ namespace rsdsfm {
 static std::atomic<int> g_frames_in_flight[64];
 int frames_in_flight(const Ctx* c) { return g_frames_in_flight[c->device & 63].load(std::memory_order_relaxed); }
 
-int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
-                  const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
-                  int const_acceleration, int flow_index_mode, double* d_inl_out, double v_out[3], double w_out[3], double* k_out,
-                  rsdsfm_lm_summary* summary, const RefineTail* tail, double* d_zpartials);
 int alpha_ones_launch(Ctx* c, double* d_alpha, int64_t n);
 int flatten_device(Ctx* c, const double* d_img, int32_t rows, int32_t cols, int32_t col0, double fx, double fy, double cx, double cy, double gamma,
                    double thr, double* d_q, double* d_u, double* d_alpha, double* d_alpha_k, int64_t* n_out);
@@ -331,11 +327,14 @@ int frame_finish(Ctx* c, FrameRun* F, rsdsfm_frame_result* res) {
     int flipped = 0;
     F->m_known = ro.num_inliers;
     if (prm->use_refinement) {
-        if (F->refinement_enqueued)
+        bool exact = false;
+        if (F->refinement_enqueued) {
             rc = refine_poll(c, &F->refine, v, w, &k, &res->refine_summary);
-        else
+            exact = rc == kRcRefineRestartExact;  // (a guard of the radius-factorised path: again from the host-side RANSAC result, iterate by iterate)
+        }
+        if (!F->refinement_enqueued || exact)
             rc = refine_device(c, F->d_u, n, ro.num_inliers, F->d_inl, F->d_in_a, F->d_in_ak, F->d_idx, v, w, k, prm->use_acceleration_mode,
-                               prm->flow_index_mode, F->d_inl_ref, v, w, &k, &res->refine_summary, &F->tail, F->d_zpartials);
+                               prm->flow_index_mode, F->d_inl_ref, v, w, &k, &res->refine_summary, &F->tail, F->d_zpartials, exact);
         if (rc != RSDSFM_OK) return rc;
         d_final = F->d_inl_ref;
         const double* h_header = header_host(c);

@@ -23,7 +23,7 @@ namespace rsdsfm {
 int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
                  const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
                  int const_acceleration, int flow_index_mode, double* d_inl_out, const RefineTail* tail, const RansacBest* d_best,
-                 void* ws_base, RefineRun* run, RefineState* hs_prefetch, double* d_zpartials) {
+                 void* ws_base, RefineRun* run, RefineState* hs_prefetch, double* d_zpartials, bool exact) {
     if (m < 0 || n_flow < 0 || (!d_best && (!v_in || !w_in))) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     if (flow_index_mode != RSDSFM_FLOW_COMPAT_RANK && flow_index_mode != RSDSFM_FLOW_GATHERED) return fail(c, RSDSFM_ERR_INVALID, "unknown flow_index_mode");
     if (flow_index_mode == RSDSFM_FLOW_GATHERED && m > 0 && !d_inlier_idx) return fail(c, RSDSFM_ERR_INVALID, "gathered mode needs inlier_idx");
@@ -64,6 +64,10 @@ int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const 
     B.bad_index = reinterpret_cast<int*>(state_block + sizeof(RefineState));
     B.zpartials = d_zpartials;
     run->np = np;
+    // the radius-factorised path (refine_rf_kernels.hip) unless the context asks for the reference's arithmetic or this solve is run again
+    // behind a tripped guard
+    run->rf = !exact && c->lm_arithmetic == 0;
+    if (run->rf) c->refine_rf_runs += 1;
     run->d_inl_out = d_inl_out;
     run->tail = tail;
     run->launched = 0;
@@ -88,13 +92,15 @@ int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const 
         hs->termination = -1;
         hs->radius = kInitialRadius;
         hs->need_schur = 1;  // the first slot of the iteration loop is the Schur pass of iteration 1
-        *h_bad = 0;
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(B.state, hs, sizeof(RefineState) + sizeof(int), hipMemcpyHostToDevice, c->stream));
+        memset(h_bad, 0, kRefineStateBlockTail);  // bad-index flag + the list counters of the radius-factorised path
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(B.state, hs, sizeof(RefineState) + kRefineStateBlockTail, hipMemcpyHostToDevice, c->stream));
     }
     rc = refine_trace_reset(c);
     if (rc != RSDSFM_OK) return rc;
-    rc = refine_init_launch(c, B, np);
-    if (rc != RSDSFM_OK) return rc;
+    if (!run->rf) {  // (the radius-factorised path's first slot IS iteration zero)
+        rc = refine_init_launch(c, B, np);
+        if (rc != RSDSFM_OK) return rc;
+    }
     // The iteration loop is enqueued in chunks of SLOTS (refine_kernels.hip: a streaming pass + the single-workgroup stage behind it; a solve
     // of `it` LM iterations consumes it + 1 of them, one more for every step that was rejected or got another radius than the speculated
     // one).  The kernels of a finished solve return immediately, but an empty slot still costs two launches (~9 us at 1280x720) and a chunk
@@ -107,14 +113,31 @@ int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const 
     // is that count + 1 as well, at most 28.  The chunking changes when the host looks at the state, never what the kernels compute.
     const int hp = run->hint_prev;
     run->chunk = (hp >= 0 && hp <= 3) ? hp + 1 : (hp > 8 ? std::min(hp + 1, 28) : 7);
+    // (radius-factorised path: a solve of `it` candidate evaluations consumes exactly it + 1 slots -- 4 .. 7 on DeepFlow-like pairs, 14 .. 16 in
+    // acceleration mode --, the same rule fits)
     return refine_enqueue_chunk(c, run);
 }
 
 // one chunk of slots of the iteration loop, the output pass and the caller's tail
 int refine_enqueue_chunk(Ctx* c, RefineRun* run) {
-    for (int i = 0; i < run->chunk; ++i) {
-        int rc = refine_iter_launch(c, run->B, run->np, i, run->chunk);
-        if (rc != RSDSFM_OK) return rc;
+    if (run->rf) {
+        // slot g's pass carries the stage of slot g - 1 in its prologue; the stage gets a launch of its own behind the chunk's last pass (into
+        // the published state) and -- while several solves share the GPU, or on request -- behind every pass
+        const bool separate = c->refine_stage_mode == 2 || (c->refine_stage_mode == 0 && (c->refine_stage_separate || frames_in_flight(c) > 1));
+        for (int i = 0; i < run->chunk; ++i) {
+            const int g = run->launched + i;
+            int rc = refine_rf_pass_launch(c, run->B, run->np, g, run->launched, nullptr, 0, -1, nullptr);
+            if (rc != RSDSFM_OK) return rc;
+            if (i == run->chunk - 1 || separate) {
+                rc = refine_rf_apply_launch(c, run->B, run->np, g, i == run->chunk - 1, nullptr, 0, -1, nullptr);
+                if (rc != RSDSFM_OK) return rc;
+            }
+        }
+    } else {
+        for (int i = 0; i < run->chunk; ++i) {
+            int rc = refine_iter_launch(c, run->B, run->np, i, run->chunk);
+            if (rc != RSDSFM_OK) return rc;
+        }
     }
     run->launched += run->chunk;
     // the output pass is enqueued before the host knows whether the solve has finished (the common case: <= 5 iterations),
@@ -145,6 +168,11 @@ int refine_poll(Ctx* c, RefineRun* run, double v_out[3], double w_out[3], double
             RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
         }
         if (*h_bad) return fail(c, RSDSFM_ERR_INVALID, "flow index out of range (flow has fewer columns than inliers / bad inlier_idx)");
+        if (hs->termination == kTermRestartExact) {  // a guard of the radius-factorised path: the caller runs the solve again, iterate by iterate
+            c->refine_rf_restarts += 1;
+            c->refine_rf_last_guard = hs->rf_guard;
+            return kRcRefineRestartExact;
+        }
         if (hs->termination >= 0) {
             if (run->tail && !run->tail_done) {  // ended earlier than the previous solve: the tail was not behind this chunk
                 int rc = (*run->tail)(run->B);
@@ -162,6 +190,7 @@ int refine_poll(Ctx* c, RefineRun* run, double v_out[3], double w_out[3], double
         if (rc != RSDSFM_OK) return rc;
     }
     c->refine_iters_hint = hs->slots;
+    if (run->rf) c->refine_rf_resolves += hs->rf_resolves;
     for (int i = 0; i < 3; ++i) {
         v_out[i] = hs->p[i];
         w_out[i] = hs->p[3 + i];
@@ -188,13 +217,17 @@ size_t refine_workspace_bytes(const Ctx* c, int64_t m, bool m_on_device) {
 int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
                   const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
                   int const_acceleration, int flow_index_mode, double* d_inl_out, double v_out[3], double w_out[3], double* k_out,
-                  rsdsfm_lm_summary* summary, const RefineTail* tail, double* d_zpartials) {
+                  rsdsfm_lm_summary* summary, const RefineTail* tail, double* d_zpartials, bool exact) {
     if (!v_out || !w_out || !k_out) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
-    RefineRun run;
-    int rc = refine_begin(c, d_flow, n_flow, m, d_inl, d_alpha, d_alpha_k, d_inlier_idx, v_in, w_in, k_in, const_acceleration, flow_index_mode,
-                          d_inl_out, tail, nullptr, nullptr, &run, nullptr, d_zpartials);
-    if (rc != RSDSFM_OK) return rc;
-    return refine_poll(c, &run, v_out, w_out, k_out, summary);
+    const double v0[3] = {v_in[0], v_in[1], v_in[2]}, w0[3] = {w_in[0], w_in[1], w_in[2]};  // (v_in may alias v_out)
+    for (int attempt = 0;; ++attempt) {
+        RefineRun run;
+        int rc = refine_begin(c, d_flow, n_flow, m, d_inl, d_alpha, d_alpha_k, d_inlier_idx, v0, w0, k_in, const_acceleration, flow_index_mode,
+                              d_inl_out, tail, nullptr, nullptr, &run, nullptr, d_zpartials, exact || attempt > 0);
+        if (rc != RSDSFM_OK) return rc;
+        rc = refine_poll(c, &run, v_out, w_out, k_out, summary);
+        if (rc != kRcRefineRestartExact || attempt > 0) return rc == kRcRefineRestartExact ? fail(c, RSDSFM_ERR_NUMERIC, "refinement: restart loop") : rc;
+    }
 }
 
 }  // namespace rsdsfm

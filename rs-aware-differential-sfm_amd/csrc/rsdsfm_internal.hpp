@@ -193,6 +193,11 @@ struct Ctx {
     // prologue; 2 = always a launch of its own.  Never a result.
     int refine_stage_mode = 0;
     bool refine_stage_separate = false;  // (what the automatic mode resolves to for the solve in flight)
+    // the joint refinement on radius-factorised Schur sums (refine_rf_kernels.hip; the default while lm_arithmetic == 0): solves that ran on
+    // it, solves one of whose guards sent them back to the iterate-by-iterate slot kernels, the guard that tripped last (RfGuard), and the
+    // reduced systems solved again from stored sums (rejected / invalid steps) -- rsdsfm_refine_restarts
+    int64_t refine_rf_runs = 0, refine_rf_restarts = 0, refine_rf_resolves = 0;
+    int refine_rf_last_guard = 0;
     std::vector<rsdsfm_ctx*> lanes;
 };
 constexpr int kSequenceLanesDefault = 3;  // measured: 1 / 2 / 3 / 4 / 6 / 8 lanes = 0.91 / 1.19 / 1.31 / 1.21 / 1.31 / 1.27 Gpix/s at 1280x720, T = 50
@@ -420,8 +425,16 @@ struct RefineState {
     int32_t spec_miss_run;
     // a slot's pass has run and its single-workgroup stage has not: the next slot kernel's prologue (or the stage kernel behind the last
     // pass of a chunk) reduces that pass's rows and runs the decision / reduced solve before anything else
-    int32_t pending_apply, _pad3;
+    int32_t pending_apply;
+    // radius-factorised path (refine_rf_kernels.hip): 1 while the solve runs on it; rf_guard = the guard that sent it back to the iterate-by-
+    // iterate slot kernels (termination == kTermRestartExact then; see RfGuard)
+    int32_t rf;
+    double dp[7];  // that path's parameter step in UNSCALED parameters (pc = p + dp)
+    double p0[7];  // the start parameters (the Jacobi scales of the rho columns are taken at them: 1 / (1 + |J_rho(x0)|))
+    int32_t rf_guard, rf_resolves;  // rf_resolves: reduced systems solved again from stored sums (rejected / invalid steps: no pass of their own)
 };
+// RefineState::termination of a radius-factorised refinement one of whose guards tripped: the host runs the solve again on the iterate-by-iterate kernels
+constexpr int kTermRestartExact = 64;
 struct RefineBuffers {
     const double* flow;  // 2 x n_flow
     int64_t n_flow, m;
@@ -512,6 +525,7 @@ int refine_finish_grid(const Ctx* c, const RefineBuffers& B);
 struct RefineRun {
     RefineBuffers B;
     int np = 6, launched = 0, chunk = 5, hint_prev = -1;
+    bool rf = false;  // on the radius-factorised path (refine_rf_kernels.hip); false: the iterate-by-iterate slot kernels
     double* d_inl_out = nullptr;
     const RefineTail* tail = nullptr;
     // pinned host copy of the state (+ bad-index flag).  prefetch: every chunk also enqueues its read-back, and the first refine_poll
@@ -523,10 +537,17 @@ struct RefineRun {
 // the last kPinnedTail bytes of the context's pinned block are reserved for the frame solve (refinement state read-back, depth-map header)
 constexpr size_t kPinnedTail = 1024;
 size_t refine_workspace_bytes(const Ctx* c, int64_t m, bool m_on_device);
+// exact: on the iterate-by-iterate slot kernels whatever the context's arithmetic (a solve that is run again behind a tripped guard)
 int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
                  const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
                  int const_acceleration, int flow_index_mode, double* d_inl_out, const RefineTail* tail, const RansacBest* d_best,
-                 void* ws_base, RefineRun* run, RefineState* hs_prefetch, double* d_zpartials);
+                 void* ws_base, RefineRun* run, RefineState* hs_prefetch, double* d_zpartials, bool exact = false);
+// refine_poll's return value when a guard of the radius-factorised path tripped: nothing was written to the outputs; run the solve again with exact = true
+constexpr int kRcRefineRestartExact = 1;
+int refine_device(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const double* d_inl, const double* d_alpha,
+                  const double* d_alpha_k, const int64_t* d_inlier_idx, const double v_in[3], const double w_in[3], double k_in,
+                  int const_acceleration, int flow_index_mode, double* d_inl_out, double v_out[3], double w_out[3], double* k_out,
+                  rsdsfm_lm_summary* summary, const RefineTail* tail, double* d_zpartials, bool exact = false);
 int refine_enqueue_chunk(Ctx* c, RefineRun* run);
 int frames_in_flight(const Ctx* c);  // frame solves between begin and the end of finish on the context's device, all contexts of the process (frame_host.hip)
 int refine_poll(Ctx* c, RefineRun* run, double v_out[3], double w_out[3], double* k_out, rsdsfm_lm_summary* summary);
@@ -539,6 +560,21 @@ inline int refine_trace_reset(Ctx* c) {
     return hipMemsetAsync(c->d_refine_trace, 0xFF, (size_t)c->refine_trace_rows * kRefineTraceCols * sizeof(double), c->stream) == hipSuccess ? RSDSFM_OK : RSDSFM_ERR_HIP;
 }
 int refine_init_launch(Ctx* c, const RefineBuffers& B, int np);
+// refine_rf_kernels.hip: slot g (global index within the solve; 0 = the first pass: iteration zero + the Schur sums of iteration 1) of a
+// chunk that started at g_first; the stage behind slot g on its own; the shard's row [sums | list] of the column-tiled solve
+int refine_rf_pass_launch(Ctx* c, const RefineBuffers& B, int np, int g, int g_first, const double* rows_all_prev, int nranks, int64_t m_total,
+                          const int64_t* m_total_dev);
+int refine_rf_apply_launch(Ctx* c, const RefineBuffers& B, int np, int g, bool to_published, const double* rows_all, int nranks, int64_t m_total,
+                           const int64_t* m_total_dev);
+int refine_rf_row_launch(Ctx* c, const RefineBuffers& B, int np, int g, double* row);
+int refine_rf_row_doubles(int np);
+int refine_rf_read_stamps(Ctx* c, unsigned long long out[8]);
+int refine_rf_extra_doubles();
+int refine_partials_half_doubles(const Ctx* c);
+int refine_state_doubles();
+// the three list counters of the radius-factorised path live behind the state and its bad-index flag (zeroed with them)
+inline int* refine_rf_counters(const RefineBuffers& B) { return B.bad_index + 4; }
+constexpr size_t kRefineStateBlockTail = 32;  // bytes behind RefineState that travel with it: bad-index flag (+0), list counters (+16, +20, +24)
 // slot `j` of a chunk of `chunk` slots (refine_kernels.hip): its pass carries the single-workgroup stage of slot j - 1 in its prologue; the
 // last one is followed by that stage on its own, which leaves the state in B.state for the output pass, the caller's tail and the host
 int refine_iter_launch(Ctx* c, const RefineBuffers& B, int np, int j, int chunk);

@@ -2009,7 +2009,7 @@ static int rf_solve(int np, const rf_sums* S, const int64_t* list, int nlist, co
     for (int j = 0; j < np; ++j) {
         double sjj = A[j * np + j], d = sjj;
         for (int t = 0; t < j; ++t) d = fma(-A[j * np + t], A[j * np + t], d);
-        if (!(fabs(d) > RF_BAND_PIVOT * fabs(sjj))) return -1;
+        if (!(fabs(d) > RF_BAND_PIVOT * fabs(sjj)) || !(fabs(d) > 1e-200 && fabs(d) < 1e200)) return -1;
         if (d < 0.0) return 0;
         double id = 1.0 / sqrt(d);
         inv_d[j] = id;

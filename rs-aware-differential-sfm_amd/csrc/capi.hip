@@ -200,17 +200,17 @@ int rsdsfm_set_profiling(rsdsfm_ctx* ctx, int on) {
 
 int rsdsfm_profile_last_ms(rsdsfm_ctx* ctx, const char* what, double* ms) {
     CTX_OR_FAIL(ctx);
-    if (what && ms && !strncmp(what, "refine_rf_phase", 15) && what[15] >= '0' && what[15] <= '7' && !what[16]) {
+    if (what && ms && !strncmp(what, "refine_rf_phase", 15) && ((what[15] >= '0' && what[15] <= '9') || (what[15] >= 'a' && what[15] <= 'f')) && !what[16]) {
         // opt-in phase stamps of the radius-factorised refinement's pass (environment RSDSFM_RF_STAMPS=1): microseconds workgroup 0 spent in
         // 0 the state load, 1 the stage in its prologue, 2 the loop over its inliers, 3 the row reduction, summed over the passes since the
         // last read of record 4 = the number of passes (reading it zeroes all five)
-        static unsigned long long h[8];
+        static unsigned long long h[16];
         if (what[15] == '0') {  // (record 0 reads -- and zeroes -- all of them; 1 .. 7 return what that read found; 5 .. 7 split the stage: rows reduced, decided, solved)
             int rc = refine_rf_read_stamps(c, h);
             if (rc != RSDSFM_OK) return fail(c, RSDSFM_ERR_INVALID, "no phase stamps: set RSDSFM_RF_STAMPS=1 before the first refinement");
         }
-        const int k = what[15] - '0';
-        *ms = k == 4 ? (double)h[4] : (double)h[k] * 0.01;
+        const int k = what[15] <= '9' ? what[15] - '0' : what[15] - 'a' + 10;
+        *ms = k == 4 ? (double)h[4] : k >= 8 ? (double)(long long)(h[k] - h[8]) * 0.01 : (double)h[k] * 0.01;  // (8 .. f: when wave k - 8 left its loop, relative to wave 0)
         return RSDSFM_OK;
     }
     const bool clock = what && !strcmp(what, "ransac_lm_round0_clock_mhz");

@@ -132,6 +132,70 @@ __device__ __forceinline__ void wave_reduce_to_row(const double (&v)[NV], int ma
     }
 }
 
+// Wave reduction of the first N (<= NV) per-lane values by HALVING: at step s (partner = lane ^ (1 << s)) a lane keeps one half of the values
+// it still holds and hands the other half to its partner, which keeps exactly that half -- N / 2 + N / 4 + ... ~ N exchanged doubles per lane
+// where a butterfly per value moves 6 N, and no LDS until every lane is down to ceil(N / 64) values (wave_reduce_to_row above pushes every
+// value of every lane through LDS twice: ~3 us for the 60 sums of a refinement pass, the LDS pipe being the limit).  Lane l ends with the wave
+// sums of the logical indices [offset, offset + count) it returns; the combination tree is fixed (deterministic), another one than
+// wave_reduce_to_row's.  Steps 0 / 1 exchange within quads (DPP), the others through ds_bpermute.
+template <int S>
+__device__ __forceinline__ double halving_exchange(double x) {
+    if (S == 0) return dpp_move<0xb1, 0xf>(x);  // quad_perm:[1,0,3,2]
+    if (S == 1) return dpp_move<0x4e, 0xf>(x);  // quad_perm:[2,3,0,1]
+    return __shfl_xor(x, 1 << S, 64);
+}
+template <int NV, int N, int S>
+struct HalvingStep {
+    __device__ static __forceinline__ void run(double (&v)[NV], int lane, int& offset, int& count) {
+        constexpr int H = (N + 1) / 2;
+        const bool bit = (lane >> S) & 1;
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const double lo = v[j];
+            const double hi = (H + j < N) ? v[H + j] : 0.0;
+            const double send = bit ? lo : hi, keep = bit ? hi : lo;
+            v[j] = keep + halving_exchange<S>(send);
+        }
+        offset += bit ? H : 0;
+        count = bit ? count - min(count, H) : min(count, H);
+        HalvingStep<NV, H, S + 1>::run(v, lane, offset, count);
+    }
+};
+template <int NV, int N>
+struct HalvingStep<NV, N, 6> {
+    __device__ static __forceinline__ void run(double (&)[NV], int, int&, int&) {}
+};
+__host__ __device__ constexpr int halving_final(int n) {  // values a lane still holds after the six steps
+    for (int s = 0; s < 6; ++s) n = (n + 1) / 2;
+    return n;
+}
+// reduces v[0 .. N) over the wave; afterwards v[j], j < count, is the wave sum of logical index offset + j (count <= halving_final(N))
+template <int NV, int N>
+__device__ __forceinline__ void wave_reduce_halving(double (&v)[NV], int& offset, int& count) {
+    offset = 0, count = N;
+    HalvingStep<NV, N, 0>::run(v, (int)(threadIdx.x & 63), offset, count);
+}
+// workgroup reduction on top of it: sums of v[0 .. NV - 1) and the maximum of v[NV - 1] (the rows of refine_rf_kernels.hip keep their one
+// max slot last) -> out_row[NV]
+template <int NV>
+__device__ __forceinline__ void block_reduce_store_halving(double (&v)[NV], double (*s_red)[NV], double* __restrict__ out_row) {
+    const int tid = threadIdx.x, wv = tid >> 6;
+    const double mx = wave_max(v[NV - 1]);
+    int offset, count;
+    wave_reduce_halving<NV, NV - 1>(v, offset, count);
+    constexpr int NF = halving_final(NV - 1);
+#pragma unroll
+    for (int j = 0; j < NF; ++j)
+        if (j < count) s_red[wv][offset + j] = v[j];
+    if ((tid & 63) == 0) s_red[wv][NV - 1] = mx;
+    __syncthreads();
+    if (tid < NV) {
+        double r = s_red[0][tid];
+        for (int w2 = 1; w2 < kFB / 64; ++w2) r = (tid == NV - 1) ? fmax(r, s_red[w2][tid]) : r + s_red[w2][tid];
+        out_row[tid] = r;
+    }
+}
+
 // generic fixed-order workgroup reduction of NV per-thread values; kinds: slot s is a max slot iff s == max_slot
 template <int NV>
 __device__ __forceinline__ void block_reduce_store(const double (&v)[NV], int max_slot, double (*s_red)[NV],

@@ -230,9 +230,41 @@ struct RfStageLds {
     double list[kRfListCap * kRfEntry];     // its listed inliers, sorted by (rank, index)
     double fe[kRfListCap][RR::NF];          // their terms at the radius in question
     double F[RR::NF];
-    int nlist, action, loop;
+    int nlist, action, loop, bad;
     double radius;
 };
+
+// Fixed-order reduction of rows[nrows][stride] (the first NW doubles of each; the LAST one a maximum of absolute values, the others sums) into
+// group sums grp[G][NW]: thread (group g, slot pair sp) adds the rows g, g + G, g + 2 G, ... of its two slots in order, 16 loads in flight
+// (reduce_partials_groups' scheme with the one max slot in a fixed place: no per-element select); reduce_partials_slots finishes it.
+template <int NW>
+__device__ __forceinline__ void rf_reduce_rows_groups(const double* __restrict__ rows, int nrows, int stride, double (*grp)[NW], int tid) {
+    constexpr int NH = NW / 2, G = kFB / NH, U = 16;
+    static_assert(G == ReduceShape<NW>::G, "grp is sized by ReduceShape");
+    const int g = tid / NH, sp = tid - g * NH;
+    if (g < G) {
+        const bool last = sp == NH - 1;
+        double a0 = 0.0, a1 = 0.0, m1 = 0.0;
+        const double2* __restrict__ base = reinterpret_cast<const double2*>(rows) + sp;
+        const int stride2 = stride / 2;
+        for (int b = g; b < nrows; b += U * G) {
+            double2 x[U];
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                const int bj = b + j * G;
+                x[j] = bj < nrows ? base[(uint32_t)bj * (uint32_t)stride2] : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int j = 0; j < U; ++j) {
+                a0 += x[j].x;
+                a1 += x[j].y;
+                m1 = fmax(m1, x[j].y);
+            }
+        }
+        grp[g][2 * sp] = a0;
+        grp[g][2 * sp + 1] = last ? m1 : a1;
+    }
+}
 
 // one listed inlier's exact terms of B and c at (P, R)
 template <int NP>
@@ -304,12 +336,12 @@ __device__ __forceinline__ int rf_solve(RefineState* st, const double* cur, cons
             double d = sjj;
 #pragma unroll
             for (int t = 0; t < j; ++t) d = __builtin_fma(-S[j][t], S[j][t], d);
-            if (!(fabs(d) > kBandPivot * fabs(sjj))) {
-                status = -1;  // (NaN lands here too)
+            if (!(fabs(d) > kBandPivot * fabs(sjj)) || !(fabs(d) > 1e-200 && fabs(d) < 1e200)) {
+                status = -1;  // (NaN lands here too; and a pivot outside the range of the function cores below)
             } else if (d < 0.0) {
                 status = 0;
             } else {
-                const double id = 1.0 / sqrt(d);
+                const double id = rcp_core(sqrt_core(d));  // = 1.0 / sqrt(d), correctly rounded twice (device_math.hpp)
                 inv_d[j] = id;
 #pragma unroll
                 for (int i = j + 1; i < NP; ++i) {
@@ -366,8 +398,9 @@ __device__ __forceinline__ void rf_apply_body(RefineState* st, RfStageLds<NP>& L
                               unsigned long long* tks = nullptr) {
     using RR = RfRow<NP>;
     const int tid = threadIdx.x;
-    // the reduced row (reduce_partials' order: the same for workgroup partials and for gathered rank rows)
-    reduce_partials_groups<RR::NW>(rows, nrows, RR::GMAX, L.grp, tid, row_stride, 0);
+    // the reduced row (the same order for workgroup partials and for gathered rank rows)
+    if (tid == 0) L.bad = 0;
+    rf_reduce_rows_groups<RR::NW>(rows, nrows, row_stride, L.grp, tid);
     // the lists' counts beside it
     int ntot = 0;
     bool overflow = false;
@@ -379,6 +412,7 @@ __device__ __forceinline__ void rf_apply_body(RefineState* st, RfStageLds<NP>& L
     overflow = overflow || ntot > kRfListCap;
     __syncthreads();
     reduce_partials_slots<RR::NW>(L.grp, RR::GMAX, L.s, tid);
+    if (tid < RR::NW && !(fabs(L.s[tid]) < 1e300)) L.bad = 1;  // (a non-finite sum, NaN included: every thread looks at the slot it has just written)
     __syncthreads();
     if (tks) tks[0] = wall_clock64();
     const bool first = st->iteration == 0 && st->num_unsuccessful == 0 && st->slots == 0;
@@ -388,9 +422,7 @@ __device__ __forceinline__ void rf_apply_body(RefineState* st, RfStageLds<NP>& L
         int action = 0;  // 0: the current point stays (rejected / invalid), 1: the pass's point becomes the current one, 2: over
         st->slots += 1;
         double* tr = (trace && st->iteration >= 1 && st->iteration <= trace_rows) ? trace + (int64_t)(st->iteration - 1) * kRefineTraceCols : nullptr;
-        bool finite = true;
-#pragma unroll
-        for (int c = 0; c < RR::NW; ++c) finite = finite && (fabs(s[c]) < 1e300);
+        const bool finite = L.bad == 0;
         if (!finite || overflow) {
             rf_restart(st, overflow ? kRfGuardList : kRfGuardNonFinite);
             action = 2;
@@ -725,13 +757,8 @@ __global__ __launch_bounds__(kFB) void refine_rf_pass_kernel(const RfPassArgs A)
         const double psi = uniform_d(1.0 / (1.0 + 1.0 / st->radius));
         const double* __restrict__ rho = st->cur ? A.rho_b : A.rho_a;
         double* __restrict__ cand = st->cur ? A.rho_a : A.rho_b;
-        // two inliers' loads in flight beyond the one in the arithmetic (two waves per SIMD: the latency is covered here, not by occupancy)
-        const int64_t last = m - 1;
-        RfLoad l0 = rf_load<NP>(A, rho, i0, i0 <= last);
-        RfLoad l1 = rf_load<NP>(A, rho, i0 + stride, i0 + stride <= last);
-        for (int64_t i = i0; i < m; i += stride) {
-            const int64_t i2 = i + 2 * stride;
-            const RfLoad l2 = rf_load<NP>(A, rho, i2, i2 <= last);
+        // one inlier: back-substitution at the current point, then everything at the candidate
+        auto body = [&](const RfLoad& l0, int64_t i) {
             const double x = l0.c4.x, y = l0.c4.y, ux = l0.c4.z, uy = l0.c4.w, rh = l0.rho;
             const RfGeom g = rf_geom(x, y);
             double be, dbe, bec, dbec, be0, dbe0;
@@ -757,10 +784,13 @@ __global__ __launch_bounds__(kFB) void refine_rf_pass_kernel(const RfPassArgs A)
             const bool flagged = rf_flagged(o.h, h0);
             // back-substitution: d rho = -ete_inv E^T (r + t) s = -psi J^T (r + t) / |J|^2 while the clamp is inactive
             double drho = -((psi * (gJ + tJ)) * rcp_core(flagged ? 1.0 : o.h));
-            if (flagged) {
-                double sr, E0, E1;
-                const double ete_inv = rf_ete_inv_exact(o.J0, o.J1, h0, inv_radius, sr, E0, E1);
-                drho = -((ete_inv * (sr * (gJ + tJ))) * sr);
+            if (__builtin_amdgcn_ballot_w64(flagged) != 0) {  // (a wave-uniform branch: left as straight-line code the compiler turns the exact form -- two divisions, a square root -- into selects every inlier pays for)
+                if (flagged) {
+                    asm volatile("; listed inlier: exact e-block inverse" ::: "memory");  // (keeps the branch a branch)
+                    double sr, E0, E1;
+                    const double ete_inv = rf_ete_inv_exact(o.J0, o.J1, h0, inv_radius, sr, E0, E1);
+                    drho = -((ete_inv * (sr * (gJ + tJ))) * sr);
+                }
             }
             const double m0 = __builtin_fma(o.J0, drho, t0), m1 = __builtin_fma(o.J1, drho, t1);
             acc[RR::MODEL] -= __builtin_fma(m0, __builtin_fma(0.5, m0, o.r0), m1 * __builtin_fma(0.5, m1, o.r1));
@@ -779,12 +809,26 @@ __global__ __launch_bounds__(kFB) void refine_rf_pass_kernel(const RfPassArgs A)
             const double ihm = flagged_c ? 0.0 : rcp_core(flagged_c ? 1.0 : oc.h);
             rf_schur_accumulate<NP>(oc, ihm, acc);
             if (flagged_c) rf_list_append(A.list_count, A.list_entries, x, y, ux, uy, l0.ab, l0.ak, cd, i);
+        };
+        // Two inliers' loads in flight beyond the one in the arithmetic: two waves per SIMD, so the latency is covered here and not by occupancy.
+        // (Measured and dropped: three register sets taking turns instead of the two copies per iteration -- the third set spills, 10.4 instead
+        // of 8.3 us per loop of the older wave; the first two sets requested ahead of the stage -- vmcnt counts in order, so the stage's own
+        // row loads then wait for them: stage + 1.4 us, loop - 1.4 us.)
+        const int64_t last = m - 1;
+        RfLoad l0 = rf_load<NP>(A, rho, i0, i0 <= last);
+        RfLoad l1 = rf_load<NP>(A, rho, i0 + stride, i0 + stride <= last);
+        for (int64_t i = i0; i < m; i += stride) {
+            const int64_t i2 = i + 2 * stride;
+            const RfLoad l2 = rf_load<NP>(A, rho, i2, i2 <= last);
+            body(l0, i);
             l0 = l1;
             l1 = l2;
         }
     }
     if (stamp) tk[3] = wall_clock64();
-    block_reduce_store<RR::NW>(acc, RR::GMAX, s_red, A.partials + (int64_t)blockIdx.x * RR::NW);
+    if (A.stamps && blockIdx.x == 0 && (threadIdx.x & 63) == 0) A.stamps[8 + (threadIdx.x >> 6)] += wall_clock64();  // (per wave: when its loop ended; sums over passes)
+    static_assert(RR::GMAX == RR::NW - 1, "the max slot is the row's last");
+    block_reduce_store_halving<RR::NW>(acc, s_red, A.partials + (int64_t)blockIdx.x * RR::NW);
     if (stamp) {
         tk[4] = wall_clock64();
         A.stamps[0] += tk[1] - tk[0], A.stamps[1] += tk[2] - tk[1], A.stamps[2] += tk[3] - tk[2], A.stamps[3] += tk[4] - tk[3], A.stamps[4] += 1;
@@ -906,7 +950,7 @@ unsigned long long* rf_stamps(Ctx* c) {
     if (on < 0) {
         const char* e = getenv("RSDSFM_RF_STAMPS");
         on = (e && e[0] == '1') ? 1 : 0;
-        if (on && (hipMalloc(&buf, 64) != hipSuccess || hipMemset(buf, 0, 64) != hipSuccess)) buf = nullptr;
+        if (on && (hipMalloc(&buf, 128) != hipSuccess || hipMemset(buf, 0, 128) != hipSuccess)) buf = nullptr;
     }
     (void)c;
     return buf;
@@ -1009,12 +1053,12 @@ int refine_rf_row_launch(Ctx* c, const RefineBuffers& B, int np, int g, double* 
 }
 
 // the accumulated phase stamps {state load, stage, publish + loop, row reduction, passes} in 100 MHz ticks; zeroes them (profiling tools only)
-int refine_rf_read_stamps(Ctx* c, unsigned long long out[8]) {
+int refine_rf_read_stamps(Ctx* c, unsigned long long out[16]) {
     unsigned long long* b = rf_stamps(c);
     if (!b) return RSDSFM_ERR_INVALID;
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-    RSDSFM_HIP_CHECK(c, hipMemcpy(out, b, 64, hipMemcpyDeviceToHost));
-    RSDSFM_HIP_CHECK(c, hipMemset(b, 0, 64));
+    RSDSFM_HIP_CHECK(c, hipMemcpy(out, b, 128, hipMemcpyDeviceToHost));
+    RSDSFM_HIP_CHECK(c, hipMemset(b, 0, 128));
     return RSDSFM_OK;
 }
 

@@ -568,7 +568,7 @@ int refine_rf_apply_launch(Ctx* c, const RefineBuffers& B, int np, int g, bool t
                            const int64_t* m_total_dev);
 int refine_rf_row_launch(Ctx* c, const RefineBuffers& B, int np, int g, double* row);
 int refine_rf_row_doubles(int np);
-int refine_rf_read_stamps(Ctx* c, unsigned long long out[8]);
+int refine_rf_read_stamps(Ctx* c, unsigned long long out[16]);
 int refine_rf_extra_doubles();
 int refine_partials_half_doubles(const Ctx* c);
 int refine_state_doubles();

@@ -93,7 +93,7 @@ typedef struct rsdsfm_ransac_out {
     uint8_t* mask;       /* [n]                                                                  */
     double* inv_depth;   /* [n]  dense rho of the best trial                                     */
     int64_t* trial_count; /* [T] HOST, or NULL                                                   */
-    double* trial_err;    /* [T] HOST, or NULL                                                   */
+    double* trial_err;    /* [T] HOST, or NULL.  trial_err / inlier_error are DIAGNOSTICS: in mode 0 (rsdsfm_set_lm_arithmetic) a trial that ends at a fused iterate gets the closed form's sum, another one the exact scoring pass's, and a context that met a tie stays on the iterate-by-iterate kernels for 16 runs -- the sums agree to ~1e-13 relative between the forms, the integers and the winner's depths are identical */
     double* trial_vel;    /* [7T] HOST (w, v, k), or NULL                                        */
     int32_t* trial_steps; /* [T] HOST accepted LM steps of each trial's depth solve, or NULL      */
 } rsdsfm_ransac_out;
@@ -106,8 +106,10 @@ int rsdsfm_create(rsdsfm_ctx** ctx, int device, void* stream_or_null);
 void rsdsfm_destroy(rsdsfm_ctx* ctx);
 const char* rsdsfm_last_error(const rsdsfm_ctx* ctx);
 const char* rsdsfm_version(void);
-/* 0: this library evaluates the per-pixel model with the REFERENCE's arithmetic (librsdsfm_hip.so: no fused multiply-add, as
- * the reference's own x86-64 build, src/CMakeLists.txt:18); 1: the opt-in librsdsfm_hip_fused.so (explicit fmas in the
+/* Which build is loaded.  0: librsdsfm_hip.so -- its ITERATE-BY-ITERATE kernels (rsdsfm_set_lm_arithmetic(1), and what a guard of the
+ * default path falls back to) evaluate the per-pixel model with the REFERENCE's arithmetic (no fused multiply-add, as the reference's own
+ * x86-64 build, src/CMakeLists.txt:18); the DEFAULT path (analytic LM trajectory, radius-factorised refinement) is the library's own
+ * arithmetic with fused multiply-adds in both builds, see rsdsfm_set_lm_arithmetic.  1: the opt-in librsdsfm_hip_fused.so (explicit fmas in the
  * residual / LM step / scoring error / scanline projection: faster, values agree to ~1e-12 relative) */
 int rsdsfm_fused_arithmetic(void);
 int rsdsfm_synchronize(rsdsfm_ctx* ctx);
@@ -165,6 +167,10 @@ int rsdsfm_lma_restarts(rsdsfm_ctx* ctx, int64_t* count, int32_t* last_guards_or
  * sent back, (optional) the reduced systems solved again from stored sums, and the guard that tripped last (1 non-finite sum, 2 gradient /
  * 3 model change / 4 parameter / 5 function tolerance inside its band, 6 step quality, 7 pivot, 8 list overflow, 9 minimum radius). */
 int rsdsfm_refine_restarts(rsdsfm_ctx* ctx, int64_t* runs, int64_t* restarts, int64_t* resolves_or_null, int32_t* last_guard_or_null);
+/* The refinement's arithmetic on its own: 0 (default) = what rsdsfm_set_lm_arithmetic selects (radius-factorised in mode 0), 1 = the
+ * iterate-by-iterate slot kernels whatever that mode is -- e.g. to compare the forms of the RANSAC's depth solves bit for bit behind one and the
+ * same refinement.  The same on every rank of a tiled solve. */
+int rsdsfm_set_refine_arithmetic(rsdsfm_ctx* ctx, int mode);
 /* how many RANSACs of this context (and its sequence lanes) ran the count-only form of the pass, and how many of those had to fetch error sums */
 int rsdsfm_lma_count_only(rsdsfm_ctx* ctx, int64_t* runs, int64_t* lazy_runs_or_null);
 /* The dense depth solve (rsdsfm_estimate_inverse_depths*, LM mode) takes the same in-range cores in launch 0 (Jacobi scaling) under the same
@@ -225,6 +231,19 @@ int rsdsfm_refine(rsdsfm_ctx* ctx, const double* flow2n, int64_t n_flow, int64_t
                   const double v_in[3], const double w_in[3], double k_in, int const_acceleration,
                   int flow_index_mode, double* inliers_out_3m, double v_out[3], double w_out[3], double* k_out,
                   rsdsfm_lm_summary* summary_or_null);
+/* The reference hands nonLinearRefinement the RansacValues -- and the flow -- that minimal::ransac has just seen (main.cc:447-457,
+ * errorMeasure.cpp:140-152).  rsdsfm_ransac leaves exactly those arrays on the device; rsdsfm_last_ransac_tag names them (0: nothing usable),
+ * and rsdsfm_refine_from_ransac = rsdsfm_refine that starts from them instead of uploading ~52 MB per 1280x720 pair again -- provided the tag is
+ * the context's last RANSAC's, no other host-pointer call of the context came in between, the sizes match and 16 probed entries of the arrays
+ * passed here still hold what was transferred then; otherwise it uploads, like rsdsfm_refine.  CONTRACT: arrays passed with a non-zero tag are
+ * the unmodified outputs of that rsdsfm_ransac (the probes catch a rebuilt array, not a single edited entry); pass tag 0 after editing them.
+ * `flow` is reused too when it is the very array (address and length) the RANSAC was given as u.  The C++ mirror (host/minimal.h,
+ * host/nonlinearRefinement.h) carries the tag in RansacValues.  cache_hits: refinements of this context that started from resident arrays. */
+int rsdsfm_last_ransac_tag(rsdsfm_ctx* ctx, uint64_t* tag, int64_t* cache_hits_or_null);
+int rsdsfm_refine_from_ransac(rsdsfm_ctx* ctx, uint64_t ransac_tag, const double* flow2n, int64_t n_flow, int64_t m, const double* inliers_3m,
+                              const double* alpha_m, const double* alpha_k_m, const int64_t* inlier_idx_or_null, const double v_in[3],
+                              const double w_in[3], double k_in, int const_acceleration, int flow_index_mode, double* inliers_out_3m,
+                              double v_out[3], double w_out[3], double* k_out, rsdsfm_lm_summary* summary_or_null);
 /* Trace of the joint refinement's trust-region iterations (the counterpart of Ceres' per-iteration log,
  * `Solver::Summary::iterations` behind nonlinearRefinement.cc:228-230 `FullReport()`; diagnostic, off by default).
  * rsdsfm_set_refine_trace(ctx, rows): rows > 0 makes every following refinement on this context (rsdsfm_refine*, the frame

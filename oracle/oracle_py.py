@@ -438,7 +438,7 @@ def refine(flow, inliers, alpha, alpha_k, v, w, k, const_acceleration=False, flo
         raise RuntimeError("rso_refine failed rc=%d" % rc)
     res = dict(inliers=out, v=np.array(vo[:]), w=np.array(wo[:]), k=ko.value, summary=sm.as_dict())
     if mode == 2:
-        res["guard"], res["resolves"] = guard.value, resolves.value
+        res["guard"], res["resolves"], res["listed_max"] = guard.value, resolves.value, int(L.rso_refine_rf_listed_max())
     if trace is not None:
         res["trace"] = trace
     return res

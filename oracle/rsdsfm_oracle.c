@@ -1331,7 +1331,7 @@ int rso_lma_trial(const double* q, const double* u, const double* alpha, const d
     for (int64_t i = 0; i < n; ++i) {
         const lma_px* p = &px[i];
         const int near = scoring && !p->clamped && lma_near(p, tol2, c1, phi2);
-        double rho = fma(p->e0, phi, p->rhos);
+        double rho = nh == 0 ? 1.0 : fma(p->e0, phi, p->rhos); /* (no accepted step: the start value untouched, exactly; depth_lma_rho) */
         int in = 0;
         double err = 0.0;
         if (p->clamped || near || study) {
@@ -2042,6 +2042,9 @@ static int rf_solve(int np, const rf_sums* S, const int64_t* list, int nlist, co
     return 1;
 }
 
+static int g_rf_listed_max = 0; /* test diagnostics: the longest list of clamped inliers the last rso_refine_rf met */
+int rso_refine_rf_listed_max(void) { return g_rf_listed_max; }
+
 int rso_refine_rf(const double* flow, int64_t n_flow, int64_t m, const double* inl, const double* alpha, const double* alpha_k,
                   const int64_t* inlier_idx, const double v_in[3], const double w_in[3], double k_in, int const_acceleration,
                   int flow_index_mode, double* inl_out, double v_out[3], double w_out[3], double* k_out, rso_lm_summary* summary,
@@ -2091,6 +2094,7 @@ int rso_refine_rf(const double* flow, int64_t n_flow, int64_t m, const double* i
             ++ncur;
         }
     }
+    g_rf_listed_max = ncur;
     double cost = 0.5 * cost2, x_norm, radius = CERES_INITIAL_RADIUS, decrease_factor = 2.0, stepsq_p = 0.0;
     int iteration = 0, invalid = 0;
     sm.termination = -1;
@@ -2202,6 +2206,7 @@ int rso_refine_rf(const double* flow, int64_t n_flow, int64_t m, const double* i
                 ++ncand;
             }
         }
+        if (ncand > g_rf_listed_max) g_rf_listed_max = ncand;
         /* the decision (rf_apply_body) */
         double* tr = refine_trace_row(iteration);
         if (tr) tr[0] = (double)iteration, tr[1] = cost, tr[3] = model, tr[5] = radius;

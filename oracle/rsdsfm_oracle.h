@@ -148,6 +148,7 @@ int rso_refine_rf(const double* flow2n, int64_t n_flow, int64_t m, const double*
                   const int64_t* inlier_idx_or_null, const double v_in[3], const double w_in[3], double k_in, int const_acceleration,
                   int flow_index_mode, double* inliers_out_3m, double v_out[3], double w_out[3], double* k_out, rso_lm_summary* summary,
                   int32_t* guard_out, int32_t* resolves_out);
+int rso_refine_rf_listed_max(void); /* test diagnostics: the longest list of clamped inliers the last rso_refine_rf met */
 
 /* main.cc:398-444 / errorMeasure.cpp:66-111 (shrinking variant).  flow image row-major rows x cols x 2.
  * returns the number of kept points. */

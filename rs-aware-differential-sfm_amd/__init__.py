@@ -264,6 +264,10 @@ class Solver:
         (rsdsfm_set_lm_arithmetic); integer outputs never depend on it"""
         self._check(self.lib.rsdsfm_set_lm_arithmetic(self._ctx, int(mode)), "rsdsfm_set_lm_arithmetic")
 
+    def set_refine_arithmetic(self, mode):
+        """the joint refinement's arithmetic on its own: 0 (default) = radius-factorised while set_lm_arithmetic is 0, 1 = iterate by iterate"""
+        self._check(self.lib.rsdsfm_set_refine_arithmetic(self._ctx, int(mode)), "rsdsfm_set_refine_arithmetic")
+
     def refine_restarts(self):
         """(refinements on the radius-factorised path, those a guard sent back to the iterate-by-iterate kernels, reduced systems solved
         again from stored sums, the guard that tripped last) -- rsdsfm_refine_restarts"""
@@ -322,24 +326,37 @@ class Solver:
         self._check(self.lib.rsdsfm_calculate_velocities(self._ctx, _p(q), _p(u), _p(alpha), _p(alpha_k), C.c_int32(T), int(use_alpha_k), int(k_sign_mode), _p(w), _p(v), _p(k)), "rsdsfm_calculate_velocities")
         return (w[0], v[0], float(k[0])) if single else (w, v, k)
 
-    def ransac(self, q, u, alpha, alpha_k, use_alpha_k, iterations, tolerance, samples=None, seed=0, depth_mode=DEPTH_CERES_LM, k_sign_mode=K_COMPAT):
+    def ransac(self, q, u, alpha, alpha_k, use_alpha_k, iterations, tolerance, samples=None, seed=0, depth_mode=DEPTH_CERES_LM, k_sign_mode=K_COMPAT, outputs=None):
+        """outputs: None = fresh arrays, copies returned; a dict (empty at first) = caller-owned output arrays kept in it and REUSED by the
+        next call with the same dict -- the returned arrays are then views into them (what a caller that streams frames does: no page faults
+        of fresh arrays, no copies, inside the call)"""
         q, u, alpha, alpha_k = _f64(q), _f64(u), _f64(alpha), _f64(alpha_k)
         n, T = q.shape[0], int(iterations)
         smp = None if samples is None else np.ascontiguousarray(samples, dtype=np.int32).reshape(-1)
-        bufs = dict(
-            inlier_idx=np.zeros(n, dtype=np.int64), inliers=np.zeros((n, 3)), alpha=np.zeros(n), alpha_k=np.zeros(n),
-            mask=np.zeros(n, dtype=np.uint8), inv_depth=np.zeros(n), trial_count=np.zeros(max(T, 1), dtype=np.int64),
-            trial_err=np.zeros(max(T, 1)), trial_vel=np.zeros((max(T, 1), 7)), trial_steps=np.zeros(max(T, 1), dtype=np.int32),
-        )
+        reuse = outputs is not None
+        if reuse and outputs.get("_shape") == (n, T):
+            bufs = outputs["_bufs"]
+        else:
+            bufs = dict(
+                inlier_idx=np.zeros(n, dtype=np.int64), inliers=np.zeros((n, 3)), alpha=np.zeros(n), alpha_k=np.zeros(n),
+                mask=np.zeros(n, dtype=np.uint8), inv_depth=np.zeros(n), trial_count=np.zeros(max(T, 1), dtype=np.int64),
+                trial_err=np.zeros(max(T, 1)), trial_vel=np.zeros((max(T, 1), 7)), trial_steps=np.zeros(max(T, 1), dtype=np.int32),
+            )
+            if reuse:
+                outputs["_shape"], outputs["_bufs"] = (n, T), bufs
         out = RansacOut()
         for name, arr in bufs.items():
             setattr(out, name, arr.ctypes.data)
         self._check(self.lib.rsdsfm_ransac(self._ctx, _p(q), _p(u), _p(alpha), _p(alpha_k), C.c_int64(n), int(use_alpha_k), C.c_int32(T), C.c_double(tolerance), _p(smp), C.c_uint64(seed), int(depth_mode), int(k_sign_mode), C.byref(out)), "rsdsfm_ransac")
         m = int(out.num_inliers)
+        tag, hits = C.c_uint64(0), C.c_int64(0)
+        self._check(self.lib.rsdsfm_last_ransac_tag(self._ctx, C.byref(tag), C.byref(hits)), "rsdsfm_last_ransac_tag")
         return dict(
+            tag=int(tag.value),  # names the device-resident copy of this result: non_linear_refinement(..., tag=...) starts from it
             num_inliers=m, best_trial=int(out.best_trial), w=np.array(out.w[:]), v=np.array(out.v[:]), k=float(out.k),
-            inlier_error=float(out.inlier_error), inlier_idx=bufs["inlier_idx"][:m].copy(), inliers=bufs["inliers"][:m].copy(),
-            alpha=bufs["alpha"][:m].copy(), alpha_k=bufs["alpha_k"][:m].copy(), mask=bufs["mask"], inv_depth=bufs["inv_depth"],
+            inlier_error=float(out.inlier_error), inlier_idx=bufs["inlier_idx"][:m] if reuse else bufs["inlier_idx"][:m].copy(),
+            inliers=bufs["inliers"][:m] if reuse else bufs["inliers"][:m].copy(), alpha=bufs["alpha"][:m] if reuse else bufs["alpha"][:m].copy(),
+            alpha_k=bufs["alpha_k"][:m] if reuse else bufs["alpha_k"][:m].copy(), mask=bufs["mask"], inv_depth=bufs["inv_depth"],
             trial_count=bufs["trial_count"][:T], trial_err=bufs["trial_err"][:T], trial_vel=bufs["trial_vel"][:T],
             trial_steps=bufs["trial_steps"][:T],
         )
@@ -358,14 +375,26 @@ class Solver:
         rho, _ = self.estimate_inverse_depths(np.asarray(q).reshape(1, 2), np.asarray(flow).reshape(1, 2), v, w, k, [alpha], [alpha_k], mode)
         return float(rho[0])
 
-    def non_linear_refinement(self, flow, inliers, alpha, alpha_k, v, w, k, const_acceleration=False, flow_index_mode=FLOW_COMPAT_RANK, inlier_idx=None):
+    def refine_cache_hits(self):
+        """refinements of this context that started from the device-resident outputs of a RANSAC (rsdsfm_refine_from_ransac)"""
+        tag, hits = C.c_uint64(0), C.c_int64(0)
+        self._check(self.lib.rsdsfm_last_ransac_tag(self._ctx, C.byref(tag), C.byref(hits)), "rsdsfm_last_ransac_tag")
+        return int(hits.value)
+
+    def non_linear_refinement(self, flow, inliers, alpha, alpha_k, v, w, k, const_acceleration=False, flow_index_mode=FLOW_COMPAT_RANK, inlier_idx=None, tag=0, out=None):
+        """tag: `tag` of the ransac() result these arrays are the UNMODIFIED outputs of (0: upload everything) -- rsdsfm_refine_from_ransac;
+        out: a caller-owned (m, 3) array for the refined inliers (None: a fresh one)"""
         flow, inliers, alpha, alpha_k = _f64(flow), _f64(inliers), _f64(alpha), _f64(alpha_k)
         m = inliers.shape[0]
         idx = None if inlier_idx is None else np.ascontiguousarray(inlier_idx, dtype=np.int64)
-        out = np.empty((m, 3))
+        if out is None or out.shape != (m, 3) or out.dtype != np.float64 or not out.flags["C_CONTIGUOUS"]:
+            out = np.empty((m, 3))
         vo, wo, ko = (C.c_double * 3)(), (C.c_double * 3)(), C.c_double()
         sm = LmSummary()
-        self._check(self.lib.rsdsfm_refine(self._ctx, _p(flow), C.c_int64(flow.shape[0]), C.c_int64(m), _p(inliers), _p(alpha), _p(alpha_k), _p(idx), _v3(v), _v3(w), C.c_double(k), int(const_acceleration), int(flow_index_mode), _p(out), vo, wo, C.byref(ko), C.byref(sm)), "rsdsfm_refine")
+        if tag:
+            self._check(self.lib.rsdsfm_refine_from_ransac(self._ctx, C.c_uint64(int(tag)), _p(flow), C.c_int64(flow.shape[0]), C.c_int64(m), _p(inliers), _p(alpha), _p(alpha_k), _p(idx), _v3(v), _v3(w), C.c_double(k), int(const_acceleration), int(flow_index_mode), _p(out), vo, wo, C.byref(ko), C.byref(sm)), "rsdsfm_refine_from_ransac")
+        else:
+            self._check(self.lib.rsdsfm_refine(self._ctx, _p(flow), C.c_int64(flow.shape[0]), C.c_int64(m), _p(inliers), _p(alpha), _p(alpha_k), _p(idx), _v3(v), _v3(w), C.c_double(k), int(const_acceleration), int(flow_index_mode), _p(out), vo, wo, C.byref(ko), C.byref(sm)), "rsdsfm_refine")
         return dict(inliers=out, v=np.array(vo[:]), w=np.array(wo[:]), k=ko.value, summary=sm.as_dict())
 
     def set_refine_trace(self, rows):

@@ -1,7 +1,9 @@
 """Builds the HIP libraries (all kernels + the C ABI) for gfx950, in-tree.
 
-    librsdsfm_hip.so        the product: REFERENCE arithmetic (no fused multiply-add; csrc/device_math.hpp)
-    librsdsfm_hip_fused.so  opt-in: the same sources with -DRSDSFM_FUSED=1 (explicit fmas in the per-pixel model)
+    librsdsfm_hip.so        the product.  Default path: analytic LM trajectory (depth solves) + radius-factorised refinement, the library's own
+                            arithmetic with fused multiply-adds, guarded to the integers of the reference's arithmetic; the iterate-by-iterate
+                            kernels behind rsdsfm_set_lm_arithmetic(1) are the REFERENCE's arithmetic (no fused multiply-add; csrc/device_math.hpp)
+    librsdsfm_hip_fused.so  opt-in: the same sources with -DRSDSFM_FUSED=1 (explicit fmas also in the iterate-by-iterate per-pixel model)
 
 Every source is compiled to its own object (in parallel) and the objects are linked; only the translation units whose
 arithmetic depends on RSDSFM_FUSED are compiled a second time for the fused library.  Optional RCCL support of the

@@ -15,6 +15,7 @@ int fail(Ctx* c, int code, const char* msg) {
 }
 
 int ensure_stage(Ctx* c, size_t bytes) {
+    c->stage_gen += 1;  // (whoever calls this is about to overwrite the staging buffer: what rsdsfm_ransac left there is gone)
     if (bytes <= c->stage_bytes) return RSDSFM_OK;
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     if (c->d_stage) RSDSFM_HIP_CHECK(c, hipFree(c->d_stage));
@@ -83,8 +84,13 @@ extern "C" {
 #define RSDSFM_FUSED 0
 #endif
 const char* rsdsfm_version(void) {
-    return RSDSFM_FUSED ? "rsdsfm-mi355x 0.3.0 (gfx950, fp64, -ffp-contract=off, FUSED per-pixel model: explicit fmas)"
-                        : "rsdsfm-mi355x 0.3.0 (gfx950, fp64, -ffp-contract=off, reference arithmetic: no fused multiply-add)";
+    // (what the DEFAULT path computes with -- not what the build flag is called: since round 5 the depth solves walk the analytic LM trajectory,
+    // since round 6 the joint refinement runs on radius-factorised Schur sums, both with fused multiply-adds and both guarded to the integers
+    // of the reference's arithmetic, which rsdsfm_set_lm_arithmetic(1) selects operation for operation)
+    return RSDSFM_FUSED ? "rsdsfm-mi355x 0.4.0 (gfx950, fp64; analytic LM trajectory + radius-factorised refinement, guarded to the reference arithmetic's "
+                          "integers; rsdsfm_set_lm_arithmetic(1) = iterate by iterate with the FUSED per-pixel model: explicit fmas)"
+                        : "rsdsfm-mi355x 0.4.0 (gfx950, fp64; analytic LM trajectory + radius-factorised refinement with fused multiply-adds, guarded to the "
+                          "reference arithmetic's integers; rsdsfm_set_lm_arithmetic(1) = iterate by iterate in the reference's arithmetic: no fused multiply-add)";
 }
 int rsdsfm_fused_arithmetic(void) { return RSDSFM_FUSED; }
 
@@ -293,6 +299,7 @@ int rsdsfm_set_lm_arithmetic(rsdsfm_ctx* ctx, int mode) {
     c->lm_arithmetic = mode == 1 ? 1 : 0;
     c->lma_count_only_force = mode == 2;
     c->lma_hold = c->lma_unique_run = 0;
+    dist_reset_hold(c);
     for (rsdsfm_ctx* lane : c->lanes)
         lane->c.lm_arithmetic = c->lm_arithmetic, lane->c.lma_count_only_force = c->lma_count_only_force, lane->c.lma_hold = lane->c.lma_unique_run = 0;
     return RSDSFM_OK;
@@ -316,6 +323,14 @@ int rsdsfm_lma_restarts(rsdsfm_ctx* ctx, int64_t* count, int32_t* last_guards) {
     for (rsdsfm_ctx* lane : c->lanes) total += lane->c.lma_restarts, guards |= lane->c.lma_last_guard;
     *count = total;
     if (last_guards) *last_guards = guards;
+    return RSDSFM_OK;
+}
+
+int rsdsfm_set_refine_arithmetic(rsdsfm_ctx* ctx, int mode) {
+    CTX_OR_FAIL(ctx);
+    if (mode != 0 && mode != 1) return fail(c, RSDSFM_ERR_INVALID, "refine arithmetic: 0 = radius-factorised (default), 1 = iterate by iterate");
+    c->refine_arithmetic = mode;
+    for (rsdsfm_ctx* lane : c->lanes) lane->c.refine_arithmetic = mode;
     return RSDSFM_OK;
 }
 

@@ -64,6 +64,7 @@ __device__ __forceinline__ void depth_list_push(int* list, int parity, int64_t i
 // rho of a pixel at the iterate after `steps` accepted steps ON THE PLAN: the closed form, or for a clamped pixel the exact recurrence
 __device__ __forceinline__ double depth_lma_rho(double x, double y, double ux, double uy, double al, double ak, const Pose& pose, double two_over,
                                                 const LmaPlan& plan, int steps, double phi) {
+    if (steps == 0) return 1.0;  // (a solve without an accepted step leaves the start value untouched: exactly 1.0, whatever the pixel holds -- the reference's)
     const LmaPx v = lma_pixel(x, y, ux, uy, al, ak, pose, two_over);
     if (!v.clamped) return __builtin_fma(v.e0, phi, v.rhos);
     LmxWalk wk;

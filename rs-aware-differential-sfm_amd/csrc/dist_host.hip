@@ -115,7 +115,6 @@ Rccl* rccl() {
 // ---------------------------------------------------------------------------------------------------
 // per-context distributed state
 // ---------------------------------------------------------------------------------------------------
-constexpr double kLmaTieMarginD = 1e-11;  // = kLmaTie (lma_common.hpp, guard d)
 
 struct Dist {
     int nranks = 1, rank = 0;
@@ -174,8 +173,9 @@ int nccl_fail(Ctx* c, ncclResult_t r, const char* what) {
 int all_gather(Ctx* c, Dist* D, const void* d_send, void* d_recv, size_t bytes) {
     if (bytes == 0) return RSDSFM_OK;
     D->collectives += 1;
-    static const bool dbg = getenv("RSDSFM_TILED_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[rank %d] collective %d: all_gather %zu bytes\n", D->rank, D->collectives, bytes);
+#ifdef RSDSFM_DEBUG_HOOKS  // (debug builds only: -DRSDSFM_DEBUG_HOOKS)
+    if (getenv("RSDSFM_TILED_DEBUG")) fprintf(stderr, "[rank %d] collective %d: all_gather %zu bytes\n", D->rank, D->collectives, bytes);
+#endif
     if (D->ag) {
         if (D->ag(D->user, d_send, d_recv, bytes, c->stream) != 0) return fail(c, RSDSFM_ERR_HIP, "caller-provided all-gather failed");
         return RSDSFM_OK;
@@ -194,8 +194,9 @@ int all_gather(Ctx* c, Dist* D, const void* d_send, void* d_recv, size_t bytes) 
 int all_reduce_sum(Ctx* c, Dist* D, double* d_buf, size_t count) {
     if (count == 0) return RSDSFM_OK;
     D->collectives += 1;
-    static const bool dbg = getenv("RSDSFM_TILED_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "[rank %d] collective %d: all_reduce %zu doubles\n", D->rank, D->collectives, count);
+#ifdef RSDSFM_DEBUG_HOOKS
+    if (getenv("RSDSFM_TILED_DEBUG")) fprintf(stderr, "[rank %d] collective %d: all_reduce %zu doubles\n", D->rank, D->collectives, count);
+#endif
     if (D->ar) {
         if (D->ar(D->user, d_buf, count, c->stream) != 0) return fail(c, RSDSFM_ERR_HIP, "caller-provided all-reduce failed");
         return RSDSFM_OK;
@@ -296,6 +297,11 @@ __global__ __launch_bounds__(256) void rank_flow_gather_kernel(const double2* __
 }  // namespace
 
 namespace rsdsfm {
+// rsdsfm_set_lm_arithmetic: the communicator's hold on the iterate-by-iterate kernels starts over with the switch (like the context's own)
+void dist_reset_hold(Ctx* c) {
+    if (c->dist) static_cast<Dist*>(c->dist)->lma_hold = 0;
+}
+
 void dist_release(Ctx* c) {
     Dist* D = static_cast<Dist*>(c->dist);
     if (!D) return;
@@ -486,7 +492,7 @@ static int solve_frame_tiled_impl(rsdsfm_ctx* ctx, const double* d_img_slab, int
     int32_t* d_ys = fa.take<int32_t>(N1);
 
     // ---- small exchange buffers ----
-    const int row_max = std::max({nsr * batch + 2, ransac_lma_rows_doubles() * batch, refine_slot_row_doubles(np), refine_stage_row_doubles(np, 0), refine_stage_row_doubles(np, 1), refine_stage_row_doubles(np, 2), 2 * batch});
+    const int row_max = std::max({nsr * batch + 2, ransac_lma_rows_doubles() * batch, refine_slot_row_doubles(np), refine_rf_row_doubles(np), refine_stage_row_doubles(np, 0), refine_stage_row_doubles(np, 1), refine_stage_row_doubles(np, 2), 2 * batch});
     size_t need_d = 2 * Arena::need(8 * (size_t)R + 64) + Arena::need(8 * (size_t)R * Tn) + Arena::need(4 * 9 * (size_t)Tn) + Arena::need(8 * (54 * (size_t)Tn + (size_t)R + 8)) + Arena::need(8 * 8 * (size_t)Tn) +
                     Arena::need(sizeof(LmState) * Tn) + Arena::need(4 * (size_t)Tn) + Arena::need(64) + 2 * Arena::need(8 * (size_t)Tn) +
                     2 * Arena::need(sizeof(RansacBest)) + Arena::need(8 * (size_t)row_max) + Arena::need(8 * (size_t)row_max * R) + Arena::need(64) +
@@ -632,7 +638,7 @@ restart_cold:
     // ---- hypotheses: deterministic sampler on every rank, sampled points by one exact all-reduce, minimal solver replicated ----
     // the in-range function cores (device_math.hpp) in the minimal solver's SVD and in round 0 of the LM solves, as the single-context solve
     // runs them: one hypothesis batch, LM mode, the user's switch (rsdsfm_set_ransac_math: the same on every rank), no recent restart
-    bool core = T > 0 && T <= kRansacBatch && depth_mode == RSDSFM_DEPTH_CERES_LM && c->ransac_math_mode == 0 && D->standard_math == 0 && setup_rc == RSDSFM_OK;
+    bool core = T > 0 && T <= kRansacBatch && depth_mode == RSDSFM_DEPTH_CERES_LM && c->ransac_math_mode == 0 && D->standard_math == 0;  // (replicated knowledge only -- not this rank's setup status: what is exchanged, and how many bytes, must be the same on every rank)
     if (!core && D->standard_math > 0) D->standard_math -= 1;
     int* d_core_flags = d_flags + 8;  // (inside the zeroed block)
     int m9_epoch = 0;
@@ -648,7 +654,7 @@ restart_cold:
     }
     // the depth solves of the trials on the analytic LM trajectory (lma_common.hpp), as in the single-context solve: the user's switch
     // (rsdsfm_set_lm_arithmetic: the same on every rank) and the communicator's hold -- replicated knowledge, every rank decides alike
-    bool analytic = T > 0 && depth_mode == RSDSFM_DEPTH_CERES_LM && c->lm_arithmetic == 0 && D->lma_hold == 0 && setup_rc == RSDSFM_OK;
+    bool analytic = T > 0 && depth_mode == RSDSFM_DEPTH_CERES_LM && c->lm_arithmetic == 0 && D->lma_hold == 0;  // (replicated knowledge only, like `core`: a rank whose setup failed still issues the exchanges its peers issue, with the same byte counts, until the counts / status check sends everyone to restart_cold)
     const bool lma_may_return = depth_mode == RSDSFM_DEPTH_CERES_LM && c->lm_arithmetic == 0;  // (ties are reported: they renew the hold)
     bool lma_restarted = false, tie_seen = false, spec_refine_tried = false;
     const int lma_cand[2] = {2, 1};  // fused iterates: fixed, like kTiledFusedBase (every rank must fuse the same ones)
@@ -677,7 +683,7 @@ restart_ransac:
         // (spec: behind round 0, ahead of the host's read of the flag words -- the pick reads them itself and marks a RANSAC that is not over
         // `undecided`, so that the final stage and everything enqueued behind it on speculation leave at once)
         int rc2 = ransac_pick_launch(c, d_tcount, d_terr, T, d_hyp, d_best, nullptr, spec ? d_flags : nullptr, nullptr, spec && spec_scored ? 1 : 0, d_cnt_rt, T, R, d_m_all,
-                                     !lma_may_return ? 0.0 : (analytic ? kLmaTieMarginD : -kLmaTieMarginD));
+                                     !lma_may_return ? 0.0 : (analytic ? kLmaTie : -kLmaTie));
         if (rc2 != RSDSFM_OK) return rc2;
         // the compaction stores the SLAB's scan total into its record: every rank works on a copy of the (identical) winner record
         RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_best_shard, d_best, sizeof(RansacBest), hipMemcpyDeviceToDevice, c->stream));
@@ -727,6 +733,9 @@ restart_ransac:
     RefineBuffers RB;
     int launched = 0;
     bool depth_done = false, spec_refine = false, final_spec = false, q2_remote = false;
+    // the refinement on radius-factorised Schur sums (refine_rf_kernels.hip) unless the reference's arithmetic is asked for (the same switch on
+    // every rank); a guard of that path ends the solve with kTermRestartExact in the REPLICATED state: every rank runs it again iterate by iterate
+    bool refine_rf = c->lm_arithmetic == 0 && c->refine_arithmetic == 0;
     const int refine_hint = D->refine_iters_hint;
     // buffers of the refinement's session; dev: the slab's inlier count is device-resident (upper bound n), no remote flow column
     auto refine_layout = [&](bool dev) -> int {
@@ -802,13 +811,30 @@ restart_ransac:
     // collectives; the chunking changes when the host looks at the state, never what the kernels compute.
     // (slot j of a chunk: the pass, whose prologue is the replicated stage of slot j - 1 on the rows gathered then; the shard's row; the exchange)
     auto refine_chunk = [&](int chunk) -> int {
-        for (int j = 0; j < chunk; ++j) {
-            int rc2 = refine_slot_rows_launch(c, RB, np, d_row, j, d_rows_all, R);
-            if (rc2 != RSDSFM_OK) return rc2;
-            rc2 = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)refine_slot_row_doubles(np));
-            if (rc2 != RSDSFM_OK) return rc2;
+        int rc2 = RSDSFM_OK;
+        if (refine_rf) {
+            // (slot g = launched + j of the solve: its pass -- slot 0: iteration zero + the Schur sums of iteration 1 --, the shard's row
+            // [sums | listed inliers], the exchange; the stage of slot g - 1 on the rows gathered then runs in the pass's prologue)
+            const int64_t* mt_dev = RB.m_on_device ? &d_best_shard->num_inliers : nullptr;
+            for (int j = 0; j < chunk; ++j) {
+                const int g = launched + j;
+                rc2 = refine_rf_pass_launch(c, RB, np, g, launched, d_rows_all, R, m_total, mt_dev);
+                if (rc2 != RSDSFM_OK) return rc2;
+                rc2 = refine_rf_row_launch(c, RB, np, g, d_row);
+                if (rc2 != RSDSFM_OK) return rc2;
+                rc2 = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)refine_rf_row_doubles(np));
+                if (rc2 != RSDSFM_OK) return rc2;
+            }
+            rc2 = refine_rf_apply_launch(c, RB, np, launched + chunk - 1, true, d_rows_all, R, m_total, mt_dev);
+        } else {
+            for (int j = 0; j < chunk; ++j) {
+                rc2 = refine_slot_rows_launch(c, RB, np, d_row, j, d_rows_all, R);
+                if (rc2 != RSDSFM_OK) return rc2;
+                rc2 = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)refine_slot_row_doubles(np));
+                if (rc2 != RSDSFM_OK) return rc2;
+            }
+            rc2 = refine_slot_apply_launch(c, RB, np, d_rows_all, R, chunk);  // the stage behind the chunk's last exchange -> RB.state
         }
-        int rc2 = refine_slot_apply_launch(c, RB, np, d_rows_all, R, chunk);  // the stage behind the chunk's last exchange -> RB.state
         if (rc2 != RSDSFM_OK) return rc2;
         launched += chunk;
         rc2 = refine_finish_launch(c, RB, d_inl_ref);  // enqueued before the poll: the common case ends within one chunk
@@ -837,11 +863,15 @@ restart_ransac:
             h_state->termination = -1;
             h_state->radius = kInitialRadius;
             h_state->need_schur = 1;  // the first slot is the Schur pass of iteration 1
-            *h_bad = 0;
-            RSDSFM_HIP_CHECK(c, hipMemcpyAsync(RB.state, h_state, sizeof(RefineState) + sizeof(int), hipMemcpyHostToDevice, c->stream));
+            memset(h_bad, 0, kRefineStateBlockTail);  // bad-index flag + the list counters of the radius-factorised path
+            RSDSFM_HIP_CHECK(c, hipMemcpyAsync(RB.state, h_state, sizeof(RefineState) + kRefineStateBlockTail, hipMemcpyHostToDevice, c->stream));
         }
         rc2 = refine_trace_reset(c);
         if (rc2 != RSDSFM_OK) return rc2;
+        if (refine_rf) {  // (no iteration zero of its own: slot 0 carries it)
+            c->refine_rf_runs += 1;
+            return refine_chunk(refine_hint >= 1 ? std::min(refine_hint, 28) : 6);
+        }
         rc2 = refine_stage_rows_launch(c, RB, np, 0, d_row);
         if (rc2 != RSDSFM_OK) return rc2;
         rc2 = all_gather(c, D, d_row, d_rows_all, sizeof(double) * (size_t)refine_stage_row_doubles(np, 0));
@@ -1038,6 +1068,23 @@ restart_ransac:
         }
         for (;;) {  // (here: a chunk is behind us and the host has its state)
             if (*h_bad) local_index_bad = true;  // (rank-local like the count check above: reported at the end, in lockstep)
+            if (refine_rf && h_state->termination == kTermRestartExact) {
+                // a guard of the radius-factorised path (replicated state: every rank sees it): the refinement again, iterate by iterate, from
+                // the host-side RANSAC result
+                c->refine_rf_restarts += 1;
+                c->refine_rf_last_guard = h_state->rf_guard;
+                refine_rf = false;
+                spec_refine = false;
+                path_flags &= ~16;
+                launched = 0;
+                depth_done = false;
+                rc = refine_layout(false);
+                if (rc == RSDSFM_OK) rc = refine_start();
+                if (rc != RSDSFM_OK) return rc;
+                rc = sync(c, D);
+                if (rc != RSDSFM_OK) return rc;
+                continue;
+            }
             if (h_state->termination >= 0) break;
             if (launched > 8 * kMaxIter + 16) return fail(c, RSDSFM_ERR_NUMERIC, "refinement did not terminate");
             rc = refine_chunk(refine_hint >= 1 ? std::min(8, std::max(2, refine_hint - launched)) : 5);
@@ -1046,6 +1093,7 @@ restart_ransac:
             if (rc != RSDSFM_OK) return rc;
         }
         D->refine_iters_hint = h_state->slots;
+        if (refine_rf) c->refine_rf_resolves += h_state->rf_resolves;
         path_flags |= (std::min(h_state->slots, 0xFFFF) << 8);
         d_zsum_global = &RB.state->zsum;  // every rank holds the same GLOBAL sum of z of the final state (replicated decide stages)
         for (int i = 0; i < 3; ++i) v[i] = h_state->p[i], w[i] = h_state->p[3 + i];

@@ -463,6 +463,7 @@ int rsdsfm_solve_frames_dev(rsdsfm_ctx* ctx, const rsdsfm_frame_job* jobs, int32
         lc->ransac_k0 = c->ransac_k0;
         lc->ransac_math_mode = c->ransac_math_mode;
         lc->lm_arithmetic = c->lm_arithmetic;
+        lc->refine_arithmetic = c->refine_arithmetic;
         lc->lma_count_only_force = c->lma_count_only_force;
         lc->frame_side_flatten = c->frame_side_flatten;
         lc->refine_stage_mode = c->refine_stage_mode;

@@ -33,7 +33,7 @@ namespace rsdsfm {
 constexpr double kLmaHIrr = 1.01e-6;  // s^2 h = h / (1 + sqrt h)^2 reaches the clamp's 1e-6 at h = 1.002003e-6
 constexpr double kLmaEta = 1e-11;     // guard (b)
 constexpr double kLmaBand = 1e-6;     // guard (c)
-constexpr double kLmaTie = 1e-11;     // guard (d)
+// (kLmaTie, guard (d): rsdsfm_internal.hpp -- the host files launch the picks with it)
 constexpr double kLmaSqrtMin = 0x1p-767;  // squared errors below this (incl. 0) add 0 to the inlier error SUM (the range of sqrt_core)
 
 constexpr int kLmaNC = 3;    // iterates whose score the pixel pass can fuse (at most)

@@ -13,7 +13,6 @@ namespace rsdsfm {
 
 namespace {
 
-constexpr double kLmaTieMargin = 1e-11;  // = kLmaTie (lma_common.hpp, guard d)
 
 inline uint64_t splitmix64(uint64_t& state) {
     uint64_t z = (state += 0x9E3779B97F4A7C15ULL);
@@ -114,7 +113,7 @@ int lma_start_over(Ctx* c, RansacRun& R, int guards) {
     R.analytic = false;
     R.lma_restarted = true;
     R.lma_guard |= guards;
-    R.tie_margin = -kLmaTieMargin;  // (from here on a tie is only reported)
+    R.tie_margin = -kLmaTie;  // (from here on a tie is only reported)
     R.not_one_step = 0;
     R.final_done = R.spec_scored = R.tail_enqueued = R.spec_final = false;
     RSDSFM_HIP_CHECK(c, hipMemsetAsync(R.zero_begin, 0, R.zero_bytes, c->stream));  // states, scored, flags, list counters
@@ -345,8 +344,9 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
             case kPcFinalWait: {
                 RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
                 const RansacBest* h_best = R.h_best;
-                static const bool dbg = getenv("RSDSFM_RANSAC_DEBUG") != nullptr;
-                if (dbg) fprintf(stderr, "[ransac] final wait: lazy_pending %d undecided %d flags %d %d %d %d hist %d %d %d %d spec_scored %d spec_final %d tail %d idle %d\n", h_best->lazy_pending, h_best->undecided, R.h_running[0], R.h_running[1], R.h_running[2], R.h_running[3], R.h_running[4], R.h_running[5], R.h_running[6], R.h_running[7], (int)R.spec_scored, (int)R.spec_final, (int)R.tail_enqueued, c->ransac_score_idle);
+#ifdef RSDSFM_DEBUG_HOOKS  // (debug builds only: -DRSDSFM_DEBUG_HOOKS)
+                if (getenv("RSDSFM_RANSAC_DEBUG")) fprintf(stderr, "[ransac] final wait: lazy_pending %d undecided %d flags %d %d %d %d hist %d %d %d %d spec_scored %d spec_final %d tail %d idle %d\n", h_best->lazy_pending, h_best->undecided, R.h_running[0], R.h_running[1], R.h_running[2], R.h_running[3], R.h_running[4], R.h_running[5], R.h_running[6], R.h_running[7], (int)R.spec_scored, (int)R.spec_final, (int)R.tail_enqueued, c->ransac_score_idle);
+#endif
                 if (R.count_only && h_best->lazy_pending) {
                     // the definitive pick found several trials sharing the best count, some without their error sum (everything behind it has
                     // left at once): the scoring pass on the list the pick wrote, then the final stage again
@@ -410,7 +410,9 @@ void ransac_commit_hints(Ctx* c, const RansacRun& R) {
     if (R.score_hint_next >= 0) c->ransac_score_idle = R.score_hint_next ? 0 : std::min(c->ransac_score_idle + 1, kScoreIdleLimit);
     c->ransac_not_one_step = R.not_one_step;
     c->ransac_spec_miss = R.spec_final ? 0 : std::min(c->ransac_spec_miss + 1, 2);
-    if (R.lma_cand_next[0]) c->lma_cand[0] = R.lma_cand_next[0], c->lma_cand[1] = R.lma_cand_next[1];
+    // (the analytic pass's fused iterates stay {2, 1} -- Ctx::lma_cand -- whatever the previous solve's step histogram was: which iterates are fused
+    // decides whose error sums come from the closed form and whose from the exact scoring pass, and those differ in their last bits; a
+    // result must not depend on what the context solved before.  R.lma_cand_next is kept as a diagnostic only.)
     if (R.count_only) c->lma_count_only_runs += 1, c->lma_lazy_runs += (R.lazy_rounds > 0 || R.shared_best > 1) ? 1 : 0;
     if (R.lazy_rounds > 0 || R.shared_best > 1) c->lma_unique_run = 0;
     else if (R.shared_best == 1) c->lma_unique_run = std::min(c->lma_unique_run + 1, 2);
@@ -442,7 +444,7 @@ int ransac_begin(Ctx* c, const double* d_q, const double* d_u, const double* d_a
     R.analytic = depth_mode == RSDSFM_DEPTH_CERES_LM && T > 0 && c->lm_arithmetic == 0 && c->lma_hold == 0;
     // guard (d): the analytic pass must not break a tie (+); an iterate-by-iterate run of a context that may go back to the analytic pass
     // reports such ties (-: they renew the hold)
-    R.tie_margin = depth_mode != RSDSFM_DEPTH_CERES_LM || c->lm_arithmetic != 0 ? 0.0 : (R.analytic ? kLmaTieMargin : -kLmaTieMargin);
+    R.tie_margin = depth_mode != RSDSFM_DEPTH_CERES_LM || c->lm_arithmetic != 0 ? 0.0 : (R.analytic ? kLmaTie : -kLmaTie);
     R.lma_cand[0] = c->lma_cand[0], R.lma_cand[1] = c->lma_cand[1];
     // count-only analytic pass + lazy error sums (ransac_lma_kernel ERR = false, ransac_pick_kernel): for callers that do not read the trials' error
     // sums (the frame solve); one hypothesis batch.  No tie guard there: where a tie has to be broken the sums are the reference arithmetic's.
@@ -613,20 +615,39 @@ int rsdsfm_ransac(rsdsfm_ctx* ctx, const double* q, const double* u, const doubl
     dev.alpha_k = sa.take<double>(N);
     dev.inv_depth = sa.take<double>(N);
     dev.mask = sa.take<uint8_t>(N);
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_q, q, 16 * N, hipMemcpyHostToDevice, c->stream));
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_u, u, 16 * N, hipMemcpyHostToDevice, c->stream));
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_a, alpha, 8 * N, hipMemcpyHostToDevice, c->stream));
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_ak, alpha_k, 8 * N, hipMemcpyHostToDevice, c->stream));
+    // (host_xfer.hip: pinned chunks filled by a few host threads while the DMA engine moves the neighbouring chunk; the kernels queue behind the
+    // last chunk on the same stream)
+    c->ransac_cache.tag = 0;
+    const uint64_t gen = c->stage_gen;
+    if ((rc = xfer_h2d(c, d_q, q, 16 * N)) != RSDSFM_OK || (rc = xfer_h2d(c, d_u, u, 16 * N)) != RSDSFM_OK || (rc = xfer_h2d(c, d_a, alpha, 8 * N)) != RSDSFM_OK ||
+        (rc = xfer_h2d(c, d_ak, alpha_k, 8 * N)) != RSDSFM_OK)
+        return rc;
     rc = ransac_device(c, d_q, d_u, d_a, d_ak, n, use_alpha_k, iterations, tolerance, samples, seed, depth_mode, k_sign_mode, &dev, nullptr, nullptr);
     if (rc != RSDSFM_OK) return rc;
     const size_t M = (size_t)dev.num_inliers;
-    if (out->inlier_idx && M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(out->inlier_idx, dev.inlier_idx, 8 * M, hipMemcpyDeviceToHost, c->stream));
-    if (out->inliers && M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(out->inliers, dev.inliers, 24 * M, hipMemcpyDeviceToHost, c->stream));
-    if (out->alpha && M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(out->alpha, dev.alpha, 8 * M, hipMemcpyDeviceToHost, c->stream));
-    if (out->alpha_k && M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(out->alpha_k, dev.alpha_k, 8 * M, hipMemcpyDeviceToHost, c->stream));
-    if (out->inv_depth) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(out->inv_depth, dev.inv_depth, 8 * N, hipMemcpyDeviceToHost, c->stream));
-    if (out->mask) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(out->mask, dev.mask, N, hipMemcpyDeviceToHost, c->stream));
+    XferItem items[6];
+    int ni = 0;
+    if (out->inliers && M) items[ni++] = {out->inliers, dev.inliers, 24 * M};
+    if (out->inlier_idx && M) items[ni++] = {out->inlier_idx, dev.inlier_idx, 8 * M};
+    if (out->alpha && M) items[ni++] = {out->alpha, dev.alpha, 8 * M};
+    if (out->alpha_k && M) items[ni++] = {out->alpha_k, dev.alpha_k, 8 * M};
+    if (out->inv_depth) items[ni++] = {out->inv_depth, dev.inv_depth, 8 * N};
+    if (out->mask) items[ni++] = {out->mask, dev.mask, N};
+    if ((rc = xfer_d2h_many(c, items, ni)) != RSDSFM_OK) return rc;
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    // what stays on the device for rsdsfm_refine_from_ransac (refine_host.hip): the inliers, their alpha / alpha_k / indices and u, until another
+    // host-pointer call takes the staging buffer
+    if (out->inliers && out->alpha && out->alpha_k && out->inlier_idx && gen == c->stage_gen) {
+        Ctx::RansacCache& rcache = c->ransac_cache;
+        rcache.stage_gen = gen;
+        rcache.d_u = d_u, rcache.d_inl = dev.inliers, rcache.d_alpha = dev.alpha, rcache.d_alpha_k = dev.alpha_k, rcache.d_idx = dev.inlier_idx;
+        rcache.n = n, rcache.m = (int64_t)M, rcache.h_u = u;
+        for (int j = 0; j < 16; ++j) {
+            rcache.u_probe[j] = u[(2 * N - 1) * (size_t)j / 15];
+            rcache.inl_probe[j] = M ? out->inliers[(3 * M - 1) * (size_t)j / 15] : 0.0;
+        }
+        rcache.tag = ++c->ransac_tag_counter;
+    }
     out->num_inliers = dev.num_inliers;
     out->best_trial = dev.best_trial;
     memcpy(out->w, dev.w, sizeof(dev.w));

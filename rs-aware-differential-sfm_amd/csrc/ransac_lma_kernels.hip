@@ -57,7 +57,8 @@ template <int NC, bool ERR>
 __global__ __launch_bounds__(kLB) __attribute__((amdgpu_waves_per_eu(4, 5))) void ransac_lma_kernel(const double2* __restrict__ q, const double2* __restrict__ u, const double* __restrict__ alpha,
                                                         const double* __restrict__ alpha_k, int64_t n, const double* __restrict__ hyp, int T,
                                                         const LmaCand cd, double* __restrict__ partials, int* __restrict__ irr_count,
-                                                        int* __restrict__ irr_list, int64_t chunk, unsigned long long* __restrict__ clk_probe, int clk_bid) {
+                                                        int* __restrict__ irr_list, int64_t chunk, unsigned long long* __restrict__ clk_probe, int clk_bid,
+                                                        int Tg, int nwg) {
     __shared__ double s_part[kLB][kLmaSlots + 1];
     const int g = threadIdx.x;
     // rsdsfm_set_profiling: one lane of one workgroup in the middle of the launch (clk_bid; -1 = off) stamps the shader clock counter and the
@@ -66,10 +67,15 @@ __global__ __launch_bounds__(kLB) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
         clk_probe[0] = __builtin_amdgcn_s_memtime();
         clk_probe[1] = __builtin_amdgcn_s_memrealtime();
     }
-    const int P = kLB / T;
-    const int slot = g / T, t = g - slot * T;
-    const bool active = slot < P;
-    const int64_t p0 = (int64_t)blockIdx.x * chunk;
+    // Hypothesis groups (lma_pass_launch): the T hypotheses in groups of Tg <= 256, `nwg` workgroups per group, each group's workgroups covering
+    // every pixel.  With ONE group the P = 256 / T pixel slots leave 256 mod T lanes idle -- 2 % at T = 50, 22 % at T = 100, 49 % at T = 130 --;
+    // groups of 50 / 43 / 26 bring that under 10 % for every T at the price of reading the pixels once per group (a VALU-bound pass).
+    const int grp = (int)blockIdx.x / nwg, bid = (int)blockIdx.x - grp * nwg;
+    const int t0 = grp * Tg, Tl = min(Tg, T - t0);  // this group's hypotheses [t0, t0 + Tl)
+    const int P = kLB / Tg;
+    const int slot = g / Tg, tl = g - slot * Tg, t = t0 + tl;
+    const bool active = slot < P && tl < Tl;
+    const int64_t p0 = (int64_t)bid * chunk;
     const int len = (int)min(chunk, n - p0);  // pixels of this workgroup (32-bit indices below: the bases are uniform)
     const double2* __restrict__ qb = q + p0;
     const double2* __restrict__ ub = u + p0;
@@ -147,11 +153,11 @@ __global__ __launch_bounds__(kLB) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
         s_part[g][7 + 2 * c] = c < NC ? es[c < NC ? c : 0] : 0.0;
     }
     __syncthreads();
-    for (int o = g; o < T * kLmaSlots; o += kLB) {
+    for (int o = g; o < Tl * kLmaSlots; o += kLB) {
         const int tt = o / kLmaSlots, sl = o - tt * kLmaSlots;
         double r = s_part[tt][sl];
-        for (int s = 1; s < P; ++s) r = sl == kLmaG ? fmax(r, s_part[s * T + tt][sl]) : r + s_part[s * T + tt][sl];
-        partials[((int64_t)tt * gridDim.x + blockIdx.x) * kLmaSlots + sl] = r;
+        for (int s = 1; s < P; ++s) r = sl == kLmaG ? fmax(r, s_part[s * Tg + tt][sl]) : r + s_part[s * Tg + tt][sl];
+        partials[((int64_t)(t0 + tt) * nwg + bid) * kLmaSlots + sl] = r;
     }
     if ((int)blockIdx.x == clk_bid && g == 0) {
         clk_probe[2] = __builtin_amdgcn_s_memtime();
@@ -303,6 +309,26 @@ LmaCand lma_candidates(const int* steps, int nc, double tol, bool count_only = f
 // workgroups of the pixel pass and the pixels each owns: ONE round of the chip's resident workgroups (every workgroup does the same work: they
 // start and end together; 2048 workgroups on 1280 resident slots ran 1.6 rounds, the second one 60 % empty), fewer for small inputs
 // (>= 8 pixels per slot and workgroup)
+// hypotheses per group for a batch of T: the fewest groups that keep >= 90 % of the lanes busy (P Tg of 256 with P = 256 / Tg pixel slots;
+// all groups but the last hold Tg hypotheses), else the best of up to 8 groups
+int ransac_lma_group_size(int T, int* groups_out) {
+    int best_ng = 1;
+    double best_u = 0.0;
+    for (int ng = 1; ng <= 8 && ng <= T; ++ng) {
+        const int tg = (T + ng - 1) / ng, ngu = (T + tg - 1) / tg;  // (groups actually used)
+        const double u = (double)T * (kLB / tg) / ((double)ngu * kLB);
+        if (u > best_u + 1e-9) best_u = u, best_ng = ng;
+        if (u >= 0.9) {
+            best_ng = ng;
+            break;
+        }
+    }
+    const int tg = (T + best_ng - 1) / best_ng;
+    if (groups_out) *groups_out = (T + tg - 1) / tg;
+    return tg;
+}
+
+// (T here: the hypotheses of ONE group; the launch has `groups` times as many workgroups)
 int ransac_lma_grid(const Ctx* c, int64_t n, int T, int64_t* chunk_out, int blocks_per_cu) {
     const int P = std::max(1, kLB / std::max(T, 1));
     if (n <= 0) {  // (an empty slab of the column-tiled solve: one workgroup that finds nothing to do)
@@ -339,13 +365,27 @@ static int lma_pass_launch(Ctx* c, const double* q, const double* u, const doubl
     }
     int64_t chunk;
     static const int grid_override = getenv("RSDSFM_LMA_BLOCKS_PER_CU") ? atoi(getenv("RSDSFM_LMA_BLOCKS_PER_CU")) : 0;  // (experiments)
-    const int grid = ransac_lma_grid(c, n, T, &chunk, grid_override > 0 ? grid_override : occ[nc]);
-    *grid_out = grid;
+    int groups = 1;
+    const int Tg = ransac_lma_group_size(T, &groups);
+    // (the resident workgroups are shared by the groups: every group gets 1 / groups of one round of the chip)
+    const int per_cu = std::max(1, (grid_override > 0 ? grid_override : occ[nc]));
+    int nwg = ransac_lma_grid(c, n, Tg, &chunk, per_cu);
+    if (groups > 1) {
+        const int64_t cap = std::max<int64_t>(1, (int64_t)c->num_cus * std::min(per_cu, 8) / groups);
+        if (nwg > cap) {
+            const int P = std::max(1, kLB / Tg);
+            chunk = (n + cap - 1) / cap;
+            chunk = ((chunk + P - 1) / P) * P;
+            nwg = (int)std::max<int64_t>(1, (n + chunk - 1) / chunk);
+        }
+    }
+    const int grid = nwg * groups;
+    *grid_out = nwg;  // (workgroups PER HYPOTHESIS: what the rows stages index the partials with)
     const double2* q2 = reinterpret_cast<const double2*>(q);
     const double2* u2 = reinterpret_cast<const double2*>(u);
     const int clk_bid = clk ? grid / 2 : -1;
 #define RSDSFM_LMA_LAUNCH(NC, ERR) \
-    hipLaunchKernelGGL((ransac_lma_kernel<NC, ERR>), dim3(grid), dim3(kLB), 0, c->stream, q2, u2, a, ak, n, hyp, T, cd, partials, irr_count, irr_list, chunk, clk, clk_bid)
+    hipLaunchKernelGGL((ransac_lma_kernel<NC, ERR>), dim3(grid), dim3(kLB), 0, c->stream, q2, u2, a, ak, n, hyp, T, cd, partials, irr_count, irr_list, chunk, clk, clk_bid, Tg, nwg)
     if (cd.count_only) {
         if (cd.nc == 1) RSDSFM_LMA_LAUNCH(1, false);
         else if (cd.nc == 2) RSDSFM_LMA_LAUNCH(2, false);

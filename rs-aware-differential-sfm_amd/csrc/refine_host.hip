@@ -66,7 +66,7 @@ int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const 
     run->np = np;
     // the radius-factorised path (refine_rf_kernels.hip) unless the context asks for the reference's arithmetic or this solve is run again
     // behind a tripped guard
-    run->rf = !exact && c->lm_arithmetic == 0;
+    run->rf = !exact && c->lm_arithmetic == 0 && c->refine_arithmetic == 0;
     if (run->rf) c->refine_rf_runs += 1;
     run->d_inl_out = d_inl_out;
     run->tail = tail;
@@ -246,37 +246,88 @@ int rsdsfm_refine_dev(rsdsfm_ctx* ctx, const double* d_flow, int64_t n_flow, int
                          flow_index_mode, d_inl_out, v_out, w_out, k_out, summary, nullptr, nullptr);
 }
 
-int rsdsfm_refine(rsdsfm_ctx* ctx, const double* flow, int64_t n_flow, int64_t m, const double* inl, const double* alpha,
-                  const double* alpha_k, const int64_t* inlier_idx, const double v_in[3], const double w_in[3], double k_in,
-                  int const_acceleration, int flow_index_mode, double* inl_out, double v_out[3], double w_out[3], double* k_out,
-                  rsdsfm_lm_summary* summary) {
+// tag: 0, or what rsdsfm_last_ransac_tag returned behind the rsdsfm_ransac whose outputs these arrays are (see include/rsdsfm.h)
+static int refine_host(rsdsfm_ctx* ctx, uint64_t tag, const double* flow, int64_t n_flow, int64_t m, const double* inl, const double* alpha,
+                       const double* alpha_k, const int64_t* inlier_idx, const double v_in[3], const double w_in[3], double k_in,
+                       int const_acceleration, int flow_index_mode, double* inl_out, double v_out[3], double w_out[3], double* k_out,
+                       rsdsfm_lm_summary* summary) {
     if (!ctx) return RSDSFM_ERR_INVALID;
     Ctx* c = &ctx->c;
     DeviceGuard device_guard_(c);
     if (m < 0 || n_flow < 0) return fail(c, RSDSFM_ERR_INVALID, "bad arguments");
     if (m > 0 && (!flow || !inl || !alpha || !alpha_k || !inl_out)) return fail(c, RSDSFM_ERR_INVALID, "null pointer");
     const size_t M = (size_t)m, NF = (size_t)n_flow;
-    int rc = ensure_stage(c, Arena::need(16 * NF) + 2 * Arena::need(24 * M) + 3 * Arena::need(8 * M) + 2048);
-    if (rc != RSDSFM_OK) return rc;
-    Arena sa(c->d_stage);
-    double* d_flow = sa.take<double>(2 * NF);
-    double* d_inl = sa.take<double>(3 * M);
-    double* d_out = sa.take<double>(3 * M);
-    double* d_a = sa.take<double>(M);
-    double* d_ak = sa.take<double>(M);
-    int64_t* d_idx = sa.take<int64_t>(M);
-    if (NF) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_flow, flow, 16 * NF, hipMemcpyHostToDevice, c->stream));
-    if (M) {
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_inl, inl, 24 * M, hipMemcpyHostToDevice, c->stream));
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_a, alpha, 8 * M, hipMemcpyHostToDevice, c->stream));
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_ak, alpha_k, 8 * M, hipMemcpyHostToDevice, c->stream));
-        if (inlier_idx) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_idx, inlier_idx, 8 * M, hipMemcpyHostToDevice, c->stream));
+    // The RANSAC's device-resident outputs instead of a second upload -- when the tag is the context's last RANSAC's, nothing has taken the staging
+    // buffer since, the sizes are that RANSAC's, and 16 probed entries of the caller's arrays still hold what was downloaded / uploaded then (a
+    // spot check against arrays rebuilt in between: the contract is that they are unmodified).  The flow is reused when it is the very array the
+    // RANSAC was given as u (pointer + size + probes), else uploaded.
+    const Ctx::RansacCache& rcache = c->ransac_cache;
+    bool cached = tag != 0 && tag == rcache.tag && rcache.stage_gen == c->stage_gen && rcache.m == m && M > 0 && inlier_idx != nullptr;
+    for (int j = 0; cached && j < 16; ++j) cached = memcmp(&rcache.inl_probe[j], &inl[(3 * M - 1) * (size_t)j / 15], sizeof(double)) == 0;
+    bool flow_cached = cached && flow == rcache.h_u && n_flow == rcache.n;
+    for (int j = 0; flow_cached && j < 16; ++j) flow_cached = memcmp(&rcache.u_probe[j], &flow[(2 * NF - 1) * (size_t)j / 15], sizeof(double)) == 0;
+    int rc = RSDSFM_OK;
+    const double *d_flow, *d_inl, *d_a, *d_ak;
+    const int64_t* d_idx;
+    double* d_out;
+    if (cached) {
+        // (the output and -- if need be -- the flow go to the workspace tail the refinement does not use; the staging buffer stays as it is)
+        const size_t extra = Arena::need(24 * M) + (flow_cached ? 0 : Arena::need(16 * NF)) + 1024;
+        const size_t ws_ref = refine_workspace_bytes(c, m, false);
+        rc = ensure_ws(c, ws_ref + extra);
+        if (rc != RSDSFM_OK) return rc;
+        Arena xa(static_cast<char*>(c->d_ws) + ((ws_ref + 255) & ~(size_t)255));
+        d_out = xa.take<double>(3 * M);
+        double* d_fl = flow_cached ? nullptr : xa.take<double>(2 * NF);
+        if (!flow_cached && NF && (rc = xfer_h2d(c, d_fl, flow, 16 * NF)) != RSDSFM_OK) return rc;
+        d_flow = flow_cached ? rcache.d_u : d_fl;
+        d_inl = rcache.d_inl, d_a = rcache.d_alpha, d_ak = rcache.d_alpha_k, d_idx = rcache.d_idx;
+        c->refine_cache_hits += 1;
+    } else {
+        rc = ensure_stage(c, Arena::need(16 * NF) + 2 * Arena::need(24 * M) + 3 * Arena::need(8 * M) + 2048);
+        if (rc != RSDSFM_OK) return rc;
+        Arena sa(c->d_stage);
+        double* s_flow = sa.take<double>(2 * NF);
+        double* s_inl = sa.take<double>(3 * M);
+        d_out = sa.take<double>(3 * M);
+        double* s_a = sa.take<double>(M);
+        double* s_ak = sa.take<double>(M);
+        int64_t* s_idx = sa.take<int64_t>(M);
+        if (NF && (rc = xfer_h2d(c, s_flow, flow, 16 * NF)) != RSDSFM_OK) return rc;
+        if (M) {
+            if ((rc = xfer_h2d(c, s_inl, inl, 24 * M)) != RSDSFM_OK || (rc = xfer_h2d(c, s_a, alpha, 8 * M)) != RSDSFM_OK || (rc = xfer_h2d(c, s_ak, alpha_k, 8 * M)) != RSDSFM_OK) return rc;
+            if (inlier_idx && (rc = xfer_h2d(c, s_idx, inlier_idx, 8 * M)) != RSDSFM_OK) return rc;
+        }
+        d_flow = s_flow, d_inl = s_inl, d_a = s_a, d_ak = s_ak, d_idx = inlier_idx ? s_idx : nullptr;
     }
-    rc = refine_device(c, d_flow, n_flow, m, d_inl, d_a, d_ak, inlier_idx ? d_idx : nullptr, v_in, w_in, k_in, const_acceleration,
-                       flow_index_mode, d_out, v_out, w_out, k_out, summary, nullptr, nullptr);
+    rc = refine_device(c, d_flow, n_flow, m, d_inl, d_a, d_ak, d_idx, v_in, w_in, k_in, const_acceleration, flow_index_mode, d_out, v_out, w_out, k_out,
+                       summary, nullptr, nullptr);
     if (rc != RSDSFM_OK) return rc;
-    if (M) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(inl_out, d_out, 24 * M, hipMemcpyDeviceToHost, c->stream));
+    if (M && (rc = xfer_d2h(c, inl_out, d_out, 24 * M)) != RSDSFM_OK) return rc;
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    return RSDSFM_OK;
+}
+
+int rsdsfm_refine(rsdsfm_ctx* ctx, const double* flow, int64_t n_flow, int64_t m, const double* inl, const double* alpha,
+                  const double* alpha_k, const int64_t* inlier_idx, const double v_in[3], const double w_in[3], double k_in,
+                  int const_acceleration, int flow_index_mode, double* inl_out, double v_out[3], double w_out[3], double* k_out,
+                  rsdsfm_lm_summary* summary) {
+    return refine_host(ctx, 0, flow, n_flow, m, inl, alpha, alpha_k, inlier_idx, v_in, w_in, k_in, const_acceleration, flow_index_mode, inl_out, v_out, w_out,
+                       k_out, summary);
+}
+
+int rsdsfm_refine_from_ransac(rsdsfm_ctx* ctx, uint64_t ransac_tag, const double* flow, int64_t n_flow, int64_t m, const double* inl,
+                              const double* alpha, const double* alpha_k, const int64_t* inlier_idx, const double v_in[3], const double w_in[3],
+                              double k_in, int const_acceleration, int flow_index_mode, double* inl_out, double v_out[3], double w_out[3],
+                              double* k_out, rsdsfm_lm_summary* summary) {
+    return refine_host(ctx, ransac_tag, flow, n_flow, m, inl, alpha, alpha_k, inlier_idx, v_in, w_in, k_in, const_acceleration, flow_index_mode, inl_out, v_out,
+                       w_out, k_out, summary);
+}
+
+int rsdsfm_last_ransac_tag(rsdsfm_ctx* ctx, uint64_t* tag, int64_t* cache_hits_or_null) {
+    if (!ctx || !tag) return RSDSFM_ERR_INVALID;
+    *tag = ctx->c.ransac_cache.stage_gen == ctx->c.stage_gen ? ctx->c.ransac_cache.tag : 0;
+    if (cache_hits_or_null) *cache_hits_or_null = ctx->c.refine_cache_hits;
     return RSDSFM_OK;
 }
 

@@ -31,6 +31,8 @@ constexpr double kGradientTol = 1e-10;
 static_assert(kGradientTol < 1.0, "the indicator encoding of the gradient-maximum slots needs kGradientTol < 1");
 constexpr double kParameterTol = 1e-8;
 constexpr int kMaxInvalid = 5;
+// analytic LM trajectory, guard (d) (lma_common.hpp): a tie in the inlier count whose error sums differ by less than kLmaTie x count
+constexpr double kLmaTie = 1e-11;
 
 // speculative LM batching: one kernel launch evaluates up to KMAX consecutive LM iterations under the
 // assumption that every step is accepted with step quality ~1 (radius x3); the decision logic (run by
@@ -136,7 +138,7 @@ struct Ctx {
     // alternately: the follow-up launch of one solve zeroes the counter the next one starts from)
     int* d_lma_list = nullptr;
     int depth_lma_parity = 0;
-    int lma_cand[2] = {2, 1};      // the two iterates (accepted steps) whose scores the next pixel pass fuses: where most hypotheses of the previous solve ended
+    int lma_cand[2] = {2, 1};      // the two iterates (accepted steps) whose scores the analytic pixel pass fuses: FIXED (a function of nothing: the error sums of a hypothesis that ends at a fused iterate and of one that ends elsewhere come from different arithmetics)
     int ransac_spec_miss = 0;  // consecutive RANSACs (saturating at 2) whose speculated final stage did not count; below 2 the frame solve enqueues the refinement behind the speculated stage
     int frame_dense_hint = 1;  // frame solve: the previous frame kept every pixel (dense flow) -> set the RANSAC up for n = rows * cols without waiting for the count
     int lm_issued_d = 0;           // depth_lm_decide_kernel launches issued for the current solve
@@ -196,12 +198,28 @@ struct Ctx {
     // the joint refinement on radius-factorised Schur sums (refine_rf_kernels.hip; the default while lm_arithmetic == 0): solves that ran on
     // it, solves one of whose guards sent them back to the iterate-by-iterate slot kernels, the guard that tripped last (RfGuard), and the
     // reduced systems solved again from stored sums (rejected / invalid steps) -- rsdsfm_refine_restarts
+    int refine_arithmetic = 0;  // rsdsfm_set_refine_arithmetic: 0 = radius-factorised (while lm_arithmetic == 0), 1 = the iterate-by-iterate slot kernels
     int64_t refine_rf_runs = 0, refine_rf_restarts = 0, refine_rf_resolves = 0;
     int refine_rf_last_guard = 0;
+    // What the last rsdsfm_ransac (host-pointer form) left on the device, so that rsdsfm_refine_from_ransac can start from it instead of
+    // uploading the same 37 + 15 MB again (reference main.cc:447-457 hands nonLinearRefinement the RansacValues and the flow that ransac has
+    // just seen): valid while `tag` is what the caller presents and no other host-pointer call has taken the staging buffer since
+    struct RansacCache {
+        uint64_t tag = 0, stage_gen = 0;
+        const double *d_u = nullptr, *d_inl = nullptr, *d_alpha = nullptr, *d_alpha_k = nullptr;
+        const int64_t* d_idx = nullptr;
+        int64_t n = 0, m = 0;
+        const void* h_u = nullptr;   // the caller's u array (identity + spot check decide whether `flow` is that array)
+        double u_probe[16] = {0};    // u[probe positions] as uploaded
+        double inl_probe[16] = {0};  // inliers[probe positions] as downloaded
+    } ransac_cache;
+    uint64_t stage_gen = 0, ransac_tag_counter = 0;  // stage_gen: bumped by every ensure_stage
+    int64_t refine_cache_hits = 0;
     std::vector<rsdsfm_ctx*> lanes;
 };
 constexpr int kSequenceLanesDefault = 3;  // measured: 1 / 2 / 3 / 4 / 6 / 8 lanes = 0.91 / 1.19 / 1.31 / 1.21 / 1.31 / 1.27 Gpix/s at 1280x720, T = 50
 void dist_release(Ctx* c);
+void dist_reset_hold(Ctx* c);
 void frame_release(Ctx* c);
 
 constexpr int kDepthBlock = 256;
@@ -236,6 +254,16 @@ struct DeviceGuard {
 
 int fail(Ctx* c, int code, const char* msg);
 int ensure_stage(Ctx* c, size_t bytes);
+// host_xfer.hip: the host-pointer boundary's transfers through a ring of pinned chunks filled / drained by a small thread pool, on the context's
+// stream.  xfer_h2d returns once the caller's array has been read, xfer_d2h once the caller's array holds the data.
+struct XferItem {
+    void* host;
+    const void* dev;
+    size_t bytes;
+};
+int xfer_h2d(Ctx* c, void* d_dst, const void* h_src, size_t bytes);
+int xfer_d2h(Ctx* c, void* h_dst, const void* d_src, size_t bytes);
+int xfer_d2h_many(Ctx* c, const XferItem* items, int count);
 int ensure_ws(Ctx* c, size_t bytes);
 int ensure_pinned(Ctx* c, size_t bytes);
 

@@ -3,7 +3,8 @@
 // (include/rsdsfm.h).  Header-only; link librsdsfm_hip.so.
 //
 // Differences from the reference, all documented in DESIGN.md:
-//  * RansacValues carries inlier_idx (the reference cannot express which points are inliers);
+//  * RansacValues carries inlier_idx (the reference cannot express which points are inliers) and rsdsfm_tag (the
+//    device-resident copy of the result: nonLinearRefinement on an unmodified RansacValues does not upload it again);
 //  * the sampler is the reference's partial Fisher-Yates driven by splitmix64(rsdsfm::ransac_seed()) instead of
 //    srand(time(NULL)) / rand()  (quirk Q1) -- set the seed with rsdsfm::set_ransac_seed();
 //  * failures throw std::runtime_error instead of producing garbage (the reference has no error path);
@@ -87,6 +88,10 @@ struct RansacValues {
     rsdsfm::lite::Vector3d v;
     double k;
     std::vector<int64_t> inlier_idx;  // index of each inlier in the arrays handed to ransac()
+    // names the device-resident copy of these arrays that minimal::ransac left behind (rsdsfm_last_ransac_tag, include/rsdsfm.h): handed to
+    // nonLinearRefinement UNMODIFIED -- what the reference's call sites do -- the refinement starts from that copy instead of uploading the
+    // arrays again; set it to 0 after editing inliers / alpha / alpha_k / inlier_idx in place
+    uint64_t rsdsfm_tag = 0;
 
     /** the reference's 5-argument form (minimal.h:67-70): beta, alpha and alpha_k all start as beta_init, k = 0 */
     RansacValues(int num_inliers_init, rsdsfm::lite::Array3Xd inliers_init, rsdsfm::lite::VectorXd beta_init, rsdsfm::lite::Vector3d w_init,
@@ -172,6 +177,7 @@ inline RansacValues ransac(const Array2Xd& q, const Array2Xd& u, const ArrayXd& 
     idx.resize((size_t)m);
     RansacValues r((int)m, inl, a, ak, Vector3d(out.w[0], out.w[1], out.w[2]), Vector3d(out.v[0], out.v[1], out.v[2]), out.k);
     r.inlier_idx = idx;
+    (void)rsdsfm_last_ransac_tag(rsdsfm::default_context(), &r.rsdsfm_tag, nullptr);
     return r;
 }
 

@@ -91,12 +91,13 @@ inline RansacValues nonLinearRefinement(const Array2Xd& flow, const RansacValues
     double k = 0;
     rsdsfm_lm_summary summary = {};
     rsdsfm::StopWatch watch;
-    rsdsfm::check(rsdsfm_refine(rsdsfm::default_context(), flow.data(), flow.cols(), m, inliers.inliers.data(), inliers.alpha.data(),
-                                inliers.alpha_k.data(), inliers.inlier_idx.empty() ? nullptr : inliers.inlier_idx.data(),
-                                inliers.v.data(), inliers.w.data(), inliers.k, const_acceleration ? 1 : 0,
-                                inliers.inlier_idx.empty() ? RSDSFM_FLOW_COMPAT_RANK : flow_index_mode(), out.data(), v.data(), w.data(),
-                                &k, &summary),
-                  "rsdsfm_refine");
+    // (rsdsfm_tag: the RansacValues minimal::ransac has just returned are still on the device -- main.cc:447-457 passes them on unmodified)
+    rsdsfm::check(rsdsfm_refine_from_ransac(rsdsfm::default_context(), inliers.rsdsfm_tag, flow.data(), flow.cols(), m, inliers.inliers.data(),
+                                            inliers.alpha.data(), inliers.alpha_k.data(), inliers.inlier_idx.empty() ? nullptr : inliers.inlier_idx.data(),
+                                            inliers.v.data(), inliers.w.data(), inliers.k, const_acceleration ? 1 : 0,
+                                            inliers.inlier_idx.empty() ? RSDSFM_FLOW_COMPAT_RANK : flow_index_mode(), out.data(), v.data(), w.data(),
+                                            &k, &summary),
+                  "rsdsfm_refine_from_ransac");
     if (show_messages) {  // nonlinearRefinement.cc:230-234
         std::cout << rsdsfm::brief_report(summary) << std::endl;
         std::cout << "Total time for solving optimization: " << watch.seconds() << " s" << std::endl;

@@ -6,7 +6,7 @@ import pytest
 
 @pytest.mark.parametrize("arith", ["reference", "fused"])
 def test_library_exports_every_declared_symbol(rsdsfm, arith):
-    """both builds of the library (reference arithmetic = the product; fused = opt-in) export the whole ABI and say which one they are"""
+    """both builds of the library (the product; fused = opt-in) export the whole ABI and say which one they are"""
     lib = rsdsfm.load_library(arith=arith)
     names = rsdsfm.declared_symbols()
     assert len(names) >= 70
@@ -14,7 +14,10 @@ def test_library_exports_every_declared_symbol(rsdsfm, arith):
     assert not missing, missing
     assert b"gfx950" in lib.rsdsfm_version()
     assert lib.rsdsfm_fused_arithmetic() == (1 if arith == "fused" else 0)
-    assert (b"reference arithmetic" in lib.rsdsfm_version()) == (arith == "reference")
+    v = lib.rsdsfm_version()
+    # the string says what the DEFAULT path is (analytic trajectory / radius-factorised refinement, guarded) and what mode 1 selects in this build
+    assert b"analytic LM trajectory" in v and b"radius-factorised refinement" in v and b"rsdsfm_set_lm_arithmetic(1)" in v
+    assert (b"no fused multiply-add" in v) == (arith == "reference") and (b"FUSED per-pixel model" in v) == (arith == "fused")
 
 
 @pytest.mark.parametrize("path", ["LIB_PATH", "LIB_PATH_FUSED"])

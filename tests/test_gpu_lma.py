@@ -11,6 +11,9 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture()
 def solver(rsdsfm):
     s = rsdsfm.Solver(0)
+    # this module compares the FORMS OF THE DEPTH SOLVES bit for bit through whole frame solves: the joint refinement behind them is pinned to ONE
+    # arithmetic (the iterate-by-iterate kernels); the refinement's own default arithmetic has its tests in test_gpu_refine_rf.py
+    s.set_refine_arithmetic(1)
     yield s
     s.close()
 
@@ -234,6 +237,7 @@ def test_count_only_follows_the_data(solver, rsdsfm):
         got.append((r1[0] - r0[0], r1[1] - r0[1]))
         ref = rsdsfm.Solver(0)
         ref.set_lm_arithmetic(1)
+        ref.set_refine_arithmetic(1)
         x, dx = _frame(ref, torch, dev, img, rows, cols, K, gamma, trials=50, tol=tol, seed=seed)
         ref.close()
         _same_frame(a, da, x, dx)

@@ -188,6 +188,7 @@ def test_native_tiled_function_cores_and_a_restart_on_one_rank(rsdsfm):
                 with rsdsfm.Solver(0) as s:
                     s.set_ransac_math(math & 1)
                     s.set_lm_arithmetic(1 if math < 2 else 0)
+                    s.set_refine_arithmetic(1)  # (the same refinement behind the three forms of the depth solves: compared bit for bit)
                     s.dist_set_transport(nranks, rank, *tr.callbacks(rank))
                     for img in imgs:
                         slab = img[:, c0:c0 + sc, :].contiguous()

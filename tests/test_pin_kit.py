@@ -25,7 +25,7 @@ def test_pin_kit_plumbing_oracle_half():
 def test_pin_kit_plumbing_hip_half():
     """the HIP path against the ORACLE's outputs in the reference fixture's layout: the parity the GPU suite asserts everywhere, through
     the code that will meet the real fixture"""
-    _run("gpu", 25)  # 5 cases x (minimal solver, depth solve, RANSAC, 2 refinements)
+    _run("gpu", 50)  # 5 cases x (minimal solver, depth solve, RANSAC, 2 refinements) x 2 arithmetics of the HIP path
 
 
 def test_pin_kit_inputs_export(tmp_path):

@@ -253,6 +253,7 @@ def parse_args(argv=None):
     ap.add_argument("--dry-launch", action="store_true", help="print the rank environments / command lines the launcher would start (JSON) and exit; starts nothing, touches no GPU")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="launcher: seconds after which the ranks are ended")
     ap.add_argument("--launch-grace", type=float, default=10.0, help="launcher: seconds the other ranks get after one rank failed")
+    ap.add_argument("--hang-dump", type=float, default=0.0, help="seconds after which every thread's Python stack is written to stderr (diagnosing a bench that does not come back); 0 = off")
     ap.add_argument("--tiled-timeout", type=float, default=240.0, help="full workload: watchdog of the tiled_full (strong scaling) sub-record; on expiry the line is printed without it")
     args = ap.parse_args(argv)
     dsteps = {"depth": 160, "depth_closed_form": 160, "full": 100, "tiled": 2000, "tiled_full": 100, "rectify": 2000, "true_flow": 500, "metrics": 2000, "launch_check": 3}
@@ -342,6 +343,10 @@ def launch_ranks(args, argv):
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
+    if args.hang_dump > 0:
+        import faulthandler
+
+        faulthandler.dump_traceback_later(args.hang_dump, repeat=True, file=sys.stderr)
     # a launched rank has WORLD_SIZE == --gpus in its environment (torch.distributed.run or launch_ranks above); anything else with
     # --gpus N > 1 is the bare command line, which must become N ranks itself -- before torch is imported or a GPU is touched
     if args.dry_launch or (args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) <= 1):
@@ -1240,7 +1245,9 @@ def _host_boundary(rsdsfm, solver, np, rank, args, reps=3):
 
     def run(reuse, reps):
         ts, r, out = [], None, None
-        outputs, ref_out = ({}, np.empty((n, 3))) if reuse else (None, None)
+        # (reuse: caller-owned output arrays kept from pair to pair, and only what the reference's RansacValues holds -- minimal.h:57-76: inliers,
+        # alpha, alpha_k -- plus the inlier indices; the dense inverse depths, the mask and the per-trial diagnostics are not asked for)
+        outputs, ref_out = ({"only": ("inliers", "alpha", "alpha_k", "inlier_idx")}, np.empty((n, 3))) if reuse else (None, None)
         for i in range(reps + 2):
             t0 = time.perf_counter()
             r = solver.ransac(q, u, a, ak, False, args.trials, args.tol, seed=11 + i, outputs=outputs)
@@ -1256,16 +1263,15 @@ def _host_boundary(rsdsfm, solver, np, rank, args, reps=3):
     hits = solver.refine_cache_hits() - hits0
     med_fresh, _, _ = run(False, reps)
     m = int(r["num_inliers"])
-    # bytes that cross PCIe per pair on the streaming path: q, u, alpha, alpha_k in; inliers, indices, alpha, alpha_k, dense inverse depths, mask
-    # out; the refined inliers out (the refinement starts from the RANSAC's device-resident outputs and the flow it was given: no second upload)
-    h2d, d2h = 48 * n, (24 + 8 + 8 + 8) * m + 9 * n + 24 * m
+    # bytes that cross PCIe per pair on the streaming path: q, u, alpha, alpha_k in; inliers, indices, alpha, alpha_k out; the refined inliers out (the refinement starts from the RANSAC's device-resident outputs and the flow it was given: no second upload)
+    h2d, d2h = 48 * n, (24 + 8 + 8 + 8) * m + 24 * m
     return {"value": d["rows"] * d["cols"] / med / 1e6, "unit": "Mpixels/s", "ms_per_pair": med * 1e3, "pairs": reps + 2, "num_inliers": m,
             "refine_iterations": int(out["summary"]["num_iterations"]), "pcie_bytes_per_pair": {"h2d": h2d, "d2h": d2h},
             "pcie_gbs_achieved": (h2d + d2h) / med / 1e9, "refine_started_from_resident_ransac_outputs": int(hits),
             "fresh_arrays_every_call": {"value": d["rows"] * d["cols"] / med_fresh / 1e6, "ms_per_pair": med_fresh * 1e3,
                                         "note": "the same two calls with fresh numpy output arrays per call and no tag (everything uploaded twice, page faults of 90 MB of new arrays inside the calls)"},
-            "note": "PCIe-inclusive: rsdsfm_ransac + rsdsfm_refine_from_ransac on host arrays the caller owns and reuses from pair to pair (inputs, per-trial "
-                    "diagnostics, inlier arrays, dense inverse depths and mask cross PCIe inside the calls through csrc/host_xfer.hip's pinned ring; Python marshalling "
+            "note": "PCIe-inclusive: rsdsfm_ransac + rsdsfm_refine_from_ransac on host arrays the caller owns and reuses from pair to pair (the inputs and "
+                    "what the reference's RansacValues holds -- inliers, alpha, alpha_k, + indices -- cross PCIe inside the calls through csrc/host_xfer.hip's pinned ring; Python marshalling "
                     "included; pcie_gbs_achieved = those bytes / the whole time, compute included); not the metric"}
 
 

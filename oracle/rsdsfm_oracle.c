@@ -1044,6 +1044,7 @@ int64_t rso_score(const double* q, const double* u, const double* alpha, const d
  * correctly rounded fma, which is the hardware instruction where the CPU has one. */
 #define LMA_H_IRR 1.01e-6 /* h below which the LM diagonal's lower clamp may bind: s^2 h = h / (1 + sqrt h)^2 = 1e-6 at h = 1.002003e-6 */
 #define LMA_ETA 1e-11     /* guard (b): see above */
+#define LMA_MARGIN_FLOOR (128.0 * 0x1p-53) /* ... and the floor of the margin's coefficient eta tol / 2: the derived forward-error bound, 128 u */
 #define LMA_TIE 1e-11     /* guard (d): two trials with the same inlier count whose error sums differ by at most LMA_TIE x count are a tie this arithmetic cannot break the way mode 1 does */
 #define LMA_BAND 1e-6     /* guard (c): relative width of the undecided band around a threshold */
 #define LMA_SQRT_MIN 0x1p-767 /* squared errors below this (incl. 0) count as error 0 in the inlier error SUM (the kernels' in-range sqrt core) */
@@ -1172,7 +1173,7 @@ int rso_lma_trial(const double* q, const double* u, const double* alpha, const d
     memset(&stt, 0, sizeof(stt));
     if (n < 0) return -1;
     const int scoring = tol >= 0.0; /* (a dense depth solve has nothing to score: guard (b) is off) */
-    const double tol2 = tol * tol, c1 = 0.5 * LMA_ETA * tol;
+    const double tol2 = tol * tol, c1 = 0.5 * LMA_ETA * tol > LMA_MARGIN_FLOOR ? 0.5 * LMA_ETA * tol : LMA_MARGIN_FLOOR;
     const double two_over = 2.0 / (2.0 + k);
     lma_px* px = (lma_px*)malloc(sizeof(lma_px) * (n > 0 ? n : 1));
     lmx_px* cl = NULL; /* the clamped pixels, on the exact recurrence */
@@ -1350,7 +1351,7 @@ int rso_lma_trial(const double* q, const double* u, const double* alpha, const d
                 if (scoring) {
                     /* the difference of the two errors in units of the margin's scale: the margin is eta tol x that scale, a pixel at
                      * the threshold differs by 2 tol |e_x - e_a| in the square -> the guard holds while kappa < eta / 2 */
-                    const double kappa = fabs(ex - sqrt(e2)) / (lma_margin(p, c1) / (LMA_ETA * tol));
+                    const double kappa = fabs(ex - sqrt(e2)) / lma_margin(p, 0.5); /* (the margin's scale (2 + |r(1)|^2 + h) / 2) */
                     if (kappa > stt.margin_use_max) stt.margin_use_max = kappa;
                     if ((ex < tol) != (e2 < tol2)) ++stt.flips_unguarded;
                 }

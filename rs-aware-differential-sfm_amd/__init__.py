@@ -346,7 +346,10 @@ class Solver:
                 outputs["_shape"], outputs["_bufs"] = (n, T), bufs
         out = RansacOut()
         for name, arr in bufs.items():
-            setattr(out, name, arr.ctypes.data)
+            # (outputs["only"]: the arrays the caller wants filled -- e.g. what the reference's RansacValues holds: inliers, alpha, alpha_k (+ indices);
+            # the others stay NULL and are neither computed for the host nor copied)
+            if not reuse or "only" not in outputs or name in outputs["only"]:
+                setattr(out, name, arr.ctypes.data)
         self._check(self.lib.rsdsfm_ransac(self._ctx, _p(q), _p(u), _p(alpha), _p(alpha_k), C.c_int64(n), int(use_alpha_k), C.c_int32(T), C.c_double(tolerance), _p(smp), C.c_uint64(seed), int(depth_mode), int(k_sign_mode), C.byref(out)), "rsdsfm_ransac")
         m = int(out.num_inliers)
         tag, hits = C.c_uint64(0), C.c_int64(0)

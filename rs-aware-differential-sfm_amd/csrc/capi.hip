@@ -5,6 +5,9 @@
 #include <new>
 #include <vector>
 
+#include <chrono>
+#include <thread>
+
 #include "rsdsfm_internal.hpp"
 
 namespace rsdsfm {
@@ -48,6 +51,32 @@ int ensure_pinned(Ctx* c, size_t bytes) {
     RSDSFM_HIP_CHECK(c, hipHostMalloc(&c->h_pinned, want, hipHostMallocDefault));
     c->pinned_bytes = want;
     return RSDSFM_OK;
+}
+
+// hipStreamSynchronize on the context's stream -- with RSDSFM_SYNC_WATCHDOG_S=<seconds> in the environment (diagnosing a solve that does not
+// come back) a polling wait that, once the time is up, says where the host was waiting, lets a registered dumper describe the device-resident
+// state through a second stream, and aborts the process
+static std::function<void(Ctx*)> g_sync_dumper;
+void set_sync_dumper(std::function<void(Ctx*)> f) { g_sync_dumper = std::move(f); }
+int sync_stream(Ctx* c, const char* where) {
+    static const double limit = getenv("RSDSFM_SYNC_WATCHDOG_S") ? atof(getenv("RSDSFM_SYNC_WATCHDOG_S")) : 0.0;
+    if (limit <= 0.0) {
+        RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+        return RSDSFM_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipSuccess) return RSDSFM_OK;
+        if (e != hipErrorNotReady) RSDSFM_HIP_CHECK(c, e);
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) {
+            fprintf(stderr, "[rsdsfm] the stream did not come back within %.1f s; the host waits at: %s\n", limit, where);
+            if (g_sync_dumper) g_sync_dumper(c);
+            fflush(stderr);
+            abort();
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
 }
 
 using StageAlloc = Arena;

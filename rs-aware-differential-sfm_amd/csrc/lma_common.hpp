@@ -32,6 +32,9 @@ namespace rsdsfm {
 
 constexpr double kLmaHIrr = 1.01e-6;  // s^2 h = h / (1 + sqrt h)^2 reaches the clamp's 1e-6 at h = 1.002003e-6
 constexpr double kLmaEta = 1e-11;     // guard (b)
+// ... and the floor of its margin's coefficient: 128 u (u = 2^-53).  The derived forward-error bound of the two arithmetics' squared errors is
+// 128 u (2 + |r(1)|^2 + h); eta tol / 2 covers it from tol = 2.9e-3 on, the floor covers it for every smaller tolerance.
+constexpr double kLmaMarginFloor = 128.0 * 0x1p-53;
 constexpr double kLmaBand = 1e-6;     // guard (c)
 // (kLmaTie, guard (d): rsdsfm_internal.hpp -- the host files launch the picks with it)
 constexpr double kLmaSqrtMin = 0x1p-767;  // squared errors below this (incl. 0) add 0 to the inlier error SUM (the range of sqrt_core)

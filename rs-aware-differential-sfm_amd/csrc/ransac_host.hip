@@ -241,7 +241,7 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
             }
             case kPcRoundWait: {
                 yield_at_wait = false;  // (a run yields once: after its first wait the caller is blocked in it anyway)
-                RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+                if (int rcs = sync_stream(c, "ransac_finish line 244")) return rcs;
                 const int* h_running = R.h_running;
                 if (R.round == 0 && R.analytic && (h_running[3] & 16) != 0) R.lma_guard |= h_running[3] >> 8;  // (hypotheses handed over: diagnostics)
                 if (R.round == 0 && R.analytic && (h_running[3] & 6) != 0 && !((h_running[3] & 1) && R.core_math)) {
@@ -342,7 +342,7 @@ int ransac_advance(Ctx* c, RansacRun& R, bool yield_at_wait) {
                 break;
             }
             case kPcFinalWait: {
-                RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+                if (int rcs = sync_stream(c, "ransac_finish line 345")) return rcs;
                 const RansacBest* h_best = R.h_best;
 #ifdef RSDSFM_DEBUG_HOOKS  // (debug builds only: -DRSDSFM_DEBUG_HOOKS)
                 if (getenv("RSDSFM_RANSAC_DEBUG")) fprintf(stderr, "[ransac] final wait: lazy_pending %d undecided %d flags %d %d %d %d hist %d %d %d %d spec_scored %d spec_final %d tail %d idle %d\n", h_best->lazy_pending, h_best->undecided, R.h_running[0], R.h_running[1], R.h_running[2], R.h_running[3], R.h_running[4], R.h_running[5], R.h_running[6], R.h_running[7], (int)R.spec_scored, (int)R.spec_final, (int)R.tail_enqueued, c->ransac_score_idle);

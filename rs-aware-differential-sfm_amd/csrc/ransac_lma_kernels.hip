@@ -300,7 +300,7 @@ LmaCand lma_candidates(const int* steps, int nc, double tol, bool count_only = f
     }
     cd.tol = tol;
     cd.tol2 = tol * tol;
-    cd.c1 = 0.5 * kLmaEta * tol;
+    cd.c1 = std::max(0.5 * kLmaEta * tol, kLmaMarginFloor);
     cd.c1x2 = 2.0 * cd.c1;
     cd.count_only = count_only ? 1 : 0;
     return cd;

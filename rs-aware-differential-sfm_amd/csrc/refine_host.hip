@@ -120,6 +120,15 @@ int refine_begin(Ctx* c, const double* d_flow, int64_t n_flow, int64_t m, const 
 
 // one chunk of slots of the iteration loop, the output pass and the caller's tail
 int refine_enqueue_chunk(Ctx* c, RefineRun* run) {
+    static const bool watch = getenv("RSDSFM_SYNC_WATCHDOG_S") != nullptr;
+    if (watch) {  // (diagnostics: what sync_stream's watchdog prints when this context's stream does not come back)
+        const RefineBuffers B = run->B;
+        const int launched = run->launched, chunk = run->chunk, rf = run->rf ? 1 : 0;
+        set_sync_dumper([B, launched, chunk, rf](Ctx* cc) {
+            fprintf(stderr, "[rsdsfm] last refinement chunk enqueued: slots [%d, %d), radius-factorised %d\n", launched, launched + chunk, rf);
+            refine_rf_debug_dump(cc, B);
+        });
+    }
     if (run->rf) {
         // slot g's pass carries the stage of slot g - 1 in its prologue; the stage gets a launch of its own behind the chunk's last pass (into
         // the published state) and -- while several solves share the GPU, or on request -- behind every pass
@@ -165,7 +174,7 @@ int refine_poll(Ctx* c, RefineRun* run, double v_out[3], double w_out[3], double
     for (bool first = true;; first = false) {
         if (!(first && run->prefetch && run->prefetched)) {  // (otherwise the read-back was enqueued with the chunk and the caller has waited)
             if (!run->prefetch) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(hs, run->B.state, sizeof(RefineState) + sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+            if (int rcs = sync_stream(c, "refine_poll line 168")) return rcs;
         }
         if (*h_bad) return fail(c, RSDSFM_ERR_INVALID, "flow index out of range (flow has fewer columns than inliers / bad inlier_idx)");
         if (hs->termination == kTermRestartExact) {  // a guard of the radius-factorised path: the caller runs the solve again, iterate by iterate
@@ -178,7 +187,7 @@ int refine_poll(Ctx* c, RefineRun* run, double v_out[3], double w_out[3], double
                 int rc = (*run->tail)(run->B);
                 if (rc != RSDSFM_OK) return rc;
                 run->tail_done = true;
-                RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+                if (int rcs = sync_stream(c, "refine_poll line 181")) return rcs;
             }
             break;
         }
@@ -262,7 +271,7 @@ static int refine_host(rsdsfm_ctx* ctx, uint64_t tag, const double* flow, int64_
     // spot check against arrays rebuilt in between: the contract is that they are unmodified).  The flow is reused when it is the very array the
     // RANSAC was given as u (pointer + size + probes), else uploaded.
     const Ctx::RansacCache& rcache = c->ransac_cache;
-    bool cached = tag != 0 && tag == rcache.tag && rcache.stage_gen == c->stage_gen && rcache.m == m && M > 0 && inlier_idx != nullptr;
+    bool cached = tag != 0 && tag == rcache.tag && rcache.stage_gen == c->stage_gen && rcache.m == m && M > 0 && (inlier_idx != nullptr || flow_index_mode == RSDSFM_FLOW_COMPAT_RANK);
     for (int j = 0; cached && j < 16; ++j) cached = memcmp(&rcache.inl_probe[j], &inl[(3 * M - 1) * (size_t)j / 15], sizeof(double)) == 0;
     bool flow_cached = cached && flow == rcache.h_u && n_flow == rcache.n;
     for (int j = 0; flow_cached && j < 16; ++j) flow_cached = memcmp(&rcache.u_probe[j], &flow[(2 * NF - 1) * (size_t)j / 15], sizeof(double)) == 0;
@@ -281,7 +290,7 @@ static int refine_host(rsdsfm_ctx* ctx, uint64_t tag, const double* flow, int64_
         double* d_fl = flow_cached ? nullptr : xa.take<double>(2 * NF);
         if (!flow_cached && NF && (rc = xfer_h2d(c, d_fl, flow, 16 * NF)) != RSDSFM_OK) return rc;
         d_flow = flow_cached ? rcache.d_u : d_fl;
-        d_inl = rcache.d_inl, d_a = rcache.d_alpha, d_ak = rcache.d_alpha_k, d_idx = rcache.d_idx;
+        d_inl = rcache.d_inl, d_a = rcache.d_alpha, d_ak = rcache.d_alpha_k, d_idx = inlier_idx ? rcache.d_idx : nullptr;
         c->refine_cache_hits += 1;
     } else {
         rc = ensure_stage(c, Arena::need(16 * NF) + 2 * Arena::need(24 * M) + 3 * Arena::need(8 * M) + 2048);

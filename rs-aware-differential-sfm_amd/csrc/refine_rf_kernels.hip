@@ -28,6 +28,10 @@
 // out four waves per SIMD (128 registers) for ANY body; the memory latency is covered by the next two inliers' loads in flight instead.
 #include "refine_common.hpp"
 
+#ifndef RF_NP7_PREFETCH
+#define RF_NP7_PREFETCH 0
+#endif
+
 namespace rsdsfm {
 
 namespace {
@@ -153,8 +157,12 @@ __device__ __forceinline__ constexpr bool rf_z0(int c) { return c == 1; }
 __device__ __forceinline__ constexpr bool rf_z1(int c) { return c == 0; }
 
 // JtJ and Jtb of one inlier (every inlier), B and c (mask = 1 / h for an unlisted inlier, 0 for a listed one: straight-line code)
+// lds (NP == 7 passes): 3 NP of the accumulators live in LDS, [slot][thread] -- c, and the k column of JtJ and of B: slots [0, NP) c_a,
+// [NP, 2 NP) JtJ(a, k), [2 NP, 3 NP) B(a, k).  75 accumulators + the body's temporaries do not fit 256 registers, and what the compiler spills goes
+// to SCRATCH memory: a kernel with a private segment that runs on several streams at once (the sequence solve's lanes) made the runtime's scratch
+// provisioning hang the queue and corrupt spilled values (reproduced with tools/seq_determinism_probe.py, gone with the private segment).
 template <int NP>
-__device__ __forceinline__ void rf_schur_accumulate(const RfEval<NP>& o, double ih_mask, double (&acc)[RfRow<NP>::NW]) {
+__device__ __forceinline__ void rf_schur_accumulate(const RfEval<NP>& o, double ih_mask, double (&acc)[RfRow<NP>::NW], double* lds = nullptr) {
     using RR = RfRow<NP>;
     double EJ[NP], W[NP];
 #pragma unroll
@@ -177,17 +185,28 @@ __device__ __forceinline__ void rf_schur_accumulate(const RfEval<NP>& o, double 
             acc[RR::OFF_JTB + a] = __builtin_fma(o.P1[a], o.r1, acc[RR::OFF_JTB + a]);
         else
             acc[RR::OFF_JTB + a] = __builtin_fma(o.P0[a], o.r0, __builtin_fma(o.P1[a], o.r1, acc[RR::OFF_JTB + a]));
-        acc[RR::OFF_C + a] = __builtin_fma(W[a], gr, acc[RR::OFF_C + a]);
+        if (lds)
+            lds[a * kFB] = __builtin_fma(W[a], gr, lds[a * kFB]);
+        else
+            acc[RR::OFF_C + a] = __builtin_fma(W[a], gr, acc[RR::OFF_C + a]);
 #pragma unroll
         for (int b = a; b < NP; ++b) {
             const bool t0 = !(rf_z0(a) || rf_z0(b)), t1 = !(rf_z1(a) || rf_z1(b));
+            const bool in_lds = lds != nullptr && b == NP - 1;
+            double jj = in_lds ? lds[(NP + a) * kFB] : acc[RR::OFF_JTJ + tri];
             if (t0 && t1)
-                acc[RR::OFF_JTJ + tri] = __builtin_fma(o.P0[a], o.P0[b], __builtin_fma(o.P1[a], o.P1[b], acc[RR::OFF_JTJ + tri]));
+                jj = __builtin_fma(o.P0[a], o.P0[b], __builtin_fma(o.P1[a], o.P1[b], jj));
             else if (t0)
-                acc[RR::OFF_JTJ + tri] = __builtin_fma(o.P0[a], o.P0[b], acc[RR::OFF_JTJ + tri]);
+                jj = __builtin_fma(o.P0[a], o.P0[b], jj);
             else if (t1)
-                acc[RR::OFF_JTJ + tri] = __builtin_fma(o.P1[a], o.P1[b], acc[RR::OFF_JTJ + tri]);
-            acc[RR::OFF_B + tri] = __builtin_fma(EJ[a], W[b], acc[RR::OFF_B + tri]);
+                jj = __builtin_fma(o.P1[a], o.P1[b], jj);
+            if (in_lds) {
+                lds[(NP + a) * kFB] = jj;
+                lds[(2 * NP + a) * kFB] = __builtin_fma(EJ[a], W[b], lds[(2 * NP + a) * kFB]);
+            } else {
+                acc[RR::OFF_JTJ + tri] = jj;
+                acc[RR::OFF_B + tri] = __builtin_fma(EJ[a], W[b], acc[RR::OFF_B + tri]);
+            }
             ++tri;
         }
     }
@@ -395,9 +414,11 @@ __device__ __forceinline__ void rf_restart(RefineState* st, int guard) {
 template <int NP>
 __device__ __forceinline__ void rf_apply_body(RefineState* st, RfStageLds<NP>& L, const double* __restrict__ rows, int nrows, int row_stride, RfLists lists,
                               const RfExt* __restrict__ ext_in, RfExt* __restrict__ ext_out, int64_t m_total, double* __restrict__ trace, int trace_rows,
-                              unsigned long long* tks = nullptr) {
+                              unsigned long long* tks = nullptr, unsigned long long* beat = nullptr) {
     using RR = RfRow<NP>;
     const int tid = threadIdx.x;
+#define RF_BEAT(code) do { if (beat && tid == 0) beat[1] = (beat[1] & ~255ull) | (code); } while (0)
+    RF_BEAT(10);
     // the reduced row (the same order for workgroup partials and for gathered rank rows)
     if (tid == 0) L.bad = 0;
     rf_reduce_rows_groups<RR::NW>(rows, nrows, row_stride, L.grp, tid);
@@ -415,6 +436,7 @@ __device__ __forceinline__ void rf_apply_body(RefineState* st, RfStageLds<NP>& L
     if (tid < RR::NW && !(fabs(L.s[tid]) < 1e300)) L.bad = 1;  // (a non-finite sum, NaN included: every thread looks at the slot it has just written)
     __syncthreads();
     if (tks) tks[0] = wall_clock64();
+    RF_BEAT(11);
     const bool first = st->iteration == 0 && st->num_unsuccessful == 0 && st->slots == 0;
     // ---- the decision of the iteration whose back-substitution the pass carried (lane 0) ----
     if (tid == 0) {
@@ -549,6 +571,7 @@ __device__ __forceinline__ void rf_apply_body(RefineState* st, RfStageLds<NP>& L
     }
     __syncthreads();
     if (tks) tks[1] = wall_clock64();
+    RF_BEAT(12 + action);
     if (action == 2) return;
     // ---- the reduced solve of the next iteration, again at half the radius while the system does not factor (no pass needed) ----
     const RfPoint P0 = rf_point(st->p0);
@@ -564,6 +587,7 @@ __device__ __forceinline__ void rf_apply_body(RefineState* st, RfStageLds<NP>& L
             L.radius = st->radius;
         }
         __syncthreads();
+        RF_BEAT(20);
         const int go = L.loop, n = L.nlist;
         const double radius = L.radius;
         __syncthreads();  // (read by everyone before lane 0 writes L.loop again)
@@ -603,11 +627,13 @@ __device__ __forceinline__ void rf_apply_body(RefineState* st, RfStageLds<NP>& L
             L.loop = again;
         }
         __syncthreads();
+        RF_BEAT(21);
         const int again = L.loop;
         __syncthreads();
         if (!again) break;
         resolve = true;
     }
+    RF_BEAT(30);
     // ---- what the next stage may need of the current point ----
     if (ext_out) {
         if (tid < RR::NSCHUR) ext_out->sums[tid] = L.cur[tid];
@@ -615,6 +641,8 @@ __device__ __forceinline__ void rf_apply_body(RefineState* st, RfStageLds<NP>& L
         for (int q = tid; q < n * kRfEntry; q += kFB) ext_out->list[q] = L.list[q];
         if (tid == 0) ext_out->nlist = (double)n;
     }
+    RF_BEAT(31);
+#undef RF_BEAT
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -651,6 +679,8 @@ struct RfPassArgs {
     const int64_t* inlier_idx;
     int flow_index_mode;
     int* bad_index;
+    unsigned long long* beat;    // opt-in (RSDSFM_SYNC_WATCHDOG_S): host-mapped heartbeat words of this context, see rf_beat
+    int slot;
     unsigned long long* stamps;  // opt-in (RSDSFM_RF_STAMPS=1): workgroup 0 adds the 100 MHz ticks of its phases here (tools/refine_rf_probe.py)
 };
 
@@ -682,7 +712,15 @@ __global__ __launch_bounds__(kFB) void refine_rf_pass_kernel(const RfPassArgs A)
     __shared__ double s_red[kFB / 64][RR::NW];
     __shared__ RefineState s_state;
     const bool stamp = A.stamps && blockIdx.x == 0 && threadIdx.x == 0;
-    unsigned long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (A.beat && threadIdx.x == 0) {
+        atomicAdd(&A.beat[2], 1ull);  // workgroups of this context's passes that started ...
+        if (blockIdx.x == 0) A.beat[0] = ((unsigned long long)A.slot << 8) | 1;
+    }
+    __shared__ unsigned long long tk[8];  // (LDS, not a private array: a private array indexed through a pointer lives in scratch memory, and a kernel that needs scratch is a kernel the runtime has to provision for on every queue)
+    if (stamp) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tk[i] = 0;
+    }
     if (stamp) tk[0] = wall_clock64();
     state_to_lds(&s_state, A.st_in);
     RefineState* st = &s_state;
@@ -700,6 +738,10 @@ __global__ __launch_bounds__(kFB) void refine_rf_pass_kernel(const RfPassArgs A)
     if (threadIdx.x == 0) st->pending_apply = st->termination < 0 ? 1 : 0;  // (this pass runs: its rows wait for a stage)
     __syncthreads();
     if (stamp) tk[2] = wall_clock64();
+    if (A.beat && threadIdx.x == 0) {
+        if (blockIdx.x == 0) A.beat[0] = ((unsigned long long)A.slot << 8) | 2;
+        if (st->termination >= 0 || (A.m < 0 && (int)blockIdx.x >= st->grid)) atomicAdd(&A.beat[3], 1ull);  // ... and that left (here, or at the end)
+    }
     if (blockIdx.x == 0) {
         state_from_lds(A.st_out, st);
         if (threadIdx.x == 0) *A.list_count_zero = 0;
@@ -711,6 +753,13 @@ __global__ __launch_bounds__(kFB) void refine_rf_pass_kernel(const RfPassArgs A)
     double acc[RR::NW];
 #pragma unroll
     for (int s = 0; s < RR::NW; ++s) acc[s] = 0.0;
+    constexpr bool kLdsC = NP == 7 && !FIRST;  // (see rf_schur_accumulate)
+    __shared__ double s_cacc[kLdsC ? 3 * NP : 1][kLdsC ? kFB : 1];
+    double* const lds_c = kLdsC ? &s_cacc[0][threadIdx.x] : nullptr;
+    if (kLdsC) {
+#pragma unroll
+        for (int a = 0; a < 3 * NP; ++a) lds_c[a * kFB] = 0.0;
+    }
     const int64_t stride = (int64_t)ps.grid * kFB;
     const int64_t i0 = (int64_t)blockIdx.x * kFB + threadIdx.x;
     RfPoint P0q = rf_point(st->p0);
@@ -807,7 +856,7 @@ __global__ __launch_bounds__(kFB) void refine_rf_pass_kernel(const RfPassArgs A)
             if (ZSUM) acc[RR::ZSUM] += 1.0 / cd;
             const bool flagged_c = rf_flagged(oc.h, h0);
             const double ihm = flagged_c ? 0.0 : rcp_core(flagged_c ? 1.0 : oc.h);
-            rf_schur_accumulate<NP>(oc, ihm, acc);
+            rf_schur_accumulate<NP>(oc, ihm, acc, lds_c);
             if (flagged_c) rf_list_append(A.list_count, A.list_entries, x, y, ux, uy, l0.ab, l0.ak, cd, i);
         };
         // Two inliers' loads in flight beyond the one in the arithmetic: two waves per SIMD, so the latency is covered here and not by occupancy.
@@ -815,20 +864,51 @@ __global__ __launch_bounds__(kFB) void refine_rf_pass_kernel(const RfPassArgs A)
         // of 8.3 us per loop of the older wave; the first two sets requested ahead of the stage -- vmcnt counts in order, so the stage's own
         // row loads then wait for them: stage + 1.4 us, loop - 1.4 us.)
         const int64_t last = m - 1;
-        RfLoad l0 = rf_load<NP>(A, rho, i0, i0 <= last);
-        RfLoad l1 = rf_load<NP>(A, rho, i0 + stride, i0 + stride <= last);
-        for (int64_t i = i0; i < m; i += stride) {
-            const int64_t i2 = i + 2 * stride;
-            const RfLoad l2 = rf_load<NP>(A, rho, i2, i2 <= last);
-            body(l0, i);
-            l0 = l1;
-            l1 = l2;
+        if (NP == 6) {
+            RfLoad l0 = rf_load<NP>(A, rho, i0, i0 <= last);
+            RfLoad l1 = rf_load<NP>(A, rho, i0 + stride, i0 + stride <= last);
+            for (int64_t i = i0; i < m; i += stride) {
+                const int64_t i2 = i + 2 * stride;
+                const RfLoad l2 = rf_load<NP>(A, rho, i2, i2 <= last);
+                body(l0, i);
+                l0 = l1;
+                l1 = l2;
+            }
+        } else {
+            // (k refined: 75 accumulators.  No register set for a load in flight: whatever the compiler cannot keep goes to scratch, and a kernel
+            // with a private segment must not run on several streams at once -- see rf_schur_accumulate.  RF_NP7_PREFETCH: experiments)
+#if RF_NP7_PREFETCH == 1
+            RfLoad l0 = rf_load<NP>(A, rho, i0, i0 <= last);
+            for (int64_t i = i0; i < m; i += stride) {
+                const RfLoad l1 = rf_load<NP>(A, rho, i + stride, i + stride <= last);
+                body(l0, i);
+                l0 = l1;
+            }
+#else
+            for (int64_t i = i0; i < m; i += stride) body(rf_load<NP>(A, rho, i, true), i);
+#endif
         }
     }
+    if (kLdsC) {  // back to the registers for the reduction (the body's temporaries are dead by now)
+        int tri = 0;
+#pragma unroll
+        for (int a = 0; a < NP; ++a) {
+            acc[RR::OFF_C + a] = lds_c[a * kFB];
+            tri += NP - 1 - a;  // index of (a, NP - 1) in the upper triangle
+            acc[RR::OFF_JTJ + tri] = lds_c[(NP + a) * kFB];
+            acc[RR::OFF_B + tri] = lds_c[(2 * NP + a) * kFB];
+            tri += 1;
+        }
+    }
+    if (A.beat && blockIdx.x == 0 && threadIdx.x == 0) A.beat[0] = ((unsigned long long)A.slot << 8) | 3;
     if (stamp) tk[3] = wall_clock64();
     if (A.stamps && blockIdx.x == 0 && (threadIdx.x & 63) == 0) A.stamps[8 + (threadIdx.x >> 6)] += wall_clock64();  // (per wave: when its loop ended; sums over passes)
     static_assert(RR::GMAX == RR::NW - 1, "the max slot is the row's last");
     block_reduce_store_halving<RR::NW>(acc, s_red, A.partials + (int64_t)blockIdx.x * RR::NW);
+    if (A.beat && threadIdx.x == 0) {
+        atomicAdd(&A.beat[3], 1ull);
+        if (blockIdx.x == 0) A.beat[0] = ((unsigned long long)A.slot << 8) | 4;
+    }
     if (stamp) {
         tk[4] = wall_clock64();
         A.stamps[0] += tk[1] - tk[0], A.stamps[1] += tk[2] - tk[1], A.stamps[2] += tk[3] - tk[2], A.stamps[3] += tk[4] - tk[3], A.stamps[4] += 1;
@@ -842,16 +922,19 @@ template <int NP>
 __global__ __launch_bounds__(kFB) void refine_rf_apply_kernel(const double* __restrict__ rows, int nrows, int row_stride, RfLists lists,
                                                              const RefineState* __restrict__ st_in, RefineState* __restrict__ st_out,
                                                              const RfExt* __restrict__ ext_in, RfExt* __restrict__ ext_out, int64_t m_total,
-                                                             const int64_t* __restrict__ m_total_dev, double* __restrict__ trace, int trace_rows) {
+                                                             const int64_t* __restrict__ m_total_dev, double* __restrict__ trace, int trace_rows,
+                                                             unsigned long long* __restrict__ beat, int slot) {
     __shared__ RfStageLds<NP> s_stage;
     __shared__ RefineState s_state;
+    if (beat && threadIdx.x == 0) beat[1] = ((unsigned long long)slot << 8) | 1;
     state_to_lds(&s_state, st_in);
     RefineState* st = &s_state;
     if (st->termination < 0 && st->pending_apply) {
         const int64_t mt = m_total_dev ? *m_total_dev : (m_total >= 0 ? m_total : st->m);
-        rf_apply_body<NP>(st, s_stage, rows, nrows >= 0 ? nrows : st->grid, row_stride, lists, ext_in, ext_out, mt, trace, trace_rows);
+        rf_apply_body<NP>(st, s_stage, rows, nrows >= 0 ? nrows : st->grid, row_stride, lists, ext_in, ext_out, mt, trace, trace_rows, nullptr, beat);
     }
     __syncthreads();
+    if (beat && threadIdx.x == 0) beat[1] = ((unsigned long long)slot << 8) | 40;
     if (threadIdx.x == 0) st->pending_apply = 0;
     __syncthreads();
     state_from_lds(st_out, st);
@@ -943,6 +1026,27 @@ inline RfLists rf_lists_of(const RfLayout& Lo, const RefineBuffers& B, int g, co
     return l;
 }
 
+// opt-in heartbeat (environment RSDSFM_SYNC_WATCHDOG_S): 8 host-mapped words per context -- [0] (slot << 8 | phase) of the last pass's
+// workgroup 0 (1 started, 2 stage done, 3 loop done, 4 row written), [2] / [3] workgroups of passes that started / left
+struct RfBeat {
+    const Ctx* c;
+    unsigned long long* words;
+};
+RfBeat g_beats[32];
+int g_nbeats = 0;
+unsigned long long* rf_beat(Ctx* c) {
+    static const bool on = getenv("RSDSFM_SYNC_WATCHDOG_S") != nullptr;
+    if (!on) return nullptr;
+    for (int i = 0; i < g_nbeats; ++i)
+        if (g_beats[i].c == c) return g_beats[i].words;
+    if (g_nbeats >= 32) return nullptr;
+    unsigned long long* w = nullptr;
+    if (hipHostMalloc((void**)&w, 64, hipHostMallocDefault) != hipSuccess) return nullptr;
+    for (int i = 0; i < 8; ++i) w[i] = 0;
+    g_beats[g_nbeats].c = c, g_beats[g_nbeats].words = w;
+    ++g_nbeats;
+    return w;
+}
 // opt-in phase stamps (environment RSDSFM_RF_STAMPS=1, read once): a small device buffer per process, never freed
 unsigned long long* rf_stamps(Ctx* c) {
     static int on = -1;
@@ -1005,6 +1109,8 @@ int refine_rf_pass_launch(Ctx* c, const RefineBuffers& B, int np, int g, int g_f
     A.flow_index_mode = B.flow_index_mode;
     A.bad_index = B.bad_index;
     A.stamps = rf_stamps(c);
+    A.beat = rf_beat(c);
+    A.slot = g;
     const bool first = g == 0;
     if (np == 7) {
         if (B.want_zsum) rf_pass_launch_t<7, true>(c, A, first, grid); else rf_pass_launch_t<7, false>(c, A, first, grid);
@@ -1030,10 +1136,10 @@ int refine_rf_apply_launch(Ctx* c, const RefineBuffers& B, int np, int g, bool t
     // (the stage of slot g is "the prologue of slot g + 1": ext in = what slot g's prologue left, out = the other copy)
     if (np == 7)
         hipLaunchKernelGGL(refine_rf_apply_kernel<7>, dim3(1), dim3(kFB), 0, c->stream, rows, nrows, stride, lists, st_io, to_published ? B.state : st_io,
-                           Lo.ext[g & 1], Lo.ext[(g + 1) & 1], m_total, m_total_dev, c->d_refine_trace, c->refine_trace_rows);
+                           Lo.ext[g & 1], Lo.ext[(g + 1) & 1], m_total, m_total_dev, c->d_refine_trace, c->refine_trace_rows, rf_beat(c), g);
     else
         hipLaunchKernelGGL(refine_rf_apply_kernel<6>, dim3(1), dim3(kFB), 0, c->stream, rows, nrows, stride, lists, st_io, to_published ? B.state : st_io,
-                           Lo.ext[g & 1], Lo.ext[(g + 1) & 1], m_total, m_total_dev, c->d_refine_trace, c->refine_trace_rows);
+                           Lo.ext[g & 1], Lo.ext[(g + 1) & 1], m_total, m_total_dev, c->d_refine_trace, c->refine_trace_rows, rf_beat(c), g);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
 }
@@ -1050,6 +1156,32 @@ int refine_rf_row_launch(Ctx* c, const RefineBuffers& B, int np, int g, double* 
                            rf_list_count(B, g), rf_list_entries(Lo, g), row);
     RSDSFM_HIP_CHECK(c, hipGetLastError());
     return RSDSFM_OK;
+}
+
+// diagnostics (sync_stream's watchdog, capi.hip): the published state, the two chunk states and the list counters of a refinement, read through
+// a stream of their own while the context's stream is stuck
+void refine_rf_debug_dump(Ctx* c, const RefineBuffers& B) {
+    const RfLayout Lo = rf_layout(c, B);
+    hipStream_t s2 = nullptr;
+    if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) return;
+    RefineState h[3];
+    int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const RefineState* src[3] = {B.state, Lo.cs[0], Lo.cs[1]};
+    for (int i = 0; i < 3; ++i) (void)hipMemcpyAsync(&h[i], src[i], sizeof(RefineState), hipMemcpyDeviceToHost, s2);
+    (void)hipMemcpyAsync(cnt, B.bad_index, sizeof(int) * 8, hipMemcpyDeviceToHost, s2);
+    if (hipStreamSynchronize(s2) != hipSuccess) {
+        fprintf(stderr, "[rsdsfm] refinement dump: the copies did not complete either\n");
+        return;
+    }
+    const char* names[3] = {"published", "chunk state 0", "chunk state 1"};
+    for (int i = 0; i < 3; ++i)
+        fprintf(stderr, "[rsdsfm] %s: np %d termination %d iteration %d slots %d pending_apply %d rf %d guard %d cur %d solve_ok %d m %lld grid %d radius %g cost %g successful %d unsuccessful %d invalid_run %d\n",
+                names[i], h[i].np, h[i].termination, h[i].iteration, h[i].slots, h[i].pending_apply, h[i].rf, h[i].rf_guard, h[i].cur, h[i].solve_ok, (long long)h[i].m, h[i].grid, h[i].radius,
+                h[i].cost, h[i].num_successful, h[i].num_unsuccessful, h[i].invalid_run);
+    fprintf(stderr, "[rsdsfm] bad_index %d, list counters %d %d %d (m_on_device %d, m %lld)\n", cnt[0], cnt[4], cnt[5], cnt[6], (int)B.m_on_device, (long long)B.m);
+    for (int i = 0; i < g_nbeats; ++i)
+        fprintf(stderr, "[rsdsfm] context %p%s: last pass slot %llu phase %llu; pass workgroups started %llu, left %llu; last stage kernel slot %llu phase %llu\n", (const void*)g_beats[i].c, g_beats[i].c == c ? " (the waiting one)" : "",
+                g_beats[i].words[0] >> 8, g_beats[i].words[0] & 255, g_beats[i].words[2], g_beats[i].words[3], g_beats[i].words[1] >> 8, g_beats[i].words[1] & 255);
 }
 
 // the accumulated phase stamps {state load, stage, publish + loop, row reduction, passes} in 100 MHz ticks; zeroes them (profiling tools only)

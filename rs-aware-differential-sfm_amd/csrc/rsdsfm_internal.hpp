@@ -265,6 +265,8 @@ int xfer_h2d(Ctx* c, void* d_dst, const void* h_src, size_t bytes);
 int xfer_d2h(Ctx* c, void* h_dst, const void* d_src, size_t bytes);
 int xfer_d2h_many(Ctx* c, const XferItem* items, int count);
 int ensure_ws(Ctx* c, size_t bytes);
+int sync_stream(Ctx* c, const char* where);  // hipStreamSynchronize(c->stream), with an opt-in watchdog (RSDSFM_SYNC_WATCHDOG_S; capi.hip)
+void set_sync_dumper(std::function<void(Ctx*)> f);
 int ensure_pinned(Ctx* c, size_t bytes);
 
 // bump allocator over a device arena (256-byte aligned slices)
@@ -596,6 +598,7 @@ int refine_rf_apply_launch(Ctx* c, const RefineBuffers& B, int np, int g, bool t
                            const int64_t* m_total_dev);
 int refine_rf_row_launch(Ctx* c, const RefineBuffers& B, int np, int g, double* row);
 int refine_rf_row_doubles(int np);
+void refine_rf_debug_dump(Ctx* c, const RefineBuffers& B);
 int refine_rf_read_stamps(Ctx* c, unsigned long long out[16]);
 int refine_rf_extra_doubles();
 int refine_partials_half_doubles(const Ctx* c);

@@ -647,6 +647,7 @@ def test_frame_solve_starts_over_with_the_standard_functions(rsdsfm):
         with rsdsfm.Solver(0) as s:
             s.set_ransac_math(math & 1)
             s.set_lm_arithmetic(1 if math < 2 else 0)
+            s.set_refine_arithmetic(1)  # (the same refinement behind the three forms of the depth solves: their results are compared bit for bit)
             res = []
             for name in ("clean", "bad", "clean"):
                 dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)

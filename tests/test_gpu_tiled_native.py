@@ -34,6 +34,7 @@ def _native_threads(rsdsfm, torch, d, nranks, **kw):
     outs, errs = [None] * nranks, [None] * nranks
     kw = dict(kw)
     kw.setdefault("flow_index_mode", rsdsfm.FLOW_GATHERED)  # (tests of the reference's rank-indexed flow pass FLOW_COMPAT_RANK)
+    refine_arithmetic = kw.pop("refine_arithmetic", 0)
 
     def work(rank):
         try:
@@ -45,6 +46,7 @@ def _native_threads(rsdsfm, torch, d, nranks, **kw):
             t = torch.empty(rows * 3, dtype=torch.float64, device=dev)
             torch.cuda.synchronize()
             with rsdsfm.Solver(0) as s:
+                s.set_refine_arithmetic(refine_arithmetic)
                 s.dist_set_transport(nranks, rank, *tr.callbacks(rank))
                 r = s.solve_frame_tiled_dev(slab.data_ptr() if sc else 0, rows, cols, K, gamma, dm.data_ptr(), R.data_ptr(), t.data_ptr(), **kw)
                 s.synchronize()
@@ -250,14 +252,21 @@ def test_native_tiled_solve_matches_single_context(rsdsfm, cfg, accel):
 
 
 rsdsfm_trace_accepted = 1.0  # RSDSFM_TRACE_ACCEPTED
+rsdsfm_trace_invalid = 2.0  # RSDSFM_TRACE_INVALID
 
 
-def _predicted_slots(trace, np_params):
-    """Slots the refinement consumes by the documented rule (refine_kernels.hip): one in front (the Schur pass of
-    iteration 1), one per LM iteration (its back-substitution + decision), and one plain Schur slot behind every iteration the solve
-    outlives unless that iteration's step was accepted with exactly the radius the pass speculated on (radius_accept(radius, 1): x 3,
-    capped) WHILE the pass was speculating -- it is while fewer than two decisions in a row failed that test, and never with k refined."""
+def _predicted_slots(trace, np_params, radius_factorised=True):
+    """Slots the refinement consumes by the documented rule.
+    Radius-factorised path (the default; DESIGN section 5b, refine_rf_kernels.hip): ONE in front (iteration zero + the Schur sums of iteration
+    1) and one per LM iteration that evaluated a candidate -- whatever the step's quality; an iteration whose reduced system did not factor
+    (outcome INVALID with no model change recorded) is solved again at half the radius inside the same stage: no slot.
+    Iterate-by-iterate slot kernels (rsdsfm_set_refine_arithmetic(1); refine_kernels.hip): one in front (the Schur pass of iteration 1), one per
+    LM iteration (its back-substitution + decision), and one plain Schur slot behind every iteration the solve outlives unless that iteration's
+    step was accepted with exactly the radius the pass speculated on (radius_accept(radius, 1): x 3, capped) WHILE the pass was speculating -- it
+    is while fewer than two decisions in a row failed that test, and never with k refined."""
     rows = trace[~np.isnan(trace[:, 0])]
+    if radius_factorised:
+        return 1 + int(sum(1 for row in rows if not (row[7] == rsdsfm_trace_invalid and row[3] == 0.0)))
     slots, miss_run = 1, 0
     for i, row in enumerate(rows):
         slots += 1
@@ -275,7 +284,8 @@ def _predicted_slots(trace, np_params):
 @pytest.mark.parametrize("cfg,accel,tol", [(5, False, 0.05), (3, False, 0.002), (3, False, 0.01), (5, True, 0.01)])
 def test_native_tiled_refinement_consumes_the_documented_number_of_slots(rsdsfm, cfg, accel, tol):
     """the exchanges of the tiled refinement (rsdsfm_tiled_info::path_flags bits 8-23) against the rule applied to the iteration trace of the
-    single-context solve of the same frame: one exchange per LM iteration where the speculation applies, two where it does not"""
+    single-context solve of the same frame -- default path: ONE exchange per LM iteration whatever the step's quality (+ the first pass);
+    iterate-by-iterate slot kernels: one where the speculation applies, two where it does not"""
     import torch
 
     dev = torch.device("cuda", 0)
@@ -285,21 +295,25 @@ def test_native_tiled_refinement_consumes_the_documented_number_of_slots(rsdsfm,
     dm = torch.empty((cols, rows), dtype=torch.float64, device=dev)
     checked = 0
     for seed in (3, 11, 29):
-        kw = dict(trials=12, tol=tol, seed=seed, use_acceleration_mode=accel)
-        with rsdsfm.Solver(0) as s:
-            s.set_refine_trace(60)
-            one = s.solve_frame_dev(img.data_ptr(), rows, cols, d["K"], d["gamma"], dm.data_ptr(), flow_index_mode=rsdsfm.FLOW_GATHERED, **kw)
-            trace = s.get_refine_trace()
-        if rsdsfm.TERMINATION[one["refine_summary"]["termination"]] not in ("gradient", "parameter", "function"):
-            continue  # (max iterations / minimum radius are found at the top of the loop, in a slot of their own)
-        want = _predicted_slots(trace, 7 if accel else 6)
-        for nranks in (1, 3):
-            til = _native_threads(rsdsfm, torch, d, nranks, **kw)
-            assert til["refine_summary"]["num_iterations"] == one["refine_summary"]["num_iterations"]
-            slots = {(i["path_flags"] >> 8) & 0xFFFF for i in til["infos"]}
-            assert slots == {want}, (seed, nranks, slots, want, trace[~np.isnan(trace[:, 0])][:, [4, 5, 7]])
-        checked += 1
-    assert checked >= 2
+        for refine_arithmetic in (0, 1):
+            kw = dict(trials=12, tol=tol, seed=seed, use_acceleration_mode=accel)
+            with rsdsfm.Solver(0) as s:
+                s.set_refine_arithmetic(refine_arithmetic)
+                s.set_refine_trace(60)
+                r0 = s.refine_restarts()["restarts"]
+                one = s.solve_frame_dev(img.data_ptr(), rows, cols, d["K"], d["gamma"], dm.data_ptr(), flow_index_mode=rsdsfm.FLOW_GATHERED, **kw)
+                trace = s.get_refine_trace()
+                restarted = s.refine_restarts()["restarts"] != r0
+            if rsdsfm.TERMINATION[one["refine_summary"]["termination"]] not in ("gradient", "parameter", "function") or restarted:
+                continue  # (max iterations / minimum radius are found at the top of the loop, in a slot of their own; a guard: two runs)
+            want = _predicted_slots(trace, 7 if accel else 6, radius_factorised=refine_arithmetic == 0)
+            for nranks in (1, 3):
+                til = _native_threads(rsdsfm, torch, d, nranks, refine_arithmetic=refine_arithmetic, **kw)
+                assert til["refine_summary"]["num_iterations"] == one["refine_summary"]["num_iterations"]
+                slots = {(i["path_flags"] >> 8) & 0xFFFF for i in til["infos"]}
+                assert slots == {want}, (seed, nranks, refine_arithmetic, slots, want, trace[~np.isnan(trace[:, 0])][:, [3, 4, 5, 7]])
+            checked += 1
+    assert checked >= 4
 
 
 def test_native_tiled_modes(rsdsfm):

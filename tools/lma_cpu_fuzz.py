@@ -2,8 +2,10 @@
 """CPU campaign for the analytic LM trajectory: the oracle's mode 2 (rso_lma_trial: the HIP library's default arithmetic for the dense
 depth solves, restated) against its mode 1 (the reference's iterate-by-iterate arithmetic) on the random cases of tests/fuzz_gpu.py.
 Every integer must agree (per-trial counts, accepted LM steps, winner, mask); prints the guards' statistics.
-    python tools/lma_cpu_fuzz.py [cases] [seed] [study]
-study = 1 also runs rso_lma_trial's study mode on every finite hypothesis (distance between the two arithmetics, in units of guard (b))."""
+    python tools/lma_cpu_fuzz.py [cases] [seed] [study] [wide]
+study = 1 also runs rso_lma_trial's study mode on every finite hypothesis (distance between the two arithmetics, in units of guard (b)).
+wide = 1 leaves synth.py's one scene family: every case in ACCELERATION mode (k != 0, k estimated per hypothesis), 10 % of the points get a flow
+vector of up to +-0.5 in normalised units on top (real DeepFlow outliers are not capped at 30 px), coordinates up to a 110 degree field of view."""
 import os
 import sys
 
@@ -21,6 +23,7 @@ def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     study = len(sys.argv) > 3 and int(sys.argv[3]) != 0
+    wide = len(sys.argv) > 4 and int(sys.argv[4]) != 0
     bad = 0
     tot = dict(listed_clamped=0, listed_near=0, fallback=0, trials=0, pxhyp=0)
     reasons = {}
@@ -33,9 +36,18 @@ def main():
         v = rng.normal(size=3) * np.array([0.03, 0.03, 0.02])
         w = rng.normal(size=3) * 0.004
         k = float(rng.choice([0.0, 0.0, rng.uniform(-0.5, 0.8)]))
+        if wide:
+            k = float(rng.uniform(-0.5, 0.8))
+            if abs(k) < 0.02:
+                k = 0.05
         d = rsdsfm.synth.make_config(cfg, seed=int(rng.integers(1 << 30)), v=v, w=w, k=k, rows=rows, cols=cols)
         q, u, a, ak = d["q"], d["u"], d["alpha"], d["alpha_k"]
         n = len(q)
+        if wide and n >= 9:
+            u = u.copy()
+            hit = rng.random(n) < 0.1
+            u[hit] += rng.uniform(-0.5, 0.5, size=(int(hit.sum()), 2))
+            q = q * float(rng.uniform(1.0, 2.2))  # (|x|, |y| up to ~1.4: a 110 degree field of view)
         if n < 9 or not (np.all(np.isfinite(q)) and np.all(np.isfinite(u))):
             continue
         tag = "case %d (%dx%d cfg %d n %d k %.3f)" % (c, rows, cols, cfg, n, k)
@@ -51,7 +63,7 @@ def main():
             assert np.allclose(r1, r2, rtol=1e-9, atol=1e-13, equal_nan=True), "depth values"
             T = int(rng.choice([1, 3, 8, 20, 50]))
             tol = float(rng.choice([0.05, 0.01, 0.003, 0.001]))
-            use_k = bool(rng.integers(2)) and k != 0.0
+            use_k = (bool(rng.integers(2)) or wide) and k != 0.0
             samples = O.sample_indices(n, T, int(rng.integers(1 << 30)))
             o1 = O.ransac(q, u, a, ak, use_k, T, tol, samples, depth_mode=1)
             o2 = O.ransac(q, u, a, ak, use_k, T, tol, samples, depth_mode=2)

@@ -59,7 +59,7 @@ int ensure_pinned(Ctx* c, size_t bytes) {
 static std::function<void(Ctx*)> g_sync_dumper;
 void set_sync_dumper(std::function<void(Ctx*)> f) { g_sync_dumper = std::move(f); }
 int sync_stream(Ctx* c, const char* where) {
-    static const double limit = getenv("RSDSFM_SYNC_WATCHDOG_S") ? atof(getenv("RSDSFM_SYNC_WATCHDOG_S")) : 0.0;
+    static const double limit = getenv("RSDSFM_SYNC_WATCHDOG_S") ? atof(getenv("RSDSFM_SYNC_WATCHDOG_S")) : (getenv("RSDSFM_SYNC_POLL") ? 1e9 : 0.0);
     if (limit <= 0.0) {
         RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
         return RSDSFM_OK;

@@ -130,18 +130,19 @@ int refine_enqueue_chunk(Ctx* c, RefineRun* run) {
         });
     }
     if (run->rf) {
-        // slot g's pass carries the stage of slot g - 1 in its prologue; the stage gets a launch of its own behind the chunk's last pass (into
-        // the published state) and -- while several solves share the GPU, or on request -- behind every pass
-        const bool separate = c->refine_stage_mode == 2 || (c->refine_stage_mode == 0 && (c->refine_stage_separate || frames_in_flight(c) > 1));
-        for (int i = 0; i < run->chunk; ++i) {
+        // Slot g's pass carries the stage of slot g - 1 in its prologue.  The chunk is CLOSED by one more pass whose prologue runs the stage of
+        // the chunk's last slot and publishes the state: on a solve that has ended -- the common case -- its workgroups leave right behind the
+        // prologue (~6 us); on one that has not, it simply is the next slot.  There is NO stage kernel of its own on this path: a single
+        // 512-thread workgroup holding 222 registers per lane, launched behind every pass while the other lanes of a sequence keep the chip busy
+        // (what the iterate-by-iterate path does with its 72-register stage kernel while several solves share the GPU), wedged the GPU on the
+        // MI355X boxes -- 3 of 3 sequence runs against 0 of 5 with the stage in the prologues (tools/seq_hang_probe.py, HISTORY.md).
+        // rsdsfm_set_refine_stage therefore only concerns the iterate-by-iterate kernels.
+        for (int i = 0; i <= run->chunk; ++i) {
             const int g = run->launched + i;
-            int rc = refine_rf_pass_launch(c, run->B, run->np, g, run->launched, nullptr, 0, -1, nullptr);
+            int rc = refine_rf_pass_launch(c, run->B, run->np, g, run->launched, nullptr, 0, -1, nullptr, i == run->chunk);
             if (rc != RSDSFM_OK) return rc;
-            if (i == run->chunk - 1 || separate) {
-                rc = refine_rf_apply_launch(c, run->B, run->np, g, i == run->chunk - 1, nullptr, 0, -1, nullptr);
-                if (rc != RSDSFM_OK) return rc;
-            }
         }
+        run->launched += 1;  // (the closing pass has a slot index of its own, whether or not it had anything left to do)
     } else {
         for (int i = 0; i < run->chunk; ++i) {
             int rc = refine_iter_launch(c, run->B, run->np, i, run->chunk);

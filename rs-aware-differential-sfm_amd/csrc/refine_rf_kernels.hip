@@ -713,8 +713,9 @@ __global__ __launch_bounds__(kFB) void refine_rf_pass_kernel(const RfPassArgs A)
     __shared__ RefineState s_state;
     const bool stamp = A.stamps && blockIdx.x == 0 && threadIdx.x == 0;
     if (A.beat && threadIdx.x == 0) {
-        atomicAdd(&A.beat[2], 1ull);  // workgroups of this context's passes that started ...
+        if (A.beat[7]) atomicAdd(&A.beat[2], 1ull);  // ([7]: count every workgroup of this context's passes that started ... -- a system-scope atomic per workgroup: slow)
         if (blockIdx.x == 0) A.beat[0] = ((unsigned long long)A.slot << 8) | 1;
+        if (blockIdx.x < 512) A.beat[8 + blockIdx.x] = ((unsigned long long)A.slot << 8) | 1;
     }
     __shared__ unsigned long long tk[8];  // (LDS, not a private array: a private array indexed through a pointer lives in scratch memory, and a kernel that needs scratch is a kernel the runtime has to provision for on every queue)
     if (stamp) {
@@ -740,7 +741,8 @@ __global__ __launch_bounds__(kFB) void refine_rf_pass_kernel(const RfPassArgs A)
     if (stamp) tk[2] = wall_clock64();
     if (A.beat && threadIdx.x == 0) {
         if (blockIdx.x == 0) A.beat[0] = ((unsigned long long)A.slot << 8) | 2;
-        if (st->termination >= 0 || (A.m < 0 && (int)blockIdx.x >= st->grid)) atomicAdd(&A.beat[3], 1ull);  // ... and that left (here, or at the end)
+        if (blockIdx.x < 512) A.beat[8 + blockIdx.x] = ((unsigned long long)A.slot << 8) | ((st->termination >= 0 || (A.m < 0 && (int)blockIdx.x >= st->grid)) ? 9 : 2);
+        if (A.beat[7] && (st->termination >= 0 || (A.m < 0 && (int)blockIdx.x >= st->grid))) atomicAdd(&A.beat[3], 1ull);  // ... and that left (here, or at the end)
     }
     if (blockIdx.x == 0) {
         state_from_lds(A.st_out, st);
@@ -900,14 +902,17 @@ __global__ __launch_bounds__(kFB) void refine_rf_pass_kernel(const RfPassArgs A)
             tri += 1;
         }
     }
+    if (A.beat && threadIdx.x == 0 && blockIdx.x < 512) A.beat[8 + blockIdx.x] = ((unsigned long long)A.slot << 8) | 3;
+    if (A.beat && (threadIdx.x & 63) == 0 && blockIdx.x < 64) A.beat[8 + 256 + blockIdx.x * 4 + 0] |= 1ull << (threadIdx.x >> 6);  // (waves of the first 64 workgroups that left the loop; [.. + 1]: that passed the reduction)
     if (A.beat && blockIdx.x == 0 && threadIdx.x == 0) A.beat[0] = ((unsigned long long)A.slot << 8) | 3;
     if (stamp) tk[3] = wall_clock64();
     if (A.stamps && blockIdx.x == 0 && (threadIdx.x & 63) == 0) A.stamps[8 + (threadIdx.x >> 6)] += wall_clock64();  // (per wave: when its loop ended; sums over passes)
     static_assert(RR::GMAX == RR::NW - 1, "the max slot is the row's last");
     block_reduce_store_halving<RR::NW>(acc, s_red, A.partials + (int64_t)blockIdx.x * RR::NW);
     if (A.beat && threadIdx.x == 0) {
-        atomicAdd(&A.beat[3], 1ull);
+        if (A.beat[7]) atomicAdd(&A.beat[3], 1ull);
         if (blockIdx.x == 0) A.beat[0] = ((unsigned long long)A.slot << 8) | 4;
+        if (blockIdx.x < 512) A.beat[8 + blockIdx.x] = ((unsigned long long)A.slot << 8) | 4;
     }
     if (stamp) {
         tk[4] = wall_clock64();
@@ -1035,14 +1040,15 @@ struct RfBeat {
 RfBeat g_beats[32];
 int g_nbeats = 0;
 unsigned long long* rf_beat(Ctx* c) {
-    static const bool on = getenv("RSDSFM_SYNC_WATCHDOG_S") != nullptr;
+    static const bool on = getenv("RSDSFM_SYNC_WATCHDOG_S") != nullptr && getenv("RSDSFM_NO_BEAT") == nullptr;  // (NO_BEAT: the watchdog without the kernels' heartbeat)
     if (!on) return nullptr;
     for (int i = 0; i < g_nbeats; ++i)
         if (g_beats[i].c == c) return g_beats[i].words;
     if (g_nbeats >= 32) return nullptr;
     unsigned long long* w = nullptr;
-    if (hipHostMalloc((void**)&w, 64, hipHostMallocDefault) != hipSuccess) return nullptr;
-    for (int i = 0; i < 8; ++i) w[i] = 0;
+    if (hipHostMalloc((void**)&w, 64 + 8 * 512, hipHostMallocDefault) != hipSuccess) return nullptr;
+    for (int i = 0; i < 8 + 512; ++i) w[i] = 0;  // ([8 + b]: (slot << 8 | phase) of workgroup b of the last pass)
+    w[7] = getenv("RSDSFM_BEAT_COUNT_WORKGROUPS") ? 1 : 0;
     g_beats[g_nbeats].c = c, g_beats[g_nbeats].words = w;
     ++g_nbeats;
     return w;
@@ -1072,7 +1078,7 @@ void rf_pass_launch_t(Ctx* c, const RfPassArgs& A, bool first, int grid) {
 // solve's gathered rows of slot g - 1 (null: a single context -- the previous pass's partials and its list).  State in: the published state for
 // the first slot of a chunk, else what slot g - 1 left.
 int refine_rf_pass_launch(Ctx* c, const RefineBuffers& B, int np, int g, int g_first, const double* rows_all_prev, int nranks, int64_t m_total,
-                          const int64_t* m_total_dev) {
+                          const int64_t* m_total_dev, bool publish) {
     const RfLayout Lo = rf_layout(c, B);
     const int grid = B.m_on_device ? rf_grid_cap(c) : rf_grid(c, B.m);
     const int nw = np == 7 ? RfRow<7>::NW : RfRow<6>::NW;
@@ -1086,7 +1092,7 @@ int refine_rf_pass_launch(Ctx* c, const RefineBuffers& B, int np, int g, int g_f
     A.rho_a = B.rho_a;
     A.rho_b = B.rho_b;
     A.st_in = g == g_first ? B.state : Lo.cs[(g - 1) & 1];
-    A.st_out = Lo.cs[g & 1];
+    A.st_out = publish ? B.state : Lo.cs[g & 1];  // (publish: the CLOSING pass of a chunk -- see refine_enqueue_chunk)
     if (rows_all_prev)
         A.rows_prev = rows_all_prev, A.nrows_prev = nranks, A.row_stride = nw + kRfListDoubles;
     else
@@ -1182,6 +1188,20 @@ void refine_rf_debug_dump(Ctx* c, const RefineBuffers& B) {
     for (int i = 0; i < g_nbeats; ++i)
         fprintf(stderr, "[rsdsfm] context %p%s: last pass slot %llu phase %llu; pass workgroups started %llu, left %llu; last stage kernel slot %llu phase %llu\n", (const void*)g_beats[i].c, g_beats[i].c == c ? " (the waiting one)" : "",
                 g_beats[i].words[0] >> 8, g_beats[i].words[0] & 255, g_beats[i].words[2], g_beats[i].words[3], g_beats[i].words[1] >> 8, g_beats[i].words[1] & 255);
+    for (int i = 0; i < g_nbeats; ++i) {
+        if (g_beats[i].c != c) continue;
+        int hist[16] = {0};
+        const unsigned long long last = g_beats[i].words[0] >> 8;
+        fprintf(stderr, "[rsdsfm] workgroups of the waiting context's pass (slot %llu) not at phase 4 / 9:", last);
+        for (int b = 0; b < 256; ++b) {
+            const unsigned long long w = g_beats[i].words[8 + b];
+            hist[w & 15] += 1;
+            if ((w & 255) != 4 && (w & 255) != 9) fprintf(stderr, " [%d: slot %llu phase %llu]", b, w >> 8, w & 255);
+        }
+        fprintf(stderr, "\n[rsdsfm] phase histogram:");
+        for (int p = 0; p < 10; ++p) fprintf(stderr, " %d:%d", p, hist[p]);
+        fprintf(stderr, "\n");
+    }
 }
 
 // the accumulated phase stamps {state load, stage, publish + loop, row reduction, passes} in 100 MHz ticks; zeroes them (profiling tools only)

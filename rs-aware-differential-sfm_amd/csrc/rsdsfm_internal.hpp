@@ -593,7 +593,7 @@ int refine_init_launch(Ctx* c, const RefineBuffers& B, int np);
 // refine_rf_kernels.hip: slot g (global index within the solve; 0 = the first pass: iteration zero + the Schur sums of iteration 1) of a
 // chunk that started at g_first; the stage behind slot g on its own; the shard's row [sums | list] of the column-tiled solve
 int refine_rf_pass_launch(Ctx* c, const RefineBuffers& B, int np, int g, int g_first, const double* rows_all_prev, int nranks, int64_t m_total,
-                          const int64_t* m_total_dev);
+                          const int64_t* m_total_dev, bool publish = false);
 int refine_rf_apply_launch(Ctx* c, const RefineBuffers& B, int np, int g, bool to_published, const double* rows_all, int nranks, int64_t m_total,
                            const int64_t* m_total_dev);
 int refine_rf_row_launch(Ctx* c, const RefineBuffers& B, int np, int g, double* row);

@@ -709,7 +709,7 @@ def run(args):
                                     "pairs": "the timed steps rotate over %d different pairs (data seeds) and a new sampler seed per step" % full["data_seeds"],
                                     **{k2: full[k2] for k2 in ("rows", "cols", "trials", "tol", "n", "num_inliers", "data_seeds", "num_inliers_min_max",
                                                                "refine_iterations_min_max", "distinct_winners", "refine_summary", "w_err", "v_angle_deg")}},
-                         "roofline": roof, "full_solve_batched": batched, "full_solve_8_threads": threads8, "full_solve_fused": fused, "full_solve_exact_kernel": exact_kernel, "host_boundary": host_boundary, "regimes": regimes, "depth_only": depth_only,
+                         "roofline": roof, "refine_pass": _refine_pass_record(full), "refine_restarts": full.get("refine_restarts"), "full_solve_batched": batched, "full_solve_8_threads": threads8, "full_solve_fused": fused, "full_solve_exact_kernel": exact_kernel, "host_boundary": host_boundary, "regimes": regimes, "depth_only": depth_only,
                          "cpu_baseline": None if (args.no_cpu_baseline or world > 1) else cpu_baseline_full(rsdsfm, np, rank, args.trials, args.tol)})
             # the regimes the headline does not exercise, lifted to the top level of the line: `value_selective` = the same one-call solve
             # at the selective tolerance 0.002 (M < N: compaction and the rank-indexed flow are NOT the identity), `value_sequence` =
@@ -1214,8 +1214,14 @@ def _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps, warmup, timed
         seen.append((int(r_.num_inliers), int(r_.refine_summary.num_iterations), int(r_.best_trial)))  # (after the clock: not in the step's own time)
 
     lma0 = solver.lma_restarts()[0]
+    rf0 = solver.refine_restarts()
     el = timed(step, steps, warmup)
     lma_restarts = solver.lma_restarts()[0] - lma0  # guard restarts of the analytic pass during the warm-up + timed steps
+    rf1 = solver.refine_restarts()
+    # the joint refinement's default path (radius-factorised Schur sums): solves that ran on it, those a guard sent back to the iterate-by-iterate
+    # kernels (rate = restarts / runs), reduced systems solved again from kept sums (rejected / invalid steps: no pass of their own)
+    refine_restarts = {"runs": rf1["runs"] - rf0["runs"], "restarts": rf1["restarts"] - rf0["restarts"], "resolves": rf1["resolves"] - rf0["resolves"],
+                       "rate": (rf1["restarts"] - rf0["restarts"]) / max(1, rf1["runs"] - rf0["runs"]), "last_guard": rf1["last_guard"]}
     # the last timed solve once more through the dict-building wrapper (same seed: same result), for the record
     r = solver.solve_frame_dev(imgs[(steps - 1) % nd].data_ptr(), rows, cols, K, gamma, depth_map.data_ptr(), R.data_ptr(),
                                tt.data_ptr(), trials=args.trials, tol=args.tol, seed=steps)
@@ -1227,7 +1233,7 @@ def _full_solve(rsdsfm, solver, torch, dev, np, rank, args, steps, warmup, timed
     return {"value": rows * cols * steps / el / 1e6, "unit": "Mpixels/s", "ms_per_solve": el / steps * 1e3,
             "median_ms_per_solve": ts[len(ts) // 2] * 1e3, "min_ms_per_solve": ts[0] * 1e3,
             "rows": rows, "cols": cols, "trials": args.trials, "tol": args.tol, "n": r["n"], "num_inliers": r["num_inliers"],
-            "lma_restarts": lma_restarts, "data_seeds": nd, "num_inliers_min_max": [min(x[0] for x in seen), max(x[0] for x in seen)],
+            "lma_restarts": lma_restarts, "refine_restarts": refine_restarts, "data_seeds": nd, "num_inliers_min_max": [min(x[0] for x in seen), max(x[0] for x in seen)],
             "refine_iterations_min_max": [min(x[1] for x in seen), max(x[1] for x in seen)], "distinct_winners": len({x[2] for x in seen}),
             "refine_summary": r["refine_summary"], "K": K, "gamma": gamma, "_img": imgs[0],
             "w_err": float(np.linalg.norm(r["w"] - t["w"])), "v_angle_deg": float(np.degrees(np.arccos(min(1.0, abs(float(vv @ vt)))))),
@@ -1326,6 +1332,32 @@ def _counters(kernel):
 
     stale = source_hash.stale_files(kernel.split(":")[0], (data.get("_meta") or {}).get("sources"))
     return {"stale": stale} if stale else ctr
+
+
+def _refine_pass_record(full):
+    """The joint refinement's pass (refine_rf_pass_kernel<6, false, false>: one per LM iteration, csrc/refine_rf_kernels.hip) against the two
+    rooflines that could bound it: fp64 lane-instructions (SQ_INSTS_VALU_*_F64 x 64) and HBM bytes (64 B per inlier and iteration algorithmic,
+    SURVEY 8 d; FETCH_SIZE x 2 + WRITE_SIZE measured) of one launch from profiles/counters.json, over the launch duration the same collection pass
+    stored there (`trace_avg_us`: rocprofv3 --kernel-trace of this command, the launches that ran their loop).  Neither bounds it: a third of a
+    launch is the replicated single-workgroup stage in every workgroup's prologue and the row reduction."""
+    kname = "refine_rf_pass_kernel<6, false, false>"
+    ctr = _counters(kname)
+    if not ctr:
+        return {"kernel": kname, "error": "profiles/counters.json has no entry for it"}
+    if ctr.get("stale"):
+        return {"kernel": kname, "counters_stale": True, "counters_stale_files": ctr["stale"]}
+    us = ctr.get("trace_avg_us")
+    insts = sum(ctr.get(k2, 0.0) for k2 in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")) * 64.0
+    m = int(full["num_inliers"])
+    alg = 64.0 * m
+    traffic = (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0 if ("FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr) else None
+    rec = {"kernel": kname, "avg_launch_us": us, "fp64_lane_instructions_per_launch": insts or None, "alg_bytes_per_launch": alg, "traffic": traffic, "inliers": m,
+           "launches_sampled": ctr.get("launches_sampled"), "counters_stale": False}
+    if us:
+        rec["fp64"] = {"bound": "fp64-valu", "achieved": insts / (us * 1e-6) / 1e12 if insts else None, "peak": FP64_VALU_PEAK / 1e12, "unit": "T fp64 lane-instructions/s",
+                       "frac": insts / (us * 1e-6) / FP64_VALU_PEAK if insts else None}
+        rec["hbm"] = {"bound": "hbm", "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS}
+    return rec
 
 
 def _full_roofline(rsdsfm, solver, torch, dev, np, stream, args, full):

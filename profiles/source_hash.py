@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "rs-aware-differential-sfm_amd")
 COMMON = ["device_math.hpp", "lm_common.hpp", "lma_common.hpp", "lma_stages.hpp", "rsdsfm_internal.hpp", "build.py", "rsdsfm.h"]
 # kernel name prefix -> the translation unit that defines it (every kernel also depends on COMMON)
-UNITS = {"ransac_lma": "ransac_lma_kernels.hip", "depth_lma": "depth_lma_kernels.hip", "ransac_": "ransac_kernels.hip", "depth_lm": "depth_kernels.hip", "depth_closed": "depth_kernels.hip", "minimal9": "minimal9_kernels.hip",
+UNITS = {"refine_rf": "refine_rf_kernels.hip", "ransac_lma": "ransac_lma_kernels.hip", "depth_lma": "depth_lma_kernels.hip", "ransac_": "ransac_kernels.hip", "depth_lm": "depth_kernels.hip", "depth_closed": "depth_kernels.hip", "minimal9": "minimal9_kernels.hip",
          "refine_": "refine_kernels.hip", "back_project": "rectify_kernels.hip", "rectify_": "rectify_kernels.hip", "interpolate_": "rectify_kernels.hip", "preview_": "rectify_kernels.hip",
          "true_flow": "gtflow_kernels.hip", "pose_bounds": "gtflow_kernels.hip", "reproj_": "metrics_kernels.hip", "flatten_": "glue_kernels.hip",
          "cell_scan": "glue_kernels.hip", "depth_claim": "glue_kernels.hip", "depth_write": "glue_kernels.hip", "zsum_": "glue_kernels.hip",
@@ -27,7 +27,8 @@ def source_hashes():
 
 def files_of(kernel):
     unit = next((u for pre, u in UNITS.items() if kernel.startswith(pre)), None)
-    return ([unit] if unit else []) + COMMON
+    extra = ["refine_common.hpp"] if kernel.startswith("refine_") else []
+    return ([unit] if unit else []) + extra + COMMON
 
 
 def stale_files(kernel, stamped):

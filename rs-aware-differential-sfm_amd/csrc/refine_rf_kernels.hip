@@ -705,6 +705,9 @@ __device__ __forceinline__ RfLoad rf_load(const RfPassArgs& A, const double* __r
     return l;
 }
 
+}  // namespace
+
+// (the kernels themselves have external names: rocprofv3 and the profile summaries list them by name)
 template <int NP, bool FIRST, bool ZSUM>
 __global__ __launch_bounds__(kFB) void refine_rf_pass_kernel(const RfPassArgs A) {
     using RR = RfRow<NP>;
@@ -975,7 +978,6 @@ __global__ __launch_bounds__(kFB) void refine_rf_row_kernel(const double* __rest
     }
 }
 
-}  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // launchers

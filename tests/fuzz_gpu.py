@@ -313,6 +313,9 @@ def main(cases=None, seed0=None):
                 # the RANSACs ran on the analytic LM trajectory (the library's default): how often a global guard sent a run back to the
                 # iterate-by-iterate kernels (ties on noise-free data, mostly), and which guards tripped last
                 print("analytic LM trajectory: %d of the RANSAC runs started over iterate by iterate (last guards: bit set %d)" % lma, flush=True)
+                # the refinements ran on radius-factorised Schur sums (the default): how many a guard sent back to the iterate-by-iterate kernels
+                print("radius-factorised refinement: %(runs)d ran on it, %(restarts)d were sent back by a guard (last guard %(last_guard)d), %(resolves)d reduced "
+                      "systems were solved again from kept sums (rejected / invalid steps)" % s.refine_restarts(), flush=True)
     if not only:
         bad += fuzz_consumers(O, rsdsfm, max(cases // 2, 1), seed0)
     print("fuzz: %d cases, %d mismatches; %d all-inlier ties decided by rounding noise, %d ill-conditioned / split refinement trajectories (outcome compared), "

@@ -1347,12 +1347,15 @@ def _refine_pass_record(full):
     if ctr.get("stale"):
         return {"kernel": kname, "counters_stale": True, "counters_stale_files": ctr["stale"]}
     us = ctr.get("trace_avg_us")
-    insts = sum(ctr.get(k2, 0.0) for k2 in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")) * 64.0
+    # (counters.json holds means over ALL launches of the kernel; 3 of the 8 passes enqueued per solve find the solve over and leave at once, counting
+    # next to nothing: per launch that ran its loop the means are divided by the fraction of such launches in the same collection's trace)
+    frac_full = ctr.get("trace_full_launch_fraction") or 1.0
+    insts = sum(ctr.get(k2, 0.0) for k2 in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64")) * 64.0 / frac_full
     m = int(full["num_inliers"])
     alg = 64.0 * m
-    traffic = (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0 if ("FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr) else None
+    traffic = (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0 / frac_full if ("FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr) else None
     rec = {"kernel": kname, "avg_launch_us": us, "fp64_lane_instructions_per_launch": insts or None, "alg_bytes_per_launch": alg, "traffic": traffic, "inliers": m,
-           "launches_sampled": ctr.get("launches_sampled"), "counters_stale": False}
+           "launches_sampled": ctr.get("launches_sampled"), "full_launch_fraction": frac_full, "counters_stale": False}
     if us:
         rec["fp64"] = {"bound": "fp64-valu", "achieved": insts / (us * 1e-6) / 1e12 if insts else None, "peak": FP64_VALU_PEAK / 1e12, "unit": "T fp64 lane-instructions/s",
                        "frac": insts / (us * 1e-6) / FP64_VALU_PEAK if insts else None}

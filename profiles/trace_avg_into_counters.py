@@ -22,11 +22,15 @@ def durations(trace_dir):
 
 def main():
     path, trace_dir, kernel, min_us = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
-    ds = [us for n, us in durations(trace_dir) if n == kernel and us > min_us]
+    all_ds = [us for n, us in durations(trace_dir) if n == kernel]
+    ds = [us for us in all_ds if us > min_us]
     data = json.load(open(path))
     if kernel in data and ds:
         data[kernel]["trace_avg_us"] = sum(ds) / len(ds)
         data[kernel]["trace_launches"] = len(ds)
+        # (the counters of this file are means over ALL launches of the kernel; the launches of a solve that has already ended leave at once and
+        # count next to nothing: per FULL launch the counters are the stored means / this fraction)
+        data[kernel]["trace_full_launch_fraction"] = len(ds) / len(all_ds)
         json.dump(data, open(path, "w"), indent=1, sort_keys=True)
         print("%s: %d launches > %.0f us, mean %.2f us" % (kernel, len(ds), min_us, sum(ds) / len(ds)))
     else:

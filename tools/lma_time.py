@@ -66,7 +66,7 @@ with rsdsfm.Solver(0) as s:
             base = med
         if T == 128:
             batch128 = med
-        tg, groups = group_size(T if T <= 128 else (T % 128 or 128))
-        extra = "" if not SWEEP else "  groups %d x %d hypotheses, lanes busy %.1f %%%s" % (groups, tg, 100.0 * T * (256 // tg) / (groups * 256), "" if base is None or T < 50 else ", %.2f x (T / 50 x the T = 50 pass)" % (med / (base * T / 50.0)))
+        tg, groups = group_size(min(T, 128))  # (T > 128: hypothesis batches of 128 + the rest; the groups of a full batch)
+        extra = "" if not SWEEP else "  groups %d x %d hypotheses, lanes busy %.1f %%%s" % (groups, tg, 100.0 * min(T, 128) * (256 // tg) / (groups * 256), "" if base is None or T < 50 else ", %.2f x (T / 50 x the T = 50 pass)" % (med / (base * T / 50.0)))
         print("T %3d tol %.3f: pixel pass %.1f us (min %.1f) at %.0f MHz; solve median %.3f ms; lma restarts %s%s" % (
             T, tol, med, 1e3 * min(ks[5:]), np.mean(mhz[5:]), np.median(ts[5:]), s.lma_restarts(), extra))

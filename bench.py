@@ -1277,7 +1277,7 @@ def _host_boundary(rsdsfm, solver, np, rank, args, reps=3):
             "fresh_arrays_every_call": {"value": d["rows"] * d["cols"] / med_fresh / 1e6, "ms_per_pair": med_fresh * 1e3,
                                         "note": "the same two calls with fresh numpy output arrays per call and no tag (everything uploaded twice, page faults of 90 MB of new arrays inside the calls)"},
             "note": "PCIe-inclusive: rsdsfm_ransac + rsdsfm_refine_from_ransac on host arrays the caller owns and reuses from pair to pair (the inputs and "
-                    "what the reference's RansacValues holds -- inliers, alpha, alpha_k, + indices -- cross PCIe inside the calls through csrc/host_xfer.hip's pinned ring; Python marshalling "
+                    "what the reference's RansacValues holds -- inliers, alpha, alpha_k, + indices -- cross PCIe inside the calls -- uploads through csrc/host_xfer.hip's pinned ring, downloads on the runtime's pageable path; Python marshalling "
                     "included; pcie_gbs_achieved = those bytes / the whole time, compute included); not the metric"}
 
 

@@ -620,10 +620,8 @@ int rsdsfm_estimate_inverse_depths(rsdsfm_ctx* ctx, const double* q, const doubl
     double* d_ak = sa.take<double>(N);
     double* d_rho = sa.take<double>(N);
     if (n > 0) {
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_q, q, 16 * N, hipMemcpyHostToDevice, c->stream));
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_u, u, 16 * N, hipMemcpyHostToDevice, c->stream));
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_a, alpha, 8 * N, hipMemcpyHostToDevice, c->stream));
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_ak, alpha_k, 8 * N, hipMemcpyHostToDevice, c->stream));
+        const XferUp up[4] = {{d_q, q, 16 * N}, {d_u, u, 16 * N}, {d_a, alpha, 8 * N}, {d_ak, alpha_k, 8 * N}};  // (host_xfer.hip)
+        if ((rc = xfer_h2d_many(c, up, 4)) != RSDSFM_OK) return rc;
     }
     rc = rsdsfm_estimate_inverse_depths_dev(ctx, d_q, d_u, n, v, w, k, d_a, d_ak, depth_mode, d_rho);
     if (rc != RSDSFM_OK) return rc;
@@ -655,7 +653,7 @@ int rsdsfm_get_alpha(rsdsfm_ctx* ctx, const double* flow_px, int64_t n, double h
     double* d_f = sa.take<double>(2 * N);
     double* d_a = sa.take<double>(N);
     if (n == 0) return RSDSFM_OK;
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_f, flow_px, 16 * N, hipMemcpyHostToDevice, c->stream));
+    if ((rc = xfer_h2d(c, d_f, flow_px, 16 * N)) != RSDSFM_OK) return rc;
     rc = alpha_launch(c, d_f, n, h, gamma, d_a);
     if (rc != RSDSFM_OK) return rc;
     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(alpha, d_a, 8 * N, hipMemcpyDeviceToHost, c->stream));
@@ -675,8 +673,8 @@ int rsdsfm_get_alpha_k(rsdsfm_ctx* ctx, const double* q_px, const double* flow_p
     double* d_f = sa.take<double>(2 * N);
     double* d_a = sa.take<double>(N);
     if (n == 0) return RSDSFM_OK;
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_q, q_px, 16 * N, hipMemcpyHostToDevice, c->stream));
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_f, flow_px, 16 * N, hipMemcpyHostToDevice, c->stream));
+    const XferUp up[2] = {{d_q, q_px, 16 * N}, {d_f, flow_px, 16 * N}};
+    if ((rc = xfer_h2d_many(c, up, 2)) != RSDSFM_OK) return rc;
     rc = alpha_k_launch(c, d_q, d_f, n, h, gamma, d_a);
     if (rc != RSDSFM_OK) return rc;
     RSDSFM_HIP_CHECK(c, hipMemcpyAsync(alpha_k, d_a, 8 * N, hipMemcpyDeviceToHost, c->stream));

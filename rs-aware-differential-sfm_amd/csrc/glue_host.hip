@@ -95,7 +95,7 @@ int rsdsfm_flatten(rsdsfm_ctx* ctx, const double* img, int32_t rows, int32_t col
     double* d_u = sa.take<double>(2 * N);
     double* d_a = sa.take<double>(N);
     double* d_ak = sa.take<double>(N);
-    RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_img, img, 16 * N, hipMemcpyHostToDevice, c->stream));
+    if ((rc = xfer_h2d(c, d_img, img, 16 * N)) != RSDSFM_OK) return rc;  // (host_xfer.hip)
     int64_t cnt = 0;
     rc = rsdsfm_flatten_dev(ctx, d_img, rows, cols, fx, fy, cx, cy, gamma, thr, d_q, d_u, d_a, d_ak, &cnt);
     if (rc != RSDSFM_OK) return rc;

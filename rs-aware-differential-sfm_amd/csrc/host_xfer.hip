@@ -2,14 +2,16 @@
 // minimal::ransac and nonLinearRefinement in host/*.h call, reference main.cc:447-457).
 //
 // The reference's API hands over pageable host arrays (Eigen objects) and wants pageable arrays back; a 1280x720 pair moves ~44 MB in and
-// ~67 MB out.  hipMemcpyAsync on pageable memory stages through the runtime's own bounce buffer on ONE thread (tools/xfer_probe.hip: the rate it
-// reaches on the box is in profiles/r06_xfer_probe.txt), well below PCIe.  Here: a ring of pinned chunks per process, filled / drained by a small
-// pool of host threads while the DMA engine moves the neighbouring chunk, on the context's stream so that kernels queue behind the last chunk
-// with no extra synchronisation.  h2d returns once the caller's array has been READ (the DMA may still be in flight); d2h returns once the
-// caller's array has been WRITTEN.  Small copies (< 256 KB) take the plain path.
+// ~67 MB out.  Uploads: hipMemcpyAsync from pageable memory stages through the runtime's own bounce buffer on ONE thread (22-28 GB/s on the box,
+// tools/xfer_probe.hip -> profiles/r06_xfer_probe.txt); here a ring of pinned chunks per process and device is filled by a small pool of host
+// threads while the DMA engines move the neighbouring chunks, alternating between the context's stream and a side stream (the commands' fixed
+// costs overlap); the kernels enqueued next run behind the last chunk with no host synchronisation.  xfer_h2d* return once the callers' arrays
+// have been READ (the DMA may still be in flight).  Downloads: the runtime's pageable path already runs at the link's rate (see xfer_d2h_many).
+// Small uploads (< 256 KB in all) take the plain path.  RSDSFM_XFER_TRACE=1 prints where a host-pointer call's time went.
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -21,8 +23,15 @@ namespace rsdsfm {
 
 namespace {
 
-constexpr size_t kXferChunk = (size_t)4 << 20;  // bytes per pinned chunk
-constexpr int kXferSlots = 4;                   // chunks in the ring
+// Chunk sizes (tools/xfer_probe.hip, profiles/r06_xfer_probe.txt: one copy command costs ~13 us beyond its bytes, an event behind it ~6 us more:
+// 4 MiB chunks reach 45 GB/s of the link's 56.7, 8 MiB chunks alternating between two streams 54): 8 MiB chunks in rotation behind a 2 and a
+// 4 MiB chunk, so that the DMA engine has work after ~45 us.
+constexpr size_t kMiB = (size_t)1 << 20;
+constexpr size_t kXferBig = 8 * kMiB;
+constexpr int kXferBigSlots = 4;
+constexpr int kXferSlots = kXferBigSlots + 2;  // [0 .. 4): 8 MiB each; 4: 2 MiB; 5: 4 MiB
+constexpr size_t kXferSlotBytes[kXferSlots] = {kXferBig, kXferBig, kXferBig, kXferBig, 2 * kMiB, 4 * kMiB};
+constexpr int kSlotSmall2 = 4, kSlotSmall4 = 5;
 constexpr size_t kXferSmall = (size_t)256 << 10;
 
 // a few persistent workers that copy pieces of one chunk (a fork / join per chunk: ~10 us)
@@ -98,20 +107,30 @@ private:
 // one ring per process and device (transfers of different contexts on a device serialise on it: they share the link anyway)
 struct XferRing {
     std::mutex m;
-    char* pinned[kXferSlots] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev[kXferSlots] = {nullptr, nullptr, nullptr, nullptr};
-    bool busy[kXferSlots] = {false, false, false, false};
+    char* pinned[kXferSlots] = {};
+    hipEvent_t ev[kXferSlots] = {};
+    bool busy[kXferSlots] = {};
+    hipStream_t side = nullptr;  // uploads alternate between the context's stream and this one: the commands' fixed costs overlap (54 vs 49 GB/s)
+    hipEvent_t ev_order = nullptr;
     bool ok = false, tried = false;
     CopyPool* pool = nullptr;
 };
 XferRing g_ring[64];
+
+// one piece of one array, in one pinned slot
+struct Piece {
+    int item;
+    size_t off, len;
+    int slot;
+};
 
 int xfer_threads() {
     static int n = -1;
     if (n < 0) {
         const char* e = getenv("RSDSFM_XFER_THREADS");  // helper threads beside the caller's (0: the caller's thread alone)
         const unsigned hw = std::thread::hardware_concurrency();
-        n = e ? std::max(0, std::min(atoi(e), 32)) : (int)std::max(0u, std::min(7u, hw > 2 ? hw / 2 - 1 : 0u));
+        // (3 helpers + the caller fill the ring faster than the link empties it; 2 ... 9 measured alike: tools/host_boundary_probe.py)
+        n = e ? std::max(0, std::min(atoi(e), 32)) : (int)std::max(0u, std::min(3u, hw > 2 ? hw / 2 - 1 : 0u));
     }
     return n;
 }
@@ -122,86 +141,157 @@ XferRing* ring_of(Ctx* c) {
         R->tried = true;
         bool good = true;
         for (int s = 0; s < kXferSlots && good; ++s)
-            good = hipHostMalloc((void**)&R->pinned[s], kXferChunk, hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&R->ev[s], hipEventDisableTiming) == hipSuccess;
+            good = hipHostMalloc((void**)&R->pinned[s], kXferSlotBytes[s], hipHostMallocDefault) == hipSuccess && hipEventCreateWithFlags(&R->ev[s], hipEventDisableTiming) == hipSuccess;
+        good = good && hipStreamCreateWithFlags(&R->side, hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&R->ev_order, hipEventDisableTiming) == hipSuccess;
         if (good) R->pool = new (std::nothrow) CopyPool(xfer_threads());
         R->ok = good && R->pool;
     }
     return R->ok ? R : nullptr;
 }
 
+// the pieces of an upload of `count` arrays of the given sizes, in transfer order: the first two pieces are 2 and 4 MiB, everything else 8 MiB,
+// slots in rotation.  A piece never spans two arrays.
+void plan_pieces(const size_t* bytes, int count, std::vector<Piece>* plan) {
+    plan->clear();
+    int big = 0, g = 0;
+    for (int i = 0; i < count; ++i) {
+        size_t off = 0, left = bytes[i];
+        while (left) {
+            size_t len;
+            int slot;
+            if (g == 0)
+                len = std::min(left, 2 * kMiB), slot = kSlotSmall2;
+            else if (g == 1)
+                len = std::min(left, 4 * kMiB), slot = kSlotSmall4;
+            else
+                len = std::min(left, kXferBig), slot = big, big = (big + 1) % kXferBigSlots;
+            plan->push_back({i, off, len, slot});
+            off += len, left -= len, ++g;
+        }
+    }
+}
+
+// RSDSFM_XFER_TRACE=1: where a host-pointer call's time goes (labels + microseconds to stderr at the end of the call; tools/host_boundary_probe.py)
+struct TraceRec {
+    const char* label;
+    double us;
+    bool span;
+};
+TraceRec g_trace[256];
+int g_ntrace = 0;
+double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+struct Span {  // adds its lifetime to *acc when tracing
+    double* acc;
+    double t0;
+    explicit Span(double* a) : acc(a), t0(a ? now_us() : 0.0) {}
+    ~Span() {
+        if (acc) *acc += now_us() - t0;
+    }
+};
+
 }  // namespace
 
-// host -> device on the context's stream; returns once `h_src` has been read
+bool xfer_trace_on() {
+    static int on = -1;
+    if (on < 0) {
+        const char* e = getenv("RSDSFM_XFER_TRACE");
+        on = e && atoi(e) > 0 ? 1 : 0;
+    }
+    return on == 1;
+}
+void xfer_trace(const char* label) {
+    if (xfer_trace_on() && g_ntrace < 256) g_trace[g_ntrace++] = {label, now_us(), false};
+}
+void xfer_trace_span(const char* label, double us) {  // (a duration, not a time stamp)
+    if (xfer_trace_on() && g_ntrace < 256) g_trace[g_ntrace++] = {label, us, true};
+}
+void xfer_trace_dump(const char* what) {
+    if (!xfer_trace_on()) return;
+    double first = 0.0, prev = 0.0;
+    fprintf(stderr, "[xfer] %s:", what);
+    for (int i = 0; i < g_ntrace; ++i) {
+        if (g_trace[i].span) {
+            fprintf(stderr, " (%s %.0f)", g_trace[i].label, g_trace[i].us);
+            continue;
+        }
+        if (first == 0.0) first = prev = g_trace[i].us;
+        fprintf(stderr, " %s +%.0f", g_trace[i].label, g_trace[i].us - prev);
+        prev = g_trace[i].us;
+    }
+    fprintf(stderr, " | total %.0f us\n", prev - first);
+    g_ntrace = 0;
+}
+
+// host -> device behind what the context's stream holds; returns once the callers' arrays have been READ (the kernels enqueued next on the
+// context's stream run behind the last piece)
+int xfer_h2d_many(Ctx* c, const XferUp* items, int count) {
+    size_t bytes[16], total = 0;
+    if (count > 16) return fail(c, RSDSFM_ERR_INVALID, "xfer_h2d_many: too many arrays");
+    for (int i = 0; i < count; ++i) total += bytes[i] = items[i].bytes;
+    if (total == 0) return RSDSFM_OK;
+    XferRing* R = total >= kXferSmall ? ring_of(c) : nullptr;
+    if (!R) {
+        for (int i = 0; i < count; ++i)
+            if (bytes[i]) RSDSFM_HIP_CHECK(c, hipMemcpyAsync(items[i].dev, items[i].host, bytes[i], hipMemcpyHostToDevice, c->stream));
+        return RSDSFM_OK;
+    }
+    std::lock_guard<std::mutex> g(R->m);
+    const bool tr = xfer_trace_on();
+    double t_wait = 0.0, t_copy = 0.0, t_enq = 0.0;
+    std::vector<Piece> plan;
+    plan_pieces(bytes, count, &plan);
+    // the side stream starts behind what the context's stream holds now (an earlier call's kernels may still read the destination)
+    const bool two = plan.size() > 1;
+    if (two) {
+        RSDSFM_HIP_CHECK(c, hipEventRecord(R->ev_order, c->stream));
+        RSDSFM_HIP_CHECK(c, hipStreamWaitEvent(R->side, R->ev_order, 0));
+    }
+    int last_side_slot = -1;
+    for (size_t k = 0; k < plan.size(); ++k) {
+        const Piece& p = plan[k];
+        if (R->busy[p.slot]) {
+            Span sp(tr ? &t_wait : nullptr);
+            RSDSFM_HIP_CHECK(c, hipEventSynchronize(R->ev[p.slot]));  // (the DMA that last read this slot)
+        }
+        {
+            Span sp(tr ? &t_copy : nullptr);
+            R->pool->copy(R->pinned[p.slot], static_cast<const char*>(items[p.item].host) + p.off, p.len);
+        }
+        Span sp(tr ? &t_enq : nullptr);
+        hipStream_t st = (k & 1) ? R->side : c->stream;
+        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(static_cast<char*>(items[p.item].dev) + p.off, R->pinned[p.slot], p.len, hipMemcpyHostToDevice, st));
+        RSDSFM_HIP_CHECK(c, hipEventRecord(R->ev[p.slot], st));
+        R->busy[p.slot] = true;
+        if (k & 1) last_side_slot = p.slot;
+    }
+    if (last_side_slot >= 0) RSDSFM_HIP_CHECK(c, hipStreamWaitEvent(c->stream, R->ev[last_side_slot], 0));
+    if (tr) xfer_trace_span("h2d wait", t_wait), xfer_trace_span("copy", t_copy), xfer_trace_span("enqueue", t_enq);
+    return RSDSFM_OK;
+}
+
 int xfer_h2d(Ctx* c, void* d_dst, const void* h_src, size_t bytes) {
-    if (bytes == 0) return RSDSFM_OK;
-    XferRing* R = bytes >= kXferSmall ? ring_of(c) : nullptr;
-    if (!R) {
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
-        return RSDSFM_OK;
-    }
-    std::lock_guard<std::mutex> g(R->m);
-    int slot = 0;
-    for (size_t off = 0; off < bytes; off += kXferChunk, slot = (slot + 1) % kXferSlots) {
-        const size_t len = std::min(kXferChunk, bytes - off);
-        if (R->busy[slot]) RSDSFM_HIP_CHECK(c, hipEventSynchronize(R->ev[slot]));  // (the DMA that last read this chunk)
-        R->pool->copy(R->pinned[slot], static_cast<const char*>(h_src) + off, len);
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(static_cast<char*>(d_dst) + off, R->pinned[slot], len, hipMemcpyHostToDevice, c->stream));
-        RSDSFM_HIP_CHECK(c, hipEventRecord(R->ev[slot], c->stream));
-        R->busy[slot] = true;
-    }
-    return RSDSFM_OK;
+    const XferUp one = {d_dst, h_src, bytes};
+    return xfer_h2d_many(c, &one, 1);
 }
 
-// device -> host behind everything enqueued on the context's stream; returns once `h_dst` holds the data
-int xfer_d2h(Ctx* c, void* h_dst, const void* d_src, size_t bytes) {
-    if (bytes == 0) return RSDSFM_OK;
-    XferRing* R = bytes >= kXferSmall ? ring_of(c) : nullptr;
-    if (!R) {
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
-        RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
-        return RSDSFM_OK;
-    }
-    std::lock_guard<std::mutex> g(R->m);
-    for (int s = 0; s < kXferSlots; ++s)  // (chunks an earlier upload still reads)
-        if (R->busy[s]) {
-            RSDSFM_HIP_CHECK(c, hipEventSynchronize(R->ev[s]));
-            R->busy[s] = false;
-        }
-    const size_t nchunks = (bytes + kXferChunk - 1) / kXferChunk;
-    // chunk k's DMA is enqueued kXferSlots - 1 chunks ahead of its drain: the pool copies chunk k to the caller while the engine fills the next ones
-    auto issue = [&](size_t k) -> int {
-        const int slot = (int)(k % kXferSlots);
-        const size_t off = k * kXferChunk, len = std::min(kXferChunk, bytes - off);
-        RSDSFM_HIP_CHECK(c, hipMemcpyAsync(R->pinned[slot], static_cast<const char*>(d_src) + off, len, hipMemcpyDeviceToHost, c->stream));
-        RSDSFM_HIP_CHECK(c, hipEventRecord(R->ev[slot], c->stream));
-        return RSDSFM_OK;
-    };
-    size_t issued = 0;
-    for (; issued < nchunks && issued < (size_t)(kXferSlots - 1); ++issued) {
-        int rc = issue(issued);
-        if (rc != RSDSFM_OK) return rc;
-    }
-    for (size_t k = 0; k < nchunks; ++k) {
-        if (issued < nchunks) {
-            int rc = issue(issued++);
-            if (rc != RSDSFM_OK) return rc;
-        }
-        const int slot = (int)(k % kXferSlots);
-        const size_t off = k * kXferChunk, len = std::min(kXferChunk, bytes - off);
-        RSDSFM_HIP_CHECK(c, hipEventSynchronize(R->ev[slot]));
-        R->pool->copy(static_cast<char*>(h_dst) + off, R->pinned[slot], len);
-    }
-    return RSDSFM_OK;
-}
-
-// several device -> host copies as ONE pipeline (the drain of one array overlaps the DMA of the next)
+// several device -> host copies behind everything enqueued on the context's stream; returns once the callers' arrays hold the data.  The
+// runtime's own path for pageable destinations moves warm arrays at the link's rate (55 GB/s: it pins the caller's pages and lets the engine
+// write them directly); draining the ring with the thread pool was measured beside it and is slower (40 GB/s: every piece's drain starts behind
+// its own DMA, HISTORY.md), so downloads do not go through the ring.
 int xfer_d2h_many(Ctx* c, const XferItem* items, int count) {
-    // (simple form: back to back -- each call's first DMA is enqueued while nothing drains, a bubble of one chunk per array)
-    for (int i = 0; i < count; ++i) {
-        int rc = xfer_d2h(c, items[i].host, items[i].dev, items[i].bytes);
-        if (rc != RSDSFM_OK) return rc;
-    }
+    bool any = false;
+    for (int i = 0; i < count; ++i)
+        if (items[i].bytes) {
+            RSDSFM_HIP_CHECK(c, hipMemcpyAsync(items[i].host, items[i].dev, items[i].bytes, hipMemcpyDeviceToHost, c->stream));
+            any = true;
+        }
+    if (any) RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
     return RSDSFM_OK;
+}
+
+int xfer_d2h(Ctx* c, void* h_dst, const void* d_src, size_t bytes) {
+    const XferItem one = {h_dst, d_src, bytes};
+    return xfer_d2h_many(c, &one, 1);
 }
 
 }  // namespace rsdsfm

@@ -619,11 +619,13 @@ int rsdsfm_ransac(rsdsfm_ctx* ctx, const double* q, const double* u, const doubl
     // last chunk on the same stream)
     c->ransac_cache.tag = 0;
     const uint64_t gen = c->stage_gen;
-    if ((rc = xfer_h2d(c, d_q, q, 16 * N)) != RSDSFM_OK || (rc = xfer_h2d(c, d_u, u, 16 * N)) != RSDSFM_OK || (rc = xfer_h2d(c, d_a, alpha, 8 * N)) != RSDSFM_OK ||
-        (rc = xfer_h2d(c, d_ak, alpha_k, 8 * N)) != RSDSFM_OK)
-        return rc;
+    xfer_trace("begin");
+    const XferUp up[4] = {{d_q, q, 16 * N}, {d_u, u, 16 * N}, {d_a, alpha, 8 * N}, {d_ak, alpha_k, 8 * N}};
+    if ((rc = xfer_h2d_many(c, up, 4)) != RSDSFM_OK) return rc;
+    xfer_trace("uploaded");
     rc = ransac_device(c, d_q, d_u, d_a, d_ak, n, use_alpha_k, iterations, tolerance, samples, seed, depth_mode, k_sign_mode, &dev, nullptr, nullptr);
     if (rc != RSDSFM_OK) return rc;
+    xfer_trace("solved");
     const size_t M = (size_t)dev.num_inliers;
     XferItem items[6];
     int ni = 0;
@@ -635,6 +637,8 @@ int rsdsfm_ransac(rsdsfm_ctx* ctx, const double* q, const double* u, const doubl
     if (out->mask) items[ni++] = {out->mask, dev.mask, N};
     if ((rc = xfer_d2h_many(c, items, ni)) != RSDSFM_OK) return rc;
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    xfer_trace("downloaded");
+    xfer_trace_dump("rsdsfm_ransac");
     // what stays on the device for rsdsfm_refine_from_ransac (refine_host.hip): the inliers, their alpha / alpha_k / indices and u, until another
     // host-pointer call takes the staging buffer
     if (out->inliers && out->alpha && out->alpha_k && out->inlier_idx && gen == c->stage_gen) {

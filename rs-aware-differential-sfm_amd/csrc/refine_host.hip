@@ -303,18 +303,19 @@ static int refine_host(rsdsfm_ctx* ctx, uint64_t tag, const double* flow, int64_
         double* s_a = sa.take<double>(M);
         double* s_ak = sa.take<double>(M);
         int64_t* s_idx = sa.take<int64_t>(M);
-        if (NF && (rc = xfer_h2d(c, s_flow, flow, 16 * NF)) != RSDSFM_OK) return rc;
-        if (M) {
-            if ((rc = xfer_h2d(c, s_inl, inl, 24 * M)) != RSDSFM_OK || (rc = xfer_h2d(c, s_a, alpha, 8 * M)) != RSDSFM_OK || (rc = xfer_h2d(c, s_ak, alpha_k, 8 * M)) != RSDSFM_OK) return rc;
-            if (inlier_idx && (rc = xfer_h2d(c, s_idx, inlier_idx, 8 * M)) != RSDSFM_OK) return rc;
-        }
+        const XferUp up[5] = {{s_flow, flow, 16 * NF}, {s_inl, inl, 24 * M}, {s_a, alpha, 8 * M}, {s_ak, alpha_k, 8 * M}, {s_idx, inlier_idx, inlier_idx ? 8 * M : 0}};
+        if ((rc = xfer_h2d_many(c, up, 5)) != RSDSFM_OK) return rc;
         d_flow = s_flow, d_inl = s_inl, d_a = s_a, d_ak = s_ak, d_idx = inlier_idx ? s_idx : nullptr;
     }
+    xfer_trace(cached ? "begin (resident)" : "uploaded");
     rc = refine_device(c, d_flow, n_flow, m, d_inl, d_a, d_ak, d_idx, v_in, w_in, k_in, const_acceleration, flow_index_mode, d_out, v_out, w_out, k_out,
                        summary, nullptr, nullptr);
     if (rc != RSDSFM_OK) return rc;
+    xfer_trace("solved");
     if (M && (rc = xfer_d2h(c, inl_out, d_out, 24 * M)) != RSDSFM_OK) return rc;
     RSDSFM_HIP_CHECK(c, hipStreamSynchronize(c->stream));
+    xfer_trace("downloaded");
+    xfer_trace_dump("rsdsfm_refine");
     return RSDSFM_OK;
 }
 

@@ -261,9 +261,20 @@ struct XferItem {
     const void* dev;
     size_t bytes;
 };
+struct XferUp {
+    void* dev;
+    const void* host;
+    size_t bytes;
+};
 int xfer_h2d(Ctx* c, void* d_dst, const void* h_src, size_t bytes);
+int xfer_h2d_many(Ctx* c, const XferUp* items, int count);
 int xfer_d2h(Ctx* c, void* h_dst, const void* d_src, size_t bytes);
 int xfer_d2h_many(Ctx* c, const XferItem* items, int count);
+// RSDSFM_XFER_TRACE=1: time stamps of a host-pointer call, printed to stderr by xfer_trace_dump at its end
+bool xfer_trace_on();
+void xfer_trace(const char* label);
+void xfer_trace_span(const char* label, double us);
+void xfer_trace_dump(const char* what);
 int ensure_ws(Ctx* c, size_t bytes);
 int sync_stream(Ctx* c, const char* where);  // hipStreamSynchronize(c->stream), with an opt-in watchdog (RSDSFM_SYNC_WATCHDOG_S; capi.hip)
 void set_sync_dumper(std::function<void(Ctx*)> f);

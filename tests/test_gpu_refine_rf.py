@@ -161,8 +161,9 @@ def test_refinement_from_the_resident_ransac_outputs_equals_the_uploaded_one(ora
 
 
 def test_host_transfers_through_the_pinned_ring_are_exact(rsdsfm, oracle):
-    """inputs / outputs larger than one chunk of the ring (4 MiB) and not a multiple of it: what comes back is what the device holds"""
-    d = rsdsfm.synth.make_config(3, rows=480, cols=707)
+    """inputs / outputs of several pieces of the ring (2 + 4 + 8 MiB ... up, 8 MiB ... + a tail of 2 MiB down; uploads alternate between two
+    streams) and not a multiple of any of them: what comes back is what the device holds"""
+    d = rsdsfm.synth.make_config(3, rows=720, cols=1279)
     q, u, a, ak, t = d["q"], d["u"], d["alpha"], d["alpha_k"], d["truth"]
     v = t["v"] / np.linalg.norm(t["v"])
     with rsdsfm.Solver(0) as s:

@@ -7,7 +7,7 @@ q,u,a,ak = d["q"],d["u"],d["alpha"],d["alpha_k"]
 n=len(q)
 s = rsdsfm.Solver(0)
 outputs={}; ref_out=np.empty((n,3))
-for i in range(6):
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
     t0=time.perf_counter()
     r = s.ransac(q,u,a,ak,False,50,0.05,seed=11+i,outputs=outputs)
     t1=time.perf_counter()

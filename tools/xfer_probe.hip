@@ -70,6 +70,36 @@ int main() {
         double t2 = now();
         printf("memcpy with %2d threads (thread start included): pageable -> pinned %.1f GB/s, pinned -> pageable %.1f GB/s\n", threads, 4 * n / (t1 - t0) / 1e9, 4 * n / (t2 - t1) / 1e9);
     }
+    // chunked pinned copies, enqueued back to back: what one command costs beyond its bytes (chunk size; an event recorded behind every chunk;
+    // chunks alternating over two streams)
+    hipStream_t s2;
+    CK(hipStreamCreate(&s2));
+    hipEvent_t ev[64];
+    for (auto& evk : ev) CK(hipEventCreateWithFlags(&evk, hipEventDisableTiming));
+    for (int dir = 0; dir < 2; ++dir)
+        for (size_t chunk : {size_t(1) << 20, size_t(2) << 20, size_t(4) << 20, size_t(8) << 20, size_t(16) << 20})
+            for (int variant = 0; variant < 4; ++variant) {  // 0: one stream; 1: + event per chunk; 2: two streams; 3: two streams + events
+                const bool events = variant & 1, two = variant & 2;
+                double best = 1e9;
+                for (int rep = 0; rep < 4; ++rep) {
+                    double t0 = now();
+                    int k = 0;
+                    for (size_t off = 0; off < n; off += chunk, ++k) {
+                        const size_t len = std::min(chunk, n - off);
+                        hipStream_t st = two && (k & 1) ? s2 : s;
+                        if (dir == 0)
+                            CK(hipMemcpyAsync(dev + off, pinned + off, len, hipMemcpyHostToDevice, st));
+                        else
+                            CK(hipMemcpyAsync(pinned + off, dev + off, len, hipMemcpyDeviceToHost, st));
+                        if (events) CK(hipEventRecord(ev[k & 63], st));
+                    }
+                    CK(hipStreamSynchronize(s));
+                    CK(hipStreamSynchronize(s2));
+                    best = std::min(best, now() - t0);
+                }
+                printf("%s 44 MiB in %2zu MiB chunks, %s%s: %.1f GB/s (%.0f us)\n", dir ? "D2H" : "H2D", chunk >> 20, two ? "two streams" : "one stream", events ? " + event per chunk" : "",
+                       n / best / 1e9, best * 1e6);
+            }
     // small-copy latency
     double t0 = now();
     for (int r = 0; r < 100; ++r) {

@@ -1,13 +1,12 @@
 // minimal9_kernels.hip -- batched 9-point minimal solver on MI355X (gfx950).
 //
-// Replaces minimal::calculateVelocities (reference minimal.cc:36-177): one wavefront LANE per hypothesis.
-// Each lane owns a private 9x9 work matrix W, a 9x9 V (two-sided Jacobi SVD, Eigen 3.3.4 JacobiSVD restated)
-// and the temporaries of the optional k-estimation (6x6 LU inverse + Hessenberg/Francis-QR eigenvalues), all
-// held in LDS with a lane-interleaved layout  element e of lane l  at  lds[e * 64 + l]  -- every dynamic index
-// is the same across lanes of an instruction, so ds_read_b64/ds_write_b64 are conflict-free and nothing spills
-// to scratch.  One wave per workgroup (the per-lane state is 1.3 KB without / 2.3 KB with k-estimation, i.e.
-// 83 KB / 150 KB of the CU's 160 KB LDS).  T is at most a few thousand: this kernel is latency-bound and tiny;
-// correctness and agreement with the CPU oracle (same algorithms, same operation order) matter, not FLOPs.
+// Replaces minimal::calculateVelocities (reference minimal.cc:36-177): one wavefront LANE per hypothesis when there are many, one WAVE
+// per hypothesis when there are few (the RANSAC case).  Each lane owns a private 9x9 work matrix W and a 9x9 V (two-sided Jacobi SVD,
+// Eigen 3.3.4 JacobiSVD restated) in LDS with a lane-interleaved layout  element e of lane l  at  lds[e * 64 + l]  -- every dynamic index
+// is the same across lanes of an instruction, so ds_read_b64/ds_write_b64 are conflict-free and nothing spills to scratch; the optional
+// k estimation (3x3 and 6x6 LU inverses + Hessenberg / Francis-QR eigenvalues) runs in registers with compile-time indices.  One wave per
+// workgroup (the per-lane state is 1.4 KB, i.e. 92 KB of the CU's 160 KB LDS).  T is at most a few thousand: this kernel is
+// latency-bound and tiny; correctness and agreement with the CPU oracle (same algorithms, same operation order) matter, not FLOPs.
 #include <float.h>
 
 #include "device_math.hpp"
@@ -201,7 +200,7 @@ constexpr int kCoopSlots = 3;   // LDS slots (of 64 doubles) behind the per-lane
 // CORE: the rotations through the in-range function cores; *outside is set when an operand was out of range (the caller has the
 // hypotheses computed again with CORE = false)
 template <bool CORE>
-__device__ void jacobi_svd9_nullvec_coop(double* W, double* V, int lane, LVec sv, LVec col, double e_out[9], bool* outside, int* counts = nullptr) {
+__device__ __forceinline__ void jacobi_svd9_nullvec_coop(double* W, double* V, int lane, LVec sv, LVec col, double (&e_out)[9], bool& outside, int& sweeps_out, int& rotations_out) {
     uint32_t wd = 0, ws = 0;
     int rotations = 0;
     const double precision = 2.0 * DBL_EPSILON;
@@ -289,8 +288,8 @@ __device__ void jacobi_svd9_nullvec_coop(double* W, double* V, int lane, LVec sv
             }
         }
     }
-    if (CORE) *outside = wd >= kDivRangeKeys || ws >= kSqrtRangeKeys;
-    if (counts) counts[0] = sweeps, counts[1] = rotations;
+    if (CORE) outside = wd >= kDivRangeKeys || ws >= kSqrtRangeKeys;
+    sweeps_out = sweeps, rotations_out = rotations;
     for (int i = 0; i < 9; ++i) {
         sv[i] = fabs(sh(W, i * 9 + i)) * scale;
         col[i] = (double)i;
@@ -320,120 +319,168 @@ __device__ void jacobi_svd9_nullvec_coop(double* W, double* V, int lane, LVec sv
     for (int i = 0; i < 9; ++i) e_out[i] = sh(V, i * 9 + c8);
 }
 
-// PartialPivLU inverse (MatrixXd::inverse()), row-major n x n (n = 3 or 6).  A, Ainv, lu: n*n slots; piv, y: n slots.
-__device__ int inverse_lu(LVec A, int n, LVec Ainv, LVec lu, LVec piv, LVec y) {
-    for (int i = 0; i < n * n; ++i) lu[i] = A[i];
-    for (int i = 0; i < n; ++i) piv[i] = (double)i;
-    for (int k = 0; k < n; ++k) {
+// ---- the k estimation's linear algebra (minimal.cc:58-80), in REGISTERS ----------------------------------------------------------------
+// The k estimation runs on a wave of its own (one hypothesis per wave when T is small): what it costs is its instruction count at ~5 clocks
+// each, and with its matrices in LDS (rounds 1-5) most instructions were address arithmetic and waits for ds_read (tools/k_sections.py:
+// 262 000 clocks per hypothesis, 86 % of them the eigenvalues; in registers 93 000).  Every index below is a compile-time constant.
+//
+// PartialPivLU inverse (MatrixXd::inverse()) of the row-major NN x NN matrix in lu (destroyed): the pivot row is applied by uniform
+// compare-and-swap instances; every element goes through the operations of Eigen's loop nest in the same order.
+template <int NN>
+__device__ __forceinline__ int inverse_lu_reg(double (&lu)[NN * NN], double (&Ainv)[NN * NN]) {
+    int piv[NN];
+#pragma unroll
+    for (int i = 0; i < NN; ++i) piv[i] = i;
+    bool singular = false;
+#pragma unroll
+    for (int k = 0; k < NN; ++k) {
         int pr = k;
-        double best = fabs(lu[k * n + k]);
-        for (int i = k + 1; i < n; ++i) {
-            double c = fabs(lu[i * n + k]);
+        double best = fabs(lu[k * NN + k]);
+#pragma unroll
+        for (int i = k + 1; i < NN; ++i) {
+            const double c = fabs(lu[i * NN + k]);
             if (c > best) {
                 best = c;
                 pr = i;
             }
         }
-        if (best == 0.0) return -1;
-        if (pr != k) {
-            for (int j = 0; j < n; ++j) {
-                double t = lu[k * n + j];
-                lu[k * n + j] = lu[pr * n + j];
-                lu[pr * n + j] = t;
+        if (best == 0.0) singular = true;  // (inverse_lu returns here; what follows is then never looked at)
+#pragma unroll
+        for (int P = k + 1; P < NN; ++P) {
+            if (pr == P) {
+#pragma unroll
+                for (int j = 0; j < NN; ++j) {
+                    const double t = lu[k * NN + j];
+                    lu[k * NN + j] = lu[P * NN + j];
+                    lu[P * NN + j] = t;
+                }
+                const int ti = piv[k];
+                piv[k] = piv[P];
+                piv[P] = ti;
             }
-            double ti = piv[k];
-            piv[k] = piv[pr];
-            piv[pr] = ti;
         }
-        for (int i = k + 1; i < n; ++i) {
-            double f = lu[i * n + k] / lu[k * n + k];
-            lu[i * n + k] = f;
-            for (int j = k + 1; j < n; ++j) lu[i * n + j] -= f * lu[k * n + j];
+#pragma unroll
+        for (int i = k + 1; i < NN; ++i) {
+            const double f = lu[i * NN + k] / lu[k * NN + k];
+            lu[i * NN + k] = f;
+#pragma unroll
+            for (int j = k + 1; j < NN; ++j) lu[i * NN + j] -= f * lu[k * NN + j];
         }
     }
-    for (int c = 0; c < n; ++c) {
-        for (int i = 0; i < n; ++i) {
-            double s = ((int)piv[i] == c) ? 1.0 : 0.0;
-            for (int j = 0; j < i; ++j) s -= lu[i * n + j] * y[j];
+    if (singular) return -1;
+#pragma unroll
+    for (int c = 0; c < NN; ++c) {
+        double y[NN];
+#pragma unroll
+        for (int i = 0; i < NN; ++i) {
+            double s = (piv[i] == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int j = 0; j < i; ++j) s -= lu[i * NN + j] * y[j];
             y[i] = s;
         }
-        for (int i = n - 1; i >= 0; --i) {
+#pragma unroll
+        for (int i = NN - 1; i >= 0; --i) {
             double s = y[i];
-            for (int j = i + 1; j < n; ++j) s -= lu[i * n + j] * Ainv[j * n + c];
-            Ainv[i * n + c] = s / lu[i * n + i];
+#pragma unroll
+            for (int j = i + 1; j < NN; ++j) s -= lu[i * NN + j] * Ainv[j * NN + c];
+            Ainv[i * NN + c] = s / lu[i * NN + i];
         }
     }
     return 0;
 }
 
-// eigenvalues of the general real 6x6 in H (destroyed): Householder Hessenberg + Francis double-shift QR (hqr).
-// Eigenvalues are stored by index (re = ev[0..6), im = ev[6..12)) so that the caller can scan them in index
-// order exactly like minimal.cc:75-80.
-__device__ int eig6_values(LVec H, LVec ort, LVec ev) {
-    const int nn = 6;
-    for (int m = 1; m < nn - 1; ++m) {
+// ---------------------------------------------------------------------------------------------------
+// Eigenvalues of the general real 6x6 (EigenSolver: Householder Hessenberg + Francis double-shift QR, hqr), matrix in registers: the active
+// block's end n is a template parameter (a wave-uniform switch picks the instance), the loops over l, m, k are unrolled with uniform guards.
+// The operations on an element and their order are the textbook loop nest's (the oracle's rso_eigvals_general: same bits), with one restriction that
+// cannot change an eigenvalue: the row part of a Francis step stops at column n -- the entries in rows <= n of columns > n are only ever
+// read by later row parts, which write the same entries (n never grows) -- while the column part keeps all its rows (the active block's
+// start l may move up again).
+// ---------------------------------------------------------------------------------------------------
+#define H_(i, j) H[(i) * 6 + (j)]
+
+__device__ __forceinline__ void hessenberg6_reg(double (&H)[36]) {
+#pragma unroll
+    for (int m = 1; m < 5; ++m) {
         double scale = 0.0;
-        for (int i = m; i < nn; ++i) scale += fabs(H[i * nn + m - 1]);
-        if (scale == 0.0) continue;
-        double hh = 0.0;
-        for (int i = nn - 1; i >= m; --i) {
-            double o = H[i * nn + m - 1] / scale;
-            ort[i] = o;
-            hh += o * o;
+#pragma unroll
+        for (int i = m; i < 6; ++i) scale += fabs(H_(i, m - 1));
+        if (scale != 0.0) {
+            double ort[6] = {0, 0, 0, 0, 0, 0};
+            double hh = 0.0;
+#pragma unroll
+            for (int i = 5; i >= m; --i) {
+                const double o = H_(i, m - 1) / scale;
+                ort[i] = o;
+                hh += o * o;
+            }
+            double g = sqrt(hh);
+            if (ort[m] > 0) g = -g;
+            hh -= ort[m] * g;
+            ort[m] = ort[m] - g;
+#pragma unroll
+            for (int j = m; j < 6; ++j) {
+                double f = 0.0;
+#pragma unroll
+                for (int i = 5; i >= m; --i) f += ort[i] * H_(i, j);
+                f /= hh;
+#pragma unroll
+                for (int i = m; i < 6; ++i) H_(i, j) -= f * ort[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                double f = 0.0;
+#pragma unroll
+                for (int j = 5; j >= m; --j) f += ort[j] * H_(i, j);
+                f /= hh;
+#pragma unroll
+                for (int j = m; j < 6; ++j) H_(i, j) -= f * ort[j];
+            }
+            H_(m, m - 1) = scale * g;
+#pragma unroll
+            for (int i = m + 1; i < 6; ++i) H_(i, m - 1) = 0.0;
         }
-        double g = sqrt(hh);
-        if (ort[m] > 0) g = -g;
-        hh -= ort[m] * g;
-        ort[m] = ort[m] - g;
-        for (int j = m; j < nn; ++j) {
-            double f = 0.0;
-            for (int i = nn - 1; i >= m; --i) f += ort[i] * H[i * nn + j];
-            f /= hh;
-            for (int i = m; i < nn; ++i) H[i * nn + j] -= f * ort[i];
-        }
-        for (int i = 0; i < nn; ++i) {
-            double f = 0.0;
-            for (int j = nn - 1; j >= m; --j) f += ort[j] * H[i * nn + j];
-            f /= hh;
-            for (int j = m; j < nn; ++j) H[i * nn + j] -= f * ort[j];
-        }
-        ort[m] = ort[m] * scale;
-        H[m * nn + m - 1] = scale * g;
-        for (int i = m + 1; i < nn; ++i) H[i * nn + m - 1] = 0.0;
     }
-    int n = nn - 1;
-    const int low = 0;
+}
+
+// one pass of hqr's `while (n >= low)` loop with n = N; returns the new n
+template <int N>
+__device__ __forceinline__ int qr_pass_reg(double (&H)[36], LVec ev, double norm, double& exshift, int& iter) {
     const double eps = DBL_EPSILON;
-    double exshift = 0.0, p = 0, q = 0, r = 0, s = 0, z = 0, w, x, y;
-    double norm = 0.0;
-    for (int i = 0; i < nn; ++i)
-        for (int j = (i - 1 > 0 ? i - 1 : 0); j < nn; ++j) norm += fabs(H[i * nn + j]);
-    int iter = 0, total = 0;
-    while (n >= low) {
-        if (++total > 10000) return -2;
-        int l = n;
-        while (l > low) {
-            s = fabs(H[(l - 1) * nn + l - 1]) + fabs(H[l * nn + l]);
-            if (s == 0.0) s = norm;
-            if (fabs(H[l * nn + l - 1]) < eps * s) break;
-            l--;
+    // l: the first small subdiagonal entry from the bottom (0 when there is none)
+    int l = 0;
+    {
+        bool searching = true;
+#pragma unroll
+        for (int L = N; L >= 1; --L) {
+            if (searching) {
+                double s = fabs(H_(L - 1, L - 1)) + fabs(H_(L, L));
+                if (s == 0.0) s = norm;
+                if (fabs(H_(L, L - 1)) < eps * s) {
+                    l = L;
+                    searching = false;
+                }
+            }
         }
-        if (l == n) {
-            double hnn = H[n * nn + n] + exshift;
-            H[n * nn + n] = hnn;
-            ev[n] = hnn;
-            ev[6 + n] = 0.0;
-            n--;
-            iter = 0;
-        } else if (l == n - 1) {
-            w = H[n * nn + n - 1] * H[(n - 1) * nn + n];
-            p = (H[(n - 1) * nn + n - 1] - H[n * nn + n]) / 2.0;
-            q = p * p + w;
-            z = sqrt(fabs(q));
-            H[n * nn + n] = H[n * nn + n] + exshift;
-            H[(n - 1) * nn + n - 1] = H[(n - 1) * nn + n - 1] + exshift;
-            x = H[n * nn + n];
-            double re_lo, re_hi, im_lo, im_hi;  // index n-1 and n
+    }
+    if (l == N) {  // one root
+        const double hnn = H_(N, N) + exshift;
+        H_(N, N) = hnn;
+        ev[N] = hnn;
+        ev[6 + N] = 0.0;
+        iter = 0;
+        return N - 1;
+    }
+    if constexpr (N >= 1) {
+        if (l == N - 1) {  // two roots
+            const double w = H_(N, N - 1) * H_(N - 1, N);
+            const double p = (H_(N - 1, N - 1) - H_(N, N)) / 2.0;
+            const double q = p * p + w;
+            double z = sqrt(fabs(q));
+            H_(N, N) = H_(N, N) + exshift;
+            H_(N - 1, N - 1) = H_(N - 1, N - 1) + exshift;
+            const double x = H_(N, N);
+            double re_lo, re_hi, im_lo, im_hi;
             if (q >= 0) {
                 z = (p >= 0) ? p + z : p - z;
                 re_lo = x + z;
@@ -447,114 +494,170 @@ __device__ int eig6_values(LVec H, LVec ort, LVec ev) {
                 im_lo = z;
                 im_hi = -z;
             }
-            ev[n - 1] = re_lo;
-            ev[n] = re_hi;
-            ev[6 + n - 1] = im_lo;
-            ev[6 + n] = im_hi;
-            n -= 2;
+            ev[N - 1] = re_lo;
+            ev[N] = re_hi;
+            ev[6 + N - 1] = im_lo;
+            ev[6 + N] = im_hi;
             iter = 0;
-        } else {
-            x = H[n * nn + n];
-            y = 0.0;
-            w = 0.0;
-            if (l < n) {
-                y = H[(n - 1) * nn + n - 1];
-                w = H[n * nn + n - 1] * H[(n - 1) * nn + n];
+            return N - 2;
+        }
+    }
+    if constexpr (N >= 2) {
+        double p = 0, q = 0, r = 0, s = 0, z = 0;
+        double x = H_(N, N);
+        double y = H_(N - 1, N - 1);
+        double w = H_(N, N - 1) * H_(N - 1, N);
+        if (iter == 10) {
+            exshift += x;
+#pragma unroll
+            for (int i = 0; i <= N; ++i) H_(i, i) -= x;
+            s = fabs(H_(N, N - 1)) + fabs(H_(N - 1, N - 2));
+            x = y = 0.75 * s;
+            w = -0.4375 * s * s;
+        }
+        if (iter == 30) {
+            s = (y - x) / 2.0;
+            s = s * s + w;
+            if (s > 0) {
+                s = sqrt(s);
+                if (y < x) s = -s;
+                s = x - w / ((y - x) / 2.0 + s);
+#pragma unroll
+                for (int i = 0; i <= N; ++i) H_(i, i) -= s;
+                exshift += s;
+                x = y = w = 0.964;
             }
-            if (iter == 10) {
-                exshift += x;
-                for (int i = low; i <= n; ++i) H[i * nn + i] -= x;
-                s = fabs(H[n * nn + n - 1]) + fabs(H[(n - 1) * nn + n - 2]);
-                x = y = 0.75 * s;
-                w = -0.4375 * s * s;
-            }
-            if (iter == 30) {
-                s = (y - x) / 2.0;
-                s = s * s + w;
-                if (s > 0) {
-                    s = sqrt(s);
-                    if (y < x) s = -s;
-                    s = x - w / ((y - x) / 2.0 + s);
-                    for (int i = low; i <= n; ++i) H[i * nn + i] -= s;
-                    exshift += s;
-                    x = y = w = 0.964;
-                }
-            }
-            iter++;
-            int m = n - 2;
-            while (m >= l) {
-                z = H[m * nn + m];
-                r = x - z;
-                s = y - z;
-                p = (r * s - w) / H[(m + 1) * nn + m] + H[m * nn + m + 1];
-                q = H[(m + 1) * nn + m + 1] - z - r - s;
-                r = H[(m + 2) * nn + m + 1];
-                s = fabs(p) + fabs(q) + fabs(r);
-                p /= s;
-                q /= s;
-                r /= s;
-                if (m == l) break;
-                if (fabs(H[m * nn + m - 1]) * (fabs(q) + fabs(r)) <
-                    eps * (fabs(p) * (fabs(H[(m - 1) * nn + m - 1]) + fabs(z) + fabs(H[(m + 1) * nn + m + 1]))))
-                    break;
-                m--;
-            }
-            for (int i = m + 2; i <= n; ++i) {
-                H[i * nn + i - 2] = 0.0;
-                if (i > m + 2) H[i * nn + i - 3] = 0.0;
-            }
-            for (int k = m; k <= n - 1; ++k) {
-                const bool notlast = (k != n - 1);
-                if (k != m) {
-                    p = H[k * nn + k - 1];
-                    q = H[(k + 1) * nn + k - 1];
-                    r = notlast ? H[(k + 2) * nn + k - 1] : 0.0;
-                    x = fabs(p) + fabs(q) + fabs(r);
-                    if (x != 0.0) {
-                        p /= x;
-                        q /= x;
-                        r /= x;
+        }
+        iter++;
+        // m: where the double-shift sweep starts
+        int m = l;
+        {
+            bool searching = true;
+#pragma unroll
+            for (int M = N - 2; M >= 0; --M) {
+                if (searching && M >= l) {
+                    z = H_(M, M);
+                    r = x - z;
+                    s = y - z;
+                    p = (r * s - w) / H_(M + 1, M) + H_(M, M + 1);
+                    q = H_(M + 1, M + 1) - z - r - s;
+                    r = H_(M + 2, M + 1);
+                    s = fabs(p) + fabs(q) + fabs(r);
+                    p /= s;
+                    q /= s;
+                    r /= s;
+                    if (M == l) {
+                        m = M;
+                        searching = false;
+                    }
+                    if (M > 0) {  // (M == 0 is l: the search has ended above; Mm keeps the dead instance's indices inside the array)
+                        const int Mm = M > 0 ? M - 1 : 0;
+                        if (searching && fabs(H_(M, Mm)) * (fabs(q) + fabs(r)) < eps * (fabs(p) * (fabs(H_(Mm, Mm)) + fabs(z) + fabs(H_(M + 1, M + 1))))) {
+                            m = M;
+                            searching = false;
+                        }
                     }
                 }
-                if (x == 0.0) break;
-                s = sqrt(p * p + q * q + r * r);
-                if (p < 0) s = -s;
-                if (s != 0) {
-                    if (k != m)
-                        H[k * nn + k - 1] = -s * x;
-                    else if (l != m)
-                        H[k * nn + k - 1] = -H[k * nn + k - 1];
-                    p += s;
-                    x = p / s;
-                    y = q / s;
-                    z = r / s;
-                    q /= p;
-                    r /= p;
-                    for (int j = k; j < nn; ++j) {
-                        p = H[k * nn + j] + q * H[(k + 1) * nn + j];
-                        if (notlast) {
-                            p += r * H[(k + 2) * nn + j];
-                            H[(k + 2) * nn + j] -= p * z;
+            }
+        }
+#pragma unroll
+        for (int i = 2; i <= N; ++i) {
+            if (i >= m + 2) {
+                H_(i, i - 2) = 0.0;
+                if (i >= 3 && i > m + 2) H_(i, i >= 3 ? i - 3 : 0) = 0.0;
+            }
+        }
+        bool live = true;
+#pragma unroll
+        for (int K = 0; K <= N - 1; ++K) {
+            if (live && K >= m) {
+                const bool notlast = (K != N - 1);  // (a constant of the unrolled instance; K2 / Km keep a dead instance's indices inside the array)
+                const int K2 = notlast ? K + 2 : K, Km = K > 0 ? K - 1 : 0;
+                if (K > 0) {
+                    if (K != m) {
+                        p = H_(K, Km);
+                        q = H_(K + 1, Km);
+                        r = notlast ? H_(K2, Km) : 0.0;
+                        x = fabs(p) + fabs(q) + fabs(r);
+                        if (x != 0.0) {
+                            p /= x;
+                            q /= x;
+                            r /= x;
                         }
-                        H[k * nn + j] -= p * x;
-                        H[(k + 1) * nn + j] -= p * y;
                     }
-                    const int imax = (n < k + 3) ? n : k + 3;
-                    for (int i = 0; i <= imax; ++i) {
-                        p = x * H[i * nn + k] + y * H[i * nn + k + 1];
-                        if (notlast) {
-                            p += z * H[i * nn + k + 2];
-                            H[i * nn + k + 2] -= p * r;
+                }
+                if (x == 0.0) {
+                    live = false;
+                } else {
+                    s = sqrt(p * p + q * q + r * r);
+                    if (p < 0) s = -s;
+                    if (s != 0) {
+                        if (K > 0) {
+                            if (K != m)
+                                H_(K, Km) = -s * x;
+                            else if (l != m)
+                                H_(K, Km) = -H_(K, Km);
                         }
-                        H[i * nn + k] -= p;
-                        H[i * nn + k + 1] -= p * q;
+                        p += s;
+                        x = p / s;
+                        y = q / s;
+                        z = r / s;
+                        q /= p;
+                        r /= p;
+#pragma unroll
+                        for (int j = K; j <= N; ++j) {
+                            p = H_(K, j) + q * H_(K + 1, j);
+                            if (notlast) {
+                                p += r * H_(K2, j);
+                                H_(K2, j) -= p * z;
+                            }
+                            H_(K, j) -= p * x;
+                            H_(K + 1, j) -= p * y;
+                        }
+                        const int imax = (N < K + 3) ? N : K + 3;
+#pragma unroll
+                        for (int i = 0; i <= imax; ++i) {
+                            p = x * H_(i, K) + y * H_(i, K + 1);
+                            if (notlast) {
+                                p += z * H_(i, K2);
+                                H_(i, K2) -= p * r;
+                            }
+                            H_(i, K) -= p;
+                            H_(i, K + 1) -= p * q;
+                        }
                     }
                 }
             }
         }
     }
+    return N;
+}
+
+// eigenvalues of the general real 6x6 in H (destroyed): re = ev[0..6), im = ev[6..12), by index (minimal.cc:75-80 scans them in index order).
+// (ev lives in LDS: the instances' stores to it get merged into one store with a run-time index, which would put a register array into scratch.)
+__device__ __forceinline__ int eig6_values_reg(double (&H)[36], LVec ev) {
+    hessenberg6_reg(H);
+    double norm = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = (i - 1 > 0 ? i - 1 : 0); j < 6; ++j) norm += fabs(H_(i, j));
+    double exshift = 0.0;
+    int n = 5, iter = 0, total = 0;
+    while (n >= 0) {
+        if (++total > 10000) return -2;
+        switch (n) {
+            case 5: n = qr_pass_reg<5>(H, ev, norm, exshift, iter); break;
+            case 4: n = qr_pass_reg<4>(H, ev, norm, exshift, iter); break;
+            case 3: n = qr_pass_reg<3>(H, ev, norm, exshift, iter); break;
+            case 2: n = qr_pass_reg<2>(H, ev, norm, exshift, iter); break;
+            case 1: n = qr_pass_reg<1>(H, ev, norm, exshift, iter); break;
+            default: n = qr_pass_reg<0>(H, ev, norm, exshift, iter); break;
+        }
+    }
     return 0;
 }
+#undef H_
 
 // ---- 3x3 helpers in registers (fully unrolled, statically indexed) ----
 __device__ __forceinline__ void mm3(const double (&A)[9], const double (&B)[9], double (&C)[9]) {
@@ -664,7 +767,7 @@ __device__ void eig_sym3(const double (&S)[9], double (&lam)[3], double (&V)[9])
 }
 
 constexpr int kSlotsNoK = 81 + 81 + 18;           // W, V, sv/col
-constexpr int kSlotsK = 294;                      // + k-estimation temporaries (partly overlaid on V / sv / col)
+constexpr int kSlotsK = kSlotsNoK;                // (the k estimation's two LDS arrays -- P, the eigenvalues -- lie in the not yet used V slots)
 
 }  // namespace
 
@@ -673,6 +776,9 @@ constexpr int kSlotsK = 294;                      // + k-estimation temporaries 
 // evaluates the (cheap, register / per-lane-LDS) scalar parts redundantly and the 9x9 SVD is shared (latency mode)
 // the solver proper: the body of minimal9_kernel and of the solver workgroups of minimal9_flatten_kernel (one wave; `nblocks` = number
 // of workgroups that run this body, for the grid-strided clearing loop)
+#ifndef RSDSFM_K_SECTIONS
+#define RSDSFM_K_SECTIONS 0
+#endif
 template <bool COOP>
 __device__ __forceinline__ void minimal9_body(double* lds, int block, int nblocks, int lane, const double* __restrict__ q,
                                               const double* __restrict__ u, const double* __restrict__ alpha,
@@ -721,57 +827,87 @@ __device__ __forceinline__ void minimal9_body(double* lds, int block, int nblock
     int rc = 0;
     double k = 0.0;
     double beta[9];
+#if RSDSFM_K_SECTIONS
+    unsigned long long ksec[7] = {0, 0, 0, 0, 0, 0, 0};
+#define KSEC(i) ksec[i] = __builtin_amdgcn_s_memtime()
+#else
+#define KSEC(i)
+#endif
+    KSEC(0);
     if (use_alpha_k) {
-        // minimal.cc:58-80; temporaries live after the SVD slots
-        // region A = the (not yet used) V / sv / col slots [81, 180); region B = [180, 294)
-        LVec P = base.at(81), PK = base.at(117), a = base.at(153), a_inv = base.at(162), piv = base.at(171);
-        LVec lu = base.at(180), PKinv = base.at(216), dga = base.at(252), yv = base.at(270), ort = base.at(276),
-             ev = base.at(282);
+        // minimal.cc:58-80 in registers (inverse_lu_reg, eig6_values_reg); LDS holds Z (built above) and, in the not yet used V slots, P between
+        // its construction and the product P PK^-1, and the eigenvalues
+        LVec P = base.at(81), ev = base.at(117);
+        double a3[9], a_inv[9];
+#pragma unroll
         for (int i = 0; i < 3; ++i)
-            for (int j = 0; j < 3; ++j) a[i * 3 + j] = Z[i * 9 + j];
-        if (inverse_lu(a, 3, a_inv, lu, piv, yv) != 0) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) a3[i * 3 + j] = Z[i * 9 + j];
+        if (inverse_lu_reg<3>(a3, a_inv) != 0) {
             k = INFINITY;
             rc = -2;
         } else {
             // dga = dg * a_inv  (dg = Z[3:9, 0:3])
-            for (int i = 0; i < 6; ++i)
+            double dga[18];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const double z0 = Z[(3 + i) * 9 + 0], z1 = Z[(3 + i) * 9 + 1], z2 = Z[(3 + i) * 9 + 2];
+#pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     double s = 0.0;
-                    for (int tt = 0; tt < 3; ++tt) s += Z[(3 + i) * 9 + tt] * a_inv[tt * 3 + j];
+                    s += z0 * a_inv[0 * 3 + j];
+                    s += z1 * a_inv[1 * 3 + j];
+                    s += z2 * a_inv[2 * 3 + j];
                     dga[i * 3 + j] = s;
                 }
-            for (int which = 0; which < 2; ++which) {
-                LVec dst = which == 0 ? P : PK;
-                const double d0 = which == 0 ? al[0] : alk[0], d1 = which == 0 ? al[1] : alk[1],
-                             d2 = which == 0 ? al[2] : alk[2];
-                for (int i = 0; i < 6; ++i) {
-                    // al[3 + i] with a dynamic index: pick it from registers without spilling
-                    double ali = 0.0;
+            }
+            KSEC(1);
+            // P (-> LDS) and PK (registers):  alpha_f6 .* efhj - (dga * diag(alpha_f3)) * bc ,  bc = Z[0:3, 3:9], efhj = Z[3:9, 3:9]
+            double bc[18], PKr[36];
 #pragma unroll
-                    for (int r = 0; r < 6; ++r)
-                        if (r == i) ali = which == 0 ? al[3 + r] : alk[3 + r];
-                    for (int j = 0; j < 6; ++j) {
-                        // (dga * diag(alpha_f3)) * bc ,  bc = Z[0:3, 3:9]
-                        double s = 0.0;
-                        s += (dga[i * 3 + 0] * d0) * Z[0 * 9 + 3 + j];
-                        s += (dga[i * 3 + 1] * d1) * Z[1 * 9 + 3 + j];
-                        s += (dga[i * 3 + 2] * d2) * Z[2 * 9 + 3 + j];
-                        dst[i * 6 + j] = ali * Z[(3 + i) * 9 + 3 + j] - s;                        // efhj = Z[3:9, 3:9]
-                    }
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) bc[i * 6 + j] = Z[i * 9 + 3 + j];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const double zz = Z[(3 + i) * 9 + 3 + j];
+                    double s = 0.0;
+                    s += (dga[i * 3 + 0] * al[0]) * bc[0 * 6 + j];
+                    s += (dga[i * 3 + 1] * al[1]) * bc[1 * 6 + j];
+                    s += (dga[i * 3 + 2] * al[2]) * bc[2 * 6 + j];
+                    P[i * 6 + j] = al[3 + i] * zz - s;
+                    double sk = 0.0;
+                    sk += (dga[i * 3 + 0] * alk[0]) * bc[0 * 6 + j];
+                    sk += (dga[i * 3 + 1] * alk[1]) * bc[1 * 6 + j];
+                    sk += (dga[i * 3 + 2] * alk[2]) * bc[2 * 6 + j];
+                    PKr[i * 6 + j] = alk[3 + i] * zz - sk;
                 }
             }
-            if (inverse_lu(PK, 6, PKinv, lu, piv, yv) != 0) {
+            KSEC(2);
+            double PKinv[36];
+            if (inverse_lu_reg<6>(PKr, PKinv) != 0) {
                 k = INFINITY;
                 rc = -2;
             } else {
-                LVec M = lu;  // lu is free again
-                for (int i = 0; i < 6; ++i)
+                KSEC(3);
+                double Hr[36];  // P PK^-1
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    double pr[6];
+#pragma unroll
+                    for (int tt = 0; tt < 6; ++tt) pr[tt] = P[i * 6 + tt];
+#pragma unroll
                     for (int j = 0; j < 6; ++j) {
                         double s = 0.0;
-                        for (int tt = 0; tt < 6; ++tt) s += P[i * 6 + tt] * PKinv[tt * 6 + j];
-                        M[i * 6 + j] = s;
+#pragma unroll
+                        for (int tt = 0; tt < 6; ++tt) s += pr[tt] * PKinv[tt * 6 + j];
+                        Hr[i * 6 + j] = s;
                     }
-                if (eig6_values(M, ort, ev) != 0) {
+                }
+                KSEC(4);
+                if (eig6_values_reg(Hr, ev) != 0) {
                     k = INFINITY;
                     rc = -2;
                 } else {
@@ -783,6 +919,7 @@ __device__ __forceinline__ void minimal9_body(double* lds, int block, int nblock
                 }
             }
         }
+        KSEC(5);
 #pragma unroll
         for (int i = 0; i < 9; ++i) beta[i] = (al[i] + k * alk[i]) * (2.0 / (2.0 + k));
     } else {
@@ -802,18 +939,18 @@ __device__ __forceinline__ void minimal9_body(double* lds, int block, int nblock
         Wc[lane] = lds[lane * 64];
         if (lane < 17) Wc[64 + lane] = lds[(64 + lane) * 64];
         __builtin_amdgcn_wave_barrier();
-        int counts[2] = {0, 0};
+        int n_sweeps = 0, n_rotations = 0;
+        bool outside = false;
         const unsigned long long svd_clk0 = direct.probe ? __builtin_amdgcn_s_memtime() : 0ull;
         if (direct.core_flag) {
-            bool outside = false;
-            jacobi_svd9_nullvec_coop<true>(Wc, Wc + kCoopV, lane, sv, col, e, &outside, direct.probe ? counts : nullptr);
+            jacobi_svd9_nullvec_coop<true>(Wc, Wc + kCoopV, lane, sv, col, e, outside, n_sweeps, n_rotations);
             if (outside && lane == 0) *direct.core_flag = direct.core_epoch;  // (every writer of this launch stores the same value)
         } else {
-            jacobi_svd9_nullvec_coop<false>(Wc, Wc + kCoopV, lane, sv, col, e, nullptr, direct.probe ? counts : nullptr);
+            jacobi_svd9_nullvec_coop<false>(Wc, Wc + kCoopV, lane, sv, col, e, outside, n_sweeps, n_rotations);
         }
         if (direct.probe && lane == 0) {
-            direct.probe[4 * t] = (double)counts[0];
-            direct.probe[4 * t + 1] = (double)counts[1];
+            direct.probe[4 * t] = (double)n_sweeps;
+            direct.probe[4 * t + 1] = (double)n_rotations;
             direct.probe[4 * t + 2] = (double)(__builtin_amdgcn_s_memtime() - svd_clk0);
         }
     } else {
@@ -893,6 +1030,14 @@ __device__ __forceinline__ void minimal9_body(double* lds, int block, int nblock
     mm3(t2, bt, w_hat);
     if (COOP && lane != 0) return;
     if (COOP && direct.probe) direct.probe[4 * t + 3] = (double)(__builtin_amdgcn_s_memtime() - body_clk0);
+#if RSDSFM_K_SECTIONS
+    if (COOP && direct.probe && use_alpha_k) {  // (diagnostic build: tools/k_sections.py) sections of the k estimation in shader clocks
+        direct.probe[4 * t + 0] = (double)(ksec[2] - ksec[0]);  // Z, 3x3 inverse, dga, P, PK
+        direct.probe[4 * t + 1] = (double)(ksec[3] - ksec[2]);  // 6x6 inverse
+        direct.probe[4 * t + 2] = (double)(ksec[4] - ksec[3]);  // P PK^-1
+        direct.probe[4 * t + 3] = (double)(ksec[5] - ksec[4]);  // eigenvalues
+    }
+#endif
     double* o = hyp_out + (int64_t)t * 8;
     o[0] = w_hat[7];
     o[1] = w_hat[2];

@@ -35,7 +35,10 @@ SLOTS_ACCEL=1 RSDSFM_RF_STAMPS=1 timeout 200 python3 tools/refine_rf_phases.py >
 timeout 300 python3 tools/refine_slots.py > $OUT/refine_slots.txt 2>/dev/null
 SLOTS_ACCEL=1 timeout 300 python3 tools/refine_slots.py >> $OUT/refine_slots.txt 2>/dev/null
 timeout 120 ./tools/xfer_probe > $OUT/xfer_probe.txt 2>&1
-timeout 120 python3 tools/host_boundary_probe.py > $OUT/host_boundary_probe.txt 2>&1
+timeout 120 python3 tools/host_boundary_probe.py 2>&1 | grep -v amdgpu.ids > $OUT/host_boundary_probe.txt
+RSDSFM_XFER_TRACE=1 timeout 120 python3 tools/host_boundary_probe.py 40 2>&1 | python3 tools/xfer_trace_stats.py > $OUT/host_boundary_phases.txt
+# the k estimation's sections (a diagnostic build of the library: tools/build_ksec.sh, made before the call)
+if [ -f rs-aware-differential-sfm_amd/librsdsfm_hip_ksec.so ]; then RSDSFM_LIB=$PWD/rs-aware-differential-sfm_amd/librsdsfm_hip_ksec.so timeout 200 python3 tools/k_sections.py 40 2>/dev/null > $OUT/k_sections.txt; fi
 t accel tools/accel_solves.py 30
 timeout 120 python3 tools/accel_solves.py 60 > $OUT/accel_solves.txt 2>/dev/null
 if [ "${1:-}" != "quick" ]; then

@@ -32,4 +32,3 @@ with rsdsfm.Solver(0) as s:
     print("passes stamped %d over %d solves (LM iterations %s); restarts %s" % (ph[4], len(its), sorted(set(its)), s.refine_restarts()))
     print("per pass that ran its loop: state load %.2f us, stage %.2f us, loop %.2f us, row reduction %.2f us" % tuple(p / n for p in ph[:4]))
     print("   loop end of waves 1 .. 7 behind wave 0's: " + " ".join("%.2f" % (p / n) for p in ph[9:16]) + " us")
-    print("   the stage: rows reduced %.2f us, decision + lists %.2f us, reduced solve %.2f us" % tuple(p / n for p in ph[5:8]))

@@ -137,6 +137,7 @@ int xfer_threads() {
 
 XferRing* ring_of(Ctx* c) {
     XferRing* R = &g_ring[c->device & 63];
+    std::lock_guard<std::mutex> g(R->m);  // (contexts of several threads may meet here for the first time)
     if (!R->tried) {
         R->tried = true;
         bool good = true;

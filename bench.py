@@ -28,8 +28,10 @@ Contract: python bench.py --gpus N --steps K --warmup W  prints ONE JSON line on
               run as launched.  `value` = N independent replicas of the whole solve (BASELINE configs[4], no data-path collective ->
               scaling "weak"); `tiled_full` = the strong-scaling record.  RSDSFM_SHARE_GPU=1 puts all ranks on device 0 with one
               NCCL_HOSTID each (RCCL then connects them over its socket transport: the N-rank path on a one-GPU box).
-  --arith fused = the opt-in librsdsfm_hip_fused.so (explicit fmas in the per-pixel model) instead of the reference-arithmetic
-              default; the default line carries its whole-solve time as `full_solve_fused`.
+  --arith fused = the opt-in librsdsfm_hip_fused.so (explicit fmas also in the iterate-by-iterate per-pixel model) instead of the
+              default library (analytic LM trajectory + radius-factorised refinement: the library's own arithmetic with fused
+              multiply-adds, guarded to the integers of the reference's arithmetic; its iterate-by-iterate kernels are the reference's
+              arithmetic operation for operation); the default line carries the fused library's whole-solve time as `full_solve_fused`.
 Frame pairs rotate through distinct HBM buffers, so the timed loops stream from HBM, not from the 256 MiB Infinity Cache.
 """
 import argparse
@@ -242,7 +244,7 @@ def parse_args(argv=None):
     ap.add_argument("--sequence-only", action="store_true", help="full workload: only the sequence solve (rsdsfm_solve_frames_dev), --steps passes of 32 pairs (profiling runs)")
     ap.add_argument("--no-side-records", action="store_true", help="full workload: skip depth_only / full_solve_batched / full_solve_fused (profiling runs)")
     ap.add_argument("--tiled-driver", default="native", choices=["native", "python"], help="tiled / tiled_full: the C++ driver inside the library (default) or the Python driver")
-    ap.add_argument("--arith", default="reference", choices=["reference", "fused"], help="library: reference arithmetic (default) or the opt-in fused-fma build")
+    ap.add_argument("--arith", default="reference", choices=["reference", "fused"], help="library: 'reference' = the default librsdsfm_hip.so (see --help's header), 'fused' = the opt-in fused-fma build")
     ap.add_argument("--nbuf", type=int, default=7, help="rotating HBM buffer sets (7 x 59 MB > 256 MiB L3)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams per GPU feeding independent batches (sequence-throughput mode, BASELINE configs[4])")
     ap.add_argument("--pairs-per-step", type=int, default=64, help="depth workloads: one step = one chunk of this many consecutive frame pairs of the sequence (default 64)")
@@ -454,7 +456,10 @@ def run(args):
         return el
 
     line = {"metric": METRIC, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "higher_is_better": True, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "arith": args.arith}
+            "higher_is_better": True, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "arith": ("default library: analytic LM trajectory (depth solves) + radius-factorised refinement, own arithmetic with fused multiply-adds guarded to the "
+                      "integers of the reference's arithmetic; iterate-by-iterate kernels = the reference's arithmetic" if args.arith == "reference" else
+                      "opt-in fused library: the default's paths, explicit fused multiply-adds also in the iterate-by-iterate per-pixel model")}
 
     # =================================================================================================
     def run_depth(workload, steps, warmup, side_records=True, cpu_budget=12.0):

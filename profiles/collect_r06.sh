@@ -57,5 +57,6 @@ if [ "${1:-}" != "quick" ]; then
   timeout 400 python3 tools/seq_sweep.py > $OUT/seq_sweep.txt 2>/dev/null
   timeout 400 python3 tools/solve_times.py > $OUT/solve_times.txt 2>/dev/null
   for i in 1 2 3; do timeout 120 python3 tools/seq_determinism_probe.py 0 3 10 2>/dev/null | tail -2; done > $OUT/seq_determinism.txt
+  (timeout 600 python3 tools/soak.py 2>&1 | grep -v amdgpu.ids; timeout 200 python3 tools/leak_check.py 2>&1 | grep -v amdgpu.ids | tail -3) > $OUT/soak.txt
 fi
 ls $OUT

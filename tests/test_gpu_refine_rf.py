@@ -175,3 +175,40 @@ def test_host_transfers_through_the_pinned_ring_are_exact(rsdsfm, oracle):
     assert np.array_equal(r["inliers"][:, :2], q[r["inlier_idx"]])  # x, y are copies of q: every chunk landed where it belongs
     assert np.array_equal(r["alpha"], a[r["inlier_idx"]]) and np.array_equal(r["alpha_k"], ak[r["inlier_idx"]])
     assert np.allclose(r["inv_depth"], ro["inv_depth"], rtol=1e-9, atol=1e-13)
+
+
+def test_host_transfers_of_two_contexts_on_two_threads_share_the_ring(rsdsfm, oracle):
+    """the pinned ring belongs to the process and the device: two contexts driven from two threads upload through it at the same time (its
+    lock serialises them) and each gets its own answer"""
+    import threading
+
+    ds = [rsdsfm.synth.make_config(3, rows=300, cols=1400 + 37 * j, seed=77 + j) for j in range(2)]
+    samples = [oracle.sample_indices(len(d["q"]), 6, 5 + j) for j, d in enumerate(ds)]
+
+    def solve(j, reps, out):
+        d = ds[j]
+        with rsdsfm.Solver(0) as s:
+            for _ in range(reps):
+                r = s.ransac(d["q"], d["u"], d["alpha"], d["alpha_k"], False, 6, 0.05, samples=samples[j], depth_mode=1)
+                out.append((r["num_inliers"], r["best_trial"], r["inlier_idx"].tobytes(), r["inliers"].tobytes(), r["inv_depth"].tobytes()))
+
+    serial = [[], []]
+    for j in range(2):
+        solve(j, 1, serial[j])
+    both = [[], []]
+    errs = []
+
+    def work(j):
+        try:
+            solve(j, 4, both[j])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(j,)) for j in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(120)
+    assert not errs, errs
+    for j in range(2):
+        assert len(both[j]) == 4 and all(x == serial[j][0] for x in both[j])

@@ -172,7 +172,8 @@ void plan_pieces(const size_t* bytes, int count, std::vector<Piece>* plan) {
     }
 }
 
-// RSDSFM_XFER_TRACE=1: where a host-pointer call's time goes (labels + microseconds to stderr at the end of the call; tools/host_boundary_probe.py)
+// RSDSFM_XFER_TRACE=1: where a host-pointer call's time goes (labels + microseconds to stderr at the end of the call; tools/host_boundary_probe.py).
+// A diagnostic for ONE calling thread: the record buffer is not locked.
 struct TraceRec {
     const char* label;
     double us;

@@ -1343,8 +1343,10 @@ def _refine_pass_record(full):
     """The joint refinement's pass (refine_rf_pass_kernel<6, false, false>: one per LM iteration, csrc/refine_rf_kernels.hip) against the two
     rooflines that could bound it: fp64 lane-instructions (SQ_INSTS_VALU_*_F64 x 64) and HBM bytes (64 B per inlier and iteration algorithmic,
     SURVEY 8 d; FETCH_SIZE x 2 + WRITE_SIZE measured) of one launch from profiles/counters.json, over the launch duration the same collection pass
-    stored there (`trace_avg_us`: rocprofv3 --kernel-trace of this command, the launches that ran their loop).  Neither bounds it: a third of a
-    launch is the replicated single-workgroup stage in every workgroup's prologue and the row reduction."""
+    stored there (`trace_avg_us`: rocprofv3 --kernel-trace of this command, the launches that ran their loop).  Over the WHOLE launch neither bounds
+    it: a third of a launch is the replicated single-workgroup stage in every workgroup's prologue and the row reduction, which move no data.  Its
+    LOOP phase (11 of the 20.5 us) is bound by its memory accesses: the same loop without its arithmetic takes 10 us (profiles/
+    r06_refine_phases_loads_only.txt, tools/build_rfproxy.sh), 56 B per inlier at ~5 TB/s (DESIGN.md sections 4, 8, 11)."""
     kname = "refine_rf_pass_kernel<6, false, false>"
     ctr = _counters(kname)
     if not ctr:
@@ -1360,7 +1362,9 @@ def _refine_pass_record(full):
     alg = 64.0 * m
     traffic = (2.0 * ctr["FETCH_SIZE"] + ctr["WRITE_SIZE"]) * 1024.0 / frac_full if ("FETCH_SIZE" in ctr and "WRITE_SIZE" in ctr) else None
     rec = {"kernel": kname, "avg_launch_us": us, "fp64_lane_instructions_per_launch": insts or None, "alg_bytes_per_launch": alg, "traffic": traffic, "inliers": m,
-           "launches_sampled": ctr.get("launches_sampled"), "full_launch_fraction": frac_full, "counters_stale": False}
+           "launches_sampled": ctr.get("launches_sampled"), "full_launch_fraction": frac_full, "counters_stale": False,
+           "note": "rooflines over the whole launch; the loop phase alone (about 11 of the 20.5 us; the rest is the replicated stage and the row reduction) is bound "
+                   "by its memory accesses -- the loop without its arithmetic takes 10 us: profiles/r06_refine_phases_loads_only.txt"}
     if us:
         rec["fp64"] = {"bound": "fp64-valu", "achieved": insts / (us * 1e-6) / 1e12 if insts else None, "peak": FP64_VALU_PEAK / 1e12, "unit": "T fp64 lane-instructions/s",
                        "frac": insts / (us * 1e-6) / FP64_VALU_PEAK if insts else None}

@@ -32,6 +32,8 @@ timeout 300 python3 tools/lma_time.py 60 > $OUT/lma_time.txt 2>/dev/null
 timeout 400 python3 tools/lma_time.py sweep 30 > $OUT/lma_T_sweep.txt 2>/dev/null
 RSDSFM_RF_STAMPS=1 timeout 200 python3 tools/refine_rf_phases.py > $OUT/refine_phases.txt 2>/dev/null
 SLOTS_ACCEL=1 RSDSFM_RF_STAMPS=1 timeout 200 python3 tools/refine_rf_phases.py >> $OUT/refine_phases.txt 2>/dev/null
+# the same stamps from the timing build whose loop performs its memory accesses only (tools/build_rfproxy.sh, made before the call; wrong results by construction)
+if [ -f rs-aware-differential-sfm_amd/librsdsfm_hip_rfproxy.so ]; then (echo "# RF_LOADS_ONLY=1 timing build: the NP = 6 loop's loads and store without its arithmetic (every solve is sent back by a guard; read the loop phase)"; RSDSFM_LIB=$PWD/rs-aware-differential-sfm_amd/librsdsfm_hip_rfproxy.so RSDSFM_RF_STAMPS=1 timeout 200 python3 tools/refine_rf_phases.py 2>/dev/null) > $OUT/refine_phases_loads_only.txt; fi
 timeout 300 python3 tools/refine_slots.py > $OUT/refine_slots.txt 2>/dev/null
 SLOTS_ACCEL=1 timeout 300 python3 tools/refine_slots.py >> $OUT/refine_slots.txt 2>/dev/null
 timeout 120 ./tools/xfer_probe > $OUT/xfer_probe.txt 2>&1

@@ -17,7 +17,7 @@ for f in glob.glob(F + "/trace_*.txt"):
     open(P + "/r06_" + os.path.basename(f), "w").write(head + "".join(body))
 if os.path.exists(F + "/counters.json"):
     shutil.copy(F + "/counters.json", P + "/counters.json")
-for name in ("timeline_full.txt", "lma_time.txt", "lma_T_sweep.txt", "refine_phases.txt", "refine_slots.txt", "xfer_probe.txt", "host_boundary_probe.txt", "host_boundary_phases.txt", "k_sections.txt", "accel_solves.txt",
+for name in ("timeline_full.txt", "lma_time.txt", "lma_T_sweep.txt", "refine_phases.txt", "refine_phases_loads_only.txt", "refine_slots.txt", "xfer_probe.txt", "host_boundary_probe.txt", "host_boundary_phases.txt", "k_sections.txt", "accel_solves.txt",
              "seq_sweep.txt", "solve_times.txt", "seq_determinism.txt", "soak.txt"):
     if os.path.exists(F + "/" + name) and os.path.getsize(F + "/" + name) > 0:
         shutil.copy(F + "/" + name, P + "/r06_" + name)

@@ -28,6 +28,12 @@
 // out four waves per SIMD (128 registers) for ANY body; the memory latency is covered by the next two inliers' loads in flight instead.
 #include "refine_common.hpp"
 
+// RF_LOADS_ONLY=1 (tools/build_rfproxy.sh -> tools/refine_rf_phases.py): a TIMING build whose NP = 6 pass performs the loop's loads and its one store
+// but none of its arithmetic -- wrong results (every solve is sent back by a guard), the loop phase's duration is what is read: 10.1 us against
+// 11.1 us with the arithmetic, i.e. the loop phase is bound by its memory accesses (51.6 MB per pass), not by instruction issue.
+#ifndef RF_LOADS_ONLY
+#define RF_LOADS_ONLY 0
+#endif
 #ifndef RF_NP7_PREFETCH
 #define RF_NP7_PREFETCH 0
 #endif
@@ -875,7 +881,12 @@ __global__ __launch_bounds__(kFB) void refine_rf_pass_kernel(const RfPassArgs A)
             for (int64_t i = i0; i < m; i += stride) {
                 const int64_t i2 = i + 2 * stride;
                 const RfLoad l2 = rf_load<NP>(A, rho, i2, i2 <= last);
+#if RF_LOADS_ONLY
+                acc[0] += l0.c4.x + l0.c4.y + l0.c4.z + l0.c4.w + l0.rho + l0.ab;  // (diagnostic build: the loop's memory accesses without its arithmetic)
+                cand[i] = l0.rho;
+#else
                 body(l0, i);
+#endif
                 l0 = l1;
                 l1 = l2;
             }
